@@ -1,0 +1,158 @@
+"""Synthetic Hqp_Program generators for parity tests and bench.py.
+
+These are OUR workload generators; they only produce the
+QP blocks an ``Hqp_Program`` carries (hqp/Hqp_Program.h:33-65):
+
+    min 1/2 x'Qx + c'x   s.t.  Ax + b = 0,  Cx + d >= 0
+
+``Q`` holds the upper triangle only (the reference reads ``col >= row`` only,
+meschach/addon2_hqp.c:1078-1086), everything is 0-based CSR with int32 indices
+and float64 values.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+class Program:
+    """QP data container mirroring ``Hqp_Program`` (hqp/Hqp_Program.h:33-65)."""
+
+    def __init__(self, n, me, m, Q, A, C, c=None, b=None, d=None):
+        self.n, self.me, self.m = int(n), int(me), int(m)
+        self.Q, self.A, self.C = Q, A, C  # (indptr, indices, data) triples
+        self.c = np.zeros(n) if c is None else c
+        self.b = np.zeros(me) if b is None else b
+        self.d = np.zeros(m) if d is None else d
+
+    @property
+    def dims(self):
+        return self.n, self.me, self.m
+
+
+def _csr(rows, cols, vals, nrows):
+    rows = np.asarray(rows, dtype=np.int64)
+    cols = np.asarray(cols, dtype=np.int64)
+    vals = np.asarray(vals, dtype=np.float64)
+    order = np.lexsort((cols, rows))
+    rows, cols, vals = rows[order], cols[order], vals[order]
+    indptr = np.zeros(nrows + 1, dtype=np.int32)
+    np.add.at(indptr, rows + 1, 1)
+    indptr = np.cumsum(indptr).astype(np.int32)
+    return indptr, cols.astype(np.int32), vals
+
+
+def banded_qp(n, b, seed=12345):
+    """Config C2 of SURVEY.md section 8(d): banded SPD ``Q`` (semi-bandwidth ``b``,
+    upper stored), ``A`` (n/2 x n) with ``b``-wide rows at column offset 2i,
+    ``C = I`` (simple bounds).  n=40000, b=80 gives KKT dim 1e5, mat_sbw 200."""
+    rng = np.random.default_rng(seed)
+    me, m = n // 2, n
+    # Q upper band
+    i = np.repeat(np.arange(n), b)
+    j = i + np.tile(np.arange(1, b + 1), n)
+    keep = j < n
+    i, j = i[keep], j[keep]
+    v = rng.uniform(-0.5, 0.5, size=i.size)
+    rowsum = np.zeros(n)
+    np.add.at(rowsum, i, np.abs(v))
+    np.add.at(rowsum, j, np.abs(v))
+    diag = 2.0 * b + 1.0 + rowsum
+    Q = _csr(np.concatenate([np.arange(n), i]), np.concatenate([np.arange(n), j]),
+             np.concatenate([diag, v]), n)
+    # A
+    ai = np.repeat(np.arange(me), b)
+    aj = 2 * ai + np.tile(np.arange(b), me)
+    keep = aj < n
+    ai, aj = ai[keep], aj[keep]
+    A = _csr(ai, aj, rng.uniform(-0.5, 0.5, size=ai.size), me)
+    C = _csr(np.arange(m), np.arange(m), np.ones(m), m)
+    return Program(n, me, m, Q, A, C, c=rng.uniform(-0.5, 0.5, n),
+                   b=np.zeros(me), d=np.ones(m))
+
+
+def did_like_qp(K, qx=1e-4):
+    """QP with the block structure of the reference's double-integrator demo
+    (hqp_docp/Prg_DID.C:32-157 through Hqp_Docp::setup_qp, hqp/Hqp_Docp.C:585-755):
+    x = [x_0(2), u_0, x_1(2), u_1, ..., x_K(2)], n = 3K+2;
+    A = 2K dynamics rows  fx x_k + fu u_k - x_{k+1}, then 2 initial-state and 2
+    final-state equalities (me = 2K+4); C = K-1 state upper bounds then K path
+    constraints (m = 2K-1).  Q = diag(2 dt on u, qx on x) (upper stored)."""
+    dt = 1.0 / K
+    n, me, m = 3 * K + 2, 2 * K + 4, 2 * K - 1
+    xi = lambda k, c: 3 * k + c
+    ui = lambda k: 3 * k + 2
+    qd = np.full(n, qx)
+    qd[[ui(k) for k in range(K)]] = 2.0 * dt
+    Q = _csr(np.arange(n), np.arange(n), qd, n)
+    r, c, v = [], [], []
+    for k in range(K):
+        # f0 = x0 + u dt ; f1 = x0 dt + x1 + u dt^2/2   (Prg_DID.C:80-82, 115-121)
+        r += [2 * k] * 3
+        c += [xi(k, 0), ui(k), xi(k + 1, 0)]
+        v += [1.0, dt, -1.0]
+        r += [2 * k + 1] * 4
+        c += [xi(k, 0), xi(k, 1), ui(k), xi(k + 1, 1)]
+        v += [dt, 1.0, 0.5 * dt * dt, -1.0]
+    r += [2 * K, 2 * K + 1, 2 * K + 2, 2 * K + 3]
+    c += [xi(0, 0), xi(0, 1), xi(K, 0), xi(K, 1)]
+    v += [1.0, 1.0, 1.0, 1.0]
+    A = _csr(r, c, v, me)
+    b = np.zeros(me)
+    b[2 * K], b[2 * K + 1], b[2 * K + 2], b[2 * K + 3] = -1.0, 0.0, 1.0, 0.0
+    r, c, v = [], [], []
+    for k in range(1, K):  # x_k[1] <= 0.01
+        r.append(k - 1)
+        c.append(xi(k, 1))
+        v.append(-1.0)
+    for k in range(K):  # 0.5 dt x0 + x1 <= 0.01  (Prg_DID.C:86-88, 126-130)
+        r += [K - 1 + k] * 2
+        c += [xi(k, 0), xi(k, 1)]
+        v += [-0.5 * dt, -1.0]
+    C = _csr(r, c, v, m)
+    return Program(n, me, m, Q, A, C, c=np.zeros(n), b=b, d=np.full(m, 0.01))
+
+
+def random_sparse_qp(n, me, m, row_nnz=4, seed=7):
+    """Irregular (non-banded) QP: random sparse A, C rows, Q = diag + random
+    symmetric sparse part made diagonally dominant.  Exercises the general path."""
+    rng = np.random.default_rng(seed)
+    i = rng.integers(0, n, size=2 * n)
+    j = rng.integers(0, n, size=2 * n)
+    lo, hi = np.minimum(i, j), np.maximum(i, j)
+    keep = lo != hi
+    key = np.unique(lo[keep].astype(np.int64) * n + hi[keep])
+    lo, hi = (key // n).astype(np.int64), (key % n).astype(np.int64)
+    v = rng.uniform(-0.5, 0.5, size=lo.size)
+    rowsum = np.zeros(n)
+    np.add.at(rowsum, lo, np.abs(v))
+    np.add.at(rowsum, hi, np.abs(v))
+    Q = _csr(np.concatenate([np.arange(n), lo]), np.concatenate([np.arange(n), hi]),
+             np.concatenate([1.0 + rowsum, v]), n)
+
+    def rows(nr):
+        rr, cc = [], []
+        for r in range(nr):
+            cols = np.unique(rng.integers(0, n, size=row_nnz))
+            rr += [r] * cols.size
+            cc += list(cols)
+        return _csr(rr, cc, rng.uniform(-1.0, 1.0, size=len(rr)), nr)
+
+    return Program(n, me, m, Q, rows(me), rows(m), c=rng.uniform(-1, 1, n),
+                   b=rng.uniform(-1, 1, me), d=rng.uniform(0.5, 1.5, m))
+
+
+def ip_state(prog, seed=1, spread=0.0):
+    """Strictly positive (z, w) and right-hand sides r1..r4 as an interior-point
+    iteration would pass them (hqp/Hqp_IpsMehrotra.C:425-445, 527-530).
+    ``spread`` > 0 draws z/w log-uniformly over 10**(+-spread) to mimic late
+    iterations where w/z spans many decades."""
+    rng = np.random.default_rng(seed)
+    n, me, m = prog.dims
+    if spread > 0:
+        z = 10.0 ** rng.uniform(-spread, spread, m)
+        w = 10.0 ** rng.uniform(-spread, spread, m)
+    else:
+        z = 0.1 + rng.uniform(0, 1, m)
+        w = 0.1 + rng.uniform(0, 1, m)
+    r = [rng.uniform(-0.5, 0.5, k) for k in (n, me, m, m)]
+    return z, w, r[0], r[1], r[2], r[3]

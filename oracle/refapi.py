@@ -1,0 +1,180 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of oracle/_ref/libhqpref.so.
+
+The library holds the reference's own Hqp_IpSpBKP / Hqp_IpRedSpBKP
+(hqp/Hqp_IpSpBKP.C, hqp/Hqp_IpRedSpBKP.C, hqp/Hqp_IpMatrix.C, hqp/spBKP.C,
+hqp/sprcm.C + Meschach) compiled by oracle/Makefile from /root/reference.
+It exists only where that build ran (this container; the prebuilt .so travels
+to the GPU box).  ``available()`` tells whether it can be loaded.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_ref", "libhqpref.so")
+_lib = None
+_err = None
+
+_dp = np.ctypeslib.ndpointer(dtype=np.float64, flags="C_CONTIGUOUS")
+_ip = np.ctypeslib.ndpointer(dtype=np.int32, flags="C_CONTIGUOUS")
+
+
+def _load():
+    global _lib, _err
+    if _lib is not None or _err is not None:
+        return _lib
+    try:
+        os.environ.setdefault("TCL_LIBRARY", "/opt/conda/lib/tcl8.6")
+        lib = C.CDLL(_PATH)
+    except OSError as e:  # not built / libtcl missing
+        _err = e
+        return None
+    lib.hqpref_create.restype = C.c_void_p
+    lib.hqpref_create.argtypes = [C.c_int]
+    lib.hqpref_set_params.argtypes = [C.c_void_p, C.c_double, C.c_double]
+    lib.hqpref_init.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp] * 3 + [C.POINTER(C.c_double)]
+    lib.hqpref_update.argtypes = [C.c_void_p] + [_ip, _ip, _dp] * 3
+    lib.hqpref_factor.argtypes = [C.c_void_p, _dp, _dp, C.POINTER(C.c_double)]
+    lib.hqpref_step.argtypes = [C.c_void_p] + [_dp] * 10
+    lib.hqpref_solve.argtypes = [C.c_void_p] + [_dp] * 10 + [C.POINTER(C.c_double)] * 2
+    lib.hqpref_residuum.argtypes = [C.c_void_p] + [_dp] * 10 + [C.POINTER(C.c_double)]
+    lib.hqpref_sbw.argtypes = [C.c_void_p]
+    lib.hqpref_dim.argtypes = [C.c_void_p]
+    lib.hqpref_get_perm.argtypes = [C.c_void_p, _ip]
+    lib.hqpref_get_pivot.argtypes = [C.c_void_p, _ip]
+    lib.hqpref_matrix_nnz.restype = C.c_long
+    lib.hqpref_matrix_nnz.argtypes = [C.c_void_p, C.c_int]
+    lib.hqpref_get_matrix.argtypes = [C.c_void_p, C.c_int, _ip, _ip, _dp]
+    lib.hqpref_destroy.argtypes = [C.c_void_p]
+    _lib = lib
+    return lib
+
+
+def available():
+    return _load() is not None
+
+
+def load_error():
+    _load()
+    return _err
+
+
+class RefError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__(f"reference raised Meschach error {code} in {where}")
+        self.code = code
+
+
+def _pad(a):
+    # ndpointer rejects 0-length views of None; keep at least one element
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    return a if a.size else np.zeros(1)
+
+
+class RefIpMatrix:
+    """The reference plugin (kind 'SpBKP' or 'RedSpBKP') driven through its own
+    virtual interface hqp/Hqp_IpMatrix.h:63-88."""
+
+    def __init__(self, kind="SpBKP", tol=1.0, eps=1e-10):
+        lib = _load()
+        if lib is None:
+            raise RuntimeError(f"oracle/_ref/libhqpref.so not loadable: {_err}")
+        self._lib = lib
+        self.kind = kind
+        self._h = lib.hqpref_create({"SpBKP": 0, "RedSpBKP": 1}[kind])
+        if not self._h:
+            raise RuntimeError("hqpref_create failed (Tcl interpreter?)")
+        lib.hqpref_set_params(self._h, tol, eps)
+        self.t_init = self.t_factor = self.t_solve = 0.0
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._lib.hqpref_destroy(self._h)
+            self._h = None
+
+    def _blocks(self, prog):
+        out = []
+        for (p, i, x) in (prog.Q, prog.A, prog.C):
+            out += [np.ascontiguousarray(p, dtype=np.int32),
+                    np.ascontiguousarray(i, dtype=np.int32) if len(i) else np.zeros(1, np.int32),
+                    _pad(x)]
+        return out
+
+    def init(self, prog):
+        self.n, self.me, self.m = prog.dims
+        t = C.c_double()
+        e = self._lib.hqpref_init(self._h, self.n, self.me, self.m, *self._blocks(prog), C.byref(t))
+        self.t_init = t.value
+        if e:
+            raise RefError(e, "init")
+
+    def update(self, prog):
+        e = self._lib.hqpref_update(self._h, *self._blocks(prog))
+        if e:
+            raise RefError(e, "update")
+
+    def factor(self, z, w):
+        t = C.c_double()
+        e = self._lib.hqpref_factor(self._h, _pad(z), _pad(w), C.byref(t))
+        self.t_factor = t.value
+        if e:
+            raise RefError(e, "factor")
+
+    def _out(self):
+        return [np.zeros(max(k, 1)) for k in (self.n, self.me, self.m, self.m)]
+
+    def _trim(self, d):
+        return [d[0][: self.n], d[1][: self.me], d[2][: self.m], d[3][: self.m]]
+
+    def step(self, z, w, r1, r2, r3, r4):
+        d = self._out()
+        e = self._lib.hqpref_step(self._h, *map(_pad, (z, w, r1, r2, r3, r4)), *d)
+        if e:
+            raise RefError(e, "step")
+        return self._trim(d)
+
+    def solve(self, z, w, r1, r2, r3, r4):
+        d = self._out()
+        res, t = C.c_double(), C.c_double()
+        e = self._lib.hqpref_solve(self._h, *map(_pad, (z, w, r1, r2, r3, r4)), *d, C.byref(res), C.byref(t))
+        self.t_solve = t.value
+        if e:
+            raise RefError(e, "solve")
+        return self._trim(d), res.value
+
+    def residuum(self, z, w, r1, r2, r3, r4, dx, dy, dz, dw):
+        res = C.c_double()
+        e = self._lib.hqpref_residuum(self._h, *map(_pad, (z, w, r1, r2, r3, r4, dx, dy, dz, dw)), C.byref(res))
+        if e:
+            raise RefError(e, "residuum")
+        return res.value
+
+    @property
+    def sbw(self):
+        return self._lib.hqpref_sbw(self._h)
+
+    @property
+    def dim(self):
+        return self._lib.hqpref_dim(self._h)
+
+    def perm(self):
+        p = np.zeros(self.dim, dtype=np.int32)
+        self._lib.hqpref_get_perm(self._h, p)
+        return p
+
+    def pivot(self):
+        p = np.zeros(self.dim, dtype=np.int32)
+        self._lib.hqpref_get_pivot(self._h, p)
+        return p
+
+    def matrix(self, which="raw"):
+        w = 0 if which == "raw" else 1
+        nnz = self._lib.hqpref_matrix_nnz(self._h, w)
+        rp = np.zeros(self.dim + 1, dtype=np.int32)
+        ci = np.zeros(max(nnz, 1), dtype=np.int32)
+        va = np.zeros(max(nnz, 1))
+        self._lib.hqpref_get_matrix(self._h, w, rp, ci, va)
+        return rp, ci[:nnz], va[:nnz]
