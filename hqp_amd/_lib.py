@@ -1,0 +1,87 @@
+"""ctypes binding of the C-ABI library ``libhqpkkt.so`` (include/hqpkkt.h).
+
+There is no CPU fallback: if the HIP extension is missing this module raises,
+and every numeric entry point returns ``HQPKKT_E_DEVICE`` without a gfx950 GPU.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libhqpkkt.so")
+
+OK, E_SIZES, E_MEM, E_SING, E_FORMAT, E_NULL, E_RANGE, E_INTERN, E_DEVICE = 0, 1, 3, 4, 6, 8, 10, 17, 100
+MODE_FULL, MODE_REDUCED = 0, 1
+LOC_HOST, LOC_DEVICE = 0, 1
+
+# every symbol include/hqpkkt.h declares
+SYMBOLS = [
+    "hqpkkt_default_opts", "hqpkkt_create", "hqpkkt_destroy", "hqpkkt_analyze",
+    "hqpkkt_set_values", "hqpkkt_factor", "hqpkkt_step", "hqpkkt_residual", "hqpkkt_solve",
+    "hqpkkt_get_sbw", "hqpkkt_get_perm", "hqpkkt_set_tol", "hqpkkt_set_eps",
+    "hqpkkt_set_stream", "hqpkkt_get_stats", "hqpkkt_strerror", "hqpkkt_debug_get",
+    "hqpkkt_selftest_mfma",
+]
+
+
+class Opts(C.Structure):
+    _fields_ = [("mode", C.c_int), ("device", C.c_int), ("loc", C.c_int), ("tol", C.c_double),
+                ("eps", C.c_double), ("pivot_eps", C.c_double), ("leaf_size", C.c_int),
+                ("max_pivots", C.c_int), ("reserved", C.c_int * 6)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("dim", C.c_int), ("sbw", C.c_int), ("n_supernodes", C.c_int),
+                ("n_levels", C.c_int), ("max_front", C.c_int), ("nnz_kkt", C.c_longlong),
+                ("nnz_factor", C.c_longlong), ("flops_factor", C.c_longlong),
+                ("bytes_panels", C.c_longlong), ("bytes_updates", C.c_longlong),
+                ("n_2x2", C.c_int), ("n_perturbed", C.c_int), ("refine_rounds", C.c_int),
+                ("kmax", C.c_double), ("ms_assemble", C.c_float), ("ms_factor", C.c_float),
+                ("ms_step", C.c_float), ("ms_residual", C.c_float), ("ms_solve", C.c_float)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+_lib = None
+
+
+def lib():
+    """Load the HIP extension; fail loudly when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(hipcc --offload-arch=gfx950).  hqp_amd has no CPU fallback.")
+    L = C.CDLL(LIB_PATH)
+    vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.c_void_p  # vectors go as raw addresses
+    L.hqpkkt_default_opts.argtypes = [C.POINTER(Opts)]
+    L.hqpkkt_create.argtypes = [C.POINTER(Opts), C.POINTER(vp)]
+    L.hqpkkt_destroy.argtypes = [vp]
+    L.hqpkkt_analyze.argtypes = [vp, C.c_int, C.c_int, C.c_int] + [vp] * 6 + [ip]
+    L.hqpkkt_set_values.argtypes = [vp, dp, dp, dp]
+    L.hqpkkt_factor.argtypes = [vp, dp, dp]
+    L.hqpkkt_step.argtypes = [vp] + [dp] * 10
+    L.hqpkkt_residual.argtypes = [vp] + [dp] * 10 + [C.POINTER(C.c_double)]
+    L.hqpkkt_solve.argtypes = [vp] + [dp] * 10 + [C.POINTER(C.c_double)]
+    L.hqpkkt_get_sbw.argtypes = [vp, ip]
+    L.hqpkkt_get_perm.argtypes = [vp, vp]
+    L.hqpkkt_set_tol.argtypes = [vp, C.c_double]
+    L.hqpkkt_set_eps.argtypes = [vp, C.c_double]
+    L.hqpkkt_set_stream.argtypes = [vp, vp]
+    L.hqpkkt_get_stats.argtypes = [vp, C.POINTER(Stats)]
+    L.hqpkkt_strerror.restype = C.c_char_p
+    L.hqpkkt_strerror.argtypes = [C.c_int]
+    L.hqpkkt_debug_get.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_longlong)]
+    L.hqpkkt_selftest_mfma.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    _lib = L
+    return L
+
+
+def strerror(code):
+    return lib().hqpkkt_strerror(code).decode()

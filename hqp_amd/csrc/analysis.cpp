@@ -1,0 +1,510 @@
+// Symbolic phase (host).  See analysis.hpp.
+//
+// Reference semantics followed here:
+//   KKT pattern  hqp/Hqp_IpSpBKP.C:117-136  (-Q upper, A, C, slack diagonal)
+//                hqp/Hqp_IpRedSpBKP.C:203-262 (-(Q + C'C) pattern, A)
+//   RCM          hqp/sprcm.C:62-211 (graph), :226-384 (order), :391-420 (sbw)
+// Everything after the RCM order (nested dissection of the band, supernodes,
+// fronts) has no counterpart in the reference, whose factorisation is a
+// sequential row-list elimination (hqp/spBKP.C:406-636).
+#include "analysis.hpp"
+
+#include <algorithm>
+#include <cstring>
+#include <numeric>
+
+namespace kktdev {
+namespace {
+
+struct LevelItem {
+  int node, deg, deg2;
+};
+
+// Reverse Cuthill-McKee exactly as the reference runs it: the start node of
+// each component is the first unnumbered node; the level structure is rebuilt
+// from the minimum-degree node of the last level while the number of levels
+// grows; inside a level, nodes are kept sorted by (live degree, sum of live
+// degrees of unnumbered neighbours) with a stable sort, the whole new level
+// being re-sorted after each parent has been expanded.
+void rcm_order(int dim, const std::vector<int> &start, const std::vector<int> &neigh,
+               std::vector<int> &order) {
+  std::vector<char> marks(dim), glob(dim, 1);
+  std::vector<LevelItem> lv(dim + 1);
+  std::vector<int> live(dim);
+  auto reset_live = [&]() {
+    for (int i = 0; i < dim; i++) live[i] = start[i + 1] - start[i];
+  };
+  auto number = [&](int v, int &count) {
+    lv[count++].node = v;
+    marks[v] = 0;
+    for (int k = start[v]; k < start[v + 1]; k++) live[neigh[k]]--;
+  };
+  reset_live();
+  int root = 0, count = 0;
+  while (root < dim) {
+    int nlev = 0, nlev_old, first = count, lb = 0, le = 0;
+    do {
+      count = first;
+      marks = glob;
+      nlev_old = nlev;
+      nlev = 0;
+      lb = le = count;
+      number(root, count);
+      do {
+        lb = le;
+        le = count;
+        nlev++;
+        for (int i = lb; i < le; i++) {
+          const int v = lv[i].node;
+          for (int j = start[v]; j < start[v + 1]; j++)
+            if (marks[neigh[j]]) number(neigh[j], count);
+          if (count - le > 1) {
+            for (int k = le; k < count; k++) {
+              const int u = lv[k].node;
+              int d2 = 0;
+              for (int j = start[u]; j < start[u + 1]; j++)
+                if (marks[neigh[j]]) d2 += live[neigh[j]];
+              lv[k].deg = live[u];
+              lv[k].deg2 = d2;
+            }
+            std::stable_sort(lv.begin() + le, lv.begin() + count,
+                             [](const LevelItem &a, const LevelItem &b) {
+                               return a.deg != b.deg ? a.deg < b.deg : a.deg2 < b.deg2;
+                             });
+          }
+        }
+      } while (count > le);
+      root = lv[lb].node;
+      for (int i = lb + 1; i < le; i++)
+        if (live[lv[i].node] < live[root]) root = lv[i].node;
+      reset_live();
+    } while (nlev > nlev_old);
+    glob = marks;
+    root = dim;
+    for (int i = 0; i < dim; i++)
+      if (marks[i]) root = i;
+  }
+  order.assign(dim, 0);
+  for (int i = 0; i < dim; i++) order[lv[i].node] = dim - 1 - i;
+}
+
+bool csr_ok(int rows, int cols, const int *p, const int *ix) {
+  if (!p) return rows == 0;
+  if (p[0] != 0) return false;
+  for (int r = 0; r < rows; r++) {
+    if (p[r + 1] < p[r]) return false;
+    for (int k = p[r]; k < p[r + 1]; k++) {
+      if (ix[k] < 0 || ix[k] >= cols) return false;
+      if (k > p[r] && ix[k] <= ix[k - 1]) return false;
+    }
+  }
+  return true;
+}
+
+struct RawEntry {
+  long long key;
+  int a, b;
+  Term t;
+};
+
+void transpose(const Analysis::Csr &M, int cols, Analysis::Csr &T) {
+  T.rows = cols;
+  T.ptr.assign(cols + 1, 0);
+  for (int c : M.col) T.ptr[c + 1]++;
+  for (int c = 0; c < cols; c++) T.ptr[c + 1] += T.ptr[c];
+  T.col.resize(M.col.size());
+  T.src.resize(M.col.size());
+  std::vector<int> fill(T.ptr.begin(), T.ptr.end() - 1);
+  for (int r = 0; r < M.rows; r++)
+    for (int k = M.ptr[r]; k < M.ptr[r + 1]; k++) {
+      int d = fill[M.col[k]]++;
+      T.col[d] = r;
+      T.src[d] = M.src[k];
+    }
+}
+
+}  // namespace
+
+int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *Qi,
+                  const int *Ap, const int *Ai, const int *Cp, const int *Ci, int leaf_size,
+                  int max_pivots) {
+  mode = mode_, n = n_, me = me_, m = m_;
+  if (n < 0 || me < 0 || m < 0 || n + me + m == 0) return 1;
+  if (!csr_ok(n, n, Qp, Qi) || !csr_ok(me, n, Ap, Ai) || !csr_ok(m, n, Cp, Ci)) return 6;
+  dim = mode == 0 ? n + me + m : n + me;
+  nq = n ? Qp[n] : 0, na = me ? Ap[me] : 0, nc = m ? Cp[m] : 0;
+  const int ONE = nq + na + nc, WONE = m;
+  if (max_pivots <= 0 || max_pivots > 128) max_pivots = 96;
+  if (leaf_size <= 0) leaf_size = 0;  // decided below from sbw
+
+  // ---------------------------------------------------------- SpMV blocks
+  {
+    std::vector<std::vector<std::pair<int, int>>> rows(n);
+    for (int i = 0; i < n; i++)
+      for (int k = Qp[i]; k < Qp[i + 1]; k++)
+        if (Qi[k] >= i) {
+          rows[i].push_back({Qi[k], k});
+          if (Qi[k] != i) rows[Qi[k]].push_back({i, k});
+        }
+    Qfull.rows = n;
+    Qfull.ptr.assign(n + 1, 0);
+    for (int i = 0; i < n; i++) {
+      std::sort(rows[i].begin(), rows[i].end());
+      Qfull.ptr[i + 1] = Qfull.ptr[i] + (int)rows[i].size();
+      for (auto &e : rows[i]) Qfull.col.push_back(e.first), Qfull.src.push_back(e.second);
+    }
+    A.rows = me;
+    A.ptr.assign(Ap ? Ap : (const int *)nullptr, Ap ? Ap + me + 1 : nullptr);
+    if (A.ptr.empty()) A.ptr.assign(1, 0);
+    A.col.assign(Ai, Ai + na);
+    A.src.resize(na);
+    std::iota(A.src.begin(), A.src.end(), nq);
+    C.rows = m;
+    C.ptr.assign(Cp ? Cp : (const int *)nullptr, Cp ? Cp + m + 1 : nullptr);
+    if (C.ptr.empty()) C.ptr.assign(1, 0);
+    C.col.assign(Ci, Ci + nc);
+    C.src.resize(nc);
+    std::iota(C.src.begin(), C.src.end(), nq + na);
+    transpose(A, n, AT);
+    transpose(C, n, CT);
+  }
+
+  // ------------------------------------------------------------- entries
+  std::vector<RawEntry> raw;
+  auto add = [&](int a, int b, Term t) {
+    int lo = std::min(a, b), hi = std::max(a, b);
+    raw.push_back({(long long)lo * dim + hi, lo, hi, t});
+  };
+  for (int i = 0; i < n; i++)
+    for (int k = Qp[i]; k < Qp[i + 1]; k++)
+      if (Qi[k] >= i) add(i, Qi[k], {k, ONE, WONE, -1.0});
+  for (int r = 0; r < me; r++)
+    for (int k = Ap[r]; k < Ap[r + 1]; k++) add(n + r, Ai[k], {nq + k, ONE, WONE, 1.0});
+  if (mode == 0) {
+    for (int r = 0; r < m; r++)
+      for (int k = Cp[r]; k < Cp[r + 1]; k++)
+        add(n + me + r, Ci[k], {nq + na + k, ONE, WONE, 1.0});
+    for (int j = 0; j < m; j++) add(n + me + j, n + me + j, {ONE, ONE, j, 1.0});
+  } else {
+    for (int r = 0; r < m; r++)
+      for (int a = Cp[r]; a < Cp[r + 1]; a++)
+        for (int b = Cp[r]; b <= a; b++)
+          add(Ci[a], Ci[b], {nq + na + a, nq + na + b, r, -1.0});
+  }
+  std::stable_sort(raw.begin(), raw.end(),
+                   [](const RawEntry &x, const RawEntry &y) { return x.key < y.key; });
+  ent_a.clear(), ent_b.clear(), term_ptr.assign(1, 0), terms.clear();
+  for (size_t k = 0; k < raw.size(); k++) {
+    if (k == 0 || raw[k].key != raw[k - 1].key) {
+      if (k) term_ptr.push_back((int)terms.size());
+      ent_a.push_back(raw[k].a), ent_b.push_back(raw[k].b);
+    }
+    terms.push_back(raw[k].t);
+  }
+  term_ptr.push_back((int)terms.size());
+  const int nent = (int)ent_a.size();
+  diag_ent.assign(n, -1);
+  for (int e = 0; e < nent; e++)
+    if (ent_a[e] == ent_b[e] && ent_a[e] < n) diag_ent[ent_a[e]] = e;
+
+  // ---------------------------------------------------------- RCM graph
+  // neighbour lists in the reference's visiting order: x-x couplings row by
+  // row (upper triangle), then the rows of A, then the rows of C
+  std::vector<int> gdeg(dim + 1, 0), gstart(dim + 1, 0);
+  auto count_edge = [&](int a, int b) { gdeg[a]++, gdeg[b]++; };
+  for (int e = 0; e < nent; e++)
+    if (ent_b[e] < n && ent_a[e] != ent_b[e]) count_edge(ent_a[e], ent_b[e]);
+  for (int r = 0; r < me; r++)
+    for (int k = Ap[r]; k < Ap[r + 1]; k++) count_edge(n + r, Ai[k]);
+  if (mode == 0)
+    for (int r = 0; r < m; r++)
+      for (int k = Cp[r]; k < Cp[r + 1]; k++) count_edge(n + me + r, Ci[k]);
+  for (int i = 0; i < dim; i++) gstart[i + 1] = gstart[i] + gdeg[i];
+  std::vector<int> gneigh(gstart[dim]), gfill(gstart.begin(), gstart.end() - 1);
+  auto link = [&](int a, int b) { gneigh[gfill[a]++] = b, gneigh[gfill[b]++] = a; };
+  for (int e = 0; e < nent; e++)
+    if (ent_b[e] < n && ent_a[e] != ent_b[e]) link(ent_a[e], ent_b[e]);
+  for (int r = 0; r < me; r++)
+    for (int k = Ap[r]; k < Ap[r + 1]; k++) link(n + r, Ai[k]);
+  if (mode == 0)
+    for (int r = 0; r < m; r++)
+      for (int k = Cp[r]; k < Cp[r + 1]; k++) link(n + me + r, Ci[k]);
+
+  rcm_order(dim, gstart, gneigh, qp2j);
+  sbw = 0;
+  std::vector<int> reach(dim);  // by band position: farthest coupled position
+  for (int v = 0; v < dim; v++) {
+    int far = qp2j[v];
+    for (int k = gstart[v]; k < gstart[v + 1]; k++) far = std::max(far, qp2j[gneigh[k]]);
+    reach[qp2j[v]] = far;
+    sbw = std::max(sbw, far - qp2j[v]);
+  }
+
+  // ------------------------------------------- nested dissection of the band
+  if (leaf_size <= 0) leaf_size = std::max(2 * std::max(sbw, 1), 32);
+  struct Tmp {
+    int lo, hi;
+    std::vector<int> kids;
+  };
+  std::vector<Tmp> tmp;
+  // chain of supernodes covering positions [lo,hi); returns the top node
+  auto chain = [&](int lo, int hi, std::vector<int> kids) {
+    int len = hi - lo, parts = (len + max_pivots - 1) / max_pivots;
+    int size = (len + parts - 1) / parts, top = -1;
+    for (int s = lo; s < hi; s += size) {
+      Tmp t{s, std::min(s + size, hi), {}};
+      if (top < 0)
+        t.kids = kids;
+      else
+        t.kids.push_back(top);
+      tmp.push_back(t);
+      top = (int)tmp.size() - 1;
+    }
+    return top;
+  };
+  // iterative recursion (explicit stack) returning the roots of [lo,hi)
+  struct Frame {
+    int lo, hi, stage, mid, send;
+    std::vector<int> left, right;
+  };
+  std::vector<int> roots;
+  {
+    std::vector<Frame> st;
+    std::vector<std::vector<int>> ret;  // return values stack
+    st.push_back({0, dim, 0, 0, 0, {}, {}});
+    while (!st.empty()) {
+      Frame &f = st.back();
+      int len = f.hi - f.lo;
+      if (f.stage == 0) {
+        if (len <= 0) {
+          ret.push_back({});
+          st.pop_back();
+          continue;
+        }
+        if (len <= leaf_size) {
+          ret.push_back({chain(f.lo, f.hi, {})});
+          st.pop_back();
+          continue;
+        }
+        // centre the separator: both sides get about (len - sbw)/2 rows
+        f.mid = f.lo + std::max(1, (len - std::min(sbw, len / 3)) / 2);
+        int send = f.mid;
+        for (int r = f.lo; r < f.mid; r++) send = std::max(send, std::min(reach[r] + 1, f.hi));
+        f.send = send;
+        if ((send - f.mid) * 3 >= len) {  // separator would dominate: keep as a chain
+          ret.push_back({chain(f.lo, f.hi, {})});
+          st.pop_back();
+          continue;
+        }
+        f.stage = 1;
+        int lo = f.lo, mid = f.mid;
+        st.push_back({lo, mid, 0, 0, 0, {}, {}});
+        continue;
+      }
+      if (f.stage == 1) {
+        f.left = ret.back();
+        ret.pop_back();
+        f.stage = 2;
+        int send = f.send, hi = f.hi;
+        st.push_back({send, hi, 0, 0, 0, {}, {}});
+        continue;
+      }
+      f.right = ret.back();
+      ret.pop_back();
+      std::vector<int> kids = f.left;
+      kids.insert(kids.end(), f.right.begin(), f.right.end());
+      if (f.send > f.mid)
+        ret.push_back({chain(f.mid, f.send, kids)});
+      else
+        ret.push_back(kids);
+      st.pop_back();
+    }
+    roots = ret.back();
+  }
+
+  // postorder renumbering
+  nnodes = (int)tmp.size();
+  std::vector<int> newid(nnodes, -1), order;
+  order.reserve(nnodes);
+  {
+    std::vector<std::pair<int, size_t>> st;
+    for (int r : roots) {
+      st.push_back({r, 0});
+      while (!st.empty()) {
+        auto &top = st.back();
+        if (top.second < tmp[top.first].kids.size()) {
+          int c = tmp[top.first].kids[top.second++];
+          st.push_back({c, 0});
+        } else {
+          newid[top.first] = (int)order.size();
+          order.push_back(top.first);
+          st.pop_back();
+        }
+      }
+    }
+  }
+  piv_start.assign(nnodes, 0), npiv.assign(nnodes, 0), parent.assign(nnodes, -1);
+  level.assign(nnodes, 0), child_slot.assign(nnodes, 0);
+  std::vector<int> j2e(dim);
+  {
+    int e = 0;
+    for (int id = 0; id < nnodes; id++) {
+      const Tmp &t = tmp[order[id]];
+      piv_start[id] = e;
+      npiv[id] = t.hi - t.lo;
+      for (int r = t.lo; r < t.hi; r++) j2e[r] = e++;
+      for (size_t s = 0; s < t.kids.size(); s++) {
+        int c = newid[t.kids[s]];
+        parent[c] = id;
+        child_slot[c] = (int)s;
+        level[id] = std::max(level[id], level[c] + 1);
+      }
+    }
+  }
+  q2e.resize(dim), e2q.resize(dim);
+  for (int q = 0; q < dim; q++) q2e[q] = j2e[qp2j[q]], e2q[q2e[q]] = q;
+  std::vector<int> owner(dim);
+  for (int id = 0; id < nnodes; id++)
+    for (int k = 0; k < npiv[id]; k++) owner[piv_start[id] + k] = id;
+
+  // ------------------------------------------------------ symbolic fronts
+  ent_er.resize(nent), ent_ec.resize(nent);
+  std::vector<std::vector<int>> node_hi(nnodes);
+  for (int e = 0; e < nent; e++) {
+    int ea = q2e[ent_a[e]], eb = q2e[ent_b[e]];
+    ent_ec[e] = std::min(ea, eb), ent_er[e] = std::max(ea, eb);
+    int o = owner[ent_ec[e]];
+    if (ent_er[e] >= piv_start[o] + npiv[o]) node_hi[o].push_back(ent_er[e]);
+  }
+  child_ptr.assign(nnodes + 1, 0);
+  for (int id = 0; id < nnodes; id++)
+    if (parent[id] >= 0) child_ptr[parent[id] + 1]++;
+  for (int id = 0; id < nnodes; id++) child_ptr[id + 1] += child_ptr[id];
+  child_idx.assign(child_ptr[nnodes], 0);
+  {
+    std::vector<int> fill(child_ptr.begin(), child_ptr.end() - 1);
+    for (int id = 0; id < nnodes; id++)
+      if (parent[id] >= 0) child_idx[child_ptr[parent[id]] + child_slot[id]] = id, fill[parent[id]]++;
+  }
+  bptr.assign(nnodes + 1, 0);
+  bidx.clear();
+  nbor.assign(nnodes, 0);
+  {
+    std::vector<int> stamp(dim, -1), cur;
+    for (int id = 0; id < nnodes; id++) {
+      cur.clear();
+      const int pend = piv_start[id] + npiv[id];
+      auto take = [&](int e) {
+        if (e >= pend && stamp[e] != id) stamp[e] = id, cur.push_back(e);
+      };
+      for (int e : node_hi[id]) take(e);
+      for (int k = child_ptr[id]; k < child_ptr[id + 1]; k++) {
+        int c = child_idx[k];
+        for (long long t = bptr[c]; t < bptr[c + 1]; t++) take(bidx[t]);
+      }
+      std::sort(cur.begin(), cur.end());
+      nbor[id] = (int)cur.size();
+      bidx.insert(bidx.end(), cur.begin(), cur.end());
+      bptr[id + 1] = (long long)bidx.size();
+      if (parent[id] < 0 && !cur.empty()) return 17;  // a root must have no border
+    }
+  }
+  rel.assign(bidx.size(), -1);
+  for (int id = 0; id < nnodes; id++) {
+    int q = parent[id];
+    if (q < 0) continue;
+    const int qs = piv_start[q], qe = qs + npiv[q];
+    const int *qb = bidx.data() + bptr[q];
+    for (long long t = bptr[id]; t < bptr[id + 1]; t++) {
+      int e = bidx[t];
+      if (e < qs) return 17;
+      if (e < qe)
+        rel[t] = e - qs;
+      else {
+        const int *pos = std::lower_bound(qb, qb + nbor[q], e);
+        if (pos == qb + nbor[q] || *pos != e) return 17;
+        rel[t] = npiv[q] + (int)(pos - qb);
+      }
+    }
+  }
+
+  // --------------------------------------------------- storage + schedules
+  panel_off.assign(nnodes, 0), upd_off.assign(nnodes, 0), x_off.assign(nnodes, 0);
+  cb_off.assign(nnodes, 0);
+  panel_elems = upd_elems = x_elems = cb_elems = 0;
+  max_front = max_npiv = max_nbor = 0;
+  nnz_factor = flops_factor = 0;
+  nlevels = 0;
+  for (int id = 0; id < nnodes; id++) {
+    const long long p = npiv[id], b = nbor[id], F = p + b;
+    panel_off[id] = panel_elems, panel_elems += F * p;
+    upd_off[id] = upd_elems, upd_elems += b * b;
+    x_off[id] = x_elems, x_elems += b * p;
+    cb_off[id] = cb_elems, cb_elems += b;
+    max_front = std::max<int>(max_front, (int)F);
+    max_npiv = std::max<int>(max_npiv, (int)p);
+    max_nbor = std::max<int>(max_nbor, (int)b);
+    nlevels = std::max(nlevels, level[id] + 1);
+    nnz_factor += p * (p + 1) / 2 + b * p;
+    flops_factor += p * p * p / 3 + b * p * p + b * b * p;  // diag block, panel solve, update (lower half)
+  }
+  level_ptr.assign(nlevels + 1, 0);
+  for (int id = 0; id < nnodes; id++) level_ptr[level[id] + 1]++;
+  for (int l = 0; l < nlevels; l++) level_ptr[l + 1] += level_ptr[l];
+  level_nodes.assign(nnodes, 0);
+  {
+    std::vector<int> fill(level_ptr.begin(), level_ptr.end() - 1);
+    for (int id = 0; id < nnodes; id++) level_nodes[fill[level[id]]++] = id;
+  }
+  // extend-add segments: for parent level l, slot s -> children list
+  ea_level_ptr.assign(nlevels + 1, 0);
+  ea_seg_ptr.assign(1, 0);
+  ea_nodes.clear();
+  for (int l = 0; l < nlevels; l++) {
+    int maxslots = 0;
+    for (int t = level_ptr[l]; t < level_ptr[l + 1]; t++) {
+      int id = level_nodes[t];
+      maxslots = std::max(maxslots, child_ptr[id + 1] - child_ptr[id]);
+    }
+    for (int s = 0; s < maxslots; s++) {
+      for (int t = level_ptr[l]; t < level_ptr[l + 1]; t++) {
+        int id = level_nodes[t];
+        if (child_ptr[id + 1] - child_ptr[id] > s) ea_nodes.push_back(child_idx[child_ptr[id] + s]);
+      }
+      ea_seg_ptr.push_back((int)ea_nodes.size());
+    }
+    ea_level_ptr[l + 1] = (int)ea_seg_ptr.size() - 1;
+  }
+  upd_tile_ptr.assign(nlevels + 1, 0), slab_ptr.assign(nlevels + 1, 0);
+  upd_tiles.clear(), slabs.clear();
+  for (int l = 0; l < nlevels; l++) {
+    for (int t = level_ptr[l]; t < level_ptr[l + 1]; t++) {
+      int id = level_nodes[t], b = nbor[id];
+      int nt = (b + UPD_TILE - 1) / UPD_TILE;
+      for (int ti = 0; ti < nt; ti++)
+        for (int tj = 0; tj <= ti; tj++) upd_tiles.insert(upd_tiles.end(), {id, ti, tj});
+      int ns = (b + SLAB_ROWS - 1) / SLAB_ROWS;
+      for (int s = 0; s < ns; s++) slabs.insert(slabs.end(), {id, s});
+    }
+    upd_tile_ptr[l + 1] = (int)upd_tiles.size() / 3;
+    slab_ptr[l + 1] = (int)slabs.size() / 2;
+  }
+
+  // ------------------------------------------------------- assembly map
+  ent_dst.resize(nent);
+  for (int e = 0; e < nent; e++) {
+    int o = owner[ent_ec[e]];
+    const long long F = npiv[o] + nbor[o];
+    int lc = ent_ec[e] - piv_start[o], lr;
+    if (ent_er[e] < piv_start[o] + npiv[o])
+      lr = ent_er[e] - piv_start[o];
+    else {
+      const int *b0 = bidx.data() + bptr[o];
+      lr = npiv[o] + (int)(std::lower_bound(b0, b0 + nbor[o], ent_er[e]) - b0);
+    }
+    ent_dst[e] = panel_off[o] + (long long)lc * F + lr;
+  }
+  return 0;
+}
+
+}  // namespace kktdev

@@ -1,0 +1,72 @@
+// Host-side symbolic phase of the KKT path: KKT pattern from the Q/A/C blocks,
+// RCM ordering (semantics of hqp/sprcm.C:62-420), nested dissection of the RCM
+// band into an assembly tree of supernodes, symbolic fronts, and the index maps
+// the device kernels consume.  Integer work only; runs once per init().
+#pragma once
+#include <cstdint>
+#include <vector>
+
+namespace kktdev {
+
+// One stored entry of the (permuted, symmetric) matrix that gets factored.
+// value = sum over its terms of  sgn * vals[s1] * vals[s2] * wt[wi]
+// (vals = [Qx | Ax | Cx | 1.0], wt = [per-inequality weight | 1.0]).
+struct Term {
+  int s1, s2, wi;
+  double sgn;
+};
+
+struct Analysis {
+  int mode = 0, n = 0, me = 0, m = 0, dim = 0, sbw = -1;
+  int nq = 0, na = 0, nc = 0;  // nnz of the Q, A, C blocks as passed in
+
+  // --- entries of the matrix in QP numbering (a <= b not required) ----------
+  std::vector<int> ent_a, ent_b;       // QP indices of the two ends
+  std::vector<int> term_ptr;           // CSR over terms, size nent+1
+  std::vector<Term> terms;
+  std::vector<int> diag_ent;           // REDUCED: entry id of the (i,i) entry, i < n
+
+  // --- orderings --------------------------------------------------------------
+  std::vector<int> qp2j;  // RCM: QP index -> band position  (reference's _QP2J)
+  std::vector<int> q2e;   // QP index -> elimination index
+  std::vector<int> e2q;
+
+  // --- assembly tree (node ids are a postorder: children before parents) -----
+  int nnodes = 0, nlevels = 0, max_front = 0, max_npiv = 0, max_nbor = 0;
+  std::vector<int> piv_start, npiv, nbor, parent, level, child_slot;
+  std::vector<long long> bptr;  // border_ptr, size nnodes+1
+  std::vector<int> bidx;        // border rows (elimination indices), sorted per node
+  std::vector<int> rel;         // same indexing as bidx: local index in the parent front
+  std::vector<long long> panel_off, upd_off, x_off;  // element offsets into the arenas
+  long long panel_elems = 0, upd_elems = 0, x_elems = 0, cb_elems = 0;
+  std::vector<long long> cb_off;  // contribution-vector offsets (solve)
+  std::vector<int> level_ptr, level_nodes;  // nodes grouped by level
+  // children grouped by (parent level, slot) for deterministic extend-add
+  std::vector<int> ea_seg_ptr, ea_nodes, ea_level_ptr;  // segments per level
+  // children lists (for the solve gather)
+  std::vector<int> child_ptr, child_idx;
+  // tiles of the Schur update and slabs of the panel solve, grouped by level
+  std::vector<int> upd_tile_ptr, upd_tiles;    // triples (node, ti, tj)
+  std::vector<int> slab_ptr, slabs;            // pairs (node, slab)
+
+  // --- numeric assembly map ----------------------------------------------------
+  std::vector<long long> ent_dst;  // offset into the panel arena per entry
+  std::vector<int> ent_er, ent_ec; // elimination indices (row >= col) per entry
+
+  // --- SpMV blocks for step()/residuum(): CSR with value indirection ----------
+  struct Csr {
+    int rows = 0;
+    std::vector<int> ptr, col, src;
+  };
+  Csr Qfull, A, AT, C, CT;
+
+  long long nnz_factor = 0, flops_factor = 0;
+
+  int run(int mode, int n, int me, int m, const int *Qp, const int *Qi, const int *Ap,
+          const int *Ai, const int *Cp, const int *Ci, int leaf_size, int max_pivots);
+};
+
+static const int UPD_TILE = 64;   // Schur-update tile edge (rows/cols per workgroup)
+static const int SLAB_ROWS = 32;  // border rows per panel-solve workgroup
+
+}  // namespace kktdev

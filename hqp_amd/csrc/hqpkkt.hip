@@ -1,0 +1,724 @@
+// C ABI of the MI355X KKT path (include/hqpkkt.h): handle management, device
+// residency of the symbolic structure, kernel sequencing for
+// assemble -> factor -> step -> residuum -> solve.
+#include "../../include/hqpkkt.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <new>
+#include <vector>
+
+#include "analysis.hpp"
+#include "kernels.hip.h"
+
+using namespace kktdev;
+
+#define HIPCHK(call)                                                              \
+  do {                                                                            \
+    hipError_t e_ = (call);                                                       \
+    if (e_ != hipSuccess) {                                                       \
+      std::snprintf(g_last_hip_error, sizeof(g_last_hip_error), "%s:%d %s: %s", __FILE__, \
+                    __LINE__, #call, hipGetErrorString(e_));                      \
+      return HQPKKT_E_DEVICE;                                                     \
+    }                                                                             \
+  } while (0)
+
+static char g_last_hip_error[512] = "";
+
+namespace {
+
+template <class T>
+struct DBuf {
+  T *p = nullptr;
+  size_t count = 0;
+  int alloc(size_t k) {
+    release();
+    count = k;
+    if (hipMalloc((void **)&p, sizeof(T) * (k ? k : 1)) != hipSuccess) {
+      p = nullptr;
+      return HQPKKT_E_MEM;
+    }
+    return 0;
+  }
+  int upload(const std::vector<T> &v) {
+    int e = alloc(v.size());
+    if (e) return e;
+    if (!v.empty() &&
+        hipMemcpy(p, v.data(), sizeof(T) * v.size(), hipMemcpyHostToDevice) != hipSuccess)
+      return HQPKKT_E_DEVICE;
+    return 0;
+  }
+  void release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    count = 0;
+  }
+};
+
+struct CsrBuf {
+  DBuf<int> ptr, col, src;
+  int upload(const Analysis::Csr &c) {
+    int e;
+    if ((e = ptr.upload(c.ptr)) || (e = col.upload(c.col)) || (e = src.upload(c.src))) return e;
+    return 0;
+  }
+  CsrDev dev() const { return CsrDev{ptr.p, col.p, src.p}; }
+  void release() { ptr.release(), col.release(), src.release(); }
+};
+
+}  // namespace
+
+struct hqpkkt {
+  hqpkkt_opts opts;
+  Analysis an;
+  bool analyzed = false, uploaded = false, have_values = false, factored = false;
+  hipStream_t own_stream = nullptr, stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr;
+  hqpkkt_stats st;
+
+  // symbolic structure on the device
+  DBuf<int> piv_start, npiv, nbor, parent, bidx, rel, child_ptr, child_idx, level_nodes,
+      ea_nodes, upd_tiles, slabs, ent_a, ent_b, term_ptr, diag_ent, q2e;
+  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst;
+  DBuf<TermDev> terms;
+  DBuf<signed char> esign;
+  CsrBuf Qf, A, AT, C, CT;
+  // numeric state
+  DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb;
+  DBuf<int> ptype, lperm, flags;  // flags: [0] status, [1] n_2x2, [2] n_perturbed
+  DBuf<unsigned long long> bits;  // [0] kmax, [1] residual max
+  // vectors: staging for host pointers + refinement work vectors
+  DBuf<double> vin;   // z w r1 r2 r3 r4
+  DBuf<double> vout;  // dx dy dz dw
+  DBuf<double> vres;  // residual vectors _r1.._r4
+  DBuf<double> vcor;  // corrections _dx.._dw
+  DBuf<double> tz;    // REDUCED temporary (m)
+  size_t lds_diag = 0, lds_panel = 0, lds_solve = 0;
+
+  DevTree tree() const {
+    return DevTree{piv_start.p, npiv.p,     nbor.p,  parent.p, bptr.p,      bidx.p,     rel.p,
+                   panel_off.p, upd_off.p, x_off.p, cb_off.p, child_ptr.p, child_idx.p};
+  }
+  void release_device() {
+    DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
+                       &level_nodes, &ea_nodes, &upd_tiles, &slabs, &ent_a, &ent_b, &term_ptr,
+                       &diag_ent, &q2e, &ptype, &lperm, &flags};
+    for (auto b : ib) b->release();
+    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst};
+    for (auto b : lb) b->release();
+    DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
+                          &cb, &vin, &vout, &vres, &vcor, &tz};
+    for (auto b : db) b->release();
+    terms.release(), esign.release(), bits.release();
+    Qf.release(), A.release(), AT.release(), C.release(), CT.release();
+    uploaded = have_values = factored = false;
+  }
+};
+
+static inline int nblk(long long work, int bs = 256) { return (int)((work + bs - 1) / bs); }
+
+static int ensure_device(hqpkkt_t *h) {
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= h->opts.device) {
+    std::snprintf(g_last_hip_error, sizeof(g_last_hip_error),
+                  "no HIP device %d (gfx950 required; there is no CPU fallback)", h->opts.device);
+    return HQPKKT_E_DEVICE;
+  }
+  HIPCHK(hipSetDevice(h->opts.device));
+  if (!h->own_stream) {
+    HIPCHK(hipStreamCreateWithFlags(&h->own_stream, hipStreamNonBlocking));
+    HIPCHK(hipEventCreate(&h->ev0));
+    HIPCHK(hipEventCreate(&h->ev1));
+    HIPCHK(hipEventCreate(&h->evs0));
+    HIPCHK(hipEventCreate(&h->evs1));
+  }
+  if (!h->stream) h->stream = h->own_stream;
+  return 0;
+}
+
+static int upload(hqpkkt_t *h) {
+  int e = ensure_device(h);
+  if (e) return e;
+  Analysis &an = h->an;
+#define UP(buf, vec) \
+  if ((e = h->buf.upload(an.vec))) return e
+  UP(piv_start, piv_start);
+  UP(npiv, npiv);
+  UP(nbor, nbor);
+  UP(parent, parent);
+  UP(bidx, bidx);
+  UP(rel, rel);
+  UP(child_ptr, child_ptr);
+  UP(child_idx, child_idx);
+  UP(level_nodes, level_nodes);
+  UP(ea_nodes, ea_nodes);
+  UP(upd_tiles, upd_tiles);
+  UP(slabs, slabs);
+  UP(ent_a, ent_a);
+  UP(ent_b, ent_b);
+  UP(term_ptr, term_ptr);
+  UP(diag_ent, diag_ent);
+  UP(q2e, q2e);
+  UP(bptr, bptr);
+  UP(panel_off, panel_off);
+  UP(upd_off, upd_off);
+  UP(x_off, x_off);
+  UP(cb_off, cb_off);
+  UP(ent_dst, ent_dst);
+#undef UP
+  {
+    std::vector<TermDev> t(an.terms.size());
+    for (size_t k = 0; k < t.size(); k++)
+      t[k] = TermDev{an.terms[k].s1, an.terms[k].s2, an.terms[k].wi, an.terms[k].sgn};
+    if ((e = h->terms.upload(t))) return e;
+    // sign a perturbed pivot takes: x rows belong to the -Q block, y / slack rows
+    // to the zero / +W/Z blocks
+    std::vector<signed char> sg(an.dim);
+    for (int q = 0; q < an.dim; q++) sg[an.q2e[q]] = q < an.n ? -1 : 1;
+    if ((e = h->esign.upload(sg))) return e;
+  }
+  if ((e = h->Qf.upload(an.Qfull)) || (e = h->A.upload(an.A)) || (e = h->AT.upload(an.AT)) ||
+      (e = h->C.upload(an.C)) || (e = h->CT.upload(an.CT)))
+    return e;
+  const int n = an.n, me = an.me, m = an.m, dim = an.dim;
+  const size_t nv = (size_t)an.nq + an.na + an.nc + 1;
+  if ((e = h->vals.alloc(nv)) || (e = h->wt.alloc(m + 1)) || (e = h->sc.alloc(dim)) ||
+      (e = h->ent_val.alloc(an.ent_a.size())) || (e = h->panel.alloc(an.panel_elems)) ||
+      (e = h->upd.alloc(an.upd_elems)) || (e = h->xar.alloc(an.x_elems)) ||
+      (e = h->dinv.alloc(2 * (size_t)dim)) || (e = h->rhs.alloc(dim)) ||
+      (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ptype.alloc(dim)) ||
+      (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(4)) || (e = h->bits.alloc(2)) ||
+      (e = h->vin.alloc(2 * (size_t)m + n + me + 2 * (size_t)m)) ||
+      (e = h->vout.alloc((size_t)n + me + 2 * (size_t)m)) ||
+      (e = h->vres.alloc((size_t)n + me + 2 * (size_t)m)) ||
+      (e = h->vcor.alloc((size_t)n + me + 2 * (size_t)m)) || (e = h->tz.alloc(m)))
+    return e;
+  {
+    std::vector<double> ones(dim, 1.0);
+    HIPCHK(hipMemcpy(h->sc.p, ones.data(), sizeof(double) * dim, hipMemcpyHostToDevice));
+    const double one = 1.0;
+    HIPCHK(hipMemcpy(h->vals.p + (nv - 1), &one, sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->wt.p + m, &one, sizeof(double), hipMemcpyHostToDevice));
+  }
+  // dynamic LDS budgets
+  const size_t mp = an.max_npiv, mf = an.max_front;
+  h->lds_diag = ((mp | 1) * mp + 4 * mp) * sizeof(double) + 2 * mp * sizeof(int) + 16;
+  h->lds_panel = (32 * mp + PS_COLS * mp) * sizeof(double);
+  h->lds_solve = (mf + mp + SV_COLS * mp + an.max_nbor) * sizeof(double);
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->lds_diag));
+  HIPCHK(hipFuncSetAttribute((const void *)k_panel_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->lds_panel));
+  HIPCHK(hipFuncSetAttribute((const void *)k_solve_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->lds_solve));
+  HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->lds_solve));
+  h->st.bytes_panels = (long long)sizeof(double) * (an.panel_elems + an.x_elems);
+  h->st.bytes_updates = (long long)sizeof(double) * an.upd_elems;
+  h->uploaded = true;
+  return 0;
+}
+
+// pointers of the six input vectors / four outputs for the current call
+struct Vecs {
+  const double *z, *w, *r1, *r2, *r3, *r4;
+  double *dx, *dy, *dz, *dw;
+};
+
+static int stage_in(hqpkkt_t *h, const double *z, const double *w, const double *r1,
+                    const double *r2, const double *r3, const double *r4, Vecs &v) {
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  if (h->opts.loc == HQPKKT_LOC_DEVICE) {
+    v.z = z, v.w = w, v.r1 = r1, v.r2 = r2, v.r3 = r3, v.r4 = r4;
+    return 0;
+  }
+  double *b = h->vin.p;
+  double *dz_ = b, *dw_ = b + m, *d1 = b + 2 * (size_t)m, *d2 = d1 + n, *d3 = d2 + me, *d4 = d3 + m;
+#define H2D(dst, src, k) \
+  if ((src) && (k) > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (k), hipMemcpyHostToDevice, h->stream))
+  H2D(dz_, z, m);
+  H2D(dw_, w, m);
+  H2D(d1, r1, n);
+  H2D(d2, r2, me);
+  H2D(d3, r3, m);
+  H2D(d4, r4, m);
+#undef H2D
+  v.z = dz_, v.w = dw_, v.r1 = d1, v.r2 = d2, v.r3 = d3, v.r4 = d4;
+  return 0;
+}
+
+static void stage_out_ptrs(hqpkkt_t *h, double *dx, double *dy, double *dz, double *dw, Vecs &v) {
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  if (h->opts.loc == HQPKKT_LOC_DEVICE) {
+    v.dx = dx, v.dy = dy, v.dz = dz, v.dw = dw;
+  } else {
+    v.dx = h->vout.p, v.dy = v.dx + n, v.dz = v.dy + me, v.dw = v.dz + m;
+  }
+}
+
+static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double *dz, double *dw) {
+  if (h->opts.loc == HQPKKT_LOC_DEVICE) return 0;
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+#define D2H(dst, src, k) \
+  if ((dst) && (k) > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (k), hipMemcpyDeviceToHost, h->stream))
+  D2H(dx, v.dx, n);
+  D2H(dy, v.dy, me);
+  D2H(dz, v.dz, m);
+  D2H(dw, v.dw, m);
+#undef D2H
+  return 0;
+}
+
+// ------------------------------------------------------------ numeric phases
+static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
+  Analysis &an = h->an;
+  hipStream_t s = h->stream;
+  const int m = an.m, nent = (int)an.ent_a.size();
+  DevTree T = h->tree();
+  HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, s));
+  if (an.upd_elems) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
+  HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 4, s));
+  HIPCHK(hipMemsetAsync(h->bits.p, 0, sizeof(unsigned long long) * 2, s));
+  HIPCHK(hipEventRecord(h->ev0, s));
+  if (m > 0)
+    k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p);
+  k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
+                                            h->ent_val.p);
+  if (an.mode == 1 && an.n > 0)
+    k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p);
+  k_scatter<<<nblk(nent), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
+                                       h->sc.p, h->panel.p, h->bits.p);
+  HIPCHK(hipEventRecord(h->ev1, s));
+  const double alpha = h->opts.tol * 0.6403882032022076;  // tol (1+sqrt 17)/8, hqp/spBKP.C:392
+  for (int l = 0; l < an.nlevels; l++) {
+    for (int seg = an.ea_level_ptr[l]; seg < an.ea_level_ptr[l + 1]; seg++) {
+      int cnt = an.ea_seg_ptr[seg + 1] - an.ea_seg_ptr[seg];
+      if (cnt <= 0) continue;
+      int ysplit = std::max(1, std::min(64, 2048 / cnt));
+      k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, h->ea_nodes.p + an.ea_seg_ptr[seg],
+                                                     h->panel.p, h->upd.p);
+    }
+    const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
+    k_factor_diag<<<nn, 256, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
+                                               h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, alpha,
+                                               h->opts.pivot_eps, h->bits.p, h->flags.p + 1);
+    const int ns = an.slab_ptr[l + 1] - an.slab_ptr[l];
+    if (ns > 0)
+      k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, h->slabs.p + 2 * (size_t)an.slab_ptr[l],
+                                                  h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
+                                                  h->lperm.p);
+    const int nt = an.upd_tile_ptr[l + 1] - an.upd_tile_ptr[l];
+    if (nt > 0)
+      k_schur_update<<<nt, 256, 0, s>>>(T, h->upd_tiles.p + 3 * (size_t)an.upd_tile_ptr[l],
+                                        h->panel.p, h->xar.p, h->upd.p);
+  }
+  HIPCHK(hipEventRecord(h->evs1, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+static int run_step(hqpkkt_t *h, const Vecs &v) {
+  Analysis &an = h->an;
+  hipStream_t s = h->stream;
+  const int n = an.n, me = an.me, m = an.m, dim = an.dim;
+  DevTree T = h->tree();
+  if (an.mode == 0) {
+    k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
+                                         h->rhs.p);
+  } else {
+    if (m > 0) k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p);
+    k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
+                                        h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p);
+  }
+  for (int l = 0; l < an.nlevels; l++) {
+    const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
+    k_solve_fwd<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
+                                              h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
+                                              h->xsol.p, h->cb.p);
+  }
+  for (int l = an.nlevels - 1; l >= 0; l--) {
+    const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
+    k_solve_bwd<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
+                                              h->lperm.p, h->xsol.p);
+  }
+  if (an.mode == 0) {
+    k_unpack_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy,
+                                            v.dz);
+    if (m > 0)
+      k_dw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, v.r3,
+                                   v.dw);
+  } else {
+    k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy);
+    if (m > 0)
+      k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx,
+                                         h->wt.p, h->tz.p, v.r3, v.dz, v.dw);
+  }
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// residual of (d) for rhs (r); leaves the residual vectors in h->vres
+static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
+  Analysis &an = h->an;
+  hipStream_t s = h->stream;
+  const int n = an.n, me = an.me, m = an.m;
+  double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
+  HIPCHK(hipMemsetAsync(h->bits.p + 1, 0, sizeof(unsigned long long), s));
+  k_residual<<<nblk((long long)n + me + m), 256, 0, s>>>(
+      n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
+      v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1);
+  unsigned long long bits = 0;
+  HIPCHK(hipMemcpyAsync(&bits, h->bits.p + 1, sizeof(bits), hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  double r;
+  std::memcpy(&r, &bits, sizeof(r));
+  *res = r;
+  return 0;
+}
+
+static float elapsed(hipEvent_t a, hipEvent_t b) {
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, a, b) != hipSuccess) ms = -1.f;
+  return ms;
+}
+
+// =========================================================================
+extern "C" {
+
+int hqpkkt_default_opts(hqpkkt_opts *o) {
+  if (!o) return HQPKKT_E_NULL;
+  std::memset(o, 0, sizeof(*o));
+  o->mode = HQPKKT_MODE_FULL;
+  o->device = 0;
+  o->loc = HQPKKT_LOC_HOST;
+  o->tol = 1.0;    // hqp/Hqp_IpSpBKP.C:46
+  o->eps = 1e-10;  // hqp/Hqp_IpMatrix.C:45
+  o->pivot_eps = 1e-10;
+  o->leaf_size = 0;
+  o->max_pivots = 0;
+  return 0;
+}
+
+int hqpkkt_create(const hqpkkt_opts *opts, hqpkkt_t **out) {
+  if (!out) return HQPKKT_E_NULL;
+  hqpkkt_opts o;
+  if (opts)
+    o = *opts;
+  else
+    hqpkkt_default_opts(&o);
+  if (o.mode != HQPKKT_MODE_FULL && o.mode != HQPKKT_MODE_REDUCED) return HQPKKT_E_RANGE;
+  if (!(o.tol > 0.0 && o.tol <= 1.0)) return HQPKKT_E_RANGE;  // hqp/spBKP.C:389-390
+  if (o.loc != HQPKKT_LOC_HOST && o.loc != HQPKKT_LOC_DEVICE) return HQPKKT_E_RANGE;
+  hqpkkt_t *h = new (std::nothrow) hqpkkt;
+  if (!h) return HQPKKT_E_MEM;
+  h->opts = o;
+  std::memset(&h->st, 0, sizeof(h->st));
+  h->st.sbw = -1;
+  *out = h;
+  return 0;
+}
+
+int hqpkkt_destroy(hqpkkt_t *h) {
+  if (!h) return 0;
+  if (h->own_stream) {
+    (void)hipSetDevice(h->opts.device);
+    (void)hipStreamSynchronize(h->own_stream);
+    h->release_device();
+    (void)hipEventDestroy(h->ev0);
+    (void)hipEventDestroy(h->ev1);
+    (void)hipEventDestroy(h->evs0);
+    (void)hipEventDestroy(h->evs1);
+    (void)hipStreamDestroy(h->own_stream);
+  }
+  delete h;
+  return 0;
+}
+
+int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *Qi,
+                   const int *Ap, const int *Ai, const int *Cp, const int *Ci, int *sbw) {
+  if (!h) return HQPKKT_E_NULL;
+  if ((n > 0 && (!Qp || (Qp[n] > 0 && !Qi))) || (me > 0 && (!Ap || (Ap[me] > 0 && !Ai))) ||
+      (m > 0 && (!Cp || (Cp[m] > 0 && !Ci))))
+    return HQPKKT_E_NULL;
+  if (h->uploaded) {
+    (void)hipSetDevice(h->opts.device);
+    (void)hipStreamSynchronize(h->stream);
+    h->release_device();
+  }
+  h->analyzed = false;
+  h->an = Analysis();
+  int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
+                    h->opts.max_pivots);
+  if (e) return e;
+  h->analyzed = true;
+  Analysis &an = h->an;
+  h->st.dim = an.dim, h->st.sbw = an.sbw, h->st.n_supernodes = an.nnodes;
+  h->st.n_levels = an.nlevels, h->st.max_front = an.max_front;
+  h->st.nnz_kkt = (long long)an.ent_a.size();
+  h->st.nnz_factor = an.nnz_factor, h->st.flops_factor = an.flops_factor;
+  h->st.bytes_panels = (long long)sizeof(double) * (an.panel_elems + an.x_elems);
+  h->st.bytes_updates = (long long)sizeof(double) * an.upd_elems;
+  if (sbw) *sbw = an.sbw;
+  return 0;
+}
+
+int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const double *Cx) {
+  if (!h) return HQPKKT_E_NULL;
+  if (!h->analyzed) return HQPKKT_E_INTERN;
+  Analysis &an = h->an;
+  if ((an.nq && !Qx) || (an.na && !Ax) || (an.nc && !Cx)) return HQPKKT_E_NULL;
+  int e;
+  if (!h->uploaded && (e = upload(h))) return e;
+  HIPCHK(hipSetDevice(h->opts.device));
+  hipMemcpyKind kind =
+      h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (an.nq) HIPCHK(hipMemcpyAsync(h->vals.p, Qx, sizeof(double) * an.nq, kind, h->stream));
+  if (an.na) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq, Ax, sizeof(double) * an.na, kind, h->stream));
+  if (an.nc)
+    HIPCHK(hipMemcpyAsync(h->vals.p + an.nq + an.na, Cx, sizeof(double) * an.nc, kind, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->have_values = true;
+  h->factored = false;
+  return 0;
+}
+
+int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
+  if (!h) return HQPKKT_E_NULL;
+  if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
+  if (h->an.m > 0 && (!z || !w)) return HQPKKT_E_NULL;
+  HIPCHK(hipSetDevice(h->opts.device));
+  Vecs v{};
+  int e = stage_in(h, z, w, nullptr, nullptr, nullptr, nullptr, v);
+  if (e) return e;
+  h->factored = false;
+  if ((e = run_factor(h, v.z, v.w))) return e;
+  int flags[4] = {0, 0, 0, 0};
+  unsigned long long kb = 0;
+  HIPCHK(hipMemcpyAsync(flags, h->flags.p, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipMemcpyAsync(&kb, h->bits.p, sizeof(kb), hipMemcpyDeviceToHost, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->st.ms_assemble = elapsed(h->ev0, h->ev1);
+  h->st.ms_factor = elapsed(h->ev1, h->evs1);
+  h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2];
+  std::memcpy(&h->st.kmax, &kb, sizeof(double));
+  if (flags[0]) return flags[0];
+  if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
+  h->factored = true;
+  return 0;
+}
+
+int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w, const double *r1,
+                const double *r2, const double *r3, const double *r4, double *dx, double *dy,
+                double *dz, double *dw) {
+  if (!h) return HQPKKT_E_NULL;
+  if (!h->factored) return HQPKKT_E_INTERN;
+  HIPCHK(hipSetDevice(h->opts.device));
+  Vecs v{};
+  int e = stage_in(h, z, w, r1, r2, r3, r4, v);
+  if (e) return e;
+  stage_out_ptrs(h, dx, dy, dz, dw, v);
+  HIPCHK(hipEventRecord(h->evs0, h->stream));
+  if ((e = run_step(h, v))) return e;
+  HIPCHK(hipEventRecord(h->evs1, h->stream));
+  if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->st.ms_step = elapsed(h->evs0, h->evs1);
+  return 0;
+}
+
+int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w, const double *r1,
+                    const double *r2, const double *r3, const double *r4, const double *dx,
+                    const double *dy, const double *dz, const double *dw, double *res) {
+  if (!h || !res) return HQPKKT_E_NULL;
+  if (!h->have_values) return HQPKKT_E_INTERN;
+  HIPCHK(hipSetDevice(h->opts.device));
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  Vecs v{};
+  int e = stage_in(h, z, w, r1, r2, r3, r4, v);
+  if (e) return e;
+  if (h->opts.loc == HQPKKT_LOC_DEVICE) {
+    v.dx = (double *)dx, v.dy = (double *)dy, v.dz = (double *)dz, v.dw = (double *)dw;
+  } else {
+    stage_out_ptrs(h, nullptr, nullptr, nullptr, nullptr, v);
+    if (n) HIPCHK(hipMemcpyAsync(v.dx, dx, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
+    if (me) HIPCHK(hipMemcpyAsync(v.dy, dy, sizeof(double) * me, hipMemcpyHostToDevice, h->stream));
+    if (m) HIPCHK(hipMemcpyAsync(v.dz, dz, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+    if (m) HIPCHK(hipMemcpyAsync(v.dw, dw, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
+  }
+  HIPCHK(hipEventRecord(h->evs0, h->stream));
+  e = run_residual(h, v, res);
+  HIPCHK(hipEventRecord(h->evs1, h->stream));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  h->st.ms_residual = elapsed(h->evs0, h->evs1);
+  return e;
+}
+
+// Hqp_IpMatrix::solve (hqp/Hqp_IpMatrix.C:65-128)
+int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1,
+                 const double *r2, const double *r3, const double *r4, double *dx, double *dy,
+                 double *dz, double *dw, double *res_out) {
+  if (!h) return HQPKKT_E_NULL;
+  if (!h->factored) return HQPKKT_E_INTERN;
+  HIPCHK(hipSetDevice(h->opts.device));
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  hipStream_t s = h->stream;
+  Vecs v{};
+  int e = stage_in(h, z, w, r1, r2, r3, r4, v);
+  if (e) return e;
+  stage_out_ptrs(h, dx, dy, dz, dw, v);
+  HIPCHK(hipEventRecord(h->ev0, s));
+  if ((e = run_step(h, v))) return e;
+  double res = 0.0, res_last;
+  if ((e = run_residual(h, v, &res))) return e;
+  // correction solve: rhs = residual vectors, result = vcor
+  Vecs c = v;
+  c.r1 = h->vres.p, c.r2 = c.r1 + n, c.r3 = c.r2 + me, c.r4 = c.r3 + m;
+  c.dx = h->vcor.p, c.dy = c.dx + n, c.dz = c.dy + me, c.dw = c.dz + m;
+  const int ntot = n + me + 2 * m;
+  int rounds = 0;
+  for (int it = 0; it < 5 && res > h->opts.eps; it++) {
+    res_last = res;
+    if ((e = run_step(h, c))) return e;
+    rounds++;
+    double alpha = 1.0;
+    do {
+      k_axpy4<<<nblk(ntot), 256, 0, s>>>(n, me, m, alpha, c.dx, c.dy, c.dz, c.dw, v.dx, v.dy, v.dz,
+                                         v.dw);
+      if ((e = run_residual(h, v, &res))) return e;
+      if (res > res_last) {
+        k_axpy4<<<nblk(ntot), 256, 0, s>>>(n, me, m, -alpha, c.dx, c.dy, c.dz, c.dw, v.dx, v.dy,
+                                           v.dz, v.dw);
+        alpha -= 0.3;
+      }
+    } while (res > res_last && alpha > 0.0);
+    if (alpha <= 0.0) break;
+  }
+  HIPCHK(hipEventRecord(h->ev1, s));
+  if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
+  HIPCHK(hipStreamSynchronize(s));
+  h->st.ms_solve = elapsed(h->ev0, h->ev1);
+  h->st.refine_rounds = rounds;
+  if (res_out) *res_out = res;
+  if (res != res) return HQPKKT_E_SING;
+  return 0;
+}
+
+int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {
+  if (!h || !sbw) return HQPKKT_E_NULL;
+  *sbw = h->analyzed ? h->an.sbw : -1;
+  return 0;
+}
+
+int hqpkkt_get_perm(const hqpkkt_t *h, int *perm) {
+  if (!h || !perm) return HQPKKT_E_NULL;
+  if (!h->analyzed) return HQPKKT_E_INTERN;
+  std::memcpy(perm, h->an.qp2j.data(), sizeof(int) * h->an.dim);
+  return 0;
+}
+
+int hqpkkt_set_tol(hqpkkt_t *h, double tol) {
+  if (!h) return HQPKKT_E_NULL;
+  if (!(tol > 0.0 && tol <= 1.0)) return HQPKKT_E_RANGE;
+  h->opts.tol = tol;
+  return 0;
+}
+
+int hqpkkt_set_eps(hqpkkt_t *h, double eps) {
+  if (!h) return HQPKKT_E_NULL;
+  h->opts.eps = eps;
+  return 0;
+}
+
+int hqpkkt_set_stream(hqpkkt_t *h, void *hip_stream) {
+  if (!h) return HQPKKT_E_NULL;
+  int e = ensure_device(h);
+  if (e) return e;
+  h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  return 0;
+}
+
+int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out) {
+  if (!h || !out) return HQPKKT_E_NULL;
+  *out = h->st;
+  return 0;
+}
+
+const char *hqpkkt_strerror(int status) {
+  switch (status) {
+    case HQPKKT_OK: return "ok";
+    case HQPKKT_E_SIZES: return "sizes of arguments mismatch";
+    case HQPKKT_E_MEM: return "out of memory";
+    case HQPKKT_E_SING: return "matrix is singular";
+    case HQPKKT_E_FORMAT: return "CSR input not sorted / out of range";
+    case HQPKKT_E_NULL: return "NULL objects passed";
+    case HQPKKT_E_RANGE: return "parameter out of range";
+    case HQPKKT_E_INTERN: return "call order violated";
+    case HQPKKT_E_DEVICE: return g_last_hip_error[0] ? g_last_hip_error : "HIP device error";
+    default: return "unknown status";
+  }
+}
+
+int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
+  if (!h || !len) return HQPKKT_E_NULL;
+  if (!h->analyzed) return HQPKKT_E_INTERN;
+  const Analysis &an = h->an;
+  const std::vector<int> *v = nullptr;
+  std::vector<int> tmp;
+  switch (what) {
+    case 0: v = &an.q2e; break;
+    case 1: v = &an.piv_start; break;
+    case 2: v = &an.npiv; break;
+    case 3: v = &an.nbor; break;
+    case 4: v = &an.parent; break;
+    case 5: v = &an.level; break;
+    case 6:
+      tmp.assign(an.bptr.begin(), an.bptr.end());
+      v = &tmp;
+      break;
+    case 7: v = &an.bidx; break;
+    case 8: v = &an.ent_er; break;
+    case 9: v = &an.ent_ec; break;
+    default: return HQPKKT_E_RANGE;
+  }
+  *len = (long long)v->size();
+  if (out && !v->empty()) std::memcpy(out, v->data(), sizeof(int) * v->size());
+  return 0;
+}
+
+int hqpkkt_selftest_mfma(int device, double *max_err) {
+  if (!max_err) return HQPKKT_E_NULL;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return HQPKKT_E_DEVICE;
+  HIPCHK(hipSetDevice(device));
+  double A[256], B[256], Cx[256], Cd[256];
+  for (int i = 0; i < 16; i++)
+    for (int j = 0; j < 16; j++) {
+      A[i * 16 + j] = (double)((i * 7 + j * 3) % 11 - 5);
+      B[i * 16 + j] = (double)((i * 5 + j * 13) % 17 - 8);
+    }
+  for (int i = 0; i < 16; i++)
+    for (int j = 0; j < 16; j++) {
+      double s = 0;
+      for (int k = 0; k < 16; k++) s += A[i * 16 + k] * B[k * 16 + j];
+      Cx[i * 16 + j] = s;
+    }
+  double *dA, *dB, *dC;
+  HIPCHK(hipMalloc((void **)&dA, sizeof(A)));
+  HIPCHK(hipMalloc((void **)&dB, sizeof(B)));
+  HIPCHK(hipMalloc((void **)&dC, sizeof(Cd)));
+  HIPCHK(hipMemcpy(dA, A, sizeof(A), hipMemcpyHostToDevice));
+  HIPCHK(hipMemcpy(dB, B, sizeof(B), hipMemcpyHostToDevice));
+  k_mfma_selftest<<<1, 64>>>(dA, dB, dC);
+  HIPCHK(hipMemcpy(Cd, dC, sizeof(Cd), hipMemcpyDeviceToHost));
+  (void)hipFree(dA), (void)hipFree(dB), (void)hipFree(dC);
+  double err = 0;
+  for (int i = 0; i < 256; i++) err = std::fmax(err, std::fabs(Cd[i] - Cx[i]));
+  *max_err = err;
+  return 0;
+}
+
+}  // extern "C"

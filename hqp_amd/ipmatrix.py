@@ -1,0 +1,232 @@
+"""Host-side mirror of the reference's ``Hqp_IpMatrix`` plugin interface
+(hqp/Hqp_IpMatrix.h:42-89) over the C ABI of include/hqpkkt.h.
+
+Same method names, argument meaning and error behaviour as the reference:
+
+    m = IpSpBKP()            # Hqp_IpSpBKP    (hqp/Hqp_IpSpBKP.C)
+    m = IpRedSpBKP()         # Hqp_IpRedSpBKP (hqp/Hqp_IpRedSpBKP.C)
+    m.init(qp)               # structure: RCM, mat_sbw, symbolic factorisation
+    m.update(qp)             # new values, same pattern
+    m.factor(qp, z, w)
+    res = m.solve(qp, z, w, r1, r2, r3, r4, dx, dy, dz, dw)   # fills dx..dw
+    m.step(...), m.residuum(...)
+
+``qp`` is an :class:`hqp_amd.problems.Program` (the Hqp_Program data contract).
+Vectors are numpy float64 arrays (host pointers, like Meschach ``VEC::ve``) or
+torch CUDA tensors (device pointers, used in place) -- one kind per object,
+chosen at construction (``device_vectors=True``).  A numerically singular system
+raises :class:`SingularError`, the counterpart of ``m_error(E_SING, ...)``
+(meschach/err.h:63,88) which the interior-point solvers catch
+(hqp/Hqp_IpsMehrotra.C:525-536).
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+
+
+class KktError(RuntimeError):
+    def __init__(self, code, where):
+        super().__init__(f"hqpkkt status {code} in {where}: {_lib.strerror(code)}")
+        self.code = code
+
+
+class SingularError(KktError):
+    """E_SING of the reference (meschach/err.h:88)."""
+
+
+def _check(code, where):
+    if code == _lib.OK:
+        return
+    if code == _lib.E_SING:
+        raise SingularError(code, where)
+    raise KktError(code, where)
+
+
+def _i32(a):
+    a = np.ascontiguousarray(a, dtype=np.int32)
+    return a
+
+
+class Hqp_IpMatrix:
+    """Abstract base (hqp/Hqp_IpMatrix.h:42-89)."""
+
+    _mode = None
+    _name = None
+
+    def __init__(self, device=0, device_vectors=False, mat_tol=1.0, mat_eps=1e-10,
+                 pivot_eps=None, leaf_size=0, max_pivots=0):
+        L = _lib.lib()
+        o = _lib.Opts()
+        L.hqpkkt_default_opts(C.byref(o))
+        o.mode = self._mode
+        o.device = device
+        o.loc = _lib.LOC_DEVICE if device_vectors else _lib.LOC_HOST
+        o.tol, o.eps = mat_tol, mat_eps
+        if pivot_eps is not None:
+            o.pivot_eps = pivot_eps
+        o.leaf_size, o.max_pivots = leaf_size, max_pivots
+        self._L = L
+        self._h = C.c_void_p()
+        self._device_vectors = bool(device_vectors)
+        _check(L.hqpkkt_create(C.byref(o), C.byref(self._h)), "create")
+        self._keep = None
+        self.n = self.me = self.m = 0
+
+    def __del__(self):
+        h = getattr(self, "_h", None)
+        if h:
+            self._L.hqpkkt_destroy(h)
+            self._h = None
+
+    # -- Tcl-visible members of the reference -------------------------------
+    @property
+    def mat_sbw(self):
+        v = C.c_int()
+        _check(self._L.hqpkkt_get_sbw(self._h, C.byref(v)), "get_sbw")
+        return v.value
+
+    def set_mat_tol(self, tol):
+        _check(self._L.hqpkkt_set_tol(self._h, tol), "set_tol")
+
+    def set_mat_eps(self, eps):
+        _check(self._L.hqpkkt_set_eps(self._h, eps), "set_eps")
+
+    def name(self):
+        return self._name
+
+    # -- pointer plumbing ------------------------------------------------------
+    def _ptr(self, a, size, what, out=False):
+        if a is None:
+            if size:
+                raise KktError(_lib.E_NULL, what)
+            return None
+        if self._device_vectors:
+            if not (hasattr(a, "data_ptr") and a.is_cuda):
+                raise TypeError(f"{what}: device_vectors=True needs torch CUDA float64 tensors")
+            if a.numel() != size or str(a.dtype) != "torch.float64" or not a.is_contiguous():
+                raise KktError(_lib.E_SIZES, what)
+            return C.c_void_p(a.data_ptr())
+        if not isinstance(a, np.ndarray) or a.dtype != np.float64 or not a.flags.c_contiguous:
+            if out:
+                raise TypeError(f"{what}: output must be a C-contiguous float64 numpy array")
+            a = np.ascontiguousarray(a, dtype=np.float64)
+            self._tmp.append(a)
+        if a.size != size:
+            raise KktError(_lib.E_SIZES, what)  # the reference asserts (Hqp_IpSpBKP.C:189-192)
+        return C.c_void_p(a.ctypes.data)
+
+    def _vecs(self, z, w, r1, r2, r3, r4, dx, dy, dz, dw, out=True):
+        self._tmp = []
+        n, me, m = self.n, self.me, self.m
+        sizes = (m, m, n, me, m, m)
+        ins = [self._ptr(a, s, nm) for a, s, nm in zip((z, w, r1, r2, r3, r4), sizes,
+                                                      ("z", "w", "r1", "r2", "r3", "r4"))]
+        outs = [self._ptr(a, s, nm, out=out) for a, s, nm in zip((dx, dy, dz, dw), (n, me, m, m),
+                                                                 ("dx", "dy", "dz", "dw"))]
+        return ins + outs
+
+    # -- the plugin interface ----------------------------------------------------
+    def init(self, qp):
+        """Hqp_IpSpBKP::init (hqp/Hqp_IpSpBKP.C:76-114): analyse, then update."""
+        self.n, self.me, self.m = qp.dims
+        arrs = []
+        for (p, i, _x) in (qp.Q, qp.A, qp.C):
+            arrs += [_i32(p), _i32(i)]
+        self._keep = arrs
+        sbw = C.c_int()
+        ptrs = [C.c_void_p(a.ctypes.data) if a.size else None for a in arrs]
+        _check(self._L.hqpkkt_analyze(self._h, self.n, self.me, self.m, *ptrs, C.byref(sbw)), "init")
+        self.update(qp)
+
+    def update(self, qp):
+        """Hqp_IpSpBKP::update (hqp/Hqp_IpSpBKP.C:117-136)."""
+        vals = []
+        for (_p, _i, x) in (qp.Q, qp.A, qp.C):
+            if self._device_vectors and hasattr(x, "data_ptr"):
+                vals.append(C.c_void_p(x.data_ptr()))
+            elif self._device_vectors:
+                import torch
+                t = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+                self._keepvals = getattr(self, "_keepvals", []) + [t]
+                vals.append(C.c_void_p(t.data_ptr()))
+            else:
+                a = np.ascontiguousarray(x, dtype=np.float64)
+                self._keep.append(a)
+                vals.append(C.c_void_p(a.ctypes.data) if a.size else None)
+        _check(self._L.hqpkkt_set_values(self._h, *vals), "update")
+        self._keepvals = []
+
+    def factor(self, qp, z, w):
+        self._tmp = []
+        m = self.m
+        _check(self._L.hqpkkt_factor(self._h, self._ptr(z, m, "z"), self._ptr(w, m, "w")), "factor")
+
+    def step(self, qp, z, w, r1, r2, r3, r4, dx, dy, dz, dw):
+        _check(self._L.hqpkkt_step(self._h, *self._vecs(z, w, r1, r2, r3, r4, dx, dy, dz, dw)), "step")
+
+    def solve(self, qp, z, w, r1, r2, r3, r4, dx, dy, dz, dw):
+        """Hqp_IpMatrix::solve (hqp/Hqp_IpMatrix.C:65-128); returns the residual."""
+        res = C.c_double()
+        _check(self._L.hqpkkt_solve(self._h, *self._vecs(z, w, r1, r2, r3, r4, dx, dy, dz, dw),
+                                    C.byref(res)), "solve")
+        return res.value
+
+    def residuum(self, qp, z, w, r1, r2, r3, r4, dx, dy, dz, dw):
+        """Hqp_IpMatrix::residuum (hqp/Hqp_IpMatrix.C:131-178)."""
+        res = C.c_double()
+        _check(self._L.hqpkkt_residual(self._h, *self._vecs(z, w, r1, r2, r3, r4, dx, dy, dz, dw, out=False),
+                                       C.byref(res)), "residuum")
+        return res.value
+
+    # -- introspection ---------------------------------------------------------------
+    def stats(self):
+        s = _lib.Stats()
+        _check(self._L.hqpkkt_get_stats(self._h, C.byref(s)), "get_stats")
+        return s.asdict()
+
+    def perm(self):
+        """_QP2J of the reference: band position of each QP index."""
+        p = np.zeros(self.stats()["dim"], dtype=np.int32)
+        _check(self._L.hqpkkt_get_perm(self._h, C.c_void_p(p.ctypes.data)), "get_perm")
+        return p
+
+    def set_stream(self, hip_stream):
+        _check(self._L.hqpkkt_set_stream(self._h, C.c_void_p(hip_stream)), "set_stream")
+
+    def debug(self, what):
+        k = C.c_longlong()
+        _check(self._L.hqpkkt_debug_get(self._h, what, None, C.byref(k)), "debug_get")
+        out = np.zeros(max(k.value, 1), dtype=np.int32)
+        _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
+        return out[: k.value]
+
+    def structure(self):
+        names = ["elim", "piv_start", "npiv", "nborder", "parent", "level", "border_ptr",
+                 "border_idx", "entry_row", "entry_col"]
+        return {nm: self.debug(i) for i, nm in enumerate(names)}
+
+
+class Hqp_IpSpBKP(Hqp_IpMatrix):
+    """Full (n+me+m) KKT system; semantics of hqp/Hqp_IpSpBKP.C."""
+    _mode = _lib.MODE_FULL
+    _name = "SpBKP"
+
+
+class Hqp_IpRedSpBKP(Hqp_IpMatrix):
+    """Reduced (n+me) system with C'ZW^-1C folded in; semantics of hqp/Hqp_IpRedSpBKP.C."""
+    _mode = _lib.MODE_REDUCED
+    _name = "RedSpBKP"
+
+
+IpSpBKP = Hqp_IpSpBKP
+IpRedSpBKP = Hqp_IpRedSpBKP
+
+
+def selftest_mfma(device=0):
+    err = C.c_double()
+    _check(_lib.lib().hqpkkt_selftest_mfma(device, C.byref(err)), "selftest_mfma")
+    return err.value

@@ -1,0 +1,178 @@
+/*
+ * hqpkkt.h -- C ABI of the MI355X-native interior-point KKT linear-system path.
+ *
+ * This is the drop-in boundary for the reference's Hqp_IpMatrix plugin point
+ * (hqp/Hqp_IpMatrix.h:63-88).  A thin C++ subclass of Hqp_IpMatrix (see
+ * shim/Hqp_IpSpBKPHip.C and INTEGRATION.md) forwards its virtual methods to
+ * these entry points exactly like the reference's own Hqp_IpPARDISO forwards to
+ * a dlopen'ed C function (hqp/pardiso_wrapper.h:33-48,
+ * hqp/Hqp_IpPARDISO.C:156-222).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; int32 indices, fp64 values; 0-based CSR
+ *    with column indices sorted inside each row (as Meschach's SPROW keeps
+ *    them, meschach/sparse.h:44-63);
+ *  - every function returns a status: 0 = ok, HQPKKT_E_SING (= Meschach's
+ *    E_SING, meschach/err.h:88) for a numerically singular system or a zero
+ *    z/w component (meschach/vecop.c:346-348), other HQPKKT_E_* otherwise.
+ *    Nothing throws, longjmps or aborts across this boundary; the shim turns a
+ *    non-zero status into m_error(...) (meschach/err.h:63);
+ *  - calls are synchronous from the caller's point of view; a handle is not
+ *    re-entrant (the reference drives the plugin from one thread);
+ *  - there is NO CPU fallback: numeric entry points need a gfx950 device and
+ *    fail with HQPKKT_E_DEVICE without one.  hqpkkt_analyze is host-only.
+ */
+#ifndef HQPKKT_H
+#define HQPKKT_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HQPKKT_VERSION 1
+
+/* status codes (values 1..17 mirror meschach/err.h:84-110 where they exist) */
+#define HQPKKT_OK 0
+#define HQPKKT_E_SIZES 1   /* E_SIZES  */
+#define HQPKKT_E_MEM 3     /* E_MEM    */
+#define HQPKKT_E_SING 4    /* E_SING   */
+#define HQPKKT_E_FORMAT 6  /* E_FORMAT: unsorted / out-of-range CSR */
+#define HQPKKT_E_NULL 8    /* E_NULL   */
+#define HQPKKT_E_RANGE 10  /* E_RANGE  */
+#define HQPKKT_E_INTERN 17 /* E_INTERN: call order (e.g. factor before analyze) */
+#define HQPKKT_E_DEVICE 100 /* HIP runtime error / no gfx950 device */
+
+/* which reference plugin's semantics the handle reproduces */
+#define HQPKKT_MODE_FULL 0    /* Hqp_IpSpBKP    (hqp/Hqp_IpSpBKP.C:76-218)    */
+#define HQPKKT_MODE_REDUCED 1 /* Hqp_IpRedSpBKP (hqp/Hqp_IpRedSpBKP.C:184-368) */
+
+/* where the vectors z,w,r1..r4,dx..dw (and Qx,Ax,Cx) live */
+#define HQPKKT_LOC_HOST 0   /* Meschach VEC::ve pointers; copied H2D / D2H per call */
+#define HQPKKT_LOC_DEVICE 1 /* device pointers on opts.device, used in place */
+
+typedef struct hqpkkt hqpkkt_t;
+
+typedef struct hqpkkt_opts {
+  int mode;          /* HQPKKT_MODE_*                                         */
+  int device;        /* HIP device ordinal                                    */
+  int loc;           /* HQPKKT_LOC_*                                          */
+  double tol;        /* mat_tol of the reference (hqp/Hqp_IpSpBKP.C:46,59):
+                        Bunch-Kaufman alpha = tol*(1+sqrt 17)/8, 0 < tol <= 1  */
+  double eps;        /* mat_eps (hqp/Hqp_IpMatrix.C:45-47): refinement target */
+  double pivot_eps;  /* static pivot perturbation, relative to max|K_ij|      */
+  int leaf_size;     /* nested-dissection leaf size in rows (0 = default)     */
+  int max_pivots;    /* max pivots per supernode, <= 128 (0 = default)        */
+  int reserved[6];
+} hqpkkt_opts;
+
+typedef struct hqpkkt_stats {
+  /* structure (valid after analyze) */
+  int dim;               /* order of the factored matrix                       */
+  int sbw;               /* mat_sbw: semi-bandwidth under the RCM order        */
+  int n_supernodes;
+  int n_levels;          /* height of the assembly tree                        */
+  int max_front;         /* largest front order (pivots + border)              */
+  long long nnz_kkt;     /* stored entries of the permuted upper KKT matrix    */
+  long long nnz_factor;  /* entries of L kept (panels), incl. diagonal blocks  */
+  long long flops_factor;/* flops of one numeric factorisation as implemented  */
+  long long bytes_panels, bytes_updates; /* device arena sizes                 */
+  /* last numeric calls (valid after factor / solve) */
+  int n_2x2;             /* 2x2 pivots chosen in the last factor               */
+  int n_perturbed;       /* pivots replaced by +-pivot_eps*max|K| in last factor */
+  int refine_rounds;     /* refinement rounds of the last solve                */
+  double kmax;           /* max |scaled K_ij| of the last factor               */
+  /* device time of the last call of each phase, HIP events on the handle's
+     stream, milliseconds */
+  float ms_assemble, ms_factor, ms_step, ms_residual, ms_solve;
+} hqpkkt_stats;
+
+/* Fill *opts with the defaults (mode FULL, device 0, host pointers, tol 1.0,
+ * eps 1e-10 as the reference's constructors set them). */
+int hqpkkt_default_opts(hqpkkt_opts *opts);
+
+/* ctor / dtor of the plugin object (Hqp_IpSpBKP::Hqp_IpSpBKP, ~Hqp_IpSpBKP,
+ * hqp/Hqp_IpSpBKP.C:43-73).  Host-only; no device is touched yet. */
+int hqpkkt_create(const hqpkkt_opts *opts, hqpkkt_t **out);
+int hqpkkt_destroy(hqpkkt_t *h);
+
+/* Hqp_IpSpBKP::init / Hqp_IpRedSpBKP::init, structure part
+ * (hqp/Hqp_IpSpBKP.C:76-114, hqp/Hqp_IpRedSpBKP.C:184-265): RCM ordering of the
+ * KKT graph (hqp/sprcm.C:62-420), semi-bandwidth, supernode partition and
+ * symbolic factorisation.  Q is n x n (only entries with col >= row are read,
+ * meschach/addon2_hqp.c:1078-1086), A is me x n, C is m x n.  Host pointers
+ * always.  Host-only: runs without a GPU.  *sbw receives mat_sbw. */
+int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m,
+                   const int *Qp, const int *Qi, const int *Ap, const int *Ai,
+                   const int *Cp, const int *Ci, int *sbw);
+
+/* Hqp_IpSpBKP::update / Hqp_IpRedSpBKP::update (hqp/Hqp_IpSpBKP.C:117-136,
+ * hqp/Hqp_IpRedSpBKP.C:268-278): new values on the analysed pattern.  Pointers
+ * per opts.loc.  First call uploads the symbolic structure to the device. */
+int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax,
+                      const double *Cx);
+
+/* Hqp_IpSpBKP::factor / Hqp_IpRedSpBKP::factor (hqp/Hqp_IpSpBKP.C:139-180,
+ * hqp/Hqp_IpRedSpBKP.C:281-320) including spBKPfactor (hqp/spBKP.C:369-645):
+ * insert w/z (resp. C'ZW^-1C), symmetric scaling, LDL' with 1x1/2x2 pivots. */
+int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w);
+
+/* Hqp_IpSpBKP::step / Hqp_IpRedSpBKP::step (hqp/Hqp_IpSpBKP.C:183-218,
+ * hqp/Hqp_IpRedSpBKP.C:323-368) including spBKPsolve (hqp/spBKP.C:647-797):
+ * one solve of  [-Q A' C' 0; A 0 0 0; C 0 0 -I; 0 0 W Z] d = r  with the
+ * current factors, no refinement. */
+int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w,
+                const double *r1, const double *r2, const double *r3,
+                const double *r4, double *dx, double *dy, double *dz,
+                double *dw);
+
+/* Hqp_IpMatrix::residuum (hqp/Hqp_IpMatrix.C:131-178): max inf-norm of the
+ * four block residuals of the unreduced system; the residual vectors stay on
+ * the device for the next refinement round. */
+int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w,
+                    const double *r1, const double *r2, const double *r3,
+                    const double *r4, const double *dx, const double *dy,
+                    const double *dz, const double *dw, double *res);
+
+/* Hqp_IpMatrix::solve (hqp/Hqp_IpMatrix.C:65-128): step, then at most five
+ * rounds of iterative refinement with the reference's back-off
+ * (alpha = 1, .7, .4, .1) while the residual exceeds opts.eps.  *res is the
+ * value the reference's solve() returns. */
+int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w,
+                 const double *r1, const double *r2, const double *r3,
+                 const double *r4, double *dx, double *dy, double *dz,
+                 double *dw, double *res);
+
+/* mat_sbw (hqp/Hqp_IpSpBKP.C:58) and _QP2J (hqp/Hqp_IpSpBKP.C:91-93):
+ * perm[qp_index] = position in the RCM order; dim entries. */
+int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw);
+int hqpkkt_get_perm(const hqpkkt_t *h, int *perm);
+
+/* mat_tol / mat_eps setters (Tcl-visible members of the reference plugin,
+ * hqp/Hqp_IpSpBKP.C:58-59, hqp/Hqp_IpMatrix.C:47) */
+int hqpkkt_set_tol(hqpkkt_t *h, double tol);
+int hqpkkt_set_eps(hqpkkt_t *h, double eps);
+
+/* Run the handle's kernels on a caller-provided hipStream_t (NULL = the
+ * handle's own stream). */
+int hqpkkt_set_stream(hqpkkt_t *h, void *hip_stream);
+
+int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out);
+const char *hqpkkt_strerror(int status);
+
+/* ---- introspection of the symbolic structure (host arrays; used by the
+ * structure tests, not by the reference-side shim) ------------------------ */
+/* what: 0 elim (QP index -> elimination index, dim), 1 node_piv_start,
+ * 2 node_npiv, 3 node_nborder, 4 node_parent, 5 node_level (n_supernodes
+ * each), 6 border_ptr (n_supernodes+1), 7 border_idx (border_ptr[last]),
+ * 8 entry_row, 9 entry_col (elimination indices, nnz_kkt each).
+ * *len receives the element count; out may be NULL to query it. */
+int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len);
+
+/* MFMA f64 16x16x4 layout self-test on the device: C = A * B for integer-valued
+ * asymmetric 16x16x16 operands; *max_err is max |C - exact|. */
+int hqpkkt_selftest_mfma(int device, double *max_err);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HQPKKT_H */

@@ -1,0 +1,155 @@
+"""GPU (-m gpu): parity of the HIP path, called through the C ABI, against the
+golden vectors of the reference and against the CPU oracle on seeded inputs.
+
+Tolerances (fp64, stated by BASELINE.json's north_star and SURVEY.md 8(c)):
+  * KKT residual after solve(): within 1e-10 (absolute) of the reference's;
+  * solution: ||d_hip - d_ref||inf / ||d_ref||inf <= 1e-8 on well-conditioned
+    inputs (the pivot sequences differ by design, so no bit parity);
+  * residuum() of a given d: 1e-12 relative (same arithmetic, other sum order).
+"""
+import numpy as np
+import pytest
+
+from common import GOLDEN, KINDS, load_golden, new_d, rel_err
+from hqp_amd import _lib, ipmatrix, problems
+from oracle import oracleapi
+
+pytestmark = pytest.mark.gpu
+
+CLS = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}
+RES_TOL = 1e-10
+SOL_TOL = 1e-8
+
+
+def test_mfma_f64_layout():
+    assert ipmatrix.selftest_mfma(0) == 0.0
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+@pytest.mark.parametrize("kind", KINDS)
+def test_against_reference_golden(name, kind):
+    prog, st, g = load_golden(name)
+    M = CLS[kind]()
+    M.init(prog)
+    assert M.mat_sbw == int(g[f"{kind}_sbw"])
+    assert np.array_equal(M.perm(), g[f"{kind}_perm"])
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    gold = [g[f"{kind}_solve_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    gres = float(g[f"{kind}_res"])
+    assert res <= gres + RES_TOL, (res, gres, M.stats())
+    # ill-conditioned fixtures (w/z spread over decades): compare through the residual
+    tol = SOL_TOL if "spread" not in name and "random" not in name else 1e-5
+    assert rel_err(d, gold) <= tol, (rel_err(d, gold), M.stats())
+    # residuum() of the reference's own step result
+    gstep = [g[f"{kind}_step_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    r = M.residuum(prog, *st, *gstep)
+    rg = float(g[f"{kind}_res_of_step"])
+    assert abs(r - rg) <= 1e-12 * max(1.0, max(np.abs(v).max() if len(v) else 0 for v in gstep)) + 1e-13
+
+
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("case", [
+    ("banded", (1500, 16, 31), 0.0), ("banded", (1000, 30, 32), 2.0), ("did", (700,), 1.0),
+    ("banded_small_blocks", (600, 10, 33), 0.0),
+])
+def test_against_oracle_seeded(kind, case):
+    what, args, spread = case
+    kw = {}
+    if what == "did":
+        prog = problems.did_like_qp(*args)
+    else:
+        prog = problems.banded_qp(*args)
+    if what == "banded_small_blocks":
+        kw = dict(leaf_size=40, max_pivots=16)  # deep tree, many levels
+    st = problems.ip_state(prog, 77, spread)
+    M = CLS[kind](**kw)
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    O = oracleapi.OracleIpMatrix(kind)
+    O.init(prog)
+    O.factor(st[0], st[1])
+    assert M.mat_sbw == O.sbw and np.array_equal(M.perm(), O.perm())
+    d = new_d(prog)
+    M.step(prog, *st, *d)
+    ostep = O.step(*st)
+    assert rel_err(d, ostep) <= (1e-8 if spread == 0.0 else 1e-5), (rel_err(d, ostep), M.stats())
+    d2 = new_d(prog)
+    res = M.solve(prog, *st, *d2)
+    osol, ores = O.solve(*st)
+    assert res <= ores + RES_TOL
+    assert rel_err(d2, osol) <= (SOL_TOL if spread == 0.0 else 1e-5)
+    assert abs(M.residuum(prog, *st, *osol) - O.residuum(*st, *osol)) <= 1e-12
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_update_and_refactor(kind):
+    prog, st, _ = load_golden("banded_n300_b10")
+    M = CLS[kind]()
+    M.init(prog)
+    O = oracleapi.OracleIpMatrix(kind)
+    O.init(prog)
+    for scale in (1.0, 3.0, 0.25):
+        prog.Q = (prog.Q[0], prog.Q[1], prog.Q[2] * scale)
+        M.update(prog), O.update(prog)
+        M.factor(prog, st[0], st[1]), O.factor(st[0], st[1])
+        d = new_d(prog)
+        res = M.solve(prog, *st, *d)
+        osol, ores = O.solve(*st)
+        assert res <= ores + RES_TOL and rel_err(d, osol) <= SOL_TOL
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_zero_slack_is_singular(kind):
+    """v_slash raises E_SING on a zero component (meschach/vecop.c:346-348)."""
+    prog, st, _ = load_golden("banded_n60_b4")
+    M = CLS[kind]()
+    M.init(prog)
+    z = st[0].copy()
+    z[5] = 0.0
+    with pytest.raises(ipmatrix.SingularError):
+        M.factor(prog, z, st[1])
+    M.factor(prog, st[0], st[1])  # handle stays usable
+    d = new_d(prog)
+    assert M.solve(prog, *st, *d) < 1e-9
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_device_vectors_torch(kind):
+    import torch
+    prog, st, g = load_golden("did_K400_spread2")
+    M = CLS[kind](device_vectors=True)
+    M.init(prog)
+    dev = [torch.as_tensor(a).cuda() for a in st]
+    M.factor(prog, dev[0], dev[1])
+    d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
+    res = M.solve(prog, *dev, *d)
+    gold = [g[f"{kind}_solve_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    assert res <= float(g[f"{kind}_res"]) + RES_TOL
+    assert rel_err([t.cpu().numpy() for t in d], gold) <= 1e-5
+
+
+def test_full_size_c2_properties():
+    """Config C2 of BASELINE.json (n=40000, b=80: KKT dim 1e5, mat_sbw 200) at full
+    size through size-independent properties: the refined KKT residual reaches
+    mat_eps, solve() is linear in the right-hand side and a second factor of the
+    same data reproduces the same solution."""
+    prog = problems.banded_qp(40000, 80, 12345)
+    st = problems.ip_state(prog, 1)
+    M = ipmatrix.IpSpBKP()
+    M.init(prog)
+    assert M.mat_sbw == 200 and M.stats()["dim"] == 100000
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    assert res <= 1e-10, (res, M.stats())
+    assert M.residuum(prog, *st, *d) == pytest.approx(res, rel=1e-6, abs=1e-14)
+    st2 = (st[0], st[1]) + tuple(2.0 * r for r in st[2:])
+    d2 = new_d(prog)
+    M.solve(prog, *st2, *d2)
+    assert rel_err(d2, [2.0 * v for v in d]) <= 1e-9
+    M.factor(prog, st[0], st[1])
+    d3 = new_d(prog)
+    M.solve(prog, *st, *d3)
+    assert rel_err(d3, d) <= 1e-12

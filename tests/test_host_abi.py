@@ -1,0 +1,111 @@
+"""CPU: the C-ABI library loads, exports every symbol of include/hqpkkt.h, the
+host-only analysis reproduces the reference's ordering (mat_sbw, _QP2J) and
+yields a valid assembly tree; no compute call is made (there is no GPU here)."""
+import os
+import re
+
+import numpy as np
+import pytest
+
+import model
+from common import GOLDEN, KINDS, load_golden
+from hqp_amd import _lib, ipmatrix, problems
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CLS = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}
+
+
+def analyzed(cls, prog, **kw):
+    M = cls(**kw)
+    try:
+        M.init(prog)  # analyze is host-only; update() needs the device
+    except ipmatrix.KktError as e:
+        assert e.code == _lib.E_DEVICE
+    return M
+
+
+def test_header_symbols_exported():
+    hdr = open(os.path.join(ROOT, "include", "hqpkkt.h")).read()
+    declared = set(re.findall(r"\b(hqpkkt_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.SYMBOLS)
+    L = _lib.lib()
+    for s in declared:
+        assert getattr(L, s) is not None
+
+
+def test_no_cpu_fallback_in_product():
+    """The product must not import, link or execute anything under oracle/."""
+    banned = ("import oracle", "from oracle", "kkt_oracle", "libkktoracle", "libhqpref", "refapi", "oracleapi")
+    for dirpath, _d, files in os.walk(os.path.join(ROOT, "hqp_amd")):
+        for f in files:
+            if f.endswith((".py", ".hip", ".cpp", ".hpp", ".h")):
+                txt = open(os.path.join(dirpath, f)).read()
+                for b in banned:
+                    assert b not in txt, (f, b)
+
+
+def test_call_order_and_argument_errors():
+    M = ipmatrix.IpSpBKP()
+    z = np.ones(3)
+    with pytest.raises(ipmatrix.KktError) as e:
+        M.factor(None, z[:0], z[:0])
+    assert e.value.code == _lib.E_INTERN
+    with pytest.raises(ipmatrix.KktError):
+        ipmatrix.IpSpBKP(mat_tol=2.0)  # hqp/spBKP.C:389-390 E_RANGE
+
+
+def test_unsorted_csr_rejected():
+    p = problems.banded_qp(20, 3, 1)
+    Ai = p.A[1].copy()
+    Ai[0], Ai[1] = Ai[1], Ai[0]
+    bad = problems.Program(p.n, p.me, p.m, p.Q, (p.A[0], Ai, p.A[2]), p.C)
+    with pytest.raises(ipmatrix.KktError) as e:
+        ipmatrix.IpSpBKP().init(bad)
+    assert e.value.code == _lib.E_FORMAT
+
+
+@pytest.mark.parametrize("name", GOLDEN)
+@pytest.mark.parametrize("kind", KINDS)
+def test_ordering_matches_reference(name, kind):
+    prog, _st, g = load_golden(name)
+    M = analyzed(CLS[kind], prog)
+    assert M.mat_sbw == int(g[f"{kind}_sbw"])
+    assert np.array_equal(M.perm(), g[f"{kind}_perm"])
+
+
+@pytest.mark.parametrize("name", ["banded_n300_b10", "did_K50_spread4", "random_n200", "noineq_n120"])
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("small", [False, True])
+def test_assembly_tree_is_valid_and_factorisable(name, kind, small):
+    """Numpy model of the kernels' algorithm on the exported structure: nothing
+    couples outside the symbolic fronts and the factors solve the scaled system."""
+    prog, st, _g = load_golden(name)
+    kw = dict(leaf_size=24, max_pivots=12) if small else {}
+    M = analyzed(CLS[kind], prog, **kw)
+    s = M.structure()
+    dim = M.stats()["dim"]
+    e = s["elim"]
+    assert sorted(e) == list(range(dim))
+    assert int(s["npiv"].sum()) == dim
+    par = s["parent"]
+    assert all(par[k] > k or par[k] < 0 for k in range(len(par)))  # postorder
+    mode = 0 if kind == "SpBKP" else 1
+    K, _sc = model.scaled_kkt(prog, st[0], st[1], mode)
+    mdl = model.Model(s)
+    mdl.factor(K, prog.n)
+    assert mdl.struct_violation == 0.0
+    rhs = np.random.default_rng(0).uniform(-1, 1, dim)
+    rhs_e = np.zeros(dim)
+    rhs_e[e] = rhs
+    x = mdl.solve(rhs_e)[e]
+    # one solve, no refinement: tiny blocks may need perturbed pivots
+    tol = 1e-3 if mdl.npert else 1e-7
+    assert np.abs(K @ x - rhs).max() <= tol * max(1.0, np.abs(K).max() * np.abs(x).max())
+
+
+def test_large_structure_counts():
+    prog = problems.banded_qp(4000, 20, 1)
+    M = analyzed(ipmatrix.IpSpBKP, prog)
+    st = M.stats()
+    assert st["sbw"] == 50 and st["dim"] == 10000
+    assert st["n_levels"] <= 12 and st["max_front"] <= 96 + 3 * 50
