@@ -1,0 +1,219 @@
+#!/usr/bin/env python3
+"""Benchmark of the MI355X KKT path: KKT factor+solve per second (fp64).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one KKT system whose data are already
+resident in HBM: Hqp_IpMatrix::factor (assemble w/z + scaling, supernodal BK
+LDL') followed by Hqp_IpMatrix::solve (triangular solves + iterative refinement
+to mat_eps), i.e. what one interior-point iteration of the reference asks of its
+plugin besides extra right-hand sides (hqp/Hqp_IpsMehrotra.C:527-530).
+
+Workload at N=1: BASELINE.json configs[1] = SURVEY.md 8(d) "C2", the synthetic
+banded KKT system n=40000, me=20000, m=40000 (KKT dim 1e5, mat_sbw 200).
+N>1: one process per GPU, every rank factors+solves its own C2 system (different
+seed): independent KKT systems shard with no data-path collective ("weak").
+
+Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 MFMA peak
+HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
+
+
+def class_work(struct):
+    """Algorithmic work per numeric factorisation, split by kernel class, from the
+    symbolic structure (p pivots, b border rows per supernode); flops count a
+    multiply-add as 2, the Schur update only its lower triangle."""
+    p = struct["npiv"].astype(np.float64)
+    b = struct["nborder"].astype(np.float64)
+    return {
+        "factor_diag": {"flops": float((p ** 3 / 3.0).sum()), "bytes": float((8 * p * p).sum())},
+        "panel_solve": {"flops": float((b * p * p).sum()), "bytes": float((8 * (3 * b * p + p * p / 2)).sum())},
+        "schur_update": {"flops": float((b * b * p).sum()), "bytes": float((8 * (2 * b * p + b * b)).sum())},
+        "extend_add": {"flops": float((b * b / 2).sum()), "bytes": float((8 * 1.5 * b * b).sum())},
+    }
+
+
+def cpu_baseline(prog, state, budget_s=25.0):
+    """Reference CPU path timed on this box's host cores (one core: the path is
+    single-threaded, hqp/spBKP.C).  kind "reference" = the reference's own
+    Hqp_IpSpBKP built from its sources (oracle/_ref); "port" = our C oracle on a
+    reduced sample when the reference build cannot be loaded."""
+    try:
+        from oracle import refapi
+        have_ref = refapi.available()
+    except Exception:
+        have_ref = False
+    if have_ref:
+        R = refapi.RefIpMatrix("SpBKP")
+        R.init(prog)
+        t_used, ts = R.t_init, []
+        while True:
+            R.factor(state[0], state[1])
+            _d, res = R.solve(*state)
+            ts.append(R.t_factor + R.t_solve)
+            t_used += ts[-1]
+            if len(ts) >= 3 or t_used + ts[-1] > budget_s:
+                break
+        t = float(np.median(ts))
+        return {"value": 1.0 / t, "unit": "KKT factor+solve/s", "cores": 1, "kind": "reference",
+                "sample": f"{len(ts)} x (Hqp_IpSpBKP::factor + Hqp_IpMatrix::solve) on the same C2 system "
+                          f"after one init ({R.t_init:.2f} s, not counted); median {t:.3f} s; residual {res:.2e}",
+                "init_s": R.t_init, "factor_plus_solve_s": t}
+    from hqp_amd import problems
+    from oracle import oracleapi
+    small = problems.banded_qp(1600, 32, 12345)
+    st = problems.ip_state(small, 1)
+    O = oracleapi.OracleIpMatrix("SpBKP")
+    O.init(small)
+    t0 = time.perf_counter()
+    O.factor(st[0], st[1])
+    O.solve(*st)
+    t = time.perf_counter() - t0
+    return {"value": 1.0 / t, "unit": "KKT factor+solve/s", "cores": 1, "kind": "port",
+            "sample": "1 x factor+solve of a REDUCED-SIZE system (n=1600, b=32, KKT dim 4000) with the dense-storage "
+                      "C oracle; oracle/_ref not loadable on this box"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=40000, help="x variables (C2: 40000)")
+    ap.add_argument("--band", type=int, default=80, help="semi-bandwidth of Q / row width of A (C2: 80)")
+    ap.add_argument("--mode", default="SpBKP", choices=["SpBKP", "RedSpBKP"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--leaf-size", type=int, default=0)
+    ap.add_argument("--max-pivots", type=int, default=0)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    from hqp_amd import ipmatrix, problems
+
+    prog = problems.banded_qp(args.n, args.band, seed=12345 + rank)
+    state = problems.ip_state(prog, seed=1 + rank)
+    cls = ipmatrix.IpSpBKP if args.mode == "SpBKP" else ipmatrix.IpRedSpBKP
+    mat = cls(device=local_rank, device_vectors=True, leaf_size=args.leaf_size, max_pivots=args.max_pivots)
+    t0 = time.perf_counter()
+    mat.init(prog)  # analysis (host) + upload; one-time, not part of a step
+    t_init = time.perf_counter() - t0
+    dev = [torch.as_tensor(a).cuda() for a in state]
+    d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
+
+    def step():
+        mat.factor(prog, dev[0], dev[1])
+        return mat.solve(prog, *dev, *d)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    st = mat.stats()
+
+    # per-kernel-class device time (HIP events on the library's stream around every
+    # launch), taken in a separate untimed pass over the same workload
+    mat.set_profile(True)
+    nprof = max(3, min(args.steps, 10))
+    for _ in range(nprof):
+        step()
+    prof = mat.profile()
+    mat.set_profile(False)
+
+    if rank == 0:
+        struct = mat.structure()
+        work = class_work(struct)
+        per_step = {k: v[0] / nprof for k, v in prof.items()}
+        launches = {k: v[1] / nprof for k, v in prof.items()}
+        dom = max(work, key=lambda k: per_step.get(k, 0.0))
+        dom_ms = per_step[dom]
+        dom_launch_ms = dom_ms / max(launches[dom], 1.0)
+        flops_per_launch = work[dom]["flops"] / max(launches[dom], 1.0)
+        achieved = flops_per_launch / (dom_launch_ms * 1e-3) / 1e12
+        roofline = {"kernel": "k_" + dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                    "launches_per_step": launches[dom], "avg_launch_ms": dom_launch_ms,
+                    "algorithmic_flops_per_step": work[dom]["flops"]}
+        # SURVEY.md 8(d) band model of the whole factorisation, for reference
+        N, beta = st["dim"], st["sbw"]
+        fac_ms = sum(per_step.get(k, 0.0) for k in ("extend_add", "factor_diag", "panel_solve", "schur_update"))
+        model = {"flops_band_model": float(N) * beta * beta, "factor_ms": fac_ms,
+                 "tflops_band_model": float(N) * beta * beta / (fac_ms * 1e-3) / 1e12 if fac_ms > 0 else None,
+                 "tflops_as_implemented": st["flops_factor"] / (fac_ms * 1e-3) / 1e12 if fac_ms > 0 else None}
+        out = {
+            "metric": "KKT factor+solve/sec (fp64)",
+            "value": args.steps * world / elapsed,
+            "unit": "KKT factor+solve/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f64",
+            "data": "synthetic",
+            "config": {"workload": f"C2 synthetic banded KKT: n={prog.n} me={prog.me} m={prog.m} band={args.band} "
+                                   f"-> KKT dim {st['dim']}, mat_sbw {st['sbw']}, plugin {args.mode} (one system per GPU)",
+                       "kkt_dim": st["dim"], "mat_sbw": st["sbw"], "plugin": args.mode,
+                       "supernodes": st["n_supernodes"], "tree_levels": st["n_levels"], "max_front": st["max_front"],
+                       "nnz_kkt": st["nnz_kkt"], "nnz_factor": st["nnz_factor"]},
+            "residual": res,
+            "refine_rounds": st["refine_rounds"],
+            "n_2x2": st["n_2x2"], "n_perturbed": st["n_perturbed"],
+            "init_s": t_init,
+            "kernel_ms_per_step": per_step,
+            "kernel_launches_per_step": launches,
+            "factor_model": model,
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(prog, state)
+            out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

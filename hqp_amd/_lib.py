@@ -23,7 +23,8 @@ SYMBOLS = [
     "hqpkkt_set_values", "hqpkkt_factor", "hqpkkt_step", "hqpkkt_residual", "hqpkkt_solve",
     "hqpkkt_get_sbw", "hqpkkt_get_perm", "hqpkkt_set_tol", "hqpkkt_set_eps",
     "hqpkkt_set_stream", "hqpkkt_get_stats", "hqpkkt_strerror", "hqpkkt_debug_get",
-    "hqpkkt_selftest_mfma",
+    "hqpkkt_selftest_mfma", "hqpkkt_set_profile", "hqpkkt_get_profile",
+    "hqpkkt_profile_class_name",
 ]
 
 
@@ -58,6 +59,13 @@ def lib():
         raise ImportError(
             f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
             "(hipcc --offload-arch=gfx950).  hqp_amd has no CPU fallback.")
+    try:
+        # PyTorch is the plumbing for device memory / streams / torch.distributed.  Its
+        # wheel bundles its own HIP runtime; load it FIRST so that the extension binds to
+        # the same libamdhip64 (two runtimes in one process lose the GPU).
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(LIB_PATH)
     vp, ip, dp = C.c_void_p, C.POINTER(C.c_int), C.c_void_p  # vectors go as raw addresses
     L.hqpkkt_default_opts.argtypes = [C.POINTER(Opts)]
@@ -79,6 +87,10 @@ def lib():
     L.hqpkkt_strerror.argtypes = [C.c_int]
     L.hqpkkt_debug_get.argtypes = [vp, C.c_int, vp, C.POINTER(C.c_longlong)]
     L.hqpkkt_selftest_mfma.argtypes = [C.c_int, C.POINTER(C.c_double)]
+    L.hqpkkt_set_profile.argtypes = [vp, C.c_int]
+    L.hqpkkt_get_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    L.hqpkkt_profile_class_name.restype = C.c_char_p
+    L.hqpkkt_profile_class_name.argtypes = [C.c_int]
     _lib = L
     return L
 

@@ -134,7 +134,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   dim = mode == 0 ? n + me + m : n + me;
   nq = n ? Qp[n] : 0, na = me ? Ap[me] : 0, nc = m ? Cp[m] : 0;
   const int ONE = nq + na + nc, WONE = m;
-  if (max_pivots <= 0 || max_pivots > 128) max_pivots = 96;
+  if (max_pivots <= 0 || max_pivots > 128) max_pivots = 128;
   if (leaf_size <= 0) leaf_size = 0;  // decided below from sbw
 
   // ---------------------------------------------------------- SpMV blocks
@@ -241,28 +241,19 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   }
 
   // ------------------------------------------- nested dissection of the band
+  // Logical nodes: leaves = intervals of the band order, inner nodes = separators
+  // (every position coupled across the cut).  Each logical node becomes a chain
+  // of supernodes of at most max_pivots pivots further down.
   if (leaf_size <= 0) leaf_size = std::max(2 * std::max(sbw, 1), 32);
   struct Tmp {
     int lo, hi;
     std::vector<int> kids;
   };
   std::vector<Tmp> tmp;
-  // chain of supernodes covering positions [lo,hi); returns the top node
-  auto chain = [&](int lo, int hi, std::vector<int> kids) {
-    int len = hi - lo, parts = (len + max_pivots - 1) / max_pivots;
-    int size = (len + parts - 1) / parts, top = -1;
-    for (int s = lo; s < hi; s += size) {
-      Tmp t{s, std::min(s + size, hi), {}};
-      if (top < 0)
-        t.kids = kids;
-      else
-        t.kids.push_back(top);
-      tmp.push_back(t);
-      top = (int)tmp.size() - 1;
-    }
-    return top;
+  auto make = [&](int lo, int hi, std::vector<int> kids) {
+    tmp.push_back(Tmp{lo, hi, std::move(kids)});
+    return (int)tmp.size() - 1;
   };
-  // iterative recursion (explicit stack) returning the roots of [lo,hi)
   struct Frame {
     int lo, hi, stage, mid, send;
     std::vector<int> left, right;
@@ -282,7 +273,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
           continue;
         }
         if (len <= leaf_size) {
-          ret.push_back({chain(f.lo, f.hi, {})});
+          ret.push_back({make(f.lo, f.hi, {})});
           st.pop_back();
           continue;
         }
@@ -291,8 +282,8 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
         int send = f.mid;
         for (int r = f.lo; r < f.mid; r++) send = std::max(send, std::min(reach[r] + 1, f.hi));
         f.send = send;
-        if ((send - f.mid) * 3 >= len) {  // separator would dominate: keep as a chain
-          ret.push_back({chain(f.lo, f.hi, {})});
+        if ((send - f.mid) * 3 >= len) {  // separator would dominate: keep as one node
+          ret.push_back({make(f.lo, f.hi, {})});
           st.pop_back();
           continue;
         }
@@ -314,7 +305,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       std::vector<int> kids = f.left;
       kids.insert(kids.end(), f.right.begin(), f.right.end());
       if (f.send > f.mid)
-        ret.push_back({chain(f.mid, f.send, kids)});
+        ret.push_back({make(f.mid, f.send, kids)});
       else
         ret.push_back(kids);
       st.pop_back();
@@ -322,10 +313,10 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     roots = ret.back();
   }
 
-  // postorder renumbering
-  nnodes = (int)tmp.size();
-  std::vector<int> newid(nnodes, -1), order;
-  order.reserve(nnodes);
+  // postorder of the logical nodes
+  const int nlog = (int)tmp.size();
+  std::vector<int> lid(nlog, -1), lorder;
+  lorder.reserve(nlog);
   {
     std::vector<std::pair<int, size_t>> st;
     for (int r : roots) {
@@ -336,25 +327,157 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
           int c = tmp[top.first].kids[top.second++];
           st.push_back({c, 0});
         } else {
-          newid[top.first] = (int)order.size();
-          order.push_back(top.first);
+          lid[top.first] = (int)lorder.size();
+          lorder.push_back(top.first);
           st.pop_back();
         }
       }
     }
   }
+  std::vector<std::vector<int>> lverts(nlog);  // pivot sets by band position
+  std::vector<int> lnode_of_pos(dim);
+  for (int id = 0; id < nlog; id++) {
+    const Tmp &t = tmp[lorder[id]];
+    for (int r = t.lo; r < t.hi; r++) lverts[id].push_back(r), lnode_of_pos[r] = id;
+  }
+  // Variables with a structurally zero diagonal (equality multipliers; x_i without
+  // Q_ii) can only be pivoted together with, or after, a neighbour that carries a
+  // diagonal.  A maximum matching assigns every such variable a DISTINCT partner
+  // (which makes every subtree's matrix structurally non-singular); a variable
+  // whose partner lives in a proper ancestor is moved up into that node, and
+  // inside a node it is ordered behind its partner, so that a 2x2 pivot with the
+  // partner is always available inside the pivot block.  Neighbours are either
+  // in the variable's subtree or in ancestors (separator property), and node ids
+  // are a postorder, so "partner id > own id" means "proper ancestor"; moving a
+  // vertex up its own root path keeps the assembly tree valid.
+  std::vector<int> partner(dim, -1);
+  {
+    std::vector<char> has_diag(dim, 0);
+    for (int e = 0; e < nent; e++)
+      if (ent_a[e] == ent_b[e]) has_diag[ent_a[e]] = 1;
+    auto node_of_q = [&](int q) { return lnode_of_pos[qp2j[q]]; };
+    std::vector<int> used_by(dim, -1), pos2q(dim);
+    for (int q = 0; q < dim; q++) pos2q[qp2j[q]] = q;
+    // pass 1: free partner inside the own subtree (largest node id <= own)
+    // pass 2: free partner in the lowest ancestor
+    for (int pass = 1; pass <= 2; pass++)
+      for (int r = 0; r < dim; r++) {
+        const int q = pos2q[r];
+        if (has_diag[q] || partner[q] >= 0) continue;
+        const int sn = node_of_q(q);
+        int best = -1, bestn = pass == 1 ? -1 : nlog;
+        for (int k = gstart[q]; k < gstart[q + 1]; k++) {
+          const int x = gneigh[k];
+          if (!has_diag[x] || used_by[x] >= 0) continue;
+          const int t = node_of_q(x);
+          if (pass == 1 ? (t <= sn && t > bestn) : (t > sn && t < bestn)) best = x, bestn = t;
+        }
+        if (best >= 0) partner[q] = best, used_by[best] = q;
+      }
+    // pass 3: augmenting paths (Kuhn) for what is still unmatched
+    {
+      std::vector<int> seen(dim, -1), stack_z, stack_k, via(dim, -1);
+      for (int r = 0; r < dim; r++) {
+        const int q0 = pos2q[r];
+        if (has_diag[q0] || partner[q0] >= 0 || gstart[q0 + 1] == gstart[q0]) continue;
+        stack_z.assign(1, q0);
+        stack_k.assign(1, gstart[q0]);
+        int found = -1;
+        while (!stack_z.empty() && found < 0) {
+          const int zq = stack_z.back();
+          int &k = stack_k.back();
+          if (k >= gstart[zq + 1]) {
+            stack_z.pop_back(), stack_k.pop_back();
+            continue;
+          }
+          const int x = gneigh[k++];
+          if (!has_diag[x] || seen[x] == q0) continue;
+          seen[x] = q0;
+          via[x] = zq;
+          if (used_by[x] < 0)
+            found = x;
+          else {
+            stack_z.push_back(used_by[x]);
+            stack_k.push_back(gstart[used_by[x]]);
+          }
+        }
+        while (found >= 0) {  // flip the path back to q0
+          const int zq = via[found], prev = partner[zq];
+          partner[zq] = found, used_by[found] = zq;
+          found = (zq == q0) ? -1 : prev;
+        }
+      }
+    }
+    for (int r = 0; r < dim; r++) {
+      const int q = pos2q[r];
+      if (has_diag[q] || partner[q] < 0) continue;
+      const int sn = lnode_of_pos[r], t = node_of_q(partner[q]);
+      if (t <= sn || lverts[sn].size() <= 1) continue;
+      lverts[sn].erase(std::find(lverts[sn].begin(), lverts[sn].end(), r));
+      lverts[t].push_back(r);
+      lnode_of_pos[r] = t;
+    }
+    // order inside a node: band order, a zero-diagonal variable right behind its
+    // partner when the partner is in the same node
+    std::vector<std::vector<int>> followers(dim);
+    for (int id = 0; id < nlog; id++) {
+      std::vector<int> &v = lverts[id];
+      std::sort(v.begin(), v.end());
+      std::vector<int> heads;
+      for (int r : v) {
+        const int q = pos2q[r];
+        const int pq = has_diag[q] ? -1 : partner[q];
+        if (pq >= 0 && lnode_of_pos[qp2j[pq]] == id)
+          followers[qp2j[pq]].push_back(r);
+        else
+          heads.push_back(r);
+      }
+      std::vector<int> out;
+      for (int r : heads) {
+        out.push_back(r);
+        for (int f : followers[r]) out.push_back(f);
+      }
+      v.swap(out);
+    }
+  }
+
+  // chains of supernodes: each logical node is cut into pieces of <= max_pivots
+  // pivots; a partner pair is never cut with the zero-diagonal variable first
+  std::vector<std::vector<int>> nverts;
+  std::vector<int> ltop(nlog, -1);
+  std::vector<std::vector<int>> nkids;
+  for (int id = 0; id < nlog; id++) {
+    const Tmp &t = tmp[lorder[id]];
+    const std::vector<int> &v = lverts[id];
+    const int len = (int)v.size(), parts = std::max(1, (len + max_pivots - 1) / max_pivots);
+    const int size = (len + parts - 1) / parts;
+    int top = -1;
+    for (int s = 0; s < len || (len == 0 && s == 0); s += std::max(size, 1)) {
+      std::vector<int> piece(v.begin() + s, v.begin() + std::min(s + size, len));
+      std::vector<int> kids;
+      if (top < 0)
+        for (int c : t.kids) kids.push_back(ltop[lid[c]]);
+      else
+        kids.push_back(top);
+      nverts.push_back(std::move(piece));
+      nkids.push_back(std::move(kids));
+      top = (int)nverts.size() - 1;
+      if (len == 0) break;
+    }
+    ltop[id] = top;
+  }
+  nnodes = (int)nverts.size();
   piv_start.assign(nnodes, 0), npiv.assign(nnodes, 0), parent.assign(nnodes, -1);
   level.assign(nnodes, 0), child_slot.assign(nnodes, 0);
   std::vector<int> j2e(dim);
   {
     int e = 0;
     for (int id = 0; id < nnodes; id++) {
-      const Tmp &t = tmp[order[id]];
       piv_start[id] = e;
-      npiv[id] = t.hi - t.lo;
-      for (int r = t.lo; r < t.hi; r++) j2e[r] = e++;
-      for (size_t s = 0; s < t.kids.size(); s++) {
-        int c = newid[t.kids[s]];
+      npiv[id] = (int)nverts[id].size();
+      for (int r : nverts[id]) j2e[r] = e++;
+      for (size_t s = 0; s < nkids[id].size(); s++) {
+        int c = nkids[id][s];
         parent[c] = id;
         child_slot[c] = (int)s;
         level[id] = std::max(level[id], level[c] + 1);
@@ -476,7 +599,11 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     ea_level_ptr[l + 1] = (int)ea_seg_ptr.size() - 1;
   }
   upd_tile_ptr.assign(nlevels + 1, 0), slab_ptr.assign(nlevels + 1, 0);
-  upd_tiles.clear(), slabs.clear();
+  gslab_ptr.assign(nlevels + 1, 0), cblk_ptr.assign(nlevels + 1, 0);
+  upd_tiles.clear(), slabs.clear(), gslabs.clear(), cblks.clear();
+  dblk_off.assign(nnodes, 0);
+  dblk_elems = 0;
+  for (int id = 0; id < nnodes; id++) dblk_off[id] = dblk_elems, dblk_elems += 256LL * ((npiv[id] + 15) / 16);
   for (int l = 0; l < nlevels; l++) {
     for (int t = level_ptr[l]; t < level_ptr[l + 1]; t++) {
       int id = level_nodes[t], b = nbor[id];
@@ -485,9 +612,13 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
         for (int tj = 0; tj <= ti; tj++) upd_tiles.insert(upd_tiles.end(), {id, ti, tj});
       int ns = (b + SLAB_ROWS - 1) / SLAB_ROWS;
       for (int s = 0; s < ns; s++) slabs.insert(slabs.end(), {id, s});
+      for (int s = 0; s < (b + 63) / 64; s++) gslabs.insert(gslabs.end(), {id, s});
+      for (int c = 0; c < (npiv[id] + 15) / 16; c++) cblks.insert(cblks.end(), {id, c});
     }
     upd_tile_ptr[l + 1] = (int)upd_tiles.size() / 3;
     slab_ptr[l + 1] = (int)slabs.size() / 2;
+    gslab_ptr[l + 1] = (int)gslabs.size() / 2;
+    cblk_ptr[l + 1] = (int)cblks.size() / 2;
   }
 
   // ------------------------------------------------------- assembly map

@@ -47,7 +47,11 @@ struct Analysis {
   std::vector<int> child_ptr, child_idx;
   // tiles of the Schur update and slabs of the panel solve, grouped by level
   std::vector<int> upd_tile_ptr, upd_tiles;    // triples (node, ti, tj)
-  std::vector<int> slab_ptr, slabs;            // pairs (node, slab)
+  std::vector<int> slab_ptr, slabs;            // pairs (node, slab): 32 border rows
+  std::vector<int> gslab_ptr, gslabs;          // pairs (node, slab): 64 border rows (solve)
+  std::vector<int> cblk_ptr, cblks;            // pairs (node, block of 16 pivot columns)
+  std::vector<long long> dblk_off;             // inverse diagonal blocks, 256 doubles each
+  long long dblk_elems = 0;
 
   // --- numeric assembly map ----------------------------------------------------
   std::vector<long long> ent_dst;  // offset into the panel arena per entry

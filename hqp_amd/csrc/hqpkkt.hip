@@ -72,8 +72,69 @@ struct CsrBuf {
 
 }  // namespace
 
+// per-kernel-class device timing (hqpkkt_set_profile): HIP events on the
+// handle's stream around every launch, summed per class after the call
+enum { KC_ASSEMBLE = 0, KC_EXTEND_ADD, KC_FACTOR_DIAG, KC_PANEL_SOLVE, KC_SCHUR_UPDATE,
+       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_COUNT };
+static const char *const kc_names[KC_COUNT] = {"assemble", "extend_add", "factor_diag", "panel_solve",
+                                               "schur_update", "solve_fwd", "solve_bwd", "vector",
+                                               "residual"};
+struct Prof {
+  bool on = false;
+  std::vector<hipEvent_t> pool;
+  std::vector<int> cls;
+  size_t used = 0;
+  double ms[KC_COUNT] = {0};
+  long long launches[KC_COUNT] = {0};
+  hipEvent_t get() {
+    if (used == pool.size()) {
+      hipEvent_t e;
+      if (hipEventCreate(&e) != hipSuccess) return nullptr;
+      pool.push_back(e);
+    }
+    return pool[used++];
+  }
+  void begin(int c, hipStream_t s) {
+    if (!on) return;
+    hipEvent_t e = get();
+    cls.push_back(c);
+    if (e) (void)hipEventRecord(e, s);
+  }
+  void end(hipStream_t s) {
+    if (!on) return;
+    hipEvent_t e = get();
+    if (e) (void)hipEventRecord(e, s);
+  }
+  // call after the stream has been synchronised
+  void collect() {
+    for (size_t k = 0; k + 1 < used && k / 2 < cls.size(); k += 2) {
+      float t = 0.f;
+      if (hipEventElapsedTime(&t, pool[k], pool[k + 1]) == hipSuccess) {
+        ms[cls[k / 2]] += t;
+        launches[cls[k / 2]]++;
+      }
+    }
+    used = 0;
+    cls.clear();
+  }
+  void reset() {
+    for (int c = 0; c < KC_COUNT; c++) ms[c] = 0, launches[c] = 0;
+  }
+  void destroy() {
+    for (auto e : pool) (void)hipEventDestroy(e);
+    pool.clear();
+  }
+};
+#define KLAUNCH(h, c, ...)        \
+  do {                            \
+    (h)->prof.begin(c, (h)->stream); \
+    __VA_ARGS__;                  \
+    (h)->prof.end((h)->stream);   \
+  } while (0)
+
 struct hqpkkt {
   hqpkkt_opts opts;
+  Prof prof;
   Analysis an;
   bool analyzed = false, uploaded = false, have_values = false, factored = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
@@ -82,13 +143,13 @@ struct hqpkkt {
 
   // symbolic structure on the device
   DBuf<int> piv_start, npiv, nbor, parent, bidx, rel, child_ptr, child_idx, level_nodes,
-      ea_nodes, upd_tiles, slabs, ent_a, ent_b, term_ptr, diag_ent, q2e;
-  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst;
+      ea_nodes, upd_tiles, slabs, gslabs, cblks, ent_a, ent_b, term_ptr, diag_ent, q2e;
+  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, dblk_off;
   DBuf<TermDev> terms;
   DBuf<signed char> esign;
   CsrBuf Qf, A, AT, C, CT;
   // numeric state
-  DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb;
+  DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb, ytmp, vtmp, dblk;
   DBuf<int> ptype, lperm, flags;  // flags: [0] status, [1] n_2x2, [2] n_perturbed
   DBuf<unsigned long long> bits;  // [0] kmax, [1] residual max
   // vectors: staging for host pointers + refinement work vectors
@@ -97,7 +158,7 @@ struct hqpkkt {
   DBuf<double> vres;  // residual vectors _r1.._r4
   DBuf<double> vcor;  // corrections _dx.._dw
   DBuf<double> tz;    // REDUCED temporary (m)
-  size_t lds_diag = 0, lds_panel = 0, lds_solve = 0;
+  size_t lds_diag = 0, lds_panel = 0, lds_solve = 0, lds_bwdb = 0;
 
   DevTree tree() const {
     return DevTree{piv_start.p, npiv.p,     nbor.p,  parent.p, bptr.p,      bidx.p,     rel.p,
@@ -105,13 +166,13 @@ struct hqpkkt {
   }
   void release_device() {
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
-                       &level_nodes, &ea_nodes, &upd_tiles, &slabs, &ent_a, &ent_b, &term_ptr,
+                       &level_nodes, &ea_nodes, &upd_tiles, &slabs, &gslabs, &cblks, &ent_a, &ent_b, &term_ptr,
                        &diag_ent, &q2e, &ptype, &lperm, &flags};
     for (auto b : ib) b->release();
-    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst};
+    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &dblk_off};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &dblk};
     for (auto b : db) b->release();
     terms.release(), esign.release(), bits.release();
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
@@ -158,6 +219,9 @@ static int upload(hqpkkt_t *h) {
   UP(ea_nodes, ea_nodes);
   UP(upd_tiles, upd_tiles);
   UP(slabs, slabs);
+  UP(gslabs, gslabs);
+  UP(cblks, cblks);
+  UP(dblk_off, dblk_off);
   UP(ent_a, ent_a);
   UP(ent_b, ent_b);
   UP(term_ptr, term_ptr);
@@ -190,8 +254,9 @@ static int upload(hqpkkt_t *h) {
       (e = h->ent_val.alloc(an.ent_a.size())) || (e = h->panel.alloc(an.panel_elems)) ||
       (e = h->upd.alloc(an.upd_elems)) || (e = h->xar.alloc(an.x_elems)) ||
       (e = h->dinv.alloc(2 * (size_t)dim)) || (e = h->rhs.alloc(dim)) ||
-      (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ptype.alloc(dim)) ||
-      (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(4)) || (e = h->bits.alloc(2)) ||
+      (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ytmp.alloc(dim)) ||
+      (e = h->vtmp.alloc(dim)) || (e = h->dblk.alloc(an.dblk_elems)) || (e = h->ptype.alloc(dim)) ||
+      (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(64)) || (e = h->bits.alloc(2)) ||
       (e = h->vin.alloc(2 * (size_t)m + n + me + 2 * (size_t)m)) ||
       (e = h->vout.alloc((size_t)n + me + 2 * (size_t)m)) ||
       (e = h->vres.alloc((size_t)n + me + 2 * (size_t)m)) ||
@@ -205,18 +270,22 @@ static int upload(hqpkkt_t *h) {
     HIPCHK(hipMemcpy(h->wt.p + m, &one, sizeof(double), hipMemcpyHostToDevice));
   }
   // dynamic LDS budgets
-  const size_t mp = an.max_npiv, mf = an.max_front;
-  h->lds_diag = ((mp | 1) * mp + 4 * mp) * sizeof(double) + 2 * mp * sizeof(int) + 16;
-  h->lds_panel = (32 * mp + PS_COLS * mp) * sizeof(double);
-  h->lds_solve = (mf + mp + SV_COLS * mp + an.max_nbor) * sizeof(double);
+  const size_t mp = an.max_npiv, ldm = mp | 1, nbm = (mp + 15) / 16;
+  h->lds_diag = (ldm * mp + 2 * mp) * sizeof(double) + 2 * mp * sizeof(int) + 16;
+  h->lds_panel = (32 * mp + PS_COLS * mp + 256) * sizeof(double);
+  h->lds_solve = (ldm * mp + 2 * mp + nbm * 256) * sizeof(double);
+  h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
+  if (h->lds_diag > 160 * 1024 || h->lds_solve > 160 * 1024 || h->lds_bwdb > 160 * 1024) return HQPKKT_E_MEM;
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_diag));
   HIPCHK(hipFuncSetAttribute((const void *)k_panel_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_panel));
-  HIPCHK(hipFuncSetAttribute((const void *)k_solve_fwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPCHK(hipFuncSetAttribute((const void *)k_solve_fwd_a, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_solve));
-  HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd, hipFuncAttributeMaxDynamicSharedMemorySize,
+  HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_solve));
+  HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize,
+                             (int)h->lds_bwdb));
   h->st.bytes_panels = (long long)sizeof(double) * (an.panel_elems + an.x_elems);
   h->st.bytes_updates = (long long)sizeof(double) * an.upd_elems;
   h->uploaded = true;
@@ -281,17 +350,17 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
   DevTree T = h->tree();
   HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, s));
   if (an.upd_elems) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
-  HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 4, s));
+  HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 64, s));
   HIPCHK(hipMemsetAsync(h->bits.p, 0, sizeof(unsigned long long) * 2, s));
   HIPCHK(hipEventRecord(h->ev0, s));
   if (m > 0)
-    k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p);
-  k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
-                                            h->ent_val.p);
+    KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
+  KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
+                                            h->ent_val.p));
   if (an.mode == 1 && an.n > 0)
-    k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p);
-  k_scatter<<<nblk(nent), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
-                                       h->sc.p, h->panel.p, h->bits.p);
+    KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
+  KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<nblk(nent), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
+                                       h->sc.p, h->panel.p, h->bits.p));
   HIPCHK(hipEventRecord(h->ev1, s));
   const double alpha = h->opts.tol * 0.6403882032022076;  // tol (1+sqrt 17)/8, hqp/spBKP.C:392
   for (int l = 0; l < an.nlevels; l++) {
@@ -299,22 +368,23 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
       int cnt = an.ea_seg_ptr[seg + 1] - an.ea_seg_ptr[seg];
       if (cnt <= 0) continue;
       int ysplit = std::max(1, std::min(64, 2048 / cnt));
-      k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, h->ea_nodes.p + an.ea_seg_ptr[seg],
-                                                     h->panel.p, h->upd.p);
+      KLAUNCH(h, KC_EXTEND_ADD, k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, h->ea_nodes.p + an.ea_seg_ptr[seg],
+                                                     h->panel.p, h->upd.p));
     }
     const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
-    k_factor_diag<<<nn, 256, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
-                                               h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, alpha,
-                                               h->opts.pivot_eps, h->bits.p, h->flags.p + 1);
+    KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn, 256, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
+                                               h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
+                                               h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                               h->flags.p + 1, h->opts.reserved[0]));
     const int ns = an.slab_ptr[l + 1] - an.slab_ptr[l];
     if (ns > 0)
-      k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, h->slabs.p + 2 * (size_t)an.slab_ptr[l],
+      KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, h->slabs.p + 2 * (size_t)an.slab_ptr[l],
                                                   h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
-                                                  h->lperm.p);
+                                                  h->lperm.p, h->dblk.p, h->dblk_off.p));
     const int nt = an.upd_tile_ptr[l + 1] - an.upd_tile_ptr[l];
     if (nt > 0)
-      k_schur_update<<<nt, 256, 0, s>>>(T, h->upd_tiles.p + 3 * (size_t)an.upd_tile_ptr[l],
-                                        h->panel.p, h->xar.p, h->upd.p);
+      KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, h->upd_tiles.p + 3 * (size_t)an.upd_tile_ptr[l],
+                                        h->panel.p, h->xar.p, h->upd.p));
   }
   HIPCHK(hipEventRecord(h->evs1, s));
   HIPCHK(hipGetLastError());
@@ -327,35 +397,48 @@ static int run_step(hqpkkt_t *h, const Vecs &v) {
   const int n = an.n, me = an.me, m = an.m, dim = an.dim;
   DevTree T = h->tree();
   if (an.mode == 0) {
-    k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
-                                         h->rhs.p);
+    KLAUNCH(h, KC_VECTOR, k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
+                                         h->rhs.p));
   } else {
-    if (m > 0) k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p);
-    k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
-                                        h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p);
+    if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
+    KLAUNCH(h, KC_VECTOR, k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
+                                        h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p));
   }
   for (int l = 0; l < an.nlevels; l++) {
     const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
-    k_solve_fwd<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
-                                              h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
-                                              h->xsol.p, h->cb.p);
+    KLAUNCH(h, KC_SOLVE_FWD,
+            k_solve_fwd_a<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l],
+                                                        h->panel.p, h->dinv.p, h->ptype.p, h->lperm.p,
+                                                        h->dblk.p, h->dblk_off.p, h->rhs.p, h->xsol.p,
+                                                        h->ytmp.p, h->cb.p));
+    const int ng = an.gslab_ptr[l + 1] - an.gslab_ptr[l];
+    if (ng > 0)
+      KLAUNCH(h, KC_SOLVE_FWD,
+              k_solve_fwd_b<<<ng, 256, 0, s>>>(T, h->gslabs.p + 2 * (size_t)an.gslab_ptr[l], h->panel.p,
+                                               h->ytmp.p, h->cb.p));
   }
   for (int l = an.nlevels - 1; l >= 0; l--) {
     const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
-    k_solve_bwd<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
-                                              h->lperm.p, h->xsol.p);
+    const int ncb = an.cblk_ptr[l + 1] - an.cblk_ptr[l];
+    KLAUNCH(h, KC_SOLVE_BWD,
+            k_solve_bwd_b<<<ncb, 256, h->lds_bwdb, s>>>(T, h->cblks.p + 2 * (size_t)an.cblk_ptr[l],
+                                                        h->panel.p, h->xsol.p, h->vtmp.p));
+    KLAUNCH(h, KC_SOLVE_BWD,
+            k_solve_bwd_a<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l],
+                                                        h->panel.p, h->lperm.p, h->dblk.p,
+                                                        h->dblk_off.p, h->vtmp.p, h->xsol.p));
   }
   if (an.mode == 0) {
-    k_unpack_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy,
-                                            v.dz);
+    KLAUNCH(h, KC_VECTOR, k_unpack_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy,
+                                            v.dz));
     if (m > 0)
-      k_dw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, v.r3,
-                                   v.dw);
+      KLAUNCH(h, KC_VECTOR, k_dw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, v.r3,
+                                   v.dw));
   } else {
-    k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy);
+    KLAUNCH(h, KC_VECTOR, k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy));
     if (m > 0)
-      k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx,
-                                         h->wt.p, h->tz.p, v.r3, v.dz, v.dw);
+      KLAUNCH(h, KC_VECTOR, k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx,
+                                         h->wt.p, h->tz.p, v.r3, v.dz, v.dw));
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -368,9 +451,9 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
   const int n = an.n, me = an.me, m = an.m;
   double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
   HIPCHK(hipMemsetAsync(h->bits.p + 1, 0, sizeof(unsigned long long), s));
-  k_residual<<<nblk((long long)n + me + m), 256, 0, s>>>(
+  KLAUNCH(h, KC_RESIDUAL, k_residual<<<nblk((long long)n + me + m), 256, 0, s>>>(
       n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
-      v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1);
+      v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
   unsigned long long bits = 0;
   HIPCHK(hipMemcpyAsync(&bits, h->bits.p + 1, sizeof(bits), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -432,6 +515,7 @@ int hqpkkt_destroy(hqpkkt_t *h) {
     (void)hipEventDestroy(h->ev1);
     (void)hipEventDestroy(h->evs0);
     (void)hipEventDestroy(h->evs1);
+    h->prof.destroy();
     (void)hipStreamDestroy(h->own_stream);
   }
   delete h;
@@ -501,9 +585,16 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   HIPCHK(hipMemcpyAsync(flags, h->flags.p, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(&kb, h->bits.p, sizeof(kb), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->prof.collect();
   h->st.ms_assemble = elapsed(h->ev0, h->ev1);
   h->st.ms_factor = elapsed(h->ev1, h->evs1);
   h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2];
+  if (h->opts.reserved[0] & 32) {  // diagnostic cycle stamps of k_factor_diag (block 0 of every level)
+    unsigned long long t[6];
+    HIPCHK(hipMemcpy(t, h->flags.p + 8, sizeof(t), hipMemcpyDeviceToHost));
+    std::fprintf(stderr, "factor_diag stamps (cycles, block 0 summed over levels): decision %llu swap %llu inverse %llu update %llu barrier %llu looptop %llu\n",
+                 t[0], t[1], t[2], t[3], t[4], t[5]);
+  }
   std::memcpy(&h->st.kmax, &kb, sizeof(double));
   if (flags[0]) return flags[0];
   if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
@@ -526,6 +617,7 @@ int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w, const double *r1,
   HIPCHK(hipEventRecord(h->evs1, h->stream));
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->prof.collect();
   h->st.ms_step = elapsed(h->evs0, h->evs1);
   return 0;
 }
@@ -553,6 +645,7 @@ int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w, const double 
   e = run_residual(h, v, res);
   HIPCHK(hipEventRecord(h->evs1, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  h->prof.collect();
   h->st.ms_residual = elapsed(h->evs0, h->evs1);
   return e;
 }
@@ -586,12 +679,12 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
     rounds++;
     double alpha = 1.0;
     do {
-      k_axpy4<<<nblk(ntot), 256, 0, s>>>(n, me, m, alpha, c.dx, c.dy, c.dz, c.dw, v.dx, v.dy, v.dz,
-                                         v.dw);
+      KLAUNCH(h, KC_VECTOR, k_axpy4<<<nblk(ntot), 256, 0, s>>>(n, me, m, alpha, c.dx, c.dy, c.dz, c.dw, v.dx, v.dy, v.dz,
+                                         v.dw));
       if ((e = run_residual(h, v, &res))) return e;
       if (res > res_last) {
-        k_axpy4<<<nblk(ntot), 256, 0, s>>>(n, me, m, -alpha, c.dx, c.dy, c.dz, c.dw, v.dx, v.dy,
-                                           v.dz, v.dw);
+        KLAUNCH(h, KC_VECTOR, k_axpy4<<<nblk(ntot), 256, 0, s>>>(n, me, m, -alpha, c.dx, c.dy, c.dz, c.dw, v.dx, v.dy,
+                                           v.dz, v.dw));
         alpha -= 0.3;
       }
     } while (res > res_last && alpha > 0.0);
@@ -600,6 +693,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   HIPCHK(hipEventRecord(h->ev1, s));
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
   HIPCHK(hipStreamSynchronize(s));
+  h->prof.collect();
   h->st.ms_solve = elapsed(h->ev0, h->ev1);
   h->st.refine_rounds = rounds;
   if (res_out) *res_out = res;
@@ -640,6 +734,21 @@ int hqpkkt_set_stream(hqpkkt_t *h, void *hip_stream) {
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
   return 0;
 }
+
+int hqpkkt_set_profile(hqpkkt_t *h, int on) {
+  if (!h) return HQPKKT_E_NULL;
+  h->prof.on = on != 0;
+  h->prof.reset();
+  return 0;
+}
+
+int hqpkkt_get_profile(const hqpkkt_t *h, int n_classes, double *ms, long long *launches) {
+  if (!h || !ms || !launches) return HQPKKT_E_NULL;
+  for (int c = 0; c < n_classes && c < KC_COUNT; c++) ms[c] = h->prof.ms[c], launches[c] = h->prof.launches[c];
+  return KC_COUNT;
+}
+
+const char *hqpkkt_profile_class_name(int c) { return (c >= 0 && c < KC_COUNT) ? kc_names[c] : ""; }
 
 int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out) {
   if (!h || !out) return HQPKKT_E_NULL;

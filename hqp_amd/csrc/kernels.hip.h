@@ -37,6 +37,57 @@ __device__ __forceinline__ double wave_max(double v) {
   for (int o = 32; o > 0; o >>= 1) v = fmax(v, __shfl_xor(v, o));
   return v;
 }
+// max over the 64 lanes of a non-negative value with DPP row operations (no LDS
+// crossbar traffic); the result is broadcast to every lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_max_dpp(double v) {
+  v = fmax(v, dpp_move<0xb1, 0xf>(v));   // quad_perm [1,0,3,2]
+  v = fmax(v, dpp_move<0x4e, 0xf>(v));   // quad_perm [2,3,0,1]
+  v = fmax(v, dpp_move<0x124, 0xf>(v));  // row_ror 4
+  v = fmax(v, dpp_move<0x128, 0xf>(v));  // row_ror 8
+  v = fmax(v, dpp_move<0x142, 0xa>(v));  // row_bcast 15
+  v = fmax(v, dpp_move<0x143, 0xc>(v));  // row_bcast 31 -> lane 63 holds the max
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// lower triangle (incl. diagonal) of a p x p column-major block -> LDS image with
+// leading dimension ld; global loads are issued in batches of 16 per thread so
+// that their latencies overlap (p <= 128)
+__device__ __forceinline__ void stage_lower(const double *__restrict__ P, long long F, int p, int ld,
+                                            double *a, int wave, int lane) {
+  for (int jb = 0; jb < p; jb += 32) {
+    double v[8][2];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = jb + wave + 4 * u;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int i = lane + 64 * h;
+        v[u][h] = (j < p && i < p && i >= j) ? P[(long long)j * F + i] : 0.0;
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int j = jb + wave + 4 * u;
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        const int i = lane + 64 * h;
+        if (j < p && i < p && i >= j) a[i + j * ld] = v[u][h];
+      }
+    }
+  }
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
@@ -140,21 +191,26 @@ __global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
 
 // ------------------------------------------------- pivot block: dense BK LDL'
 // One workgroup per supernode.  The p x p pivot block sits in LDS (lower
-// triangle, leading dimension p|1).  Bunch-Kaufman partial pivoting with the
-// reference's threshold alpha = tol (1+sqrt 17)/8 and test order
-// (hqp/spBKP.C:392, 431-438, 471, 480), restricted to the pivot block; a pivot
-// below pert = pivot_eps * max|K| is replaced by +-pert (sign from the block the
-// row belongs to: x rows negative, y/slack rows positive).
-struct DiagShared {
-  int kind, r;
-  double d0, d1, d2;
-};
-
+// triangle, odd leading dimension so that row walks are conflict-free).
+// Bunch-Kaufman partial pivoting with the reference's threshold
+// alpha = tol (1+sqrt 17)/8 and test order (hqp/spBKP.C:392, 431-438, 471, 480),
+// restricted to the pivot block.  Every wave takes the pivot decision
+// redundantly from the same LDS data (wave shuffles for the max / arg-max
+// reductions), so a pivot step costs one barrier, three when rows are swapped.
+// Eliminated columns stay unscaled (c = l*d) until the write-back.  A pivot
+// smaller than pert = pivot_eps * max|K| is replaced by +-pert (x rows negative,
+// y / slack rows positive); the symbolic phase places zero-diagonal variables
+// so that this does not happen for structurally non-singular systems.
+// Also writes the inverses of the 16x16 diagonal blocks of L11 for the
+// triangular solves (block forward / backward substitution without a
+// sequential inner loop).
+#define DB 16
 __global__ void __launch_bounds__(256)
 k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
               double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
-              const signed char *__restrict__ esign, double alpha, double pivot_eps,
-              const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
+              const signed char *__restrict__ esign, double *__restrict__ dblk,
+              const long long *__restrict__ dblk_off, double alpha, double pivot_eps,
+              const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters, int dbg) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
@@ -162,62 +218,64 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   const int e0 = T.piv_start[node];
   double *P = panel + T.panel_off[node];
   const int ld = p | 1;
-  double *a = lds;                 // ld * p
-  double *v1 = a + ld * p;         // p   scaled column(s)
-  double *v2 = v1 + p;
-  double *w1 = v2 + p;             // p   unscaled column(s)
-  double *w2 = w1 + p;
-  int *lp = (int *)(w2 + p);       // p   local pivot order
-  int *pt = lp + p;                // p   pivot type per position
-  __shared__ DiagShared sh;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const double pert = pivot_eps * __longlong_as_double((long long)*kmax_bits);
+  double *a = lds;            // ld * p
+  double *dv = a + ld * p;    // 2p: inverse pivot data per position
+  int *lp = (int *)(dv + 2 * p);  // p   local pivot order
+  int *pt = lp + p;               // p   pivot type per position
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tx = tid & 31, ty = tid >> 5;
+  const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
 
-  for (int idx = tid; idx < p * p; idx += blockDim.x) {
-    int i = idx % p, j = idx / p;
-    a[i + j * ld] = (i >= j) ? P[(long long)j * F + i] : 0.0;
-  }
+  stage_lower(P, F, p, ld, a, wave, lane);
   for (int i = tid; i < p; i += blockDim.x) lp[i] = i;
   __syncthreads();
 
+#define STAMP(slot)                                                              \
+  if (dbg & 32) {                                                                \
+    unsigned long long t_;                                                       \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
+    if (tid == 0 && blockIdx.x == 0) tacc[slot] += t_ - tlast;                   \
+    tlast = t_;                                                                  \
+  }
+  unsigned long long tlast = 0, tacc[6] = {0, 0, 0, 0, 0, 0};
+  if (dbg & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
   int k = 0;
   while (k < p) {
-    // ---- decision (wave 0) ------------------------------------------------
-    if (tid < 64) {
-      double best = -1.0;
-      int bi = p;
-      for (int i = k + 1 + lane; i < p; i += 64) {
-        double t = fabs(a[i + k * ld]);
-        if (t > best) best = t, bi = i;  // ascending i inside a lane: first max wins
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) {
-        double ob = __shfl_xor(best, o);
-        int oi = __shfl_xor(bi, o);
-        if (ob > best || (ob == best && oi < bi)) best = ob, bi = oi;
-      }
-      const double akk = fabs(a[k + k * ld]);
-      const double lambda = best < 0.0 ? 0.0 : best;
-      int kind = 0, r = bi;
-      if (!(akk >= alpha * lambda)) {
-        double s = 0.0;
-        for (int t = k + lane; t < p; t += 64)
-          if (t != r) s = fmax(s, fabs(t < r ? a[r + t * ld] : a[t + r * ld]));
-        const double sigma = wave_max(s);
-        if (sigma * akk >= alpha * lambda * lambda)
-          kind = 0;
-        else if (fabs(a[r + r * ld]) >= alpha * sigma)
-          kind = 1;
-        else
-          kind = 2;
-      }
-      if (lane == 0) sh.kind = kind, sh.r = r;
+    STAMP(5)
+    // ---- decision, redundantly per wave --------------------------------------
+    // column max lambda and its first row index r (hqp/spBKP.C:431-437): two
+    // candidates per lane, DPP max over the wave, ballot for the arg-max
+    const int i1 = k + 1 + lane, i2 = i1 + 64;
+    const double t1 = i1 < p ? fabs(a[i1 + k * ld]) : -1.0;
+    const double t2 = i2 < p ? fabs(a[i2 + k * ld]) : -1.0;
+    const double lambda = wave_max_dpp(fmax(fmax(t1, t2), 0.0));
+    int r = p;
+    {
+      const unsigned long long m1 = __ballot(t1 == lambda), m2 = __ballot(t2 == lambda);
+      if (m1)
+        r = k + 1 + __builtin_ctzll(m1);
+      else if (m2)
+        r = k + 65 + __builtin_ctzll(m2);
     }
-    __syncthreads();
-    const int kind = sh.kind, r = sh.r;
-    // ---- symmetric interchange -------------------------------------------
+    const double akk = fabs(a[k + k * ld]);
+    int kind = 0;
+    if (r < p && !(akk >= alpha * lambda)) {
+      double s = 0.0;
+      for (int t = k + lane; t < p; t += 64)
+        if (t != r) s = fmax(s, fabs(t < r ? a[r + t * ld] : a[t + r * ld]));
+      const double sigma = wave_max_dpp(s);
+      if (sigma * akk >= alpha * lambda * lambda)
+        kind = 0;
+      else if (fabs(a[r + r * ld]) >= alpha * sigma)
+        kind = 1;
+      else
+        kind = 2;
+    }
+    STAMP(0)
+    // ---- symmetric interchange -------------------------------------------------
     const int p1 = (kind == 2) ? k + 1 : k;
-    if (kind != 0 && r != p1) {
+    if (kind != 0 && r != p1) {  // block-uniform
+      __syncthreads();
       for (int t = tid; t < p; t += blockDim.x) {
         double *x, *y;
         if (t < p1)
@@ -241,96 +299,177 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
       }
       __syncthreads();
     }
-    // ---- pivot inverse -----------------------------------------------------
-    if (tid == 0) {
-      if (kind != 2) {
-        double d = a[k + k * ld];
-        if (!(fabs(d) >= pert) || d == 0.0) {
-          d = (double)esign[e0 + lp[k]] * fmax(pert, 1e-300);
-          atomicAdd(&counters[1], 1);
-        }
-        sh.d0 = 1.0 / d;
-        a[k + k * ld] = d;
-        ptype[e0 + k] = 0, pt[k] = 0;
-        dinv[2 * (e0 + k)] = 1.0 / d;
-        dinv[2 * (e0 + k) + 1] = 0.0;
-      } else {
-        double d11 = a[k + k * ld], d21 = a[k + 1 + k * ld], d22 = a[k + 1 + (k + 1) * ld];
-        double det = d11 * d22 - d21 * d21;
-        if (!(fabs(det) >= pert * pert) || det == 0.0) {
-          // degenerate 2x2: make it a perturbed diagonal pair
-          d11 = (double)esign[e0 + lp[k]] * fmax(pert, 1e-300);
-          d22 = (double)esign[e0 + lp[k + 1]] * fmax(pert, 1e-300);
-          d21 = 0.0;
-          det = d11 * d22;
-          a[k + k * ld] = d11, a[k + 1 + k * ld] = 0.0, a[k + 1 + (k + 1) * ld] = d22;
-          atomicAdd(&counters[1], 2);
-        }
-        sh.d0 = d22 / det, sh.d1 = -d21 / det, sh.d2 = d11 / det;
-        ptype[e0 + k] = 1, ptype[e0 + k + 1] = 2, pt[k] = 1, pt[k + 1] = 2;
-        dinv[2 * (e0 + k)] = sh.d0, dinv[2 * (e0 + k) + 1] = sh.d1;
-        dinv[2 * (e0 + k + 1)] = sh.d2, dinv[2 * (e0 + k + 1) + 1] = sh.d1;
-        atomicAdd(&counters[0], 1);
+    STAMP(1)
+    // ---- pivot inverse (registers, identical in every thread) + trailing update --
+    if (kind != 2) {
+      double d = a[k + k * ld];
+      bool pertd = false;
+      if (!(fabs(d) >= pert)) {
+        d = (double)esign[e0 + lp[k]] * pert;
+        pertd = true;
       }
-    }
-    __syncthreads();
-    // ---- multipliers ---------------------------------------------------------
-    const int kw = (kind == 2) ? 2 : 1;
-    if (kw == 1) {
-      const double di = sh.d0;
-      for (int i = k + 1 + tid; i < p; i += blockDim.x) {
-        double c = a[i + k * ld];
-        w1[i] = c;
-        c *= di;
-        v1[i] = c;
-        a[i + k * ld] = c;
+      const double di = 1.0 / d;
+      if (tid == 0) {
+        dv[2 * k] = di, dv[2 * k + 1] = 0.0, pt[k] = 0;
+        if (pertd) atomicAdd(&counters[1], 1);
       }
+      const int s = k + 1;
+      STAMP(2)
+      // rank-1 update of the trailing lower triangle.  Thread (tx, ty) owns rows
+      // s+tx+32m and columns s+ty+8n; all LDS reads of a 4x4 patch are issued before
+      // its writes so that the read latencies overlap.
+      const int nm = (p - s + 31) >> 5;
+      double ck[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int i = s + tx + 32 * m;
+        ck[m] = (m < nm && i < p) ? a[i + k * ld] : 0.0;
+      }
+      for (int j0 = s + ty; j0 < p; j0 += 32) {
+        double lj[4], v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = j0 + 8 * u;
+          lj[u] = j < p ? a[j + k * ld] * di : 0.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const int j = j0 + 8 * u, i = s + tx + 32 * m;
+            if (m < nm && j < p && i < p && i >= j) v[u][m] = a[i + j * ld];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const int j = j0 + 8 * u, i = s + tx + 32 * m;
+            if (m < nm && j < p && i < p && i >= j) a[i + j * ld] = v[u][m] - ck[m] * lj[u];
+          }
+      }
+      k += 1;
     } else {
-      const double i11 = sh.d0, i21 = sh.d1, i22 = sh.d2;
-      for (int i = k + 2 + tid; i < p; i += blockDim.x) {
-        double c1 = a[i + k * ld], c2 = a[i + (k + 1) * ld];
-        w1[i] = c1, w2[i] = c2;
-        double l1 = c1 * i11 + c2 * i21, l2 = c1 * i21 + c2 * i22;
-        v1[i] = l1, v2[i] = l2;
-        a[i + k * ld] = l1, a[i + (k + 1) * ld] = l2;
+      double d11 = a[k + k * ld], d21 = a[k + 1 + k * ld], d22 = a[k + 1 + (k + 1) * ld];
+      double det = d11 * d22 - d21 * d21;
+      bool pertd = false;
+      if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
+        d11 = (double)esign[e0 + lp[k]] * pert;
+        d22 = (double)esign[e0 + lp[k + 1]] * pert;
+        d21 = 0.0;
+        det = d11 * d22;
+        pertd = true;
       }
-    }
-    __syncthreads();
-    // ---- trailing update (lower triangle) ------------------------------------
-    {
-      const int s = k + kw, nt = p - s;
-      // thread owns column strips: element (i, j), i >= j
-      for (int idx = tid; idx < nt * nt; idx += blockDim.x) {
-        int i = s + idx % nt, j = s + idx / nt;
-        if (i < j) continue;
-        double u = v1[i] * w1[j];
-        if (kw == 2) u += v2[i] * w2[j];
-        a[i + j * ld] -= u;
+      const double i11 = d22 / det, i21 = -d21 / det, i22 = d11 / det;
+      if (tid == 0) {
+        dv[2 * k] = i11, dv[2 * k + 1] = i21, dv[2 * k + 2] = i22, dv[2 * k + 3] = i21;
+        pt[k] = 1, pt[k + 1] = 2;
+        atomicAdd(&counters[0], 1);
+        if (pertd) atomicAdd(&counters[1], 2);
       }
+      const int s = k + 2;
+      const int nm = (p - s + 31) >> 5;
+      double ck1[4], ck2[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++) {
+        const int i = s + tx + 32 * m;
+        ck1[m] = (m < nm && i < p) ? a[i + k * ld] : 0.0;
+        ck2[m] = (m < nm && i < p) ? a[i + (k + 1) * ld] : 0.0;
+      }
+      for (int j0 = s + ty; j0 < p; j0 += 32) {
+        double l1[4], l2[4], v[4][4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int j = j0 + 8 * u;
+          const double c1 = j < p ? a[j + k * ld] : 0.0, c2 = j < p ? a[j + (k + 1) * ld] : 0.0;
+          l1[u] = c1 * i11 + c2 * i21, l2[u] = c1 * i21 + c2 * i22;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const int j = j0 + 8 * u, i = s + tx + 32 * m;
+            if (m < nm && j < p && i < p && i >= j) v[u][m] = a[i + j * ld];
+          }
+#pragma unroll
+        for (int u = 0; u < 4; u++)
+#pragma unroll
+          for (int m = 0; m < 4; m++) {
+            const int j = j0 + 8 * u, i = s + tx + 32 * m;
+            if (m < nm && j < p && i < p && i >= j)
+              a[i + j * ld] = v[u][m] - (ck1[m] * l1[u] + ck2[m] * l2[u]);
+          }
+      }
+      k += 2;
     }
+    STAMP(3)
     __syncthreads();
-    k += kw;
+    STAMP(4)
   }
-  // ---- write back: L11 (strict lower, zero under 2x2 diagonals), diag = D ----
-  for (int idx = tid; idx < p * p; idx += blockDim.x) {
-    int i = idx % p, j = idx / p;
-    if (i < j) continue;
-    double v = a[i + j * ld];
-    if (i == j + 1 && pt[j] == 1) v = 0.0;
-    P[(long long)j * F + i] = v;
+  if ((dbg & 32) && tid == 0 && blockIdx.x == 0)
+    for (int q = 0; q < 6; q++) atomicAdd((unsigned long long *)(counters + 7) + q, tacc[q]);
+  // ---- scale the stored columns: L = C D^-1 ------------------------------------
+  for (int j = wave; j < p; j += 4) {
+    const int ty_ = pt[j];
+    if (ty_ == 2) continue;  // handled with its partner
+    if (ty_ == 0) {
+      const double di = dv[2 * j];
+      for (int i = j + 1 + lane; i < p; i += 64) a[i + j * ld] *= di;
+    } else {
+      const double i11 = dv[2 * j], i21 = dv[2 * j + 1], i22 = dv[2 * j + 2];
+      for (int i = j + 2 + lane; i < p; i += 64) {
+        const double c1 = a[i + j * ld], c2 = a[i + (j + 1) * ld];
+        a[i + j * ld] = c1 * i11 + c2 * i21;
+        a[i + (j + 1) * ld] = c1 * i21 + c2 * i22;
+      }
+      if (lane == 0) a[j + 1 + j * ld] = 0.0;
+    }
   }
-  for (int i = tid; i < p; i += blockDim.x) lperm[e0 + i] = lp[i];
+  __syncthreads();
+  for (int j = wave; j < p; j += 4)
+    for (int i = j + lane; i < p; i += 64) P[(long long)j * F + i] = a[i + j * ld];
+  for (int i = tid; i < p; i += blockDim.x) {
+    lperm[e0 + i] = lp[i];
+    ptype[e0 + i] = pt[i];
+    dinv[2 * (e0 + i)] = dv[2 * i];
+    dinv[2 * (e0 + i) + 1] = dv[2 * i + 1];
+  }
+  // ---- inverses of the 16x16 diagonal blocks of L11 (unit lower) ---------------
+  double *DBo = dblk + dblk_off[node];
+  const int nb = (p + DB - 1) / DB;
+  for (int blk = wave; blk < nb; blk += 4) {
+    const int kb = blk * DB, kw = min(DB, p - kb);
+    if (lane < DB) {
+      const int c = lane;
+      double x[DB];
+#pragma unroll
+      for (int rr = 0; rr < DB; rr++) x[rr] = (rr == c) ? 1.0 : 0.0;
+#pragma unroll
+      for (int rr = 1; rr < DB; rr++) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < rr; t++) {
+          const double l = (rr < kw && t >= 0) ? a[kb + rr + (kb + t) * ld] : 0.0;
+          acc += l * x[t];
+        }
+        if (rr > c) x[rr] = -acc;
+      }
+#pragma unroll
+      for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];
+    }
+  }
 }
 
 // --------------------------------------------------- panel solve (border rows)
-// X = A21 P' L11^-T,  L21 = X D^-1.  One workgroup per (supernode, 32-row slab).
-// Column blocks of 16: in-block forward substitution, then a rank-16 update of
-// the remaining columns.
+// X = A21 P' L11^-T,  L21 = X D^-1.  One workgroup per (supernode, 32-row slab),
+// the slab in LDS.  Right-looking over column blocks of 16: the block itself is
+// multiplied by the transposed inverse of its diagonal block, then the columns
+// to its right receive a rank-16 update.
 #define PS_COLS 16
 __global__ void __launch_bounds__(256)
 k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ panel,
               double *__restrict__ xar, const double *__restrict__ dinv,
-              const int *__restrict__ ptype, const int *__restrict__ lperm) {
+              const int *__restrict__ ptype, const int *__restrict__ lperm,
+              const double *__restrict__ dblk, const long long *__restrict__ dblk_off) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = slabs[2 * blockIdx.x], slab = slabs[2 * blockIdx.x + 1];
   const int p = T.npiv[node], b = T.nbor[node];
@@ -338,32 +477,79 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
   const int e0 = T.piv_start[node];
   double *P = panel + T.panel_off[node];
   double *X = xar + T.x_off[node];
+  const double *DBo = dblk + dblk_off[node];
   const int r0 = slab * 32;
   const int tid = threadIdx.x, r = tid & 31, g = tid >> 5;
   const bool live = (r0 + r) < b;
   double *s = lds;                  // 32 x p, s[r + 32*k]
   double *Lb = s + 32 * p;          // p x PS_COLS block of L11: Lb[j + p*kk]
-  // load the slab with the pivot-block column permutation
-  for (int kcol = g; kcol < p; kcol += 8)
-    s[r + 32 * kcol] = live ? P[(long long)lperm[e0 + kcol] * F + p + r0 + r] : 0.0;
+  double *iv = Lb + PS_COLS * p;    // 16 x 16 inverse diagonal block
+  {
+    int lc[16];  // p <= 128: 16 columns per thread, loads batched
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int kcol = g + 8 * u;
+      lc[u] = kcol < p ? lperm[e0 + kcol] : 0;
+    }
+    double v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int kcol = g + 8 * u;
+      v[u] = (live && kcol < p) ? P[(long long)lc[u] * F + p + r0 + r] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int kcol = g + 8 * u;
+      if (kcol < p) s[r + 32 * kcol] = v[u];
+    }
+  }
   for (int kb = 0; kb < p; kb += PS_COLS) {
     const int kw = min(PS_COLS, p - kb);
     __syncthreads();
-    for (int idx = tid; idx < (p - kb) * kw; idx += blockDim.x) {
-      int j = kb + idx % (p - kb), kk = idx / (p - kb);
-      Lb[j + p * kk] = P[(long long)(kb + kk) * F + j];
+    {
+      double v[2][4];
+      const double ivv = DBo[(kb / PS_COLS) * 256 + tid];
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int kk = g + 8 * u, j = kb + kw + r + 32 * m;
+          v[u][m] = (kk < kw && j < p) ? P[(long long)(kb + kk) * F + j] : 0.0;
+        }
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+#pragma unroll
+        for (int m = 0; m < 4; m++) {
+          const int kk = g + 8 * u, j = kb + kw + r + 32 * m;
+          if (kk < kw && j < p) Lb[j + p * kk] = v[u][m];
+        }
+      iv[tid] = ivv;
     }
     __syncthreads();
-    // in-block sequential part
-    for (int kk = 0; kk < kw; kk++) {
-      const double xk = s[r + 32 * (kb + kk)];
-      for (int j = kb + kk + 1 + g; j < kb + kw; j += 8) s[r + 32 * j] -= xk * Lb[j + p * kk];
-      __syncthreads();
+    // in-block: Xb <- Xb * inv(Lbb)'   (x_c = sum_{t<=c} s_t inv[c][t])
+    double xin[PS_COLS];
+#pragma unroll
+    for (int t = 0; t < PS_COLS; t++) xin[t] = t < kw ? s[r + 32 * (kb + t)] : 0.0;
+    __syncthreads();
+#pragma unroll
+    for (int cc = 0; cc < 2; cc++) {
+      const int c = g + 8 * cc;
+      if (c < kw) {
+        double acc = 0.0;
+#pragma unroll
+        for (int t = 0; t < PS_COLS; t++) acc += (t <= c) ? xin[t] * iv[c * 16 + t] : 0.0;
+        s[r + 32 * (kb + c)] = acc;
+      }
     }
+    __syncthreads();
     // rank-kw update of the columns to the right of the block
+    double xb[PS_COLS];
+#pragma unroll
+    for (int t = 0; t < PS_COLS; t++) xb[t] = t < kw ? s[r + 32 * (kb + t)] : 0.0;
     for (int j = kb + kw + g; j < p; j += 8) {
       double acc = 0.0;
-      for (int kk = 0; kk < kw; kk++) acc += s[r + 32 * (kb + kk)] * Lb[j + p * kk];
+#pragma unroll
+      for (int kk = 0; kk < PS_COLS; kk++) acc += xb[kk] * (kk < kw ? Lb[j + p * kk] : 0.0);
       s[r + 32 * j] -= acc;
     }
   }
@@ -446,66 +632,81 @@ __global__ void k_mfma_selftest(const double *A, const double *B, double *C) {
 }
 
 // ------------------------------------------------------------------ solves
-// Forward sweep of one level: t = [rhs(pivots); 0] + children contributions,
-// y = L11^-1 P t1, contribution = t2 - L21 y, xsol(pivots) = D^-1 y.
-#define SV_COLS 16
+// The sweeps over the assembly tree run level by level, two kernels per level:
+//   forward  A: per supernode   t = rhs(pivots) + children contributions,
+//                               y = L11^-1 P t1 (block substitution with the
+//                               inverted 16x16 diagonal blocks), xsol = D^-1 y
+//            B: per 64-row slab contribution -= L21 y
+//   backward B: per 16 columns  v = yd - L21' x(border)
+//            A: per supernode   x1 = P' L11^-T v
+// L11 is staged once in LDS by the A kernels; the L21 products are spread over
+// many workgroups because they carry the bytes (nnz(L) is streamed once per sweep).
 __global__ void __launch_bounds__(256)
-k_solve_fwd(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
-            const double *__restrict__ dinv, const int *__restrict__ ptype,
-            const int *__restrict__ lperm, const double *__restrict__ rhs,
-            double *__restrict__ xsol, double *__restrict__ cb) {
+k_solve_fwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
+              const double *__restrict__ dinv, const int *__restrict__ ptype,
+              const int *__restrict__ lperm, const double *__restrict__ dblk,
+              const long long *__restrict__ dblk_off, const double *__restrict__ rhs,
+              double *__restrict__ xsol, double *__restrict__ ytmp, double *__restrict__ cb) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
   const int e0 = T.piv_start[node];
   const double *P = panel + T.panel_off[node];
-  const int tid = threadIdx.x;
-  double *t = lds;            // F
-  double *y = t + (p + b);    // p
-  double *Lb = y + p;         // p x SV_COLS
-  for (int i = tid; i < p + b; i += blockDim.x) t[i] = i < p ? rhs[e0 + i] : 0.0;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ld = p | 1, nb = (p + DB - 1) / DB;
+  double *a = lds;              // ld * p
+  double *t1 = a + ld * p;      // p
+  double *y = t1 + p;           // p
+  double *iv = y + p;           // nb * 256
+  double *cbn = cb + T.cb_off[node];
+  stage_lower(P, F, p, ld, a, wave, lane);
+  {
+    const double *DBo = dblk + dblk_off[node];
+    double t[8];  // nb <= 8 (p <= 128): batch the loads
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = u < nb ? DBo[u * 256 + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (u < nb) iv[u * 256 + tid] = t[u];
+  }
+  for (int i = tid; i < p; i += blockDim.x) t1[i] = rhs[e0 + i];
+  for (int i = tid; i < b; i += blockDim.x) cbn[i] = 0.0;
   __syncthreads();
   for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
     const int c = T.child_idx[cc];
     const int bc = T.nbor[c];
     const int *rel = T.rel + T.bptr[c];
     const double *cbc = cb + T.cb_off[c];
-    for (int i = tid; i < bc; i += blockDim.x) t[rel[i]] += cbc[i];
-    __syncthreads();
-  }
-  for (int k = tid; k < p; k += blockDim.x) y[k] = t[lperm[e0 + k]];
-  for (int kb = 0; kb < p; kb += SV_COLS) {
-    const int kw = min(SV_COLS, p - kb);
-    __syncthreads();
-    for (int idx = tid; idx < (p - kb) * kw; idx += blockDim.x) {
-      int j = kb + idx % (p - kb), kk = idx / (p - kb);
-      Lb[j + p * kk] = P[(long long)(kb + kk) * F + j];
+    for (int i = tid; i < bc; i += blockDim.x) {
+      const int ri = rel[i];
+      if (ri < p)
+        t1[ri] += cbc[i];
+      else
+        cbn[ri - p] += cbc[i];
     }
     __syncthreads();
-    if (tid < 64) {  // sequential part inside the block (kw <= 16 rows)
-      for (int kk = 0; kk < kw; kk++) {
-        const double yk = y[kb + kk];
-        const int j = kb + kk + 1 + tid;
-        if (j < kb + kw) y[j] -= Lb[j + p * kk] * yk;
-        __builtin_amdgcn_wave_barrier();
-      }
+  }
+  for (int k = tid; k < p; k += blockDim.x) y[k] = t1[lperm[e0 + k]];
+  for (int blk = 0; blk < nb; blk++) {
+    const int kb = blk * DB, kw = min(DB, p - kb);
+    __syncthreads();
+    if (tid < DB) {  // one wave: all reads of the block happen before the writes
+      double acc = 0.0;
+#pragma unroll
+      for (int t = 0; t < DB; t++)
+        acc += (t <= tid && t < kw) ? iv[blk * 256 + tid * DB + t] * y[kb + t] : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (tid < kw) y[kb + tid] = acc;
     }
     __syncthreads();
     for (int j = kb + kw + tid; j < p; j += blockDim.x) {
       double acc = 0.0;
-      for (int kk = 0; kk < kw; kk++) acc += Lb[j + p * kk] * y[kb + kk];
+      for (int kk = 0; kk < kw; kk++) acc += a[j + (kb + kk) * ld] * y[kb + kk];
       y[j] -= acc;
     }
   }
   __syncthreads();
-  double *cbn = cb + T.cb_off[node];
-  for (int i = tid; i < b; i += blockDim.x) {
-    double acc = t[p + i];
-    const double *Li = P + p + i;
-    for (int k = 0; k < p; k++) acc -= Li[(long long)k * F] * y[k];
-    cbn[i] = acc;
-  }
   for (int k = tid; k < p; k += blockDim.x) {
     const int e = e0 + k, ty = ptype[e];
     double v;
@@ -516,59 +717,105 @@ k_solve_fwd(DevTree T, const int *__restrict__ level_nodes, const double *__rest
     else
       v = y[k - 1] * dinv[2 * e + 1] + y[k] * dinv[2 * e];
     xsol[e] = v;
+    ytmp[e] = y[k];
   }
 }
 
-// Backward sweep of one level: x1 = P' L11^-T (yd - L21' x2)
+// contribution(slab) -= L21(slab,:) y ; 64 rows per workgroup, the four waves
+// split the columns and their partial sums meet in LDS
 __global__ void __launch_bounds__(256)
-k_solve_bwd(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
-            const int *__restrict__ lperm, double *__restrict__ xsol) {
+k_solve_fwd_b(DevTree T, const int *__restrict__ gslabs, const double *__restrict__ panel,
+              const double *__restrict__ ytmp, double *__restrict__ cb) {
+  __shared__ double part[4][64];
+  __shared__ double ysh[128];
+  const int node = gslabs[2 * blockIdx.x], slab = gslabs[2 * blockIdx.x + 1];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const long long F = p + b;
+  const int e0 = T.piv_start[node];
+  const double *L = panel + T.panel_off[node] + p;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = slab * 64 + lane;
+  for (int k = tid; k < p; k += blockDim.x) ysh[k] = ytmp[e0 + k];
+  __syncthreads();
+  double acc = 0.0;
+  if (i < b)
+    for (int k = wave; k < p; k += 4) acc += L[(long long)k * F + i] * ysh[k];
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < b)
+    cb[T.cb_off[node] + i] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
+// v(16 columns) = yd - L21(:, cols)' x(border)
+__global__ void __launch_bounds__(256)
+k_solve_bwd_b(DevTree T, const int *__restrict__ cblks, const double *__restrict__ panel,
+              const double *__restrict__ xsol, double *__restrict__ vtmp) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int node = level_nodes[blockIdx.x];
+  const int node = cblks[2 * blockIdx.x], cblk = cblks[2 * blockIdx.x + 1];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
   const int e0 = T.piv_start[node];
   const double *P = panel + T.panel_off[node];
   const int *bi = T.bidx + T.bptr[node];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  double *x2 = lds;          // b
-  double *v = x2 + b;        // p
-  double *Lb = v + p;        // p x SV_COLS
+  double *x2 = lds;  // b
   for (int i = tid; i < b; i += blockDim.x) x2[i] = xsol[bi[i]];
-  for (int k = tid; k < p; k += blockDim.x) v[k] = xsol[e0 + k];
   __syncthreads();
-  // v -= L21' x2 : one wave per column, lanes stride the rows
-  for (int k = wave; k < p; k += 4) {
+  for (int kk = wave; kk < 16; kk += 4) {
+    const int k = cblk * 16 + kk;
+    if (k >= p) break;
     const double *Lk = P + (long long)k * F + p;
     double acc = 0.0;
     for (int i = lane; i < b; i += 64) acc += Lk[i] * x2[i];
     acc = wave_sum(acc);
-    if (lane == 0) v[k] -= acc;
+    if (lane == 0) vtmp[e0 + k] = xsol[e0 + k] - acc;
   }
-  // x = L11^-T v, column blocks from the right
-  const int nblk = (p + SV_COLS - 1) / SV_COLS;
-  for (int blk = nblk - 1; blk >= 0; blk--) {
-    const int kb = blk * SV_COLS, kw = min(SV_COLS, p - kb);
+}
+
+// x1 = P' L11^-T v
+__global__ void __launch_bounds__(256)
+k_solve_bwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
+              const int *__restrict__ lperm, const double *__restrict__ dblk,
+              const long long *__restrict__ dblk_off, const double *__restrict__ vtmp,
+              double *__restrict__ xsol) {
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  const int node = level_nodes[blockIdx.x];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const long long F = p + b;
+  const int e0 = T.piv_start[node];
+  const double *P = panel + T.panel_off[node];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int ld = p | 1, nb = (p + DB - 1) / DB;
+  double *a = lds;          // ld * p
+  double *v = a + ld * p;   // p
+  double *iv = v + p;       // nb * 256
+  stage_lower(P, F, p, ld, a, wave, lane);
+  {
+    const double *DBo = dblk + dblk_off[node];
+    double t[8];  // nb <= 8 (p <= 128): batch the loads
+#pragma unroll
+    for (int u = 0; u < 8; u++) t[u] = u < nb ? DBo[u * 256 + tid] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 8; u++)
+      if (u < nb) iv[u * 256 + tid] = t[u];
+  }
+  for (int k = tid; k < p; k += blockDim.x) v[k] = vtmp[e0 + k];
+  for (int blk = nb - 1; blk >= 0; blk--) {
+    const int kb = blk * DB, kw = min(DB, p - kb);
     __syncthreads();
-    for (int idx = tid; idx < (p - kb) * kw; idx += blockDim.x) {
-      int j = kb + idx % (p - kb), kk = idx / (p - kb);
-      Lb[j + p * kk] = P[(long long)(kb + kk) * F + j];
-    }
-    __syncthreads();
-    // contributions of the already solved rows j >= kb+kw
-    for (int kk = wave; kk < kw; kk += 4) {
+    if (tid < DB) {  // x_r = sum_{t>=r} inv[t][r] v_t
       double acc = 0.0;
-      for (int j = kb + kw + lane; j < p; j += 64) acc += Lb[j + p * kk] * v[j];
-      acc = wave_sum(acc);
-      if (lane == 0) v[kb + kk] -= acc;
+#pragma unroll
+      for (int t = 0; t < DB; t++)
+        acc += (t >= tid && t < kw) ? iv[blk * 256 + t * DB + tid] * v[kb + t] : 0.0;
+      __builtin_amdgcn_wave_barrier();
+      if (tid < kw) v[kb + tid] = acc;
     }
     __syncthreads();
-    if (tid == 0) {
-      for (int kk = kw - 1; kk >= 0; kk--) {
-        double acc = v[kb + kk];
-        for (int j = kb + kk + 1; j < kb + kw; j++) acc -= Lb[j + p * kk] * v[j];
-        v[kb + kk] = acc;
-      }
+    for (int j = tid; j < kb; j += blockDim.x) {
+      double acc = 0.0;
+      for (int kk = 0; kk < kw; kk++) acc += a[kb + kk + j * ld] * v[kb + kk];
+      v[j] -= acc;
     }
   }
   __syncthreads();

@@ -58,7 +58,7 @@ class Hqp_IpMatrix:
     _name = None
 
     def __init__(self, device=0, device_vectors=False, mat_tol=1.0, mat_eps=1e-10,
-                 pivot_eps=None, leaf_size=0, max_pivots=0):
+                 pivot_eps=None, leaf_size=0, max_pivots=0, _dbg=0):
         L = _lib.lib()
         o = _lib.Opts()
         L.hqpkkt_default_opts(C.byref(o))
@@ -69,6 +69,7 @@ class Hqp_IpMatrix:
         if pivot_eps is not None:
             o.pivot_eps = pivot_eps
         o.leaf_size, o.max_pivots = leaf_size, max_pivots
+        o.reserved[0] = _dbg
         self._L = L
         self._h = C.c_void_p()
         self._device_vectors = bool(device_vectors)
@@ -193,6 +194,16 @@ class Hqp_IpMatrix:
         p = np.zeros(self.stats()["dim"], dtype=np.int32)
         _check(self._L.hqpkkt_get_perm(self._h, C.c_void_p(p.ctypes.data)), "get_perm")
         return p
+
+    def set_profile(self, on=True):
+        _check(self._L.hqpkkt_set_profile(self._h, 1 if on else 0), "set_profile")
+
+    def profile(self):
+        """{kernel class: (summed device ms, launches)} since set_profile()."""
+        ms = (C.c_double * 16)()
+        ln = (C.c_longlong * 16)()
+        k = self._L.hqpkkt_get_profile(self._h, 16, ms, ln)
+        return {self._L.hqpkkt_profile_class_name(c).decode(): (ms[c], ln[c]) for c in range(k)}
 
     def set_stream(self, hip_stream):
         _check(self._L.hqpkkt_set_stream(self._h, C.c_void_p(hip_stream)), "set_stream")

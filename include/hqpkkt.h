@@ -157,6 +157,16 @@ int hqpkkt_set_eps(hqpkkt_t *h, double eps);
 int hqpkkt_set_stream(hqpkkt_t *h, void *hip_stream);
 
 int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out);
+
+/* Per-kernel-class device timing for bench.py's roofline line: with on != 0
+ * every kernel launch is bracketed by HIP events on the handle's stream and the
+ * elapsed times are summed per class (hqpkkt_profile_class_name(c), c = 0..) at
+ * the end of each call.  set_profile also zeroes the sums.  get_profile fills
+ * up to n_classes entries and returns the number of classes that exist (as a
+ * positive value, not a status). */
+int hqpkkt_set_profile(hqpkkt_t *h, int on);
+int hqpkkt_get_profile(const hqpkkt_t *h, int n_classes, double *ms, long long *launches);
+const char *hqpkkt_profile_class_name(int c);
 const char *hqpkkt_strerror(int status);
 
 /* ---- introspection of the symbolic structure (host arrays; used by the
