@@ -635,6 +635,34 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
     ent_dst[e] = panel_off[o] + (long long)lc * F + lr;
   }
+  // store the entries in destination order: the numeric scatter then writes
+  // (mostly) consecutive addresses from consecutive threads
+  {
+    std::vector<int> perm(nent);
+    std::iota(perm.begin(), perm.end(), 0);
+    std::sort(perm.begin(), perm.end(), [&](int x, int y) { return ent_dst[x] < ent_dst[y]; });
+    auto apply_i = [&](std::vector<int> &v) {
+      std::vector<int> t(nent);
+      for (int k = 0; k < nent; k++) t[k] = v[perm[k]];
+      v.swap(t);
+    };
+    std::vector<int> new_ptr(1, 0);
+    std::vector<Term> new_terms;
+    new_terms.reserve(terms.size());
+    for (int k = 0; k < nent; k++) {
+      for (int t = term_ptr[perm[k]]; t < term_ptr[perm[k] + 1]; t++) new_terms.push_back(terms[t]);
+      new_ptr.push_back((int)new_terms.size());
+    }
+    term_ptr.swap(new_ptr), terms.swap(new_terms);
+    std::vector<long long> nd(nent);
+    for (int k = 0; k < nent; k++) nd[k] = ent_dst[perm[k]];
+    ent_dst.swap(nd);
+    apply_i(ent_a), apply_i(ent_b), apply_i(ent_er), apply_i(ent_ec);
+    std::vector<int> inv(nent);
+    for (int k = 0; k < nent; k++) inv[perm[k]] = k;
+    for (int i = 0; i < n; i++)
+      if (diag_ent[i] >= 0) diag_ent[i] = inv[diag_ent[i]];
+  }
   return 0;
 }
 

@@ -271,7 +271,7 @@ static int upload(hqpkkt_t *h) {
   }
   // dynamic LDS budgets
   const size_t mp = an.max_npiv, ldm = mp | 1, nbm = (mp + 15) / 16;
-  h->lds_diag = (ldm * mp + 2 * mp) * sizeof(double) + 2 * mp * sizeof(int) + 16;
+  h->lds_diag = (ldm * mp + 5 * 128 + 2 * mp) * sizeof(double) + 2 * mp * sizeof(int) + 16;
   h->lds_panel = (32 * mp + PS_COLS * mp + 256) * sizeof(double);
   h->lds_solve = (ldm * mp + 2 * mp + nbm * 256) * sizeof(double);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
@@ -359,7 +359,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
                                             h->ent_val.p));
   if (an.mode == 1 && an.n > 0)
     KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
-  KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<nblk(nent), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
+  KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
                                        h->sc.p, h->panel.p, h->bits.p));
   HIPCHK(hipEventRecord(h->ev1, s));
   const double alpha = h->opts.tol * 0.6403882032022076;  // tol (1+sqrt 17)/8, hqp/spBKP.C:392
@@ -372,10 +372,10 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
                                                      h->panel.p, h->upd.p));
     }
     const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
-    KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn, 256, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
+    KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn, FD_THREADS, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
                                                h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
                                                h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                               h->flags.p + 1, h->opts.reserved[0]));
+                                               h->flags.p + 1));
     const int ns = an.slab_ptr[l + 1] - an.slab_ptr[l];
     if (ns > 0)
       KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, h->slabs.p + 2 * (size_t)an.slab_ptr[l],
@@ -480,7 +480,7 @@ int hqpkkt_default_opts(hqpkkt_opts *o) {
   o->loc = HQPKKT_LOC_HOST;
   o->tol = 1.0;    // hqp/Hqp_IpSpBKP.C:46
   o->eps = 1e-10;  // hqp/Hqp_IpMatrix.C:45
-  o->pivot_eps = 1e-10;
+  o->pivot_eps = 1e-20;  // only (near-)exact zeros are replaced: the reference accepts any non-zero pivot
   o->leaf_size = 0;
   o->max_pivots = 0;
   return 0;
@@ -589,13 +589,6 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   h->st.ms_assemble = elapsed(h->ev0, h->ev1);
   h->st.ms_factor = elapsed(h->ev1, h->evs1);
   h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2];
-  if (h->opts.reserved[0] & 32) {  // diagnostic cycle stamps of k_factor_diag (block 0 of every level)
-    unsigned long long t[6];
-    HIPCHK(hipMemcpy(t, h->flags.p + 8, sizeof(t), hipMemcpyDeviceToHost));
-    std::fprintf(stderr, "factor_diag stamps (cycles, block 0 summed over levels): decision %llu swap %llu inverse %llu update %llu barrier %llu looptop %llu\n",
-                 t[0], t[1], t[2], t[3], t[4], t[5]);
-  }
-  std::memcpy(&h->st.kmax, &kb, sizeof(double));
   if (flags[0]) return flags[0];
   if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
   h->factored = true;

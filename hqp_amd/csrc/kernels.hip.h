@@ -60,6 +60,31 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// same for a float (the arg-max search of the pivot column runs in fp32: an fp64
+// max costs ~40 cycles of latency per step on gfx950, an fp32 one a few)
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move_f(float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(v), __float_as_int(v), CTRL,
+                                                    ROW_MASK, 0xf, false));
+}
+__device__ __forceinline__ float wave_max_dpp_f(float v) {
+  v = fmaxf(v, dpp_move_f<0xb1, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x4e, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x124, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x128, 0xf>(v));
+  v = fmaxf(v, dpp_move_f<0x142, 0xa>(v));
+  v = fmaxf(v, dpp_move_f<0x143, 0xc>(v));
+  return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), 63));
+}
+// 1/d by the hardware estimate and two Newton steps (error ~1 ulp; the pivot is
+// bounded away from zero and from overflow by the perturbation test)
+__device__ __forceinline__ double fast_rcp(double d) {
+  double x = __builtin_amdgcn_rcp(d);
+  x = fma(fma(-d, x, 1.0), x, x);
+  x = fma(fma(-d, x, 1.0), x, x);
+  return x;
+}
+
 // lower triangle (incl. diagonal) of a p x p column-major block -> LDS image with
 // leading dimension ld; global loads are issued in batches of 16 per thread so
 // that their latencies overlap (p <= 128)
@@ -148,19 +173,29 @@ __global__ void k_red_scale(int n, const int *__restrict__ diag_ent,
   sc[i] = e >= 0 ? fmin(1.0, sqrt(-1.0 / ent_val[e])) : 1.0;
 }
 
-// J <- S J S scattered into the supernode panels (hqp/Hqp_IpSpBKP.C:162-176)
-__global__ void k_scatter(int nent, const int *__restrict__ ent_a, const int *__restrict__ ent_b,
-                          const long long *__restrict__ ent_dst,
-                          const double *__restrict__ ent_val, const double *__restrict__ sc,
-                          double *__restrict__ panel, unsigned long long *__restrict__ kmax) {
-  int e = blockIdx.x * blockDim.x + threadIdx.x;
-  double v = 0.0;
-  if (e < nent) {
-    v = ent_val[e] * sc[ent_a[e]] * sc[ent_b[e]];
+// J <- S J S scattered into the supernode panels (hqp/Hqp_IpSpBKP.C:162-176);
+// entries are stored in destination order, so consecutive threads write (mostly)
+// consecutive addresses.  max|K_ij| for the pivot-perturbation threshold: one
+// atomic per workgroup (one per wave on a single word serialises at ~12 ns each).
+__global__ void __launch_bounds__(256)
+k_scatter(int nent, const int *__restrict__ ent_a, const int *__restrict__ ent_b,
+          const long long *__restrict__ ent_dst, const double *__restrict__ ent_val,
+          const double *__restrict__ sc, double *__restrict__ panel,
+          unsigned long long *__restrict__ kmax) {
+  __shared__ double red[4];
+  double mx = 0.0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nent; e += gridDim.x * blockDim.x) {
+    const double v = ent_val[e] * sc[ent_a[e]] * sc[ent_b[e]];
     panel[ent_dst[e]] = v;
+    mx = fmax(mx, fabs(v));
   }
-  double mx = wave_max(fabs(v));
-  if ((threadIdx.x & 63) == 0 && mx > 0.0) atomic_max_pos(kmax, mx);
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (mx > 0.0) atomic_max_pos(kmax, mx);
+  }
 }
 
 // ------------------------------------------------------------- extend-add
@@ -190,27 +225,96 @@ __global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
 }
 
 // ------------------------------------------------- pivot block: dense BK LDL'
-// One workgroup per supernode.  The p x p pivot block sits in LDS (lower
-// triangle, odd leading dimension so that row walks are conflict-free).
+// One workgroup of 512 threads per supernode.  The p x p pivot block (p <= 128)
+// lives in REGISTERS as a full symmetric matrix: thread (tx, ty) = (tid & 31,
+// tid >> 5) owns rows ty+16m (m < 8) and columns tx+32n (n < 4), 32 values.
+// Per pivot the 16 owners of the pivot column publish it to a small LDS vector,
+// every thread reads the 8 + 4 entries it needs and updates its patch with 32
+// independent FMAs (strips of rows / columns that are already eliminated are
+// skipped) - no LDS read-modify-write of the trailing matrix and a hot loop of
+// a few hundred instructions.  One barrier per pivot; extra ones only when a
+// second column is needed (2x2 test) or rows are interchanged (rows / columns
+// are exchanged between threads through LDS).
+//
 // Bunch-Kaufman partial pivoting with the reference's threshold
 // alpha = tol (1+sqrt 17)/8 and test order (hqp/spBKP.C:392, 431-438, 471, 480),
-// restricted to the pivot block.  Every wave takes the pivot decision
-// redundantly from the same LDS data (wave shuffles for the max / arg-max
-// reductions), so a pivot step costs one barrier, three when rows are swapped.
-// Eliminated columns stay unscaled (c = l*d) until the write-back.  A pivot
-// smaller than pert = pivot_eps * max|K| is replaced by +-pert (x rows negative,
-// y / slack rows positive); the symbolic phase places zero-diagonal variables
-// so that this does not happen for structurally non-singular systems.
-// Also writes the inverses of the 16x16 diagonal blocks of L11 for the
-// triangular solves (block forward / backward substitution without a
-// sequential inner loop).
+// restricted to the pivot block; every wave takes the decision redundantly (DPP
+// max over the wave, ballot for the first arg-max).  A pivot smaller than
+// pert = pivot_eps * max|K| is replaced by +-pert (x rows negative, y / slack
+// rows positive); the symbolic phase orders zero-diagonal variables so that this
+// does not happen for structurally non-singular systems.  Eliminated columns
+// stay unscaled (c = l d) until the write-back, which also produces the inverses
+// of the 16x16 diagonal blocks of L11 used by the triangular solves.
 #define DB 16
-__global__ void __launch_bounds__(256)
+#define FD_THREADS 512
+typedef double PatchT[8][4];  // [row strip m][column strip n]
+
+// Dynamic strip selection is written as chains of selects on VALUES (uniform
+// conditions): an if-chain over the strip index gets merged by the optimiser
+// into a variably indexed access, which forces the whole patch into scratch.
+#define PATCH_PUT_COL_CASE(N)                       \
+  {                                                 \
+    _Pragma("unroll") for (int m = 0; m < 8; m++) { \
+      double v = A[m][N];                           \
+      asm volatile("" : "+v"(v));                   \
+      if (mine) buf[ty + 16 * m] = v;               \
+    }                                               \
+  }
+__device__ __forceinline__ void patch_put_col(const PatchT &A, int c, int tx, int ty, int p,
+                                              double *buf) {
+  const int cn = c >> 5;  // wave-uniform
+  const bool mine = tx == (c & 31);
+  // The empty asm pins each value in a VGPR: without it the optimiser merges the
+  // four branches into one variably indexed access and the patch lands in scratch.
+  if (cn == 0) PATCH_PUT_COL_CASE(0)
+  else if (cn == 1) PATCH_PUT_COL_CASE(1)
+  else if (cn == 2) PATCH_PUT_COL_CASE(2)
+  else PATCH_PUT_COL_CASE(3)
+}
+__device__ __forceinline__ void patch_get_col(PatchT &A, int c, int tx, int ty, int p,
+                                              const double *buf) {
+  const int cn = c >> 5;
+  const bool mine = tx == (c & 31);
+#pragma unroll
+  for (int m = 0; m < 8; m++) {
+    const double v = buf[ty + 16 * m];
+#pragma unroll
+    for (int n = 0; n < 4; n++) A[m][n] = (mine && n == cn) ? v : A[m][n];
+  }
+}
+__device__ __forceinline__ void patch_put_row(const PatchT &A, int r, int tx, int ty, int p,
+                                              double *buf) {
+  const int rm = r >> 4;
+  const bool mine = ty == (r & 15);
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    double v = A[0][n];
+#pragma unroll
+    for (int m = 1; m < 8; m++) {
+      const double am = A[m][n];
+      v = rm == m ? am : v;
+    }
+    if (mine) buf[tx + 32 * n] = v;
+  }
+}
+__device__ __forceinline__ void patch_get_row(PatchT &A, int r, int tx, int ty, int p,
+                                              const double *buf) {
+  const int rm = r >> 4;
+  const bool mine = ty == (r & 15);
+#pragma unroll
+  for (int n = 0; n < 4; n++) {
+    const double v = buf[tx + 32 * n];
+#pragma unroll
+    for (int m = 0; m < 8; m++) A[m][n] = (mine && m == rm) ? v : A[m][n];
+  }
+}
+
+__global__ void __launch_bounds__(FD_THREADS)
 k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
               double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
               const signed char *__restrict__ esign, double *__restrict__ dblk,
               const long long *__restrict__ dblk_off, double alpha, double pivot_eps,
-              const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters, int dbg) {
+              const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
@@ -218,138 +322,140 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   const int e0 = T.piv_start[node];
   double *P = panel + T.panel_off[node];
   const int ld = p | 1;
-  double *a = lds;            // ld * p
-  double *dv = a + ld * p;    // 2p: inverse pivot data per position
-  int *lp = (int *)(dv + 2 * p);  // p   local pivot order
-  int *pt = lp + p;               // p   pivot type per position
+  double *a = lds;                  // ld * p: staging at load and write-back
+  // 128-entry vectors (the patch is zero padded beyond p, so they are written and
+  // read without bounds predicates)
+  double *cbuf0 = a + ld * p;       // pivot column, even steps
+  double *cbuf1 = cbuf0 + 128;      // pivot column, odd steps
+  double *cbr = cbuf1 + 128;        // column r (second column of a 2x2)
+  double *xb0 = cbr + 128, *xb1 = xb0 + 128;  // row / column exchange
+  double *dv = xb1 + 128;           // 2p: inverse pivot data per position
+  int *lp = (int *)(dv + 2 * p);    // p   local pivot order
+  int *pt = lp + p;                 // p   pivot type per position
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tid & 31, ty = tid >> 5;
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
 
-  stage_lower(P, F, p, ld, a, wave, lane);
+  if (wave < 4) stage_lower(P, F, p, ld, a, wave, lane);
   for (int i = tid; i < p; i += blockDim.x) lp[i] = i;
   __syncthreads();
+  PatchT A;
+#pragma unroll
+  for (int m = 0; m < 8; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int i = ty + 16 * m, j = tx + 32 * n;
+      A[m][n] = (i < p && j < p) ? (i >= j ? a[i + j * ld] : a[j + i * ld]) : 0.0;
+    }
+  patch_put_col(A, 0, tx, ty, p, cbuf0);
+  __syncthreads();
 
-#define STAMP(slot)                                                              \
-  if (dbg & 32) {                                                                \
-    unsigned long long t_;                                                       \
-    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_)::"memory");  \
-    if (tid == 0 && blockIdx.x == 0) tacc[slot] += t_ - tlast;                   \
-    tlast = t_;                                                                  \
-  }
-  unsigned long long tlast = 0, tacc[6] = {0, 0, 0, 0, 0, 0};
-  if (dbg & 32) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(tlast)::"memory");
-  int k = 0;
+  int k = 0, step = 0;
   while (k < p) {
-    STAMP(5)
+    k = __builtin_amdgcn_readfirstlane(k);  // wave-uniform: keep it scalar
+    double *cur = (step & 1) ? cbuf1 : cbuf0, *nxt = (step & 1) ? cbuf0 : cbuf1;
     // ---- decision, redundantly per wave --------------------------------------
-    // column max lambda and its first row index r (hqp/spBKP.C:431-437): two
-    // candidates per lane, DPP max over the wave, ballot for the arg-max
+    // column max and its first row index r (hqp/spBKP.C:431-437): two candidates
+    // per lane, the arg-max search in fp32 (DPP max + ballot), lambda re-read in fp64
     const int i1 = k + 1 + lane, i2 = i1 + 64;
-    const double t1 = i1 < p ? fabs(a[i1 + k * ld]) : -1.0;
-    const double t2 = i2 < p ? fabs(a[i2 + k * ld]) : -1.0;
-    const double lambda = wave_max_dpp(fmax(fmax(t1, t2), 0.0));
+    const double v1 = cur[i1 & 127], v2 = cur[i2 & 127], vkk = cur[k];
+    const float t1 = i1 < p ? fabsf((float)v1) : -1.0f;
+    const float t2 = i2 < p ? fabsf((float)v2) : -1.0f;
+    const float tmax = wave_max_dpp_f(fmaxf(fmaxf(t1, t2), 0.0f));
     int r = p;
     {
-      const unsigned long long m1 = __ballot(t1 == lambda), m2 = __ballot(t2 == lambda);
+      const unsigned long long m1 = __ballot(t1 == tmax), m2 = __ballot(t2 == tmax);
       if (m1)
         r = k + 1 + __builtin_ctzll(m1);
       else if (m2)
         r = k + 65 + __builtin_ctzll(m2);
     }
-    const double akk = fabs(a[k + k * ld]);
+    r = __builtin_amdgcn_readfirstlane(r);
+    const double akk = fabs(vkk);
+    const double lambda = r < p ? fabs(cur[r]) : 0.0;
     int kind = 0;
-    if (r < p && !(akk >= alpha * lambda)) {
+    bool have_r = false;
+    if (r < p && !(akk >= alpha * lambda)) {  // block-uniform
+      patch_put_col(A, r, tx, ty, p, cbr);
+      __syncthreads();
+      have_r = true;
       double s = 0.0;
       for (int t = k + lane; t < p; t += 64)
-        if (t != r) s = fmax(s, fabs(t < r ? a[r + t * ld] : a[t + r * ld]));
+        if (t != r) s = fmax(s, fabs(cbr[t]));
       const double sigma = wave_max_dpp(s);
       if (sigma * akk >= alpha * lambda * lambda)
         kind = 0;
-      else if (fabs(a[r + r * ld]) >= alpha * sigma)
+      else if (fabs(cbr[r]) >= alpha * sigma)
         kind = 1;
       else
         kind = 2;
     }
-    STAMP(0)
-    // ---- symmetric interchange -------------------------------------------------
+    kind = __builtin_amdgcn_readfirstlane(kind);
+    // ---- symmetric interchange p1 <-> r of the register matrix ------------------
     const int p1 = (kind == 2) ? k + 1 : k;
-    if (kind != 0 && r != p1) {  // block-uniform
+    if (kind != 0 && r != p1) {
+      patch_put_row(A, p1, tx, ty, p, xb0);
+      patch_put_row(A, r, tx, ty, p, xb1);
       __syncthreads();
-      for (int t = tid; t < p; t += blockDim.x) {
-        double *x, *y;
-        if (t < p1)
-          x = &a[p1 + t * ld], y = &a[r + t * ld];
-        else if (t == p1)
-          x = &a[p1 + p1 * ld], y = &a[r + r * ld];
-        else if (t < r)
-          x = &a[t + p1 * ld], y = &a[r + t * ld];
-        else if (t == r)
-          continue;
-        else
-          x = &a[t + p1 * ld], y = &a[t + r * ld];
-        double tmp = *x;
-        *x = *y;
-        *y = tmp;
-      }
+      patch_get_row(A, p1, tx, ty, p, xb1);
+      patch_get_row(A, r, tx, ty, p, xb0);
+      __syncthreads();
+      patch_put_col(A, p1, tx, ty, p, xb0);
+      patch_put_col(A, r, tx, ty, p, xb1);
+      __syncthreads();
+      patch_get_col(A, p1, tx, ty, p, xb1);
+      patch_get_col(A, r, tx, ty, p, xb0);
       if (tid == 0) {
-        int t = lp[p1];
+        const int t = lp[p1];
         lp[p1] = lp[r];
         lp[r] = t;
       }
       __syncthreads();
+      // refresh the published pivot column(s)
+      patch_put_col(A, k, tx, ty, p, cur);
+      if (kind == 2) patch_put_col(A, k + 1, tx, ty, p, cbr);
+      __syncthreads();
+    } else if (kind == 2 && !have_r) {
+      patch_put_col(A, k + 1, tx, ty, p, cbr);
+      __syncthreads();
     }
-    STAMP(1)
-    // ---- pivot inverse (registers, identical in every thread) + trailing update --
+    // ---- pivot inverse (identical in every thread) + update of the patch --------
+    // row strip m holds rows ty+16m (all <= 16m+15), column strip n columns tx+32n
     if (kind != 2) {
-      double d = a[k + k * ld];
+      // all LDS reads first (12 independent ds_reads), then straight-line math
+      double cv[8], cj[4];
+#pragma unroll
+      for (int m = 0; m < 8; m++) cv[m] = cur[ty + 16 * m];
+#pragma unroll
+      for (int n = 0; n < 4; n++) cj[n] = cur[tx + 32 * n];
+      double d = cur[k];
       bool pertd = false;
       if (!(fabs(d) >= pert)) {
         d = (double)esign[e0 + lp[k]] * pert;
         pertd = true;
       }
-      const double di = 1.0 / d;
+      const double di = fast_rcp(d);
       if (tid == 0) {
         dv[2 * k] = di, dv[2 * k + 1] = 0.0, pt[k] = 0;
         if (pertd) atomicAdd(&counters[1], 1);
       }
-      const int s = k + 1;
-      STAMP(2)
-      // rank-1 update of the trailing lower triangle.  Thread (tx, ty) owns rows
-      // s+tx+32m and columns s+ty+8n; all LDS reads of a 4x4 patch are issued before
-      // its writes so that the read latencies overlap.
-      const int nm = (p - s + 31) >> 5;
-      double ck[4];
+      double lj[4];
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const int i = s + tx + 32 * m;
-        ck[m] = (m < nm && i < p) ? a[i + k * ld] : 0.0;
-      }
-      for (int j0 = s + ty; j0 < p; j0 += 32) {
-        double lj[4], v[4][4];
+      for (int n = 0; n < 4; n++) lj[n] = (tx + 32 * n > k) ? cj[n] * di : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int j = j0 + 8 * u;
-          lj[u] = j < p ? a[j + k * ld] * di : 0.0;
-        }
+      for (int m = 0; m < 8; m++) {
+        const double ck = (ty + 16 * m > k) ? cv[m] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const int j = j0 + 8 * u, i = s + tx + 32 * m;
-            if (m < nm && j < p && i < p && i >= j) v[u][m] = a[i + j * ld];
-          }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const int j = j0 + 8 * u, i = s + tx + 32 * m;
-            if (m < nm && j < p && i < p && i >= j) a[i + j * ld] = v[u][m] - ck[m] * lj[u];
-          }
+        for (int n = 0; n < 4; n++) A[m][n] = fma(-ck, lj[n], A[m][n]);
       }
       k += 1;
     } else {
-      double d11 = a[k + k * ld], d21 = a[k + 1 + k * ld], d22 = a[k + 1 + (k + 1) * ld];
+      double cv1[8], cv2[8], cj1[4], cj2[4];
+#pragma unroll
+      for (int m = 0; m < 8; m++) cv1[m] = cur[ty + 16 * m], cv2[m] = cbr[ty + 16 * m];
+#pragma unroll
+      for (int n = 0; n < 4; n++) cj1[n] = cur[tx + 32 * n], cj2[n] = cbr[tx + 32 * n];
+      double d11 = cur[k], d21 = cur[k + 1], d22 = cbr[k + 1];
       double det = d11 * d22 - d21 * d21;
       bool pertd = false;
       if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
@@ -359,56 +465,45 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
         det = d11 * d22;
         pertd = true;
       }
-      const double i11 = d22 / det, i21 = -d21 / det, i22 = d11 / det;
+      const double rdet = fast_rcp(det);
+      const double i11 = d22 * rdet, i21 = -d21 * rdet, i22 = d11 * rdet;
       if (tid == 0) {
         dv[2 * k] = i11, dv[2 * k + 1] = i21, dv[2 * k + 2] = i22, dv[2 * k + 3] = i21;
         pt[k] = 1, pt[k + 1] = 2;
         atomicAdd(&counters[0], 1);
         if (pertd) atomicAdd(&counters[1], 2);
       }
-      const int s = k + 2;
-      const int nm = (p - s + 31) >> 5;
-      double ck1[4], ck2[4];
+      double l1[4], l2[4];
 #pragma unroll
-      for (int m = 0; m < 4; m++) {
-        const int i = s + tx + 32 * m;
-        ck1[m] = (m < nm && i < p) ? a[i + k * ld] : 0.0;
-        ck2[m] = (m < nm && i < p) ? a[i + (k + 1) * ld] : 0.0;
+      for (int n = 0; n < 4; n++) {
+        const bool on = tx + 32 * n > k + 1;
+        const double u1 = on ? cj1[n] : 0.0, u2 = on ? cj2[n] : 0.0;
+        l1[n] = u1 * i11 + u2 * i21;
+        l2[n] = u1 * i21 + u2 * i22;
       }
-      for (int j0 = s + ty; j0 < p; j0 += 32) {
-        double l1[4], l2[4], v[4][4];
 #pragma unroll
-        for (int u = 0; u < 4; u++) {
-          const int j = j0 + 8 * u;
-          const double c1 = j < p ? a[j + k * ld] : 0.0, c2 = j < p ? a[j + (k + 1) * ld] : 0.0;
-          l1[u] = c1 * i11 + c2 * i21, l2[u] = c1 * i21 + c2 * i22;
-        }
+      for (int m = 0; m < 8; m++) {
+        const bool on = ty + 16 * m > k + 1;
+        const double c1 = on ? cv1[m] : 0.0, c2 = on ? cv2[m] : 0.0;
 #pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const int j = j0 + 8 * u, i = s + tx + 32 * m;
-            if (m < nm && j < p && i < p && i >= j) v[u][m] = a[i + j * ld];
-          }
-#pragma unroll
-        for (int u = 0; u < 4; u++)
-#pragma unroll
-          for (int m = 0; m < 4; m++) {
-            const int j = j0 + 8 * u, i = s + tx + 32 * m;
-            if (m < nm && j < p && i < p && i >= j)
-              a[i + j * ld] = v[u][m] - (ck1[m] * l1[u] + ck2[m] * l2[u]);
-          }
+        for (int n = 0; n < 4; n++) A[m][n] = fma(-c2, l2[n], fma(-c1, l1[n], A[m][n]));
       }
       k += 2;
     }
-    STAMP(3)
+    if (k < p) patch_put_col(A, k, tx, ty, p, nxt);
+    step++;
     __syncthreads();
-    STAMP(4)
   }
-  if ((dbg & 32) && tid == 0 && blockIdx.x == 0)
-    for (int q = 0; q < 6; q++) atomicAdd((unsigned long long *)(counters + 7) + q, tacc[q]);
-  // ---- scale the stored columns: L = C D^-1 ------------------------------------
-  for (int j = wave; j < p; j += 4) {
+  // ---- registers -> LDS (lower triangle), then scale the columns: L = C D^-1 ------
+#pragma unroll
+  for (int m = 0; m < 8; m++)
+#pragma unroll
+    for (int n = 0; n < 4; n++) {
+      const int i = ty + 16 * m, j = tx + 32 * n;
+      if (i < p && j < p && i >= j) a[i + j * ld] = A[m][n];
+    }
+  __syncthreads();
+  for (int j = wave; j < p; j += FD_THREADS / 64) {
     const int ty_ = pt[j];
     if (ty_ == 2) continue;  // handled with its partner
     if (ty_ == 0) {
@@ -425,7 +520,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
     }
   }
   __syncthreads();
-  for (int j = wave; j < p; j += 4)
+  for (int j = wave; j < p; j += FD_THREADS / 64)
     for (int i = j + lane; i < p; i += 64) P[(long long)j * F + i] = a[i + j * ld];
   for (int i = tid; i < p; i += blockDim.x) {
     lperm[e0 + i] = lp[i];
@@ -434,24 +529,28 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
     dinv[2 * (e0 + i) + 1] = dv[2 * i + 1];
   }
   // ---- inverses of the 16x16 diagonal blocks of L11 (unit lower) ---------------
+  // one 16-lane group per block: lane c solves L x = e_c by forward substitution
   double *DBo = dblk + dblk_off[node];
   const int nb = (p + DB - 1) / DB;
-  for (int blk = wave; blk < nb; blk += 4) {
-    const int kb = blk * DB, kw = min(DB, p - kb);
-    if (lane < DB) {
-      const int c = lane;
+  {
+    const int blk = tid >> 4, c = tid & 15;
+    if (blk < nb) {
+      const int kb = blk * DB, kw = min(DB, p - kb);
       double x[DB];
 #pragma unroll
       for (int rr = 0; rr < DB; rr++) x[rr] = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int rr = 1; rr < DB; rr++) {
-        double acc = 0.0;
+        double acc0 = 0.0, acc1 = 0.0;
 #pragma unroll
         for (int t = 0; t < rr; t++) {
-          const double l = (rr < kw && t >= 0) ? a[kb + rr + (kb + t) * ld] : 0.0;
-          acc += l * x[t];
+          const double l = (rr < kw) ? a[kb + rr + (kb + t) * ld] : 0.0;
+          if (t & 1)
+            acc1 += l * x[t];
+          else
+            acc0 += l * x[t];
         }
-        if (rr > c) x[rr] = -acc;
+        if (rr > c) x[rr] = -(acc0 + acc1);
       }
 #pragma unroll
       for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];
@@ -692,18 +791,21 @@ k_solve_fwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__re
     const int kb = blk * DB, kw = min(DB, p - kb);
     __syncthreads();
     if (tid < DB) {  // one wave: all reads of the block happen before the writes
-      double acc = 0.0;
+      // fp64 FMA latency is ~32 cycles on gfx950: four independent partial sums
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int t = 0; t < DB; t++)
-        acc += (t <= tid && t < kw) ? iv[blk * 256 + tid * DB + t] * y[kb + t] : 0.0;
+        acc[t & 3] += (t <= tid && t < kw) ? iv[blk * 256 + tid * DB + t] * y[kb + t] : 0.0;
       __builtin_amdgcn_wave_barrier();
-      if (tid < kw) y[kb + tid] = acc;
+      if (tid < kw) y[kb + tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
     __syncthreads();
     for (int j = kb + kw + tid; j < p; j += blockDim.x) {
-      double acc = 0.0;
-      for (int kk = 0; kk < kw; kk++) acc += a[j + (kb + kk) * ld] * y[kb + kk];
-      y[j] -= acc;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < DB; kk++)
+        acc[kk & 3] += kk < kw ? a[j + (kb + kk) * ld] * y[kb + kk] : 0.0;
+      y[j] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
   }
   __syncthreads();
@@ -738,8 +840,23 @@ k_solve_fwd_b(DevTree T, const int *__restrict__ gslabs, const double *__restric
   for (int k = tid; k < p; k += blockDim.x) ysh[k] = ytmp[e0 + k];
   __syncthreads();
   double acc = 0.0;
-  if (i < b)
-    for (int k = wave; k < p; k += 4) acc += L[(long long)k * F + i] * ysh[k];
+  if (i < b) {
+    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k0 = wave; k0 < p; k0 += 32) {  // 8 columns of this wave per trip, loads in flight together
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 + 4 * u;
+        l[u] = k < p ? L[(long long)k * F + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 + 4 * u;
+        a8[u] += k < p ? l[u] * ysh[k] : 0.0;
+      }
+    }
+    acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
   part[wave][lane] = acc;
   __syncthreads();
   if (wave == 0 && i < b)
@@ -761,14 +878,36 @@ k_solve_bwd_b(DevTree T, const int *__restrict__ cblks, const double *__restrict
   double *x2 = lds;  // b
   for (int i = tid; i < b; i += blockDim.x) x2[i] = xsol[bi[i]];
   __syncthreads();
-  for (int kk = wave; kk < 16; kk += 4) {
-    const int k = cblk * 16 + kk;
-    if (k >= p) break;
-    const double *Lk = P + (long long)k * F + p;
-    double acc = 0.0;
-    for (int i = lane; i < b; i += 64) acc += Lk[i] * x2[i];
-    acc = wave_sum(acc);
-    if (lane == 0) vtmp[e0 + k] = xsol[e0 + k] - acc;
+  {
+    // this wave's four columns at once; per trip 4 x 4 independent loads / sums
+    double acc[4][4];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+      for (int u = 0; u < 4; u++) acc[c][u] = 0.0;
+    for (int i0 = lane; i0 < b; i0 += 256) {
+      double l[4][4], xv[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int i = i0 + 64 * u;
+        xv[u] = i < b ? x2[i] : 0.0;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+          const int k = cblk * 16 + wave + 4 * c;
+          l[c][u] = (i < b && k < p) ? P[(long long)k * F + p + i] : 0.0;
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++)
+#pragma unroll
+        for (int c = 0; c < 4; c++) acc[c][u] += l[c][u] * xv[u];
+    }
+#pragma unroll
+    for (int c = 0; c < 4; c++) {
+      const int k = cblk * 16 + wave + 4 * c;
+      const double t = wave_sum((acc[c][0] + acc[c][1]) + (acc[c][2] + acc[c][3]));
+      if (lane == 0 && k < p) vtmp[e0 + k] = xsol[e0 + k] - t;
+    }
   }
 }
 
@@ -804,18 +943,20 @@ k_solve_bwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__re
     const int kb = blk * DB, kw = min(DB, p - kb);
     __syncthreads();
     if (tid < DB) {  // x_r = sum_{t>=r} inv[t][r] v_t
-      double acc = 0.0;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int t = 0; t < DB; t++)
-        acc += (t >= tid && t < kw) ? iv[blk * 256 + t * DB + tid] * v[kb + t] : 0.0;
+        acc[t & 3] += (t >= tid && t < kw) ? iv[blk * 256 + t * DB + tid] * v[kb + t] : 0.0;
       __builtin_amdgcn_wave_barrier();
-      if (tid < kw) v[kb + tid] = acc;
+      if (tid < kw) v[kb + tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
     __syncthreads();
     for (int j = tid; j < kb; j += blockDim.x) {
-      double acc = 0.0;
-      for (int kk = 0; kk < kw; kk++) acc += a[kb + kk + j * ld] * v[kb + kk];
-      v[j] -= acc;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int kk = 0; kk < DB; kk++)
+        acc[kk & 3] += kk < kw ? a[kb + kk + j * ld] * v[kb + kk] : 0.0;
+      v[j] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
   }
   __syncthreads();

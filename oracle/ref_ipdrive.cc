@@ -1,0 +1,83 @@
+// TEST INFRASTRUCTURE -- not part of the product path.
+//
+// Drives the REFERENCE's own interior-point QP solvers (hqp/Hqp_IpsMehrotra.C,
+// hqp/Hqp_IpsFranke.C, unmodified, compiled from /root/reference by
+// oracle/Makefile) on a QP given as CSR arrays, with the KKT plugin chosen by
+// name through the reference's own plugin registry ("qp_mat_solver <name>",
+// iftcl/If_Module.h:50-96).  With name = "SpBKP"/"RedSpBKP" this is the pure
+// reference; with "SpBKPHip"/"RedSpBKPHip" (only in libhqphost_hip.so, which also
+// holds shim/Hqp_IpSpBKPHip.C) the SAME solver object code calls our C ABI --
+// the drop-in check of BASELINE.json's north_star ("Hqp_IpsMehrotra /
+// Hqp_IpsFranke call it unchanged").  This file is our code; nothing of the
+// reference is copied.
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <ctime>
+
+#include <If.h>
+#include <Hqp_Program.h>
+#include <Hqp_IpsMehrotra.h>
+#include <Hqp_IpsFranke.h>
+
+extern "C" int hqpref_startup(void);
+
+static double now_s() {
+  struct timespec ts;
+  clock_gettime(CLOCK_MONOTONIC, &ts);
+  return ts.tv_sec + 1e-9 * ts.tv_nsec;
+}
+
+static void fill(SPMAT *M, int rows, const int *p, const int *i, const double *x) {
+  for (int r = 0; r < rows; r++)
+    for (int k = p[r]; k < p[r + 1]; k++) sp_set_val(M, r, i[k], x[k]);
+}
+
+extern "C" {
+
+// solver: 0 = Mehrotra, 1 = Franke.  Returns 0, or the Meschach error number,
+// or -1 (setup) / -2 (unknown plugin name).
+// out[0] = iterations, out[1] = Hqp_Result (0 optimal), out[2] = seconds in
+// cold_start + solve, out[3] = seconds in init + update.
+int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const int *Qp,
+                const int *Qi, const double *Qx, const double *c, const int *Ap,
+                const int *Ai, const double *Ax, const double *b, const int *Cp,
+                const int *Ci, const double *Cx, const double *d, double qp_eps,
+                int max_iters, double *x, double *y, double *z, double *out) {
+  if (hqpref_startup() != 0) return -1;
+  Hqp_Solver *S = solver == 0 ? (Hqp_Solver *)new Hqp_IpsMehrotra : (Hqp_Solver *)new Hqp_IpsFranke;
+  // select the plugin exactly as a user would: Tcl command qp_mat_solver
+  if (If_SetString("qp_mat_solver", mat_solver) != IF_OK) {
+    delete S;
+    return -2;
+  }
+  Hqp_Program *qp = new Hqp_Program;
+  qp->resize(n, me, m);
+  fill(qp->Q, n, Qp, Qi, Qx);
+  fill(qp->A, me, Ap, Ai, Ax);
+  fill(qp->C, m, Cp, Ci, Cx);
+  for (int i = 0; i < n; i++) qp->c->ve[i] = c[i], qp->x->ve[i] = 0.0;
+  for (int i = 0; i < me; i++) qp->b->ve[i] = b[i];
+  for (int i = 0; i < m; i++) qp->d->ve[i] = d[i];
+  S->qp(qp);
+  S->eps(qp_eps);
+  S->max_iters(max_iters);
+  int err = 0;
+  double t0 = now_s(), t1 = t0, t2 = t0;
+  m_catchall(S->init(); S->update(); t1 = now_s(); S->cold_start(); S->solve(); t2 = now_s(),
+             err = _err_num);
+  if (!err) {
+    for (int i = 0; i < n; i++) x[i] = qp->x->ve[i];
+    for (int i = 0; i < me; i++) y[i] = S->y()->ve[i];
+    for (int i = 0; i < m; i++) z[i] = S->z()->ve[i];
+    out[0] = S->iter();
+    out[1] = (double)S->result();
+    out[2] = t2 - t1;
+    out[3] = t1 - t0;
+  }
+  delete S;
+  delete qp;
+  return err;
+}
+
+}  // extern "C"

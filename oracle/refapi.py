@@ -178,3 +178,56 @@ class RefIpMatrix:
         va = np.zeros(max(nnz, 1))
         self._lib.hqpref_get_matrix(self._h, w, rp, ci, va)
         return rp, ci[:nnz], va[:nnz]
+
+
+# ---------------------------------------------------------------------------
+# The reference's own interior-point solvers (oracle/ref_ipdrive.cc).
+# host = "ref"  -> oracle/_ref/libhqpref.so       (reference only)
+# host = "hip"  -> oracle/_ref/libhqphost_hip.so  (reference + shim/Hqp_IpSpBKPHip.C
+#                  + the product's libhqpkkt.so): adds the plugins SpBKPHip / RedSpBKPHip
+_HOST_LIBS = {}
+
+
+def _host(host):
+    if host in _HOST_LIBS:
+        return _HOST_LIBS[host]
+    os.environ.setdefault("TCL_LIBRARY", "/opt/conda/lib/tcl8.6")
+    if host == "hip":
+        try:
+            import torch  # noqa: F401  (same HIP runtime as the product binding, see hqp_amd/_lib.py)
+        except ImportError:
+            pass
+    path = os.path.join(_HERE, "_ref", "libhqpref.so" if host == "ref" else "libhqphost_hip.so")
+    lib = C.CDLL(path)
+    lib.hqpip_solve.argtypes = ([C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp, _dp] * 3
+                                + [C.c_double, C.c_int, _dp, _dp, _dp, _dp])
+    _HOST_LIBS[host] = lib
+    return lib
+
+
+def host_available(host="ref"):
+    try:
+        _host(host)
+        return True
+    except OSError:
+        return False
+
+
+def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250):
+    """Run Hqp_IpsMehrotra / Hqp_IpsFranke of the reference on ``prog`` with the KKT
+    plugin ``mat_solver``.  Returns dict(x, y, z, iters, result, seconds)."""
+    lib = _host(host)
+    n, me, m = prog.dims
+    args = []
+    for (p, i, x), vec in zip((prog.Q, prog.A, prog.C), (prog.c, prog.b, prog.d)):
+        args += [np.ascontiguousarray(p, dtype=np.int32),
+                 np.ascontiguousarray(i, dtype=np.int32) if len(i) else np.zeros(1, np.int32),
+                 _pad(x), _pad(vec)]
+    x, y, z = np.zeros(max(n, 1)), np.zeros(max(me, 1)), np.zeros(max(m, 1))
+    out = np.zeros(4)
+    e = lib.hqpip_solve({"Mehrotra": 0, "Franke": 1}[solver], mat_solver.encode(), n, me, m, *args,
+                        qp_eps, max_iters, x, y, z, out)
+    if e:
+        raise RefError(e, f"ip_solve[{solver},{mat_solver}]")
+    return dict(x=x[:n], y=y[:me], z=z[:m], iters=int(out[0]), result=int(out[1]), seconds=out[2],
+                setup_seconds=out[3])

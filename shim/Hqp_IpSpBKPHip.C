@@ -1,0 +1,200 @@
+/*
+ * Hqp_IpSpBKPHip.C -- see Hqp_IpSpBKPHip.h.  Thin C++ shim: walks the
+ * Hqp_Program's row-list SPMATs into int32 CSR, forwards the Hqp_IpMatrix
+ * virtual calls to libhqpkkt.so and converts a non-zero status into the
+ * reference's error convention (m_error -> longjmp to the IP solver's m_catch,
+ * meschach/err.h:63,118-135; hqp/Hqp_IpsMehrotra.C:525-536).
+ *
+ * No C++ object with a non-trivial destructor is alive across a possible
+ * m_error(): everything the shim owns hangs off `this` as Meschach objects.
+ */
+#include "Hqp_IpSpBKPHip.h"
+
+#include <If_Int.h>
+#include <If_Real.h>
+
+#include "Hqp_Program.h"
+#include "hqpkkt.h"
+
+IF_CLASS_DEFINE("SpBKPHip", Hqp_IpSpBKPHip, Hqp_IpMatrix);
+IF_CLASS_DEFINE("RedSpBKPHip", Hqp_IpRedSpBKPHip, Hqp_IpMatrix);
+
+//--------------------------------------------------------------------------
+Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
+{
+  _mode = mode;
+  _n = _me = _m = 0;
+  _sbw = -1;
+  _tol = 1.0;
+  _device = 0;
+  _refine = 1;
+  _h = NULL;
+  _Qp = _Qi = _Ap = _Ai = _Cp = _Ci = IVNULL;
+  _Qx = _Ax = _Cx = VNULL;
+
+  // same Tcl-visible members as hqp/Hqp_IpSpBKP.C:58-59, plus the device knobs
+  _ifList.append(new If_Int("mat_sbw", &_sbw));
+  _ifList.append(new If_Real("mat_tol", &_tol));
+  _ifList.append(new If_Int("mat_device", &_device));
+  _ifList.append(new If_Int("mat_device_refine", &_refine));
+}
+
+//--------------------------------------------------------------------------
+Hqp_IpMatrixHip::~Hqp_IpMatrixHip()
+{
+  hqpkkt_destroy(_h);
+  iv_free(_Qp); iv_free(_Qi); iv_free(_Ap); iv_free(_Ai); iv_free(_Cp); iv_free(_Ci);
+  v_free(_Qx); v_free(_Ax); v_free(_Cx);
+}
+
+//--------------------------------------------------------------------------
+void Hqp_IpMatrixHip::check(int status, const char *where)
+{
+  if (status == HQPKKT_OK)
+    return;
+  // numerical singularity / zero slack -> E_SING, which the IP solvers catch and
+  // turn into Hqp_Degenerate (hqp/Hqp_IpsMehrotra.C:525-536, Hqp_IpsFranke.C:303-310)
+  if (status == HQPKKT_E_SING)
+    m_error(E_SING, where);
+  if (status == HQPKKT_E_SIZES)
+    m_error(E_SIZES, where);
+  if (status == HQPKKT_E_MEM)
+    m_error(E_MEM, where);
+  if (status == HQPKKT_E_NULL)
+    m_error(E_NULL, where);
+  if (status == HQPKKT_E_FORMAT)
+    m_error(E_FORMAT, where);
+  fprintf(stderr, "%s: %s\n", where, hqpkkt_strerror(status));
+  m_error(E_INTERN, where);  // HIP runtime failures, call-order violations
+}
+
+//--------------------------------------------------------------------------
+// one block: SPMAT -> (ptr, idx, val); upper = keep col >= row only
+// (the reference reads only that part of Q, meschach/addon2_hqp.c:1078-1086)
+static void extract_block(const SPMAT *M, bool upper,
+                          IVEC *&ptr, IVEC *&idx, VEC *&val, bool &changed)
+{
+  int i, j, k, m = M->m;
+  int nnz = 0;
+  for (i = 0; i < m; i++) {
+    const SPROW *row = M->row + i;
+    for (j = 0; j < row->len; j++)
+      if (!upper || row->elt[j].col >= i)
+        nnz++;
+  }
+  if (!ptr || (int)ptr->dim != m + 1 || !idx || (int)idx->dim != nnz)
+    changed = true;
+  ptr = iv_resize(ptr, m + 1);
+  idx = iv_resize(idx, nnz);
+  val = v_resize(val, nnz);
+  k = 0;
+  for (i = 0; i < m; i++) {
+    const SPROW *row = M->row + i;
+    if (ptr->ive[i] != k)
+      changed = true;
+    ptr->ive[i] = k;
+    for (j = 0; j < row->len; j++) {
+      const row_elt *elt = row->elt + j;
+      if (upper && elt->col < i)
+        continue;
+      if (idx->ive[k] != elt->col)
+        changed = true;
+      idx->ive[k] = elt->col;
+      val->ve[k] = elt->val;
+      k++;
+    }
+  }
+  if (ptr->ive[m] != k)
+    changed = true;
+  ptr->ive[m] = k;
+}
+
+void Hqp_IpMatrixHip::extract(const Hqp_Program *qp, bool &pattern_changed)
+{
+  pattern_changed = false;
+  extract_block(qp->Q, true, _Qp, _Qi, _Qx, pattern_changed);
+  extract_block(qp->A, false, _Ap, _Ai, _Ax, pattern_changed);
+  extract_block(qp->C, false, _Cp, _Ci, _Cx, pattern_changed);
+}
+
+//--------------------------------------------------------------------------
+void Hqp_IpMatrixHip::init(const Hqp_Program *qp)
+{
+  bool changed;
+  hqpkkt_opts opts;
+
+  _n = qp->c->dim;
+  _me = qp->b->dim;
+  _m = qp->d->dim;
+
+  // (re)create the handle: mat_tol / mat_eps / mat_device may have been set
+  hqpkkt_destroy(_h);
+  _h = NULL;
+  hqpkkt_default_opts(&opts);
+  opts.mode = _mode;
+  opts.device = _device;
+  opts.loc = HQPKKT_LOC_HOST;   // Meschach VEC::ve pointers
+  opts.tol = _tol;
+  opts.eps = _eps;
+  check(hqpkkt_create(&opts, &_h), "Hqp_IpMatrixHip::init");
+
+  extract(qp, changed);
+  check(hqpkkt_analyze(_h, _n, _me, _m,
+                       _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,
+                       &_sbw),
+        "Hqp_IpMatrixHip::init");
+  check(hqpkkt_set_values(_h, _Qx->ve, _Ax->ve, _Cx->ve), "Hqp_IpMatrixHip::init");
+}
+
+//--------------------------------------------------------------------------
+void Hqp_IpMatrixHip::update(const Hqp_Program *qp)
+{
+  bool changed;
+  extract(qp, changed);
+  if (changed) {
+    // structure changed behind our back: analyse again (the reference's own
+    // plugins assume a fixed pattern between init() calls)
+    check(hqpkkt_analyze(_h, _n, _me, _m,
+                         _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,
+                         &_sbw),
+          "Hqp_IpMatrixHip::update");
+  }
+  check(hqpkkt_set_values(_h, _Qx->ve, _Ax->ve, _Cx->ve), "Hqp_IpMatrixHip::update");
+}
+
+//--------------------------------------------------------------------------
+void Hqp_IpMatrixHip::factor(const Hqp_Program *, const VEC *z, const VEC *w)
+{
+  assert((int)z->dim == _m && (int)w->dim == _m);
+  hqpkkt_set_tol(_h, _tol);
+  check(hqpkkt_factor(_h, z->ve, w->ve), "Hqp_IpMatrixHip::factor");
+}
+
+//--------------------------------------------------------------------------
+void Hqp_IpMatrixHip::step(const Hqp_Program *, const VEC *z, const VEC *w,
+                           const VEC *r1, const VEC *r2, const VEC *r3,
+                           const VEC *r4, VEC *dx, VEC *dy, VEC *dz, VEC *dw)
+{
+  assert((int)r1->dim == _n && (int)dx->dim == _n);
+  assert((int)r2->dim == _me && (int)dy->dim == _me);
+  assert((int)r3->dim == _m && (int)dz->dim == _m);
+  assert((int)r4->dim == _m && (int)dw->dim == _m);
+  check(hqpkkt_step(_h, z->ve, w->ve, r1->ve, r2->ve, r3->ve, r4->ve,
+                    dx->ve, dy->ve, dz->ve, dw->ve),
+        "Hqp_IpMatrixHip::step");
+}
+
+//--------------------------------------------------------------------------
+Real Hqp_IpMatrixHip::solve(const Hqp_Program *qp, const VEC *z, const VEC *w,
+                            const VEC *r1, const VEC *r2, const VEC *r3,
+                            const VEC *r4, VEC *dx, VEC *dy, VEC *dz, VEC *dw)
+{
+  double res = 0.0;
+  if (!_refine)  // host-side refinement of the base class, device step()
+    return Hqp_IpMatrix::solve(qp, z, w, r1, r2, r3, r4, dx, dy, dz, dw);
+  hqpkkt_set_eps(_h, _eps);
+  check(hqpkkt_solve(_h, z->ve, w->ve, r1->ve, r2->ve, r3->ve, r4->ve,
+                     dx->ve, dy->ve, dz->ve, dw->ve, &res),
+        "Hqp_IpMatrixHip::solve");
+  return res;
+}

@@ -1,0 +1,67 @@
+/*
+ * Hqp_IpSpBKPHip.h -- Hqp_IpMatrix plugins that run the KKT linear-system path
+ * on an MI355X through the C ABI of include/hqpkkt.h.
+ *
+ * Reference-side binding: this file and Hqp_IpSpBKPHip.C are compiled INTO (or
+ * next to) an HQP build, against the reference's own headers, exactly like the
+ * reference's Hqp_IpPARDISO (hqp/Hqp_IpPARDISO.{h,C}) which forwards to a C
+ * function.  Two classes are registered with the plugin factory
+ * (iftcl/If_Class.h:53-60):
+ *     qp_mat_solver SpBKPHip      -- semantics of Hqp_IpSpBKP    (full system)
+ *     qp_mat_solver RedSpBKPHip   -- semantics of Hqp_IpRedSpBKP (reduced)
+ * Hqp_IpsMehrotra / Hqp_IpsFranke / Hqp_SqpSolver call them unchanged through
+ * the Hqp_IpMatrix virtual interface (hqp/Hqp_IpMatrix.h:63-88).
+ */
+#ifndef Hqp_IpSpBKPHip_H
+#define Hqp_IpSpBKPHip_H
+
+#include "Hqp_IpMatrix.h"
+
+struct hqpkkt;
+
+class Hqp_IpMatrixHip : public Hqp_IpMatrix {
+ protected:
+  int _mode;          // HQPKKT_MODE_FULL / HQPKKT_MODE_REDUCED
+  int _n, _me, _m;    // dimensions of the analysed program
+  int _sbw;           // mat_sbw (read-only for the user, as in hqp/Hqp_IpSpBKP.C:58)
+  Real _tol;          // mat_tol (hqp/Hqp_IpSpBKP.C:59)
+  int _device;        // mat_device: HIP device ordinal
+  int _refine;        // mat_device_refine: run Hqp_IpMatrix::solve's refinement on the GPU
+  struct hqpkkt *_h;
+  // CSR copies of the pattern the handle was analysed for (pattern-change
+  // detection like hqp/Hqp_IpPARDISO.C:247-248,293-296) and value staging
+  IVEC *_Qp, *_Qi, *_Ap, *_Ai, *_Cp, *_Ci;
+  VEC *_Qx, *_Ax, *_Cx;
+
+  void extract(const Hqp_Program *qp, bool &pattern_changed);
+  void check(int status, const char *where);
+
+ public:
+  Hqp_IpMatrixHip(int mode);
+  ~Hqp_IpMatrixHip();
+
+  void init(const Hqp_Program *);
+  void update(const Hqp_Program *);
+  void factor(const Hqp_Program *, const VEC *z, const VEC *w);
+  void step(const Hqp_Program *, const VEC *z, const VEC *w,
+            const VEC *r1, const VEC *r2, const VEC *r3, const VEC *r4,
+            VEC *dx, VEC *dy, VEC *dz, VEC *dw);
+  // refinement loop on the device (same algorithm as hqp/Hqp_IpMatrix.C:65-128)
+  Real solve(const Hqp_Program *, const VEC *z, const VEC *w,
+             const VEC *r1, const VEC *r2, const VEC *r3, const VEC *r4,
+             VEC *dx, VEC *dy, VEC *dz, VEC *dw);
+};
+
+class Hqp_IpSpBKPHip : public Hqp_IpMatrixHip {
+ public:
+  Hqp_IpSpBKPHip() : Hqp_IpMatrixHip(0) {}
+  const char *name() { return "SpBKPHip"; }
+};
+
+class Hqp_IpRedSpBKPHip : public Hqp_IpMatrixHip {
+ public:
+  Hqp_IpRedSpBKPHip() : Hqp_IpMatrixHip(1) {}
+  const char *name() { return "RedSpBKPHip"; }
+};
+
+#endif
