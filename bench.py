@@ -98,43 +98,44 @@ def main():
     ap.add_argument("--band", type=int, default=80, help="semi-bandwidth of Q / row width of A (C2: 80)")
     ap.add_argument("--mode", default="SpBKP", choices=["SpBKP", "RedSpBKP"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--host-vectors", action="store_true",
+                    help="z,w,r*,d* as host pointers (the shim's mode): PCIe-inclusive, never the headline value")
     ap.add_argument("--leaf-size", type=int, default=0)
     ap.add_argument("--max-pivots", type=int, default=0)
     args = ap.parse_args()
 
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    from hqp_amd import dist as kdist
+
+    rank, local_rank, world = kdist.env_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
     torch.cuda.set_device(local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    kdist.init("nccl")
 
     from hqp_amd import ipmatrix, problems
 
     prog = problems.banded_qp(args.n, args.band, seed=12345 + rank)
     state = problems.ip_state(prog, seed=1 + rank)
     cls = ipmatrix.IpSpBKP if args.mode == "SpBKP" else ipmatrix.IpRedSpBKP
-    mat = cls(device=local_rank, device_vectors=True, leaf_size=args.leaf_size, max_pivots=args.max_pivots)
+    mat = cls(device=local_rank, device_vectors=not args.host_vectors, leaf_size=args.leaf_size,
+              max_pivots=args.max_pivots)
     t0 = time.perf_counter()
     mat.init(prog)  # analysis (host) + upload; one-time, not part of a step
     t_init = time.perf_counter() - t0
-    dev = [torch.as_tensor(a).cuda() for a in state]
-    d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
+    if args.host_vectors:
+        dev = [np.ascontiguousarray(a) for a in state]
+        d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    else:
+        dev = [torch.as_tensor(a).cuda() for a in state]
+        d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
 
     def step():
         mat.factor(prog, dev[0], dev[1])
         return mat.solve(prog, *dev, *d)
 
-    def fence():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
+    fence = kdist.fence
 
     for _ in range(args.warmup):
         step()
@@ -144,10 +145,7 @@ def main():
         res = step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = kdist.max_over_ranks(elapsed)
     st = mat.stats()
 
     # per-kernel-class device time (HIP events on the library's stream around every
@@ -169,8 +167,14 @@ def main():
         dom_launch_ms = dom_ms / max(launches[dom], 1.0)
         flops_per_launch = work[dom]["flops"] / max(launches[dom], 1.0)
         achieved = flops_per_launch / (dom_launch_ms * 1e-3) / 1e12
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+        if os.path.exists(pmc) and prog.n == 40000 and args.band == 80 and args.mode == "SpBKP":
+            # HBM bytes per launch of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
+            # this same command (separate runs, gfx950 corrections applied; see profiles/README.md)
+            traffic = json.load(open(pmc)).get("k_" + dom, {}).get("hbm_bytes_per_launch")
         roofline = {"kernel": "k_" + dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
-                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                    "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                     "launches_per_step": launches[dom], "avg_launch_ms": dom_launch_ms,
                     "algorithmic_flops_per_step": work[dom]["flops"]}
         # SURVEY.md 8(d) band model of the whole factorisation, for reference
@@ -192,6 +196,7 @@ def main():
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
+            "vectors": "host pointers (PCIe per call)" if args.host_vectors else "resident in HBM",
             "config": {"workload": f"C2 synthetic banded KKT: n={prog.n} me={prog.me} m={prog.m} band={args.band} "
                                    f"-> KKT dim {st['dim']}, mat_sbw {st['sbw']}, plugin {args.mode} (one system per GPU)",
                        "kkt_dim": st["dim"], "mat_sbw": st["sbw"], "plugin": args.mode,
@@ -210,9 +215,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(prog, state)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
         print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+    kdist.finalize()
 
 
 if __name__ == "__main__":

@@ -1,0 +1,50 @@
+"""CPU, world_size 2 over gloo: the N>1 plumbing bench.py uses (unit sharding,
+fence, max / sum over ranks).  The KKT path shards by system with no data-path
+collective, so this is all the multi-process logic there is."""
+import os
+import subprocess
+import sys
+import textwrap
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+WORKER = textwrap.dedent("""
+    import json, os, sys, time
+    sys.path.insert(0, %r)
+    from hqp_amd import dist
+    rank, local_rank, world = dist.init(backend="gloo")
+    units = dist.shard_units(5, rank, world)
+    dist.fence(device_sync=False)
+    t0 = time.perf_counter()
+    time.sleep(0.05 * (rank + 1))          # uneven work
+    dist.fence(device_sync=False)
+    el = time.perf_counter() - t0
+    tmax = dist.max_over_ranks(0.05 * (rank + 1))
+    total = dist.sum_over_ranks(len(units))
+    if rank == 0:
+        print(json.dumps(dict(world=world, units=units, tmax=tmax, total=total, el=el)))
+    dist.finalize()
+""") % ROOT
+
+
+def test_two_ranks_gloo(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(WORKER)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29541", str(script)]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=180, cwd=ROOT)
+    assert out.returncode == 0, out.stderr[-2000:]
+    import json
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["world"] == 2 and d["units"] == [0, 2, 4]
+    assert abs(d["tmax"] - 0.10) < 1e-12          # slowest rank
+    assert d["total"] == 5.0                      # every unit owned exactly once
+    assert d["el"] >= 0.09                        # rank 0 waited for rank 1 at the fence
+
+
+def test_shard_units_cover_exactly_once():
+    from hqp_amd import dist
+    for world in (1, 2, 3, 8):
+        owned = sorted(u for r in range(world) for u in dist.shard_units(11, r, world))
+        assert owned == list(range(11))
