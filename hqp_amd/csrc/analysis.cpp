@@ -241,71 +241,95 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   }
 
   // ------------------------------------------- nested dissection of the band
-  // Logical nodes: leaves = intervals of the band order, inner nodes = separators
-  // (every position coupled across the cut).  Each logical node becomes a chain
-  // of supernodes of at most max_pivots pivots further down.
+  // Logical nodes: leaves = the still unassigned positions of an interval of the
+  // band order, inner nodes = vertex separators.  Cutting the interval at `mid`,
+  // the separator is the set of positions >= mid that are coupled to a position
+  // < mid (all of them lie within sbw of the cut); positions of the window that
+  // are not coupled across the cut (e.g. slack rows whose x sits on the right)
+  // stay in the right part, so a separator is usually well below sbw rows.  Each
+  // logical node becomes a chain of supernodes of <= max_pivots pivots below.
   if (leaf_size <= 0) leaf_size = std::max(2 * std::max(sbw, 1), 32);
   struct Tmp {
-    int lo, hi;
+    std::vector<int> verts;  // band positions
     std::vector<int> kids;
   };
   std::vector<Tmp> tmp;
-  auto make = [&](int lo, int hi, std::vector<int> kids) {
-    tmp.push_back(Tmp{lo, hi, std::move(kids)});
+  std::vector<int> pos2q_nd(dim);
+  for (int q = 0; q < dim; q++) pos2q_nd[qp2j[q]] = q;
+  std::vector<char> taken(dim, 0);  // position already belongs to a separator
+  auto make = [&](std::vector<int> verts, std::vector<int> kids) {
+    tmp.push_back(Tmp{std::move(verts), std::move(kids)});
     return (int)tmp.size() - 1;
   };
+  auto free_positions = [&](int lo, int hi) {
+    std::vector<int> v;
+    for (int r = lo; r < hi; r++)
+      if (!taken[r]) v.push_back(r);
+    return v;
+  };
   struct Frame {
-    int lo, hi, stage, mid, send;
-    std::vector<int> left, right;
+    int lo, hi, stage, mid;
+    std::vector<int> sep, left, right;
   };
   std::vector<int> roots;
   {
     std::vector<Frame> st;
     std::vector<std::vector<int>> ret;  // return values stack
-    st.push_back({0, dim, 0, 0, 0, {}, {}});
+    st.push_back({0, dim, 0, 0, {}, {}, {}});
     while (!st.empty()) {
       Frame &f = st.back();
-      int len = f.hi - f.lo;
       if (f.stage == 0) {
-        if (len <= 0) {
+        std::vector<int> fr = free_positions(f.lo, f.hi);
+        const int len = (int)fr.size();
+        if (len == 0) {
           ret.push_back({});
           st.pop_back();
           continue;
         }
         if (len <= leaf_size) {
-          ret.push_back({make(f.lo, f.hi, {})});
+          ret.push_back({make(fr, {})});
           st.pop_back();
           continue;
         }
-        // centre the separator: both sides get about (len - sbw)/2 rows
-        f.mid = f.lo + std::max(1, (len - std::min(sbw, len / 3)) / 2);
-        int send = f.mid;
-        for (int r = f.lo; r < f.mid; r++) send = std::max(send, std::min(reach[r] + 1, f.hi));
-        f.send = send;
-        if ((send - f.mid) * 3 >= len) {  // separator would dominate: keep as one node
-          ret.push_back({make(f.lo, f.hi, {})});
+        // cut so that both sides keep about (len - separator)/2 free rows
+        f.mid = fr[std::max(1, (len - std::min(sbw, len / 3)) / 2)];
+        std::vector<int> sep;
+        for (int r = f.mid; r < f.hi && r <= f.mid + sbw; r++) {
+          if (taken[r]) continue;
+          const int q = pos2q_nd[r];
+          bool coupled = false;
+          for (int k = gstart[q]; k < gstart[q + 1] && !coupled; k++) {
+            const int u = qp2j[gneigh[k]];
+            coupled = u >= f.lo && u < f.mid && !taken[u];
+          }
+          if (coupled) sep.push_back(r);
+        }
+        if ((int)sep.size() * 3 >= len) {  // separator would dominate: keep as one node
+          ret.push_back({make(fr, {})});
           st.pop_back();
           continue;
         }
+        for (int r : sep) taken[r] = 1;
+        f.sep = sep;
         f.stage = 1;
-        int lo = f.lo, mid = f.mid;
-        st.push_back({lo, mid, 0, 0, 0, {}, {}});
+        const int lo = f.lo, mid = f.mid;
+        st.push_back({lo, mid, 0, 0, {}, {}, {}});
         continue;
       }
       if (f.stage == 1) {
         f.left = ret.back();
         ret.pop_back();
         f.stage = 2;
-        int send = f.send, hi = f.hi;
-        st.push_back({send, hi, 0, 0, 0, {}, {}});
+        const int mid = f.mid, hi = f.hi;
+        st.push_back({mid, hi, 0, 0, {}, {}, {}});
         continue;
       }
       f.right = ret.back();
       ret.pop_back();
       std::vector<int> kids = f.left;
       kids.insert(kids.end(), f.right.begin(), f.right.end());
-      if (f.send > f.mid)
-        ret.push_back({make(f.mid, f.send, kids)});
+      if (!f.sep.empty())
+        ret.push_back({make(f.sep, kids)});
       else
         ret.push_back(kids);
       st.pop_back();
@@ -338,7 +362,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   std::vector<int> lnode_of_pos(dim);
   for (int id = 0; id < nlog; id++) {
     const Tmp &t = tmp[lorder[id]];
-    for (int r = t.lo; r < t.hi; r++) lverts[id].push_back(r), lnode_of_pos[r] = id;
+    for (int r : t.verts) lverts[id].push_back(r), lnode_of_pos[r] = id;
   }
   // Variables with a structurally zero diagonal (equality multipliers; x_i without
   // Q_ii) can only be pivoted together with, or after, a neighbour that carries a
