@@ -159,6 +159,19 @@ struct hqpkkt {
   DBuf<double> vcor;  // corrections _dx.._dw
   DBuf<double> tz;    // REDUCED temporary (m)
   size_t lds_diag = 0, lds_panel = 0, lds_solve = 0, lds_bwdb = 0;
+  // captured kernel sequences (factor; step on the caller's vectors; step on the
+  // refinement's residual vectors): replayed with hipGraphLaunch
+  struct GraphSlot {
+    hipGraph_t g = nullptr;
+    hipGraphExec_t ge = nullptr;
+    void drop() {
+      if (ge) (void)hipGraphExecDestroy(ge);
+      if (g) (void)hipGraphDestroy(g);
+      ge = nullptr, g = nullptr;
+    }
+  } gfactor, gstep[2];
+  bool use_graphs = true, capturing = false;
+  void drop_graphs() { gfactor.drop(), gstep[0].drop(), gstep[1].drop(); }
 
   DevTree tree() const {
     return DevTree{piv_start.p, npiv.p,     nbor.p,  parent.p, bptr.p,      bidx.p,     rel.p,
@@ -176,6 +189,7 @@ struct hqpkkt {
     for (auto b : db) b->release();
     terms.release(), esign.release(), bits.release();
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
+    drop_graphs();
     uploaded = have_values = factored = false;
   }
 };
@@ -301,37 +315,38 @@ struct Vecs {
 static int stage_in(hqpkkt_t *h, const double *z, const double *w, const double *r1,
                     const double *r2, const double *r3, const double *r4, Vecs &v) {
   const int n = h->an.n, me = h->an.me, m = h->an.m;
-  if (h->opts.loc == HQPKKT_LOC_DEVICE) {
-    v.z = z, v.w = w, v.r1 = r1, v.r2 = r2, v.r3 = r3, v.r4 = r4;
-    return 0;
-  }
   double *b = h->vin.p;
   double *dz_ = b, *dw_ = b + m, *d1 = b + 2 * (size_t)m, *d2 = d1 + n, *d3 = d2 + me, *d4 = d3 + m;
+  if (h->opts.loc == HQPKKT_LOC_DEVICE) {
+    CopyList L{{z, w, r1, r2, r3, r4}, {dz_, dw_, d1, d2, d3, d4}, {m, m, n, me, m, m}};
+    k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 6);
+  } else {
 #define H2D(dst, src, k) \
   if ((src) && (k) > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (k), hipMemcpyHostToDevice, h->stream))
-  H2D(dz_, z, m);
-  H2D(dw_, w, m);
-  H2D(d1, r1, n);
-  H2D(d2, r2, me);
-  H2D(d3, r3, m);
-  H2D(d4, r4, m);
+    H2D(dz_, z, m);
+    H2D(dw_, w, m);
+    H2D(d1, r1, n);
+    H2D(d2, r2, me);
+    H2D(d3, r3, m);
+    H2D(d4, r4, m);
 #undef H2D
+  }
   v.z = dz_, v.w = dw_, v.r1 = d1, v.r2 = d2, v.r3 = d3, v.r4 = d4;
   return 0;
 }
 
-static void stage_out_ptrs(hqpkkt_t *h, double *dx, double *dy, double *dz, double *dw, Vecs &v) {
+static void stage_out_ptrs(hqpkkt_t *h, Vecs &v) {
   const int n = h->an.n, me = h->an.me, m = h->an.m;
-  if (h->opts.loc == HQPKKT_LOC_DEVICE) {
-    v.dx = dx, v.dy = dy, v.dz = dz, v.dw = dw;
-  } else {
-    v.dx = h->vout.p, v.dy = v.dx + n, v.dz = v.dy + me, v.dw = v.dz + m;
-  }
+  v.dx = h->vout.p, v.dy = v.dx + n, v.dz = v.dy + me, v.dw = v.dz + m;
 }
 
 static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double *dz, double *dw) {
-  if (h->opts.loc == HQPKKT_LOC_DEVICE) return 0;
   const int n = h->an.n, me = h->an.me, m = h->an.m;
+  if (h->opts.loc == HQPKKT_LOC_DEVICE) {
+    CopyList L{{v.dx, v.dy, v.dz, v.dw, nullptr, nullptr}, {dx, dy, dz, dw, nullptr, nullptr}, {n, me, m, m, 0, 0}};
+    k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 4);
+    return 0;
+  }
 #define D2H(dst, src, k) \
   if ((dst) && (k) > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (k), hipMemcpyDeviceToHost, h->stream))
   D2H(dx, v.dx, n);
@@ -352,7 +367,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
   if (an.upd_elems) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
   HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 64, s));
   HIPCHK(hipMemsetAsync(h->bits.p, 0, sizeof(unsigned long long) * 2, s));
-  HIPCHK(hipEventRecord(h->ev0, s));
+  if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
   if (m > 0)
     KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
   KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
@@ -361,7 +376,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
     KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
   KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
                                        h->sc.p, h->panel.p, h->bits.p));
-  HIPCHK(hipEventRecord(h->ev1, s));
+  if (!h->capturing) HIPCHK(hipEventRecord(h->ev1, s));
   const double alpha = h->opts.tol * 0.6403882032022076;  // tol (1+sqrt 17)/8, hqp/spBKP.C:392
   for (int l = 0; l < an.nlevels; l++) {
     for (int seg = an.ea_level_ptr[l]; seg < an.ea_level_ptr[l + 1]; seg++) {
@@ -386,7 +401,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
       KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, h->upd_tiles.p + 3 * (size_t)an.upd_tile_ptr[l],
                                         h->panel.p, h->xar.p, h->upd.p));
   }
-  HIPCHK(hipEventRecord(h->evs1, s));
+  if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
   HIPCHK(hipGetLastError());
   return 0;
 }
@@ -444,6 +459,39 @@ static int run_step(hqpkkt_t *h, const Vecs &v) {
   return 0;
 }
 
+// replay (or first capture) of a kernel sequence as a hipGraph; falls back to
+// eager launches while per-kernel profiling is on
+template <class F>
+static int graphed(hqpkkt_t *h, hqpkkt::GraphSlot &slot, F body) {
+  if (!h->use_graphs || h->prof.on) return body();
+  if (!slot.ge) {
+    HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
+    h->capturing = true;
+    int e = body();
+    h->capturing = false;
+    hipGraph_t g = nullptr;
+    hipError_t ce = hipStreamEndCapture(h->stream, &g);
+    if (e) {
+      if (g) (void)hipGraphDestroy(g);
+      return e;
+    }
+    if (ce != hipSuccess || !g) {  // capture not possible: run eagerly from now on
+      h->use_graphs = false;
+      (void)hipGetLastError();
+      return body();
+    }
+    slot.g = g;
+    if (hipGraphInstantiate(&slot.ge, g, nullptr, nullptr, 0) != hipSuccess) {
+      slot.drop();
+      h->use_graphs = false;
+      (void)hipGetLastError();
+      return body();
+    }
+  }
+  HIPCHK(hipGraphLaunch(slot.ge, h->stream));
+  return 0;
+}
+
 // residual of (d) for rhs (r); leaves the residual vectors in h->vres
 static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
   Analysis &an = h->an;
@@ -451,7 +499,7 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
   const int n = an.n, me = an.me, m = an.m;
   double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
   HIPCHK(hipMemsetAsync(h->bits.p + 1, 0, sizeof(unsigned long long), s));
-  KLAUNCH(h, KC_RESIDUAL, k_residual<<<nblk((long long)n + me + m), 256, 0, s>>>(
+  KLAUNCH(h, KC_RESIDUAL, k_residual<<<std::min(nblk(16LL * ((long long)n + me + m)), 4096), 256, 0, s>>>(
       n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
       v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
   unsigned long long bits = 0;
@@ -579,15 +627,25 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   int e = stage_in(h, z, w, nullptr, nullptr, nullptr, nullptr, v);
   if (e) return e;
   h->factored = false;
-  if ((e = run_factor(h, v.z, v.w))) return e;
+  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  if ((e = graphed(h, h->gfactor, [&]() { return run_factor(h, v.z, v.w); }))) return e;
+  if (h->use_graphs && !h->prof.on) {  // phases are not timed separately inside a graph replay
+    HIPCHK(hipEventRecord(h->ev1, h->stream));
+    HIPCHK(hipEventRecord(h->evs1, h->stream));
+  }
   int flags[4] = {0, 0, 0, 0};
   unsigned long long kb = 0;
   HIPCHK(hipMemcpyAsync(flags, h->flags.p, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipMemcpyAsync(&kb, h->bits.p, sizeof(kb), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->prof.collect();
-  h->st.ms_assemble = elapsed(h->ev0, h->ev1);
-  h->st.ms_factor = elapsed(h->ev1, h->evs1);
+  if (h->use_graphs && !h->prof.on) {
+    h->st.ms_assemble = 0.f;  // inside the replayed graph
+    h->st.ms_factor = elapsed(h->ev0, h->evs1);
+  } else {
+    h->st.ms_assemble = elapsed(h->ev0, h->ev1);
+    h->st.ms_factor = elapsed(h->ev1, h->evs1);
+  }
   h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2];
   if (flags[0]) return flags[0];
   if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
@@ -604,9 +662,9 @@ int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w, const double *r1,
   Vecs v{};
   int e = stage_in(h, z, w, r1, r2, r3, r4, v);
   if (e) return e;
-  stage_out_ptrs(h, dx, dy, dz, dw, v);
+  stage_out_ptrs(h, v);
   HIPCHK(hipEventRecord(h->evs0, h->stream));
-  if ((e = run_step(h, v))) return e;
+  if ((e = graphed(h, h->gstep[0], [&]() { return run_step(h, v); }))) return e;
   HIPCHK(hipEventRecord(h->evs1, h->stream));
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -625,10 +683,11 @@ int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w, const double 
   Vecs v{};
   int e = stage_in(h, z, w, r1, r2, r3, r4, v);
   if (e) return e;
+  stage_out_ptrs(h, v);
   if (h->opts.loc == HQPKKT_LOC_DEVICE) {
-    v.dx = (double *)dx, v.dy = (double *)dy, v.dz = (double *)dz, v.dw = (double *)dw;
+    CopyList L{{dx, dy, dz, dw, nullptr, nullptr}, {v.dx, v.dy, v.dz, v.dw, nullptr, nullptr}, {n, me, m, m, 0, 0}};
+    k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 4);
   } else {
-    stage_out_ptrs(h, nullptr, nullptr, nullptr, nullptr, v);
     if (n) HIPCHK(hipMemcpyAsync(v.dx, dx, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
     if (me) HIPCHK(hipMemcpyAsync(v.dy, dy, sizeof(double) * me, hipMemcpyHostToDevice, h->stream));
     if (m) HIPCHK(hipMemcpyAsync(v.dz, dz, sizeof(double) * m, hipMemcpyHostToDevice, h->stream));
@@ -655,9 +714,9 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   Vecs v{};
   int e = stage_in(h, z, w, r1, r2, r3, r4, v);
   if (e) return e;
-  stage_out_ptrs(h, dx, dy, dz, dw, v);
+  stage_out_ptrs(h, v);
   HIPCHK(hipEventRecord(h->ev0, s));
-  if ((e = run_step(h, v))) return e;
+  if ((e = graphed(h, h->gstep[0], [&]() { return run_step(h, v); }))) return e;
   double res = 0.0, res_last;
   if ((e = run_residual(h, v, &res))) return e;
   // correction solve: rhs = residual vectors, result = vcor
@@ -668,7 +727,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   int rounds = 0;
   for (int it = 0; it < 5 && res > h->opts.eps; it++) {
     res_last = res;
-    if ((e = run_step(h, c))) return e;
+    if ((e = graphed(h, h->gstep[1], [&]() { return run_step(h, c); }))) return e;
     rounds++;
     double alpha = 1.0;
     do {
@@ -710,6 +769,7 @@ int hqpkkt_get_perm(const hqpkkt_t *h, int *perm) {
 int hqpkkt_set_tol(hqpkkt_t *h, double tol) {
   if (!h) return HQPKKT_E_NULL;
   if (!(tol > 0.0 && tol <= 1.0)) return HQPKKT_E_RANGE;
+  if (tol != h->opts.tol) h->gfactor.drop();  // alpha is baked into the captured launch
   h->opts.tol = tol;
   return 0;
 }
@@ -725,6 +785,7 @@ int hqpkkt_set_stream(hqpkkt_t *h, void *hip_stream) {
   int e = ensure_device(h);
   if (e) return e;
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
+  h->drop_graphs();
   return 0;
 }
 

@@ -634,10 +634,10 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
     for (int cc = 0; cc < 2; cc++) {
       const int c = g + 8 * cc;
       if (c < kw) {
-        double acc = 0.0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-        for (int t = 0; t < PS_COLS; t++) acc += (t <= c) ? xin[t] * iv[c * 16 + t] : 0.0;
-        s[r + 32 * (kb + c)] = acc;
+        for (int t = 0; t < PS_COLS; t++) acc[t & 3] += (t <= c) ? xin[t] * iv[c * 16 + t] : 0.0;
+        s[r + 32 * (kb + c)] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
       }
     }
     __syncthreads();
@@ -646,10 +646,10 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
 #pragma unroll
     for (int t = 0; t < PS_COLS; t++) xb[t] = t < kw ? s[r + 32 * (kb + t)] : 0.0;
     for (int j = kb + kw + g; j < p; j += 8) {
-      double acc = 0.0;
+      double acc[4] = {0.0, 0.0, 0.0, 0.0};  // independent chains: fp64 FMA latency ~32 cycles
 #pragma unroll
-      for (int kk = 0; kk < PS_COLS; kk++) acc += xb[kk] * (kk < kw ? Lb[j + p * kk] : 0.0);
-      s[r + 32 * j] -= acc;
+      for (int kk = 0; kk < PS_COLS; kk++) acc[kk & 3] += xb[kk] * (kk < kw ? Lb[j + p * kk] : 0.0);
+      s[r + 32 * j] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
     }
   }
   __syncthreads();
@@ -1069,48 +1069,90 @@ __global__ void k_red_dzdw(int m, const int *__restrict__ Cp, const int *__restr
 }
 
 // ---------------------------------------------------------------- residuum
-// Hqp_IpMatrix::residuum (hqp/Hqp_IpMatrix.C:147-176), one thread per row of
-// the concatenated [n | me | m] index space:
+// Hqp_IpMatrix::residuum (hqp/Hqp_IpMatrix.C:147-176) over the concatenated
+// [n | me | m] row space:
 //   rho1 = r1 + Q dx - A' dy - C' dz,  rho2 = r2 - A dx,
 //   rho3 = r3 - (C dx - dw),           rho4 = r4 - (z.*dw + w.*dz)
+// Sixteen lanes (one DPP row) share a matrix row: they stride its non-zeros with
+// coalesced index / value loads and add up with DPP row rotations.
 struct CsrDev {
   const int *ptr, *col, *src;
 };
-__global__ void k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev C,
-                           const double *__restrict__ vals, const double *__restrict__ z,
-                           const double *__restrict__ w, const double *__restrict__ r1,
-                           const double *__restrict__ r2, const double *__restrict__ r3,
-                           const double *__restrict__ r4, const double *__restrict__ dx,
-                           const double *__restrict__ dy, const double *__restrict__ dz,
-                           const double *__restrict__ dw, double *__restrict__ o1,
-                           double *__restrict__ o2, double *__restrict__ o3,
-                           double *__restrict__ o4, unsigned long long *__restrict__ resbits) {
-  int q = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ double row16_sum(double v) {
+  v += dpp_move<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move<0x124, 0xf>(v);  // row_ror 4
+  v += dpp_move<0x128, 0xf>(v);  // row_ror 8 -> every lane of the row holds the sum
+  return v;
+}
+__device__ __forceinline__ double row_dot16(const CsrDev M, const double *__restrict__ vals,
+                                            const double *__restrict__ x, int row, int sub) {
+  double s = 0.0;
+  const int e = M.ptr[row + 1];
+  for (int k = M.ptr[row] + sub; k < e; k += 16) s += vals[M.src[k]] * x[M.col[k]];
+  return row16_sum(s);
+}
+__global__ void __launch_bounds__(256)
+k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev C,
+           const double *__restrict__ vals, const double *__restrict__ z,
+           const double *__restrict__ w, const double *__restrict__ r1,
+           const double *__restrict__ r2, const double *__restrict__ r3,
+           const double *__restrict__ r4, const double *__restrict__ dx,
+           const double *__restrict__ dy, const double *__restrict__ dz,
+           const double *__restrict__ dw, double *__restrict__ o1, double *__restrict__ o2,
+           double *__restrict__ o3, double *__restrict__ o4,
+           unsigned long long *__restrict__ resbits) {
+  __shared__ double red[4];
+  const int sub = threadIdx.x & 15;
+  const int total = n + me + m;
   double mag = 0.0;
-  if (q < n) {
-    double s = row_dot(Q.ptr, Q.col, Q.src, vals, dx, q);
-    s += -1.0 * row_dot(AT.ptr, AT.col, AT.src, vals, dy, q);
-    s += -1.0 * row_dot(CT.ptr, CT.col, CT.src, vals, dz, q);
-    s = r1[q] + s;
-    o1[q] = s;
-    mag = fabs(s);
-  } else if (q < n + me) {
-    int i = q - n;
-    double s = r2[i] - row_dot(A.ptr, A.col, A.src, vals, dx, i);
-    o2[i] = s;
-    mag = fabs(s);
-  } else if (q < n + me + m) {
-    int j = q - n - me;
-    double cdx = row_dot(C.ptr, C.col, C.src, vals, dx, j);
-    double s3 = r3[j] - (cdx - dw[j]);
-    double s4 = r4[j] - (z[j] * dw[j] + w[j] * dz[j]);
-    o3[j] = s3, o4[j] = s4;
-    mag = fmax(fabs(s3), fabs(s4));
+  for (int q = blockIdx.x * 16 + (threadIdx.x >> 4); q < total; q += gridDim.x * 16) {
+    if (q < n) {
+      double s = row_dot16(Q, vals, dx, q, sub);
+      s += -1.0 * row_dot16(AT, vals, dy, q, sub);
+      s += -1.0 * row_dot16(CT, vals, dz, q, sub);
+      s = r1[q] + s;
+      if (sub == 0) o1[q] = s;
+      mag = fmax(mag, fabs(s) == fabs(s) ? fabs(s) : __longlong_as_double(0x7ff0000000000000LL));
+    } else if (q < n + me) {
+      const int i = q - n;
+      const double s = r2[i] - row_dot16(A, vals, dx, i, sub);
+      if (sub == 0) o2[i] = s;
+      mag = fmax(mag, fabs(s) == fabs(s) ? fabs(s) : __longlong_as_double(0x7ff0000000000000LL));
+    } else {
+      const int j = q - n - me;
+      const double cdx = row_dot16(C, vals, dx, j, sub);
+      const double s3 = r3[j] - (cdx - dw[j]);
+      const double s4 = r4[j] - (z[j] * dw[j] + w[j] * dz[j]);
+      if (sub == 0) o3[j] = s3, o4[j] = s4;
+      const double t = fmax(fabs(s3), fabs(s4));
+      // a NaN must not get lost in the max
+      mag = fmax(mag, (s3 == s3 && s4 == s4) ? t : __longlong_as_double(0x7ff0000000000000LL));
+    }
   }
-  // NaN must not be lost by the max
-  if (mag != mag) mag = __longlong_as_double(0x7ff0000000000000LL);
   mag = wave_max(mag);
-  if ((threadIdx.x & 63) == 0 && mag > 0.0) atomic_max_pos(resbits, mag);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mag;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mag = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (mag > 0.0) atomic_max_pos(resbits, mag);
+  }
+}
+
+// several vectors moved by one launch (staging of caller pointers into the
+// handle's fixed buffers, so that the numeric sequences can be replayed as graphs)
+struct CopyList {
+  const double *src[6];
+  double *dst[6];
+  int len[6];
+};
+__global__ void k_copy_vectors(CopyList L, int nvec) {
+  for (int v = 0; v < nvec; v++) {
+    const double *__restrict__ s = L.src[v];
+    double *__restrict__ d = L.dst[v];
+    if (!s || !d) continue;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < L.len[v]; i += gridDim.x * blockDim.x) d[i] = s[i];
+  }
 }
 
 // d <- d + alpha e over the four blocks (v_mltadd, hqp/Hqp_IpMatrix.C:103-106)
