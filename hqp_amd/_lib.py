@@ -31,7 +31,7 @@ SYMBOLS = [
 class Opts(C.Structure):
     _fields_ = [("mode", C.c_int), ("device", C.c_int), ("loc", C.c_int), ("tol", C.c_double),
                 ("eps", C.c_double), ("pivot_eps", C.c_double), ("leaf_size", C.c_int),
-                ("max_pivots", C.c_int), ("reserved", C.c_int * 6)]
+                ("max_pivots", C.c_int), ("zd_policy", C.c_int), ("reserved", C.c_int * 5)]
 
 
 class Stats(C.Structure):

@@ -127,7 +127,7 @@ void transpose(const Analysis::Csr &M, int cols, Analysis::Csr &T) {
 
 int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *Qi,
                   const int *Ap, const int *Ai, const int *Cp, const int *Ci, int leaf_size,
-                  int max_pivots) {
+                  int max_pivots, int zd_policy) {
   mode = mode_, n = n_, me = me_, m = m_;
   if (n < 0 || me < 0 || m < 0 || n + me + m == 0) return 1;
   if (!csr_ok(n, n, Qp, Qi) || !csr_ok(me, n, Ap, Ai) || !csr_ok(m, n, Cp, Ci)) return 6;
@@ -434,24 +434,37 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
     for (int r = 0; r < dim; r++) {
       const int q = pos2q[r];
-      if (has_diag[q] || partner[q] < 0) continue;
-      const int sn = lnode_of_pos[r], t = node_of_q(partner[q]);
+      if (has_diag[q]) continue;
+      const int sn = lnode_of_pos[r];
+      int t = sn;
+      bool all_diag = true;
+      for (int k = gstart[q]; k < gstart[q + 1]; k++) all_diag = all_diag && has_diag[gneigh[k]];
+      if (zd_policy == 2 && all_diag) {
+        // behind ALL its neighbours: the node of the last eliminated neighbour.  The
+        // pivot is then the complete Schur complement (e.g. A Q^-1 A' for an equality
+        // multiplier), never a partial sum that is tiny against the border entries.
+        for (int k = gstart[q]; k < gstart[q + 1]; k++) t = std::max(t, node_of_q(gneigh[k]));
+      } else if (partner[q] >= 0) {
+        t = node_of_q(partner[q]);
+      }
       if (t <= sn || lverts[sn].size() <= 1) continue;
       lverts[sn].erase(std::find(lverts[sn].begin(), lverts[sn].end(), r));
       lverts[t].push_back(r);
       lnode_of_pos[r] = t;
     }
-    // order inside a node: band order, a zero-diagonal variable right behind its
-    // partner when the partner is in the same node
+    // order inside a node: band order; a zero-diagonal variable right behind its
+    // partner (policy 0) or behind every variable that carries a diagonal (1, 2)
     std::vector<std::vector<int>> followers(dim);
     for (int id = 0; id < nlog; id++) {
       std::vector<int> &v = lverts[id];
       std::sort(v.begin(), v.end());
-      std::vector<int> heads;
+      std::vector<int> heads, tail;
       for (int r : v) {
         const int q = pos2q[r];
         const int pq = has_diag[q] ? -1 : partner[q];
-        if (pq >= 0 && lnode_of_pos[qp2j[pq]] == id)
+        if (zd_policy != 0 && !has_diag[q])
+          tail.push_back(r);
+        else if (pq >= 0 && lnode_of_pos[qp2j[pq]] == id)
           followers[qp2j[pq]].push_back(r);
         else
           heads.push_back(r);
@@ -461,6 +474,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
         out.push_back(r);
         for (int f : followers[r]) out.push_back(f);
       }
+      out.insert(out.end(), tail.begin(), tail.end());
       v.swap(out);
     }
   }

@@ -67,7 +67,8 @@ struct Analysis {
   long long nnz_factor = 0, flops_factor = 0;
 
   int run(int mode, int n, int me, int m, const int *Qp, const int *Qi, const int *Ap,
-          const int *Ai, const int *Cp, const int *Ci, int leaf_size, int max_pivots);
+          const int *Ai, const int *Cp, const int *Ci, int leaf_size, int max_pivots,
+          int zd_policy = 0);
 };
 
 static const int UPD_TILE = 64;   // Schur-update tile edge (rows/cols per workgroup)

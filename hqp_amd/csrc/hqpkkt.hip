@@ -531,6 +531,7 @@ int hqpkkt_default_opts(hqpkkt_opts *o) {
   o->pivot_eps = 1e-20;  // only (near-)exact zeros are replaced: the reference accepts any non-zero pivot
   o->leaf_size = 0;
   o->max_pivots = 0;
+  o->zd_policy = 2;
   return 0;
 }
 
@@ -584,7 +585,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->analyzed = false;
   h->an = Analysis();
   int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
-                    h->opts.max_pivots);
+                    h->opts.max_pivots, h->opts.zd_policy);
   if (e) return e;
   h->analyzed = true;
   Analysis &an = h->an;

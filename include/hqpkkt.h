@@ -62,7 +62,10 @@ typedef struct hqpkkt_opts {
   double pivot_eps;  /* static pivot perturbation, relative to max|K_ij|      */
   int leaf_size;     /* nested-dissection leaf size in rows (0 = default)     */
   int max_pivots;    /* max pivots per supernode, <= 128 (0 = default)        */
-  int reserved[6];
+  int zd_policy;     /* placement of variables with a structurally zero diagonal
+                        (equality multipliers): 2 = behind all their neighbours
+                        (default), 0 = behind one matched neighbour             */
+  int reserved[5];
 } hqpkkt_opts;
 
 typedef struct hqpkkt_stats {

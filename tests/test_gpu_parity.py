@@ -157,3 +157,57 @@ def test_full_size_c2_properties():
     d3 = new_d(prog)
     M.solve(prog, *st, *d3)
     assert rel_err(d3, d) <= 1e-12
+
+
+def _empty_block():
+    return (np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+
+
+@pytest.mark.parametrize("kind", KINDS)
+def test_edge_shapes(kind):
+    """Tiny and degenerate shapes the reference's callers can produce: no
+    equalities, no inequalities (Hqp_IpsMehrotra passes zero-length z, w, r3, r4,
+    hqp/Hqp_IpsMehrotra.C:364-415), a 3-variable program."""
+    rng = np.random.default_rng(3)
+    base = problems.banded_qp(40, 3, 2)
+    cases = {
+        "no_eq": problems.Program(base.n, 0, base.m, base.Q, _empty_block(), base.C),
+        "no_ineq": problems.Program(base.n, base.me, 0, base.Q, base.A, _empty_block()),
+        "tiny": problems.banded_qp(3, 1, 1),
+    }
+    for name, prog in cases.items():
+        if prog.m == 0:
+            # without inequalities the KKT matrix [-Q A'; A 0] must have full row rank A: ok here
+            pass
+        st = problems.ip_state(prog, 4)
+        M = CLS[kind]()
+        M.init(prog)
+        M.factor(prog, st[0], st[1])
+        d = new_d(prog)
+        res = M.solve(prog, *st, *d)
+        O = oracleapi.OracleIpMatrix(kind)
+        O.init(prog)
+        O.factor(st[0], st[1])
+        osol, ores = O.solve(*st)
+        assert M.mat_sbw == O.sbw, name
+        assert res <= ores + RES_TOL, (name, res, ores)
+        assert rel_err(d, osol) <= 1e-7, (name, rel_err(d, osol))
+
+
+def test_reinit_and_two_handles():
+    """init() again with another structure on the same object (the reference
+    re-inits on sqp_init) and two plugin objects alive at once."""
+    a, b = problems.banded_qp(200, 6, 1), problems.did_like_qp(60)
+    M1, M2 = ipmatrix.IpSpBKP(), ipmatrix.IpRedSpBKP()
+    for prog in (a, b, a):
+        st = problems.ip_state(prog, 9)
+        for M, kind in ((M1, "SpBKP"), (M2, "RedSpBKP")):
+            M.init(prog)
+            M.factor(prog, st[0], st[1])
+            d = new_d(prog)
+            res = M.solve(prog, *st, *d)
+            O = oracleapi.OracleIpMatrix(kind)
+            O.init(prog)
+            O.factor(st[0], st[1])
+            osol, ores = O.solve(*st)
+            assert res <= ores + RES_TOL and rel_err(d, osol) <= 1e-7
