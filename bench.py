@@ -89,6 +89,30 @@ def cpu_baseline(prog, state, budget_s=25.0):
                       "C oracle; oracle/_ref not loadable on this box"}
 
 
+def ip_iterations(K=2000):
+    """Second half of BASELINE.json's metric, IP-iterations/s: the REFERENCE's own
+    Hqp_IpsMehrotra (oracle/_ref/libhqphost_hip.so, built from the reference sources)
+    solving the double-integrator-like QP of config C3 once with the reference plugin
+    and once with ours (shim/Hqp_IpSpBKPHip.C -> C ABI -> HIP, host pointers as in a
+    real HQP run).  None when that library did not travel to this box."""
+    try:
+        from oracle import refapi
+        if not refapi.host_available("hip"):
+            return None
+        from hqp_amd import problems
+        prog = problems.did_like_qp(K)
+        out = {"workload": f"C3-like Prg_DID structure K={K}: n={prog.n} me={prog.me} m={prog.m}, Hqp_IpsMehrotra, "
+                           "plugin RedSpBKP (reference default) vs RedSpBKPHip"}
+        refapi.ip_solve(prog, "Mehrotra", "RedSpBKPHip", host="hip")  # warm-up (analysis upload, graphs)
+        for key, mat in (("reference_cpu", "RedSpBKP"), ("hip", "RedSpBKPHip")):
+            r = refapi.ip_solve(prog, "Mehrotra", mat, host="hip")
+            out[key] = {"iters": r["iters"], "result": r["result"], "seconds": r["seconds"],
+                        "ip_iters_per_s": r["iters"] / r["seconds"] if r["seconds"] > 0 else None}
+        return out
+    except Exception as e:  # never let the secondary measurement break the bench line
+        return {"error": str(e)}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -214,6 +238,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prog, state)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            out["ip_iterations"] = ip_iterations(2000)
+            out["ip_iterations_large"] = ip_iterations(33333)
         print(json.dumps(out))
     kdist.finalize()
 

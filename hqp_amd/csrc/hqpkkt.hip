@@ -285,7 +285,8 @@ static int upload(hqpkkt_t *h) {
   }
   // dynamic LDS budgets
   const size_t mp = an.max_npiv, ldm = mp | 1, nbm = (mp + 15) / 16;
-  h->lds_diag = (ldm * mp + 5 * 128 + 2 * mp) * sizeof(double) + 2 * mp * sizeof(int) + 16;
+  h->lds_diag = (std::max<size_t>(ldm * mp, 2 * 128 * FD_PANEL) + 5 * 128 + 2 * mp) * sizeof(double) +
+                2 * mp * sizeof(int) + 16;
   h->lds_panel = (32 * mp + PS_COLS * mp + 256) * sizeof(double);
   h->lds_solve = (ldm * mp + 2 * mp + nbm * 256) * sizeof(double);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);

@@ -247,6 +247,7 @@ __global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
 // of the 16x16 diagonal blocks of L11 used by the triangular solves.
 #define DB 16
 #define FD_THREADS 512
+#define FD_PANEL 16
 typedef double PatchT[8][4];  // [row strip m][column strip n]
 
 // Dynamic strip selection is written as chains of selects on VALUES (uniform
@@ -325,8 +326,8 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   double *a = lds;                  // ld * p: staging at load and write-back
   // 128-entry vectors (the patch is zero padded beyond p, so they are written and
   // read without bounds predicates)
-  double *cbuf0 = a + ld * p;       // pivot column, even steps
-  double *cbuf1 = cbuf0 + 128;      // pivot column, odd steps
+  double *cbuf0 = a + max(ld * p, 2 * 128 * FD_PANEL);  // behind the staging image / panel
+  double *cbuf1 = cbuf0 + 128;      // (spare)
   double *cbr = cbuf1 + 128;        // column r (second column of a 2x2)
   double *xb0 = cbr + 128, *xb1 = xb0 + 128;  // row / column exchange
   double *dv = xb1 + 128;           // 2p: inverse pivot data per position
@@ -350,10 +351,110 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   patch_put_col(A, 0, tx, ty, p, cbuf0);
   __syncthreads();
 
-  int k = 0, step = 0;
+  // LDS panel of the fast path (aliases the staging image, which is idle in the loop):
+  // Pc[i + 128 jj] = current column k+jj (unscaled), Pl[i + 128 jj] = its multipliers
+  double *Pc = a, *Pl = a + 128 * FD_PANEL;
+  int k = 0;
   while (k < p) {
     k = __builtin_amdgcn_readfirstlane(k);  // wave-uniform: keep it scalar
-    double *cur = (step & 1) ? cbuf1 : cbuf0, *nxt = (step & 1) ? cbuf0 : cbuf1;
+    // ======== fast path: up to FD_PANEL consecutive 1x1 pivots without interchange ========
+    // The panel columns are published to LDS once; each pivot then costs one arg-max
+    // search, one rank-1 update of the (<= 16-column) LDS panel and one barrier.  The
+    // register patches receive the pivots' rank-1 updates afterwards in one sweep.
+    {
+      const int kb = min(FD_PANEL, p - k);
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        const int jj = tx + 32 * n - k;  // panel slot of this thread's column strip n
+        if (jj >= 0 && jj < kb) {
+#pragma unroll
+          for (int m = 0; m < 8; m++) Pc[ty + 16 * m + 128 * jj] = A[m][n];
+        }
+      }
+      __syncthreads();
+      int done = 0;
+      bool slow = false;
+      for (int kk = 0; kk < kb; kk++) {
+        const int kc = k + kk;
+        const double *col = Pc + 128 * kk;
+        const int i1 = kc + 1 + lane, i2 = i1 + 64;
+        const double v1 = col[i1 & 127], v2 = col[i2 & 127], vkk = col[kc];
+        const float t1 = i1 < p ? fabsf((float)v1) : -1.0f;
+        const float t2 = i2 < p ? fabsf((float)v2) : -1.0f;
+        const float tmax = wave_max_dpp_f(fmaxf(fmaxf(t1, t2), 0.0f));
+        int r = p;
+        {
+          const unsigned long long m1 = __ballot(t1 == tmax), m2 = __ballot(t2 == tmax);
+          if (m1)
+            r = kc + 1 + __builtin_ctzll(m1);
+          else if (m2)
+            r = kc + 65 + __builtin_ctzll(m2);
+        }
+        r = __builtin_amdgcn_readfirstlane(r);
+        const double lambda = r < p ? fabs(col[r]) : 0.0;
+        if (r < p && !(fabs(vkk) >= alpha * lambda)) {  // needs the full Bunch-Kaufman test
+          slow = true;
+          break;
+        }
+        double d = vkk;
+        bool pertd = false;
+        if (!(fabs(d) >= pert)) {
+          d = (double)esign[e0 + lp[kc]] * pert;
+          pertd = true;
+        }
+        const double di = fast_rcp(d);
+        if (tid == 0) {
+          dv[2 * kc] = di, dv[2 * kc + 1] = 0.0, pt[kc] = 0;
+          if (pertd) atomicAdd(&counters[1], 1);
+        }
+        {
+          const int i = tid & 127, grp = tid >> 7;  // row, column group (4 groups)
+          // columns kk+1+grp, +4, +8, +12 of the panel: all loads first
+          double cj[4], pv[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int jj = kk + 1 + grp + 4 * u;
+            const bool on = jj < kb;
+            cj[u] = on ? col[(k + jj) & 127] : 0.0;
+            pv[u] = on ? Pc[i + 128 * (jj & (FD_PANEL - 1))] : 0.0;
+          }
+          const double li = (i > kc) ? col[i] * di : 0.0;
+          if (grp == 0) Pl[i + 128 * kk] = li;
+#pragma unroll
+          for (int u = 0; u < 4; u++) {
+            const int jj = kk + 1 + grp + 4 * u;
+            if (jj < kb) Pc[i + 128 * jj] = fma(-li, cj[u], pv[u]);
+          }
+        }
+        __syncthreads();
+        done++;
+      }
+      // registers <- registers - sum_t l_t c_t'  (rows / columns <= k+t are masked out;
+      // the panel's own columns end up equal to their LDS images)
+#pragma unroll
+      for (int t = 0; t < FD_PANEL; t++) {
+        if (t < done) {  // uniform
+          double lt[8], ct[4];
+#pragma unroll
+          for (int m = 0; m < 8; m++) lt[m] = Pl[ty + 16 * m + 128 * t];
+#pragma unroll
+          for (int n = 0; n < 4; n++) ct[n] = Pc[tx + 32 * n + 128 * t];
+#pragma unroll
+          for (int n = 0; n < 4; n++) ct[n] = (tx + 32 * n > k + t) ? ct[n] : 0.0;
+#pragma unroll
+          for (int m = 0; m < 8; m++)
+#pragma unroll
+            for (int n = 0; n < 4; n++) A[m][n] = fma(-lt[m], ct[n], A[m][n]);
+        }
+      }
+      k += done;
+      __syncthreads();  // the panel is re-used by the next publish
+      if (!slow) continue;
+    }
+    // ======== slow path: one pivot with the complete test, interchanges, 2x2 pivots ========
+    double *cur = cbuf0;
+    patch_put_col(A, k, tx, ty, p, cur);
+    __syncthreads();
     // ---- decision, redundantly per wave --------------------------------------
     // column max and its first row index r (hqp/spBKP.C:431-437): two candidates
     // per lane, the arg-max search in fp32 (DPP max + ballot), lambda re-read in fp64
@@ -490,8 +591,6 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
       }
       k += 2;
     }
-    if (k < p) patch_put_col(A, k, tx, ty, p, nxt);
-    step++;
     __syncthreads();
   }
   // ---- registers -> LDS (lower triangle), then scale the columns: L = C D^-1 ------
