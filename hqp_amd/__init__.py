@@ -9,7 +9,7 @@ from .problems import Program  # noqa: F401
 
 
 def __getattr__(name):
-    if name in ("Hqp_IpMatrix", "Hqp_IpSpBKP", "Hqp_IpRedSpBKP", "IpSpBKP", "IpRedSpBKP",
+    if name in ("Hqp_IpMatrix", "Hqp_IpSpBKP", "Hqp_IpRedSpBKP", "Hqp_IpLQDOCP", "IpSpBKP", "IpRedSpBKP", "IpLQDOCP",
                 "SingularError", "KktError", "selftest_mfma"):
         from . import ipmatrix
         return getattr(ipmatrix, name)

@@ -234,8 +234,16 @@ class Hqp_IpRedSpBKP(Hqp_IpMatrix):
     _name = "RedSpBKP"
 
 
+class Hqp_IpLQDOCP(Hqp_IpMatrix):
+    """Stand-in for the multistage plugin hqp/Hqp_IpLQDOCP.C: same KKT system, solved
+    by the full-system engine (the band ordering carries the stage structure)."""
+    _mode = _lib.MODE_FULL
+    _name = "LQDOCP"
+
+
 IpSpBKP = Hqp_IpSpBKP
 IpRedSpBKP = Hqp_IpRedSpBKP
+IpLQDOCP = Hqp_IpLQDOCP
 
 
 def selftest_mfma(device=0):

@@ -20,6 +20,7 @@
 #include <Hqp_Program.h>
 #include <Hqp_IpSpBKP.h>
 #include <Hqp_IpRedSpBKP.h>
+#include <Hqp_IpLQDOCP.h>
 
 namespace {
 
@@ -44,7 +45,7 @@ struct ProbeRedSpBKP : public Hqp_IpRedSpBKP {
 };
 
 struct Handle {
-  int kind;  // 0 SpBKP, 1 RedSpBKP
+  int kind;  // 0 SpBKP, 1 RedSpBKP, 2 LQDOCP (multistage Riccati, hqp/Hqp_IpLQDOCP.C)
   ProbeSpBKP *full;
   ProbeRedSpBKP *red;
   Hqp_IpMatrix *mat;
@@ -106,9 +107,11 @@ void *hqpref_create(int kind) {
   if (kind == 0) {
     h->full = new ProbeSpBKP;
     h->mat = h->full;
-  } else {
+  } else if (kind == 1) {
     h->red = new ProbeRedSpBKP;
     h->mat = h->red;
+  } else {
+    h->mat = new Hqp_IpLQDOCP;  // no probe: only the virtual interface is used
   }
   return h;
 }
@@ -118,7 +121,7 @@ void hqpref_set_params(void *hv, double tol, double eps) {
   if (h->full) {
     h->full->set_tol(tol);
     h->full->set_eps(eps);
-  } else {
+  } else if (h->red) {
     h->red->set_tol(tol);
     h->red->set_eps(eps);
   }
@@ -254,12 +257,12 @@ int hqpref_residuum(void *hv, const double *z, const double *w,
 
 int hqpref_sbw(void *hv) {
   Handle *h = (Handle *)hv;
-  return h->full ? h->full->sbw() : h->red->sbw();
+  return h->full ? h->full->sbw() : h->red ? h->red->sbw() : -1;
 }
 
 int hqpref_dim(void *hv) {
   Handle *h = (Handle *)hv;
-  return h->full ? h->n + h->me + h->m : h->n + h->me;
+  return h->red ? h->n + h->me : h->n + h->me + h->m;
 }
 
 void hqpref_get_perm(void *hv, int *qp2j) {

@@ -84,7 +84,7 @@ class RefIpMatrix:
             raise RuntimeError(f"oracle/_ref/libhqpref.so not loadable: {_err}")
         self._lib = lib
         self.kind = kind
-        self._h = lib.hqpref_create({"SpBKP": 0, "RedSpBKP": 1}[kind])
+        self._h = lib.hqpref_create({"SpBKP": 0, "RedSpBKP": 1, "LQDOCP": 2}[kind])
         if not self._h:
             raise RuntimeError("hqpref_create failed (Tcl interpreter?)")
         lib.hqpref_set_params(self._h, tol, eps)

@@ -18,6 +18,7 @@
 
 IF_CLASS_DEFINE("SpBKPHip", Hqp_IpSpBKPHip, Hqp_IpMatrix);
 IF_CLASS_DEFINE("RedSpBKPHip", Hqp_IpRedSpBKPHip, Hqp_IpMatrix);
+IF_CLASS_DEFINE("LQDOCPHip", Hqp_IpLQDOCPHip, Hqp_IpMatrix);
 
 //--------------------------------------------------------------------------
 Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)

@@ -9,6 +9,7 @@
  * (iftcl/If_Class.h:53-60):
  *     qp_mat_solver SpBKPHip      -- semantics of Hqp_IpSpBKP    (full system)
  *     qp_mat_solver RedSpBKPHip   -- semantics of Hqp_IpRedSpBKP (reduced)
+ *     qp_mat_solver LQDOCPHip     -- stands in for Hqp_IpLQDOCP (same system, full engine)
  * Hqp_IpsMehrotra / Hqp_IpsFranke / Hqp_SqpSolver call them unchanged through
  * the Hqp_IpMatrix virtual interface (hqp/Hqp_IpMatrix.h:63-88).
  */
@@ -62,6 +63,18 @@ class Hqp_IpRedSpBKPHip : public Hqp_IpMatrixHip {
  public:
   Hqp_IpRedSpBKPHip() : Hqp_IpMatrixHip(1) {}
   const char *name() { return "RedSpBKPHip"; }
+};
+
+// Drop-in for users that select the multistage plugin (hqp_docp/Docp_Main.C:42-49,
+// odc/crane.tcl:58: qp_mat_solver LQDOCP).  Hqp_IpLQDOCP solves the SAME KKT system
+// with an extended Riccati recursion over the stages (hqp/Hqp_IpLQDOCP.C:796-976);
+// here the stage structure is exploited through the band ordering instead: the
+// nested dissection of the RCM band cuts between stages, which is the tree-parallel
+// form of that recursion.  Unlike the reference it does not require DOCP structure.
+class Hqp_IpLQDOCPHip : public Hqp_IpMatrixHip {
+ public:
+  Hqp_IpLQDOCPHip() : Hqp_IpMatrixHip(0) {}
+  const char *name() { return "LQDOCPHip"; }
 };
 
 #endif

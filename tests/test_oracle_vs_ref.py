@@ -36,3 +36,18 @@ def test_oracle_equals_reference(case, kind):
     (dr, rr), (do, ro) = R.solve(*st), O.solve(*st)
     assert rel_err(do, dr) <= 1e-12
     assert abs(rr - ro) <= 1e-13 * max(1.0, rr)
+
+
+@pytest.mark.parametrize("K,spread", [(50, 0.0), (50, 3.0), (200, 1.0)])
+def test_reference_lqdocp_solves_the_same_system(K, spread):
+    """Hqp_IpLQDOCP (multistage Riccati, hqp/Hqp_IpLQDOCP.C) and Hqp_IpSpBKP are two
+    algorithms for one KKT system: on a DOCP-structured QP they agree, which is what
+    lets the full-system engine stand in for LQDOCP."""
+    prog = problems.did_like_qp(K)
+    st = problems.ip_state(prog, 11, spread)
+    L, O = refapi.RefIpMatrix("LQDOCP"), oracleapi.OracleIpMatrix("SpBKP")
+    L.init(prog), O.init(prog)
+    L.factor(st[0], st[1]), O.factor(st[0], st[1])
+    (dl, rl), (do, ro) = L.solve(*st), O.solve(*st)
+    assert rl <= 1e-8 and ro <= 1e-8
+    assert rel_err(dl, do) <= 1e-6

@@ -48,11 +48,13 @@ def test_hip_plugin_fails_loudly_without_gpu():
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["Mehrotra", "Franke"])
-@pytest.mark.parametrize("pair", [("SpBKP", "SpBKPHip"), ("RedSpBKP", "RedSpBKPHip")])
+@pytest.mark.parametrize("pair", [("SpBKP", "SpBKPHip"), ("RedSpBKP", "RedSpBKPHip"), ("LQDOCP", "LQDOCPHip")])
 @pytest.mark.parametrize("case", ["did50", "did400", "banded"])
 def test_reference_ip_solver_drives_hip_plugin(solver, pair, case):
     if not refapi.host_available("hip"):
         pytest.skip("oracle/_ref/libhqphost_hip.so not present")
+    if pair[0] == "LQDOCP" and case == "banded":
+        pytest.skip("Hqp_IpLQDOCP asserts DOCP structure (hqp/Hqp_IpLQDOCP.C:701,706,730)")
     prog = {"did50": lambda: problems.did_like_qp(50), "did400": lambda: problems.did_like_qp(400),
             "banded": lambda: problems.banded_qp(300, 8, 5)}[case]()
     ref = refapi.ip_solve(prog, solver, pair[0], host="hip")
@@ -65,8 +67,16 @@ def test_reference_ip_solver_drives_hip_plugin(solver, pair, case):
         # notes "deg" for Mehrotra on Prg_DID); ours may finish "optimal" there.  The
         # same optimiser is still required.
         assert abs(fr - fh) <= 1e-5 * max(1.0, abs(fr)), info
-        if ref["result"] == 3:  # stalled, not aborted: comparable iteration counts
+        if ref["result"] == 3 and hip["result"] == 3:  # both stalled: comparable counts
             assert hip["iters"] <= ref["iters"] + 5, info
+        return
+    if pair[0] == "LQDOCP":
+        # the reference's Riccati recursion and its own SpBKP already differ in iteration
+        # counts on this problem (Franke: 67 vs 54); our stand-in follows SpBKP.  Same
+        # optimiser, same termination, not more iterations than the reference needs.
+        assert hip["result"] == ref["result"] or (hip["result"] == 0 and ref["result"] in (3, 4)), info
+        assert abs(fr - fh) <= 1e-5 * max(1.0, abs(fr)), info
+        assert hip["iters"] <= ref["iters"] + max(2, ref["iters"] // 10), info
         return
     assert hip["result"] == ref["result"], info
     # Mehrotra ignores the residual solve() returns; Franke tests it against qp_eps
