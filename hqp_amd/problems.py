@@ -112,6 +112,61 @@ def did_like_qp(K, qx=1e-4):
     return Program(n, me, m, Q, A, C, c=np.zeros(n), b=b, d=np.full(m, 0.01))
 
 
+def lq_docp(K, nx, nu, seed=3, density=1.0):
+    """Multistage LQ optimal-control QP (config 4 of BASELINE.json at a chosen size) in
+    the layout Hqp_Docp::setup_qp produces (hqp/Hqp_Docp.C:585-755) and
+    Hqp_IpLQDOCP::Get_Dim expects (hqp/Hqp_IpLQDOCP.C:201-287):
+    x = [x_0, u_0, x_1, u_1, ..., x_K]; A = K*nx dynamics rows
+    fx x_k + fu u_k - x_{k+1} (the -1.0 is the last entry of each row), then nx
+    initial-state equalities; C = box bounds on every u (2 K nu rows);
+    Q = block diagonal (I + low rank on x_k, 0.1 I on u_k), upper stored.
+    fx is a dense random matrix scaled to spectral radius ~0.9, fu dense random."""
+    rng = np.random.default_rng(seed)
+    nz = nx + nu
+    n = K * nz + nx
+    xi = lambda k: k * nz
+    ui = lambda k: k * nz + nx
+    fx = rng.uniform(-1, 1, (nx, nx))
+    if density < 1.0:
+        fx *= rng.uniform(0, 1, (nx, nx)) < density
+    fx *= 0.9 / max(np.abs(np.linalg.eigvals(fx)).max(), 1e-12)
+    fu = rng.uniform(-1, 1, (nx, nu))
+    # Q
+    qr, qc, qv = [], [], []
+    low = rng.uniform(-0.3, 0.3, (nx, 2))
+    Lxx = np.eye(nx) + low @ low.T
+    iu, ju = np.triu_indices(nx)
+    for k in range(K + 1):
+        qr.append(xi(k) + iu), qc.append(xi(k) + ju), qv.append(Lxx[iu, ju])
+        if k < K:
+            qr.append(ui(k) + np.arange(nu)), qc.append(ui(k) + np.arange(nu)), qv.append(np.full(nu, 0.1))
+    Q = _csr(np.concatenate(qr), np.concatenate(qc), np.concatenate(qv), n)
+    # A: dynamics (columns ascending: x_k, u_k, then the single -1 on x_{k+1})
+    ar, ac, av = [], [], []
+    rows = np.arange(nx)
+    for k in range(K):
+        r0 = k * nx
+        rr = np.repeat(r0 + rows, nx)
+        ar.append(rr), ac.append(xi(k) + np.tile(np.arange(nx), nx)), av.append(fx.ravel())
+        rr = np.repeat(r0 + rows, nu)
+        ar.append(rr), ac.append(ui(k) + np.tile(np.arange(nu), nx)), av.append(fu.ravel())
+        ar.append(r0 + rows), ac.append(xi(k + 1) + rows), av.append(np.full(nx, -1.0))
+    ar.append(K * nx + rows), ac.append(xi(0) + rows), av.append(np.ones(nx))
+    ar, ac, av = np.concatenate(ar), np.concatenate(ac), np.concatenate(av)
+    keep = av != 0.0
+    me = K * nx + nx
+    A = _csr(ar[keep], ac[keep], av[keep], me)
+    b = np.zeros(me)
+    b[K * nx:] = -rng.uniform(-1, 1, nx)  # x_0 fixed
+    # C: -1 <= u <= 1
+    m = 2 * K * nu
+    cr = np.arange(m)
+    cc = np.concatenate([[ui(k) + j for j in range(nu)] * 2 for k in range(K)]) if K else np.zeros(0, int)
+    cv = np.concatenate([np.concatenate([np.ones(nu), -np.ones(nu)]) for _ in range(K)]) if K else np.zeros(0)
+    C = _csr(cr, cc, cv, m)
+    return Program(n, me, m, Q, A, C, c=rng.uniform(-0.1, 0.1, n), b=b, d=np.ones(m))
+
+
 def random_sparse_qp(n, me, m, row_nnz=4, seed=7):
     """Irregular (non-banded) QP: random sparse A, C rows, Q = diag + random
     symmetric sparse part made diagonally dominant.  Exercises the general path."""

@@ -211,3 +211,31 @@ def test_reinit_and_two_handles():
             O.factor(st[0], st[1])
             osol, ores = O.solve(*st)
             assert res <= ores + RES_TOL and rel_err(d, osol) <= 1e-7
+
+
+@pytest.mark.parametrize("shape", [(10, 6, 2), (40, 16, 4)])
+def test_multistage_docp_against_reference_lqdocp(shape):
+    """Config 4 structure (multistage LQ DOCP) at test size: the full-system engine,
+    under the plugin name LQDOCP, against the REFERENCE's Riccati-based Hqp_IpLQDOCP
+    (from oracle/_ref when it travelled to this box) and against the oracle."""
+    from oracle import refapi
+    K, nx, nu = shape
+    prog = problems.lq_docp(K, nx, nu)
+    st = problems.ip_state(prog, 3, 1.0)
+    M = ipmatrix.IpLQDOCP()
+    assert M.name() == "LQDOCP"
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    O = oracleapi.OracleIpMatrix("SpBKP")
+    O.init(prog)
+    O.factor(st[0], st[1])
+    osol, ores = O.solve(*st)
+    assert res <= ores + RES_TOL and rel_err(d, osol) <= SOL_TOL
+    if refapi.available():
+        L = refapi.RefIpMatrix("LQDOCP")
+        L.init(prog)
+        L.factor(st[0], st[1])
+        lsol, lres = L.solve(*st)
+        assert res <= lres + RES_TOL and rel_err(d, lsol) <= 1e-7
