@@ -614,8 +614,15 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   for (int l = 0; l < nlevels; l++) level_ptr[l + 1] += level_ptr[l];
   level_nodes.assign(nnodes, 0);
   {
+    // inside a level the supernodes with at most SMALL_PIVOTS pivots come first:
+    // they are factored by the one-wavefront kernel
     std::vector<int> fill(level_ptr.begin(), level_ptr.end() - 1);
-    for (int id = 0; id < nnodes; id++) level_nodes[fill[level[id]]++] = id;
+    for (int id = 0; id < nnodes; id++)
+      if (npiv[id] <= SMALL_PIVOTS) level_nodes[fill[level[id]]++] = id;
+    level_small.assign(nlevels, 0);
+    for (int l = 0; l < nlevels; l++) level_small[l] = fill[l] - level_ptr[l];
+    for (int id = 0; id < nnodes; id++)
+      if (npiv[id] > SMALL_PIVOTS) level_nodes[fill[level[id]]++] = id;
   }
   // extend-add segments: for parent level l, slot s -> children list
   ea_level_ptr.assign(nlevels + 1, 0);

@@ -41,6 +41,7 @@ struct Analysis {
   long long panel_elems = 0, upd_elems = 0, x_elems = 0, cb_elems = 0;
   std::vector<long long> cb_off;  // contribution-vector offsets (solve)
   std::vector<int> level_ptr, level_nodes;  // nodes grouped by level
+  std::vector<int> level_small;             // per level: leading nodes with npiv <= SMALL_PIVOTS
   // children grouped by (parent level, slot) for deterministic extend-add
   std::vector<int> ea_seg_ptr, ea_nodes, ea_level_ptr;  // segments per level
   // children lists (for the solve gather)
@@ -73,5 +74,6 @@ struct Analysis {
 
 static const int UPD_TILE = 64;   // Schur-update tile edge (rows/cols per workgroup)
 static const int SLAB_ROWS = 32;  // border rows per panel-solve workgroup
+static const int SMALL_PIVOTS = 32;  // supernodes up to this size use k_factor_diag_small
 
 }  // namespace kktdev

@@ -358,6 +358,7 @@ static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double 
   return 0;
 }
 
+static_assert(FS_MAXP == kktdev::SMALL_PIVOTS, "small-supernode kernel and schedule disagree");
 // ------------------------------------------------------------ numeric phases
 static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
   Analysis &an = h->an;
@@ -387,8 +388,14 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
       KLAUNCH(h, KC_EXTEND_ADD, k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, h->ea_nodes.p + an.ea_seg_ptr[seg],
                                                      h->panel.p, h->upd.p));
     }
-    const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
-    KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn, FD_THREADS, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
+    const int nn = an.level_ptr[l + 1] - an.level_ptr[l], nsm = an.level_small[l];
+    if (nsm > 0)
+      KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<<<nsm, 64, 0, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
+                                               h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
+                                               h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                               h->flags.p + 1));
+    if (nn > nsm)
+      KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nsm, FD_THREADS, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l] + nsm, h->panel.p,
                                                h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
                                                h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                h->flags.p + 1));

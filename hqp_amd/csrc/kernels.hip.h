@@ -657,6 +657,176 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   }
 }
 
+// ---------------------------------------- pivot block of a small supernode
+// Narrow-band systems (Prg_DID: sbw 5) have thousands of supernodes with a
+// handful of pivots each; the 512-thread kernel above would spend its time in
+// barriers and leave the CU to one node at a time.  For p <= FS_MAXP one
+// wavefront factors the block in LDS (full symmetric image, so interchanges are
+// plain row + column swaps) and ~18 nodes are resident per CU.  Same pivoting
+// rules, same outputs as k_factor_diag.
+#define FS_MAXP 32
+#define FS_LD 33
+__global__ void __launch_bounds__(64)
+k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
+                    double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
+                    const signed char *__restrict__ esign, double *__restrict__ dblk,
+                    const long long *__restrict__ dblk_off, double alpha, double pivot_eps,
+                    const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
+  __shared__ double a[FS_MAXP * FS_LD];
+  __shared__ double dv[2 * FS_MAXP];
+  __shared__ int lp[FS_MAXP], pt[FS_MAXP];
+  const int node = level_nodes[blockIdx.x];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const long long F = p + b;
+  const int e0 = T.piv_start[node];
+  double *P = panel + T.panel_off[node];
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const bool row_on = i < p;
+  const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
+  for (int j = h; j < p; j += 2)
+    if (row_on) a[i + j * FS_LD] = (i >= j) ? P[(long long)j * F + i] : P[(long long)i * F + j];
+  if (lane < p) lp[lane] = lane;
+  __syncthreads();
+  int k = 0;
+  while (k < p) {
+    // column max below the diagonal and its first row (hqp/spBKP.C:431-437)
+    const bool below = lane > k && lane < p;
+    const float t1 = below ? fabsf((float)a[lane + k * FS_LD]) : -1.0f;
+    const float tmax = wave_max_dpp_f(fmaxf(t1, 0.0f));
+    const unsigned long long m1 = __ballot(t1 == tmax);
+    int r = m1 ? (int)__builtin_ctzll(m1) : p;
+    r = __builtin_amdgcn_readfirstlane(r);
+    const double akk = fabs(a[k + k * FS_LD]);
+    const double lambda = r < p ? fabs(a[r + k * FS_LD]) : 0.0;
+    int kind = 0;
+    if (r < p && !(akk >= alpha * lambda)) {
+      const double sv = (lane >= k && lane < p && lane != r) ? fabs(a[lane + r * FS_LD]) : 0.0;
+      const double sigma = wave_max_dpp(sv);
+      if (sigma * akk >= alpha * lambda * lambda)
+        kind = 0;
+      else if (fabs(a[r + r * FS_LD]) >= alpha * sigma)
+        kind = 1;
+      else
+        kind = 2;
+    }
+    kind = __builtin_amdgcn_readfirstlane(kind);
+    const int p1 = (kind == 2) ? k + 1 : k;
+    if (kind != 0 && r != p1) {  // symmetric interchange p1 <-> r
+      if (lane < p) {
+        const double x = a[p1 + lane * FS_LD], y = a[r + lane * FS_LD];
+        a[p1 + lane * FS_LD] = y, a[r + lane * FS_LD] = x;
+      }
+      __syncthreads();
+      if (lane < p) {
+        const double x = a[lane + p1 * FS_LD], y = a[lane + r * FS_LD];
+        a[lane + p1 * FS_LD] = y, a[lane + r * FS_LD] = x;
+      }
+      if (lane == 0) {
+        const int t = lp[p1];
+        lp[p1] = lp[r], lp[r] = t;
+      }
+      __syncthreads();
+    }
+    if (kind != 2) {
+      double d = a[k + k * FS_LD];
+      bool pertd = false;
+      if (!(fabs(d) >= pert)) {
+        d = (double)esign[e0 + lp[k]] * pert;
+        pertd = true;
+      }
+      const double di = fast_rcp(d);
+      if (lane == 0) {
+        dv[2 * k] = di, dv[2 * k + 1] = 0.0, pt[k] = 0;
+        if (pertd) atomicAdd(&counters[1], 1), a[k + k * FS_LD] = d;
+      }
+      if (row_on && i > k) {
+        const double li = a[i + k * FS_LD] * di;
+        for (int j = k + 1 + h; j < p; j += 2)
+          a[i + j * FS_LD] = fma(-li, a[j + k * FS_LD], a[i + j * FS_LD]);
+      }
+      k += 1;
+    } else {
+      double d11 = a[k + k * FS_LD], d21 = a[k + 1 + k * FS_LD], d22 = a[k + 1 + (k + 1) * FS_LD];
+      double det = d11 * d22 - d21 * d21;
+      bool pertd = false;
+      if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
+        d11 = (double)esign[e0 + lp[k]] * pert;
+        d22 = (double)esign[e0 + lp[k + 1]] * pert;
+        d21 = 0.0;
+        det = d11 * d22;
+        pertd = true;
+      }
+      const double rdet = fast_rcp(det);
+      const double i11 = d22 * rdet, i21 = -d21 * rdet, i22 = d11 * rdet;
+      if (lane == 0) {
+        dv[2 * k] = i11, dv[2 * k + 1] = i21, dv[2 * k + 2] = i22, dv[2 * k + 3] = i21;
+        pt[k] = 1, pt[k + 1] = 2;
+        atomicAdd(&counters[0], 1);
+        if (pertd) atomicAdd(&counters[1], 2);
+      }
+      if (row_on && i > k + 1) {
+        const double c1 = a[i + k * FS_LD], c2 = a[i + (k + 1) * FS_LD];
+        const double l1 = c1 * i11 + c2 * i21, l2 = c1 * i21 + c2 * i22;
+        for (int j = k + 2 + h; j < p; j += 2)
+          a[i + j * FS_LD] =
+              fma(-l2, a[j + (k + 1) * FS_LD], fma(-l1, a[j + k * FS_LD], a[i + j * FS_LD]));
+      }
+      k += 2;
+    }
+    __syncthreads();
+  }
+  // L = C D^-1 (columns were kept unscaled), then write-back of the lower triangle
+  for (int j = 0; j < p; j++) {
+    const int tj = pt[j];
+    if (tj == 2) continue;
+    if (tj == 0) {
+      if (h == 0 && row_on && i > j) a[i + j * FS_LD] *= dv[2 * j];
+    } else {
+      if (h == 0 && row_on && i > j + 1) {
+        const double i11 = dv[2 * j], i21 = dv[2 * j + 1], i22 = dv[2 * j + 2];
+        const double c1 = a[i + j * FS_LD], c2 = a[i + (j + 1) * FS_LD];
+        a[i + j * FS_LD] = c1 * i11 + c2 * i21;
+        a[i + (j + 1) * FS_LD] = c1 * i21 + c2 * i22;
+      }
+      if (lane == 0) a[j + 1 + j * FS_LD] = 0.0;
+    }
+  }
+  __syncthreads();
+  for (int j = h; j < p; j += 2)
+    if (row_on && i >= j) P[(long long)j * F + i] = a[i + j * FS_LD];
+  if (lane < p) {
+    lperm[e0 + lane] = lp[lane];
+    ptype[e0 + lane] = pt[lane];
+    dinv[2 * (e0 + lane)] = dv[2 * lane];
+    dinv[2 * (e0 + lane) + 1] = dv[2 * lane + 1];
+  }
+  // inverses of the (at most two) 16x16 diagonal blocks of L11
+  double *DBo = dblk + dblk_off[node];
+  const int nb = (p + DB - 1) / DB;
+  const int blk = lane >> 4, c = lane & 15;
+  if (blk < nb) {
+    const int kb = blk * DB, kw = min(DB, p - kb);
+    double x[DB];
+#pragma unroll
+    for (int rr = 0; rr < DB; rr++) x[rr] = (rr == c) ? 1.0 : 0.0;
+#pragma unroll
+    for (int rr = 1; rr < DB; rr++) {
+      double acc0 = 0.0, acc1 = 0.0;
+#pragma unroll
+      for (int t = 0; t < rr; t++) {
+        const double l = (rr < kw) ? a[kb + rr + (kb + t) * FS_LD] : 0.0;
+        if (t & 1)
+          acc1 += l * x[t];
+        else
+          acc0 += l * x[t];
+      }
+      if (rr > c) x[rr] = -(acc0 + acc1);
+    }
+#pragma unroll
+    for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];
+  }
+}
+
 // --------------------------------------------------- panel solve (border rows)
 // X = A21 P' L11^-T,  L21 = X D^-1.  One workgroup per (supernode, 32-row slab),
 // the slab in LDS.  Right-looking over column blocks of 16: the block itself is
