@@ -34,12 +34,16 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 MFMA peak (SURVEY.md 7, 8
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 
 
-def class_work(struct):
+def class_work(struct, rank=None):
     """Algorithmic work per numeric factorisation, split by kernel class, from the
     symbolic structure (p pivots, b border rows per supernode); flops count a
-    multiply-add as 2, the Schur update only its lower triangle."""
+    multiply-add as 2, the Schur update only its lower triangle.  With ``rank`` set
+    (one system sharded over the ranks) only the supernodes that rank factors."""
     p = struct["npiv"].astype(np.float64)
     b = struct["nborder"].astype(np.float64)
+    if rank is not None:
+        mine = (struct["node_owner"] == rank) | (struct["node_owner"] < 0)
+        p, b = p[mine], b[mine]
     return {
         "factor_diag": {"flops": float((p ** 3 / 3.0).sum()), "bytes": float((8 * p * p).sum())},
         "panel_solve": {"flops": float((b * p * p).sum()), "bytes": float((8 * (3 * b * p + p * p / 2)).sum())},
@@ -124,6 +128,13 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-vectors", action="store_true",
                     help="z,w,r*,d* as host pointers (the shim's mode): PCIe-inclusive, never the headline value")
+    ap.add_argument("--one-system", action="store_true",
+                    help="N>1: all ranks factor and solve ONE system together (subtrees of the assembly tree per "
+                         "rank, one all-gather per factor, all-gather + all-reduce per solve over RCCL; strong "
+                         "scaling) instead of one independent system per GPU")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="gloo + --share-gpu: functional check of the N>1 paths on a one-GPU box (not a measurement)")
+    ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0")
     ap.add_argument("--leaf-size", type=int, default=0)
     ap.add_argument("--max-pivots", type=int, default=0)
     args = ap.parse_args()
@@ -135,16 +146,26 @@ def main():
     rank, local_rank, world = kdist.env_world()
     if world != args.gpus and world > 1:
         raise SystemExit(f"WORLD_SIZE={world} but --gpus {args.gpus}")
+    if args.share_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
-    kdist.init("nccl")
+    if args.share_gpu and world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group(args.backend)
+    else:
+        kdist.init(args.backend)
 
     from hqp_amd import ipmatrix, problems
 
-    prog = problems.banded_qp(args.n, args.band, seed=12345 + rank)
-    state = problems.ip_state(prog, seed=1 + rank)
+    one = args.one_system and world > 1
+    seed_off = 0 if one else rank  # one system: every rank holds the same (replicated) inputs
+    prog = problems.banded_qp(args.n, args.band, seed=12345 + seed_off)
+    state = problems.ip_state(prog, seed=1 + seed_off)
     cls = ipmatrix.IpSpBKP if args.mode == "SpBKP" else ipmatrix.IpRedSpBKP
     mat = cls(device=local_rank, device_vectors=not args.host_vectors, leaf_size=args.leaf_size,
-              max_pivots=args.max_pivots)
+              max_pivots=args.max_pivots,
+              shard=(rank, world, kdist.make_exchange(rank, local_rank)) if one else None)
     t0 = time.perf_counter()
     mat.init(prog)  # analysis (host) + upload; one-time, not part of a step
     t_init = time.perf_counter() - t0
@@ -183,7 +204,7 @@ def main():
 
     if rank == 0:
         struct = mat.structure()
-        work = class_work(struct)
+        work = class_work(struct, 0 if one else None)
         per_step = {k: v[0] / nprof for k, v in prof.items()}
         launches = {k: v[1] / nprof for k, v in prof.items()}
         dom = max(work, key=lambda k: per_step.get(k, 0.0))
@@ -209,20 +230,21 @@ def main():
                  "tflops_as_implemented": st["flops_factor"] / (fac_ms * 1e-3) / 1e12 if fac_ms > 0 else None}
         out = {
             "metric": "KKT factor+solve/sec (fp64)",
-            "value": args.steps * world / elapsed,
+            "value": args.steps * (1 if one else world) / elapsed,
             "unit": "KKT factor+solve/s",
             "n_gpus": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps,
             "higher_is_better": True,
-            "scaling": "weak",
+            "scaling": "strong" if one else "weak",
             "vs_baseline": None,
             "dtype": "f64",
             "data": "synthetic",
             "vectors": "host pointers (PCIe per call)" if args.host_vectors else "resident in HBM",
             "config": {"workload": f"C2 synthetic banded KKT: n={prog.n} me={prog.me} m={prog.m} band={args.band} "
-                                   f"-> KKT dim {st['dim']}, mat_sbw {st['sbw']}, plugin {args.mode} (one system per GPU)",
+                                   f"-> KKT dim {st['dim']}, mat_sbw {st['sbw']}, plugin {args.mode} "
+                                   + (f"(ONE system sharded over {world} GPUs)" if one else "(one system per GPU)"),
                        "kkt_dim": st["dim"], "mat_sbw": st["sbw"], "plugin": args.mode,
                        "supernodes": st["n_supernodes"], "tree_levels": st["n_levels"], "max_front": st["max_front"],
                        "nnz_kkt": st["nnz_kkt"], "nnz_factor": st["nnz_factor"]},
@@ -230,6 +252,10 @@ def main():
             "refine_rounds": st["refine_rounds"],
             "n_2x2": st["n_2x2"], "n_perturbed": st["n_perturbed"],
             "init_s": t_init,
+            "shard": {"ranks": st["shard_count"], "replicated_top_supernodes": st["n_top"],
+                      "exchange_blocks": st["n_exchange_blocks"], "flops_rank0": st["flops_local"],
+                      "flops_top": st["flops_top"], "bytes_exchange_factor": st["bytes_exchange_factor"],
+                      "bytes_exchange_step": st["bytes_exchange_step"]} if one else None,
             "kernel_ms_per_step": per_step,
             "kernel_launches_per_step": launches,
             "factor_model": model,

@@ -24,8 +24,12 @@ SYMBOLS = [
     "hqpkkt_get_sbw", "hqpkkt_get_perm", "hqpkkt_set_tol", "hqpkkt_set_eps",
     "hqpkkt_set_stream", "hqpkkt_get_stats", "hqpkkt_strerror", "hqpkkt_debug_get",
     "hqpkkt_selftest_mfma", "hqpkkt_set_profile", "hqpkkt_get_profile",
-    "hqpkkt_profile_class_name",
+    "hqpkkt_profile_class_name", "hqpkkt_set_shard",
 ]
+
+XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
+# int fn(void *ctx, int op, double *buf, long long slot_elems, int nslots)
+EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int)
 
 
 class Opts(C.Structure):
@@ -41,7 +45,11 @@ class Stats(C.Structure):
                 ("bytes_panels", C.c_longlong), ("bytes_updates", C.c_longlong),
                 ("n_2x2", C.c_int), ("n_perturbed", C.c_int), ("refine_rounds", C.c_int),
                 ("kmax", C.c_double), ("ms_assemble", C.c_float), ("ms_factor", C.c_float),
-                ("ms_step", C.c_float), ("ms_residual", C.c_float), ("ms_solve", C.c_float)]
+                ("ms_step", C.c_float), ("ms_residual", C.c_float), ("ms_solve", C.c_float),
+                ("shard_rank", C.c_int), ("shard_count", C.c_int), ("n_top", C.c_int),
+                ("n_exchange_blocks", C.c_int), ("flops_local", C.c_longlong),
+                ("flops_top", C.c_longlong), ("bytes_exchange_factor", C.c_longlong),
+                ("bytes_exchange_step", C.c_longlong)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -91,6 +99,7 @@ def lib():
     L.hqpkkt_get_profile.argtypes = [vp, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     L.hqpkkt_profile_class_name.restype = C.c_char_p
     L.hqpkkt_profile_class_name.argtypes = [C.c_int]
+    L.hqpkkt_set_shard.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
     _lib = L
     return L
 

@@ -589,6 +589,66 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
   }
 
+  // ------------------------------------------- shard plan (one system, P ranks)
+  // The top of the assembly tree is replicated on every rank, the subtrees below
+  // it are dealt to the ranks: walk down from the roots, always opening the
+  // heaviest remaining subtree, until a longest-processing-time assignment of the
+  // open subtrees is balanced.  With one rank everything belongs to rank 0.
+  std::vector<long long> nflops(nnodes);
+  for (int id = 0; id < nnodes; id++) {
+    const long long p = npiv[id], b = nbor[id];
+    nflops[id] = p * p * p / 3 + b * p * p + b * b * p;  // diag block, panel solve, update (lower half)
+  }
+  node_owner.assign(nnodes, 0);
+  xroots.clear();
+  if (shard_count > 1) {
+    std::vector<long long> work(nflops);
+    for (int id = 0; id < nnodes; id++)
+      if (parent[id] >= 0) work[parent[id]] += work[id];
+    std::vector<int> open;
+    for (int id = 0; id < nnodes; id++)
+      if (parent[id] < 0) open.push_back(id);
+    std::vector<char> is_top(nnodes, 0);
+    std::vector<int> assign;
+    auto lpt = [&](std::vector<int> &who) -> double {  // returns max load / mean load
+      std::vector<int> ord(open.size());
+      std::iota(ord.begin(), ord.end(), 0);
+      std::stable_sort(ord.begin(), ord.end(), [&](int x, int y) { return work[open[x]] > work[open[y]]; });
+      std::vector<long long> load(shard_count, 0);
+      who.assign(open.size(), 0);
+      long long tot = 0;
+      for (int t : ord) {
+        int q = (int)(std::min_element(load.begin(), load.end()) - load.begin());
+        who[t] = q, load[q] += work[open[t]], tot += work[open[t]];
+      }
+      const long long mx = *std::max_element(load.begin(), load.end());
+      return tot > 0 ? (double)mx * shard_count / (double)tot : 1.0;
+    };
+    for (;;) {
+      std::sort(open.begin(), open.end());
+      const double imb = lpt(assign);
+      if ((int)open.size() >= shard_count && imb <= 1.10) break;
+      if ((int)open.size() >= 16 * shard_count) break;
+      int best = -1;
+      for (size_t t = 0; t < open.size(); t++)
+        if (child_ptr[open[t] + 1] > child_ptr[open[t]] && (best < 0 || work[open[t]] > work[open[best]]))
+          best = (int)t;
+      if (best < 0) break;  // only leaves left
+      const int r = open[best];
+      open.erase(open.begin() + best);
+      is_top[r] = 1;
+      for (int k = child_ptr[r]; k < child_ptr[r + 1]; k++) open.push_back(child_idx[k]);
+    }
+    std::vector<int> root_owner(nnodes, -2);
+    for (size_t t = 0; t < open.size(); t++) root_owner[open[t]] = assign[t];
+    for (int id = nnodes - 1; id >= 0; id--)
+      node_owner[id] = is_top[id] ? -1 : (root_owner[id] != -2 ? root_owner[id] : node_owner[parent[id]]);
+    // exchanged blocks: subtree roots that feed a replicated parent, grouped by owner
+    for (int q = 0; q < shard_count; q++)
+      for (int id : open)
+        if (node_owner[id] == q && parent[id] >= 0) xroots.push_back(id);
+  }
+
   // --------------------------------------------------- storage + schedules
   panel_off.assign(nnodes, 0), upd_off.assign(nnodes, 0), x_off.assign(nnodes, 0);
   cb_off.assign(nnodes, 0);
@@ -596,74 +656,128 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   max_front = max_npiv = max_nbor = 0;
   nnz_factor = flops_factor = 0;
   nlevels = 0;
+  std::vector<char> is_xroot(nnodes, 0);
+  for (int id : xroots) is_xroot[id] = 1;
   for (int id = 0; id < nnodes; id++) {
     const long long p = npiv[id], b = nbor[id], F = p + b;
     panel_off[id] = panel_elems, panel_elems += F * p;
-    upd_off[id] = upd_elems, upd_elems += b * b;
+    if (!is_xroot[id]) {
+      upd_off[id] = upd_elems, upd_elems += b * b;
+      cb_off[id] = cb_elems, cb_elems += b;
+    }
     x_off[id] = x_elems, x_elems += b * p;
-    cb_off[id] = cb_elems, cb_elems += b;
     max_front = std::max<int>(max_front, (int)F);
     max_npiv = std::max<int>(max_npiv, (int)p);
     max_nbor = std::max<int>(max_nbor, (int)b);
     nlevels = std::max(nlevels, level[id] + 1);
     nnz_factor += p * (p + 1) / 2 + b * p;
-    flops_factor += p * p * p / 3 + b * p * p + b * b * p;  // diag block, panel solve, update (lower half)
+    flops_factor += nflops[id];
   }
-  level_ptr.assign(nlevels + 1, 0);
-  for (int id = 0; id < nnodes; id++) level_ptr[level[id] + 1]++;
-  for (int l = 0; l < nlevels; l++) level_ptr[l + 1] += level_ptr[l];
-  level_nodes.assign(nnodes, 0);
-  {
-    // inside a level the supernodes with at most SMALL_PIVOTS pivots come first:
-    // they are factored by the one-wavefront kernel
-    std::vector<int> fill(level_ptr.begin(), level_ptr.end() - 1);
-    for (int id = 0; id < nnodes; id++)
-      if (npiv[id] <= SMALL_PIVOTS) level_nodes[fill[level[id]]++] = id;
-    level_small.assign(nlevels, 0);
-    for (int l = 0; l < nlevels; l++) level_small[l] = fill[l] - level_ptr[l];
-    for (int id = 0; id < nnodes; id++)
-      if (npiv[id] > SMALL_PIVOTS) level_nodes[fill[level[id]]++] = id;
-  }
-  // extend-add segments: for parent level l, slot s -> children list
-  ea_level_ptr.assign(nlevels + 1, 0);
-  ea_seg_ptr.assign(1, 0);
-  ea_nodes.clear();
-  for (int l = 0; l < nlevels; l++) {
-    int maxslots = 0;
-    for (int t = level_ptr[l]; t < level_ptr[l + 1]; t++) {
-      int id = level_nodes[t];
-      maxslots = std::max(maxslots, child_ptr[id + 1] - child_ptr[id]);
+  // exchange regions behind the ordinary blocks: one slot per rank, a rank's
+  // subtree roots packed inside its slot
+  upd_x_off = upd_elems, cb_x_off = cb_elems, upd_x_slot = cb_x_slot = 0;
+  if (!xroots.empty()) {
+    std::vector<long long> ufill(shard_count, 0), cfill(shard_count, 0);
+    for (int id : xroots) {
+      const long long b = nbor[id];
+      ufill[node_owner[id]] += b * b, cfill[node_owner[id]] += b;
     }
-    for (int s = 0; s < maxslots; s++) {
-      for (int t = level_ptr[l]; t < level_ptr[l + 1]; t++) {
-        int id = level_nodes[t];
-        if (child_ptr[id + 1] - child_ptr[id] > s) ea_nodes.push_back(child_idx[child_ptr[id] + s]);
-      }
-      ea_seg_ptr.push_back((int)ea_nodes.size());
+    upd_x_slot = *std::max_element(ufill.begin(), ufill.end());
+    cb_x_slot = *std::max_element(cfill.begin(), cfill.end());
+    upd_x_slot = (upd_x_slot + 1) & ~1LL, cb_x_slot = (cb_x_slot + 1) & ~1LL;
+    std::fill(ufill.begin(), ufill.end(), 0), std::fill(cfill.begin(), cfill.end(), 0);
+    for (int id : xroots) {
+      const int q = node_owner[id];
+      const long long b = nbor[id];
+      upd_off[id] = upd_x_off + q * upd_x_slot + ufill[q], ufill[q] += b * b;
+      cb_off[id] = cb_x_off + q * cb_x_slot + cfill[q], cfill[q] += b;
     }
-    ea_level_ptr[l + 1] = (int)ea_seg_ptr.size() - 1;
+    upd_elems += shard_count * upd_x_slot, cb_elems += shard_count * cb_x_slot;
   }
-  upd_tile_ptr.assign(nlevels + 1, 0), slab_ptr.assign(nlevels + 1, 0);
-  gslab_ptr.assign(nlevels + 1, 0), cblk_ptr.assign(nlevels + 1, 0);
-  upd_tiles.clear(), slabs.clear(), gslabs.clear(), cblks.clear();
   dblk_off.assign(nnodes, 0);
   dblk_elems = 0;
   for (int id = 0; id < nnodes; id++) dblk_off[id] = dblk_elems, dblk_elems += 256LL * ((npiv[id] + 15) / 16);
-  for (int l = 0; l < nlevels; l++) {
-    for (int t = level_ptr[l]; t < level_ptr[l + 1]; t++) {
-      int id = level_nodes[t], b = nbor[id];
-      int nt = (b + UPD_TILE - 1) / UPD_TILE;
-      for (int ti = 0; ti < nt; ti++)
-        for (int tj = 0; tj <= ti; tj++) upd_tiles.insert(upd_tiles.end(), {id, ti, tj});
-      int ns = (b + SLAB_ROWS - 1) / SLAB_ROWS;
-      for (int s = 0; s < ns; s++) slabs.insert(slabs.end(), {id, s});
-      for (int s = 0; s < (b + 63) / 64; s++) gslabs.insert(gslabs.end(), {id, s});
-      for (int c = 0; c < (npiv[id] + 15) / 16; c++) cblks.insert(cblks.end(), {id, c});
+
+  // per-level work lists: [0] this rank's subtrees, [1] the replicated top
+  for (int which = 0; which < 2; which++) {
+    Sched &S = sched[which];
+    S = Sched();
+    auto keep = [&](int id) { return which == 0 ? node_owner[id] == shard_rank : node_owner[id] < 0; };
+    S.level_ptr.assign(nlevels + 1, 0);
+    for (int id = 0; id < nnodes; id++)
+      if (keep(id)) S.level_ptr[level[id] + 1]++, S.nnodes++, S.flops += nflops[id];
+    for (int l = 0; l < nlevels; l++) S.level_ptr[l + 1] += S.level_ptr[l];
+    S.level_nodes.assign(S.nnodes, 0);
+    {
+      // inside a level the supernodes with at most SMALL_PIVOTS pivots come first:
+      // they are factored by the one-wavefront kernel
+      std::vector<int> fill(S.level_ptr.begin(), S.level_ptr.end() - 1);
+      for (int id = 0; id < nnodes; id++)
+        if (keep(id) && npiv[id] <= SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
+      S.level_small.assign(nlevels, 0);
+      for (int l = 0; l < nlevels; l++) S.level_small[l] = fill[l] - S.level_ptr[l];
+      for (int id = 0; id < nnodes; id++)
+        if (keep(id) && npiv[id] > SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
     }
-    upd_tile_ptr[l + 1] = (int)upd_tiles.size() / 3;
-    slab_ptr[l + 1] = (int)slabs.size() / 2;
-    gslab_ptr[l + 1] = (int)gslabs.size() / 2;
-    cblk_ptr[l + 1] = (int)cblks.size() / 2;
+    // extend-add segments: for parent level l, slot s -> children list
+    S.ea_level_ptr.assign(nlevels + 1, 0);
+    S.ea_seg_ptr.assign(1, 0);
+    for (int l = 0; l < nlevels; l++) {
+      int maxslots = 0;
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; t++) {
+        int id = S.level_nodes[t];
+        maxslots = std::max(maxslots, child_ptr[id + 1] - child_ptr[id]);
+      }
+      for (int s = 0; s < maxslots; s++) {
+        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; t++) {
+          int id = S.level_nodes[t];
+          if (child_ptr[id + 1] - child_ptr[id] > s) S.ea_nodes.push_back(child_idx[child_ptr[id] + s]);
+        }
+        S.ea_seg_ptr.push_back((int)S.ea_nodes.size());
+      }
+      S.ea_level_ptr[l + 1] = (int)S.ea_seg_ptr.size() - 1;
+    }
+    S.upd_tile_ptr.assign(nlevels + 1, 0), S.slab_ptr.assign(nlevels + 1, 0);
+    S.gslab_ptr.assign(nlevels + 1, 0), S.cblk_ptr.assign(nlevels + 1, 0);
+    for (int l = 0; l < nlevels; l++) {
+      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; t++) {
+        int id = S.level_nodes[t], b = nbor[id];
+        int nt = (b + UPD_TILE - 1) / UPD_TILE;
+        for (int ti = 0; ti < nt; ti++)
+          for (int tj = 0; tj <= ti; tj++) S.upd_tiles.insert(S.upd_tiles.end(), {id, ti, tj});
+        int ns = (b + SLAB_ROWS - 1) / SLAB_ROWS;
+        for (int sl = 0; sl < ns; sl++) S.slabs.insert(S.slabs.end(), {id, sl});
+        for (int sl = 0; sl < (b + 63) / 64; sl++) S.gslabs.insert(S.gslabs.end(), {id, sl});
+        for (int c = 0; c < (npiv[id] + 15) / 16; c++) S.cblks.insert(S.cblks.end(), {id, c});
+      }
+      S.upd_tile_ptr[l + 1] = (int)S.upd_tiles.size() / 3;
+      S.slab_ptr[l + 1] = (int)S.slabs.size() / 2;
+      S.gslab_ptr[l + 1] = (int)S.gslabs.size() / 2;
+      S.cblk_ptr[l + 1] = (int)S.cblks.size() / 2;
+    }
+  }
+  // arena ranges this rank writes (zeroed at the start of every factorisation)
+  // and the solution entries it contributes to the all-reduce of a sharded solve
+  zero_panel.clear(), zero_upd.clear();
+  keep_e.assign(dim, 0);
+  {
+    auto push = [](std::vector<long long> &v, long long off, long long len) {
+      if (len <= 0) return;
+      if (!v.empty() && v[v.size() - 2] + v.back() == off)
+        v.back() += len;
+      else
+        v.push_back(off), v.push_back(len);
+    };
+    for (int id = 0; id < nnodes; id++) {
+      const bool mine = node_owner[id] == shard_rank, top = node_owner[id] < 0;
+      if (!mine && !top) continue;
+      const long long p = npiv[id], b = nbor[id];
+      push(zero_panel, panel_off[id], (p + b) * p);
+      if (!is_xroot[id]) push(zero_upd, upd_off[id], b * b);
+      if (mine || shard_rank == 0)
+        for (int k = 0; k < p; k++) keep_e[piv_start[id] + k] = 1;
+    }
+    if (!xroots.empty()) push(zero_upd, upd_x_off + shard_rank * upd_x_slot, upd_x_slot);
   }
 
   // ------------------------------------------------------- assembly map

@@ -40,17 +40,31 @@ struct Analysis {
   std::vector<long long> panel_off, upd_off, x_off;  // element offsets into the arenas
   long long panel_elems = 0, upd_elems = 0, x_elems = 0, cb_elems = 0;
   std::vector<long long> cb_off;  // contribution-vector offsets (solve)
-  std::vector<int> level_ptr, level_nodes;  // nodes grouped by level
-  std::vector<int> level_small;             // per level: leading nodes with npiv <= SMALL_PIVOTS
-  // children grouped by (parent level, slot) for deterministic extend-add
-  std::vector<int> ea_seg_ptr, ea_nodes, ea_level_ptr;  // segments per level
-  // children lists (for the solve gather)
-  std::vector<int> child_ptr, child_idx;
-  // tiles of the Schur update and slabs of the panel solve, grouped by level
-  std::vector<int> upd_tile_ptr, upd_tiles;    // triples (node, ti, tj)
-  std::vector<int> slab_ptr, slabs;            // pairs (node, slab): 32 border rows
-  std::vector<int> gslab_ptr, gslabs;          // pairs (node, slab): 64 border rows (solve)
-  std::vector<int> cblk_ptr, cblks;            // pairs (node, block of 16 pivot columns)
+  std::vector<int> child_ptr, child_idx;  // children lists
+  // Per-level work lists of a set of supernodes.
+  struct Sched {
+    int nnodes = 0;
+    long long flops = 0;
+    std::vector<int> level_ptr, level_nodes;  // nodes grouped by level
+    std::vector<int> level_small;             // per level: leading nodes with npiv <= SMALL_PIVOTS
+    // children grouped by (parent level, slot) for deterministic extend-add
+    std::vector<int> ea_seg_ptr, ea_nodes, ea_level_ptr;  // segments per level
+    // tiles of the Schur update and slabs of the panel solve, grouped by level
+    std::vector<int> upd_tile_ptr, upd_tiles;  // triples (node, ti, tj)
+    std::vector<int> slab_ptr, slabs;          // pairs (node, slab): 32 border rows
+    std::vector<int> gslab_ptr, gslabs;        // pairs (node, slab): 64 border rows (solve)
+    std::vector<int> cblk_ptr, cblks;          // pairs (node, block of 16 pivot columns)
+  };
+  Sched sched[2];  // [0] this rank's subtrees (everything when not sharded), [1] replicated top
+
+  // --- one system sharded over several ranks ----------------------
+  int shard_rank = 0, shard_count = 1;
+  std::vector<int> node_owner;  // owning rank per supernode, -1 = replicated top of the tree
+  std::vector<int> xroots;      // subtree roots whose update / contribution blocks are exchanged
+  long long upd_x_off = 0, upd_x_slot = 0;  // exchange region of the update arena: shard_count slots
+  long long cb_x_off = 0, cb_x_slot = 0;    // same for the solve's contribution vectors
+  std::vector<long long> zero_panel, zero_upd;  // (offset, length) pairs this rank clears per factor
+  std::vector<signed char> keep_e;  // per elimination index: this rank contributes it to the all-reduce
   std::vector<long long> dblk_off;             // inverse diagonal blocks, 256 doubles each
   long long dblk_elems = 0;
 

@@ -142,8 +142,21 @@ struct hqpkkt {
   hqpkkt_stats st;
 
   // symbolic structure on the device
-  DBuf<int> piv_start, npiv, nbor, parent, bidx, rel, child_ptr, child_idx, level_nodes,
-      ea_nodes, upd_tiles, slabs, gslabs, cblks, ent_a, ent_b, term_ptr, diag_ent, q2e;
+  DBuf<int> piv_start, npiv, nbor, parent, bidx, rel, child_ptr, child_idx, ent_a, ent_b,
+      term_ptr, diag_ent, q2e;
+  struct DevSched {  // device copy of an Analysis::Sched
+    DBuf<int> level_nodes, ea_nodes, upd_tiles, slabs, gslabs, cblks;
+    void release() {
+      level_nodes.release(), ea_nodes.release(), upd_tiles.release(), slabs.release();
+      gslabs.release(), cblks.release();
+    }
+  } ds[2];
+  DBuf<long long> zero_panel, zero_upd;  // (offset, length) pairs, sharded mode
+  DBuf<signed char> keep_e;
+  // one system over several ranks: collectives are delegated to the caller
+  int shard_rank = 0, shard_count = 1;
+  hqpkkt_exchange_fn xchg_fn = nullptr;
+  void *xchg_ctx = nullptr;
   DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, dblk_off;
   DBuf<TermDev> terms;
   DBuf<signed char> esign;
@@ -169,9 +182,13 @@ struct hqpkkt {
       if (g) (void)hipGraphDestroy(g);
       ge = nullptr, g = nullptr;
     }
-  } gfactor, gstep[2];
+  } gfactor[2], gstep[2][3];  // [phase], [caller's / refinement's vectors][phase]
   bool use_graphs = true, capturing = false;
-  void drop_graphs() { gfactor.drop(), gstep[0].drop(), gstep[1].drop(); }
+  void drop_graphs() {
+    for (auto &g : gfactor) g.drop();
+    for (auto &gs : gstep)
+      for (auto &g : gs) g.drop();
+  }
 
   DevTree tree() const {
     return DevTree{piv_start.p, npiv.p,     nbor.p,  parent.p, bptr.p,      bidx.p,     rel.p,
@@ -179,10 +196,11 @@ struct hqpkkt {
   }
   void release_device() {
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
-                       &level_nodes, &ea_nodes, &upd_tiles, &slabs, &gslabs, &cblks, &ent_a, &ent_b, &term_ptr,
-                       &diag_ent, &q2e, &ptype, &lperm, &flags};
+                       &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &ptype, &lperm, &flags};
     for (auto b : ib) b->release();
-    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &dblk_off};
+    ds[0].release(), ds[1].release(), keep_e.release();
+    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &dblk_off,
+                             &zero_panel, &zero_upd};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
                           &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &dblk};
@@ -229,12 +247,17 @@ static int upload(hqpkkt_t *h) {
   UP(rel, rel);
   UP(child_ptr, child_ptr);
   UP(child_idx, child_idx);
-  UP(level_nodes, level_nodes);
-  UP(ea_nodes, ea_nodes);
-  UP(upd_tiles, upd_tiles);
-  UP(slabs, slabs);
-  UP(gslabs, gslabs);
-  UP(cblks, cblks);
+  for (int w = 0; w < 2; w++) {
+    UP(ds[w].level_nodes, sched[w].level_nodes);
+    UP(ds[w].ea_nodes, sched[w].ea_nodes);
+    UP(ds[w].upd_tiles, sched[w].upd_tiles);
+    UP(ds[w].slabs, sched[w].slabs);
+    UP(ds[w].gslabs, sched[w].gslabs);
+    UP(ds[w].cblks, sched[w].cblks);
+  }
+  UP(zero_panel, zero_panel);
+  UP(zero_upd, zero_upd);
+  UP(keep_e, keep_e);
   UP(dblk_off, dblk_off);
   UP(ent_a, ent_a);
   UP(ent_b, ent_b);
@@ -360,108 +383,151 @@ static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double 
 
 static_assert(FS_MAXP == kktdev::SMALL_PIVOTS, "small-supernode kernel and schedule disagree");
 // ------------------------------------------------------------ numeric phases
-static int run_factor(hqpkkt_t *h, const double *z, const double *w) {
+// phases: 1 = assemble + this rank's subtrees, 2 = replicated top of the tree
+// (3 = everything, the single-rank case)
+static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases) {
   Analysis &an = h->an;
   hipStream_t s = h->stream;
   const int m = an.m, nent = (int)an.ent_a.size();
   DevTree T = h->tree();
-  HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, s));
-  if (an.upd_elems) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
-  HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 64, s));
-  HIPCHK(hipMemsetAsync(h->bits.p, 0, sizeof(unsigned long long) * 2, s));
-  if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
-  if (m > 0)
-    KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
-  KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
-                                            h->ent_val.p));
-  if (an.mode == 1 && an.n > 0)
-    KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
-  KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
-                                       h->sc.p, h->panel.p, h->bits.p));
-  if (!h->capturing) HIPCHK(hipEventRecord(h->ev1, s));
-  const double alpha = h->opts.tol * 0.6403882032022076;  // tol (1+sqrt 17)/8, hqp/spBKP.C:392
-  for (int l = 0; l < an.nlevels; l++) {
-    for (int seg = an.ea_level_ptr[l]; seg < an.ea_level_ptr[l + 1]; seg++) {
-      int cnt = an.ea_seg_ptr[seg + 1] - an.ea_seg_ptr[seg];
-      if (cnt <= 0) continue;
-      int ysplit = std::max(1, std::min(64, 2048 / cnt));
-      KLAUNCH(h, KC_EXTEND_ADD, k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, h->ea_nodes.p + an.ea_seg_ptr[seg],
-                                                     h->panel.p, h->upd.p));
+  if (phases & 1) {
+    if (an.shard_count <= 1) {
+      HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, s));
+      if (an.upd_elems) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
+    } else {  // only the blocks this rank writes
+      const int np = (int)an.zero_panel.size() / 2, nu = (int)an.zero_upd.size() / 2;
+      if (np) k_zero_ranges<<<dim3(512, np), 256, 0, s>>>(h->panel.p, h->zero_panel.p);
+      if (nu) k_zero_ranges<<<dim3(512, nu), 256, 0, s>>>(h->upd.p, h->zero_upd.p);
     }
-    const int nn = an.level_ptr[l + 1] - an.level_ptr[l], nsm = an.level_small[l];
-    if (nsm > 0)
-      KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<<<nsm, 64, 0, s>>>(T, h->level_nodes.p + an.level_ptr[l], h->panel.p,
-                                               h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
-                                               h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                               h->flags.p + 1));
-    if (nn > nsm)
-      KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nsm, FD_THREADS, h->lds_diag, s>>>(T, h->level_nodes.p + an.level_ptr[l] + nsm, h->panel.p,
-                                               h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
-                                               h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                               h->flags.p + 1));
-    const int ns = an.slab_ptr[l + 1] - an.slab_ptr[l];
-    if (ns > 0)
-      KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, h->slabs.p + 2 * (size_t)an.slab_ptr[l],
-                                                  h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
-                                                  h->lperm.p, h->dblk.p, h->dblk_off.p));
-    const int nt = an.upd_tile_ptr[l + 1] - an.upd_tile_ptr[l];
-    if (nt > 0)
-      KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, h->upd_tiles.p + 3 * (size_t)an.upd_tile_ptr[l],
-                                        h->panel.p, h->xar.p, h->upd.p));
+    HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 64, s));
+    HIPCHK(hipMemsetAsync(h->bits.p, 0, sizeof(unsigned long long) * 2, s));
+    if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
+    if (m > 0)
+      KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
+    KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
+                                              h->ent_val.p));
+    if (an.mode == 1 && an.n > 0)
+      KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
+    KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
+                                         h->sc.p, h->panel.p, h->bits.p));
+    if (!h->capturing) HIPCHK(hipEventRecord(h->ev1, s));
+  }
+  const double alpha = h->opts.tol * 0.6403882032022076;  // tol (1+sqrt 17)/8, hqp/spBKP.C:392
+  for (int which = 0; which < 2; which++) {
+    if (!(phases & (1 << which))) continue;
+    const Analysis::Sched &S = an.sched[which];
+    const hqpkkt::DevSched &D = h->ds[which];
+    if (S.nnodes == 0) continue;
+    for (int l = 0; l < an.nlevels; l++) {
+      for (int seg = S.ea_level_ptr[l]; seg < S.ea_level_ptr[l + 1]; seg++) {
+        int cnt = S.ea_seg_ptr[seg + 1] - S.ea_seg_ptr[seg];
+        if (cnt <= 0) continue;
+        int ysplit = std::max(1, std::min(64, 2048 / cnt));
+        KLAUNCH(h, KC_EXTEND_ADD, k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, D.ea_nodes.p + S.ea_seg_ptr[seg],
+                                                       h->panel.p, h->upd.p));
+      }
+      const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nsm = S.level_small[l];
+      if (nsm > 0)
+        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<<<nsm, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
+                                                 h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->flags.p + 1));
+      if (nn > nsm)
+        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nsm, h->panel.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
+                                                 h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->flags.p + 1));
+      const int ns = S.slab_ptr[l + 1] - S.slab_ptr[l];
+      if (ns > 0)
+        KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, D.slabs.p + 2 * (size_t)S.slab_ptr[l],
+                                                    h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
+                                                    h->lperm.p, h->dblk.p, h->dblk_off.p));
+      const int nt = S.upd_tile_ptr[l + 1] - S.upd_tile_ptr[l];
+      if (nt > 0)
+        KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_tile_ptr[l],
+                                          h->panel.p, h->xar.p, h->upd.p));
+    }
   }
   if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
   HIPCHK(hipGetLastError());
   return 0;
 }
 
-static int run_step(hqpkkt_t *h, const Vecs &v) {
+// phases: 1 = right-hand side + forward sweep over this rank's subtrees,
+// 2 = forward / backward over the replicated top, backward over the subtrees,
+// 4 = unscale + scatter of the solution (7 = everything, the single-rank case)
+static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   Analysis &an = h->an;
   hipStream_t s = h->stream;
   const int n = an.n, me = an.me, m = an.m, dim = an.dim;
   DevTree T = h->tree();
-  if (an.mode == 0) {
-    KLAUNCH(h, KC_VECTOR, k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
-                                         h->rhs.p));
-  } else {
-    if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
-    KLAUNCH(h, KC_VECTOR, k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
-                                        h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p));
+  auto forward = [&](int which) -> int {
+    const Analysis::Sched &S = an.sched[which];
+    const hqpkkt::DevSched &D = h->ds[which];
+    for (int l = 0; l < an.nlevels && S.nnodes; l++) {
+      const int nn = S.level_ptr[l + 1] - S.level_ptr[l];
+      if (nn > 0)
+        KLAUNCH(h, KC_SOLVE_FWD,
+                k_solve_fwd_a<<<nn, 256, h->lds_solve, s>>>(T, D.level_nodes.p + S.level_ptr[l],
+                                                            h->panel.p, h->dinv.p, h->ptype.p, h->lperm.p,
+                                                            h->dblk.p, h->dblk_off.p, h->rhs.p, h->xsol.p,
+                                                            h->ytmp.p, h->cb.p));
+      const int ng = S.gslab_ptr[l + 1] - S.gslab_ptr[l];
+      if (ng > 0)
+        KLAUNCH(h, KC_SOLVE_FWD,
+                k_solve_fwd_b<<<ng, 256, 0, s>>>(T, D.gslabs.p + 2 * (size_t)S.gslab_ptr[l], h->panel.p,
+                                                 h->ytmp.p, h->cb.p));
+    }
+    return 0;
+  };
+  auto backward = [&](int which) -> int {
+    const Analysis::Sched &S = an.sched[which];
+    const hqpkkt::DevSched &D = h->ds[which];
+    for (int l = an.nlevels - 1; l >= 0 && S.nnodes; l--) {
+      const int nn = S.level_ptr[l + 1] - S.level_ptr[l];
+      const int ncb = S.cblk_ptr[l + 1] - S.cblk_ptr[l];
+      if (nn <= 0) continue;
+      KLAUNCH(h, KC_SOLVE_BWD,
+              k_solve_bwd_b<<<ncb, 256, h->lds_bwdb, s>>>(T, D.cblks.p + 2 * (size_t)S.cblk_ptr[l],
+                                                          h->panel.p, h->xsol.p, h->vtmp.p));
+      KLAUNCH(h, KC_SOLVE_BWD,
+              k_solve_bwd_a<<<nn, 256, h->lds_solve, s>>>(T, D.level_nodes.p + S.level_ptr[l],
+                                                          h->panel.p, h->lperm.p, h->dblk.p,
+                                                          h->dblk_off.p, h->vtmp.p, h->xsol.p));
+    }
+    return 0;
+  };
+  if (phases & 1) {
+    if (an.mode == 0) {
+      KLAUNCH(h, KC_VECTOR, k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
+                                           h->rhs.p));
+    } else {
+      if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
+      KLAUNCH(h, KC_VECTOR, k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
+                                          h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p));
+    }
+    forward(0);
   }
-  for (int l = 0; l < an.nlevels; l++) {
-    const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
-    KLAUNCH(h, KC_SOLVE_FWD,
-            k_solve_fwd_a<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l],
-                                                        h->panel.p, h->dinv.p, h->ptype.p, h->lperm.p,
-                                                        h->dblk.p, h->dblk_off.p, h->rhs.p, h->xsol.p,
-                                                        h->ytmp.p, h->cb.p));
-    const int ng = an.gslab_ptr[l + 1] - an.gslab_ptr[l];
-    if (ng > 0)
-      KLAUNCH(h, KC_SOLVE_FWD,
-              k_solve_fwd_b<<<ng, 256, 0, s>>>(T, h->gslabs.p + 2 * (size_t)an.gslab_ptr[l], h->panel.p,
-                                               h->ytmp.p, h->cb.p));
+  if (phases & 2) {
+    forward(1);
+    backward(1);
+    backward(0);
+    if (an.shard_count > 1)  // leave only this rank's share for the all-reduce
+      KLAUNCH(h, KC_VECTOR, k_mask_vector<<<nblk(dim), 256, 0, s>>>(dim, h->keep_e.p, h->xsol.p));
   }
-  for (int l = an.nlevels - 1; l >= 0; l--) {
-    const int nn = an.level_ptr[l + 1] - an.level_ptr[l];
-    const int ncb = an.cblk_ptr[l + 1] - an.cblk_ptr[l];
-    KLAUNCH(h, KC_SOLVE_BWD,
-            k_solve_bwd_b<<<ncb, 256, h->lds_bwdb, s>>>(T, h->cblks.p + 2 * (size_t)an.cblk_ptr[l],
-                                                        h->panel.p, h->xsol.p, h->vtmp.p));
-    KLAUNCH(h, KC_SOLVE_BWD,
-            k_solve_bwd_a<<<nn, 256, h->lds_solve, s>>>(T, h->level_nodes.p + an.level_ptr[l],
-                                                        h->panel.p, h->lperm.p, h->dblk.p,
-                                                        h->dblk_off.p, h->vtmp.p, h->xsol.p));
-  }
-  if (an.mode == 0) {
-    KLAUNCH(h, KC_VECTOR, k_unpack_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy,
-                                            v.dz));
-    if (m > 0)
-      KLAUNCH(h, KC_VECTOR, k_dw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, v.r3,
-                                   v.dw));
-  } else {
-    KLAUNCH(h, KC_VECTOR, k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy));
-    if (m > 0)
-      KLAUNCH(h, KC_VECTOR, k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx,
-                                         h->wt.p, h->tz.p, v.r3, v.dz, v.dw));
+  if (phases & 4) {
+    if (an.mode == 0) {
+      KLAUNCH(h, KC_VECTOR, k_unpack_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy,
+                                              v.dz));
+      if (m > 0)
+        KLAUNCH(h, KC_VECTOR, k_dw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, v.r3,
+                                     v.dw));
+    } else {
+      KLAUNCH(h, KC_VECTOR, k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy));
+      if (m > 0)
+        KLAUNCH(h, KC_VECTOR, k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx,
+                                           h->wt.p, h->tz.p, v.r3, v.dz, v.dw));
+    }
   }
   HIPCHK(hipGetLastError());
   return 0;
@@ -498,6 +564,39 @@ static int graphed(hqpkkt_t *h, hqpkkt::GraphSlot &slot, F body) {
   }
   HIPCHK(hipGraphLaunch(slot.ge, h->stream));
   return 0;
+}
+
+// The exchange steps of a sharded system: the handle's stream is
+// drained, the caller's collective runs, and the next phase starts afterwards.
+static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots) {
+  if (!h->xchg_fn) return HQPKKT_E_INTERN;
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const int rc = h->xchg_fn(h->xchg_ctx, op, buf, slot, nslots);
+  return rc ? HQPKKT_E_DEVICE : 0;
+}
+
+static int do_factor(hqpkkt_t *h, const Vecs &v) {
+  Analysis &an = h->an;
+  int e;
+  if (an.shard_count <= 1) return graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 3); });
+  if ((e = graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 1); }))) return e;
+  if (an.upd_x_slot > 0 &&
+      (e = exchange(h, HQPKKT_XCHG_ALLGATHER, h->upd.p + an.upd_x_off, an.upd_x_slot, an.shard_count)))
+    return e;
+  return graphed(h, h->gfactor[1], [&]() { return run_factor(h, v.z, v.w, 2); });
+}
+
+static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
+  Analysis &an = h->an;
+  int e;
+  if (an.shard_count <= 1) return graphed(h, h->gstep[which][0], [&]() { return run_step(h, v, 7); });
+  if ((e = graphed(h, h->gstep[which][0], [&]() { return run_step(h, v, 1); }))) return e;
+  if (an.cb_x_slot > 0 &&
+      (e = exchange(h, HQPKKT_XCHG_ALLGATHER, h->cb.p + an.cb_x_off, an.cb_x_slot, an.shard_count)))
+    return e;
+  if ((e = graphed(h, h->gstep[which][1], [&]() { return run_step(h, v, 2); }))) return e;
+  if ((e = exchange(h, HQPKKT_XCHG_ALLREDUCE_SUM, h->xsol.p, an.dim, 1))) return e;
+  return graphed(h, h->gstep[which][2], [&]() { return run_step(h, v, 4); });
 }
 
 // residual of (d) for rhs (r); leaves the residual vectors in h->vres
@@ -592,6 +691,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   }
   h->analyzed = false;
   h->an = Analysis();
+  h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
   int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
                     h->opts.max_pivots, h->opts.zd_policy);
   if (e) return e;
@@ -603,6 +703,12 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->st.nnz_factor = an.nnz_factor, h->st.flops_factor = an.flops_factor;
   h->st.bytes_panels = (long long)sizeof(double) * (an.panel_elems + an.x_elems);
   h->st.bytes_updates = (long long)sizeof(double) * an.upd_elems;
+  h->st.shard_rank = an.shard_rank, h->st.shard_count = an.shard_count;
+  h->st.n_top = an.sched[1].nnodes, h->st.n_exchange_blocks = (int)an.xroots.size();
+  h->st.flops_local = an.sched[0].flops, h->st.flops_top = an.sched[1].flops;
+  h->st.bytes_exchange_factor = (long long)sizeof(double) * an.upd_x_slot * (an.xroots.empty() ? 0 : an.shard_count);
+  h->st.bytes_exchange_step =
+      an.shard_count > 1 ? (long long)sizeof(double) * (an.cb_x_slot * an.shard_count + an.dim) : 0;
   if (sbw) *sbw = an.sbw;
   return 0;
 }
@@ -637,7 +743,7 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   if (e) return e;
   h->factored = false;
   HIPCHK(hipEventRecord(h->ev0, h->stream));
-  if ((e = graphed(h, h->gfactor, [&]() { return run_factor(h, v.z, v.w); }))) return e;
+  if ((e = do_factor(h, v))) return e;
   if (h->use_graphs && !h->prof.on) {  // phases are not timed separately inside a graph replay
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventRecord(h->evs1, h->stream));
@@ -673,7 +779,7 @@ int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w, const double *r1,
   if (e) return e;
   stage_out_ptrs(h, v);
   HIPCHK(hipEventRecord(h->evs0, h->stream));
-  if ((e = graphed(h, h->gstep[0], [&]() { return run_step(h, v); }))) return e;
+  if ((e = do_step(h, v, 0))) return e;
   HIPCHK(hipEventRecord(h->evs1, h->stream));
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
   HIPCHK(hipStreamSynchronize(h->stream));
@@ -725,7 +831,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if (e) return e;
   stage_out_ptrs(h, v);
   HIPCHK(hipEventRecord(h->ev0, s));
-  if ((e = graphed(h, h->gstep[0], [&]() { return run_step(h, v); }))) return e;
+  if ((e = do_step(h, v, 0))) return e;
   double res = 0.0, res_last;
   if ((e = run_residual(h, v, &res))) return e;
   // correction solve: rhs = residual vectors, result = vcor
@@ -736,7 +842,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   int rounds = 0;
   for (int it = 0; it < 5 && res > h->opts.eps; it++) {
     res_last = res;
-    if ((e = graphed(h, h->gstep[1], [&]() { return run_step(h, c); }))) return e;
+    if ((e = do_step(h, c, 1))) return e;
     rounds++;
     double alpha = 1.0;
     do {
@@ -778,7 +884,7 @@ int hqpkkt_get_perm(const hqpkkt_t *h, int *perm) {
 int hqpkkt_set_tol(hqpkkt_t *h, double tol) {
   if (!h) return HQPKKT_E_NULL;
   if (!(tol > 0.0 && tol <= 1.0)) return HQPKKT_E_RANGE;
-  if (tol != h->opts.tol) h->gfactor.drop();  // alpha is baked into the captured launch
+  if (tol != h->opts.tol) h->gfactor[0].drop(), h->gfactor[1].drop();  // alpha is baked into the captured launches
   h->opts.tol = tol;
   return 0;
 }
@@ -795,6 +901,16 @@ int hqpkkt_set_stream(hqpkkt_t *h, void *hip_stream) {
   if (e) return e;
   h->stream = hip_stream ? (hipStream_t)hip_stream : h->own_stream;
   h->drop_graphs();
+  return 0;
+}
+
+int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, void *ctx) {
+  if (!h) return HQPKKT_E_NULL;
+  if (count < 1 || rank < 0 || rank >= count) return HQPKKT_E_RANGE;
+  if (count > 1 && !fn) return HQPKKT_E_NULL;
+  if (h->analyzed && (rank != h->shard_rank || count != h->shard_count)) return HQPKKT_E_INTERN;
+  h->shard_rank = rank, h->shard_count = count;
+  h->xchg_fn = fn, h->xchg_ctx = ctx;
   return 0;
 }
 
@@ -854,6 +970,8 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
     case 7: v = &an.bidx; break;
     case 8: v = &an.ent_er; break;
     case 9: v = &an.ent_ec; break;
+    case 10: v = &an.node_owner; break;
+    case 11: v = &an.xroots; break;
     default: return HQPKKT_E_RANGE;
   }
   *len = (long long)v->size();

@@ -1410,6 +1410,20 @@ k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDe
 
 // several vectors moved by one launch (staging of caller pointers into the
 // handle's fixed buffers, so that the numeric sequences can be replayed as graphs)
+// sharded mode: clear the (offset, length) ranges of an arena this rank writes
+__global__ void k_zero_ranges(double *__restrict__ base, const long long *__restrict__ ranges) {
+  const long long off = ranges[2 * blockIdx.y], len = ranges[2 * blockIdx.y + 1];
+  double *p = base + off;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len;
+       i += (long long)gridDim.x * blockDim.x)
+    p[i] = 0.0;
+}
+// sharded mode: keep only the entries this rank contributes to the all-reduce
+__global__ void k_mask_vector(int n, const signed char *__restrict__ keep, double *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && !keep[i]) x[i] = 0.0;
+}
+
 struct CopyList {
   const double *src[6];
   double *dst[6];

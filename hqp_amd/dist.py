@@ -1,12 +1,17 @@
 """One process per GPU over torch.distributed (backend "nccl" is RCCL on ROCm;
 "gloo" on CPU for the tests).
 
-The KKT path shards by KKT SYSTEM: independent interior-point problems (scenarios,
-MPC instances, the QPs of separate SQP runs) are dealt round-robin to the ranks
-and need no data-path collective; the only collectives are the barrier and the
-max-over-ranks of the wall time that the benchmark contract asks for.  (Sharding
-ONE system over GPUs - subtrees of the assembly tree per rank, separator update
-matrices exchanged over xGMI - is the next step)
+Two ways to use several GPUs on the KKT path:
+
+* by KKT SYSTEM: independent interior-point problems (scenarios, MPC instances,
+  the QPs of separate SQP runs) are dealt round-robin to the ranks and need no
+  data-path collective (``shard_units``); the only collectives are the barrier
+  and the max-over-ranks of the wall time that the benchmark contract asks for;
+* ONE system over the ranks: every rank analyses the same system,
+  the symbolic phase deals the subtrees of the assembly tree to the ranks and
+  replicates the top separators; one all-gather per factorisation and one
+  all-gather + one all-reduce per solve are delegated to ``make_exchange`` below
+  through the C-ABI callback ``hqpkkt_set_shard`` (include/hqpkkt.h).
 """
 from __future__ import annotations
 
@@ -78,3 +83,59 @@ def finalize():
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
+
+
+# ----------------------------------------------------------- one system, P ranks
+XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
+
+
+class _DevicePtr:
+    """Zero-copy view of device memory owned by libhqpkkt (CUDA array interface)."""
+
+    def __init__(self, ptr, n):
+        self.__cuda_array_interface__ = {"shape": (int(n),), "typestr": "<f8", "data": (int(ptr), False),
+                                         "version": 2}
+
+
+def exchange_tensor(op, t, slot, nslots, rank, group=None):
+    """The two collectives of a sharded system on a 1-D float64 tensor ``t``.
+
+    ALLGATHER: ``t`` holds ``nslots`` slots of ``slot`` values, slot ``rank`` is
+    filled; on return all are.  ALLREDUCE_SUM: the first ``slot`` values are
+    replaced by their sum over the ranks.  Device tensors go straight to RCCL
+    when the group's backend is nccl; with gloo they are staged through the host
+    (CPU tests, and two ranks sharing one GPU)."""
+    import torch
+    import torch.distributed as dist
+    direct = (not t.is_cuda) or dist.get_backend(group) == "nccl"
+    buf = t if direct else t.cpu()
+    if op == XCHG_ALLGATHER:
+        slots = buf[: slot * nslots].view(nslots, slot)
+        mine = slots[rank].clone()
+        if buf.is_cuda:
+            dist.all_gather_into_tensor(buf[: slot * nslots], mine, group=group)
+        else:
+            dist.all_gather(list(slots.unbind(0)), mine, group=group)
+    elif op == XCHG_ALLREDUCE_SUM:
+        dist.all_reduce(buf[:slot], op=dist.ReduceOp.SUM, group=group)
+    else:
+        raise ValueError(f"unknown exchange op {op}")
+    if not direct:
+        t.copy_(buf)
+    if t.is_cuda:
+        torch.cuda.synchronize(t.device)
+    return t
+
+
+def make_exchange(rank, device=0, group=None):
+    """Callable for ``Hqp_IpMatrix(shard=(rank, count, make_exchange(rank, device)))``:
+    invoked by the library as ``fn(op, device_pointer, slot_elems, nslots)`` with its
+    stream drained; must return after the result is complete."""
+    import torch
+
+    def fn(op, ptr, slot, nslots):
+        n = slot * nslots
+        t = torch.as_tensor(_DevicePtr(ptr, n), device=torch.device("cuda", device))
+        exchange_tensor(op, t, slot, nslots, rank, group)
+
+    return fn

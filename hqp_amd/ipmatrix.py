@@ -58,7 +58,7 @@ class Hqp_IpMatrix:
     _name = None
 
     def __init__(self, device=0, device_vectors=False, mat_tol=1.0, mat_eps=1e-10,
-                 pivot_eps=None, leaf_size=0, max_pivots=0, zd_policy=None):
+                 pivot_eps=None, leaf_size=0, max_pivots=0, zd_policy=None, shard=None):
         L = _lib.lib()
         o = _lib.Opts()
         L.hqpkkt_default_opts(C.byref(o))
@@ -76,7 +76,29 @@ class Hqp_IpMatrix:
         self._device_vectors = bool(device_vectors)
         _check(L.hqpkkt_create(C.byref(o), C.byref(self._h)), "create")
         self._keep = None
+        self._xchg = None
         self.n = self.me = self.m = 0
+        if shard is not None:
+            self.set_shard(*shard)
+
+    def set_shard(self, rank, count, exchange=None):
+        """One system over ``count`` ranks (call before init()).  ``exchange(op,
+        device_pointer, slot_elems, nslots)`` performs the collectives, see
+        hqp_amd.dist.make_exchange and hqpkkt_set_shard in include/hqpkkt.h."""
+        import sys
+        import traceback
+
+        def tramp(_ctx, op, buf, slot, nslots):
+            try:
+                exchange(op, buf, slot, nslots)
+                return 0
+            except Exception:  # never unwind through the C frames
+                traceback.print_exc(file=sys.stderr)
+                return 1
+
+        cb = _lib.EXCHANGE_FN(tramp) if exchange is not None else C.cast(None, _lib.EXCHANGE_FN)
+        _check(self._L.hqpkkt_set_shard(self._h, rank, count, cb, None), "set_shard")
+        self._xchg = cb  # keep the thunk alive as long as the handle
 
     def __del__(self):
         h = getattr(self, "_h", None)
@@ -218,7 +240,7 @@ class Hqp_IpMatrix:
 
     def structure(self):
         names = ["elim", "piv_start", "npiv", "nborder", "parent", "level", "border_ptr",
-                 "border_idx", "entry_row", "entry_col"]
+                 "border_idx", "entry_row", "entry_col", "node_owner", "exchange_roots"]
         return {nm: self.debug(i) for i, nm in enumerate(names)}
 
 

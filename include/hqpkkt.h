@@ -87,6 +87,13 @@ typedef struct hqpkkt_stats {
   /* device time of the last call of each phase, HIP events on the handle's
      stream, milliseconds */
   float ms_assemble, ms_factor, ms_step, ms_residual, ms_solve;
+  /* one system sharded over several ranks (valid after analyze; hqpkkt_set_shard) */
+  int shard_rank, shard_count;
+  int n_top;              /* supernodes of the replicated top of the tree          */
+  int n_exchange_blocks;  /* subtree roots whose update blocks are all-gathered    */
+  long long flops_local, flops_top; /* factor flops of this rank's subtrees / top  */
+  long long bytes_exchange_factor;  /* all-gather volume per factor (all slots)    */
+  long long bytes_exchange_step;    /* all-gather + all-reduce volume per step     */
 } hqpkkt_stats;
 
 /* Fill *opts with the defaults (mode FULL, device 0, host pointers, tol 1.0,
@@ -161,6 +168,31 @@ int hqpkkt_set_stream(hqpkkt_t *h, void *hip_stream);
 
 int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out);
 
+/* ---- one system over several GPUs (nested-dissection / SPIKE cut
+ * of the RCM band; the reference's spBKPfactor, hqp/spBKP.C:369-645, is
+ * sequential and has no counterpart) ------------------------------------------
+ * Every rank holds one handle on its own device and makes the same calls with
+ * the same (replicated) arguments.  The symbolic phase splits the assembly tree:
+ * the top (the outermost separators) is replicated, the subtrees below it are
+ * dealt to the ranks.  Each factor needs ONE all-gather (the update blocks of the
+ * subtree roots), each step one all-gather (their contribution vectors) and one
+ * all-reduce (the solution in elimination order).  The library does not link a
+ * communication library: it calls back into the host, after draining the
+ * handle's stream, and continues when the callback returns -- the callback must
+ * not return before the result is complete in `buf` (device memory on the
+ * handle's device).  With torch.distributed (backend "nccl" = RCCL over xGMI)
+ * this is hqp_amd.dist.make_exchange(); a C++ host passes a function that calls
+ * ncclAllGather / ncclAllReduce on its communicator.
+ *   op HQPKKT_XCHG_ALLGATHER:     buf holds nslots slots of slot_elems doubles,
+ *                                 slot `rank` is filled; fill all of them.
+ *   op HQPKKT_XCHG_ALLREDUCE_SUM: buf holds slot_elems doubles (nslots = 1);
+ *                                 replace them by the sum over the ranks.
+ * Returns 0 on success.  Call hqpkkt_set_shard before hqpkkt_analyze. */
+#define HQPKKT_XCHG_ALLGATHER 0
+#define HQPKKT_XCHG_ALLREDUCE_SUM 1
+typedef int (*hqpkkt_exchange_fn)(void *ctx, int op, double *buf, long long slot_elems, int nslots);
+int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, void *ctx);
+
 /* Per-kernel-class device timing for bench.py's roofline line: with on != 0
  * every kernel launch is bracketed by HIP events on the handle's stream and the
  * elapsed times are summed per class (hqpkkt_profile_class_name(c), c = 0..) at
@@ -177,7 +209,8 @@ const char *hqpkkt_strerror(int status);
 /* what: 0 elim (QP index -> elimination index, dim), 1 node_piv_start,
  * 2 node_npiv, 3 node_nborder, 4 node_parent, 5 node_level (n_supernodes
  * each), 6 border_ptr (n_supernodes+1), 7 border_idx (border_ptr[last]),
- * 8 entry_row, 9 entry_col (elimination indices, nnz_kkt each).
+ * 8 entry_row, 9 entry_col (elimination indices, nnz_kkt each), 10 node_owner
+ * (rank per supernode, -1 = replicated top), 11 exchanged subtree roots.
  * *len receives the element count; out may be NULL to query it. */
 int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len);
 

@@ -159,30 +159,37 @@ class Model:
             B = s["border_idx"][s["border_ptr"][k]:s["border_ptr"][k + 1]]
             yield k, P, np.asarray(B, dtype=int)
 
-    def factor(self, Kq, n):
+    def begin(self, Kq, n):
         """Kq: dense scaled matrix in QP numbering; n: number of x variables."""
         s = self.s
         e = np.asarray(s["elim"], dtype=int)
         dim = Kq.shape[0]
-        S = np.zeros((dim, dim))
-        S[np.ix_(e, e)] = Kq
-        signs = np.ones(dim)
-        signs[e[:n]] = -1.0
-        pert = self.pivot_eps * np.abs(Kq).max()
-        self.fac = []
+        self.S = np.zeros((dim, dim))
+        self.S[np.ix_(e, e)] = Kq
+        self.signs = np.ones(dim)
+        self.signs[e[:n]] = -1.0
+        self.pert = self.pivot_eps * np.abs(Kq).max()
+        self.fac = {}
         self.n2 = self.npert = 0
         self.struct_violation = 0.0
-        done = np.zeros(dim, dtype=bool)
+        self.done = np.zeros(dim, dtype=bool)
+
+    def eliminate(self, ids=None):
+        """Eliminate the supernodes ``ids`` (ascending = children first; default all)."""
+        S, dim = self.S, self.S.shape[0]
+        want = None if ids is None else set(int(i) for i in ids)
         for k, P, B in self.nodes():
+            if want is not None and k not in want:
+                continue
             rest = np.ones(dim, dtype=bool)
             rest[P] = False
             rest[B] = False
-            rest[done] = False
+            rest[self.done] = False
             # everything coupled to the pivots must be inside the symbolic front
             if rest.any():
                 self.struct_violation = max(self.struct_violation, np.abs(S[np.ix_(rest, P)]).max())
             A11 = S[np.ix_(P, P)]
-            L, blocks, lp, n2, npert = bk_block(A11, self.alpha, pert, signs[P])
+            L, blocks, lp, n2, npert = bk_block(A11, self.alpha, self.pert, self.signs[P])
             self.n2 += n2
             self.npert += npert
             A21 = S[np.ix_(B, P)][:, lp]
@@ -190,20 +197,32 @@ class Model:
             L21 = apply_dinv(blocks, X.T).T if B.size else X
             if B.size:
                 S[np.ix_(B, B)] -= L21 @ X.T
-            self.fac.append((P, B, L, blocks, lp, L21))
-            done[P] = True
+            self.fac[k] = (P, B, L, blocks, lp, L21)
+            self.done[P] = True
 
-    def solve(self, rhs_e):
-        x = np.array(rhs_e, dtype=float)
-        for (P, B, L, blocks, lp, L21) in self.fac:
+    def factor(self, Kq, n):
+        self.begin(Kq, n)
+        self.eliminate()
+
+    def forward(self, x, ids=None):
+        for k in sorted(self.fac if ids is None else ids):
+            P, B, L, blocks, lp, L21 = self.fac[int(k)]
             y = np.linalg.solve(L, x[P][lp])
             if B.size:
                 x[B] -= L21 @ y
             x[P] = apply_dinv(blocks, y)
-        for (P, B, L, blocks, lp, L21) in reversed(self.fac):
+        return x
+
+    def backward(self, x, ids=None):
+        for k in sorted(self.fac if ids is None else ids, reverse=True):
+            P, B, L, blocks, lp, L21 = self.fac[int(k)]
             v = x[P] - (L21.T @ x[B] if B.size else 0.0)
             xp = np.linalg.solve(L.T, v)
             out = np.zeros(P.size)
             out[lp] = xp
             x[P] = out
         return x
+
+    def solve(self, rhs_e):
+        x = np.array(rhs_e, dtype=float)
+        return self.backward(self.forward(x))

@@ -1,0 +1,78 @@
+"""Worker of test_gpu_shard.py / bench.py --shard-system check: every rank factors
+and solves the SAME KKT system with one handle sharded over the ranks
+(hqpkkt_set_shard) and rank 0 compares with an unsharded handle in-process.
+Launched by torchrun; all ranks may share cuda:0 (backend gloo, host-staged
+exchange) or own a GPU each (backend nccl = RCCL)."""
+import json
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+
+
+def main():
+    import torch
+    import torch.distributed as tdist
+    from hqp_amd import dist, ipmatrix, problems
+    from common import new_d
+
+    backend = os.environ.get("SHARD_BACKEND", "gloo")
+    rank, local_rank, world = dist.env_world()
+    dev = local_rank if backend == "nccl" else 0
+    torch.cuda.set_device(dev)
+    if backend == "nccl":
+        tdist.init_process_group("nccl", device_id=torch.device("cuda", dev))
+    else:
+        tdist.init_process_group("gloo")
+    out = []
+    cases = json.loads(os.environ.get("SHARD_CASES", '[["banded", 1500, 12, "SpBKP"]]'))
+    for case in cases:
+        kind = case[-1]
+        if case[0] == "banded":
+            prog = problems.banded_qp(case[1], case[2])
+        elif case[0] == "docp":
+            prog = problems.lq_docp(case[1], case[2], case[3])
+        else:
+            prog = problems.did_like_qp(case[1])
+        st = problems.ip_state(prog, 7, 1.0)
+        cls = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}[kind]
+        M = cls(device=dev, shard=(rank, world, dist.make_exchange(rank, dev)))
+        M.init(prog)
+        d = new_d(prog)
+        for rep in range(2):  # second round replays the captured graphs
+            M.factor(prog, st[0], st[1])
+            res = M.solve(prog, *st, *d)
+        s = M.stats()
+        owner = M.debug(10)
+        rec = dict(case=case, rank=rank, res=res, n_top=s["n_top"], xblocks=s["n_exchange_blocks"],
+                   flops_local=s["flops_local"], flops_top=s["flops_top"], nodes=s["n_supernodes"],
+                   owned=int((owner == rank).sum()), top=int((owner < 0).sum()),
+                   bytes_factor=s["bytes_exchange_factor"], bytes_step=s["bytes_exchange_step"])
+        if rank == 0:
+            R = cls(device=dev)
+            R.init(prog)
+            R.factor(prog, st[0], st[1])
+            d0 = new_d(prog)
+            res0 = R.solve(prog, *st, *d0)
+            rec["res_single"] = res0
+            rec["diff"] = max(float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
+                              for a, b in zip(d, d0) if len(b))
+        # all ranks must hold the same full solution
+        t = torch.tensor(np.concatenate(d))
+        ref = t.clone()
+        tdist.broadcast(ref, src=0)
+        rec["same_as_rank0"] = bool(torch.equal(t, ref))
+        out.append(rec)
+    gathered = [None] * world
+    tdist.all_gather_object(gathered, out)
+    if rank == 0:
+        print("SHARD_RESULT " + json.dumps(gathered))
+    tdist.barrier()
+    tdist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
