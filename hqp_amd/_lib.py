@@ -11,7 +11,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libhqpkkt.so")
+LIB_PATH = os.environ.get("HQPKKT_LIB") or os.path.join(_HERE, "libhqpkkt.so")  # override: instrumented builds
 
 OK, E_SIZES, E_MEM, E_SING, E_FORMAT, E_NULL, E_RANGE, E_INTERN, E_DEVICE = 0, 1, 3, 4, 6, 8, 10, 17, 100
 MODE_FULL, MODE_REDUCED = 0, 1

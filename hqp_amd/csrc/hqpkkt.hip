@@ -308,7 +308,7 @@ static int upload(hqpkkt_t *h) {
   }
   // dynamic LDS budgets
   const size_t mp = an.max_npiv, ldm = mp | 1, nbm = (mp + 15) / 16;
-  h->lds_diag = (std::max<size_t>(ldm * mp, 2 * 128 * FD_PANEL) + 5 * 128 + 2 * mp) * sizeof(double) +
+  h->lds_diag = (std::max<size_t>(ldm * mp, 2 * FD_PLD * FD_PANEL) + 5 * 128 + 2 * mp) * sizeof(double) +
                 2 * mp * sizeof(int) + 16;
   h->lds_panel = (32 * mp + PS_COLS * mp + 256) * sizeof(double);
   h->lds_solve = (ldm * mp + 2 * mp + nbm * 256) * sizeof(double);
@@ -978,6 +978,14 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
   if (out && !v->empty()) std::memcpy(out, v->data(), sizeof(int) * v->size());
   return 0;
 }
+
+#ifdef HQPKKT_STAMPS
+int hqpkkt_debug_stamps(hqpkkt_t *h, int *out) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpy(out, h->flags.p, sizeof(int) * 64, hipMemcpyDeviceToHost));
+  return 0;
+}
+#endif
 
 int hqpkkt_selftest_mfma(int device, double *max_err) {
   if (!max_err) return HQPKKT_E_NULL;

@@ -247,7 +247,10 @@ __global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
 // of the 16x16 diagonal blocks of L11 used by the triangular solves.
 #define DB 16
 #define FD_THREADS 512
+#ifndef FD_PANEL
 #define FD_PANEL 16
+#endif
+#define FD_PLD 130  // leading dimension of the LDS panel: columns land in different banks
 typedef double PatchT[8][4];  // [row strip m][column strip n]
 
 // Dynamic strip selection is written as chains of selects on VALUES (uniform
@@ -310,6 +313,128 @@ __device__ __forceinline__ void patch_get_row(PatchT &A, int r, int tx, int ty, 
   }
 }
 
+#ifdef HQPKKT_STAMPS
+// instrumented build (tools/): 32-bit s_memtime stamps of block 0 into the spare
+// words of the flags buffer (counters = flags + 1)
+#define STAMP(slot)                                                                              \
+  do {                                                                                           \
+    if (blockIdx.x == 0 && threadIdx.x == 0 && p > 64 && (slot) < 50)                           \
+      counters[8 + (slot)] = (int)__builtin_amdgcn_s_memtime(), counters[8 + 50] = p;            \
+  } while (0)
+#else
+#define STAMP(slot)
+#endif
+
+// broadcast of one lane's double to the wavefront through SGPRs (src is uniform)
+__device__ __forceinline__ double bcast_lane(double v, int src) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+  return __hiloint2double(hi, lo);
+}
+
+// Fast path of k_factor_diag, run by ONE wavefront: up to FD_PANEL consecutive 1x1
+// pivots of the LDS panel Pc (16 columns x 128 rows, column-major, leading
+// dimension FD_PLD).  Each lane keeps its row(s) of the panel in registers (rows
+// lane and lane+64) and the pivot row is broadcast with v_readlane, so a pivot
+// costs no LDS round trip and no barrier.  The body is one basic block: all
+// FD_PANEL pivots are eliminated speculatively while the position of the first one
+// that fails |a_kk| >= alpha max|column| (hqp/spBKP.C:431-438) or is smaller than
+// the perturbation threshold is recorded; if there is one, the panel is redone
+// from its published image with the eliminations behind that position masked out.
+// Per pivot the next diagonal entry is updated and broadcast first, so that its
+// reciprocal (the dependent chain) overlaps the rest of the rank-1 update.
+// HI: the pivots are rows >= 64 (the caller never lets a panel straddle row 64);
+// rows 0..63 are eliminated already and only rows 64.. are updated.
+// Returns the number of pivots done; the panel columns (unscaled) go back to Pc,
+// the multipliers to Pl.  `sink` is LDS scratch for the masked-out stores.
+template <bool TWO, bool HI>
+__device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb, int lane, double alpha,
+                                          double pert, double *dv, int *pt, double *sink) {
+  int limit = kb;
+  for (int attempt = 0; attempt < 2; attempt++) {
+    double R0[FD_PANEL], R1[FD_PANEL];
+#pragma unroll
+    for (int j = 0; j < FD_PANEL; j++) {
+      R0[j] = Pc[lane + FD_PLD * j];
+      R1[j] = TWO ? Pc[lane + 64 + FD_PLD * j] : 0.0;
+    }
+    int first_bad = FD_PANEL;
+    double c[FD_PANEL];  // the pivot row, broadcast through SGPRs
+    {
+      const int src = k & 63;
+#pragma unroll
+      for (int j = 0; j < FD_PANEL; j++) c[j] = bcast_lane(HI ? R1[j] : R0[j], src);
+    }
+    double d = c[0];
+#pragma unroll
+    for (int kk = 0; kk < FD_PANEL; kk++) {
+      const bool act = kk < limit;  // uniform
+      const int kc = k + kk;
+      // (no short-circuit operators: they would become branches)
+      const bool on0 = !HI & act & (lane > kc), on1 = TWO & act & (HI ? lane + 64 > kc : true);
+      const double cmax = fmax(on0 ? fabs(R0[kk]) : 0.0, on1 ? fabs(R1[kk]) : 0.0);
+      const bool bad = (int)!(fabs(d) >= alpha * cmax) | ((int)act & (int)!(fabs(d) >= pert));
+      first_bad = __any(bad) ? min(first_bad, kk) : first_bad;
+      const double di = fast_rcp(d);
+      const double l0 = on0 ? R0[kk] * di : 0.0;
+      const double l1 = on1 ? R1[kk] * di : 0.0;
+      Pl[lane + FD_PLD * kk] = l0;
+      Pl[lane + 64 + FD_PLD * kk] = l1;
+      {  // every lane stores the same values; masked-out pivots go to the sink
+        double *dvp = act ? dv + 2 * kc : sink;
+        int *ptp = act ? pt + kc : (int *)(sink + 2);
+        dvp[0] = di, dvp[1] = 0.0, *ptp = 0;
+      }
+      if (kk + 1 < FD_PANEL) {
+        const int srcn = (kc + 1) & 63;
+        if (!HI) R0[kk + 1] = fma(-l0, c[kk + 1], R0[kk + 1]);
+        if (TWO) R1[kk + 1] = fma(-l1, c[kk + 1], R1[kk + 1]);
+        d = bcast_lane(HI ? R1[kk + 1] : R0[kk + 1], srcn);  // starts the next reciprocal
+#pragma unroll
+        for (int j = kk + 2; j < FD_PANEL; j++) {
+          if (!HI) R0[j] = fma(-l0, c[j], R0[j]);
+          if (TWO) R1[j] = fma(-l1, c[j], R1[j]);
+        }
+#pragma unroll
+        for (int j = kk + 2; j < FD_PANEL; j++) c[j] = bcast_lane(HI ? R1[j] : R0[j], srcn);
+      }
+    }
+    if (first_bad >= limit) {  // uniform; the usual case on the first attempt
+#pragma unroll
+      for (int j = 0; j < FD_PANEL; j++) {
+        if (!HI) Pc[lane + FD_PLD * j] = R0[j];
+        if (TWO) Pc[lane + 64 + FD_PLD * j] = R1[j];
+      }
+      break;
+    }
+    limit = first_bad;
+  }
+  return limit;
+}
+
+// registers <- registers - sum_{t < done} l_t c_t' for the pivots k..k+done-1 of the
+// panel; row strips below MLO and column strips below MLO/2 hold only rows /
+// columns that are already eliminated and are skipped.
+template <int MLO>
+__device__ __forceinline__ void sweep_patch(PatchT &A, const double *Pc, const double *Pl, int k, int done,
+                                            int tx, int ty) {
+  constexpr int NLO = MLO >> 1;
+#pragma unroll 2
+  for (int t = 0; t < done; t++) {
+    double lt[8], ct[4];
+#pragma unroll
+    for (int m = MLO; m < 8; m++) lt[m] = Pl[ty + 16 * m + FD_PLD * t];
+#pragma unroll
+    for (int n = NLO; n < 4; n++) ct[n] = Pc[tx + 32 * n + FD_PLD * t];
+#pragma unroll
+    for (int n = NLO; n < 4; n++) ct[n] = (tx + 32 * n > k + t) ? ct[n] : 0.0;
+#pragma unroll
+    for (int m = MLO; m < 8; m++)
+#pragma unroll
+      for (int n = NLO; n < 4; n++) A[m][n] = fma(-lt[m], ct[n], A[m][n]);
+  }
+}
+
 __global__ void __launch_bounds__(FD_THREADS)
 k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
               double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
@@ -326,17 +451,19 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   double *a = lds;                  // ld * p: staging at load and write-back
   // 128-entry vectors (the patch is zero padded beyond p, so they are written and
   // read without bounds predicates)
-  double *cbuf0 = a + max(ld * p, 2 * 128 * FD_PANEL);  // behind the staging image / panel
+  double *cbuf0 = a + max(ld * p, 2 * FD_PLD * FD_PANEL);  // behind the staging image / panel
   double *cbuf1 = cbuf0 + 128;      // (spare)
   double *cbr = cbuf1 + 128;        // column r (second column of a 2x2)
   double *xb0 = cbr + 128, *xb1 = xb0 + 128;  // row / column exchange
   double *dv = xb1 + 128;           // 2p: inverse pivot data per position
   int *lp = (int *)(dv + 2 * p);    // p   local pivot order
   int *pt = lp + p;                 // p   pivot type per position
+  int *pdone = pt + p;              // 1   pivots done by the fast path of the current panel
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tid & 31, ty = tid >> 5;
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
 
+  STAMP(0);
   if (wave < 4) stage_lower(P, F, p, ld, a, wave, lane);
   for (int i = tid; i < p; i += blockDim.x) lp[i] = i;
   __syncthreads();
@@ -353,8 +480,10 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
 
   // LDS panel of the fast path (aliases the staging image, which is idle in the loop):
   // Pc[i + 128 jj] = current column k+jj (unscaled), Pl[i + 128 jj] = its multipliers
-  double *Pc = a, *Pl = a + 128 * FD_PANEL;
+  double *Pc = a, *Pl = a + FD_PLD * FD_PANEL;
   int k = 0;
+  STAMP(1);
+  int npan = 0;
   while (k < p) {
     k = __builtin_amdgcn_readfirstlane(k);  // wave-uniform: keep it scalar
     // ======== fast path: up to FD_PANEL consecutive 1x1 pivots without interchange ========
@@ -362,92 +491,48 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
     // search, one rank-1 update of the (<= 16-column) LDS panel and one barrier.  The
     // register patches receive the pivots' rank-1 updates afterwards in one sweep.
     {
-      const int kb = min(FD_PANEL, p - k);
+      // (a panel does not straddle row 64: the panel wave keeps rows lane / lane+64 apart)
+      const int kb = min(min(FD_PANEL, p - k), k < 64 ? 64 - k : FD_PANEL);
 #pragma unroll
       for (int n = 0; n < 4; n++) {
         const int jj = tx + 32 * n - k;  // panel slot of this thread's column strip n
         if (jj >= 0 && jj < kb) {
 #pragma unroll
-          for (int m = 0; m < 8; m++) Pc[ty + 16 * m + 128 * jj] = A[m][n];
+          for (int m = 0; m < 8; m++) Pc[ty + 16 * m + FD_PLD * jj] = A[m][n];
         }
       }
       __syncthreads();
-      int done = 0;
-      bool slow = false;
-      for (int kk = 0; kk < kb; kk++) {
-        const int kc = k + kk;
-        const double *col = Pc + 128 * kk;
-        const int i1 = kc + 1 + lane, i2 = i1 + 64;
-        const double v1 = col[i1 & 127], v2 = col[i2 & 127], vkk = col[kc];
-        const float t1 = i1 < p ? fabsf((float)v1) : -1.0f;
-        const float t2 = i2 < p ? fabsf((float)v2) : -1.0f;
-        const float tmax = wave_max_dpp_f(fmaxf(fmaxf(t1, t2), 0.0f));
-        int r = p;
-        {
-          const unsigned long long m1 = __ballot(t1 == tmax), m2 = __ballot(t2 == tmax);
-          if (m1)
-            r = kc + 1 + __builtin_ctzll(m1);
-          else if (m2)
-            r = kc + 65 + __builtin_ctzll(m2);
-        }
-        r = __builtin_amdgcn_readfirstlane(r);
-        const double lambda = r < p ? fabs(col[r]) : 0.0;
-        if (r < p && !(fabs(vkk) >= alpha * lambda)) {  // needs the full Bunch-Kaufman test
-          slow = true;
-          break;
-        }
-        double d = vkk;
-        bool pertd = false;
-        if (!(fabs(d) >= pert)) {
-          d = (double)esign[e0 + lp[kc]] * pert;
-          pertd = true;
-        }
-        const double di = fast_rcp(d);
-        if (tid == 0) {
-          dv[2 * kc] = di, dv[2 * kc + 1] = 0.0, pt[kc] = 0;
-          if (pertd) atomicAdd(&counters[1], 1);
-        }
-        {
-          const int i = tid & 127, grp = tid >> 7;  // row, column group (4 groups)
-          // columns kk+1+grp, +4, +8, +12 of the panel: all loads first
-          double cj[4], pv[4];
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int jj = kk + 1 + grp + 4 * u;
-            const bool on = jj < kb;
-            cj[u] = on ? col[(k + jj) & 127] : 0.0;
-            pv[u] = on ? Pc[i + 128 * (jj & (FD_PANEL - 1))] : 0.0;
-          }
-          const double li = (i > kc) ? col[i] * di : 0.0;
-          if (grp == 0) Pl[i + 128 * kk] = li;
-#pragma unroll
-          for (int u = 0; u < 4; u++) {
-            const int jj = kk + 1 + grp + 4 * u;
-            if (jj < kb) Pc[i + 128 * jj] = fma(-li, cj[u], pv[u]);
-          }
-        }
-        __syncthreads();
-        done++;
+      STAMP(2 + 4 * npan);
+      if (wave == 0) {
+int dn;
+        if (p <= 64)
+          dn = panel_wave<false, false>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt, xb0);
+        else if (k < 64)
+          dn = panel_wave<true, false>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt, xb0);
+        else
+          dn = panel_wave<true, true>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt, xb0);
+        if (lane == 0) *pdone = dn;
       }
+      STAMP(3 + 4 * npan);
+      __syncthreads();
+      STAMP(4 + 4 * npan);
+      const int done = *pdone;
+      const bool slow = done < kb;
       // registers <- registers - sum_t l_t c_t'  (rows / columns <= k+t are masked out;
       // the panel's own columns end up equal to their LDS images)
-#pragma unroll
-      for (int t = 0; t < FD_PANEL; t++) {
-        if (t < done) {  // uniform
-          double lt[8], ct[4];
-#pragma unroll
-          for (int m = 0; m < 8; m++) lt[m] = Pl[ty + 16 * m + 128 * t];
-#pragma unroll
-          for (int n = 0; n < 4; n++) ct[n] = Pc[tx + 32 * n + 128 * t];
-#pragma unroll
-          for (int n = 0; n < 4; n++) ct[n] = (tx + 32 * n > k + t) ? ct[n] : 0.0;
-#pragma unroll
-          for (int m = 0; m < 8; m++)
-#pragma unroll
-            for (int n = 0; n < 4; n++) A[m][n] = fma(-lt[m], ct[n], A[m][n]);
-        }
+      switch ((k + 1) >> 4) {  // uniform: strips of 16 rows that are completely eliminated
+        case 0: sweep_patch<0>(A, Pc, Pl, k, done, tx, ty); break;
+        case 1: sweep_patch<1>(A, Pc, Pl, k, done, tx, ty); break;
+        case 2: sweep_patch<2>(A, Pc, Pl, k, done, tx, ty); break;
+        case 3: sweep_patch<3>(A, Pc, Pl, k, done, tx, ty); break;
+        case 4: sweep_patch<4>(A, Pc, Pl, k, done, tx, ty); break;
+        case 5: sweep_patch<5>(A, Pc, Pl, k, done, tx, ty); break;
+        case 6: sweep_patch<6>(A, Pc, Pl, k, done, tx, ty); break;
+        default: sweep_patch<7>(A, Pc, Pl, k, done, tx, ty); break;
       }
       k += done;
+      STAMP(5 + 4 * npan);
+      npan++;
       __syncthreads();  // the panel is re-used by the next publish
       if (!slow) continue;
     }
@@ -593,6 +678,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
     }
     __syncthreads();
   }
+  STAMP(44);
   // ---- registers -> LDS (lower triangle), then scale the columns: L = C D^-1 ------
 #pragma unroll
   for (int m = 0; m < 8; m++)
@@ -619,8 +705,10 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
     }
   }
   __syncthreads();
+  STAMP(45);
   for (int j = wave; j < p; j += FD_THREADS / 64)
     for (int i = j + lane; i < p; i += 64) P[(long long)j * F + i] = a[i + j * ld];
+  STAMP(46);
   for (int i = tid; i < p; i += blockDim.x) {
     lperm[e0 + i] = lp[i];
     ptype[e0 + i] = pt[i];
@@ -655,6 +743,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
       for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];
     }
   }
+  STAMP(47);
 }
 
 // ---------------------------------------- pivot block of a small supernode
