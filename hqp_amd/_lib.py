@@ -35,7 +35,8 @@ EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong
 class Opts(C.Structure):
     _fields_ = [("mode", C.c_int), ("device", C.c_int), ("loc", C.c_int), ("tol", C.c_double),
                 ("eps", C.c_double), ("pivot_eps", C.c_double), ("leaf_size", C.c_int),
-                ("max_pivots", C.c_int), ("zd_policy", C.c_int), ("reserved", C.c_int * 5)]
+                ("max_pivots", C.c_int), ("zd_policy", C.c_int), ("slack_policy", C.c_int),
+                ("reserved", C.c_int * 4)]
 
 
 class Stats(C.Structure):
@@ -49,7 +50,7 @@ class Stats(C.Structure):
                 ("shard_rank", C.c_int), ("shard_count", C.c_int), ("n_top", C.c_int),
                 ("n_exchange_blocks", C.c_int), ("flops_local", C.c_longlong),
                 ("flops_top", C.c_longlong), ("bytes_exchange_factor", C.c_longlong),
-                ("bytes_exchange_step", C.c_longlong)]
+                ("bytes_exchange_step", C.c_longlong), ("n_slow_pivots", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -469,6 +469,12 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
         else
           heads.push_back(r);
       }
+      // FULL mode, optional: the slack rows (diagonal w/z, which goes to zero for active
+      // constraints) behind the x variables of the node, so that -Q_ii is pivoted first
+      // without a run-time interchange.  Inside a node the front is dense, so the order
+      // is free; the fill of the chain of supernodes grows by ~10 %.
+      if (slack_last && mode == 0)
+        std::stable_partition(heads.begin(), heads.end(), [&](int r) { return pos2q[r] < n + me; });
       std::vector<int> out;
       for (int r : heads) {
         out.push_back(r);

@@ -692,6 +692,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->analyzed = false;
   h->an = Analysis();
   h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
+  h->an.slack_last = h->opts.slack_policy == 1;
   int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
                     h->opts.max_pivots, h->opts.zd_policy);
   if (e) return e;
@@ -761,7 +762,7 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
     h->st.ms_assemble = elapsed(h->ev0, h->ev1);
     h->st.ms_factor = elapsed(h->ev1, h->evs1);
   }
-  h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2];
+  h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
   if (flags[0]) return flags[0];
   if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
   h->factored = true;

@@ -245,6 +245,32 @@ __global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
 // does not happen for structurally non-singular systems.  Eliminated columns
 // stay unscaled (c = l d) until the write-back, which also produces the inverses
 // of the 16x16 diagonal blocks of L11 used by the triangular solves.
+// the same for the 8 wavefronts of k_factor_diag: all loads of a thread (up to 16
+// columns x 2 row halves) are in flight together - one memory latency instead of one
+// per batch
+__device__ __forceinline__ void stage_lower8(const double *__restrict__ P, long long F, int p, int ld,
+                                             double *a, int wave, int lane) {
+  double v[16][2];
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int j = wave + 8 * u;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int i = lane + 64 * h;
+      v[u][h] = (j < p && i < p && i >= j) ? P[(long long)j * F + i] : 0.0;
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int j = wave + 8 * u;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+      const int i = lane + 64 * h;
+      if (j < p && i < p && i >= j) a[i + j * ld] = v[u][h];
+    }
+  }
+}
+
 #define DB 16
 #define FD_THREADS 512
 #ifndef FD_PANEL
@@ -336,13 +362,13 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 // pivots of the LDS panel Pc (16 columns x 128 rows, column-major, leading
 // dimension FD_PLD).  Each lane keeps its row(s) of the panel in registers (rows
 // lane and lane+64) and the pivot row is broadcast with v_readlane, so a pivot
-// costs no LDS round trip and no barrier.  The body is one basic block: all
-// FD_PANEL pivots are eliminated speculatively while the position of the first one
-// that fails |a_kk| >= alpha max|column| (hqp/spBKP.C:431-438) or is smaller than
-// the perturbation threshold is recorded; if there is one, the panel is redone
-// from its published image with the eliminations behind that position masked out.
-// Per pivot the next diagonal entry is updated and broadcast first, so that its
-// reciprocal (the dependent chain) overlaps the rest of the rank-1 update.
+// costs no LDS round trip and no barrier.  The body is one basic block without
+// branches: from the first pivot that fails |a_kk| >= alpha max|column|
+// (hqp/spBKP.C:431-438) or is smaller than the perturbation threshold on, the
+// eliminations are masked out (multipliers 0), so the panel comes back in the
+// state in front of that pivot.  Per pivot the next diagonal entry is updated and
+// broadcast first, so that its reciprocal (the dependent chain) overlaps the rest
+// of the rank-1 update.
 // HI: the pivots are rows >= 64 (the caller never lets a panel straddle row 64);
 // rows 0..63 are eliminated already and only rows 64.. are updated.
 // Returns the number of pivots done; the panel columns (unscaled) go back to Pc,
@@ -350,88 +376,117 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 template <bool TWO, bool HI>
 __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb, int lane, double alpha,
                                           double pert, double *dv, int *pt, double *sink) {
-  int limit = kb;
-  for (int attempt = 0; attempt < 2; attempt++) {
-    double R0[FD_PANEL], R1[FD_PANEL];
+  // one quarter of the rank-1 update that is still pending from the previous pivot
+  // (columns j0, j0+4, ... of the panel): issued between the dependent steps of the
+  // current pivot's reciprocal
+#define PW_PENDING(Q)                                            \
+  _Pragma("unroll") for (int j = kk + 1 + (Q); j < FD_PANEL; j += 4) { \
+    if (!HI) R0[j] = fma(-lp0, cp[j], R0[j]);                    \
+    if (TWO) R1[j] = fma(-lp1, cp[j], R1[j]);                    \
+  }                                                              \
+  __builtin_amdgcn_sched_barrier(0)
+  double R0[FD_PANEL], R1[FD_PANEL];
 #pragma unroll
-    for (int j = 0; j < FD_PANEL; j++) {
-      R0[j] = Pc[lane + FD_PLD * j];
-      R1[j] = TWO ? Pc[lane + 64 + FD_PLD * j] : 0.0;
-    }
-    int first_bad = FD_PANEL;
-    double c[FD_PANEL];  // the pivot row, broadcast through SGPRs
-    {
-      const int src = k & 63;
-#pragma unroll
-      for (int j = 0; j < FD_PANEL; j++) c[j] = bcast_lane(HI ? R1[j] : R0[j], src);
-    }
-    double d = c[0];
-#pragma unroll
-    for (int kk = 0; kk < FD_PANEL; kk++) {
-      const bool act = kk < limit;  // uniform
-      const int kc = k + kk;
-      // (no short-circuit operators: they would become branches)
-      const bool on0 = !HI & act & (lane > kc), on1 = TWO & act & (HI ? lane + 64 > kc : true);
-      const double cmax = fmax(on0 ? fabs(R0[kk]) : 0.0, on1 ? fabs(R1[kk]) : 0.0);
-      const bool bad = (int)!(fabs(d) >= alpha * cmax) | ((int)act & (int)!(fabs(d) >= pert));
-      first_bad = __any(bad) ? min(first_bad, kk) : first_bad;
-      const double di = fast_rcp(d);
-      const double l0 = on0 ? R0[kk] * di : 0.0;
-      const double l1 = on1 ? R1[kk] * di : 0.0;
-      Pl[lane + FD_PLD * kk] = l0;
-      Pl[lane + 64 + FD_PLD * kk] = l1;
-      {  // every lane stores the same values; masked-out pivots go to the sink
-        double *dvp = act ? dv + 2 * kc : sink;
-        int *ptp = act ? pt + kc : (int *)(sink + 2);
-        dvp[0] = di, dvp[1] = 0.0, *ptp = 0;
-      }
-      if (kk + 1 < FD_PANEL) {
-        const int srcn = (kc + 1) & 63;
-        if (!HI) R0[kk + 1] = fma(-l0, c[kk + 1], R0[kk + 1]);
-        if (TWO) R1[kk + 1] = fma(-l1, c[kk + 1], R1[kk + 1]);
-        d = bcast_lane(HI ? R1[kk + 1] : R0[kk + 1], srcn);  // starts the next reciprocal
-#pragma unroll
-        for (int j = kk + 2; j < FD_PANEL; j++) {
-          if (!HI) R0[j] = fma(-l0, c[j], R0[j]);
-          if (TWO) R1[j] = fma(-l1, c[j], R1[j]);
-        }
-#pragma unroll
-        for (int j = kk + 2; j < FD_PANEL; j++) c[j] = bcast_lane(HI ? R1[j] : R0[j], srcn);
-      }
-    }
-    if (first_bad >= limit) {  // uniform; the usual case on the first attempt
-#pragma unroll
-      for (int j = 0; j < FD_PANEL; j++) {
-        if (!HI) Pc[lane + FD_PLD * j] = R0[j];
-        if (TWO) Pc[lane + 64 + FD_PLD * j] = R1[j];
-      }
-      break;
-    }
-    limit = first_bad;
+  for (int j = 0; j < FD_PANEL; j++) {
+    R0[j] = Pc[lane + FD_PLD * j];
+    R1[j] = TWO ? Pc[lane + 64 + FD_PLD * j] : 0.0;
   }
-  return limit;
+  int done = kb;        // pivots in front of the first one that failed the test (uniform)
+  double cp[FD_PANEL];  // the previous pivot's row (broadcast through SGPRs) and multipliers
+  double lp0 = 0.0, lp1 = 0.0;
+#pragma unroll
+  for (int j = 0; j < FD_PANEL; j++) cp[j] = 0.0;
+  double d = bcast_lane(HI ? R1[0] : R0[0], k & 63);
+#pragma unroll
+  for (int kk = 0; kk < FD_PANEL; kk++) {
+    const int kc = k + kk, src = kc & 63;
+    // 1/d: hardware estimate (2^-24) and one cubic step x (1 + e + e^2), e = 1 - d x
+    double x = __builtin_amdgcn_rcp(d);
+    __builtin_amdgcn_sched_barrier(0);
+    PW_PENDING(0);
+    const double e = fma(-d, x, 1.0);
+    __builtin_amdgcn_sched_barrier(0);
+    PW_PENDING(1);
+    const double e2 = fma(e, e, e);
+    __builtin_amdgcn_sched_barrier(0);
+    PW_PENDING(2);
+    const double di = fma(x, e2, x);
+    __builtin_amdgcn_sched_barrier(0);
+    PW_PENDING(3);
+    // this pivot's row (columns behind the pivot), now that they are up to date
+    double c[FD_PANEL];
+#pragma unroll
+    for (int j = kk + 1; j < FD_PANEL; j++) c[j] = bcast_lane(HI ? R1[j] : R0[j], src);
+    // the test (off the dependent chain; no short-circuit operators: they would
+    // become branches).  From the first failing pivot on nothing is eliminated.
+    const bool r0 = !HI & (lane > kc), r1 = TWO & (HI ? lane + 64 > kc : true);
+    const double cmax = fmax(r0 ? fabs(R0[kk]) : 0.0, r1 ? fabs(R1[kk]) : 0.0);
+    const bool bad = (int)!(fabs(d) >= alpha * cmax) | (int)!(fabs(d) >= pert);
+    done = (__any(bad) && kk < done) ? kk : done;
+    const bool act = kk < done;  // uniform
+    const double l0 = (act & r0) ? R0[kk] * di : 0.0;
+    const double l1 = (act & r1) ? R1[kk] * di : 0.0;
+    if (kk + 1 < FD_PANEL) {  // the next diagonal entry first: it starts the next chain
+      if (!HI) R0[kk + 1] = fma(-l0, c[kk + 1], R0[kk + 1]);
+      if (TWO) R1[kk + 1] = fma(-l1, c[kk + 1], R1[kk + 1]);
+      d = bcast_lane(HI ? R1[kk + 1] : R0[kk + 1], (kc + 1) & 63);
+    }
+    Pl[lane + FD_PLD * kk] = l0;
+    Pl[lane + 64 + FD_PLD * kk] = l1;
+    {  // every lane stores the same values; masked-out pivots go to the sink
+      double *dvp = act ? dv + 2 * kc : sink;
+      int *ptp = act ? pt + kc : (int *)(sink + 2);
+      dvp[0] = di, dvp[1] = 0.0, *ptp = 0;
+    }
+    lp0 = l0, lp1 = l1;
+#pragma unroll
+    for (int j = kk + 2; j < FD_PANEL; j++) cp[j] = c[j];
+    __builtin_amdgcn_sched_barrier(0);
+  }
+#pragma unroll
+  for (int j = 0; j < FD_PANEL; j++) {
+    if (!HI) Pc[lane + FD_PLD * j] = R0[j];
+    if (TWO) Pc[lane + 64 + FD_PLD * j] = R1[j];
+  }
+#undef PW_PENDING
+  return done;
 }
 
 // registers <- registers - sum_{t < done} l_t c_t' for the pivots k..k+done-1 of the
-// panel; row strips below MLO and column strips below MLO/2 hold only rows /
-// columns that are already eliminated and are skipped.
-template <int MLO>
+// panel.  Only the strips MLO <= m < MHI of 16 rows (and the matching strips of 32
+// columns) take part: below MLO everything is eliminated already, from MHI on the
+// patch is the zero padding behind row / column p.
+template <int MLO, int MHI>
 __device__ __forceinline__ void sweep_patch(PatchT &A, const double *Pc, const double *Pl, int k, int done,
                                             int tx, int ty) {
-  constexpr int NLO = MLO >> 1;
+  constexpr int NLO = MLO >> 1, NHI = (MHI + 1) >> 1;
 #pragma unroll 2
   for (int t = 0; t < done; t++) {
     double lt[8], ct[4];
 #pragma unroll
-    for (int m = MLO; m < 8; m++) lt[m] = Pl[ty + 16 * m + FD_PLD * t];
+    for (int m = MLO; m < MHI; m++) lt[m] = Pl[ty + 16 * m + FD_PLD * t];
 #pragma unroll
-    for (int n = NLO; n < 4; n++) ct[n] = Pc[tx + 32 * n + FD_PLD * t];
+    for (int n = NLO; n < NHI; n++) ct[n] = Pc[tx + 32 * n + FD_PLD * t];
 #pragma unroll
-    for (int n = NLO; n < 4; n++) ct[n] = (tx + 32 * n > k + t) ? ct[n] : 0.0;
+    for (int n = NLO; n < NHI; n++) ct[n] = (tx + 32 * n > k + t) ? ct[n] : 0.0;
 #pragma unroll
-    for (int m = MLO; m < 8; m++)
+    for (int m = MLO; m < MHI; m++)
 #pragma unroll
-      for (int n = NLO; n < 4; n++) A[m][n] = fma(-lt[m], ct[n], A[m][n]);
+      for (int n = NLO; n < NHI; n++) A[m][n] = fma(-lt[m], ct[n], A[m][n]);
+  }
+}
+template <int MHI>
+__device__ __forceinline__ void sweep_rows(PatchT &A, const double *Pc, const double *Pl, int k, int done,
+                                           int tx, int ty) {
+  switch ((k + 1) >> 4) {  // uniform: strips of 16 rows that are completely eliminated
+    case 0: sweep_patch<0, MHI>(A, Pc, Pl, k, done, tx, ty); break;
+    case 1: if constexpr (MHI > 1) sweep_patch<1, MHI>(A, Pc, Pl, k, done, tx, ty); break;
+    case 2: if constexpr (MHI > 2) sweep_patch<2, MHI>(A, Pc, Pl, k, done, tx, ty); break;
+    case 3: if constexpr (MHI > 3) sweep_patch<3, MHI>(A, Pc, Pl, k, done, tx, ty); break;
+    case 4: if constexpr (MHI > 4) sweep_patch<4, MHI>(A, Pc, Pl, k, done, tx, ty); break;
+    case 5: if constexpr (MHI > 5) sweep_patch<5, MHI>(A, Pc, Pl, k, done, tx, ty); break;
+    case 6: if constexpr (MHI > 6) sweep_patch<6, MHI>(A, Pc, Pl, k, done, tx, ty); break;
+    default: if constexpr (MHI > 7) sweep_patch<7, MHI>(A, Pc, Pl, k, done, tx, ty); break;
   }
 }
 
@@ -464,7 +519,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
 
   STAMP(0);
-  if (wave < 4) stage_lower(P, F, p, ld, a, wave, lane);
+  stage_lower8(P, F, p, ld, a, wave, lane);
   for (int i = tid; i < p; i += blockDim.x) lp[i] = i;
   __syncthreads();
   PatchT A;
@@ -482,6 +537,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   // Pc[i + 128 jj] = current column k+jj (unscaled), Pl[i + 128 jj] = its multipliers
   double *Pc = a, *Pl = a + FD_PLD * FD_PANEL;
   int k = 0;
+  bool had2x2 = false;  // block-uniform
   STAMP(1);
   int npan = 0;
   while (k < p) {
@@ -520,15 +576,15 @@ int dn;
       const bool slow = done < kb;
       // registers <- registers - sum_t l_t c_t'  (rows / columns <= k+t are masked out;
       // the panel's own columns end up equal to their LDS images)
-      switch ((k + 1) >> 4) {  // uniform: strips of 16 rows that are completely eliminated
-        case 0: sweep_patch<0>(A, Pc, Pl, k, done, tx, ty); break;
-        case 1: sweep_patch<1>(A, Pc, Pl, k, done, tx, ty); break;
-        case 2: sweep_patch<2>(A, Pc, Pl, k, done, tx, ty); break;
-        case 3: sweep_patch<3>(A, Pc, Pl, k, done, tx, ty); break;
-        case 4: sweep_patch<4>(A, Pc, Pl, k, done, tx, ty); break;
-        case 5: sweep_patch<5>(A, Pc, Pl, k, done, tx, ty); break;
-        case 6: sweep_patch<6>(A, Pc, Pl, k, done, tx, ty); break;
-        default: sweep_patch<7>(A, Pc, Pl, k, done, tx, ty); break;
+      switch ((p + 15) >> 4) {  // uniform: strips of 16 rows that hold rows < p
+        case 1: sweep_rows<1>(A, Pc, Pl, k, done, tx, ty); break;
+        case 2: sweep_rows<2>(A, Pc, Pl, k, done, tx, ty); break;
+        case 3: sweep_rows<3>(A, Pc, Pl, k, done, tx, ty); break;
+        case 4: sweep_rows<4>(A, Pc, Pl, k, done, tx, ty); break;
+        case 5: sweep_rows<5>(A, Pc, Pl, k, done, tx, ty); break;
+        case 6: sweep_rows<6>(A, Pc, Pl, k, done, tx, ty); break;
+        case 7: sweep_rows<7>(A, Pc, Pl, k, done, tx, ty); break;
+        default: sweep_rows<8>(A, Pc, Pl, k, done, tx, ty); break;
       }
       k += done;
       STAMP(5 + 4 * npan);
@@ -537,6 +593,7 @@ int dn;
       if (!slow) continue;
     }
     // ======== slow path: one pivot with the complete test, interchanges, 2x2 pivots ========
+    if (tid == 0) atomicAdd(&counters[2], 1);  // statistics: pivots that needed the complete test
     double *cur = cbuf0;
     patch_put_col(A, k, tx, ty, p, cur);
     __syncthreads();
@@ -651,6 +708,7 @@ int dn;
         det = d11 * d22;
         pertd = true;
       }
+      had2x2 = true;
       const double rdet = fast_rcp(det);
       const double i11 = d22 * rdet, i21 = -d21 * rdet, i22 = d11 * rdet;
       if (tid == 0) {
@@ -679,22 +737,30 @@ int dn;
     __syncthreads();
   }
   STAMP(44);
-  // ---- registers -> LDS (lower triangle), then scale the columns: L = C D^-1 ------
-#pragma unroll
-  for (int m = 0; m < 8; m++)
+  // ---- registers -> LDS (lower triangle), scaling the columns on the way: L = C D^-1 ---
+  // (columns of 1x1 pivots are scaled here; the rare 2x2 pairs need both columns and
+  // are finished in LDS)
+  {
+    double dj[4];
+    int tj[4];
 #pragma unroll
     for (int n = 0; n < 4; n++) {
-      const int i = ty + 16 * m, j = tx + 32 * n;
-      if (i < p && j < p && i >= j) a[i + j * ld] = A[m][n];
+      const int j = min(tx + 32 * n, p - 1);
+      dj[n] = dv[2 * j], tj[n] = pt[j];
     }
+#pragma unroll
+    for (int m = 0; m < 8; m++)
+#pragma unroll
+      for (int n = 0; n < 4; n++) {
+        const int i = ty + 16 * m, j = tx + 32 * n;
+        const double v = (i > j && tj[n] == 0) ? A[m][n] * dj[n] : A[m][n];
+        if (i < p && j < p && i >= j) a[i + j * ld] = v;
+      }
+  }
   __syncthreads();
-  for (int j = wave; j < p; j += FD_THREADS / 64) {
-    const int ty_ = pt[j];
-    if (ty_ == 2) continue;  // handled with its partner
-    if (ty_ == 0) {
-      const double di = dv[2 * j];
-      for (int i = j + 1 + lane; i < p; i += 64) a[i + j * ld] *= di;
-    } else {
+  if (had2x2) {  // block-uniform
+    for (int j = wave; j < p; j += FD_THREADS / 64) {
+      if (pt[j] != 1) continue;
       const double i11 = dv[2 * j], i21 = dv[2 * j + 1], i22 = dv[2 * j + 2];
       for (int i = j + 2 + lane; i < p; i += 64) {
         const double c1 = a[i + j * ld], c2 = a[i + (j + 1) * ld];
@@ -703,23 +769,25 @@ int dn;
       }
       if (lane == 0) a[j + 1 + j * ld] = 0.0;
     }
+    __syncthreads();
   }
-  __syncthreads();
   STAMP(45);
-  for (int j = wave; j < p; j += FD_THREADS / 64)
-    for (int i = j + lane; i < p; i += 64) P[(long long)j * F + i] = a[i + j * ld];
-  STAMP(46);
-  for (int i = tid; i < p; i += blockDim.x) {
-    lperm[e0 + i] = lp[i];
-    ptype[e0 + i] = pt[i];
-    dinv[2 * (e0 + i)] = dv[2 * i];
-    dinv[2 * (e0 + i) + 1] = dv[2 * i + 1];
-  }
-  // ---- inverses of the 16x16 diagonal blocks of L11 (unit lower) ---------------
-  // one 16-lane group per block: lane c solves L x = e_c by forward substitution
-  double *DBo = dblk + dblk_off[node];
-  const int nb = (p + DB - 1) / DB;
-  {
+  // waves 2..7 write L11 and the pivot data back while waves 0..1 invert the 16x16
+  // diagonal blocks of L11 (unit lower) for the triangular solves: one 16-lane group
+  // per block, lane c solves L x = e_c by forward substitution
+  if (wave >= 2) {
+    for (int j = wave - 2; j < p; j += FD_THREADS / 64 - 2)
+      for (int i = j + lane; i < p; i += 64) P[(long long)j * F + i] = a[i + j * ld];
+    for (int i = tid - 128; i < p; i += blockDim.x - 128) {
+      lperm[e0 + i] = lp[i];
+      ptype[e0 + i] = pt[i];
+      dinv[2 * (e0 + i)] = dv[2 * i];
+      dinv[2 * (e0 + i) + 1] = dv[2 * i + 1];
+    }
+    STAMP(46);
+  } else {
+    double *DBo = dblk + dblk_off[node];
+    const int nb = (p + DB - 1) / DB;
     const int blk = tid >> 4, c = tid & 15;
     if (blk < nb) {
       const int kb = blk * DB, kw = min(DB, p - kb);
@@ -728,16 +796,13 @@ int dn;
       for (int rr = 0; rr < DB; rr++) x[rr] = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
       for (int rr = 1; rr < DB; rr++) {
-        double acc0 = 0.0, acc1 = 0.0;
+        double acc[4] = {0.0, 0.0, 0.0, 0.0};  // fp64 FMA latency: independent partial sums
 #pragma unroll
         for (int t = 0; t < rr; t++) {
           const double l = (rr < kw) ? a[kb + rr + (kb + t) * ld] : 0.0;
-          if (t & 1)
-            acc1 += l * x[t];
-          else
-            acc0 += l * x[t];
+          acc[t & 3] += l * x[t];
         }
-        if (rr > c) x[rr] = -(acc0 + acc1);
+        if (rr > c) x[rr] = -((acc[0] + acc[1]) + (acc[2] + acc[3]));
       }
 #pragma unroll
       for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];

@@ -65,7 +65,13 @@ typedef struct hqpkkt_opts {
   int zd_policy;     /* placement of variables with a structurally zero diagonal
                         (equality multipliers): 2 = behind all their neighbours
                         (default), 0 = behind one matched neighbour             */
-  int reserved[5];
+  int slack_policy;  /* FULL mode, order of the slack rows inside a supernode:
+                        0 = band order (default; a slack row with small w/z in
+                        front of its x variable is interchanged at run time by the
+                        Bunch-Kaufman test), 1 = behind the x variables of the node
+                        (no run-time interchanges, ~10 % more fill; less accurate
+                        next to a degenerate solution)                            */
+  int reserved[4];
 } hqpkkt_opts;
 
 typedef struct hqpkkt_stats {
@@ -94,6 +100,9 @@ typedef struct hqpkkt_stats {
   long long flops_local, flops_top; /* factor flops of this rank's subtrees / top  */
   long long bytes_exchange_factor;  /* all-gather volume per factor (all slots)    */
   long long bytes_exchange_step;    /* all-gather + all-reduce volume per step     */
+  int n_slow_pivots;      /* pivots of the last factor that failed the cheap test
+                             |a_kk| >= alpha max|column| and took the complete
+                             Bunch-Kaufman decision (k_factor_diag's slow path)   */
 } hqpkkt_stats;
 
 /* Fill *opts with the defaults (mode FULL, device 0, host pointers, tol 1.0,
