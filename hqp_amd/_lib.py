@@ -24,7 +24,7 @@ SYMBOLS = [
     "hqpkkt_get_sbw", "hqpkkt_get_perm", "hqpkkt_set_tol", "hqpkkt_set_eps",
     "hqpkkt_set_stream", "hqpkkt_get_stats", "hqpkkt_strerror", "hqpkkt_debug_get",
     "hqpkkt_selftest_mfma", "hqpkkt_set_profile", "hqpkkt_get_profile",
-    "hqpkkt_profile_class_name", "hqpkkt_set_shard",
+    "hqpkkt_profile_class_name", "hqpkkt_set_shard", "hqpkkt_debug_read",
 ]
 
 XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
@@ -101,6 +101,7 @@ def lib():
     L.hqpkkt_profile_class_name.restype = C.c_char_p
     L.hqpkkt_profile_class_name.argtypes = [C.c_int]
     L.hqpkkt_set_shard.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
+    L.hqpkkt_debug_read.argtypes = [vp, C.c_int, C.c_int, vp, C.c_longlong, C.POINTER(C.c_longlong)]
     _lib = L
     return L
 

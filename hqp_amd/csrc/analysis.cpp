@@ -703,6 +703,9 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   dblk_off.assign(nnodes, 0);
   dblk_elems = 0;
   for (int id = 0; id < nnodes; id++) dblk_off[id] = dblk_elems, dblk_elems += 256LL * ((npiv[id] + 15) / 16);
+  linv_off.assign(nnodes, 0);
+  linv_elems = 0;
+  for (int id = 0; id < nnodes; id++) linv_off[id] = linv_elems, linv_elems += (long long)npiv[id] * npiv[id];
 
   // per-level work lists: [0] this rank's subtrees, [1] the replicated top
   for (int which = 0; which < 2; which++) {

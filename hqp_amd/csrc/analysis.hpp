@@ -68,6 +68,8 @@ struct Analysis {
   std::vector<signed char> keep_e;  // per elimination index: this rank contributes it to the all-reduce
   std::vector<long long> dblk_off;             // inverse diagonal blocks, 256 doubles each
   long long dblk_elems = 0;
+  std::vector<long long> linv_off;             // explicit inverses of the L11 blocks, p x p each
+  long long linv_elems = 0;
 
   // --- numeric assembly map ----------------------------------------------------
   std::vector<long long> ent_dst;  // offset into the panel arena per entry

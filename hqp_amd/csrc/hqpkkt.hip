@@ -157,12 +157,12 @@ struct hqpkkt {
   int shard_rank = 0, shard_count = 1;
   hqpkkt_exchange_fn xchg_fn = nullptr;
   void *xchg_ctx = nullptr;
-  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, dblk_off;
+  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, dblk_off, linv_off;
   DBuf<TermDev> terms;
   DBuf<signed char> esign;
   CsrBuf Qf, A, AT, C, CT;
   // numeric state
-  DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb, ytmp, vtmp, dblk;
+  DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb, ytmp, vtmp, dblk, linv;
   DBuf<int> ptype, lperm, flags;  // flags: [0] status, [1] n_2x2, [2] n_perturbed
   DBuf<unsigned long long> bits;  // [0] kmax, [1] residual max
   // vectors: staging for host pointers + refinement work vectors
@@ -199,11 +199,11 @@ struct hqpkkt {
                        &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &ptype, &lperm, &flags};
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release();
-    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &dblk_off,
+    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &dblk_off, &linv_off,
                              &zero_panel, &zero_upd};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &dblk};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &dblk, &linv};
     for (auto b : db) b->release();
     terms.release(), esign.release(), bits.release();
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
@@ -259,6 +259,7 @@ static int upload(hqpkkt_t *h) {
   UP(zero_upd, zero_upd);
   UP(keep_e, keep_e);
   UP(dblk_off, dblk_off);
+  UP(linv_off, linv_off);
   UP(ent_a, ent_a);
   UP(ent_b, ent_b);
   UP(term_ptr, term_ptr);
@@ -292,7 +293,7 @@ static int upload(hqpkkt_t *h) {
       (e = h->upd.alloc(an.upd_elems)) || (e = h->xar.alloc(an.x_elems)) ||
       (e = h->dinv.alloc(2 * (size_t)dim)) || (e = h->rhs.alloc(dim)) ||
       (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ytmp.alloc(dim)) ||
-      (e = h->vtmp.alloc(dim)) || (e = h->dblk.alloc(an.dblk_elems)) || (e = h->ptype.alloc(dim)) ||
+      (e = h->vtmp.alloc(dim)) || (e = h->dblk.alloc(an.dblk_elems)) || (e = h->linv.alloc(an.linv_elems)) || (e = h->ptype.alloc(dim)) ||
       (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(64)) || (e = h->bits.alloc(2)) ||
       (e = h->vin.alloc(2 * (size_t)m + n + me + 2 * (size_t)m)) ||
       (e = h->vout.alloc((size_t)n + me + 2 * (size_t)m)) ||
@@ -310,7 +311,7 @@ static int upload(hqpkkt_t *h) {
   const size_t mp = an.max_npiv, ldm = mp | 1, nbm = (mp + 15) / 16;
   h->lds_diag = (std::max<size_t>(ldm * mp, 2 * FD_PLD * FD_PANEL) + 5 * 128 + 2 * mp) * sizeof(double) +
                 2 * mp * sizeof(int) + 16;
-  h->lds_panel = (32 * mp + PS_COLS * mp + 256) * sizeof(double);
+  h->lds_panel = 32 * mp * sizeof(double);
   h->lds_solve = (ldm * mp + 2 * mp + nbm * 256) * sizeof(double);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
   if (h->lds_diag > 160 * 1024 || h->lds_solve > 160 * 1024 || h->lds_bwdb > 160 * 1024) return HQPKKT_E_MEM;
@@ -318,10 +319,6 @@ static int upload(hqpkkt_t *h) {
                              (int)h->lds_diag));
   HIPCHK(hipFuncSetAttribute((const void *)k_panel_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_panel));
-  HIPCHK(hipFuncSetAttribute((const void *)k_solve_fwd_a, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)h->lds_solve));
-  HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd_a, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)h->lds_solve));
   HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_bwdb));
   h->st.bytes_panels = (long long)sizeof(double) * (an.panel_elems + an.x_elems);
@@ -430,18 +427,18 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
       if (nsm > 0)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<<<nsm, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
-                                                 h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->dblk_off.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1));
       if (nn > nsm)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
-                                                 h->dblk_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->dblk_off.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1));
       const int ns = S.slab_ptr[l + 1] - S.slab_ptr[l];
       if (ns > 0)
         KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, D.slabs.p + 2 * (size_t)S.slab_ptr[l],
                                                     h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
-                                                    h->lperm.p, h->dblk.p, h->dblk_off.p));
+                                                    h->lperm.p, h->linv.p, h->linv_off.p));
       const int nt = S.upd_tile_ptr[l + 1] - S.upd_tile_ptr[l];
       if (nt > 0)
         KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_tile_ptr[l],
@@ -468,10 +465,9 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l];
       if (nn > 0)
         KLAUNCH(h, KC_SOLVE_FWD,
-                k_solve_fwd_a<<<nn, 256, h->lds_solve, s>>>(T, D.level_nodes.p + S.level_ptr[l],
-                                                            h->panel.p, h->dinv.p, h->ptype.p, h->lperm.p,
-                                                            h->dblk.p, h->dblk_off.p, h->rhs.p, h->xsol.p,
-                                                            h->ytmp.p, h->cb.p));
+                k_solve_fwd_a<<<nn, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->linv.p,
+                                                 h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p,
+                                                 h->rhs.p, h->xsol.p, h->ytmp.p, h->cb.p));
       const int ng = S.gslab_ptr[l + 1] - S.gslab_ptr[l];
       if (ng > 0)
         KLAUNCH(h, KC_SOLVE_FWD,
@@ -491,9 +487,8 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
               k_solve_bwd_b<<<ncb, 256, h->lds_bwdb, s>>>(T, D.cblks.p + 2 * (size_t)S.cblk_ptr[l],
                                                           h->panel.p, h->xsol.p, h->vtmp.p));
       KLAUNCH(h, KC_SOLVE_BWD,
-              k_solve_bwd_a<<<nn, 256, h->lds_solve, s>>>(T, D.level_nodes.p + S.level_ptr[l],
-                                                          h->panel.p, h->lperm.p, h->dblk.p,
-                                                          h->dblk_off.p, h->vtmp.p, h->xsol.p));
+              k_solve_bwd_a<<<nn, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->linv.p,
+                                               h->linv_off.p, h->lperm.p, h->vtmp.p, h->xsol.p));
     }
     return 0;
   };
@@ -987,6 +982,30 @@ int hqpkkt_debug_stamps(hqpkkt_t *h, int *out) {
   return 0;
 }
 #endif
+
+int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long cap, long long *len) {
+  if (!h || !len) return HQPKKT_E_NULL;
+  if (!h->uploaded) return HQPKKT_E_INTERN;
+  const Analysis &an = h->an;
+  if (node < 0 || node >= an.nnodes) return HQPKKT_E_RANGE;
+  const long long p = an.npiv[node], b = an.nbor[node];
+  const double *src = nullptr;
+  long long n = 0;
+  switch (what) {
+    case 0: src = h->panel.p + an.panel_off[node], n = (p + b) * p; break;
+    case 1: src = h->linv.p + an.linv_off[node], n = p * p; break;
+    case 2: src = h->xar.p + an.x_off[node], n = b * p; break;
+    case 3: src = h->upd.p + an.upd_off[node], n = b * b; break;
+    default: return HQPKKT_E_RANGE;
+  }
+  *len = n;
+  if (!out) return 0;
+  if (cap < n) return HQPKKT_E_SIZES;
+  HIPCHK(hipSetDevice(h->opts.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  if (n) HIPCHK(hipMemcpy(out, src, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return 0;
+}
 
 int hqpkkt_selftest_mfma(int device, double *max_err) {
   if (!max_err) return HQPKKT_E_NULL;

@@ -18,6 +18,9 @@
 namespace kktdev {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
 
 struct DevTree {
   const int *piv_start, *npiv, *nbor, *parent;
@@ -494,7 +497,8 @@ __global__ void __launch_bounds__(FD_THREADS)
 k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
               double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
               const signed char *__restrict__ esign, double *__restrict__ dblk,
-              const long long *__restrict__ dblk_off, double alpha, double pivot_eps,
+              const long long *__restrict__ dblk_off, double *__restrict__ linv,
+              const long long *__restrict__ linv_off, double alpha, double pivot_eps,
               const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = level_nodes[blockIdx.x];
@@ -773,42 +777,99 @@ int dn;
   }
   STAMP(45);
   // waves 2..7 write L11 and the pivot data back while waves 0..1 invert the 16x16
-  // diagonal blocks of L11 (unit lower) for the triangular solves: one 16-lane group
-  // per block, lane c solves L x = e_c by forward substitution
-  if (wave >= 2) {
-    for (int j = wave - 2; j < p; j += FD_THREADS / 64 - 2)
-      for (int i = j + lane; i < p; i += 64) P[(long long)j * F + i] = a[i + j * ld];
-    for (int i = tid - 128; i < p; i += blockDim.x - 128) {
-      lperm[e0 + i] = lp[i];
-      ptype[e0 + i] = pt[i];
-      dinv[2 * (e0 + i)] = dv[2 * i];
-      dinv[2 * (e0 + i) + 1] = dv[2 * i + 1];
-    }
-    STAMP(46);
-  } else {
-    double *DBo = dblk + dblk_off[node];
-    const int nb = (p + DB - 1) / DB;
+  // diagonal blocks of L11 (unit lower): one 16-lane group per block, lane c solves
+  // L x = e_c column-oriented (15 dependent steps of independent FMAs)
+  const int nb = (p + DB - 1) / DB;
+  double xinv[DB];
+  {
     const int blk = tid >> 4, c = tid & 15;
-    if (blk < nb) {
+    if (wave >= 2) {
+      for (int j = wave - 2; j < p; j += FD_THREADS / 64 - 2)
+        for (int i = j + lane; i < p; i += 64) P[(long long)j * F + i] = a[i + j * ld];
+      for (int i = tid - 128; i < p; i += blockDim.x - 128) {
+        lperm[e0 + i] = lp[i];
+        ptype[e0 + i] = pt[i];
+        dinv[2 * (e0 + i)] = dv[2 * i];
+        dinv[2 * (e0 + i) + 1] = dv[2 * i + 1];
+      }
+    } else if (blk < nb) {
       const int kb = blk * DB, kw = min(DB, p - kb);
-      double x[DB];
 #pragma unroll
-      for (int rr = 0; rr < DB; rr++) x[rr] = (rr == c) ? 1.0 : 0.0;
+      for (int rr = 0; rr < DB; rr++) xinv[rr] = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
-      for (int rr = 1; rr < DB; rr++) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};  // fp64 FMA latency: independent partial sums
+      for (int t = 0; t < DB - 1; t++) {
+        const double xt = xinv[t];
 #pragma unroll
-        for (int t = 0; t < rr; t++) {
+        for (int rr = t + 1; rr < DB; rr++) {
           const double l = (rr < kw) ? a[kb + rr + (kb + t) * ld] : 0.0;
-          acc[t & 3] += l * x[t];
+          xinv[rr] = fma(-l, xt, xinv[rr]);
         }
-        if (rr > c) x[rr] = -((acc[0] + acc[1]) + (acc[2] + acc[3]));
+      }
+      double *DBo = dblk + dblk_off[node];
+#pragma unroll
+      for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = xinv[rr];
+    }
+    __syncthreads();  // the write-back has read a[]
+    STAMP(46);
+    // ---- M = L11^-1 in place (hqp/spBKP.C has no counterpart: it substitutes row by
+    // row; the explicit inverse turns the panel solve and the tree solves into
+    // products).  The diagonal blocks first ...
+    if (wave < 2 && blk < nb) {
+      const int kb = blk * DB, kw = min(DB, p - kb);
+#pragma unroll
+      for (int rr = 0; rr < DB; rr++)
+        if (rr < kw && c < kw) a[kb + rr + (kb + c) * ld] = xinv[rr];  // zeros above the diagonal
+    }
+    __syncthreads();
+  }
+  // ... then row block i from the rows above it: M_ij = -M_ii sum_{k=j}^{i-1} L_ik M_kj,
+  // wave j owns block (i, j): 16x16x4 MFMAs with both operands from the LDS image.
+  // The first product's result, in the MFMA C/D layout (lane: column l&15, rows
+  // (l>>4)+4q), is exactly the B operand of the second product's four k-slices, so
+  // it never leaves the registers; the row block is overwritten after a barrier.
+  for (int i = 1; i < nb; i++) {
+    const int ri = DB * i, j = wave;
+    const bool have = j < i;  // wave-uniform
+    const int ml = lane & 15, kl = lane >> 4;
+    double4_t res = {0.0, 0.0, 0.0, 0.0};
+    if (have) {
+      double4_t tacc = {0.0, 0.0, 0.0, 0.0};
+      const bool rowon = ri + ml < p;
+      for (int k = j; k < i; k++) {
+        double av[4], bv[4];
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) {
+          const int kc = DB * k + 4 * s4 + kl;
+          av[s4] = rowon ? a[ri + ml + kc * ld] : 0.0;  // L_ik
+          bv[s4] = a[kc + (DB * j + ml) * ld];           // M_kj (k == j: zeros above the diagonal)
+        }
+#pragma unroll
+        for (int s4 = 0; s4 < 4; s4++) tacc = mfma_f64(av[s4], bv[s4], tacc);
       }
 #pragma unroll
-      for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];
+      for (int s4 = 0; s4 < 4; s4++) {
+        const int kc = ri + 4 * s4 + kl;
+        const double av = (rowon && kc < p) ? a[ri + ml + kc * ld] : 0.0;  // M_ii
+        res = mfma_f64(av, tacc[s4], res);
+      }
     }
+    __syncthreads();
+    if (have) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const int row = ri + kl + 4 * q;
+        if (row < p) a[row + (DB * j + ml) * ld] = -res[q];
+      }
+    }
+    __syncthreads();
   }
   STAMP(47);
+  {
+    double *W = linv + linv_off[node];  // p x p, column-major; whole diagonal blocks + below
+    for (int j = wave; j < p; j += FD_THREADS / 64)
+      for (int i = (j & ~(DB - 1)) + lane; i < p; i += 64) W[(long long)j * p + i] = a[i + j * ld];
+  }
+  STAMP(48);
 }
 
 // ---------------------------------------- pivot block of a small supernode
@@ -824,7 +885,8 @@ __global__ void __launch_bounds__(64)
 k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
                     double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
                     const signed char *__restrict__ esign, double *__restrict__ dblk,
-                    const long long *__restrict__ dblk_off, double alpha, double pivot_eps,
+                    const long long *__restrict__ dblk_off, double *__restrict__ linv,
+                    const long long *__restrict__ linv_off, double alpha, double pivot_eps,
                     const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
   __shared__ double a[FS_MAXP * FS_LD];
   __shared__ double dv[2 * FS_MAXP];
@@ -954,44 +1016,88 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
     dinv[2 * (e0 + lane)] = dv[2 * lane];
     dinv[2 * (e0 + lane) + 1] = dv[2 * lane + 1];
   }
-  // inverses of the (at most two) 16x16 diagonal blocks of L11
+  // inverses of the (at most two) 16x16 diagonal blocks of L11, then M = L11^-1 in
+  // place (M_10 = -M_11 L_10 M_00) for the product-form panel solve / tree solves
   double *DBo = dblk + dblk_off[node];
   const int nb = (p + DB - 1) / DB;
   const int blk = lane >> 4, c = lane & 15;
+  double x[DB];
   if (blk < nb) {
     const int kb = blk * DB, kw = min(DB, p - kb);
-    double x[DB];
 #pragma unroll
     for (int rr = 0; rr < DB; rr++) x[rr] = (rr == c) ? 1.0 : 0.0;
 #pragma unroll
-    for (int rr = 1; rr < DB; rr++) {
-      double acc0 = 0.0, acc1 = 0.0;
+    for (int t = 0; t < DB - 1; t++) {
+      const double xt = x[t];
 #pragma unroll
-      for (int t = 0; t < rr; t++) {
+      for (int rr = t + 1; rr < DB; rr++) {
         const double l = (rr < kw) ? a[kb + rr + (kb + t) * FS_LD] : 0.0;
-        if (t & 1)
-          acc1 += l * x[t];
-        else
-          acc0 += l * x[t];
+        x[rr] = fma(-l, xt, x[rr]);
       }
-      if (rr > c) x[rr] = -(acc0 + acc1);
     }
 #pragma unroll
     for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];
   }
+  __syncthreads();
+  if (blk < nb) {
+    const int kb = blk * DB, kw = min(DB, p - kb);
+#pragma unroll
+    for (int rr = 0; rr < DB; rr++)
+      if (rr < kw && c < kw) a[kb + rr + (kb + c) * FS_LD] = x[rr];
+  }
+  __syncthreads();
+  if (nb == 2) {
+    const int kw1 = p - DB, r = lane & 15, cq = (lane >> 4) * 4;
+    const bool rowon = r < kw1;
+    double t4[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int tt = 0; tt < DB; tt++) {
+      const double l = rowon ? a[DB + r + tt * FS_LD] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) t4[q] = fma(l, a[tt + (cq + q) * FS_LD], t4[q]);
+    }
+    __syncthreads();
+    if (rowon) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) a[DB + r + (cq + q) * FS_LD] = t4[q];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int q = 0; q < 4; q++) t4[q] = 0.0;
+    for (int sft = 0; sft < kw1; sft++) {
+      const double mii = rowon ? a[DB + r + (DB + sft) * FS_LD] : 0.0;
+#pragma unroll
+      for (int q = 0; q < 4; q++) t4[q] = fma(mii, a[DB + sft + (cq + q) * FS_LD], t4[q]);
+    }
+    __syncthreads();
+    if (rowon) {
+#pragma unroll
+      for (int q = 0; q < 4; q++) a[DB + r + (cq + q) * FS_LD] = -t4[q];
+    }
+    __syncthreads();
+  }
+  {
+    double *W = linv + linv_off[node];  // p x p, column-major; whole diagonal blocks + below
+    for (int j = h; j < p; j += 2)
+      if (row_on && i >= (j & ~(DB - 1))) W[(long long)j * p + i] = a[i + j * FS_LD];
+  }
 }
 
 // --------------------------------------------------- panel solve (border rows)
-// X = A21 P' L11^-T,  L21 = X D^-1.  One workgroup per (supernode, 32-row slab),
-// the slab in LDS.  Right-looking over column blocks of 16: the block itself is
-// multiplied by the transposed inverse of its diagonal block, then the columns
-// to its right receive a rank-16 update.
-#define PS_COLS 16
+// X = A21 P' L11^-T,  L21 = X D^-1, as a product with the explicit inverse
+// M = L11^-1 that k_factor_diag leaves behind: x(i,c) = sum_{t<=c} s(i,t) M(c,t).
+// One workgroup per (supernode, 32-row slab); the permuted slab s is staged in LDS
+// once, every wavefront owns column tiles of 16 (dealt so that the triangular work
+// balances) for both 16-row halves and accumulates them with v_mfma_f64_16x16x4,
+// reading M straight from L2 (128-byte rows, shared by all slabs of the node).
+// No sequential sweep over column blocks and no barrier inside the product.
+// MFMA operand layout (verified by hqpkkt_selftest_mfma): A: lane l holds
+// A[l&15][l>>4]; B: B[l>>4][l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
+
 __global__ void __launch_bounds__(256)
 k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ panel,
               double *__restrict__ xar, const double *__restrict__ dinv,
               const int *__restrict__ ptype, const int *__restrict__ lperm,
-              const double *__restrict__ dblk, const long long *__restrict__ dblk_off) {
+              const double *__restrict__ linv, const long long *__restrict__ linv_off) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = slabs[2 * blockIdx.x], slab = slabs[2 * blockIdx.x + 1];
   const int p = T.npiv[node], b = T.nbor[node];
@@ -999,19 +1105,25 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
   const int e0 = T.piv_start[node];
   double *P = panel + T.panel_off[node];
   double *X = xar + T.x_off[node];
-  const double *DBo = dblk + dblk_off[node];
+  const double *W = linv + linv_off[node];
   const int r0 = slab * 32;
   const int tid = threadIdx.x, r = tid & 31, g = tid >> 5;
+  const int wave = tid >> 6, lane = tid & 63;
   const bool live = (r0 + r) < b;
-  double *s = lds;                  // 32 x p, s[r + 32*k]
-  double *Lb = s + 32 * p;          // p x PS_COLS block of L11: Lb[j + p*kk]
-  double *iv = Lb + PS_COLS * p;    // 16 x 16 inverse diagonal block
+  double *s = lds;  // 32 x p, s[r + 32*k]
+  // pivot data of this thread's columns (g, g+8, ...): loaded up front, together with
+  // the permutation, so that the epilogue has no dependent global loads
+  int pty[16];
+  double pd0[16], pd1[16];
   {
     int lc[16];  // p <= 128: 16 columns per thread, loads batched
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const int kcol = g + 8 * u;
       lc[u] = kcol < p ? lperm[e0 + kcol] : 0;
+      pty[u] = kcol < p ? ptype[e0 + kcol] : 0;
+      pd0[u] = kcol < p ? dinv[2 * (e0 + kcol)] : 0.0;
+      pd1[u] = kcol < p ? dinv[2 * (e0 + kcol) + 1] : 0.0;
     }
     double v[16];
 #pragma unroll
@@ -1025,70 +1137,68 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
       if (kcol < p) s[r + 32 * kcol] = v[u];
     }
   }
-  for (int kb = 0; kb < p; kb += PS_COLS) {
-    const int kw = min(PS_COLS, p - kb);
-    __syncthreads();
-    {
-      double v[2][4];
-      const double ivv = DBo[(kb / PS_COLS) * 256 + tid];
+  __syncthreads();
+  const int nbc = (p + 15) >> 4;
+  const int ml = lane & 15, kl = lane >> 4;
+  double4_t acc[2][2];  // [column tile of this wave][row half]
+  int ctile[2];
 #pragma unroll
-      for (int u = 0; u < 2; u++)
+  for (int u = 0; u < 2; u++) {
+    // column tiles from the most expensive down, dealt 0 1 2 3 3 2 1 0 to the waves
+    const int idx = u == 0 ? wave : 7 - wave;
+    const int ct = nbc - 1 - idx;
+    ctile[u] = ct;
+    acc[u][0] = double4_t{0.0, 0.0, 0.0, 0.0};
+    acc[u][1] = double4_t{0.0, 0.0, 0.0, 0.0};
+    if (ct < 0) continue;  // wave-uniform
+    const int c0 = 16 * ct, tend = min(p, c0 + 16);
+    const bool con = c0 + ml < p;
+    // all of the tile's M operands first (up to 32 per lane, one memory latency),
+    // then the products with the slab in LDS
+    double bv[32];
 #pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const int kk = g + 8 * u, j = kb + kw + r + 32 * m;
-          v[u][m] = (kk < kw && j < p) ? P[(long long)(kb + kk) * F + j] : 0.0;
-        }
-#pragma unroll
-      for (int u = 0; u < 2; u++)
-#pragma unroll
-        for (int m = 0; m < 4; m++) {
-          const int kk = g + 8 * u, j = kb + kw + r + 32 * m;
-          if (kk < kw && j < p) Lb[j + p * kk] = v[u][m];
-        }
-      iv[tid] = ivv;
+    for (int q = 0; q < 32; q++) {
+      const int t = 4 * q + kl;
+      bv[q] = (con && t < tend) ? W[(long long)t * p + c0 + ml] : 0.0;
     }
-    __syncthreads();
-    // in-block: Xb <- Xb * inv(Lbb)'   (x_c = sum_{t<=c} s_t inv[c][t])
-    double xin[PS_COLS];
 #pragma unroll
-    for (int t = 0; t < PS_COLS; t++) xin[t] = t < kw ? s[r + 32 * (kb + t)] : 0.0;
-    __syncthreads();
-#pragma unroll
-    for (int cc = 0; cc < 2; cc++) {
-      const int c = g + 8 * cc;
-      if (c < kw) {
-        double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < PS_COLS; t++) acc[t & 3] += (t <= c) ? xin[t] * iv[c * 16 + t] : 0.0;
-        s[r + 32 * (kb + c)] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
+    for (int q = 0; q < 32; q++) {
+      if (4 * q < tend) {  // wave-uniform
+        const int t = 4 * q + kl;
+        const bool ton = t < tend;
+        const double a0 = ton ? s[ml + 32 * t] : 0.0;
+        const double a1 = ton ? s[16 + ml + 32 * t] : 0.0;
+        acc[u][0] = mfma_f64(a0, bv[q], acc[u][0]);
+        acc[u][1] = mfma_f64(a1, bv[q], acc[u][1]);
       }
     }
-    __syncthreads();
-    // rank-kw update of the columns to the right of the block
-    double xb[PS_COLS];
+  }
+  __syncthreads();  // everybody has read s
 #pragma unroll
-    for (int t = 0; t < PS_COLS; t++) xb[t] = t < kw ? s[r + 32 * (kb + t)] : 0.0;
-    for (int j = kb + kw + g; j < p; j += 8) {
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};  // independent chains: fp64 FMA latency ~32 cycles
+  for (int u = 0; u < 2; u++) {
+    const int ct = ctile[u];
+    if (ct < 0) continue;
+    const int c = 16 * ct + ml;
+    if (c < p) {
 #pragma unroll
-      for (int kk = 0; kk < PS_COLS; kk++) acc[kk & 3] += xb[kk] * (kk < kw ? Lb[j + p * kk] : 0.0);
-      s[r + 32 * j] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
+      for (int h = 0; h < 2; h++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) s[16 * h + kl + 4 * q + 32 * c] = acc[u][h][q];
     }
   }
   __syncthreads();
   if (!live) return;
-  for (int kcol = g; kcol < p; kcol += 8) {
-    const int e = e0 + kcol, ty = ptype[e];
-    const double x = s[r + 32 * kcol];
-    double l;
-    if (ty == 0)
-      l = x * dinv[2 * e];
-    else if (ty == 1)
-      l = x * dinv[2 * e] + s[r + 32 * (kcol + 1)] * dinv[2 * e + 1];
-    else
-      l = s[r + 32 * (kcol - 1)] * dinv[2 * e + 1] + x * dinv[2 * e];
-    X[(long long)kcol * b + r0 + r] = x;
-    P[(long long)kcol * F + p + r0 + r] = l;
+#pragma unroll
+  for (int u = 0; u < 16; u++) {
+    const int kcol = g + 8 * u;
+    if (kcol < p) {
+      const double x = s[r + 32 * kcol];
+      // partner column of a 2x2 pivot (kcol+1 / kcol-1); 1x1 pivots have pd1 = 0
+      const int kp = pty[u] == 2 ? kcol - 1 : min(kcol + 1, p - 1);
+      const double l = pty[u] == 0 ? x * pd0[u] : x * pd0[u] + s[r + 32 * kp] * pd1[u];
+      X[(long long)kcol * b + r0 + r] = x;
+      P[(long long)kcol * F + p + r0 + r] = l;
+    }
   }
 }
 
@@ -1097,9 +1207,6 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
 // waves per workgroup, each wave a 32x32 block = 2x2 v_mfma_f64_16x16x4_f64.
 // A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
 // C/D: 4 values per lane, col = l&15, row = (l>>4) + 4*reg  (f64 layout).
-__device__ __forceinline__ double4_t mfma_f64(double a, double b, double4_t c) {
-  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
-}
 
 __global__ void __launch_bounds__(256)
 k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restrict__ panel,
@@ -1121,17 +1228,28 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
 #pragma unroll
     for (int y = 0; y < 2; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int ia = i0 + lr, ib = i0 + 16 + lr, ja = j0 + lr, jb = j0 + 16 + lr;
-  for (int k0 = 0; k0 < p; k0 += 4) {
-    const int k = k0 + lk;
-    const bool kin = k < p;
-    const double a0 = (kin && ia < b) ? L[(long long)k * F + ia] : 0.0;
-    const double a1 = (kin && ib < b) ? L[(long long)k * F + ib] : 0.0;
-    const double b0 = (kin && ja < b) ? X[(long long)k * b + ja] : 0.0;
-    const double b1 = (kin && jb < b) ? X[(long long)k * b + jb] : 0.0;
-    acc[0][0] = mfma_f64(a0, b0, acc[0][0]);
-    acc[0][1] = mfma_f64(a0, b1, acc[0][1]);
-    acc[1][0] = mfma_f64(a1, b0, acc[1][0]);
-    acc[1][1] = mfma_f64(a1, b1, acc[1][1]);
+  // eight k-steps (32 pivots) per trip: all operand loads of the trip are in flight
+  // together, so a trip costs one memory latency instead of eight
+  for (int k0 = 0; k0 < p; k0 += 32) {
+    double a0[8], a1[8], b0[8], b1[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int k = k0 + 4 * q + lk;
+      const bool kin = k < p;
+      a0[q] = (kin && ia < b) ? L[(long long)k * F + ia] : 0.0;
+      a1[q] = (kin && ib < b) ? L[(long long)k * F + ib] : 0.0;
+      b0[q] = (kin && ja < b) ? X[(long long)k * b + ja] : 0.0;
+      b1[q] = (kin && jb < b) ? X[(long long)k * b + jb] : 0.0;
+    }
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      if (k0 + 4 * q < p) {  // wave-uniform
+        acc[0][0] = mfma_f64(a0[q], b0[q], acc[0][0]);
+        acc[0][1] = mfma_f64(a0[q], b1[q], acc[0][1]);
+        acc[1][0] = mfma_f64(a1[q], b0[q], acc[1][0]);
+        acc[1][1] = mfma_f64(a1[q], b1[q], acc[1][1]);
+      }
+    }
   }
 #pragma unroll
   for (int x = 0; x < 2; x++)
@@ -1163,36 +1281,93 @@ __global__ void k_mfma_selftest(const double *A, const double *B, double *C) {
 //            A: per supernode   x1 = P' L11^-T v
 // L11 is staged once in LDS by the A kernels; the L21 products are spread over
 // many workgroups because they carry the bytes (nnz(L) is streamed once per sweep).
+// y(16-row block ib) = sum_{tb <= ib} M(ib, tb) t(tb) with M = L11^-1 read straight
+// from L2: the matrix-vector product runs on the MFMA pipe with the vector in
+// column 0 of the B operand (the flops are free, the loads are exactly the lower
+// triangle of M, all in flight together).  Row blocks are dealt 0 1 2 3 3 2 1 0.
+__device__ __forceinline__ void mfma_lower_times_vec(const double *__restrict__ W, int p, const double *tp,
+                                                     double *y, int wave, int lane) {
+  const int nb = (p + DB - 1) / DB, ml = lane & 15, kl = lane >> 4;
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int ib = nb - 1 - (u == 0 ? wave : 7 - wave);
+    if (ib < 0) continue;  // wave-uniform
+    const int i0 = DB * ib, tend = min(p, i0 + DB);
+    const bool ron = i0 + ml < p;
+    double av[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      const int t = 4 * q + kl;
+      av[q] = (ron && t < tend) ? W[(long long)t * p + i0 + ml] : 0.0;
+    }
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      if (4 * q < tend) {  // wave-uniform
+        const int t = 4 * q + kl;
+        const double bv = (ml == 0 && t < tend) ? tp[t] : 0.0;
+        acc = mfma_f64(av[q], bv, acc);
+      }
+    }
+    if (ml == 0) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        if (i0 + kl + 4 * q < p) y[i0 + kl + 4 * q] = acc[q];
+    }
+  }
+}
+
+// z(16-column block tb) = sum_{ib >= tb} M(ib, tb)' v(ib): the transposed product, the
+// vector in row 0 of the A operand
+__device__ __forceinline__ void mfma_lower_trans_times_vec(const double *__restrict__ W, int p,
+                                                           const double *v, double *z, int wave, int lane) {
+  const int nb = (p + DB - 1) / DB, ml = lane & 15, kl = lane >> 4;
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int tb = u == 0 ? wave : 7 - wave;  // column block 0 is the longest
+    if (tb >= nb) continue;                   // wave-uniform
+    const int t0 = DB * tb;
+    const bool con = t0 + ml < p;
+    double bv[32];
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      const int i = t0 + 4 * q + kl;
+      bv[q] = (con && i < p) ? W[(long long)(t0 + ml) * p + i] : 0.0;
+    }
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int q = 0; q < 32; q++) {
+      if (t0 + 4 * q < p) {  // wave-uniform
+        const int i = t0 + 4 * q + kl;
+        const double av = (ml == 0 && i < p) ? v[i] : 0.0;
+        acc = mfma_f64(av, bv[q], acc);
+      }
+    }
+    if (kl == 0 && con) z[t0 + ml] = acc[0];
+  }
+}
+
 __global__ void __launch_bounds__(256)
-k_solve_fwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
-              const double *__restrict__ dinv, const int *__restrict__ ptype,
-              const int *__restrict__ lperm, const double *__restrict__ dblk,
-              const long long *__restrict__ dblk_off, const double *__restrict__ rhs,
-              double *__restrict__ xsol, double *__restrict__ ytmp, double *__restrict__ cb) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+k_solve_fwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ linv,
+              const long long *__restrict__ linv_off, const double *__restrict__ dinv,
+              const int *__restrict__ ptype, const int *__restrict__ lperm,
+              const double *__restrict__ rhs, double *__restrict__ xsol, double *__restrict__ ytmp,
+              double *__restrict__ cb) {
+  __shared__ double t1[128], tp[128], y[128];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
-  const long long F = p + b;
   const int e0 = T.piv_start[node];
-  const double *P = panel + T.panel_off[node];
+  const double *W = linv + linv_off[node];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int ld = p | 1, nb = (p + DB - 1) / DB;
-  double *a = lds;              // ld * p
-  double *t1 = a + ld * p;      // p
-  double *y = t1 + p;           // p
-  double *iv = y + p;           // nb * 256
   double *cbn = cb + T.cb_off[node];
-  stage_lower(P, F, p, ld, a, wave, lane);
-  {
-    const double *DBo = dblk + dblk_off[node];
-    double t[8];  // nb <= 8 (p <= 128): batch the loads
-#pragma unroll
-    for (int u = 0; u < 8; u++) t[u] = u < nb ? DBo[u * 256 + tid] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (u < nb) iv[u * 256 + tid] = t[u];
+  // this thread's pivot (tid < p): permutation and pivot data, loaded up front
+  int lpk = 0, pty = 0;
+  double pd0 = 0.0, pd1 = 0.0;
+  if (tid < p) {
+    lpk = lperm[e0 + tid], pty = ptype[e0 + tid];
+    pd0 = dinv[2 * (e0 + tid)], pd1 = dinv[2 * (e0 + tid) + 1];
+    t1[tid] = rhs[e0 + tid];
   }
-  for (int i = tid; i < p; i += blockDim.x) t1[i] = rhs[e0 + i];
   for (int i = tid; i < b; i += blockDim.x) cbn[i] = 0.0;
   __syncthreads();
   for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
@@ -1209,40 +1384,14 @@ k_solve_fwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__re
     }
     __syncthreads();
   }
-  for (int k = tid; k < p; k += blockDim.x) y[k] = t1[lperm[e0 + k]];
-  for (int blk = 0; blk < nb; blk++) {
-    const int kb = blk * DB, kw = min(DB, p - kb);
-    __syncthreads();
-    if (tid < DB) {  // one wave: all reads of the block happen before the writes
-      // fp64 FMA latency is ~32 cycles on gfx950: four independent partial sums
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int t = 0; t < DB; t++)
-        acc[t & 3] += (t <= tid && t < kw) ? iv[blk * 256 + tid * DB + t] * y[kb + t] : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      if (tid < kw) y[kb + tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    }
-    __syncthreads();
-    for (int j = kb + kw + tid; j < p; j += blockDim.x) {
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < DB; kk++)
-        acc[kk & 3] += kk < kw ? a[j + (kb + kk) * ld] * y[kb + kk] : 0.0;
-      y[j] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    }
-  }
+  if (tid < p) tp[tid] = t1[lpk];
   __syncthreads();
-  for (int k = tid; k < p; k += blockDim.x) {
-    const int e = e0 + k, ty = ptype[e];
-    double v;
-    if (ty == 0)
-      v = y[k] * dinv[2 * e];
-    else if (ty == 1)
-      v = y[k] * dinv[2 * e] + y[k + 1] * dinv[2 * e + 1];
-    else
-      v = y[k - 1] * dinv[2 * e + 1] + y[k] * dinv[2 * e];
-    xsol[e] = v;
-    ytmp[e] = y[k];
+  mfma_lower_times_vec(W, p, tp, y, wave, lane);
+  __syncthreads();
+  if (tid < p) {
+    const int kp = pty == 2 ? tid - 1 : min(tid + 1, p - 1);  // partner of a 2x2 pivot
+    xsol[e0 + tid] = pty == 0 ? y[tid] * pd0 : y[tid] * pd0 + y[kp] * pd1;
+    ytmp[e0 + tid] = y[tid];
   }
 }
 
@@ -1336,54 +1485,21 @@ k_solve_bwd_b(DevTree T, const int *__restrict__ cblks, const double *__restrict
 
 // x1 = P' L11^-T v
 __global__ void __launch_bounds__(256)
-k_solve_bwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
-              const int *__restrict__ lperm, const double *__restrict__ dblk,
-              const long long *__restrict__ dblk_off, const double *__restrict__ vtmp,
-              double *__restrict__ xsol) {
-  extern __shared__ __attribute__((aligned(16))) double lds[];
+k_solve_bwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ linv,
+              const long long *__restrict__ linv_off, const int *__restrict__ lperm,
+              const double *__restrict__ vtmp, double *__restrict__ xsol) {
+  __shared__ double v[128], z[128];
   const int node = level_nodes[blockIdx.x];
-  const int p = T.npiv[node], b = T.nbor[node];
-  const long long F = p + b;
+  const int p = T.npiv[node];
   const int e0 = T.piv_start[node];
-  const double *P = panel + T.panel_off[node];
+  const double *W = linv + linv_off[node];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int ld = p | 1, nb = (p + DB - 1) / DB;
-  double *a = lds;          // ld * p
-  double *v = a + ld * p;   // p
-  double *iv = v + p;       // nb * 256
-  stage_lower(P, F, p, ld, a, wave, lane);
-  {
-    const double *DBo = dblk + dblk_off[node];
-    double t[8];  // nb <= 8 (p <= 128): batch the loads
-#pragma unroll
-    for (int u = 0; u < 8; u++) t[u] = u < nb ? DBo[u * 256 + tid] : 0.0;
-#pragma unroll
-    for (int u = 0; u < 8; u++)
-      if (u < nb) iv[u * 256 + tid] = t[u];
-  }
-  for (int k = tid; k < p; k += blockDim.x) v[k] = vtmp[e0 + k];
-  for (int blk = nb - 1; blk >= 0; blk--) {
-    const int kb = blk * DB, kw = min(DB, p - kb);
-    __syncthreads();
-    if (tid < DB) {  // x_r = sum_{t>=r} inv[t][r] v_t
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int t = 0; t < DB; t++)
-        acc[t & 3] += (t >= tid && t < kw) ? iv[blk * 256 + t * DB + tid] * v[kb + t] : 0.0;
-      __builtin_amdgcn_wave_barrier();
-      if (tid < kw) v[kb + tid] = (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    }
-    __syncthreads();
-    for (int j = tid; j < kb; j += blockDim.x) {
-      double acc[4] = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int kk = 0; kk < DB; kk++)
-        acc[kk & 3] += kk < kw ? a[kb + kk + j * ld] * v[kb + kk] : 0.0;
-      v[j] -= (acc[0] + acc[1]) + (acc[2] + acc[3]);
-    }
-  }
+  int lpk = 0;
+  if (tid < p) lpk = lperm[e0 + tid], v[tid] = vtmp[e0 + tid];
   __syncthreads();
-  for (int k = tid; k < p; k += blockDim.x) xsol[e0 + lperm[e0 + k]] = v[k];
+  mfma_lower_trans_times_vec(W, p, v, z, wave, lane);
+  __syncthreads();
+  if (tid < p) xsol[e0 + lpk] = z[tid];
 }
 
 // ------------------------------------------------------------ step pre/post

@@ -239,6 +239,16 @@ class Hqp_IpMatrix:
         _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
         return out[: k.value]
 
+    def read_block(self, what, node):
+        """Numeric block of a supernode after factor() (tests): 0 panel, 1 inverse of
+        L11, 2 X, 3 update block; flat float64 array, column-major."""
+        k = C.c_longlong()
+        _check(self._L.hqpkkt_debug_read(self._h, what, node, None, 0, C.byref(k)), "debug_read")
+        out = np.zeros(max(k.value, 1))
+        _check(self._L.hqpkkt_debug_read(self._h, what, node, C.c_void_p(out.ctypes.data), k.value,
+                                         C.byref(k)), "debug_read")
+        return out[: k.value]
+
     def structure(self):
         names = ["elim", "piv_start", "npiv", "nborder", "parent", "level", "border_ptr",
                  "border_idx", "entry_row", "entry_col", "node_owner", "exchange_roots"]

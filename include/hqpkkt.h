@@ -223,6 +223,13 @@ const char *hqpkkt_strerror(int status);
  * *len receives the element count; out may be NULL to query it. */
 int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len);
 
+/* Numeric blocks of one supernode after factor (device -> host copy, tests only):
+ * what 0 = panel ((p+b) x p, column-major: L11 below the diagonal, L21), 1 = the
+ * explicit inverse of the unit lower L11 (p x p, column-major, diagonal blocks of
+ * 16 complete), 2 = X = A21 P' L11^-T (b x p), 3 = update block (b x b).
+ * *len receives the element count; out may be NULL to query it. */
+int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long cap, long long *len);
+
 /* MFMA f64 16x16x4 layout self-test on the device: C = A * B for integer-valued
  * asymmetric 16x16x16 operands; *max_err is max |C - exact|. */
 int hqpkkt_selftest_mfma(int device, double *max_err);
