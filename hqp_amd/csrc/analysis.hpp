@@ -59,7 +59,7 @@ struct Analysis {
 
   // --- one system sharded over several ranks ----------------------
   int shard_rank = 0, shard_count = 1;
-  bool slack_last = false;  // FULL mode: slack rows behind the x variables inside a node
+  int slack_policy = 2;  // FULL mode, slack rows inside a node: 0 band order, 1 behind all x, 2 behind their own x
   std::vector<int> node_owner;  // owning rank per supernode, -1 = replicated top of the tree
   std::vector<int> xroots;      // subtree roots whose update / contribution blocks are exchanged
   long long upd_x_off = 0, upd_x_slot = 0;  // exchange region of the update arena: shard_count slots

@@ -634,6 +634,7 @@ int hqpkkt_default_opts(hqpkkt_opts *o) {
   o->leaf_size = 0;
   o->max_pivots = 0;
   o->zd_policy = 2;
+  o->slack_policy = 2;
   return 0;
 }
 
@@ -687,7 +688,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->analyzed = false;
   h->an = Analysis();
   h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
-  h->an.slack_last = h->opts.slack_policy == 1;
+  h->an.slack_policy = h->opts.slack_policy;
   int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
                     h->opts.max_pivots, h->opts.zd_policy);
   if (e) return e;

@@ -66,11 +66,12 @@ typedef struct hqpkkt_opts {
                         (equality multipliers): 2 = behind all their neighbours
                         (default), 0 = behind one matched neighbour             */
   int slack_policy;  /* FULL mode, order of the slack rows inside a supernode:
-                        0 = band order (default; a slack row with small w/z in
-                        front of its x variable is interchanged at run time by the
-                        Bunch-Kaufman test), 1 = behind the x variables of the node
-                        (no run-time interchanges, ~10 % more fill; less accurate
-                        next to a degenerate solution)                            */
+                        2 = a slack row in front of one of its own x variables is
+                        moved right behind it (default: avoids the run-time
+                        interchange the Bunch-Kaufman test makes when w/z is small;
+                        ~3 % more fill), 0 = band order as it comes (better when
+                        the x variables carry weak diagonals, e.g. DOCP states),
+                        1 = behind all x variables of the node (~10 % more fill)  */
   int reserved[4];
 } hqpkkt_opts;
 
