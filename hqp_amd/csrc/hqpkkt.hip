@@ -311,7 +311,7 @@ static int upload(hqpkkt_t *h) {
   const size_t mp = an.max_npiv, ldm = mp | 1, nbm = (mp + 15) / 16;
   h->lds_diag = (std::max<size_t>(ldm * mp, 2 * FD_PLD * FD_PANEL) + 5 * 128 + 2 * mp) * sizeof(double) +
                 2 * mp * sizeof(int) + 16;
-  h->lds_panel = 32 * mp * sizeof(double);
+  h->lds_panel = (32 * mp + 2 * mp) * sizeof(double) + mp * sizeof(int);
   h->lds_solve = (ldm * mp + 2 * mp + nbm * 256) * sizeof(double);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
   if (h->lds_diag > 160 * 1024 || h->lds_solve > 160 * 1024 || h->lds_bwdb > 160 * 1024) return HQPKKT_E_MEM;
@@ -419,7 +419,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
       for (int seg = S.ea_level_ptr[l]; seg < S.ea_level_ptr[l + 1]; seg++) {
         int cnt = S.ea_seg_ptr[seg + 1] - S.ea_seg_ptr[seg];
         if (cnt <= 0) continue;
-        int ysplit = std::max(1, std::min(64, 2048 / cnt));
+        int ysplit = std::max(1, std::min(512, 8192 / cnt));  // few children: one column per workgroup
         KLAUNCH(h, KC_EXTEND_ADD, k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, D.ea_nodes.p + S.ea_seg_ptr[seg],
                                                        h->panel.p, h->upd.p));
       }

@@ -1111,19 +1111,21 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
   const int wave = tid >> 6, lane = tid & 63;
   const bool live = (r0 + r) < b;
   double *s = lds;  // 32 x p, s[r + 32*k]
-  // pivot data of this thread's columns (g, g+8, ...): loaded up front, together with
-  // the permutation, so that the epilogue has no dependent global loads
-  int pty[16];
-  double pd0[16], pd1[16];
+  // pivot data (type, D^-1) of all columns: to LDS up front, together with the
+  // permutation, so that the epilogue has no dependent global loads
+  double *pd = s + 32 * p;        // 2 p
+  int *pty = (int *)(pd + 2 * p);  // p
+  if (tid < p) {
+    pty[tid] = ptype[e0 + tid];
+    pd[2 * tid] = dinv[2 * (e0 + tid)];
+    pd[2 * tid + 1] = dinv[2 * (e0 + tid) + 1];
+  }
   {
     int lc[16];  // p <= 128: 16 columns per thread, loads batched
 #pragma unroll
     for (int u = 0; u < 16; u++) {
       const int kcol = g + 8 * u;
       lc[u] = kcol < p ? lperm[e0 + kcol] : 0;
-      pty[u] = kcol < p ? ptype[e0 + kcol] : 0;
-      pd0[u] = kcol < p ? dinv[2 * (e0 + kcol)] : 0.0;
-      pd1[u] = kcol < p ? dinv[2 * (e0 + kcol) + 1] : 0.0;
     }
     double v[16];
 #pragma unroll
@@ -1153,23 +1155,27 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
     if (ct < 0) continue;  // wave-uniform
     const int c0 = 16 * ct, tend = min(p, c0 + 16);
     const bool con = c0 + ml < p;
-    // all of the tile's M operands first (up to 32 per lane, one memory latency),
-    // then the products with the slab in LDS
-    double bv[32];
+    // the tile's M operands in two batches of 16 k-steps (64 pivots): all loads of a
+    // batch are in flight together, then the products with the slab in LDS
 #pragma unroll
-    for (int q = 0; q < 32; q++) {
-      const int t = 4 * q + kl;
-      bv[q] = (con && t < tend) ? W[(long long)t * p + c0 + ml] : 0.0;
-    }
+    for (int half = 0; half < 2; half++) {
+      if (64 * half >= tend) continue;  // wave-uniform
+      double bv[16];
 #pragma unroll
-    for (int q = 0; q < 32; q++) {
-      if (4 * q < tend) {  // wave-uniform
-        const int t = 4 * q + kl;
-        const bool ton = t < tend;
-        const double a0 = ton ? s[ml + 32 * t] : 0.0;
-        const double a1 = ton ? s[16 + ml + 32 * t] : 0.0;
-        acc[u][0] = mfma_f64(a0, bv[q], acc[u][0]);
-        acc[u][1] = mfma_f64(a1, bv[q], acc[u][1]);
+      for (int q = 0; q < 16; q++) {
+        const int t = 64 * half + 4 * q + kl;
+        bv[q] = (con && t < tend) ? W[(long long)t * p + c0 + ml] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 16; q++) {
+        if (64 * half + 4 * q < tend) {  // wave-uniform
+          const int t = 64 * half + 4 * q + kl;
+          const bool ton = t < tend;
+          const double a0 = ton ? s[ml + 32 * t] : 0.0;
+          const double a1 = ton ? s[16 + ml + 32 * t] : 0.0;
+          acc[u][0] = mfma_f64(a0, bv[q], acc[u][0]);
+          acc[u][1] = mfma_f64(a1, bv[q], acc[u][1]);
+        }
       }
     }
   }
@@ -1188,17 +1194,14 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
   }
   __syncthreads();
   if (!live) return;
-#pragma unroll
-  for (int u = 0; u < 16; u++) {
-    const int kcol = g + 8 * u;
-    if (kcol < p) {
-      const double x = s[r + 32 * kcol];
-      // partner column of a 2x2 pivot (kcol+1 / kcol-1); 1x1 pivots have pd1 = 0
-      const int kp = pty[u] == 2 ? kcol - 1 : min(kcol + 1, p - 1);
-      const double l = pty[u] == 0 ? x * pd0[u] : x * pd0[u] + s[r + 32 * kp] * pd1[u];
-      X[(long long)kcol * b + r0 + r] = x;
-      P[(long long)kcol * F + p + r0 + r] = l;
-    }
+  for (int kcol = g; kcol < p; kcol += 8) {
+    const double x = s[r + 32 * kcol];
+    const int ty = pty[kcol];
+    // partner column of a 2x2 pivot (kcol+1 / kcol-1)
+    const int kp = ty == 2 ? kcol - 1 : min(kcol + 1, p - 1);
+    const double l = ty == 0 ? x * pd[2 * kcol] : x * pd[2 * kcol] + s[r + 32 * kp] * pd[2 * kcol + 1];
+    X[(long long)kcol * b + r0 + r] = x;
+    P[(long long)kcol * F + p + r0 + r] = l;
   }
 }
 
