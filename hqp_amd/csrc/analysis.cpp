@@ -725,9 +725,6 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
     upd_elems += shard_count * upd_x_slot, cb_elems += shard_count * cb_x_slot;
   }
-  dblk_off.assign(nnodes, 0);
-  dblk_elems = 0;
-  for (int id = 0; id < nnodes; id++) dblk_off[id] = dblk_elems, dblk_elems += 256LL * ((npiv[id] + 15) / 16);
   linv_off.assign(nnodes, 0);
   linv_elems = 0;
   for (int id = 0; id < nnodes; id++) linv_off[id] = linv_elems, linv_elems += (long long)npiv[id] * npiv[id];

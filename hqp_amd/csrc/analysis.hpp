@@ -66,8 +66,6 @@ struct Analysis {
   long long cb_x_off = 0, cb_x_slot = 0;    // same for the solve's contribution vectors
   std::vector<long long> zero_panel, zero_upd;  // (offset, length) pairs this rank clears per factor
   std::vector<signed char> keep_e;  // per elimination index: this rank contributes it to the all-reduce
-  std::vector<long long> dblk_off;             // inverse diagonal blocks, 256 doubles each
-  long long dblk_elems = 0;
   std::vector<long long> linv_off;             // explicit inverses of the L11 blocks, p x p each
   long long linv_elems = 0;
 

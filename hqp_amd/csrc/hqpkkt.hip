@@ -157,12 +157,12 @@ struct hqpkkt {
   int shard_rank = 0, shard_count = 1;
   hqpkkt_exchange_fn xchg_fn = nullptr;
   void *xchg_ctx = nullptr;
-  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, dblk_off, linv_off;
+  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, linv_off;
   DBuf<TermDev> terms;
   DBuf<signed char> esign;
   CsrBuf Qf, A, AT, C, CT;
   // numeric state
-  DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb, ytmp, vtmp, dblk, linv;
+  DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb, ytmp, vtmp, linv;
   DBuf<int> ptype, lperm, flags;  // flags: [0] status, [1] n_2x2, [2] n_perturbed
   DBuf<unsigned long long> bits;  // [0] kmax, [1] residual max
   // vectors: staging for host pointers + refinement work vectors
@@ -171,7 +171,7 @@ struct hqpkkt {
   DBuf<double> vres;  // residual vectors _r1.._r4
   DBuf<double> vcor;  // corrections _dx.._dw
   DBuf<double> tz;    // REDUCED temporary (m)
-  size_t lds_diag = 0, lds_panel = 0, lds_solve = 0, lds_bwdb = 0;
+  size_t lds_diag = 0, lds_panel = 0, lds_bwdb = 0;
   // captured kernel sequences (factor; step on the caller's vectors; step on the
   // refinement's residual vectors): replayed with hipGraphLaunch
   struct GraphSlot {
@@ -199,11 +199,11 @@ struct hqpkkt {
                        &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &ptype, &lperm, &flags};
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release();
-    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &dblk_off, &linv_off,
+    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off,
                              &zero_panel, &zero_upd};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &dblk, &linv};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv};
     for (auto b : db) b->release();
     terms.release(), esign.release(), bits.release();
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
@@ -258,7 +258,6 @@ static int upload(hqpkkt_t *h) {
   UP(zero_panel, zero_panel);
   UP(zero_upd, zero_upd);
   UP(keep_e, keep_e);
-  UP(dblk_off, dblk_off);
   UP(linv_off, linv_off);
   UP(ent_a, ent_a);
   UP(ent_b, ent_b);
@@ -293,7 +292,7 @@ static int upload(hqpkkt_t *h) {
       (e = h->upd.alloc(an.upd_elems)) || (e = h->xar.alloc(an.x_elems)) ||
       (e = h->dinv.alloc(2 * (size_t)dim)) || (e = h->rhs.alloc(dim)) ||
       (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ytmp.alloc(dim)) ||
-      (e = h->vtmp.alloc(dim)) || (e = h->dblk.alloc(an.dblk_elems)) || (e = h->linv.alloc(an.linv_elems)) || (e = h->ptype.alloc(dim)) ||
+      (e = h->vtmp.alloc(dim)) || (e = h->linv.alloc(an.linv_elems)) || (e = h->ptype.alloc(dim)) ||
       (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(64)) || (e = h->bits.alloc(2)) ||
       (e = h->vin.alloc(2 * (size_t)m + n + me + 2 * (size_t)m)) ||
       (e = h->vout.alloc((size_t)n + me + 2 * (size_t)m)) ||
@@ -308,13 +307,12 @@ static int upload(hqpkkt_t *h) {
     HIPCHK(hipMemcpy(h->wt.p + m, &one, sizeof(double), hipMemcpyHostToDevice));
   }
   // dynamic LDS budgets
-  const size_t mp = an.max_npiv, ldm = mp | 1, nbm = (mp + 15) / 16;
+  const size_t mp = an.max_npiv, ldm = mp | 1;
   h->lds_diag = (std::max<size_t>(ldm * mp, 2 * FD_PLD * FD_PANEL) + 5 * 128 + 2 * mp) * sizeof(double) +
                 2 * mp * sizeof(int) + 16;
   h->lds_panel = (32 * mp + 2 * mp) * sizeof(double) + mp * sizeof(int);
-  h->lds_solve = (ldm * mp + 2 * mp + nbm * 256) * sizeof(double);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
-  if (h->lds_diag > 160 * 1024 || h->lds_solve > 160 * 1024 || h->lds_bwdb > 160 * 1024) return HQPKKT_E_MEM;
+  if (h->lds_diag > 160 * 1024 || h->lds_bwdb > 160 * 1024) return HQPKKT_E_MEM;
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_diag));
   HIPCHK(hipFuncSetAttribute((const void *)k_panel_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -426,13 +424,11 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nsm = S.level_small[l];
       if (nsm > 0)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<<<nsm, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
-                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
-                                                 h->dblk_off.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1));
       if (nn > nsm)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nsm, h->panel.p,
-                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->dblk.p,
-                                                 h->dblk_off.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1));
       const int ns = S.slab_ptr[l + 1] - S.slab_ptr[l];
       if (ns > 0)

@@ -88,33 +88,6 @@ __device__ __forceinline__ double fast_rcp(double d) {
   return x;
 }
 
-// lower triangle (incl. diagonal) of a p x p column-major block -> LDS image with
-// leading dimension ld; global loads are issued in batches of 16 per thread so
-// that their latencies overlap (p <= 128)
-__device__ __forceinline__ void stage_lower(const double *__restrict__ P, long long F, int p, int ld,
-                                            double *a, int wave, int lane) {
-  for (int jb = 0; jb < p; jb += 32) {
-    double v[8][2];
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int j = jb + wave + 4 * u;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int i = lane + 64 * h;
-        v[u][h] = (j < p && i < p && i >= j) ? P[(long long)j * F + i] : 0.0;
-      }
-    }
-#pragma unroll
-    for (int u = 0; u < 8; u++) {
-      const int j = jb + wave + 4 * u;
-#pragma unroll
-      for (int h = 0; h < 2; h++) {
-        const int i = lane + 64 * h;
-        if (j < p && i < p && i >= j) a[i + j * ld] = v[u][h];
-      }
-    }
-  }
-}
 
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
@@ -228,29 +201,35 @@ __global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
 }
 
 // ------------------------------------------------- pivot block: dense BK LDL'
-// One workgroup of 512 threads per supernode.  The p x p pivot block (p <= 128)
-// lives in REGISTERS as a full symmetric matrix: thread (tx, ty) = (tid & 31,
-// tid >> 5) owns rows ty+16m (m < 8) and columns tx+32n (n < 4), 32 values.
-// Per pivot the 16 owners of the pivot column publish it to a small LDS vector,
-// every thread reads the 8 + 4 entries it needs and updates its patch with 32
-// independent FMAs (strips of rows / columns that are already eliminated are
-// skipped) - no LDS read-modify-write of the trailing matrix and a hot loop of
-// a few hundred instructions.  One barrier per pivot; extra ones only when a
-// second column is needed (2x2 test) or rows are interchanged (rows / columns
-// are exchanged between threads through LDS).
+// k_factor_diag: one workgroup of 512 threads per supernode.  The p x p pivot
+// block (p <= 128) lives in REGISTERS as a full symmetric matrix: thread
+// (tx, ty) = (tid & 31, tid >> 5) owns rows ty+16m (m < 8) and columns tx+32n
+// (n < 4), 32 values ("patch").  The elimination is blocked by panels of 16
+// columns:
+//   1. the owners publish the panel's columns to LDS;
+//   2. ONE wavefront eliminates the panel's pivots with its rows in registers
+//      (panel_wave below: no barrier and no LDS round trip per pivot);
+//   3. all threads apply the panel's rank-16 update to their patches (sweep_patch,
+//      restricted to the strips that are still alive).
+// A pivot that fails the cheap test ends the panel early and goes through the
+// slow path: one pivot with the complete Bunch-Kaufman decision, symmetric
+// interchange (rows / columns are exchanged between threads through LDS) and 2x2
+// pivots, one barrier per step.
 //
 // Bunch-Kaufman partial pivoting with the reference's threshold
 // alpha = tol (1+sqrt 17)/8 and test order (hqp/spBKP.C:392, 431-438, 471, 480),
-// restricted to the pivot block; every wave takes the decision redundantly (DPP
-// max over the wave, ballot for the first arg-max).  A pivot smaller than
-// pert = pivot_eps * max|K| is replaced by +-pert (x rows negative, y / slack
-// rows positive); the symbolic phase orders zero-diagonal variables so that this
-// does not happen for structurally non-singular systems.  Eliminated columns
-// stay unscaled (c = l d) until the write-back, which also produces the inverses
-// of the 16x16 diagonal blocks of L11 used by the triangular solves.
-// the same for the 8 wavefronts of k_factor_diag: all loads of a thread (up to 16
-// columns x 2 row halves) are in flight together - one memory latency instead of one
-// per batch
+// restricted to the pivot block.  A pivot smaller than pert = pivot_eps * max|K|
+// is replaced by +-pert (x rows negative, y / slack rows positive); the symbolic
+// phase orders zero-diagonal variables so that this does not happen for
+// structurally non-singular systems.  Eliminated columns stay unscaled (c = l d)
+// until the write-back.  The tail inverts the unit lower L11 in place (MFMA) and
+// leaves M = L11^-1 in its own arena: the panel solve and the tree solves are
+// products with M.
+
+// lower triangle (incl. diagonal) of a p x p column-major block -> LDS image with
+// leading dimension ld, by the 8 wavefronts of k_factor_diag: all loads of a
+// thread (up to 16 columns x 2 row halves) are in flight together - one memory
+// latency
 __device__ __forceinline__ void stage_lower8(const double *__restrict__ P, long long F, int p, int ld,
                                              double *a, int wave, int lane) {
   double v[16][2];
@@ -496,8 +475,7 @@ __device__ __forceinline__ void sweep_rows(PatchT &A, const double *Pc, const do
 __global__ void __launch_bounds__(FD_THREADS)
 k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
               double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
-              const signed char *__restrict__ esign, double *__restrict__ dblk,
-              const long long *__restrict__ dblk_off, double *__restrict__ linv,
+              const signed char *__restrict__ esign, double *__restrict__ linv,
               const long long *__restrict__ linv_off, double alpha, double pivot_eps,
               const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -805,9 +783,6 @@ int dn;
           xinv[rr] = fma(-l, xt, xinv[rr]);
         }
       }
-      double *DBo = dblk + dblk_off[node];
-#pragma unroll
-      for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = xinv[rr];
     }
     __syncthreads();  // the write-back has read a[]
     STAMP(46);
@@ -827,11 +802,18 @@ int dn;
   // The first product's result, in the MFMA C/D layout (lane: column l&15, rows
   // (l>>4)+4q), is exactly the B operand of the second product's four k-slices, so
   // it never leaves the registers; the row block is overwritten after a barrier.
+  double *W = linv + linv_off[node];  // p x p, column-major; whole diagonal blocks + below
   for (int i = 1; i < nb; i++) {
     const int ri = DB * i, j = wave;
     const bool have = j < i;  // wave-uniform
     const int ml = lane & 15, kl = lane >> 4;
     double4_t res = {0.0, 0.0, 0.0, 0.0};
+    if (!have) {
+      // the waves without a block write the previous row block (final) to memory:
+      // 16 rows x 16 i columns, four columns of 128 bytes per instruction
+      for (int c = 4 * (wave - i) + kl; c < ri; c += 4 * (FD_THREADS / 64 - i))
+        W[(long long)c * p + ri - DB + ml] = a[ri - DB + ml + c * ld];
+    }
     if (have) {
       double4_t tacc = {0.0, 0.0, 0.0, 0.0};
       const bool rowon = ri + ml < p;
@@ -864,10 +846,10 @@ int dn;
     __syncthreads();
   }
   STAMP(47);
-  {
-    double *W = linv + linv_off[node];  // p x p, column-major; whole diagonal blocks + below
-    for (int j = wave; j < p; j += FD_THREADS / 64)
-      for (int i = (j & ~(DB - 1)) + lane; i < p; i += 64) W[(long long)j * p + i] = a[i + j * ld];
+  {  // the last row block
+    const int rl = DB * (nb - 1), ml = lane & 15, kl = lane >> 4;
+    if (rl + ml < p)
+      for (int c = 4 * wave + kl; c < p; c += 4 * (FD_THREADS / 64)) W[(long long)c * p + rl + ml] = a[rl + ml + c * ld];
   }
   STAMP(48);
 }
@@ -884,8 +866,7 @@ int dn;
 __global__ void __launch_bounds__(64)
 k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
                     double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
-                    const signed char *__restrict__ esign, double *__restrict__ dblk,
-                    const long long *__restrict__ dblk_off, double *__restrict__ linv,
+                    const signed char *__restrict__ esign, double *__restrict__ linv,
                     const long long *__restrict__ linv_off, double alpha, double pivot_eps,
                     const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
   __shared__ double a[FS_MAXP * FS_LD];
@@ -1018,7 +999,6 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   }
   // inverses of the (at most two) 16x16 diagonal blocks of L11, then M = L11^-1 in
   // place (M_10 = -M_11 L_10 M_00) for the product-form panel solve / tree solves
-  double *DBo = dblk + dblk_off[node];
   const int nb = (p + DB - 1) / DB;
   const int blk = lane >> 4, c = lane & 15;
   double x[DB];
@@ -1035,8 +1015,6 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
         x[rr] = fma(-l, xt, x[rr]);
       }
     }
-#pragma unroll
-    for (int rr = 0; rr < DB; rr++) DBo[blk * DB * DB + rr * DB + c] = x[rr];
   }
   __syncthreads();
   if (blk < nb) {
@@ -1231,6 +1209,17 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
 #pragma unroll
     for (int y = 0; y < 2; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int ia = i0 + lr, ib = i0 + 16 + lr, ja = j0 + lr, jb = j0 + 16 + lr;
+  // the old values of this wave's part of U travel while the products run
+  double uold[2][2][4];
+#pragma unroll
+  for (int x = 0; x < 2; x++)
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int i = i0 + 16 * x + lk + 4 * rg, j = j0 + 16 * y + lr;
+        uold[x][y][rg] = (i < b && j < b && i >= j) ? U[(long long)j * b + i] : 0.0;
+      }
   // eight k-steps (32 pivots) per trip: all operand loads of the trip are in flight
   // together, so a trip costs one memory latency instead of eight
   for (int k0 = 0; k0 < p; k0 += 32) {
@@ -1261,7 +1250,7 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int i = i0 + 16 * x + lk + 4 * rg, j = j0 + 16 * y + lr;
-        if (i < b && j < b && i >= j) U[(long long)j * b + i] -= acc[x][y][rg];
+        if (i < b && j < b && i >= j) U[(long long)j * b + i] = uold[x][y][rg] - acc[x][y][rg];
       }
 }
 
