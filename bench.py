@@ -45,10 +45,15 @@ def class_work(struct, rank=None):
         mine = (struct["node_owner"] == rank) | (struct["node_owner"] < 0)
         p, b = p[mine], b[mine]
     return {
-        "factor_diag": {"flops": float((p ** 3 / 3.0).sum()), "bytes": float((8 * p * p).sum())},
+        # LDL' of the pivot block (p^3/3) + explicit inverse of the unit lower L11 (p^3/3)
+        "factor_diag": {"flops": float((2 * p ** 3 / 3.0).sum()), "bytes": float((8 * 2 * p * p).sum())},
+        # X = A21 P' M' (b p^2) ; reads A21 and M, writes X and L21
         "panel_solve": {"flops": float((b * p * p).sum()), "bytes": float((8 * (3 * b * p + p * p / 2)).sum())},
         "schur_update": {"flops": float((b * b * p).sum()), "bytes": float((8 * (2 * b * p + b * b)).sum())},
         "extend_add": {"flops": float((b * b / 2).sum()), "bytes": float((8 * 1.5 * b * b).sum())},
+        # one sweep over the factor: M (lower) and L21 are streamed once
+        "solve_fwd": {"flops": float((p * p + 2 * b * p).sum()), "bytes": float((8 * (p * p / 2 + b * p)).sum())},
+        "solve_bwd": {"flops": float((p * p + 2 * b * p).sum()), "bytes": float((8 * (p * p / 2 + b * p)).sum())},
     }
 
 
@@ -207,7 +212,17 @@ def main():
         work = class_work(struct, 0 if one else None)
         per_step = {k: v[0] / nprof for k, v in prof.items()}
         launches = {k: v[1] / nprof for k, v in prof.items()}
-        dom = max(work, key=lambda k: per_step.get(k, 0.0))
+        solves_per_step = 1 + st["refine_rounds"]
+        for k in ("solve_fwd", "solve_bwd"):  # the sweeps run once per solve of the step
+            work[k] = {q: v * solves_per_step for q, v in work[k].items()}
+        # every kernel class against both ceilings (algorithmic flops / bytes per step)
+        kernels = {k: {"ms_per_step": per_step.get(k, 0.0), "launches_per_step": launches.get(k, 0.0),
+                       "tflops": w["flops"] / (per_step[k] * 1e-3) / 1e12 if per_step.get(k) else None,
+                       "gbs": w["bytes"] / (per_step[k] * 1e-3) / 1e9 if per_step.get(k) else None,
+                       "frac_fp64_peak": w["flops"] / (per_step[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if per_step.get(k) else None,
+                       "frac_hbm_peak": w["bytes"] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if per_step.get(k) else None}
+                   for k, w in work.items()}
+        dom = max(("factor_diag", "panel_solve", "schur_update", "extend_add"), key=lambda k: per_step.get(k, 0.0))
         dom_ms = per_step[dom]
         dom_launch_ms = dom_ms / max(launches[dom], 1.0)
         flops_per_launch = work[dom]["flops"] / max(launches[dom], 1.0)
@@ -258,6 +273,7 @@ def main():
                       "bytes_exchange_step": st["bytes_exchange_step"]} if one else None,
             "kernel_ms_per_step": per_step,
             "kernel_launches_per_step": launches,
+            "kernels": kernels,
             "factor_model": model,
             "roofline": roofline,
         }
