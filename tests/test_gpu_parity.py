@@ -239,3 +239,50 @@ def test_multistage_docp_against_reference_lqdocp(shape):
         L.factor(st[0], st[1])
         lsol, lres = L.solve(*st)
         assert res <= lres + RES_TOL and rel_err(d, lsol) <= 1e-7
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["banded", "did", "docp"])
+def test_explicit_inverse_of_pivot_blocks(case):
+    """k_factor_diag / k_factor_diag_small leave M = L11^-1 next to L11: the panel
+    solve and both tree sweeps are products with it.  Checked block by block
+    (supernodes of 1..128 pivots, 1x1 and 2x2 pivots, partial 16-blocks)."""
+    prog = {"banded": lambda: problems.banded_qp(6000, 60, 2), "did": lambda: problems.did_like_qp(300),
+            "docp": lambda: problems.lq_docp(30, 20, 6)}[case]()
+    st = problems.ip_state(prog, 5, 1.0)
+    M = ipmatrix.IpSpBKP()
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    s = M.structure()
+    assert s["npiv"].max() > (100 if case == "banded" else 16)
+    worst = 0.0
+    for node in range(len(s["npiv"])):
+        p, b = int(s["npiv"][node]), int(s["nborder"][node])
+        P = M.read_block(0, node).reshape(p, p + b).T
+        L = np.tril(P[:p, :p], -1) + np.eye(p)
+        W = M.read_block(1, node).reshape(p, p).T
+        for kb in range(0, p, 16):  # the diagonal blocks are complete: zeros above the diagonal
+            assert not np.triu(W[kb:kb + 16, kb:kb + 16], 1).any()
+        worst = max(worst, float(np.abs(np.tril(W) @ L - np.eye(p)).max()))
+    assert worst < 1e-12, worst
+
+
+@pytest.mark.gpu
+def test_slack_order_policies_agree():
+    """The order of the slack rows inside a supernode (hqpkkt_opts.slack_policy) changes
+    which pivots need a run-time interchange, not the solution."""
+    prog = problems.banded_qp(3000, 24, 4)
+    st = problems.ip_state(prog, 9, 1.0)
+    sols, slow = [], []
+    for sp in (0, 1, 2):
+        M = ipmatrix.IpSpBKP(slack_policy=sp)
+        M.init(prog)
+        M.factor(prog, st[0], st[1])
+        d = new_d(prog)
+        res = M.solve(prog, *st, *d)
+        assert res <= 1e-10
+        sols.append(d)
+        slow.append(M.stats()["n_slow_pivots"])
+    assert rel_err(sols[1], sols[0]) < 1e-9 and rel_err(sols[2], sols[0]) < 1e-9
+    assert slow[2] <= slow[0] and slow[1] <= slow[0]  # behind-its-x orders avoid the interchanges
+    assert slow[0] > 0
