@@ -25,6 +25,7 @@ SYMBOLS = [
     "hqpkkt_set_stream", "hqpkkt_get_stats", "hqpkkt_strerror", "hqpkkt_debug_get",
     "hqpkkt_selftest_mfma", "hqpkkt_set_profile", "hqpkkt_get_profile",
     "hqpkkt_profile_class_name", "hqpkkt_set_shard", "hqpkkt_debug_read",
+    "hqpkkt_default_ip_opts", "hqpkkt_mehrotra",
 ]
 
 XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
@@ -51,6 +52,20 @@ class Stats(C.Structure):
                 ("n_exchange_blocks", C.c_int), ("flops_local", C.c_longlong),
                 ("flops_top", C.c_longlong), ("bytes_exchange_factor", C.c_longlong),
                 ("bytes_exchange_step", C.c_longlong), ("n_slow_pivots", C.c_int)]
+
+    def asdict(self):
+        return {k: getattr(self, k) for k, _ in self._fields_}
+
+
+class IpOpts(C.Structure):
+    _fields_ = [("eps", C.c_double), ("max_iters", C.c_int), ("gammaf", C.c_double),
+                ("norm_data", C.c_double), ("reserved", C.c_int * 4)]
+
+
+class IpResult(C.Structure):
+    _fields_ = [("result", C.c_int), ("iters", C.c_int), ("n_factor", C.c_int), ("n_solve", C.c_int),
+                ("gap", C.c_double), ("mu", C.c_double), ("phi", C.c_double), ("pcost", C.c_double),
+                ("alpha", C.c_double), ("ms_total", C.c_float)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}
@@ -102,6 +117,8 @@ def lib():
     L.hqpkkt_profile_class_name.argtypes = [C.c_int]
     L.hqpkkt_set_shard.argtypes = [vp, C.c_int, C.c_int, EXCHANGE_FN, vp]
     L.hqpkkt_debug_read.argtypes = [vp, C.c_int, C.c_int, vp, C.c_longlong, C.POINTER(C.c_longlong)]
+    L.hqpkkt_default_ip_opts.argtypes = [C.POINTER(IpOpts)]
+    L.hqpkkt_mehrotra.argtypes = [vp, C.POINTER(IpOpts)] + [dp] * 7 + [C.POINTER(IpResult)]
     _lib = L
     return L
 

@@ -14,6 +14,7 @@
 
 #include "analysis.hpp"
 #include "kernels.hip.h"
+#include "ipdriver.hip.h"
 
 using namespace kktdev;
 
@@ -171,6 +172,7 @@ struct hqpkkt {
   DBuf<double> vres;  // residual vectors _r1.._r4
   DBuf<double> vcor;  // corrections _dx.._dw
   DBuf<double> tz;    // REDUCED temporary (m)
+  DBuf<double> ipv;   // interior-point driver: x y z w | r1..r4 | dxa..dwa | dx..dw | c b d | partials | scalars
   size_t lds_diag = 0, lds_panel = 0, lds_bwdb = 0;
   // captured kernel sequences (factor; step on the caller's vectors; step on the
   // refinement's residual vectors): replayed with hipGraphLaunch
@@ -203,7 +205,7 @@ struct hqpkkt {
                              &zero_panel, &zero_upd};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &ipv};
     for (auto b : db) b->release();
     terms.release(), esign.release(), bits.release();
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
@@ -859,6 +861,286 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if (res_out) *res_out = res;
   if (res != res) return HQPKKT_E_SING;
   return 0;
+}
+
+// ---- device-resident Mehrotra predictor-corrector loop ----------------------
+// Restatement of hqp/Hqp_IpsMehrotra.C: cold_start (:209-327), step (:355-693),
+// solve (:696-735, cold start only).  Scalars are reduced on the device in a fixed
+// order and read back; vectors stay on the device.
+namespace {
+struct IpCtx {
+  hqpkkt_t *h;
+  int n, me, m;
+  double *x, *y, *z, *w, *r1, *r2, *r3, *r4, *dxa, *dya, *dza, *dwa, *dx, *dy, *dz, *dw, *c, *b, *d, *part, *out;
+  double hout[16];
+  int reduce(const int (&ops)[IP_SLOTS], int nout) {
+    IpOps o;
+    for (int k = 0; k < IP_SLOTS; k++) o.op[k] = ops[k];
+    k_ip_final<<<1, 256, 0, h->stream>>>(part, o, out);
+    HIPCHK(hipMemcpyAsync(hout, out, sizeof(double) * nout, hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(hipStreamSynchronize(h->stream));
+    return 0;
+  }
+};
+}  // namespace
+
+int hqpkkt_default_ip_opts(hqpkkt_ip_opts *o) {
+  if (!o) return HQPKKT_E_NULL;
+  std::memset(o, 0, sizeof(*o));
+  o->eps = 1e-10;       // hqp/Hqp_Solver.C:53
+  o->max_iters = 200;   // hqp/Hqp_Solver.C:52
+  o->gammaf = 0.01;     // hqp/Hqp_IpsMehrotra.C:95
+  return 0;
+}
+
+int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
+                    const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
+  if (!h || !res) return HQPKKT_E_NULL;
+  if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
+  if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
+  hqpkkt_ip_opts o;
+  if (opts)
+    o = *opts;
+  else
+    hqpkkt_default_ip_opts(&o);
+  Analysis &an = h->an;
+  const int n = an.n, me = an.me, m = an.m;
+  if ((n && !c) || (me && !b) || (m && !d) || (n && !x) || (me && !y) || (m && (!z || !w))) return HQPKKT_E_NULL;
+  HIPCHK(hipSetDevice(h->opts.device));
+  hipStream_t s = h->stream;
+  const size_t nv = (size_t)n + me + 2 * (size_t)m;
+  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 32;
+  int e;
+  if (h->ipv.count < need && (e = h->ipv.alloc(need))) return e;
+  IpCtx C;
+  C.h = h, C.n = n, C.me = me, C.m = m;
+  double *q = h->ipv.p;
+  auto take = [&](size_t k) { double *r = q; q += k; return r; };
+  C.x = take(n), C.y = take(me), C.z = take(m), C.w = take(m);
+  C.r1 = take(n), C.r2 = take(me), C.r3 = take(m), C.r4 = take(m);
+  C.dxa = take(n), C.dya = take(me), C.dza = take(m), C.dwa = take(m);
+  C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
+  C.c = take(n), C.b = take(me), C.d = take(m);
+  C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(32);
+  const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
+  if (me) HIPCHK(hipMemcpyAsync(C.b, b, sizeof(double) * me, in_kind, s));
+  if (m) HIPCHK(hipMemcpyAsync(C.d, d, sizeof(double) * m, in_kind, s));
+  // the plugin entry points below take the driver's DEVICE vectors
+  const int saved_loc = h->opts.loc;
+  struct Restore {
+    hqpkkt_t *h;
+    int loc;
+    ~Restore() { h->opts.loc = loc; }
+  } restore{h, saved_loc};
+  h->opts.loc = HQPKKT_LOC_DEVICE;
+  hipEvent_t t0 = h->ev0;  // total time: own pair of events (the plugin calls reuse the handle's)
+  hipEvent_t tb, te;
+  HIPCHK(hipEventCreate(&tb));
+  HIPCHK(hipEventCreate(&te));
+  (void)t0;
+  HIPCHK(hipEventRecord(tb, s));
+  std::memset(res, 0, sizeof(*res));
+  res->result = 2;  // Hqp_Infeasible until decided (hqp/Hqp_IpsMehrotra.C:219)
+  const int total = n + me + m;
+  double resid = 0.0;
+  int iter = 0, n_factor = 0, n_solve = 0;
+  auto finish = [&](int result) -> int {
+    res->result = result, res->iters = iter, res->n_factor = n_factor, res->n_solve = n_solve;
+    if (n) HIPCHK(hipMemcpyAsync(x, C.x, sizeof(double) * n, out_kind, s));
+    if (me) HIPCHK(hipMemcpyAsync(y, C.y, sizeof(double) * me, out_kind, s));
+    if (m) HIPCHK(hipMemcpyAsync(z, C.z, sizeof(double) * m, out_kind, s));
+    if (m) HIPCHK(hipMemcpyAsync(w, C.w, sizeof(double) * m, out_kind, s));
+    HIPCHK(hipEventRecord(te, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, tb, te);
+    res->ms_total = ms;
+    (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+    return 0;
+  };
+  auto factor = [&]() -> int { n_factor++; return hqpkkt_factor(h, C.z, C.w); };
+  auto solve = [&](double *ox, double *oy, double *oz, double *ow) -> int {
+    n_solve++;
+    return hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, ox, oy, oz, ow, &resid);
+  };
+  const int OPS_NONE[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+
+  // ------------------------------------------------------------ cold start
+  if (m > 0) {
+    k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
+    if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
+      if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:262-269)
+      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+      return e;
+    }
+    HIPCHK(hipMemcpyAsync(C.x, C.dx, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+    if (me) HIPCHK(hipMemcpyAsync(C.y, C.dy, sizeof(double) * me, hipMemcpyDeviceToDevice, s));
+    k_ip_cold_stats<<<IP_BLOCKS, 256, 0, s>>>(m, C.dz, C.dw, C.part);
+    const int ops1[IP_SLOTS] = {IP_MIN, IP_MIN, IP_MAX, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+    if ((e = C.reduce(ops1, 6))) return e;
+    double mindz = C.hout[0], mindw = C.hout[1], sumdz = C.hout[4], sumdw = C.hout[5];
+    if (C.hout[2] == 0.0) {  // :301-304
+      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dz);
+      mindz = 1.0e-10, sumdz = 1.0e-10 * m;
+    }
+    if (C.hout[3] == 0.0) {
+      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dw);
+      mindw = 1.0e-10, sumdw = 1.0e-10 * m;
+    }
+    double delz = std::fmax(-1.5 * mindz, 0.0), delw = std::fmax(-1.5 * mindw, 0.0);
+    // gap = (dz + delz)'(dw + delw): k_ip_mupl with alpha = 1 on (delz, dz), (delw, dw) shifted vectors
+    k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
+    k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, C.z, C.w, C.dz, C.dw, C.part);
+    if ((e = C.reduce(OPS_NONE, 1))) return e;
+    const double gap0 = C.hout[0];
+    delz += 0.5 * gap0 / (sumdw + m * delw);
+    delw += 0.5 * gap0 / (sumdz + m * delz);
+    k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
+  } else {
+    if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
+    if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
+  }
+
+  // ------------------------------------------------------------ iterations
+  std::vector<double> phimin((size_t)o.max_iters + 2, 0.0);
+  double mu0 = 0.0, norm_r0 = 0.0, norm_data = 1.0;
+  const double gamma = std::pow(1.0e-4, 0.25);
+  int result = 2;
+  while (true) {
+    // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
+    k_ip_rhs<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                       h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
+                                       C.part);
+    if (m == 0) {  // equality-constrained QP: one Newton step (:364-413)
+      if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
+        if (e == HQPKKT_E_SING) return finish(4);
+        (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+        return e;
+      }
+      k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
+      iter++;
+      return finish(0);
+    }
+    const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
+    if ((e = C.reduce(ops2, 6))) return e;
+    const double gap = C.hout[0], mu = C.hout[2] / m, norm_r = C.hout[3];
+    res->gap = gap, res->mu = mu, res->pcost = C.hout[1];
+    if (iter == 0) {
+      mu0 = mu, norm_r0 = norm_r;
+      norm_data = o.norm_data > 0.0 ? o.norm_data : 1.0;
+    }
+    const double phi = (norm_r + std::fabs(gap)) / norm_data;
+    phimin[iter] = phi;
+    res->phi = phi;
+    if (mu <= o.eps && norm_r <= o.eps * norm_data) {  // :487-490
+      result = 0;
+      break;
+    }
+    double pm = phimin[0];
+    for (int i = 1; i <= iter; i++) pm = std::fmin(pm, phimin[i]);
+    if (phi > o.eps && phi >= 1.0e4 * pm) {  // :494-502
+      result = 3;
+      break;
+    }
+    if (iter >= 30) {  // slow convergence (:506-516)
+      double pm30 = phimin[1];
+      for (int i = 2; i <= iter - 30; i++) pm30 = std::fmin(pm30, phimin[i]);
+      if (pm >= 0.5 * pm30) {
+        result = 3;
+        break;
+      }
+    }
+    if (norm_r > o.eps * norm_data && norm_r / mu >= 1.0e8 * norm_r0 / mu0) result = 3;  // :520-524 (no return)
+    // factorise; predictor (affine) step
+    if ((e = factor()) || (e = solve(C.dxa, C.dya, C.dza, C.dwa))) {
+      if (e == HQPKKT_E_SING) return finish(4);
+      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+      return e;
+    }
+    k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.part);
+    const int ops3[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+    if ((e = C.reduce(ops3, 2))) return e;
+    const double alpha_aff = std::fmax(0.0, std::fmin(std::fmin(1.0, C.hout[0]), 1.0));
+    const double t = C.hout[1];
+    double sigma = gamma * (t + 1.0 - alpha_aff) / (1.0 - gamma);  // Terlaky's modification (:583-590)
+    double smm = sigma * mu;
+    bool have_corr = false;
+    if (alpha_aff >= 0.1) {
+      k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, C.r4);
+      if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
+        if (e == HQPKKT_E_SING) return finish(4);
+        (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+        return e;
+      }
+      have_corr = true;
+    }
+    {
+      // (:604-624) the corrector's own largest step; a second corrector with the safe sigma
+      // when the predictor step or this one is too short.  Without a first corrector the
+      // reference tests the stale d* of the previous iteration; the test is skipped then
+      // only in the very first iteration, where they hold the cold start's step.
+      k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+      if ((e = C.reduce(ops3, 1))) return e;
+      const double alpha_corr = std::fmax(0.0, std::fmin(std::fmin(1.0, C.hout[0]), 1.0));
+      if (alpha_aff < 0.1 || alpha_corr < gamma * gamma / 2.0 / m / m) {
+        sigma = gamma / (1.0 - gamma);
+        smm = sigma * mu;
+        k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, C.r4);
+        if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
+          if (e == HQPKKT_E_SING) return finish(4);
+          (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+          return e;
+        }
+      }
+      (void)have_corr;
+    }
+    // Mehrotra's adaptive step size (:629-672)
+    k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, C.out);
+    HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const double zmin = C.hout[0], wmin = C.hout[6];
+    const int izmin = (int)C.hout[1], iwmin = (int)C.hout[7];
+    const double z_iz = C.hout[2], dz_iz = C.hout[3], w_iz = C.hout[4], dw_iz = C.hout[5];
+    const double z_iw = C.hout[8], dz_iw = C.hout[9], w_iw = C.hout[10], dw_iw = C.hout[11];
+    double alpha;
+    if (izmin < 0 && iwmin < 0)
+      alpha = 1.0;
+    else {
+      if (izmin < 0)
+        alpha = wmin;
+      else if (iwmin < 0)
+        alpha = zmin;
+      else
+        alpha = std::fmin(zmin, wmin);
+      k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, alpha, C.z, C.w, C.dz, C.dw, C.part);
+      if ((e = C.reduce(OPS_NONE, 1))) return e;
+      const double mu_pl = C.hout[0] / m;
+      double fpd;
+      if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
+        fpd = (o.gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
+      else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
+        fpd = (o.gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
+      else
+        fpd = 0.0;
+      alpha = std::fmax(0.0, std::fmin(std::fmax(1.0 - o.gammaf, fpd) * alpha, 1.0));
+    }
+    res->alpha = alpha;
+    k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
+    const int ops5[IP_SLOTS] = {IP_SUM, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+    if ((e = C.reduce(ops5, 2))) return e;
+    const double mu_new = C.hout[0] / m;
+    if (!std::isfinite(mu_new) || !std::isfinite(C.hout[1])) {  // :684-690
+      result = 4;
+      break;
+    }
+    iter++;
+    if (result == 3 || result == 4) break;  // set by the blow-up test above
+    if (iter >= o.max_iters) break;         // :716
+  }
+  return finish(result);
 }
 
 int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {

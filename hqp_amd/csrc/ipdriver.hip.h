@@ -1,0 +1,293 @@
+// Device-resident interior-point loop around the KKT path: the vector work of the
+// reference's Mehrotra predictor-corrector solver (hqp/Hqp_IpsMehrotra.C:209-327
+// cold_start, :355-693 step, :696-735 solve), restated as kernels over the
+// handle's CSR blocks so that x, y, z, w, the right-hand sides and the steps never
+// leave the GPU between factor and solve.  The
+// scalars that steer the iteration (gap, mu, step lengths, sigma) are reduced on
+// the device in a FIXED order (per-block partials, then one block) and read back:
+// the iteration is deterministic run to run.
+#pragma once
+
+namespace kktdev {
+
+#define IP_BLOCKS 256
+#define IP_SLOTS 8
+enum { IP_SUM = 0, IP_MAX = 1, IP_MIN = 2 };
+
+// block-level combine of one slot (256 threads), result in thread 0
+__device__ __forceinline__ double ip_block_reduce(double v, int op, double *red) {
+  v = op == IP_SUM ? wave_sum(v) : (op == IP_MAX ? wave_max(v) : -wave_max(-v));
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red[0];
+  if (threadIdx.x == 0) {
+    for (int k = 1; k < 4; k++) r = op == IP_SUM ? r + red[k] : (op == IP_MAX ? fmax(r, red[k]) : fmin(r, red[k]));
+  }
+  __syncthreads();
+  return r;
+}
+__device__ __forceinline__ double nan_to_inf(double a) {
+  return a == a ? a : __longlong_as_double(0x7ff0000000000000LL);
+}
+
+// partials[IP_BLOCKS][IP_SLOTS] -> out[IP_SLOTS], slot k combined with ops[k]
+struct IpOps {
+  int op[IP_SLOTS];
+};
+__global__ void __launch_bounds__(256) k_ip_final(const double *__restrict__ part, IpOps ops, double *__restrict__ out) {
+  __shared__ double red[4];
+  for (int k = 0; k < IP_SLOTS; k++) {
+    const double v = part[threadIdx.x * IP_SLOTS + k];  // IP_BLOCKS == blockDim.x
+    const double r = ip_block_reduce(v, ops.op[k], red);
+    if (threadIdx.x == 0) out[k] = r;
+  }
+}
+
+// right-hand sides of an iteration (hqp/Hqp_IpsMehrotra.C:425-447) and the
+// quantities of the convergence test:
+//   r1 = Qx + c - A'y - C'z, r2 = -(Ax + b), r3 = -(Cx + d - w), r4 = -z.*w
+//   slots: 0 gap = x'(Qx+c) + y'b + z'd, 1 pcost, 2 z'w, 3 max(|r1|,|r2|,|r3|), 4 min z, 5 min w
+__global__ void __launch_bounds__(256)
+k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev C,
+         const double *__restrict__ vals, const double *__restrict__ c, const double *__restrict__ b,
+         const double *__restrict__ d, const double *__restrict__ x, const double *__restrict__ y,
+         const double *__restrict__ z, const double *__restrict__ w, double *__restrict__ r1,
+         double *__restrict__ r2, double *__restrict__ r3, double *__restrict__ r4,
+         double *__restrict__ part) {
+  __shared__ double red[4];
+  const int sub = threadIdx.x & 15;
+  const int total = n + me + m;
+  double gap = 0.0, pc = 0.0, zw = 0.0, nr = 0.0, zmin = 1e300, wmin = 1e300;
+  for (int q = blockIdx.x * 16 + (threadIdx.x >> 4); q < total; q += gridDim.x * 16) {
+    if (q < n) {
+      const double qx = row_dot16(Q, vals, x, q, sub);
+      const double g = qx + c[q];
+      const double s = g - row_dot16(AT, vals, y, q, sub) - row_dot16(CT, vals, z, q, sub);
+      if (sub == 0) {
+        r1[q] = s;
+        gap += x[q] * g, pc += x[q] * (0.5 * qx + c[q]);
+        nr = fmax(nr, nan_to_inf(fabs(s)));
+      }
+    } else if (q < n + me) {
+      const int i = q - n;
+      const double s = -(row_dot16(A, vals, x, i, sub) + b[i]);
+      if (sub == 0) {
+        r2[i] = s;
+        gap += y[i] * b[i];
+        nr = fmax(nr, nan_to_inf(fabs(s)));
+      }
+    } else {
+      const int j = q - n - me;
+      const double s = -(row_dot16(C, vals, x, j, sub) + d[j] - w[j]);
+      if (sub == 0) {
+        r3[j] = s, r4[j] = -(z[j] * w[j]);
+        gap += z[j] * d[j], zw += z[j] * w[j];
+        nr = fmax(nr, nan_to_inf(fabs(s)));
+        zmin = fmin(zmin, z[j]), wmin = fmin(wmin, w[j]);
+      }
+    }
+  }
+  double *P = part + blockIdx.x * IP_SLOTS;
+  double r;
+  r = ip_block_reduce(gap, IP_SUM, red); if (threadIdx.x == 0) P[0] = r;
+  r = ip_block_reduce(pc, IP_SUM, red);  if (threadIdx.x == 0) P[1] = r;
+  r = ip_block_reduce(zw, IP_SUM, red);  if (threadIdx.x == 0) P[2] = r;
+  r = ip_block_reduce(nr, IP_MAX, red);  if (threadIdx.x == 0) P[3] = r;
+  r = ip_block_reduce(zmin, IP_MIN, red); if (threadIdx.x == 0) P[4] = r;
+  r = ip_block_reduce(wmin, IP_MIN, red); if (threadIdx.x == 0) P[5] = r, P[6] = 0.0, P[7] = 0.0;
+}
+
+// largest feasible step (hqp/Hqp_IpsMehrotra.C:566-572, 605-611) and Terlaky's
+// t = max dz dw / (z w) over dz dw > 0 (:584-588)
+//   slots: 0 min ratio (1e300 if none), 1 t
+__global__ void __launch_bounds__(256)
+k_ip_ratio(int m, const double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ dz,
+           const double *__restrict__ dw, double *__restrict__ part) {
+  __shared__ double red[4];
+  double a = 1e300, t = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    const double zi = z[i], wi = w[i], dzi = dz[i], dwi = dw[i];
+    if (dzi < 0.0) a = fmin(a, -zi / dzi);
+    if (dwi < 0.0) a = fmin(a, -wi / dwi);
+    if (dzi * dwi > 0.0) t = fmax(t, dzi * dwi / zi / wi);
+  }
+  double *P = part + blockIdx.x * IP_SLOTS;
+  double r;
+  r = ip_block_reduce(a, IP_MIN, red); if (threadIdx.x == 0) P[0] = r;
+  r = ip_block_reduce(t, IP_MAX, red);
+  if (threadIdx.x == 0) {
+    P[1] = r;
+    for (int k = 2; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+
+// corrector right-hand side r4 = -(z.*w + dza.*dwa - sigma mu)  (:596-600, :617-622)
+__global__ void k_ip_corr_rhs(int m, const double *__restrict__ z, const double *__restrict__ w,
+                              const double *__restrict__ dza, const double *__restrict__ dwa, double smm,
+                              double *__restrict__ r4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) r4[i] = -(z[i] * w[i] + (dza[i] * dwa[i] - smm));
+}
+
+// Mehrotra's adaptive step (:629-646): the blocking component of z and of w, first
+// index of the minimum as the reference's loop finds it.  One block; out: zmin,
+// izmin, wmin, iwmin (indices as doubles, -1 if none).
+__global__ void __launch_bounds__(256)
+k_ip_minratio_part(int m, const double *__restrict__ z, const double *__restrict__ w,
+                   const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ part) {
+  __shared__ double sv[256];
+  __shared__ int si[256];
+  double zv = 1e300, wv = 1e300;
+  int zi = 0x7fffffff, wi = 0x7fffffff;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    if (dz[i] < 0.0) {
+      const double q = -z[i] / dz[i];
+      if (q < zv || (q == zv && i < zi)) zv = q, zi = i;
+    }
+    if (dw[i] < 0.0) {
+      const double q = -w[i] / dw[i];
+      if (q < wv || (q == wv && i < wi)) wv = q, wi = i;
+    }
+  }
+  double *P = part + blockIdx.x * IP_SLOTS;
+  for (int pass = 0; pass < 2; pass++) {
+    sv[threadIdx.x] = pass ? wv : zv, si[threadIdx.x] = pass ? wi : zi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        const double ov = sv[threadIdx.x + s];
+        const int oi = si[threadIdx.x + s];
+        if (ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x]))
+          sv[threadIdx.x] = ov, si[threadIdx.x] = oi;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) P[2 * pass] = sv[0], P[2 * pass + 1] = (double)si[0];
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256)
+k_ip_minratio_final(const double *__restrict__ part, const double *__restrict__ z, const double *__restrict__ w,
+                    const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ out) {
+  __shared__ double sv[256];
+  __shared__ int si[256];
+  for (int pass = 0; pass < 2; pass++) {
+    sv[threadIdx.x] = part[threadIdx.x * IP_SLOTS + 2 * pass];
+    si[threadIdx.x] = (int)part[threadIdx.x * IP_SLOTS + 2 * pass + 1];
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        const double ov = sv[threadIdx.x + s];
+        const int oi = si[threadIdx.x + s];
+        if (ov < sv[threadIdx.x] || (ov == sv[threadIdx.x] && oi < si[threadIdx.x]))
+          sv[threadIdx.x] = ov, si[threadIdx.x] = oi;
+      }
+      __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+      const bool none = !(sv[0] < 1e300);
+      const int i = none ? -1 : si[0];
+      out[6 * pass] = sv[0], out[6 * pass + 1] = (double)i;
+      // the four components the damping rule looks at (:660-668)
+      out[6 * pass + 2] = none ? 0.0 : z[i], out[6 * pass + 3] = none ? 0.0 : dz[i];
+      out[6 * pass + 4] = none ? 0.0 : w[i], out[6 * pass + 5] = none ? 0.0 : dw[i];
+    }
+    __syncthreads();
+  }
+}
+
+// slot 0: (z + alpha dz)'(w + alpha dw)  (:657-659)
+__global__ void __launch_bounds__(256)
+k_ip_mupl(int m, double alpha, const double *__restrict__ z, const double *__restrict__ w,
+          const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ part) {
+  __shared__ double red[4];
+  double s = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+    s += (z[i] + alpha * dz[i]) * (w[i] + alpha * dw[i]);
+  const double r = ip_block_reduce(s, IP_SUM, red);
+  if (threadIdx.x == 0) {
+    double *P = part + blockIdx.x * IP_SLOTS;
+    P[0] = r;
+    for (int k = 1; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+
+// the step (:677-680): x, y, z, w += alpha d*;  slots: 0 z'w, 1 max|x| (NaN -> inf)
+__global__ void __launch_bounds__(256)
+k_ip_update(int n, int me, int m, double alpha, double *__restrict__ x, double *__restrict__ y,
+            double *__restrict__ z, double *__restrict__ w, const double *__restrict__ dx,
+            const double *__restrict__ dy, const double *__restrict__ dz, const double *__restrict__ dw,
+            double *__restrict__ part) {
+  __shared__ double red[4];
+  double zw = 0.0, xm = 0.0;
+  const int total = n + me + m;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    if (q < n) {
+      const double v = x[q] + alpha * dx[q];
+      x[q] = v;
+      xm = fmax(xm, nan_to_inf(fabs(v)));
+    } else if (q < n + me) {
+      y[q - n] += alpha * dy[q - n];
+    } else {
+      const int j = q - n - me;
+      const double zn = z[j] + alpha * dz[j], wn = w[j] + alpha * dw[j];
+      z[j] = zn, w[j] = wn;
+      zw += zn * wn;
+    }
+  }
+  double *P = part + blockIdx.x * IP_SLOTS;
+  double r;
+  r = ip_block_reduce(zw, IP_SUM, red); if (threadIdx.x == 0) P[0] = r;
+  r = ip_block_reduce(xm, IP_MAX, red);
+  if (threadIdx.x == 0) {
+    P[1] = r;
+    for (int k = 2; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+
+// cold start (:236-252): z = w = 1, r1 = c, r2 = -b, r3 = -d, r4 = 0
+__global__ void k_ip_cold_rhs(int n, int me, int m, const double *__restrict__ c, const double *__restrict__ b,
+                              const double *__restrict__ d, double *__restrict__ z, double *__restrict__ w,
+                              double *__restrict__ r1, double *__restrict__ r2, double *__restrict__ r3,
+                              double *__restrict__ r4) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n)
+    r1[q] = c[q];
+  else if (q < n + me)
+    r2[q - n] = -b[q - n];
+  else if (q < n + me + m) {
+    const int j = q - n - me;
+    z[j] = 1.0, w[j] = 1.0, r3[j] = -d[j], r4[j] = 0.0;
+  }
+}
+// slots: 0 min dz, 1 min dw, 2 max|dz|, 3 max|dw|, 4 sum dz, 5 sum dw  (:305-310)
+__global__ void __launch_bounds__(256)
+k_ip_cold_stats(int m, const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ part) {
+  __shared__ double red[4];
+  double a = 1e300, bq = 1e300, ma = 0.0, mb = 0.0, sa = 0.0, sb = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    a = fmin(a, dz[i]), bq = fmin(bq, dw[i]);
+    ma = fmax(ma, fabs(dz[i])), mb = fmax(mb, fabs(dw[i]));
+    sa += dz[i], sb += dw[i];
+  }
+  double *P = part + blockIdx.x * IP_SLOTS;
+  double r;
+  r = ip_block_reduce(a, IP_MIN, red);  if (threadIdx.x == 0) P[0] = r;
+  r = ip_block_reduce(bq, IP_MIN, red); if (threadIdx.x == 0) P[1] = r;
+  r = ip_block_reduce(ma, IP_MAX, red); if (threadIdx.x == 0) P[2] = r;
+  r = ip_block_reduce(mb, IP_MAX, red); if (threadIdx.x == 0) P[3] = r;
+  r = ip_block_reduce(sa, IP_SUM, red); if (threadIdx.x == 0) P[4] = r;
+  r = ip_block_reduce(sb, IP_SUM, red); if (threadIdx.x == 0) P[5] = r, P[6] = 0.0, P[7] = 0.0;
+}
+// z = dz + delz, w = dw + delw  (:316-319)
+__global__ void k_ip_shift(int m, const double *__restrict__ dz, const double *__restrict__ dw, double delz,
+                           double delw, double *__restrict__ z, double *__restrict__ w) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < m) z[i] = dz[i] + delz, w[i] = dw[i] + delw;
+}
+__global__ void k_ip_fill(int n, double v, double *__restrict__ x) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) x[i] = v;
+}
+
+}  // namespace kktdev

@@ -76,6 +76,7 @@ class Hqp_IpMatrix:
         self._L = L
         self._h = C.c_void_p()
         self._device_vectors = bool(device_vectors)
+        self._dev = int(device)
         _check(L.hqpkkt_create(C.byref(o), C.byref(self._h)), "create")
         self._keep = None
         self._xchg = None
@@ -239,6 +240,42 @@ class Hqp_IpMatrix:
         out = np.zeros(max(k.value, 1), dtype=np.int32)
         _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
         return out[: k.value]
+
+    def mehrotra(self, qp, eps=1e-10, max_iters=200):
+        """Device-resident Mehrotra predictor-corrector solve of the QP (cold start), the
+        restatement of hqp/Hqp_IpsMehrotra.C behind ``hqpkkt_mehrotra``: returns
+        (x, y, z, w, info).  init()/update() must have been called with ``qp``."""
+        o = _lib.IpOpts()
+        self._L.hqpkkt_default_ip_opts(C.byref(o))
+        o.eps, o.max_iters = eps, max_iters
+
+        def rowsum(csr, rows):  # sp_norm_inf (meschach/addon2_hqp.c:723-743)
+            p, _i, x = csr
+            if rows == 0 or len(x) == 0:
+                return 0.0
+            return float(np.add.reduceat(np.abs(np.r_[np.asarray(x, dtype=float), 0.0]),
+                                         np.asarray(p[:-1], dtype=np.int64))[np.diff(p) > 0].max(initial=0.0))
+
+        def ninf(v):
+            return float(np.abs(v).max()) if len(v) else 0.0
+
+        o.norm_data = max(rowsum(qp.Q, qp.n), rowsum(qp.A, qp.me), rowsum(qp.C, qp.m), ninf(qp.c), ninf(qp.b),
+                          ninf(qp.d))
+        res = _lib.IpResult()
+        self._tmp = []
+        if self._device_vectors:
+            import torch
+            dev = torch.device("cuda", self._dev)
+            mk = lambda k: torch.zeros(k, dtype=torch.float64, device=dev)
+            cin = [torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64)).to(dev) for v in (qp.c, qp.b, qp.d)]
+        else:
+            mk = lambda k: np.zeros(k)
+            cin = [np.ascontiguousarray(v, dtype=np.float64) for v in (qp.c, qp.b, qp.d)]
+        x, y, z, w = mk(qp.n), mk(qp.me), mk(qp.m), mk(qp.m)
+        ptrs = [self._ptr(a, k, nm) for a, k, nm in zip(cin + [x, y, z, w], (qp.n, qp.me, qp.m, qp.n, qp.me, qp.m, qp.m),
+                                                      ("c", "b", "d", "x", "y", "z", "w"))]
+        _check(self._L.hqpkkt_mehrotra(self._h, C.byref(o), *ptrs, C.byref(res)), "mehrotra")
+        return x, y, z, w, res.asdict()
 
     def read_block(self, what, node):
         """Numeric block of a supernode after factor() (tests): 0 panel, 1 inverse of

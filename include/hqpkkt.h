@@ -214,6 +214,34 @@ int hqpkkt_get_profile(const hqpkkt_t *h, int n_classes, double *ms, long long *
 const char *hqpkkt_profile_class_name(int c);
 const char *hqpkkt_strerror(int status);
 
+/* ---- device-resident interior-point loop ------------------
+ * The reference's Mehrotra predictor-corrector solver (hqp/Hqp_IpsMehrotra.C:
+ * cold_start :209-327, step :355-693, solve :696-735) with all vector work on the
+ * device: per iteration one factor and two (rarely three) solves of this library plus
+ * a handful of kernels over the CSR blocks; only the scalars that steer the iteration
+ * come back to the host.  The handle must hold the QP's matrices (hqpkkt_analyze +
+ * hqpkkt_set_values with Q, A, C of the Hqp_Program, hqp/Hqp_Program.h:43-60); c, b, d
+ * and the outputs x, y, z, w follow opts.loc of the handle.  Cold start only
+ * (qp_init_method 0).  result uses the reference's Hqp_Result numbering
+ * (hqp/Hqp_impl.h:37-43): 0 optimal, 3 suboptimal, 4 degenerate. */
+typedef struct hqpkkt_ip_opts {
+  double eps;       /* qp_eps (hqp/Hqp_Solver.C:53)                                   */
+  int max_iters;    /* qp_max_iters (hqp/Hqp_Solver.C:52)                             */
+  double gammaf;    /* step damping (hqp/Hqp_IpsMehrotra.C:95)                        */
+  double norm_data; /* max inf-norm of Q, A, C, c, b, d (hqp/Hqp_IpsMehrotra.C:462-464);
+                       the caller holds the data, 0 = use 1                            */
+  int reserved[4];
+} hqpkkt_ip_opts;
+typedef struct hqpkkt_ip_result {
+  int result, iters;     /* Hqp_Result, iterations                                    */
+  int n_factor, n_solve; /* plugin calls made                                         */
+  double gap, mu, phi, pcost, alpha; /* of the last iteration                         */
+  float ms_total;        /* device time of the whole call                             */
+} hqpkkt_ip_result;
+int hqpkkt_default_ip_opts(hqpkkt_ip_opts *opts);
+int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
+                    const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res);
+
 /* ---- introspection of the symbolic structure (host arrays; used by the
  * structure tests, not by the reference-side shim) ------------------------ */
 /* what: 0 elim (QP index -> elimination index, dim), 1 node_piv_start,

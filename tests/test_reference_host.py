@@ -88,3 +88,36 @@ def test_reference_ip_solver_drives_hip_plugin(solver, pair, case):
     assert abs(hip["iters"] - ref["iters"]) <= slack, info
     assert abs(fr - fh) <= 1e-6 * max(1.0, abs(fr)), info
     assert np.abs(hip["x"] - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max()), info
+
+
+def _without_inequalities(prog):
+    e = np.zeros(0)
+    return problems.Program(prog.n, prog.me, 0, prog.Q, prog.A,
+                            (np.zeros(1, dtype=np.int32), np.zeros(0, dtype=np.int32), e), c=prog.c, b=prog.b, d=e)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RedSpBKP", "SpBKP"])
+@pytest.mark.parametrize("case", ["did400", "did2000", "banded", "banded3k", "noineq"])
+def test_device_resident_mehrotra_follows_the_reference(case, kind):
+    """hqpkkt_mehrotra (the reference's Mehrotra loop restated with all vector work on
+    the GPU) against the reference's own Hqp_IpsMehrotra with its own plugin: same
+    termination, iteration count within +-1, same optimiser."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    prog = {"did400": lambda: problems.did_like_qp(400), "did2000": lambda: problems.did_like_qp(2000),
+            "banded": lambda: problems.banded_qp(300, 8, 5), "banded3k": lambda: problems.banded_qp(3000, 24, 4),
+            "noineq": lambda: _without_inequalities(problems.banded_qp(400, 10, 6))}[case]()
+    ref = refapi.ip_solve(prog, "Mehrotra", kind)
+    M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)()
+    M.init(prog)
+    x, y, z, w, info = M.mehrotra(prog)
+    assert info["result"] == ref["result"] == 0, (info, ref["result"], ref["iters"])
+    assert abs(info["iters"] - ref["iters"]) <= 1, (info, ref["iters"])
+    assert info["n_factor"] == info["iters"] + (1 if prog.m else 0)  # one per iteration + the cold start
+    fr, fd = objective(prog, ref["x"]), objective(prog, x)
+    assert abs(fr - fd) <= 1e-6 * max(1.0, abs(fr))
+    assert np.abs(x - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
+    if prog.m:
+        assert z.min() > 0 and w.min() > 0
