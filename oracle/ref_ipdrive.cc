@@ -35,7 +35,7 @@ static void fill(SPMAT *M, int rows, const int *p, const int *i, const double *x
 
 extern "C" {
 
-// solver: 0 = Mehrotra, 1 = Franke.  Returns 0, or the Meschach error number,
+// solver: 0 = Mehrotra, 1 = Franke, 2 = MehrotraHip (our Hqp_Solver plugin).  Returns 0, or the Meschach error number,
 // or -1 (setup) / -2 (unknown plugin name).
 // out[0] = iterations, out[1] = Hqp_Result (0 optimal), out[2] = seconds in
 // cold_start + solve, out[3] = seconds in init + update.
@@ -45,7 +45,15 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
                 const int *Ci, const double *Cx, const double *d, double qp_eps,
                 int max_iters, double *x, double *y, double *z, double *out) {
   if (hqpref_startup() != 0) return -1;
-  Hqp_Solver *S = solver == 0 ? (Hqp_Solver *)new Hqp_IpsMehrotra : (Hqp_Solver *)new Hqp_IpsFranke;
+  Hqp_Solver *S;
+  if (solver == 2) {
+    // our device-resident solver class (shim/Hqp_IpsMehrotraHip.C), created BY NAME through
+    // the reference's solver factory (iftcl/If_Class.h:92-105) as "sqp_qp_solver MehrotraHip"
+    // would do; only registered in libhqphost_hip.so
+    S = If_ClassList_Hqp_Solver() ? If_ClassList_Hqp_Solver()->createObject("MehrotraHip") : NULL;
+    if (!S) return -2;
+  } else
+    S = solver == 0 ? (Hqp_Solver *)new Hqp_IpsMehrotra : (Hqp_Solver *)new Hqp_IpsFranke;
   // select the plugin exactly as a user would: Tcl command qp_mat_solver
   if (If_SetString("qp_mat_solver", mat_solver) != IF_OK) {
     delete S;

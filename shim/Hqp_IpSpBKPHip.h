@@ -41,6 +41,9 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   Hqp_IpMatrixHip(int mode);
   ~Hqp_IpMatrixHip();
 
+  // the C-ABI handle (for Hqp_IpsMehrotraHip, which runs the whole iteration on it)
+  struct hqpkkt *handle() { return _h; }
+
   void init(const Hqp_Program *);
   void update(const Hqp_Program *);
   void factor(const Hqp_Program *, const VEC *z, const VEC *w);

@@ -1,0 +1,48 @@
+/*
+ * Hqp_IpsMehrotraHip.h -- Hqp_Solver plugin that runs the WHOLE interior-point
+ * iteration of the reference's Hqp_IpsMehrotra (hqp/Hqp_IpsMehrotra.C) on the
+ * device through hqpkkt_mehrotra (include/hqpkkt.h): x, y, z, w, the right-hand
+ * sides and the steps stay in HBM, the host sees one call per QP.
+ *
+ * Reference-side binding, compiled against the reference's headers like
+ * Hqp_IpSpBKPHip.C.  Registered with the solver factory (iftcl/If_Class.h:53-60):
+ *     sqp_qp_solver MehrotraHip
+ * and it owns an Hqp_IpMatrixHip plugin selected the usual way
+ *     qp_mat_solver RedSpBKPHip      (default, as the reference defaults to RedSpBKP,
+ *                                     hqp/Hqp_IpsMehrotra.C:92) | SpBKPHip | LQDOCPHip
+ * Differences to Hqp_IpsMehrotra: cold start only (hot_start() starts cold:
+ * Mehrotra's adaptive step makes the reference's hot start a heuristic, not a
+ * contract, hqp/Hqp_IpsMehrotra.C:343-344), qp_init_method 0 only, no qp_step
+ * (single iterations are not exposed).
+ */
+#ifndef Hqp_IpsMehrotraHip_H
+#define Hqp_IpsMehrotraHip_H
+
+#include "Hqp_Solver.h"
+
+class Hqp_IpMatrix;
+
+class Hqp_IpsMehrotraHip : public Hqp_Solver {
+ protected:
+  int _n, _me, _m;
+  VEC *_w;
+  Real _gap, _alpha, _gammaf;
+  int _n_factor, _n_solve;  // plugin calls of the last solve (read-only for the user)
+  Real _ms_total;           // device time of the last solve, milliseconds
+  Hqp_IpMatrix *_matrix;
+
+ public:
+  Hqp_IpsMehrotraHip();
+  ~Hqp_IpsMehrotraHip();
+
+  void init();
+  void update();
+  void cold_start();
+  void hot_start();
+  void step();
+  void solve();
+
+  const char *name() { return "MehrotraHip"; }
+};
+
+#endif

@@ -121,3 +121,25 @@ def test_device_resident_mehrotra_follows_the_reference(case, kind):
     assert np.abs(x - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
     if prog.m:
         assert z.min() > 0 and w.min() > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mat", ["RedSpBKPHip", "SpBKPHip"])
+def test_solver_plugin_mehrotra_hip_in_the_reference_host(mat):
+    """shim/Hqp_IpsMehrotraHip.C: an Hqp_Solver subclass created BY NAME through the
+    reference's solver factory ("sqp_qp_solver MehrotraHip"), with the KKT plugin
+    selected through the reference's own Tcl command; the whole iteration runs on the
+    device.  Same iteration count and optimiser as the reference's solver + plugin."""
+    if not refapi.host_available("hip"):
+        pytest.skip("oracle/_ref/libhqphost_hip.so not present")
+    prog = problems.did_like_qp(400)
+    ref = refapi.ip_solve(prog, "Mehrotra", "RedSpBKP", host="hip")
+    hip = refapi.ip_solve(prog, "MehrotraHip", mat, host="hip")
+    assert hip["result"] == ref["result"] == 0
+    assert abs(hip["iters"] - ref["iters"]) <= 1
+    fr, fh = objective(prog, ref["x"]), objective(prog, hip["x"])
+    assert abs(fr - fh) <= 1e-6 * max(1.0, abs(fr))
+    assert np.abs(hip["x"] - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
+    # a plugin that is not one of ours is refused (the loop needs the C-ABI handle)
+    with pytest.raises(refapi.RefError):
+        refapi.ip_solve(prog, "MehrotraHip", "SpBKP", host="hip")
