@@ -739,28 +739,37 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       if (keep(id)) S.level_ptr[level[id] + 1]++, S.nnodes++, S.flops += nflops[id];
     for (int l = 0; l < nlevels; l++) S.level_ptr[l + 1] += S.level_ptr[l];
     S.level_nodes.assign(S.nnodes, 0);
+    // a "small front" (few pivots AND few border rows, the fronts of narrow-band
+    // systems) is processed by one wavefront per supernode that does extend-add,
+    // pivot block, panel and update in one kernel (and the solves likewise)
+    auto fsmall = [&](int id) { return small_fronts && npiv[id] <= SMALL_PIVOTS && nbor[id] <= SMALL_BORDER; };
     {
-      // inside a level the supernodes with at most SMALL_PIVOTS pivots come first:
-      // they are factored by the one-wavefront kernel
+      // order inside a level: small fronts, then the other supernodes with at most
+      // SMALL_PIVOTS pivots (one-wavefront pivot-block kernel), then the rest
       std::vector<int> fill(S.level_ptr.begin(), S.level_ptr.end() - 1);
       for (int id = 0; id < nnodes; id++)
-        if (keep(id) && npiv[id] <= SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
+        if (keep(id) && fsmall(id)) S.level_nodes[fill[level[id]]++] = id;
+      S.level_fsmall.assign(nlevels, 0);
+      for (int l = 0; l < nlevels; l++) S.level_fsmall[l] = fill[l] - S.level_ptr[l];
+      for (int id = 0; id < nnodes; id++)
+        if (keep(id) && !fsmall(id) && npiv[id] <= SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
       S.level_small.assign(nlevels, 0);
-      for (int l = 0; l < nlevels; l++) S.level_small[l] = fill[l] - S.level_ptr[l];
+      for (int l = 0; l < nlevels; l++) S.level_small[l] = fill[l] - S.level_ptr[l] - S.level_fsmall[l];
       for (int id = 0; id < nnodes; id++)
         if (keep(id) && npiv[id] > SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
     }
-    // extend-add segments: for parent level l, slot s -> children list
+    // extend-add segments: for parent level l, slot s -> children list (the small
+    // fronts gather their children themselves)
     S.ea_level_ptr.assign(nlevels + 1, 0);
     S.ea_seg_ptr.assign(1, 0);
     for (int l = 0; l < nlevels; l++) {
       int maxslots = 0;
-      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; t++) {
+      for (int t = S.level_ptr[l] + S.level_fsmall[l]; t < S.level_ptr[l + 1]; t++) {
         int id = S.level_nodes[t];
         maxslots = std::max(maxslots, child_ptr[id + 1] - child_ptr[id]);
       }
       for (int s = 0; s < maxslots; s++) {
-        for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; t++) {
+        for (int t = S.level_ptr[l] + S.level_fsmall[l]; t < S.level_ptr[l + 1]; t++) {
           int id = S.level_nodes[t];
           if (child_ptr[id + 1] - child_ptr[id] > s) S.ea_nodes.push_back(child_idx[child_ptr[id] + s]);
         }
@@ -771,7 +780,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     S.upd_tile_ptr.assign(nlevels + 1, 0), S.slab_ptr.assign(nlevels + 1, 0);
     S.gslab_ptr.assign(nlevels + 1, 0), S.cblk_ptr.assign(nlevels + 1, 0);
     for (int l = 0; l < nlevels; l++) {
-      for (int t = S.level_ptr[l]; t < S.level_ptr[l + 1]; t++) {
+      for (int t = S.level_ptr[l] + S.level_fsmall[l]; t < S.level_ptr[l + 1]; t++) {
         int id = S.level_nodes[t], b = nbor[id];
         int nt = (b + UPD_TILE - 1) / UPD_TILE;
         for (int ti = 0; ti < nt; ti++)

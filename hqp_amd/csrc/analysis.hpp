@@ -46,7 +46,8 @@ struct Analysis {
     int nnodes = 0;
     long long flops = 0;
     std::vector<int> level_ptr, level_nodes;  // nodes grouped by level
-    std::vector<int> level_small;             // per level: leading nodes with npiv <= SMALL_PIVOTS
+    std::vector<int> level_fsmall;            // per level: leading nodes that are small fronts
+    std::vector<int> level_small;             // per level: the following nodes with npiv <= SMALL_PIVOTS
     // children grouped by (parent level, slot) for deterministic extend-add
     std::vector<int> ea_seg_ptr, ea_nodes, ea_level_ptr;  // segments per level
     // tiles of the Schur update and slabs of the panel solve, grouped by level
@@ -59,6 +60,7 @@ struct Analysis {
 
   // --- one system sharded over several ranks ----------------------
   int shard_rank = 0, shard_count = 1;
+  bool small_fronts = true;  // fused one-wavefront kernels for fronts with few pivots and few border rows
   int slack_policy = 2;  // FULL mode, slack rows inside a node: 0 band order, 1 behind all x, 2 behind their own x
   std::vector<int> node_owner;  // owning rank per supernode, -1 = replicated top of the tree
   std::vector<int> xroots;      // subtree roots whose update / contribution blocks are exchanged
@@ -90,5 +92,6 @@ struct Analysis {
 static const int UPD_TILE = 64;   // Schur-update tile edge (rows/cols per workgroup)
 static const int SLAB_ROWS = 32;  // border rows per panel-solve workgroup
 static const int SMALL_PIVOTS = 32;  // supernodes up to this size use k_factor_diag_small
+static const int SMALL_BORDER = 16;  // ... and with at most this many border rows are "small fronts"
 
 }  // namespace kktdev

@@ -378,7 +378,7 @@ static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double 
   return 0;
 }
 
-static_assert(FS_MAXP == kktdev::SMALL_PIVOTS, "small-supernode kernel and schedule disagree");
+static_assert(FS_MAXP == kktdev::SMALL_PIVOTS && FS_MAXB == kktdev::SMALL_BORDER, "small-supernode kernels and schedule disagree");
 // ------------------------------------------------------------ numeric phases
 // phases: 1 = assemble + this rank's subtrees, 2 = replicated top of the tree
 // (3 = everything, the single-rank case)
@@ -423,13 +423,17 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
         KLAUNCH(h, KC_EXTEND_ADD, k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, D.ea_nodes.p + S.ea_seg_ptr[seg],
                                                        h->panel.p, h->upd.p));
       }
-      const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nsm = S.level_small[l];
-      if (nsm > 0)
-        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<<<nsm, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
+      const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l], nsm = S.level_small[l];
+      if (nfs > 0)  // small fronts: extend-add, pivot block, panel and update in one kernel
+        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<true><<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                                 h->flags.p + 1));
-      if (nn > nsm)
-        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nsm, h->panel.p,
+                                                 h->flags.p + 1, h->upd.p, h->xar.p));
+      if (nsm > 0)
+        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<false><<<nsm, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->panel.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->flags.p + 1, h->upd.p, h->xar.p));
+      if (nn > nfs + nsm)
+        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nfs - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1));
       const int ns = S.slab_ptr[l + 1] - S.slab_ptr[l];
@@ -460,10 +464,15 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
     const Analysis::Sched &S = an.sched[which];
     const hqpkkt::DevSched &D = h->ds[which];
     for (int l = 0; l < an.nlevels && S.nnodes; l++) {
-      const int nn = S.level_ptr[l + 1] - S.level_ptr[l];
-      if (nn > 0)
+      const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l];
+      if (nfs > 0)
         KLAUNCH(h, KC_SOLVE_FWD,
-                k_solve_fwd_a<<<nn, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->linv.p,
+                k_solve_fwd_small<<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
+                                                     h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
+                                                     h->xsol.p, h->ytmp.p, h->cb.p));
+      if (nn > nfs)
+        KLAUNCH(h, KC_SOLVE_FWD,
+                k_solve_fwd_a<<<nn - nfs, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->linv.p,
                                                  h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p,
                                                  h->rhs.p, h->xsol.p, h->ytmp.p, h->cb.p));
       const int ng = S.gslab_ptr[l + 1] - S.gslab_ptr[l];
@@ -478,14 +487,19 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
     const Analysis::Sched &S = an.sched[which];
     const hqpkkt::DevSched &D = h->ds[which];
     for (int l = an.nlevels - 1; l >= 0 && S.nnodes; l--) {
-      const int nn = S.level_ptr[l + 1] - S.level_ptr[l];
+      const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l];
       const int ncb = S.cblk_ptr[l + 1] - S.cblk_ptr[l];
       if (nn <= 0) continue;
+      if (nfs > 0)
+        KLAUNCH(h, KC_SOLVE_BWD,
+                k_solve_bwd_small<<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
+                                                     h->linv_off.p, h->lperm.p, h->xsol.p));
+      if (nn <= nfs) continue;
       KLAUNCH(h, KC_SOLVE_BWD,
               k_solve_bwd_b<<<ncb, 256, h->lds_bwdb, s>>>(T, D.cblks.p + 2 * (size_t)S.cblk_ptr[l],
                                                           h->panel.p, h->xsol.p, h->vtmp.p));
       KLAUNCH(h, KC_SOLVE_BWD,
-              k_solve_bwd_a<<<nn, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->linv.p,
+              k_solve_bwd_a<<<nn - nfs, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->linv.p,
                                                h->linv_off.p, h->lperm.p, h->vtmp.p, h->xsol.p));
     }
     return 0;
@@ -687,6 +701,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->an = Analysis();
   h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
   h->an.slack_policy = h->opts.slack_policy;
+  h->an.small_fronts = !h->opts.no_small_fronts;
   int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
                     h->opts.max_pivots, h->opts.zd_policy);
   if (e) return e;
@@ -1008,6 +1023,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   double mu0 = 0.0, norm_r0 = 0.0, norm_data = 1.0;
   const double gamma = std::pow(1.0e-4, 0.25);
   int result = 2;
+  bool stepped = false;
   while (true) {
     // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
     k_ip_rhs<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
@@ -1026,6 +1042,11 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
     if ((e = C.reduce(ops2, 6))) return e;
     const double gap = C.hout[0], mu = C.hout[2] / m, norm_r = C.hout[3];
+    if (stepped && (!std::isfinite(mu) || !std::isfinite(norm_r) || !std::isfinite(gap))) {
+      iter--;  // the reference leaves the failed step uncounted
+      result = 4;
+      break;
+    }
     res->gap = gap, res->mu = mu, res->pcost = C.hout[1];
     if (iter == 0) {
       mu0 = mu, norm_r0 = norm_r;
@@ -1076,14 +1097,21 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       }
       have_corr = true;
     }
+    // (:604-624) the corrector's own largest step = the smaller of the two blocking ratios
+    // that Mehrotra's step rule needs anyway (:629-646); a second corrector with the safe
+    // sigma when the predictor step or this one is too short.  Without a first corrector
+    // the reference tests the stale d* of the previous iteration; so does this.
+    auto blocking = [&]() -> int {
+      k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+      k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, C.out);
+      HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      return 0;
+    };
+    if ((e = blocking())) return e;
     {
-      // (:604-624) the corrector's own largest step; a second corrector with the safe sigma
-      // when the predictor step or this one is too short.  Without a first corrector the
-      // reference tests the stale d* of the previous iteration; the test is skipped then
-      // only in the very first iteration, where they hold the cold start's step.
-      k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-      if ((e = C.reduce(ops3, 1))) return e;
-      const double alpha_corr = std::fmax(0.0, std::fmin(std::fmin(1.0, C.hout[0]), 1.0));
+      const double amin = std::fmin(C.hout[1] < 0 ? 1e300 : C.hout[0], C.hout[7] < 0 ? 1e300 : C.hout[6]);
+      const double alpha_corr = std::fmax(0.0, std::fmin(std::fmin(1.0, amin), 1.0));
       if (alpha_aff < 0.1 || alpha_corr < gamma * gamma / 2.0 / m / m) {
         sigma = gamma / (1.0 - gamma);
         smm = sigma * mu;
@@ -1093,14 +1121,11 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
           (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
           return e;
         }
+        if ((e = blocking())) return e;
       }
       (void)have_corr;
     }
     // Mehrotra's adaptive step size (:629-672)
-    k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, C.out);
-    HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
     const double zmin = C.hout[0], wmin = C.hout[6];
     const int izmin = (int)C.hout[1], iwmin = (int)C.hout[7];
     const double z_iz = C.hout[2], dz_iz = C.hout[3], w_iz = C.hout[4], dw_iz = C.hout[5];
@@ -1129,14 +1154,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     }
     res->alpha = alpha;
     k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
-    const int ops5[IP_SLOTS] = {IP_SUM, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-    if ((e = C.reduce(ops5, 2))) return e;
-    const double mu_new = C.hout[0] / m;
-    if (!std::isfinite(mu_new) || !std::isfinite(C.hout[1])) {  // :684-690
-      result = 4;
-      break;
-    }
+    // (:684-690: a non-finite mu or x ends the solve as degenerate; seen here by the next
+    // pass through k_ip_rhs, whose sums and maximum carry the NaN / inf)
     iter++;
+    stepped = true;
     if (result == 3 || result == 4) break;  // set by the blow-up test above
     if (iter >= o.max_iters) break;         // :716
   }

@@ -861,17 +861,29 @@ int dn;
 // wavefront factors the block in LDS (full symmetric image, so interchanges are
 // plain row + column swaps) and ~18 nodes are resident per CU.  Same pivoting
 // rules, same outputs as k_factor_diag.
+//
+// FRONT = true: the whole front of a "small front" (also at most FS_MAXB border rows):
+// the same wavefront first gathers the children's update blocks (extend-add, children
+// in slot order as k_extend_add does), and after the pivot block it does the panel
+// solve X = A21 P' M', L21 = X D^-1 and the update U = (gathered) - L21 X' - five
+// launches per tree level become one.
 #define FS_MAXP 32
 #define FS_LD 33
+#define FS_MAXB 16
+template <bool FRONT>
 __global__ void __launch_bounds__(64)
 k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
                     double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
                     const signed char *__restrict__ esign, double *__restrict__ linv,
                     const long long *__restrict__ linv_off, double alpha, double pivot_eps,
-                    const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
+                    const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters,
+                    double *__restrict__ upd, double *__restrict__ xar) {
   __shared__ double a[FS_MAXP * FS_LD];
   __shared__ double dv[2 * FS_MAXP];
   __shared__ int lp[FS_MAXP], pt[FS_MAXP];
+  // FRONT: border rows of the pivot columns (later L21), X, the update block
+  __shared__ double s21[FRONT ? FS_MAXB * FS_MAXP : 1], xs[FRONT ? FS_MAXB * FS_MAXP : 1],
+      ub[FRONT ? FS_MAXB * FS_MAXB : 1];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
@@ -883,6 +895,32 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   for (int j = h; j < p; j += 2)
     if (row_on) a[i + j * FS_LD] = (i >= j) ? P[(long long)j * F + i] : P[(long long)i * F + j];
   if (lane < p) lp[lane] = lane;
+  if constexpr (FRONT) {
+    for (int t = lane; t < b * p; t += 64) s21[(t % b) + FS_MAXB * (t / b)] = P[(long long)(t / b) * F + p + t % b];
+    for (int t = lane; t < FS_MAXB * FS_MAXB; t += 64) ub[t] = 0.0;
+    __syncthreads();
+    for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+      const int ch = T.child_idx[cc], bc = T.nbor[ch];
+      const int *rel = T.rel + T.bptr[ch];
+      const double *Uc = upd + T.upd_off[ch];
+      for (int j = 0; j < bc; j++) {
+        const int rj = rel[j];
+        for (int ii = j + lane; ii < bc; ii += 64) {
+          const int ri = rel[ii];
+          const double v = Uc[(long long)j * bc + ii];
+          if (rj >= p)
+            ub[(ri - p) + FS_MAXB * (rj - p)] += v;
+          else if (ri >= p)
+            s21[(ri - p) + FS_MAXB * rj] += v;
+          else {
+            a[ri + rj * FS_LD] += v;
+            if (ri != rj) a[rj + ri * FS_LD] += v;  // the image is the full symmetric matrix
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
   __syncthreads();
   int k = 0;
   while (k < p) {
@@ -1057,6 +1095,126 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
     double *W = linv + linv_off[node];  // p x p, column-major; whole diagonal blocks + below
     for (int j = h; j < p; j += 2)
       if (row_on && i >= (j & ~(DB - 1))) W[(long long)j * p + i] = a[i + j * FS_LD];
+  }
+  if constexpr (FRONT) {
+    if (b > 0) {
+      // x(r,c) = sum_{t <= c} s21(r, lp[t]) M(c,t)
+      for (int t = lane; t < b * p; t += 64) {
+        const int r = t % b, c2 = t / b;
+        double acc = 0.0;
+        for (int u = 0; u <= c2; u++) acc = fma(s21[r + FS_MAXB * lp[u]], a[c2 + u * FS_LD], acc);
+        xs[r + FS_MAXB * c2] = acc;
+      }
+      __syncthreads();
+      // L21 = X D^-1 (over s21, which is no longer needed), both to memory
+      double *X = xar + T.x_off[node];
+      for (int t = lane; t < b * p; t += 64) {
+        const int r = t % b, c2 = t / b, ty = pt[c2];
+        const double xv = xs[r + FS_MAXB * c2];
+        const int kp = ty == 2 ? c2 - 1 : min(c2 + 1, p - 1);
+        const double l = ty == 0 ? xv * dv[2 * c2] : xv * dv[2 * c2] + xs[r + FS_MAXB * kp] * dv[2 * c2 + 1];
+        X[(long long)c2 * b + r] = xv;
+        P[(long long)c2 * F + p + r] = l;
+        s21[r + FS_MAXB * c2] = l;
+      }
+      __syncthreads();
+      double *U = upd + T.upd_off[node];
+      for (int t = lane; t < b * b; t += 64) {
+        const int r = t % b, c2 = t / b;
+        if (r < c2) continue;
+        double acc = ub[r + FS_MAXB * c2];
+        for (int u = 0; u < p; u++) acc = fma(-s21[r + FS_MAXB * u], xs[c2 + FS_MAXB * u], acc);
+        U[(long long)c2 * b + r] = acc;
+      }
+    }
+  }
+}
+
+// ---- tree solves of the small fronts: one wavefront per supernode does what the
+// A and B kernels below do for the general fronts (two launches per level, not four)
+__global__ void __launch_bounds__(64)
+k_solve_fwd_small(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
+                  const double *__restrict__ linv, const long long *__restrict__ linv_off,
+                  const double *__restrict__ dinv, const int *__restrict__ ptype,
+                  const int *__restrict__ lperm, const double *__restrict__ rhs, double *__restrict__ xsol,
+                  double *__restrict__ ytmp, double *__restrict__ cb) {
+  __shared__ double t1[FS_MAXP], tp[FS_MAXP], y[FS_MAXP], cbs[FS_MAXB];
+  const int node = level_nodes[blockIdx.x];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const long long F = p + b;
+  const int e0 = T.piv_start[node];
+  const double *P = panel + T.panel_off[node];
+  const double *W = linv + linv_off[node];
+  const int lane = threadIdx.x;
+  int lpk = 0, pty = 0;
+  double pd0 = 0.0, pd1 = 0.0;
+  if (lane < p) {
+    lpk = lperm[e0 + lane], pty = ptype[e0 + lane];
+    pd0 = dinv[2 * (e0 + lane)], pd1 = dinv[2 * (e0 + lane) + 1];
+    t1[lane] = rhs[e0 + lane];
+  }
+  if (lane < b) cbs[lane] = 0.0;
+  __syncthreads();
+  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+    const int ch = T.child_idx[cc], bc = T.nbor[ch];
+    const int *rel = T.rel + T.bptr[ch];
+    const double *cbc = cb + T.cb_off[ch];
+    for (int ii = lane; ii < bc; ii += 64) {
+      const int ri = rel[ii];
+      if (ri < p)
+        t1[ri] += cbc[ii];
+      else
+        cbs[ri - p] += cbc[ii];
+    }
+    __syncthreads();
+  }
+  if (lane < p) tp[lane] = t1[lpk];
+  __syncthreads();
+  if (lane < p) {  // y = M tp
+    double acc = 0.0;
+    for (int t = 0; t <= lane; t++) acc = fma(W[(long long)t * p + lane], tp[t], acc);
+    y[lane] = acc;
+  }
+  __syncthreads();
+  if (lane < p) {
+    const int kp = pty == 2 ? lane - 1 : min(lane + 1, p - 1);
+    xsol[e0 + lane] = pty == 0 ? y[lane] * pd0 : y[lane] * pd0 + y[kp] * pd1;
+    ytmp[e0 + lane] = y[lane];
+  }
+  if (lane < b) {  // contribution -= L21 y
+    double acc = cbs[lane];
+    for (int c2 = 0; c2 < p; c2++) acc = fma(-P[(long long)c2 * F + p + lane], y[c2], acc);
+    cb[T.cb_off[node] + lane] = acc;
+  }
+}
+
+__global__ void __launch_bounds__(64)
+k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
+                  const double *__restrict__ linv, const long long *__restrict__ linv_off,
+                  const int *__restrict__ lperm, double *__restrict__ xsol) {
+  __shared__ double x2[FS_MAXB], v[FS_MAXP];
+  const int node = level_nodes[blockIdx.x];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const long long F = p + b;
+  const int e0 = T.piv_start[node];
+  const double *P = panel + T.panel_off[node];
+  const double *W = linv + linv_off[node];
+  const int *bi = T.bidx + T.bptr[node];
+  const int lane = threadIdx.x;
+  if (lane < b) x2[lane] = xsol[bi[lane]];
+  __syncthreads();
+  int lpk = 0;
+  if (lane < p) {  // v = yd - L21' x(border)
+    lpk = lperm[e0 + lane];
+    double acc = xsol[e0 + lane];
+    for (int r = 0; r < b; r++) acc = fma(-P[(long long)lane * F + p + r], x2[r], acc);
+    v[lane] = acc;
+  }
+  __syncthreads();
+  if (lane < p) {  // z = M' v, x1 = P' z
+    double acc = 0.0;
+    for (int r = lane; r < p; r++) acc = fma(W[(long long)lane * p + r], v[r], acc);
+    xsol[e0 + lpk] = acc;
   }
 }
 

@@ -72,7 +72,9 @@ typedef struct hqpkkt_opts {
                         ~3 % more fill), 0 = band order as it comes (better when
                         the x variables carry weak diagonals, e.g. DOCP states),
                         1 = behind all x variables of the node (~10 % more fill)  */
-  int reserved[4];
+  int no_small_fronts; /* 1 = do not use the fused one-wavefront kernels for fronts with
+                        <= 32 pivots and <= 16 border rows (tests: both paths must agree) */
+  int reserved[3];
 } hqpkkt_opts;
 
 typedef struct hqpkkt_stats {

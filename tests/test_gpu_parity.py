@@ -286,3 +286,27 @@ def test_slack_order_policies_agree():
     assert rel_err(sols[1], sols[0]) < 1e-9 and rel_err(sols[2], sols[0]) < 1e-9
     assert slow[2] <= slow[0] and slow[1] <= slow[0]  # behind-its-x orders avoid the interchanges
     assert slow[0] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_fused_small_fronts_agree_with_the_general_kernels(kind):
+    """Fronts with <= 32 pivots and <= 16 border rows go through one-wavefront kernels that
+    fuse extend-add, pivot block, panel and update (and the two solve kernels of a sweep);
+    hqpkkt_opts.no_small_fronts sends them through the general kernels instead.  Same
+    factorisation: same pivots, solutions equal to rounding."""
+    cls = ipmatrix.IpSpBKP if kind == "SpBKP" else ipmatrix.IpRedSpBKP
+    for prog, spread in ((problems.did_like_qp(400), 0.0), (problems.did_like_qp(400), 4.0),
+                         (problems.banded_qp(500, 3, 8), 1.0)):
+        st = problems.ip_state(prog, 5, spread)
+        sol, piv = [], []
+        for sf in (False, True):
+            M = cls(small_fronts=sf)
+            M.init(prog)
+            M.factor(prog, st[0], st[1])
+            d = new_d(prog)
+            M.step(prog, *st, *d)
+            sol.append(d)
+            piv.append((M.stats()["n_2x2"], M.stats()["n_perturbed"]))
+        assert piv[0] == piv[1]
+        assert rel_err(sol[1], sol[0]) < 1e-9
