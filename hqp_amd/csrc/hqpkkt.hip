@@ -186,6 +186,7 @@ struct hqpkkt {
     }
   } gfactor[2], gstep[2][3];  // [phase], [caller's / refinement's vectors][phase]
   bool use_graphs = true, capturing = false;
+  bool short_rows = false;  // CSR rows of a handful of entries: 4 lanes per row in the SpMV kernels
   void drop_graphs() {
     for (auto &g : gfactor) g.drop();
     for (auto &gs : gstep)
@@ -321,6 +322,11 @@ static int upload(hqpkkt_t *h) {
                              (int)h->lds_panel));
   HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize,
                              (int)h->lds_bwdb));
+  {
+    const double rows = 2.0 * n + me + m;  // Q, A', C' per x row; A, C rows
+    const double nnz = (double)an.Qfull.col.size() + 2.0 * an.A.col.size() + 2.0 * an.C.col.size();
+    h->short_rows = rows > 0 && nnz / rows < 8.0;
+  }
   h->st.bytes_panels = (long long)sizeof(double) * (an.panel_elems + an.x_elems);
   h->st.bytes_updates = (long long)sizeof(double) * an.upd_elems;
   h->uploaded = true;
@@ -613,9 +619,14 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
   const int n = an.n, me = an.me, m = an.m;
   double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
   HIPCHK(hipMemsetAsync(h->bits.p + 1, 0, sizeof(unsigned long long), s));
-  KLAUNCH(h, KC_RESIDUAL, k_residual<<<std::min(nblk(16LL * ((long long)n + me + m)), 4096), 256, 0, s>>>(
-      n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
-      v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
+  if (h->short_rows)
+    KLAUNCH(h, KC_RESIDUAL, k_residual<4><<<std::min(nblk(4LL * ((long long)n + me + m)), 4096), 256, 0, s>>>(
+        n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
+        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
+  else
+    KLAUNCH(h, KC_RESIDUAL, k_residual<16><<<std::min(nblk(16LL * ((long long)n + me + m)), 4096), 256, 0, s>>>(
+        n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
+        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
   unsigned long long bits = 0;
   HIPCHK(hipMemcpyAsync(&bits, h->bits.p + 1, sizeof(bits), hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
@@ -1026,9 +1037,14 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   bool stepped = false;
   while (true) {
     // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
-    k_ip_rhs<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                       h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
-                                       C.part);
+    if (h->short_rows)
+      k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                            h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
+                                            C.part);
+    else
+      k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                             h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
+                                             C.part);
     if (m == 0) {  // equality-constrained QP: one Newton step (:364-413)
       if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
         if (e == HQPKKT_E_SING) return finish(4);

@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(256) k_ip_final(const double *__restrict__ par
 // quantities of the convergence test:
 //   r1 = Qx + c - A'y - C'z, r2 = -(Ax + b), r3 = -(Cx + d - w), r4 = -z.*w
 //   slots: 0 gap = x'(Qx+c) + y'b + z'd, 1 pcost, 2 z'w, 3 max(|r1|,|r2|,|r3|), 4 min z, 5 min w
+template <int LPR>
 __global__ void __launch_bounds__(256)
 k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev C,
          const double *__restrict__ vals, const double *__restrict__ c, const double *__restrict__ b,
@@ -55,14 +56,15 @@ k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev 
          double *__restrict__ r2, double *__restrict__ r3, double *__restrict__ r4,
          double *__restrict__ part) {
   __shared__ double red[4];
-  const int sub = threadIdx.x & 15;
+  const int sub = threadIdx.x & (LPR - 1);
+  constexpr int RPB = 256 / LPR;
   const int total = n + me + m;
   double gap = 0.0, pc = 0.0, zw = 0.0, nr = 0.0, zmin = 1e300, wmin = 1e300;
-  for (int q = blockIdx.x * 16 + (threadIdx.x >> 4); q < total; q += gridDim.x * 16) {
+  for (int q = blockIdx.x * RPB + threadIdx.x / LPR; q < total; q += gridDim.x * RPB) {
     if (q < n) {
-      const double qx = row_dot16(Q, vals, x, q, sub);
+      const double qx = row_dot<LPR>(Q, vals, x, q, sub);
       const double g = qx + c[q];
-      const double s = g - row_dot16(AT, vals, y, q, sub) - row_dot16(CT, vals, z, q, sub);
+      const double s = g - row_dot<LPR>(AT, vals, y, q, sub) - row_dot<LPR>(CT, vals, z, q, sub);
       if (sub == 0) {
         r1[q] = s;
         gap += x[q] * g, pc += x[q] * (0.5 * qx + c[q]);
@@ -70,7 +72,7 @@ k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev 
       }
     } else if (q < n + me) {
       const int i = q - n;
-      const double s = -(row_dot16(A, vals, x, i, sub) + b[i]);
+      const double s = -(row_dot<LPR>(A, vals, x, i, sub) + b[i]);
       if (sub == 0) {
         r2[i] = s;
         gap += y[i] * b[i];
@@ -78,7 +80,7 @@ k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev 
       }
     } else {
       const int j = q - n - me;
-      const double s = -(row_dot16(C, vals, x, j, sub) + d[j] - w[j]);
+      const double s = -(row_dot<LPR>(C, vals, x, j, sub) + d[j] - w[j]);
       if (sub == 0) {
         r3[j] = s, r4[j] = -(z[j] * w[j]);
         gap += z[j] * d[j], zw += z[j] * w[j];

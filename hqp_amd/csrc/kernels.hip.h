@@ -1767,20 +1767,28 @@ __global__ void k_red_dzdw(int m, const int *__restrict__ Cp, const int *__restr
 struct CsrDev {
   const int *ptr, *col, *src;
 };
-__device__ __forceinline__ double row16_sum(double v) {
+// sum over the LPR (16 or 4) consecutive lanes that share a CSR row
+template <int LPR>
+__device__ __forceinline__ double row_sum(double v) {
   v += dpp_move<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
   v += dpp_move<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
-  v += dpp_move<0x124, 0xf>(v);  // row_ror 4
-  v += dpp_move<0x128, 0xf>(v);  // row_ror 8 -> every lane of the row holds the sum
+  if (LPR == 16) {
+    v += dpp_move<0x124, 0xf>(v);  // row_ror 4
+    v += dpp_move<0x128, 0xf>(v);  // row_ror 8 -> every lane of the row holds the sum
+  }
   return v;
 }
-__device__ __forceinline__ double row_dot16(const CsrDev M, const double *__restrict__ vals,
-                                            const double *__restrict__ x, int row, int sub) {
+template <int LPR>
+__device__ __forceinline__ double row_dot(const CsrDev M, const double *__restrict__ vals,
+                                          const double *__restrict__ x, int row, int sub) {
   double s = 0.0;
   const int e = M.ptr[row + 1];
-  for (int k = M.ptr[row] + sub; k < e; k += 16) s += vals[M.src[k]] * x[M.col[k]];
-  return row16_sum(s);
+  for (int k = M.ptr[row] + sub; k < e; k += LPR) s += vals[M.src[k]] * x[M.col[k]];
+  return row_sum<LPR>(s);
 }
+// LPR lanes per CSR row: 16 for the banded systems, 4 when the rows hold a handful of
+// entries (DOCP / Prg_DID matrices: 1-3 per row)
+template <int LPR>
 __global__ void __launch_bounds__(256)
 k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev C,
            const double *__restrict__ vals, const double *__restrict__ z,
@@ -1792,25 +1800,26 @@ k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDe
            double *__restrict__ o3, double *__restrict__ o4,
            unsigned long long *__restrict__ resbits) {
   __shared__ double red[4];
-  const int sub = threadIdx.x & 15;
+  const int sub = threadIdx.x & (LPR - 1);
   const int total = n + me + m;
   double mag = 0.0;
-  for (int q = blockIdx.x * 16 + (threadIdx.x >> 4); q < total; q += gridDim.x * 16) {
+  constexpr int RPB = 256 / LPR;  // rows per block and trip
+  for (int q = blockIdx.x * RPB + threadIdx.x / LPR; q < total; q += gridDim.x * RPB) {
     if (q < n) {
-      double s = row_dot16(Q, vals, dx, q, sub);
-      s += -1.0 * row_dot16(AT, vals, dy, q, sub);
-      s += -1.0 * row_dot16(CT, vals, dz, q, sub);
+      double s = row_dot<LPR>(Q, vals, dx, q, sub);
+      s += -1.0 * row_dot<LPR>(AT, vals, dy, q, sub);
+      s += -1.0 * row_dot<LPR>(CT, vals, dz, q, sub);
       s = r1[q] + s;
       if (sub == 0) o1[q] = s;
       mag = fmax(mag, fabs(s) == fabs(s) ? fabs(s) : __longlong_as_double(0x7ff0000000000000LL));
     } else if (q < n + me) {
       const int i = q - n;
-      const double s = r2[i] - row_dot16(A, vals, dx, i, sub);
+      const double s = r2[i] - row_dot<LPR>(A, vals, dx, i, sub);
       if (sub == 0) o2[i] = s;
       mag = fmax(mag, fabs(s) == fabs(s) ? fabs(s) : __longlong_as_double(0x7ff0000000000000LL));
     } else {
       const int j = q - n - me;
-      const double cdx = row_dot16(C, vals, dx, j, sub);
+      const double cdx = row_dot<LPR>(C, vals, dx, j, sub);
       const double s3 = r3[j] - (cdx - dw[j]);
       const double s4 = r4[j] - (z[j] * dw[j] + w[j] * dz[j]);
       if (sub == 0) o3[j] = s3, o4[j] = s4;
