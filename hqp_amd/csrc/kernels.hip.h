@@ -1375,7 +1375,7 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
     for (int y = 0; y < 2; y++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
-        const int i = i0 + 16 * x + lk + 4 * rg, j = j0 + 16 * y + lr;
+        const int i = i0 + 16 * x + lr, j = j0 + 16 * y + lk + 4 * rg;
         uold[x][y][rg] = (i < b && j < b && i >= j) ? U[(long long)j * b + i] : 0.0;
       }
   // eight k-steps (32 pivots) per trip: all operand loads of the trip are in flight
@@ -1394,10 +1394,12 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       if (k0 + 4 * q < p) {  // wave-uniform
-        acc[0][0] = mfma_f64(a0[q], b0[q], acc[0][0]);
-        acc[0][1] = mfma_f64(a0[q], b1[q], acc[0][1]);
-        acc[1][0] = mfma_f64(a1[q], b0[q], acc[1][0]);
-        acc[1][1] = mfma_f64(a1[q], b1[q], acc[1][1]);
+        // D = X-tile * L-tile': the accumulator holds U(i,j) with i along the lanes, so that
+        // the read-modify-write of U below moves 128-byte segments
+        acc[0][0] = mfma_f64(b0[q], a0[q], acc[0][0]);
+        acc[0][1] = mfma_f64(b1[q], a0[q], acc[0][1]);
+        acc[1][0] = mfma_f64(b0[q], a1[q], acc[1][0]);
+        acc[1][1] = mfma_f64(b1[q], a1[q], acc[1][1]);
       }
     }
   }
@@ -1407,7 +1409,7 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
     for (int y = 0; y < 2; y++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
-        const int i = i0 + 16 * x + lk + 4 * rg, j = j0 + 16 * y + lr;
+        const int i = i0 + 16 * x + lr, j = j0 + 16 * y + lk + 4 * rg;
         if (i < b && j < b && i >= j) U[(long long)j * b + i] = uold[x][y][rg] - acc[x][y][rg];
       }
 }
