@@ -13,12 +13,33 @@
 #include <cstring>
 #include <numeric>
 
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+static std::chrono::steady_clock::time_point g_t0;
+#define TMARK(x) do { if (getenv("HQPKKT_TIMING")) { auto t=std::chrono::steady_clock::now(); fprintf(stderr, "phase before %s: %.2f s\n", x, std::chrono::duration<double>(t-g_t0).count()); g_t0=t; } } while(0)
 namespace kktdev {
 namespace {
 
 struct LevelItem {
   int node, deg, deg2;
 };
+
+// stable LSD radix sort of (key, payload) pairs by key, 16 bits per pass: the entry
+// lists of dense stage blocks hold 10^7..10^8 items
+static void radix_sort_pairs(std::vector<std::pair<long long, int>> &v) {
+  if (v.size() < 2) return;
+  long long mx = 0;
+  for (auto &e : v) mx = std::max(mx, e.first);
+  std::vector<std::pair<long long, int>> tmp(v.size());
+  for (int shift = 0; shift < 64 && (mx >> shift) > 0; shift += 16) {
+    std::vector<size_t> cnt(65537, 0);
+    for (auto &e : v) cnt[((e.first >> shift) & 0xffff) + 1]++;
+    for (int d = 0; d < 65536; d++) cnt[d + 1] += cnt[d];
+    for (auto &e : v) tmp[cnt[(e.first >> shift) & 0xffff]++] = e;
+    v.swap(tmp);
+  }
+}
 
 // Reverse Cuthill-McKee exactly as the reference runs it: the start node of
 // each component is the first unnumbered node; the level structure is rebuilt
@@ -137,6 +158,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   if (max_pivots <= 0 || max_pivots > 128) max_pivots = 128;
   if (leaf_size <= 0) leaf_size = 0;  // decided below from sbw
 
+  TMARK("0");
   // ---------------------------------------------------------- SpMV blocks
   {
     std::vector<std::vector<std::pair<int, int>>> rows(n);
@@ -169,8 +191,10 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     transpose(C, n, CT);
   }
 
+  TMARK("1");
   // ------------------------------------------------------------- entries
   std::vector<RawEntry> raw;
+  raw.reserve((size_t)nq + na + (mode == 0 ? (size_t)nc + m : 4 * (size_t)nc));
   auto add = [&](int a, int b, Term t) {
     int lo = std::min(a, b), hi = std::max(a, b);
     raw.push_back({(long long)lo * dim + hi, lo, hi, t});
@@ -191,22 +215,32 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
         for (int b = Cp[r]; b <= a; b++)
           add(Ci[a], Ci[b], {nq + na + a, nq + na + b, r, -1.0});
   }
-  std::stable_sort(raw.begin(), raw.end(),
-                   [](const RawEntry &x, const RawEntry &y) { return x.key < y.key; });
-  ent_a.clear(), ent_b.clear(), term_ptr.assign(1, 0), terms.clear();
-  for (size_t k = 0; k < raw.size(); k++) {
-    if (k == 0 || raw[k].key != raw[k - 1].key) {
-      if (k) term_ptr.push_back((int)terms.size());
-      ent_a.push_back(raw[k].a), ent_b.push_back(raw[k].b);
+  // entries with the same (row, col) are merged into one entry with several terms; the
+  // order is (key, order of generation).  Sorting (key, index) pairs instead of the
+  // 48-byte records keeps this phase short for the 10^7..10^8 entries of dense stage blocks.
+  {
+    std::vector<std::pair<long long, int>> order(raw.size());
+    for (size_t k = 0; k < raw.size(); k++) order[k] = {raw[k].key, (int)k};
+    radix_sort_pairs(order);
+    ent_a.clear(), ent_b.clear(), term_ptr.assign(1, 0), terms.clear();
+    ent_a.reserve(raw.size()), ent_b.reserve(raw.size()), terms.reserve(raw.size());
+    for (size_t k = 0; k < order.size(); k++) {
+      const RawEntry &r = raw[order[k].second];
+      if (k == 0 || order[k].first != order[k - 1].first) {
+        if (k) term_ptr.push_back((int)terms.size());
+        ent_a.push_back(r.a), ent_b.push_back(r.b);
+      }
+      terms.push_back(r.t);
     }
-    terms.push_back(raw[k].t);
+    term_ptr.push_back((int)terms.size());
   }
-  term_ptr.push_back((int)terms.size());
+  { std::vector<RawEntry>().swap(raw); }
   const int nent = (int)ent_a.size();
   diag_ent.assign(n, -1);
   for (int e = 0; e < nent; e++)
     if (ent_a[e] == ent_b[e] && ent_a[e] < n) diag_ent[ent_a[e]] = e;
 
+  TMARK("2");
   // ---------------------------------------------------------- RCM graph
   // neighbour lists in the reference's visiting order: x-x couplings row by
   // row (upper triangle), then the rows of A, then the rows of C
@@ -240,6 +274,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     sbw = std::max(sbw, far - qp2j[v]);
   }
 
+  TMARK("3");
   // ------------------------------------------- nested dissection of the band
   // Logical nodes: leaves = the still unassigned positions of an interval of the
   // band order, inner nodes = vertex separators.  Cutting the interval at `mid`,
@@ -510,6 +545,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
   }
 
+  TMARK("4");
   // chains of supernodes: each logical node is cut into pieces of <= max_pivots
   // pivots; a partner pair is never cut with the zero-diagonal variable first
   std::vector<std::vector<int>> nverts;
@@ -559,6 +595,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   for (int id = 0; id < nnodes; id++)
     for (int k = 0; k < npiv[id]; k++) owner[piv_start[id] + k] = id;
 
+  TMARK("5");
   // ------------------------------------------------------ symbolic fronts
   ent_er.resize(nent), ent_ec.resize(nent);
   std::vector<std::vector<int>> node_hi(nnodes);
@@ -620,6 +657,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
   }
 
+  TMARK("6");
   // ------------------------------------------- shard plan (one system, P ranks)
   // The top of the assembly tree is replicated on every rank, the subtrees below
   // it are dealt to the ranks: walk down from the roots, always opening the
@@ -680,6 +718,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
         if (node_owner[id] == q && parent[id] >= 0) xroots.push_back(id);
   }
 
+  TMARK("7");
   // --------------------------------------------------- storage + schedules
   panel_off.assign(nnodes, 0), upd_off.assign(nnodes, 0), x_off.assign(nnodes, 0);
   cb_off.assign(nnodes, 0);
@@ -820,6 +859,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     if (!xroots.empty()) push(zero_upd, upd_x_off + shard_rank * upd_x_slot, upd_x_slot);
   }
 
+  TMARK("8");
   // ------------------------------------------------------- assembly map
   ent_dst.resize(nent);
   for (int e = 0; e < nent; e++) {
@@ -838,8 +878,12 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   // (mostly) consecutive addresses from consecutive threads
   {
     std::vector<int> perm(nent);
-    std::iota(perm.begin(), perm.end(), 0);
-    std::sort(perm.begin(), perm.end(), [&](int x, int y) { return ent_dst[x] < ent_dst[y]; });
+    {
+      std::vector<std::pair<long long, int>> order(nent);  // destinations are distinct
+      for (int k = 0; k < nent; k++) order[k] = {ent_dst[k], k};
+      radix_sort_pairs(order);
+      for (int k = 0; k < nent; k++) perm[k] = order[k].second;
+    }
     auto apply_i = [&](std::vector<int> &v) {
       std::vector<int> t(nent);
       for (int k = 0; k < nent; k++) t[k] = v[perm[k]];
