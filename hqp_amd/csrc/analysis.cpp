@@ -728,10 +728,43 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   nlevels = 0;
   std::vector<char> is_xroot(nnodes, 0);
   for (int id : xroots) is_xroot[id] = 1;
+  // Update blocks: by default every supernode keeps its own b x b block for the whole
+  // factorisation (one memset, nothing to manage).  When that would take more than
+  // upd_pingpong_bytes, the blocks of a tree level live only until the next level has
+  // consumed them: levels are re-assigned "as late as possible" (every child exactly one
+  // level below its parent) and the blocks of even / odd levels alternate between two
+  // halves of the arena, each as large as its fullest level.
+  upd_pingpong = false;
+  {
+    long long tot = 0;
+    for (int id = 0; id < nnodes; id++) tot += (long long)nbor[id] * nbor[id];
+    upd_pingpong = shard_count <= 1 && upd_pingpong_bytes > 0 && 8 * tot > upd_pingpong_bytes;
+  }
+  if (upd_pingpong) {
+    for (int id = nnodes - 1; id >= 0; id--)
+      if (parent[id] >= 0) level[id] = level[parent[id]] - 1;
+  }
+  upd_level_off.clear(), upd_level_len.clear();
+  std::vector<long long> lvl_fill;
+  if (upd_pingpong) {
+    int nl = 0;
+    for (int id = 0; id < nnodes; id++) nl = std::max(nl, level[id] + 1);
+    std::vector<long long> used(nl, 0);
+    for (int id = 0; id < nnodes; id++) used[level[id]] += (long long)nbor[id] * nbor[id];
+    long long cap[2] = {0, 0};
+    for (int l = 0; l < nl; l++) cap[l & 1] = std::max(cap[l & 1], used[l]);
+    upd_level_off.assign(nl, 0), upd_level_len = used;
+    for (int l = 0; l < nl; l++) upd_level_off[l] = (l & 1) ? cap[0] : 0;
+    lvl_fill = upd_level_off;
+    upd_elems = cap[0] + cap[1];
+  }
   for (int id = 0; id < nnodes; id++) {
     const long long p = npiv[id], b = nbor[id], F = p + b;
     panel_off[id] = panel_elems, panel_elems += F * p;
-    if (!is_xroot[id]) {
+    if (upd_pingpong) {
+      upd_off[id] = lvl_fill[level[id]], lvl_fill[level[id]] += b * b;
+      cb_off[id] = cb_elems, cb_elems += b;
+    } else if (!is_xroot[id]) {
       upd_off[id] = upd_elems, upd_elems += b * b;
       cb_off[id] = cb_elems, cb_elems += b;
     }

@@ -60,6 +60,9 @@ struct Analysis {
 
   // --- one system sharded over several ranks ----------------------
   int shard_rank = 0, shard_count = 1;
+  long long upd_pingpong_bytes = 16LL << 30;  // update blocks beyond this: two alternating half-arenas
+  bool upd_pingpong = false;
+  std::vector<long long> upd_level_off, upd_level_len;  // ping-pong: the range a level's blocks occupy
   bool small_fronts = true;  // fused one-wavefront kernels for fronts with few pivots and few border rows
   int slack_policy = 2;  // FULL mode, slack rows inside a node: 0 band order, 1 behind all x, 2 behind their own x
   std::vector<int> node_owner;  // owning rank per supernode, -1 = replicated top of the tree

@@ -396,7 +396,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
   if (phases & 1) {
     if (an.shard_count <= 1) {
       HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, s));
-      if (an.upd_elems) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
+      if (an.upd_elems && !an.upd_pingpong) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
     } else {  // only the blocks this rank writes
       const int np = (int)an.zero_panel.size() / 2, nu = (int)an.zero_upd.size() / 2;
       if (np) k_zero_ranges<<<dim3(512, np), 256, 0, s>>>(h->panel.p, h->zero_panel.p);
@@ -422,6 +422,8 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
     const hqpkkt::DevSched &D = h->ds[which];
     if (S.nnodes == 0) continue;
     for (int l = 0; l < an.nlevels; l++) {
+      if (an.upd_pingpong && an.upd_level_len[l] > 0)  // this level's update blocks reuse the half-arena of level l-2
+        HIPCHK(hipMemsetAsync(h->upd.p + an.upd_level_off[l], 0, sizeof(double) * an.upd_level_len[l], s));
       for (int seg = S.ea_level_ptr[l]; seg < S.ea_level_ptr[l + 1]; seg++) {
         int cnt = S.ea_seg_ptr[seg + 1] - S.ea_seg_ptr[seg];
         if (cnt <= 0) continue;
@@ -713,6 +715,8 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
   h->an.slack_policy = h->opts.slack_policy;
   h->an.small_fronts = !h->opts.no_small_fronts;
+  if (h->opts.upd_pingpong_mb > 0) h->an.upd_pingpong_bytes = (long long)h->opts.upd_pingpong_mb << 20;
+  if (h->opts.upd_pingpong_mb < 0) h->an.upd_pingpong_bytes = 0;
   int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
                     h->opts.max_pivots, h->opts.zd_policy);
   if (e) return e;

@@ -74,7 +74,11 @@ typedef struct hqpkkt_opts {
                         1 = behind all x variables of the node (~10 % more fill)  */
   int no_small_fronts; /* 1 = do not use the fused one-wavefront kernels for fronts with
                         <= 32 pivots and <= 16 border rows (tests: both paths must agree) */
-  int reserved[3];
+  int upd_pingpong_mb; /* update blocks (b x b per supernode) beyond this many MB are not kept for
+                        the whole factorisation: tree levels are re-assigned as late as possible
+                        and the blocks of even / odd levels alternate between two half-arenas
+                        (0 = default 16384, < 0 = never)                                      */
+  int reserved[2];
 } hqpkkt_opts;
 
 typedef struct hqpkkt_stats {

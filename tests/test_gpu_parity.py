@@ -310,3 +310,32 @@ def test_fused_small_fronts_agree_with_the_general_kernels(kind):
             piv.append((M.stats()["n_2x2"], M.stats()["n_perturbed"]))
         assert piv[0] == piv[1]
         assert rel_err(sol[1], sol[0]) < 1e-9
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", ["banded", "random", "did"])
+def test_pingpong_update_arena_agrees(case):
+    """Large systems do not keep every supernode's update block for the whole
+    factorisation (hqpkkt_opts.upd_pingpong_mb): levels as late as possible, two
+    alternating half-arenas.  Forced here on small systems: same solution, less memory."""
+    prog = {"banded": lambda: problems.banded_qp(6000, 60, 2),
+            "random": lambda: problems.random_sparse_qp(1500, 700, 1500, 4, 5),
+            "did": lambda: problems.did_like_qp(500)}[case]()
+    st = problems.ip_state(prog, 5, 1.0)
+    sols, mem = [], []
+    for mb in (-1, 1):
+        M = ipmatrix.IpSpBKP(upd_pingpong_mb=mb)
+        M.init(prog)
+        M.factor(prog, st[0], st[1])
+        d = new_d(prog)
+        res = M.solve(prog, *st, *d)
+        assert res <= 1e-10
+        sols.append(d)
+        mem.append(M.stats()["bytes_updates"])
+    assert rel_err(sols[1], sols[0]) < 1e-9
+    # a chain (RCM of a random sparse system) keeps two blocks instead of all of them; a
+    # balanced tree still holds its two fullest levels
+    if case == "random":
+        assert mem[1] < 0.25 * mem[0]
+    elif case == "banded":
+        assert mem[1] < 0.8 * mem[0]
