@@ -5,6 +5,7 @@ O=gpurun_out/prof; rm -rf $O; mkdir -p $O
 python bench.py --steps 20 --warmup 3 2>/dev/null | grep '^{' | tail -1 > $O/r01_bench.json
 python bench.py --steps 20 --warmup 3 --host-vectors --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/r01_bench_hostptr.json
 python bench.py --steps 20 --warmup 3 --mode RedSpBKP --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/r01_bench_redspbkp.json
+python bench.py --n 400000 --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/r01_bench_n1e6.json
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 20 --warmup 3 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/r01_bench_under_rocprof.json
 cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/r01_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
