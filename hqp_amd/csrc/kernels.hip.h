@@ -354,10 +354,10 @@ __device__ __forceinline__ double bcast_lane(double v, int src) {
 // HI: the pivots are rows >= 64 (the caller never lets a panel straddle row 64);
 // rows 0..63 are eliminated already and only rows 64.. are updated.
 // Returns the number of pivots done; the panel columns (unscaled) go back to Pc,
-// the multipliers to Pl.  `sink` is LDS scratch for the masked-out stores.
+// the multipliers to Pl.
 template <bool TWO, bool HI>
 __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb, int lane, double alpha,
-                                          double pert, double *dv, int *pt, double *sink) {
+                                          double pert, double *dv, int *pt) {
   // one quarter of the rank-1 update that is still pending from the previous pivot
   // (columns j0, j0+4, ... of the panel): issued between the dependent steps of the
   // current pivot's reciprocal
@@ -374,6 +374,7 @@ __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb,
     R1[j] = TWO ? Pc[lane + 64 + FD_PLD * j] : 0.0;
   }
   int done = kb;        // pivots in front of the first one that failed the test (uniform)
+  double mydi = 0.0;
   double cp[FD_PANEL];  // the previous pivot's row (broadcast through SGPRs) and multipliers
   double lp0 = 0.0, lp1 = 0.0;
 #pragma unroll
@@ -415,11 +416,7 @@ __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb,
     }
     Pl[lane + FD_PLD * kk] = l0;
     Pl[lane + 64 + FD_PLD * kk] = l1;
-    {  // every lane stores the same values; masked-out pivots go to the sink
-      double *dvp = act ? dv + 2 * kc : sink;
-      int *ptp = act ? pt + kc : (int *)(sink + 2);
-      dvp[0] = di, dvp[1] = 0.0, *ptp = 0;
-    }
+    mydi = (lane == kk) ? di : mydi;  // lane kk keeps the inverse pivot until the panel is done
     lp0 = l0, lp1 = l1;
 #pragma unroll
     for (int j = kk + 2; j < FD_PANEL; j++) cp[j] = c[j];
@@ -430,6 +427,7 @@ __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb,
     if (!HI) Pc[lane + FD_PLD * j] = R0[j];
     if (TWO) Pc[lane + 64 + FD_PLD * j] = R1[j];
   }
+  if (lane < done) dv[2 * (k + lane)] = mydi, dv[2 * (k + lane) + 1] = 0.0, pt[k + lane] = 0;
 #undef PW_PENDING
   return done;
 }
@@ -544,11 +542,11 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
       if (wave == 0) {
 int dn;
         if (p <= 64)
-          dn = panel_wave<false, false>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt, xb0);
+          dn = panel_wave<false, false>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt);
         else if (k < 64)
-          dn = panel_wave<true, false>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt, xb0);
+          dn = panel_wave<true, false>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt);
         else
-          dn = panel_wave<true, true>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt, xb0);
+          dn = panel_wave<true, true>(Pc, Pl, k, kb, lane, alpha, pert, dv, pt);
         if (lane == 0) *pdone = dn;
       }
       STAMP(3 + 4 * npan);
