@@ -658,6 +658,20 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   }
 
   TMARK("6");
+  // inverse of `rel`, per child: position in the parent's front -> position in the child's
+  // border (or -1).  The consumers of a front (pivot block, panel solve, Schur update)
+  // pull the children's update blocks through it - there is no extend-add pass.
+  pinv_off.assign(nnodes, 0);
+  {
+    long long tot = 0;
+    for (int id = 0; id < nnodes; id++)
+      if (parent[id] >= 0) pinv_off[id] = tot, tot += npiv[parent[id]] + nbor[parent[id]];
+    pinv.assign(tot, -1);
+    for (int id = 0; id < nnodes; id++)
+      if (parent[id] >= 0)
+        for (long long t = bptr[id]; t < bptr[id + 1]; t++) pinv[pinv_off[id] + rel[t]] = (int)(t - bptr[id]);
+  }
+
   // ------------------------------------------- shard plan (one system, P ranks)
   // The top of the assembly tree is replicated on every rank, the subtrees below
   // it are dealt to the ranks: walk down from the roots, always opening the

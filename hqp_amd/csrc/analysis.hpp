@@ -37,6 +37,8 @@ struct Analysis {
   std::vector<long long> bptr;  // border_ptr, size nnodes+1
   std::vector<int> bidx;        // border rows (elimination indices), sorted per node
   std::vector<int> rel;         // same indexing as bidx: local index in the parent front
+  std::vector<int> pinv;        // per child: parent front index -> index in the child's border, -1 if none
+  std::vector<long long> pinv_off;
   std::vector<long long> panel_off, upd_off, x_off;  // element offsets into the arenas
   long long panel_elems = 0, upd_elems = 0, x_elems = 0, cb_elems = 0;
   std::vector<long long> cb_off;  // contribution-vector offsets (solve)

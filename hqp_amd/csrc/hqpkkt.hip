@@ -144,7 +144,7 @@ struct hqpkkt {
 
   // symbolic structure on the device
   DBuf<int> piv_start, npiv, nbor, parent, bidx, rel, child_ptr, child_idx, ent_a, ent_b,
-      term_ptr, diag_ent, q2e;
+      term_ptr, diag_ent, q2e, pinv;
   struct DevSched {  // device copy of an Analysis::Sched
     DBuf<int> level_nodes, ea_nodes, upd_tiles, slabs, gslabs, cblks;
     void release() {
@@ -158,7 +158,7 @@ struct hqpkkt {
   int shard_rank = 0, shard_count = 1;
   hqpkkt_exchange_fn xchg_fn = nullptr;
   void *xchg_ctx = nullptr;
-  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, linv_off;
+  DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, linv_off, pinv_off;
   DBuf<TermDev> terms;
   DBuf<signed char> esign;
   CsrBuf Qf, A, AT, C, CT;
@@ -195,14 +195,14 @@ struct hqpkkt {
 
   DevTree tree() const {
     return DevTree{piv_start.p, npiv.p,     nbor.p,  parent.p, bptr.p,      bidx.p,     rel.p,
-                   panel_off.p, upd_off.p, x_off.p, cb_off.p, child_ptr.p, child_idx.p};
+                   panel_off.p, upd_off.p, x_off.p, cb_off.p, child_ptr.p, child_idx.p, pinv.p, pinv_off.p};
   }
   void release_device() {
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
-                       &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &ptype, &lperm, &flags};
+                       &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags};
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release();
-    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off,
+    DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off, &pinv_off,
                              &zero_panel, &zero_upd};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
@@ -262,6 +262,8 @@ static int upload(hqpkkt_t *h) {
   UP(zero_upd, zero_upd);
   UP(keep_e, keep_e);
   UP(linv_off, linv_off);
+  UP(pinv, pinv);
+  UP(pinv_off, pinv_off);
   UP(ent_a, ent_a);
   UP(ent_b, ent_b);
   UP(term_ptr, term_ptr);
@@ -396,11 +398,9 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
   if (phases & 1) {
     if (an.shard_count <= 1) {
       HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, s));
-      if (an.upd_elems && !an.upd_pingpong) HIPCHK(hipMemsetAsync(h->upd.p, 0, sizeof(double) * an.upd_elems, s));
     } else {  // only the blocks this rank writes
-      const int np = (int)an.zero_panel.size() / 2, nu = (int)an.zero_upd.size() / 2;
+      const int np = (int)an.zero_panel.size() / 2;
       if (np) k_zero_ranges<<<dim3(512, np), 256, 0, s>>>(h->panel.p, h->zero_panel.p);
-      if (nu) k_zero_ranges<<<dim3(512, nu), 256, 0, s>>>(h->upd.p, h->zero_upd.p);
     }
     HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 64, s));
     HIPCHK(hipMemsetAsync(h->bits.p, 0, sizeof(unsigned long long) * 2, s));
@@ -422,15 +422,6 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
     const hqpkkt::DevSched &D = h->ds[which];
     if (S.nnodes == 0) continue;
     for (int l = 0; l < an.nlevels; l++) {
-      if (an.upd_pingpong && an.upd_level_len[l] > 0)  // this level's update blocks reuse the half-arena of level l-2
-        HIPCHK(hipMemsetAsync(h->upd.p + an.upd_level_off[l], 0, sizeof(double) * an.upd_level_len[l], s));
-      for (int seg = S.ea_level_ptr[l]; seg < S.ea_level_ptr[l + 1]; seg++) {
-        int cnt = S.ea_seg_ptr[seg + 1] - S.ea_seg_ptr[seg];
-        if (cnt <= 0) continue;
-        int ysplit = std::max(1, std::min(512, 8192 / cnt));  // few children: one column per workgroup
-        KLAUNCH(h, KC_EXTEND_ADD, k_extend_add<<<dim3(cnt, ysplit), 256, 0, s>>>(T, D.ea_nodes.p + S.ea_seg_ptr[seg],
-                                                       h->panel.p, h->upd.p));
-      }
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l], nsm = S.level_small[l];
       if (nfs > 0)  // small fronts: extend-add, pivot block, panel and update in one kernel
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<true><<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
@@ -443,12 +434,12 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
       if (nn > nfs + nsm)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nfs - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                                 h->flags.p + 1));
+                                                 h->flags.p + 1, h->upd.p));
       const int ns = S.slab_ptr[l + 1] - S.slab_ptr[l];
       if (ns > 0)
         KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, D.slabs.p + 2 * (size_t)S.slab_ptr[l],
                                                     h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
-                                                    h->lperm.p, h->linv.p, h->linv_off.p));
+                                                    h->lperm.p, h->linv.p, h->linv_off.p, h->upd.p));
       const int nt = S.upd_tile_ptr[l + 1] - S.upd_tile_ptr[l];
       if (nt > 0)
         KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_tile_ptr[l],

@@ -28,7 +28,23 @@ struct DevTree {
   const int *bidx, *rel;
   const long long *panel_off, *upd_off, *x_off, *cb_off;
   const int *child_ptr, *child_idx;
+  const int *pinv;            // per child: parent front index -> child border index (-1: none)
+  const long long *pinv_off;
 };
+
+// Sum of the children's update blocks at front position (fi, fj), fi >= fj, of `node`:
+// what an extend-add pass would have added to that entry (children in slot order).
+__device__ __forceinline__ double gather_children(const DevTree &T, const double *__restrict__ upd, int node,
+                                                  int fi, int fj) {
+  double s = 0.0;
+  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+    const int c = T.child_idx[cc];
+    const int *iv = T.pinv + T.pinv_off[c];
+    const int ci = iv[fi], cj = iv[fj];
+    if (ci >= 0 && cj >= 0) s += upd[T.upd_off[c] + (long long)cj * T.nbor[c] + ci];
+  }
+  return s;
+}
 
 // order-preserving max for non-negative doubles through their bit pattern
 __device__ __forceinline__ void atomic_max_pos(unsigned long long *addr, double v) {
@@ -231,7 +247,8 @@ __global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
 // thread (up to 16 columns x 2 row halves) are in flight together - one memory
 // latency
 __device__ __forceinline__ void stage_lower8(const double *__restrict__ P, long long F, int p, int ld,
-                                             double *a, int wave, int lane) {
+                                             double *a, int wave, int lane, const DevTree &T,
+                                             const double *__restrict__ upd, int node) {
   double v[16][2];
 #pragma unroll
   for (int u = 0; u < 16; u++) {
@@ -241,6 +258,27 @@ __device__ __forceinline__ void stage_lower8(const double *__restrict__ P, long 
       const int i = lane + 64 * h;
       v[u][h] = (j < p && i < p && i >= j) ? P[(long long)j * F + i] : 0.0;
     }
+  }
+  // + the children's update blocks (pulled through the inverse maps, slot order)
+  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+    const int c = T.child_idx[cc], bc = T.nbor[c];
+    const int *iv = T.pinv + T.pinv_off[c];
+    const double *Uc = upd + T.upd_off[c];
+    int ci[2], cj[16];
+#pragma unroll
+    for (int h = 0; h < 2; h++) ci[h] = (lane + 64 * h < p) ? iv[lane + 64 * h] : -1;
+#pragma unroll
+    for (int u = 0; u < 16; u++) cj[u] = (wave + 8 * u < p) ? iv[wave + 8 * u] : -1;
+    double g[16][2];
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+#pragma unroll
+      for (int h = 0; h < 2; h++)
+        g[u][h] = (ci[h] >= 0 && cj[u] >= 0 && lane + 64 * h >= wave + 8 * u) ? Uc[(long long)cj[u] * bc + ci[h]] : 0.0;
+#pragma unroll
+    for (int u = 0; u < 16; u++)
+#pragma unroll
+      for (int h = 0; h < 2; h++) v[u][h] += g[u][h];
   }
 #pragma unroll
   for (int u = 0; u < 16; u++) {
@@ -475,7 +513,8 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
               double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
               const signed char *__restrict__ esign, double *__restrict__ linv,
               const long long *__restrict__ linv_off, double alpha, double pivot_eps,
-              const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters) {
+              const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters,
+              const double *__restrict__ upd) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
@@ -499,7 +538,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
 
   STAMP(0);
-  stage_lower8(P, F, p, ld, a, wave, lane);
+  stage_lower8(P, F, p, ld, a, wave, lane, T, upd, node);
   for (int i = tid; i < p; i += blockDim.x) lp[i] = i;
   __syncthreads();
   PatchT A;
@@ -893,6 +932,11 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   for (int j = h; j < p; j += 2)
     if (row_on) a[i + j * FS_LD] = (i >= j) ? P[(long long)j * F + i] : P[(long long)i * F + j];
   if (lane < p) lp[lane] = lane;
+  if constexpr (!FRONT) {  // pivot block += children's update blocks (pulled; the border parts are
+                           // pulled by the panel solve and the Schur update)
+    for (int j = h; j < p; j += 2)
+      if (row_on) a[i + j * FS_LD] += gather_children(T, upd, node, max(i, j), min(i, j));
+  }
   if constexpr (FRONT) {
     for (int t = lane; t < b * p; t += 64) s21[(t % b) + FS_MAXB * (t / b)] = P[(long long)(t / b) * F + p + t % b];
     for (int t = lane; t < FS_MAXB * FS_MAXB; t += 64) ub[t] = 0.0;
@@ -1231,7 +1275,8 @@ __global__ void __launch_bounds__(256)
 k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ panel,
               double *__restrict__ xar, const double *__restrict__ dinv,
               const int *__restrict__ ptype, const int *__restrict__ lperm,
-              const double *__restrict__ linv, const long long *__restrict__ linv_off) {
+              const double *__restrict__ linv, const long long *__restrict__ linv_off,
+              const double *__restrict__ upd) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
   const int node = slabs[2 * blockIdx.x], slab = slabs[2 * blockIdx.x + 1];
   const int p = T.npiv[node], b = T.nbor[node];
@@ -1266,6 +1311,21 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
     for (int u = 0; u < 16; u++) {
       const int kcol = g + 8 * u;
       v[u] = (live && kcol < p) ? P[(long long)lc[u] * F + p + r0 + r] : 0.0;
+    }
+    // + the children's update blocks at (border row, pivot column)
+    for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+      const int c = T.child_idx[cc], bc = T.nbor[c];
+      const int *iv = T.pinv + T.pinv_off[c];
+      const double *Uc = upd + T.upd_off[c];
+      const int ci = live ? iv[p + r0 + r] : -1;
+      int cj[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) cj[u] = (g + 8 * u < p) ? iv[lc[u]] : -1;
+      double gv[16];
+#pragma unroll
+      for (int u = 0; u < 16; u++) gv[u] = (ci >= 0 && cj[u] >= 0) ? Uc[(long long)cj[u] * bc + ci] : 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u++) v[u] += gv[u];
     }
 #pragma unroll
     for (int u = 0; u < 16; u++) {
@@ -1365,17 +1425,42 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
 #pragma unroll
     for (int y = 0; y < 2; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
   const int ia = i0 + lr, ib = i0 + 16 + lr, ja = j0 + lr, jb = j0 + 16 + lr;
-  // the old values of this wave's part of U travel while the products run
+  // the children's contributions to this wave's part of U (there is no extend-add pass and
+  // U is not pre-zeroed: this kernel writes every entry once) travel while the products run
   double uold[2][2][4];
 #pragma unroll
   for (int x = 0; x < 2; x++)
 #pragma unroll
     for (int y = 0; y < 2; y++)
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int i = i0 + 16 * x + lr, j = j0 + 16 * y + lk + 4 * rg;
-        uold[x][y][rg] = (i < b && j < b && i >= j) ? U[(long long)j * b + i] : 0.0;
-      }
+      for (int rg = 0; rg < 4; rg++) uold[x][y][rg] = 0.0;
+  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+    const int c = T.child_idx[cc], bc = T.nbor[c];
+    const int *iv = T.pinv + T.pinv_off[c] + p;  // border part of the parent's front
+    const double *Uc = upd + T.upd_off[c];
+    int ci[2], cj[2][4];  // this lane's two rows and eight columns in the child's numbering
+#pragma unroll
+    for (int x = 0; x < 2; x++) ci[x] = (i0 + 16 * x + lr < b) ? iv[i0 + 16 * x + lr] : -1;
+#pragma unroll
+    for (int y = 0; y < 2; y++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) cj[y][rg] = (j0 + 16 * y + lk + 4 * rg < b) ? iv[j0 + 16 * y + lk + 4 * rg] : -1;
+    double gv[2][2][4];
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+      for (int y = 0; y < 2; y++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+          gv[x][y][rg] = (ci[x] >= 0 && cj[y][rg] >= 0 && ci[x] >= cj[y][rg])
+                             ? Uc[(long long)cj[y][rg] * bc + ci[x]] : 0.0;
+#pragma unroll
+    for (int x = 0; x < 2; x++)
+#pragma unroll
+      for (int y = 0; y < 2; y++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) uold[x][y][rg] += gv[x][y][rg];
+  }
   // eight k-steps (32 pivots) per trip: all operand loads of the trip are in flight
   // together, so a trip costs one memory latency instead of eight
   for (int k0 = 0; k0 < p; k0 += 32) {
