@@ -49,8 +49,8 @@ def class_work(struct, rank=None):
         "factor_diag": {"flops": float((2 * p ** 3 / 3.0).sum()), "bytes": float((8 * 2 * p * p).sum())},
         # X = A21 P' M' (b p^2) ; reads A21 and M, writes X and L21
         "panel_solve": {"flops": float((b * p * p).sum()), "bytes": float((8 * (3 * b * p + p * p / 2)).sum())},
+        # U = (children's blocks, pulled) - L21 X': reads L21, X and the children's entries, writes U once
         "schur_update": {"flops": float((b * b * p).sum()), "bytes": float((8 * (2 * b * p + b * b)).sum())},
-        "extend_add": {"flops": float((b * b / 2).sum()), "bytes": float((8 * 1.5 * b * b).sum())},
         # one sweep over the factor: M (lower) and L21 are streamed once
         "solve_fwd": {"flops": float((p * p + 2 * b * p).sum()), "bytes": float((8 * (p * p / 2 + b * p)).sum())},
         "solve_bwd": {"flops": float((p * p + 2 * b * p).sum()), "bytes": float((8 * (p * p / 2 + b * p)).sum())},
@@ -233,7 +233,7 @@ def main():
                        "frac_fp64_peak": w["flops"] / (per_step[k] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS if per_step.get(k) else None,
                        "frac_hbm_peak": w["bytes"] / (per_step[k] * 1e-3) / 1e9 / HBM_PEAK_GBS if per_step.get(k) else None}
                    for k, w in work.items()}
-        dom = max(("factor_diag", "panel_solve", "schur_update", "extend_add"), key=lambda k: per_step.get(k, 0.0))
+        dom = max(("factor_diag", "panel_solve", "schur_update"), key=lambda k: per_step.get(k, 0.0))
         dom_ms = per_step[dom]
         dom_launch_ms = dom_ms / max(launches[dom], 1.0)
         flops_per_launch = work[dom]["flops"] / max(launches[dom], 1.0)
@@ -250,7 +250,7 @@ def main():
                     "algorithmic_flops_per_step": work[dom]["flops"]}
         # SURVEY.md 8(d) band model of the whole factorisation, for reference
         N, beta = st["dim"], st["sbw"]
-        fac_ms = sum(per_step.get(k, 0.0) for k in ("extend_add", "factor_diag", "panel_solve", "schur_update"))
+        fac_ms = sum(per_step.get(k, 0.0) for k in ("factor_diag", "panel_solve", "schur_update"))
         model = {"flops_band_model": float(N) * beta * beta, "factor_ms": fac_ms,
                  "tflops_band_model": float(N) * beta * beta / (fac_ms * 1e-3) / 1e12 if fac_ms > 0 else None,
                  "tflops_as_implemented": st["flops_factor"] / (fac_ms * 1e-3) / 1e12 if fac_ms > 0 else None}

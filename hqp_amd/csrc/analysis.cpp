@@ -844,25 +844,6 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       for (int id = 0; id < nnodes; id++)
         if (keep(id) && npiv[id] > SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
     }
-    // extend-add segments: for parent level l, slot s -> children list (the small
-    // fronts gather their children themselves)
-    S.ea_level_ptr.assign(nlevels + 1, 0);
-    S.ea_seg_ptr.assign(1, 0);
-    for (int l = 0; l < nlevels; l++) {
-      int maxslots = 0;
-      for (int t = S.level_ptr[l] + S.level_fsmall[l]; t < S.level_ptr[l + 1]; t++) {
-        int id = S.level_nodes[t];
-        maxslots = std::max(maxslots, child_ptr[id + 1] - child_ptr[id]);
-      }
-      for (int s = 0; s < maxslots; s++) {
-        for (int t = S.level_ptr[l] + S.level_fsmall[l]; t < S.level_ptr[l + 1]; t++) {
-          int id = S.level_nodes[t];
-          if (child_ptr[id + 1] - child_ptr[id] > s) S.ea_nodes.push_back(child_idx[child_ptr[id] + s]);
-        }
-        S.ea_seg_ptr.push_back((int)S.ea_nodes.size());
-      }
-      S.ea_level_ptr[l + 1] = (int)S.ea_seg_ptr.size() - 1;
-    }
     S.upd_tile_ptr.assign(nlevels + 1, 0), S.slab_ptr.assign(nlevels + 1, 0);
     S.gslab_ptr.assign(nlevels + 1, 0), S.cblk_ptr.assign(nlevels + 1, 0);
     for (int l = 0; l < nlevels; l++) {
@@ -884,7 +865,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   }
   // arena ranges this rank writes (zeroed at the start of every factorisation)
   // and the solution entries it contributes to the all-reduce of a sharded solve
-  zero_panel.clear(), zero_upd.clear();
+  zero_panel.clear();
   keep_e.assign(dim, 0);
   {
     auto push = [](std::vector<long long> &v, long long off, long long len) {
@@ -899,11 +880,9 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       if (!mine && !top) continue;
       const long long p = npiv[id], b = nbor[id];
       push(zero_panel, panel_off[id], (p + b) * p);
-      if (!is_xroot[id]) push(zero_upd, upd_off[id], b * b);
       if (mine || shard_rank == 0)
         for (int k = 0; k < p; k++) keep_e[piv_start[id] + k] = 1;
     }
-    if (!xroots.empty()) push(zero_upd, upd_x_off + shard_rank * upd_x_slot, upd_x_slot);
   }
 
   TMARK("8");

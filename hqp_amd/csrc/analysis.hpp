@@ -50,8 +50,6 @@ struct Analysis {
     std::vector<int> level_ptr, level_nodes;  // nodes grouped by level
     std::vector<int> level_fsmall;            // per level: leading nodes that are small fronts
     std::vector<int> level_small;             // per level: the following nodes with npiv <= SMALL_PIVOTS
-    // children grouped by (parent level, slot) for deterministic extend-add
-    std::vector<int> ea_seg_ptr, ea_nodes, ea_level_ptr;  // segments per level
     // tiles of the Schur update and slabs of the panel solve, grouped by level
     std::vector<int> upd_tile_ptr, upd_tiles;  // triples (node, ti, tj)
     std::vector<int> slab_ptr, slabs;          // pairs (node, slab): 32 border rows
@@ -71,7 +69,7 @@ struct Analysis {
   std::vector<int> xroots;      // subtree roots whose update / contribution blocks are exchanged
   long long upd_x_off = 0, upd_x_slot = 0;  // exchange region of the update arena: shard_count slots
   long long cb_x_off = 0, cb_x_slot = 0;    // same for the solve's contribution vectors
-  std::vector<long long> zero_panel, zero_upd;  // (offset, length) pairs this rank clears per factor
+  std::vector<long long> zero_panel;  // (offset, length) pairs this rank clears per factor
   std::vector<signed char> keep_e;  // per elimination index: this rank contributes it to the all-reduce
   std::vector<long long> linv_off;             // explicit inverses of the L11 blocks, p x p each
   long long linv_elems = 0;

@@ -75,9 +75,9 @@ struct CsrBuf {
 
 // per-kernel-class device timing (hqpkkt_set_profile): HIP events on the
 // handle's stream around every launch, summed per class after the call
-enum { KC_ASSEMBLE = 0, KC_EXTEND_ADD, KC_FACTOR_DIAG, KC_PANEL_SOLVE, KC_SCHUR_UPDATE,
+enum { KC_ASSEMBLE = 0, KC_FACTOR_DIAG, KC_PANEL_SOLVE, KC_SCHUR_UPDATE,
        KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_COUNT };
-static const char *const kc_names[KC_COUNT] = {"assemble", "extend_add", "factor_diag", "panel_solve",
+static const char *const kc_names[KC_COUNT] = {"assemble", "factor_diag", "panel_solve",
                                                "schur_update", "solve_fwd", "solve_bwd", "vector",
                                                "residual"};
 struct Prof {
@@ -146,13 +146,13 @@ struct hqpkkt {
   DBuf<int> piv_start, npiv, nbor, parent, bidx, rel, child_ptr, child_idx, ent_a, ent_b,
       term_ptr, diag_ent, q2e, pinv;
   struct DevSched {  // device copy of an Analysis::Sched
-    DBuf<int> level_nodes, ea_nodes, upd_tiles, slabs, gslabs, cblks;
+    DBuf<int> level_nodes, upd_tiles, slabs, gslabs, cblks;
     void release() {
-      level_nodes.release(), ea_nodes.release(), upd_tiles.release(), slabs.release();
+      level_nodes.release(), upd_tiles.release(), slabs.release();
       gslabs.release(), cblks.release();
     }
   } ds[2];
-  DBuf<long long> zero_panel, zero_upd;  // (offset, length) pairs, sharded mode
+  DBuf<long long> zero_panel;  // (offset, length) pairs, sharded mode
   DBuf<signed char> keep_e;
   // one system over several ranks: collectives are delegated to the caller
   int shard_rank = 0, shard_count = 1;
@@ -203,7 +203,7 @@ struct hqpkkt {
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release();
     DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off, &pinv_off,
-                             &zero_panel, &zero_upd};
+                             &zero_panel};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
                           &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &ipv};
@@ -252,14 +252,12 @@ static int upload(hqpkkt_t *h) {
   UP(child_idx, child_idx);
   for (int w = 0; w < 2; w++) {
     UP(ds[w].level_nodes, sched[w].level_nodes);
-    UP(ds[w].ea_nodes, sched[w].ea_nodes);
     UP(ds[w].upd_tiles, sched[w].upd_tiles);
     UP(ds[w].slabs, sched[w].slabs);
     UP(ds[w].gslabs, sched[w].gslabs);
     UP(ds[w].cblks, sched[w].cblks);
   }
   UP(zero_panel, zero_panel);
-  UP(zero_upd, zero_upd);
   UP(keep_e, keep_e);
   UP(linv_off, linv_off);
   UP(pinv, pinv);

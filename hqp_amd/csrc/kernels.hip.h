@@ -190,32 +190,6 @@ k_scatter(int nent, const int *__restrict__ ent_a, const int *__restrict__ ent_b
   }
 }
 
-// ------------------------------------------------------------- extend-add
-// child update matrix -> parent front (panel columns or parent update block)
-__global__ void k_extend_add(DevTree T, const int *__restrict__ seg_nodes,
-                             double *__restrict__ panel, double *__restrict__ upd) {
-  const int c = seg_nodes[blockIdx.x];
-  const int q = T.parent[c];
-  const int b = T.nbor[c];
-  const int pq = T.npiv[q], bq = T.nbor[q];
-  const long long Fq = pq + bq;
-  const int *rel = T.rel + T.bptr[c];
-  const double *U = upd + T.upd_off[c];
-  double *Pq = panel + T.panel_off[q];
-  double *Uq = upd + T.upd_off[q];
-  for (int j = blockIdx.y; j < b; j += gridDim.y) {
-    const int rj = rel[j];
-    for (int i = j + threadIdx.x; i < b; i += blockDim.x) {
-      const int ri = rel[i];
-      const double v = U[(long long)j * b + i];
-      if (rj < pq)
-        Pq[(long long)rj * Fq + ri] += v;
-      else
-        Uq[(long long)(rj - pq) * bq + (ri - pq)] += v;
-    }
-  }
-}
-
 // ------------------------------------------------- pivot block: dense BK LDL'
 // k_factor_diag: one workgroup of 512 threads per supernode.  The p x p pivot
 // block (p <= 128) lives in REGISTERS as a full symmetric matrix: thread
@@ -901,7 +875,7 @@ int dn;
 //
 // FRONT = true: the whole front of a "small front" (also at most FS_MAXB border rows):
 // the same wavefront first gathers the children's update blocks (extend-add, children
-// in slot order as k_extend_add does), and after the pivot block it does the panel
+// in slot order), and after the pivot block it does the panel
 // solve X = A21 P' M', L21 = X D^-1 and the update U = (gathered) - L21 X' - five
 // launches per tree level become one.
 #define FS_MAXP 32
