@@ -908,8 +908,16 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   if (lane < p) lp[lane] = lane;
   if constexpr (!FRONT) {  // pivot block += children's update blocks (pulled; the border parts are
                            // pulled by the panel solve and the Schur update)
-    for (int j = h; j < p; j += 2)
-      if (row_on) a[i + j * FS_LD] += gather_children(T, upd, node, max(i, j), min(i, j));
+    for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+      const int c = T.child_idx[cc], bc = T.nbor[c];
+      const int *iv = T.pinv + T.pinv_off[c];
+      const double *Uc = upd + T.upd_off[c];
+      const int ci = row_on ? iv[i] : -1;  // this lane's row in the child's numbering
+      for (int j = h; j < p; j += 2) {
+        const int cj = iv[j];
+        if (ci >= 0 && cj >= 0) a[i + j * FS_LD] += Uc[(long long)min(ci, cj) * bc + max(ci, cj)];
+      }
+    }
   }
   if constexpr (FRONT) {
     for (int t = lane; t < b * p; t += 64) s21[(t % b) + FS_MAXB * (t / b)] = P[(long long)(t / b) * F + p + t % b];
