@@ -153,6 +153,7 @@ struct hqpkkt {
     }
   } ds[2];
   DBuf<long long> zero_panel;  // (offset, length) pairs, sharded mode
+  DBuf<int> simple_src, simple_wi;  // FULL: compact single-term records of the entries (k_assemble_simple)
   DBuf<signed char> keep_e;
   // one system over several ranks: collectives are delegated to the caller
   int shard_rank = 0, shard_count = 1;
@@ -201,7 +202,7 @@ struct hqpkkt {
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
                        &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags};
     for (auto b : ib) b->release();
-    ds[0].release(), ds[1].release(), keep_e.release();
+    ds[0].release(), ds[1].release(), keep_e.release(), simple_src.release(), simple_wi.release();
     DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off, &pinv_off,
                              &zero_panel};
     for (auto b : lb) b->release();
@@ -279,6 +280,16 @@ static int upload(hqpkkt_t *h) {
     for (size_t k = 0; k < t.size(); k++)
       t[k] = TermDev{an.terms[k].s1, an.terms[k].s2, an.terms[k].wi, an.terms[k].sgn};
     if ((e = h->terms.upload(t))) return e;
+    // all entries single terms sgn * vals[s1] * wt[wi] with s2 = the constant 1 (FULL plugin)?
+    const int one = an.nq + an.na + an.nc;
+    bool simple = an.mode == 0 && an.terms.size() == an.ent_a.size();
+    for (size_t k = 0; simple && k < t.size(); k++)
+      simple = t[k].s2 == one && (t[k].sgn == 1.0 || t[k].sgn == -1.0);
+    if (simple) {
+      std::vector<int> ss(t.size()), ww(t.size());
+      for (size_t k = 0; k < t.size(); k++) ss[k] = t[k].s1 | (t[k].sgn < 0 ? (int)0x80000000 : 0), ww[k] = t[k].wi;
+      if ((e = h->simple_src.upload(ss)) || (e = h->simple_wi.upload(ww))) return e;
+    }
     // sign a perturbed pivot takes: x rows belong to the -Q block, y / slack rows
     // to the zero / +W/Z blocks
     std::vector<signed char> sg(an.dim);
@@ -405,12 +416,18 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
     if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
     if (m > 0)
       KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
-    KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
-                                              h->ent_val.p));
-    if (an.mode == 1 && an.n > 0)
-      KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
-    KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
-                                         h->sc.p, h->panel.p, h->bits.p));
+    if (h->simple_src.count) {  // FULL: one pass
+      KLAUNCH(h, KC_ASSEMBLE, k_assemble_simple<<<std::min(nblk(nent), 2048), 256, 0, s>>>(
+                                  nent, h->simple_src.p, h->simple_wi.p, h->ent_a.p, h->ent_b.p, h->ent_dst.p,
+                                  h->vals.p, h->wt.p, h->sc.p, h->panel.p, h->bits.p));
+    } else {
+      KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
+                                                h->ent_val.p));
+      if (an.mode == 1 && an.n > 0)
+        KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
+      KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
+                                           h->sc.p, h->panel.p, h->bits.p));
+    }
     if (!h->capturing) HIPCHK(hipEventRecord(h->ev1, s));
   }
   const double alpha = h->opts.tol * 0.6403882032022076;  // tol (1+sqrt 17)/8, hqp/spBKP.C:392

@@ -190,6 +190,33 @@ k_scatter(int nent, const int *__restrict__ ent_a, const int *__restrict__ ent_b
   }
 }
 
+// FULL plugin: every stored entry is a single term sgn * vals[s1] * wt[wi] (an entry of
+// -Q, A or C, or a slack diagonal w/z), so value, scaling and scatter are one pass over a
+// compact record (source index with the sign in its top bit, weight index).
+__global__ void __launch_bounds__(256)
+k_assemble_simple(int nent, const int *__restrict__ src, const int *__restrict__ wi,
+                  const int *__restrict__ ent_a, const int *__restrict__ ent_b,
+                  const long long *__restrict__ ent_dst, const double *__restrict__ vals,
+                  const double *__restrict__ wt, const double *__restrict__ sc, double *__restrict__ panel,
+                  unsigned long long *__restrict__ kmax) {
+  __shared__ double red[4];
+  double mx = 0.0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nent; e += gridDim.x * blockDim.x) {
+    const int sg = src[e];
+    const double raw = vals[sg & 0x7fffffff] * wt[wi[e]];
+    const double v = (sg < 0 ? -raw : raw) * sc[ent_a[e]] * sc[ent_b[e]];
+    panel[ent_dst[e]] = v;
+    mx = fmax(mx, fabs(v));
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (mx > 0.0) atomic_max_pos(kmax, mx);
+  }
+}
+
 // ------------------------------------------------- pivot block: dense BK LDL'
 // k_factor_diag: one workgroup of 512 threads per supernode.  The p x p pivot
 // block (p <= 128) lives in REGISTERS as a full symmetric matrix: thread
