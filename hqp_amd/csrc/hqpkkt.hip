@@ -62,13 +62,15 @@ struct DBuf {
 
 struct CsrBuf {
   DBuf<int> ptr, col, src;
+  DBuf<double> val;  // values in CSR order, refreshed by hqpkkt_set_values
   int upload(const Analysis::Csr &c) {
     int e;
-    if ((e = ptr.upload(c.ptr)) || (e = col.upload(c.col)) || (e = src.upload(c.src))) return e;
+    if ((e = ptr.upload(c.ptr)) || (e = col.upload(c.col)) || (e = src.upload(c.src)) || (e = val.alloc(c.src.size())))
+      return e;
     return 0;
   }
-  CsrDev dev() const { return CsrDev{ptr.p, col.p, src.p}; }
-  void release() { ptr.release(), col.release(), src.release(); }
+  CsrDev dev() const { return CsrDev{ptr.p, col.p, src.p, val.p}; }
+  void release() { ptr.release(), col.release(), src.release(), val.release(); }
 };
 
 }  // namespace
@@ -758,6 +760,9 @@ int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const dou
   if (an.na) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq, Ax, sizeof(double) * an.na, kind, h->stream));
   if (an.nc)
     HIPCHK(hipMemcpyAsync(h->vals.p + an.nq + an.na, Cx, sizeof(double) * an.nc, kind, h->stream));
+  for (CsrBuf *c : {&h->Qf, &h->A, &h->AT, &h->C, &h->CT})
+    if (c->src.count)
+      k_gather_values<<<nblk((long long)c->src.count), 256, 0, h->stream>>>((int)c->src.count, c->src.p, h->vals.p, c->val.p);
   HIPCHK(hipStreamSynchronize(h->stream));
   h->have_values = true;
   h->factored = false;

@@ -1860,7 +1860,13 @@ __global__ void k_red_dzdw(int m, const int *__restrict__ Cp, const int *__restr
 // coalesced index / value loads and add up with DPP row rotations.
 struct CsrDev {
   const int *ptr, *col, *src;
+  const double *val;  // the values in CSR order (gathered through src once per update())
 };
+__global__ void k_gather_values(int nnz, const int *__restrict__ src, const double *__restrict__ vals,
+                                double *__restrict__ out) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k < nnz) out[k] = vals[src[k]];
+}
 // sum over the LPR (16 or 4) consecutive lanes that share a CSR row
 template <int LPR>
 __device__ __forceinline__ double row_sum(double v) {
@@ -1877,7 +1883,7 @@ __device__ __forceinline__ double row_dot(const CsrDev M, const double *__restri
                                           const double *__restrict__ x, int row, int sub) {
   double s = 0.0;
   const int e = M.ptr[row + 1];
-  for (int k = M.ptr[row] + sub; k < e; k += LPR) s += vals[M.src[k]] * x[M.col[k]];
+  for (int k = M.ptr[row] + sub; k < e; k += LPR) s += M.val[k] * x[M.col[k]];
   return row_sum<LPR>(s);
 }
 // LPR lanes per CSR row: 16 for the banded systems, 4 when the rows hold a handful of
