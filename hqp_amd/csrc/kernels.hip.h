@@ -15,6 +15,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <type_traits>
 namespace kktdev {
 
 typedef double double4_t __attribute__((ext_vector_type(4)));
@@ -419,8 +420,9 @@ __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb,
 #pragma unroll
   for (int j = 0; j < FD_PANEL; j++) cp[j] = 0.0;
   double d = bcast_lane(HI ? R1[0] : R0[0], k & 63);
-#pragma unroll
-  for (int kk = 0; kk < FD_PANEL; kk++) {
+  // one pivot; kk is a compile-time constant so that every register index is static
+  auto pivot = [&](auto KK) __attribute__((always_inline)) {
+    constexpr int kk = decltype(KK)::value;
     const int kc = k + kk, src = kc & 63;
     // 1/d: hardware estimate (2^-24) and one cubic step x (1 + e + e^2), e = 1 - d x
     double x = __builtin_amdgcn_rcp(d);
@@ -448,7 +450,7 @@ __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb,
     const bool act = kk < done;  // uniform
     const double l0 = (act & r0) ? R0[kk] * di : 0.0;
     const double l1 = (act & r1) ? R1[kk] * di : 0.0;
-    if (kk + 1 < FD_PANEL) {  // the next diagonal entry first: it starts the next chain
+    if constexpr (kk + 1 < FD_PANEL) {  // the next diagonal entry first: it starts the next chain
       if (!HI) R0[kk + 1] = fma(-l0, c[kk + 1], R0[kk + 1]);
       if (TWO) R1[kk + 1] = fma(-l1, c[kk + 1], R1[kk + 1]);
       d = bcast_lane(HI ? R1[kk + 1] : R0[kk + 1], (kc + 1) & 63);
@@ -460,7 +462,21 @@ __device__ __forceinline__ int panel_wave(double *Pc, double *Pl, int k, int kb,
 #pragma unroll
     for (int j = kk + 2; j < FD_PANEL; j++) cp[j] = c[j];
     __builtin_amdgcn_sched_barrier(0);
+  };
+#define PW4(B)                                                   \
+  pivot(std::integral_constant<int, (B)>()), pivot(std::integral_constant<int, (B) + 1>()), \
+      pivot(std::integral_constant<int, (B) + 2>()), pivot(std::integral_constant<int, (B) + 3>())
+  // groups of four pivots: a group is skipped (uniform branch) once a pivot has failed or the
+  // panel is shorter - after a slow-path pivot the next panel often fails again soon
+  PW4(0);
+  if (done > 3 && kb > 4) {
+    PW4(4);
+    if (done > 7 && kb > 8) {
+      PW4(8);
+      if (done > 11 && kb > 12) PW4(12);
+    }
   }
+#undef PW4
 #pragma unroll
   for (int j = 0; j < FD_PANEL; j++) {
     if (!HI) Pc[lane + FD_PLD * j] = R0[j];
