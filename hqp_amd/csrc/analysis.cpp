@@ -551,8 +551,44 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   std::vector<std::vector<int>> nverts;
   std::vector<int> ltop(nlog, -1);
   std::vector<std::vector<int>> nkids;
+  std::vector<std::vector<int>> lkids(nlog);  // children by logical id
+  for (int id = 0; id < nlog; id++)
+    for (int c : tmp[lorder[id]].kids) lkids[id].push_back(lid[c]);
+  // Narrow bands: a separator holds a handful of rows, and what a tree level costs there is
+  // the latency of its launches, not its arithmetic.  A separator absorbs its child
+  // separators while the merged pivot set still fits a small front: their rows first, each
+  // node's rows in the order settled above, so the elimination order does not change; the
+  // child separators are not coupled with each other, the merged pivot block has explicit
+  // zeros.  The levels above the leaves shrink to a half or a third.
+  std::vector<char> absorbed(nlog, 0);
+  if (amalgamation && small_fronts) {
+    for (int id = nlog - 1; id >= 0; id--) {  // ids are a postorder: parents first this way
+      if (absorbed[id]) continue;
+      for (bool again = true; again;) {
+        again = false;
+        size_t tot = lverts[id].size();
+        bool internal = false;
+        for (int c : lkids[id])
+          if (!lkids[c].empty()) tot += lverts[c].size(), internal = true;
+        if (!internal || tot > (size_t)SMALL_PIVOTS) break;
+        std::vector<int> verts, kids;
+        for (int c : lkids[id]) {
+          if (lkids[c].empty()) {
+            kids.push_back(c);
+            continue;
+          }
+          verts.insert(verts.end(), lverts[c].begin(), lverts[c].end());
+          kids.insert(kids.end(), lkids[c].begin(), lkids[c].end());
+          absorbed[c] = 1;
+        }
+        verts.insert(verts.end(), lverts[id].begin(), lverts[id].end());
+        lverts[id].swap(verts), lkids[id].swap(kids);
+        again = true;
+      }
+    }
+  }
   for (int id = 0; id < nlog; id++) {
-    const Tmp &t = tmp[lorder[id]];
+    if (absorbed[id]) continue;
     const std::vector<int> &v = lverts[id];
     const int len = (int)v.size(), parts = std::max(1, (len + max_pivots - 1) / max_pivots);
     const int size = (len + parts - 1) / parts;
@@ -561,7 +597,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       std::vector<int> piece(v.begin() + s, v.begin() + std::min(s + size, len));
       std::vector<int> kids;
       if (top < 0)
-        for (int c : t.kids) kids.push_back(ltop[lid[c]]);
+        for (int c : lkids[id]) kids.push_back(ltop[c]);
       else
         kids.push_back(top);
       nverts.push_back(std::move(piece));
@@ -843,6 +879,15 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       for (int l = 0; l < nlevels; l++) S.level_small[l] = fill[l] - S.level_ptr[l] - S.level_fsmall[l];
       for (int id = 0; id < nnodes; id++)
         if (keep(id) && npiv[id] > SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
+      S.level_fs_p.assign(nlevels, 1), S.level_fs_b.assign(nlevels, 1), S.level_sm_p.assign(nlevels, 1);
+      for (int id = 0; id < nnodes; id++) {
+        if (!keep(id) || npiv[id] > SMALL_PIVOTS) continue;
+        const int l = level[id];
+        if (fsmall(id))
+          S.level_fs_p[l] = std::max(S.level_fs_p[l], npiv[id]), S.level_fs_b[l] = std::max(S.level_fs_b[l], nbor[id]);
+        else
+          S.level_sm_p[l] = std::max(S.level_sm_p[l], npiv[id]);
+      }
     }
     S.upd_tile_ptr.assign(nlevels + 1, 0), S.slab_ptr.assign(nlevels + 1, 0);
     S.gslab_ptr.assign(nlevels + 1, 0), S.cblk_ptr.assign(nlevels + 1, 0);

@@ -50,6 +50,8 @@ struct Analysis {
     std::vector<int> level_ptr, level_nodes;  // nodes grouped by level
     std::vector<int> level_fsmall;            // per level: leading nodes that are small fronts
     std::vector<int> level_small;             // per level: the following nodes with npiv <= SMALL_PIVOTS
+    std::vector<int> level_fs_p, level_fs_b;  // per level: largest npiv / nbor of its small fronts
+    std::vector<int> level_sm_p;              // per level: largest npiv of the other small supernodes
     // tiles of the Schur update and slabs of the panel solve, grouped by level
     std::vector<int> upd_tile_ptr, upd_tiles;  // triples (node, ti, tj)
     std::vector<int> slab_ptr, slabs;          // pairs (node, slab): 32 border rows
@@ -64,6 +66,7 @@ struct Analysis {
   bool upd_pingpong = false;
   std::vector<long long> upd_level_off, upd_level_len;  // ping-pong: the range a level's blocks occupy
   bool small_fronts = true;  // fused one-wavefront kernels for fronts with few pivots and few border rows
+  bool amalgamation = false;  // separators absorb their child separators while they stay small fronts
   int slack_policy = 2;  // FULL mode, slack rows inside a node: 0 band order, 1 behind all x, 2 behind their own x
   std::vector<int> node_owner;  // owning rank per supernode, -1 = replicated top of the tree
   std::vector<int> xroots;      // subtree roots whose update / contribution blocks are exchanged

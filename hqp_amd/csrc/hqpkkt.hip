@@ -168,7 +168,12 @@ struct hqpkkt {
   // numeric state
   DBuf<double> vals, wt, sc, ent_val, panel, upd, xar, dinv, rhs, xsol, cb, ytmp, vtmp, linv;
   DBuf<int> ptype, lperm, flags;  // flags: [0] status, [1] n_2x2, [2] n_perturbed
-  DBuf<unsigned long long> bits;  // [0] kmax, [1] residual max
+  // [0] kmax, [1] residual max: inside the flags buffer (ints 120..123) so that status and
+  // maxima come back in ONE copy; hpin: pinned host memory those copies land in
+  struct {
+    unsigned long long *p = nullptr;
+  } bits;
+  double *hpin = nullptr;  // 128 doubles: 0..63 status words (as ints), 64.. the IP loop's scalars
   // vectors: staging for host pointers + refinement work vectors
   DBuf<double> vin;   // z w r1 r2 r3 r4
   DBuf<double> vout;  // dx dy dz dw
@@ -189,6 +194,9 @@ struct hqpkkt {
     }
   } gfactor[2], gstep[2][3];  // [phase], [caller's / refinement's vectors][phase]
   bool use_graphs = true, capturing = false;
+  // inside hqpkkt_mehrotra: factor() returns without waiting for its status (read with the
+  // residual of the solve that follows), solve() leaves its result in the stream
+  bool lazy = false, factor_unchecked = false;
   bool short_rows = false;  // CSR rows of a handful of entries: 4 lanes per row in the SpMV kernels
   void drop_graphs() {
     for (auto &g : gfactor) g.drop();
@@ -211,7 +219,8 @@ struct hqpkkt {
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
                           &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &ipv};
     for (auto b : db) b->release();
-    terms.release(), esign.release(), bits.release();
+    terms.release(), esign.release(), bits.p = nullptr;
+    if (hpin) (void)hipHostFree(hpin), hpin = nullptr;
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
     drop_graphs();
     uploaded = have_values = factored = false;
@@ -309,12 +318,14 @@ static int upload(hqpkkt_t *h) {
       (e = h->dinv.alloc(2 * (size_t)dim)) || (e = h->rhs.alloc(dim)) ||
       (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ytmp.alloc(dim)) ||
       (e = h->vtmp.alloc(dim)) || (e = h->linv.alloc(an.linv_elems)) || (e = h->ptype.alloc(dim)) ||
-      (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(64)) || (e = h->bits.alloc(2)) ||
+      (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(128)) ||
       (e = h->vin.alloc(2 * (size_t)m + n + me + 2 * (size_t)m)) ||
       (e = h->vout.alloc((size_t)n + me + 2 * (size_t)m)) ||
       (e = h->vres.alloc((size_t)n + me + 2 * (size_t)m)) ||
       (e = h->vcor.alloc((size_t)n + me + 2 * (size_t)m)) || (e = h->tz.alloc(m)))
     return e;
+  h->bits.p = (unsigned long long *)(h->flags.p + 120);
+  if (!h->hpin) HIPCHK(hipHostMalloc((void **)&h->hpin, sizeof(double) * 128, hipHostMallocDefault));
   {
     std::vector<double> ones(dim, 1.0);
     HIPCHK(hipMemcpy(h->sc.p, ones.data(), sizeof(double) * dim, hipMemcpyHostToDevice));
@@ -413,8 +424,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
       const int np = (int)an.zero_panel.size() / 2;
       if (np) k_zero_ranges<<<dim3(512, np), 256, 0, s>>>(h->panel.p, h->zero_panel.p);
     }
-    HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 64, s));
-    HIPCHK(hipMemsetAsync(h->bits.p, 0, sizeof(unsigned long long) * 2, s));
+    HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 128, s));  // status, counters and the two maxima
     if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
     if (m > 0)
       KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
@@ -440,14 +450,18 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
     if (S.nnodes == 0) continue;
     for (int l = 0; l < an.nlevels; l++) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l], nsm = S.level_small[l];
-      if (nfs > 0)  // small fronts: extend-add, pivot block, panel and update in one kernel
-        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<true><<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
+      if (nfs > 0) {  // small fronts: extend-add, pivot block, panel and update in one kernel
+        const int ldp = S.level_fs_p[l] | 1, ldb = S.level_fs_b[l];
+        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<true><<<nfs, 64, fs_lds_bytes(true, ldp, ldb), s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                                 h->flags.p + 1, h->upd.p, h->xar.p));
-      if (nsm > 0)
-        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<false><<<nsm, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->panel.p,
+                                                 h->flags.p + 1, h->upd.p, h->xar.p, ldp, ldb));
+      }
+      if (nsm > 0) {
+        const int ldp = S.level_sm_p[l] | 1;
+        KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<false><<<nsm, 64, fs_lds_bytes(false, ldp, 1), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                                 h->flags.p + 1, h->upd.p, h->xar.p));
+                                                 h->flags.p + 1, h->upd.p, h->xar.p, ldp, 1));
+      }
       if (nn > nfs + nsm)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nfs - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
@@ -630,19 +644,33 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
   double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
   HIPCHK(hipMemsetAsync(h->bits.p + 1, 0, sizeof(unsigned long long), s));
   if (h->short_rows)
-    KLAUNCH(h, KC_RESIDUAL, k_residual<4><<<std::min(nblk(4LL * ((long long)n + me + m)), 4096), 256, 0, s>>>(
+    KLAUNCH(h, KC_RESIDUAL, k_residual<4><<<std::min(nblk(4LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
         v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
   else
-    KLAUNCH(h, KC_RESIDUAL, k_residual<16><<<std::min(nblk(16LL * ((long long)n + me + m)), 4096), 256, 0, s>>>(
+    KLAUNCH(h, KC_RESIDUAL, k_residual<16><<<std::min(nblk(16LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
         v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
-  unsigned long long bits = 0;
-  HIPCHK(hipMemcpyAsync(&bits, h->bits.p + 1, sizeof(bits), hipMemcpyDeviceToHost, s));
+  // one copy: the residual maximum and the status of the factorisation this solve belongs to
+  const bool check = h->factor_unchecked;
+  int *hs = (int *)h->hpin;
+  HIPCHK(hipMemcpyAsync(hs, h->flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost, s));
   HIPCHK(hipStreamSynchronize(s));
+  int flags[4] = {hs[0], hs[1], hs[2], hs[3]};
+  unsigned long long kb, bits;
+  std::memcpy(&kb, hs + 120, sizeof(kb)), std::memcpy(&bits, hs + 122, sizeof(bits));
   double r;
   std::memcpy(&r, &bits, sizeof(r));
   *res = r;
+  if (check) {
+    h->factor_unchecked = false;
+    std::memcpy(&h->st.kmax, &kb, sizeof(kb));
+    h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
+    if (flags[0] || std::isinf(h->st.kmax)) {
+      h->factored = false;
+      return flags[0] ? flags[0] : HQPKKT_E_SING;
+    }
+  }
   return 0;
 }
 
@@ -723,6 +751,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
   h->an.slack_policy = h->opts.slack_policy;
   h->an.small_fronts = !h->opts.no_small_fronts;
+  h->an.amalgamation = h->opts.amalgamation != 0;
   if (h->opts.upd_pingpong_mb > 0) h->an.upd_pingpong_bytes = (long long)h->opts.upd_pingpong_mb << 20;
   if (h->opts.upd_pingpong_mb < 0) h->an.upd_pingpong_bytes = 0;
   int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
@@ -784,11 +813,15 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventRecord(h->evs1, h->stream));
   }
-  int flags[4] = {0, 0, 0, 0};
-  unsigned long long kb = 0;
-  HIPCHK(hipMemcpyAsync(flags, h->flags.p, sizeof(flags), hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipMemcpyAsync(&kb, h->bits.p, sizeof(kb), hipMemcpyDeviceToHost, h->stream));
+  if (h->lazy) {
+    h->factor_unchecked = true, h->factored = true;
+    return 0;
+  }
+  int *hs = (int *)h->hpin;
+  HIPCHK(hipMemcpyAsync(hs, h->flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  const int flags[4] = {hs[0], hs[1], hs[2], hs[3]};
+  std::memcpy(&h->st.kmax, hs + 120, sizeof(double));
   h->prof.collect();
   if (h->use_graphs && !h->prof.on) {
     h->st.ms_assemble = 0.f;  // inside the replayed graph
@@ -895,9 +928,11 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   }
   HIPCHK(hipEventRecord(h->ev1, s));
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
-  HIPCHK(hipStreamSynchronize(s));
-  h->prof.collect();
-  h->st.ms_solve = elapsed(h->ev0, h->ev1);
+  if (!h->lazy) {
+    HIPCHK(hipStreamSynchronize(s));
+    h->prof.collect();
+    h->st.ms_solve = elapsed(h->ev0, h->ev1);
+  }
   h->st.refine_rounds = rounds;
   if (res_out) *res_out = res;
   if (res != res) return HQPKKT_E_SING;
@@ -913,7 +948,7 @@ struct IpCtx {
   hqpkkt_t *h;
   int n, me, m;
   double *x, *y, *z, *w, *r1, *r2, *r3, *r4, *dxa, *dya, *dza, *dwa, *dx, *dy, *dz, *dw, *c, *b, *d, *part, *out;
-  double hout[16];
+  double *hout;  // pinned (h->hpin + 64)
   int reduce(const int (&ops)[IP_SLOTS], int nout) {
     IpOps o;
     for (int k = 0; k < IP_SLOTS; k++) o.op[k] = ops[k];
@@ -950,11 +985,11 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   HIPCHK(hipSetDevice(h->opts.device));
   hipStream_t s = h->stream;
   const size_t nv = (size_t)n + me + 2 * (size_t)m;
-  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 32;
+  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64;
   int e;
   if (h->ipv.count < need && (e = h->ipv.alloc(need))) return e;
   IpCtx C;
-  C.h = h, C.n = n, C.me = me, C.m = m;
+  C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
   double *q = h->ipv.p;
   auto take = [&](size_t k) { double *r = q; q += k; return r; };
   C.x = take(n), C.y = take(me), C.z = take(m), C.w = take(m);
@@ -962,7 +997,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   C.dxa = take(n), C.dya = take(me), C.dza = take(m), C.dwa = take(m);
   C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
   C.c = take(n), C.b = take(me), C.d = take(m);
-  C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(32);
+  C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
+  // out: 0..7 reductions (k_ip_final), 16..27 the blocking components (k_ip_minratio_final),
+  // 32..39 the step's scalars (IPS_*)
+  double *const Bk = C.out + 16, *const S = C.out + 32;
   const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
   const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
   if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
@@ -973,9 +1011,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   struct Restore {
     hqpkkt_t *h;
     int loc;
-    ~Restore() { h->opts.loc = loc; }
+    ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
   } restore{h, saved_loc};
   h->opts.loc = HQPKKT_LOC_DEVICE;
+  h->lazy = true;  // no host round trip where the loop does not need the answer at once
   hipEvent_t t0 = h->ev0;  // total time: own pair of events (the plugin calls reuse the handle's)
   hipEvent_t tb, te;
   HIPCHK(hipEventCreate(&tb));
@@ -1033,7 +1072,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     double delz = std::fmax(-1.5 * mindz, 0.0), delw = std::fmax(-1.5 * mindw, 0.0);
     // gap = (dz + delz)'(dw + delw): k_ip_mupl with alpha = 1 on (delz, dz), (delw, dw) shifted vectors
     k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
-    k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, C.z, C.w, C.dz, C.dw, C.part);
+    k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, nullptr, C.z, C.w, C.dz, C.dw, C.part);
     if ((e = C.reduce(OPS_NONE, 1))) return e;
     const double gap0 = C.hout[0];
     delz += 0.5 * gap0 / (sumdw + m * delw);
@@ -1049,7 +1088,54 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   double mu0 = 0.0, norm_r0 = 0.0, norm_data = 1.0;
   const double gamma = std::pow(1.0e-4, 0.25);
   int result = 2;
-  bool stepped = false;
+  bool stepped = false, pending = false;  // pending: a step is in the stream whose scalars were not read yet
+  double mu_pending = 0.0;
+  // The rare second corrector (hqp/Hqp_IpsMehrotra.C:612-624: the first corrector's own
+  // step is tiny): safe sigma, then Mehrotra's step rule with the host in the loop.
+  auto second_corrector = [&](double mu) -> int {
+    int e2;
+    const double smm = gamma / (1.0 - gamma) * mu;
+    k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, nullptr, C.r4);
+    if ((e2 = solve(C.dx, C.dy, C.dz, C.dw))) return e2;
+    k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk);
+    HIPCHK(hipMemcpyAsync(C.hout, Bk, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const double zmin = C.hout[0], wmin = C.hout[6];
+    const int izmin = (int)C.hout[1], iwmin = (int)C.hout[7];
+    const double z_iz = C.hout[2], dz_iz = C.hout[3], w_iz = C.hout[4], dw_iz = C.hout[5];
+    const double z_iw = C.hout[8], dz_iw = C.hout[9], w_iw = C.hout[10], dw_iw = C.hout[11];
+    double alpha;
+    if (izmin < 0 && iwmin < 0)
+      alpha = 1.0;
+    else {
+      alpha = izmin < 0 ? wmin : iwmin < 0 ? zmin : std::fmin(zmin, wmin);
+      k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, alpha, nullptr, C.z, C.w, C.dz, C.dw, C.part);
+      if ((e2 = C.reduce(OPS_NONE, 1))) return e2;
+      const double mu_pl = C.hout[0] / m;
+      double fpd;
+      if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
+        fpd = (o.gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
+      else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
+        fpd = (o.gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
+      else
+        fpd = 0.0;
+      alpha = std::fmax(0.0, std::fmin(std::fmax(1.0 - o.gammaf, fpd) * alpha, 1.0));
+    }
+    res->alpha = alpha;
+    k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, nullptr, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
+    return 0;
+  };
+  // before leaving the loop with a step still in the stream: was it taken?
+  auto settle = [&]() -> int {
+    if (!pending) return 0;
+    pending = false;
+    HIPCHK(hipMemcpyAsync(C.hout + 32, S, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    res->alpha = C.hout[32 + IPS_ALPHA];
+    if (C.hout[32 + IPS_NEED2] != 0.0) return second_corrector(mu_pending);
+    return 0;
+  };
   while (true) {
     // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
     if (h->short_rows)
@@ -1066,12 +1152,32 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
         return e;
       }
-      k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
+      k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, nullptr, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
       iter++;
       return finish(0);
     }
-    const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
-    if ((e = C.reduce(ops2, 6))) return e;
+    {  // the reductions of this iterate and what the step before left behind, one round trip
+      const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
+      IpOps o2;
+      for (int k = 0; k < IP_SLOTS; k++) o2.op[k] = ops2[k];
+      k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out);
+      HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    if (pending) {
+      pending = false;
+      res->alpha = C.hout[32 + IPS_ALPHA];
+      if (C.hout[32 + IPS_NEED2] != 0.0) {  // that step was not taken (alpha 0): second corrector first
+        iter--;
+        if ((e = second_corrector(mu_pending))) {
+          if (e == HQPKKT_E_SING) return finish(4);
+          (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+          return e;
+        }
+        iter++;
+        continue;  // right-hand sides and reductions of the new iterate
+      }
+    }
     const double gap = C.hout[0], mu = C.hout[2] / m, norm_r = C.hout[3];
     if (stepped && (!std::isfinite(mu) || !std::isfinite(norm_r) || !std::isfinite(gap))) {
       iter--;  // the reference leaves the failed step uncounted
@@ -1111,86 +1217,48 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
       return e;
     }
+    // From here to the step itself nothing is read back: sigma (Terlaky's modification,
+    // :583-590; the safe value when the predictor step is short and the reference skips the
+    // first corrector, :612-616), the corrector's blocking components, the damped step length
+    // (:629-672) are computed by one-thread kernels and consumed through device pointers.
     k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.part);
-    const int ops3[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-    if ((e = C.reduce(ops3, 2))) return e;
-    const double alpha_aff = std::fmax(0.0, std::fmin(std::fmin(1.0, C.hout[0]), 1.0));
-    const double t = C.hout[1];
-    double sigma = gamma * (t + 1.0 - alpha_aff) / (1.0 - gamma);  // Terlaky's modification (:583-590)
-    double smm = sigma * mu;
-    bool have_corr = false;
-    if (alpha_aff >= 0.1) {
-      k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, C.r4);
-      if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
+    {
+      const int ops3[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+      IpOps o3;
+      for (int k = 0; k < IP_SLOTS; k++) o3.op[k] = ops3[k];
+      k_ip_final<<<1, 256, 0, s>>>(C.part, o3, C.out);
+    }
+    k_ip_sigma<<<1, 1, 0, s>>>(C.out, mu, gamma, S);
+    k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, 0.0, S + IPS_SMM, C.r4);
+    if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
+      if (e == HQPKKT_E_SING) return finish(4);
+      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+      return e;
+    }
+    k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk);
+    k_ip_alpha_pre<<<1, 1, 0, s>>>(Bk, m, gamma, S);
+    k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, S + IPS_ALPHA_PRE, C.z, C.w, C.dz, C.dw, C.part);
+    {
+      IpOps on;
+      for (int k = 0; k < IP_SLOTS; k++) on.op[k] = IP_SUM;
+      k_ip_final<<<1, 256, 0, s>>>(C.part, on, C.out);
+    }
+    k_ip_alpha_fin<<<1, 1, 0, s>>>(C.out, Bk, m, o.gammaf, S);
+    k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 0.0, S + IPS_ALPHA, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw,
+                                          C.part);
+    // (:684-690: a non-finite mu or x ends the solve as degenerate; seen here by the next
+    // pass through k_ip_rhs, whose sums and maximum carry the NaN / inf)
+    iter++;
+    stepped = true, pending = true, mu_pending = mu;
+    if (result == 3 || result == 4 || iter >= o.max_iters) {  // blow-up test above; :716
+      if ((e = settle())) {
         if (e == HQPKKT_E_SING) return finish(4);
         (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
         return e;
       }
-      have_corr = true;
+      break;
     }
-    // (:604-624) the corrector's own largest step = the smaller of the two blocking ratios
-    // that Mehrotra's step rule needs anyway (:629-646); a second corrector with the safe
-    // sigma when the predictor step or this one is too short.  Without a first corrector
-    // the reference tests the stale d* of the previous iteration; so does this.
-    auto blocking = [&]() -> int {
-      k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-      k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, C.out);
-      HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-      HIPCHK(hipStreamSynchronize(s));
-      return 0;
-    };
-    if ((e = blocking())) return e;
-    {
-      const double amin = std::fmin(C.hout[1] < 0 ? 1e300 : C.hout[0], C.hout[7] < 0 ? 1e300 : C.hout[6]);
-      const double alpha_corr = std::fmax(0.0, std::fmin(std::fmin(1.0, amin), 1.0));
-      if (alpha_aff < 0.1 || alpha_corr < gamma * gamma / 2.0 / m / m) {
-        sigma = gamma / (1.0 - gamma);
-        smm = sigma * mu;
-        k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, C.r4);
-        if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
-          if (e == HQPKKT_E_SING) return finish(4);
-          (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-          return e;
-        }
-        if ((e = blocking())) return e;
-      }
-      (void)have_corr;
-    }
-    // Mehrotra's adaptive step size (:629-672)
-    const double zmin = C.hout[0], wmin = C.hout[6];
-    const int izmin = (int)C.hout[1], iwmin = (int)C.hout[7];
-    const double z_iz = C.hout[2], dz_iz = C.hout[3], w_iz = C.hout[4], dw_iz = C.hout[5];
-    const double z_iw = C.hout[8], dz_iw = C.hout[9], w_iw = C.hout[10], dw_iw = C.hout[11];
-    double alpha;
-    if (izmin < 0 && iwmin < 0)
-      alpha = 1.0;
-    else {
-      if (izmin < 0)
-        alpha = wmin;
-      else if (iwmin < 0)
-        alpha = zmin;
-      else
-        alpha = std::fmin(zmin, wmin);
-      k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, alpha, C.z, C.w, C.dz, C.dw, C.part);
-      if ((e = C.reduce(OPS_NONE, 1))) return e;
-      const double mu_pl = C.hout[0] / m;
-      double fpd;
-      if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
-        fpd = (o.gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
-      else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
-        fpd = (o.gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
-      else
-        fpd = 0.0;
-      alpha = std::fmax(0.0, std::fmin(std::fmax(1.0 - o.gammaf, fpd) * alpha, 1.0));
-    }
-    res->alpha = alpha;
-    k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
-    // (:684-690: a non-finite mu or x ends the solve as degenerate; seen here by the next
-    // pass through k_ip_rhs, whose sums and maximum carry the NaN / inf)
-    iter++;
-    stepped = true;
-    if (result == 3 || result == 4) break;  // set by the blow-up test above
-    if (iter >= o.max_iters) break;         // :716
   }
   return finish(result);
 }

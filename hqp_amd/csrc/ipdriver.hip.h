@@ -126,7 +126,8 @@ k_ip_ratio(int m, const double *__restrict__ z, const double *__restrict__ w, co
 // corrector right-hand side r4 = -(z.*w + dza.*dwa - sigma mu)  (:596-600, :617-622)
 __global__ void k_ip_corr_rhs(int m, const double *__restrict__ z, const double *__restrict__ w,
                               const double *__restrict__ dza, const double *__restrict__ dwa, double smm,
-                              double *__restrict__ r4) {
+                              const double *__restrict__ smm_dev, double *__restrict__ r4) {
+  if (smm_dev) smm = *smm_dev;  // sigma mu computed on the device (k_ip_sigma): no host round trip
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < m) r4[i] = -(z[i] * w[i] + (dza[i] * dwa[i] - smm));
 }
@@ -200,9 +201,11 @@ k_ip_minratio_final(const double *__restrict__ part, const double *__restrict__ 
 
 // slot 0: (z + alpha dz)'(w + alpha dw)  (:657-659)
 __global__ void __launch_bounds__(256)
-k_ip_mupl(int m, double alpha, const double *__restrict__ z, const double *__restrict__ w,
-          const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ part) {
+k_ip_mupl(int m, double alpha, const double *__restrict__ alpha_dev, const double *__restrict__ z,
+          const double *__restrict__ w, const double *__restrict__ dz, const double *__restrict__ dw,
+          double *__restrict__ part) {
   __shared__ double red[4];
+  if (alpha_dev) alpha = *alpha_dev;
   double s = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
     s += (z[i] + alpha * dz[i]) * (w[i] + alpha * dw[i]);
@@ -216,11 +219,12 @@ k_ip_mupl(int m, double alpha, const double *__restrict__ z, const double *__res
 
 // the step (:677-680): x, y, z, w += alpha d*;  slots: 0 z'w, 1 max|x| (NaN -> inf)
 __global__ void __launch_bounds__(256)
-k_ip_update(int n, int me, int m, double alpha, double *__restrict__ x, double *__restrict__ y,
-            double *__restrict__ z, double *__restrict__ w, const double *__restrict__ dx,
+k_ip_update(int n, int me, int m, double alpha, const double *__restrict__ alpha_dev, double *__restrict__ x,
+            double *__restrict__ y, double *__restrict__ z, double *__restrict__ w, const double *__restrict__ dx,
             const double *__restrict__ dy, const double *__restrict__ dz, const double *__restrict__ dw,
             double *__restrict__ part) {
   __shared__ double red[4];
+  if (alpha_dev) alpha = *alpha_dev;
   double zw = 0.0, xm = 0.0;
   const int total = n + me + m;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
@@ -245,6 +249,64 @@ k_ip_update(int n, int me, int m, double alpha, double *__restrict__ x, double *
     P[1] = r;
     for (int k = 2; k < IP_SLOTS; k++) P[k] = 0.0;
   }
+}
+
+// ---- the scalar logic of a step on the device (one thread): the host reads the results
+// together with the next iteration's convergence data instead of stopping the stream
+// after every reduction.  S: 0 alpha_aff, 1 sigma mu, 2 alpha before damping, 3 damping
+// needed (0/1), 4 second corrector needed (0/1), 5 alpha of the step (0 if 4), 6 sigma
+#define IPS_ALPHA_AFF 0
+#define IPS_SMM 1
+#define IPS_ALPHA_PRE 2
+#define IPS_DAMP 3
+#define IPS_NEED2 4
+#define IPS_ALPHA 5
+#define IPS_SIGMA 6
+// Terlaky's sigma (hqp/Hqp_IpsMehrotra.C:583-590); the safe one when the predictor step
+// is short (:612-616, the first corrector is skipped then).  red: 0 min ratio, 1 t
+__global__ void k_ip_sigma(const double *__restrict__ red, double mu, double gamma, double *__restrict__ S) {
+  const double alpha_aff = fmax(0.0, fmin(fmin(1.0, red[0]), 1.0));
+  const double t = red[1];
+  const double sigma = alpha_aff >= 0.1 ? gamma * (t + 1.0 - alpha_aff) / (1.0 - gamma) : gamma / (1.0 - gamma);
+  S[IPS_ALPHA_AFF] = alpha_aff, S[IPS_SIGMA] = sigma, S[IPS_SMM] = sigma * mu;
+}
+// after the corrector: its own largest step (:604-611) decides about a second corrector
+// (:612); Mehrotra's step rule up to the damping (:629-656).  B: k_ip_minratio_final's 12
+__global__ void k_ip_alpha_pre(const double *__restrict__ B, int m, double gamma, double *__restrict__ S) {
+  const double zmin = B[0], wmin = B[6];
+  const int izmin = (int)B[1], iwmin = (int)B[7];
+  const double amin = fmin(izmin < 0 ? 1e300 : zmin, iwmin < 0 ? 1e300 : wmin);
+  const double alpha_corr = fmax(0.0, fmin(fmin(1.0, amin), 1.0));
+  S[IPS_NEED2] = (S[IPS_ALPHA_AFF] >= 0.1 && alpha_corr < gamma * gamma / 2.0 / m / m) ? 1.0 : 0.0;
+  double alpha;
+  if (izmin < 0 && iwmin < 0)
+    alpha = 1.0, S[IPS_DAMP] = 0.0;
+  else {
+    alpha = izmin < 0 ? wmin : iwmin < 0 ? zmin : fmin(zmin, wmin);
+    S[IPS_DAMP] = 1.0;
+  }
+  S[IPS_ALPHA_PRE] = alpha;
+}
+// the damped step (:657-672).  red: 0 (z + alpha dz)'(w + alpha dw)
+__global__ void k_ip_alpha_fin(const double *__restrict__ red, const double *__restrict__ B, int m, double gammaf,
+                               double *__restrict__ S) {
+  double alpha = S[IPS_ALPHA_PRE];
+  if (S[IPS_DAMP] != 0.0) {
+    const double zmin = B[0], wmin = B[6];
+    const int izmin = (int)B[1], iwmin = (int)B[7];
+    const double z_iz = B[2], dz_iz = B[3], w_iz = B[4], dw_iz = B[5];
+    const double z_iw = B[8], dz_iw = B[9], w_iw = B[10], dw_iw = B[11];
+    const double mu_pl = red[0] / m;
+    double fpd;
+    if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
+      fpd = (gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
+    else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
+      fpd = (gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
+    else
+      fpd = 0.0;
+    alpha = fmax(0.0, fmin(fmax(1.0 - gammaf, fpd) * alpha, 1.0));
+  }
+  S[IPS_ALPHA] = S[IPS_NEED2] != 0.0 ? 0.0 : alpha;  // a second corrector first: this step is not taken
 }
 
 // cold start (:236-252): z = w = 1, r1 = c, r2 = -b, r3 = -d, r4 = 0

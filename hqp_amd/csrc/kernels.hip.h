@@ -369,8 +369,18 @@ __device__ __forceinline__ void patch_get_row(PatchT &A, int r, int tx, int ty, 
     if (blockIdx.x == 0 && threadIdx.x == 0 && p > 64 && (slot) < 50)                           \
       counters[8 + (slot)] = (int)__builtin_amdgcn_s_memtime(), counters[8 + 50] = p;            \
   } while (0)
+#ifndef FSTAMP_GRID
+#define FSTAMP_GRID 8
+#define FSTAMP_BLOCK 0
+#endif
+#define FSTAMP(slot)                                                                             \
+  do {                                                                                           \
+    if (FRONT && gridDim.x == FSTAMP_GRID && blockIdx.x == FSTAMP_BLOCK && threadIdx.x == 0)     \
+      counters[8 + (slot)] = (int)__builtin_amdgcn_s_memtime(), counters[8 + 50] = p, counters[8 + 51] = b; \
+  } while (0)
 #else
 #define STAMP(slot)
+#define FSTAMP(slot)
 #endif
 
 // broadcast of one lane's double to the wavefront through SGPRs (src is uniform)
@@ -922,32 +932,90 @@ int dn;
 // solve X = A21 P' M', L21 = X D^-1 and the update U = (gathered) - L21 X' - five
 // launches per tree level become one.
 #define FS_MAXP 32
-#define FS_LD 33
 #define FS_MAXB 16
+// LDS bytes of one front for the leading dimensions of a launch: ldp odd and >= the largest p,
+// ldb >= the largest b of the fronts in the launch (a level of a narrow-band tree has
+// fronts of 5..20 pivots, a quarter of the room the limits would need)
+__host__ __device__ inline size_t fs_lds_bytes(bool front, int ldp, int ldb) {
+  const size_t d = (size_t)ldp * ldp + 2 * (size_t)ldp + (front ? 2 * (size_t)ldb * ldp + (size_t)ldb * ldb : 0);
+  return 8 * d + 8 * (size_t)ldp;
+}
+// value of a lane's double in a uniform lane
+__device__ __forceinline__ double rdlane(double v, int l) {
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), l);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), l);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
+// One wavefront per front and no other parallelism: what counts is the length of the
+// dependent chains.  Global loads are issued in predicated, fully unrolled batches
+// (one memory latency per batch, not one per loop trip), the LDS updates of a pivot
+// step likewise, and the registers are capped at 128 so that 16 fronts share a CU.
 template <bool FRONT>
-__global__ void __launch_bounds__(64)
+__global__ void __launch_bounds__(64, 4)
 k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
                     double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
                     const signed char *__restrict__ esign, double *__restrict__ linv,
                     const long long *__restrict__ linv_off, double alpha, double pivot_eps,
                     const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters,
-                    double *__restrict__ upd, double *__restrict__ xar) {
-  __shared__ double a[FS_MAXP * FS_LD];
-  __shared__ double dv[2 * FS_MAXP];
-  __shared__ int lp[FS_MAXP], pt[FS_MAXP];
+                    double *__restrict__ upd, double *__restrict__ xar, int ldp, int ldb) {
+  extern __shared__ __attribute__((aligned(16))) double fsm[];
+  double *a = fsm;               // ldp x ldp: full symmetric image of the pivot block
+  double *dv = a + ldp * ldp;    // 2 ldp
   // FRONT: border rows of the pivot columns (later L21), X, the update block
-  __shared__ double s21[FRONT ? FS_MAXB * FS_MAXP : 1], xs[FRONT ? FS_MAXB * FS_MAXP : 1],
-      ub[FRONT ? FS_MAXB * FS_MAXB : 1];
+  double *s21 = dv + 2 * ldp, *xs = s21 + (FRONT ? ldb * ldp : 0), *ub = xs + (FRONT ? ldb * ldp : 0);
+  int *lp = (int *)(ub + (FRONT ? ldb * ldb : 0)), *pt = lp + ldp;
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
   const int e0 = T.piv_start[node];
   double *P = panel + T.panel_off[node];
-  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5, r16 = lane & 15, cq = lane >> 4;
   const bool row_on = i < p;
+  FSTAMP(0);
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
-  for (int j = h; j < p; j += 2)
-    if (row_on) a[i + j * FS_LD] = (i >= j) ? P[(long long)j * F + i] : P[(long long)i * F + j];
+  // The columns in groups of 16 (most fronts have one), eight loads per lane and group in
+  // flight.  Every unrolled slot sits behind a uniform test of p or b: a front of four
+  // pivots executes a quarter of the instructions of one with sixteen (one wavefront per
+  // front: the instruction count IS the run time).
+  const int ng = p > FS_MAXP / 2 ? 2 : 1;
+#pragma unroll 1
+  for (int g = 0; g < ng; g++) {
+    const int j0 = FS_MAXP / 2 * g;
+    double v[FS_MAXP / 4], sv[FRONT ? FS_MAXP / 8 : 1];
+#pragma unroll
+    for (int u = 0; u < FS_MAXP / 4; u++)
+      if (j0 + 2 * u < p) {
+        const int j = j0 + 2 * u + h;  // masked lanes read P[0]: no branch around the load
+        v[u] = P[(row_on && j < p) ? (long long)min(i, j) * F + max(i, j) : 0];
+      }
+    if constexpr (FRONT) {
+#pragma unroll
+      for (int u = 0; u < FS_MAXP / 8; u++)
+        if (j0 + 4 * u < p && b > 0) {
+          const int c = j0 + 4 * u + cq;
+          sv[u] = P[(r16 < b && c < p) ? (long long)c * F + p + r16 : 0];
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < FS_MAXP / 4; u++)
+      if (j0 + 2 * u < p) {
+        const int j = j0 + 2 * u + h;
+        if (row_on && j < p) a[i + j * ldp] = v[u];
+      }
+    if constexpr (FRONT) {
+#pragma unroll
+      for (int u = 0; u < FS_MAXP / 8; u++)
+        if (j0 + 4 * u < p && b > 0) {
+          const int c = j0 + 4 * u + cq;
+          if (r16 < b && c < p) s21[r16 + ldb * c] = sv[u];
+        }
+    }
+  }
+  if constexpr (FRONT)
+    for (int t = lane; t < ldb * b; t += 64) ub[t] = 0.0;
+  FSTAMP(1);
   if (lane < p) lp[lane] = lane;
   if constexpr (!FRONT) {  // pivot block += children's update blocks (pulled; the border parts are
                            // pulled by the panel solve and the Schur update)
@@ -955,58 +1023,106 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       const int c = T.child_idx[cc], bc = T.nbor[c];
       const int *iv = T.pinv + T.pinv_off[c];
       const double *Uc = upd + T.upd_off[c];
-      const int ci = row_on ? iv[i] : -1;  // this lane's row in the child's numbering
-      for (int j = h; j < p; j += 2) {
-        const int cj = iv[j];
-        if (ci >= 0 && cj >= 0) a[i + j * FS_LD] += Uc[(long long)min(ci, cj) * bc + max(ci, cj)];
+      const int civ = lane < p ? iv[lane] : -1;  // the pivot rows in the child's numbering
+      const int ci = __shfl(civ, i);
+#pragma unroll 1
+      for (int g2 = 0; g2 < ng; g2++) {
+        const int j0 = FS_MAXP / 2 * g2;
+        double g[FS_MAXP / 4];
+#pragma unroll
+        for (int u = 0; u < FS_MAXP / 4; u++)
+          if (j0 + 2 * u < p) {
+            const int j = j0 + 2 * u + h, cj = __shfl(civ, j);
+            const bool ok = row_on && j < p && ci >= 0 && cj >= 0;
+            const double *src = ok ? Uc + ((long long)min(ci, cj) * bc + max(ci, cj)) : P;
+            const double t = *src;
+            g[u] = ok ? t : 0.0;
+          }
+#pragma unroll
+        for (int u = 0; u < FS_MAXP / 4; u++)
+          if (j0 + 2 * u < p) {
+            const int j = j0 + 2 * u + h;
+            if (row_on && j < p) a[i + j * ldp] += g[u];  // entry (i, j) belongs to this lane alone
+          }
       }
     }
   }
   if constexpr (FRONT) {
-    for (int t = lane; t < b * p; t += 64) s21[(t % b) + FS_MAXB * (t / b)] = P[(long long)(t / b) * F + p + t % b];
-    for (int t = lane; t < FS_MAXB * FS_MAXB; t += 64) ub[t] = 0.0;
+    // extend-add: the lower triangle of each child's update block in 16 x 16 tiles (lane =
+    // row of the tile + 16 * column mod 4), two children's loads in flight; a child's entries
+    // go to distinct places (rel is one-to-one), children follow each other in slot order
+    const int c0 = T.child_ptr[node], c1 = T.child_ptr[node + 1];
     __syncthreads();
-    for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
-      const int ch = T.child_idx[cc], bc = T.nbor[ch];
-      const int *rel = T.rel + T.bptr[ch];
-      const double *Uc = upd + T.upd_off[ch];
-      for (int j = 0; j < bc; j++) {
-        const int rj = rel[j];
-        for (int ii = j + lane; ii < bc; ii += 64) {
-          const int ri = rel[ii];
-          const double v = Uc[(long long)j * bc + ii];
-          if (rj >= p)
-            ub[(ri - p) + FS_MAXB * (rj - p)] += v;
-          else if (ri >= p)
-            s21[(ri - p) + FS_MAXB * rj] += v;
-          else {
-            a[ri + rj * FS_LD] += v;
-            if (ri != rj) a[rj + ri * FS_LD] += v;  // the image is the full symmetric matrix
+    for (int cc = c0; cc < c1; cc += 2) {
+      const bool two = cc + 1 < c1;
+      const int ch0 = T.child_idx[cc], ch1 = T.child_idx[two ? cc + 1 : cc];
+      const int bc0 = T.nbor[ch0], bc1 = two ? T.nbor[ch1] : 0;  // <= p + b <= 48
+      const int *rel0 = T.rel + T.bptr[ch0], *rel1 = T.rel + T.bptr[ch1];
+      const double *U0 = upd + T.upd_off[ch0], *U1 = upd + T.upd_off[ch1];
+      const int relv0 = lane < bc0 ? rel0[lane] : 0, relv1 = lane < bc1 ? rel1[lane] : 0;
+      const int bcm = max(bc0, bc1);
+      for (int jb = 0; jb < bcm; jb += 16)
+        for (int ib = jb; ib < bcm; ib += 16) {
+          const int ii = ib + r16;
+          double v0[4], v1[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (jb + 4 * u < bcm) {
+              const int j = jb + 4 * u + cq;
+              v0[u] = U0[(j < bc0 && ii < bc0 && ii >= j) ? (long long)j * bc0 + ii : 0];
+              v1[u] = U1[(j < bc1 && ii < bc1 && ii >= j) ? (long long)j * bc1 + ii : 0];
+            }
+#pragma unroll
+          for (int w = 0; w < 2; w++) {
+            const int bc = w ? bc1 : bc0;
+            const int relv = w ? relv1 : relv0;
+            const int ri = __shfl(relv, ii);
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+              if (jb + 4 * u < bc) {
+                const int j = jb + 4 * u + cq;
+                const int rj = __shfl(relv, j);
+                const double v = w ? v1[u] : v0[u];
+                if (j < bc && ii < bc && ii >= j) {
+                  if (rj >= p)
+                    ub[(ri - p) + ldb * (rj - p)] += v;
+                  else if (ri >= p)
+                    s21[(ri - p) + ldb * rj] += v;
+                  else {
+                    a[ri + rj * ldp] += v;
+                    if (ri != rj) a[rj + ri * ldp] += v;  // the image is the full symmetric matrix
+                  }
+                }
+              }
+            __syncthreads();
           }
         }
-      }
-      __syncthreads();
     }
   }
   __syncthreads();
-  int k = 0;
+  FSTAMP(2);
+  int k = 0, n2x2 = 0, npert = 0;  // statistics: one atomic per front, not one per pivot (thousands of
+                                   // fronts of a level would queue up on the same address)
   while (k < p) {
-    // column max below the diagonal and its first row (hqp/spBKP.C:431-437)
-    const bool below = lane > k && lane < p;
-    const float t1 = below ? fabsf((float)a[lane + k * FS_LD]) : -1.0f;
+    FSTAMP(10 + k);
+    // column k, row i in both halves; its max below the diagonal and the first row that
+    // attains it (hqp/spBKP.C:431-437)
+    double ck = row_on ? a[i + k * ldp] : 0.0;
+    const bool below = h == 0 && row_on && i > k;
+    const float t1 = below ? fabsf((float)ck) : -1.0f;
     const float tmax = wave_max_dpp_f(fmaxf(t1, 0.0f));
     const unsigned long long m1 = __ballot(t1 == tmax);
     int r = m1 ? (int)__builtin_ctzll(m1) : p;
     r = __builtin_amdgcn_readfirstlane(r);
-    const double akk = fabs(a[k + k * FS_LD]);
-    const double lambda = r < p ? fabs(a[r + k * FS_LD]) : 0.0;
+    const double akk = fabs(rdlane(ck, k));
+    const double lambda = r < p ? fabs(rdlane(ck, r)) : 0.0;
     int kind = 0;
     if (r < p && !(akk >= alpha * lambda)) {
-      const double sv = (lane >= k && lane < p && lane != r) ? fabs(a[lane + r * FS_LD]) : 0.0;
+      const double sv = (h == 0 && row_on && i >= k && i != r) ? fabs(a[i + r * ldp]) : 0.0;
       const double sigma = wave_max_dpp(sv);
       if (sigma * akk >= alpha * lambda * lambda)
         kind = 0;
-      else if (fabs(a[r + r * FS_LD]) >= alpha * sigma)
+      else if (fabs(a[r + r * ldp]) >= alpha * sigma)
         kind = 1;
       else
         kind = 2;
@@ -1015,22 +1131,23 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
     const int p1 = (kind == 2) ? k + 1 : k;
     if (kind != 0 && r != p1) {  // symmetric interchange p1 <-> r
       if (lane < p) {
-        const double x = a[p1 + lane * FS_LD], y = a[r + lane * FS_LD];
-        a[p1 + lane * FS_LD] = y, a[r + lane * FS_LD] = x;
+        const double x = a[p1 + lane * ldp], y = a[r + lane * ldp];
+        a[p1 + lane * ldp] = y, a[r + lane * ldp] = x;
       }
       __syncthreads();
       if (lane < p) {
-        const double x = a[lane + p1 * FS_LD], y = a[lane + r * FS_LD];
-        a[lane + p1 * FS_LD] = y, a[lane + r * FS_LD] = x;
+        const double x = a[lane + p1 * ldp], y = a[lane + r * ldp];
+        a[lane + p1 * ldp] = y, a[lane + r * ldp] = x;
       }
       if (lane == 0) {
         const int t = lp[p1];
         lp[p1] = lp[r], lp[r] = t;
       }
       __syncthreads();
+      ck = row_on ? a[i + k * ldp] : 0.0;
     }
     if (kind != 2) {
-      double d = a[k + k * FS_LD];
+      double d = rdlane(ck, k);
       bool pertd = false;
       if (!(fabs(d) >= pert)) {
         d = (double)esign[e0 + lp[k]] * pert;
@@ -1039,16 +1156,30 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       const double di = fast_rcp(d);
       if (lane == 0) {
         dv[2 * k] = di, dv[2 * k + 1] = 0.0, pt[k] = 0;
-        if (pertd) atomicAdd(&counters[1], 1), a[k + k * FS_LD] = d;
+        if (pertd) a[k + k * ldp] = d;
       }
+      npert += pertd;
       if (row_on && i > k) {
-        const double li = a[i + k * FS_LD] * di;
-        for (int j = k + 1 + h; j < p; j += 2)
-          a[i + j * FS_LD] = fma(-li, a[j + k * FS_LD], a[i + j * FS_LD]);
+        const double li = ck * di;
+        for (int jb = k + 1; jb < p; jb += 8) {
+          double akj[4], aij[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (jb + 2 * u < p) {
+              const int j = min(jb + 2 * u + h, p - 1);
+              akj[u] = a[j + k * ldp], aij[u] = a[i + j * ldp];
+            }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (jb + 2 * u < p) {
+              const int j = jb + 2 * u + h;
+              if (j < p) a[i + j * ldp] = fma(-li, akj[u], aij[u]);
+            }
+        }
       }
       k += 1;
     } else {
-      double d11 = a[k + k * FS_LD], d21 = a[k + 1 + k * FS_LD], d22 = a[k + 1 + (k + 1) * FS_LD];
+      double d11 = rdlane(ck, k), d21 = rdlane(ck, k + 1), d22 = a[k + 1 + (k + 1) * ldp];
       double det = d11 * d22 - d21 * d21;
       bool pertd = false;
       if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
@@ -1063,39 +1194,75 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       if (lane == 0) {
         dv[2 * k] = i11, dv[2 * k + 1] = i21, dv[2 * k + 2] = i22, dv[2 * k + 3] = i21;
         pt[k] = 1, pt[k + 1] = 2;
-        atomicAdd(&counters[0], 1);
-        if (pertd) atomicAdd(&counters[1], 2);
       }
+      n2x2 += 1, npert += pertd ? 2 : 0;
       if (row_on && i > k + 1) {
-        const double c1 = a[i + k * FS_LD], c2 = a[i + (k + 1) * FS_LD];
+        const double c1 = ck, c2 = a[i + (k + 1) * ldp];
         const double l1 = c1 * i11 + c2 * i21, l2 = c1 * i21 + c2 * i22;
-        for (int j = k + 2 + h; j < p; j += 2)
-          a[i + j * FS_LD] =
-              fma(-l2, a[j + (k + 1) * FS_LD], fma(-l1, a[j + k * FS_LD], a[i + j * FS_LD]));
+        for (int jb = k + 2; jb < p; jb += 8) {
+          double ak0[4], ak1[4], aij[4];
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (jb + 2 * u < p) {
+              const int j = min(jb + 2 * u + h, p - 1);
+              ak0[u] = a[j + k * ldp], ak1[u] = a[j + (k + 1) * ldp], aij[u] = a[i + j * ldp];
+            }
+#pragma unroll
+          for (int u = 0; u < 4; u++)
+            if (jb + 2 * u < p) {
+              const int j = jb + 2 * u + h;
+              if (j < p) a[i + j * ldp] = fma(-l2, ak1[u], fma(-l1, ak0[u], aij[u]));
+            }
+        }
       }
       k += 2;
     }
     __syncthreads();
   }
-  // L = C D^-1 (columns were kept unscaled), then write-back of the lower triangle
-  for (int j = 0; j < p; j++) {
-    const int tj = pt[j];
-    if (tj == 2) continue;
-    if (tj == 0) {
-      if (h == 0 && row_on && i > j) a[i + j * FS_LD] *= dv[2 * j];
-    } else {
-      if (h == 0 && row_on && i > j + 1) {
-        const double i11 = dv[2 * j], i21 = dv[2 * j + 1], i22 = dv[2 * j + 2];
-        const double c1 = a[i + j * FS_LD], c2 = a[i + (j + 1) * FS_LD];
-        a[i + j * FS_LD] = c1 * i11 + c2 * i21;
-        a[i + (j + 1) * FS_LD] = c1 * i21 + c2 * i22;
-      }
-      if (lane == 0) a[j + 1 + j * FS_LD] = 0.0;
+  FSTAMP(3);
+  if (lane == 0) {
+    if (n2x2) atomicAdd(&counters[0], n2x2);
+    if (npert) atomicAdd(&counters[1], npert);
+  }
+  // L = C D^-1 (columns were kept unscaled): every entry below the diagonal on its own, all
+  // reads before the first write (a 2x2 pivot mixes two columns)
+  {
+    const int ic = row_on ? i : 0;
+    // a 2x2 pivot on the columns 15 | 16 straddles the two column groups: column 15 unscaled
+    const double c15 = a[ic + min(15, p - 1) * ldp];
+#pragma unroll 1
+    for (int g = 0; g < ng; g++) {
+      double nv[FS_MAXP / 4];
+#pragma unroll
+      for (int u = 0; u < FS_MAXP / 4; u++)
+        if (FS_MAXP / 2 * g + 2 * u < p - 1) {  // the last column has nothing below the diagonal
+          const int j = min(FS_MAXP / 2 * g + 2 * u + h, p - 1), jn = min(j + 1, p - 1), jp = max(j - 1, 0);
+          const int ty = pt[j];
+          const double c0 = a[ic + j * ldp], cn = a[ic + jn * ldp], cq0 = a[ic + jp * ldp];
+          const double cp = jp == 15 ? c15 : cq0;
+          const double d0 = dv[2 * j], d1 = dv[2 * j + 1];
+          nv[u] = ty == 0 ? c0 * d0 : ty == 1 ? (i > j + 1 ? c0 * d0 + cn * d1 : 0.0) : cp * d1 + c0 * d0;
+        }
+      __syncthreads();
+#pragma unroll
+      for (int u = 0; u < FS_MAXP / 4; u++)
+        if (FS_MAXP / 2 * g + 2 * u < p - 1) {
+          const int j = FS_MAXP / 2 * g + 2 * u + h;
+          if (row_on && j < i) a[i + j * ldp] = nv[u];
+        }
+      __syncthreads();
     }
   }
-  __syncthreads();
-  for (int j = h; j < p; j += 2)
-    if (row_on && i >= j) P[(long long)j * F + i] = a[i + j * FS_LD];
+#pragma unroll 1
+  for (int g = 0; g < ng; g++) {
+#pragma unroll
+    for (int u = 0; u < FS_MAXP / 4; u++)
+      if (FS_MAXP / 2 * g + 2 * u < p) {
+        const int j = FS_MAXP / 2 * g + 2 * u + h;
+        if (row_on && j <= i) P[(long long)j * F + i] = a[i + j * ldp];
+      }
+  }
+  FSTAMP(4);
   if (lane < p) {
     lperm[e0 + lane] = lp[lane];
     ptype[e0 + lane] = pt[lane];
@@ -1105,100 +1272,172 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   // inverses of the (at most two) 16x16 diagonal blocks of L11, then M = L11^-1 in
   // place (M_10 = -M_11 L_10 M_00) for the product-form panel solve / tree solves
   const int nb = (p + DB - 1) / DB;
-  const int blk = lane >> 4, c = lane & 15;
-  double x[DB];
-  if (blk < nb) {
+  {
+    // lane (blk, c): column c of the inverse of diagonal block blk by substitution; no
+    // divergent control flow (clamped reads + selects), lanes of blocks >= nb repeat the last
+    const int blk = min(cq, nb - 1), c = r16;
     const int kb = blk * DB, kw = min(DB, p - kb);
+    double x[DB];  // row by row: x_rr = [rr == c] - sum_{t < rr} L(rr, t) x_t, two partial sums
+    const int kwu = min(DB, p);  // uniform bound of the rows any block has
+    x[0] = c == 0 ? 1.0 : 0.0;
 #pragma unroll
-    for (int rr = 0; rr < DB; rr++) x[rr] = (rr == c) ? 1.0 : 0.0;
+    for (int rr = 1; rr < DB; rr++) {
+      x[rr] = 0.0;
+      if (rr < kwu) {
+        const int rc = min(rr, kw - 1);
+        double s0 = rr == c ? 1.0 : 0.0, s1 = 0.0;
 #pragma unroll
-    for (int t = 0; t < DB - 1; t++) {
-      const double xt = x[t];
-#pragma unroll
-      for (int rr = t + 1; rr < DB; rr++) {
-        const double l = (rr < kw) ? a[kb + rr + (kb + t) * FS_LD] : 0.0;
-        x[rr] = fma(-l, xt, x[rr]);
+        for (int t = 0; t < rr; t++) {
+          const double l = a[kb + rc + (kb + min(t, kw - 1)) * ldp];
+          if (t & 1)
+            s1 = fma(-l, x[t], s1);
+          else
+            s0 = fma(-l, x[t], s0);
+        }
+        x[rr] = rr < kw ? s0 + s1 : 0.0;
       }
+      // a few rows' reads of L in flight at a time (all 120 hoisted would not fit the registers)
+      if (rr == 5 || rr == 8 || rr == 10 || rr == 12 || rr == 14) __builtin_amdgcn_sched_barrier(0);
     }
-  }
-  __syncthreads();
-  if (blk < nb) {
-    const int kb = blk * DB, kw = min(DB, p - kb);
+    __syncthreads();
 #pragma unroll
     for (int rr = 0; rr < DB; rr++)
-      if (rr < kw && c < kw) a[kb + rr + (kb + c) * FS_LD] = x[rr];
+      if (rr < kwu) {
+        if (cq < nb && rr < kw && c < kw) a[kb + rr + (kb + c) * ldp] = x[rr];
+      }
   }
   __syncthreads();
+  FSTAMP(5);
   if (nb == 2) {
-    const int kw1 = p - DB, r = lane & 15, cq = (lane >> 4) * 4;
+    const int kw1 = p - DB, r = r16, c4 = cq * 4;
     const bool rowon = r < kw1;
     double t4[4] = {0.0, 0.0, 0.0, 0.0};
     for (int tt = 0; tt < DB; tt++) {
-      const double l = rowon ? a[DB + r + tt * FS_LD] : 0.0;
+      const double l = rowon ? a[DB + r + tt * ldp] : 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) t4[q] = fma(l, a[tt + (cq + q) * FS_LD], t4[q]);
+      for (int q = 0; q < 4; q++) t4[q] = fma(l, a[tt + (c4 + q) * ldp], t4[q]);
     }
     __syncthreads();
     if (rowon) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) a[DB + r + (cq + q) * FS_LD] = t4[q];
+      for (int q = 0; q < 4; q++) a[DB + r + (c4 + q) * ldp] = t4[q];
     }
     __syncthreads();
 #pragma unroll
     for (int q = 0; q < 4; q++) t4[q] = 0.0;
     for (int sft = 0; sft < kw1; sft++) {
-      const double mii = rowon ? a[DB + r + (DB + sft) * FS_LD] : 0.0;
+      const double mii = rowon ? a[DB + r + (DB + sft) * ldp] : 0.0;
 #pragma unroll
-      for (int q = 0; q < 4; q++) t4[q] = fma(mii, a[DB + sft + (cq + q) * FS_LD], t4[q]);
+      for (int q = 0; q < 4; q++) t4[q] = fma(mii, a[DB + sft + (c4 + q) * ldp], t4[q]);
     }
     __syncthreads();
     if (rowon) {
 #pragma unroll
-      for (int q = 0; q < 4; q++) a[DB + r + (cq + q) * FS_LD] = -t4[q];
+      for (int q = 0; q < 4; q++) a[DB + r + (c4 + q) * ldp] = -t4[q];
     }
     __syncthreads();
   }
   {
     double *W = linv + linv_off[node];  // p x p, column-major; whole diagonal blocks + below
-    for (int j = h; j < p; j += 2)
-      if (row_on && i >= (j & ~(DB - 1))) W[(long long)j * p + i] = a[i + j * FS_LD];
+#pragma unroll 1
+    for (int g = 0; g < ng; g++) {
+#pragma unroll
+      for (int u = 0; u < FS_MAXP / 4; u++)
+        if (FS_MAXP / 2 * g + 2 * u < p) {
+          const int j = FS_MAXP / 2 * g + 2 * u + h;
+          if (row_on && j < p && i >= (j & ~(DB - 1))) W[(long long)j * p + i] = a[i + j * ldp];
+        }
+    }
   }
+  FSTAMP(6);
   if constexpr (FRONT) {
     if (b > 0) {
-      // x(r,c) = sum_{t <= c} s21(r, lp[t]) M(c,t)
-      for (int t = lane; t < b * p; t += 64) {
-        const int r = t % b, c2 = t / b;
+      const bool ron = r16 < b;
+      const int rc = min(r16, b - 1);
+      {  // columns of the border rows in pivot order
+        double t[FS_MAXP / 4];
+#pragma unroll
+        for (int u = 0; u < FS_MAXP / 4; u++)
+          if (4 * u < p) t[u] = s21[rc + ldb * lp[min(4 * u + cq, p - 1)]];
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < FS_MAXP / 4; u++)
+          if (4 * u < p) {
+            if (ron && 4 * u + cq < p) s21[r16 + ldb * (4 * u + cq)] = t[u];
+          }
+        __syncthreads();
+      }
+      // x(r,c) = sum_{t <= c} s(r, t) M(c,t)
+      for (int u = 0; 4 * u < p; u++) {
+        const int c2 = 4 * u + cq, cc2 = min(c2, p - 1);
         double acc = 0.0;
-        for (int u = 0; u <= c2; u++) acc = fma(s21[r + FS_MAXB * lp[u]], a[c2 + u * FS_LD], acc);
-        xs[r + FS_MAXB * c2] = acc;
+        for (int tb = 0; tb <= 4 * u + 3 && tb < p; tb += 4) {
+          double sq[4], mq[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int t = min(tb + q, p - 1);
+            sq[q] = s21[rc + ldb * t], mq[q] = a[cc2 + t * ldp];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (tb + q <= c2 && tb + q < p) acc = fma(sq[q], mq[q], acc);
+        }
+        if (ron && c2 < p) xs[r16 + ldb * c2] = acc;
       }
       __syncthreads();
-      // L21 = X D^-1 (over s21, which is no longer needed), both to memory
+      FSTAMP(7);
+      // L21 = X D^-1 (over s21), both to memory
       double *X = xar + T.x_off[node];
-      for (int t = lane; t < b * p; t += 64) {
-        const int r = t % b, c2 = t / b, ty = pt[c2];
-        const double xv = xs[r + FS_MAXB * c2];
-        const int kp = ty == 2 ? c2 - 1 : min(c2 + 1, p - 1);
-        const double l = ty == 0 ? xv * dv[2 * c2] : xv * dv[2 * c2] + xs[r + FS_MAXB * kp] * dv[2 * c2 + 1];
-        X[(long long)c2 * b + r] = xv;
-        P[(long long)c2 * F + p + r] = l;
-        s21[r + FS_MAXB * c2] = l;
+      {
+        double lv[FS_MAXP / 4], xv[FS_MAXP / 4];
+#pragma unroll
+        for (int u = 0; u < FS_MAXP / 4; u++)
+          if (4 * u < p) {
+            const int c2 = min(4 * u + cq, p - 1), ty = pt[c2];
+            const int kp = ty == 2 ? c2 - 1 : min(c2 + 1, p - 1);
+            xv[u] = xs[rc + ldb * c2];
+            const double xk = xs[rc + ldb * kp], d0 = dv[2 * c2], d1 = dv[2 * c2 + 1];
+            lv[u] = ty == 0 ? xv[u] * d0 : xv[u] * d0 + xk * d1;
+          }
+#pragma unroll
+        for (int u = 0; u < FS_MAXP / 4; u++)
+          if (4 * u < p) {
+            const int c2 = 4 * u + cq;
+            if (ron && c2 < p) {
+              X[(long long)c2 * b + r16] = xv[u];
+              P[(long long)c2 * F + p + r16] = lv[u];
+              s21[r16 + ldb * c2] = lv[u];
+            }
+          }
       }
       __syncthreads();
+      FSTAMP(8);
       double *U = upd + T.upd_off[node];
-      for (int t = lane; t < b * b; t += 64) {
-        const int r = t % b, c2 = t / b;
-        if (r < c2) continue;
-        double acc = ub[r + FS_MAXB * c2];
-        for (int u = 0; u < p; u++) acc = fma(-s21[r + FS_MAXB * u], xs[c2 + FS_MAXB * u], acc);
-        U[(long long)c2 * b + r] = acc;
+      for (int u = 0; 4 * u < b; u++) {
+        const int c2 = 4 * u + cq, cc2 = min(c2, b - 1);
+        double acc = ub[rc + ldb * cc2];
+        for (int tb = 0; tb < p; tb += 4) {
+          double lq[4], xq[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const int t = min(tb + q, p - 1);
+            lq[q] = s21[rc + ldb * t], xq[q] = xs[cc2 + ldb * t];
+          }
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+            if (tb + q < p) acc = fma(-lq[q], xq[q], acc);
+        }
+        if (ron && c2 < b && r16 >= c2) U[(long long)c2 * b + r16] = acc;
       }
     }
   }
+  FSTAMP(9);
 }
 
 // ---- tree solves of the small fronts: one wavefront per supernode does what the
-// A and B kernels below do for the general fronts (two launches per level, not four)
+// A and B kernels below do for the general fronts (two launches per level, not four).
+// Like the factorisation above they are latency chains: every load that depends on the
+// node alone (M, L21) is issued before anything else.
 __global__ void __launch_bounds__(64)
 k_solve_fwd_small(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
                   const double *__restrict__ linv, const long long *__restrict__ linv_off,
@@ -1212,7 +1451,22 @@ k_solve_fwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
   const int e0 = T.piv_start[node];
   const double *P = panel + T.panel_off[node];
   const double *W = linv + linv_off[node];
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5, r16 = lane & 15, cq = lane >> 4;
+  double wv[FS_MAXP / 2], lv[FS_MAXP / 4];  // M(i, t) for the t of parity h; L21(r16, 4u + cq)
+#pragma unroll
+  for (int u = 0; u < FS_MAXP / 2; u++) {
+    const int t = 2 * u + h;
+    const bool ok = i < p && t <= i;
+    const double w = W[ok ? (long long)t * p + i : 0];  // masked lanes read W[0]: no branch around the load
+    wv[u] = ok ? w : 0.0;
+  }
+#pragma unroll
+  for (int u = 0; u < FS_MAXP / 4; u++) {
+    const int c2 = 4 * u + cq;
+    const bool ok = r16 < b && c2 < p;
+    const double l = P[ok ? (long long)c2 * F + p + r16 : 0];
+    lv[u] = ok ? l : 0.0;
+  }
   int lpk = 0, pty = 0;
   double pd0 = 0.0, pd1 = 0.0;
   if (lane < p) {
@@ -1220,39 +1474,51 @@ k_solve_fwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
     pd0 = dinv[2 * (e0 + lane)], pd1 = dinv[2 * (e0 + lane) + 1];
     t1[lane] = rhs[e0 + lane];
   }
-  if (lane < b) cbs[lane] = 0.0;
+  if (lane < FS_MAXB) cbs[lane] = 0.0;
   __syncthreads();
-  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
-    const int ch = T.child_idx[cc], bc = T.nbor[ch];
-    const int *rel = T.rel + T.bptr[ch];
-    const double *cbc = cb + T.cb_off[ch];
-    for (int ii = lane; ii < bc; ii += 64) {
-      const int ri = rel[ii];
-      if (ri < p)
-        t1[ri] += cbc[ii];
+  const int c0 = T.child_ptr[node], c1 = T.child_ptr[node + 1];
+  for (int cc = c0; cc < c1; cc += 2) {  // two children's loads in flight (their borders have <= 48 rows)
+    const bool two = cc + 1 < c1;
+    const int ch0 = T.child_idx[cc], ch1 = T.child_idx[two ? cc + 1 : cc];
+    const int bc0 = T.nbor[ch0], bc1 = two ? T.nbor[ch1] : 0;
+    const int *rel0 = T.rel + T.bptr[ch0], *rel1 = T.rel + T.bptr[ch1];
+    const double *cb0 = cb + T.cb_off[ch0], *cb1 = cb + T.cb_off[ch1];
+    const int ri0 = lane < bc0 ? rel0[lane] : -1, ri1 = lane < bc1 ? rel1[lane] : -1;
+    const double v0 = lane < bc0 ? cb0[lane] : 0.0, v1 = lane < bc1 ? cb1[lane] : 0.0;
+    if (ri0 >= 0) {
+      if (ri0 < p)
+        t1[ri0] += v0;
       else
-        cbs[ri - p] += cbc[ii];
+        cbs[ri0 - p] += v0;
+    }
+    __syncthreads();
+    if (ri1 >= 0) {
+      if (ri1 < p)
+        t1[ri1] += v1;
+      else
+        cbs[ri1 - p] += v1;
     }
     __syncthreads();
   }
-  if (lane < p) tp[lane] = t1[lpk];
+  if (lane < FS_MAXP) tp[lane] = lane < p ? t1[lpk] : 0.0;
   __syncthreads();
-  if (lane < p) {  // y = M tp
-    double acc = 0.0;
-    for (int t = 0; t <= lane; t++) acc = fma(W[(long long)t * p + lane], tp[t], acc);
-    y[lane] = acc;
-  }
+  double acc = 0.0;  // y = M tp: the columns of parity h, then both halves
+#pragma unroll
+  for (int u = 0; u < FS_MAXP / 2; u++) acc = fma(wv[u], tp[2 * u + h], acc);
+  acc += __shfl_xor(acc, 32);
+  if (lane < FS_MAXP) y[lane] = lane < p ? acc : 0.0;
   __syncthreads();
   if (lane < p) {
     const int kp = pty == 2 ? lane - 1 : min(lane + 1, p - 1);
     xsol[e0 + lane] = pty == 0 ? y[lane] * pd0 : y[lane] * pd0 + y[kp] * pd1;
     ytmp[e0 + lane] = y[lane];
   }
-  if (lane < b) {  // contribution -= L21 y
-    double acc = cbs[lane];
-    for (int c2 = 0; c2 < p; c2++) acc = fma(-P[(long long)c2 * F + p + lane], y[c2], acc);
-    cb[T.cb_off[node] + lane] = acc;
-  }
+  double s = 0.0;  // contribution -= L21 y
+#pragma unroll
+  for (int u = 0; u < FS_MAXP / 4; u++) s = fma(lv[u], y[4 * u + cq], s);
+  s += __shfl_xor(s, 16);
+  s += __shfl_xor(s, 32);
+  if (lane < b) cb[T.cb_off[node] + lane] = cbs[lane] - s;
 }
 
 __global__ void __launch_bounds__(64)
@@ -1267,22 +1533,37 @@ k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
   const double *P = panel + T.panel_off[node];
   const double *W = linv + linv_off[node];
   const int *bi = T.bidx + T.bptr[node];
-  const int lane = threadIdx.x;
-  if (lane < b) x2[lane] = xsol[bi[lane]];
-  __syncthreads();
-  int lpk = 0;
-  if (lane < p) {  // v = yd - L21' x(border)
-    lpk = lperm[e0 + lane];
-    double acc = xsol[e0 + lane];
-    for (int r = 0; r < b; r++) acc = fma(-P[(long long)lane * F + p + r], x2[r], acc);
-    v[lane] = acc;
+  const int lane = threadIdx.x, i = lane & 31, h = lane >> 5;
+  double pv[FS_MAXB / 2], wv[FS_MAXP / 2];  // L21(2u + h, i); M(2u + h, i)
+#pragma unroll
+  for (int u = 0; u < FS_MAXB / 2; u++) {
+    const int r = 2 * u + h;
+    const bool ok = i < p && r < b;
+    const double l = P[ok ? (long long)i * F + p + r : 0];
+    pv[u] = ok ? l : 0.0;
   }
-  __syncthreads();
-  if (lane < p) {  // z = M' v, x1 = P' z
-    double acc = 0.0;
-    for (int r = lane; r < p; r++) acc = fma(W[(long long)lane * p + r], v[r], acc);
-    xsol[e0 + lpk] = acc;
+#pragma unroll
+  for (int u = 0; u < FS_MAXP / 2; u++) {
+    const int r = 2 * u + h;
+    const bool ok = i < p && r >= i && r < p;
+    const double w = W[ok ? (long long)i * p + r : 0];
+    wv[u] = ok ? w : 0.0;
   }
+  if (lane < FS_MAXB) x2[lane] = lane < b ? xsol[bi[lane]] : 0.0;
+  const int lpk = i < p ? lperm[e0 + i] : 0;
+  const double xv = i < p ? xsol[e0 + i] : 0.0;
+  __syncthreads();
+  double acc = 0.0;  // v = yd - L21' x(border)
+#pragma unroll
+  for (int u = 0; u < FS_MAXB / 2; u++) acc = fma(pv[u], x2[2 * u + h], acc);
+  acc += __shfl_xor(acc, 32);
+  if (lane < FS_MAXP) v[lane] = lane < p ? xv - acc : 0.0;
+  __syncthreads();
+  double z = 0.0;  // z = M' v, x1 = P' z
+#pragma unroll
+  for (int u = 0; u < FS_MAXP / 2; u++) z = fma(wv[u], v[2 * u + h], z);
+  z += __shfl_xor(z, 32);
+  if (lane < p) xsol[e0 + lpk] = z;
 }
 
 // --------------------------------------------------- panel solve (border rows)

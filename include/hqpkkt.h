@@ -78,7 +78,16 @@ typedef struct hqpkkt_opts {
                         the whole factorisation: tree levels are re-assigned as late as possible
                         and the blocks of even / odd levels alternate between two half-arenas
                         (0 = default 16384, < 0 = never)                                      */
-  int reserved[2];
+  int amalgamation;  /* 1 = a separator of the nested dissection absorbs its child separators while
+                        the merged pivot set still fits a small front (<= 32 pivots, elimination
+                        order unchanged).  For narrow bands (a handful of rows per separator) the
+                        tree levels above the leaves shrink to a third, and a level costs launch
+                        latency there, not arithmetic: +7..12 % interior-point iterations/s on the
+                        Prg_DID structure.  Default 0: the Bunch-Kaufman search then runs over
+                        larger, mostly zero pivot blocks and picks other pivots; in the last
+                        iterations of a degenerate QP (weights z/w spread over 15 decades) that
+                        cost accuracy on one of the reference cases       */
+  int reserved[1];
 } hqpkkt_opts;
 
 typedef struct hqpkkt_stats {

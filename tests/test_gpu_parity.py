@@ -313,6 +313,33 @@ def test_fused_small_fronts_agree_with_the_general_kernels(kind):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", KINDS)
+def test_amalgamated_separators_agree(kind):
+    """Narrow bands, hqpkkt_opts.amalgamation: a separator absorbs its child separators while
+    the merged pivot set still fits a small front.  Fewer tree levels, every front still a
+    small front, the same solution to rounding."""
+    cls = ipmatrix.IpSpBKP if kind == "SpBKP" else ipmatrix.IpRedSpBKP
+    for prog, spread in ((problems.did_like_qp(600), 0.0), (problems.did_like_qp(600), 4.0),
+                         (problems.banded_qp(2000, 3, 8), 1.0)):
+        st = problems.ip_state(prog, 5, spread)
+        sol, lev = [], []
+        for am in (False, True):
+            M = cls(amalgamation=am)
+            M.init(prog)
+            M.factor(prog, st[0], st[1])
+            d = new_d(prog)
+            res = M.solve(prog, *st, *d)
+            assert res <= (1e-10 if spread <= 1.0 else 1e-8)  # z/w spread over eight decades: five rounds may not do
+            sol.append(d)
+            lev.append(M.stats()["n_levels"])
+            if am:
+                p, b = np.array(M.debug(2)), np.array(M.debug(3))
+                assert p.max() <= 32 and b.max() <= 16
+        assert lev[1] < lev[0]
+        assert rel_err(sol[1], sol[0]) < 1e-8
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("case", ["banded", "random", "did"])
 def test_pingpong_update_arena_agrees(case):
     """Large systems do not keep every supernode's update block for the whole

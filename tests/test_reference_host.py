@@ -81,12 +81,13 @@ def test_reference_ip_solver_drives_hip_plugin(solver, pair, case):
         assert abs(fr - fh) <= 1e-5 * max(1.0, abs(fr)), info
         assert hip["iters"] <= ref["iters"] + max(2, ref["iters"] // 10), info
         return
-    if {hip["result"], ref["result"]} == {0, 3} and abs(hip["iters"] - ref["iters"]) <= 1:
+    if {hip["result"], ref["result"]} == {0, 3} and abs(hip["iters"] - ref["iters"]) <= 2:
         # one of the two misses the final test mu <= eps, |r| <= eps |data| (hqp/Hqp_IpsMehrotra.C:487)
-        # by a hair in the last iteration and reports "suboptimal" one iteration later: the last
-        # bits of the step decide (the reference's own two plugins differ the same way on DID
-        # K=50).  The optimiser must agree all the more.
-        assert abs(fr - fh) <= 1e-7 * max(1.0, abs(fr)), info
+        # by a hair in the last iteration and reports "suboptimal" an iteration or two later (the
+        # stall test needs two iterations without progress): the last bits of the step decide
+        # (the reference's own two plugins differ the same way on DID K=50).  The optimiser must
+        # agree all the more.
+        assert abs(fr - fh) <= 1e-8 * max(1.0, abs(fr)), info
         return
     assert hip["result"] == ref["result"], info
     # Mehrotra ignores the residual solve() returns; Franke tests it against qp_eps
