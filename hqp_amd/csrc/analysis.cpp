@@ -899,7 +899,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
           for (int tj = 0; tj <= ti; tj++) S.upd_tiles.insert(S.upd_tiles.end(), {id, ti, tj});
         int ns = (b + SLAB_ROWS - 1) / SLAB_ROWS;
         for (int sl = 0; sl < ns; sl++) S.slabs.insert(S.slabs.end(), {id, sl});
-        for (int sl = 0; sl < (b + 63) / 64; sl++) S.gslabs.insert(S.gslabs.end(), {id, sl});
+        for (int sl = 0; sl < std::max(1, (b + 63) / 64); sl++) S.gslabs.insert(S.gslabs.end(), {id, sl});
         for (int c = 0; c < (npiv[id] + 15) / 16; c++) S.cblks.insert(S.cblks.end(), {id, c});
       }
       S.upd_tile_ptr[l + 1] = (int)S.upd_tiles.size() / 3;

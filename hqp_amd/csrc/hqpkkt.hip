@@ -500,16 +500,13 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
                 k_solve_fwd_small<<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
                                                      h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
                                                      h->xsol.p, h->ytmp.p, h->cb.p));
-      if (nn > nfs)
-        KLAUNCH(h, KC_SOLVE_FWD,
-                k_solve_fwd_a<<<nn - nfs, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->linv.p,
-                                                 h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p,
-                                                 h->rhs.p, h->xsol.p, h->ytmp.p, h->cb.p));
-      const int ng = S.gslab_ptr[l + 1] - S.gslab_ptr[l];
+      const int ng = S.gslab_ptr[l + 1] - S.gslab_ptr[l];  // (front, 64-row slab), at least one per front
       if (ng > 0)
         KLAUNCH(h, KC_SOLVE_FWD,
-                k_solve_fwd_b<<<ng, 256, 0, s>>>(T, D.gslabs.p + 2 * (size_t)S.gslab_ptr[l], h->panel.p,
-                                                 h->ytmp.p, h->cb.p));
+                k_solve_fwd<<<ng, 256, 0, s>>>(T, D.gslabs.p + 2 * (size_t)S.gslab_ptr[l], h->panel.p, h->linv.p,
+                                               h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
+                                               h->xsol.p, h->ytmp.p, h->cb.p));
+      (void)nn;
     }
     return 0;
   };
@@ -525,6 +522,8 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
                 k_solve_bwd_small<<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
                                                      h->linv_off.p, h->lperm.p, h->xsol.p));
       if (nn <= nfs) continue;
+      // (one workgroup per front doing both steps was measured slower: L21' x needs the
+      // column blocks spread over the chip)
       KLAUNCH(h, KC_SOLVE_BWD,
               k_solve_bwd_b<<<ncb, 256, h->lds_bwdb, s>>>(T, D.cblks.p + 2 * (size_t)S.cblk_ptr[l],
                                                           h->panel.p, h->xsol.p, h->vtmp.p));
