@@ -128,6 +128,15 @@ def ip_iterations(K=2000):
                                       "seconds": info["ms_total"] * 1e-3, "factorisations": info["n_factor"],
                                       "solves": info["n_solve"],
                                       "ip_iters_per_s": info["iters"] / (info["ms_total"] * 1e-3)}
+        # optional (hqpkkt_opts.amalgamation, off by default): separators absorb their child
+        # separators, a third of the tree levels above the leaves
+        M = ipmatrix.IpRedSpBKP(amalgamation=True)
+        M.init(prog)
+        M.mehrotra(prog)
+        _x, _y, _z, _w, info = M.mehrotra(prog)
+        out["hip_device_resident_amalgamated"] = {"iters": info["iters"], "result": info["result"],
+                                                  "seconds": info["ms_total"] * 1e-3,
+                                                  "ip_iters_per_s": info["iters"] / (info["ms_total"] * 1e-3)}
         return out
     except Exception as e:  # never let the secondary measurement break the bench line
         return {"error": str(e)}

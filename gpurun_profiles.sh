@@ -11,5 +11,13 @@ cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/r01_kernel_stats.csv
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- python3 bench.py --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O
+# the device-resident Mehrotra loop on the Prg_DID structure (second half of the metric): kernel
+# statistics and the kernel timeline of one iteration (launch gaps = host round trips)
+for K in 2000 33333; do
+  rocprofv3 --kernel-trace --stats -d $O/ip$K -o ip -- python3 tools/ip_profile.py $K RedSpBKP > $O/r01_ip_K${K}_run.txt 2>/dev/null
+  python3 tools/kstat.py $O/ip$K/ip_results.db k_factor_diag_small 16 > $O/r01_ip_K${K}_kernels.txt 2>&1
+  python3 tools/timeline.py $O/ip$K/ip_results.db > $O/r01_ip_K${K}_timeline.txt 2>&1
+  rm -rf $O/ip$K
+done
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write
 ls -la $O

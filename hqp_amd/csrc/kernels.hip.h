@@ -1711,7 +1711,7 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
 // A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
 // C/D: 4 values per lane, col = l&15, row = (l>>4) + 4*reg  (f64 layout).
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 3)
 k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restrict__ panel,
                const double *__restrict__ xar, double *__restrict__ upd) {
   const int node = tiles[3 * blockIdx.x], ti = tiles[3 * blockIdx.x + 1],
