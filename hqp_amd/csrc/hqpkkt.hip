@@ -174,6 +174,11 @@ struct hqpkkt {
     unsigned long long *p = nullptr;
   } bits;
   double *hpin = nullptr;  // 128 doubles: 0..63 status words (as ints), 64.. the IP loop's scalars
+  // host vectors of a small system: packed into / out of pinned memory by the CPU, ONE
+  // transfer each way instead of six + four staged copies from pageable memory
+  double *hstage = nullptr;
+  size_t hstage_in = 0, hstage_out = 0;  // doubles; 0 = system too large, copy vector by vector
+  const double *out_pending = nullptr;   // results wait in hstage + hstage_in for unstage()
   // vectors: staging for host pointers + refinement work vectors
   DBuf<double> vin;   // z w r1 r2 r3 r4
   DBuf<double> vout;  // dx dy dz dw
@@ -221,6 +226,8 @@ struct hqpkkt {
     for (auto b : db) b->release();
     terms.release(), esign.release(), bits.p = nullptr;
     if (hpin) (void)hipHostFree(hpin), hpin = nullptr;
+    if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
+    hstage_in = hstage_out = 0;
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
     drop_graphs();
     uploaded = have_values = factored = false;
@@ -326,6 +333,15 @@ static int upload(hqpkkt_t *h) {
     return e;
   h->bits.p = (unsigned long long *)(h->flags.p + 120);
   if (!h->hpin) HIPCHK(hipHostMalloc((void **)&h->hpin, sizeof(double) * 128, hipHostMallocDefault));
+  if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr;
+  h->hstage_in = h->hstage_out = 0;
+  {
+    const size_t nin = 4 * (size_t)m + n + me, nout = (size_t)n + me + 2 * (size_t)m;
+    if ((nin + nout) * sizeof(double) <= (size_t)512 * 1024 && nin + nout > 0) {
+      HIPCHK(hipHostMalloc((void **)&h->hstage, sizeof(double) * (nin + nout), hipHostMallocDefault));
+      h->hstage_in = nin, h->hstage_out = nout;
+    }
+  }
   {
     std::vector<double> ones(dim, 1.0);
     HIPCHK(hipMemcpy(h->sc.p, ones.data(), sizeof(double) * dim, hipMemcpyHostToDevice));
@@ -371,6 +387,17 @@ static int stage_in(hqpkkt_t *h, const double *z, const double *w, const double 
   if (h->opts.loc == HQPKKT_LOC_DEVICE) {
     CopyList L{{z, w, r1, r2, r3, r4}, {dz_, dw_, d1, d2, d3, d4}, {m, m, n, me, m, m}};
     k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 6);
+  } else if (h->hstage_in) {
+    // packed by the CPU; the prefix up to the last vector the caller passes
+    double *q = h->hstage;
+    const double *src[6] = {z, w, r1, r2, r3, r4};
+    const int len[6] = {m, m, n, me, m, m};
+    size_t used = 0, off = 0;
+    for (int k = 0; k < 6; k++) {
+      if (src[k] && len[k] > 0) std::memcpy(q + off, src[k], sizeof(double) * len[k]), used = off + len[k];
+      off += len[k];
+    }
+    if (used) HIPCHK(hipMemcpyAsync(b, q, sizeof(double) * used, hipMemcpyHostToDevice, h->stream));
   } else {
 #define H2D(dst, src, k) \
   if ((src) && (k) > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (k), hipMemcpyHostToDevice, h->stream))
@@ -398,6 +425,12 @@ static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double 
     k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 4);
     return 0;
   }
+  if (h->hstage_out) {  // one transfer into pinned memory; unstage() hands it out after the sync
+    HIPCHK(hipMemcpyAsync(h->hstage + h->hstage_in, v.dx, sizeof(double) * h->hstage_out, hipMemcpyDeviceToHost,
+                          h->stream));
+    h->out_pending = h->hstage + h->hstage_in;
+    return 0;
+  }
 #define D2H(dst, src, k) \
   if ((dst) && (k) > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (k), hipMemcpyDeviceToHost, h->stream))
   D2H(dx, v.dx, n);
@@ -406,6 +439,18 @@ static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double 
   D2H(dw, v.dw, m);
 #undef D2H
   return 0;
+}
+
+// after the stream has been drained: the packed results to the caller's vectors
+static void unstage(hqpkkt_t *h, double *dx, double *dy, double *dz, double *dw) {
+  if (!h->out_pending) return;
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  const double *q = h->out_pending;
+  h->out_pending = nullptr;
+  if (dx && n) std::memcpy(dx, q, sizeof(double) * n);
+  if (dy && me) std::memcpy(dy, q + n, sizeof(double) * me);
+  if (dz && m) std::memcpy(dz, q + n + me, sizeof(double) * m);
+  if (dw && m) std::memcpy(dw, q + n + me + m, sizeof(double) * m);
 }
 
 static_assert(FS_MAXP == kktdev::SMALL_PIVOTS && FS_MAXB == kktdev::SMALL_BORDER, "small-supernode kernels and schedule disagree");
@@ -851,6 +896,7 @@ int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w, const double *r1,
   HIPCHK(hipEventRecord(h->evs1, h->stream));
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
   HIPCHK(hipStreamSynchronize(h->stream));
+  unstage(h, dx, dy, dz, dw);
   h->prof.collect();
   h->st.ms_step = elapsed(h->evs0, h->evs1);
   return 0;
@@ -929,6 +975,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
   if (!h->lazy) {
     HIPCHK(hipStreamSynchronize(s));
+    unstage(h, dx, dy, dz, dw);
     h->prof.collect();
     h->st.ms_solve = elapsed(h->ev0, h->ev1);
   }
