@@ -453,6 +453,7 @@ static void unstage(hqpkkt_t *h, double *dx, double *dy, double *dz, double *dw)
   if (dw && m) std::memcpy(dw, q + n + me + m, sizeof(double) * m);
 }
 
+static const int FWD_FUSED_MAX_SLABS = 1024;  // above: forward step of a level in two launches
 static_assert(FS_MAXP == kktdev::SMALL_PIVOTS && FS_MAXB == kktdev::SMALL_BORDER, "small-supernode kernels and schedule disagree");
 // ------------------------------------------------------------ numeric phases
 // phases: 1 = assemble + this rank's subtrees, 2 = replicated top of the tree
@@ -546,12 +547,20 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
                                                      h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
                                                      h->xsol.p, h->ytmp.p, h->cb.p));
       const int ng = S.gslab_ptr[l + 1] - S.gslab_ptr[l];  // (front, 64-row slab), at least one per front
-      if (ng > 0)
+      if (ng > 0 && ng <= FWD_FUSED_MAX_SLABS)  // a handful of fronts: the launch is what costs
         KLAUNCH(h, KC_SOLVE_FWD,
                 k_solve_fwd<<<ng, 256, 0, s>>>(T, D.gslabs.p + 2 * (size_t)S.gslab_ptr[l], h->panel.p, h->linv.p,
                                                h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
                                                h->xsol.p, h->ytmp.p, h->cb.p));
-      (void)nn;
+      else if (ng > 0) {  // thousands of slabs: M once per front, then the slabs
+        KLAUNCH(h, KC_SOLVE_FWD,
+                k_solve_fwd_a<<<nn - nfs, 256, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->linv.p,
+                                                 h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p,
+                                                 h->rhs.p, h->xsol.p, h->ytmp.p, h->cb.p));
+        KLAUNCH(h, KC_SOLVE_FWD,
+                k_solve_fwd_b<<<ng, 256, 0, s>>>(T, D.gslabs.p + 2 * (size_t)S.gslab_ptr[l], h->panel.p,
+                                                 h->ytmp.p, h->cb.p));
+      }
     }
     return 0;
   };

@@ -1887,6 +1887,96 @@ __device__ __forceinline__ void mfma_lower_trans_times_vec(const double *__restr
   }
 }
 
+// forward step in two launches (levels with thousands of slabs: M is read once per front,
+// not once per slab): A gathers and computes y, B the slabs' L21 y
+__global__ void __launch_bounds__(256)
+k_solve_fwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ linv,
+              const long long *__restrict__ linv_off, const double *__restrict__ dinv,
+              const int *__restrict__ ptype, const int *__restrict__ lperm,
+              const double *__restrict__ rhs, double *__restrict__ xsol, double *__restrict__ ytmp,
+              double *__restrict__ cb) {
+  __shared__ double t1[128], tp[128], y[128];
+  const int node = level_nodes[blockIdx.x];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const int e0 = T.piv_start[node];
+  const double *W = linv + linv_off[node];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  double *cbn = cb + T.cb_off[node];
+  // this thread's pivot (tid < p): permutation and pivot data, loaded up front
+  int lpk = 0, pty = 0;
+  double pd0 = 0.0, pd1 = 0.0;
+  if (tid < p) {
+    lpk = lperm[e0 + tid], pty = ptype[e0 + tid];
+    pd0 = dinv[2 * (e0 + tid)], pd1 = dinv[2 * (e0 + tid) + 1];
+    t1[tid] = rhs[e0 + tid];
+  }
+  for (int i = tid; i < b; i += blockDim.x) cbn[i] = 0.0;
+  __syncthreads();
+  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+    const int c = T.child_idx[cc];
+    const int bc = T.nbor[c];
+    const int *rel = T.rel + T.bptr[c];
+    const double *cbc = cb + T.cb_off[c];
+    for (int i = tid; i < bc; i += blockDim.x) {
+      const int ri = rel[i];
+      if (ri < p)
+        t1[ri] += cbc[i];
+      else
+        cbn[ri - p] += cbc[i];
+    }
+    __syncthreads();
+  }
+  if (tid < p) tp[tid] = t1[lpk];
+  __syncthreads();
+  mfma_lower_times_vec(W, p, tp, y, wave, lane);
+  __syncthreads();
+  if (tid < p) {
+    const int kp = pty == 2 ? tid - 1 : min(tid + 1, p - 1);  // partner of a 2x2 pivot
+    xsol[e0 + tid] = pty == 0 ? y[tid] * pd0 : y[tid] * pd0 + y[kp] * pd1;
+    ytmp[e0 + tid] = y[tid];
+  }
+}
+
+// contribution(slab) -= L21(slab,:) y ; 64 rows per workgroup, the four waves
+// split the columns and their partial sums meet in LDS
+__global__ void __launch_bounds__(256)
+k_solve_fwd_b(DevTree T, const int *__restrict__ gslabs, const double *__restrict__ panel,
+              const double *__restrict__ ytmp, double *__restrict__ cb) {
+  __shared__ double part[4][64];
+  __shared__ double ysh[128];
+  const int node = gslabs[2 * blockIdx.x], slab = gslabs[2 * blockIdx.x + 1];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const long long F = p + b;
+  const int e0 = T.piv_start[node];
+  const double *L = panel + T.panel_off[node] + p;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int i = slab * 64 + lane;
+  for (int k = tid; k < p; k += blockDim.x) ysh[k] = ytmp[e0 + k];
+  __syncthreads();
+  double acc = 0.0;
+  if (i < b) {
+    double a8[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    for (int k0 = wave; k0 < p; k0 += 32) {  // 8 columns of this wave per trip, loads in flight together
+      double l[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 + 4 * u;
+        l[u] = k < p ? L[(long long)k * F + i] : 0.0;
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int k = k0 + 4 * u;
+        a8[u] += k < p ? l[u] * ysh[k] : 0.0;
+      }
+    }
+    acc = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+  }
+  part[wave][lane] = acc;
+  __syncthreads();
+  if (wave == 0 && i < b)
+    cb[T.cb_off[node] + i] -= (part[0][lane] + part[1][lane]) + (part[2][lane] + part[3][lane]);
+}
+
 // v(16 columns) = yd - L21(:, cols)' x(border)
 __global__ void __launch_bounds__(256)
 k_solve_bwd_b(DevTree T, const int *__restrict__ cblks, const double *__restrict__ panel,
