@@ -690,7 +690,12 @@ static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
 }
 
 // residual of (d) for rhs (r); leaves the residual vectors in h->vres
-static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
+// out != nullptr: the caller's copy of (d) is put into the stream before the read-back, so
+// that a solve that needs no refinement round is over with this one round trip
+struct OutPtrs {
+  double *dx, *dy, *dz, *dw;
+};
+static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *out = nullptr) {
   Analysis &an = h->an;
   hipStream_t s = h->stream;
   const int n = an.n, me = an.me, m = an.m;
@@ -704,6 +709,10 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res) {
     KLAUNCH(h, KC_RESIDUAL, k_residual<16><<<std::min(nblk(16LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
         v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
+  if (out) {
+    int e2 = stage_out(h, v, out->dx, out->dy, out->dz, out->dw);
+    if (e2) return e2;
+  }
   // one copy: the residual maximum and the status of the factorisation this solve belongs to
   const bool check = h->factor_unchecked;
   int *hs = (int *)h->hpin;
@@ -956,7 +965,9 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   HIPCHK(hipEventRecord(h->ev0, s));
   if ((e = do_step(h, v, 0))) return e;
   double res = 0.0, res_last;
-  if ((e = run_residual(h, v, &res))) return e;
+  const OutPtrs outp{dx, dy, dz, dw};
+  if ((e = run_residual(h, v, &res, h->lazy ? nullptr : &outp))) return e;
+  const bool refined = res > h->opts.eps;  // otherwise the caller's copy is already complete
   // correction solve: rhs = residual vectors, result = vcor
   Vecs c = v;
   c.r1 = h->vres.p, c.r2 = c.r1 + n, c.r3 = c.r2 + me, c.r4 = c.r3 + m;
@@ -981,9 +992,13 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
     if (alpha <= 0.0) break;
   }
   HIPCHK(hipEventRecord(h->ev1, s));
-  if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
-  if (!h->lazy) {
-    HIPCHK(hipStreamSynchronize(s));
+  if (h->lazy) {
+    if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
+  } else {
+    if (refined) {
+      if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
+    }
+    HIPCHK(hipStreamSynchronize(s));  // (returns at once when nothing was queued after the read-back)
     unstage(h, dx, dy, dz, dw);
     h->prof.collect();
     h->st.ms_solve = elapsed(h->ev0, h->ev1);
