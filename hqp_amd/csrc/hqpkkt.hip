@@ -1022,7 +1022,7 @@ struct IpCtx {
   int reduce(const int (&ops)[IP_SLOTS], int nout) {
     IpOps o;
     for (int k = 0; k < IP_SLOTS; k++) o.op[k] = ops[k];
-    k_ip_final<<<1, 256, 0, h->stream>>>(part, o, out);
+    k_ip_final<<<1, 256, 0, h->stream>>>(part, o, out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
     HIPCHK(hipMemcpyAsync(hout, out, sizeof(double) * nout, hipMemcpyDeviceToHost, h->stream));
     HIPCHK(hipStreamSynchronize(h->stream));
     return 0;
@@ -1168,7 +1168,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, nullptr, C.r4);
     if ((e2 = solve(C.dx, C.dy, C.dz, C.dw))) return e2;
     k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk);
+    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk, m, gamma, nullptr);
     HIPCHK(hipMemcpyAsync(C.hout, Bk, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
     const double zmin = C.hout[0], wmin = C.hout[6];
@@ -1230,7 +1230,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
       IpOps o2;
       for (int k = 0; k < IP_SLOTS; k++) o2.op[k] = ops2[k];
-      k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out);
+      k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
       HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
       HIPCHK(hipStreamSynchronize(s));
     }
@@ -1290,15 +1290,14 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     // From here to the step itself nothing is read back: sigma (Terlaky's modification,
     // :583-590; the safe value when the predictor step is short and the reference skips the
     // first corrector, :612-616), the corrector's blocking components, the damped step length
-    // (:629-672) are computed by one-thread kernels and consumed through device pointers.
+    // (:629-672) are computed by thread 0 of the reduction kernels and consumed through device pointers.
     k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.part);
     {
       const int ops3[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
       IpOps o3;
       for (int k = 0; k < IP_SLOTS; k++) o3.op[k] = ops3[k];
-      k_ip_final<<<1, 256, 0, s>>>(C.part, o3, C.out);
+      k_ip_final<<<1, 256, 0, s>>>(C.part, o3, C.out, IpEpi{1, m, mu, gamma, 0.0, nullptr, S});
     }
-    k_ip_sigma<<<1, 1, 0, s>>>(C.out, mu, gamma, S);
     k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, 0.0, S + IPS_SMM, C.r4);
     if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
       if (e == HQPKKT_E_SING) return finish(4);
@@ -1306,15 +1305,13 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       return e;
     }
     k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk);
-    k_ip_alpha_pre<<<1, 1, 0, s>>>(Bk, m, gamma, S);
+    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk, m, gamma, S);
     k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, S + IPS_ALPHA_PRE, C.z, C.w, C.dz, C.dw, C.part);
     {
       IpOps on;
       for (int k = 0; k < IP_SLOTS; k++) on.op[k] = IP_SUM;
-      k_ip_final<<<1, 256, 0, s>>>(C.part, on, C.out);
+      k_ip_final<<<1, 256, 0, s>>>(C.part, on, C.out, IpEpi{2, m, 0.0, 0.0, o.gammaf, Bk, S});
     }
-    k_ip_alpha_fin<<<1, 1, 0, s>>>(C.out, Bk, m, o.gammaf, S);
     k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 0.0, S + IPS_ALPHA, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw,
                                           C.part);
     // (:684-690: a non-finite mu or x ends the solve as degenerate; seen here by the next

@@ -34,12 +34,86 @@ __device__ __forceinline__ double nan_to_inf(double a) {
 struct IpOps {
   int op[IP_SLOTS];
 };
-__global__ void __launch_bounds__(256) k_ip_final(const double *__restrict__ part, IpOps ops, double *__restrict__ out) {
+// ---- the scalar logic of a step on the device (thread 0 of the final reduction kernels, no
+// launches of its own): the host reads the results
+// together with the next iteration's convergence data instead of stopping the stream
+// after every reduction.  S: 0 alpha_aff, 1 sigma mu, 2 alpha before damping, 3 damping
+// needed (0/1), 4 second corrector needed (0/1), 5 alpha of the step (0 if 4), 6 sigma
+#define IPS_ALPHA_AFF 0
+#define IPS_SMM 1
+#define IPS_ALPHA_PRE 2
+#define IPS_DAMP 3
+#define IPS_NEED2 4
+#define IPS_ALPHA 5
+#define IPS_SIGMA 6
+// Terlaky's sigma (hqp/Hqp_IpsMehrotra.C:583-590); the safe one when the predictor step
+// is short (:612-616, the first corrector is skipped then).  red: 0 min ratio, 1 t
+__device__ __forceinline__ void ip_sigma(const double *__restrict__ red, double mu, double gamma, double *__restrict__ S) {
+  const double alpha_aff = fmax(0.0, fmin(fmin(1.0, red[0]), 1.0));
+  const double t = red[1];
+  const double sigma = alpha_aff >= 0.1 ? gamma * (t + 1.0 - alpha_aff) / (1.0 - gamma) : gamma / (1.0 - gamma);
+  S[IPS_ALPHA_AFF] = alpha_aff, S[IPS_SIGMA] = sigma, S[IPS_SMM] = sigma * mu;
+}
+// after the corrector: its own largest step (:604-611) decides about a second corrector
+// (:612); Mehrotra's step rule up to the damping (:629-656).  B: k_ip_minratio_final's 12
+__device__ __forceinline__ void ip_alpha_pre(const double *__restrict__ B, int m, double gamma, double *__restrict__ S) {
+  const double zmin = B[0], wmin = B[6];
+  const int izmin = (int)B[1], iwmin = (int)B[7];
+  const double amin = fmin(izmin < 0 ? 1e300 : zmin, iwmin < 0 ? 1e300 : wmin);
+  const double alpha_corr = fmax(0.0, fmin(fmin(1.0, amin), 1.0));
+  S[IPS_NEED2] = (S[IPS_ALPHA_AFF] >= 0.1 && alpha_corr < gamma * gamma / 2.0 / m / m) ? 1.0 : 0.0;
+  double alpha;
+  if (izmin < 0 && iwmin < 0)
+    alpha = 1.0, S[IPS_DAMP] = 0.0;
+  else {
+    alpha = izmin < 0 ? wmin : iwmin < 0 ? zmin : fmin(zmin, wmin);
+    S[IPS_DAMP] = 1.0;
+  }
+  S[IPS_ALPHA_PRE] = alpha;
+}
+// the damped step (:657-672).  red: 0 (z + alpha dz)'(w + alpha dw)
+__device__ __forceinline__ void ip_alpha_fin(const double *__restrict__ red, const double *__restrict__ B, int m, double gammaf,
+                               double *__restrict__ S) {
+  double alpha = S[IPS_ALPHA_PRE];
+  if (S[IPS_DAMP] != 0.0) {
+    const double zmin = B[0], wmin = B[6];
+    const int izmin = (int)B[1], iwmin = (int)B[7];
+    const double z_iz = B[2], dz_iz = B[3], w_iz = B[4], dw_iz = B[5];
+    const double z_iw = B[8], dz_iw = B[9], w_iw = B[10], dw_iw = B[11];
+    const double mu_pl = red[0] / m;
+    double fpd;
+    if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
+      fpd = (gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
+    else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
+      fpd = (gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
+    else
+      fpd = 0.0;
+    alpha = fmax(0.0, fmin(fmax(1.0 - gammaf, fpd) * alpha, 1.0));
+  }
+  S[IPS_ALPHA] = S[IPS_NEED2] != 0.0 ? 0.0 : alpha;  // a second corrector first: this step is not taken
+}
+
+// what thread 0 does with the reduced values before the kernel ends
+struct IpEpi {
+  int kind;  // 0 nothing, 1 sigma (k_ip_ratio's reduction), 2 damped step length (k_ip_mupl's)
+  int m;
+  double mu, gamma, gammaf;
+  const double *B;  // k_ip_minratio_final's 12 values
+  double *S;
+};
+__global__ void __launch_bounds__(256)
+k_ip_final(const double *__restrict__ part, IpOps ops, double *__restrict__ out, IpEpi epi) {
   __shared__ double red[4];
+  double mine[IP_SLOTS];
   for (int k = 0; k < IP_SLOTS; k++) {
     const double v = part[threadIdx.x * IP_SLOTS + k];  // IP_BLOCKS == blockDim.x
     const double r = ip_block_reduce(v, ops.op[k], red);
+    mine[k] = r;
     if (threadIdx.x == 0) out[k] = r;
+  }
+  if (threadIdx.x == 0) {
+    if (epi.kind == 1) ip_sigma(mine, epi.mu, epi.gamma, epi.S);
+    if (epi.kind == 2) ip_alpha_fin(mine, epi.B, epi.m, epi.gammaf, epi.S);
   }
 }
 
@@ -171,7 +245,8 @@ k_ip_minratio_part(int m, const double *__restrict__ z, const double *__restrict
 }
 __global__ void __launch_bounds__(256)
 k_ip_minratio_final(const double *__restrict__ part, const double *__restrict__ z, const double *__restrict__ w,
-                    const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ out) {
+                    const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ out, int m,
+                    double gamma, double *__restrict__ S) {  // S != nullptr: Mehrotra's step rule up to the damping
   __shared__ double sv[256];
   __shared__ int si[256];
   for (int pass = 0; pass < 2; pass++) {
@@ -194,6 +269,7 @@ k_ip_minratio_final(const double *__restrict__ part, const double *__restrict__ 
       // the four components the damping rule looks at (:660-668)
       out[6 * pass + 2] = none ? 0.0 : z[i], out[6 * pass + 3] = none ? 0.0 : dz[i];
       out[6 * pass + 4] = none ? 0.0 : w[i], out[6 * pass + 5] = none ? 0.0 : dw[i];
+      if (pass == 1 && S) ip_alpha_pre(out, m, gamma, S);  // same thread wrote all twelve values
     }
     __syncthreads();
   }
@@ -249,64 +325,6 @@ k_ip_update(int n, int me, int m, double alpha, const double *__restrict__ alpha
     P[1] = r;
     for (int k = 2; k < IP_SLOTS; k++) P[k] = 0.0;
   }
-}
-
-// ---- the scalar logic of a step on the device (one thread): the host reads the results
-// together with the next iteration's convergence data instead of stopping the stream
-// after every reduction.  S: 0 alpha_aff, 1 sigma mu, 2 alpha before damping, 3 damping
-// needed (0/1), 4 second corrector needed (0/1), 5 alpha of the step (0 if 4), 6 sigma
-#define IPS_ALPHA_AFF 0
-#define IPS_SMM 1
-#define IPS_ALPHA_PRE 2
-#define IPS_DAMP 3
-#define IPS_NEED2 4
-#define IPS_ALPHA 5
-#define IPS_SIGMA 6
-// Terlaky's sigma (hqp/Hqp_IpsMehrotra.C:583-590); the safe one when the predictor step
-// is short (:612-616, the first corrector is skipped then).  red: 0 min ratio, 1 t
-__global__ void k_ip_sigma(const double *__restrict__ red, double mu, double gamma, double *__restrict__ S) {
-  const double alpha_aff = fmax(0.0, fmin(fmin(1.0, red[0]), 1.0));
-  const double t = red[1];
-  const double sigma = alpha_aff >= 0.1 ? gamma * (t + 1.0 - alpha_aff) / (1.0 - gamma) : gamma / (1.0 - gamma);
-  S[IPS_ALPHA_AFF] = alpha_aff, S[IPS_SIGMA] = sigma, S[IPS_SMM] = sigma * mu;
-}
-// after the corrector: its own largest step (:604-611) decides about a second corrector
-// (:612); Mehrotra's step rule up to the damping (:629-656).  B: k_ip_minratio_final's 12
-__global__ void k_ip_alpha_pre(const double *__restrict__ B, int m, double gamma, double *__restrict__ S) {
-  const double zmin = B[0], wmin = B[6];
-  const int izmin = (int)B[1], iwmin = (int)B[7];
-  const double amin = fmin(izmin < 0 ? 1e300 : zmin, iwmin < 0 ? 1e300 : wmin);
-  const double alpha_corr = fmax(0.0, fmin(fmin(1.0, amin), 1.0));
-  S[IPS_NEED2] = (S[IPS_ALPHA_AFF] >= 0.1 && alpha_corr < gamma * gamma / 2.0 / m / m) ? 1.0 : 0.0;
-  double alpha;
-  if (izmin < 0 && iwmin < 0)
-    alpha = 1.0, S[IPS_DAMP] = 0.0;
-  else {
-    alpha = izmin < 0 ? wmin : iwmin < 0 ? zmin : fmin(zmin, wmin);
-    S[IPS_DAMP] = 1.0;
-  }
-  S[IPS_ALPHA_PRE] = alpha;
-}
-// the damped step (:657-672).  red: 0 (z + alpha dz)'(w + alpha dw)
-__global__ void k_ip_alpha_fin(const double *__restrict__ red, const double *__restrict__ B, int m, double gammaf,
-                               double *__restrict__ S) {
-  double alpha = S[IPS_ALPHA_PRE];
-  if (S[IPS_DAMP] != 0.0) {
-    const double zmin = B[0], wmin = B[6];
-    const int izmin = (int)B[1], iwmin = (int)B[7];
-    const double z_iz = B[2], dz_iz = B[3], w_iz = B[4], dw_iz = B[5];
-    const double z_iw = B[8], dz_iw = B[9], w_iw = B[10], dw_iw = B[11];
-    const double mu_pl = red[0] / m;
-    double fpd;
-    if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
-      fpd = (gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
-    else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
-      fpd = (gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
-    else
-      fpd = 0.0;
-    alpha = fmax(0.0, fmin(fmax(1.0 - gammaf, fpd) * alpha, 1.0));
-  }
-  S[IPS_ALPHA] = S[IPS_NEED2] != 0.0 ? 0.0 : alpha;  // a second corrector first: this step is not taken
 }
 
 // cold start (:236-252): z = w = 1, r1 = c, r2 = -b, r3 = -d, r4 = 0

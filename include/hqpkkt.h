@@ -86,7 +86,7 @@ typedef struct hqpkkt_opts {
                         Prg_DID structure.  Default 0: the Bunch-Kaufman search then runs over
                         larger, mostly zero pivot blocks and picks other pivots; in the last
                         iterations of a degenerate QP (weights z/w spread over 15 decades) that
-                        cost accuracy on one of the reference cases (DESIGN.md section 6)       */
+                        cost accuracy on one of the reference cases (DESIGN.md section 4)       */
   int reserved[1];
 } hqpkkt_opts;
 
