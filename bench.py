@@ -142,6 +142,45 @@ def ip_iterations(K=2000):
         return {"error": str(e)}
 
 
+def concurrent_systems(prog, state, cls, local_rank, steps, counts=(2, 4)):
+    """Extra information, never `value`: aggregate factor+solve/s when SEVERAL independent
+    KKT systems of the bench's size are in flight on the one GPU (one handle + stream + host
+    thread each; scenario trees, the QPs of separate SQP runs).  A single C2 system leaves
+    most of the chip idle (its upper tree levels are a handful of workgroups), so the
+    aggregate rate says how much of that idle time other systems can use."""
+    import threading
+    import torch
+    out = {}
+    try:
+        mats, vecs = [], []
+        for k in range(max(counts)):
+            m = cls(device=local_rank, device_vectors=True)
+            m.init(prog)
+            dev = [torch.as_tensor(a).cuda() for a in state]
+            d = [torch.zeros(q, dtype=torch.float64, device="cuda") for q in (prog.n, prog.me, prog.m, prog.m)]
+            m.factor(prog, dev[0], dev[1])
+            m.solve(prog, *dev, *d)
+            mats.append(m), vecs.append((dev, d))
+        for c in counts:
+            def work(i):
+                dev, d = vecs[i]
+                for _ in range(steps):
+                    mats[i].factor(prog, dev[0], dev[1])
+                    mats[i].solve(prog, *dev, *d)
+            th = [threading.Thread(target=work, args=(i,)) for i in range(c)]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for t in th:
+                t.start()
+            for t in th:
+                t.join()
+            torch.cuda.synchronize()
+            out[str(c)] = c * steps / (time.perf_counter() - t0)
+    except Exception as e:  # never let the secondary measurement break the bench line
+        out["error"] = str(e)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -300,6 +339,8 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(prog, state)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+            if not args.host_vectors:
+                out["concurrent_systems_per_gpu"] = concurrent_systems(prog, state, cls, local_rank, args.steps)
             out["ip_iterations"] = ip_iterations(2000)
             out["ip_iterations_large"] = ip_iterations(33333)
         print(json.dumps(out))
