@@ -194,7 +194,26 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   TMARK("1");
   // ------------------------------------------------------------- entries
   std::vector<RawEntry> raw;
-  raw.reserve((size_t)nq + na + (mode == 0 ? (size_t)nc + m : 4 * (size_t)nc));
+  if (mode == 0) {
+    // FULL: every entry is a single term and the sorted order (row-major over the upper
+    // triangle: x row i holds its Q entries, then column i of A, then column i of C; the
+    // slack rows hold their diagonal) can be written down directly - no 48-byte records,
+    // no sort (dense stage blocks: 10^7..10^8 entries)
+    const size_t tot = (size_t)na + nc + m + (size_t)nq;
+    ent_a.clear(), ent_b.clear(), term_ptr.assign(1, 0), terms.clear();
+    ent_a.reserve(tot), ent_b.reserve(tot), terms.reserve(tot), term_ptr.reserve(tot + 1);
+    auto put = [&](int a, int b, Term t) {
+      ent_a.push_back(a), ent_b.push_back(b), terms.push_back(t), term_ptr.push_back((int)terms.size());
+    };
+    for (int i = 0; i < n; i++) {
+      for (int k = Qp[i]; k < Qp[i + 1]; k++)
+        if (Qi[k] >= i) put(i, Qi[k], {k, ONE, WONE, -1.0});
+      for (int t = AT.ptr[i]; t < AT.ptr[i + 1]; t++) put(i, n + AT.col[t], {AT.src[t], ONE, WONE, 1.0});
+      for (int t = CT.ptr[i]; t < CT.ptr[i + 1]; t++) put(i, n + me + CT.col[t], {CT.src[t], ONE, WONE, 1.0});
+    }
+    for (int j = 0; j < m; j++) put(n + me + j, n + me + j, {ONE, ONE, j, 1.0});
+  } else {
+  raw.reserve((size_t)nq + na + 4 * (size_t)nc);
   auto add = [&](int a, int b, Term t) {
     int lo = std::min(a, b), hi = std::max(a, b);
     raw.push_back({(long long)lo * dim + hi, lo, hi, t});
@@ -204,17 +223,10 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       if (Qi[k] >= i) add(i, Qi[k], {k, ONE, WONE, -1.0});
   for (int r = 0; r < me; r++)
     for (int k = Ap[r]; k < Ap[r + 1]; k++) add(n + r, Ai[k], {nq + k, ONE, WONE, 1.0});
-  if (mode == 0) {
-    for (int r = 0; r < m; r++)
-      for (int k = Cp[r]; k < Cp[r + 1]; k++)
-        add(n + me + r, Ci[k], {nq + na + k, ONE, WONE, 1.0});
-    for (int j = 0; j < m; j++) add(n + me + j, n + me + j, {ONE, ONE, j, 1.0});
-  } else {
-    for (int r = 0; r < m; r++)
-      for (int a = Cp[r]; a < Cp[r + 1]; a++)
-        for (int b = Cp[r]; b <= a; b++)
-          add(Ci[a], Ci[b], {nq + na + a, nq + na + b, r, -1.0});
-  }
+  for (int r = 0; r < m; r++)
+    for (int a = Cp[r]; a < Cp[r + 1]; a++)
+      for (int b = Cp[r]; b <= a; b++)
+        add(Ci[a], Ci[b], {nq + na + a, nq + na + b, r, -1.0});
   // entries with the same (row, col) are merged into one entry with several terms; the
   // order is (key, order of generation).  Sorting (key, index) pairs instead of the
   // 48-byte records keeps this phase short for the 10^7..10^8 entries of dense stage blocks.
@@ -233,6 +245,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       terms.push_back(r.t);
     }
     term_ptr.push_back((int)terms.size());
+  }
   }
   { std::vector<RawEntry>().swap(raw); }
   const int nent = (int)ent_a.size();
@@ -945,16 +958,27 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
     ent_dst[e] = panel_off[o] + (long long)lc * F + lr;
   }
+  TMARK("9");
   // store the entries in destination order: the numeric scatter then writes
   // (mostly) consecutive addresses from consecutive threads
   {
     std::vector<int> perm(nent);
     {
-      std::vector<std::pair<long long, int>> order(nent);  // destinations are distinct
-      for (int k = 0; k < nent; k++) order[k] = {ent_dst[k], k};
-      radix_sort_pairs(order);
-      for (int k = 0; k < nent; k++) perm[k] = order[k].second;
+      // destinations are distinct and ascend with (elimination column, row): a counting sort
+      // by column, then each column's handful of entries by row
+      std::vector<int> cptr(dim + 1, 0);
+      for (int k = 0; k < nent; k++) cptr[ent_ec[k] + 1]++;
+      for (int c = 0; c < dim; c++) cptr[c + 1] += cptr[c];
+      {
+        std::vector<int> fill(cptr.begin(), cptr.end() - 1);
+        for (int k = 0; k < nent; k++) perm[fill[ent_ec[k]]++] = k;
+      }
+      for (int c = 0; c < dim; c++)
+        if (cptr[c + 1] - cptr[c] > 1)
+          std::sort(perm.begin() + cptr[c], perm.begin() + cptr[c + 1],
+                    [&](int x, int y) { return ent_dst[x] < ent_dst[y]; });
     }
+    TMARK("10");
     auto apply_i = [&](std::vector<int> &v) {
       std::vector<int> t(nent);
       for (int k = 0; k < nent; k++) t[k] = v[perm[k]];
@@ -977,6 +1001,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     for (int i = 0; i < n; i++)
       if (diag_ent[i] >= 0) diag_ent[i] = inv[diag_ent[i]];
   }
+  TMARK("11");
   return 0;
 }
 
