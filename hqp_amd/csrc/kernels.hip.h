@@ -720,6 +720,7 @@ int dn;
       double d = cur[k];
       bool pertd = false;
       if (!(fabs(d) >= pert)) {
+        if (d == 0.0) counters[-1] = 4;  // an exact zero pivot is E_SING for the reference (hqp/spBKP.C:699-700)
         d = (double)esign[e0 + lp[k]] * pert;
         pertd = true;
       }
@@ -748,6 +749,7 @@ int dn;
       double det = d11 * d22 - d21 * d21;
       bool pertd = false;
       if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
+        if (det == 0.0) counters[-1] = 4;  // hqp/spBKP.C:731-732
         d11 = (double)esign[e0 + lp[k]] * pert;
         d22 = (double)esign[e0 + lp[k + 1]] * pert;
         d21 = 0.0;
@@ -1150,6 +1152,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       double d = rdlane(ck, k);
       bool pertd = false;
       if (!(fabs(d) >= pert)) {
+        if (d == 0.0) counters[-1] = 4;  // an exact zero pivot is E_SING for the reference (hqp/spBKP.C:699-700)
         d = (double)esign[e0 + lp[k]] * pert;
         pertd = true;
       }
@@ -1183,6 +1186,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       double det = d11 * d22 - d21 * d21;
       bool pertd = false;
       if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
+        if (det == 0.0) counters[-1] = 4;  // hqp/spBKP.C:731-732
         d11 = (double)esign[e0 + lp[k]] * pert;
         d22 = (double)esign[e0 + lp[k + 1]] * pert;
         d21 = 0.0;

@@ -151,3 +151,51 @@ def test_solver_plugin_mehrotra_hip_in_the_reference_host(mat):
     # a plugin that is not one of ours is refused (the loop needs the C-ABI handle)
     with pytest.raises(refapi.RefError):
         refapi.ip_solve(prog, "MehrotraHip", "SpBKP", host="hip")
+
+
+def _duplicated_equality(prog):
+    """The first equality row twice: a consistent but rank-deficient A, i.e. an exactly
+    singular KKT matrix."""
+    p, i, v = prog.A
+    row0 = slice(p[0], p[1])
+    p2 = np.concatenate([p, [p[-1] + (p[1] - p[0])]]).astype(np.int32)
+    i2 = np.concatenate([i, i[row0]]).astype(np.int32)
+    v2 = np.concatenate([v, v[row0]])
+    return problems.Program(prog.n, prog.me + 1, prog.m, prog.Q, (p2, i2, v2), prog.C, c=prog.c,
+                            b=np.concatenate([prog.b, prog.b[:1]]), d=prog.d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RedSpBKP", "SpBKP"])
+def test_singular_kkt_ends_degenerate_like_the_reference(kind):
+    """An exactly zero pivot is E_SING in the reference (hqp/spBKP.C:699-700, 731-732), which
+    its Mehrotra solver turns into Hqp_Degenerate (hqp/Hqp_IpsMehrotra.C:262-269).  Same
+    here: status HQPKKT_E_SING from the plugin entry points (reported with the residual of
+    the solve that follows inside hqpkkt_mehrotra), result 4 from the loops."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    prog = _duplicated_equality(problems.banded_qp(60, 6, 5))
+    ref = refapi.ip_solve(prog, "Mehrotra", kind)
+    assert ref["result"] == 4
+    cls = ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP
+    M = cls()
+    M.init(prog)
+    _x, _y, _z, _w, info = M.mehrotra(prog)
+    assert info["result"] == 4 and info["iters"] == ref["iters"] == 0
+    # the plugin entry points: the reference raises in spBKPsolve, i.e. in factor() or in
+    # the solve that follows; so may we (zero pivot seen by the factorisation, or a residual
+    # that is not a number)
+    z, w = np.ones(prog.m), np.ones(prog.m)
+    r = [np.ones(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    if kind == "RedSpBKP":  # exact cancellation: the pivot is 0.0
+        with pytest.raises(ipmatrix.KktError) as e:
+            M.factor(prog, z, w)
+            M.solve(prog, z, w, *r, *d)
+        assert e.value.code == 4
+    # (FULL: the pivot is a rounding error, not 0.0; like the reference, which accepts any
+    # non-zero pivot, the plugin then solves the consistent singular system without a status)
+    if refapi.host_available("hip"):
+        hip = refapi.ip_solve(prog, "Mehrotra", kind + "Hip", host="hip")
+        assert hip["result"] == 4 and hip["iters"] == 0
