@@ -1118,6 +1118,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   const int OPS_NONE[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
 
   // ------------------------------------------------------------ cold start
+  // (x = y = 0 until the cold start's solve has succeeded: what the caller gets back when the
+  // very first factorisation is singular, as from the reference)
+  if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
+  if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
   if (m > 0) {
     k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
     if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
@@ -1148,9 +1152,6 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     delz += 0.5 * gap0 / (sumdw + m * delw);
     delw += 0.5 * gap0 / (sumdz + m * delz);
     k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
-  } else {
-    if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
-    if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
   }
 
   // ------------------------------------------------------------ iterations

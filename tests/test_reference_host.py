@@ -199,3 +199,48 @@ def test_singular_kkt_ends_degenerate_like_the_reference(kind):
     if refapi.host_available("hip"):
         hip = refapi.ip_solve(prog, "Mehrotra", kind + "Hip", host="hip")
         assert hip["result"] == 4 and hip["iters"] == 0
+
+
+def _small_qp(n, Q, A, C, c, b, d):
+    def csr(rows):
+        p, i, v = [0], [], []
+        for r in rows:
+            for col, x in sorted(r):
+                i.append(col), v.append(x)
+            p.append(len(i))
+        return np.array(p, dtype=np.int32), np.array(i, dtype=np.int32), np.array(v, dtype=float)
+    return problems.Program(n, len(A), len(C), csr(Q), csr(A), csr(C), c=np.array(c, float),
+                            b=np.array(b, float), d=np.array(d, float))
+
+
+PATHOLOGICAL = {
+    # x0 >= 1 and x0 <= 0
+    "infeasible": lambda: _small_qp(2, [[(0, 1.0)], [(1, 1.0)]], [], [[(0, 1.0)], [(0, -1.0)]], [0, 0], [], [-1.0, 0.0]),
+    # min -x0 with no curvature and no bound on x0
+    "unbounded": lambda: _small_qp(2, [[(0, 0.0)], [(1, 1.0)]], [], [[(1, 1.0)]], [-1.0, 0.0], [], [0.0]),
+    # three constraints active at the optimum of a two-variable problem
+    "degenerate_vertex": lambda: _small_qp(2, [[(0, 1.0)], [(1, 1.0)]], [],
+                                           [[(0, 1.0)], [(1, 1.0)], [(0, 1.0), (1, 1.0)]], [1.0, 1.0], [], [0.0, 0.0, 0.0]),
+    # equalities only (one Newton step, hqp/Hqp_IpsMehrotra.C:364-413)
+    "equalities_only": lambda: _small_qp(3, [[(0, 2.0)], [(1, 2.0)], [(2, 2.0)]], [[(0, 1.0), (1, 1.0)], [(2, 1.0)]], [],
+                                         [1, 1, 1], [-1.0, -2.0], []),
+}
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RedSpBKP", "SpBKP"])
+@pytest.mark.parametrize("case", sorted(PATHOLOGICAL))
+def test_device_resident_mehrotra_on_pathological_qps(case, kind):
+    """Infeasible, unbounded, degenerate and equality-only QPs: the same Hqp_Result, the same
+    iteration count and the same x as the reference's Hqp_IpsMehrotra with its own plugin
+    (suboptimal after 4 iterations, degenerate at once, optimal after 3, optimal after 1)."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    prog = PATHOLOGICAL[case]()
+    ref = refapi.ip_solve(prog, "Mehrotra", kind)
+    M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)()
+    M.init(prog)
+    x, _y, _z, _w, info = M.mehrotra(prog)
+    assert (info["result"], info["iters"]) == (ref["result"], ref["iters"]), (info, ref["result"], ref["iters"])
+    assert np.abs(x - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
