@@ -244,3 +244,20 @@ def test_device_resident_mehrotra_on_pathological_qps(case, kind):
     x, _y, _z, _w, info = M.mehrotra(prog)
     assert (info["result"], info["iters"]) == (ref["result"], ref["iters"]), (info, ref["result"], ref["iters"])
     assert np.abs(x - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["Mehrotra", "Franke"])
+@pytest.mark.parametrize("pair", [("SpBKP", "SpBKPHip"), ("RedSpBKP", "RedSpBKPHip")])
+@pytest.mark.parametrize("case", sorted(PATHOLOGICAL))
+def test_reference_solvers_on_pathological_qps_with_the_hip_plugin(case, pair, solver):
+    """The reference's own IP solvers on the pathological QPs, once with the reference plugin
+    and once with ours: same Hqp_Result, same iteration count (Franke: 13 / 1 / 7 / 0), same x.
+    The E_SING of the unbounded case travels status -> shim -> m_error -> m_catch."""
+    if not refapi.host_available("hip"):
+        pytest.skip("oracle/_ref/libhqphost_hip.so not present")
+    prog = PATHOLOGICAL[case]()
+    ref = refapi.ip_solve(prog, solver, pair[0], host="hip")
+    hip = refapi.ip_solve(prog, solver, pair[1], host="hip")
+    assert (hip["result"], hip["iters"]) == (ref["result"], ref["iters"])
+    assert np.abs(hip["x"] - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
