@@ -106,7 +106,7 @@ def _without_inequalities(prog):
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("kind", ["RedSpBKP", "SpBKP"])
-@pytest.mark.parametrize("case", ["did400", "did2000", "banded", "banded3k", "noineq"])
+@pytest.mark.parametrize("case", ["did400", "did2000", "did33333", "banded", "banded3k", "noineq"])
 def test_device_resident_mehrotra_follows_the_reference(case, kind):
     """hqpkkt_mehrotra (the reference's Mehrotra loop restated with all vector work on
     the GPU) against the reference's own Hqp_IpsMehrotra with its own plugin: same
@@ -115,6 +115,7 @@ def test_device_resident_mehrotra_follows_the_reference(case, kind):
     if not refapi.host_available("ref"):
         pytest.skip("oracle/_ref not present")
     prog = {"did400": lambda: problems.did_like_qp(400), "did2000": lambda: problems.did_like_qp(2000),
+            "did33333": lambda: problems.did_like_qp(33333),  # n = 10^5: BASELINE's config C3 at full size
             "banded": lambda: problems.banded_qp(300, 8, 5), "banded3k": lambda: problems.banded_qp(3000, 24, 4),
             "noineq": lambda: _without_inequalities(problems.banded_qp(400, 10, 6))}[case]()
     ref = refapi.ip_solve(prog, "Mehrotra", kind)
@@ -126,7 +127,10 @@ def test_device_resident_mehrotra_follows_the_reference(case, kind):
     assert info["n_factor"] == info["iters"] + (1 if prog.m else 0)  # one per iteration + the cold start
     fr, fd = objective(prog, ref["x"]), objective(prog, x)
     assert abs(fr - fd) <= 1e-6 * max(1.0, abs(fr))
-    assert np.abs(x - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
+    # (n = 10^5: the long horizon leaves x flat directions of curvature 1e-4; both runs stop at
+    # mu, |r| <= 1e-10 |data| with the same objective, x then agrees to 5e-5 of its maximum)
+    xtol = 1e-4 if case == "did33333" else 1e-5
+    assert np.abs(x - ref["x"]).max() <= xtol * max(1.0, np.abs(ref["x"]).max())
     if prog.m:
         assert z.min() > 0 and w.min() > 0
 
