@@ -1581,7 +1581,7 @@ k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
 // MFMA operand layout (verified by hqpkkt_selftest_mfma): A: lane l holds
 // A[l&15][l>>4]; B: B[l>>4][l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
 
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(256, 4)
 k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ panel,
               double *__restrict__ xar, const double *__restrict__ dinv,
               const int *__restrict__ ptype, const int *__restrict__ lperm,
