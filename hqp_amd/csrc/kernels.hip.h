@@ -1737,6 +1737,20 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
   const int ia = i0 + lr, ib = i0 + 16 + lr, ja = j0 + lr, jb = j0 + 16 + lr;
   // the children's contributions to this wave's part of U (there is no extend-add pass and
   // U is not pre-zeroed: this kernel writes every entry once) travel while the products run
+  // the first trip's operands are requested before the index chase of the children's blocks
+  double a0[8], a1[8], b0[8], b1[8];
+  auto load = [&](int k0) {
+#pragma unroll
+    for (int q = 0; q < 8; q++) {
+      const int k = k0 + 4 * q + lk;
+      const bool kin = k < p;
+      a0[q] = (kin && ia < b) ? L[(long long)k * F + ia] : 0.0;
+      a1[q] = (kin && ib < b) ? L[(long long)k * F + ib] : 0.0;
+      b0[q] = (kin && ja < b) ? X[(long long)k * b + ja] : 0.0;
+      b1[q] = (kin && jb < b) ? X[(long long)k * b + jb] : 0.0;
+    }
+  };
+  load(0);
   double uold[2][2][4];
 #pragma unroll
   for (int x = 0; x < 2; x++)
@@ -1774,16 +1788,7 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
   // eight k-steps (32 pivots) per trip: all operand loads of the trip are in flight
   // together, so a trip costs one memory latency instead of eight
   for (int k0 = 0; k0 < p; k0 += 32) {
-    double a0[8], a1[8], b0[8], b1[8];
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int k = k0 + 4 * q + lk;
-      const bool kin = k < p;
-      a0[q] = (kin && ia < b) ? L[(long long)k * F + ia] : 0.0;
-      a1[q] = (kin && ib < b) ? L[(long long)k * F + ib] : 0.0;
-      b0[q] = (kin && ja < b) ? X[(long long)k * b + ja] : 0.0;
-      b1[q] = (kin && jb < b) ? X[(long long)k * b + jb] : 0.0;
-    }
+    if (k0) load(k0);
 #pragma unroll
     for (int q = 0; q < 8; q++) {
       if (k0 + 4 * q < p) {  // wave-uniform
