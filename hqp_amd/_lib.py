@@ -60,7 +60,8 @@ class Stats(C.Structure):
 
 class IpOpts(C.Structure):
     _fields_ = [("eps", C.c_double), ("max_iters", C.c_int), ("gammaf", C.c_double),
-                ("norm_data", C.c_double), ("reserved", C.c_int * 4)]
+                ("norm_data", C.c_double), ("hot_start", C.c_int), ("max_warm_iters", C.c_int),
+                ("reserved", C.c_int * 2)]
 
 
 class IpResult(C.Structure):

@@ -202,6 +202,8 @@ struct hqpkkt {
   // inside hqpkkt_mehrotra: factor() returns without waiting for its status (read with the
   // residual of the solve that follows), solve() leaves its result in the stream
   bool lazy = false, factor_unchecked = false;
+  // hqpkkt_mehrotra left x, y and the hot-start candidates of z, w in ipv (same dimensions)
+  bool ip_hot_valid = false;
   bool short_rows = false;  // CSR rows of a handful of entries: 4 lanes per row in the SpMV kernels
   void drop_graphs() {
     for (auto &g : gfactor) g.drop();
@@ -809,6 +811,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
     h->release_device();
   }
   h->analyzed = false;
+  h->ip_hot_valid = false;
   h->an = Analysis();
   h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
   h->an.slack_policy = h->opts.slack_policy;
@@ -1018,6 +1021,7 @@ struct IpCtx {
   hqpkkt_t *h;
   int n, me, m;
   double *x, *y, *z, *w, *r1, *r2, *r3, *r4, *dxa, *dya, *dza, *dwa, *dx, *dy, *dz, *dw, *c, *b, *d, *part, *out;
+  double *zh, *wh;  // hot-start candidates (hqp/Hqp_IpsMehrotra.C:475-478)
   double *hout;  // pinned (h->hpin + 64)
   int reduce(const int (&ops)[IP_SLOTS], int nout) {
     IpOps o;
@@ -1055,9 +1059,12 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   HIPCHK(hipSetDevice(h->opts.device));
   hipStream_t s = h->stream;
   const size_t nv = (size_t)n + me + 2 * (size_t)m;
-  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64;
+  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
   int e;
-  if (h->ipv.count < need && (e = h->ipv.alloc(need))) return e;
+  if (h->ipv.count < need) {
+    if ((e = h->ipv.alloc(need))) return e;
+    h->ip_hot_valid = false;
+  }
   IpCtx C;
   C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
   double *q = h->ipv.p;
@@ -1068,6 +1075,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
   C.c = take(n), C.b = take(me), C.d = take(m);
   C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
+  C.zh = take(m), C.wh = take(m);
   // out: 0..7 reductions (k_ip_final), 16..27 the blocking components (k_ip_minratio_final),
   // 32..39 the step's scalars (IPS_*)
   double *const Bk = C.out + 16, *const S = C.out + 32;
@@ -1117,46 +1125,19 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   };
   const int OPS_NONE[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
 
-  // ------------------------------------------------------------ cold start
-  // (x = y = 0 until the cold start's solve has succeeded: what the caller gets back when the
-  // very first factorisation is singular, as from the reference)
-  if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
-  if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
-  if (m > 0) {
-    k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
-    if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
-      if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:262-269)
-      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-      return e;
-    }
-    HIPCHK(hipMemcpyAsync(C.x, C.dx, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-    if (me) HIPCHK(hipMemcpyAsync(C.y, C.dy, sizeof(double) * me, hipMemcpyDeviceToDevice, s));
-    k_ip_cold_stats<<<IP_BLOCKS, 256, 0, s>>>(m, C.dz, C.dw, C.part);
-    const int ops1[IP_SLOTS] = {IP_MIN, IP_MIN, IP_MAX, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-    if ((e = C.reduce(ops1, 6))) return e;
-    double mindz = C.hout[0], mindw = C.hout[1], sumdz = C.hout[4], sumdw = C.hout[5];
-    if (C.hout[2] == 0.0) {  // :301-304
-      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dz);
-      mindz = 1.0e-10, sumdz = 1.0e-10 * m;
-    }
-    if (C.hout[3] == 0.0) {
-      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dw);
-      mindw = 1.0e-10, sumdw = 1.0e-10 * m;
-    }
-    double delz = std::fmax(-1.5 * mindz, 0.0), delw = std::fmax(-1.5 * mindw, 0.0);
-    // gap = (dz + delz)'(dw + delw): k_ip_mupl with alpha = 1 on (delz, dz), (delw, dw) shifted vectors
-    k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
-    k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, nullptr, C.z, C.w, C.dz, C.dw, C.part);
-    if ((e = C.reduce(OPS_NONE, 1))) return e;
-    const double gap0 = C.hout[0];
-    delz += 0.5 * gap0 / (sumdw + m * delw);
-    delw += 0.5 * gap0 / (sumdz + m * delz);
-    k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
-  }
-
   // ------------------------------------------------------------ iterations
   std::vector<double> phimin((size_t)o.max_iters + 2, 0.0);
   double mu0 = 0.0, norm_r0 = 0.0, norm_data = 1.0;
+  // hot start (hqp/Hqp_IpsMehrotra.C:330-352, 475-478, 696-733): x, y of the last solve and
+  // the (z, w) kept from its last iteration far enough from the solution; a hot start that
+  // does not reduce phi by 1.2 per iteration, takes a step below 1e-5, runs max_warm_iters or
+  // does not end optimal is thrown away and the QP solved again from a cold start
+  const bool keep_hot = o.hot_start != 0 && m > 0;  // 1: hot start if possible, 2: cold, but prepare the next
+  bool hot = o.hot_start == 1 && m > 0 && h->ip_hot_valid;
+  const int max_warm = o.max_warm_iters > 0 ? o.max_warm_iters : 25;
+  const double hot_thresh = std::pow(o.eps, 0.3333);
+  int fail_iters = 0;
+  double test1 = 0.0;
   const double gamma = std::pow(1.0e-4, 0.25);
   int result = 2;
   bool stepped = false, pending = false;  // pending: a step is in the stream whose scalars were not read yet
@@ -1207,7 +1188,60 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     if (C.hout[32 + IPS_NEED2] != 0.0) return second_corrector(mu_pending);
     return 0;
   };
+  for (;;) {  // hot first (if asked for and possible), cold after a failed hot start
+  iter = 0, result = 2, stepped = false, pending = false;
+  std::fill(phimin.begin(), phimin.end(), 0.0);
+  res->alpha = 1.0;
+  if (hot) {
+    CopyList L{{C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
+    k_copy_vectors<<<64, 256, 0, s>>>(L, 2);
+  } else {
+      // (x = y = 0 until the cold start's solve has succeeded: what the caller gets back when the
+      // very first factorisation is singular, as from the reference)
+      if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
+      if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
+      if (m > 0) {
+        k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
+        if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
+          if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:262-269)
+          (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+          return e;
+        }
+        HIPCHK(hipMemcpyAsync(C.x, C.dx, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+        if (me) HIPCHK(hipMemcpyAsync(C.y, C.dy, sizeof(double) * me, hipMemcpyDeviceToDevice, s));
+        k_ip_cold_stats<<<IP_BLOCKS, 256, 0, s>>>(m, C.dz, C.dw, C.part);
+        const int ops1[IP_SLOTS] = {IP_MIN, IP_MIN, IP_MAX, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+        if ((e = C.reduce(ops1, 6))) return e;
+        double mindz = C.hout[0], mindw = C.hout[1], sumdz = C.hout[4], sumdw = C.hout[5];
+        if (C.hout[2] == 0.0) {  // :301-304
+          k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dz);
+          mindz = 1.0e-10, sumdz = 1.0e-10 * m;
+        }
+        if (C.hout[3] == 0.0) {
+          k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dw);
+          mindw = 1.0e-10, sumdw = 1.0e-10 * m;
+        }
+        double delz = std::fmax(-1.5 * mindz, 0.0), delw = std::fmax(-1.5 * mindw, 0.0);
+        // gap = (dz + delz)'(dw + delw): k_ip_mupl with alpha = 1 on (delz, dz), (delw, dw) shifted vectors
+        k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
+        k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, nullptr, C.z, C.w, C.dz, C.dw, C.part);
+        if ((e = C.reduce(OPS_NONE, 1))) return e;
+        const double gap0 = C.hout[0];
+        delz += 0.5 * gap0 / (sumdw + m * delw);
+        delw += 0.5 * gap0 / (sumdz + m * delz);
+        k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
+      }
+
+    if (keep_hot) {  // :318-319
+      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0, C.zh);
+      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0, C.wh);
+    }
+  }
+  bool restart_cold = false;
   while (true) {
+    double phi = 0.0;
+    bool redo = false;  // the second corrector replaced the step: same step() call, new right-hand sides
+    do {
     // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
     if (h->short_rows)
       k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
@@ -1246,7 +1280,8 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
           return e;
         }
         iter++;
-        continue;  // right-hand sides and reductions of the new iterate
+        redo = true;  // right-hand sides and reductions of the new iterate
+        break;
       }
     }
     const double gap = C.hout[0], mu = C.hout[2] / m, norm_r = C.hout[3];
@@ -1260,9 +1295,13 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       mu0 = mu, norm_r0 = norm_r;
       norm_data = o.norm_data > 0.0 ? o.norm_data : 1.0;
     }
-    const double phi = (norm_r + std::fabs(gap)) / norm_data;
+    phi = (norm_r + std::fabs(gap)) / norm_data;
     phimin[iter] = phi;
     res->phi = phi;
+    if (keep_hot && phi > hot_thresh) {  // prepare the next hot start (:475-478)
+      CopyList L{{C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
+      k_copy_vectors<<<64, 256, 0, s>>>(L, 2);
+    }
     if (mu <= o.eps && norm_r <= o.eps * norm_data) {  // :487-490
       result = 0;
       break;
@@ -1319,15 +1358,38 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     // pass through k_ip_rhs, whose sums and maximum carry the NaN / inf)
     iter++;
     stepped = true, pending = true, mu_pending = mu;
-    if (result == 3 || result == 4 || iter >= o.max_iters) {  // blow-up test above; :716
+    } while (0);
+    if (redo) continue;
+    // ---- what solve() does after every step() call (:703-718)
+    const bool leave = result == 0 || result == 3 || result == 4 || iter + fail_iters >= o.max_iters ||
+                       (hot && iter >= max_warm);
+    if (hot || leave) {  // the step's own scalars are needed now: was it taken, how long was it
       if ((e = settle())) {
         if (e == HQPKKT_E_SING) return finish(4);
         (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
         return e;
       }
-      break;
     }
+    if (hot) {
+      if (iter == 1)
+        test1 = phi;
+      else if (phi > test1 / std::pow(1.2, iter - 1.0) || res->alpha < 1.0e-5) {
+        fail_iters += iter;
+        restart_cold = true;
+        break;
+      }
+    }
+    if (leave) break;
   }
+  if (restart_cold || (hot && result != 0)) {  // bad hot start: its iterations are lost (:723-727)
+    if (!restart_cold) fail_iters += iter;
+    hot = false;
+    continue;
+  }
+  break;
+  }
+  iter += fail_iters;
+  if (m > 0) h->ip_hot_valid = keep_hot;
   return finish(result);
 }
 

@@ -245,13 +245,15 @@ class Hqp_IpMatrix:
         _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
         return out[: k.value]
 
-    def mehrotra(self, qp, eps=1e-10, max_iters=200):
-        """Device-resident Mehrotra predictor-corrector solve of the QP (cold start), the
-        restatement of hqp/Hqp_IpsMehrotra.C behind ``hqpkkt_mehrotra``: returns
-        (x, y, z, w, info).  init()/update() must have been called with ``qp``."""
+    def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0):
+        """Device-resident Mehrotra predictor-corrector solve of the QP, the restatement of
+        hqp/Hqp_IpsMehrotra.C behind ``hqpkkt_mehrotra``: returns (x, y, z, w, info).
+        init()/update() must have been called with ``qp``.  ``hot_start``: 0 cold start,
+        1 Hqp_IpsMehrotra::hot_start from this handle's previous solve (which must have run
+        with hot_start != 0), 2 cold start that keeps what the next hot start needs."""
         o = _lib.IpOpts()
         self._L.hqpkkt_default_ip_opts(C.byref(o))
-        o.eps, o.max_iters = eps, max_iters
+        o.eps, o.max_iters, o.hot_start = eps, max_iters, int(hot_start)
 
         def rowsum(csr, rows):  # sp_norm_inf (meschach/addon2_hqp.c:723-743)
             p, _i, x = csr

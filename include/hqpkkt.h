@@ -236,8 +236,8 @@ const char *hqpkkt_strerror(int status);
  * a handful of kernels over the CSR blocks; only the scalars that steer the iteration
  * come back to the host.  The handle must hold the QP's matrices (hqpkkt_analyze +
  * hqpkkt_set_values with Q, A, C of the Hqp_Program, hqp/Hqp_Program.h:43-60); c, b, d
- * and the outputs x, y, z, w follow opts.loc of the handle.  Cold start only
- * (qp_init_method 0).  result uses the reference's Hqp_Result numbering
+ * and the outputs x, y, z, w follow opts.loc of the handle.  Cold start
+ * (qp_init_method 0) or hot start from the handle's previous solve.  result uses the reference's Hqp_Result numbering
  * (hqp/Hqp_impl.h:37-43): 0 optimal, 3 suboptimal, 4 degenerate. */
 typedef struct hqpkkt_ip_opts {
   double eps;       /* qp_eps (hqp/Hqp_Solver.C:53)                                   */
@@ -245,7 +245,16 @@ typedef struct hqpkkt_ip_opts {
   double gammaf;    /* step damping (hqp/Hqp_IpsMehrotra.C:95)                        */
   double norm_data; /* max inf-norm of Q, A, C, c, b, d (hqp/Hqp_IpsMehrotra.C:462-464);
                        the caller holds the data, 0 = use 1                            */
-  int reserved[4];
+  int hot_start;    /* 0 = cold start (Hqp_IpsMehrotra::cold_start, :209-327);
+                       1 = Hqp_IpsMehrotra::hot_start (:330-352) if the previous call on this handle
+                       (same dimensions, hot_start != 0) left its x, y and the (z, w) of its last
+                       iteration far from the solution (:475-478); as in Hqp_IpsMehrotra::solve
+                       (:696-733) a hot start that does not reduce phi by 1.2 per iteration, takes a
+                       step below 1e-5, runs max_warm_iters or does not end optimal is thrown away,
+                       the QP is solved again from a cold start and its iterations are added to
+                       iters; 2 = cold start, but keep what the next hot start needs           */
+  int max_warm_iters; /* qp_max_warm_iters (hqp/Hqp_IpsMehrotra.C:111), 0 = 25                */
+  int reserved[2];
 } hqpkkt_ip_opts;
 typedef struct hqpkkt_ip_result {
   int result, iters;     /* Hqp_Result, iterations                                    */

@@ -88,4 +88,59 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
   return err;
 }
 
+// Two QPs in a row with the same matrices, as an SQP iteration makes them: (c, b, d) solved
+// from a cold start, then (c2, b2, d2) after update() + hot_start()
+// (hqp/Hqp_SqpSolver.C:285-296, hqp/Hqp_IpsMehrotra.C:330-352, 696-733).  x, y, z and out
+// receive the SECOND solve; out[4] = iterations of the first.
+int hqpip_solve_hot(int solver, const char *mat_solver, int n, int me, int m, const int *Qp,
+                    const int *Qi, const double *Qx, const double *c, const int *Ap,
+                    const int *Ai, const double *Ax, const double *b, const int *Cp,
+                    const int *Ci, const double *Cx, const double *d, const double *c2,
+                    const double *b2, const double *d2, double qp_eps, int max_iters, double *x,
+                    double *y, double *z, double *out) {
+  if (hqpref_startup() != 0) return -1;
+  Hqp_Solver *S;
+  if (solver == 2) {
+    S = If_ClassList_Hqp_Solver() ? If_ClassList_Hqp_Solver()->createObject("MehrotraHip") : NULL;
+    if (!S) return -2;
+  } else
+    S = solver == 0 ? (Hqp_Solver *)new Hqp_IpsMehrotra : (Hqp_Solver *)new Hqp_IpsFranke;
+  if (If_SetString("qp_mat_solver", mat_solver) != IF_OK) {
+    delete S;
+    return -2;
+  }
+  Hqp_Program *qp = new Hqp_Program;
+  qp->resize(n, me, m);
+  fill(qp->Q, n, Qp, Qi, Qx);
+  fill(qp->A, me, Ap, Ai, Ax);
+  fill(qp->C, m, Cp, Ci, Cx);
+  for (int i = 0; i < n; i++) qp->c->ve[i] = c[i], qp->x->ve[i] = 0.0;
+  for (int i = 0; i < me; i++) qp->b->ve[i] = b[i];
+  for (int i = 0; i < m; i++) qp->d->ve[i] = d[i];
+  S->qp(qp);
+  S->eps(qp_eps);
+  S->max_iters(max_iters);
+  int err = 0, it1 = 0;
+  double t1 = now_s(), t2 = t1;
+  m_catchall(S->init(); S->update(); S->cold_start(); S->solve(); it1 = S->iter();
+             for (int i = 0; i < n; i++) qp->c->ve[i] = c2[i];
+             for (int i = 0; i < me; i++) qp->b->ve[i] = b2[i];
+             for (int i = 0; i < m; i++) qp->d->ve[i] = d2[i];
+             S->update(); t1 = now_s(); S->hot_start(); S->solve(); t2 = now_s(),
+             err = _err_num);
+  if (!err) {
+    for (int i = 0; i < n; i++) x[i] = qp->x->ve[i];
+    for (int i = 0; i < me; i++) y[i] = S->y()->ve[i];
+    for (int i = 0; i < m; i++) z[i] = S->z()->ve[i];
+    out[0] = S->iter();
+    out[1] = (double)S->result();
+    out[2] = t2 - t1;
+    out[3] = 0.0;
+    out[4] = it1;
+  }
+  delete S;
+  delete qp;
+  return err;
+}
+
 }  // extern "C"

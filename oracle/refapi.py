@@ -201,6 +201,10 @@ def _host(host):
     lib = C.CDLL(path)
     lib.hqpip_solve.argtypes = ([C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp, _dp] * 3
                                 + [C.c_double, C.c_int, _dp, _dp, _dp, _dp])
+    if hasattr(lib, "hqpip_solve_hot"):
+        lib.hqpip_solve_hot.restype = C.c_int
+        lib.hqpip_solve_hot.argtypes = ([C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp, _dp] * 3
+                                        + [_dp, _dp, _dp, C.c_double, C.c_int, _dp, _dp, _dp, _dp])
     _HOST_LIBS[host] = lib
     return lib
 
@@ -231,3 +235,24 @@ def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-
         raise RefError(e, f"ip_solve[{solver},{mat_solver}]")
     return dict(x=x[:n], y=y[:me], z=z[:m], iters=int(out[0]), result=int(out[1]), seconds=out[2],
                 setup_seconds=out[3])
+
+
+def ip_solve_hot(prog, c2, b2, d2, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250):
+    """Two QPs in a row as an SQP iteration makes them: ``prog`` from a cold start, then the same
+    matrices with (c2, b2, d2) after update() + hot_start() (hqp/Hqp_IpsMehrotra.C:330-352,
+    696-733).  Returns the SECOND solve: dict(x, y, z, iters, result, seconds, first_iters)."""
+    lib = _host(host)
+    n, me, m = prog.dims
+    args = []
+    for (p, i, x), vec in zip((prog.Q, prog.A, prog.C), (prog.c, prog.b, prog.d)):
+        args += [np.ascontiguousarray(p, dtype=np.int32),
+                 np.ascontiguousarray(i, dtype=np.int32) if len(i) else np.zeros(1, np.int32),
+                 _pad(x), _pad(vec)]
+    x, y, z = np.zeros(max(n, 1)), np.zeros(max(me, 1)), np.zeros(max(m, 1))
+    out = np.zeros(5)
+    e = lib.hqpip_solve_hot({"Mehrotra": 0, "Franke": 1, "MehrotraHip": 2}[solver], mat_solver.encode(), n, me, m,
+                            *args, _pad(c2), _pad(b2), _pad(d2), qp_eps, max_iters, x, y, z, out)
+    if e:
+        raise RefError(e, f"ip_solve_hot[{solver},{mat_solver}]")
+    return dict(x=x[:n], y=y[:me], z=z[:m], iters=int(out[0]), result=int(out[1]), seconds=out[2],
+                first_iters=int(out[4]))

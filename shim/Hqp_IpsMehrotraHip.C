@@ -21,6 +21,8 @@ Hqp_IpsMehrotraHip::Hqp_IpsMehrotraHip()
   _gap = 0.0;
   _alpha = 1.0;
   _gammaf = 0.01;  // hqp/Hqp_IpsMehrotra.C:95
+  _hot = 2;
+  _max_warm_iters = 25;  // hqp/Hqp_IpsMehrotra.C:111
   _n_factor = _n_solve = 0;
   _ms_total = 0.0;
   _matrix = new Hqp_IpRedSpBKPHip;
@@ -31,6 +33,7 @@ Hqp_IpsMehrotraHip::Hqp_IpsMehrotraHip()
   _ifList.append(new If_Int("qp_n_factor", &_n_factor));
   _ifList.append(new If_Int("qp_n_solve", &_n_solve));
   _ifList.append(new If_Real("qp_device_ms", &_ms_total));
+  _ifList.append(new If_Int("qp_max_warm_iters", &_max_warm_iters));
   _ifList.append(new IF_MODULE("qp_mat_solver", &_matrix, Hqp_IpMatrix));
 }
 
@@ -65,11 +68,16 @@ void Hqp_IpsMehrotraHip::cold_start()
   _iter = 0;
   _alpha = 1.0;
   _result = Hqp_Infeasible;
+  _hot = 2;  // cold, but keep what a later hot start needs (hqp/Hqp_IpsMehrotra.C:318-319, 475-478)
 }
 
+// hqp/Hqp_IpsMehrotra.C:330-352: x, y of the last solve and the (z, w) kept on the device
 void Hqp_IpsMehrotraHip::hot_start()
 {
-  cold_start();
+  _iter = 0;
+  _alpha = 1.0;
+  _result = Hqp_Infeasible;
+  _hot = 1;
 }
 
 void Hqp_IpsMehrotraHip::step()
@@ -90,6 +98,8 @@ void Hqp_IpsMehrotraHip::solve()
   opts.eps = _eps;
   opts.max_iters = _max_iters;
   opts.gammaf = _gammaf;
+  opts.hot_start = _hot;
+  opts.max_warm_iters = _max_warm_iters;
   // hqp/Hqp_IpsMehrotra.C:462-464
   opts.norm_data = max(max(max(max(max(sp_norm_inf(_qp->Q), sp_norm_inf(_qp->A)),
                                    sp_norm_inf(_qp->C)), v_norm_inf(_qp->c)),

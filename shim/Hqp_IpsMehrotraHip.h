@@ -10,10 +10,10 @@
  * and it owns an Hqp_IpMatrixHip plugin selected the usual way
  *     qp_mat_solver RedSpBKPHip      (default, as the reference defaults to RedSpBKP,
  *                                     hqp/Hqp_IpsMehrotra.C:92) | SpBKPHip | LQDOCPHip
- * Differences to Hqp_IpsMehrotra: cold start only (hot_start() starts cold:
- * Mehrotra's adaptive step makes the reference's hot start a heuristic, not a
- * contract, hqp/Hqp_IpsMehrotra.C:343-344), qp_init_method 0 only, no qp_step
- * (single iterations are not exposed).
+ * cold_start() / hot_start() select how the next solve() begins (the hot start with the
+ * reference's own fall-back to a cold start, hqp/Hqp_IpsMehrotra.C:696-733).
+ * Differences to Hqp_IpsMehrotra: qp_init_method 0 only, no qp_step (single iterations
+ * are not exposed).
  */
 #ifndef Hqp_IpsMehrotraHip_H
 #define Hqp_IpsMehrotraHip_H
@@ -29,6 +29,8 @@ class Hqp_IpsMehrotraHip : public Hqp_Solver {
   Real _gap, _alpha, _gammaf;
   int _n_factor, _n_solve;  // plugin calls of the last solve (read-only for the user)
   Real _ms_total;           // device time of the last solve, milliseconds
+  int _hot;                 // how the next solve() starts: hqpkkt_ip_opts.hot_start
+  int _max_warm_iters;      // qp_max_warm_iters (hqp/Hqp_IpsMehrotra.C:111,122)
   Hqp_IpMatrix *_matrix;
 
  public:

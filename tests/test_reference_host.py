@@ -265,3 +265,44 @@ def test_reference_solvers_on_pathological_qps_with_the_hip_plugin(case, pair, s
     hip = refapi.ip_solve(prog, solver, pair[1], host="hip")
     assert (hip["result"], hip["iters"]) == (ref["result"], ref["iters"])
     assert np.abs(hip["x"] - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RedSpBKP", "SpBKP"])
+@pytest.mark.parametrize("scale", [1e-3, 1e-1])
+@pytest.mark.parametrize("K", [400, 2000])
+def test_hot_start_follows_the_reference(K, scale, kind):
+    """Two QPs in a row with the same matrices, as an SQP iteration makes them: cold start, then
+    update() + hot_start() with a perturbed c (hqp/Hqp_IpsMehrotra.C:330-352, 475-478, 696-733).
+    A small perturbation: the hot start ends optimal after 8-11 iterations instead of ~30; a
+    large one: the hot start is thrown away after two iterations and the QP solved again from a
+    cold start, its iterations added (29).  Same result, iteration counts within one, same x
+    as the reference's Hqp_IpsMehrotra with its own plugin - for hqpkkt_mehrotra and for the
+    MehrotraHip solver class inside the reference host."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    prog = problems.did_like_qp(K)
+    rng = np.random.default_rng(0)
+    c2 = prog.c + scale * rng.standard_normal(prog.n) * (np.abs(prog.c).max() + 1)
+    prog2 = problems.Program(prog.n, prog.me, prog.m, prog.Q, prog.A, prog.C, c=c2, b=prog.b, d=prog.d)
+    ref = refapi.ip_solve_hot(prog, c2, prog.b, prog.d, "Mehrotra", kind)
+    cold = refapi.ip_solve(prog2, "Mehrotra", kind)
+    assert ref["result"] == 0
+    assert (ref["iters"] < cold["iters"] // 2) if scale < 1e-2 else (ref["iters"] > cold["iters"])  # the two regimes
+    M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)()
+    M.init(prog)
+    _x, _y, _z, _w, first = M.mehrotra(prog, hot_start=2)
+    x, _y, z, w, info = M.mehrotra(prog2, hot_start=1)
+    assert abs(first["iters"] - ref["first_iters"]) <= 1
+    assert info["result"] == 0 and abs(info["iters"] - ref["iters"]) <= 1, (info, ref["iters"])
+    assert np.abs(x - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
+    assert z.min() > 0 and w.min() > 0
+    # without the preparation (hot_start=0 before) a hot start is not available: cold start
+    M.mehrotra(prog, hot_start=0)
+    _x, _y, _z, _w, info0 = M.mehrotra(prog2, hot_start=1)
+    assert abs(info0["iters"] - cold["iters"]) <= 1
+    if K == 400 and refapi.host_available("hip"):
+        hh = refapi.ip_solve_hot(prog, c2, prog.b, prog.d, "MehrotraHip", kind + "Hip", host="hip")
+        assert hh["result"] == 0 and abs(hh["iters"] - ref["iters"]) <= 1
+        assert np.abs(hh["x"] - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
