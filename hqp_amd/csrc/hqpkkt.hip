@@ -1201,7 +1201,13 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
       if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
       if (m > 0) {
-        k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
+    // qp_init_method (:226-250, 294-297): 0 z = w = 1, r4 = 0; 1, 2 w = a ratio of the data's norms;
+    // 3 as 0 with r4 = -z.*w and the solve's dz, dw added to z, w
+    double w0 = 1.0;
+    if (o.init_method == 1) w0 = std::fmax(o.norm_d, 1e-10) * o.norm_Q / o.norm_C;
+    if (o.init_method == 2) w0 = o.norm_C / std::fmax(o.norm_d, 1e-10) / o.norm_Q;
+    k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4, w0,
+                                              o.init_method ? -w0 : 0.0);
         if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
           if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:262-269)
           (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
@@ -1209,7 +1215,8 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         }
         HIPCHK(hipMemcpyAsync(C.x, C.dx, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
         if (me) HIPCHK(hipMemcpyAsync(C.y, C.dy, sizeof(double) * me, hipMemcpyDeviceToDevice, s));
-        k_ip_cold_stats<<<IP_BLOCKS, 256, 0, s>>>(m, C.dz, C.dw, C.part);
+    if (o.init_method == 3) k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, 1.0, 1.0, C.dz, C.dw);  // :294-297
+    k_ip_cold_stats<<<IP_BLOCKS, 256, 0, s>>>(m, C.dz, C.dw, C.part);
         const int ops1[IP_SLOTS] = {IP_MIN, IP_MIN, IP_MAX, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
         if ((e = C.reduce(ops1, 6))) return e;
         double mindz = C.hout[0], mindw = C.hout[1], sumdz = C.hout[4], sumdw = C.hout[5];

@@ -327,11 +327,12 @@ k_ip_update(int n, int me, int m, double alpha, const double *__restrict__ alpha
   }
 }
 
-// cold start (:236-252): z = w = 1, r1 = c, r2 = -b, r3 = -d, r4 = 0
+// cold start (:226-250): z = 1, w = w0 (1; a norm ratio with qp_init_method 1, 2), r1 = c,
+// r2 = -b, r3 = -d, r4 = r40 (0; -z.*w with qp_init_method 1-3)
 __global__ void k_ip_cold_rhs(int n, int me, int m, const double *__restrict__ c, const double *__restrict__ b,
                               const double *__restrict__ d, double *__restrict__ z, double *__restrict__ w,
                               double *__restrict__ r1, double *__restrict__ r2, double *__restrict__ r3,
-                              double *__restrict__ r4) {
+                              double *__restrict__ r4, double w0, double r40) {
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n)
     r1[q] = c[q];
@@ -339,7 +340,7 @@ __global__ void k_ip_cold_rhs(int n, int me, int m, const double *__restrict__ c
     r2[q - n] = -b[q - n];
   else if (q < n + me + m) {
     const int j = q - n - me;
-    z[j] = 1.0, w[j] = 1.0, r3[j] = -d[j], r4[j] = 0.0;
+    z[j] = 1.0, w[j] = w0, r3[j] = -d[j], r4[j] = r40;
   }
 }
 // slots: 0 min dz, 1 min dw, 2 max|dz|, 3 max|dw|, 4 sum dz, 5 sum dw  (:305-310)

@@ -245,7 +245,7 @@ class Hqp_IpMatrix:
         _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
         return out[: k.value]
 
-    def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0):
+    def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0, init_method=0):
         """Device-resident Mehrotra predictor-corrector solve of the QP, the restatement of
         hqp/Hqp_IpsMehrotra.C behind ``hqpkkt_mehrotra``: returns (x, y, z, w, info).
         init()/update() must have been called with ``qp``.  ``hot_start``: 0 cold start,
@@ -253,7 +253,7 @@ class Hqp_IpMatrix:
         with hot_start != 0), 2 cold start that keeps what the next hot start needs."""
         o = _lib.IpOpts()
         self._L.hqpkkt_default_ip_opts(C.byref(o))
-        o.eps, o.max_iters, o.hot_start = eps, max_iters, int(hot_start)
+        o.eps, o.max_iters, o.hot_start, o.init_method = eps, max_iters, int(hot_start), int(init_method)
 
         def rowsum(csr, rows):  # sp_norm_inf (meschach/addon2_hqp.c:723-743)
             p, _i, x = csr
@@ -265,8 +265,8 @@ class Hqp_IpMatrix:
         def ninf(v):
             return float(np.abs(v).max()) if len(v) else 0.0
 
-        o.norm_data = max(rowsum(qp.Q, qp.n), rowsum(qp.A, qp.me), rowsum(qp.C, qp.m), ninf(qp.c), ninf(qp.b),
-                          ninf(qp.d))
+        o.norm_Q, o.norm_C, o.norm_d = rowsum(qp.Q, qp.n), rowsum(qp.C, qp.m), ninf(qp.d)
+        o.norm_data = max(o.norm_Q, rowsum(qp.A, qp.me), o.norm_C, ninf(qp.c), ninf(qp.b), o.norm_d)
         res = _lib.IpResult()
         self._tmp = []
         if self._device_vectors:

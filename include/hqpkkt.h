@@ -237,7 +237,7 @@ const char *hqpkkt_strerror(int status);
  * come back to the host.  The handle must hold the QP's matrices (hqpkkt_analyze +
  * hqpkkt_set_values with Q, A, C of the Hqp_Program, hqp/Hqp_Program.h:43-60); c, b, d
  * and the outputs x, y, z, w follow opts.loc of the handle.  Cold start
- * (qp_init_method 0) or hot start from the handle's previous solve.  result uses the reference's Hqp_Result numbering
+ * (qp_init_method 0-3) or hot start from the handle's previous solve.  result uses the reference's Hqp_Result numbering
  * (hqp/Hqp_impl.h:37-43): 0 optimal, 3 suboptimal, 4 degenerate. */
 typedef struct hqpkkt_ip_opts {
   double eps;       /* qp_eps (hqp/Hqp_Solver.C:53)                                   */
@@ -254,7 +254,11 @@ typedef struct hqpkkt_ip_opts {
                        the QP is solved again from a cold start and its iterations are added to
                        iters; 2 = cold start, but keep what the next hot start needs           */
   int max_warm_iters; /* qp_max_warm_iters (hqp/Hqp_IpsMehrotra.C:111), 0 = 25                */
-  int reserved[2];
+  int init_method;  /* qp_init_method of the cold start (hqp/Hqp_IpsMehrotra.C:226-250, 294-297):
+                       0 z = w = 1, r4 = 0 (default); 1 w = max(|d|,1e-10) |Q| / |C|; 2 w =
+                       |C| / max(|d|,1e-10) / |Q|; 3 as 0 with r4 = -z.*w and dz, dw added to z, w */
+  int reserved[1];
+  double norm_Q, norm_C, norm_d; /* inf-norms of Q, C (largest absolute row sum) and d: init_method 1, 2 */
 } hqpkkt_ip_opts;
 typedef struct hqpkkt_ip_result {
   int result, iters;     /* Hqp_Result, iterations                                    */

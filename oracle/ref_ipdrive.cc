@@ -35,6 +35,11 @@ static void fill(SPMAT *M, int rows, const int *p, const int *i, const double *x
 
 extern "C" {
 
+// qp_init_method of the solvers created below (hqp/Hqp_IpsMehrotra.C:124), set through the
+// reference's own Tcl variable after the solver exists
+static int g_init_method = 0;
+void hqpip_set_init_method(int v) { g_init_method = v; }
+
 // solver: 0 = Mehrotra, 1 = Franke, 2 = MehrotraHip (our Hqp_Solver plugin).  Returns 0, or the Meschach error number,
 // or -1 (setup) / -2 (unknown plugin name).
 // out[0] = iterations, out[1] = Hqp_Result (0 optimal), out[2] = seconds in
@@ -70,6 +75,7 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
   S->qp(qp);
   S->eps(qp_eps);
   S->max_iters(max_iters);
+  if (solver != 1) (void)If_SetInt("qp_init_method", g_init_method);
   int err = 0;
   double t0 = now_s(), t1 = t0, t2 = t0;
   m_catchall(S->init(); S->update(); t1 = now_s(); S->cold_start(); S->solve(); t2 = now_s(),
@@ -120,6 +126,7 @@ int hqpip_solve_hot(int solver, const char *mat_solver, int n, int me, int m, co
   S->qp(qp);
   S->eps(qp_eps);
   S->max_iters(max_iters);
+  if (solver != 1) (void)If_SetInt("qp_init_method", g_init_method);
   int err = 0, it1 = 0;
   double t1 = now_s(), t2 = t1;
   m_catchall(S->init(); S->update(); S->cold_start(); S->solve(); it1 = S->iter();

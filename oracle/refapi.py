@@ -201,6 +201,9 @@ def _host(host):
     lib = C.CDLL(path)
     lib.hqpip_solve.argtypes = ([C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp, _dp] * 3
                                 + [C.c_double, C.c_int, _dp, _dp, _dp, _dp])
+    if hasattr(lib, "hqpip_set_init_method"):
+        lib.hqpip_set_init_method.restype = None
+        lib.hqpip_set_init_method.argtypes = [C.c_int]
     if hasattr(lib, "hqpip_solve_hot"):
         lib.hqpip_solve_hot.restype = C.c_int
         lib.hqpip_solve_hot.argtypes = ([C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp, _dp] * 3
@@ -217,10 +220,11 @@ def host_available(host="ref"):
         return False
 
 
-def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250):
+def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250, init_method=0):
     """Run Hqp_IpsMehrotra / Hqp_IpsFranke of the reference on ``prog`` with the KKT
     plugin ``mat_solver``.  Returns dict(x, y, z, iters, result, seconds)."""
     lib = _host(host)
+    lib.hqpip_set_init_method(int(init_method))
     n, me, m = prog.dims
     args = []
     for (p, i, x), vec in zip((prog.Q, prog.A, prog.C), (prog.c, prog.b, prog.d)):

@@ -23,6 +23,7 @@ Hqp_IpsMehrotraHip::Hqp_IpsMehrotraHip()
   _gammaf = 0.01;  // hqp/Hqp_IpsMehrotra.C:95
   _hot = 2;
   _max_warm_iters = 25;  // hqp/Hqp_IpsMehrotra.C:111
+  _init_method = 0;      // hqp/Hqp_IpsMehrotra.C:112
   _n_factor = _n_solve = 0;
   _ms_total = 0.0;
   _matrix = new Hqp_IpRedSpBKPHip;
@@ -34,6 +35,7 @@ Hqp_IpsMehrotraHip::Hqp_IpsMehrotraHip()
   _ifList.append(new If_Int("qp_n_solve", &_n_solve));
   _ifList.append(new If_Real("qp_device_ms", &_ms_total));
   _ifList.append(new If_Int("qp_max_warm_iters", &_max_warm_iters));
+  _ifList.append(new If_Int("qp_init_method", &_init_method));
   _ifList.append(new IF_MODULE("qp_mat_solver", &_matrix, Hqp_IpMatrix));
 }
 
@@ -100,10 +102,11 @@ void Hqp_IpsMehrotraHip::solve()
   opts.gammaf = _gammaf;
   opts.hot_start = _hot;
   opts.max_warm_iters = _max_warm_iters;
+  opts.init_method = _init_method;
+  opts.norm_Q = sp_norm_inf(_qp->Q), opts.norm_C = sp_norm_inf(_qp->C), opts.norm_d = v_norm_inf(_qp->d);
   // hqp/Hqp_IpsMehrotra.C:462-464
-  opts.norm_data = max(max(max(max(max(sp_norm_inf(_qp->Q), sp_norm_inf(_qp->A)),
-                                   sp_norm_inf(_qp->C)), v_norm_inf(_qp->c)),
-                           v_norm_inf(_qp->b)), v_norm_inf(_qp->d));
+  opts.norm_data = max(max(max(max(max(opts.norm_Q, sp_norm_inf(_qp->A)), opts.norm_C), v_norm_inf(_qp->c)),
+                           v_norm_inf(_qp->b)), opts.norm_d);
 
   int status = hqpkkt_mehrotra(mat->handle(), &opts, _qp->c->ve, _qp->b->ve, _qp->d->ve,
                                _qp->x->ve, _y->ve, _z->ve, _w->ve, &res);

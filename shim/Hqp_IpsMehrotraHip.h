@@ -12,8 +12,7 @@
  *                                     hqp/Hqp_IpsMehrotra.C:92) | SpBKPHip | LQDOCPHip
  * cold_start() / hot_start() select how the next solve() begins (the hot start with the
  * reference's own fall-back to a cold start, hqp/Hqp_IpsMehrotra.C:696-733).
- * Differences to Hqp_IpsMehrotra: qp_init_method 0 only, no qp_step (single iterations
- * are not exposed).
+ * Difference to Hqp_IpsMehrotra: no qp_step (single iterations are not exposed).
  */
 #ifndef Hqp_IpsMehrotraHip_H
 #define Hqp_IpsMehrotraHip_H
@@ -31,6 +30,7 @@ class Hqp_IpsMehrotraHip : public Hqp_Solver {
   Real _ms_total;           // device time of the last solve, milliseconds
   int _hot;                 // how the next solve() starts: hqpkkt_ip_opts.hot_start
   int _max_warm_iters;      // qp_max_warm_iters (hqp/Hqp_IpsMehrotra.C:111,122)
+  int _init_method;         // qp_init_method (hqp/Hqp_IpsMehrotra.C:112,124)
   Hqp_IpMatrix *_matrix;
 
  public:

@@ -306,3 +306,38 @@ def test_hot_start_follows_the_reference(K, scale, kind):
         hh = refapi.ip_solve_hot(prog, c2, prog.b, prog.d, "MehrotraHip", kind + "Hip", host="hip")
         assert hh["result"] == 0 and abs(hh["iters"] - ref["iters"]) <= 1
         assert np.abs(hh["x"] - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RedSpBKP", "SpBKP"])
+@pytest.mark.parametrize("init_method", [1, 2, 3])
+@pytest.mark.parametrize("case", ["did400", "banded"])
+def test_cold_start_init_methods_follow_the_reference(case, init_method, kind):
+    """qp_init_method 1-3 of the cold start (hqp/Hqp_IpsMehrotra.C:226-250, 294-297): other
+    initial slacks / multipliers, other iteration counts (DID K = 400: 13 / 21 / 23 instead of
+    31) - the same ones on both sides, same optimiser."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    prog = problems.did_like_qp(400) if case == "did400" else problems.banded_qp(300, 8, 5)
+    ref = refapi.ip_solve(prog, "Mehrotra", kind, init_method=init_method)
+    M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)()
+    M.init(prog)
+    x, _y, _z, _w, info = M.mehrotra(prog, init_method=init_method)
+    assert ref["result"] == 0
+    if case == "did400" and kind == "RedSpBKP" and init_method in (2, 3):
+        # the accuracy envelope of DESIGN.md section 6: with these starting points the last two
+        # iterations of the degenerate K = 400 problem see z/w over 15+ decades, and the REDUCED
+        # system loses the last step (phi jumps from 1e-8 to 1e-3; "suboptimal" two iterations
+        # after the reference's "optimal", objective equal to 1e-5) - the FULL plugin and
+        # init_method 0, 1 agree exactly
+        assert info["result"] in (0, 3) and abs(info["iters"] - ref["iters"]) <= 2, (info, ref["iters"])
+        fr, fd = objective(prog, ref["x"]), objective(prog, x)
+        assert abs(fr - fd) <= 1e-5 * max(1.0, abs(fr))
+        return
+    assert info["result"] == 0
+    assert abs(info["iters"] - ref["iters"]) <= 1, (info["iters"], ref["iters"])
+    assert np.abs(x - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max())
+    if case == "did400" and refapi.host_available("hip"):
+        hh = refapi.ip_solve(prog, "MehrotraHip", kind + "Hip", host="hip", init_method=init_method)
+        assert hh["result"] == 0 and abs(hh["iters"] - ref["iters"]) <= 1
