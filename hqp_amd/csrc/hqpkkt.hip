@@ -204,6 +204,11 @@ struct hqpkkt {
   bool lazy = false, factor_unchecked = false;
   // hqpkkt_mehrotra left x, y and the hot-start candidates of z, w in ipv (same dimensions)
   bool ip_hot_valid = false;
+  // the caller's pattern (hqpkkt_analyze), kept for the one repetition of the symbolic phase
+  // that zd_policy -1 may ask for when the first values arrive; zd_used: policy of h->an
+  std::vector<int> pQp, pQi, pAp, pAi, pCp, pCi;
+  int zd_used = 2;
+  bool zd_decided = true;
   bool short_rows = false;  // CSR rows of a handful of entries: 4 lanes per row in the SpMV kernels
   void drop_graphs() {
     for (auto &g : gfactor) g.drop();
@@ -758,7 +763,7 @@ int hqpkkt_default_opts(hqpkkt_opts *o) {
   o->pivot_eps = 1e-20;  // only (near-)exact zeros are replaced: the reference accepts any non-zero pivot
   o->leaf_size = 0;
   o->max_pivots = 0;
-  o->zd_policy = 2;
+  o->zd_policy = -1;  // by the values (hqpkkt_set_values)
   o->slack_policy = 2;
   return 0;
 }
@@ -799,6 +804,8 @@ int hqpkkt_destroy(hqpkkt_t *h) {
   return 0;
 }
 
+static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd);
+
 int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *Qi,
                    const int *Ap, const int *Ai, const int *Cp, const int *Ci, int *sbw) {
   if (!h) return HQPKKT_E_NULL;
@@ -812,6 +819,23 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   }
   h->analyzed = false;
   h->ip_hot_valid = false;
+  auto keep = [](std::vector<int> &dst, const int *src, size_t k) {
+    dst.clear();
+    if (src && k) dst.assign(src, src + k);
+  };
+  keep(h->pQp, Qp, n ? (size_t)n + 1 : 0), keep(h->pQi, Qi, n ? (size_t)Qp[n] : 0);
+  keep(h->pAp, Ap, me ? (size_t)me + 1 : 0), keep(h->pAi, Ai, me ? (size_t)Ap[me] : 0);
+  keep(h->pCp, Cp, m ? (size_t)m + 1 : 0), keep(h->pCi, Ci, m ? (size_t)Cp[m] : 0);
+  h->zd_decided = h->opts.zd_policy >= 0;
+  int e = run_analysis(h, n, me, m, h->zd_decided ? h->opts.zd_policy : 2);
+  if (e) return e;
+  if (sbw) *sbw = h->an.sbw;
+  return 0;
+}
+
+// the symbolic phase with the zero-diagonal policy zd (hqpkkt_analyze; once more from
+// hqpkkt_set_values when zd_policy -1 sees weak Hessian diagonals)
+static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd) {
   h->an = Analysis();
   h->an.shard_rank = h->shard_rank, h->an.shard_count = h->shard_count;
   h->an.slack_policy = h->opts.slack_policy;
@@ -819,9 +843,10 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->an.amalgamation = h->opts.amalgamation != 0;
   if (h->opts.upd_pingpong_mb > 0) h->an.upd_pingpong_bytes = (long long)h->opts.upd_pingpong_mb << 20;
   if (h->opts.upd_pingpong_mb < 0) h->an.upd_pingpong_bytes = 0;
-  int e = h->an.run(h->opts.mode, n, me, m, Qp, Qi, Ap, Ai, Cp, Ci, h->opts.leaf_size,
-                    h->opts.max_pivots, h->opts.zd_policy);
+  int e = h->an.run(h->opts.mode, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),
+                    h->pCp.data(), h->pCi.data(), h->opts.leaf_size, h->opts.max_pivots, zd);
   if (e) return e;
+  h->zd_used = zd;
   h->analyzed = true;
   Analysis &an = h->an;
   h->st.dim = an.dim, h->st.sbw = an.sbw, h->st.n_supernodes = an.nnodes;
@@ -836,7 +861,6 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   h->st.bytes_exchange_factor = (long long)sizeof(double) * an.upd_x_slot * (an.xroots.empty() ? 0 : an.shard_count);
   h->st.bytes_exchange_step =
       an.shard_count > 1 ? (long long)sizeof(double) * (an.cb_x_slot * an.shard_count + an.dim) : 0;
-  if (sbw) *sbw = an.sbw;
   return 0;
 }
 
@@ -846,6 +870,37 @@ int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const dou
   Analysis &an = h->an;
   if ((an.nq && !Qx) || (an.na && !Ax) || (an.nc && !Cx)) return HQPKKT_E_NULL;
   int e;
+  if (!h->zd_decided) {
+    // zd_policy -1: an x whose Hessian diagonal is weak against its coupling to an equality
+    // needs the 2x2 pivot with that equality's multiplier inside its own pivot block
+    h->zd_decided = true;
+    const int n = an.n, me = an.me;
+    std::vector<double> hq, ha;
+    const double *q = Qx, *a = Ax;
+    if (h->opts.loc == HQPKKT_LOC_DEVICE) {
+      HIPCHK(hipSetDevice(h->opts.device));
+      hq.resize(an.nq), ha.resize(an.na);
+      if (an.nq) HIPCHK(hipMemcpy(hq.data(), Qx, sizeof(double) * an.nq, hipMemcpyDeviceToHost));
+      if (an.na) HIPCHK(hipMemcpy(ha.data(), Ax, sizeof(double) * an.na, hipMemcpyDeviceToHost));
+      q = hq.data(), a = ha.data();
+    }
+    std::vector<double> qd(n, 0.0), am(n, 0.0);
+    for (int i = 0; i < n; i++)
+      for (int k = h->pQp[i]; k < h->pQp[i + 1]; k++)
+        if (h->pQi[k] == i) qd[i] = std::fabs(q[k]);
+    for (int r = 0; r < me; r++)
+      for (int k = h->pAp[r]; k < h->pAp[r + 1]; k++) am[h->pAi[k]] = std::fmax(am[h->pAi[k]], std::fabs(a[k]));
+    bool weak = false;
+    for (int i = 0; i < n && !weak; i++) weak = am[i] > 0.0 && qd[i] < 0.01 * am[i];
+    if (weak) {
+      if (h->uploaded) {
+        (void)hipStreamSynchronize(h->stream);
+        h->release_device();
+      }
+      const int n2 = an.n, me2 = an.me, m2 = an.m;
+      if ((e = run_analysis(h, n2, me2, m2, 0))) return e;
+    }
+  }
   if (!h->uploaded && (e = upload(h))) return e;
   HIPCHK(hipSetDevice(h->opts.device));
   hipMemcpyKind kind =

@@ -63,8 +63,18 @@ typedef struct hqpkkt_opts {
   int leaf_size;     /* nested-dissection leaf size in rows (0 = default)     */
   int max_pivots;    /* max pivots per supernode, <= 128 (0 = default)        */
   int zd_policy;     /* placement of variables with a structurally zero diagonal
-                        (equality multipliers): 2 = behind all their neighbours
-                        (default), 0 = behind one matched neighbour             */
+                        (equality multipliers): 2 = behind all their neighbours - the
+                        pivot is the complete Schur complement A H^-1 A', all pivots 1x1
+                        when the Hessian diagonal is strong (fast); 0 = right behind one
+                        matched neighbour, so that a 2x2 pivot with it is available inside
+                        the pivot block - what QPs with weak Hessian diagonals need (a
+                        state with Q_ii = 1e-4 coupled by 1.0 to a multiplier in an
+                        ancestor supernode is otherwise eliminated with a multiplier of
+                        1e4: in the last iterations of Prg_DID the residual of a solve is
+                        1e-1 instead of 1e-15).  -1 (default) = decided by the values at
+                        the first hqpkkt_set_values after hqpkkt_analyze: 0 if some x has
+                        |Q_ii| < 0.01 max_r |A_ri|, else 2 (the symbolic phase is then
+                        repeated once, mat_sbw does not change)                           */
   int slack_policy;  /* FULL mode, order of the slack rows inside a supernode:
                         2 = a slack row in front of one of its own x variables is
                         moved right behind it (default: avoids the run-time
@@ -82,11 +92,10 @@ typedef struct hqpkkt_opts {
                         the merged pivot set still fits a small front (<= 32 pivots, elimination
                         order unchanged).  For narrow bands (a handful of rows per separator) the
                         tree levels above the leaves shrink to a third, and a level costs launch
-                        latency there, not arithmetic: +7..12 % interior-point iterations/s on the
-                        Prg_DID structure.  Default 0: the Bunch-Kaufman search then runs over
-                        larger, mostly zero pivot blocks and picks other pivots; in the last
-                        iterations of a degenerate QP (weights z/w spread over 15 decades) that
-                        cost accuracy on one of the reference cases       */
+                        latency there, not arithmetic.  Default 0: +10 % interior-point
+                        iterations/s on the Prg_DID structure at K = 2000, -11 % at K = 33333
+                        (merged fronts of 25 pivots with many 2x2 pivots cost more than the
+                        launches they save); same iteration counts        */
   int reserved[1];
 } hqpkkt_opts;
 
