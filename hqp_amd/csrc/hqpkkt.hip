@@ -209,6 +209,11 @@ struct hqpkkt {
   std::vector<int> pQp, pQi, pAp, pAi, pCp, pCi;
   int zd_used = 2;
   bool zd_decided = true;
+  // zd_policy -1 on a QP with weak Hessian diagonals: the values on the host, so that a solve
+  // whose refinement fails can switch the handle to policy 0 (symbolic phase, upload, values,
+  // factorisation again) and repeat itself
+  bool zd_weak = false;
+  std::vector<double> hQ, hA, hC;
   bool short_rows = false;  // CSR rows of a handful of entries: 4 lanes per row in the SpMV kernels
   void drop_graphs() {
     for (auto &g : gfactor) g.drop();
@@ -220,7 +225,7 @@ struct hqpkkt {
     return DevTree{piv_start.p, npiv.p,     nbor.p,  parent.p, bptr.p,      bidx.p,     rel.p,
                    panel_off.p, upd_off.p, x_off.p, cb_off.p, child_ptr.p, child_idx.p, pinv.p, pinv_off.p};
   }
-  void release_device() {
+  void release_device(bool keep_ip = false) {  // keep_ip: hqpkkt_mehrotra's vectors and the pinned words stay
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
                        &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags};
     for (auto b : ib) b->release();
@@ -229,10 +234,11 @@ struct hqpkkt {
                              &zero_panel};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &ipv};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv};
     for (auto b : db) b->release();
+    if (!keep_ip) ipv.release();
     terms.release(), esign.release(), bits.p = nullptr;
-    if (hpin) (void)hipHostFree(hpin), hpin = nullptr;
+    if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr;
     if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
     hstage_in = hstage_out = 0;
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
@@ -827,6 +833,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   keep(h->pAp, Ap, me ? (size_t)me + 1 : 0), keep(h->pAi, Ai, me ? (size_t)Ap[me] : 0);
   keep(h->pCp, Cp, m ? (size_t)m + 1 : 0), keep(h->pCi, Ci, m ? (size_t)Cp[m] : 0);
   h->zd_decided = h->opts.zd_policy >= 0;
+  h->zd_weak = false;
   int e = run_analysis(h, n, me, m, h->zd_decided ? h->opts.zd_policy : 2);
   if (e) return e;
   if (sbw) *sbw = h->an.sbw;
@@ -892,14 +899,20 @@ int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const dou
       for (int k = h->pAp[r]; k < h->pAp[r + 1]; k++) am[h->pAi[k]] = std::fmax(am[h->pAi[k]], std::fabs(a[k]));
     bool weak = false;
     for (int i = 0; i < n && !weak; i++) weak = am[i] > 0.0 && qd[i] < 0.01 * am[i];
-    if (weak) {
-      if (h->uploaded) {
-        (void)hipStreamSynchronize(h->stream);
-        h->release_device();
-      }
-      const int n2 = an.n, me2 = an.me, m2 = an.m;
-      if ((e = run_analysis(h, n2, me2, m2, 0))) return e;
-    }
+    h->zd_weak = weak;
+  }
+  if (h->zd_weak && h->zd_used != 0) {  // what the switch to policy 0 will need
+    auto keep = [&](std::vector<double> &dst, const double *src, size_t k) -> int {
+      dst.resize(k);
+      if (!k) return 0;
+      if (h->opts.loc == HQPKKT_LOC_DEVICE) {
+        HIPCHK(hipSetDevice(h->opts.device));
+        HIPCHK(hipMemcpy(dst.data(), src, sizeof(double) * k, hipMemcpyDeviceToHost));
+      } else
+        std::memcpy(dst.data(), src, sizeof(double) * k);
+      return 0;
+    };
+    if ((e = keep(h->hQ, Qx, an.nq)) || (e = keep(h->hA, Ax, an.na)) || (e = keep(h->hC, Cx, an.nc))) return e;
   }
   if (!h->uploaded && (e = upload(h))) return e;
   HIPCHK(hipSetDevice(h->opts.device));
@@ -916,6 +929,25 @@ int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const dou
   h->have_values = true;
   h->factored = false;
   return 0;
+}
+
+// zd_policy -1, weak Hessian diagonals, a solve whose refinement did not reach mat_eps: from now
+// on every multiplier right behind a matched neighbour (policy 0).  Symbolic phase, upload and
+// values again (hqpkkt_mehrotra's vectors stay); the caller factorises and solves once more.
+static int switch_to_policy0(hqpkkt_t *h) {
+  HIPCHK(hipSetDevice(h->opts.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const bool lazy = h->lazy, hot = h->ip_hot_valid;
+  const int loc = h->opts.loc;
+  h->release_device(true);
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  int e = run_analysis(h, n, me, m, 0);
+  if (e) return e;
+  h->opts.loc = HQPKKT_LOC_HOST;  // the kept values are host copies
+  h->lazy = false;
+  e = hqpkkt_set_values(h, h->hQ.data(), h->hA.data(), h->hC.data());
+  h->opts.loc = loc, h->lazy = lazy, h->ip_hot_valid = hot;
+  return e;
 }
 
 int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
@@ -1026,6 +1058,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   const OutPtrs outp{dx, dy, dz, dw};
   if ((e = run_residual(h, v, &res, h->lazy ? nullptr : &outp))) return e;
   const bool refined = res > h->opts.eps;  // otherwise the caller's copy is already complete
+  const double res_first = res;
   // correction solve: rhs = residual vectors, result = vcor
   Vecs c = v;
   c.r1 = h->vres.p, c.r2 = c.r1 + n, c.r3 = c.r2 + me, c.r4 = c.r3 + m;
@@ -1049,6 +1082,13 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
     } while (res > res_last && alpha > 0.0);
     if (alpha <= 0.0) break;
   }
+  if (!(res <= h->opts.eps) && h->zd_weak && h->zd_used == 2 && h->an.shard_count <= 1) {
+    // the refinement did not reach mat_eps: weak Hessian diagonals and every multiplier behind
+    // ALL its neighbours is the placement that loses accuracy when z/w spreads (hqpkkt_opts.
+    // zd_policy); switch the handle to the matching rule and do this factor + solve again
+    if ((e = switch_to_policy0(h)) || (e = hqpkkt_factor(h, z, w))) return e;
+    return hqpkkt_solve(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res_out);
+  }
   HIPCHK(hipEventRecord(h->ev1, s));
   if (h->lazy) {
     if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
@@ -1062,6 +1102,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
     h->st.ms_solve = elapsed(h->ev0, h->ev1);
   }
   h->st.refine_rounds = rounds;
+  if (getenv("HQPKKT_TRACE_SOLVE")) fprintf(stderr, "solve: first residual %.3e, %d rounds, final %.3e\n", res_first, rounds, res);
   if (res_out) *res_out = res;
   if (res != res) return HQPKKT_E_SING;
   return 0;

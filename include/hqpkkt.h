@@ -71,10 +71,11 @@ typedef struct hqpkkt_opts {
                         state with Q_ii = 1e-4 coupled by 1.0 to a multiplier in an
                         ancestor supernode is otherwise eliminated with a multiplier of
                         1e4: in the last iterations of Prg_DID the residual of a solve is
-                        1e-1 instead of 1e-15).  -1 (default) = decided by the values at
-                        the first hqpkkt_set_values after hqpkkt_analyze: 0 if some x has
-                        |Q_ii| < 0.01 max_r |A_ri|, else 2 (the symbolic phase is then
-                        repeated once, mat_sbw does not change)                           */
+                        1e-1 instead of 1e-15).  -1 (default) = 2, and where the values say
+                        that 0 may be needed (some x with |Q_ii| < 0.01 max_r |A_ri|) the
+                        first hqpkkt_solve whose refinement does not reach mat_eps switches
+                        the handle to 0 (symbolic phase, upload, values and factorisation
+                        once more; mat_sbw does not change) and repeats itself             */
   int slack_policy;  /* FULL mode, order of the slack rows inside a supernode:
                         2 = a slack row in front of one of its own x variables is
                         moved right behind it (default: avoids the run-time
@@ -92,10 +93,9 @@ typedef struct hqpkkt_opts {
                         the merged pivot set still fits a small front (<= 32 pivots, elimination
                         order unchanged).  For narrow bands (a handful of rows per separator) the
                         tree levels above the leaves shrink to a third, and a level costs launch
-                        latency there, not arithmetic.  Default 0: +10 % interior-point
-                        iterations/s on the Prg_DID structure at K = 2000, -11 % at K = 33333
-                        (merged fronts of 25 pivots with many 2x2 pivots cost more than the
-                        launches they save); same iteration counts        */
+                        latency there, not arithmetic: +7..10 % interior-point iterations/s on
+                        the Prg_DID structure, same iteration counts.  Default 0 (DESIGN.md
+                        section 4)                                                              */
   int reserved[1];
 } hqpkkt_opts;
 
