@@ -137,6 +137,19 @@ def ip_iterations(K=2000):
         out["hip_device_resident_amalgamated"] = {"iters": info["iters"], "result": info["result"],
                                                   "seconds": info["ms_total"] * 1e-3,
                                                   "ip_iters_per_s": info["iters"] / (info["ms_total"] * 1e-3)}
+        if K <= 4000:
+            # the reference's other IP solver (Hqp_IpsFranke, the default of Hqp_SqpSolver): one
+            # factor + one solve per iteration; reference alone vs hqpkkt_franke
+            r = refapi.ip_solve(prog, "Franke", "RedSpBKP", host="hip", max_iters=400)
+            out["franke_reference_cpu"] = {"iters": r["iters"], "result": r["result"], "seconds": r["seconds"],
+                                           "ip_iters_per_s": r["iters"] / r["seconds"] if r["seconds"] > 0 else None}
+            M = ipmatrix.IpRedSpBKP()
+            M.init(prog)
+            M.franke(prog, max_iters=400)
+            _x, _y, _z, _w, info = M.franke(prog, max_iters=400)
+            out["franke_device_resident"] = {"iters": info["iters"], "result": info["result"],
+                                             "seconds": info["ms_total"] * 1e-3,
+                                             "ip_iters_per_s": info["iters"] / (info["ms_total"] * 1e-3)}
         return out
     except Exception as e:  # never let the secondary measurement break the bench line
         return {"error": str(e)}

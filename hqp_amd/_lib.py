@@ -25,7 +25,7 @@ SYMBOLS = [
     "hqpkkt_set_stream", "hqpkkt_get_stats", "hqpkkt_strerror", "hqpkkt_debug_get",
     "hqpkkt_selftest_mfma", "hqpkkt_set_profile", "hqpkkt_get_profile",
     "hqpkkt_profile_class_name", "hqpkkt_set_shard", "hqpkkt_debug_read",
-    "hqpkkt_default_ip_opts", "hqpkkt_mehrotra",
+    "hqpkkt_default_ip_opts", "hqpkkt_mehrotra", "hqpkkt_franke",
 ]
 
 XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
@@ -122,6 +122,7 @@ def lib():
     L.hqpkkt_debug_read.argtypes = [vp, C.c_int, C.c_int, vp, C.c_longlong, C.POINTER(C.c_longlong)]
     L.hqpkkt_default_ip_opts.argtypes = [C.POINTER(IpOpts)]
     L.hqpkkt_mehrotra.argtypes = [vp, C.POINTER(IpOpts)] + [dp] * 7 + [C.POINTER(IpResult)]
+    L.hqpkkt_franke.argtypes = [vp, C.POINTER(IpOpts)] + [dp] * 7 + [C.POINTER(IpResult)]
     _lib = L
     return L
 

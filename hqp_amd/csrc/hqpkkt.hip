@@ -1496,6 +1496,155 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   return finish(result);
 }
 
+// ---- device-resident Franke loop ----------------------------------------------
+// Restatement of hqp/Hqp_IpsFranke.C: cold_start (:156-216), step (:271-378), solve
+// (:381-416, cold start only).  One factor + one solve per iteration; the scalars (mu from
+// the gap and rhomin, the step length, zeta) live on the host as in the reference.
+int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
+                  const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
+  if (!h || !res) return HQPKKT_E_NULL;
+  if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
+  if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
+  hqpkkt_ip_opts o;
+  if (opts)
+    o = *opts;
+  else
+    hqpkkt_default_ip_opts(&o);
+  Analysis &an = h->an;
+  const int n = an.n, me = an.me, m = an.m;
+  if ((n && !c) || (me && !b) || (m && !d) || (n && !x) || (me && !y) || (m && (!z || !w))) return HQPKKT_E_NULL;
+  HIPCHK(hipSetDevice(h->opts.device));
+  hipStream_t s = h->stream;
+  const size_t nv = (size_t)n + me + 2 * (size_t)m;
+  // same arena as hqpkkt_mehrotra (its hot-start data does not survive this call)
+  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
+  int e;
+  if (h->ipv.count < need && (e = h->ipv.alloc(need))) return e;
+  h->ip_hot_valid = false;
+  IpCtx C;
+  C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
+  double *q = h->ipv.p;
+  auto take = [&](size_t k) { double *r = q; q += k; return r; };
+  C.x = take(n), C.y = take(me), C.z = take(m), C.w = take(m);
+  C.r1 = take(n), C.r2 = take(me), C.r3 = take(m), C.r4 = take(m);
+  double *a1 = take(n), *a2 = take(me), *a3 = take(m);
+  (void)take(m);
+  C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
+  C.c = take(n), C.b = take(me), C.d = take(m);
+  C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
+  const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+  if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
+  if (me) HIPCHK(hipMemcpyAsync(C.b, b, sizeof(double) * me, in_kind, s));
+  if (m) HIPCHK(hipMemcpyAsync(C.d, d, sizeof(double) * m, in_kind, s));
+  const int saved_loc = h->opts.loc;
+  struct Restore {
+    hqpkkt_t *h;
+    int loc;
+    ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
+  } restore{h, saved_loc};
+  h->opts.loc = HQPKKT_LOC_DEVICE;
+  h->lazy = true;
+  hipEvent_t tb, te;
+  HIPCHK(hipEventCreate(&tb));
+  HIPCHK(hipEventCreate(&te));
+  HIPCHK(hipEventRecord(tb, s));
+  std::memset(res, 0, sizeof(*res));
+  res->result = 2;
+  int iter = 0, n_factor = 0, n_solve = 0;
+  auto finish = [&](int result) -> int {
+    res->result = result, res->iters = iter, res->n_factor = n_factor, res->n_solve = n_solve;
+    if (n) HIPCHK(hipMemcpyAsync(x, C.x, sizeof(double) * n, out_kind, s));
+    if (me) HIPCHK(hipMemcpyAsync(y, C.y, sizeof(double) * me, out_kind, s));
+    if (m) HIPCHK(hipMemcpyAsync(z, C.z, sizeof(double) * m, out_kind, s));
+    if (m) HIPCHK(hipMemcpyAsync(w, C.w, sizeof(double) * m, out_kind, s));
+    HIPCHK(hipEventRecord(te, s));
+    HIPCHK(hipStreamSynchronize(s));
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, tb, te);
+    res->ms_total = ms;
+    (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+    return 0;
+  };
+  const int total = n + me + m;
+  const double beta = 0.995;  // qp_beta (:77)
+  double rhomin = 0.0, Ltilde = 0.0, zeta = 1.0, gap = 0.0, alpha = 1.0, alphabar = 1.0;
+  // ---- cold start (:156-216)
+  if (m > 0) {
+    rhomin = 1000.0 * m;
+    k_fr_dstats<<<IP_BLOCKS, 256, 0, s>>>(m, C.d, C.part);
+    const int opsd[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+    if ((e = C.reduce(opsd, 3))) return e;
+    const double min_d = C.hout[0], norm_d = C.hout[1];
+    Ltilde = std::fmax(norm_d, -min_d);  // "according Wright" (qp_mu0 = 0)
+    Ltilde = std::fmax(Ltilde, 1e2 * m);
+  }
+  if (h->short_rows)
+    k_fr_cold<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
+  else
+    k_fr_cold<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
+  const int OPS_SUM[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+  if (m > 0) {
+    if ((e = C.reduce(OPS_SUM, 1))) return e;
+    gap = C.hout[0];
+  }
+  int result = 2;
+  // ---- iterations (:381-416 around :271-378)
+  while (true) {
+    if (iter == 0) alphabar = 1.0;
+    double mu;
+    if (1.0 / gap < rhomin || alpha < 1.0) {
+      mu = alphabar * gap / rhomin;             // potential reduction
+      mu += (1.0 - alphabar) * gap / (double)m;  // centering
+    } else
+      mu = gap * gap;  // quadratic convergence
+    if (m == 0) mu = 0.0;
+    k_fr_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, zeta, mu, a1, a2, a3, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
+    double resid = 0.0;
+    n_factor++, n_solve++;
+    if ((e = hqpkkt_factor(h, C.z, C.w)) ||
+        (e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid))) {
+      if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:308-310)
+      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
+      return e;
+    }
+    double val1 = 2.0;
+    if (m > 0) {
+      k_fr_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+      const int opsr[IP_SLOTS] = {IP_MIN, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+      if ((e = C.reduce(opsr, 1))) return e;
+      val1 = C.hout[0];
+    }
+    val1 *= beta;
+    alpha = std::fmin(1.0, val1);
+    alphabar = 0.5 * alphabar + 0.5 * alpha;
+    if (alphabar == 1.0)
+      rhomin *= 2.0;
+    else if (alphabar < 0.5 && rhomin > 100.0 * m)
+      rhomin /= 2.0;
+    k_fr_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
+    zeta *= (1.0 - alpha);
+    const int opsu[IP_SLOTS] = {IP_SUM, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+    if ((e = C.reduce(opsu, 2))) return e;
+    gap = m > 0 ? C.hout[0] : 0.0;
+    res->gap = gap, res->alpha = alpha, res->mu = mu, res->phi = zeta;
+    if (!std::isfinite(gap) || !std::isfinite(C.hout[1])) {  // :351-354
+      result = 4;
+      break;
+    }
+    iter++;
+    if (!(zeta < o.eps))  // (:361-374, comparisons written to filter out NaN)
+      result = alpha < o.eps ? 3 : 2;
+    else if (!(gap < o.eps) || !(resid < o.eps))
+      result = 1;  // Hqp_Feasible
+    else
+      result = 0;
+    if (iter >= o.max_iters) break;
+    if (result == 0 || result == 3 || result == 4) break;
+  }
+  return finish(result);
+}
+
 int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {
   if (!h || !sbw) return HQPKKT_E_NULL;
   *sbw = h->analyzed ? h->an.sbw : -1;

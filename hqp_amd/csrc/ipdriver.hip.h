@@ -373,4 +373,128 @@ __global__ void k_ip_fill(int n, double v, double *__restrict__ x) {
   if (i < n) x[i] = v;
 }
 
+// ---------------------------------------------------------------- Franke's solver
+// Device kernels of hqpkkt_franke, the restatement of hqp/Hqp_IpsFranke.C (potential
+// reduction method with the infeasibility measure zeta; cold_start :156-216, step :271-378).
+//   slots: 0 min d, 1 max|d|, 2 sum d
+__global__ void __launch_bounds__(256) k_fr_dstats(int m, const double *__restrict__ d, double *__restrict__ part) {
+  __shared__ double red[4];
+  double a = 1e300, b = 0.0, c = 0.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
+    a = fmin(a, d[i]), b = fmax(b, fabs(d[i])), c += d[i];
+  double *P = part + blockIdx.x * IP_SLOTS;
+  double r;
+  r = ip_block_reduce(a, IP_MIN, red); if (threadIdx.x == 0) P[0] = r;
+  r = ip_block_reduce(b, IP_MAX, red); if (threadIdx.x == 0) P[1] = r;
+  r = ip_block_reduce(c, IP_SUM, red);
+  if (threadIdx.x == 0) {
+    P[2] = r;
+    for (int k = 3; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+// cold start (:186-203): x = y = 0, z = Ltilde / m^2, w = Ltilde + d + 1e-10,
+// a1 = c - C'z, a2 = -b, a3 = Ltilde (zeta = 1); slot 0: z'w.  m = 0: a1 = c, a2 = -b.
+template <int LPR>
+__global__ void __launch_bounds__(256)
+k_fr_cold(int n, int me, int m, CsrDev CT, double Ltilde, const double *__restrict__ c, const double *__restrict__ b,
+          const double *__restrict__ d, double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+          double *__restrict__ w, double *__restrict__ a1, double *__restrict__ a2, double *__restrict__ a3,
+          double *__restrict__ part) {
+  __shared__ double red[4];
+  const int sub = threadIdx.x & (LPR - 1);
+  constexpr int RPB = 256 / LPR;
+  const int total = n + me + m;
+  const double z0 = m > 0 ? Ltilde / ((double)m * m) : 0.0;
+  double zw = 0.0;
+  for (int q = blockIdx.x * RPB + threadIdx.x / LPR; q < total; q += gridDim.x * RPB) {
+    if (q < n) {
+      double s = 0.0;  // (C'z)_q with the constant z
+      if (m > 0) {
+        const int e = CT.ptr[q + 1];
+        for (int k = CT.ptr[q] + sub; k < e; k += LPR) s += CT.val[k];
+        s = row_sum<LPR>(s) * z0;
+      }
+      if (sub == 0) x[q] = 0.0, a1[q] = c[q] - s;
+    } else if (q < n + me) {
+      if (sub == 0) y[q - n] = 0.0, a2[q - n] = -b[q - n];
+    } else if (sub == 0) {
+      const int j = q - n - me;
+      const double wj = Ltilde + d[j] + 1e-10;
+      z[j] = z0, w[j] = wj, a3[j] = Ltilde;
+      zw += z0 * wj;
+    }
+  }
+  const double r = ip_block_reduce(zw, IP_SUM, red);
+  if (threadIdx.x == 0) {
+    double *P = part + blockIdx.x * IP_SLOTS;
+    P[0] = r;
+    for (int k = 1; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+// right-hand sides of a step (:291-299): r1..r3 = -zeta a1..a3, r4 = z.*w - mu
+__global__ void k_fr_rhs(int n, int me, int m, double zeta, double mu, const double *__restrict__ a1,
+                         const double *__restrict__ a2, const double *__restrict__ a3, const double *__restrict__ z,
+                         const double *__restrict__ w, double *__restrict__ r1, double *__restrict__ r2,
+                         double *__restrict__ r3, double *__restrict__ r4) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q < n)
+    r1[q] = -zeta * a1[q];
+  else if (q < n + me)
+    r2[q - n] = -zeta * a2[q - n];
+  else if (q < n + me + m) {
+    const int j = q - n - me;
+    r3[j] = -zeta * a3[j], r4[j] = z[j] * w[j] - mu;
+  }
+}
+// maximal feasible step (:315-331): slot 0 = min(2, min over dz_i > 0 of z_i / dz_i, same for w);
+// the reference's running test "z_i < val dz_i" with dz_i >= 0 is exactly this minimum
+__global__ void __launch_bounds__(256)
+k_fr_ratio(int m, const double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ dz,
+           const double *__restrict__ dw, double *__restrict__ part) {
+  __shared__ double red[4];
+  double a = 2.0;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x) {
+    if (dz[i] > 0.0) a = fmin(a, z[i] / dz[i]);
+    if (dw[i] > 0.0) a = fmin(a, w[i] / dw[i]);
+  }
+  const double r = ip_block_reduce(a, IP_MIN, red);
+  if (threadIdx.x == 0) {
+    double *P = part + blockIdx.x * IP_SLOTS;
+    P[0] = r;
+    for (int k = 1; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+// the step (:343-349): x, y, z, w -= alpha d*; slots: 0 z'w, 1 max|x| (NaN -> inf)
+__global__ void __launch_bounds__(256)
+k_fr_update(int n, int me, int m, double alpha, double *__restrict__ x, double *__restrict__ y,
+            double *__restrict__ z, double *__restrict__ w, const double *__restrict__ dx,
+            const double *__restrict__ dy, const double *__restrict__ dz, const double *__restrict__ dw,
+            double *__restrict__ part) {
+  __shared__ double red[4];
+  double zw = 0.0, xm = 0.0;
+  const int total = n + me + m;
+  for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
+    if (q < n) {
+      const double v = x[q] - alpha * dx[q];
+      x[q] = v;
+      xm = fmax(xm, nan_to_inf(fabs(v)));
+    } else if (q < n + me) {
+      y[q - n] -= alpha * dy[q - n];
+    } else {
+      const int j = q - n - me;
+      const double zn = z[j] - alpha * dz[j], wn = w[j] - alpha * dw[j];
+      z[j] = zn, w[j] = wn;
+      zw += zn * wn;
+    }
+  }
+  double *P = part + blockIdx.x * IP_SLOTS;
+  double r;
+  r = ip_block_reduce(zw, IP_SUM, red); if (threadIdx.x == 0) P[0] = r;
+  r = ip_block_reduce(xm, IP_MAX, red);
+  if (threadIdx.x == 0) {
+    P[1] = r;
+    for (int k = 2; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+
 }  // namespace kktdev

@@ -245,7 +245,12 @@ class Hqp_IpMatrix:
         _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
         return out[: k.value]
 
-    def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0, init_method=0):
+    def franke(self, qp, eps=1e-10, max_iters=200):
+        """Device-resident run of the reference's other interior-point solver, Hqp_IpsFranke
+        (``hqpkkt_franke``, cold start): returns (x, y, z, w, info)."""
+        return self.mehrotra(qp, eps, max_iters, _entry="hqpkkt_franke")
+
+    def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0, init_method=0, _entry="hqpkkt_mehrotra"):
         """Device-resident Mehrotra predictor-corrector solve of the QP, the restatement of
         hqp/Hqp_IpsMehrotra.C behind ``hqpkkt_mehrotra``: returns (x, y, z, w, info).
         init()/update() must have been called with ``qp``.  ``hot_start``: 0 cold start,
@@ -280,7 +285,7 @@ class Hqp_IpMatrix:
         x, y, z, w = mk(qp.n), mk(qp.me), mk(qp.m), mk(qp.m)
         ptrs = [self._ptr(a, k, nm) for a, k, nm in zip(cin + [x, y, z, w], (qp.n, qp.me, qp.m, qp.n, qp.me, qp.m, qp.m),
                                                       ("c", "b", "d", "x", "y", "z", "w"))]
-        _check(self._L.hqpkkt_mehrotra(self._h, C.byref(o), *ptrs, C.byref(res)), "mehrotra")
+        _check(getattr(self._L, _entry)(self._h, C.byref(o), *ptrs, C.byref(res)), _entry)
         return x, y, z, w, res.asdict()
 
     def read_block(self, what, node):
