@@ -40,7 +40,7 @@ extern "C" {
 static int g_init_method = 0;
 void hqpip_set_init_method(int v) { g_init_method = v; }
 
-// solver: 0 = Mehrotra, 1 = Franke, 2 = MehrotraHip (our Hqp_Solver plugin).  Returns 0, or the Meschach error number,
+// solver: 0 = Mehrotra, 1 = Franke, 2 = MehrotraHip, 3 = FrankeHip (our Hqp_Solver plugins).  Returns 0, or the Meschach error number,
 // or -1 (setup) / -2 (unknown plugin name).
 // out[0] = iterations, out[1] = Hqp_Result (0 optimal), out[2] = seconds in
 // cold_start + solve, out[3] = seconds in init + update.
@@ -51,11 +51,12 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
                 int max_iters, double *x, double *y, double *z, double *out) {
   if (hqpref_startup() != 0) return -1;
   Hqp_Solver *S;
-  if (solver == 2) {
-    // our device-resident solver class (shim/Hqp_IpsMehrotraHip.C), created BY NAME through
+  if (solver >= 2) {
+    // our device-resident solver classes (shim/Hqp_IpsMehrotraHip.C), created BY NAME through
     // the reference's solver factory (iftcl/If_Class.h:92-105) as "sqp_qp_solver MehrotraHip"
     // would do; only registered in libhqphost_hip.so
-    S = If_ClassList_Hqp_Solver() ? If_ClassList_Hqp_Solver()->createObject("MehrotraHip") : NULL;
+    S = If_ClassList_Hqp_Solver() ? If_ClassList_Hqp_Solver()->createObject(solver == 2 ? "MehrotraHip" : "FrankeHip")
+                                  : NULL;
     if (!S) return -2;
   } else
     S = solver == 0 ? (Hqp_Solver *)new Hqp_IpsMehrotra : (Hqp_Solver *)new Hqp_IpsFranke;
@@ -75,7 +76,7 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
   S->qp(qp);
   S->eps(qp_eps);
   S->max_iters(max_iters);
-  if (solver != 1) (void)If_SetInt("qp_init_method", g_init_method);
+  if (solver == 0 || solver == 2) (void)If_SetInt("qp_init_method", g_init_method);
   int err = 0;
   double t0 = now_s(), t1 = t0, t2 = t0;
   m_catchall(S->init(); S->update(); t1 = now_s(); S->cold_start(); S->solve(); t2 = now_s(),
@@ -126,7 +127,7 @@ int hqpip_solve_hot(int solver, const char *mat_solver, int n, int me, int m, co
   S->qp(qp);
   S->eps(qp_eps);
   S->max_iters(max_iters);
-  if (solver != 1) (void)If_SetInt("qp_init_method", g_init_method);
+  if (solver == 0 || solver == 2) (void)If_SetInt("qp_init_method", g_init_method);
   int err = 0, it1 = 0;
   double t1 = now_s(), t2 = t1;
   m_catchall(S->init(); S->update(); S->cold_start(); S->solve(); it1 = S->iter();

@@ -233,7 +233,7 @@ def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-
                  _pad(x), _pad(vec)]
     x, y, z = np.zeros(max(n, 1)), np.zeros(max(me, 1)), np.zeros(max(m, 1))
     out = np.zeros(4)
-    e = lib.hqpip_solve({"Mehrotra": 0, "Franke": 1, "MehrotraHip": 2}[solver], mat_solver.encode(), n, me, m, *args,
+    e = lib.hqpip_solve({"Mehrotra": 0, "Franke": 1, "MehrotraHip": 2, "FrankeHip": 3}[solver], mat_solver.encode(), n, me, m, *args,
                         qp_eps, max_iters, x, y, z, out)
     if e:
         raise RefError(e, f"ip_solve[{solver},{mat_solver}]")
@@ -254,7 +254,7 @@ def ip_solve_hot(prog, c2, b2, d2, solver="Mehrotra", mat_solver="SpBKP", host="
                  _pad(x), _pad(vec)]
     x, y, z = np.zeros(max(n, 1)), np.zeros(max(me, 1)), np.zeros(max(m, 1))
     out = np.zeros(5)
-    e = lib.hqpip_solve_hot({"Mehrotra": 0, "Franke": 1, "MehrotraHip": 2}[solver], mat_solver.encode(), n, me, m,
+    e = lib.hqpip_solve_hot({"Mehrotra": 0, "Franke": 1, "MehrotraHip": 2, "FrankeHip": 3}[solver], mat_solver.encode(), n, me, m,
                             *args, _pad(c2), _pad(b2), _pad(d2), qp_eps, max_iters, x, y, z, out)
     if e:
         raise RefError(e, f"ip_solve_hot[{solver},{mat_solver}]")

@@ -12,6 +12,7 @@
 #include "hqpkkt.h"
 
 IF_CLASS_DEFINE("MehrotraHip", Hqp_IpsMehrotraHip, Hqp_Solver);
+IF_CLASS_DEFINE("FrankeHip", Hqp_IpsFrankeHip, Hqp_Solver);
 
 //--------------------------------------------------------------------------
 Hqp_IpsMehrotraHip::Hqp_IpsMehrotraHip()
@@ -90,6 +91,17 @@ void Hqp_IpsMehrotraHip::step()
 //--------------------------------------------------------------------------
 void Hqp_IpsMehrotraHip::solve()
 {
+  run(false);
+}
+
+// hqp/Hqp_IpsFranke.C on the device (hqpkkt_franke; cold start, qp_beta 0.995, qp_mu0 0)
+void Hqp_IpsFrankeHip::solve()
+{
+  run(true);
+}
+
+void Hqp_IpsMehrotraHip::run(bool franke)
+{
   Hqp_IpMatrixHip *mat = dynamic_cast<Hqp_IpMatrixHip *>(_matrix);
   if (!mat)
     m_error(E_INTERN, "Hqp_IpsMehrotraHip::solve: qp_mat_solver must be SpBKPHip, RedSpBKPHip or LQDOCPHip");
@@ -108,8 +120,8 @@ void Hqp_IpsMehrotraHip::solve()
   opts.norm_data = max(max(max(max(max(opts.norm_Q, sp_norm_inf(_qp->A)), opts.norm_C), v_norm_inf(_qp->c)),
                            v_norm_inf(_qp->b)), opts.norm_d);
 
-  int status = hqpkkt_mehrotra(mat->handle(), &opts, _qp->c->ve, _qp->b->ve, _qp->d->ve,
-                               _qp->x->ve, _y->ve, _z->ve, _w->ve, &res);
+  int status = (franke ? hqpkkt_franke : hqpkkt_mehrotra)(mat->handle(), &opts, _qp->c->ve, _qp->b->ve, _qp->d->ve,
+                                                          _qp->x->ve, _y->ve, _z->ve, _w->ve, &res);
   if (status != HQPKKT_OK) {
     fprintf(stderr, "Hqp_IpsMehrotraHip::solve: %s\n", hqpkkt_strerror(status));
     m_error(status == HQPKKT_E_MEM ? E_MEM : E_INTERN, "Hqp_IpsMehrotraHip::solve");

@@ -6,7 +6,7 @@
  *
  * Reference-side binding, compiled against the reference's headers like
  * Hqp_IpSpBKPHip.C.  Registered with the solver factory (iftcl/If_Class.h:53-60):
- *     sqp_qp_solver MehrotraHip
+ *     sqp_qp_solver MehrotraHip      (and FrankeHip, below)
  * and it owns an Hqp_IpMatrixHip plugin selected the usual way
  *     qp_mat_solver RedSpBKPHip      (default, as the reference defaults to RedSpBKP,
  *                                     hqp/Hqp_IpsMehrotra.C:92) | SpBKPHip | LQDOCPHip
@@ -45,6 +45,18 @@ class Hqp_IpsMehrotraHip : public Hqp_Solver {
   void solve();
 
   const char *name() { return "MehrotraHip"; }
+
+ protected:
+  void run(bool franke);
+};
+
+// sqp_qp_solver FrankeHip: the reference's Hqp_IpsFranke (hqp/Hqp_IpsFranke.C, the default
+// of Hqp_SqpSolver) on the device through hqpkkt_franke; same members, cold start only
+// (hot_start() starts cold)
+class Hqp_IpsFrankeHip : public Hqp_IpsMehrotraHip {
+ public:
+  void solve();
+  const char *name() { return "FrankeHip"; }
 };
 
 #endif

@@ -408,3 +408,8 @@ def test_device_resident_franke_follows_the_reference(case, kind):
     assert abs(info["iters"] - ref["iters"]) <= slack, (info["iters"], ref["iters"])
     assert np.abs(x - ref["x"]).max() <= (1e-4 if case.startswith("did") else 1e-6) * max(1.0, np.abs(ref["x"]).max())
     assert info["n_factor"] == info["n_solve"] == max(info["iters"], 1) or info["result"] == 4
+    if case in ("did400", "banded", "infeasible") and refapi.host_available("hip"):
+        # the Hqp_Solver class around it, created by name in the reference host ("sqp_qp_solver FrankeHip")
+        hh = refapi.ip_solve(prog, "FrankeHip", kind + "Hip", host="hip", max_iters=300)
+        assert (hh["result"], hh["iters"]) == (info["result"], info["iters"])
+        assert np.abs(hh["x"] - x).max() <= 1e-9 * max(1.0, np.abs(x).max())
