@@ -201,6 +201,9 @@ def _host(host):
     lib = C.CDLL(path)
     lib.hqpip_solve.argtypes = ([C.c_int, C.c_char_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp, _dp] * 3
                                 + [C.c_double, C.c_int, _dp, _dp, _dp, _dp])
+    if hasattr(lib, "hqpsqp_did"):
+        lib.hqpsqp_did.restype = C.c_int
+        lib.hqpsqp_did.argtypes = [C.c_int, C.c_char_p, C.c_char_p, C.c_double, C.c_int, _dp]
     if hasattr(lib, "hqpip_set_init_method"):
         lib.hqpip_set_init_method.restype = None
         lib.hqpip_set_init_method.argtypes = [C.c_int]
@@ -260,3 +263,16 @@ def ip_solve_hot(prog, c2, b2, d2, solver="Mehrotra", mat_solver="SpBKP", host="
         raise RefError(e, f"ip_solve_hot[{solver},{mat_solver}]")
     return dict(x=x[:n], y=y[:me], z=z[:m], iters=int(out[0]), result=int(out[1]), seconds=out[2],
                 first_iters=int(out[4]))
+
+
+def sqp_did(kmax, qp_solver="Mehrotra", mat_solver="SpBKP", host="ref", sqp_eps=1e-5, sqp_max_iters=100):
+    """BASELINE.json configs[0]: the reference's hqp_docp demo (Prg_DID, Hqp_SqpPowell) with the
+    QP solver / KKT plugin given by name (oracle/ref_sqpdrive.cc).  Returns dict(f, sqp_iters,
+    qp_iters, seconds, norm_inf, norm_grd_L, rc) - rc 0 = optimal."""
+    lib = _host(host)
+    out = np.zeros(8)
+    e = lib.hqpsqp_did(int(kmax), qp_solver.encode(), mat_solver.encode(), float(sqp_eps), int(sqp_max_iters), out)
+    if e > 0:
+        raise RefError(e, f"sqp_did[{qp_solver},{mat_solver}]")
+    return dict(f=out[0], sqp_iters=int(out[1]), qp_iters=int(out[2]), seconds=out[3], norm_inf=out[4],
+                norm_grd_L=out[5], rc=e)
