@@ -204,6 +204,8 @@ struct hqpkkt {
   bool lazy = false, factor_unchecked = false;
   // hqpkkt_mehrotra left x, y and the hot-start candidates of z, w in ipv (same dimensions)
   bool ip_hot_valid = false;
+  bool fr_hot_valid = false;  // hqpkkt_franke left x, y, z, w in ipv (same dimensions)
+  double fr_rhomin = 0.0;     // ... and its qp_rhomin, which hot_start keeps (hqp/Hqp_IpsFranke.C:222-266)
   // the caller's pattern (hqpkkt_analyze), kept for the one repetition of the symbolic phase
   // that zd_policy -1 may ask for when the first values arrive; zd_used: policy of h->an
   std::vector<int> pQp, pQi, pAp, pAi, pCp, pCi;
@@ -824,7 +826,7 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
     h->release_device();
   }
   h->analyzed = false;
-  h->ip_hot_valid = false;
+  h->ip_hot_valid = h->fr_hot_valid = false;
   auto keep = [](std::vector<int> &dst, const int *src, size_t k) {
     dst.clear();
     if (src && k) dst.assign(src, src + k);
@@ -1161,6 +1163,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     if ((e = h->ipv.alloc(need))) return e;
     h->ip_hot_valid = false;
   }
+  h->fr_hot_valid = false;  // the arena is shared with hqpkkt_franke
   IpCtx C;
   C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
   double *q = h->ipv.p;
@@ -1519,7 +1522,10 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
   // same arena as hqpkkt_mehrotra (its hot-start data does not survive this call)
   const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
   int e;
-  if (h->ipv.count < need && (e = h->ipv.alloc(need))) return e;
+  if (h->ipv.count < need) {
+    if ((e = h->ipv.alloc(need))) return e;
+    h->fr_hot_valid = false;
+  }
   h->ip_hot_valid = false;
   IpCtx C;
   C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
@@ -1568,7 +1574,27 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
   };
   const int total = n + me + m;
   const double beta = 0.995;  // qp_beta (:77)
-  double rhomin = 0.0, Ltilde = 0.0, zeta = 1.0, gap = 0.0, alpha = 1.0, alphabar = 1.0;
+  const int max_warm = o.max_warm_iters > 0 ? o.max_warm_iters : 15;  // qp_max_warm_iters (:81)
+  bool hot = o.hot_start == 1 && m > 0 && h->fr_hot_valid;
+  int fail_iters = 0, result = 2;
+  double rhomin = 0.0, Ltilde = 0.0, zeta = 1.0, gap = 0.0, alpha = 1.0, alphabar = 1.0, gap1 = 0.0;
+  const int OPS_SUM[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+  for (;;) {  // hot first (if asked for and possible), cold after a failed hot start (:381-416)
+  iter = 0, alpha = 1.0, zeta = 1.0, result = 2;
+  if (hot) {
+    // hot_start (:222-266): x, y, z, w of the last solve, w += 1e-10, the slack vectors a1..a3
+    // of that point - which are the right-hand sides r1..r3 of Mehrotra's loop
+    k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, 0.0, 1e-10, C.z, C.w);
+    if (h->short_rows)
+      k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                            h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
+    else
+      k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                             h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
+    if ((e = C.reduce(OPS_SUM, 3))) return e;
+    gap = C.hout[2] + 1.0;  // in_prod(z, w) + 1 (:248)
+    if (rhomin == 0.0) rhomin = h->fr_rhomin;
+  } else {
   // ---- cold start (:156-216)
   if (m > 0) {
     rhomin = 1000.0 * m;
@@ -1583,12 +1609,13 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     k_fr_cold<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
   else
     k_fr_cold<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
-  const int OPS_SUM[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+  gap = 0.0;
   if (m > 0) {
     if ((e = C.reduce(OPS_SUM, 1))) return e;
     gap = C.hout[0];
   }
-  int result = 2;
+  }
+  bool restart_cold = false;
   // ---- iterations (:381-416 around :271-378)
   while (true) {
     if (iter == 0) alphabar = 1.0;
@@ -1630,18 +1657,39 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     res->gap = gap, res->alpha = alpha, res->mu = mu, res->phi = zeta;
     if (!std::isfinite(gap) || !std::isfinite(C.hout[1])) {  // :351-354
       result = 4;
-      break;
+    } else {
+      iter++;
+      if (!(zeta < o.eps))  // (:361-374, comparisons written to filter out NaN)
+        result = alpha < o.eps ? 3 : 2;
+      else if (!(gap < o.eps) || !(resid < o.eps))
+        result = 1;  // Hqp_Feasible
+      else
+        result = 0;
     }
-    iter++;
-    if (!(zeta < o.eps))  // (:361-374, comparisons written to filter out NaN)
-      result = alpha < o.eps ? 3 : 2;
-    else if (!(gap < o.eps) || !(resid < o.eps))
-      result = 1;  // Hqp_Feasible
-    else
-      result = 0;
-    if (iter >= o.max_iters) break;
+    // ---- what solve() does after every step() (:388-403)
+    if (hot) {
+      if (iter == 1)
+        gap1 = gap;
+      else if (gap > gap1) {
+        fail_iters += iter;
+        restart_cold = true;
+        break;
+      }
+    }
+    if (iter + fail_iters >= o.max_iters) break;
+    if (hot && iter >= max_warm) break;
     if (result == 0 || result == 3 || result == 4) break;
   }
+  if (restart_cold || (hot && result != 0)) {  // bad hot start (:405-411)
+    if (!restart_cold) fail_iters += iter;
+    hot = false;
+    continue;
+  }
+  break;
+  }
+  iter += fail_iters;
+  h->fr_hot_valid = m > 0 && result != 4;
+  h->fr_rhomin = rhomin;
   return finish(result);
 }
 

@@ -245,10 +245,11 @@ class Hqp_IpMatrix:
         _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
         return out[: k.value]
 
-    def franke(self, qp, eps=1e-10, max_iters=200):
+    def franke(self, qp, eps=1e-10, max_iters=200, hot_start=0):
         """Device-resident run of the reference's other interior-point solver, Hqp_IpsFranke
-        (``hqpkkt_franke``, cold start): returns (x, y, z, w, info)."""
-        return self.mehrotra(qp, eps, max_iters, _entry="hqpkkt_franke")
+        (``hqpkkt_franke``): returns (x, y, z, w, info).  ``hot_start`` 1: Hqp_IpsFranke::hot_start
+        from the iterate this handle's previous franke() call ended with."""
+        return self.mehrotra(qp, eps, max_iters, hot_start, _entry="hqpkkt_franke")
 
     def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0, init_method=0, _entry="hqpkkt_mehrotra"):
         """Device-resident Mehrotra predictor-corrector solve of the QP, the restatement of

@@ -283,8 +283,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
  * reduction with the infeasibility measure zeta; cold_start :156-216, step :271-378, solve
  * :381-416), the default of Hqp_SqpSolver: per iteration one factor and one solve of this
  * library, whose returned residual is part of its optimality test (:372).  Same conventions as
- * hqpkkt_mehrotra; of hqpkkt_ip_opts it reads eps and max_iters (qp_beta 0.995 and qp_mu0 0 are
- * the reference's defaults); cold start only.  res->result: 0 optimal, 3 suboptimal, 4
+ * hqpkkt_mehrotra; of hqpkkt_ip_opts it reads eps, max_iters, hot_start (1 = Hqp_IpsFranke::
+ * hot_start, :222-266, from the iterate the previous hqpkkt_franke call on this handle ended with;
+ * thrown away as in :388-411) and max_warm_iters (0 = 15); qp_beta 0.995 and qp_mu0 0 are the
+ * reference's defaults.  res->result: 0 optimal, 3 suboptimal, 4
  * degenerate, 1 feasible / 2 infeasible when max_iters ends the run. */
 int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
                   const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res);

@@ -51,10 +51,11 @@ class Hqp_IpsMehrotraHip : public Hqp_Solver {
 };
 
 // sqp_qp_solver FrankeHip: the reference's Hqp_IpsFranke (hqp/Hqp_IpsFranke.C, the default
-// of Hqp_SqpSolver) on the device through hqpkkt_franke; same members, cold start only
-// (hot_start() starts cold)
+// of Hqp_SqpSolver) on the device through hqpkkt_franke; same members (qp_max_warm_iters 15,
+// hqp/Hqp_IpsFranke.C:81)
 class Hqp_IpsFrankeHip : public Hqp_IpsMehrotraHip {
  public:
+  Hqp_IpsFrankeHip() { _max_warm_iters = 15; }
   void solve();
   const char *name() { return "FrankeHip"; }
 };

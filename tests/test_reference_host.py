@@ -462,3 +462,31 @@ def test_reference_sqp_solver_with_our_qp_solvers_and_plugins(kmax, combo):
     assert abs(hip["f"] - ref["f"]) <= 1e-6 * max(1.0, abs(ref["f"])), (hip, ref)
     slack = 2 * max(1, ref["sqp_iters"]) if combo[0] == "Mehrotra" else max(2, ref["qp_iters"] // 10)
     assert abs(hip["qp_iters"] - ref["qp_iters"]) <= slack, (hip, ref)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["RedSpBKP", "SpBKP"])
+@pytest.mark.parametrize("scale", [1e-2, 1.0])
+@pytest.mark.parametrize("case", ["banded", "did400"])
+def test_franke_hot_start_follows_the_reference(case, scale, kind):
+    """Hqp_IpsFranke::hot_start + the restart logic of its solve (hqp/Hqp_IpsFranke.C:222-266,
+    381-416) in hqpkkt_franke: two QPs in a row with the same matrices and a perturbed c.  On
+    the banded QP the hot start pays (5 iterations instead of 8, both sides); on the DID
+    structure it is thrown away (gap above its first value, or qp_max_warm_iters) and the
+    iterations lost are added, both sides (161-167 at the small perturbation, 52 at the large)."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    prog = problems.banded_qp(300, 8, 5) if case == "banded" else problems.did_like_qp(400)
+    rng = np.random.default_rng(0)
+    c2 = prog.c + scale * rng.standard_normal(prog.n) * (np.abs(prog.c).max() + 1)
+    prog2 = problems.Program(prog.n, prog.me, prog.m, prog.Q, prog.A, prog.C, c=c2, b=prog.b, d=prog.d)
+    ref = refapi.ip_solve_hot(prog, c2, prog.b, prog.d, "Franke", kind, max_iters=400)
+    M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)()
+    M.init(prog)
+    M.franke(prog, max_iters=400)
+    x, _y, _z, _w, info = M.franke(prog2, max_iters=400, hot_start=1)
+    assert info["result"] == ref["result"] == 0
+    slack = 0 if case == "banded" else max(2, ref["iters"] // 10)
+    assert abs(info["iters"] - ref["iters"]) <= slack, (info["iters"], ref["iters"])
+    assert np.abs(x - ref["x"]).max() <= 1e-4 * max(1.0, np.abs(ref["x"]).max())
