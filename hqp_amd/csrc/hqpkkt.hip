@@ -1635,24 +1635,32 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
       return e;
     }
-    double val1 = 2.0;
+    // the step length is computed and consumed on the device; it comes back with the new gap
+    double *const Sfr = C.out + 32;
     if (m > 0) {
       k_fr_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-      const int opsr[IP_SLOTS] = {IP_MIN, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-      if ((e = C.reduce(opsr, 1))) return e;
-      val1 = C.hout[0];
+      IpOps orat;
+      orat.op[0] = IP_MIN;
+      for (int k = 1; k < IP_SLOTS; k++) orat.op[k] = IP_SUM;
+      k_ip_final<<<1, 256, 0, s>>>(C.part, orat, C.out, IpEpi{3, m, 0.0, 0.0, beta, nullptr, Sfr});
     }
-    val1 *= beta;
-    alpha = std::fmin(1.0, val1);
+    k_fr_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, m > 0 ? Sfr + IPS_ALPHA : nullptr, C.x, C.y, C.z, C.w, C.dx,
+                                          C.dy, C.dz, C.dw, C.part);
+    {
+      IpOps ou;
+      for (int k = 0; k < IP_SLOTS; k++) ou.op[k] = IP_SUM;
+      ou.op[1] = IP_MAX;
+      k_ip_final<<<1, 256, 0, s>>>(C.part, ou, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
+      HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+    }
+    alpha = m > 0 ? C.hout[32 + IPS_ALPHA] : std::fmin(1.0, 2.0 * beta);
     alphabar = 0.5 * alphabar + 0.5 * alpha;
     if (alphabar == 1.0)
       rhomin *= 2.0;
     else if (alphabar < 0.5 && rhomin > 100.0 * m)
       rhomin /= 2.0;
-    k_fr_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
     zeta *= (1.0 - alpha);
-    const int opsu[IP_SLOTS] = {IP_SUM, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-    if ((e = C.reduce(opsu, 2))) return e;
     gap = m > 0 ? C.hout[0] : 0.0;
     res->gap = gap, res->alpha = alpha, res->mu = mu, res->phi = zeta;
     if (!std::isfinite(gap) || !std::isfinite(C.hout[1])) {  // :351-354

@@ -95,7 +95,8 @@ __device__ __forceinline__ void ip_alpha_fin(const double *__restrict__ red, con
 
 // what thread 0 does with the reduced values before the kernel ends
 struct IpEpi {
-  int kind;  // 0 nothing, 1 sigma (k_ip_ratio's reduction), 2 damped step length (k_ip_mupl's)
+  int kind;  // 0 nothing, 1 sigma (k_ip_ratio's reduction), 2 damped step length (k_ip_mupl's),
+             // 3 Franke's step length min(1, beta val1) (k_fr_ratio's reduction; beta in gammaf)
   int m;
   double mu, gamma, gammaf;
   const double *B;  // k_ip_minratio_final's 12 values
@@ -114,6 +115,7 @@ k_ip_final(const double *__restrict__ part, IpOps ops, double *__restrict__ out,
   if (threadIdx.x == 0) {
     if (epi.kind == 1) ip_sigma(mine, epi.mu, epi.gamma, epi.S);
     if (epi.kind == 2) ip_alpha_fin(mine, epi.B, epi.m, epi.gammaf, epi.S);
+    if (epi.kind == 3) epi.S[IPS_ALPHA] = fmin(1.0, epi.gammaf * mine[0]);  // hqp/Hqp_IpsFranke.C:333-334
   }
 }
 
@@ -466,11 +468,12 @@ k_fr_ratio(int m, const double *__restrict__ z, const double *__restrict__ w, co
 }
 // the step (:343-349): x, y, z, w -= alpha d*; slots: 0 z'w, 1 max|x| (NaN -> inf)
 __global__ void __launch_bounds__(256)
-k_fr_update(int n, int me, int m, double alpha, double *__restrict__ x, double *__restrict__ y,
-            double *__restrict__ z, double *__restrict__ w, const double *__restrict__ dx,
+k_fr_update(int n, int me, int m, double alpha, const double *__restrict__ alpha_dev, double *__restrict__ x,
+            double *__restrict__ y, double *__restrict__ z, double *__restrict__ w, const double *__restrict__ dx,
             const double *__restrict__ dy, const double *__restrict__ dz, const double *__restrict__ dw,
             double *__restrict__ part) {
   __shared__ double red[4];
+  if (alpha_dev) alpha = *alpha_dev;
   double zw = 0.0, xm = 0.0;
   const int total = n + me + m;
   for (int q = blockIdx.x * blockDim.x + threadIdx.x; q < total; q += gridDim.x * blockDim.x) {
