@@ -250,6 +250,12 @@ struct hqpkkt {
 };
 
 static inline int nblk(long long work, int bs = 256) { return (int)((work + bs - 1) / bs); }
+// grid of k_copy_vectors: enough workgroups for the longest vector, at most 1024
+static inline int copy_blocks(const CopyList &L) {
+  int mx = 1;
+  for (int v = 0; v < 6; v++) mx = std::max(mx, L.len[v]);
+  return std::min(1024, std::max(1, nblk(mx)));
+}
 
 static int ensure_device(hqpkkt_t *h) {
   int ndev = 0;
@@ -401,7 +407,7 @@ static int stage_in(hqpkkt_t *h, const double *z, const double *w, const double 
   double *dz_ = b, *dw_ = b + m, *d1 = b + 2 * (size_t)m, *d2 = d1 + n, *d3 = d2 + me, *d4 = d3 + m;
   if (h->opts.loc == HQPKKT_LOC_DEVICE) {
     CopyList L{{z, w, r1, r2, r3, r4}, {dz_, dw_, d1, d2, d3, d4}, {m, m, n, me, m, m}};
-    k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 6);
+    k_copy_vectors<<<copy_blocks(L), 256, 0, h->stream>>>(L, 6);
   } else if (h->hstage_in) {
     // packed by the CPU; the prefix up to the last vector the caller passes
     double *q = h->hstage;
@@ -437,7 +443,7 @@ static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double 
   const int n = h->an.n, me = h->an.me, m = h->an.m;
   if (h->opts.loc == HQPKKT_LOC_DEVICE) {
     CopyList L{{v.dx, v.dy, v.dz, v.dw, nullptr, nullptr}, {dx, dy, dz, dw, nullptr, nullptr}, {n, me, m, m, 0, 0}};
-    k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 4);
+    k_copy_vectors<<<copy_blocks(L), 256, 0, h->stream>>>(L, 4);
     return 0;
   }
   if (h->hstage_out) {  // one transfer into pinned memory; unstage() hands it out after the sync
@@ -1025,7 +1031,7 @@ int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w, const double 
   stage_out_ptrs(h, v);
   if (h->opts.loc == HQPKKT_LOC_DEVICE) {
     CopyList L{{dx, dy, dz, dw, nullptr, nullptr}, {v.dx, v.dy, v.dz, v.dw, nullptr, nullptr}, {n, me, m, m, 0, 0}};
-    k_copy_vectors<<<64, 256, 0, h->stream>>>(L, 4);
+    k_copy_vectors<<<copy_blocks(L), 256, 0, h->stream>>>(L, 4);
   } else {
     if (n) HIPCHK(hipMemcpyAsync(v.dx, dx, sizeof(double) * n, hipMemcpyHostToDevice, h->stream));
     if (me) HIPCHK(hipMemcpyAsync(v.dy, dy, sizeof(double) * me, hipMemcpyHostToDevice, h->stream));
@@ -1293,7 +1299,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   res->alpha = 1.0;
   if (hot) {
     CopyList L{{C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
-    k_copy_vectors<<<64, 256, 0, s>>>(L, 2);
+    k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 2);
   } else {
       // (x = y = 0 until the cold start's solve has succeeded: what the caller gets back when the
       // very first factorisation is singular, as from the reference)
@@ -1406,7 +1412,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     res->phi = phi;
     if (keep_hot && phi > hot_thresh) {  // prepare the next hot start (:475-478)
       CopyList L{{C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
-      k_copy_vectors<<<64, 256, 0, s>>>(L, 2);
+      k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 2);
     }
     if (mu <= o.eps && norm_r <= o.eps * norm_data) {  // :487-490
       result = 0;
