@@ -495,7 +495,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       } else if (partner[q] >= 0) {
         t = node_of_q(partner[q]);
       }
-      if (t <= sn || lverts[sn].size() <= 1) continue;
+      if (t <= sn) continue;  // (a node emptied by these moves is spliced out of the tree below)
       lverts[sn].erase(std::find(lverts[sn].begin(), lverts[sn].end(), r));
       lverts[t].push_back(r);
       lnode_of_pos[r] = t;
@@ -567,13 +567,25 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   std::vector<std::vector<int>> lkids(nlog);  // children by logical id
   for (int id = 0; id < nlog; id++)
     for (int c : tmp[lorder[id]].kids) lkids[id].push_back(lid[c]);
+  // a node whose rows all moved up to ancestors (small leaves of multipliers) leaves the tree:
+  // its children hang on its parent, in its place
+  std::vector<char> absorbed(nlog, 0);
+  for (int id = 0; id < nlog; id++) {  // postorder: the children's lists are final
+    std::vector<int> kids;
+    for (int c : lkids[id])
+      if (lverts[c].empty())
+        kids.insert(kids.end(), lkids[c].begin(), lkids[c].end());
+      else
+        kids.push_back(c);
+    lkids[id].swap(kids);
+    if (lverts[id].empty()) absorbed[id] = 1;
+  }
   // Narrow bands: a separator holds a handful of rows, and what a tree level costs there is
   // the latency of its launches, not its arithmetic.  A separator absorbs its child
   // separators while the merged pivot set still fits a small front: their rows first, each
   // node's rows in the order settled above, so the elimination order does not change; the
   // child separators are not coupled with each other, the merged pivot block has explicit
   // zeros.  The levels above the leaves shrink to a half or a third.
-  std::vector<char> absorbed(nlog, 0);
   if (amalgamation && small_fronts) {
     for (int id = nlog - 1; id >= 0; id--) {  // ids are a postorder: parents first this way
       if (absorbed[id]) continue;

@@ -366,3 +366,29 @@ def test_pingpong_update_arena_agrees(case):
         assert mem[1] < 0.25 * mem[0]
     elif case == "banded":
         assert mem[1] < 0.8 * mem[0]
+
+
+@pytest.mark.parametrize("case", [
+    ("banded", (1067, 29, 465), "SpBKP", 2.0, dict(leaf_size=8, max_pivots=128)),
+    ("docp", (41, 4, 2, 56, 1.0), "SpBKP", 0.0, dict(leaf_size=8, max_pivots=16)),
+    ("sparse", (281, 36, 26, 2, 496), "RedSpBKP", 0.0, dict(leaf_size=8, max_pivots=128)),
+])
+def test_leaves_of_multipliers_only(case):
+    """Leaves so small that all their rows are equality multipliers, which move up to the node
+    of their last neighbour: the emptied node leaves the tree (found by tools/fuzz.py: the row
+    used to stay behind as a 1x1 leaf with an exactly zero pivot)."""
+    what, args, kind, spread, kw = case
+    prog = {"banded": problems.banded_qp, "docp": problems.lq_docp, "sparse": problems.random_sparse_qp}[what](*args)
+    st = problems.ip_state(prog, 5, spread)
+    M = CLS[kind](**kw)
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    O = oracleapi.OracleIpMatrix(kind)
+    O.init(prog)
+    O.factor(st[0], st[1])
+    osol, ores = O.solve(*st)
+    assert np.array_equal(M.perm(), O.perm())
+    assert res <= ores + RES_TOL, (res, ores, M.stats())
+    assert rel_err(d, osol) <= 1e-5, (rel_err(d, osol), M.stats())
