@@ -202,6 +202,8 @@ struct hqpkkt {
   // inside hqpkkt_mehrotra: factor() returns without waiting for its status (read with the
   // residual of the solve that follows), solve() leaves its result in the stream
   bool lazy = false, factor_unchecked = false;
+  bool soft_singular = false;  // the factorisation perturbed an exactly zero pivot (counters[3])
+  double refine_target = 0.0;  // > 0: the refinement of hqpkkt_solve aims below mat_eps (set by hqpkkt_franke)
   // hqpkkt_mehrotra left x, y and the hot-start candidates of z, w in ipv (same dimensions)
   bool ip_hot_valid = false;
   bool fr_hot_valid = false;  // hqpkkt_franke left x, y, z, w in ipv (same dimensions)
@@ -333,6 +335,16 @@ static int upload(hqpkkt_t *h) {
     // to the zero / +W/Z blocks
     std::vector<signed char> sg(an.dim);
     for (int q = 0; q < an.dim; q++) sg[an.q2e[q]] = q < an.n ? -1 : 1;
+    // +-2: no diagonal of its own (see zero_pivot_slot in kernels.hip.h)
+    std::vector<char> in_c(an.n, 0);  // REDUCED: C' (Z/W) C gives x_i a diagonal as well
+    if (an.mode != 0)
+      for (int c : h->pCi) in_c[c] = 1;
+    for (int q = 0; q < an.n; q++) {
+      bool diag = in_c[q] != 0;
+      for (int k = h->pQp[q]; k < h->pQp[q + 1]; k++) diag = diag || h->pQi[k] == q;
+      if (!diag) sg[an.q2e[q]] = -2;
+    }
+    for (int q = an.n; q < an.n + an.me; q++) sg[an.q2e[q]] = 2;
     if ((e = h->esign.upload(sg))) return e;
   }
   if ((e = h->Qf.upload(an.Qfull)) || (e = h->A.upload(an.A)) || (e = h->AT.upload(an.AT)) ||
@@ -749,6 +761,7 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
     h->factor_unchecked = false;
     std::memcpy(&h->st.kmax, &kb, sizeof(kb));
     h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
+    h->soft_singular = hs[4] != 0;
     if (flags[0] || std::isinf(h->st.kmax)) {
       h->factored = false;
       return flags[0] ? flags[0] : HQPKKT_E_SING;
@@ -991,6 +1004,7 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
     h->st.ms_factor = elapsed(h->ev1, h->evs1);
   }
   h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
+  h->soft_singular = hs[4] != 0;
   if (flags[0]) return flags[0];
   if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
   h->factored = true;
@@ -1065,7 +1079,8 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   double res = 0.0, res_last;
   const OutPtrs outp{dx, dy, dz, dw};
   if ((e = run_residual(h, v, &res, h->lazy ? nullptr : &outp))) return e;
-  const bool refined = res > h->opts.eps;  // otherwise the caller's copy is already complete
+  const double target = h->refine_target > 0.0 ? std::fmin(h->opts.eps, h->refine_target) : h->opts.eps;
+  const bool refined = res > target;  // otherwise the caller's copy is already complete
   const double res_first = res;
   // correction solve: rhs = residual vectors, result = vcor
   Vecs c = v;
@@ -1073,7 +1088,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   c.dx = h->vcor.p, c.dy = c.dx + n, c.dz = c.dy + me, c.dw = c.dz + m;
   const int ntot = n + me + 2 * m;
   int rounds = 0;
-  for (int it = 0; it < 5 && res > h->opts.eps; it++) {
+  for (int it = 0; it < 5 && res > target; it++) {
     res_last = res;
     if ((e = do_step(h, c, 1))) return e;
     rounds++;
@@ -1113,6 +1128,8 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if (getenv("HQPKKT_TRACE_SOLVE")) fprintf(stderr, "solve: first residual %.3e, %d rounds, final %.3e\n", res_first, rounds, res);
   if (res_out) *res_out = res;
   if (res != res) return HQPKKT_E_SING;
+  // an exactly zero pivot outside a root front was perturbed: singular if the refinement failed
+  if (h->soft_singular && !(res <= h->opts.eps)) return HQPKKT_E_SING;
   return 0;
 }
 
@@ -1635,8 +1652,15 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     k_fr_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, zeta, mu, a1, a2, a3, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
     double resid = 0.0;
     n_factor++, n_solve++;
-    if ((e = hqpkkt_factor(h, C.z, C.w)) ||
-        (e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid))) {
+    // The step length below compares dw = C dx - r3 with w, whose active components are of the
+    // order gap / m: a residual of mat_eps = 1e-10, which the reference's global pivoting stays
+    // far below without refinement, lets that noise block the step near the solution (the loop
+    // then creeps on with alpha -> 0).  Ask the solve for a residual below the slacks.
+    h->refine_target = m > 0 ? std::fmax(0.05 * gap / (double)m, 2e-12) : 0.0;
+    e = hqpkkt_factor(h, C.z, C.w);
+    if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
+    h->refine_target = 0.0;
+    if (e) {
       if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:308-310)
       (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
       return e;

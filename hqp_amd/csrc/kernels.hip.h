@@ -142,6 +142,18 @@ struct TermDev {
   double sgn;
 };
 
+// An exactly zero pivot is E_SING for the reference (hqp/spBKP.C:699-700), whose pivot search
+// sees the whole remaining column.  Here the search ends at the supernode's pivot block: in a
+// root front, or on a variable without a diagonal of its own (esign +-2: an equality multiplier
+// or an x without Q_ii - the zero then says that its rows are rank deficient), the zero is the
+// reference's E_SING (status word counters[-1]).  Elsewhere (e.g. a slack row whose w/z = 1e-18
+// was absorbed by c^2/Q_ii = 1 and cancelled again, its coupling to an ancestor's x still to
+// come) the pivot is perturbed like a tiny one and only counters[3] is marked: hqpkkt_solve
+// reports E_SING if the refinement then does not reach mat_eps.
+__device__ __forceinline__ int zero_pivot_slot(int sg1, int sg2, int b) {
+  return (b == 0 || sg1 == 2 || sg1 == -2 || sg2 == 2 || sg2 == -2) ? -1 : 3;
+}
+
 // unscaled value of every stored entry of the matrix to factor
 __global__ void k_entry_values(int nent, const int *__restrict__ term_ptr,
                                const TermDev *__restrict__ terms,
@@ -720,8 +732,9 @@ int dn;
       double d = cur[k];
       bool pertd = false;
       if (!(fabs(d) >= pert)) {
-        if (d == 0.0) counters[-1] = 4;  // an exact zero pivot is E_SING for the reference (hqp/spBKP.C:699-700)
-        d = (double)esign[e0 + lp[k]] * pert;
+        const int sg = esign[e0 + lp[k]];
+        if (d == 0.0) counters[zero_pivot_slot(sg, sg, b)] = 4;
+        d = sg < 0 ? -pert : pert;
         pertd = true;
       }
       const double di = fast_rcp(d);
@@ -749,9 +762,10 @@ int dn;
       double det = d11 * d22 - d21 * d21;
       bool pertd = false;
       if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
-        if (det == 0.0) counters[-1] = 4;  // hqp/spBKP.C:731-732
-        d11 = (double)esign[e0 + lp[k]] * pert;
-        d22 = (double)esign[e0 + lp[k + 1]] * pert;
+        const int sg1 = esign[e0 + lp[k]], sg2 = esign[e0 + lp[k + 1]];
+        if (det == 0.0) counters[zero_pivot_slot(sg1, sg2, b)] = 4;  // hqp/spBKP.C:731-732
+        d11 = sg1 < 0 ? -pert : pert;
+        d22 = sg2 < 0 ? -pert : pert;
         d21 = 0.0;
         det = d11 * d22;
         pertd = true;
@@ -1152,8 +1166,9 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       double d = rdlane(ck, k);
       bool pertd = false;
       if (!(fabs(d) >= pert)) {
-        if (d == 0.0) counters[-1] = 4;  // an exact zero pivot is E_SING for the reference (hqp/spBKP.C:699-700)
-        d = (double)esign[e0 + lp[k]] * pert;
+        const int sg = esign[e0 + lp[k]];
+        if (d == 0.0) counters[zero_pivot_slot(sg, sg, b)] = 4;
+        d = sg < 0 ? -pert : pert;
         pertd = true;
       }
       const double di = fast_rcp(d);
@@ -1186,9 +1201,10 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       double det = d11 * d22 - d21 * d21;
       bool pertd = false;
       if (!(fabs(det) >= pert * pert)) {  // degenerate 2x2: perturbed diagonal pair
-        if (det == 0.0) counters[-1] = 4;  // hqp/spBKP.C:731-732
-        d11 = (double)esign[e0 + lp[k]] * pert;
-        d22 = (double)esign[e0 + lp[k + 1]] * pert;
+        const int sg1 = esign[e0 + lp[k]], sg2 = esign[e0 + lp[k + 1]];
+        if (det == 0.0) counters[zero_pivot_slot(sg1, sg2, b)] = 4;  // hqp/spBKP.C:731-732
+        d11 = sg1 < 0 ? -pert : pert;
+        d22 = sg2 < 0 ? -pert : pert;
         d21 = 0.0;
         det = d11 * d22;
         pertd = true;

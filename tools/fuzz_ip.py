@@ -1,0 +1,78 @@
+"""Randomised sweep of the device-resident interior-point loops (hqpkkt_mehrotra / hqpkkt_franke)
+against the reference's own Hqp_IpsMehrotra / Hqp_IpsFranke with its own plugin (oracle/_ref):
+random QPs of the three structured families, plugin kinds, starting points.  Same termination,
+iteration counts within the tolerance of tests/test_reference_host.py, same objective.
+Usage: python tools/fuzz_ip.py [cases] [seed0]"""
+import sys, os, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from hqp_amd import problems, ipmatrix
+from oracle import refapi
+
+
+def objective(prog, x):
+    p, i, v = prog.Q
+    rows = np.repeat(np.arange(prog.n), np.diff(p))
+    return float((np.where(rows == i, 0.5, 1.0) * v * x[rows] * x[i]).sum() + prog.c @ x)
+
+
+OPTS = eval(os.environ.get("FUZZ_OPTS", "{}"))  # plugin options for every case, e.g. "dict(slack_policy=1)"
+ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+bad = odd = 0
+t0 = time.time()
+for case in range(seed0, seed0 + ncases):
+    rng = np.random.default_rng(5000 + case)
+    what = str(rng.choice(["banded", "did", "docp"]))
+    if what == "banded":
+        b = int(rng.integers(1, 30))
+        args = (int(rng.integers(2 * b + 2, 1200)), b, int(rng.integers(1, 1000)))
+        prog = problems.banded_qp(*args)
+    elif what == "did":
+        args = (int(rng.integers(2, 800)), float(rng.choice([1e-4, 1e-2, 1.0])))
+        prog = problems.did_like_qp(*args)
+    else:
+        args = (int(rng.integers(2, 60)), int(rng.integers(1, 10)), int(rng.integers(1, 5)), int(rng.integers(1, 99)))
+        prog = problems.lq_docp(*args)
+    kind = str(rng.choice(["SpBKP", "RedSpBKP"]))
+    solver = str(rng.choice(["Mehrotra", "Mehrotra", "Franke"]))
+    im = int(rng.integers(0, 4)) if solver == "Mehrotra" else 0
+    tag = f"case {case}: {what}{args} {solver} {kind} init {im}"
+    try:
+        ref = refapi.ip_solve(prog, solver, kind, init_method=im)
+        M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)(**OPTS)
+        M.init(prog)
+        if solver == "Mehrotra":
+            x, y, z, w, info = M.mehrotra(prog, max_iters=250, init_method=im)
+        else:
+            x, y, z, w, info = M.franke(prog, max_iters=250)
+    except Exception as e:
+        bad += 1
+        print("EXCEPTION", tag, repr(e)[:120], flush=True)
+        continue
+    fr, fd = objective(prog, ref["x"]), objective(prog, x)
+    same_f = abs(fr - fd) <= 1e-6 * max(1.0, abs(fr))
+    slack = 2 if solver == "Mehrotra" else max(2, ref["iters"] // 10)
+    same_it = abs(info["iters"] - ref["iters"]) <= slack
+    line = f"{tag}: result {info['result']}/{ref['result']} iters {info['iters']}/{ref['iters']} f {fd:.10g}/{fr:.10g}"
+    if info["result"] == ref["result"] and same_it and (same_f or ref["result"] != 0):
+        continue
+    if ref["result"] != 0 and info["result"] in (0, 3, 4):
+        odd += 1  # the reference does not end "optimal" itself: stall / E_SING next to the solution
+        print("reference not optimal:", line, flush=True)
+        continue
+    if {info["result"], ref["result"]} == {0, 3} and same_it and same_f:
+        odd += 1
+        print("final test missed by a hair on one side:", line, flush=True)
+        continue
+    # how far apart are the reference's own two plugins on this QP?
+    other = refapi.ip_solve(prog, solver, "RedSpBKP" if kind == "SpBKP" else "SpBKP", init_method=im)
+    if info["result"] == ref["result"] == other["result"] and same_f and \
+            abs(info["iters"] - ref["iters"]) <= 2 * abs(other["iters"] - ref["iters"]) + slack:
+        odd += 1
+        print(f"counts spread like the reference's own plugins ({other['iters']} with the other one):", line, flush=True)
+        continue
+    bad += 1
+    print("MISMATCH", line, f"(reference with its other plugin: {other['result']}, {other['iters']})", flush=True)
+print(f"{ncases} cases from {seed0}: {bad} bad, {odd} odd, {time.time() - t0:.0f} s")
+sys.exit(1 if bad else 0)
