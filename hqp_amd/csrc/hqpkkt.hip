@@ -644,7 +644,7 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
                                               v.dz));
       if (m > 0)
         KLAUNCH(h, KC_VECTOR, k_dw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, v.r3,
-                                     v.dw));
+                                     v.z, v.w, v.r4, v.dz, v.dw));
     } else {
       KLAUNCH(h, KC_VECTOR, k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy));
       if (m > 0)

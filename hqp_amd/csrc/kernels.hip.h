@@ -2188,14 +2188,22 @@ __global__ void k_unpack_full(int n, int me, int m, const int *__restrict__ q2e,
     dz[q - n - me] = v * sc[q];
 }
 
-// dw = C dx - r3   (hqp/Hqp_IpSpBKP.C:216-217, hqp/Hqp_IpRedSpBKP.C:364-365)
+// dw = C dx - r3   (hqp/Hqp_IpSpBKP.C:216-217, hqp/Hqp_IpRedSpBKP.C:364-365).  That row carries the
+// absolute error of dx; for an active constraint (w_j < z_j, w_j -> 0) the other row that defines
+// dw_j, z_j dw_j + w_j dz_j = r4_j, gives it to a relative accuracy instead (the same number in
+// exact arithmetic): the step length tests of the interior-point solvers compare dw_j with w_j.
 __global__ void k_dw(int m, const int *__restrict__ Cp, const int *__restrict__ Cc,
                      const int *__restrict__ Cs, const double *__restrict__ vals,
                      const double *__restrict__ dx, const double *__restrict__ r3,
+                     const double *__restrict__ z, const double *__restrict__ w,
+                     const double *__restrict__ r4, const double *__restrict__ dz,
                      double *__restrict__ dw) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
-  dw[j] = -1.0 * r3[j] + row_dot(Cp, Cc, Cs, vals, dx, j);
+  if (w[j] < z[j])
+    dw[j] = (r4[j] - w[j] * dz[j]) / z[j];
+  else
+    dw[j] = -1.0 * r3[j] + row_dot(Cp, Cc, Cs, vals, dx, j);
 }
 
 // REDUCED, part 1: tz = r4./w + (z/w).*r3   (hqp/Hqp_IpRedSpBKP.C:339-341)

@@ -490,3 +490,29 @@ def test_franke_hot_start_follows_the_reference(case, scale, kind):
     slack = 0 if case == "banded" else max(2, ref["iters"] // 10)
     assert abs(info["iters"] - ref["iters"]) <= slack, (info["iters"], ref["iters"])
     assert np.abs(x - ref["x"]).max() <= 1e-4 * max(1.0, np.abs(ref["x"]).max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("K", [105, 207, 252, 596, 772])
+def test_franke_full_plugin_on_did_with_unit_hessian(K):
+    """Finds of tools/fuzz_ip.py: Hqp_IpsFranke + the full plugin on the DID structure with
+    Q = I ended "degenerate" or at the iteration limit where the reference needs ~100
+    iterations - an exactly zero slack pivot inside a non-root front (now perturbed, E_SING
+    only if the refinement then fails), and dw = C dx - r3 carrying the solve's absolute error
+    against slacks of order gap/m (k_dw takes an active constraint's dw from the r4 row)."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    prog = problems.did_like_qp(K, 1.0)
+    ref = refapi.ip_solve(prog, "Franke", "SpBKP", max_iters=250)
+    other = refapi.ip_solve(prog, "Franke", "RedSpBKP", max_iters=250)
+    assert ref["result"] == 0
+    M = ipmatrix.IpSpBKP()
+    M.init(prog)
+    x, _y, _z, _w, info = M.franke(prog, max_iters=250)
+    assert info["result"] == 0, (info, ref["iters"])
+    # the reference's own two plugins are up to 30 iterations apart on these
+    assert abs(info["iters"] - ref["iters"]) <= max(2, ref["iters"] // 10) + 2 * abs(other["iters"] - ref["iters"]), \
+        (info["iters"], ref["iters"], other["iters"])
+    fr, fd = objective(prog, ref["x"]), objective(prog, x)
+    assert abs(fr - fd) <= 1e-6 * max(1.0, abs(fr))

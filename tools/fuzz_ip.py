@@ -16,6 +16,7 @@ def objective(prog, x):
     return float((np.where(rows == i, 0.5, 1.0) * v * x[rows] * x[i]).sum() + prog.c @ x)
 
 
+SHIM = os.environ.get("FUZZ_SHIM", "") == "1"  # 1: Hqp_IpsMehrotra / Hqp_IpsFranke + SpBKPHip / RedSpBKPHip instead of the device loops
 OPTS = eval(os.environ.get("FUZZ_OPTS", "{}"))  # plugin options for every case, e.g. "dict(slack_policy=1)"
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
@@ -40,11 +41,16 @@ for case in range(seed0, seed0 + ncases):
     tag = f"case {case}: {what}{args} {solver} {kind} init {im}"
     try:
         ref = refapi.ip_solve(prog, solver, kind, init_method=im)
-        M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)(**OPTS)
-        M.init(prog)
-        if solver == "Mehrotra":
+        if SHIM:  # the reference's own IP solver driving the plugin through shim/ (oracle/_ref/libhqphost_hip.so)
+            hip = refapi.ip_solve(prog, solver, kind + "Hip", host="hip", init_method=im)
+            x, info = hip["x"], dict(result=hip["result"], iters=hip["iters"])
+        elif solver == "Mehrotra":
+            M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)(**OPTS)
+            M.init(prog)
             x, y, z, w, info = M.mehrotra(prog, max_iters=250, init_method=im)
         else:
+            M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)(**OPTS)
+            M.init(prog)
             x, y, z, w, info = M.franke(prog, max_iters=250)
     except Exception as e:
         bad += 1
