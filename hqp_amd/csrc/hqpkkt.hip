@@ -1262,6 +1262,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
   double test1 = 0.0;
   const double gamma = std::pow(1.0e-4, 0.25);
   int result = 2;
+  bool sing_hot = false;  // E_SING inside a hot-started run: restart cold like any failed hot start
   bool stepped = false, pending = false;  // pending: a step is in the stream whose scalars were not read yet
   double mu_pending = 0.0;
   // The rare second corrector (hqp/Hqp_IpsMehrotra.C:612-624: the first corrector's own
@@ -1311,7 +1312,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     return 0;
   };
   for (;;) {  // hot first (if asked for and possible), cold after a failed hot start
-  iter = 0, result = 2, stepped = false, pending = false;
+  iter = 0, result = 2, stepped = false, pending = false, sing_hot = false;
   std::fill(phimin.begin(), phimin.end(), 0.0);
   res->alpha = 1.0;
   if (hot) {
@@ -1404,6 +1405,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       if (C.hout[32 + IPS_NEED2] != 0.0) {  // that step was not taken (alpha 0): second corrector first
         iter--;
         if ((e = second_corrector(mu_pending))) {
+            if (e == HQPKKT_E_SING && hot) {
+            sing_hot = true;
+            break;
+          }
           if (e == HQPKKT_E_SING) return finish(4);
           (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
           return e;
@@ -1452,6 +1457,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     if (norm_r > o.eps * norm_data && norm_r / mu >= 1.0e8 * norm_r0 / mu0) result = 3;  // :520-524 (no return)
     // factorise; predictor (affine) step
     if ((e = factor()) || (e = solve(C.dxa, C.dya, C.dza, C.dwa))) {
+      if (e == HQPKKT_E_SING && hot) {  // a hot start that ends degenerate is thrown away (:723-727)
+        sing_hot = true;
+        break;
+      }
       if (e == HQPKKT_E_SING) return finish(4);
       (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
       return e;
@@ -1469,6 +1478,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     }
     k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, 0.0, S + IPS_SMM, C.r4);
     if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
+      if (e == HQPKKT_E_SING && hot) {
+        sing_hot = true;
+        break;
+      }
       if (e == HQPKKT_E_SING) return finish(4);
       (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
       return e;
@@ -1488,12 +1501,20 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     iter++;
     stepped = true, pending = true, mu_pending = mu;
     } while (0);
+    if (sing_hot) {
+      result = 4;
+      break;
+    }
     if (redo) continue;
     // ---- what solve() does after every step() call (:703-718)
     const bool leave = result == 0 || result == 3 || result == 4 || iter + fail_iters >= o.max_iters ||
                        (hot && iter >= max_warm);
     if (hot || leave) {  // the step's own scalars are needed now: was it taken, how long was it
       if ((e = settle())) {
+        if (e == HQPKKT_E_SING && hot) {
+          result = 4;
+          break;
+        }
         if (e == HQPKKT_E_SING) return finish(4);
         (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
         return e;
@@ -1660,6 +1681,10 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     e = hqpkkt_factor(h, C.z, C.w);
     if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
     h->refine_target = 0.0;
+    if (e == HQPKKT_E_SING && hot) {  // Hqp_Degenerate inside a hot start: thrown away (:405-411)
+      result = 4;
+      break;
+    }
     if (e) {
       if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:308-310)
       (void)hipEventDestroy(tb), (void)hipEventDestroy(te);

@@ -16,6 +16,7 @@ def objective(prog, x):
     return float((np.where(rows == i, 0.5, 1.0) * v * x[rows] * x[i]).sum() + prog.c @ x)
 
 
+HOT = os.environ.get("FUZZ_HOT", "") == "1"  # 1: hot starts (two QPs in a row) instead of cold starts
 SHIM = os.environ.get("FUZZ_SHIM", "") == "1"  # 1: Hqp_IpsMehrotra / Hqp_IpsFranke + SpBKPHip / RedSpBKPHip instead of the device loops
 OPTS = eval(os.environ.get("FUZZ_OPTS", "{}"))  # plugin options for every case, e.g. "dict(slack_policy=1)"
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
@@ -40,8 +41,28 @@ for case in range(seed0, seed0 + ncases):
     im = int(rng.integers(0, 4)) if solver == "Mehrotra" else 0
     tag = f"case {case}: {what}{args} {solver} {kind} init {im}"
     try:
-        ref = refapi.ip_solve(prog, solver, kind, init_method=im)
-        if SHIM:  # the reference's own IP solver driving the plugin through shim/ (oracle/_ref/libhqphost_hip.so)
+        if HOT:  # a second QP with the same matrices and a perturbed c, hot-started from the first
+            if solver == "Mehrotra":
+                im = 0
+            scale = float(rng.choice([1e-4, 1e-3, 1e-2, 1e-1]))
+            c2 = prog.c + scale * rng.standard_normal(prog.n) * (np.abs(prog.c).max() + 1)
+            tag += f" hot {scale}"
+            ref = refapi.ip_solve_hot(prog, c2, prog.b, prog.d, solver, kind, max_iters=400)
+            M = (ipmatrix.IpRedSpBKP if kind == "RedSpBKP" else ipmatrix.IpSpBKP)(**OPTS)
+            M.init(prog)
+            prog2 = problems.Program(prog.n, prog.me, prog.m, prog.Q, prog.A, prog.C, c=c2, b=prog.b, d=prog.d)
+            if solver == "Mehrotra":
+                M.mehrotra(prog, max_iters=400, hot_start=2)
+                x, y, z, w, info = M.mehrotra(prog2, max_iters=400, hot_start=1)
+            else:
+                M.franke(prog, max_iters=400)
+                x, y, z, w, info = M.franke(prog2, max_iters=400, hot_start=1)
+            prog = prog2
+        else:
+            ref = refapi.ip_solve(prog, solver, kind, init_method=im)
+        if HOT:
+            pass
+        elif SHIM:  # the reference's own IP solver driving the plugin through shim/ (oracle/_ref/libhqphost_hip.so)
             hip = refapi.ip_solve(prog, solver, kind + "Hip", host="hip", init_method=im)
             x, info = hip["x"], dict(result=hip["result"], iters=hip["iters"])
         elif solver == "Mehrotra":
@@ -72,6 +93,10 @@ for case in range(seed0, seed0 + ncases):
         print("final test missed by a hair on one side:", line, flush=True)
         continue
     # how far apart are the reference's own two plugins on this QP?
+    if HOT:
+        bad += 1
+        print("MISMATCH", line, flush=True)
+        continue
     other = refapi.ip_solve(prog, solver, "RedSpBKP" if kind == "SpBKP" else "SpBKP", init_method=im)
     if info["result"] == ref["result"] == other["result"] and same_f and \
             abs(info["iters"] - ref["iters"]) <= 2 * abs(other["iters"] - ref["iters"]) + slack:
