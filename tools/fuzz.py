@@ -9,16 +9,19 @@ from hqp_amd import problems, ipmatrix
 from oracle import oracleapi
 
 CLS = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}
+SCALE = int(os.environ.get("FUZZ_SCALE", "1"))  # > 1: larger banded / DID systems (the oracle then takes seconds per case)
+
+
 def make_case(case):
     """-> (prog, state, kind, opts, tag) of fuzz case number ``case``"""
     rng = np.random.default_rng(1000 + case)
     what = rng.choice(["banded", "did", "docp", "sparse"])
     if what == "banded":
-        args = (int(rng.integers(20, 1500)), int(rng.integers(1, 40)), int(rng.integers(1, 1000)))
+        args = (int(rng.integers(20, 1500 * SCALE)), int(rng.integers(1, 40 * min(SCALE, 3))), int(rng.integers(1, 1000)))
         args = (max(args[0], 2 * args[1] + 2),) + args[1:]
         prog = problems.banded_qp(*args)
     elif what == "did":
-        args = (int(rng.integers(2, 600)),)
+        args = (int(rng.integers(2, 600 * SCALE)),)
         prog = problems.did_like_qp(*args)
     elif what == "docp":
         args = (int(rng.integers(2, 60)), int(rng.integers(1, 12)), int(rng.integers(1, 6)), int(rng.integers(1, 99)),
@@ -74,6 +77,23 @@ def main():
             if not ok:
                 bad += 1
                 print("MISMATCH", tag, "res", res, "oracle", ores, "check", rchk, M.stats(), flush=True)
+            # update(): new values on the same pattern (scaled blocks, as an SQP iteration changes them),
+            # then factor + solve again on the same handle
+            f = 1.0 + 0.5 * np.sin(np.arange(7) + case)
+            prog2 = problems.Program(prog.n, prog.me, prog.m, (prog.Q[0], prog.Q[1], prog.Q[2] * f[0]),
+                                     (prog.A[0], prog.A[1], prog.A[2] * (1.0 + 0.1 * np.cos(np.arange(len(prog.A[2])) + case))),
+                                     (prog.C[0], prog.C[1], prog.C[2] * f[2]), c=prog.c, b=prog.b, d=prog.d)
+            M.update(prog2)
+            M.factor(prog2, st[0], st[1])
+            d2 = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+            res2 = M.solve(prog2, *st, *d2)
+            O.update(prog2)
+            O.factor(st[0], st[1])
+            osol2, ores2 = O.solve(*st)
+            scale2 = max(1.0, max((np.abs(v).max() if len(v) else 0.0) for v in d2))
+            if ores2 <= 1e-8 * scale2 and not O.residuum(*st, *d2) <= ores2 + 1e-10 * scale2:
+                bad += 1
+                print("MISMATCH after update()", tag, "res", res2, "oracle", ores2, "check", O.residuum(*st, *d2), flush=True)
         except Exception as e:  # both sides must agree on singular systems
             try:
                 O = oracleapi.OracleIpMatrix(kind)
