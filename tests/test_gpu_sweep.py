@@ -1,0 +1,86 @@
+"""GPU (-m gpu): a fixed slice of the randomised sweeps of tools/fuzz.py and tools/fuzz_ip.py
+ - random structures, sizes, w/z spreads, plugin kinds and tree options
+against the CPU oracle; random QPs through the device-resident Mehrotra loop against the
+reference's Hqp_IpsMehrotra (oracle/_ref)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+from hqp_amd import ipmatrix, problems  # noqa: E402
+from oracle import oracleapi, refapi  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+CLS = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}
+
+
+@pytest.mark.parametrize("block", range(8))
+def test_random_kkt_systems_against_the_oracle(block):
+    import fuzz
+    compared = 0
+    for case in range(40 * block, 40 * block + 40):
+        prog, st, kind, kw, tag = fuzz.make_case(case)
+        O = oracleapi.OracleIpMatrix(kind)
+        O.init(prog)
+        try:
+            O.factor(st[0], st[1])
+            osol, ores = O.solve(*st)
+        except oracleapi.OracleError:
+            continue  # singular for the reference (E_SING): nothing to compare
+        M = CLS[kind](**kw)
+        M.init(prog)
+        assert M.mat_sbw == O.sbw and np.array_equal(M.perm(), O.perm()), tag
+        d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+        try:
+            M.factor(prog, st[0], st[1])
+            M.solve(prog, *st, *d)
+        except ipmatrix.KktError:
+            # E_SING here: only where the reference does not solve the system either
+            assert ores > 1e-8, (tag, ores)
+            continue
+        scale = max(1.0, max((np.abs(v).max() if len(v) else 0.0) for v in d))
+        if ores > 1e-8 * scale:
+            continue  # the reference's own solution does not satisfy the system
+        # the oracle's residual of OUR solution (a solve whose last damped refinement step is
+        # rejected returns that trial's residual on both sides, hqp/Hqp_IpMatrix.C:104-121)
+        assert O.residuum(*st, *d) <= ores + 1e-10 * scale, (tag, ores)
+        compared += 1
+    assert compared >= 30
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_qps_through_the_mehrotra_loop(block):
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    agreed = 0
+    for case in range(25 * block, 25 * block + 25):
+        rng = np.random.default_rng(9000 + case)
+        what = str(rng.choice(["banded", "did", "docp"]))
+        if what == "banded":
+            b = int(rng.integers(1, 30))
+            prog = problems.banded_qp(int(rng.integers(2 * b + 2, 1200)), b, int(rng.integers(1, 1000)))
+        elif what == "did":
+            prog = problems.did_like_qp(int(rng.integers(60, 800)), float(rng.choice([1e-4, 1e-2, 1.0])))
+        else:
+            prog = problems.lq_docp(int(rng.integers(2, 60)), int(rng.integers(1, 10)), int(rng.integers(1, 5)), int(rng.integers(1, 99)))
+        kind = str(rng.choice(["SpBKP", "RedSpBKP"]))
+        im = int(rng.integers(0, 4))
+        ref = refapi.ip_solve(prog, "Mehrotra", kind, init_method=im)
+        M = CLS[kind]()
+        M.init(prog)
+        x, _y, _z, _w, info = M.mehrotra(prog, max_iters=250, init_method=im)
+        tag = (case, what, prog.dims, kind, im, info["result"], info["iters"], ref["result"], ref["iters"])
+        if ref["result"] != 0:
+            assert info["result"] in (0, 3, 4), tag  # the reference stalls next to the solution itself
+            continue
+        assert info["result"] == 0 and abs(info["iters"] - ref["iters"]) <= 2, tag
+        p, i, v = prog.Q
+        rows = np.repeat(np.arange(prog.n), np.diff(p))
+        f = lambda xx: float((np.where(rows == i, 0.5, 1.0) * v * xx[rows] * xx[i]).sum() + prog.c @ xx)
+        assert abs(f(x) - f(ref["x"])) <= 1e-6 * max(1.0, abs(f(ref["x"]))), tag
+        agreed += 1
+    assert agreed >= 20
