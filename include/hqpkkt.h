@@ -157,13 +157,20 @@ int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax,
 
 /* Hqp_IpSpBKP::factor / Hqp_IpRedSpBKP::factor (hqp/Hqp_IpSpBKP.C:139-180,
  * hqp/Hqp_IpRedSpBKP.C:281-320) including spBKPfactor (hqp/spBKP.C:369-645):
- * insert w/z (resp. C'ZW^-1C), symmetric scaling, LDL' with 1x1/2x2 pivots. */
+ * insert w/z (resp. C'ZW^-1C), symmetric scaling, LDL' with 1x1/2x2 pivots.
+ * HQPKKT_E_SING: an exactly zero pivot (hqp/spBKP.C:699-700, 731-732) in a root
+ * front or on a variable without a diagonal of its own (equality multiplier, x
+ * without Q_ii).  An exactly zero pivot elsewhere is perturbed (the pivot search
+ * ends at the supernode, the rest of the column is still to come); hqpkkt_solve
+ * then returns HQPKKT_E_SING if its refinement does not reach opts.eps. */
 int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w);
 
 /* Hqp_IpSpBKP::step / Hqp_IpRedSpBKP::step (hqp/Hqp_IpSpBKP.C:183-218,
  * hqp/Hqp_IpRedSpBKP.C:323-368) including spBKPsolve (hqp/spBKP.C:647-797):
  * one solve of  [-Q A' C' 0; A 0 0 0; C 0 0 -I; 0 0 W Z] d = r  with the
- * current factors, no refinement. */
+ * current factors, no refinement.  FULL mode: dw = C dx - r3 as the reference
+ * computes it, except for active constraints (w_j < z_j), whose dw_j comes from
+ * z_j dw_j + w_j dz_j = r4_j - the same number, to a relative accuracy. */
 int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w,
                 const double *r1, const double *r2, const double *r3,
                 const double *r4, double *dx, double *dy, double *dz,
