@@ -14,7 +14,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("HQPKKT_LIB") or os.path.join(_HERE, "libhqpkkt.so")  # override: instrumented builds
 
 OK, E_SIZES, E_MEM, E_SING, E_FORMAT, E_NULL, E_RANGE, E_INTERN, E_DEVICE = 0, 1, 3, 4, 6, 8, 10, 17, 100
-MODE_FULL, MODE_REDUCED = 0, 1
+MODE_FULL, MODE_REDUCED, MODE_STAGED = 0, 1, 2
 LOC_HOST, LOC_DEVICE = 0, 1
 
 # every symbol include/hqpkkt.h declares
@@ -26,6 +26,7 @@ SYMBOLS = [
     "hqpkkt_selftest_mfma", "hqpkkt_set_profile", "hqpkkt_get_profile",
     "hqpkkt_profile_class_name", "hqpkkt_set_shard", "hqpkkt_debug_read",
     "hqpkkt_default_ip_opts", "hqpkkt_mehrotra", "hqpkkt_franke",
+    "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm",
 ]
 
 XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
@@ -123,6 +124,9 @@ def lib():
     L.hqpkkt_default_ip_opts.argtypes = [C.POINTER(IpOpts)]
     L.hqpkkt_mehrotra.argtypes = [vp, C.POINTER(IpOpts)] + [dp] * 7 + [C.POINTER(IpResult)]
     L.hqpkkt_franke.argtypes = [vp, C.POINTER(IpOpts)] + [dp] * 7 + [C.POINTER(IpResult)]
+    L.hqpkkt_set_stages.argtypes = [vp, C.c_int, vp, vp]
+    L.hqpkkt_debug_stage_ranks.argtypes = [vp, vp, C.c_int]
+    L.hqpkkt_debug_dgemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)] * 2
     _lib = L
     return L
 

@@ -146,19 +146,14 @@ void transpose(const Analysis::Csr &M, int cols, Analysis::Csr &T) {
 
 }  // namespace
 
-int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *Qi,
-                  const int *Ap, const int *Ai, const int *Cp, const int *Ci, int leaf_size,
-                  int max_pivots, int zd_policy) {
+int Analysis::setup_blocks(int mode_, int n_, int me_, int m_, const int *Qp, const int *Qi,
+                           const int *Ap, const int *Ai, const int *Cp, const int *Ci) {
   mode = mode_, n = n_, me = me_, m = m_;
   if (n < 0 || me < 0 || m < 0 || n + me + m == 0) return 1;
   if (!csr_ok(n, n, Qp, Qi) || !csr_ok(me, n, Ap, Ai) || !csr_ok(m, n, Cp, Ci)) return 6;
   dim = mode == 0 ? n + me + m : n + me;
   nq = n ? Qp[n] : 0, na = me ? Ap[me] : 0, nc = m ? Cp[m] : 0;
-  const int ONE = nq + na + nc, WONE = m;
-  if (max_pivots <= 0 || max_pivots > 128) max_pivots = 128;
-  if (leaf_size <= 0) leaf_size = 0;  // decided below from sbw
-
-  TMARK("0");
+  Qfull = Csr(), A = Csr(), AT = Csr(), C = Csr(), CT = Csr();
   // ---------------------------------------------------------- SpMV blocks
   {
     std::vector<std::vector<std::pair<int, int>>> rows(n);
@@ -190,6 +185,17 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     transpose(A, n, AT);
     transpose(C, n, CT);
   }
+  return 0;
+}
+
+int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *Qi,
+                  const int *Ap, const int *Ai, const int *Cp, const int *Ci, int leaf_size,
+                  int max_pivots, int zd_policy) {
+  TMARK("0");
+  if (int e0 = setup_blocks(mode_, n_, me_, m_, Qp, Qi, Ap, Ai, Cp, Ci)) return e0;
+  const int ONE = nq + na + nc, WONE = m;
+  if (max_pivots <= 0 || max_pivots > 128) max_pivots = 128;
+  if (leaf_size <= 0) leaf_size = 0;  // decided below from sbw
 
   TMARK("1");
   // ------------------------------------------------------------- entries

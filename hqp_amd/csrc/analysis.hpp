@@ -90,6 +90,9 @@ struct Analysis {
 
   long long nnz_factor = 0, flops_factor = 0;
 
+  // dimensions and the SpMV blocks only (what step()/residuum() of every mode need)
+  int setup_blocks(int mode, int n, int me, int m, const int *Qp, const int *Qi, const int *Ap,
+                   const int *Ai, const int *Cp, const int *Ci);
   int run(int mode, int n, int me, int m, const int *Qp, const int *Qi, const int *Ap,
           const int *Ai, const int *Cp, const int *Ci, int leaf_size, int max_pivots,
           int zd_policy = 0);

@@ -9,12 +9,15 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <new>
 #include <vector>
 
 #include "analysis.hpp"
+#include "staged_plan.hpp"
 #include "kernels.hip.h"
 #include "ipdriver.hip.h"
+#include "staged.hip.h"
 
 using namespace kktdev;
 
@@ -78,10 +81,10 @@ struct CsrBuf {
 // per-kernel-class device timing (hqpkkt_set_profile): HIP events on the
 // handle's stream around every launch, summed per class after the call
 enum { KC_ASSEMBLE = 0, KC_FACTOR_DIAG, KC_PANEL_SOLVE, KC_SCHUR_UPDATE,
-       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_COUNT };
+       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_ST_GEMM, KC_ST_SMALL, KC_ST_VEC, KC_COUNT };
 static const char *const kc_names[KC_COUNT] = {"assemble", "factor_diag", "panel_solve",
                                                "schur_update", "solve_fwd", "solve_bwd", "vector",
-                                               "residual"};
+                                               "residual", "staged_gemm", "staged_small", "staged_gemv"};
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;
@@ -135,10 +138,15 @@ struct Prof {
     (h)->prof.end((h)->stream);   \
   } while (0)
 
+struct StagedDev;
+static void staged_release(StagedDev *sd, bool destroy);
+
 struct hqpkkt {
   hqpkkt_opts opts;
   Prof prof;
   Analysis an;
+  StagedDev *sd = nullptr;  // HQPKKT_MODE_STAGED: the stage blocks (staged_host.hip.h)
+  double ge_tol = 1.0e-6;   // rank decision of the stage constraints (_ge_tol, hqp/Hqp_IpLQDOCP.C:113)
   bool analyzed = false, uploaded = false, have_values = false, factored = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr;
@@ -246,6 +254,7 @@ struct hqpkkt {
     if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
     hstage_in = hstage_out = 0;
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
+    if (sd) staged_release(sd, false);
     drop_graphs();
     uploaded = have_values = factored = false;
   }
@@ -698,9 +707,14 @@ static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots
   return rc ? HQPKKT_E_DEVICE : 0;
 }
 
+static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w);
+static int staged_run_step(hqpkkt_t *h, const Vecs &v);
+
 static int do_factor(hqpkkt_t *h, const Vecs &v) {
   Analysis &an = h->an;
   int e;
+  if (h->opts.mode == HQPKKT_MODE_STAGED)
+    return graphed(h, h->gfactor[0], [&]() { return staged_run_factor(h, v.z, v.w); });
   if (an.shard_count <= 1) return graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 3); });
   if ((e = graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 1); }))) return e;
   if (an.upd_x_slot > 0 &&
@@ -712,6 +726,8 @@ static int do_factor(hqpkkt_t *h, const Vecs &v) {
 static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
   Analysis &an = h->an;
   int e;
+  if (h->opts.mode == HQPKKT_MODE_STAGED)
+    return graphed(h, h->gstep[which][0], [&]() { return staged_run_step(h, v); });
   if (an.shard_count <= 1) return graphed(h, h->gstep[which][0], [&]() { return run_step(h, v, 7); });
   if ((e = graphed(h, h->gstep[which][0], [&]() { return run_step(h, v, 1); }))) return e;
   if (an.cb_x_slot > 0 &&
@@ -776,6 +792,13 @@ static float elapsed(hipEvent_t a, hipEvent_t b) {
   return ms;
 }
 
+#include "staged_host.hip.h"
+static void staged_release(StagedDev *sd, bool destroy) {
+  if (!sd) return;
+  sd->release();
+  if (destroy) delete sd;
+}
+
 // =========================================================================
 extern "C" {
 
@@ -802,7 +825,7 @@ int hqpkkt_create(const hqpkkt_opts *opts, hqpkkt_t **out) {
     o = *opts;
   else
     hqpkkt_default_opts(&o);
-  if (o.mode != HQPKKT_MODE_FULL && o.mode != HQPKKT_MODE_REDUCED) return HQPKKT_E_RANGE;
+  if (o.mode != HQPKKT_MODE_FULL && o.mode != HQPKKT_MODE_REDUCED && o.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_RANGE;
   if (!(o.tol > 0.0 && o.tol <= 1.0)) return HQPKKT_E_RANGE;  // hqp/spBKP.C:389-390
   if (o.loc != HQPKKT_LOC_HOST && o.loc != HQPKKT_LOC_DEVICE) return HQPKKT_E_RANGE;
   hqpkkt_t *h = new (std::nothrow) hqpkkt;
@@ -827,6 +850,7 @@ int hqpkkt_destroy(hqpkkt_t *h) {
     h->prof.destroy();
     (void)hipStreamDestroy(h->own_stream);
   }
+  staged_release(h->sd, true);
   delete h;
   return 0;
 }
@@ -855,6 +879,13 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *
   keep(h->pCp, Cp, m ? (size_t)m + 1 : 0), keep(h->pCi, Ci, m ? (size_t)Cp[m] : 0);
   h->zd_decided = h->opts.zd_policy >= 0;
   h->zd_weak = false;
+  if (h->opts.mode == HQPKKT_MODE_STAGED) {
+    h->zd_decided = true;
+    int es = staged_analyze(h, n, me, m);
+    if (es) return es;
+    if (sbw) *sbw = -1;
+    return 0;
+  }
   int e = run_analysis(h, n, me, m, h->zd_decided ? h->opts.zd_policy : 2);
   if (e) return e;
   if (sbw) *sbw = h->an.sbw;
@@ -898,6 +929,7 @@ int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const dou
   Analysis &an = h->an;
   if ((an.nq && !Qx) || (an.na && !Ax) || (an.nc && !Cx)) return HQPKKT_E_NULL;
   int e;
+  if (h->opts.mode == HQPKKT_MODE_STAGED) return staged_set_values(h, Qx, Ax, Cx);
   if (!h->zd_decided) {
     // zd_policy -1: an x whose Hessian diagonal is weak against its coupling to an equality
     // needs the 2x2 pivot with that equality's multiplier inside its own pivot block
@@ -1765,6 +1797,7 @@ int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {
 int hqpkkt_get_perm(const hqpkkt_t *h, int *perm) {
   if (!h || !perm) return HQPKKT_E_NULL;
   if (!h->analyzed) return HQPKKT_E_INTERN;
+  if ((int)h->an.qp2j.size() != h->an.dim) return HQPKKT_E_INTERN;  // STAGED: stage order, no RCM
   std::memcpy(perm, h->an.qp2j.data(), sizeof(int) * h->an.dim);
   return 0;
 }
@@ -1800,6 +1833,120 @@ int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, vo
   h->shard_rank = rank, h->shard_count = count;
   h->xchg_fn = fn, h->xchg_ctx = ctx;
   return 0;
+}
+
+int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu) {
+  if (!h) return HQPKKT_E_NULL;
+  if (h->opts.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_INTERN;
+  if (!h->sd) h->sd = new (std::nothrow) StagedDev;
+  if (!h->sd) return HQPKKT_E_MEM;
+  kktdev::StagedPlan &P = h->sd->plan;
+  P.given_nx.clear(), P.given_nu.clear();
+  if (K <= 0) return 0;  // back to detection from the staircase of A
+  if (!nx || !nu) return HQPKKT_E_NULL;
+  for (int k = 0; k <= K; k++)
+    if (nx[k] < 1) return HQPKKT_E_RANGE;
+  for (int k = 0; k < K; k++)
+    if (nu[k] < 0) return HQPKKT_E_RANGE;
+  P.given_nx.assign(nx, nx + K + 1), P.given_nu.assign(nu, nu + K);
+  return 0;
+}
+
+// STAGED: rank and number of carried rows of every stage in the last factorisation
+// (2 ints per stage, K+1 stages); tests only
+int hqpkkt_debug_stage_ranks(hqpkkt_t *h, int *out, int cap) {
+  if (!h || !out) return HQPKKT_E_NULL;
+  if (!h->sd || !h->uploaded) return HQPKKT_E_INTERN;
+  HIPCHK(hipSetDevice(h->opts.device));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  const kktdev::StagedPlan &P = h->sd->plan;
+  for (int k = 0; k <= P.K && 2 * k + 1 < cap; k++)
+    HIPCHK(hipMemcpy(out + 2 * k, h->sd->dyn.p + P.dyn_off[k], 2 * sizeof(int), hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// Micro-benchmark and self-check of the dense fp64 product the STAGED engine is made of
+// (k_dgemm_tn): C = A'B (+ lower / mirror) on pseudo-random operands, `reps` timed launches;
+// *ms = average device time per launch, *max_err = max |C - exact| over 4096 sampled entries
+// relative to sum |a||b|.  Used by tests/ and bench.py (roofline of the kernel on its own).
+namespace {
+__global__ void k_fill_rand(double *p, long long n, unsigned long long seed) {
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  unsigned long long x = (unsigned long long)i * 0x9E3779B97F4A7C15ULL + seed;
+  x ^= x >> 30, x *= 0xBF58476D1CE4E5B9ULL, x ^= x >> 27, x *= 0x94D049BB133111EBULL, x ^= x >> 31;
+  p[i] = (double)(x >> 11) * (1.0 / 9007199254740992.0) - 0.5;
+}
+__global__ void k_gemm_check(stg::GemmArgs g, int nsample, double *err) {
+  const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (sidx >= nsample) return;
+  unsigned long long x = (unsigned long long)sidx * 0x9E3779B97F4A7C15ULL + 12345;
+  x ^= x >> 29, x *= 0xBF58476D1CE4E5B9ULL, x ^= x >> 32;
+  int i = (int)(x % (unsigned long long)g.M), j = (int)((x >> 20) % (unsigned long long)g.N);
+  // lower: only i >= j is computed; mirror: C[j][i] is a copy of C[i][j] (the product is
+  // symmetric in the engine; here the operands are not, so the copy is what gets checked)
+  int ci = i, cj = j;
+  if (g.lower && i < j) {
+    const int t = i;
+    i = j, j = t;
+    if (!g.mirror) ci = i, cj = j;
+  }
+  double s = 0.0, sa = 0.0;
+  for (int k = 0; k < g.K; k++) {
+    const double a = g.A[(long long)k * g.lda + i], b = g.B[(long long)k * g.ldb + j];
+    s += a * b, sa += fabs(a * b);
+  }
+  const double e = fabs(g.C[(long long)ci * g.ldc + cj] - g.alpha * s) / (sa + 1e-300);
+  atomic_max_pos((unsigned long long *)err, e);
+}
+}  // namespace
+int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, int reps, double *ms, double *max_err) {
+  if (M <= 0 || N <= 0 || K < 0 || reps <= 0) return HQPKKT_E_RANGE;
+  if (lower && M != N) return HQPKKT_E_RANGE;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return HQPKKT_E_DEVICE;
+  HIPCHK(hipSetDevice(device));
+  const long long lda = (M + 7) / 8 * 8, ldb = (N + 7) / 8 * 8, ldc = ldb;
+  double *A = nullptr, *B = nullptr, *Cm = nullptr, *err = nullptr;
+  auto fin = [&](int rc) {
+    (void)hipFree(A), (void)hipFree(B), (void)hipFree(Cm), (void)hipFree(err);
+    return rc;
+  };
+  const size_t kk = K > 0 ? K : 1;
+  if (hipMalloc((void **)&A, sizeof(double) * kk * lda) != hipSuccess || hipMalloc((void **)&B, sizeof(double) * kk * ldb) != hipSuccess ||
+      hipMalloc((void **)&Cm, sizeof(double) * (size_t)std::max(M, N) * ldc) != hipSuccess || hipMalloc((void **)&err, 8) != hipSuccess)
+    return fin(HQPKKT_E_MEM);
+  k_fill_rand<<<nblk((long long)kk * lda), 256>>>(A, (long long)kk * lda, 1);
+  k_fill_rand<<<nblk((long long)kk * ldb), 256>>>(B, (long long)kk * ldb, 2);
+  (void)hipMemset(err, 0, 8);
+  (void)hipMemset(Cm, 0, sizeof(double) * (size_t)std::max(M, N) * ldc);
+  stg::GemmArgs g{A, lda, B, ldb, nullptr, 0, Cm, ldc, M, N, K, 1.0, 0.0, lower, mirror};
+  const bool big = stg::gemm_big_tiles(M, N, lower);
+  const int b = big ? 128 : 64;
+  const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
+  (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(128, 128));
+  (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(64, 64));
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
+  for (int r = -1; r < reps; r++) {
+    if (r == 0) (void)hipEventRecord(e0, 0);
+    if (big)
+      stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
+    else
+      stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64)>>>(g);
+  }
+  (void)hipEventRecord(e1, 0);
+  hipError_t se = hipDeviceSynchronize();
+  float t = 0.f;
+  (void)hipEventElapsedTime(&t, e0, e1);
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+  if (se != hipSuccess) return fin(HQPKKT_E_DEVICE);
+  k_gemm_check<<<16, 256>>>(g, 4096, err);
+  double he = 0.0;
+  if (hipMemcpy(&he, err, 8, hipMemcpyDeviceToHost) != hipSuccess) return fin(HQPKKT_E_DEVICE);
+  if (ms) *ms = t / reps;
+  if (max_err) *max_err = he;
+  return fin(0);
 }
 
 int hqpkkt_set_profile(hqpkkt_t *h, int on) {
@@ -1860,6 +2007,18 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
     case 9: v = &an.ent_ec; break;
     case 10: v = &an.node_owner; break;
     case 11: v = &an.xroots; break;
+    case 20: case 21: case 22: case 23: case 24: case 25: case 26: {  // STAGED: the plan
+      if (!h->sd) return HQPKKT_E_INTERN;
+      const kktdev::StagedPlan &P = h->sd->plan;
+      if (what == 20) v = &P.nk;
+      if (what == 21) v = &P.mk;
+      if (what == 22) v = &P.nmk;
+      if (what == 23) v = &P.eq_ptr;
+      if (what == 24) v = &P.eq_rows;
+      if (what == 25) v = &P.fix_rows;
+      if (what == 26) v = &P.cap;
+      break;
+    }
     default: return HQPKKT_E_RANGE;
   }
   *len = (long long)v->size();

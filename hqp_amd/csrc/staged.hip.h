@@ -1,0 +1,783 @@
+// gfx950 kernels of the STAGED engine (HQPKKT_MODE_STAGED): the stage-structured
+// solution of the interior-point Newton system for multistage (DOCP) problems, i.e. the
+// job of the reference's Hqp_IpLQDOCP (hqp/Hqp_IpLQDOCP.C:796-976; extended Riccati
+// recursion ExRiccatiFactorSc :1794-1999, ExRiccatiSolveSc :2007-2182).  Included once by
+// hqpkkt.hip.  The algorithm and its notation: tests/model_staged.py (numpy model).
+//
+// Layout in HBM: every dense block row-major with an even leading dimension (16-byte
+// loads), so that EVERY matrix product of the recursion is of the one form
+//     C (M x N) = alpha * sum_k A[k][i] * B[k][j] + beta * Cin        ("TN": both operands k-major)
+//   W   = V+ F          A = V+ (symmetric), B = F = [fx fu] (n+ x (n+m))
+//   G   = F' W          lower tiles only
+//   Nc  = B+ F          A = BT+ (n+ x cap: the carried constraint rows, transposed)
+//   Rm  = K^-1 Y        A = K^-1 (symmetric)
+//   V   = Gxx - Y' Rm   lower tiles + mirror
+// v_mfma_f64_16x16x4 operand layout (hqpkkt_selftest_mfma): A: lane l holds A[l&15][l>>4];
+// B: B[l>>4][l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace stg {
+
+using kktdev::double4_t;
+using kktdev::mfma_f64;
+
+typedef double double2_t __attribute__((ext_vector_type(2)));
+
+struct GemmArgs {
+  const double *A;
+  long long lda;  // K x M, row-major (k-major)
+  const double *B;
+  long long ldb;  // K x N
+  const double *Cin;
+  long long ldcin;  // M x N, read when beta != 0
+  double *C;
+  long long ldc;
+  int M, N, K;
+  double alpha, beta;
+  int lower;   // only tiles with tile row >= tile column (M == N)
+  int mirror;  // with lower: C[j][i] = C[i][j] as well (exactly symmetric result)
+};
+
+static const int GEMM_BK = 16;
+static inline size_t gemm_lds_bytes(int bm, int bn) { return sizeof(double) * 2 * GEMM_BK * (size_t)(bm + 16 + bn + 16); }
+
+// 128 x 128 tiles (16 flop per operand byte) once they fill the chip: 256 CUs x 2 workgroups;
+// 64 x 64 tiles (four times as many workgroups) below
+static inline bool gemm_big_tiles(int M, int N, int lower) {
+  const long long tm = (M + 127) / 128, tn = (N + 127) / 128;
+  return (lower ? tm * (tm + 1) / 2 : tm * tn) >= 384;
+}
+
+// blockIdx -> position in a sequence in which the workgroups of one XCD (blockIdx % 8) are
+// neighbours (each XCD has its own L2; neighbouring tiles share operand panels)
+__device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7, x = bid & 7;
+  return x * q + (x < r ? x : r) + (bid >> 3);
+}
+
+// One workgroup (256 threads, 2 x 2 wavefronts) per BM x BN tile of C; k-slabs of 16 rows
+// of both operands go global -> registers -> LDS (two buffers: the loads of slab t+1 are in
+// flight while slab t is multiplied), fragments LDS -> registers with ds_read_b64, conflict
+// free because an LDS row is BM + 16 doubles (rows k, k+1 of a fragment: banks 32 apart).
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
+  constexpr int BK = GEMM_BK;
+  constexpr int LDA = BM + 16, LDB = BN + 16;
+  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  constexpr int LA = BK * BM / 2 / 256, LB = BK * BN / 2 / 256;  // 16-byte loads per thread and slab
+  constexpr int RA = 256 / (BM / 2), RB = 256 / (BN / 2);        // slab rows covered by one pass
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 * BK * (LDA + LDB) doubles
+  double *As = lds, *Bs = lds + 2 * BK * LDA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int lr = lane & 15, lk = lane >> 4;
+
+  // tile of this workgroup
+  int t = xcd_swizzle(blockIdx.x, gridDim.x);
+  int tm, tn;
+  const int tiles_n = (g.N + BN - 1) / BN;
+  if (g.lower) {
+    tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+    while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
+    while (tm * (tm + 1) / 2 > t) tm--;
+    tn = t - tm * (tm + 1) / 2;
+  } else {
+    const int tiles_m = (g.M + BM - 1) / BM;
+    constexpr int GM = 8;  // tile rows walked together: their A panels stay in L2
+    const int grp = t / (GM * tiles_n), first = grp * GM;
+    const int rows = min(GM, tiles_m - first);
+    const int in = t - grp * GM * tiles_n;
+    tm = first + in % rows;
+    tn = in / rows;
+  }
+  const int i0 = tm * BM, j0 = tn * BN;
+
+  // global -> register staging: thread covers columns ca, ca+1 of rows ra + p*RA
+  const int ca = 2 * (tid % (BM / 2)), ra = tid / (BM / 2);
+  const int cb = 2 * (tid % (BN / 2)), rb = tid / (BN / 2);
+  // a 16-byte load is inside its row when its first column is < ld (ld even)
+  const long long acol = (i0 + ca < g.lda) ? i0 + ca : 0;
+  const long long bcol = (j0 + cb < g.ldb) ? j0 + cb : 0;
+  double2_t sa[LA], sb[LB];
+  auto gload = [&](int k0) {
+#pragma unroll
+    for (int p = 0; p < LA; p++) {
+      const int k = k0 + ra + p * RA;
+      const int kc = k < g.K ? k : g.K - 1;
+      double2_t v = *(const double2_t *)(g.A + (long long)kc * g.lda + acol);
+      if (k >= g.K) v = (double2_t){0.0, 0.0};
+      sa[p] = v;
+    }
+#pragma unroll
+    for (int p = 0; p < LB; p++) {
+      const int k = k0 + rb + p * RB;
+      const int kc = k < g.K ? k : g.K - 1;
+      double2_t v = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
+      if (k >= g.K) v = (double2_t){0.0, 0.0};
+      sb[p] = v;
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int p = 0; p < LA; p++) *(double2_t *)(As + (buf * BK + ra + p * RA) * LDA + ca) = sa[p];
+#pragma unroll
+    for (int p = 0; p < LB; p++) *(double2_t *)(Bs + (buf * BK + rb + p * RB) * LDB + cb) = sb[p];
+  };
+
+  double4_t acc[TM][TN];
+#pragma unroll
+  for (int x = 0; x < TM; x++)
+#pragma unroll
+    for (int y = 0; y < TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+
+  const int nslab = (g.K + BK - 1) / BK;
+  if (nslab > 0) {
+    gload(0);
+    lstore(0);
+  }
+  __syncthreads();
+  for (int s = 0; s < nslab; s++) {
+    const int buf = s & 1;
+    if (s + 1 < nslab) gload((s + 1) * BK);
+    const double *Ab = As + buf * BK * LDA + wm * WM + lr;
+    const double *Bb = Bs + buf * BK * LDB + wn * WN + lr;
+#pragma unroll
+    for (int ks = 0; ks < BK / 4; ks++) {
+      double af[TM], bf[TN];
+#pragma unroll
+      for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * LDA + 16 * x];
+#pragma unroll
+      for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * LDB + 16 * y];
+#pragma unroll
+      for (int x = 0; x < TM; x++)
+#pragma unroll
+        for (int y = 0; y < TN; y++) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+    }
+    if (s + 1 < nslab) lstore(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue
+  const bool diag = g.lower && tm == tn;
+#pragma unroll
+  for (int x = 0; x < TM; x++)
+#pragma unroll
+    for (int y = 0; y < TN; y++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int i = i0 + wm * WM + 16 * x + lk + 4 * rg, j = j0 + wn * WN + 16 * y + lr;
+        if (i >= g.M || j >= g.N) continue;
+        if (diag && g.mirror && i < j) continue;
+        double v = g.alpha * acc[x][y][rg];
+        if (g.beta != 0.0) v += g.beta * g.Cin[(long long)i * g.ldcin + j];
+        g.C[(long long)i * g.ldc + j] = v;
+        if (g.mirror && i != j) g.C[(long long)j * g.ldc + i] = v;
+      }
+}
+
+// ---------------------------------------------------------------------------------------
+// H = Q + C'(Z/W)C of one stage added into the dense block (term lists as in the REDUCED
+// plugin: value = sum sgn * vals[s1] * vals[s2] * wt[wi]); every entry has one writer
+struct HTerm {
+  int s1, s2, wi;
+};
+__global__ void k_st_add_h(int nent, const long long *__restrict__ dst, const int *__restrict__ tptr,
+                           const HTerm *__restrict__ terms, const double *__restrict__ vals,
+                           const double *__restrict__ wt, double *__restrict__ G, int add) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nent) return;
+  double s = 0.0;
+  for (int k = tptr[e]; k < tptr[e + 1]; k++) s += vals[terms[k].s1] * vals[terms[k].s2] * wt[terms[k].wi];
+  if (add)
+    G[dst[e]] += s;
+  else
+    G[dst[e]] = s;
+}
+
+// values of the A block scattered into dense storage: dst >= 0 offset into the F arena (dynamics
+// rows), dst <= -2 offset -(dst + 2) into the misc arena (own equality rows of N), -1 not stored
+// (the -1.0 of a dynamics row, the rows that fix x_0)
+__global__ void k_st_scatter(long long nent, const long long *__restrict__ dst, const double *__restrict__ vals,
+                             double *__restrict__ F, double *__restrict__ misc) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nent) return;
+  const long long d = dst[e];
+  if (d >= 0)
+    F[d] = vals[e];
+  else if (d <= -2)
+    misc[-(d + 2)] = vals[e];
+}
+// check of the staircase: the last entry of every dynamics row is -1.0 (Hqp_IpLQDOCP::Get_Dim,
+// hqp/Hqp_IpLQDOCP.C:214-215), the entries that fix x_0 are non-zero
+__global__ void k_st_check(int nchk, const int *__restrict__ idx, const int *__restrict__ kind,
+                           const double *__restrict__ vals, int *__restrict__ status) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nchk) return;
+  const double v = vals[idx[e]];
+  if (kind[e] == 0 ? v != -1.0 : v == 0.0) atomicExch(status, 6);
+}
+
+// ---------------------------------------------------------------------------------------
+// block-wide arg-max of |value| with the smallest index winning ties (deterministic)
+struct ArgMax {
+  double v;
+  int i;
+};
+__device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
+__device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax *red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    ArgMax b;
+    b.v = __shfl_xor(a.v, o);
+    b.i = __shfl_xor(a.i, o);
+    a = better(a, b);
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
+  __syncthreads();
+  ArgMax r = red[0];
+  for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = better(r, red[w]);
+  return r;
+}
+
+// In-place inverse of the q x q matrix a (LDS, leading dimension ld) by Gauss-Jordan
+// elimination with complete pivoting.  Returns 0, or 1 when a pivot is exactly zero / NaN.
+// ip, ir, ic: int work arrays of q entries; colv, rowv: double work arrays of q entries.
+__device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv,
+                          ArgMax *red) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  for (int j = tid; j < q; j += nt) ip[j] = 0;
+  __syncthreads();
+  int bad = 0;
+  for (int s = 0; s < q; s++) {
+    ArgMax best{-1.0, 0x7fffffff};
+    for (int e = tid; e < q * q; e += nt) {
+      const int r = e / q, c = e - r * q;
+      if (ip[r] == 0 && ip[c] == 0) {
+        const double v = fabs(a[r * ld + c]);
+        ArgMax cand{v == v ? v : __longlong_as_double(0x7ff0000000000000LL), e};
+        best = better(best, cand);
+      }
+    }
+    best = block_argmax(best, red);
+    const int irow = best.i / q, icol = best.i - irow * q;
+    if (!(best.v > 0.0) || best.v == __longlong_as_double(0x7ff0000000000000LL)) bad = 1;
+    __syncthreads();
+    if (irow != icol)
+      for (int c = tid; c < q; c += nt) {
+        const double x = a[irow * ld + c];
+        a[irow * ld + c] = a[icol * ld + c];
+        a[icol * ld + c] = x;
+      }
+    if (tid == 0) ip[icol] = 1, ir[s] = irow, ic[s] = icol;
+    __syncthreads();
+    const double piv = a[icol * ld + icol];
+    const double pinv = bad ? 1.0 : 1.0 / piv;
+    __syncthreads();
+    for (int c = tid; c < q; c += nt) {
+      colv[c] = (c == icol) ? 0.0 : a[c * ld + icol];
+      rowv[c] = (c == icol ? 1.0 : a[icol * ld + c]) * pinv;
+    }
+    __syncthreads();
+    for (int e = tid; e < q * q; e += nt) {
+      const int r = e / q, c = e - r * q;
+      if (r == icol)
+        a[e / q * ld + c] = rowv[c];
+      else
+        a[r * ld + c] = (c == icol ? 0.0 : a[r * ld + c]) - rowv[c] * colv[r];
+    }
+    __syncthreads();
+  }
+  for (int s = q - 1; s >= 0; s--) {
+    const int r1 = ir[s], c1 = ic[s];
+    if (r1 != c1)
+      for (int r = tid; r < q; r += nt) {
+        const double x = a[r * ld + r1];
+        a[r * ld + r1] = a[r * ld + c1];
+        a[r * ld + c1] = x;
+      }
+    __syncthreads();
+  }
+  return bad;
+}
+
+// Per stage, one workgroup: (A) rank-revealing elimination of the control part N_u of the
+// stage's constraint rows (own equalities, then the rows carried back from stage k+1) with
+// complete pivoting: consumed rows R (they determine controls), leftover rows L (free of u
+// after subtracting t times the consumed rows: carried on to stage k-1) - the job of GE_QP
+// in the reference (meschach/addon_hqp.c:399-475, QR with column pivoting there);
+// (B) K = [G_uu N_uR'; N_uR 0], symmetric scaling, explicit inverse (the reference factors
+// Z' G_uu Z by Bunch-Kaufman and forms Z (Z'G_uu Z)^-1 Z' explicitly, :1907-1924).
+struct SmallArgs {
+  const double *G;
+  long long ldg;
+  int n, m;             // states, controls of the stage
+  const double *N;
+  long long ldn;        // constraint rows, capn x (n + m)
+  int e;                // own rows
+  const int *cnt_next;  // carried rows coming in (device), nullptr: none
+  int capn, cap, qmax;
+  double ge_tol;
+  double *Kinv;
+  long long ldq;        // qmax x qmax, zero padded
+  double *t;
+  long long ldt;        // cap x ldt : t[li][s]
+  int *dyn;             // [0] r, [1] number of leftover rows, [2..2+capn) R, [2+capn..2+2capn) L
+  int *status;          // set to 4 (E_SING) on a singular K
+};
+__global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ ArgMax red[4];
+  __shared__ int s_r, s_stop;
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int m = a.m, n = a.n;
+  const int c = a.e + (a.cnt_next ? *a.cnt_next : 0);
+  int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
+  // ---------------- (A)
+  int r = 0;
+  if (c > 0 && m > 0) {
+    const int ld = m + c;
+    double *aug = sm;
+    int *rfree = (int *)(sm + (size_t)c * ld);
+    int *cfree = rfree + c;
+    for (int e = tid; e < c * ld; e += nt) {
+      const int i = e / ld, j = e - i * ld;
+      aug[e] = j < m ? a.N[(long long)i * a.ldn + n + j] : (j - m == i ? 1.0 : 0.0);
+    }
+    for (int i = tid; i < c; i += nt) rfree[i] = 1;
+    for (int j = tid; j < m; j += nt) cfree[j] = 1;
+    if (tid == 0) s_r = 0, s_stop = 0;
+    __syncthreads();
+    const int steps = c < m ? c : m;
+    for (int s = 0; s < steps; s++) {
+      ArgMax best{-1.0, 0x7fffffff};
+      for (int e = tid; e < c * m; e += nt) {
+        const int i = e / m, j = e - i * m;
+        if (rfree[i] && cfree[j]) {
+          const double v = fabs(aug[i * ld + j]);
+          best = better(best, ArgMax{v, e});
+        }
+      }
+      best = block_argmax(best, red);
+      if (!(best.v > a.ge_tol)) break;  // uniform
+      const int pi = best.i / m, pj = best.i - pi * m;
+      __syncthreads();
+      if (tid == 0) rfree[pi] = 0, cfree[pj] = 0, Rl[s] = pi, s_r = s + 1;
+      const double piv = aug[pi * ld + pj];
+      // multipliers of the free rows (column pj), then the update
+      double *fac = (double *)(cfree + m + ((c + m) & 1));  // c doubles behind the flags, 8-byte aligned
+      __syncthreads();
+      for (int i = tid; i < c; i += nt) fac[i] = (rfree[i]) ? aug[i * ld + pj] / piv : 0.0;
+      __syncthreads();
+      for (int e = tid; e < c * ld; e += nt) {
+        const int i = e / ld, j = e - i * ld;
+        if (rfree[i] && fac[i] != 0.0) aug[e] = (j == pj) ? 0.0 : aug[e] - fac[i] * aug[pi * ld + j];
+      }
+      __syncthreads();
+    }
+    __syncthreads();
+    r = s_r;
+    // leftover rows in increasing order, t = -coef[L, R]
+    if (tid == 0) {
+      int nl = 0;
+      for (int i = 0; i < c; i++)
+        if (rfree[i]) Ll[nl++] = i;
+      if (nl > a.cap) nl = a.cap, atomicExch(a.status, 1);  // more rows to carry than the plan holds
+      a.dyn[0] = r, a.dyn[1] = nl;
+    }
+    __syncthreads();
+    const int nl = min(c - r, a.cap);
+    for (int e = tid; e < nl * r; e += nt) {
+      const int li = e / r, s = e - li * r;
+      a.t[(long long)li * a.ldt + s] = -aug[Ll[li] * ld + m + Rl[s]];
+    }
+    __syncthreads();
+  } else {
+    if (tid == 0) {
+      int nl = c;
+      if (nl > a.cap) nl = a.cap, atomicExch(a.status, 1);
+      a.dyn[0] = 0, a.dyn[1] = nl;
+      for (int i = 0; i < nl; i++) Ll[i] = i;
+    }
+    __syncthreads();
+  }
+  // ---------------- (B)
+  const int q = m + r;
+  if (q > 0) {
+    const int ld = q | 1;
+    double *Km = sm;
+    double *dsc = Km + (size_t)q * ld;
+    double *colv = dsc + q, *rowv = colv + q;
+    int *ip = (int *)(rowv + q), *ir = ip + q, *ic = ir + q;
+    for (int e = tid; e < q * q; e += nt) {
+      const int i = e / q, j = e - i * q;
+      double v;
+      if (i < m && j < m) {
+        const int hi = i > j ? i : j, lo = i > j ? j : i;
+        v = a.G[(long long)(n + hi) * a.ldg + n + lo];
+      } else if (i >= m && j >= m)
+        v = 0.0;
+      else {
+        const int s = (i >= m ? i : j) - m, u = i >= m ? j : i;
+        v = a.N[(long long)Rl[s] * a.ldn + n + u];
+      }
+      Km[i * ld + j] = v;
+    }
+    __syncthreads();
+    // scaling: u rows 1/sqrt(K_ii) where K_ii > 1 (hqp/Hqp_IpLQDOCP.C:1851-1858), constraint rows
+    // by their largest entry
+    for (int i = tid; i < q; i += nt) {
+      double d = 1.0;
+      if (i < m) {
+        const double kii = Km[i * ld + i];
+        if (kii > 1.0) d = 1.0 / sqrt(kii);
+      } else {
+        double mx = 0.0;
+        for (int j = 0; j < m; j++) mx = fmax(mx, fabs(Km[i * ld + j]));
+        if (mx > 0.0) d = 1.0 / mx;
+      }
+      dsc[i] = d;
+    }
+    __syncthreads();
+    for (int e = tid; e < q * q; e += nt) {
+      const int i = e / q, j = e - i * q;
+      Km[i * ld + j] *= dsc[i] * dsc[j];
+    }
+    __syncthreads();
+    const int bad = gj_inverse(Km, q, ld, ip, ir, ic, colv, rowv, red);
+    if (bad && tid == 0) atomicExch(a.status, 4);
+    __syncthreads();
+    for (int e = tid; e < a.qmax * a.qmax; e += nt) {
+      const int i = e / a.qmax, j = e - i * a.qmax;
+      double v = 0.0;
+      if (i < q && j < q) v = 0.5 * (Km[i * ld + j] + Km[j * ld + i]) * dsc[i] * dsc[j];
+      a.Kinv[(long long)i * a.ldq + j] = v;
+    }
+  } else {
+    for (int e = tid; e < a.qmax * a.qmax; e += nt) a.Kinv[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0;
+  }
+}
+static size_t st_small_lds(int m, int capn) {
+  const size_t q = (size_t)m + (size_t)(capn < m ? capn : m);
+  const size_t a = (size_t)capn * (m + capn) * 8 + (size_t)(capn + m + 2) * 4 + (size_t)capn * 8 + 16;
+  const size_t b = q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4 + 16;
+  return (a > b ? a : b) + 64;
+}
+
+// Per stage, one thread per state column j: Y = [G_ux ; N_xR ; 0] and the transposed carried
+// rows BT[j][li] = (N_L - t N_R)[li][j] (zero beyond the live count)
+struct WideArgs {
+  const double *G;
+  long long ldg;
+  int n, m;
+  const double *N;
+  long long ldn;
+  int capn, cap, qmax;
+  const double *t;
+  long long ldt;
+  const int *dyn;
+  double *Y;
+  long long ldy;
+  double *BT;
+  long long ldb;
+};
+__global__ void k_st_wide(WideArgs a) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= a.n) return;
+  const int r = a.dyn[0], nl = a.dyn[1];
+  const int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
+  for (int i = 0; i < a.m; i++) a.Y[(long long)i * a.ldy + j] = a.G[(long long)(a.n + i) * a.ldg + j];
+  for (int s = 0; s < a.qmax - a.m; s++)
+    a.Y[(long long)(a.m + s) * a.ldy + j] = s < r ? a.N[(long long)Rl[s] * a.ldn + j] : 0.0;
+  for (int li = 0; li < a.cap; li++) {
+    double v = 0.0;
+    if (li < nl) {
+      v = a.N[(long long)Ll[li] * a.ldn + j];
+      for (int s = 0; s < r; s++) v -= a.t[(long long)li * a.ldt + s] * a.N[(long long)Rl[s] * a.ldn + j];
+    }
+    a.BT[(long long)j * a.ldb + li] = v;
+  }
+}
+// last stage K: all its equality rows are carried (no control): BT_K = E_K', count = e
+__global__ void k_st_last(int n, int e, int cap, const double *__restrict__ N, long long ldn, double *__restrict__ BT,
+                          long long ldb, int *__restrict__ dyn) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j == 0) dyn[0] = 0, dyn[1] = e;
+  if (j >= n) return;
+  for (int li = 0; li < cap; li++) BT[(long long)j * ldb + li] = li < e ? N[(long long)li * ldn + j] : 0.0;
+}
+// a fixed initial state must not be left with constraints of its own (the reference cannot
+// solve that either, hqp/Hqp_IpLQDOCP.C:2097-2108)
+__global__ void k_st_check_fixed(const int *__restrict__ dyn0, int *__restrict__ status) {
+  if (threadIdx.x == 0 && blockIdx.x == 0 && dyn0[1] > 0) atomicExch(status, 4);
+}
+
+// free initial state: inverse of [V_0 B_0'; B_0 0]  (hqp/Hqp_IpLQDOCP.C:1972-1996)
+__global__ void __launch_bounds__(256) k_st_init_factor(int n0, int cap, const double *__restrict__ V, long long ldv,
+                                                        const double *__restrict__ BT, long long ldb,
+                                                        const int *__restrict__ dyn0, double *__restrict__ K0inv,
+                                                        long long ldq, int qmax, int *__restrict__ status) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  __shared__ ArgMax red[4];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int c = dyn0[1], q = n0 + c, ld = q | 1;
+  double *Km = sm, *dsc = Km + (size_t)q * ld, *colv = dsc + q, *rowv = colv + q;
+  int *ip = (int *)(rowv + q), *ir = ip + q, *ic = ir + q;
+  for (int e = tid; e < q * q; e += nt) {
+    const int i = e / q, j = e - i * q;
+    double v;
+    if (i < n0 && j < n0)
+      v = V[(long long)i * ldv + j];
+    else if (i >= n0 && j >= n0)
+      v = 0.0;
+    else
+      v = BT[(long long)(i < n0 ? i : j) * ldb + (i < n0 ? j : i) - n0];
+    Km[i * ld + j] = v;
+  }
+  __syncthreads();
+  for (int i = tid; i < q; i += nt) {
+    double d = 1.0;
+    if (i < n0) {
+      const double kii = Km[i * ld + i];
+      if (kii > 1.0) d = 1.0 / sqrt(kii);
+    }
+    dsc[i] = d;
+  }
+  __syncthreads();
+  for (int e = tid; e < q * q; e += nt) Km[(e / q) * ld + e % q] *= dsc[e / q] * dsc[e % q];
+  __syncthreads();
+  const int bad = gj_inverse(Km, q, ld, ip, ir, ic, colv, rowv, red);
+  if (bad && tid == 0) atomicExch(status, 4);
+  __syncthreads();
+  for (int e = tid; e < qmax * qmax; e += nt) {
+    const int i = e / qmax, j = e - i * qmax;
+    K0inv[(long long)i * ldq + j] = (i < q && j < q) ? 0.5 * (Km[i * ld + j] + Km[j * ld + i]) * dsc[i] * dsc[j] : 0.0;
+  }
+}
+
+// ---------------------------------------------------------------------------------------
+// dense matrix-vector products of the two sweeps (HBM-bound: a stage block is read once)
+// rows form: y[i] = add[i] + sum_j A[i][j] x[j] (+ sum_l A2[i][l] x2[l]), one wavefront per row
+struct GemvRows {
+  const double *A;
+  long long lda;
+  int M, N;
+  const double *x;
+  const double *add;  // may be null
+  const double *A2;   // optional second block (the carried rows: BT eta)
+  long long lda2;
+  const int *n2;      // live columns of A2 (device)
+  const double *x2;
+  double *y;
+  double scale;       // y = scale * (...)
+};
+__global__ void __launch_bounds__(256) k_st_gemv_rows(GemvRows g) {
+  const int lane = threadIdx.x & 63, row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= g.M) return;
+  const double *ar = g.A + (long long)row * g.lda;
+  double s = 0.0;
+  for (int j = lane; j < g.N; j += 64) s += ar[j] * g.x[j];
+  if (g.A2) {
+    const int k2 = *g.n2;
+    const double *br = g.A2 + (long long)row * g.lda2;
+    for (int j = lane; j < k2; j += 64) s += br[j] * g.x2[j];
+  }
+  s = kktdev::wave_sum(s);
+  if (lane == 0) g.y[row] = g.scale * ((g.add ? g.add[row] : 0.0) + s);
+}
+// columns form: part[s][j] = sum over the rows k of chunk s of A[k][j] x[k]; with one chunk the
+// result y[j] = add[j] + alpha * sum is written directly
+struct GemvCols {
+  const double *A;
+  long long lda;
+  int K, N;
+  const double *x;
+  const double *add;
+  double alpha;
+  double *y;
+  double *part;  // nchunk x N
+  int rows_per_chunk;
+};
+__global__ void __launch_bounds__(256) k_st_gemv_cols(GemvCols g) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= g.N) return;
+  const int k0 = blockIdx.y * g.rows_per_chunk, k1 = min(g.K, k0 + g.rows_per_chunk);
+  double s = 0.0;
+  for (int k = k0; k < k1; k++) s += g.A[(long long)k * g.lda + j] * g.x[k];
+  if (gridDim.y == 1)
+    g.y[j] = (g.add ? g.add[j] : 0.0) + g.alpha * s;
+  else
+    g.part[(long long)blockIdx.y * g.N + j] = s;
+}
+__global__ void k_st_cols_finish(int N, int nchunk, const double *__restrict__ part, const double *__restrict__ add,
+                                 double alpha, double *__restrict__ y) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= N) return;
+  double s = 0.0;
+  for (int c = 0; c < nchunk; c++) s += part[(long long)c * N + j];
+  y[j] = (add ? add[j] : 0.0) + alpha * s;
+}
+
+// q = -(r1 - C' tz)   (the reference's gx, gu: hqp/Hqp_IpLQDOCP.C:884-918)
+__global__ void k_st_q(int n, const int *__restrict__ CTp, const int *__restrict__ CTc, const int *__restrict__ CTs,
+                       const double *__restrict__ vals, const double *__restrict__ tz, const double *__restrict__ r1,
+                       double *__restrict__ q) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = 0.0;
+  for (int k = CTp[i]; k < CTp[i + 1]; k++) s += vals[CTs[k]] * tz[CTc[k]];
+  q[i] = s - r1[i];
+}
+
+// backward sweep, the small part of a stage (one workgroup):
+//   nu = [a_k ; beta+ + B+ f],  y0 = [gam_u ; nu_R],  rho = K^-1 y0,  beta = nu_L - t nu_R
+struct BwdSmall {
+  int n, m, np, e, capn, cap, qmax;
+  const int *eq_rows;        // QP row index of the own equality rows
+  const double *r2;
+  const int *cnt_next;       // live carried rows coming in (nullptr: none)
+  const double *beta_next;
+  const double *BT_next;     // np x ldbn
+  long long ldbn;
+  const double *f;           // r2 + first dynamics row of the stage
+  const double *gam;         // n + m
+  const double *Kinv;
+  long long ldq;
+  const double *t;
+  long long ldt;
+  const int *dyn;
+  double *rho;               // qmax
+  double *beta;              // cap
+};
+__global__ void __launch_bounds__(256) k_st_bwd_small(BwdSmall a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int cn = a.cnt_next ? *a.cnt_next : 0;
+  const int r = a.dyn[0], nl = a.dyn[1];
+  const int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
+  double *nu = sm, *y0 = sm + a.capn + 1;
+  for (int i = tid; i < a.e; i += nt) nu[i] = a.r2[a.eq_rows[i]];
+  // carried rows: beta+ + B+ f, one wavefront per row
+  for (int li = tid >> 6; li < cn; li += nt >> 6) {
+    double s = 0.0;
+    for (int k = tid & 63; k < a.np; k += 64) s += a.BT_next[(long long)k * a.ldbn + li] * a.f[k];
+    s = kktdev::wave_sum(s);
+    if ((tid & 63) == 0) nu[a.e + li] = a.beta_next[li] + s;
+  }
+  __syncthreads();
+  const int q = a.m + r;
+  for (int i = tid; i < q; i += nt) y0[i] = i < a.m ? a.gam[a.n + i] : nu[Rl[i - a.m]];
+  __syncthreads();
+  for (int i = tid; i < a.qmax; i += nt) {
+    double s = 0.0;
+    if (i < q)
+      for (int j = 0; j < q; j++) s += a.Kinv[(long long)i * a.ldq + j] * y0[j];
+    a.rho[i] = s;
+  }
+  for (int li = tid; li < a.cap; li += nt) {
+    double s = 0.0;
+    if (li < nl) {
+      s = nu[Ll[li]];
+      for (int k = 0; k < r; k++) s -= a.t[(long long)li * a.ldt + k] * nu[Rl[k]];
+    }
+    a.beta[li] = s;
+  }
+}
+
+// forward sweep, the small part of a stage (one workgroup):
+//   [u ; yhat] = -(Rm x + rho);  multipliers of the rows of N: consumed yhat - t' eta, leftover eta;
+//   own rows -> dy, carried rows -> eta of stage k+1
+struct FwdSmall {
+  int n, m, e, capn, cap, qmax;
+  const double *Rm;
+  long long ldy;
+  const double *x;     // x_k (inside the s vector)
+  const double *rho;
+  const double *t;
+  long long ldt;
+  const int *dyn;
+  const double *eta;   // multipliers of this stage's leftover rows (cap)
+  const int *eq_rows;
+  double *u;           // m (inside the s vector)
+  double *dy;
+  double *eta_next;    // capn - e entries at most
+  int cap_next;
+};
+__global__ void __launch_bounds__(256) k_st_fwd_small(FwdSmall a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+  const int r = a.dyn[0], nl = a.dyn[1];
+  const int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
+  const int q = a.m + r;
+  double *uy = sm, *yN = sm + a.qmax + 1;
+  for (int i = tid >> 6; i < q; i += nt >> 6) {
+    double s = 0.0;
+    const double *rr = a.Rm + (long long)i * a.ldy;
+    for (int j = lane; j < a.n; j += 64) s += rr[j] * a.x[j];
+    s = kktdev::wave_sum(s);
+    if (lane == 0) uy[i] = -(s + a.rho[i]);
+  }
+  __syncthreads();
+  for (int i = tid; i < a.m; i += nt) a.u[i] = uy[i];
+  for (int s = tid; s < r; s += nt) {
+    double v = uy[a.m + s];
+    for (int li = 0; li < nl; li++) v -= a.t[(long long)li * a.ldt + s] * a.eta[li];
+    yN[Rl[s]] = v;
+  }
+  for (int li = tid; li < nl; li += nt) yN[Ll[li]] = a.eta[li];
+  __syncthreads();
+  const int c = r + nl;
+  for (int i = tid; i < a.e; i += nt) a.dy[a.eq_rows[i]] = yN[i];
+  for (int i = tid; i < a.cap_next; i += nt) a.eta_next[i] = (a.e + i < c) ? yN[a.e + i] : 0.0;
+}
+
+// initial state.  Fixed: x_0 = -r2[fix] / val, eta_0 = 0.  Free: [x_0 ; eta_0] = -K0^-1 [v_0 ; beta_0]
+__global__ void k_st_x0_fixed(int n0, const int *__restrict__ fix_rows, const int *__restrict__ fix_src,
+                              const double *__restrict__ vals, const double *__restrict__ r2, double *__restrict__ x0,
+                              double *__restrict__ eta0, int cap0) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n0) x0[i] = -r2[fix_rows[i]] / vals[fix_src[i]];
+  if (i < cap0) eta0[i] = 0.0;
+}
+// multipliers of the rows that fix x_0: -(V_0 x_0 + v_0) / val   (tmp = v_0 + V_0 x_0)
+__global__ void k_st_y_fixed(int n0, const int *__restrict__ fix_rows, const int *__restrict__ fix_src,
+                             const double *__restrict__ vals, const double *__restrict__ tmp, double *__restrict__ dy) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n0) dy[fix_rows[i]] = -tmp[i] / vals[fix_src[i]];
+}
+__global__ void __launch_bounds__(256) k_st_x0_free(int n0, int cap0, int qmax, const double *__restrict__ K0inv,
+                                                    long long ldq, const int *__restrict__ dyn0,
+                                                    const double *__restrict__ v0, const double *__restrict__ beta0,
+                                                    double *__restrict__ x0, double *__restrict__ eta0) {
+  const int c = dyn0[1], q = n0 + c;
+  for (int i = threadIdx.x; i < n0 + cap0; i += blockDim.x) {
+    double s = 0.0;
+    if (i < q)
+      for (int j = 0; j < q; j++) s += K0inv[(long long)i * ldq + j] * (j < n0 ? v0[j] : beta0[j - n0]);
+    if (i < n0)
+      x0[i] = -s;
+    else
+      eta0[i - n0] = -s;
+  }
+}
+// last stage: multipliers of its equality rows = eta_K
+__global__ void k_st_y_last(int e, const int *__restrict__ eq_rows, const double *__restrict__ eta, double *__restrict__ dy) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < e) dy[eq_rows[i]] = eta[i];
+}
+__global__ void k_st_gather(int e, const int *__restrict__ rows, const double *__restrict__ src, double *__restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < e) out[i] = src[rows[i]];
+}
+__global__ void k_st_negate(int n, const double *__restrict__ s, double *__restrict__ dx) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dx[i] = -s[i];
+}
+__global__ void k_st_copy(int n, const double *__restrict__ s, double *__restrict__ d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = s[i];
+}
+
+}  // namespace stg

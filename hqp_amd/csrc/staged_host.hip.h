@@ -1,0 +1,361 @@
+// Host side of the STAGED engine: device residency of the stage blocks and the kernel
+// sequences of factor (backward recursion over the stages) and step (backward vector sweep,
+// initial state, forward sweep).  Included by hqpkkt.hip after struct hqpkkt.
+// Reference counterpart: Hqp_IpLQDOCP::update / factor / step (hqp/Hqp_IpLQDOCP.C:722-976).
+#pragma once
+
+struct StagedDev {
+  kktdev::StagedPlan plan;
+  DBuf<double> F, V, misc;
+  DBuf<int> dyn, eq_rows, fix_rows, fix_src, h_tptr, chk_idx, chk_kind;
+  DBuf<long long> h_dst, a_dst;
+  DBuf<stg::HTerm> h_terms;
+  size_t lds_small = 0, lds_init = 0;
+  void release() {
+    F.release(), V.release(), misc.release();
+    dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
+    chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
+  }
+};
+
+namespace {
+
+// per-stage pointers into the arenas
+struct StagePtr {
+  double *F, *V, *Y, *Rm, *Kinv, *N, *BT, *T, *v, *beta, *eta, *rho;
+  int *dyn;
+};
+inline StagePtr stage_ptr(StagedDev &d, int k) {
+  const kktdev::StagedPlan &P = d.plan;
+  StagePtr s{};
+  double *M = d.misc.p;
+  s.V = d.V.p + P.oV[k];
+  s.BT = M + P.oBT[k], s.N = M + P.oN[k];
+  const int capx = std::max(P.cap[k], 1);
+  s.v = M + P.oVec[k], s.beta = s.v + P.nk[k], s.eta = s.beta + capx, s.rho = s.eta + capx;
+  s.dyn = d.dyn.p + P.dyn_off[k];
+  if (k < P.K) {
+    s.F = d.F.p + P.oF[k];
+    s.Y = M + P.oY[k], s.Rm = M + P.oR[k], s.Kinv = M + P.oK[k], s.T = M + P.oT[k];
+  }
+  return s;
+}
+
+// C = alpha A'B + beta Cin on the handle's stream; 128 x 128 tiles for large products, 64 x 64 below
+int st_gemm(hqpkkt_t *h, stg::GemmArgs g) {
+  if (g.M <= 0 || g.N <= 0) return 0;
+  const bool big = stg::gemm_big_tiles(g.M, g.N, g.lower);
+  const int b = big ? 128 : 64;
+  const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
+  const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
+  if (big)
+    KLAUNCH(h, KC_ST_GEMM, stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
+  else
+    KLAUNCH(h, KC_ST_GEMM, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
+  return 0;
+}
+
+int st_gemv_rows(hqpkkt_t *h, stg::GemvRows g) {
+  if (g.M <= 0) return 0;
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_rows<<<(g.M + 3) / 4, 256, 0, h->stream>>>(g));
+  return 0;
+}
+// y = add + alpha A'x over a K x N row-major block
+int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int K, int N, const double *x,
+                 const double *add, double alpha, double *y) {
+  if (N <= 0) return 0;
+  const kktdev::StagedPlan &P = d.plan;
+  int chunks = std::max(1, std::min(P.part_chunks, K / 64));
+  stg::GemvCols g{A, lda, K, N, x, add, alpha, y, d.misc.p + P.oPart, (K + chunks - 1) / chunks};
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_cols<<<dim3((N + 255) / 256, chunks), 256, 0, h->stream>>>(g));
+  if (chunks > 1)
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_cols_finish<<<(N + 255) / 256, 256, 0, h->stream>>>(N, chunks, d.misc.p + P.oPart, add,
+                                                                                       alpha, y));
+  return 0;
+}
+
+}  // namespace
+
+static int staged_analyze(hqpkkt_t *h, int n, int me, int m) {
+  if (!h->sd) h->sd = new (std::nothrow) StagedDev;
+  if (!h->sd) return HQPKKT_E_MEM;
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  std::vector<int> gnx = P.given_nx, gnu = P.given_nu;
+  P = kktdev::StagedPlan();
+  P.given_nx = gnx, P.given_nu = gnu;
+  int e = h->an.setup_blocks(1, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),
+                             h->pCp.data(), h->pCi.data());
+  if (e) return e;
+  e = P.run(n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(), h->pCp.data(), h->pCi.data());
+  if (e) return e;
+  h->an.sbw = -1;
+  h->analyzed = true;
+  std::memset(&h->st, 0, sizeof(h->st));
+  h->st.dim = n + me, h->st.sbw = -1;
+  h->st.n_supernodes = P.K + 1, h->st.n_levels = P.K + 1;
+  int mf = 0;
+  for (int k = 0; k < P.K; k++) mf = std::max(mf, P.nk[k] + P.mk[k] + P.nk[k + 1]);
+  h->st.max_front = mf;
+  h->st.nnz_kkt = (long long)P.nq + P.na + P.nc;
+  h->st.nnz_factor = P.v_elems + P.misc_elems;
+  h->st.flops_factor = P.flops_factor;
+  h->st.bytes_panels = (long long)sizeof(double) * (P.f_elems + P.v_elems);
+  h->st.bytes_updates = (long long)sizeof(double) * P.misc_elems;
+  h->st.shard_count = 1;
+  return 0;
+}
+
+static int staged_upload(hqpkkt_t *h) {
+  int e = ensure_device(h);
+  if (e) return e;
+  Analysis &an = h->an;
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  const int n = an.n, me = an.me, m = an.m;
+  if ((e = h->Qf.upload(an.Qfull)) || (e = h->A.upload(an.A)) || (e = h->AT.upload(an.AT)) ||
+      (e = h->C.upload(an.C)) || (e = h->CT.upload(an.CT)))
+    return e;
+  const size_t nv = (size_t)an.nq + an.na + an.nc + 1;
+  if ((e = h->vals.alloc(nv)) || (e = h->wt.alloc(m + 1)) || (e = h->flags.alloc(128)) ||
+      (e = h->vin.alloc(2 * (size_t)m + n + me + 2 * (size_t)m)) ||
+      (e = h->vout.alloc((size_t)n + me + 2 * (size_t)m)) || (e = h->vres.alloc((size_t)n + me + 2 * (size_t)m)) ||
+      (e = h->vcor.alloc((size_t)n + me + 2 * (size_t)m)) || (e = h->tz.alloc(m)))
+    return e;
+  h->bits.p = (unsigned long long *)(h->flags.p + 120);
+  if (!h->hpin) HIPCHK(hipHostMalloc((void **)&h->hpin, sizeof(double) * 128, hipHostMallocDefault));
+  if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr;
+  h->hstage_in = h->hstage_out = 0;
+  {
+    const size_t nin = 4 * (size_t)m + n + me, nout = (size_t)n + me + 2 * (size_t)m;
+    if ((nin + nout) * sizeof(double) <= (size_t)512 * 1024 && nin + nout > 0) {
+      HIPCHK(hipHostMalloc((void **)&h->hstage, sizeof(double) * (nin + nout), hipHostMallocDefault));
+      h->hstage_in = nin, h->hstage_out = nout;
+    }
+  }
+  {
+    const double one = 1.0;
+    HIPCHK(hipMemcpy(h->vals.p + (nv - 1), &one, sizeof(double), hipMemcpyHostToDevice));
+    HIPCHK(hipMemcpy(h->wt.p + m, &one, sizeof(double), hipMemcpyHostToDevice));
+    const double rows = 2.0 * n + me + m;
+    const double nnz = (double)an.Qfull.col.size() + 2.0 * an.A.col.size() + 2.0 * an.C.col.size();
+    h->short_rows = rows > 0 && nnz / rows < 8.0;
+  }
+  if ((e = d.F.alloc(P.f_elems)) || (e = d.V.alloc(P.v_elems)) || (e = d.misc.alloc(P.misc_elems)) ||
+      (e = d.dyn.alloc(P.dyn_ints)) || (e = d.eq_rows.upload(P.eq_rows)) || (e = d.fix_rows.upload(P.fix_rows)) ||
+      (e = d.fix_src.upload(P.fix_src)) || (e = d.h_tptr.upload(P.h_tptr)) || (e = d.chk_idx.upload(P.chk_idx)) ||
+      (e = d.chk_kind.upload(P.chk_kind)) || (e = d.h_dst.upload(P.h_dst)) || (e = d.a_dst.upload(P.a_dst)))
+    return e;
+  {
+    std::vector<stg::HTerm> t(P.h_terms.size());
+    for (size_t k = 0; k < t.size(); k++) t[k] = stg::HTerm{P.h_terms[k].s1, P.h_terms[k].s2, P.h_terms[k].wi};
+    if ((e = d.h_terms.upload(t))) return e;
+  }
+  HIPCHK(hipMemset(d.F.p, 0, sizeof(double) * std::max<long long>(P.f_elems, 1)));
+  HIPCHK(hipMemset(d.V.p, 0, sizeof(double) * std::max<long long>(P.v_elems, 1)));
+  HIPCHK(hipMemset(d.misc.p, 0, sizeof(double) * std::max<long long>(P.misc_elems, 1)));
+  HIPCHK(hipMemset(d.dyn.p, 0, sizeof(int) * std::max(P.dyn_ints, 1)));
+  d.lds_small = 0;
+  for (int k = 0; k < P.K; k++) d.lds_small = std::max(d.lds_small, stg::st_small_lds(P.mk[k], P.capn[k]));
+  {
+    const size_t q = (size_t)P.q0max;
+    d.lds_init = q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4 + 64;
+  }
+  static std::mutex attr_mutex;  // function attributes are process state, shared by all handles
+  static size_t attr_small = 0, attr_init = 0;
+  static bool attr_gemm = false;
+  {
+    std::lock_guard<std::mutex> lk(attr_mutex);
+    if (!attr_gemm) {
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)stg::gemm_lds_bytes(128, 128)));
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)stg::gemm_lds_bytes(64, 64)));
+      attr_gemm = true;
+    }
+    if (d.lds_small > attr_small) {
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)d.lds_small));
+      attr_small = d.lds_small;
+    }
+    if (d.lds_init > attr_init) {
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_init_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)d.lds_init));
+      attr_init = d.lds_init;
+    }
+  }
+  h->uploaded = true;
+  return 0;
+}
+
+static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const double *Cx) {
+  Analysis &an = h->an;
+  int e;
+  if (!h->uploaded && (e = staged_upload(h))) return e;
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  HIPCHK(hipSetDevice(h->opts.device));
+  hipStream_t s = h->stream;
+  hipMemcpyKind kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (an.nq) HIPCHK(hipMemcpyAsync(h->vals.p, Qx, sizeof(double) * an.nq, kind, s));
+  if (an.na) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq, Ax, sizeof(double) * an.na, kind, s));
+  if (an.nc) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq + an.na, Cx, sizeof(double) * an.nc, kind, s));
+  for (CsrBuf *c : {&h->Qf, &h->A, &h->AT, &h->C, &h->CT})
+    if (c->src.count)
+      k_gather_values<<<nblk((long long)c->src.count), 256, 0, s>>>((int)c->src.count, c->src.p, h->vals.p, c->val.p);
+  HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 128, s));
+  if (an.na)
+    stg::k_st_scatter<<<nblk(an.na), 256, 0, s>>>(an.na, d.a_dst.p, h->vals.p + an.nq, d.F.p, d.misc.p);
+  const int nchk = (int)P.chk_idx.size();
+  if (nchk) stg::k_st_check<<<nblk(nchk), 256, 0, s>>>(nchk, d.chk_idx.p, d.chk_kind.p, h->vals.p, h->flags.p);
+  int *hs = (int *)h->hpin;
+  HIPCHK(hipMemcpyAsync(hs, h->flags.p, sizeof(int) * 4, hipMemcpyDeviceToHost, s));
+  HIPCHK(hipStreamSynchronize(s));
+  if (hs[0]) return HQPKKT_E_FORMAT;  // not the -1.0 staircase (hqp/Hqp_IpLQDOCP.C:214-215) / a zero that fixes x_0
+  h->have_values = true;
+  h->factored = false;
+  return 0;
+}
+
+// Hqp_IpLQDOCP::factor (hqp/Hqp_IpLQDOCP.C:796-862): W^-1 Z, C'(W^-1 Z)C, then the backward
+// recursion over the stages (ExRiccatiFactorSc, :1794-1999)
+static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
+  Analysis &an = h->an;
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  hipStream_t s = h->stream;
+  const int m = an.m, K = P.K;
+  int e;
+  HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 128, s));
+  if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
+  if (m > 0) KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(1, m, an.n + an.me, z, w, h->wt.p, nullptr, h->flags.p));
+  if (!h->capturing) HIPCHK(hipEventRecord(h->ev1, s));
+  double *G = d.misc.p + P.oG, *W = d.misc.p + P.oW;
+  {  // last stage: V_K = H_K, all its equality rows are carried
+    StagePtr sp = stage_ptr(d, K);
+    const int nK = P.nk[K], eK = P.eq_ptr[K + 1] - P.eq_ptr[K];
+    HIPCHK(hipMemsetAsync(sp.V, 0, sizeof(double) * (size_t)nK * P.ldv[K], s));
+    const int ne = P.h_ptr[K + 1] - P.h_ptr[K];
+    if (ne)
+      KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(ne), 256, 0, s>>>(ne, d.h_dst.p + P.h_ptr[K], d.h_tptr.p + P.h_ptr[K], d.h_terms.p,
+                                                                       h->vals.p, h->wt.p, sp.V, 0));
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_last<<<nblk(std::max(nK, 1)), 256, 0, s>>>(nK, eK, P.cap[K], sp.N, P.ldn[K], sp.BT, P.ldb[K], sp.dyn));
+  }
+  for (int k = K - 1; k >= 0; k--) {
+    StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
+    const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
+    const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k];
+    // W = V+ F ; G = F'W (lower tiles) + H
+    if ((e = st_gemm(h, stg::GemmArgs{sn.V, P.ldv[k + 1], sp.F, P.ldf[k], nullptr, 0, W, P.ldf[k], np, nz, np, 1.0, 0.0, 0, 0})))
+      return e;
+    if ((e = st_gemm(h, stg::GemmArgs{sp.F, P.ldf[k], W, P.ldf[k], nullptr, 0, G, P.ldg[k], nz, nz, np, 1.0, 0.0, 1, 0})))
+      return e;
+    const int ne = P.h_ptr[k + 1] - P.h_ptr[k];
+    if (ne)
+      KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(ne), 256, 0, s>>>(ne, d.h_dst.p + P.h_ptr[k], d.h_tptr.p + P.h_ptr[k], d.h_terms.p,
+                                                                       h->vals.p, h->wt.p, G, 1));
+    // carried rows: N_k[e..] = B+ F
+    if (P.cap[k + 1] > 0 &&
+        (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, P.ldf[k], nullptr, 0, sp.N + (size_t)ek * P.ldn[k], P.ldn[k],
+                                      P.cap[k + 1], nz, np, 1.0, 0.0, 0, 0})))
+      return e;
+    stg::SmallArgs sa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
+                      P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.T, P.ldt[k], sp.dyn, h->flags.p};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<<<1, 256, d.lds_small, s>>>(sa));
+    stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,
+                     sp.Y, P.ldy[k], sp.BT, P.ldb[k]};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, s>>>(wa));
+    // Rm = K^-1 Y ; V = Gxx - Y'Rm (lower tiles, mirrored)
+    if (P.qmax[k] > 0 &&
+        (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, P.ldy[k], nullptr, 0, sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
+                                      1.0, 0.0, 0, 0})))
+      return e;
+    if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1})))
+      return e;
+  }
+  {
+    StagePtr s0 = stage_ptr(d, 0);
+    if (P.fixed_x0)
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_check_fixed<<<1, 64, 0, s>>>(s0.dyn, h->flags.p));
+    else
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<<<1, 256, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
+                                                                             d.misc.p + P.oK0, P.ldq0, P.q0max, h->flags.p));
+  }
+  if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
+// Hqp_IpLQDOCP::step (hqp/Hqp_IpLQDOCP.C:869-976) with ExRiccatiSolveSc (:2007-2182)
+static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
+  Analysis &an = h->an;
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  hipStream_t s = h->stream;
+  const int n = an.n, m = an.m, K = P.K;
+  double *M = d.misc.p;
+  double *S = M + P.oS, *qv = M + P.oQv, *gam = M + P.oGam, *tt = M + P.oTT, *tmp = M + P.oTmp;
+  int e;
+  if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
+  KLAUNCH(h, KC_VECTOR, stg::k_st_q<<<nblk(n), 256, 0, s>>>(n, h->CT.ptr.p, h->CT.col.p, h->CT.src.p, h->vals.p, h->tz.p, v.r1, qv));
+  {  // last stage
+    StagePtr sp = stage_ptr(d, K);
+    const int nK = P.nk[K], eK = P.eq_ptr[K + 1] - P.eq_ptr[K];
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(nK), 256, 0, s>>>(nK, qv + P.nmk[K], sp.v));
+    if (eK) KLAUNCH(h, KC_ST_VEC, stg::k_st_gather<<<nblk(eK), 256, 0, s>>>(eK, d.eq_rows.p + P.eq_ptr[K], v.r2, sp.beta));
+  }
+  for (int k = K - 1; k >= 0; k--) {
+    StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
+    const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
+    const double *f = v.r2 + P.nks[k];
+    // tt = v+ + V+ f ; gam = q_k + F' tt
+    if ((e = st_gemv_rows(h, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, f, sn.v, nullptr, 0, nullptr, nullptr, tt, 1.0}))) return e;
+    if ((e = st_gemv_cols(h, d, sp.F, P.ldf[k], np, nz, tt, qv + P.nmk[k], 1.0, gam))) return e;
+    stg::BwdSmall ba{nn, mm, np, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], d.eq_rows.p + P.eq_ptr[k], v.r2,
+                     P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr, sn.beta, sn.BT, P.ldb[k + 1], f, gam, sp.Kinv, P.ldq[k], sp.T, P.ldt[k],
+                     sp.dyn, sp.rho, sp.beta};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_bwd_small<<<1, 256, sizeof(double) * (P.capn[k] + P.qmax[k] + 4), s>>>(ba));
+    // v_k = gam_x - Y' rho
+    if ((e = st_gemv_cols(h, d, sp.Y, P.ldy[k], P.qmax[k], nn, sp.rho, gam, -1.0, sp.v))) return e;
+  }
+  {
+    StagePtr s0 = stage_ptr(d, 0);
+    const int n0 = P.nk[0];
+    if (P.fixed_x0)
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_x0_fixed<<<nblk(std::max(n0, P.cap[0])), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, v.r2, S,
+                                                                                         s0.eta, P.cap[0]));
+    else
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_x0_free<<<1, 256, 0, s>>>(n0, P.cap[0], P.q0max, M + P.oK0, P.ldq0, s0.dyn, s0.v,
+                                                                s0.beta, S, s0.eta));
+  }
+  for (int k = 0; k < K; k++) {
+    StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
+    const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
+    double *xk = S + P.nmk[k];
+    stg::FwdSmall fa{nn, mm, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], sp.Rm, P.ldy[k], xk, sp.rho, sp.T, P.ldt[k],
+                     sp.dyn, sp.eta, d.eq_rows.p + P.eq_ptr[k], xk + nn, v.dy, sn.eta, P.cap[k + 1]};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_fwd_small<<<1, 256, sizeof(double) * (P.capn[k] + P.qmax[k] + 4), s>>>(fa));
+    // x+ = F s + f ; p = V+ x+ + v+ + B+' eta+
+    if ((e = st_gemv_rows(h, stg::GemvRows{sp.F, P.ldf[k], np, nz, xk, v.r2 + P.nks[k], nullptr, 0, nullptr, nullptr, S + P.nmk[k + 1], 1.0})))
+      return e;
+    if ((e = st_gemv_rows(h, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, S + P.nmk[k + 1], sn.v, P.cap[k + 1] > 0 ? sn.BT : nullptr,
+                                           P.ldb[k + 1], sn.dyn + 1, sn.eta, v.dy + P.nks[k], 1.0})))
+      return e;
+  }
+  {
+    StagePtr sK = stage_ptr(d, K), s0 = stage_ptr(d, 0);
+    const int eK = P.eq_ptr[K + 1] - P.eq_ptr[K];
+    if (eK) KLAUNCH(h, KC_ST_VEC, stg::k_st_y_last<<<nblk(eK), 256, 0, s>>>(eK, d.eq_rows.p + P.eq_ptr[K], sK.eta, v.dy));
+    if (P.fixed_x0) {
+      const int n0 = P.nk[0];
+      if ((e = st_gemv_rows(h, stg::GemvRows{s0.V, P.ldv[0], n0, n0, S, s0.v, nullptr, 0, nullptr, nullptr, tmp, 1.0}))) return e;
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_y_fixed<<<nblk(n0), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, tmp, v.dy));
+    }
+  }
+  KLAUNCH(h, KC_VECTOR, stg::k_st_negate<<<nblk(n), 256, 0, s>>>(n, S, v.dx));
+  if (m > 0)
+    KLAUNCH(h, KC_VECTOR, k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, h->wt.p, h->tz.p,
+                                                             v.r3, v.dz, v.dw));
+  HIPCHK(hipGetLastError());
+  return 0;
+}

@@ -1,0 +1,292 @@
+// Symbolic phase of the STAGED engine (see staged_plan.hpp).
+#include "staged_plan.hpp"
+
+#include <algorithm>
+#include <cstdint>
+#include <numeric>
+
+namespace kktdev {
+
+namespace {
+const int CARRY_MAX = 48;
+inline int up8(long long x) { return (int)((x + 7) / 8 * 8); }
+inline long long up16(long long x) { return (x + 15) / 16 * 16; }
+}  // namespace
+
+int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const int *Ap, const int *Ai,
+                    const int *Cp, const int *Ci) {
+  n = n_, m = m_;
+  nq = n ? Qp[n] : 0, nc = m ? Cp[m] : 0;
+  const int arows = me_;  // rows of the A that was handed over
+  na = arows ? Ap[arows] : 0;
+  nk.clear(), mk.clear(), nmk.clear(), nks.clear();
+
+  // ------------------------------------------------------------------ stage sizes
+  if (!given_nx.empty()) {
+    K = (int)given_nx.size() - 1;
+    if (K < 1 || (int)given_nu.size() != K) return 6;
+    nk = given_nx;
+    mk = given_nu;
+    nmk.assign(K + 1, 0);
+    for (int k = 0; k < K; k++) nmk[k + 1] = nmk[k] + nk[k] + mk[k];
+    if (nmk[K] + nk[K] != n) return 6;
+    nks.assign(K + 1, 0);
+    for (int k = 0; k < K; k++) nks[k + 1] = nks[k] + nk[k + 1];
+    ndyn = nks[K];
+    if (!dense_dyn) {
+      // the rows must be the staircase these sizes describe
+      if (arows < ndyn) return 6;
+      for (int k = 0; k < K; k++)
+        for (int i = nks[k]; i < nks[k + 1]; i++) {
+          if (Ap[i + 1] - Ap[i] < 1 || Ai[Ap[i + 1] - 1] != nmk[k + 1] + (i - nks[k])) return 6;
+        }
+    }
+  } else {
+    // the -1.0 staircase (values are checked when they arrive: chk_idx): a new stage starts
+    // where the last column jumps by more than one or the row reaches back into the block of
+    // states the current stage produces
+    if (dense_dyn || arows == 0) return 6;
+    nk.push_back(0), nmk.push_back(0);
+    int cur = 0, last = -1;
+    ndyn = -1;
+    for (int i = 0; i < arows; i++) {
+      const int len = Ap[i + 1] - Ap[i];
+      if (len <= 1) return 6;
+      const int icl = Ai[Ap[i + 1] - 1], icl1 = Ai[Ap[i + 1] - 2];
+      if (icl <= last) return 6;
+      if (icl - last > 1 || icl - icl1 < cur) {
+        if (nk.size() > 1) nk.back() = cur;
+        nk.push_back(0), nmk.push_back(icl);
+        cur = 1;
+      } else
+        cur++;
+      last = icl;
+      if (icl == n - 1) {
+        nk.back() = cur;
+        ndyn = i + 1;
+        break;
+      }
+    }
+    if (ndyn < 0 || nk.size() < 2) return 6;
+    K = (int)nk.size() - 1;
+    nk[0] = std::min(nk[1], nmk[1]);  // hqp/Hqp_IpLQDOCP.C:265
+    mk.assign(K, 0);
+    for (int k = 0; k < K; k++) {
+      mk[k] = nmk[k + 1] - nmk[k] - nk[k];
+      if (mk[k] < 0) return 6;
+    }
+    nks.assign(K + 1, 0);
+    for (int k = 0; k < K; k++) nks[k + 1] = nks[k] + nk[k + 1];
+    if (nks[K] != ndyn) return 6;
+  }
+  me = dense_dyn ? ndyn + arows : arows;
+  std::vector<int> stage_of(n);
+  for (int k = 0; k <= K; k++) {
+    const int c1 = k < K ? nmk[k + 1] : n;
+    for (int c = nmk[k]; c < c1; c++) stage_of[c] = k;
+  }
+  auto lcol = [&](int c) { return c - nmk[stage_of[c]]; };
+
+  // ------------------------------------------------------------------ rows per stage
+  // dynamics rows stay inside their stage (Check_Structure, hqp/Hqp_IpLQDOCP.C:304-313)
+  if (!dense_dyn)
+    for (int k = 0; k < K; k++)
+      for (int i = nks[k]; i < nks[k + 1]; i++) {
+        const int p0 = Ap[i], p1 = Ap[i + 1];
+        if (p1 - p0 < 2 || stage_of[Ai[p0]] != k || stage_of[Ai[p1 - 2]] != k || stage_of[Ai[p1 - 1]] != k + 1)
+          return 6;
+      }
+  const int row0 = dense_dyn ? 0 : ndyn;  // first non-dynamics row of the A handed over
+  std::vector<std::vector<int>> eq(K + 1);
+  for (int i = row0; i < arows; i++) {
+    const int p0 = Ap[i], p1 = Ap[i + 1];
+    if (p1 == p0) return 6;
+    const int k = stage_of[Ai[p0]];
+    if (stage_of[Ai[p1 - 1]] != k) return 6;
+    eq[k].push_back(i);
+  }
+  for (int i = 0; i < m; i++) {
+    const int p0 = Cp[i], p1 = Cp[i + 1];
+    if (p1 == p0) return 6;
+    if (stage_of[Ci[p0]] != stage_of[Ci[p1 - 1]]) return 6;
+  }
+  for (int i = 0; i < n; i++) {
+    const int p0 = Qp[i], p1 = Qp[i + 1];
+    if (p1 > p0 && (stage_of[Qi[p0]] != stage_of[i] || stage_of[Qi[p1 - 1]] != stage_of[i])) return 6;
+  }
+  // fixed initial state: a singleton row for every component of x_0 (hqp/Hqp_IpLQDOCP.C:343-351)
+  {
+    std::vector<int> frow(nk[0], -1), fsrc(nk[0], -1);
+    int found = 0;
+    for (int i : eq[0])
+      if (Ap[i + 1] - Ap[i] == 1 && Ai[Ap[i]] < nk[0] && frow[Ai[Ap[i]]] < 0)
+        frow[Ai[Ap[i]]] = i, fsrc[Ai[Ap[i]]] = Ap[i], found++;
+    fixed_x0 = nk[0] > 0 && found == nk[0];
+    fix_rows.clear(), fix_src.clear();
+    if (fixed_x0) {
+      std::vector<char> isfix(arows, 0);
+      for (int j = 0; j < nk[0]; j++) isfix[frow[j]] = 1;
+      std::vector<int> rest;
+      for (int i : eq[0])
+        if (!isfix[i]) rest.push_back(i);
+      eq[0].swap(rest);
+      fix_rows = frow;
+      fix_src.resize(nk[0]);
+      for (int j = 0; j < nk[0]; j++) fix_src[j] = nq + fsrc[j];
+    }
+  }
+  const int rshift = dense_dyn ? ndyn : 0;  // row index in the full dy vector
+  eq_ptr.assign(K + 2, 0);
+  eq_rows.clear();
+  for (int k = 0; k <= K; k++) {
+    for (int i : eq[k]) eq_rows.push_back(i + rshift);
+    eq_ptr[k + 1] = (int)eq_rows.size();
+  }
+  for (int &r : fix_rows) r += rshift;
+
+  // ------------------------------------------------------------------ capacities
+  cap.assign(K + 1, 0), capn.assign(K + 1, 0), qmax.assign(K + 1, 0);
+  cap[K] = capn[K] = (int)eq[K].size();
+  for (int k = K - 1; k >= 0; k--) {
+    capn[k] = (int)eq[k].size() + cap[k + 1];
+    // structural bound (nothing consumed), cut at what the kernels are built for: a stage that
+    // would carry more than CARRY_MAX rows reports HQPKKT_E_SIZES at run time
+    cap[k] = std::min(capn[k], CARRY_MAX);
+    qmax[k] = mk[k] + std::min(mk[k], capn[k]);
+  }
+  q0max = fixed_x0 ? 0 : nk[0] + cap[0];
+  // what the one-workgroup kernels hold in LDS (~150 KB)
+  for (int k = 0; k < K; k++) {
+    const long long q = qmax[k];
+    const long long a = (long long)capn[k] * (mk[k] + capn[k]) * 8 + (capn[k] + mk[k] + 2) * 4LL + capn[k] * 8LL;
+    const long long b = q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4;
+    if (std::max(a, b) + 256 > 150 * 1024) return 1;
+  }
+  if (!fixed_x0) {
+    const long long q = q0max;
+    if (q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4 + 256 > 150 * 1024) return 1;
+  }
+
+  // ------------------------------------------------------------------ storage
+  ldf.assign(K + 1, 8), ldv.assign(K + 1, 8), ldy.assign(K + 1, 8), ldn.assign(K + 1, 8);
+  ldb.assign(K + 1, 8), ldq.assign(K + 1, 8), ldt.assign(K + 1, 8), ldg.assign(K + 1, 8);
+  oF.assign(K + 1, 0), oV.assign(K + 1, 0);
+  oY.assign(K + 1, 0), oR.assign(K + 1, 0), oK.assign(K + 1, 0), oN.assign(K + 1, 0);
+  oBT.assign(K + 1, 0), oT.assign(K + 1, 0), oVec.assign(K + 1, 0);
+  long long fo = 0, vo = 0, mo = 0;
+  long long wmax = 0, gmax = 0;
+  int nzmax = 0, nmax = 0;
+  for (int k = 0; k <= K; k++) {
+    const int nz = k < K ? nk[k] + mk[k] : nk[k];
+    nzmax = std::max(nzmax, nz), nmax = std::max(nmax, nk[k]);
+    ldv[k] = up8(nk[k]);
+    oV[k] = vo, vo += up16((long long)nk[k] * ldv[k]);
+    ldb[k] = up8(std::max(cap[k], 1));
+    oBT[k] = mo, mo += up16((long long)nk[k] * ldb[k]);
+    ldn[k] = up8(std::max(nz, 1));
+    oN[k] = mo, mo += up16((long long)std::max(capn[k], 1) * ldn[k]);
+    oVec[k] = mo, mo += up16((long long)nk[k] + 2LL * std::max(cap[k], 1) + std::max(qmax[k], 1) + 8);
+    if (k < K) {
+      ldf[k] = up8(nz), ldg[k] = up8(nz);
+      oF[k] = fo, fo += up16((long long)nk[k + 1] * ldf[k]);
+      ldy[k] = up8(std::max(nk[k], 1)), ldq[k] = up8(std::max(qmax[k], 1)), ldt[k] = up8(std::max(mk[k], 1));
+      oY[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldy[k]);
+      oR[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldy[k]);
+      oK[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldq[k]);
+      oT[k] = mo, mo += up16((long long)std::max(cap[k], 1) * ldt[k]);
+      wmax = std::max(wmax, (long long)nk[k + 1] * ldf[k]);
+      gmax = std::max(gmax, (long long)nz * ldg[k]);
+    }
+  }
+  oW = mo, mo += up16(wmax);
+  oG = mo, mo += up16(gmax);
+  ldq0 = up8(std::max(q0max, 1));
+  oK0 = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
+  oGam = mo, mo += up16(nzmax + 8);
+  oTT = mo, mo += up16(nmax + 8);
+  oTmp = mo, mo += up16(nmax + 8);
+  part_chunks = std::max(1, std::min(64, nmax / 64));
+  oPart = mo, mo += up16((long long)part_chunks * (nzmax + 8));
+  oS = mo, mo += up16(n + 8);
+  oQv = mo, mo += up16(n + 8);
+  f_elems = fo, v_elems = vo, misc_elems = mo;
+  dyn_off.assign(K + 1, 0);
+  dyn_ints = 0;
+  for (int k = 0; k <= K; k++) dyn_off[k] = dyn_ints, dyn_ints += 2 + 2 * std::max(capn[k], 1);
+
+  // ------------------------------------------------------------------ scatter of A
+  a_dst.assign(na, -1);
+  chk_idx.clear(), chk_kind.clear();
+  if (!dense_dyn)
+    for (int k = 0; k < K; k++)
+      for (int i = nks[k]; i < nks[k + 1]; i++) {
+        const int li = i - nks[k];
+        for (int p = Ap[i]; p < Ap[i + 1] - 1; p++)
+          a_dst[p] = oF[k] + (long long)li * ldf[k] + (Ai[p] - nmk[k]);
+        chk_idx.push_back(nq + Ap[i + 1] - 1), chk_kind.push_back(0);
+      }
+  for (int k = 0; k <= K; k++)
+    for (int li = 0; li < (int)eq[k].size(); li++) {
+      const int i = eq[k][li];
+      for (int p = Ap[i]; p < Ap[i + 1]; p++) a_dst[p] = -(oN[k] + (long long)li * ldn[k] + lcol(Ai[p]) + 2);
+    }
+  for (int s : fix_src) chk_idx.push_back(s), chk_kind.push_back(1);
+
+  // ------------------------------------------------------------------ H term lists
+  {
+    struct Raw {
+      long long key;  // stage << 44 | li * ld + lj
+      Term t;
+    };
+    std::vector<Raw> raw;
+    raw.reserve((size_t)nq * 2 + (size_t)nc * 2);
+    const int ONE = nq + na + nc, WONE = m;
+    auto ldof = [&](int k) { return k < K ? ldg[k] : ldv[K]; };
+    auto push = [&](int k, int li, int lj, Term t) {
+      raw.push_back({((long long)k << 44) | ((long long)li * ldof(k) + lj), t});
+    };
+    for (int i = 0; i < n; i++)
+      for (int p = Qp[i]; p < Qp[i + 1]; p++) {
+        const int j = Qi[p];
+        if (j < i) continue;  // only col >= row is read (meschach/addon2_hqp.c:1078-1086)
+        const int k = stage_of[i];
+        push(k, lcol(i), lcol(j), Term{p, ONE, WONE});
+        if (j != i) push(k, lcol(j), lcol(i), Term{p, ONE, WONE});
+      }
+    for (int r = 0; r < m; r++) {
+      const int k = stage_of[Ci[Cp[r]]];
+      for (int pa = Cp[r]; pa < Cp[r + 1]; pa++)
+        for (int pb = Cp[r]; pb < Cp[r + 1]; pb++)
+          push(k, lcol(Ci[pa]), lcol(Ci[pb]), Term{nq + na + pa, nq + na + pb, r});
+    }
+    std::stable_sort(raw.begin(), raw.end(), [](const Raw &a, const Raw &b) { return a.key < b.key; });
+    h_ptr.assign(K + 2, 0), h_tptr.assign(1, 0), h_dst.clear(), h_terms.clear();
+    h_terms.reserve(raw.size());
+    long long prev = -1;
+    for (const Raw &e : raw) {
+      if (e.key != prev) {
+        h_dst.push_back(e.key & ((1LL << 44) - 1));
+        h_tptr.push_back(h_tptr.back());
+        h_ptr[(int)(e.key >> 44) + 1]++;
+        prev = e.key;
+      }
+      h_terms.push_back(e.t);
+      h_tptr.back()++;
+    }
+    for (int k = 0; k <= K; k++) h_ptr[k + 1] += h_ptr[k];
+  }
+
+  // ------------------------------------------------------------------ work counts
+  flops_factor = 0, bytes_step = 0;
+  for (int k = 0; k < K; k++) {
+    const long long nn = nk[k], mm = mk[k], np = nk[k + 1], nz = nn + mm, q = qmax[k];
+    flops_factor += 2 * np * np * nz;       // W = V+ F
+    flops_factor += np * nz * nz;           // G = F' W, lower half
+    flops_factor += 2 * (long long)cap[k + 1] * np * nz;  // carried rows
+    flops_factor += 2 * q * q * nn + q * nn * nn;         // Rm, V update (lower half)
+    bytes_step += 8 * (2 * np * np + 2 * np * nz + 2 * q * nn);
+  }
+  return 0;
+}
+
+}  // namespace kktdev

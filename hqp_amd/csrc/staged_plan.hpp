@@ -1,0 +1,62 @@
+// Host-side symbolic phase of the STAGED engine: stage dimensions from the staircase of
+// A (semantics of Hqp_IpLQDOCP::Get_Dim / Get_Constr_Dim / Check_Structure,
+// hqp/Hqp_IpLQDOCP.C:201-287, 368-407, 298-354), static capacities of the carried
+// constraint rows, storage plan of the dense stage blocks, term lists of the reduced
+// Hessian H = Q + C'(Z/W)C and the scatter maps of the CSR values.  Integer work only.
+#pragma once
+#include <vector>
+
+namespace kktdev {
+
+struct StagedPlan {
+  int n = 0, me = 0, m = 0, K = 0;
+  int nq = 0, na = 0, nc = 0;
+  std::vector<int> nk, mk, nmk;  // states (K+1), controls (K), first column of a stage (K+1)
+  std::vector<int> nks;          // first dynamics row of stage k (K+1 entries, nks[K] = ndyn)
+  int ndyn = 0;
+  std::vector<int> eq_ptr, eq_rows;  // own equality rows per stage (QP row indices), K+2 / total
+  bool fixed_x0 = false;
+  std::vector<int> fix_rows, fix_src;  // per x_0 component: its row of A and the index of its value in vals
+  bool dense_dyn = false;  // dynamics handed over as dense blocks: A holds the other equalities only
+
+  // static bounds: cap[k] carried rows leaving stage k, capn[k] rows of N_k, qmax[k] order of K_k
+  std::vector<int> cap, capn, qmax;
+  int q0max = 0, ldq0 = 8;  // free initial state: order of [V_0 B_0'; B_0 0]
+
+  // dense storage (element offsets; leading dimensions are multiples of 8)
+  std::vector<int> ldf, ldv, ldy, ldn, ldb, ldq, ldt, ldg;
+  std::vector<long long> oF, oV;                      // F arena, V arena
+  std::vector<long long> oY, oR, oK, oN, oBT, oT;     // misc arena
+  std::vector<long long> oVec;                        // per stage: v(n) beta(cap) rho(qmax) eta(cap)
+  long long oW = 0, oG = 0, oK0 = 0, oGam = 0, oTT = 0, oPart = 0, oS = 0, oQv = 0, oTmp = 0;
+  long long f_elems = 0, v_elems = 0, misc_elems = 0;
+  int part_chunks = 1;
+  std::vector<int> dyn_off;  // int arena: per stage [r, nl, R(capn), L(capn)]
+  int dyn_ints = 0;
+
+  // H term lists: entries of stage k are h_ptr[k] .. h_ptr[k+1]; dst = li * ld + lj inside the
+  // stage's dense block (ld = ldg[k], last stage: ldv[K])
+  struct Term {
+    int s1, s2, wi;
+  };
+  std::vector<int> h_ptr, h_tptr;
+  std::vector<long long> h_dst;
+  std::vector<Term> h_terms;
+
+  // scatter of the A values: >= 0 offset into the F arena, <= -2: -(offset into misc + 2), -1: none
+  std::vector<long long> a_dst;
+  std::vector<int> chk_idx, chk_kind;  // values to check: kind 0 must be -1.0, kind 1 must be non-zero
+
+  long long flops_factor = 0;  // as implemented (dense products of the recursion)
+  long long bytes_step = 0;    // dense bytes one step streams
+
+  // explicit stage sizes (hqpkkt_set_stages): K, nx[K+1], nu[K]; empty: detect from A
+  std::vector<int> given_nx, given_nu;
+
+  // returns 0, or a HQPKKT_E_* code: 6 the pattern is not a staircase / rows leave their stage,
+  // 1 a stage exceeds what the one-workgroup kernels hold
+  int run(int n, int me, int m, const int *Qp, const int *Qi, const int *Ap, const int *Ai, const int *Cp,
+          const int *Ci);
+};
+
+}  // namespace kktdev

@@ -318,8 +318,35 @@ class Hqp_IpRedSpBKP(Hqp_IpMatrix):
 
 
 class Hqp_IpLQDOCP(Hqp_IpMatrix):
-    """Stand-in for the multistage plugin hqp/Hqp_IpLQDOCP.C: same KKT system, solved
-    by the full-system engine (the band ordering carries the stage structure)."""
+    """The multistage plugin hqp/Hqp_IpLQDOCP.C: stage structure found from the staircase of
+    A (Get_Dim, :201-287), dense per-stage blocks, the extended Riccati recursion as fp64
+    MFMA products (HQPKKT_MODE_STAGED).  ``set_stages(nx, nu)`` before init() gives the stage
+    sizes explicitly."""
+    _mode = _lib.MODE_STAGED
+    _name = "LQDOCP"
+
+    def set_stages(self, nx, nu):
+        nx, nu = _i32(nx), _i32(nu)
+        _check(self._L.hqpkkt_set_stages(self._h, len(nu), C.c_void_p(nx.ctypes.data),
+                                         C.c_void_p(nu.ctypes.data) if nu.size else None), "set_stages")
+
+    def stage_structure(self):
+        names = {"nk": 20, "mk": 21, "nmk": 22, "eq_ptr": 23, "eq_rows": 24, "fix_rows": 25, "cap": 26}
+        return {nm: self.debug(i) for nm, i in names.items()}
+
+    def stage_ranks(self):
+        """(rank, carried rows) per stage of the last factorisation (tests)."""
+        K1 = len(self.debug(20))
+        out = np.zeros(2 * K1, dtype=np.int32)
+        _check(self._L.hqpkkt_debug_stage_ranks(self._h, C.c_void_p(out.ctypes.data), out.size), "stage_ranks")
+        return out.reshape(K1, 2)
+
+
+class Hqp_IpLQDOCPFull(Hqp_IpMatrix):
+    """The same KKT system under the plugin name LQDOCP solved by the full-system engine
+    (the band ordering carries the stage structure): the comparison partner of the STAGED
+    engine, and what the reference-side shim falls back to for QPs whose stages the STAGED
+    kernels do not hold."""
     _mode = _lib.MODE_FULL
     _name = "LQDOCP"
 
@@ -327,6 +354,15 @@ class Hqp_IpLQDOCP(Hqp_IpMatrix):
 IpSpBKP = Hqp_IpSpBKP
 IpRedSpBKP = Hqp_IpRedSpBKP
 IpLQDOCP = Hqp_IpLQDOCP
+IpLQDOCPFull = Hqp_IpLQDOCPFull
+
+
+def bench_dgemm(M, N, K, lower=False, mirror=False, reps=5, device=0):
+    """(ms per launch, TFLOP/s, max relative error) of the STAGED engine's fp64 MFMA product."""
+    ms, err = C.c_double(), C.c_double()
+    _check(_lib.lib().hqpkkt_debug_dgemm(device, M, N, K, int(lower), int(mirror), reps, C.byref(ms), C.byref(err)), "debug_dgemm")
+    flops = (1.0 if lower else 2.0) * M * N * K
+    return ms.value, flops / (ms.value * 1e-3) / 1e12, err.value
 
 
 def selftest_mfma(device=0):

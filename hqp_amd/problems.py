@@ -112,7 +112,8 @@ def did_like_qp(K, qx=1e-4):
     return Program(n, me, m, Q, A, C, c=np.zeros(n), b=b, d=np.full(m, 0.01))
 
 
-def lq_docp(K, nx, nu, seed=3, density=1.0):
+def lq_docp(K, nx, nu, seed=3, density=1.0, x0_fixed=True, final_eq=0, path_eq=0, path_eq_every=1,
+            x_bounds=0):
     """Multistage LQ optimal-control QP (config 4 of BASELINE.json at a chosen size) in
     the layout Hqp_Docp::setup_qp produces (hqp/Hqp_Docp.C:585-755) and
     Hqp_IpLQDOCP::Get_Dim expects (hqp/Hqp_IpLQDOCP.C:201-287):
@@ -120,7 +121,14 @@ def lq_docp(K, nx, nu, seed=3, density=1.0):
     fx x_k + fu u_k - x_{k+1} (the -1.0 is the last entry of each row), then nx
     initial-state equalities; C = box bounds on every u (2 K nu rows);
     Q = block diagonal (I + low rank on x_k, 0.1 I on u_k), upper stored.
-    fx is a dense random matrix scaled to spectral radius ~0.9, fu dense random."""
+    fx is a dense random matrix scaled to spectral radius ~0.9, fu dense random.
+    Options (the equality rows follow the dynamics rows, as Hqp_Docp::setup_qp puts its
+    variable / constraint equalities, hqp/Hqp_Docp.C:680-743): ``x0_fixed`` the nx rows
+    x_0 = const; ``final_eq`` rows fixing the first components of x_K (they cannot be
+    eliminated by a control of their own stage: Hqp_IpLQDOCP carries them back through the
+    stages, hqp/Hqp_IpLQDOCP.C:1829-1846); ``path_eq`` random equality rows on (x_k, u_k)
+    of every ``path_eq_every``-th stage; ``x_bounds`` upper bounds on the first components
+    of every x_k, k >= 1."""
     rng = np.random.default_rng(seed)
     nz = nx + nu
     n = K * nz + nx
@@ -151,18 +159,39 @@ def lq_docp(K, nx, nu, seed=3, density=1.0):
         rr = np.repeat(r0 + rows, nu)
         ar.append(rr), ac.append(ui(k) + np.tile(np.arange(nu), nx)), av.append(fu.ravel())
         ar.append(r0 + rows), ac.append(xi(k + 1) + rows), av.append(np.full(nx, -1.0))
-    ar.append(K * nx + rows), ac.append(xi(0) + rows), av.append(np.ones(nx))
+    me = K * nx
+    bvals = [np.zeros(K * nx)]
+    if x0_fixed:
+        ar.append(me + rows), ac.append(xi(0) + rows), av.append(np.ones(nx))
+        bvals.append(-rng.uniform(-1, 1, nx))  # x_0 fixed
+        me += nx
+    if path_eq:
+        for k in range(0, K, path_eq_every):
+            for _ in range(path_eq):
+                cols = np.arange(xi(k), xi(k) + nz)
+                ar.append(np.full(nz, me)), ac.append(cols), av.append(rng.uniform(-1, 1, nz))
+                bvals.append(rng.uniform(-0.1, 0.1, 1))
+                me += 1
+    if final_eq:
+        fr = np.arange(final_eq)
+        ar.append(me + fr), ac.append(xi(K) + fr), av.append(np.ones(final_eq))
+        bvals.append(rng.uniform(-0.1, 0.1, final_eq))
+        me += final_eq
     ar, ac, av = np.concatenate(ar), np.concatenate(ac), np.concatenate(av)
     keep = av != 0.0
-    me = K * nx + nx
     A = _csr(ar[keep], ac[keep], av[keep], me)
-    b = np.zeros(me)
-    b[K * nx:] = -rng.uniform(-1, 1, nx)  # x_0 fixed
+    b = np.concatenate(bvals)
     # C: -1 <= u <= 1
     m = 2 * K * nu
     cr = np.arange(m)
     cc = np.concatenate([[ui(k) + j for j in range(nu)] * 2 for k in range(K)]) if K else np.zeros(0, int)
     cv = np.concatenate([np.concatenate([np.ones(nu), -np.ones(nu)]) for _ in range(K)]) if K else np.zeros(0)
+    if x_bounds:
+        xb = np.concatenate([xi(k) + np.arange(x_bounds) for k in range(1, K + 1)])
+        cr = np.concatenate([cr, m + np.arange(xb.size)])
+        cc = np.concatenate([cc, xb])
+        cv = np.concatenate([cv, -np.ones(xb.size)])
+        m += xb.size
     C = _csr(cr, cc, cv, m)
     return Program(n, me, m, Q, A, C, c=rng.uniform(-0.1, 0.1, n), b=b, d=np.ones(m))
 

@@ -45,6 +45,8 @@ extern "C" {
 /* which reference plugin's semantics the handle reproduces */
 #define HQPKKT_MODE_FULL 0    /* Hqp_IpSpBKP    (hqp/Hqp_IpSpBKP.C:76-218)    */
 #define HQPKKT_MODE_REDUCED 1 /* Hqp_IpRedSpBKP (hqp/Hqp_IpRedSpBKP.C:184-368) */
+#define HQPKKT_MODE_STAGED 2  /* Hqp_IpLQDOCP    (hqp/Hqp_IpLQDOCP.C:693-976): multistage (DOCP)
+                                 structure, dense per-stage blocks, see hqpkkt_set_stages */
 
 /* where the vectors z,w,r1..r4,dx..dw (and Qx,Ax,Cx) live */
 #define HQPKKT_LOC_HOST 0   /* Meschach VEC::ve pointers; copied H2D / D2H per call */
@@ -234,6 +236,33 @@ int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out);
 typedef int (*hqpkkt_exchange_fn)(void *ctx, int op, double *buf, long long slot_elems, int nslots);
 int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, void *ctx);
 
+/* ---- STAGED mode (Hqp_IpLQDOCP, hqp/Hqp_IpLQDOCP.C) ---------------------------------
+ * The QP of a discrete-time optimal control problem as Hqp_Docp::setup_qp lays it out
+ * (hqp/Hqp_Docp.C:585-755): x = [x_0, u_0, x_1, u_1, ..., x_K]; the first rows of A are the
+ * dynamics  fx_k x_k + fu_k u_k - x_{k+1}  (the -1.0 is the last entry of each row), the
+ * other equality rows, all rows of C and all rows of Q stay inside one stage.  The engine
+ * keeps fx, fu and the cost-to-go Hessians as dense blocks and runs the reference's extended
+ * Riccati recursion (ExRiccatiFactorSc / ExRiccatiSolveSc, :1794-2182) as fp64 MFMA matrix
+ * products over them; the equality constraints of a stage are eliminated with the controls
+ * they determine and carried back to the previous stage otherwise (GE_QP's job,
+ * meschach/addon_hqp.c:399-475), a fixed initial state is recognised as in
+ * Check_Structure (:343-351).  hqpkkt_analyze finds the stage sizes from the staircase
+ * of A exactly as Hqp_IpLQDOCP::Get_Dim does (:201-287) unless hqpkkt_set_stages has given
+ * them (K stages, nx[K+1] states, nu[K] controls; K <= 0 returns to the detection);
+ * HQPKKT_E_FORMAT: the pattern / the values are not such a staircase (the reference
+ * asserts), HQPKKT_E_SIZES: a stage has more controls or carries more constraint rows
+ * than the one-workgroup kernels hold (about 64 controls + 48 carried rows).  mat_sbw is -1. */
+int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu);
+/* tests: rank and number of carried rows per stage (2 ints each, K+1 stages) of the last factor */
+int hqpkkt_debug_stage_ranks(hqpkkt_t *h, int *out, int cap);
+
+/* Micro-benchmark and self-check of the dense fp64 MFMA product the STAGED engine is made of:
+ * C (M x N) = A'B for pseudo-random k-major operands (K x M, K x N), `reps` timed launches
+ * (lower: only the tiles of the lower triangle, mirror: the upper one written from them).
+ * *ms: average device time of a launch; *max_err: largest |C_ij - exact| / sum_k |a_ki b_kj|
+ * over 4096 sampled entries. */
+int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, int reps, double *ms, double *max_err);
+
 /* Per-kernel-class device timing for bench.py's roofline line: with on != 0
  * every kernel launch is bracketed by HIP events on the handle's stream and the
  * elapsed times are summed per class (hqpkkt_profile_class_name(c), c = 0..) at
@@ -304,7 +333,9 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
  * 2 node_npiv, 3 node_nborder, 4 node_parent, 5 node_level (n_supernodes
  * each), 6 border_ptr (n_supernodes+1), 7 border_idx (border_ptr[last]),
  * 8 entry_row, 9 entry_col (elimination indices, nnz_kkt each), 10 node_owner
- * (rank per supernode, -1 = replicated top), 11 exchanged subtree roots.
+ * (rank per supernode, -1 = replicated top), 11 exchanged subtree roots; STAGED: 20 states
+ * per stage, 21 controls, 22 first column, 23 / 24 own equality rows (ptr / rows), 25 rows
+ * that fix x_0, 26 capacity of carried rows.
  * *len receives the element count; out may be NULL to query it. */
 int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len);
 

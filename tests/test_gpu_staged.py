@@ -1,0 +1,219 @@
+"""GPU parity tests of the STAGED engine (HQPKKT_MODE_STAGED, plugin name LQDOCP) through
+the C ABI: against the reference's own Hqp_IpLQDOCP (oracle/_ref, where it travelled),
+against the CPU oracle of the full system, against the numpy model of the recursion and
+against the full-system HIP engine, on multistage QPs with and without stage equalities
+(fixed / free initial state, final-state constraints that are carried back through the
+stages, path equalities, state bounds), and at K = 200 through size-independent properties.
+"""
+import numpy as np
+import pytest
+
+from common import new_d, rel_err
+from hqp_amd import ipmatrix, problems
+
+pytestmark = pytest.mark.gpu
+
+RES_TOL = 1e-10  # north_star: ||KKT residual||inf within 1e-10 of the reference
+SOL_TOL = 1e-8
+
+CASES = {
+    "plain": lambda: problems.lq_docp(10, 6, 2),
+    "final2": lambda: problems.lq_docp(12, 5, 3, final_eq=2),
+    "final5": lambda: problems.lq_docp(12, 5, 3, final_eq=5),
+    "path1": lambda: problems.lq_docp(12, 5, 3, path_eq=1),
+    "path2_final3_xb": lambda: problems.lq_docp(12, 5, 3, path_eq=2, final_eq=3, x_bounds=2),
+    "free_x0": lambda: problems.lq_docp(8, 4, 2, x0_fixed=False),
+    "free_x0_final2": lambda: problems.lq_docp(8, 4, 2, x0_fixed=False, final_eq=2),
+    "did50": lambda: problems.did_like_qp(50),
+    "did400_q1": lambda: problems.did_like_qp(400, qx=1.0),
+    "wide": lambda: problems.lq_docp(6, 70, 9, final_eq=3),
+    "tiles": lambda: problems.lq_docp(3, 150, 20, seed=5),
+}
+
+
+def _solve(M, prog, st):
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    return d, res
+
+
+@pytest.mark.parametrize("case", sorted(CASES))
+def test_staged_against_reference_and_oracle(case):
+    from oracle import oracleapi, refapi
+    prog = CASES[case]()
+    st = problems.ip_state(prog, 3, 1.0)
+    M = ipmatrix.IpLQDOCP()
+    assert M.name() == "LQDOCP"
+    d, res = _solve(M, prog, st)
+    O = oracleapi.OracleIpMatrix("SpBKP")
+    O.init(prog)
+    O.factor(st[0], st[1])
+    osol, ores = O.solve(*st)
+    assert res <= ores + RES_TOL, (res, ores)
+    assert rel_err(d, osol) <= SOL_TOL
+    if refapi.available():
+        L = refapi.RefIpMatrix("LQDOCP")
+        L.init(prog)
+        L.factor(st[0], st[1])
+        lsol, lres = L.solve(*st)
+        assert res <= lres + RES_TOL, (res, lres)
+        assert rel_err(d, lsol) <= SOL_TOL
+
+
+@pytest.mark.parametrize("case", ["final5", "path2_final3_xb", "free_x0_final2", "did50"])
+def test_staged_step_equals_the_model(case):
+    """One unrefined step() against the numpy model of the recursion (same algorithm: the
+    results agree to rounding), and the same stage structure / ranks."""
+    from model_staged import StagedModel
+    prog = CASES[case]()
+    st = problems.ip_state(prog, 4, 1.0)
+    M = ipmatrix.IpLQDOCP()
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    M.step(prog, *st, *d)
+    R = StagedModel(prog)
+    R.factor(st[0], st[1])
+    md = R.step(*st[2:])
+    S = M.stage_structure()
+    assert list(S["nk"]) == R.S["nk"] and list(S["mk"]) == R.S["mk"]
+    ranks = M.stage_ranks()
+    for k in range(R.S["K"]):
+        assert ranks[k, 0] == len(R.st[k]["R"]) and ranks[k, 1] == len(R.st[k]["L"]), (k, ranks[k])
+    assert rel_err(d, md) <= 1e-9
+
+
+def test_staged_equals_full_engine_and_update():
+    """Same solution as the full-system engine; update() with new values on the same pattern."""
+    prog = problems.lq_docp(20, 12, 4, final_eq=2, x_bounds=3)
+    st = problems.ip_state(prog, 7, 2.0)
+    S, F = ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()
+    ds, rs = _solve(S, prog, st)
+    df, rf = _solve(F, prog, st)
+    assert rs <= RES_TOL and rf <= RES_TOL
+    assert rel_err(ds, df) <= SOL_TOL
+    prog2 = problems.lq_docp(20, 12, 4, final_eq=2, x_bounds=3, seed=9)
+    S.update(prog2), F.update(prog2)
+    for M in (S, F):
+        M.factor(prog2, st[0], st[1])
+    ds, df = new_d(prog), new_d(prog)
+    rs = S.solve(prog2, *st, *ds)
+    rf = F.solve(prog2, *st, *df)
+    assert rs <= RES_TOL and rel_err(ds, df) <= SOL_TOL
+
+
+def test_staged_rejects_what_is_not_a_staircase():
+    prog = problems.banded_qp(200, 6, 1)
+    M = ipmatrix.IpLQDOCP()
+    with pytest.raises(ipmatrix.KktError) as e:
+        M.init(prog)
+    assert e.value.code == 6  # E_FORMAT; the reference asserts (hqp/Hqp_IpLQDOCP.C:700)
+    # the right pattern with a value that is not -1.0
+    prog = problems.lq_docp(5, 4, 2)
+    p, i, x = prog.A
+    x = x.copy()
+    x[p[1] - 1] = -2.0
+    bad = problems.Program(prog.n, prog.me, prog.m, prog.Q, (p, i, x), prog.C)
+    with pytest.raises(ipmatrix.KktError) as e:
+        M.init(bad)
+    assert e.value.code == 6
+
+
+def test_staged_explicit_stage_sizes():
+    K, nx, nu = 7, 5, 2
+    prog = problems.lq_docp(K, nx, nu, final_eq=1)
+    st = problems.ip_state(prog, 2, 1.0)
+    A, B = ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCP()
+    B.set_stages([nx] * (K + 1), [nu] * K)
+    da, ra = _solve(A, prog, st)
+    db, rb = _solve(B, prog, st)
+    assert ra <= RES_TOL and rb <= RES_TOL and rel_err(da, db) <= 1e-12
+
+
+def test_staged_singular_stage_is_e_sing():
+    """A control without cost, without bounds and without influence on the state: K_k has an
+    exactly zero row, the reference's dense BKPsolve raises E_SING there
+    (meschach/bkpfacto.c:230-314)."""
+    K, nx, nu = 4, 3, 2
+    prog = problems.lq_docp(K, nx, nu)
+    nz = nx + nu
+    dead = {k * nz + nx + 1 for k in range(K)}  # second control of every stage
+    qp, qi, qx = prog.Q
+    qx = qx.copy()
+    for r in dead:
+        qx[qp[r]:qp[r + 1]] = 0.0
+    ap, ai, ax = prog.A
+    ax = ax.copy()
+    ax[np.isin(ai, list(dead))] = 0.0
+    empty = (np.zeros(1, np.int32), np.zeros(0, np.int32), np.zeros(0))
+    noc = problems.Program(prog.n, prog.me, 0, (qp, qi, qx), (ap, ai, ax), empty)
+    st = problems.ip_state(noc, 1)
+    M = ipmatrix.IpLQDOCP()
+    M.init(noc)
+    with pytest.raises(ipmatrix.SingularError):
+        M.factor(noc, st[0], st[1])
+
+
+@pytest.mark.parametrize("nx", [50, 100, 200, 400])
+def test_staged_k200(nx):
+    """BASELINE configs[3] structure at K = 200 (the reference's Hqp_IpLQDOCP needs 0.03 .. 9 s
+    per factorisation at these sizes): parity with the reference where it
+    travelled and the case is small, with the full-system engine up to nx = 200, and through
+    size-independent properties (residual of the refined solve, linearity in the right-hand
+    side, reproducibility of a second factorisation) always."""
+    from oracle import refapi
+    K, nu = 200, 10
+    prog = problems.lq_docp(K, nx, nu, seed=11)
+    st = problems.ip_state(prog, 5, 1.0)
+    M = ipmatrix.IpLQDOCP()
+    d, res = _solve(M, prog, st)
+    assert res <= RES_TOL, res
+    if nx <= 200:
+        F = ipmatrix.IpLQDOCPFull()
+        df, rf = _solve(F, prog, st)
+        assert rel_err(d, df) <= SOL_TOL
+    if nx <= 100 and refapi.available():
+        L = refapi.RefIpMatrix("LQDOCP")
+        L.init(prog)
+        L.factor(st[0], st[1])
+        lsol, lres = L.solve(*st)
+        assert res <= lres + RES_TOL and rel_err(d, lsol) <= SOL_TOL
+    # linearity: solve(2 r) = 2 solve(r)
+    st2 = (st[0], st[1]) + tuple(2.0 * r for r in st[2:])
+    d2 = new_d(prog)
+    M.solve(prog, *st2, *d2)
+    assert rel_err(d2, [2.0 * x for x in d]) <= 1e-8
+    # a second factorisation reproduces the first one bit for bit
+    M.factor(prog, st[0], st[1])
+    d3 = new_d(prog)
+    M.step(prog, *st, *d3)
+    M.factor(prog, st[0], st[1])
+    d4 = new_d(prog)
+    M.step(prog, *st, *d4)
+    assert all(np.array_equal(a, b) for a, b in zip(d3, d4))
+
+
+def test_dgemm_kernel_against_exact_products():
+    """k_dgemm_tn (both tile sizes, ragged edges, lower / mirrored output, K not a multiple
+    of the slab) against exactly accumulated sample entries."""
+    for (M, N, K, lower, mirror) in [(64, 64, 16, 0, 0), (100, 37, 53, 0, 0), (130, 130, 70, 1, 0), (130, 130, 70, 1, 1),
+                                     (640, 520, 300, 0, 0), (700, 700, 129, 1, 1), (513, 1100, 1, 0, 0), (48, 2000, 48, 0, 0)]:
+        ms, tf, err = ipmatrix.bench_dgemm(M, N, K, lower, mirror, reps=1)
+        assert err <= 1e-14, (M, N, K, lower, mirror, err)
+
+
+def test_staged_mehrotra_loop():
+    """The device-resident interior-point loop on top of the STAGED engine: same optimiser as
+    with the reduced full-system engine."""
+    prog = problems.lq_docp(30, 8, 3, final_eq=2)
+    A, B = ipmatrix.IpLQDOCP(), ipmatrix.IpRedSpBKP()
+    out = []
+    for M in (A, B):
+        M.init(prog)
+        x, y, z, w, info = M.mehrotra(prog)
+        assert info["result"] == 0, info
+        out.append((x, info))
+    assert abs(out[0][1]["iters"] - out[1][1]["iters"]) <= 1
+    assert np.abs(out[0][0] - out[1][0]).max() <= 1e-6 * max(1.0, np.abs(out[1][0]).max())
