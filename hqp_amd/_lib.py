@@ -27,6 +27,7 @@ SYMBOLS = [
     "hqpkkt_profile_class_name", "hqpkkt_set_shard", "hqpkkt_debug_read",
     "hqpkkt_default_ip_opts", "hqpkkt_mehrotra", "hqpkkt_franke",
     "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm",
+    "hqpkkt_analyze_staged", "hqpkkt_set_values_staged",
 ]
 
 XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
@@ -126,6 +127,8 @@ def lib():
     L.hqpkkt_franke.argtypes = [vp, C.POINTER(IpOpts)] + [dp] * 7 + [C.POINTER(IpResult)]
     L.hqpkkt_set_stages.argtypes = [vp, C.c_int, vp, vp]
     L.hqpkkt_debug_stage_ranks.argtypes = [vp, vp, C.c_int]
+    L.hqpkkt_analyze_staged.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int] + [vp] * 6
+    L.hqpkkt_set_values_staged.argtypes = [vp, dp, vp, vp, dp, dp]
     L.hqpkkt_debug_dgemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)] * 2
     _lib = L
     return L

@@ -744,20 +744,28 @@ static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
 struct OutPtrs {
   double *dx, *dy, *dz, *dw;
 };
+static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, const double **x2, int *ndyn);
+
 static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *out = nullptr) {
   Analysis &an = h->an;
   hipStream_t s = h->stream;
   const int n = an.n, me = an.me, m = an.m;
   double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
   HIPCHK(hipMemsetAsync(h->bits.p + 1, 0, sizeof(unsigned long long), s));
+  const double *x1 = nullptr, *x2 = nullptr;  // STAGED, dense dynamics: their share of A dx and A'dy
+  int ndyn = 0;
+  if (h->opts.mode == HQPKKT_MODE_STAGED) {
+    int e1 = staged_dense_products(h, v, &x1, &x2, &ndyn);
+    if (e1) return e1;
+  }
   if (h->short_rows)
     KLAUNCH(h, KC_RESIDUAL, k_residual<4><<<std::min(nblk(4LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
-        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
+        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1, x1, x2, ndyn));
   else
     KLAUNCH(h, KC_RESIDUAL, k_residual<16><<<std::min(nblk(16LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
-        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1));
+        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1, x1, x2, ndyn));
   if (out) {
     int e2 = stage_out(h, v, out->dx, out->dy, out->dz, out->dw);
     if (e2) return e2;
@@ -793,6 +801,20 @@ static float elapsed(hipEvent_t a, hipEvent_t b) {
 }
 
 #include "staged_host.hip.h"
+static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, const double **x2, int *ndyn) {
+  StagedDev &d = *h->sd;
+  const kktdev::StagedPlan &P = d.plan;
+  if (!P.dense_dyn) return 0;
+  int nzmax = 1, npmax = 1;
+  for (int k = 0; k < P.K; k++) nzmax = std::max(nzmax, P.nk[k] + P.mk[k]), npmax = std::max(npmax, P.nk[k + 1]);
+  nzmax = std::max(nzmax, P.nk[P.K]);
+  KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_ax<<<dim3(std::min((npmax + 3) / 4, 2048), P.K), 256, 0, h->stream>>>(d.dyn_desc.p, d.F.p, v.dx,
+                                                                                                        d.dyn_x2.p));
+  KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_aty<<<dim3((nzmax + 255) / 256, P.K + 1), 256, 0, h->stream>>>(d.dyn_desc.p, d.F.p, v.dy,
+                                                                                                 d.dyn_x1.p));
+  *x1 = d.dyn_x1.p, *x2 = d.dyn_x2.p, *ndyn = P.ndyn;
+  return 0;
+}
 static void staged_release(StagedDev *sd, bool destroy) {
   if (!sd) return;
   sd->release();
@@ -1200,6 +1222,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
                     const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
   if (!h || !res) return HQPKKT_E_NULL;
   if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
+  if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
   if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
   hqpkkt_ip_opts o;
   if (opts)
@@ -1583,6 +1606,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
                   const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
   if (!h || !res) return HQPKKT_E_NULL;
   if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
+  if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
   if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
   hqpkkt_ip_opts o;
   if (opts)
@@ -1850,6 +1874,47 @@ int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu) {
     if (nu[k] < 0) return HQPKKT_E_RANGE;
   P.given_nx.assign(nx, nx + K + 1), P.given_nu.assign(nu, nu + K);
   return 0;
+}
+
+int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int me_rest, int m, const int *Qp,
+                          const int *Qi, const int *Ep, const int *Ei, const int *Cp, const int *Ci) {
+  if (!h) return HQPKKT_E_NULL;
+  if (h->opts.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_INTERN;
+  int e = hqpkkt_set_stages(h, K, nx, nu);
+  if (e) return e;
+  if (K < 1) return HQPKKT_E_RANGE;
+  long long n = nx[K], ndyn = 0;
+  for (int k = 0; k < K; k++) n += (long long)nx[k] + nu[k], ndyn += nx[k + 1];
+  if (n > 0x7fffffffLL || ndyn + me_rest > 0x7fffffffLL || me_rest < 0 || m < 0) return HQPKKT_E_RANGE;
+  if ((n > 0 && (!Qp || (Qp[n] > 0 && !Qi))) || (me_rest > 0 && (!Ep || (Ep[me_rest] > 0 && !Ei))) ||
+      (m > 0 && (!Cp || (Cp[m] > 0 && !Ci))))
+    return HQPKKT_E_NULL;
+  if (h->uploaded) {
+    (void)hipSetDevice(h->opts.device);
+    (void)hipStreamSynchronize(h->stream);
+    h->release_device();
+  }
+  h->analyzed = false;
+  h->ip_hot_valid = h->fr_hot_valid = false;
+  const int me = (int)ndyn + me_rest;
+  h->pQp.assign(Qp, Qp + n + 1), h->pQi.assign(Qi, Qi + Qp[n]);
+  h->pAp.assign((size_t)me + 1, 0);  // the dynamics rows are empty: they come as dense blocks
+  for (int i = 0; i <= me_rest; i++) h->pAp[ndyn + i] = me_rest ? Ep[i] : 0;
+  h->pAi.clear();
+  if (me_rest && Ep[me_rest]) h->pAi.assign(Ei, Ei + Ep[me_rest]);
+  h->pCp.clear(), h->pCi.clear();
+  if (m) h->pCp.assign(Cp, Cp + m + 1), h->pCi.assign(Ci, Ci + Cp[m]);
+  h->zd_decided = true, h->zd_weak = false;
+  return staged_analyze(h, (int)n, me, m, true);
+}
+
+int hqpkkt_set_values_staged(hqpkkt_t *h, const double *Qx, const double *const *F, const long long *ldF,
+                             const double *Ex, const double *Cx) {
+  if (!h) return HQPKKT_E_NULL;
+  if (!h->analyzed || h->opts.mode != HQPKKT_MODE_STAGED || !h->sd) return HQPKKT_E_INTERN;
+  Analysis &an = h->an;
+  if ((an.nq && !Qx) || (an.na && !Ex) || (an.nc && !Cx) || !F || !ldF) return HQPKKT_E_NULL;
+  return staged_set_values(h, Qx, Ex, Cx, F, ldF);
 }
 
 // STAGED: rank and number of carried rows of every stage in the last factorisation

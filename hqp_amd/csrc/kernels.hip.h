@@ -2301,7 +2301,10 @@ k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDe
            const double *__restrict__ dy, const double *__restrict__ dz,
            const double *__restrict__ dw, double *__restrict__ o1, double *__restrict__ o2,
            double *__restrict__ o3, double *__restrict__ o4,
-           unsigned long long *__restrict__ resbits) {
+           unsigned long long *__restrict__ resbits,
+           // STAGED with dense dynamics: x1 = A_dyn' dy (n), x2 = A_dyn dx (first ndyn rows of A,
+           // which are empty in the CSR block), computed by the dense kernels of staged.hip.h
+           const double *__restrict__ x1 = nullptr, const double *__restrict__ x2 = nullptr, int ndyn = 0) {
   __shared__ double red[4];
   const int sub = threadIdx.x & (LPR - 1);
   const int total = n + me + m;
@@ -2312,12 +2315,13 @@ k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDe
       double s = row_dot<LPR>(Q, vals, dx, q, sub);
       s += -1.0 * row_dot<LPR>(AT, vals, dy, q, sub);
       s += -1.0 * row_dot<LPR>(CT, vals, dz, q, sub);
+      if (x1) s -= x1[q];
       s = r1[q] + s;
       if (sub == 0) o1[q] = s;
       mag = fmax(mag, fabs(s) == fabs(s) ? fabs(s) : __longlong_as_double(0x7ff0000000000000LL));
     } else if (q < n + me) {
       const int i = q - n;
-      const double s = r2[i] - row_dot<LPR>(A, vals, dx, i, sub);
+      const double s = r2[i] - row_dot<LPR>(A, vals, dx, i, sub) - (i < ndyn ? x2[i] : 0.0);
       if (sub == 0) o2[i] = s;
       mag = fmax(mag, fabs(s) == fabs(s) ? fabs(s) : __longlong_as_double(0x7ff0000000000000LL));
     } else {

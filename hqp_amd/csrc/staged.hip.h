@@ -780,4 +780,40 @@ __global__ void k_st_copy(int n, const double *__restrict__ s, double *__restric
   if (i < n) d[i] = s[i];
 }
 
+// ---------------------------------------------------------------------------------------
+// Dense dynamics (hqpkkt_set_values_staged): the products with the dynamics rows of A that
+// residuum() needs, all stages in one launch (blockIdx.y = stage)
+struct DynDesc {
+  long long oF;
+  int ldf, np, nz, col0, row0, ncur;  // F block, its sizes, first column / dynamics row, states of the stage
+};
+// out2[row0 + li] = F_k[li][:] dx_k - dx_{k+1}[li]
+__global__ void __launch_bounds__(256) k_st_dyn_ax(const DynDesc *__restrict__ desc, const double *__restrict__ F,
+                                                   const double *__restrict__ dx, double *__restrict__ out2) {
+  const DynDesc d = desc[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < d.np; li += gridDim.x * 4) {
+    const double *fr = F + d.oF + (long long)li * d.ldf;
+    double s = 0.0;
+    for (int j = lane; j < d.nz; j += 64) s += fr[j] * dx[d.col0 + j];
+    s = kktdev::wave_sum(s);
+    if (lane == 0) out2[d.row0 + li] = s - dx[d.col0 + d.nz + li];
+  }
+}
+// out1[c] = sum_li F_k[li][lc] dy[row0 + li] - dy[row of x_k's dynamics equation]   (c in stage k;
+// the last stage has no F: np = 0)
+__global__ void __launch_bounds__(256) k_st_dyn_aty(const DynDesc *__restrict__ desc, const double *__restrict__ F,
+                                                    const double *__restrict__ dy, double *__restrict__ out1) {
+  const DynDesc d = desc[blockIdx.y];
+  const int ncols = d.np > 0 ? d.nz : d.ncur;
+  for (int lc = blockIdx.x * blockDim.x + threadIdx.x; lc < ncols; lc += gridDim.x * blockDim.x) {
+    double s = 0.0;
+    const double *fc = F + d.oF + lc;
+    for (int li = 0; li < d.np; li++) s += fc[(long long)li * d.ldf] * dy[d.row0 + li];
+    // x_k is the state the previous stage's dynamics produce: -1.0 in that row
+    if (blockIdx.y > 0 && lc < d.ncur) s -= dy[d.row0 - d.ncur + lc];
+    out1[d.col0 + lc] = s;
+  }
+}
+
 }  // namespace stg

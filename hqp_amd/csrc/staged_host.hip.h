@@ -10,11 +10,14 @@ struct StagedDev {
   DBuf<int> dyn, eq_rows, fix_rows, fix_src, h_tptr, chk_idx, chk_kind;
   DBuf<long long> h_dst, a_dst;
   DBuf<stg::HTerm> h_terms;
+  DBuf<stg::DynDesc> dyn_desc;  // dense dynamics: per stage (K+1) what k_st_dyn_ax / _aty need
+  DBuf<double> dyn_x1, dyn_x2;  // A_dyn' dy (n), A_dyn dx (ndyn)
   size_t lds_small = 0, lds_init = 0;
   void release() {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
+    dyn_desc.release(), dyn_x1.release(), dyn_x2.release();
   }
 };
 
@@ -76,7 +79,7 @@ int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int 
 
 }  // namespace
 
-static int staged_analyze(hqpkkt_t *h, int n, int me, int m) {
+static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = false) {
   if (!h->sd) h->sd = new (std::nothrow) StagedDev;
   if (!h->sd) return HQPKKT_E_MEM;
   StagedDev &d = *h->sd;
@@ -84,6 +87,7 @@ static int staged_analyze(hqpkkt_t *h, int n, int me, int m) {
   std::vector<int> gnx = P.given_nx, gnu = P.given_nu;
   P = kktdev::StagedPlan();
   P.given_nx = gnx, P.given_nu = gnu;
+  P.dense_dyn = dense_dyn;
   int e = h->an.setup_blocks(1, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),
                              h->pCp.data(), h->pCi.data());
   if (e) return e;
@@ -151,6 +155,15 @@ static int staged_upload(hqpkkt_t *h) {
     for (size_t k = 0; k < t.size(); k++) t[k] = stg::HTerm{P.h_terms[k].s1, P.h_terms[k].s2, P.h_terms[k].wi};
     if ((e = d.h_terms.upload(t))) return e;
   }
+  if (P.dense_dyn) {
+    std::vector<stg::DynDesc> dd(P.K + 1);
+    for (int k = 0; k <= P.K; k++) {
+      dd[k].oF = k < P.K ? P.oF[k] : 0, dd[k].ldf = k < P.K ? P.ldf[k] : 0;
+      dd[k].np = k < P.K ? P.nk[k + 1] : 0, dd[k].nz = k < P.K ? P.nk[k] + P.mk[k] : P.nk[k];
+      dd[k].col0 = P.nmk[k], dd[k].row0 = k < P.K ? P.nks[k] : P.ndyn, dd[k].ncur = P.nk[k];
+    }
+    if ((e = d.dyn_desc.upload(dd)) || (e = d.dyn_x1.alloc(n)) || (e = d.dyn_x2.alloc(P.ndyn))) return e;
+  }
   HIPCHK(hipMemset(d.F.p, 0, sizeof(double) * std::max<long long>(P.f_elems, 1)));
   HIPCHK(hipMemset(d.V.p, 0, sizeof(double) * std::max<long long>(P.v_elems, 1)));
   HIPCHK(hipMemset(d.misc.p, 0, sizeof(double) * std::max<long long>(P.misc_elems, 1)));
@@ -188,15 +201,24 @@ static int staged_upload(hqpkkt_t *h) {
   return 0;
 }
 
-static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const double *Cx) {
+static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const double *Cx,
+                             const double *const *Fblk = nullptr, const long long *ldF = nullptr) {
   Analysis &an = h->an;
   int e;
   if (!h->uploaded && (e = staged_upload(h))) return e;
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;
+  if (P.dense_dyn != (Fblk != nullptr)) return HQPKKT_E_INTERN;  // analysed for the other hand-over
   HIPCHK(hipSetDevice(h->opts.device));
   hipStream_t s = h->stream;
   hipMemcpyKind kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+  if (Fblk)
+    for (int k = 0; k < P.K; k++) {
+      const int nz = P.nk[k] + P.mk[k];
+      if (!Fblk[k] || ldF[k] < nz) return HQPKKT_E_SIZES;
+      HIPCHK(hipMemcpy2DAsync(d.F.p + P.oF[k], sizeof(double) * P.ldf[k], Fblk[k], sizeof(double) * ldF[k],
+                              sizeof(double) * nz, P.nk[k + 1], kind, s));
+    }
   if (an.nq) HIPCHK(hipMemcpyAsync(h->vals.p, Qx, sizeof(double) * an.nq, kind, s));
   if (an.na) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq, Ax, sizeof(double) * an.na, kind, s));
   if (an.nc) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq + an.na, Cx, sizeof(double) * an.nc, kind, s));

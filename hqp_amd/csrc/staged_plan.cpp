@@ -33,14 +33,15 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     nks.assign(K + 1, 0);
     for (int k = 0; k < K; k++) nks[k + 1] = nks[k] + nk[k + 1];
     ndyn = nks[K];
+    if (arows < ndyn) return 6;
     if (!dense_dyn) {
       // the rows must be the staircase these sizes describe
-      if (arows < ndyn) return 6;
       for (int k = 0; k < K; k++)
         for (int i = nks[k]; i < nks[k + 1]; i++) {
           if (Ap[i + 1] - Ap[i] < 1 || Ai[Ap[i + 1] - 1] != nmk[k + 1] + (i - nks[k])) return 6;
         }
-    }
+    } else if (Ap[ndyn] != 0)
+      return 6;  // dense dynamics: their rows of A are empty
   } else {
     // the -1.0 staircase (values are checked when they arrive: chk_idx): a new stage starts
     // where the last column jumps by more than one or the row reaches back into the block of
@@ -79,7 +80,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     for (int k = 0; k < K; k++) nks[k + 1] = nks[k] + nk[k + 1];
     if (nks[K] != ndyn) return 6;
   }
-  me = dense_dyn ? ndyn + arows : arows;
+  me = arows;
   std::vector<int> stage_of(n);
   for (int k = 0; k <= K; k++) {
     const int c1 = k < K ? nmk[k + 1] : n;
@@ -96,7 +97,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
         if (p1 - p0 < 2 || stage_of[Ai[p0]] != k || stage_of[Ai[p1 - 2]] != k || stage_of[Ai[p1 - 1]] != k + 1)
           return 6;
       }
-  const int row0 = dense_dyn ? 0 : ndyn;  // first non-dynamics row of the A handed over
+  const int row0 = ndyn;  // first non-dynamics row
   std::vector<std::vector<int>> eq(K + 1);
   for (int i = row0; i < arows; i++) {
     const int p0 = Ap[i], p1 = Ap[i + 1];
@@ -135,14 +136,12 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       for (int j = 0; j < nk[0]; j++) fix_src[j] = nq + fsrc[j];
     }
   }
-  const int rshift = dense_dyn ? ndyn : 0;  // row index in the full dy vector
   eq_ptr.assign(K + 2, 0);
   eq_rows.clear();
   for (int k = 0; k <= K; k++) {
-    for (int i : eq[k]) eq_rows.push_back(i + rshift);
+    for (int i : eq[k]) eq_rows.push_back(i);
     eq_ptr[k + 1] = (int)eq_rows.size();
   }
-  for (int &r : fix_rows) r += rshift;
 
   // ------------------------------------------------------------------ capacities
   cap.assign(K + 1, 0), capn.assign(K + 1, 0), qmax.assign(K + 1, 0);

@@ -17,7 +17,7 @@ struct StagedPlan {
   std::vector<int> eq_ptr, eq_rows;  // own equality rows per stage (QP row indices), K+2 / total
   bool fixed_x0 = false;
   std::vector<int> fix_rows, fix_src;  // per x_0 component: its row of A and the index of its value in vals
-  bool dense_dyn = false;  // dynamics handed over as dense blocks: A holds the other equalities only
+  bool dense_dyn = false;  // dynamics handed over as dense blocks: their rows of A are empty
 
   // static bounds: cap[k] carried rows leaving stage k, capn[k] rows of N_k, qmax[k] order of K_k
   std::vector<int> cap, capn, qmax;

@@ -330,6 +330,49 @@ class Hqp_IpLQDOCP(Hqp_IpMatrix):
         _check(self._L.hqpkkt_set_stages(self._h, len(nu), C.c_void_p(nx.ctypes.data),
                                          C.c_void_p(nu.ctypes.data) if nu.size else None), "set_stages")
 
+    def init_dense(self, dq):
+        """init() for a :class:`hqp_amd.problems.DenseDocp`: the dynamics as dense blocks
+        (hqpkkt_analyze_staged + hqpkkt_set_values_staged)."""
+        self.n, self.me, self.m = dq.dims
+        nx, nu = _i32(dq.nx), _i32(dq.nu)
+        arrs = []
+        for (p, i, _x) in (dq.Q, dq.E, dq.C):
+            arrs += [_i32(p), _i32(i)]
+        self._keep = arrs + [nx, nu]
+        ptrs = [C.c_void_p(a.ctypes.data) if a.size else None for a in arrs]
+        _check(self._L.hqpkkt_analyze_staged(self._h, dq.K, C.c_void_p(nx.ctypes.data), C.c_void_p(nu.ctypes.data),
+                                             dq.me_rest, dq.m, *ptrs), "init_dense")
+        self.update_dense(dq)
+
+    def update_dense(self, dq):
+        vals, keep = [], []
+        for (_p, _i, x) in (dq.Q, dq.E, dq.C):
+            if self._device_vectors and not hasattr(x, "data_ptr"):
+                import torch
+                x = torch.as_tensor(np.ascontiguousarray(x, dtype=np.float64)).cuda()
+            if hasattr(x, "data_ptr"):
+                keep.append(x)
+                vals.append(C.c_void_p(x.data_ptr()) if x.numel() else None)
+            else:
+                a = np.ascontiguousarray(x, dtype=np.float64)
+                keep.append(a)
+                vals.append(C.c_void_p(a.ctypes.data) if a.size else None)
+        fp = (C.c_void_p * dq.K)()
+        ld = (C.c_longlong * dq.K)()
+        for k, blk in enumerate(dq.F):
+            if hasattr(blk, "data_ptr"):
+                if not self._device_vectors or blk.stride(1) != 1:
+                    raise TypeError("F blocks: row-major torch CUDA tensors need device_vectors=True")
+                fp[k], ld[k] = blk.data_ptr(), blk.stride(0)
+                keep.append(blk)
+            else:
+                if self._device_vectors:
+                    raise TypeError("device_vectors=True needs torch CUDA F blocks")
+                a = np.ascontiguousarray(blk, dtype=np.float64)
+                fp[k], ld[k] = a.ctypes.data, a.shape[1]
+                keep.append(a)
+        _check(self._L.hqpkkt_set_values_staged(self._h, vals[0], fp, ld, vals[1], vals[2]), "update_dense")
+
     def stage_structure(self):
         names = {"nk": 20, "mk": 21, "nmk": 22, "eq_ptr": 23, "eq_rows": 24, "fix_rows": 25, "cap": 26}
         return {nm: self.debug(i) for nm, i in names.items()}

@@ -196,6 +196,48 @@ def lq_docp(K, nx, nu, seed=3, density=1.0, x0_fixed=True, final_eq=0, path_eq=0
     return Program(n, me, m, Q, A, C, c=rng.uniform(-0.1, 0.1, n), b=b, d=np.ones(m))
 
 
+class DenseDocp:
+    """A multistage QP whose dynamics rows are handed over as dense blocks
+    (hqpkkt_analyze_staged / hqpkkt_set_values_staged): ``F[k]`` = [fx_k fu_k], row-major
+    nx[k+1] x (nx[k] + nu[k]) (numpy arrays, or torch CUDA tensors for device hand-over);
+    ``E`` = the other equality rows (me_rest x n CSR).  Vectors of length ``me`` keep the
+    reference's order: dynamics rows first."""
+
+    def __init__(self, nx, nu, Q, E, C, F, me_rest, m):
+        self.nx, self.nu = [int(v) for v in nx], [int(v) for v in nu]
+        self.K = len(self.nu)
+        self.n = sum(self.nx) + sum(self.nu)
+        self.ndyn = sum(self.nx[1:])
+        self.me_rest, self.me, self.m = int(me_rest), self.ndyn + int(me_rest), int(m)
+        self.Q, self.E, self.C, self.F = Q, E, C, F
+
+    @property
+    def dims(self):
+        return self.n, self.me, self.m
+
+
+def dense_docp_from_program(prog, nx, nu):
+    """The dense-dynamics form of a Program in Hqp_Docp's layout (tests: both hand-overs must
+    give the same results)."""
+    K = len(nu)
+    p, i, x = prog.A
+    nmk = np.concatenate([[0], np.cumsum([nx[k] + nu[k] for k in range(K)])])
+    F, row = [], 0
+    for k in range(K):
+        nz = nx[k] + nu[k]
+        blk = np.zeros((nx[k + 1], nz))
+        for li in range(nx[k + 1]):
+            r = row + li
+            cols, vals = i[p[r]:p[r + 1] - 1], x[p[r]:p[r + 1] - 1]
+            blk[li, cols - nmk[k]] = vals
+        F.append(blk)
+        row += nx[k + 1]
+    ndyn = row
+    Ep = (p[ndyn:] - p[ndyn]).astype(np.int32)
+    E = (Ep, i[p[ndyn]:].astype(np.int32), x[p[ndyn]:].copy())
+    return DenseDocp(nx, nu, prog.Q, E, prog.C, F, prog.me - ndyn, prog.m)
+
+
 def random_sparse_qp(n, me, m, row_nnz=4, seed=7):
     """Irregular (non-banded) QP: random sparse A, C rows, Q = diag + random
     symmetric sparse part made diagonally dominant.  Exercises the general path."""

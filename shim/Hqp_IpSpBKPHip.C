@@ -24,6 +24,7 @@ IF_CLASS_DEFINE("LQDOCPHip", Hqp_IpLQDOCPHip, Hqp_IpMatrix);
 Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
 {
   _mode = mode;
+  _mode_used = mode;
   _n = _me = _m = 0;
   _sbw = -1;
   _tol = 1.0;
@@ -119,48 +120,74 @@ void Hqp_IpMatrixHip::extract(const Hqp_Program *qp, bool &pattern_changed)
 }
 
 //--------------------------------------------------------------------------
+// (re)create the handle for `mode` and hand the structure and the values over.
+// Returns the status of the first call that fails (the handle then stays
+// created, but not analysed).
+int Hqp_IpMatrixHip::open(int mode)
+{
+  hqpkkt_opts opts;
+  int e;
+
+  hqpkkt_destroy(_h);
+  _h = NULL;
+  hqpkkt_default_opts(&opts);
+  opts.mode = mode;
+  opts.device = _device;
+  opts.loc = HQPKKT_LOC_HOST;   // Meschach VEC::ve pointers
+  opts.tol = _tol;
+  opts.eps = _eps;
+  if ((e = hqpkkt_create(&opts, &_h)))
+    return e;
+  _mode_used = mode;
+  if ((e = hqpkkt_analyze(_h, _n, _me, _m,
+                          _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,
+                          &_sbw)))
+    return e;
+  return hqpkkt_set_values(_h, _Qx->ve, _Ax->ve, _Cx->ve);
+}
+
+//--------------------------------------------------------------------------
 void Hqp_IpMatrixHip::init(const Hqp_Program *qp)
 {
   bool changed;
-  hqpkkt_opts opts;
+  int e;
 
   _n = qp->c->dim;
   _me = qp->b->dim;
   _m = qp->d->dim;
 
-  // (re)create the handle: mat_tol / mat_eps / mat_device may have been set
-  hqpkkt_destroy(_h);
-  _h = NULL;
-  hqpkkt_default_opts(&opts);
-  opts.mode = _mode;
-  opts.device = _device;
-  opts.loc = HQPKKT_LOC_HOST;   // Meschach VEC::ve pointers
-  opts.tol = _tol;
-  opts.eps = _eps;
-  check(hqpkkt_create(&opts, &_h), "Hqp_IpMatrixHip::init");
-
+  // the handle is created here: mat_tol / mat_eps / mat_device may have been set
   extract(qp, changed);
-  check(hqpkkt_analyze(_h, _n, _me, _m,
-                       _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,
-                       &_sbw),
-        "Hqp_IpMatrixHip::init");
-  check(hqpkkt_set_values(_h, _Qx->ve, _Ax->ve, _Cx->ve), "Hqp_IpMatrixHip::init");
+  e = open(_mode);
+  if (_mode == HQPKKT_MODE_STAGED && (e == HQPKKT_E_FORMAT || e == HQPKKT_E_SIZES)) {
+    // not the staircase of a DOCP (where Hqp_IpLQDOCP::init asserts,
+    // hqp/Hqp_IpLQDOCP.C:700-707), or a stage with more controls / carried
+    // constraint rows than the STAGED kernels hold: the same KKT system through
+    // the full-system engine
+    e = open(HQPKKT_MODE_FULL);
+  }
+  check(e, "Hqp_IpMatrixHip::init");
 }
 
 //--------------------------------------------------------------------------
 void Hqp_IpMatrixHip::update(const Hqp_Program *qp)
 {
   bool changed;
+  int e;
   extract(qp, changed);
   if (changed) {
     // structure changed behind our back: analyse again (the reference's own
     // plugins assume a fixed pattern between init() calls)
-    check(hqpkkt_analyze(_h, _n, _me, _m,
-                         _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,
-                         &_sbw),
-          "Hqp_IpMatrixHip::update");
-  }
-  check(hqpkkt_set_values(_h, _Qx->ve, _Ax->ve, _Cx->ve), "Hqp_IpMatrixHip::update");
+    e = hqpkkt_analyze(_h, _n, _me, _m,
+                       _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,
+                       &_sbw);
+    if (!e)
+      e = hqpkkt_set_values(_h, _Qx->ve, _Ax->ve, _Cx->ve);
+  } else
+    e = hqpkkt_set_values(_h, _Qx->ve, _Ax->ve, _Cx->ve);
+  if (_mode_used == HQPKKT_MODE_STAGED && (e == HQPKKT_E_FORMAT || e == HQPKKT_E_SIZES))
+    e = open(HQPKKT_MODE_FULL);   // see init()
+  check(e, "Hqp_IpMatrixHip::update");
 }
 
 //--------------------------------------------------------------------------

@@ -9,7 +9,7 @@
  * (iftcl/If_Class.h:53-60):
  *     qp_mat_solver SpBKPHip      -- semantics of Hqp_IpSpBKP    (full system)
  *     qp_mat_solver RedSpBKPHip   -- semantics of Hqp_IpRedSpBKP (reduced)
- *     qp_mat_solver LQDOCPHip     -- stands in for Hqp_IpLQDOCP (same system, full engine)
+ *     qp_mat_solver LQDOCPHip     -- semantics of Hqp_IpLQDOCP   (multistage, STAGED engine)
  * Hqp_IpsMehrotra / Hqp_IpsFranke / Hqp_SqpSolver call them unchanged through
  * the Hqp_IpMatrix virtual interface (hqp/Hqp_IpMatrix.h:63-88).
  */
@@ -22,7 +22,8 @@ struct hqpkkt;
 
 class Hqp_IpMatrixHip : public Hqp_IpMatrix {
  protected:
-  int _mode;          // HQPKKT_MODE_FULL / HQPKKT_MODE_REDUCED
+  int _mode;          // HQPKKT_MODE_FULL / HQPKKT_MODE_REDUCED / HQPKKT_MODE_STAGED
+  int _mode_used;     // the engine the current handle runs (STAGED falls back to FULL, see init())
   int _n, _me, _m;    // dimensions of the analysed program
   int _sbw;           // mat_sbw (read-only for the user, as in hqp/Hqp_IpSpBKP.C:58)
   Real _tol;          // mat_tol (hqp/Hqp_IpSpBKP.C:59)
@@ -35,6 +36,7 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   VEC *_Qx, *_Ax, *_Cx;
 
   void extract(const Hqp_Program *qp, bool &pattern_changed);
+  int open(int mode);
   void check(int status, const char *where);
 
  public:
@@ -69,14 +71,15 @@ class Hqp_IpRedSpBKPHip : public Hqp_IpMatrixHip {
 };
 
 // Drop-in for users that select the multistage plugin (hqp_docp/Docp_Main.C:42-49,
-// odc/crane.tcl:58: qp_mat_solver LQDOCP).  Hqp_IpLQDOCP solves the SAME KKT system
-// with an extended Riccati recursion over the stages (hqp/Hqp_IpLQDOCP.C:796-976);
-// here the stage structure is exploited through the band ordering instead: the
-// nested dissection of the RCM band cuts between stages, which is the tree-parallel
-// form of that recursion.  Unlike the reference it does not require DOCP structure.
+// odc/crane.tcl:58: qp_mat_solver LQDOCP).  Like Hqp_IpLQDOCP (hqp/Hqp_IpLQDOCP.C:693-976)
+// it finds the stages from the -1.0 staircase of A, keeps fx, fu and the cost-to-go
+// Hessians as dense per-stage blocks and runs the extended Riccati recursion over them
+// (HQPKKT_MODE_STAGED: fp64 MFMA products on the device).  Where the reference asserts
+// (no DOCP structure) or a stage is beyond the STAGED kernels (> ~64 controls, > 48
+// carried constraint rows) the same KKT system goes to the full-system engine.
 class Hqp_IpLQDOCPHip : public Hqp_IpMatrixHip {
  public:
-  Hqp_IpLQDOCPHip() : Hqp_IpMatrixHip(0) {}
+  Hqp_IpLQDOCPHip() : Hqp_IpMatrixHip(2) {}
   const char *name() { return "LQDOCPHip"; }
 };
 

@@ -195,6 +195,40 @@ def test_staged_k200(nx):
     assert all(np.array_equal(a, b) for a, b in zip(d3, d4))
 
 
+@pytest.mark.parametrize("device_vectors", [False, True])
+def test_dense_handover_equals_csr_handover(device_vectors):
+    """hqpkkt_analyze_staged / hqpkkt_set_values_staged (dynamics as dense blocks, what the
+    10^6-variable DOCP needs) against the CSR hand-over of the same QP: same step, same residuum,
+    same refined solve; host and device pointers."""
+    K, nx, nu = 9, 7, 3
+    prog = problems.lq_docp(K, nx, nu, final_eq=2, path_eq=1, path_eq_every=3, x_bounds=2)
+    dq = problems.dense_docp_from_program(prog, [nx] * (K + 1), [nu] * K)
+    st = problems.ip_state(prog, 6, 1.0)
+    A = ipmatrix.IpLQDOCP()
+    da, ra = _solve(A, prog, st)
+    B = ipmatrix.IpLQDOCP(device_vectors=device_vectors)
+    if device_vectors:
+        import torch
+        dq.F = [torch.as_tensor(f).cuda() for f in dq.F]
+        stv = [torch.as_tensor(v).cuda() for v in st]
+        db = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
+    else:
+        stv, db = st, new_d(prog)
+    B.init_dense(dq)
+    B.factor(None, stv[0], stv[1])
+    rb = B.solve(None, *stv, *db)
+    dbh = [v.cpu().numpy() if device_vectors else v for v in db]
+    assert ra <= RES_TOL and rb <= RES_TOL
+    assert rel_err(dbh, da) <= 1e-10
+    # residuum() of a given d: the dense products with the dynamics rows
+    if not device_vectors:
+        r1 = A.residuum(prog, *st, *da)
+        r2 = B.residuum(None, *st, *da)
+        assert abs(r1 - r2) <= 1e-13
+        with pytest.raises(ipmatrix.KktError):
+            B.mehrotra(prog)
+
+
 def test_dgemm_kernel_against_exact_products():
     """k_dgemm_tn (both tile sizes, ragged edges, lower / mirrored output, K not a multiple
     of the slab) against exactly accumulated sample entries."""
