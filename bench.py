@@ -1,18 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the MI355X KKT path: KKT factor+solve per second (fp64).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--workload c4|c2]
 
 A "step" is one pass of the hot path over one KKT system whose data are already
-resident in HBM: Hqp_IpMatrix::factor (assemble w/z + scaling, supernodal BK
-LDL') followed by Hqp_IpMatrix::solve (triangular solves + iterative refinement
-to mat_eps), i.e. what one interior-point iteration of the reference asks of its
-plugin besides extra right-hand sides (hqp/Hqp_IpsMehrotra.C:527-530).
+resident in HBM: Hqp_IpMatrix::factor followed by Hqp_IpMatrix::solve (one solve +
+iterative refinement to mat_eps), i.e. what one interior-point iteration of the reference
+asks of its plugin besides extra right-hand sides (hqp/Hqp_IpsMehrotra.C:527-530).
 
-Workload at N=1: BASELINE.json configs[1] = SURVEY.md 8(d) "C2", the synthetic
-banded KKT system n=40000, me=20000, m=40000 (KKT dim 1e5, mat_sbw 200).
-N>1: one process per GPU, every rank factors+solves its own C2 system (different
-seed): independent KKT systems shard with no data-path collective ("weak").
+Workload at N=1 (default, --workload c4): the configuration BASELINE.json's metric is quoted
+on, the 10^6-variable DOCP = configs[3] / SURVEY.md 8(d) "C4": synthetic multistage LQ
+optimal control QP, K = 200 stages of nx = 5000 states and nu = 50 controls (n = 1 015 000,
+me = 1 005 000, m = 20 000), dense random stable fx, dense fu, x_0 fixed, box bounds on the
+controls; plugin LQDOCP = the STAGED engine (hqpkkt_analyze_staged: dynamics handed over as
+dense blocks).  --workload c2: configs[1], the synthetic banded KKT system of dim 10^5 through
+the full-system engine (round 1's headline; its rate is also carried as an extra of the c4
+line).  N>1: one process per GPU, every rank factors+solves its own system (different seed):
+independent KKT systems shard with no data-path collective ("weak"); --one-system: ONE system
+over the ranks ("strong").
 
 Prints ONE JSON line on rank 0.
 """
@@ -194,11 +199,302 @@ def concurrent_systems(prog, state, cls, local_rank, steps, counts=(2, 4)):
     return out
 
 
-def main():
+# ------------------------------------------------------------------ C4: the 10^6-variable DOCP
+def c4_dense(K, nx, nu, seed=0, device="cuda"):
+    """SURVEY.md 8(d) "C4" generated on the device: fx dense random with spectral radius ~0.9
+    (a different block for every stage), fu dense random, Q = diag(1 on states, 0.1 on
+    controls), x_0 fixed, -1 <= u <= 1.  Returns a problems.DenseDocp (F blocks = torch tensors)."""
+    import torch
+    from hqp_amd import problems
+    g = torch.Generator(device=device).manual_seed(seed)
+    nz = nx + nu
+    F = []
+    for _k in range(K):
+        blk = torch.empty((nx, nz), dtype=torch.float64, device=device)
+        blk.uniform_(-1.0, 1.0, generator=g)
+        blk[:, :nx] *= 0.9 / np.sqrt(nx / 3.0)
+        F.append(blk)
+    n = K * nz + nx
+    qd = np.ones(n)
+    qd.reshape(-1)[:K * nz].reshape(K, nz)[:, nx:] = 0.1
+    Q = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), qd)
+    E = (np.arange(nx + 1, dtype=np.int32), np.arange(nx, dtype=np.int32), np.ones(nx))
+    ucols = (np.arange(K)[:, None] * nz + nx + np.arange(nu)[None, :]).ravel()
+    cols = np.concatenate([ucols, ucols]).astype(np.int32)
+    vals = np.concatenate([np.ones(ucols.size), -np.ones(ucols.size)])
+    C = (np.arange(cols.size + 1, dtype=np.int32), cols, vals)
+    return problems.DenseDocp([nx] * (K + 1), [nu] * K, Q, E, C, F, nx, cols.size)
+
+
+def c4_program(K, nx, nu, seed=0):
+    """The same QP family in CSR form (Hqp_Docp's layout) for the CPU reference: what
+    Hqp_IpLQDOCP::init / factor / step are timed on."""
+    from hqp_amd import problems
+    rng = np.random.default_rng(seed)
+    nz = nx + nu
+    n = K * nz + nx
+    ar, ac, av = [], [], []
+    rows = np.arange(nx)
+    for k in range(K):
+        blk = rng.uniform(-1.0, 1.0, (nx, nz))
+        blk[:, :nx] *= 0.9 / np.sqrt(nx / 3.0)
+        ar.append(np.repeat(k * nx + rows, nz)), ac.append(np.tile(k * nz + np.arange(nz), nx)), av.append(blk.ravel())
+        ar.append(k * nx + rows), ac.append((k + 1) * nz + rows), av.append(np.full(nx, -1.0))
+    ar.append(K * nx + rows), ac.append(rows), av.append(np.ones(nx))
+    A = problems._csr(np.concatenate(ar), np.concatenate(ac), np.concatenate(av), K * nx + nx)
+    qd = np.ones(n)
+    qd[:K * nz].reshape(K, nz)[:, nx:] = 0.1
+    Q = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), qd)
+    ucols = (np.arange(K)[:, None] * nz + nx + np.arange(nu)[None, :]).ravel()
+    cols = np.concatenate([ucols, ucols]).astype(np.int32)
+    C = (np.arange(cols.size + 1, dtype=np.int32), cols, np.concatenate([np.ones(ucols.size), -np.ones(ucols.size)]))
+    return problems.Program(n, K * nx + nx, cols.size, Q, A, C)
+
+
+def _ref_lqdocp_time(args):
+    """One process: median factor+solve time of the reference's Hqp_IpLQDOCP on c4_program(K, nx, nu)."""
+    K, nx, nu, reps = args
+    from hqp_amd import problems
+    from oracle import refapi
+    prog = c4_program(K, nx, nu, seed=1)
+    st = problems.ip_state(prog, 1)
+    R = refapi.RefIpMatrix("LQDOCP")
+    R.init(prog)
+    ts, res = [], None
+    for _ in range(reps):
+        R.factor(st[0], st[1])
+        _d, res = R.solve(*st)
+        ts.append(R.t_factor + R.t_solve)
+    return float(np.median(ts)), float(res)
+
+
+def cpu_baseline_c4(K, nx, nu):
+    """The reference's own multistage plugin Hqp_IpLQDOCP (oracle/_ref, built from the reference's
+    sources) timed on this box's host cores on a BOUNDED sample of the workload: the same QP family
+    at K stages with nx = 100 and 200 states (the full nx = 5000 needs ~10^14 flops of Meschach's
+    triple-loop m_mlt: about half a day on one core), extrapolated with the exponent the two samples
+    give (SURVEY.md 8(d) C4 prescribes this).  One core (the path is single-threaded) plus the
+    aggregate of 8 instances on 8 cores."""
+    try:
+        from oracle import refapi
+        have_ref = refapi.available()
+    except Exception:
+        have_ref = False
+    cores = os.cpu_count()
+    if not have_ref:
+        from hqp_amd import problems
+        from oracle import oracleapi
+        small = c4_program(12, 12, 3, seed=1)
+        st = problems.ip_state(small, 1)
+        O = oracleapi.OracleIpMatrix("SpBKP")
+        O.init(small)
+        t0 = time.perf_counter()
+        O.factor(st[0], st[1])
+        O.solve(*st)
+        t = time.perf_counter() - t0
+        return {"value": 1.0 / t, "unit": "KKT factor+solve/s", "cores": 1, "kind": "port", "host_cores": cores,
+                "sample": "1 x factor+solve of a REDUCED-SIZE multistage QP (K=12, nx=12, nu=3) with the dense-storage C oracle of "
+                          "the full system; oracle/_ref not loadable on this box; NOT extrapolated"}
+    t100, r100 = _ref_lqdocp_time((K, 100, nu, 5))
+    t200, r200 = _ref_lqdocp_time((K, 200, nu, 5))
+    expo = float(np.log(t200 / t100) / np.log(2.0))
+    t_full = t200 * (nx / 200.0) ** expo
+    out = {"value": 1.0 / t_full, "unit": "KKT factor+solve/s", "cores": 1, "kind": "reference", "host_cores": cores,
+           "sample": f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve, median of 5 after one init, same QP family at K={K}, nu={nu}: "
+                     f"nx=100 {t100:.3f} s, nx=200 {t200:.3f} s (residuals {r100:.1e}, {r200:.1e}); EXTRAPOLATED to nx={nx} with the "
+                     f"measured exponent {expo:.2f}: {t_full:.0f} s per factor+solve",
+           "measured": {"nx100_s": t100, "nx200_s": t200, "exponent": expo}, "extrapolated_s": t_full}
+    try:  # 8 independent instances on the host's cores (SURVEY.md 8(d)): aggregate rate at the nx=100 sample
+        import subprocess
+        inst = min(8, cores or 1)
+        code = ("import sys; sys.path.insert(0, %r); import bench; t, r = bench._ref_lqdocp_time((%d, 100, %d, 3)); print(t)"
+                % (ROOT, K, nu))
+        t0 = time.perf_counter()
+        procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
+                 for _ in range(inst)]
+        ts = [float(p.communicate(timeout=300)[0].strip().splitlines()[-1]) for p in procs]
+        wall = time.perf_counter() - t0
+        tm = float(np.median(ts))
+        out["aggregate_instances"] = {"instances": inst, "median_s_per_instance_nx100": tm, "slowdown_vs_alone": tm / t100,
+                                      "aggregate_value_extrapolated": inst / (t_full * tm / t100), "wall_s": wall}
+    except Exception as e:
+        out["aggregate_instances"] = {"error": str(e)}
+    return out
+
+
+def staged_small_sizes(local_rank):
+    """Extra information: the STAGED engine at the sizes the reference's Hqp_IpLQDOCP is timed at in
+    SURVEY.md section 6 (K=200, nu=10, CSR hand-over), next to the full-system engine on the same QPs."""
+    import torch
+    from hqp_amd import ipmatrix, problems
+    out = {}
+    try:
+        for nx in (50, 100, 200, 400):
+            prog = problems.lq_docp(200, nx, 10, seed=11)
+            st = [torch.as_tensor(a).cuda() for a in problems.ip_state(prog, 5, 1.0)]
+            row = {}
+            for name, cls in (("staged", ipmatrix.IpLQDOCP), ("full_engine", ipmatrix.IpLQDOCPFull)):
+                M = cls(device=local_rank, device_vectors=True)
+                M.init(prog)
+                d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
+                ts = []
+                for _ in range(4):
+                    torch.cuda.synchronize()
+                    t0 = time.perf_counter()
+                    M.factor(prog, st[0], st[1])
+                    res = M.solve(prog, *st, *d)
+                    ts.append(time.perf_counter() - t0)
+                row[name] = {"ms": 1e3 * float(np.median(ts[1:])), "residual": res}
+                del M
+            out[f"nx{nx}"] = row
+    except Exception as e:
+        out["error"] = str(e)
+    return out
+
+
+def bench_c4(args):
+    import torch
+    from hqp_amd import dist as kdist
+    rank, local_rank, world = kdist.env_world()
+    if args.share_gpu:
+        local_rank = 0
+    torch.cuda.set_device(local_rank)
+    if args.share_gpu and world > 1:
+        import torch.distributed as tdist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        tdist.init_process_group(args.backend)
+    else:
+        kdist.init(args.backend)
+    from hqp_amd import ipmatrix
+    K, nx, nu = args.stages, args.nx, args.nu
+    dq = c4_dense(K, nx, nu, seed=rank)
+    n, me, m = dq.dims
+    mat = ipmatrix.IpLQDOCP(device=local_rank, device_vectors=True)
+    t0 = time.perf_counter()
+    mat.init_dense(dq)
+    t_init = time.perf_counter() - t0
+    dq.F = None  # the engine holds its own copy of the blocks
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    rnd = lambda k, lo, hi: torch.empty(k, dtype=torch.float64, device="cuda").uniform_(lo, hi, generator=g)
+    z, w = rnd(m, 0.1, 1.1), rnd(m, 0.1, 1.1)
+    r = [rnd(k, -0.5, 0.5) for k in (n, me, m, m)]
+    d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (n, me, m, m)]
+
+    def step():
+        mat.factor(None, z, w)
+        return mat.solve(None, z, w, *r, *d)
+
+    for _ in range(args.warmup):
+        step()
+    kdist.fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    kdist.fence()
+    elapsed = kdist.max_over_ranks(time.perf_counter() - t0)
+    st = mat.stats()
+    # per-kernel-class device time: HIP events on the library's stream around every launch,
+    # in a separate untimed pass over the same workload
+    mat.set_profile(True)
+    nprof = max(2, min(args.steps, 3))
+    for _ in range(nprof):
+        step()
+    prof = mat.profile()
+    mat.set_profile(False)
+    if rank != 0:
+        return None
+    per_step = {k: v[0] / nprof for k, v in prof.items() if v[1]}
+    launches = {k: v[1] / nprof for k, v in prof.items() if v[1]}
+    nz, np1 = nx + nu, nx
+    # algorithmic work of the recursion per factorisation (DESIGN.md section 4)
+    flops_big = K * (2.0 * np1 * np1 * nz + 1.0 * np1 * nz * nz)          # W = V+ F ; G = F'W (lower half)
+    q = nu
+    flops_upd = K * (2.0 * q * q * nx + 1.0 * q * nx * nx)                 # Rm = K^-1 Y ; V = Gxx - Y'Rm (lower half)
+    bytes_gemv = K * 8.0 * (2.0 * np1 * np1 + 2.0 * np1 * nz + 2.0 * q * nx) * (1 + st["refine_rounds"])
+    gemm_ms, gemm_launch = per_step.get("staged_gemm", 0.0), launches.get("staged_gemm", 1.0)
+    achieved = flops_big / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_c4.json")
+    if os.path.exists(pmc) and (K, nx, nu) == (200, 5000, 50):
+        traffic = json.load(open(pmc)).get("k_dgemm_tn", {}).get("hbm_bytes_per_launch")
+    roofline = {"kernel": "k_dgemm_tn<128,128>", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS if achieved else None, "traffic": traffic,
+                "launches_per_step": gemm_launch, "avg_launch_ms": gemm_ms / gemm_launch if gemm_launch else None,
+                "algorithmic_flops_per_launch": flops_big / gemm_launch if gemm_launch else None,
+                "algorithmic_flops_per_step": flops_big,
+                "algorithmic_bytes_per_launch": 8.0 * (np1 * np1 + 2 * np1 * nz + nz * nz / 2) / 2}
+    kernels = {
+        "staged_gemm": {"ms_per_step": gemm_ms, "launches_per_step": gemm_launch, "tflops": achieved,
+                        "frac_fp64_peak": achieved / FP64_PEAK_TFLOPS if achieved else None},
+        "staged_gemm_upd": {"ms_per_step": per_step.get("staged_gemm_upd"), "launches_per_step": launches.get("staged_gemm_upd"),
+                            "tflops": flops_upd / (per_step["staged_gemm_upd"] * 1e-3) / 1e12 if per_step.get("staged_gemm_upd") else None},
+        "staged_gemv": {"ms_per_step": per_step.get("staged_gemv"), "launches_per_step": launches.get("staged_gemv"),
+                        "gbs": bytes_gemv / (per_step["staged_gemv"] * 1e-3) / 1e9 if per_step.get("staged_gemv") else None,
+                        "frac_hbm_peak": bytes_gemv / (per_step["staged_gemv"] * 1e-3) / 1e9 / HBM_PEAK_GBS if per_step.get("staged_gemv") else None},
+        "staged_small": {"ms_per_step": per_step.get("staged_small"), "launches_per_step": launches.get("staged_small")},
+        "residual": {"ms_per_step": per_step.get("residual"), "launches_per_step": launches.get("residual")},
+    }
+    fac_ms = sum(per_step.get(k, 0.0) for k in ("staged_gemm", "staged_gemm_upd", "staged_small", "assemble"))
+    out = {
+        "metric": "KKT factor+solve/sec (fp64)",
+        "value": args.steps * world / elapsed,
+        "unit": "KKT factor+solve/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f64",
+        "data": "synthetic",
+        "vectors": "resident in HBM",
+        "config": {"workload": f"C4 = BASELINE configs[3], the metric's 10^6-variable DOCP: multistage LQ optimal control QP, K={K} stages, "
+                               f"nx={nx} states, nu={nu} controls -> n={n} me={me} m={m}, dense fx/fu handed over as blocks, x_0 fixed, "
+                               f"box bounds on u; plugin LQDOCP (STAGED engine), one system per GPU",
+                   "stages": K, "nx": nx, "nu": nu, "n": n, "me": me, "m": m, "plugin": "LQDOCP",
+                   "kkt_dim_full": n + me + m, "hbm_gb": (st["bytes_panels"] + st["bytes_updates"]) / 1e9},
+        "residual": res,
+        "refine_rounds": st["refine_rounds"],
+        "init_s": t_init,
+        "ms_factor": st["ms_factor"], "ms_solve": st["ms_solve"],
+        "kernel_ms_per_step": per_step,
+        "kernel_launches_per_step": launches,
+        "kernels": kernels,
+        "factor_model": {"flops_as_implemented": st["flops_factor"], "factor_ms": fac_ms,
+                         "tflops_whole_factor": st["flops_factor"] / (st["ms_factor"] * 1e-3) / 1e12 if st["ms_factor"] else None,
+                         "frac_fp64_peak_whole_factor": st["flops_factor"] / (st["ms_factor"] * 1e-3) / 1e12 / FP64_PEAK_TFLOPS
+                         if st["ms_factor"] else None},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline_c4(K, nx, nu)
+        out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        del mat
+        torch.cuda.empty_cache()
+        out["staged_small_sizes"] = staged_small_sizes(local_rank)
+        # round 1's headline workload (BASELINE configs[1]) through the full-system engine
+        a2 = argparse.Namespace(**vars(args))
+        a2.steps, a2.warmup = min(args.steps, 10), min(args.warmup, 2)
+        c2 = bench_c2(a2, extras=False)
+        out["c2_banded_kkt"] = {k: c2[k] for k in ("value", "unit", "ms_per_step", "residual", "roofline", "init_s")} if c2 else None
+        out["ip_iterations"] = ip_iterations(2000)
+    return out
+
+
+
+def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2"],
+                    help="c4: 10^6-variable multistage DOCP, STAGED engine (the metric's own configuration); "
+                         "c2: banded KKT system of dim 10^5, full-system engine")
+    ap.add_argument("--stages", type=int, default=200, help="c4: K")
+    ap.add_argument("--nx", type=int, default=5000, help="c4: states per stage")
+    ap.add_argument("--nu", type=int, default=50, help="c4: controls per stage")
     ap.add_argument("--n", type=int, default=40000, help="x variables (C2: 40000)")
     ap.add_argument("--band", type=int, default=80, help="semi-bandwidth of Q / row width of A (C2: 80)")
     ap.add_argument("--mode", default="SpBKP", choices=["SpBKP", "RedSpBKP"])
@@ -215,7 +511,13 @@ def main():
     ap.add_argument("--leaf-size", type=int, default=0)
     ap.add_argument("--max-pivots", type=int, default=0)
     args = ap.parse_args()
+    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
+                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+    return args
 
+
+def bench_c2(args, extras=True):
     import torch
 
     from hqp_amd import dist as kdist
@@ -305,7 +607,7 @@ def main():
             # HBM bytes per launch of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
             # this same command (separate runs, gfx950 corrections applied; see profiles/README.md)
             traffic = json.load(open(pmc)).get("k_" + dom, {}).get("hbm_bytes_per_launch")
-        roofline = {"kernel": "k_" + dom, "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+        roofline = {"kernel": "k_" + dom, "bound": "latency" if dom == "factor_diag" else "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                     "launches_per_step": launches[dom], "avg_launch_ms": dom_launch_ms,
                     "algorithmic_flops_per_step": work[dom]["flops"]}
@@ -349,13 +651,22 @@ def main():
             "factor_model": model,
             "roofline": roofline,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and extras:
             out["cpu_baseline"] = cpu_baseline(prog, state)
             out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
             if not args.host_vectors:
                 out["concurrent_systems_per_gpu"] = concurrent_systems(prog, state, cls, local_rank, args.steps)
             out["ip_iterations"] = ip_iterations(2000)
             out["ip_iterations_large"] = ip_iterations(33333)
+        return out
+    return None
+
+
+def main():
+    args = parse_args()
+    from hqp_amd import dist as kdist
+    out = bench_c4(args) if args.workload == "c4" else bench_c2(args)
+    if out is not None:
         print(json.dumps(out))
     kdist.finalize()
 

@@ -81,10 +81,10 @@ struct CsrBuf {
 // per-kernel-class device timing (hqpkkt_set_profile): HIP events on the
 // handle's stream around every launch, summed per class after the call
 enum { KC_ASSEMBLE = 0, KC_FACTOR_DIAG, KC_PANEL_SOLVE, KC_SCHUR_UPDATE,
-       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_ST_GEMM, KC_ST_SMALL, KC_ST_VEC, KC_COUNT };
+       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_ST_GEMM, KC_ST_SMALL, KC_ST_VEC, KC_ST_GEMM_UPD, KC_COUNT };
 static const char *const kc_names[KC_COUNT] = {"assemble", "factor_diag", "panel_solve",
                                                "schur_update", "solve_fwd", "solve_bwd", "vector",
-                                               "residual", "staged_gemm", "staged_small", "staged_gemv"};
+                                               "residual", "staged_gemm", "staged_small", "staged_gemv", "staged_gemm_upd"};
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;

@@ -45,16 +45,16 @@ inline StagePtr stage_ptr(StagedDev &d, int k) {
 }
 
 // C = alpha A'B + beta Cin on the handle's stream; 128 x 128 tiles for large products, 64 x 64 below
-int st_gemm(hqpkkt_t *h, stg::GemmArgs g) {
+int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM) {
   if (g.M <= 0 || g.N <= 0) return 0;
   const bool big = stg::gemm_big_tiles(g.M, g.N, g.lower);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
   const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
   if (big)
-    KLAUNCH(h, KC_ST_GEMM, stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
+    KLAUNCH(h, cls, stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
   else
-    KLAUNCH(h, KC_ST_GEMM, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
+    KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
   return 0;
 }
 
@@ -279,7 +279,7 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     // carried rows: N_k[e..] = B+ F
     if (P.cap[k + 1] > 0 &&
         (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, P.ldf[k], nullptr, 0, sp.N + (size_t)ek * P.ldn[k], P.ldn[k],
-                                      P.cap[k + 1], nz, np, 1.0, 0.0, 0, 0})))
+                                      P.cap[k + 1], nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD)))
       return e;
     stg::SmallArgs sa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
                       P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.T, P.ldt[k], sp.dyn, h->flags.p};
@@ -290,9 +290,10 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     // Rm = K^-1 Y ; V = Gxx - Y'Rm (lower tiles, mirrored)
     if (P.qmax[k] > 0 &&
         (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, P.ldy[k], nullptr, 0, sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
-                                      1.0, 0.0, 0, 0})))
+                                      1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD)))
       return e;
-    if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1})))
+    if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1},
+                     KC_ST_GEMM_UPD)))
       return e;
   }
   {
