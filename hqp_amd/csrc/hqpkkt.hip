@@ -1991,17 +1991,36 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
   (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(128, 128));
   (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(64, 64));
+  // stream-K form where the engine would use it (staged_host.hip.h, st_gemm)
+  int cus = 0;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  const int skg = 2 * cus;
+  const bool use_sk = big && cus > 0 && tiles > skg && tiles % skg != 0 && !getenv("HQPKKT_NO_STREAMK");
+  double *skws = nullptr;
+  unsigned *skcnt = nullptr;
+  if (use_sk) {
+    (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_sk_lds_bytes());
+    if (hipMalloc((void **)&skws, sizeof(double) * (size_t)skg * 2 * 128 * 128) != hipSuccess ||
+        hipMalloc((void **)&skcnt, sizeof(unsigned) * (skg + 4)) != hipSuccess) {
+      (void)hipFree(skws), (void)hipFree(skcnt);
+      return fin(HQPKKT_E_MEM);
+    }
+  }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
   for (int r = -1; r < reps; r++) {
     if (r == 0) (void)hipEventRecord(e0, 0);
-    if (big)
+    if (use_sk) {
+      (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (skg + 4), 0);
+      stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, stg::StreamK{skws, skcnt, (int)tiles, (int)(tiles / skg) - 1});
+    } else if (big)
       stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
     else
       stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64)>>>(g);
   }
   (void)hipEventRecord(e1, 0);
   hipError_t se = hipDeviceSynchronize();
+  (void)hipFree(skws), (void)hipFree(skcnt);
   float t = 0.f;
   (void)hipEventElapsedTime(&t, e0, e1);
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);

@@ -61,121 +61,227 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // flight while slab t is multiplied), fragments LDS -> registers with ds_read_b64, conflict
 // free because an LDS row is BM + 16 doubles (rows k, k+1 of a fragment: banks 32 apart).
 template <int BM, int BN>
-__global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
-  constexpr int BK = GEMM_BK;
-  constexpr int LDA = BM + 16, LDB = BN + 16;
-  constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
-  constexpr int LA = BK * BM / 2 / 256, LB = BK * BN / 2 / 256;  // 16-byte loads per thread and slab
-  constexpr int RA = 256 / (BM / 2), RB = 256 / (BN / 2);        // slab rows covered by one pass
-  extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 * BK * (LDA + LDB) doubles
-  double *As = lds, *Bs = lds + 2 * BK * LDA;
+struct GemmTile {
+  static constexpr int BK = GEMM_BK;
+  static constexpr int LDA = BM + 16, LDB = BN + 16;
+  static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  static constexpr int LA = BK * BM / 2 / 256, LB = BK * BN / 2 / 256;  // 16-byte loads per thread and slab
+  static constexpr int RA = 256 / (BM / 2), RB = 256 / (BN / 2);        // slab rows covered by one pass
 
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int lr = lane & 15, lk = lane >> 4;
-
-  // tile of this workgroup
-  int t = xcd_swizzle(blockIdx.x, gridDim.x);
-  int tm, tn;
-  const int tiles_n = (g.N + BN - 1) / BN;
-  if (g.lower) {
-    tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-    while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
-    while (tm * (tm + 1) / 2 > t) tm--;
-    tn = t - tm * (tm + 1) / 2;
-  } else {
-    const int tiles_m = (g.M + BM - 1) / BM;
-    constexpr int GM = 8;  // tile rows walked together: their A panels stay in L2
-    const int grp = t / (GM * tiles_n), first = grp * GM;
-    const int rows = min(GM, tiles_m - first);
-    const int in = t - grp * GM * tiles_n;
-    tm = first + in % rows;
-    tn = in / rows;
-  }
-  const int i0 = tm * BM, j0 = tn * BN;
-
-  // global -> register staging: thread covers columns ca, ca+1 of rows ra + p*RA
-  const int ca = 2 * (tid % (BM / 2)), ra = tid / (BM / 2);
-  const int cb = 2 * (tid % (BN / 2)), rb = tid / (BN / 2);
-  // a 16-byte load is inside its row when its first column is < ld (ld even)
-  const long long acol = (i0 + ca < g.lda) ? i0 + ca : 0;
-  const long long bcol = (j0 + cb < g.ldb) ? j0 + cb : 0;
-  double2_t sa[LA], sb[LB];
-  auto gload = [&](int k0) {
-#pragma unroll
-    for (int p = 0; p < LA; p++) {
-      const int k = k0 + ra + p * RA;
-      const int kc = k < g.K ? k : g.K - 1;
-      double2_t v = *(const double2_t *)(g.A + (long long)kc * g.lda + acol);
-      if (k >= g.K) v = (double2_t){0.0, 0.0};
-      sa[p] = v;
+  // tile index -> (tile row, tile column)
+  static __device__ __forceinline__ void tile_of(const GemmArgs &g, int t, int &tm, int &tn) {
+    if (g.lower) {
+      tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+      while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
+      while (tm * (tm + 1) / 2 > t) tm--;
+      tn = t - tm * (tm + 1) / 2;
+    } else {
+      const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
+      constexpr int GM = 8;  // tile rows walked together: their A panels stay in L2
+      const int grp = t / (GM * tiles_n), first = grp * GM;
+      const int rows = min(GM, tiles_m - first);
+      const int in = t - grp * GM * tiles_n;
+      tm = first + in % rows;
+      tn = in / rows;
     }
-#pragma unroll
-    for (int p = 0; p < LB; p++) {
-      const int k = k0 + rb + p * RB;
-      const int kc = k < g.K ? k : g.K - 1;
-      double2_t v = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
-      if (k >= g.K) v = (double2_t){0.0, 0.0};
-      sb[p] = v;
-    }
-  };
-  auto lstore = [&](int buf) {
-#pragma unroll
-    for (int p = 0; p < LA; p++) *(double2_t *)(As + (buf * BK + ra + p * RA) * LDA + ca) = sa[p];
-#pragma unroll
-    for (int p = 0; p < LB; p++) *(double2_t *)(Bs + (buf * BK + rb + p * RB) * LDB + cb) = sb[p];
-  };
-
-  double4_t acc[TM][TN];
-#pragma unroll
-  for (int x = 0; x < TM; x++)
-#pragma unroll
-    for (int y = 0; y < TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
-
-  const int nslab = (g.K + BK - 1) / BK;
-  if (nslab > 0) {
-    gload(0);
-    lstore(0);
-  }
-  __syncthreads();
-  for (int s = 0; s < nslab; s++) {
-    const int buf = s & 1;
-    if (s + 1 < nslab) gload((s + 1) * BK);
-    const double *Ab = As + buf * BK * LDA + wm * WM + lr;
-    const double *Bb = Bs + buf * BK * LDB + wn * WN + lr;
-#pragma unroll
-    for (int ks = 0; ks < BK / 4; ks++) {
-      double af[TM], bf[TN];
-#pragma unroll
-      for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * LDA + 16 * x];
-#pragma unroll
-      for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * LDB + 16 * y];
-#pragma unroll
-      for (int x = 0; x < TM; x++)
-#pragma unroll
-        for (int y = 0; y < TN; y++) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
-    }
-    if (s + 1 < nslab) lstore(buf ^ 1);
-    __syncthreads();
   }
 
-  // epilogue
-  const bool diag = g.lower && tm == tn;
+  // acc += sum over the slabs [s0, s1) of the tile at (i0, j0); ends with a barrier (LDS free again)
+  static __device__ __forceinline__ void accumulate(const GemmArgs &g, int i0, int j0, int s0, int s1,
+                                                    double4_t (&acc)[TM][TN], double *As, double *Bs) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    // global -> register staging: thread covers columns ca, ca+1 of rows ra + p*RA
+    const int ca = 2 * (tid % (BM / 2)), ra = tid / (BM / 2);
+    const int cb = 2 * (tid % (BN / 2)), rb = tid / (BN / 2);
+    // a 16-byte load is inside its row when its first column is < ld (ld even)
+    const long long acol = (i0 + ca < g.lda) ? i0 + ca : 0;
+    const long long bcol = (j0 + cb < g.ldb) ? j0 + cb : 0;
+    double2_t sa[LA], sb[LB];
+    auto gload = [&](int k0) {
 #pragma unroll
-  for (int x = 0; x < TM; x++)
-#pragma unroll
-    for (int y = 0; y < TN; y++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        const int i = i0 + wm * WM + 16 * x + lk + 4 * rg, j = j0 + wn * WN + 16 * y + lr;
-        if (i >= g.M || j >= g.N) continue;
-        if (diag && g.mirror && i < j) continue;
-        double v = g.alpha * acc[x][y][rg];
-        if (g.beta != 0.0) v += g.beta * g.Cin[(long long)i * g.ldcin + j];
-        g.C[(long long)i * g.ldc + j] = v;
-        if (g.mirror && i != j) g.C[(long long)j * g.ldc + i] = v;
+      for (int p = 0; p < LA; p++) {
+        const int k = k0 + ra + p * RA;
+        const int kc = k < g.K ? k : g.K - 1;
+        double2_t v = *(const double2_t *)(g.A + (long long)kc * g.lda + acol);
+        if (k >= g.K) v = (double2_t){0.0, 0.0};
+        sa[p] = v;
       }
+#pragma unroll
+      for (int p = 0; p < LB; p++) {
+        const int k = k0 + rb + p * RB;
+        const int kc = k < g.K ? k : g.K - 1;
+        double2_t v = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
+        if (k >= g.K) v = (double2_t){0.0, 0.0};
+        sb[p] = v;
+      }
+    };
+    auto lstore = [&](int buf) {
+#pragma unroll
+      for (int p = 0; p < LA; p++) *(double2_t *)(As + (buf * BK + ra + p * RA) * LDA + ca) = sa[p];
+#pragma unroll
+      for (int p = 0; p < LB; p++) *(double2_t *)(Bs + (buf * BK + rb + p * RB) * LDB + cb) = sb[p];
+    };
+    if (s1 > s0) {
+      gload(s0 * BK);
+      lstore(0);
+    }
+    __syncthreads();
+    for (int s = s0; s < s1; s++) {
+      const int buf = (s - s0) & 1;
+      if (s + 1 < s1) gload((s + 1) * BK);
+      const double *Ab = As + buf * BK * LDA + wm * WM + lr;
+      const double *Bb = Bs + buf * BK * LDB + wn * WN + lr;
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ks++) {
+        double af[TM], bf[TN];
+#pragma unroll
+        for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * LDA + 16 * x];
+#pragma unroll
+        for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * LDB + 16 * y];
+#pragma unroll
+        for (int x = 0; x < TM; x++)
+#pragma unroll
+          for (int y = 0; y < TN; y++) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+      }
+      if (s + 1 < s1) lstore(buf ^ 1);
+      __syncthreads();
+    }
+  }
+
+  static __device__ __forceinline__ void epilogue(const GemmArgs &g, int tm, int tn, const double4_t (&acc)[TM][TN]) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    const int i0 = tm * BM, j0 = tn * BN;
+    const bool diag = g.lower && tm == tn;
+#pragma unroll
+    for (int x = 0; x < TM; x++)
+#pragma unroll
+      for (int y = 0; y < TN; y++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const int i = i0 + wm * WM + 16 * x + lk + 4 * rg, j = j0 + wn * WN + 16 * y + lr;
+          if (i >= g.M || j >= g.N) continue;
+          if (diag && g.mirror && i < j) continue;
+          double v = g.alpha * acc[x][y][rg];
+          if (g.beta != 0.0) v += g.beta * g.Cin[(long long)i * g.ldcin + j];
+          g.C[(long long)i * g.ldc + j] = v;
+          if (g.mirror && i != j) g.C[(long long)j * g.ldc + i] = v;
+        }
+  }
+};
+
+template <int BM, int BN>
+__global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
+  using T = GemmTile<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 * BK * (LDA + LDB) doubles
+  double *As = lds, *Bs = lds + 2 * T::BK * T::LDA;
+  int tm, tn;
+  T::tile_of(g, xcd_swizzle(blockIdx.x, gridDim.x), tm, tn);
+  double4_t acc[T::TM][T::TN];
+#pragma unroll
+  for (int x = 0; x < T::TM; x++)
+#pragma unroll
+    for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  T::accumulate(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
+  T::epilogue(g, tm, tn, acc);
 }
+
+// The same product for tile counts that do not divide by the chip (1600 tiles on 512 workgroup
+// slots: the last of four rounds would be an eighth full).  A fixed grid of workgroups shares the
+// (tile, k-slab) units evenly: every workgroup runs a contiguous range of them in tile order, i.e.
+// the tail of one tile, whole tiles, the head of another one.  A tile that two workgroups share
+// (never more: a workgroup's range is longer than a tile) is finished by whichever of the two
+// arrives second: both park their partial sums (plain stores, then an agent-scope release and one
+// counter add); the second one adds the other's to its own - a + b = b + a, so the result does
+// not depend on the order of arrival - and writes the tile.  Nobody waits for anybody.
+struct StreamK {
+  double *ws;     // 2 slots of 128 x 128 doubles per workgroup: [0] its first, [1] its last partial tile
+  unsigned *cnt;  // per boundary between workgroups v-1 | v (zeroed before every launch)
+  int tiles;
+  int dp_rounds;  // leading rounds of whole tiles, one per workgroup and round (all workgroups at the same
+                  // k: neighbours share their operand panels in L2); the rest is shared by units
+};
+__global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) {
+  constexpr int BM = 128, BN = 128;
+  using T = GemmTile<BM, BN>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // tiles + one word for the arrival order
+  double *As = lds, *Bs = lds + 2 * T::BK * T::LDA;
+  unsigned *s_old = (unsigned *)(lds + 2 * T::BK * (T::LDA + T::LDB));
+  const int G = gridDim.x, v = xcd_swizzle(blockIdx.x, G);
+  const int nslab = (g.K + T::BK - 1) / T::BK;
+  for (int r = 0; r < sk.dp_rounds; r++) {
+    int tm, tn;
+    T::tile_of(g, r * G + v, tm, tn);
+    double4_t acc[T::TM][T::TN];
+#pragma unroll
+    for (int x = 0; x < T::TM; x++)
+#pragma unroll
+      for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    T::accumulate(g, tm * BM, tn * BN, 0, nslab, acc, As, Bs);
+    T::epilogue(g, tm, tn, acc);
+  }
+  const int t_first = sk.dp_rounds * G;
+  const long long U = (long long)(sk.tiles - t_first) * nslab, per = U / G, rem = U % G;
+  long long u = v * per + (v < rem ? v : rem);
+  const long long u1 = u + per + (v < rem ? 1 : 0);
+  constexpr int SLOT = BM * BN;
+  while (u < u1) {
+    const int tl = (int)(u / nslab), s0 = (int)(u - (long long)tl * nslab), t = t_first + tl;
+    const int s1 = (int)((long long)nslab < s0 + (u1 - u) ? nslab : s0 + (u1 - u));
+    int tm, tn;
+    T::tile_of(g, t, tm, tn);
+    double4_t acc[T::TM][T::TN];
+#pragma unroll
+    for (int x = 0; x < T::TM; x++)
+#pragma unroll
+      for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+    T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
+    bool finish = true;
+    if (s0 > 0 || s1 < nslab) {
+      // shared tile: s0 > 0 -> with workgroup v-1 (this is my first range), else with v+1 (my last)
+      const bool first = s0 > 0;
+      double *mine = sk.ws + ((long long)v * 2 + (first ? 0 : 1)) * SLOT;
+      const double *theirs = sk.ws + ((long long)(first ? v - 1 : v + 1) * 2 + (first ? 1 : 0)) * SLOT;
+      unsigned *counter = sk.cnt + (first ? v : v + 1);
+#pragma unroll
+      for (int x = 0; x < T::TM; x++)
+#pragma unroll
+        for (int y = 0; y < T::TN; y++)
+#pragma unroll
+          for (int rg = 0; rg < 4; rg++) mine[((x * T::TN + y) * 4 + rg) * 256 + threadIdx.x] = acc[x][y][rg];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      if (threadIdx.x == 0) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        *s_old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      finish = *s_old == 1u;
+      if (finish) {
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        }
+        __syncthreads();
+#pragma unroll
+        for (int x = 0; x < T::TM; x++)
+#pragma unroll
+          for (int y = 0; y < T::TN; y++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++)
+              acc[x][y][rg] += theirs[((x * T::TN + y) * 4 + rg) * 256 + threadIdx.x];
+      }
+      __syncthreads();  // s_old is rewritten at the next shared tile
+    }
+    if (finish) T::epilogue(g, tm, tn, acc);
+    u += s1 - s0;
+  }
+}
+static inline size_t gemm_sk_lds_bytes() { return gemm_lds_bytes(128, 128) + 16; }
 
 // ---------------------------------------------------------------------------------------
 // H = Q + C'(Z/W)C of one stage added into the dense block (term lists as in the REDUCED
@@ -245,26 +351,26 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax *red) {
 // In-place inverse of the q x q matrix a (LDS, leading dimension ld) by Gauss-Jordan
 // elimination with complete pivoting.  Returns 0, or 1 when a pivot is exactly zero / NaN.
 // ip, ir, ic: int work arrays of q entries; colv, rowv: double work arrays of q entries.
+// 256 threads as a 16 x 16 grid: thread (ty, tx) owns the entries (ty + 16 i, tx + 16 j); the
+// pivot search of step s+1 rides on the update sweep of step s.
 __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv,
                           ArgMax *red) {
   const int tid = threadIdx.x, nt = blockDim.x;
+  const int ty = tid >> 4, tx = tid & 15;
+  const double INF = __longlong_as_double(0x7ff0000000000000LL);
   for (int j = tid; j < q; j += nt) ip[j] = 0;
   __syncthreads();
   int bad = 0;
-  for (int s = 0; s < q; s++) {
-    ArgMax best{-1.0, 0x7fffffff};
-    for (int e = tid; e < q * q; e += nt) {
-      const int r = e / q, c = e - r * q;
-      if (ip[r] == 0 && ip[c] == 0) {
-        const double v = fabs(a[r * ld + c]);
-        ArgMax cand{v == v ? v : __longlong_as_double(0x7ff0000000000000LL), e};
-        best = better(best, cand);
-      }
+  ArgMax best{-1.0, 0x7fffffff};
+  for (int r = ty; r < q; r += 16)
+    for (int c = tx; c < q; c += 16) {
+      const double v = fabs(a[r * ld + c]);
+      best = better(best, ArgMax{v == v ? v : INF, r * q + c});
     }
+  for (int s = 0; s < q; s++) {
     best = block_argmax(best, red);
     const int irow = best.i / q, icol = best.i - irow * q;
-    if (!(best.v > 0.0) || best.v == __longlong_as_double(0x7ff0000000000000LL)) bad = 1;
-    __syncthreads();
+    if (!(best.v > 0.0) || best.v == INF) bad = 1;
     if (irow != icol)
       for (int c = tid; c < q; c += nt) {
         const double x = a[irow * ld + c];
@@ -281,15 +387,25 @@ __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, d
       rowv[c] = (c == icol ? 1.0 : a[icol * ld + c]) * pinv;
     }
     __syncthreads();
-    for (int e = tid; e < q * q; e += nt) {
-      const int r = e / q, c = e - r * q;
-      if (r == icol)
-        a[e / q * ld + c] = rowv[c];
-      else
-        a[r * ld + c] = (c == icol ? 0.0 : a[r * ld + c]) - rowv[c] * colv[r];
+    best = ArgMax{-1.0, 0x7fffffff};
+    for (int r = ty; r < q; r += 16) {
+      const double cr = colv[r];
+      const bool rfree = ip[r] == 0;
+      for (int c = tx; c < q; c += 16) {
+        double v;
+        if (r == icol)
+          v = rowv[c];
+        else
+          v = (c == icol ? 0.0 : a[r * ld + c]) - rowv[c] * cr;
+        a[r * ld + c] = v;
+        if (rfree && ip[c] == 0) {
+          const double av = fabs(v);
+          best = better(best, ArgMax{av == av ? av : INF, r * q + c});
+        }
+      }
     }
-    __syncthreads();
   }
+  __syncthreads();
   for (int s = q - 1; s >= 0; s--) {
     const int r1 = ir[s], c1 = ic[s];
     if (r1 != c1)
@@ -587,6 +703,19 @@ __global__ void __launch_bounds__(256) k_st_gemv_rows(GemvRows g) {
   s = kktdev::wave_sum(s);
   if (lane == 0) g.y[row] = g.scale * ((g.add ? g.add[row] : 0.0) + s);
 }
+// the same for few, long rows (Rm x with a handful of controls and thousands of states): one
+// workgroup per row, so that a row's bytes are in flight from 256 threads
+__global__ void __launch_bounds__(256) k_st_gemv_wide(GemvRows g) {
+  __shared__ double red[4];
+  const int row = blockIdx.x;
+  const double *ar = g.A + (long long)row * g.lda;
+  double s = 0.0;
+  for (int j = threadIdx.x; j < g.N; j += 256) s += ar[j] * g.x[j];
+  s = kktdev::wave_sum(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) g.y[row] = g.scale * ((g.add ? g.add[row] : 0.0) + ((red[0] + red[1]) + (red[2] + red[3])));
+}
 // columns form: part[s][j] = sum over the rows k of chunk s of A[k][j] x[k]; with one chunk the
 // result y[j] = add[j] + alpha * sum is written directly
 struct GemvCols {
@@ -672,8 +801,8 @@ __global__ void __launch_bounds__(256) k_st_bwd_small(BwdSmall a) {
   __syncthreads();
   for (int i = tid; i < a.qmax; i += nt) {
     double s = 0.0;
-    if (i < q)
-      for (int j = 0; j < q; j++) s += a.Kinv[(long long)i * a.ldq + j] * y0[j];
+    if (i < q)  // K^-1 is stored symmetric: column i, so that neighbouring threads read neighbouring words
+      for (int j = 0; j < q; j++) s += a.Kinv[(long long)j * a.ldq + i] * y0[j];
     a.rho[i] = s;
   }
   for (int li = tid; li < a.cap; li += nt) {
@@ -691,10 +820,7 @@ __global__ void __launch_bounds__(256) k_st_bwd_small(BwdSmall a) {
 //   own rows -> dy, carried rows -> eta of stage k+1
 struct FwdSmall {
   int n, m, e, capn, cap, qmax;
-  const double *Rm;
-  long long ldy;
-  const double *x;     // x_k (inside the s vector)
-  const double *rho;
+  const double *uy;    // -(Rm x_k + rho), qmax entries (k_st_gemv_wide)
   const double *t;
   long long ldt;
   const int *dyn;
@@ -707,19 +833,11 @@ struct FwdSmall {
 };
 __global__ void __launch_bounds__(256) k_st_fwd_small(FwdSmall a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int tid = threadIdx.x, nt = blockDim.x, lane = tid & 63;
+  const int tid = threadIdx.x, nt = blockDim.x;
   const int r = a.dyn[0], nl = a.dyn[1];
   const int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
-  const int q = a.m + r;
-  double *uy = sm, *yN = sm + a.qmax + 1;
-  for (int i = tid >> 6; i < q; i += nt >> 6) {
-    double s = 0.0;
-    const double *rr = a.Rm + (long long)i * a.ldy;
-    for (int j = lane; j < a.n; j += 64) s += rr[j] * a.x[j];
-    s = kktdev::wave_sum(s);
-    if (lane == 0) uy[i] = -(s + a.rho[i]);
-  }
-  __syncthreads();
+  const double *uy = a.uy;
+  double *yN = sm;
   for (int i = tid; i < a.m; i += nt) a.u[i] = uy[i];
   for (int s = tid; s < r; s += nt) {
     double v = uy[a.m + s];

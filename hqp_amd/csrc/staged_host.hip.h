@@ -12,12 +12,15 @@ struct StagedDev {
   DBuf<stg::HTerm> h_terms;
   DBuf<stg::DynDesc> dyn_desc;  // dense dynamics: per stage (K+1) what k_st_dyn_ax / _aty need
   DBuf<double> dyn_x1, dyn_x2;  // A_dyn' dy (n), A_dyn dx (ndyn)
+  DBuf<double> sk_ws;           // stream-K dgemm: two partial tiles per workgroup
+  DBuf<unsigned> sk_cnt;
+  int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
   size_t lds_small = 0, lds_init = 0;
   void release() {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
-    dyn_desc.release(), dyn_x1.release(), dyn_x2.release();
+    dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release();
   }
 };
 
@@ -51,6 +54,14 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM) {
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
   const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
+  StagedDev *d = h->sd;
+  if (big && d && d->sk_grid > 0 && tiles > d->sk_grid && tiles % d->sk_grid != 0) {
+    // tile count not a multiple of the chip: even shares of the (tile, k-slab) units (k_dgemm_tn_sk)
+    HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_grid + 4), h->stream));
+    stg::StreamK sk{d->sk_ws.p, d->sk_cnt.p, (int)tiles, (int)(tiles / d->sk_grid) - 1};
+    KLAUNCH(h, cls, stg::k_dgemm_tn_sk<<<d->sk_grid, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
+    return 0;
+  }
   if (big)
     KLAUNCH(h, cls, stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
   else
@@ -168,6 +179,20 @@ static int staged_upload(hqpkkt_t *h) {
   HIPCHK(hipMemset(d.V.p, 0, sizeof(double) * std::max<long long>(P.v_elems, 1)));
   HIPCHK(hipMemset(d.misc.p, 0, sizeof(double) * std::max<long long>(P.misc_elems, 1)));
   HIPCHK(hipMemset(d.dyn.p, 0, sizeof(int) * std::max(P.dyn_ints, 1)));
+  {  // stream-K grid: two workgroups per CU, if some product of the recursion has more tiles than that
+    int cus = 0;
+    HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->opts.device));
+    long long tmax = 0;
+    for (int k = 0; k < P.K; k++) {
+      const long long t1 = (P.nk[k + 1] + 127) / 128, t2 = (P.nk[k] + P.mk[k] + 127) / 128;
+      tmax = std::max(tmax, t1 * t2);
+    }
+    d.sk_grid = 0;
+    if (cus > 0 && tmax > 2LL * cus && !getenv("HQPKKT_NO_STREAMK")) {
+      d.sk_grid = 2 * cus;
+      if ((e = d.sk_ws.alloc((size_t)d.sk_grid * 2 * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_grid + 4))) return e;
+    }
+  }
   d.lds_small = 0;
   for (int k = 0; k < P.K; k++) d.lds_small = std::max(d.lds_small, stg::st_small_lds(P.mk[k], P.capn[k]));
   {
@@ -184,6 +209,8 @@ static int staged_upload(hqpkkt_t *h) {
                                  (int)stg::gemm_lds_bytes(128, 128)));
       HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)stg::gemm_lds_bytes(64, 64)));
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)stg::gemm_sk_lds_bytes()));
       attr_gemm = true;
     }
     if (d.lds_small > attr_small) {
@@ -355,9 +382,15 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
     const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
     double *xk = S + P.nmk[k];
-    stg::FwdSmall fa{nn, mm, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], sp.Rm, P.ldy[k], xk, sp.rho, sp.T, P.ldt[k],
+    // [u ; yhat] = -(Rm x + rho)
+    double *uy = M + P.oUy;
+    if (P.qmax[k] > 0) {
+      stg::GemvRows gr{sp.Rm, P.ldy[k], P.qmax[k], nn, xk, sp.rho, nullptr, 0, nullptr, nullptr, uy, -1.0};
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_wide<<<P.qmax[k], 256, 0, s>>>(gr));
+    }
+    stg::FwdSmall fa{nn, mm, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], uy, sp.T, P.ldt[k],
                      sp.dyn, sp.eta, d.eq_rows.p + P.eq_ptr[k], xk + nn, v.dy, sn.eta, P.cap[k + 1]};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_fwd_small<<<1, 256, sizeof(double) * (P.capn[k] + P.qmax[k] + 4), s>>>(fa));
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_fwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 4), s>>>(fa));
     // x+ = F s + f ; p = V+ x+ + v+ + B+' eta+
     if ((e = st_gemv_rows(h, stg::GemvRows{sp.F, P.ldf[k], np, nz, xk, v.r2 + P.nks[k], nullptr, 0, nullptr, nullptr, S + P.nmk[k + 1], 1.0})))
       return e;

@@ -202,6 +202,11 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   ldq0 = up8(std::max(q0max, 1));
   oK0 = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
   oGam = mo, mo += up16(nzmax + 8);
+  {
+    int qm = 1;
+    for (int k = 0; k < K; k++) qm = std::max(qm, qmax[k]);
+    oUy = mo, mo += up16(qm + 8);
+  }
   oTT = mo, mo += up16(nmax + 8);
   oTmp = mo, mo += up16(nmax + 8);
   part_chunks = std::max(1, std::min(64, nmax / 64));
