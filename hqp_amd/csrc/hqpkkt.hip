@@ -1986,22 +1986,22 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipMemset(err, 0, 8);
   (void)hipMemset(Cm, 0, sizeof(double) * (size_t)std::max(M, N) * ldc);
   stg::GemmArgs g{A, lda, B, ldb, nullptr, 0, Cm, ldc, M, N, K, 1.0, 0.0, lower, mirror};
-  const bool big = stg::gemm_big_tiles(M, N, lower);
+  int cus = 0;
+  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
+  const int skg = getenv("HQPKKT_NO_STREAMK") ? 0 : stg::gemm_streamk_grid(M, N, K, lower, 2 * cus);
+  const bool use_sk = skg > 0;
+  const bool big = use_sk || stg::gemm_big_tiles(M, N, lower);
   const int b = big ? 128 : 64;
   const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
   (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(128, 128));
   (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(64, 64));
   // stream-K form where the engine would use it (staged_host.hip.h, st_gemm)
-  int cus = 0;
-  (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  const int skg = 2 * cus;
-  const bool use_sk = big && cus > 0 && tiles > skg && tiles % skg != 0 && !getenv("HQPKKT_NO_STREAMK");
   double *skws = nullptr;
   unsigned *skcnt = nullptr;
   if (use_sk) {
     (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_sk_lds_bytes());
-    if (hipMalloc((void **)&skws, sizeof(double) * (size_t)skg * 2 * 128 * 128) != hipSuccess ||
-        hipMalloc((void **)&skcnt, sizeof(unsigned) * (skg + 4)) != hipSuccess) {
+    if (hipMalloc((void **)&skws, sizeof(double) * (size_t)(skg + 1) * 2 * 128 * 128) != hipSuccess ||
+        hipMalloc((void **)&skcnt, sizeof(unsigned) * (tiles + 4)) != hipSuccess) {
       (void)hipFree(skws), (void)hipFree(skcnt);
       return fin(HQPKKT_E_MEM);
     }
@@ -2011,8 +2011,8 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   for (int r = -1; r < reps; r++) {
     if (r == 0) (void)hipEventRecord(e0, 0);
     if (use_sk) {
-      (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (skg + 4), 0);
-      stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, stg::StreamK{skws, skcnt, (int)tiles, (int)(tiles / skg) - 1});
+      (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (tiles + 4), 0);
+      stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, stg::StreamK{skws, skcnt, (int)tiles, std::max(0, (int)(tiles / skg) - 1)});
     } else if (big)
       stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
     else

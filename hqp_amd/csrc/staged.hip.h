@@ -17,6 +17,8 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
+
 namespace stg {
 
 using kktdev::double4_t;
@@ -47,6 +49,24 @@ static inline size_t gemm_lds_bytes(int bm, int bn) { return sizeof(double) * 2 
 static inline bool gemm_big_tiles(int M, int N, int lower) {
   const long long tm = (M + 127) / 128, tn = (N + 127) / 128;
   return (lower ? tm * (tm + 1) / 2 : tm * tn) >= 384;
+}
+
+// The stream-K form (k_dgemm_tn_sk) pays where whole rounds of 128 x 128 tiles would leave slots idle
+// and the product is deep enough to be worth sharing.  Returns the grid to launch (0: use the plain
+// kernels): all `grid` workgroups when there are more tiles than that; for fewer tiles at most 8
+// workgroups per tile (the last arriver reads the others' partial sums one after the other) and at
+// least 96 k-slabs per workgroup (parking and adding the partial sums costs as much as ~20 slabs:
+// measured, shares of 8 .. 40 slabs were slower than the plain 64 x 64 tiles).
+static inline int gemm_streamk_grid(int M, int N, int K, int lower, int grid) {
+  if (grid <= 0 || (long long)M * N < 256LL * 256) return 0;
+  const long long tm = (M + 127) / 128, tn = (N + 127) / 128, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
+  const long long nslab = (K + GEMM_BK - 1) / GEMM_BK;
+  if (tiles % grid == 0 || tiles >= 8LL * grid) return 0;  // even, or the tail does not matter
+  if (tiles > grid) return grid;
+  const long long gl = std::min<long long>(std::min<long long>(grid, tiles * 8), tiles * nslab / 96);
+  // worth it only with clearly more workgroups than tiles
+  if (gl * 2 < tiles * 3) return 0;
+  return (int)gl;
 }
 
 // blockIdx -> position in a sequence in which the workgroups of one XCD (blockIdx % 8) are
@@ -189,20 +209,21 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
   T::epilogue(g, tm, tn, acc);
 }
 
-// The same product for tile counts that do not divide by the chip (1600 tiles on 512 workgroup
-// slots: the last of four rounds would be an eighth full).  A fixed grid of workgroups shares the
-// (tile, k-slab) units evenly: every workgroup runs a contiguous range of them in tile order, i.e.
-// the tail of one tile, whole tiles, the head of another one.  A tile that two workgroups share
-// (never more: a workgroup's range is longer than a tile) is finished by whichever of the two
-// arrives second: both park their partial sums (plain stores, then an agent-scope release and one
-// counter add); the second one adds the other's to its own - a + b = b + a, so the result does
-// not depend on the order of arrival - and writes the tile.  Nobody waits for anybody.
+// The same product for tile counts that do not fill the chip evenly (1600 tiles on 512 workgroup
+// slots: the last of four rounds would be an eighth full; 100 tiles of a column slice: a fifth of
+// the slots busy for a whole tile time).  A fixed grid of workgroups first runs `dp_rounds` rounds
+// of whole tiles (one per workgroup and round, all at the same k: neighbours share their operand
+// panels in L2), then shares the (tile, k-slab) units of the remaining tiles evenly: every
+// workgroup gets a contiguous range of them in tile order, i.e. at most the tail of one tile, whole
+// tiles and the head of another one.  The workgroups that share a tile park their partial sums
+// (plain stores, then an agent-scope release and one counter add); the one that arrives last adds
+// all of them in the order of the k ranges (its own from registers) and writes the tile: the result
+// does not depend on the order of arrival, and nobody waits for anybody.
 struct StreamK {
-  double *ws;     // 2 slots of 128 x 128 doubles per workgroup: [0] its first, [1] its last partial tile
-  unsigned *cnt;  // per boundary between workgroups v-1 | v (zeroed before every launch)
+  double *ws;     // 2 slots of 128 x 128 doubles per workgroup: [0] its first, [1] its second partial tile
+  unsigned *cnt;  // per tile (zeroed before every launch)
   int tiles;
-  int dp_rounds;  // leading rounds of whole tiles, one per workgroup and round (all workgroups at the same
-                  // k: neighbours share their operand panels in L2); the rest is shared by units
+  int dp_rounds;
 };
 __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) {
   constexpr int BM = 128, BN = 128;
@@ -225,8 +246,11 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) 
   }
   const int t_first = sk.dp_rounds * G;
   const long long U = (long long)(sk.tiles - t_first) * nslab, per = U / G, rem = U % G;
-  long long u = v * per + (v < rem ? v : rem);
-  const long long u1 = u + per + (v < rem ? 1 : 0);
+  // workgroup w owns the units [start(w), start(w + 1)); owner(u) is its inverse
+  auto start = [&](long long w) { return w * per + (w < rem ? w : rem); };
+  auto owner = [&](long long uu) { return uu < rem * (per + 1) ? uu / (per + 1) : rem + (uu - rem * (per + 1)) / per; };
+  long long u = start(v);
+  const long long u0 = u, u1 = start(v + 1);
   constexpr int SLOT = BM * BN;
   while (u < u1) {
     const int tl = (int)(u / nslab), s0 = (int)(u - (long long)tl * nslab), t = t_first + tl;
@@ -241,11 +265,9 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) 
     T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
     bool finish = true;
     if (s0 > 0 || s1 < nslab) {
-      // shared tile: s0 > 0 -> with workgroup v-1 (this is my first range), else with v+1 (my last)
-      const bool first = s0 > 0;
-      double *mine = sk.ws + ((long long)v * 2 + (first ? 0 : 1)) * SLOT;
-      const double *theirs = sk.ws + ((long long)(first ? v - 1 : v + 1) * 2 + (first ? 1 : 0)) * SLOT;
-      unsigned *counter = sk.cnt + (first ? v : v + 1);
+      // shared tile: the workgroups that own its first and its last unit, and everybody between them
+      const int w_first = (int)owner((long long)tl * nslab), w_last = (int)owner((long long)(tl + 1) * nslab - 1);
+      double *mine = sk.ws + ((long long)v * 2 + (u == u0 ? 0 : 1)) * SLOT;
 #pragma unroll
       for (int x = 0; x < T::TM; x++)
 #pragma unroll
@@ -257,23 +279,32 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) 
       if (threadIdx.x == 0) {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        *s_old = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_old = __hip_atomic_fetch_add(sk.cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
-      finish = *s_old == 1u;
+      finish = *s_old == (unsigned)(w_last - w_first);
       if (finish) {
         if (threadIdx.x == 0) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
+        // (the own partial comes back from memory as well: one code path, one order)
 #pragma unroll
         for (int x = 0; x < T::TM; x++)
 #pragma unroll
-          for (int y = 0; y < T::TN; y++)
+          for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+        for (int w = w_first; w <= w_last; w++) {
+          // workgroup w's partial of this tile is its first one iff its range starts inside the tile
+          const int slot = start(w) >= (long long)tl * nslab ? 0 : 1;
+          const double *theirs = sk.ws + ((long long)w * 2 + slot) * SLOT;
 #pragma unroll
-            for (int rg = 0; rg < 4; rg++)
-              acc[x][y][rg] += theirs[((x * T::TN + y) * 4 + rg) * 256 + threadIdx.x];
+          for (int x = 0; x < T::TM; x++)
+#pragma unroll
+            for (int y = 0; y < T::TN; y++)
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++) acc[x][y][rg] += theirs[((x * T::TN + y) * 4 + rg) * 256 + threadIdx.x];
+        }
       }
       __syncthreads();  // s_old is rewritten at the next shared tile
     }

@@ -15,6 +15,7 @@ struct StagedDev {
   DBuf<double> sk_ws;           // stream-K dgemm: two partial tiles per workgroup
   DBuf<unsigned> sk_cnt;
   int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
+  int sk_tiles = 0;             // most tiles a product of this handle has (size of the counter array)
   size_t lds_small = 0, lds_init = 0;
   void release() {
     F.release(), V.release(), misc.release();
@@ -50,16 +51,17 @@ inline StagePtr stage_ptr(StagedDev &d, int k) {
 // C = alpha A'B + beta Cin on the handle's stream; 128 x 128 tiles for large products, 64 x 64 below
 int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM) {
   if (g.M <= 0 || g.N <= 0) return 0;
-  const bool big = stg::gemm_big_tiles(g.M, g.N, g.lower);
+  StagedDev *d = h->sd;
+  const int skg = d ? stg::gemm_streamk_grid(g.M, g.N, g.K, g.lower, d->sk_grid) : 0;
+  const bool big = skg > 0 || stg::gemm_big_tiles(g.M, g.N, g.lower);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
   const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
-  StagedDev *d = h->sd;
-  if (big && d && d->sk_grid > 0 && tiles > d->sk_grid && tiles % d->sk_grid != 0) {
-    // tile count not a multiple of the chip: even shares of the (tile, k-slab) units (k_dgemm_tn_sk)
-    HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_grid + 4), h->stream));
-    stg::StreamK sk{d->sk_ws.p, d->sk_cnt.p, (int)tiles, (int)(tiles / d->sk_grid) - 1};
-    KLAUNCH(h, cls, stg::k_dgemm_tn_sk<<<d->sk_grid, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
+  if (skg > 0 && tiles <= d->sk_tiles) {
+    // tile count that does not fill the chip evenly: even shares of the (tile, k-slab) units (k_dgemm_tn_sk)
+    HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
+    stg::StreamK sk{d->sk_ws.p, d->sk_cnt.p, (int)tiles, std::max(0, (int)(tiles / skg) - 1)};
+    KLAUNCH(h, cls, stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
     return 0;
   }
   if (big)
@@ -187,10 +189,10 @@ static int staged_upload(hqpkkt_t *h) {
       const long long t1 = (P.nk[k + 1] + 127) / 128, t2 = (P.nk[k] + P.mk[k] + 127) / 128;
       tmax = std::max(tmax, t1 * t2);
     }
-    d.sk_grid = 0;
-    if (cus > 0 && tmax > 2LL * cus && !getenv("HQPKKT_NO_STREAMK")) {
+    d.sk_grid = 0, d.sk_tiles = (int)tmax;
+    if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
       d.sk_grid = 2 * cus;
-      if ((e = d.sk_ws.alloc((size_t)d.sk_grid * 2 * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_grid + 4))) return e;
+      if ((e = d.sk_ws.alloc((size_t)d.sk_grid * 2 * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_tiles + 4))) return e;
     }
   }
   d.lds_small = 0;

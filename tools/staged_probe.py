@@ -11,7 +11,7 @@ def relerr(a, b):
 
 if "gemm" in sys.argv:
     for (M, N, K, lo) in [(512, 512, 512, 0), (1024, 1024, 1024, 0), (2048, 2048, 2048, 0), (4096, 4096, 4096, 0), (5000, 5050, 5000, 0),
-                          (5050, 5050, 5000, 1), (8192, 8192, 8192, 0), (400, 410, 400, 0), (200, 210, 200, 0), (60, 5000, 60, 0)]:
+                          (5050, 5050, 5000, 1), (8192, 8192, 8192, 0), (1000, 1050, 1000, 0), (5000, 640, 5000, 0), (640, 640, 5000, 1), (4360, 640, 5000, 0), (400, 410, 400, 0), (200, 210, 200, 0), (60, 5000, 60, 0)]:
         ms, tf, err = ipmatrix.bench_dgemm(M, N, K, lo, lo, reps=3)
         print(f"dgemm M={M} N={N} K={K} lower={lo}: {ms:.3f} ms  {tf:.2f} TFLOP/s  ({tf/78.6*100:.1f}% of 78.6)  err {err:.1e}", flush=True)
 if "parity" in sys.argv:
