@@ -367,15 +367,27 @@ def bench_c4(args):
         kdist.init(args.backend)
     from hqp_amd import ipmatrix
     K, nx, nu = args.stages, args.nx, args.nu
-    dq = c4_dense(K, nx, nu, seed=rank)
+    # N > 1: ONE system over the ranks (strong scaling) unless --replicas
+    one = world > 1 and not args.replicas
+    dq = c4_dense(K, nx, nu, seed=0 if one else rank)
     n, me, m = dq.dims
-    mat = ipmatrix.IpLQDOCP(device=local_rank, device_vectors=True)
+    shard, transport = None, None
+    if one:
+        if args.backend == "nccl" and args.transport == "rccl":
+            try:  # libhqpkkt_rccl.so: ncclAllGather in the handle's stream
+                shard, transport = kdist.RcclShard(rank, world, local_rank), "libhqpkkt_rccl (RCCL, stream-ordered)"
+            except Exception as e:  # fall back to torch.distributed's collectives behind the callback
+                print(f"bench: RcclShard failed ({e}); using the torch.distributed callback", file=sys.stderr)
+        if shard is None:
+            shard = (rank, world, kdist.make_exchange(rank, local_rank))
+            transport = f"torch.distributed ({args.backend}) behind the exchange callback"
+    mat = ipmatrix.IpLQDOCP(device=local_rank, device_vectors=True, shard=shard)
     t0 = time.perf_counter()
     mat.init_dense(dq)
     t_init = time.perf_counter() - t0
     dq.F = None  # the engine holds its own copy of the blocks
     torch.cuda.empty_cache()
-    g = torch.Generator(device="cuda").manual_seed(100 + rank)
+    g = torch.Generator(device="cuda").manual_seed(100 + (0 if one else rank))
     rnd = lambda k, lo, hi: torch.empty(k, dtype=torch.float64, device="cuda").uniform_(lo, hi, generator=g)
     z, w = rnd(m, 0.1, 1.1), rnd(m, 0.1, 1.1)
     r = [rnd(k, -0.5, 0.5) for k in (n, me, m, m)]
@@ -438,21 +450,25 @@ def bench_c4(args):
     fac_ms = sum(per_step.get(k, 0.0) for k in ("staged_gemm", "staged_gemm_upd", "staged_small", "assemble"))
     out = {
         "metric": "KKT factor+solve/sec (fp64)",
-        "value": args.steps * world / elapsed,
+        "value": args.steps * (1 if one else world) / elapsed,
         "unit": "KKT factor+solve/s",
         "n_gpus": world,
         "steps": args.steps,
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if one else "weak",
         "vs_baseline": None,
         "dtype": "f64",
         "data": "synthetic",
         "vectors": "resident in HBM",
+        "shard": {"ranks": world, "transport": transport, "bytes_allgather_per_factor": st["bytes_exchange_factor"],
+                  "flops_rank0": st["flops_local"], "allgathers_per_factor": st["n_exchange_blocks"]} if one else None,
         "config": {"workload": f"C4 = BASELINE configs[3], the metric's 10^6-variable DOCP: multistage LQ optimal control QP, K={K} stages, "
                                f"nx={nx} states, nu={nu} controls -> n={n} me={me} m={m}, dense fx/fu handed over as blocks, x_0 fixed, "
-                               f"box bounds on u; plugin LQDOCP (STAGED engine), one system per GPU",
+                               f"box bounds on u; plugin LQDOCP (STAGED engine), "
+                               + (f"ONE system over {world} GPUs (state columns of every stage's products per rank, one all-gather per stage)"
+                                  if one else "one system per GPU"),
                    "stages": K, "nx": nx, "nu": nu, "n": n, "me": me, "m": m, "plugin": "LQDOCP",
                    "kkt_dim_full": n + me + m, "hbm_gb": (st["bytes_panels"] + st["bytes_updates"]) / 1e9},
         "residual": res,
@@ -501,6 +517,11 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--host-vectors", action="store_true",
                     help="z,w,r*,d* as host pointers (the shim's mode): PCIe-inclusive, never the headline value")
+    ap.add_argument("--replicas", action="store_true",
+                    help="c4, N>1: one independent system per GPU (weak scaling) instead of ONE system over the ranks")
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "torch"],
+                    help="c4, N>1, one system: libhqpkkt_rccl.so (collectives in the handle's stream) or the "
+                         "torch.distributed callback")
     ap.add_argument("--one-system", action="store_true",
                     help="N>1: all ranks factor and solve ONE system together (subtrees of the assembly tree per "
                          "rank, one all-gather per factor, all-gather + all-reduce per solve over RCCL; strong "

@@ -27,8 +27,11 @@ SYMBOLS = [
     "hqpkkt_profile_class_name", "hqpkkt_set_shard", "hqpkkt_debug_read",
     "hqpkkt_default_ip_opts", "hqpkkt_mehrotra", "hqpkkt_franke",
     "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm",
-    "hqpkkt_analyze_staged", "hqpkkt_set_values_staged",
+    "hqpkkt_analyze_staged", "hqpkkt_set_values_staged", "hqpkkt_set_shard_stream",
 ]
+RCCL_LIB_PATH = os.path.join(_HERE, "libhqpkkt_rccl.so")
+RCCL_SYMBOLS = ["hqpkkt_rccl_unique_id", "hqpkkt_rccl_create", "hqpkkt_rccl_create_from_env",
+                "hqpkkt_rccl_exchange", "hqpkkt_rccl_destroy"]
 
 XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
 # int fn(void *ctx, int op, double *buf, long long slot_elems, int nslots)
@@ -129,9 +132,27 @@ def lib():
     L.hqpkkt_debug_stage_ranks.argtypes = [vp, vp, C.c_int]
     L.hqpkkt_analyze_staged.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int] + [vp] * 6
     L.hqpkkt_set_values_staged.argtypes = [vp, dp, vp, vp, dp, dp]
+    L.hqpkkt_set_shard_stream.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.hqpkkt_debug_dgemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)] * 2
     _lib = L
     return L
+
+
+_rccl = None
+
+
+def rccl_lib():
+    """libhqpkkt_rccl.so (include/hqpkkt_rccl.h): the RCCL transport of a sharded system."""
+    global _rccl
+    if _rccl is None:
+        lib()  # torch (and its RCCL) first
+        R = C.CDLL(RCCL_LIB_PATH)
+        R.hqpkkt_rccl_unique_id.argtypes = [C.c_char_p]
+        R.hqpkkt_rccl_create.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(C.c_void_p)]
+        R.hqpkkt_rccl_exchange.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
+        R.hqpkkt_rccl_destroy.argtypes = [C.c_void_p]
+        _rccl = R
+    return _rccl
 
 
 def strerror(code):

@@ -168,6 +168,7 @@ struct hqpkkt {
   // one system over several ranks: collectives are delegated to the caller
   int shard_rank = 0, shard_count = 1;
   hqpkkt_exchange_fn xchg_fn = nullptr;
+  hqpkkt_exchange_stream_fn xchg_sfn = nullptr;  // stream-ordered form (RCCL): nothing is drained
   void *xchg_ctx = nullptr;
   DBuf<long long> bptr, panel_off, upd_off, x_off, cb_off, ent_dst, linv_off, pinv_off;
   DBuf<TermDev> terms;
@@ -701,6 +702,8 @@ static int graphed(hqpkkt_t *h, hqpkkt::GraphSlot &slot, F body) {
 // The exchange steps of a sharded system: the handle's stream is
 // drained, the caller's collective runs, and the next phase starts afterwards.
 static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots) {
+  if (h->xchg_sfn)  // the collective is put into the handle's stream behind the kernels that fill `buf`
+    return h->xchg_sfn(h->xchg_ctx, op, buf, slot, nslots, (void *)h->stream) ? HQPKKT_E_DEVICE : 0;
   if (!h->xchg_fn) return HQPKKT_E_INTERN;
   HIPCHK(hipStreamSynchronize(h->stream));
   const int rc = h->xchg_fn(h->xchg_ctx, op, buf, slot, nslots);
@@ -709,12 +712,15 @@ static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots
 
 static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w);
 static int staged_run_step(hqpkkt_t *h, const Vecs &v);
+static bool staged_is_sharded(hqpkkt_t *h);
 
 static int do_factor(hqpkkt_t *h, const Vecs &v) {
   Analysis &an = h->an;
   int e;
-  if (h->opts.mode == HQPKKT_MODE_STAGED)
+  if (h->opts.mode == HQPKKT_MODE_STAGED) {
+    if (staged_is_sharded(h)) return staged_run_factor(h, v.z, v.w);  // an exchange per stage: not captured
     return graphed(h, h->gfactor[0], [&]() { return staged_run_factor(h, v.z, v.w); });
+  }
   if (an.shard_count <= 1) return graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 3); });
   if ((e = graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 1); }))) return e;
   if (an.upd_x_slot > 0 &&
@@ -815,6 +821,7 @@ static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, 
   *x1 = d.dyn_x1.p, *x2 = d.dyn_x2.p, *ndyn = P.ndyn;
   return 0;
 }
+static bool staged_is_sharded(hqpkkt_t *h) { return h->sd && h->sd->plan.sharded; }
 static void staged_release(StagedDev *sd, bool destroy) {
   if (!sd) return;
   sd->release();
@@ -1855,7 +1862,16 @@ int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, vo
   if (count > 1 && !fn) return HQPKKT_E_NULL;
   if (h->analyzed && (rank != h->shard_rank || count != h->shard_count)) return HQPKKT_E_INTERN;
   h->shard_rank = rank, h->shard_count = count;
-  h->xchg_fn = fn, h->xchg_ctx = ctx;
+  h->xchg_fn = fn, h->xchg_sfn = nullptr, h->xchg_ctx = ctx;
+  return 0;
+}
+int hqpkkt_set_shard_stream(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_stream_fn fn, void *ctx) {
+  if (!h) return HQPKKT_E_NULL;
+  if (count < 1 || rank < 0 || rank >= count) return HQPKKT_E_RANGE;
+  if (count > 1 && !fn) return HQPKKT_E_NULL;
+  if (h->analyzed && (rank != h->shard_rank || count != h->shard_count)) return HQPKKT_E_INTERN;
+  h->shard_rank = rank, h->shard_count = count;
+  h->xchg_fn = nullptr, h->xchg_sfn = fn, h->xchg_ctx = ctx;
   return 0;
 }
 
@@ -2101,6 +2117,11 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       if (what == 24) v = &P.eq_rows;
       if (what == 25) v = &P.fix_rows;
       if (what == 26) v = &P.cap;
+      break;
+    }
+    case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)
+      if (!h->sd) return HQPKKT_E_INTERN;
+      v = &h->sd->plan.xcut;
       break;
     }
     default: return HQPKKT_E_RANGE;

@@ -930,6 +930,37 @@ __global__ void k_st_copy(int n, const double *__restrict__ s, double *__restric
 }
 
 // ---------------------------------------------------------------------------------------
+// One system over several ranks: rank p computes the columns [c0, c1) of the lower triangle of V_k
+// (rows c0 .. n-1: a strip (n - c0) x (c1 - c0), row-major in its slot of the exchange buffer); after
+// the all-gather every rank writes all strips, and their mirror images, into its V_k.
+__global__ void __launch_bounds__(256) k_st_pack(const double *__restrict__ V, long long ldv, int n, int c0, int c1,
+                                                 double *__restrict__ slot) {
+  const int w = c1 - c0;
+  for (int i = c0 + blockIdx.x; i < n; i += gridDim.x)
+    for (int jj = threadIdx.x; jj < w; jj += blockDim.x) slot[(long long)(i - c0) * w + jj] = V[(long long)i * ldv + c0 + jj];
+}
+struct UnpackArgs {
+  double *V;
+  long long ldv;
+  int n, nranks;
+  const double *xbuf;
+  long long slot_elems;
+  int cut[17];  // nranks + 1 column cuts (nranks <= 16)
+};
+__global__ void __launch_bounds__(256) k_st_unpack(UnpackArgs a) {
+  const int p = blockIdx.y, c0 = a.cut[p], c1 = a.cut[p + 1], w = c1 - c0;
+  const double *slot = a.xbuf + (long long)p * a.slot_elems;
+  for (int i = c0 + blockIdx.x; i < a.n; i += gridDim.x)
+    for (int jj = threadIdx.x; jj < w; jj += blockDim.x) {
+      const int j = c0 + jj;
+      if (i < j) continue;  // upper part of the diagonal block: not computed
+      const double v = slot[(long long)(i - c0) * w + jj];
+      a.V[(long long)i * a.ldv + j] = v;
+      if (i != j) a.V[(long long)j * a.ldv + i] = v;
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // Dense dynamics (hqpkkt_set_values_staged): the products with the dynamics rows of A that
 // residuum() needs, all stages in one launch (blockIdx.y = stage)
 struct DynDesc {

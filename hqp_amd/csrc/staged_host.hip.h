@@ -101,6 +101,10 @@ static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = fa
   P = kktdev::StagedPlan();
   P.given_nx = gnx, P.given_nu = gnu;
   P.dense_dyn = dense_dyn;
+  if (h->shard_count > 16) return HQPKKT_E_RANGE;
+  P.shard_rank = h->shard_rank, P.shard_count = h->shard_count;
+  P.sharded = h->shard_count > 1 || h->xchg_fn || h->xchg_sfn;
+  h->an.shard_rank = h->shard_rank, h->an.shard_count = 1;  // (the tree engine's exchange plan is not used)
   int e = h->an.setup_blocks(1, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),
                              h->pCp.data(), h->pCi.data());
   if (e) return e;
@@ -119,7 +123,18 @@ static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = fa
   h->st.flops_factor = P.flops_factor;
   h->st.bytes_panels = (long long)sizeof(double) * (P.f_elems + P.v_elems);
   h->st.bytes_updates = (long long)sizeof(double) * P.misc_elems;
-  h->st.shard_count = 1;
+  h->st.shard_rank = P.shard_rank, h->st.shard_count = P.shard_count;
+  if (P.sharded) {
+    long long bytes = 0, fl = 0;
+    for (int k = 0; k < P.K; k++) {
+      bytes += (long long)sizeof(double) * P.xslot[k] * P.shard_count;
+      const int *cut = &P.xcut[(size_t)k * (P.shard_count + 1)];
+      const long long wd = cut[P.shard_rank + 1] - cut[P.shard_rank], c0 = cut[P.shard_rank];
+      const long long np = P.nk[k + 1], nz = P.nk[k] + P.mk[k], mm = P.mk[k], nn = P.nk[k], q = P.qmax[k];
+      fl += 2 * np * np * (wd + mm) + 2 * np * wd * (nz - c0) - np * wd * wd + 2 * np * mm * nz + 2 * q * wd * (nn - c0);
+    }
+    h->st.bytes_exchange_factor = bytes, h->st.flops_local = fl, h->st.n_exchange_blocks = P.K;
+  }
   return 0;
 }
 
@@ -158,7 +173,8 @@ static int staged_upload(hqpkkt_t *h) {
     const double nnz = (double)an.Qfull.col.size() + 2.0 * an.A.col.size() + 2.0 * an.C.col.size();
     h->short_rows = rows > 0 && nnz / rows < 8.0;
   }
-  if ((e = d.F.alloc(P.f_elems)) || (e = d.V.alloc(P.v_elems)) || (e = d.misc.alloc(P.misc_elems)) ||
+  // (slack: 16-byte operand loads of column slices may read a tile's width past a block's last row)
+  if ((e = d.F.alloc(P.f_elems + 8192)) || (e = d.V.alloc(P.v_elems + 8192)) || (e = d.misc.alloc(P.misc_elems + 8192)) ||
       (e = d.dyn.alloc(P.dyn_ints)) || (e = d.eq_rows.upload(P.eq_rows)) || (e = d.fix_rows.upload(P.fix_rows)) ||
       (e = d.fix_src.upload(P.fix_src)) || (e = d.h_tptr.upload(P.h_tptr)) || (e = d.chk_idx.upload(P.chk_idx)) ||
       (e = d.chk_kind.upload(P.chk_kind)) || (e = d.h_dst.upload(P.h_dst)) || (e = d.a_dst.upload(P.a_dst)))
@@ -270,12 +286,15 @@ static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, co
 
 // Hqp_IpLQDOCP::factor (hqp/Hqp_IpLQDOCP.C:796-862): W^-1 Z, C'(W^-1 Z)C, then the backward
 // recursion over the stages (ExRiccatiFactorSc, :1794-1999)
+static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots);
+
 static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
   Analysis &an = h->an;
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;
   hipStream_t s = h->stream;
   const int m = an.m, K = P.K;
+  const int NR = P.shard_count, RK = P.shard_rank;
   int e;
   HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 128, s));
   if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
@@ -296,11 +315,29 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
     const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
     const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k];
-    // W = V+ F ; G = F'W (lower tiles) + H
-    if ((e = st_gemm(h, stg::GemmArgs{sn.V, P.ldv[k + 1], sp.F, P.ldf[k], nullptr, 0, W, P.ldf[k], np, nz, np, 1.0, 0.0, 0, 0})))
-      return e;
-    if ((e = st_gemm(h, stg::GemmArgs{sp.F, P.ldf[k], W, P.ldf[k], nullptr, 0, G, P.ldg[k], nz, nz, np, 1.0, 0.0, 1, 0})))
-      return e;
+    // this rank's state columns [c0, c1) of the products (everything when not sharded)
+    const int *cut = P.sharded ? &P.xcut[(size_t)k * (NR + 1)] : nullptr;
+    const int c0 = cut ? cut[RK] : 0, c1 = cut ? cut[RK + 1] : nn, wd = c1 - c0;
+    const long long ldf = P.ldf[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1];
+    if (!P.sharded) {
+      // W = V+ F ; G = F'W (lower tiles) + H
+      if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldf, nullptr, 0, W, ldf, np, nz, np, 1.0, 0.0, 0, 0}))) return e;
+      if ((e = st_gemm(h, stg::GemmArgs{sp.F, ldf, W, ldf, nullptr, 0, G, ldg, nz, nz, np, 1.0, 0.0, 1, 0}))) return e;
+    } else {
+      // own columns of W and of the lower triangle of Gxx (diagonal block + the rows below it) ...
+      if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + c0, ldf, nullptr, 0, W + c0, ldf, np, wd, np, 1.0, 0.0, 0, 0})))
+        return e;
+      if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + c0 * ldg + c0, ldg, wd, wd, np, 1.0, 0.0, 1, 0})))
+        return e;
+      if (wd > 0 && nn > c1 &&
+          (e = st_gemm(h, stg::GemmArgs{sp.F + c1, ldf, W + c0, ldf, nullptr, 0, G + c1 * ldg + c0, ldg, nn - c1, wd, np, 1.0, 0.0, 0, 0})))
+        return e;
+      // ... and, on every rank, the control columns of W and the control rows of G (Gux, Guu)
+      if (mm > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + nn, ldf, nullptr, 0, W + nn, ldf, np, mm, np, 1.0, 0.0, 0, 0})))
+        return e;
+      if (mm > 0 && (e = st_gemm(h, stg::GemmArgs{W + nn, ldf, sp.F, ldf, nullptr, 0, G + nn * ldg, ldg, mm, nz, np, 1.0, 0.0, 0, 0})))
+        return e;
+    }
     const int ne = P.h_ptr[k + 1] - P.h_ptr[k];
     if (ne)
       KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(ne), 256, 0, s>>>(ne, d.h_dst.p + P.h_ptr[k], d.h_tptr.p + P.h_ptr[k], d.h_terms.p,
@@ -321,9 +358,28 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
         (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, P.ldy[k], nullptr, 0, sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
                                       1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD)))
       return e;
-    if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1},
-                     KC_ST_GEMM_UPD)))
-      return e;
+    if (!P.sharded) {
+      if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1},
+                       KC_ST_GEMM_UPD)))
+        return e;
+    } else {
+      const long long ldy = P.ldy[k], ldv = P.ldv[k];
+      if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sp.Y + c0, ldy, sp.Rm + c0, ldy, G + c0 * ldg + c0, ldg, sp.V + c0 * ldv + c0, ldv, wd, wd,
+                                                 P.qmax[k], -1.0, 1.0, 1, 0}, KC_ST_GEMM_UPD)))
+        return e;
+      if (wd > 0 && nn > c1 &&
+          (e = st_gemm(h, stg::GemmArgs{sp.Y + c1, ldy, sp.Rm + c0, ldy, G + c1 * ldg + c0, ldg, sp.V + c1 * ldv + c0, ldv, nn - c1, wd,
+                                        P.qmax[k], -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD)))
+        return e;
+      // the strips of V_k: pack, ONE all-gather, unpack + mirror
+      double *xb = d.misc.p + P.oX;
+      if (wd > 0)
+        KLAUNCH(h, KC_ST_VEC, stg::k_st_pack<<<std::min(nn - c0, 4096), 256, 0, s>>>(sp.V, ldv, nn, c0, c1, xb + (long long)RK * P.xslot[k]));
+      if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR))) return e;
+      stg::UnpackArgs ua{sp.V, ldv, nn, NR, xb, P.xslot[k], {0}};
+      for (int p = 0; p <= NR; p++) ua.cut[p] = cut[p];
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_unpack<<<dim3(std::min(nn, 4096), NR), 256, 0, s>>>(ua));
+    }
   }
   {
     StagePtr s0 = stage_ptr(d, 0);

@@ -213,6 +213,38 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   oPart = mo, mo += up16((long long)part_chunks * (nzmax + 8));
   oS = mo, mo += up16(n + 8);
   oQv = mo, mo += up16(n + 8);
+  // ------------------------------------------------------------------ column ranges of the ranks
+  xcut.clear(), xslot.assign(K + 1, 0), oX = 0;
+  if (sharded) {
+    long long xmax = 0;
+    xcut.assign((size_t)(K + 1) * (shard_count + 1), 0);
+    for (int k = 0; k < K; k++) {
+      const long long nn = nk[k], nz = nk[k] + mk[k], np = nk[k + 1], q = qmax[k];
+      if (nn & 1) return 1;  // the control columns start at column n_k: 16-byte loads need it even
+      const int nb = (int)((nn + 127) / 128);
+      std::vector<double> cost(nb);
+      double tot = 0.0;
+      for (int b = 0; b < nb; b++) {
+        const double c0 = 128.0 * b, wdt = std::min<double>(128.0, nn - c0);
+        cost[b] = wdt * (2.0 * np * np + 2.0 * np * (nz - c0) + 2.0 * q * (nn - c0));
+        tot += cost[b];
+      }
+      int *cut = &xcut[(size_t)k * (shard_count + 1)];
+      double acc = 0.0;
+      int b = 0;
+      for (int p = 0; p < shard_count; p++) {
+        cut[p] = std::min<long long>(128LL * b, nn);
+        const double target = tot * (p + 1) / shard_count;
+        while (b < nb && (acc + 0.5 * cost[b] <= target || p == shard_count - 1)) acc += cost[b++];
+      }
+      cut[shard_count] = (int)nn;
+      for (int p = 0; p < shard_count; p++)
+        xslot[k] = std::max(xslot[k], (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]));
+      xslot[k] = up16(xslot[k]);
+      xmax = std::max(xmax, xslot[k]);
+    }
+    oX = mo, mo += up16(xmax * shard_count);
+  }
   f_elems = fo, v_elems = vo, misc_elems = mo;
   dyn_off.assign(K + 1, 0);
   dyn_ints = 0;

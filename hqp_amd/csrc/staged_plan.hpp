@@ -50,6 +50,17 @@ struct StagedPlan {
   long long flops_factor = 0;  // as implemented (dense products of the recursion)
   long long bytes_step = 0;    // dense bytes one step streams
 
+  // one system over several ranks (hqpkkt_set_shard): every rank holds all blocks; the state columns
+  // of a stage's products W = V+ F, G = F'W and V = Gxx - Y'Rm are cut into one contiguous range per
+  // rank (multiples of 128, balanced by the work of the three products together: the ranges differ in
+  // height in the triangular ones), the control columns and everything small are computed by all;
+  // ONE all-gather per stage brings the strips of V_k (lower part) together.
+  int shard_rank = 0, shard_count = 1;
+  bool sharded = false;          // several ranks, or one rank with a transport set (tests the exchange path)
+  std::vector<int> xcut;         // (K+1) x (shard_count+1): first column of rank p's range in stage k
+  std::vector<long long> xslot;  // per stage: elements of one slot of the exchange buffer (largest strip)
+  long long oX = 0;              // exchange buffer in the misc arena: shard_count slots
+
   // explicit stage sizes (hqpkkt_set_stages): K, nx[K+1], nu[K]; empty: detect from A
   std::vector<int> given_nx, given_nu;
 

@@ -139,3 +139,36 @@ def make_exchange(rank, device=0, group=None):
         exchange_tensor(op, t, slot, nslots, rank, group)
 
     return fn
+
+
+class RcclShard:
+    """The native transport of a sharded system: one RCCL communicator per process
+    (libhqpkkt_rccl.so, include/hqpkkt_rccl.h), its collectives put into the handle's HIP
+    stream by the library itself (hqpkkt_set_shard_stream) - no callback into Python, no
+    drained stream.  The ncclUniqueId travels over the default torch.distributed group.
+    ``Hqp_IpMatrix(shard=RcclShard(rank, world, device))``."""
+
+    def __init__(self, rank, world, device=0, group=None):
+        import ctypes as C
+        import torch.distributed as dist
+        from . import _lib
+        R = _lib.rccl_lib()
+        uid = C.create_string_buffer(128)
+        if rank == 0:
+            e = R.hqpkkt_rccl_unique_id(uid)
+            if e:
+                raise RuntimeError(f"hqpkkt_rccl_unique_id: {e}")
+        box = [uid.raw if rank == 0 else None]
+        if world > 1:
+            dist.broadcast_object_list(box, src=0, group=group)
+        self._ctx = C.c_void_p()
+        e = R.hqpkkt_rccl_create(box[0], world, rank, device, C.byref(self._ctx))
+        if e:
+            raise RuntimeError(f"hqpkkt_rccl_create: {e}")
+        self._R, self.rank, self.world = R, rank, world
+        self.fn = C.cast(R.hqpkkt_rccl_exchange, C.c_void_p)
+
+    def close(self):
+        if getattr(self, "_ctx", None):
+            self._R.hqpkkt_rccl_destroy(self._ctx)
+            self._ctx = None

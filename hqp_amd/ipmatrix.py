@@ -86,7 +86,11 @@ class Hqp_IpMatrix:
         self._xchg = None
         self.n = self.me = self.m = 0
         if shard is not None:
-            self.set_shard(*shard)
+            if hasattr(shard, "fn"):  # hqp_amd.dist.RcclShard: stream-ordered RCCL collectives
+                _check(L.hqpkkt_set_shard_stream(self._h, shard.rank, shard.world, shard.fn, shard._ctx), "set_shard_stream")
+                self._xchg = shard
+            else:
+                self.set_shard(*shard)
 
     def set_shard(self, rank, count, exchange=None):
         """One system over ``count`` ranks (call before init()).  ``exchange(op,

@@ -235,6 +235,18 @@ int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out);
 #define HQPKKT_XCHG_ALLREDUCE_SUM 1
 typedef int (*hqpkkt_exchange_fn)(void *ctx, int op, double *buf, long long slot_elems, int nslots);
 int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, void *ctx);
+/* The stream-ordered form of the same hook: the callback puts the collective into `hip_stream` (the
+ * handle's stream, behind the kernels that fill `buf`) and returns at once; nothing is drained, the
+ * kernels that follow wait in the stream.  hqpkkt_rccl_exchange of libhqpkkt_rccl.so
+ * (include/hqpkkt_rccl.h: ncclAllGather / ncclAllReduce of RCCL over xGMI) has this signature.
+ * STAGED mode over several ranks: every rank holds all stage blocks; the state columns of the three
+ * products of a stage (W = V+ F, G = F'W, V = Gxx - Y'Rm) are cut into one range per rank, the
+ * control columns and all small work are done by every rank; ONE all-gather per stage (the strips
+ * of the lower triangle of V_k: n^2/2 doubles in all) brings the cost-to-go Hessian together; the
+ * solves run replicated, without communication.  Needs an even number of states per stage. */
+typedef int (*hqpkkt_exchange_stream_fn)(void *ctx, int op, double *buf, long long slot_elems, int nslots,
+                                         void *hip_stream);
+int hqpkkt_set_shard_stream(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_stream_fn fn, void *ctx);
 
 /* ---- STAGED mode (Hqp_IpLQDOCP, hqp/Hqp_IpLQDOCP.C) ---------------------------------
  * The QP of a discrete-time optimal control problem as Hqp_Docp::setup_qp lays it out
@@ -351,7 +363,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
  * 8 entry_row, 9 entry_col (elimination indices, nnz_kkt each), 10 node_owner
  * (rank per supernode, -1 = replicated top), 11 exchanged subtree roots; STAGED: 20 states
  * per stage, 21 controls, 22 first column, 23 / 24 own equality rows (ptr / rows), 25 rows
- * that fix x_0, 26 capacity of carried rows.
+ * that fix x_0, 26 capacity of carried rows, 27 column cuts of the ranks ((K+1) x (ranks+1)).
  * *len receives the element count; out may be NULL to query it. */
 int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len);
 

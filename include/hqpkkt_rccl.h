@@ -1,0 +1,38 @@
+/*
+ * hqpkkt_rccl.h -- the collectives of a KKT system that is sharded over several GPUs
+ * (hqpkkt_set_shard_stream, include/hqpkkt.h) on RCCL over xGMI: one process per GPU, one
+ * communicator per process, ncclAllGather / ncclAllReduce in the handle's HIP stream.
+ *
+ * The reference has no counterpart (hqp/Hqp_Client.C is an unimplemented stub).
+ * libhqpkkt_rccl.so is separate from libhqpkkt.so so that the latter keeps depending on the HIP
+ * runtime only.
+ */
+#ifndef HQPKKT_RCCL_H
+#define HQPKKT_RCCL_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HQPKKT_RCCL_ID_BYTES 128
+
+/* rank 0: a fresh ncclUniqueId, to be handed to the other ranks by whatever the host has
+ * (torch.distributed broadcast, MPI_Bcast, a file) */
+int hqpkkt_rccl_unique_id(char id[HQPKKT_RCCL_ID_BYTES]);
+/* every rank: ncclCommInitRank on HIP device `device` */
+int hqpkkt_rccl_create(const char id[HQPKKT_RCCL_ID_BYTES], int nranks, int rank, int device, void **ctx);
+/* the same from the environment, for hosts without a transport of their own (the C++ HQP host with
+ * mat_ngpu > 1, started once per GPU): HQPKKT_RANK / HQPKKT_WORLD_SIZE (default: RANK / WORLD_SIZE of
+ * torchrun, OMPI_COMM_WORLD_RANK / _SIZE of mpirun), device = HQPKKT_DEVICE or LOCAL_RANK or the rank;
+ * rank 0 writes the id to the file HQPKKT_ID_FILE (default /tmp/hqpkkt_rccl_id.<MASTER_PORT or 0>), the
+ * others wait for it */
+int hqpkkt_rccl_create_from_env(void **ctx, int *rank, int *nranks, int *device);
+/* hqpkkt_exchange_stream_fn: HQPKKT_XCHG_ALLGATHER in place (slot `rank` of `buf` is the send part),
+ * HQPKKT_XCHG_ALLREDUCE_SUM in place; returns 0 or the ncclResult_t */
+int hqpkkt_rccl_exchange(void *ctx, int op, double *buf, long long slot_elems, int nslots, void *hip_stream);
+int hqpkkt_rccl_destroy(void *ctx);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -38,19 +38,27 @@ def main():
         else:
             prog = problems.did_like_qp(case[1])
         st = problems.ip_state(prog, 7, 1.0)
-        cls = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}[kind]
-        M = cls(device=dev, shard=(rank, world, dist.make_exchange(rank, dev)))
+        cls = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP, "LQDOCP": ipmatrix.IpLQDOCP}[kind]
+        if os.environ.get("SHARD_TRANSPORT") == "rccl":  # libhqpkkt_rccl.so: stream-ordered collectives
+            M = cls(device=dev, shard=dist.RcclShard(rank, world, dev))
+        else:
+            M = cls(device=dev, shard=(rank, world, dist.make_exchange(rank, dev)))
         M.init(prog)
         d = new_d(prog)
         for rep in range(2):  # second round replays the captured graphs
             M.factor(prog, st[0], st[1])
             res = M.solve(prog, *st, *d)
         s = M.stats()
-        owner = M.debug(10)
-        rec = dict(case=case, rank=rank, res=res, n_top=s["n_top"], xblocks=s["n_exchange_blocks"],
-                   flops_local=s["flops_local"], flops_top=s["flops_top"], nodes=s["n_supernodes"],
-                   owned=int((owner == rank).sum()), top=int((owner < 0).sum()),
-                   bytes_factor=s["bytes_exchange_factor"], bytes_step=s["bytes_exchange_step"])
+        if kind == "LQDOCP":
+            cuts = M.debug(27).reshape(-1, world + 1)
+            rec = dict(case=case, rank=rank, res=res, staged=True, cuts=cuts[0].tolist(), flops_local=s["flops_local"],
+                       bytes_factor=s["bytes_exchange_factor"], ranks=s["shard_count"])
+        else:
+            owner = M.debug(10)
+            rec = dict(case=case, rank=rank, res=res, n_top=s["n_top"], xblocks=s["n_exchange_blocks"],
+                       flops_local=s["flops_local"], flops_top=s["flops_top"], nodes=s["n_supernodes"],
+                       owned=int((owner == rank).sum()), top=int((owner < 0).sum()),
+                       bytes_factor=s["bytes_exchange_factor"], bytes_step=s["bytes_exchange_step"])
         if rank == 0:
             R = cls(device=dev)
             R.init(prog)

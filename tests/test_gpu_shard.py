@@ -39,3 +39,44 @@ def test_sharded_system_matches_single(world, port):
         # every supernode is either replicated or owned by exactly one rank
         assert sum(r["owned"] for r in recs) + r0["top"] == r0["nodes"], (case, recs)
         assert r0["xblocks"] >= world - 1
+
+
+STAGED_CASES = [["docp", 5, 300, 6, "LQDOCP"], ["docp", 3, 520, 20, "LQDOCP"]]
+
+
+@pytest.mark.parametrize("world,port", [(2, 29571), (3, 29572)])
+def test_sharded_staged_system_matches_single(world, port):
+    """STAGED engine over several ranks: the state columns of a stage's three products cut into one
+    range per rank, ONE all-gather per stage (the strips of V_k).  Same solution as the unsharded
+    handle, identical vectors on all ranks."""
+    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_CASES=json.dumps(STAGED_CASES), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
+    per_rank = json.loads(line[len("SHARD_RESULT "):])
+    for ci, case in enumerate(STAGED_CASES):
+        recs = [r[ci] for r in per_rank]
+        assert recs[0]["diff"] < 1e-9, (case, recs[0])
+        cuts = recs[0]["cuts"]
+        assert cuts[0] == 0 and cuts[-1] == case[2] and all(a <= b for a, b in zip(cuts, cuts[1:]))
+        assert all(c % 128 == 0 for c in cuts[:-1]) and sum(1 for a, b in zip(cuts, cuts[1:]) if b > a) >= 2
+        for r in recs:
+            assert r["res"] <= 1e-10 and r["same_as_rank0"] and r["ranks"] == world, (case, r)
+
+
+def test_rccl_transport_single_rank():
+    """libhqpkkt_rccl.so on the one GPU of the test box: a communicator of one rank, the STAGED
+    engine's exchange path with the collectives in the handle's stream (hqpkkt_set_shard_stream).
+    The several-rank form of the same code runs in bench.py --one-system."""
+    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_TRANSPORT="rccl", SHARD_CASES=json.dumps(STAGED_CASES[:1]),
+               MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+           "--master-addr", "127.0.0.1", "--master-port", "29575", os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
+    rec = json.loads(line[len("SHARD_RESULT "):])[0][0]
+    assert rec["diff"] < 1e-9 and rec["res"] <= 1e-10
