@@ -421,6 +421,8 @@ def bench_c4(args):
     nz, np1 = nx + nu, nx
     # algorithmic work of the recursion per factorisation
     flops_big = K * (2.0 * np1 * np1 * nz + 1.0 * np1 * nz * nz)          # W = V+ F ; G = F'W (lower half)
+    if one:  # rank 0's share of the products (its column range; the update products are ~1 % of it)
+        flops_big = float(st["flops_local"])
     q = nu
     flops_upd = K * (2.0 * q * q * nx + 1.0 * q * nx * nx)                 # Rm = K^-1 Y ; V = Gxx - Y'Rm (lower half)
     bytes_gemv = K * 8.0 * (2.0 * np1 * np1 + 2.0 * np1 * nz + 2.0 * q * nx) * (1 + st["refine_rounds"])
@@ -428,9 +430,11 @@ def bench_c4(args):
     achieved = flops_big / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_c4.json")
-    if os.path.exists(pmc) and (K, nx, nu) == (200, 5000, 50):
-        traffic = json.load(open(pmc)).get("k_dgemm_tn", {}).get("hbm_bytes_per_launch")
-    roofline = {"kernel": "k_dgemm_tn<128,128>", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+    if os.path.exists(pmc) and (nx, nu) == (5000, 50) and not one:
+        # HBM bytes per launch of the stream-K dgemm from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
+        # workload (separate runs, gfx950 correction applied: profiles/README.md)
+        traffic = json.load(open(pmc)).get("k_dgemm_tn_sk", {}).get("hbm_bytes_per_launch")
+    roofline = {"kernel": "k_dgemm_tn_sk / k_dgemm_tn<128,128> (W = V+ F, G = F'W)", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS if achieved else None, "traffic": traffic,
                 "launches_per_step": gemm_launch, "avg_launch_ms": gemm_ms / gemm_launch if gemm_launch else None,
                 "algorithmic_flops_per_launch": flops_big / gemm_launch if gemm_launch else None,
@@ -510,7 +514,7 @@ def parse_args():
                          "c2: banded KKT system of dim 10^5, full-system engine")
     ap.add_argument("--stages", type=int, default=200, help="c4: K")
     ap.add_argument("--nx", type=int, default=5000, help="c4: states per stage")
-    ap.add_argument("--nu", type=int, default=50, help="c4: controls per stage")
+    ap.add_argument("--ctrl", dest="nu", type=int, default=50, help="c4: controls per stage")
     ap.add_argument("--n", type=int, default=40000, help="x variables (C2: 40000)")
     ap.add_argument("--band", type=int, default=80, help="semi-bandwidth of Q / row width of A (C2: 80)")
     ap.add_argument("--mode", default="SpBKP", choices=["SpBKP", "RedSpBKP"])

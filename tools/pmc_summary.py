@@ -1,6 +1,6 @@
 """HBM traffic per kernel launch from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE).
 
-usage: python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out dir>
+usage: python tools/pmc_summary.py <dir of the FETCH_SIZE pass> <dir of the WRITE_SIZE pass> <out dir> [tag]
 
 Writes r01_pmc_fetch_by_kernel.csv, r01_pmc_write_by_kernel.csv and pmc_traffic.json into the
 out dir.  HBM bytes per launch = (2 FETCH_SIZE + WRITE_SIZE) 1024: on gfx950 FETCH_SIZE counts
@@ -22,7 +22,8 @@ def by_kernel(d, counter):
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] != counter:
             continue
-        nm = r["Kernel_Name"].split("(")[0].replace("kktdev::", "")
+        nm = r["Kernel_Name"].split("(")[0].replace("kktdev::", "").replace("stg::", "").replace("void ", "")
+        nm = nm.split("<")[0]
         tot[nm] += float(r["Counter_Value"])
         cnt[nm].add(r["Dispatch_Id"])
     return {k: (tot[k], len(cnt[k])) for k in tot}
@@ -30,8 +31,9 @@ def by_kernel(d, counter):
 
 def main():
     fd, wd, out = sys.argv[1:4]
+    tag = sys.argv[4] if len(sys.argv) > 4 else "r01"
     fetch, write = by_kernel(fd, "FETCH_SIZE"), by_kernel(wd, "WRITE_SIZE")
-    for name, data, col in (("r01_pmc_fetch_by_kernel.csv", fetch, "FETCH_SIZE_KB"), ("r01_pmc_write_by_kernel.csv", write, "WRITE_SIZE_KB")):
+    for name, data, col in ((tag + "_pmc_fetch_by_kernel.csv", fetch, "FETCH_SIZE_KB"), (tag + "_pmc_write_by_kernel.csv", write, "WRITE_SIZE_KB")):
         with open(os.path.join(out, name), "w") as g:
             g.write(f"kernel,launches,{col}_total,{col}_per_launch\n")
             for k, (t, n) in sorted(data.items(), key=lambda kv: -kv[1][0]):
