@@ -130,7 +130,7 @@ def lib():
     L.hqpkkt_franke.argtypes = [vp, C.POINTER(IpOpts)] + [dp] * 7 + [C.POINTER(IpResult)]
     L.hqpkkt_set_stages.argtypes = [vp, C.c_int, vp, vp]
     L.hqpkkt_debug_stage_ranks.argtypes = [vp, vp, C.c_int]
-    L.hqpkkt_analyze_staged.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int] + [vp] * 6
+    L.hqpkkt_analyze_staged.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int] + [vp] * 6
     L.hqpkkt_set_values_staged.argtypes = [vp, dp, vp, vp, dp, dp]
     L.hqpkkt_set_shard_stream.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.hqpkkt_debug_dgemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)] * 2

@@ -1892,7 +1892,7 @@ int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu) {
   return 0;
 }
 
-int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int me_rest, int m, const int *Qp,
+int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int n_total, int me_rest, int m, const int *Qp,
                           const int *Qi, const int *Ep, const int *Ei, const int *Cp, const int *Ci) {
   if (!h) return HQPKKT_E_NULL;
   if (h->opts.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_INTERN;
@@ -1902,6 +1902,7 @@ int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int 
   long long n = nx[K], ndyn = 0;
   for (int k = 0; k < K; k++) n += (long long)nx[k] + nu[k], ndyn += nx[k + 1];
   if (n > 0x7fffffffLL || ndyn + me_rest > 0x7fffffffLL || me_rest < 0 || m < 0) return HQPKKT_E_RANGE;
+  if (n != n_total) return HQPKKT_E_SIZES;  // Q, E, C were built for another number of variables
   if ((n > 0 && (!Qp || (Qp[n] > 0 && !Qi))) || (me_rest > 0 && (!Ep || (Ep[me_rest] > 0 && !Ei))) ||
       (m > 0 && (!Cp || (Cp[m] > 0 && !Ci))))
     return HQPKKT_E_NULL;

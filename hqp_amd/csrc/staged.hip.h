@@ -19,6 +19,8 @@
 
 #include <algorithm>
 
+#include "staged_plan.hpp"
+
 namespace stg {
 
 using kktdev::double4_t;
@@ -62,6 +64,7 @@ static inline int gemm_streamk_grid(int M, int N, int K, int lower, int grid) {
   const long long tm = (M + 127) / 128, tn = (N + 127) / 128, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
   const long long nslab = (K + GEMM_BK - 1) / GEMM_BK;
   if (tiles % grid == 0 || tiles >= 8LL * grid) return 0;  // even, or the tail does not matter
+  if (nslab < 64) return 0;  // shallow products (the rank-q update of V): sharing a tile costs more than it saves
   if (tiles > grid) return grid;
   const long long gl = std::min<long long>(std::min<long long>(grid, tiles * 8), tiles * nslab / 96);
   // worth it only with clearly more workgroups than tiles
@@ -119,33 +122,50 @@ struct GemmTile {
     const long long acol = (i0 + ca < g.lda) ? i0 + ca : 0;
     const long long bcol = (j0 + cb < g.ldb) ? j0 + cb : 0;
     double2_t sa[LA], sb[LB];
+    // The loads of a slab are issued BEFORE the multiplications of the previous one and consumed
+    // (masked for k >= K, stored to LDS) AFTER them: nothing between the two touches the staging
+    // registers, so that the wait for the loads comes behind the MFMA block.
+    const double *pa = g.A + (long long)(s0 * BK + ra) * g.lda + acol;
+    const double *pb = g.B + (long long)(s0 * BK + rb) * g.ldb + bcol;
+    const long long stepa = (long long)RA * g.lda, stepb = (long long)RB * g.ldb;
     auto gload = [&](int k0) {
+      if (k0 + BK <= g.K) {  // whole slab inside the operands (uniform)
+#pragma unroll
+        for (int p = 0; p < LA; p++) sa[p] = *(const double2_t *)(pa + p * stepa);
+#pragma unroll
+        for (int p = 0; p < LB; p++) sb[p] = *(const double2_t *)(pb + p * stepb);
+      } else {  // last, partial slab: rows beyond K are read from row K-1 and zeroed in lstore
+#pragma unroll
+        for (int p = 0; p < LA; p++) {
+          const int k = k0 + ra + p * RA, kc = k < g.K ? k : g.K - 1;
+          sa[p] = *(const double2_t *)(g.A + (long long)kc * g.lda + acol);
+        }
+#pragma unroll
+        for (int p = 0; p < LB; p++) {
+          const int k = k0 + rb + p * RB, kc = k < g.K ? k : g.K - 1;
+          sb[p] = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
+        }
+      }
+      pa += (long long)BK * g.lda, pb += (long long)BK * g.ldb;
+    };
+    auto lstore = [&](int buf, int k0) {
+      const bool tail = k0 + BK > g.K;
 #pragma unroll
       for (int p = 0; p < LA; p++) {
-        const int k = k0 + ra + p * RA;
-        const int kc = k < g.K ? k : g.K - 1;
-        double2_t v = *(const double2_t *)(g.A + (long long)kc * g.lda + acol);
-        if (k >= g.K) v = (double2_t){0.0, 0.0};
-        sa[p] = v;
+        double2_t v = sa[p];
+        if (tail && k0 + ra + p * RA >= g.K) v = (double2_t){0.0, 0.0};
+        *(double2_t *)(As + (buf * BK + ra + p * RA) * LDA + ca) = v;
       }
 #pragma unroll
       for (int p = 0; p < LB; p++) {
-        const int k = k0 + rb + p * RB;
-        const int kc = k < g.K ? k : g.K - 1;
-        double2_t v = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
-        if (k >= g.K) v = (double2_t){0.0, 0.0};
-        sb[p] = v;
+        double2_t v = sb[p];
+        if (tail && k0 + rb + p * RB >= g.K) v = (double2_t){0.0, 0.0};
+        *(double2_t *)(Bs + (buf * BK + rb + p * RB) * LDB + cb) = v;
       }
-    };
-    auto lstore = [&](int buf) {
-#pragma unroll
-      for (int p = 0; p < LA; p++) *(double2_t *)(As + (buf * BK + ra + p * RA) * LDA + ca) = sa[p];
-#pragma unroll
-      for (int p = 0; p < LB; p++) *(double2_t *)(Bs + (buf * BK + rb + p * RB) * LDB + cb) = sb[p];
     };
     if (s1 > s0) {
       gload(s0 * BK);
-      lstore(0);
+      lstore(0, s0 * BK);
     }
     __syncthreads();
     for (int s = s0; s < s1; s++) {
@@ -165,7 +185,7 @@ struct GemmTile {
 #pragma unroll
           for (int y = 0; y < TN; y++) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
       }
-      if (s + 1 < s1) lstore(buf ^ 1);
+      if (s + 1 < s1) lstore(buf ^ 1, (s + 1) * BK);
       __syncthreads();
     }
   }
@@ -364,18 +384,19 @@ struct ArgMax {
 };
 __device__ __forceinline__ ArgMax better(ArgMax a, ArgMax b) { return (b.v > a.v || (b.v == a.v && b.i < a.i)) ? b : a; }
 __device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax *red) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    ArgMax b;
-    b.v = __shfl_xor(a.v, o);
-    b.i = __shfl_xor(a.i, o);
-    a = better(a, b);
-  }
+  // wavefront: the maximum by DPP row operations, then the first lane that holds it (a fixed rule:
+  // the thread -> entry map is fixed, so ties always go the same way)
+  const double vmax = kktdev::wave_max_dpp(a.v);
+  const unsigned long long hit = __ballot(a.v == vmax);
+  const int src = hit ? __ffsll((long long)hit) - 1 : 0;
+  a.v = vmax;
+  a.i = __builtin_amdgcn_readlane(a.i, src);
   __syncthreads();
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = a;
   __syncthreads();
   ArgMax r = red[0];
-  for (int w = 1; w < (int)(blockDim.x >> 6); w++) r = better(r, red[w]);
+  for (int w = 1; w < (int)(blockDim.x >> 6); w++)
+    if (red[w].v > r.v) r = red[w];
   return r;
 }
 
@@ -448,6 +469,111 @@ __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, d
     __syncthreads();
   }
   return bad;
+}
+
+// The same inverse for q <= 16 NB with the matrix in REGISTERS: thread (ty, tx) of the 16 x 16 grid
+// holds the entries (ty + 16 i, tx + 16 j) of the augmented matrix [K | I] (NB x 2 NB doubles), so a
+// step costs the broadcast of the pivot row and column through LDS and NB x 2 NB multiply-adds; no
+// row or column is ever moved: after q steps the left half is a permutation, row r of the right half
+// is row pcol(r) of the inverse.  a (LDS, q x q, ld) holds K on entry and the inverse on return.
+template <int NB>
+__device__ int gj_inverse_reg(double *a, int q, int ld, int *ip, int *pc_of_row, double *colv, double *rowv, ArgMax *red) {
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  const double INF = __longlong_as_double(0x7ff0000000000000LL);
+  double m[NB][2 * NB];
+  int rfree = 0, cfree = 0;  // bit i: own row ty + 16 i / own column tx + 16 i not yet a pivot row / column
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int r = ty + 16 * i;
+    if (r < q) rfree |= 1 << i;
+    if (tx + 16 * i < q) cfree |= 1 << i;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const int c = tx + 16 * j;
+      m[i][j] = (r < q && c < q) ? a[r * ld + c] : 0.0;
+      m[i][NB + j] = (r == c && r < q) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  int bad = 0;
+  for (int s = 0; s < q; s++) {
+    ArgMax best{-1.0, 0x7fffffff};
+#pragma unroll
+    for (int i = 0; i < NB; i++)
+#pragma unroll
+      for (int j = 0; j < NB; j++)
+        if ((rfree >> i & 1) && (cfree >> j & 1)) {
+          const double v = fabs(m[i][j]);
+          best = better(best, ArgMax{v == v ? v : INF, (ty + 16 * i) * q + tx + 16 * j});
+        }
+    best = block_argmax(best, red);
+    const int pr = best.i / q, pc = best.i - pr * q;
+    if (!(best.v > 0.0) || best.v == INF) bad = 1;
+    // owners publish the pivot row (2 q values) and the pivot column
+    if ((pr & 15) == ty) {
+      const int i = pr >> 4;
+#pragma unroll
+      for (int ii = 0; ii < NB; ii++)
+        if (ii == i) {
+#pragma unroll
+          for (int j = 0; j < 2 * NB; j++) rowv[tx + 16 * j] = m[ii][j];
+        }
+    }
+    if ((pc & 15) == tx) {
+      const int j = pc >> 4;
+#pragma unroll
+      for (int jj = 0; jj < NB; jj++)
+        if (jj == j) {
+#pragma unroll
+          for (int i = 0; i < NB; i++) colv[ty + 16 * i] = m[i][jj];
+        }
+    }
+    if (tid == 0) pc_of_row[pr] = pc;
+    __syncthreads();
+    const double piv = rowv[(pc & 15) + 16 * (pc >> 4)];
+    const double pinv = bad ? 1.0 : 1.0 / piv;
+    double rv[2 * NB];
+#pragma unroll
+    for (int j = 0; j < 2 * NB; j++) rv[j] = rowv[tx + 16 * j] * pinv;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int r = ty + 16 * i;
+      const double f = colv[r];
+      if (r == pr) {
+#pragma unroll
+        for (int j = 0; j < 2 * NB; j++) m[i][j] = rv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2 * NB; j++) m[i][j] -= f * rv[j];
+      }
+    }
+    if ((pr & 15) == ty) rfree &= ~(1 << (pr >> 4));
+    if ((pc & 15) == tx) cfree &= ~(1 << (pc >> 4));
+    __syncthreads();  // rowv / colv are rewritten in the next step
+  }
+  // row r of the right half is row pc_of_row[r] of the inverse
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int r = ty + 16 * i;
+    if (r < q) {
+      const int dst = pc_of_row[r];
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const int c = tx + 16 * j;
+        if (c < q) a[dst * ld + c] = m[i][NB + j];
+      }
+    }
+  }
+  __syncthreads();
+  (void)ip;
+  return bad;
+}
+// dispatch: registers up to order 64, LDS above
+__device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red) {
+  if (q <= 16) return gj_inverse_reg<1>(a, q, ld, ip, ir, colv, rowv, red);
+  if (q <= 32) return gj_inverse_reg<2>(a, q, ld, ip, ir, colv, rowv, red);
+  if (q <= 64) return gj_inverse_reg<4>(a, q, ld, ip, ir, colv, rowv, red);
+  return gj_inverse(a, q, ld, ip, ir, ic, colv, rowv, red);
 }
 
 // Per stage, one workgroup: (A) rank-revealing elimination of the control part N_u of the
@@ -556,8 +682,8 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
     const int ld = q | 1;
     double *Km = sm;
     double *dsc = Km + (size_t)q * ld;
-    double *colv = dsc + q, *rowv = colv + q;
-    int *ip = (int *)(rowv + q), *ir = ip + q, *ic = ir + q;
+    double *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
+    int *ip = (int *)(rowv + (q > 128 ? q : 128)), *ir = ip + q, *ic = ir + q;
     for (int e = tid; e < q * q; e += nt) {
       const int i = e / q, j = e - i * q;
       double v;
@@ -593,7 +719,7 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
       Km[i * ld + j] *= dsc[i] * dsc[j];
     }
     __syncthreads();
-    const int bad = gj_inverse(Km, q, ld, ip, ir, ic, colv, rowv, red);
+    const int bad = gj_inverse_any(Km, q, ld, ip, ir, ic, colv, rowv, red);
     if (bad && tid == 0) atomicExch(a.status, 4);
     __syncthreads();
     for (int e = tid; e < a.qmax * a.qmax; e += nt) {
@@ -609,7 +735,7 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
 static size_t st_small_lds(int m, int capn) {
   const size_t q = (size_t)m + (size_t)(capn < m ? capn : m);
   const size_t a = (size_t)capn * (m + capn) * 8 + (size_t)(capn + m + 2) * 4 + (size_t)capn * 8 + 16;
-  const size_t b = q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4 + 16;
+  const size_t b = (size_t)kktdev::gj_lds_bytes((long long)q);
   return (a > b ? a : b) + 64;
 }
 
@@ -670,8 +796,8 @@ __global__ void __launch_bounds__(256) k_st_init_factor(int n0, int cap, const d
   __shared__ ArgMax red[4];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int c = dyn0[1], q = n0 + c, ld = q | 1;
-  double *Km = sm, *dsc = Km + (size_t)q * ld, *colv = dsc + q, *rowv = colv + q;
-  int *ip = (int *)(rowv + q), *ir = ip + q, *ic = ir + q;
+  double *Km = sm, *dsc = Km + (size_t)q * ld, *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
+  int *ip = (int *)(rowv + (q > 128 ? q : 128)), *ir = ip + q, *ic = ir + q;
   for (int e = tid; e < q * q; e += nt) {
     const int i = e / q, j = e - i * q;
     double v;
@@ -695,7 +821,7 @@ __global__ void __launch_bounds__(256) k_st_init_factor(int n0, int cap, const d
   __syncthreads();
   for (int e = tid; e < q * q; e += nt) Km[(e / q) * ld + e % q] *= dsc[e / q] * dsc[e % q];
   __syncthreads();
-  const int bad = gj_inverse(Km, q, ld, ip, ir, ic, colv, rowv, red);
+  const int bad = gj_inverse_any(Km, q, ld, ip, ir, ic, colv, rowv, red);
   if (bad && tid == 0) atomicExch(status, 4);
   __syncthreads();
   for (int e = tid; e < qmax * qmax; e += nt) {
@@ -725,7 +851,27 @@ __global__ void __launch_bounds__(256) k_st_gemv_rows(GemvRows g) {
   if (row >= g.M) return;
   const double *ar = g.A + (long long)row * g.lda;
   double s = 0.0;
-  for (int j = lane; j < g.N; j += 64) s += ar[j] * g.x[j];
+  if ((((size_t)ar) & 15) == 0) {
+    // 16-byte loads of the matrix row (it is what streams from HBM), four in flight per lane
+    const double2_t *a2 = (const double2_t *)ar;
+    const int n2 = g.N >> 1;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int j = lane;
+    for (; j + 192 < n2; j += 256) {
+      const double2_t v0 = a2[j], v1 = a2[j + 64], v2 = a2[j + 128], v3 = a2[j + 192];
+      s0 += v0.x * g.x[2 * j] + v0.y * g.x[2 * j + 1];
+      s1 += v1.x * g.x[2 * (j + 64)] + v1.y * g.x[2 * (j + 64) + 1];
+      s2 += v2.x * g.x[2 * (j + 128)] + v2.y * g.x[2 * (j + 128) + 1];
+      s3 += v3.x * g.x[2 * (j + 192)] + v3.y * g.x[2 * (j + 192) + 1];
+    }
+    for (; j < n2; j += 64) {
+      const double2_t v0 = a2[j];
+      s0 += v0.x * g.x[2 * j] + v0.y * g.x[2 * j + 1];
+    }
+    if ((g.N & 1) && lane == 0) s0 += ar[g.N - 1] * g.x[g.N - 1];
+    s = (s0 + s1) + (s2 + s3);
+  } else
+    for (int j = lane; j < g.N; j += 64) s += ar[j] * g.x[j];
   if (g.A2) {
     const int k2 = *g.n2;
     const double *br = g.A2 + (long long)row * g.lda2;

@@ -215,7 +215,7 @@ static int staged_upload(hqpkkt_t *h) {
   for (int k = 0; k < P.K; k++) d.lds_small = std::max(d.lds_small, stg::st_small_lds(P.mk[k], P.capn[k]));
   {
     const size_t q = (size_t)P.q0max;
-    d.lds_init = q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4 + 64;
+    d.lds_init = (size_t)kktdev::gj_lds_bytes((long long)q);
   }
   static std::mutex attr_mutex;  // function attributes are process state, shared by all handles
   static size_t attr_small = 0, attr_init = 0;

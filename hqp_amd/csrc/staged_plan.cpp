@@ -158,12 +158,12 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   for (int k = 0; k < K; k++) {
     const long long q = qmax[k];
     const long long a = (long long)capn[k] * (mk[k] + capn[k]) * 8 + (capn[k] + mk[k] + 2) * 4LL + capn[k] * 8LL;
-    const long long b = q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4;
+    const long long b = gj_lds_bytes(q);
     if (std::max(a, b) + 256 > 150 * 1024) return 1;
   }
   if (!fixed_x0) {
     const long long q = q0max;
-    if (q * (q | 1) * 8 + 3 * q * 8 + 3 * q * 4 + 256 > 150 * 1024) return 1;
+    if (gj_lds_bytes(q) + 256 > 150 * 1024) return 1;
   }
 
   // ------------------------------------------------------------------ storage
@@ -230,13 +230,27 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
         tot += cost[b];
       }
       int *cut = &xcut[(size_t)k * (shard_count + 1)];
-      double acc = 0.0;
-      int b = 0;
-      for (int p = 0; p < shard_count; p++) {
-        cut[p] = std::min<long long>(128LL * b, nn);
-        const double target = tot * (p + 1) / shard_count;
-        while (b < nb && (acc + 0.5 * cost[b] <= target || p == shard_count - 1)) acc += cost[b++];
+      // contiguous ranges of 128-column blocks with the smallest possible largest share: bisection on
+      // the bound, greedy filling for a given bound
+      auto fill = [&](double bound, int *out) {
+        int b = 0;
+        for (int p = 0; p < shard_count; p++) {
+          if (out) out[p] = (int)std::min<long long>(128LL * b, nn);
+          double acc = 0.0;
+          while (b < nb && (acc + cost[b] <= bound || (acc == 0.0 && p == shard_count - 1 && false))) acc += cost[b++];
+        }
+        return b == nb;
+      };
+      double lo = tot / shard_count, hi = tot;
+      for (int b2 = 0; b2 < nb; b2++) lo = std::max(lo, cost[b2]);
+      for (int it = 0; it < 60 && hi - lo > 1e-9 * tot; it++) {
+        const double mid = 0.5 * (lo + hi);
+        if (fill(mid, nullptr))
+          hi = mid;
+        else
+          lo = mid;
       }
+      fill(hi, cut);
       cut[shard_count] = (int)nn;
       for (int p = 0; p < shard_count; p++)
         xslot[k] = std::max(xslot[k], (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]));

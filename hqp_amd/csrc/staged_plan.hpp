@@ -8,6 +8,14 @@
 
 namespace kktdev {
 
+// LDS bytes of the one-workgroup inverse of an order-q matrix (gj_inverse_any in staged.hip.h):
+// the matrix, its scaling, the pivot column (>= 64) and row (>= 128: the register form broadcasts
+// the augmented row), three int work arrays
+inline long long gj_lds_bytes(long long q) {
+  const long long cv = q > 64 ? q : 64, rv = q > 128 ? q : 128;
+  return q * (q | 1) * 8 + (q + cv + rv) * 8 + 3 * q * 4 + 64;
+}
+
 struct StagedPlan {
   int n = 0, me = 0, m = 0, K = 0;
   int nq = 0, na = 0, nc = 0;

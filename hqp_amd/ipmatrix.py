@@ -345,7 +345,7 @@ class Hqp_IpLQDOCP(Hqp_IpMatrix):
         self._keep = arrs + [nx, nu]
         ptrs = [C.c_void_p(a.ctypes.data) if a.size else None for a in arrs]
         _check(self._L.hqpkkt_analyze_staged(self._h, dq.K, C.c_void_p(nx.ctypes.data), C.c_void_p(nu.ctypes.data),
-                                             dq.me_rest, dq.m, *ptrs), "init_dense")
+                                             dq.n, dq.me_rest, dq.m, *ptrs), "init_dense")
         self.update_dense(dq)
 
     def update_dense(self, dq):

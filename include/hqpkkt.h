@@ -269,15 +269,16 @@ int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu);
  * 10^6 variables needs (K = 200 stages of 5000 states: the CSR form of fx alone would hold
  * 5*10^9 entries, beyond int32 row pointers; Hqp_IpLQDOCP::update extracts exactly these dense
  * blocks fx[k], fu[k] from A, hqp/Hqp_IpLQDOCP.C:748-755).  hqpkkt_analyze_staged replaces
- * hqpkkt_analyze: stage sizes as in hqpkkt_set_stages; E (me_rest x n) holds the equality rows
- * other than the dynamics.  The vectors r2 / dy of factor / step / solve keep the reference's
+ * hqpkkt_analyze: stage sizes as in hqpkkt_set_stages; n_total = number of variables the blocks Q, E,
+ * C are built for (must equal nx[K] + sum of nx[k] + nu[k]: HQPKKT_E_SIZES otherwise); E (me_rest x n)
+ * holds the equality rows other than the dynamics.  The vectors r2 / dy of factor / step / solve keep the reference's
  * row order: the sum of nx[1..K] dynamics rows first, then the me_rest rows of E.
  * hqpkkt_set_values_staged replaces hqpkkt_set_values: F[k] points to the row-major
  * nx[k+1] x (nx[k] + nu[k]) block [fx_k fu_k] with leading dimension ldF[k] (the -1.0 of the
  * staircase is implied); pointers per opts.loc (the array F itself is a host array).  The
  * blocks are copied: the caller may release them afterwards.  hqpkkt_mehrotra / _franke do not
  * take this form (HQPKKT_E_INTERN). */
-int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int me_rest, int m, const int *Qp,
+int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int n_total, int me_rest, int m, const int *Qp,
                           const int *Qi, const int *Ep, const int *Ei, const int *Cp, const int *Ci);
 int hqpkkt_set_values_staged(hqpkkt_t *h, const double *Qx, const double *const *F, const long long *ldF,
                              const double *Ex, const double *Cx);
