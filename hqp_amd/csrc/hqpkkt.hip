@@ -150,6 +150,7 @@ struct hqpkkt {
   bool analyzed = false, uploaded = false, have_values = false, factored = false;
   hipStream_t own_stream = nullptr, stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr, evs0 = nullptr, evs1 = nullptr;
+  hipEvent_t evt0 = nullptr, evt1 = nullptr;  // total time of an interior-point run (hqpkkt_mehrotra / _franke)
   hqpkkt_stats st;
 
   // symbolic structure on the device
@@ -283,6 +284,8 @@ static int ensure_device(hqpkkt_t *h) {
     HIPCHK(hipEventCreate(&h->ev1));
     HIPCHK(hipEventCreate(&h->evs0));
     HIPCHK(hipEventCreate(&h->evs1));
+    HIPCHK(hipEventCreate(&h->evt0));
+    HIPCHK(hipEventCreate(&h->evt1));
   }
   if (!h->stream) h->stream = h->own_stream;
   return 0;
@@ -366,7 +369,7 @@ static int upload(hqpkkt_t *h) {
       (e = h->ent_val.alloc(an.ent_a.size())) || (e = h->panel.alloc(an.panel_elems)) ||
       (e = h->upd.alloc(an.upd_elems)) || (e = h->xar.alloc(an.x_elems)) ||
       (e = h->dinv.alloc(2 * (size_t)dim)) || (e = h->rhs.alloc(dim)) ||
-      (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ytmp.alloc(dim)) ||
+      (e = h->xsol.alloc(dim)) || (e = h->cb.alloc(an.cb_elems)) || (e = h->ytmp.alloc(std::max(dim, 8))) ||
       (e = h->vtmp.alloc(dim)) || (e = h->linv.alloc(an.linv_elems)) || (e = h->ptype.alloc(dim)) ||
       (e = h->lperm.alloc(dim)) || (e = h->flags.alloc(128)) ||
       (e = h->vin.alloc(2 * (size_t)m + n + me + 2 * (size_t)m)) ||
@@ -399,12 +402,26 @@ static int upload(hqpkkt_t *h) {
   h->lds_panel = (32 * mp + 2 * mp) * sizeof(double) + mp * sizeof(int);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
   if (h->lds_diag > 160 * 1024 || h->lds_bwdb > 160 * 1024) return HQPKKT_E_MEM;
-  HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)h->lds_diag));
-  HIPCHK(hipFuncSetAttribute((const void *)k_panel_solve, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)h->lds_panel));
-  HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize,
-                             (int)h->lds_bwdb));
+  {
+    // the attribute is state of the PROCESS, not of the handle: a second handle with smaller fronts must
+    // not lower the limit under one that still launches with more (several plugins in one host, the
+    // bench's concurrent systems): keep the largest value ever asked for, under a mutex
+    static std::mutex attr_mutex;
+    static size_t a_diag = 0, a_panel = 0, a_bwdb = 0;
+    std::lock_guard<std::mutex> lk(attr_mutex);
+    if (h->lds_diag > a_diag) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_diag));
+      a_diag = h->lds_diag;
+    }
+    if (h->lds_panel > a_panel) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_panel_solve, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_panel));
+      a_panel = h->lds_panel;
+    }
+    if (h->lds_bwdb > a_bwdb) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_bwd_b, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_bwdb));
+      a_bwdb = h->lds_bwdb;
+    }
+  }
   {
     const double rows = 2.0 * n + me + m;  // Q, A', C' per x row; A, C rows
     const double nnz = (double)an.Qfull.col.size() + 2.0 * an.A.col.size() + 2.0 * an.C.col.size();
@@ -726,7 +743,13 @@ static int do_factor(hqpkkt_t *h, const Vecs &v) {
   if (an.upd_x_slot > 0 &&
       (e = exchange(h, HQPKKT_XCHG_ALLGATHER, h->upd.p + an.upd_x_off, an.upd_x_slot, an.shard_count)))
     return e;
-  return graphed(h, h->gfactor[1], [&]() { return run_factor(h, v.z, v.w, 2); });
+  if ((e = graphed(h, h->gfactor[1], [&]() { return run_factor(h, v.z, v.w, 2); }))) return e;
+  // A zero pivot inside a subtree is seen by its owner only: agree on the status words (one small
+  // all-reduce), so that every rank returns the same code and nobody waits in a collective alone
+  k_status_pack<<<1, 64, 0, h->stream>>>(h->flags.p, h->bits.p, h->ytmp.p);
+  if ((e = exchange(h, HQPKKT_XCHG_ALLREDUCE_SUM, h->ytmp.p, 4, 1))) return e;
+  k_status_unpack<<<1, 64, 0, h->stream>>>(h->ytmp.p, h->flags.p, h->bits.p);
+  return 0;
 }
 
 static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
@@ -829,6 +852,19 @@ static void staged_release(StagedDev *sd, bool destroy) {
 }
 
 // =========================================================================
+// The C ABI promises that nothing is thrown across it (the shim's callers longjmp through Meschach
+// frames): every entry point that allocates with the standard library runs inside this guard.
+template <class F>
+static int guarded(F body) {
+  try {
+    return body();
+  } catch (const std::bad_alloc &) {
+    return HQPKKT_E_MEM;
+  } catch (...) {
+    return HQPKKT_E_INTERN;
+  }
+}
+
 extern "C" {
 
 int hqpkkt_default_opts(hqpkkt_opts *o) {
@@ -876,6 +912,8 @@ int hqpkkt_destroy(hqpkkt_t *h) {
     (void)hipEventDestroy(h->ev1);
     (void)hipEventDestroy(h->evs0);
     (void)hipEventDestroy(h->evs1);
+    (void)hipEventDestroy(h->evt0);
+    (void)hipEventDestroy(h->evt1);
     h->prof.destroy();
     (void)hipStreamDestroy(h->own_stream);
   }
@@ -888,37 +926,39 @@ static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd);
 
 int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m, const int *Qp, const int *Qi,
                    const int *Ap, const int *Ai, const int *Cp, const int *Ci, int *sbw) {
-  if (!h) return HQPKKT_E_NULL;
-  if ((n > 0 && (!Qp || (Qp[n] > 0 && !Qi))) || (me > 0 && (!Ap || (Ap[me] > 0 && !Ai))) ||
-      (m > 0 && (!Cp || (Cp[m] > 0 && !Ci))))
-    return HQPKKT_E_NULL;
-  if (h->uploaded) {
-    (void)hipSetDevice(h->opts.device);
-    (void)hipStreamSynchronize(h->stream);
-    h->release_device();
-  }
-  h->analyzed = false;
-  h->ip_hot_valid = h->fr_hot_valid = false;
-  auto keep = [](std::vector<int> &dst, const int *src, size_t k) {
-    dst.clear();
-    if (src && k) dst.assign(src, src + k);
-  };
-  keep(h->pQp, Qp, n ? (size_t)n + 1 : 0), keep(h->pQi, Qi, n ? (size_t)Qp[n] : 0);
-  keep(h->pAp, Ap, me ? (size_t)me + 1 : 0), keep(h->pAi, Ai, me ? (size_t)Ap[me] : 0);
-  keep(h->pCp, Cp, m ? (size_t)m + 1 : 0), keep(h->pCi, Ci, m ? (size_t)Cp[m] : 0);
-  h->zd_decided = h->opts.zd_policy >= 0;
-  h->zd_weak = false;
-  if (h->opts.mode == HQPKKT_MODE_STAGED) {
-    h->zd_decided = true;
-    int es = staged_analyze(h, n, me, m);
-    if (es) return es;
-    if (sbw) *sbw = -1;
+  return guarded([&]() -> int {
+    if (!h) return HQPKKT_E_NULL;
+    if ((n > 0 && (!Qp || (Qp[n] > 0 && !Qi))) || (me > 0 && (!Ap || (Ap[me] > 0 && !Ai))) ||
+        (m > 0 && (!Cp || (Cp[m] > 0 && !Ci))))
+      return HQPKKT_E_NULL;
+    if (h->uploaded) {
+      (void)hipSetDevice(h->opts.device);
+      (void)hipStreamSynchronize(h->stream);
+      h->release_device();
+    }
+    h->analyzed = false;
+    h->ip_hot_valid = h->fr_hot_valid = false;
+    auto keep = [](std::vector<int> &dst, const int *src, size_t k) {
+      dst.clear();
+      if (src && k) dst.assign(src, src + k);
+    };
+    keep(h->pQp, Qp, n ? (size_t)n + 1 : 0), keep(h->pQi, Qi, n ? (size_t)Qp[n] : 0);
+    keep(h->pAp, Ap, me ? (size_t)me + 1 : 0), keep(h->pAi, Ai, me ? (size_t)Ap[me] : 0);
+    keep(h->pCp, Cp, m ? (size_t)m + 1 : 0), keep(h->pCi, Ci, m ? (size_t)Cp[m] : 0);
+    h->zd_decided = h->opts.zd_policy >= 0;
+    h->zd_weak = false;
+    if (h->opts.mode == HQPKKT_MODE_STAGED) {
+      h->zd_decided = true;
+      int es = staged_analyze(h, n, me, m);
+      if (es) return es;
+      if (sbw) *sbw = -1;
+      return 0;
+    }
+    int e = run_analysis(h, n, me, m, h->zd_decided ? h->opts.zd_policy : 2);
+    if (e) return e;
+    if (sbw) *sbw = h->an.sbw;
     return 0;
-  }
-  int e = run_analysis(h, n, me, m, h->zd_decided ? h->opts.zd_policy : 2);
-  if (e) return e;
-  if (sbw) *sbw = h->an.sbw;
-  return 0;
+  });
 }
 
 // the symbolic phase with the zero-diagonal policy zd (hqpkkt_analyze; once more from
@@ -953,64 +993,56 @@ static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd) {
 }
 
 int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const double *Cx) {
-  if (!h) return HQPKKT_E_NULL;
-  if (!h->analyzed) return HQPKKT_E_INTERN;
-  Analysis &an = h->an;
-  if ((an.nq && !Qx) || (an.na && !Ax) || (an.nc && !Cx)) return HQPKKT_E_NULL;
-  int e;
-  if (h->opts.mode == HQPKKT_MODE_STAGED) return staged_set_values(h, Qx, Ax, Cx);
-  if (!h->zd_decided) {
-    // zd_policy -1: an x whose Hessian diagonal is weak against its coupling to an equality
-    // needs the 2x2 pivot with that equality's multiplier inside its own pivot block
-    h->zd_decided = true;
-    const int n = an.n, me = an.me;
-    std::vector<double> hq, ha;
-    const double *q = Qx, *a = Ax;
-    if (h->opts.loc == HQPKKT_LOC_DEVICE) {
-      HIPCHK(hipSetDevice(h->opts.device));
-      hq.resize(an.nq), ha.resize(an.na);
-      if (an.nq) HIPCHK(hipMemcpy(hq.data(), Qx, sizeof(double) * an.nq, hipMemcpyDeviceToHost));
-      if (an.na) HIPCHK(hipMemcpy(ha.data(), Ax, sizeof(double) * an.na, hipMemcpyDeviceToHost));
-      q = hq.data(), a = ha.data();
+  return guarded([&]() -> int {
+    if (!h) return HQPKKT_E_NULL;
+    if (!h->analyzed) return HQPKKT_E_INTERN;
+    Analysis &an = h->an;
+    if ((an.nq && !Qx) || (an.na && !Ax) || (an.nc && !Cx)) return HQPKKT_E_NULL;
+    int e;
+    if (h->opts.mode == HQPKKT_MODE_STAGED) return staged_set_values(h, Qx, Ax, Cx);
+    if (!h->uploaded && (e = upload(h))) return e;
+    HIPCHK(hipSetDevice(h->opts.device));
+    hipMemcpyKind kind =
+        h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    if (an.nq) HIPCHK(hipMemcpyAsync(h->vals.p, Qx, sizeof(double) * an.nq, kind, h->stream));
+    if (an.na) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq, Ax, sizeof(double) * an.na, kind, h->stream));
+    if (an.nc)
+      HIPCHK(hipMemcpyAsync(h->vals.p + an.nq + an.na, Cx, sizeof(double) * an.nc, kind, h->stream));
+    for (CsrBuf *c : {&h->Qf, &h->A, &h->AT, &h->C, &h->CT})
+      if (c->src.count)
+        k_gather_values<<<nblk((long long)c->src.count), 256, 0, h->stream>>>((int)c->src.count, c->src.p, h->vals.p, c->val.p);
+    if (h->opts.zd_policy < 0 && h->zd_used != 0) {
+      // zd_policy -1: an x whose Hessian diagonal is weak against its coupling to an equality needs the
+      // 2x2 pivot with that equality's multiplier inside its own pivot block.  Tested on EVERY update (the
+      // values of an SQP run change: an identity Hessian may turn weak later), on the device: one pass
+      // over Q's diagonal and the columns of A, one word read back.
+      h->zd_decided = true;
+      int *flag = h->flags.p + 100;
+      HIPCHK(hipMemsetAsync(flag, 0, sizeof(int), h->stream));
+      if (an.n > 0 && an.me > 0)
+        k_zd_weak<<<nblk(an.n), 256, 0, h->stream>>>(an.n, h->Qf.dev(), h->AT.dev(), flag);
+      int *hs = (int *)h->hpin;
+      HIPCHK(hipMemcpyAsync(hs, flag, sizeof(int), hipMemcpyDeviceToHost, h->stream));
+      HIPCHK(hipStreamSynchronize(h->stream));
+      h->zd_weak = hs[0] != 0;
+      if (h->zd_weak) {  // what the switch to policy 0 will need: the values on the host
+        auto keep = [&](std::vector<double> &dst, const double *src, size_t k) -> int {
+          dst.resize(k);
+          if (!k) return 0;
+          if (h->opts.loc == HQPKKT_LOC_DEVICE)
+            HIPCHK(hipMemcpy(dst.data(), src, sizeof(double) * k, hipMemcpyDeviceToHost));
+          else
+            std::memcpy(dst.data(), src, sizeof(double) * k);
+          return 0;
+        };
+        if ((e = keep(h->hQ, Qx, an.nq)) || (e = keep(h->hA, Ax, an.na)) || (e = keep(h->hC, Cx, an.nc))) return e;
+      }
     }
-    std::vector<double> qd(n, 0.0), am(n, 0.0);
-    for (int i = 0; i < n; i++)
-      for (int k = h->pQp[i]; k < h->pQp[i + 1]; k++)
-        if (h->pQi[k] == i) qd[i] = std::fabs(q[k]);
-    for (int r = 0; r < me; r++)
-      for (int k = h->pAp[r]; k < h->pAp[r + 1]; k++) am[h->pAi[k]] = std::fmax(am[h->pAi[k]], std::fabs(a[k]));
-    bool weak = false;
-    for (int i = 0; i < n && !weak; i++) weak = am[i] > 0.0 && qd[i] < 0.01 * am[i];
-    h->zd_weak = weak;
-  }
-  if (h->zd_weak && h->zd_used != 0) {  // what the switch to policy 0 will need
-    auto keep = [&](std::vector<double> &dst, const double *src, size_t k) -> int {
-      dst.resize(k);
-      if (!k) return 0;
-      if (h->opts.loc == HQPKKT_LOC_DEVICE) {
-        HIPCHK(hipSetDevice(h->opts.device));
-        HIPCHK(hipMemcpy(dst.data(), src, sizeof(double) * k, hipMemcpyDeviceToHost));
-      } else
-        std::memcpy(dst.data(), src, sizeof(double) * k);
-      return 0;
-    };
-    if ((e = keep(h->hQ, Qx, an.nq)) || (e = keep(h->hA, Ax, an.na)) || (e = keep(h->hC, Cx, an.nc))) return e;
-  }
-  if (!h->uploaded && (e = upload(h))) return e;
-  HIPCHK(hipSetDevice(h->opts.device));
-  hipMemcpyKind kind =
-      h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  if (an.nq) HIPCHK(hipMemcpyAsync(h->vals.p, Qx, sizeof(double) * an.nq, kind, h->stream));
-  if (an.na) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq, Ax, sizeof(double) * an.na, kind, h->stream));
-  if (an.nc)
-    HIPCHK(hipMemcpyAsync(h->vals.p + an.nq + an.na, Cx, sizeof(double) * an.nc, kind, h->stream));
-  for (CsrBuf *c : {&h->Qf, &h->A, &h->AT, &h->C, &h->CT})
-    if (c->src.count)
-      k_gather_values<<<nblk((long long)c->src.count), 256, 0, h->stream>>>((int)c->src.count, c->src.p, h->vals.p, c->val.p);
-  HIPCHK(hipStreamSynchronize(h->stream));
-  h->have_values = true;
-  h->factored = false;
-  return 0;
+    HIPCHK(hipStreamSynchronize(h->stream));
+    h->have_values = true;
+    h->factored = false;
+    return 0;
+  });
 }
 
 // zd_policy -1, weak Hessian diagonals, a solve whose refinement did not reach mat_eps: from now
@@ -1227,382 +1259,376 @@ int hqpkkt_default_ip_opts(hqpkkt_ip_opts *o) {
 
 int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
                     const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
-  if (!h || !res) return HQPKKT_E_NULL;
-  if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
-  if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
-  if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
-  hqpkkt_ip_opts o;
-  if (opts)
-    o = *opts;
-  else
-    hqpkkt_default_ip_opts(&o);
-  Analysis &an = h->an;
-  const int n = an.n, me = an.me, m = an.m;
-  if ((n && !c) || (me && !b) || (m && !d) || (n && !x) || (me && !y) || (m && (!z || !w))) return HQPKKT_E_NULL;
-  HIPCHK(hipSetDevice(h->opts.device));
-  hipStream_t s = h->stream;
-  const size_t nv = (size_t)n + me + 2 * (size_t)m;
-  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
-  int e;
-  if (h->ipv.count < need) {
-    if ((e = h->ipv.alloc(need))) return e;
-    h->ip_hot_valid = false;
-  }
-  h->fr_hot_valid = false;  // the arena is shared with hqpkkt_franke
-  IpCtx C;
-  C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
-  double *q = h->ipv.p;
-  auto take = [&](size_t k) { double *r = q; q += k; return r; };
-  C.x = take(n), C.y = take(me), C.z = take(m), C.w = take(m);
-  C.r1 = take(n), C.r2 = take(me), C.r3 = take(m), C.r4 = take(m);
-  C.dxa = take(n), C.dya = take(me), C.dza = take(m), C.dwa = take(m);
-  C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
-  C.c = take(n), C.b = take(me), C.d = take(m);
-  C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
-  C.zh = take(m), C.wh = take(m);
-  // out: 0..7 reductions (k_ip_final), 16..27 the blocking components (k_ip_minratio_final),
-  // 32..39 the step's scalars (IPS_*)
-  double *const Bk = C.out + 16, *const S = C.out + 32;
-  const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-  if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
-  if (me) HIPCHK(hipMemcpyAsync(C.b, b, sizeof(double) * me, in_kind, s));
-  if (m) HIPCHK(hipMemcpyAsync(C.d, d, sizeof(double) * m, in_kind, s));
-  // the plugin entry points below take the driver's DEVICE vectors
-  const int saved_loc = h->opts.loc;
-  struct Restore {
-    hqpkkt_t *h;
-    int loc;
-    ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
-  } restore{h, saved_loc};
-  h->opts.loc = HQPKKT_LOC_DEVICE;
-  h->lazy = true;  // no host round trip where the loop does not need the answer at once
-  hipEvent_t t0 = h->ev0;  // total time: own pair of events (the plugin calls reuse the handle's)
-  hipEvent_t tb, te;
-  HIPCHK(hipEventCreate(&tb));
-  HIPCHK(hipEventCreate(&te));
-  (void)t0;
-  HIPCHK(hipEventRecord(tb, s));
-  std::memset(res, 0, sizeof(*res));
-  res->result = 2;  // Hqp_Infeasible until decided (hqp/Hqp_IpsMehrotra.C:219)
-  const int total = n + me + m;
-  double resid = 0.0;
-  int iter = 0, n_factor = 0, n_solve = 0;
-  auto finish = [&](int result) -> int {
-    res->result = result, res->iters = iter, res->n_factor = n_factor, res->n_solve = n_solve;
-    if (n) HIPCHK(hipMemcpyAsync(x, C.x, sizeof(double) * n, out_kind, s));
-    if (me) HIPCHK(hipMemcpyAsync(y, C.y, sizeof(double) * me, out_kind, s));
-    if (m) HIPCHK(hipMemcpyAsync(z, C.z, sizeof(double) * m, out_kind, s));
-    if (m) HIPCHK(hipMemcpyAsync(w, C.w, sizeof(double) * m, out_kind, s));
-    HIPCHK(hipEventRecord(te, s));
-    HIPCHK(hipStreamSynchronize(s));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, tb, te);
-    res->ms_total = ms;
-    (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-    return 0;
-  };
-  auto factor = [&]() -> int { n_factor++; return hqpkkt_factor(h, C.z, C.w); };
-  auto solve = [&](double *ox, double *oy, double *oz, double *ow) -> int {
-    n_solve++;
-    return hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, ox, oy, oz, ow, &resid);
-  };
-  const int OPS_NONE[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-
-  // ------------------------------------------------------------ iterations
-  std::vector<double> phimin((size_t)o.max_iters + 2, 0.0);
-  double mu0 = 0.0, norm_r0 = 0.0, norm_data = 1.0;
-  // hot start (hqp/Hqp_IpsMehrotra.C:330-352, 475-478, 696-733): x, y of the last solve and
-  // the (z, w) kept from its last iteration far enough from the solution; a hot start that
-  // does not reduce phi by 1.2 per iteration, takes a step below 1e-5, runs max_warm_iters or
-  // does not end optimal is thrown away and the QP solved again from a cold start
-  const bool keep_hot = o.hot_start != 0 && m > 0;  // 1: hot start if possible, 2: cold, but prepare the next
-  bool hot = o.hot_start == 1 && m > 0 && h->ip_hot_valid;
-  const int max_warm = o.max_warm_iters > 0 ? o.max_warm_iters : 25;
-  const double hot_thresh = std::pow(o.eps, 0.3333);
-  int fail_iters = 0;
-  double test1 = 0.0;
-  const double gamma = std::pow(1.0e-4, 0.25);
-  int result = 2;
-  bool sing_hot = false;  // E_SING inside a hot-started run: restart cold like any failed hot start
-  bool stepped = false, pending = false;  // pending: a step is in the stream whose scalars were not read yet
-  double mu_pending = 0.0;
-  // The rare second corrector (hqp/Hqp_IpsMehrotra.C:612-624: the first corrector's own
-  // step is tiny): safe sigma, then Mehrotra's step rule with the host in the loop.
-  auto second_corrector = [&](double mu) -> int {
-    int e2;
-    const double smm = gamma / (1.0 - gamma) * mu;
-    k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, nullptr, C.r4);
-    if ((e2 = solve(C.dx, C.dy, C.dz, C.dw))) return e2;
-    k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk, m, gamma, nullptr);
-    HIPCHK(hipMemcpyAsync(C.hout, Bk, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    const double zmin = C.hout[0], wmin = C.hout[6];
-    const int izmin = (int)C.hout[1], iwmin = (int)C.hout[7];
-    const double z_iz = C.hout[2], dz_iz = C.hout[3], w_iz = C.hout[4], dw_iz = C.hout[5];
-    const double z_iw = C.hout[8], dz_iw = C.hout[9], w_iw = C.hout[10], dw_iw = C.hout[11];
-    double alpha;
-    if (izmin < 0 && iwmin < 0)
-      alpha = 1.0;
-    else {
-      alpha = izmin < 0 ? wmin : iwmin < 0 ? zmin : std::fmin(zmin, wmin);
-      k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, alpha, nullptr, C.z, C.w, C.dz, C.dw, C.part);
-      if ((e2 = C.reduce(OPS_NONE, 1))) return e2;
-      const double mu_pl = C.hout[0] / m;
-      double fpd;
-      if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
-        fpd = (o.gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
-      else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
-        fpd = (o.gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
-      else
-        fpd = 0.0;
-      alpha = std::fmax(0.0, std::fmin(std::fmax(1.0 - o.gammaf, fpd) * alpha, 1.0));
-    }
-    res->alpha = alpha;
-    k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, nullptr, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
-    return 0;
-  };
-  // before leaving the loop with a step still in the stream: was it taken?
-  auto settle = [&]() -> int {
-    if (!pending) return 0;
-    pending = false;
-    HIPCHK(hipMemcpyAsync(C.hout + 32, S, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    res->alpha = C.hout[32 + IPS_ALPHA];
-    if (C.hout[32 + IPS_NEED2] != 0.0) return second_corrector(mu_pending);
-    return 0;
-  };
-  for (;;) {  // hot first (if asked for and possible), cold after a failed hot start
-  iter = 0, result = 2, stepped = false, pending = false, sing_hot = false;
-  std::fill(phimin.begin(), phimin.end(), 0.0);
-  res->alpha = 1.0;
-  if (hot) {
-    CopyList L{{C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
-    k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 2);
-  } else {
-      // (x = y = 0 until the cold start's solve has succeeded: what the caller gets back when the
-      // very first factorisation is singular, as from the reference)
-      if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
-      if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
-      if (m > 0) {
-    // qp_init_method (:226-250, 294-297): 0 z = w = 1, r4 = 0; 1, 2 w = a ratio of the data's norms;
-    // 3 as 0 with r4 = -z.*w and the solve's dz, dw added to z, w
-    double w0 = 1.0;
-    if (o.init_method == 1) w0 = std::fmax(o.norm_d, 1e-10) * o.norm_Q / o.norm_C;
-    if (o.init_method == 2) w0 = o.norm_C / std::fmax(o.norm_d, 1e-10) / o.norm_Q;
-    k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4, w0,
-                                              o.init_method ? -w0 : 0.0);
-        if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
-          if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:262-269)
-          (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-          return e;
-        }
-        HIPCHK(hipMemcpyAsync(C.x, C.dx, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
-        if (me) HIPCHK(hipMemcpyAsync(C.y, C.dy, sizeof(double) * me, hipMemcpyDeviceToDevice, s));
-    if (o.init_method == 3) k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, 1.0, 1.0, C.dz, C.dw);  // :294-297
-    k_ip_cold_stats<<<IP_BLOCKS, 256, 0, s>>>(m, C.dz, C.dw, C.part);
-        const int ops1[IP_SLOTS] = {IP_MIN, IP_MIN, IP_MAX, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-        if ((e = C.reduce(ops1, 6))) return e;
-        double mindz = C.hout[0], mindw = C.hout[1], sumdz = C.hout[4], sumdw = C.hout[5];
-        if (C.hout[2] == 0.0) {  // :301-304
-          k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dz);
-          mindz = 1.0e-10, sumdz = 1.0e-10 * m;
-        }
-        if (C.hout[3] == 0.0) {
-          k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dw);
-          mindw = 1.0e-10, sumdw = 1.0e-10 * m;
-        }
-        double delz = std::fmax(-1.5 * mindz, 0.0), delw = std::fmax(-1.5 * mindw, 0.0);
-        // gap = (dz + delz)'(dw + delw): k_ip_mupl with alpha = 1 on (delz, dz), (delw, dw) shifted vectors
-        k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
-        k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, nullptr, C.z, C.w, C.dz, C.dw, C.part);
-        if ((e = C.reduce(OPS_NONE, 1))) return e;
-        const double gap0 = C.hout[0];
-        delz += 0.5 * gap0 / (sumdw + m * delw);
-        delw += 0.5 * gap0 / (sumdz + m * delz);
-        k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
-      }
-
-    if (keep_hot) {  // :318-319
-      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0, C.zh);
-      k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0, C.wh);
-    }
-  }
-  bool restart_cold = false;
-  while (true) {
-    double phi = 0.0;
-    bool redo = false;  // the second corrector replaced the step: same step() call, new right-hand sides
-    do {
-    // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
-    if (h->short_rows)
-      k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                            h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
-                                            C.part);
+  return guarded([&]() -> int {
+    if (!h || !res) return HQPKKT_E_NULL;
+    if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
+    if (opts && opts->max_iters < 0) return HQPKKT_E_RANGE;
+    if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
+    if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
+    hqpkkt_ip_opts o;
+    if (opts)
+      o = *opts;
     else
-      k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                             h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
-                                             C.part);
-    if (m == 0) {  // equality-constrained QP: one Newton step (:364-413)
-      if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
-        if (e == HQPKKT_E_SING) return finish(4);
-        (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-        return e;
-      }
-      k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, nullptr, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
-      iter++;
-      return finish(0);
+      hqpkkt_default_ip_opts(&o);
+    Analysis &an = h->an;
+    const int n = an.n, me = an.me, m = an.m;
+    if ((n && !c) || (me && !b) || (m && !d) || (n && !x) || (me && !y) || (m && (!z || !w))) return HQPKKT_E_NULL;
+    HIPCHK(hipSetDevice(h->opts.device));
+    hipStream_t s = h->stream;
+    const size_t nv = (size_t)n + me + 2 * (size_t)m;
+    const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
+    int e;
+    if (h->ipv.count < need) {
+      if ((e = h->ipv.alloc(need))) return e;
+      h->ip_hot_valid = false;
     }
-    {  // the reductions of this iterate and what the step before left behind, one round trip
-      const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
-      IpOps o2;
-      for (int k = 0; k < IP_SLOTS; k++) o2.op[k] = ops2[k];
-      k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-      HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
+    h->fr_hot_valid = false;  // the arena is shared with hqpkkt_franke
+    IpCtx C;
+    C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
+    double *q = h->ipv.p;
+    auto take = [&](size_t k) { double *r = q; q += k; return r; };
+    C.x = take(n), C.y = take(me), C.z = take(m), C.w = take(m);
+    C.r1 = take(n), C.r2 = take(me), C.r3 = take(m), C.r4 = take(m);
+    C.dxa = take(n), C.dya = take(me), C.dza = take(m), C.dwa = take(m);
+    C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
+    C.c = take(n), C.b = take(me), C.d = take(m);
+    C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
+    C.zh = take(m), C.wh = take(m);
+    // out: 0..7 reductions (k_ip_final), 16..27 the blocking components (k_ip_minratio_final),
+    // 32..39 the step's scalars (IPS_*)
+    double *const Bk = C.out + 16, *const S = C.out + 32;
+    const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
+    if (me) HIPCHK(hipMemcpyAsync(C.b, b, sizeof(double) * me, in_kind, s));
+    if (m) HIPCHK(hipMemcpyAsync(C.d, d, sizeof(double) * m, in_kind, s));
+    // the plugin entry points below take the driver's DEVICE vectors
+    const int saved_loc = h->opts.loc;
+    struct Restore {
+      hqpkkt_t *h;
+      int loc;
+      ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
+    } restore{h, saved_loc};
+    h->opts.loc = HQPKKT_LOC_DEVICE;
+    h->lazy = true;  // no host round trip where the loop does not need the answer at once
+    hipEvent_t t0 = h->ev0;  // total time: own pair of events (the plugin calls reuse the handle's)
+    const hipEvent_t tb = h->evt0, te = h->evt1;  // owned by the handle: no early return can leak them
+    (void)t0;
+    HIPCHK(hipEventRecord(tb, s));
+    std::memset(res, 0, sizeof(*res));
+    res->result = 2;  // Hqp_Infeasible until decided (hqp/Hqp_IpsMehrotra.C:219)
+    const int total = n + me + m;
+    double resid = 0.0;
+    int iter = 0, n_factor = 0, n_solve = 0;
+    auto finish = [&](int result) -> int {
+      res->result = result, res->iters = iter, res->n_factor = n_factor, res->n_solve = n_solve;
+      if (n) HIPCHK(hipMemcpyAsync(x, C.x, sizeof(double) * n, out_kind, s));
+      if (me) HIPCHK(hipMemcpyAsync(y, C.y, sizeof(double) * me, out_kind, s));
+      if (m) HIPCHK(hipMemcpyAsync(z, C.z, sizeof(double) * m, out_kind, s));
+      if (m) HIPCHK(hipMemcpyAsync(w, C.w, sizeof(double) * m, out_kind, s));
+      HIPCHK(hipEventRecord(te, s));
       HIPCHK(hipStreamSynchronize(s));
-    }
-    if (pending) {
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, tb, te);
+      res->ms_total = ms;
+      return 0;
+    };
+    auto factor = [&]() -> int { n_factor++; return hqpkkt_factor(h, C.z, C.w); };
+    auto solve = [&](double *ox, double *oy, double *oz, double *ow) -> int {
+      n_solve++;
+      return hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, ox, oy, oz, ow, &resid);
+    };
+    const int OPS_NONE[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+  
+    // ------------------------------------------------------------ iterations
+    std::vector<double> phimin((size_t)o.max_iters + 2, 0.0);
+    double mu0 = 0.0, norm_r0 = 0.0, norm_data = 1.0;
+    // hot start (hqp/Hqp_IpsMehrotra.C:330-352, 475-478, 696-733): x, y of the last solve and
+    // the (z, w) kept from its last iteration far enough from the solution; a hot start that
+    // does not reduce phi by 1.2 per iteration, takes a step below 1e-5, runs max_warm_iters or
+    // does not end optimal is thrown away and the QP solved again from a cold start
+    const bool keep_hot = o.hot_start != 0 && m > 0;  // 1: hot start if possible, 2: cold, but prepare the next
+    bool hot = o.hot_start == 1 && m > 0 && h->ip_hot_valid;
+    const int max_warm = o.max_warm_iters > 0 ? o.max_warm_iters : 25;
+    const double hot_thresh = std::pow(o.eps, 0.3333);
+    int fail_iters = 0;
+    double test1 = 0.0;
+    const double gamma = std::pow(1.0e-4, 0.25);
+    int result = 2;
+    bool sing_hot = false;  // E_SING inside a hot-started run: restart cold like any failed hot start
+    bool stepped = false, pending = false;  // pending: a step is in the stream whose scalars were not read yet
+    double mu_pending = 0.0;
+    // The rare second corrector (hqp/Hqp_IpsMehrotra.C:612-624: the first corrector's own
+    // step is tiny): safe sigma, then Mehrotra's step rule with the host in the loop.
+    auto second_corrector = [&](double mu) -> int {
+      int e2;
+      const double smm = gamma / (1.0 - gamma) * mu;
+      k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, smm, nullptr, C.r4);
+      if ((e2 = solve(C.dx, C.dy, C.dz, C.dw))) return e2;
+      k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+      k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk, m, gamma, nullptr);
+      HIPCHK(hipMemcpyAsync(C.hout, Bk, sizeof(double) * 12, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
+      const double zmin = C.hout[0], wmin = C.hout[6];
+      const int izmin = (int)C.hout[1], iwmin = (int)C.hout[7];
+      const double z_iz = C.hout[2], dz_iz = C.hout[3], w_iz = C.hout[4], dw_iz = C.hout[5];
+      const double z_iw = C.hout[8], dz_iw = C.hout[9], w_iw = C.hout[10], dw_iw = C.hout[11];
+      double alpha;
+      if (izmin < 0 && iwmin < 0)
+        alpha = 1.0;
+      else {
+        alpha = izmin < 0 ? wmin : iwmin < 0 ? zmin : std::fmin(zmin, wmin);
+        k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, alpha, nullptr, C.z, C.w, C.dz, C.dw, C.part);
+        if ((e2 = C.reduce(OPS_NONE, 1))) return e2;
+        const double mu_pl = C.hout[0] / m;
+        double fpd;
+        if (iwmin >= 0 && alpha == wmin && z_iw > -alpha * dz_iw)
+          fpd = (o.gammaf * mu_pl / (z_iw + alpha * dz_iw) - w_iw) / (alpha * dw_iw);
+        else if (izmin >= 0 && alpha == zmin && w_iz > -alpha * dw_iz)
+          fpd = (o.gammaf * mu_pl / (w_iz + alpha * dw_iz) - z_iz) / (alpha * dz_iz);
+        else
+          fpd = 0.0;
+        alpha = std::fmax(0.0, std::fmin(std::fmax(1.0 - o.gammaf, fpd) * alpha, 1.0));
+      }
+      res->alpha = alpha;
+      k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, alpha, nullptr, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
+      return 0;
+    };
+    // before leaving the loop with a step still in the stream: was it taken?
+    auto settle = [&]() -> int {
+      if (!pending) return 0;
       pending = false;
+      HIPCHK(hipMemcpyAsync(C.hout + 32, S, sizeof(double) * 8, hipMemcpyDeviceToHost, s));
+      HIPCHK(hipStreamSynchronize(s));
       res->alpha = C.hout[32 + IPS_ALPHA];
-      if (C.hout[32 + IPS_NEED2] != 0.0) {  // that step was not taken (alpha 0): second corrector first
-        iter--;
-        if ((e = second_corrector(mu_pending))) {
-            if (e == HQPKKT_E_SING && hot) {
-            sing_hot = true;
-            break;
+      if (C.hout[32 + IPS_NEED2] != 0.0) return second_corrector(mu_pending);
+      return 0;
+    };
+    for (;;) {  // hot first (if asked for and possible), cold after a failed hot start
+    iter = 0, result = 2, stepped = false, pending = false, sing_hot = false;
+    std::fill(phimin.begin(), phimin.end(), 0.0);
+    res->alpha = 1.0;
+    if (hot) {
+      CopyList L{{C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
+      k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 2);
+    } else {
+        // (x = y = 0 until the cold start's solve has succeeded: what the caller gets back when the
+        // very first factorisation is singular, as from the reference)
+        if (n) HIPCHK(hipMemsetAsync(C.x, 0, sizeof(double) * n, s));
+        if (me) HIPCHK(hipMemsetAsync(C.y, 0, sizeof(double) * me, s));
+        if (m > 0) {
+      // qp_init_method (:226-250, 294-297): 0 z = w = 1, r4 = 0; 1, 2 w = a ratio of the data's norms;
+      // 3 as 0 with r4 = -z.*w and the solve's dz, dw added to z, w
+      double w0 = 1.0;
+      if (o.init_method == 1) w0 = std::fmax(o.norm_d, 1e-10) * o.norm_Q / o.norm_C;
+      if (o.init_method == 2) w0 = o.norm_C / std::fmax(o.norm_d, 1e-10) / o.norm_Q;
+      k_ip_cold_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, C.c, C.b, C.d, C.z, C.w, C.r1, C.r2, C.r3, C.r4, w0,
+                                                o.init_method ? -w0 : 0.0);
+          if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
+            if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:262-269)
+            return e;
           }
+          HIPCHK(hipMemcpyAsync(C.x, C.dx, sizeof(double) * n, hipMemcpyDeviceToDevice, s));
+          if (me) HIPCHK(hipMemcpyAsync(C.y, C.dy, sizeof(double) * me, hipMemcpyDeviceToDevice, s));
+      if (o.init_method == 3) k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, 1.0, 1.0, C.dz, C.dw);  // :294-297
+      k_ip_cold_stats<<<IP_BLOCKS, 256, 0, s>>>(m, C.dz, C.dw, C.part);
+          const int ops1[IP_SLOTS] = {IP_MIN, IP_MIN, IP_MAX, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+          if ((e = C.reduce(ops1, 6))) return e;
+          double mindz = C.hout[0], mindw = C.hout[1], sumdz = C.hout[4], sumdw = C.hout[5];
+          if (C.hout[2] == 0.0) {  // :301-304
+            k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dz);
+            mindz = 1.0e-10, sumdz = 1.0e-10 * m;
+          }
+          if (C.hout[3] == 0.0) {
+            k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0e-10, C.dw);
+            mindw = 1.0e-10, sumdw = 1.0e-10 * m;
+          }
+          double delz = std::fmax(-1.5 * mindz, 0.0), delw = std::fmax(-1.5 * mindw, 0.0);
+          // gap = (dz + delz)'(dw + delw): k_ip_mupl with alpha = 1 on (delz, dz), (delw, dw) shifted vectors
+          k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
+          k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, nullptr, C.z, C.w, C.dz, C.dw, C.part);
+          if ((e = C.reduce(OPS_NONE, 1))) return e;
+          const double gap0 = C.hout[0];
+          delz += 0.5 * gap0 / (sumdw + m * delw);
+          delw += 0.5 * gap0 / (sumdz + m * delz);
+          k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.dz, C.dw, delz, delw, C.z, C.w);
+        }
+  
+      if (keep_hot) {  // :318-319
+        k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0, C.zh);
+        k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0, C.wh);
+      }
+    }
+    bool restart_cold = false;
+    while (true) {
+      double phi = 0.0;
+      bool redo = false;  // the second corrector replaced the step: same step() call, new right-hand sides
+      do {
+      // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
+      if (h->short_rows)
+        k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                              h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
+                                              C.part);
+      else
+        k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                               h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
+                                               C.part);
+      if (m == 0) {  // equality-constrained QP: one Newton step (:364-413)
+        if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
           if (e == HQPKKT_E_SING) return finish(4);
-          (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
           return e;
         }
+        k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, nullptr, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, C.part);
         iter++;
-        redo = true;  // right-hand sides and reductions of the new iterate
+        return finish(0);
+      }
+      {  // the reductions of this iterate and what the step before left behind, one round trip
+        const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
+        IpOps o2;
+        for (int k = 0; k < IP_SLOTS; k++) o2.op[k] = ops2[k];
+        k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
+        HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+      }
+      if (pending) {
+        pending = false;
+        res->alpha = C.hout[32 + IPS_ALPHA];
+        if (C.hout[32 + IPS_NEED2] != 0.0) {  // that step was not taken (alpha 0): second corrector first
+          iter--;
+          if ((e = second_corrector(mu_pending))) {
+              if (e == HQPKKT_E_SING && hot) {
+              sing_hot = true;
+              break;
+            }
+            if (e == HQPKKT_E_SING) return finish(4);
+            return e;
+          }
+          iter++;
+          redo = true;  // right-hand sides and reductions of the new iterate
+          break;
+        }
+      }
+      const double gap = C.hout[0], mu = C.hout[2] / m, norm_r = C.hout[3];
+      if (stepped && (!std::isfinite(mu) || !std::isfinite(norm_r) || !std::isfinite(gap))) {
+        iter--;  // the reference leaves the failed step uncounted
+        result = 4;
         break;
       }
-    }
-    const double gap = C.hout[0], mu = C.hout[2] / m, norm_r = C.hout[3];
-    if (stepped && (!std::isfinite(mu) || !std::isfinite(norm_r) || !std::isfinite(gap))) {
-      iter--;  // the reference leaves the failed step uncounted
-      result = 4;
-      break;
-    }
-    res->gap = gap, res->mu = mu, res->pcost = C.hout[1];
-    if (iter == 0) {
-      mu0 = mu, norm_r0 = norm_r;
-      norm_data = o.norm_data > 0.0 ? o.norm_data : 1.0;
-    }
-    phi = (norm_r + std::fabs(gap)) / norm_data;
-    phimin[iter] = phi;
-    res->phi = phi;
-    if (keep_hot && phi > hot_thresh) {  // prepare the next hot start (:475-478)
-      CopyList L{{C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
-      k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 2);
-    }
-    if (mu <= o.eps && norm_r <= o.eps * norm_data) {  // :487-490
-      result = 0;
-      break;
-    }
-    double pm = phimin[0];
-    for (int i = 1; i <= iter; i++) pm = std::fmin(pm, phimin[i]);
-    if (phi > o.eps && phi >= 1.0e4 * pm) {  // :494-502
-      result = 3;
-      break;
-    }
-    if (iter >= 30) {  // slow convergence (:506-516)
-      double pm30 = phimin[1];
-      for (int i = 2; i <= iter - 30; i++) pm30 = std::fmin(pm30, phimin[i]);
-      if (pm >= 0.5 * pm30) {
+      res->gap = gap, res->mu = mu, res->pcost = C.hout[1];
+      if (iter == 0) {
+        mu0 = mu, norm_r0 = norm_r;
+        norm_data = o.norm_data > 0.0 ? o.norm_data : 1.0;
+      }
+      phi = (norm_r + std::fabs(gap)) / norm_data;
+      phimin[iter] = phi;
+      res->phi = phi;
+      if (keep_hot && phi > hot_thresh) {  // prepare the next hot start (:475-478)
+        CopyList L{{C.z, C.w, nullptr, nullptr, nullptr, nullptr}, {C.zh, C.wh, nullptr, nullptr, nullptr, nullptr}, {m, m, 0, 0, 0, 0}};
+        k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 2);
+      }
+      if (mu <= o.eps && norm_r <= o.eps * norm_data) {  // :487-490
+        result = 0;
+        break;
+      }
+      double pm = phimin[0];
+      for (int i = 1; i <= iter; i++) pm = std::fmin(pm, phimin[i]);
+      if (phi > o.eps && phi >= 1.0e4 * pm) {  // :494-502
         result = 3;
         break;
       }
-    }
-    if (norm_r > o.eps * norm_data && norm_r / mu >= 1.0e8 * norm_r0 / mu0) result = 3;  // :520-524 (no return)
-    // factorise; predictor (affine) step
-    if ((e = factor()) || (e = solve(C.dxa, C.dya, C.dza, C.dwa))) {
-      if (e == HQPKKT_E_SING && hot) {  // a hot start that ends degenerate is thrown away (:723-727)
-        sing_hot = true;
-        break;
+      if (iter >= 30) {  // slow convergence (:506-516)
+        double pm30 = phimin[1];
+        for (int i = 2; i <= iter - 30; i++) pm30 = std::fmin(pm30, phimin[i]);
+        if (pm >= 0.5 * pm30) {
+          result = 3;
+          break;
+        }
       }
-      if (e == HQPKKT_E_SING) return finish(4);
-      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-      return e;
-    }
-    // From here to the step itself nothing is read back: sigma (Terlaky's modification,
-    // :583-590; the safe value when the predictor step is short and the reference skips the
-    // first corrector, :612-616), the corrector's blocking components, the damped step length
-    // (:629-672) are computed by thread 0 of the reduction kernels and consumed through device pointers.
-    k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.part);
-    {
-      const int ops3[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-      IpOps o3;
-      for (int k = 0; k < IP_SLOTS; k++) o3.op[k] = ops3[k];
-      k_ip_final<<<1, 256, 0, s>>>(C.part, o3, C.out, IpEpi{1, m, mu, gamma, 0.0, nullptr, S});
-    }
-    k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, 0.0, S + IPS_SMM, C.r4);
-    if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
-      if (e == HQPKKT_E_SING && hot) {
-        sing_hot = true;
-        break;
-      }
-      if (e == HQPKKT_E_SING) return finish(4);
-      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-      return e;
-    }
-    k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-    k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk, m, gamma, S);
-    k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, S + IPS_ALPHA_PRE, C.z, C.w, C.dz, C.dw, C.part);
-    {
-      IpOps on;
-      for (int k = 0; k < IP_SLOTS; k++) on.op[k] = IP_SUM;
-      k_ip_final<<<1, 256, 0, s>>>(C.part, on, C.out, IpEpi{2, m, 0.0, 0.0, o.gammaf, Bk, S});
-    }
-    k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 0.0, S + IPS_ALPHA, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw,
-                                          C.part);
-    // (:684-690: a non-finite mu or x ends the solve as degenerate; seen here by the next
-    // pass through k_ip_rhs, whose sums and maximum carry the NaN / inf)
-    iter++;
-    stepped = true, pending = true, mu_pending = mu;
-    } while (0);
-    if (sing_hot) {
-      result = 4;
-      break;
-    }
-    if (redo) continue;
-    // ---- what solve() does after every step() call (:703-718)
-    const bool leave = result == 0 || result == 3 || result == 4 || iter + fail_iters >= o.max_iters ||
-                       (hot && iter >= max_warm);
-    if (hot || leave) {  // the step's own scalars are needed now: was it taken, how long was it
-      if ((e = settle())) {
-        if (e == HQPKKT_E_SING && hot) {
-          result = 4;
+      if (norm_r > o.eps * norm_data && norm_r / mu >= 1.0e8 * norm_r0 / mu0) result = 3;  // :520-524 (no return)
+      // factorise; predictor (affine) step
+      if ((e = factor()) || (e = solve(C.dxa, C.dya, C.dza, C.dwa))) {
+        if (e == HQPKKT_E_SING && hot) {  // a hot start that ends degenerate is thrown away (:723-727)
+          sing_hot = true;
           break;
         }
         if (e == HQPKKT_E_SING) return finish(4);
-        (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
         return e;
       }
-    }
-    if (hot) {
-      if (iter == 1)
-        test1 = phi;
-      else if (phi > test1 / std::pow(1.2, iter - 1.0) || res->alpha < 1.0e-5) {
-        fail_iters += iter;
-        restart_cold = true;
+      // From here to the step itself nothing is read back: sigma (Terlaky's modification,
+      // :583-590; the safe value when the predictor step is short and the reference skips the
+      // first corrector, :612-616), the corrector's blocking components, the damped step length
+      // (:629-672) are computed by thread 0 of the reduction kernels and consumed through device pointers.
+      k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.part);
+      {
+        const int ops3[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+        IpOps o3;
+        for (int k = 0; k < IP_SLOTS; k++) o3.op[k] = ops3[k];
+        k_ip_final<<<1, 256, 0, s>>>(C.part, o3, C.out, IpEpi{1, m, mu, gamma, 0.0, nullptr, S});
+      }
+      k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, 0.0, S + IPS_SMM, C.r4);
+      if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
+        if (e == HQPKKT_E_SING && hot) {
+          sing_hot = true;
+          break;
+        }
+        if (e == HQPKKT_E_SING) return finish(4);
+        return e;
+      }
+      k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+      k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk, m, gamma, S);
+      k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, S + IPS_ALPHA_PRE, C.z, C.w, C.dz, C.dw, C.part);
+      {
+        IpOps on;
+        for (int k = 0; k < IP_SLOTS; k++) on.op[k] = IP_SUM;
+        k_ip_final<<<1, 256, 0, s>>>(C.part, on, C.out, IpEpi{2, m, 0.0, 0.0, o.gammaf, Bk, S});
+      }
+      k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 0.0, S + IPS_ALPHA, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw,
+                                            C.part);
+      // (:684-690: a non-finite mu or x ends the solve as degenerate; seen here by the next
+      // pass through k_ip_rhs, whose sums and maximum carry the NaN / inf)
+      iter++;
+      stepped = true, pending = true, mu_pending = mu;
+      } while (0);
+      if (sing_hot) {
+        result = 4;
         break;
       }
+      if (redo) continue;
+      // ---- what solve() does after every step() call (:703-718)
+      const bool leave = result == 0 || result == 3 || result == 4 || iter + fail_iters >= o.max_iters ||
+                         (hot && iter >= max_warm);
+      if (hot || leave) {  // the step's own scalars are needed now: was it taken, how long was it
+        if ((e = settle())) {
+          if (e == HQPKKT_E_SING && hot) {
+            result = 4;
+            break;
+          }
+          if (e == HQPKKT_E_SING) return finish(4);
+          return e;
+        }
+      }
+      if (hot) {
+        if (iter == 1)
+          test1 = phi;
+        else if (phi > test1 / std::pow(1.2, iter - 1.0) || res->alpha < 1.0e-5) {
+          fail_iters += iter;
+          restart_cold = true;
+          break;
+        }
+      }
+      if (leave) break;
     }
-    if (leave) break;
-  }
-  if (restart_cold || (hot && result != 0)) {  // bad hot start: its iterations are lost (:723-727)
-    if (!restart_cold) fail_iters += iter;
-    hot = false;
-    continue;
-  }
-  break;
-  }
-  iter += fail_iters;
-  if (m > 0) h->ip_hot_valid = keep_hot;
-  return finish(result);
+    if (restart_cold || (hot && result != 0)) {  // bad hot start: its iterations are lost (:723-727)
+      if (!restart_cold) fail_iters += iter;
+      hot = false;
+      continue;
+    }
+    break;
+    }
+    iter += fail_iters;
+    if (m > 0) h->ip_hot_valid = keep_hot;
+    return finish(result);
+  });
 }
 
 // ---- device-resident Franke loop ----------------------------------------------
@@ -1611,212 +1637,211 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
 // the gap and rhomin, the step length, zeta) live on the host as in the reference.
 int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
                   const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
-  if (!h || !res) return HQPKKT_E_NULL;
-  if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
-  if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
-  if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
-  hqpkkt_ip_opts o;
-  if (opts)
-    o = *opts;
-  else
-    hqpkkt_default_ip_opts(&o);
-  Analysis &an = h->an;
-  const int n = an.n, me = an.me, m = an.m;
-  if ((n && !c) || (me && !b) || (m && !d) || (n && !x) || (me && !y) || (m && (!z || !w))) return HQPKKT_E_NULL;
-  HIPCHK(hipSetDevice(h->opts.device));
-  hipStream_t s = h->stream;
-  const size_t nv = (size_t)n + me + 2 * (size_t)m;
-  // same arena as hqpkkt_mehrotra (its hot-start data does not survive this call)
-  const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
-  int e;
-  if (h->ipv.count < need) {
-    if ((e = h->ipv.alloc(need))) return e;
-    h->fr_hot_valid = false;
-  }
-  h->ip_hot_valid = false;
-  IpCtx C;
-  C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
-  double *q = h->ipv.p;
-  auto take = [&](size_t k) { double *r = q; q += k; return r; };
-  C.x = take(n), C.y = take(me), C.z = take(m), C.w = take(m);
-  C.r1 = take(n), C.r2 = take(me), C.r3 = take(m), C.r4 = take(m);
-  double *a1 = take(n), *a2 = take(me), *a3 = take(m);
-  (void)take(m);
-  C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
-  C.c = take(n), C.b = take(me), C.d = take(m);
-  C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
-  const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-  const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
-  if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
-  if (me) HIPCHK(hipMemcpyAsync(C.b, b, sizeof(double) * me, in_kind, s));
-  if (m) HIPCHK(hipMemcpyAsync(C.d, d, sizeof(double) * m, in_kind, s));
-  const int saved_loc = h->opts.loc;
-  struct Restore {
-    hqpkkt_t *h;
-    int loc;
-    ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
-  } restore{h, saved_loc};
-  h->opts.loc = HQPKKT_LOC_DEVICE;
-  h->lazy = true;
-  hipEvent_t tb, te;
-  HIPCHK(hipEventCreate(&tb));
-  HIPCHK(hipEventCreate(&te));
-  HIPCHK(hipEventRecord(tb, s));
-  std::memset(res, 0, sizeof(*res));
-  res->result = 2;
-  int iter = 0, n_factor = 0, n_solve = 0;
-  auto finish = [&](int result) -> int {
-    res->result = result, res->iters = iter, res->n_factor = n_factor, res->n_solve = n_solve;
-    if (n) HIPCHK(hipMemcpyAsync(x, C.x, sizeof(double) * n, out_kind, s));
-    if (me) HIPCHK(hipMemcpyAsync(y, C.y, sizeof(double) * me, out_kind, s));
-    if (m) HIPCHK(hipMemcpyAsync(z, C.z, sizeof(double) * m, out_kind, s));
-    if (m) HIPCHK(hipMemcpyAsync(w, C.w, sizeof(double) * m, out_kind, s));
-    HIPCHK(hipEventRecord(te, s));
-    HIPCHK(hipStreamSynchronize(s));
-    float ms = 0.f;
-    (void)hipEventElapsedTime(&ms, tb, te);
-    res->ms_total = ms;
-    (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-    return 0;
-  };
-  const int total = n + me + m;
-  const double beta = 0.995;  // qp_beta (:77)
-  const int max_warm = o.max_warm_iters > 0 ? o.max_warm_iters : 15;  // qp_max_warm_iters (:81)
-  bool hot = o.hot_start == 1 && m > 0 && h->fr_hot_valid;
-  int fail_iters = 0, result = 2;
-  double rhomin = 0.0, Ltilde = 0.0, zeta = 1.0, gap = 0.0, alpha = 1.0, alphabar = 1.0, gap1 = 0.0;
-  const int OPS_SUM[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-  for (;;) {  // hot first (if asked for and possible), cold after a failed hot start (:381-416)
-  iter = 0, alpha = 1.0, zeta = 1.0, result = 2;
-  if (hot) {
-    // hot_start (:222-266): x, y, z, w of the last solve, w += 1e-10, the slack vectors a1..a3
-    // of that point - which are the right-hand sides r1..r3 of Mehrotra's loop
-    k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, 0.0, 1e-10, C.z, C.w);
-    if (h->short_rows)
-      k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                            h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
+  return guarded([&]() -> int {
+    if (!h || !res) return HQPKKT_E_NULL;
+    if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
+    if (opts && opts->max_iters < 0) return HQPKKT_E_RANGE;
+    if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
+    if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
+    hqpkkt_ip_opts o;
+    if (opts)
+      o = *opts;
     else
-      k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                             h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
-    if ((e = C.reduce(OPS_SUM, 3))) return e;
-    gap = C.hout[2] + 1.0;  // in_prod(z, w) + 1 (:248)
-    if (rhomin == 0.0) rhomin = h->fr_rhomin;
-  } else {
-  // ---- cold start (:156-216)
-  if (m > 0) {
-    rhomin = 1000.0 * m;
-    k_fr_dstats<<<IP_BLOCKS, 256, 0, s>>>(m, C.d, C.part);
-    const int opsd[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
-    if ((e = C.reduce(opsd, 3))) return e;
-    const double min_d = C.hout[0], norm_d = C.hout[1];
-    Ltilde = std::fmax(norm_d, -min_d);  // "according Wright" (qp_mu0 = 0)
-    Ltilde = std::fmax(Ltilde, 1e2 * m);
-  }
-  if (h->short_rows)
-    k_fr_cold<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
-  else
-    k_fr_cold<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
-  gap = 0.0;
-  if (m > 0) {
-    if ((e = C.reduce(OPS_SUM, 1))) return e;
-    gap = C.hout[0];
-  }
-  }
-  bool restart_cold = false;
-  // ---- iterations (:381-416 around :271-378)
-  while (true) {
-    if (iter == 0) alphabar = 1.0;
-    double mu;
-    if (1.0 / gap < rhomin || alpha < 1.0) {
-      mu = alphabar * gap / rhomin;             // potential reduction
-      mu += (1.0 - alphabar) * gap / (double)m;  // centering
-    } else
-      mu = gap * gap;  // quadratic convergence
-    if (m == 0) mu = 0.0;
-    k_fr_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, zeta, mu, a1, a2, a3, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
-    double resid = 0.0;
-    n_factor++, n_solve++;
-    // The step length below compares dw = C dx - r3 with w, whose active components are of the
-    // order gap / m: a residual of mat_eps = 1e-10, which the reference's global pivoting stays
-    // far below without refinement, lets that noise block the step near the solution (the loop
-    // then creeps on with alpha -> 0).  Ask the solve for a residual below the slacks.
-    h->refine_target = m > 0 ? std::fmax(0.05 * gap / (double)m, 2e-12) : 0.0;
-    e = hqpkkt_factor(h, C.z, C.w);
-    if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
-    h->refine_target = 0.0;
-    if (e == HQPKKT_E_SING && hot) {  // Hqp_Degenerate inside a hot start: thrown away (:405-411)
-      result = 4;
-      break;
+      hqpkkt_default_ip_opts(&o);
+    Analysis &an = h->an;
+    const int n = an.n, me = an.me, m = an.m;
+    if ((n && !c) || (me && !b) || (m && !d) || (n && !x) || (me && !y) || (m && (!z || !w))) return HQPKKT_E_NULL;
+    HIPCHK(hipSetDevice(h->opts.device));
+    hipStream_t s = h->stream;
+    const size_t nv = (size_t)n + me + 2 * (size_t)m;
+    // same arena as hqpkkt_mehrotra (its hot-start data does not survive this call)
+    const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
+    int e;
+    if (h->ipv.count < need) {
+      if ((e = h->ipv.alloc(need))) return e;
+      h->fr_hot_valid = false;
     }
-    if (e) {
-      if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:308-310)
-      (void)hipEventDestroy(tb), (void)hipEventDestroy(te);
-      return e;
-    }
-    // the step length is computed and consumed on the device; it comes back with the new gap
-    double *const Sfr = C.out + 32;
-    if (m > 0) {
-      k_fr_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-      IpOps orat;
-      orat.op[0] = IP_MIN;
-      for (int k = 1; k < IP_SLOTS; k++) orat.op[k] = IP_SUM;
-      k_ip_final<<<1, 256, 0, s>>>(C.part, orat, C.out, IpEpi{3, m, 0.0, 0.0, beta, nullptr, Sfr});
-    }
-    k_fr_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, m > 0 ? Sfr + IPS_ALPHA : nullptr, C.x, C.y, C.z, C.w, C.dx,
-                                          C.dy, C.dz, C.dw, C.part);
-    {
-      IpOps ou;
-      for (int k = 0; k < IP_SLOTS; k++) ou.op[k] = IP_SUM;
-      ou.op[1] = IP_MAX;
-      k_ip_final<<<1, 256, 0, s>>>(C.part, ou, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-      HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
+    h->ip_hot_valid = false;
+    IpCtx C;
+    C.h = h, C.n = n, C.me = me, C.m = m, C.hout = h->hpin + 64;
+    double *q = h->ipv.p;
+    auto take = [&](size_t k) { double *r = q; q += k; return r; };
+    C.x = take(n), C.y = take(me), C.z = take(m), C.w = take(m);
+    C.r1 = take(n), C.r2 = take(me), C.r3 = take(m), C.r4 = take(m);
+    double *a1 = take(n), *a2 = take(me), *a3 = take(m);
+    (void)take(m);
+    C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
+    C.c = take(n), C.b = take(me), C.d = take(m);
+    C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
+    const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
+    if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
+    if (me) HIPCHK(hipMemcpyAsync(C.b, b, sizeof(double) * me, in_kind, s));
+    if (m) HIPCHK(hipMemcpyAsync(C.d, d, sizeof(double) * m, in_kind, s));
+    const int saved_loc = h->opts.loc;
+    struct Restore {
+      hqpkkt_t *h;
+      int loc;
+      ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
+    } restore{h, saved_loc};
+    h->opts.loc = HQPKKT_LOC_DEVICE;
+    h->lazy = true;
+    const hipEvent_t tb = h->evt0, te = h->evt1;  // owned by the handle: no early return can leak them
+    HIPCHK(hipEventRecord(tb, s));
+    std::memset(res, 0, sizeof(*res));
+    res->result = 2;
+    int iter = 0, n_factor = 0, n_solve = 0;
+    auto finish = [&](int result) -> int {
+      res->result = result, res->iters = iter, res->n_factor = n_factor, res->n_solve = n_solve;
+      if (n) HIPCHK(hipMemcpyAsync(x, C.x, sizeof(double) * n, out_kind, s));
+      if (me) HIPCHK(hipMemcpyAsync(y, C.y, sizeof(double) * me, out_kind, s));
+      if (m) HIPCHK(hipMemcpyAsync(z, C.z, sizeof(double) * m, out_kind, s));
+      if (m) HIPCHK(hipMemcpyAsync(w, C.w, sizeof(double) * m, out_kind, s));
+      HIPCHK(hipEventRecord(te, s));
       HIPCHK(hipStreamSynchronize(s));
-    }
-    alpha = m > 0 ? C.hout[32 + IPS_ALPHA] : std::fmin(1.0, 2.0 * beta);
-    alphabar = 0.5 * alphabar + 0.5 * alpha;
-    if (alphabar == 1.0)
-      rhomin *= 2.0;
-    else if (alphabar < 0.5 && rhomin > 100.0 * m)
-      rhomin /= 2.0;
-    zeta *= (1.0 - alpha);
-    gap = m > 0 ? C.hout[0] : 0.0;
-    res->gap = gap, res->alpha = alpha, res->mu = mu, res->phi = zeta;
-    if (!std::isfinite(gap) || !std::isfinite(C.hout[1])) {  // :351-354
-      result = 4;
-    } else {
-      iter++;
-      if (!(zeta < o.eps))  // (:361-374, comparisons written to filter out NaN)
-        result = alpha < o.eps ? 3 : 2;
-      else if (!(gap < o.eps) || !(resid < o.eps))
-        result = 1;  // Hqp_Feasible
-      else
-        result = 0;
-    }
-    // ---- what solve() does after every step() (:388-403)
+      float ms = 0.f;
+      (void)hipEventElapsedTime(&ms, tb, te);
+      res->ms_total = ms;
+      return 0;
+    };
+    const int total = n + me + m;
+    const double beta = 0.995;  // qp_beta (:77)
+    const int max_warm = o.max_warm_iters > 0 ? o.max_warm_iters : 15;  // qp_max_warm_iters (:81)
+    bool hot = o.hot_start == 1 && m > 0 && h->fr_hot_valid;
+    int fail_iters = 0, result = 2;
+    double rhomin = 0.0, Ltilde = 0.0, zeta = 1.0, gap = 0.0, alpha = 1.0, alphabar = 1.0, gap1 = 0.0;
+    const int OPS_SUM[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+    for (;;) {  // hot first (if asked for and possible), cold after a failed hot start (:381-416)
+    iter = 0, alpha = 1.0, zeta = 1.0, result = 2;
     if (hot) {
-      if (iter == 1)
-        gap1 = gap;
-      else if (gap > gap1) {
-        fail_iters += iter;
-        restart_cold = true;
+      // hot_start (:222-266): x, y, z, w of the last solve, w += 1e-10, the slack vectors a1..a3
+      // of that point - which are the right-hand sides r1..r3 of Mehrotra's loop
+      k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, 0.0, 1e-10, C.z, C.w);
+      if (h->short_rows)
+        k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                              h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
+      else
+        k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                               h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
+      if ((e = C.reduce(OPS_SUM, 3))) return e;
+      gap = C.hout[2] + 1.0;  // in_prod(z, w) + 1 (:248)
+      if (rhomin == 0.0) rhomin = h->fr_rhomin;
+    } else {
+    // ---- cold start (:156-216)
+    if (m > 0) {
+      rhomin = 1000.0 * m;
+      k_fr_dstats<<<IP_BLOCKS, 256, 0, s>>>(m, C.d, C.part);
+      const int opsd[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+      if ((e = C.reduce(opsd, 3))) return e;
+      const double min_d = C.hout[0], norm_d = C.hout[1];
+      Ltilde = std::fmax(norm_d, -min_d);  // "according Wright" (qp_mu0 = 0)
+      Ltilde = std::fmax(Ltilde, 1e2 * m);
+    }
+    if (h->short_rows)
+      k_fr_cold<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
+    else
+      k_fr_cold<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
+    gap = 0.0;
+    if (m > 0) {
+      if ((e = C.reduce(OPS_SUM, 1))) return e;
+      gap = C.hout[0];
+    }
+    }
+    bool restart_cold = false;
+    // ---- iterations (:381-416 around :271-378)
+    while (true) {
+      if (iter == 0) alphabar = 1.0;
+      double mu;
+      if (1.0 / gap < rhomin || alpha < 1.0) {
+        mu = alphabar * gap / rhomin;             // potential reduction
+        mu += (1.0 - alphabar) * gap / (double)m;  // centering
+      } else
+        mu = gap * gap;  // quadratic convergence
+      if (m == 0) mu = 0.0;
+      k_fr_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, zeta, mu, a1, a2, a3, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
+      double resid = 0.0;
+      n_factor++, n_solve++;
+      // The step length below compares dw = C dx - r3 with w, whose active components are of the
+      // order gap / m: a residual of mat_eps = 1e-10, which the reference's global pivoting stays
+      // far below without refinement, lets that noise block the step near the solution (the loop
+      // then creeps on with alpha -> 0).  Ask the solve for a residual below the slacks.
+      h->refine_target = m > 0 ? std::fmax(0.05 * gap / (double)m, 2e-12) : 0.0;
+      e = hqpkkt_factor(h, C.z, C.w);
+      if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
+      h->refine_target = 0.0;
+      if (e == HQPKKT_E_SING && hot) {  // Hqp_Degenerate inside a hot start: thrown away (:405-411)
+        result = 4;
         break;
       }
+      if (e) {
+        if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:308-310)
+        return e;
+      }
+      // the step length is computed and consumed on the device; it comes back with the new gap
+      double *const Sfr = C.out + 32;
+      if (m > 0) {
+        k_fr_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+        IpOps orat;
+        orat.op[0] = IP_MIN;
+        for (int k = 1; k < IP_SLOTS; k++) orat.op[k] = IP_SUM;
+        k_ip_final<<<1, 256, 0, s>>>(C.part, orat, C.out, IpEpi{3, m, 0.0, 0.0, beta, nullptr, Sfr});
+      }
+      k_fr_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, m > 0 ? Sfr + IPS_ALPHA : nullptr, C.x, C.y, C.z, C.w, C.dx,
+                                            C.dy, C.dz, C.dw, C.part);
+      {
+        IpOps ou;
+        for (int k = 0; k < IP_SLOTS; k++) ou.op[k] = IP_SUM;
+        ou.op[1] = IP_MAX;
+        k_ip_final<<<1, 256, 0, s>>>(C.part, ou, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
+        HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+      }
+      alpha = m > 0 ? C.hout[32 + IPS_ALPHA] : std::fmin(1.0, 2.0 * beta);
+      alphabar = 0.5 * alphabar + 0.5 * alpha;
+      if (alphabar == 1.0)
+        rhomin *= 2.0;
+      else if (alphabar < 0.5 && rhomin > 100.0 * m)
+        rhomin /= 2.0;
+      zeta *= (1.0 - alpha);
+      gap = m > 0 ? C.hout[0] : 0.0;
+      res->gap = gap, res->alpha = alpha, res->mu = mu, res->phi = zeta;
+      if (!std::isfinite(gap) || !std::isfinite(C.hout[1])) {  // :351-354
+        result = 4;
+      } else {
+        iter++;
+        if (!(zeta < o.eps))  // (:361-374, comparisons written to filter out NaN)
+          result = alpha < o.eps ? 3 : 2;
+        else if (!(gap < o.eps) || !(resid < o.eps))
+          result = 1;  // Hqp_Feasible
+        else
+          result = 0;
+      }
+      // ---- what solve() does after every step() (:388-403)
+      if (hot) {
+        if (iter == 1)
+          gap1 = gap;
+        else if (gap > gap1) {
+          fail_iters += iter;
+          restart_cold = true;
+          break;
+        }
+      }
+      if (iter + fail_iters >= o.max_iters) break;
+      if (hot && iter >= max_warm) break;
+      if (result == 0 || result == 3 || result == 4) break;
     }
-    if (iter + fail_iters >= o.max_iters) break;
-    if (hot && iter >= max_warm) break;
-    if (result == 0 || result == 3 || result == 4) break;
-  }
-  if (restart_cold || (hot && result != 0)) {  // bad hot start (:405-411)
-    if (!restart_cold) fail_iters += iter;
-    hot = false;
-    continue;
-  }
-  break;
-  }
-  iter += fail_iters;
-  h->fr_hot_valid = m > 0 && result != 4;
-  h->fr_rhomin = rhomin;
-  return finish(result);
+    if (restart_cold || (hot && result != 0)) {  // bad hot start (:405-411)
+      if (!restart_cold) fail_iters += iter;
+      hot = false;
+      continue;
+    }
+    break;
+    }
+    iter += fail_iters;
+    h->fr_hot_valid = m > 0 && result != 4;
+    h->fr_rhomin = rhomin;
+    return finish(result);
+  });
 }
 
 int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {
@@ -1876,62 +1901,68 @@ int hqpkkt_set_shard_stream(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_st
 }
 
 int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu) {
-  if (!h) return HQPKKT_E_NULL;
-  if (h->opts.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_INTERN;
-  if (!h->sd) h->sd = new (std::nothrow) StagedDev;
-  if (!h->sd) return HQPKKT_E_MEM;
-  kktdev::StagedPlan &P = h->sd->plan;
-  P.given_nx.clear(), P.given_nu.clear();
-  if (K <= 0) return 0;  // back to detection from the staircase of A
-  if (!nx || !nu) return HQPKKT_E_NULL;
-  for (int k = 0; k <= K; k++)
-    if (nx[k] < 1) return HQPKKT_E_RANGE;
-  for (int k = 0; k < K; k++)
-    if (nu[k] < 0) return HQPKKT_E_RANGE;
-  P.given_nx.assign(nx, nx + K + 1), P.given_nu.assign(nu, nu + K);
-  return 0;
+  return guarded([&]() -> int {
+    if (!h) return HQPKKT_E_NULL;
+    if (h->opts.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_INTERN;
+    if (!h->sd) h->sd = new (std::nothrow) StagedDev;
+    if (!h->sd) return HQPKKT_E_MEM;
+    kktdev::StagedPlan &P = h->sd->plan;
+    P.given_nx.clear(), P.given_nu.clear();
+    if (K <= 0) return 0;  // back to detection from the staircase of A
+    if (!nx || !nu) return HQPKKT_E_NULL;
+    for (int k = 0; k <= K; k++)
+      if (nx[k] < 1) return HQPKKT_E_RANGE;
+    for (int k = 0; k < K; k++)
+      if (nu[k] < 0) return HQPKKT_E_RANGE;
+    P.given_nx.assign(nx, nx + K + 1), P.given_nu.assign(nu, nu + K);
+    return 0;
+  });
 }
 
 int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int n_total, int me_rest, int m, const int *Qp,
                           const int *Qi, const int *Ep, const int *Ei, const int *Cp, const int *Ci) {
-  if (!h) return HQPKKT_E_NULL;
-  if (h->opts.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_INTERN;
-  int e = hqpkkt_set_stages(h, K, nx, nu);
-  if (e) return e;
-  if (K < 1) return HQPKKT_E_RANGE;
-  long long n = nx[K], ndyn = 0;
-  for (int k = 0; k < K; k++) n += (long long)nx[k] + nu[k], ndyn += nx[k + 1];
-  if (n > 0x7fffffffLL || ndyn + me_rest > 0x7fffffffLL || me_rest < 0 || m < 0) return HQPKKT_E_RANGE;
-  if (n != n_total) return HQPKKT_E_SIZES;  // Q, E, C were built for another number of variables
-  if ((n > 0 && (!Qp || (Qp[n] > 0 && !Qi))) || (me_rest > 0 && (!Ep || (Ep[me_rest] > 0 && !Ei))) ||
-      (m > 0 && (!Cp || (Cp[m] > 0 && !Ci))))
-    return HQPKKT_E_NULL;
-  if (h->uploaded) {
-    (void)hipSetDevice(h->opts.device);
-    (void)hipStreamSynchronize(h->stream);
-    h->release_device();
-  }
-  h->analyzed = false;
-  h->ip_hot_valid = h->fr_hot_valid = false;
-  const int me = (int)ndyn + me_rest;
-  h->pQp.assign(Qp, Qp + n + 1), h->pQi.assign(Qi, Qi + Qp[n]);
-  h->pAp.assign((size_t)me + 1, 0);  // the dynamics rows are empty: they come as dense blocks
-  for (int i = 0; i <= me_rest; i++) h->pAp[ndyn + i] = me_rest ? Ep[i] : 0;
-  h->pAi.clear();
-  if (me_rest && Ep[me_rest]) h->pAi.assign(Ei, Ei + Ep[me_rest]);
-  h->pCp.clear(), h->pCi.clear();
-  if (m) h->pCp.assign(Cp, Cp + m + 1), h->pCi.assign(Ci, Ci + Cp[m]);
-  h->zd_decided = true, h->zd_weak = false;
-  return staged_analyze(h, (int)n, me, m, true);
+  return guarded([&]() -> int {
+    if (!h) return HQPKKT_E_NULL;
+    if (h->opts.mode != HQPKKT_MODE_STAGED) return HQPKKT_E_INTERN;
+    int e = hqpkkt_set_stages(h, K, nx, nu);
+    if (e) return e;
+    if (K < 1) return HQPKKT_E_RANGE;
+    long long n = nx[K], ndyn = 0;
+    for (int k = 0; k < K; k++) n += (long long)nx[k] + nu[k], ndyn += nx[k + 1];
+    if (n > 0x7fffffffLL || ndyn + me_rest > 0x7fffffffLL || me_rest < 0 || m < 0) return HQPKKT_E_RANGE;
+    if (n != n_total) return HQPKKT_E_SIZES;  // Q, E, C were built for another number of variables
+    if ((n > 0 && (!Qp || (Qp[n] > 0 && !Qi))) || (me_rest > 0 && (!Ep || (Ep[me_rest] > 0 && !Ei))) ||
+        (m > 0 && (!Cp || (Cp[m] > 0 && !Ci))))
+      return HQPKKT_E_NULL;
+    if (h->uploaded) {
+      (void)hipSetDevice(h->opts.device);
+      (void)hipStreamSynchronize(h->stream);
+      h->release_device();
+    }
+    h->analyzed = false;
+    h->ip_hot_valid = h->fr_hot_valid = false;
+    const int me = (int)ndyn + me_rest;
+    h->pQp.assign(Qp, Qp + n + 1), h->pQi.assign(Qi, Qi + Qp[n]);
+    h->pAp.assign((size_t)me + 1, 0);  // the dynamics rows are empty: they come as dense blocks
+    for (int i = 0; i <= me_rest; i++) h->pAp[ndyn + i] = me_rest ? Ep[i] : 0;
+    h->pAi.clear();
+    if (me_rest && Ep[me_rest]) h->pAi.assign(Ei, Ei + Ep[me_rest]);
+    h->pCp.clear(), h->pCi.clear();
+    if (m) h->pCp.assign(Cp, Cp + m + 1), h->pCi.assign(Ci, Ci + Cp[m]);
+    h->zd_decided = true, h->zd_weak = false;
+    return staged_analyze(h, (int)n, me, m, true);
+  });
 }
 
 int hqpkkt_set_values_staged(hqpkkt_t *h, const double *Qx, const double *const *F, const long long *ldF,
                              const double *Ex, const double *Cx) {
-  if (!h) return HQPKKT_E_NULL;
-  if (!h->analyzed || h->opts.mode != HQPKKT_MODE_STAGED || !h->sd) return HQPKKT_E_INTERN;
-  Analysis &an = h->an;
-  if ((an.nq && !Qx) || (an.na && !Ex) || (an.nc && !Cx) || !F || !ldF) return HQPKKT_E_NULL;
-  return staged_set_values(h, Qx, Ex, Cx, F, ldF);
+  return guarded([&]() -> int {
+    if (!h) return HQPKKT_E_NULL;
+    if (!h->analyzed || h->opts.mode != HQPKKT_MODE_STAGED || !h->sd) return HQPKKT_E_INTERN;
+    Analysis &an = h->an;
+    if ((an.nq && !Qx) || (an.na && !Ex) || (an.nc && !Cx) || !F || !ldF) return HQPKKT_E_NULL;
+    return staged_set_values(h, Qx, Ex, Cx, F, ldF);
+  });
 }
 
 // STAGED: rank and number of carried rows of every stage in the last factorisation
@@ -2120,6 +2151,10 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       if (what == 26) v = &P.cap;
       break;
     }
+    case 30:  // zero-diagonal placement in use, and whether the last values have weak Hessian diagonals
+      tmp = {h->zd_used, h->zd_weak ? 1 : 0};
+      v = &tmp;
+      break;
     case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)
       if (!h->sd) return HQPKKT_E_INTERN;
       v = &h->sd->plan.xcut;

@@ -2270,6 +2270,18 @@ __global__ void k_gather_values(int nnz, const int *__restrict__ src, const doub
   const int k = blockIdx.x * blockDim.x + threadIdx.x;
   if (k < nnz) out[k] = vals[src[k]];
 }
+// zd_policy -1 (hqpkkt_opts): does some x have a Hessian diagonal that is weak against its coupling to an
+// equality, |Q_ii| < 0.01 max_r |A_ri| ?  Evaluated on the device after every hqpkkt_set_values (the values
+// of an SQP run change: a Hessian that starts as the identity may become weak later).
+__global__ void k_zd_weak(int n, CsrDev Q, CsrDev AT, int *__restrict__ flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double qd = 0.0, am = 0.0;
+  for (int k = Q.ptr[i]; k < Q.ptr[i + 1]; k++)
+    if (Q.col[k] == i) qd = fabs(Q.val[k]);
+  for (int k = AT.ptr[i]; k < AT.ptr[i + 1]; k++) am = fmax(am, fabs(AT.val[k]));
+  if (am > 0.0 && qd < 0.01 * am) atomicOr(flag, 1);
+}
 // sum over the LPR (16 or 4) consecutive lanes that share a CSR row
 template <int LPR>
 __device__ __forceinline__ double row_sum(double v) {
@@ -2353,6 +2365,29 @@ __global__ void k_zero_ranges(double *__restrict__ base, const long long *__rest
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < len;
        i += (long long)gridDim.x * blockDim.x)
     p[i] = 0.0;
+}
+// sharded mode: the status words of a factorisation as doubles for one all-reduce (sum): [0] ranks
+// with E_SING (or an infinite / NaN max|K|), [1] ranks with another error, [2] ranks that perturbed an
+// exactly zero pivot (soft singular), [3] unused; and back: every rank ends with the same words
+__global__ void k_status_pack(const int *__restrict__ flags, const unsigned long long *__restrict__ bits,
+                              double *__restrict__ out) {
+  if (threadIdx.x != 0) return;
+  const double kmax = __longlong_as_double((long long)bits[0]);
+  const bool badk = !(kmax == kmax) || kmax == __longlong_as_double(0x7ff0000000000000LL);
+  out[0] = (flags[0] == 4 || badk) ? 1.0 : 0.0;
+  out[1] = (flags[0] != 0 && flags[0] != 4) ? 1.0 : 0.0;
+  out[2] = flags[4] != 0 ? 1.0 : 0.0;
+  out[3] = 0.0;
+}
+__global__ void k_status_unpack(const double *__restrict__ in, int *__restrict__ flags,
+                                unsigned long long *__restrict__ bits) {
+  if (threadIdx.x != 0) return;
+  if (in[1] > 0.0)
+    flags[0] = 17;
+  else if (in[0] > 0.0)
+    flags[0] = 4;
+  if (in[2] > 0.0) flags[4] = 1;
+  (void)bits;
 }
 // sharded mode: keep only the entries this rank contributes to the all-reduce
 __global__ void k_mask_vector(int n, const signed char *__restrict__ keep, double *__restrict__ x) {

@@ -31,6 +31,33 @@ def main():
     cases = json.loads(os.environ.get("SHARD_CASES", '[["banded", 1500, 12, "SpBKP"]]'))
     for case in cases:
         kind = case[-1]
+        if case[0] == "singular":
+            # a duplicated equality row: the zero pivot turns up inside ONE rank's subtree (or in the top);
+            # every rank must return the same status - nobody may be left waiting in a collective
+            prog = problems.banded_qp(case[1], case[2])
+            p, i, x = prog.A
+            r = case[1] // 8
+            lo, hi = p[r], p[r + 1]
+            lo2, hi2 = p[r + 1], p[r + 2]
+            i, x = i.copy(), x.copy()
+            k = min(hi - lo, hi2 - lo2)
+            i[lo2:lo2 + k], x[lo2:lo2 + k] = i[lo:lo + k], x[lo:lo + k]
+            if hi2 - lo2 > k:
+                x[lo2 + k:hi2] = 0.0
+            prog = problems.Program(prog.n, prog.me, prog.m, prog.Q, (p, i, x), prog.C)
+            st = problems.ip_state(prog, 7, 1.0)
+            cls = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}[kind]
+            M = cls(device=dev, shard=(rank, world, dist.make_exchange(rank, dev)))
+            M.init(prog)
+            code = 0
+            try:
+                M.factor(prog, st[0], st[1])
+                d = new_d(prog)
+                M.solve(prog, *st, *d)
+            except ipmatrix.KktError as err:
+                code = err.code
+            out.append(dict(case=case, rank=rank, code=code))
+            continue
         if case[0] == "banded":
             prog = problems.banded_qp(case[1], case[2])
         elif case[0] == "docp":

@@ -392,3 +392,22 @@ def test_leaves_of_multipliers_only(case):
     assert np.array_equal(M.perm(), O.perm())
     assert res <= ores + RES_TOL, (res, ores, M.stats())
     assert rel_err(d, osol) <= 1e-5, (rel_err(d, osol), M.stats())
+
+
+@pytest.mark.gpu
+def test_weak_hessian_test_runs_on_every_update():
+    """zd_policy -1: whether some x has a Hessian diagonal that is weak against its coupling to an
+    equality is decided from the VALUES, on every update() (an SQP run starts from an identity Hessian and
+    may get weak ones later), so that a solve whose refinement fails can still switch the placement."""
+    strong, weak = problems.did_like_qp(200, qx=1.0), problems.did_like_qp(200, qx=1e-4)
+    M = ipmatrix.IpSpBKP()
+    M.init(strong)
+    assert list(M.debug(30)) == [2, 0]
+    M.update(weak)
+    assert list(M.debug(30)) == [2, 1]
+    st = problems.ip_state(weak, 3, 1.0)
+    M.factor(weak, st[0], st[1])
+    d = new_d(weak)
+    assert M.solve(weak, *st, *d) <= 1e-10
+    M.update(strong)
+    assert M.debug(30)[1] == 0

@@ -80,3 +80,23 @@ def test_rccl_transport_single_rank():
     line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
     rec = json.loads(line[len("SHARD_RESULT "):])[0][0]
     assert rec["diff"] < 1e-9 and rec["res"] <= 1e-10
+
+
+@pytest.mark.parametrize("world,port", [(2, 29577), (3, 29578)])
+def test_sharded_singular_system_same_status_on_all_ranks(world, port):
+    """A rank-deficient equality block: the exactly zero pivot appears in one rank's subtree only; the
+    status words are agreed by an all-reduce, so every rank raises E_SING (none hangs in the next
+    collective)."""
+    cases = [["singular", 1500, 12, "RedSpBKP"], ["banded", 1500, 12, "RedSpBKP"]]
+    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_CASES=json.dumps(cases), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
+    per_rank = json.loads(line[len("SHARD_RESULT "):])
+    codes = [r[0]["code"] for r in per_rank]
+    assert codes == [4] * world, codes
+    # ... and the ranks go on together: the next (regular) system is solved as usual
+    for r in per_rank:
+        assert r[1]["res"] <= 1e-10 and r[1]["same_as_rank0"]
