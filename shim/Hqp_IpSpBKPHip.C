@@ -13,8 +13,11 @@
 #include <If_Int.h>
 #include <If_Real.h>
 
+#include <dlfcn.h>
+
 #include "Hqp_Program.h"
 #include "hqpkkt.h"
+#include "hqpkkt_rccl.h"
 
 IF_CLASS_DEFINE("SpBKPHip", Hqp_IpSpBKPHip, Hqp_IpMatrix);
 IF_CLASS_DEFINE("RedSpBKPHip", Hqp_IpRedSpBKPHip, Hqp_IpMatrix);
@@ -30,6 +33,10 @@ Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
   _tol = 1.0;
   _device = 0;
   _refine = 1;
+  _ngpu = 1;
+  _rccl = NULL;
+  _rccl_lib = NULL;
+  _rank = 0;
   _h = NULL;
   _Qp = _Qi = _Ap = _Ai = _Cp = _Ci = IVNULL;
   _Qx = _Ax = _Cx = VNULL;
@@ -39,12 +46,22 @@ Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
   _ifList.append(new If_Real("mat_tol", &_tol));
   _ifList.append(new If_Int("mat_device", &_device));
   _ifList.append(new If_Int("mat_device_refine", &_refine));
+  // mat_ngpu > 1: ONE KKT system over that many GPUs.  The HQP host is then started once per GPU
+  // (mpirun / torchrun style: RANK, WORLD_SIZE, LOCAL_RANK in the environment, every process running
+  // the same deterministic SQP iteration); the plugins of the processes form an RCCL communicator
+  // (libhqpkkt_rccl.so, include/hqpkkt_rccl.h) and share every factorisation
+  _ifList.append(new If_Int("mat_ngpu", &_ngpu));
 }
 
 //--------------------------------------------------------------------------
 Hqp_IpMatrixHip::~Hqp_IpMatrixHip()
 {
   hqpkkt_destroy(_h);
+  if (_rccl && _rccl_lib) {
+    typedef int (*destroy_t)(void *);
+    destroy_t f = (destroy_t)dlsym(_rccl_lib, "hqpkkt_rccl_destroy");
+    if (f) f(_rccl);
+  }
   iv_free(_Qp); iv_free(_Qi); iv_free(_Ap); iv_free(_Ai); iv_free(_Cp); iv_free(_Ci);
   v_free(_Qx); v_free(_Ax); v_free(_Cx);
 }
@@ -136,8 +153,27 @@ int Hqp_IpMatrixHip::open(int mode)
   opts.loc = HQPKKT_LOC_HOST;   // Meschach VEC::ve pointers
   opts.tol = _tol;
   opts.eps = _eps;
+  if (_ngpu > 1 && !_rccl) {
+    // the communicator is made once per plugin object (it outlives re-inits)
+    typedef int (*create_t)(void **, int *, int *, int *);
+    int nranks = 1, dev = _device;
+    _rccl_lib = dlopen("libhqpkkt_rccl.so", RTLD_NOW | RTLD_LOCAL);
+    create_t create = _rccl_lib ? (create_t)dlsym(_rccl_lib, "hqpkkt_rccl_create_from_env") : NULL;
+    if (!create || create(&_rccl, &_rank, &nranks, &dev) || nranks != _ngpu) {
+      fprintf(stderr, "Hqp_IpMatrixHip: mat_ngpu %d needs libhqpkkt_rccl.so and %d processes "
+              "(RANK / WORLD_SIZE / LOCAL_RANK in the environment)\n", _ngpu, _ngpu);
+      return HQPKKT_E_DEVICE;
+    }
+    _device = dev;
+    opts.device = dev;
+  }
   if ((e = hqpkkt_create(&opts, &_h)))
     return e;
+  if (_ngpu > 1) {
+    hqpkkt_exchange_stream_fn xfn = (hqpkkt_exchange_stream_fn)dlsym(_rccl_lib, "hqpkkt_rccl_exchange");
+    if (!xfn || (e = hqpkkt_set_shard_stream(_h, _rank, _ngpu, xfn, _rccl)))
+      return e ? e : HQPKKT_E_DEVICE;
+  }
   _mode_used = mode;
   if ((e = hqpkkt_analyze(_h, _n, _me, _m,
                           _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,

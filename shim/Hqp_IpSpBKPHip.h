@@ -29,6 +29,10 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   Real _tol;          // mat_tol (hqp/Hqp_IpSpBKP.C:59)
   int _device;        // mat_device: HIP device ordinal
   int _refine;        // mat_device_refine: run Hqp_IpMatrix::solve's refinement on the GPU
+  int _ngpu;          // mat_ngpu: ONE system over this many GPUs (one HQP process per GPU, RCCL)
+  void *_rccl;        // communicator context of libhqpkkt_rccl.so (include/hqpkkt_rccl.h)
+  void *_rccl_lib;    // its dlopen handle
+  int _rank;
   struct hqpkkt *_h;
   // CSR copies of the pattern the handle was analysed for (pattern-change
   // detection like hqp/Hqp_IpPARDISO.C:247-248,293-296) and value staging
