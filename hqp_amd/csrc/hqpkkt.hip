@@ -2033,7 +2033,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   k_fill_rand<<<nblk((long long)kk * ldb), 256>>>(B, (long long)kk * ldb, 2);
   (void)hipMemset(err, 0, 8);
   (void)hipMemset(Cm, 0, sizeof(double) * (size_t)std::max(M, N) * ldc);
-  stg::GemmArgs g{A, lda, B, ldb, nullptr, 0, Cm, ldc, M, N, K, 1.0, 0.0, lower, mirror};
+  stg::GemmArgs g{A, lda, B, ldb, nullptr, 0, Cm, ldc, M, N, K, 1.0, 0.0, lower, mirror, nullptr};
   int cus = 0;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
   const int skg = getenv("HQPKKT_NO_STREAMK") ? 0 : stg::gemm_streamk_grid(M, N, K, lower, 2 * cus);

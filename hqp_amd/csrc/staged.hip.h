@@ -41,6 +41,9 @@ struct GemmArgs {
   double alpha, beta;
   int lower;   // only tiles with tile row >= tile column (M == N)
   int mirror;  // with lower: C[j][i] = C[i][j] as well (exactly symmetric result)
+  const int *tile_map;  // lower, 128 x 128 tiles: tile index -> tile row << 16 | tile column, in blocks of
+                        // 8 x 8 tiles (neighbours in the launch order share operand panels in their XCD's L2);
+                        // null: row by row
 };
 
 static const int GEMM_BK = 16;
@@ -93,7 +96,10 @@ struct GemmTile {
 
   // tile index -> (tile row, tile column)
   static __device__ __forceinline__ void tile_of(const GemmArgs &g, int t, int &tm, int &tn) {
-    if (g.lower) {
+    if (g.lower && g.tile_map && BM == 128) {
+      const int e = g.tile_map[t];
+      tm = e >> 16, tn = e & 0xffff;
+    } else if (g.lower) {
       tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
       while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
       while (tm * (tm + 1) / 2 > t) tm--;

@@ -16,12 +16,34 @@ struct StagedDev {
   DBuf<unsigned> sk_cnt;
   int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
   int sk_tiles = 0;             // most tiles a product of this handle has (size of the counter array)
+  // order of the tiles of a lower-triangular product with T tile rows (GemmArgs::tile_map), by T
+  std::vector<std::pair<int, DBuf<int> *>> tri_maps;
+  const int *tri_map(int T) {
+    for (auto &e : tri_maps)
+      if (e.first == T) return e.second->p;
+    std::vector<int> m;
+    m.reserve((size_t)T * (T + 1) / 2);
+    const int S = 8;  // super-blocks of 8 x 8 tiles, row by row; inside a block column by column
+    for (int I = 0; I < (T + S - 1) / S; I++)
+      for (int J = 0; J <= I; J++)
+        for (int tn = J * S; tn < std::min(T, (J + 1) * S); tn++)
+          for (int tm = std::max(I * S, tn); tm < std::min(T, (I + 1) * S); tm++) m.push_back(tm << 16 | tn);
+    DBuf<int> *b = new (std::nothrow) DBuf<int>;
+    if (!b || b->upload(m)) {
+      delete b;
+      return nullptr;
+    }
+    tri_maps.push_back({T, b});
+    return b->p;
+  }
   size_t lds_small = 0, lds_init = 0;
   void release() {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release();
+    for (auto &e : tri_maps) e.second->release(), delete e.second;
+    tri_maps.clear();
   }
 };
 
@@ -57,6 +79,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM) {
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
   const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
+  if (g.lower && big && d && tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
   if (skg > 0 && tiles <= d->sk_tiles) {
     // tile count that does not fill the chip evenly: even shares of the (tile, k-slab) units (k_dgemm_tn_sk)
     HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
