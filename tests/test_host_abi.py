@@ -33,6 +33,17 @@ def test_header_symbols_exported():
         assert getattr(L, s) is not None
 
 
+def test_rccl_header_symbols_exported():
+    """include/hqpkkt_rccl.h against libhqpkkt_rccl.so (the RCCL transport of a sharded system): every
+    declared symbol is exported; no communicator is made here (no GPU)."""
+    hdr = open(os.path.join(ROOT, "include", "hqpkkt_rccl.h")).read()
+    declared = set(re.findall(r"\b(hqpkkt_rccl_[a-z_0-9]+)\s*\(", hdr))
+    assert declared == set(_lib.RCCL_SYMBOLS)
+    R = _lib.rccl_lib()
+    for s in declared:
+        assert getattr(R, s) is not None
+
+
 def test_no_cpu_fallback_in_product():
     """The product must not import, link or execute anything under oracle/."""
     banned = ("import oracle", "from oracle", "kkt_oracle", "libkktoracle", "libhqpref", "refapi", "oracleapi")
