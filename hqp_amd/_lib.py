@@ -33,7 +33,7 @@ RCCL_LIB_PATH = os.path.join(_HERE, "libhqpkkt_rccl.so")
 RCCL_SYMBOLS = ["hqpkkt_rccl_unique_id", "hqpkkt_rccl_create", "hqpkkt_rccl_create_from_env",
                 "hqpkkt_rccl_exchange", "hqpkkt_rccl_destroy"]
 
-XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
+XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM, XCHG_BCAST_BASE = 0, 1, 16
 # int fn(void *ctx, int op, double *buf, long long slot_elems, int nslots)
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int)
 

@@ -597,7 +597,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   int k = 0;
   bool had2x2 = false;  // block-uniform
   STAMP(1);
-  int npan = 0;
+  [[maybe_unused]] int npan = 0;  // index of the STAMP slots (instrumented builds, -DHQPKKT_STAMPS)
   while (k < p) {
     k = __builtin_amdgcn_readfirstlane(k);  // wave-uniform: keep it scalar
     // ======== fast path: up to FD_PANEL consecutive 1x1 pivots without interchange ========

@@ -103,6 +103,15 @@ int hqpkkt_rccl_exchange(void *ctx, int op, double *buf, long long slot_elems, i
     r = ncclAllGather(buf + (size_t)c->rank * slot_elems, buf, (size_t)slot_elems, ncclDouble, c->comm, s);
   } else if (op == 1) {  // HQPKKT_XCHG_ALLREDUCE_SUM
     r = ncclAllReduce(buf, buf, (size_t)slot_elems, ncclDouble, ncclSum, c->comm, s);
+  } else if (op >= 16 && op < 16 + c->nranks) {  // HQPKKT_XCHG_BCAST_BASE + root
+    // the broadcasts of one gather come back to back: the first opens a group, the last (root = nranks-1) closes it
+    const int root = op - 16;
+    if (root == 0) (void)ncclGroupStart();
+    r = slot_elems > 0 ? ncclBroadcast(buf, buf, (size_t)slot_elems, ncclDouble, root, c->comm, s) : ncclSuccess;
+    if (root == c->nranks - 1) {
+      const ncclResult_t g = ncclGroupEnd();
+      if (r == ncclSuccess) r = g;
+    }
   } else
     return -1;
   return r == ncclSuccess ? 0 : (int)r;

@@ -1096,12 +1096,12 @@ struct UnpackArgs {
   long long ldv;
   int n, nranks;
   const double *xbuf;
-  long long slot_elems;
-  int cut[17];  // nranks + 1 column cuts (nranks <= 16)
+  long long off[17];  // start of every rank's strip in xbuf
+  int cut[17];        // nranks + 1 column cuts (nranks <= 16)
 };
 __global__ void __launch_bounds__(256) k_st_unpack(UnpackArgs a) {
   const int p = blockIdx.y, c0 = a.cut[p], c1 = a.cut[p + 1], w = c1 - c0;
-  const double *slot = a.xbuf + (long long)p * a.slot_elems;
+  const double *slot = a.xbuf + a.off[p];
   for (int i = c0 + blockIdx.x; i < a.n; i += gridDim.x)
     for (int jj = threadIdx.x; jj < w; jj += blockDim.x) {
       const int j = c0 + jj;

@@ -394,13 +394,24 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
           (e = st_gemm(h, stg::GemmArgs{sp.Y + c1, ldy, sp.Rm + c0, ldy, G + c1 * ldg + c0, ldg, sp.V + c1 * ldv + c0, ldv, nn - c1, wd,
                                         P.qmax[k], -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD)))
         return e;
-      // the strips of V_k: pack, ONE all-gather, unpack + mirror
+      // the strips of V_k: pack, gather, unpack + mirror.  With the stream-ordered transport one broadcast
+      // per rank with the strip's own size (back to back: one RCCL group); behind the drained-stream callback
+      // ONE all-gather of slots padded to the largest strip
       double *xb = d.misc.p + P.oX;
+      stg::UnpackArgs ua{sp.V, ldv, nn, NR, xb, {0}, {0}};
+      const bool exact = h->xchg_sfn != nullptr;
+      long long off = 0;
+      for (int p = 0; p <= NR; p++) {
+        ua.cut[p] = cut[p];
+        if (p < NR) ua.off[p] = exact ? off : (long long)p * P.xslot[k], off += (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]);
+      }
       if (wd > 0)
-        KLAUNCH(h, KC_ST_VEC, stg::k_st_pack<<<std::min(nn - c0, 4096), 256, 0, s>>>(sp.V, ldv, nn, c0, c1, xb + (long long)RK * P.xslot[k]));
-      if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR))) return e;
-      stg::UnpackArgs ua{sp.V, ldv, nn, NR, xb, P.xslot[k], {0}};
-      for (int p = 0; p <= NR; p++) ua.cut[p] = cut[p];
+        KLAUNCH(h, KC_ST_VEC, stg::k_st_pack<<<std::min(nn - c0, 4096), 256, 0, s>>>(sp.V, ldv, nn, c0, c1, xb + ua.off[RK]));
+      if (exact) {
+        for (int p = 0; p < NR; p++)
+          if ((e = exchange(h, HQPKKT_XCHG_BCAST_BASE + p, xb + ua.off[p], (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]), 1))) return e;
+      } else if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR)))
+        return e;
       KLAUNCH(h, KC_ST_VEC, stg::k_st_unpack<<<dim3(std::min(nn, 4096), NR), 256, 0, s>>>(ua));
     }
   }

@@ -86,7 +86,7 @@ def finalize():
 
 
 # ----------------------------------------------------------- one system, P ranks
-XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM = 0, 1
+XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM, XCHG_BCAST_BASE = 0, 1, 16
 
 
 class _DevicePtr:
@@ -118,6 +118,8 @@ def exchange_tensor(op, t, slot, nslots, rank, group=None):
             dist.all_gather(list(slots.unbind(0)), mine, group=group)
     elif op == XCHG_ALLREDUCE_SUM:
         dist.all_reduce(buf[:slot], op=dist.ReduceOp.SUM, group=group)
+    elif op >= XCHG_BCAST_BASE:  # slot values that rank (op - base) has filled, to everybody
+        dist.broadcast(buf[:slot], src=op - XCHG_BCAST_BASE, group=group)
     else:
         raise ValueError(f"unknown exchange op {op}")
     if not direct:
@@ -167,6 +169,28 @@ class RcclShard:
             raise RuntimeError(f"hqpkkt_rccl_create: {e}")
         self._R, self.rank, self.world = R, rank, world
         self.fn = C.cast(R.hqpkkt_rccl_exchange, C.c_void_p)
+        # self-test of the three collectives on 8 values per rank (wrong data here must not reach a solve)
+        import torch
+        dev = torch.device("cuda", device)
+        with torch.cuda.device(dev):
+            t = torch.zeros(8 * world, dtype=torch.float64, device=dev)
+            t[8 * rank:8 * rank + 8] = rank + 1.0
+            stream = torch.cuda.current_stream(dev).cuda_stream
+            if R.hqpkkt_rccl_exchange(self._ctx, 0, t.data_ptr(), 8, world, stream):
+                raise RuntimeError("hqpkkt_rccl_exchange: all-gather failed")
+            want = torch.arange(1, world + 1, dtype=torch.float64, device=dev).repeat_interleave(8)
+            ok = bool(torch.equal(t, want))
+            if R.hqpkkt_rccl_exchange(self._ctx, 1, t.data_ptr(), 8, 1, stream):
+                raise RuntimeError("hqpkkt_rccl_exchange: all-reduce failed")
+            ok = ok and bool(torch.allclose(t[:8], torch.full((8,), float(world), dtype=torch.float64, device=dev)))
+            bs = [torch.full((8,), float(rank), dtype=torch.float64, device=dev) for _ in range(world)]
+            for r in range(world):  # one group: opened by root 0, closed by the last root
+                if R.hqpkkt_rccl_exchange(self._ctx, 16 + r, bs[r].data_ptr(), 8, 1, stream):
+                    raise RuntimeError("hqpkkt_rccl_exchange: broadcast failed")
+            torch.cuda.synchronize(dev)
+            ok = ok and all(bool((bs[r] == float(r)).all()) for r in range(world))
+            if not ok:
+                raise RuntimeError("libhqpkkt_rccl.so: self-test of the collectives returned wrong data")
 
     def close(self):
         if getattr(self, "_ctx", None):

@@ -233,6 +233,11 @@ int hqpkkt_get_stats(const hqpkkt_t *h, hqpkkt_stats *out);
  * Returns 0 on success.  Call hqpkkt_set_shard before hqpkkt_analyze. */
 #define HQPKKT_XCHG_ALLGATHER 0
 #define HQPKKT_XCHG_ALLREDUCE_SUM 1
+/* op HQPKKT_XCHG_BCAST_BASE + r (r = 0 .. nranks-1): buf holds slot_elems doubles that rank r has
+ * filled (nslots = 1); bring them to every rank.  The STAGED engine gathers the strips of V_k this way
+ * when their sizes differ much (one broadcast per rank, issued back to back: hqpkkt_rccl_exchange
+ * puts them into one ncclGroup) instead of padding every strip to the largest. */
+#define HQPKKT_XCHG_BCAST_BASE 16
 typedef int (*hqpkkt_exchange_fn)(void *ctx, int op, double *buf, long long slot_elems, int nslots);
 int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, void *ctx);
 /* The stream-ordered form of the same hook: the callback puts the collective into `hip_stream` (the
