@@ -12,6 +12,7 @@
 #include <algorithm>
 #include <cstring>
 #include <numeric>
+#include <thread>
 
 #include <chrono>
 #include <cstdio>
@@ -20,6 +21,25 @@ static std::chrono::steady_clock::time_point g_t0;
 #define TMARK(x) do { if (getenv("HQPKKT_TIMING")) { auto t=std::chrono::steady_clock::now(); fprintf(stderr, "phase before %s: %.2f s\n", x, std::chrono::duration<double>(t-g_t0).count()); g_t0=t; } } while(0)
 namespace kktdev {
 namespace {
+
+// fn(lo, hi) over [0, n) on up to 16 host threads (the symbolic phase is otherwise single-threaded, as the
+// reference's init() is; only loops without dependences between their iterations use this)
+template <class F>
+void parallel_for(long long n, F fn) {
+  unsigned nt = std::thread::hardware_concurrency();
+  nt = nt < 1 ? 1 : (nt > 16 ? 16 : nt);
+  if (n < 200000 || nt == 1) {
+    fn(0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const long long chunk = (n + nt - 1) / nt;
+  for (unsigned t = 0; t < nt; t++) {
+    const long long lo = t * chunk, hi = std::min(n, lo + chunk);
+    if (lo < hi) th.emplace_back([=, &fn]() { fn(lo, hi); });
+  }
+  for (auto &x : th) x.join();
+}
 
 struct LevelItem {
   int node, deg, deg2;
@@ -51,14 +71,21 @@ void rcm_order(int dim, const std::vector<int> &start, const std::vector<int> &n
                std::vector<int> &order) {
   std::vector<char> marks(dim), glob(dim, 1);
   std::vector<LevelItem> lv(dim + 1);
-  std::vector<int> live(dim);
+  // live[v]: neighbours of v that are not numbered yet; lum[v] = marks[v] ? live[v] : 0, so that the
+  // second sort key of a node (sum of the live degrees of its unnumbered neighbours) is ONE gather
+  std::vector<int> live(dim), lum(dim);
   auto reset_live = [&]() {
     for (int i = 0; i < dim; i++) live[i] = start[i + 1] - start[i];
   };
   auto number = [&](int v, int &count) {
     lv[count++].node = v;
     marks[v] = 0;
-    for (int k = start[v]; k < start[v + 1]; k++) live[neigh[k]]--;
+    lum[v] = 0;
+    for (int k = start[v]; k < start[v + 1]; k++) {
+      const int w = neigh[k];
+      live[w]--;
+      if (marks[w]) lum[w]--;
+    }
   };
   reset_live();
   int root = 0, count = 0;
@@ -67,6 +94,7 @@ void rcm_order(int dim, const std::vector<int> &start, const std::vector<int> &n
     do {
       count = first;
       marks = glob;
+      for (int i = 0; i < dim; i++) lum[i] = marks[i] ? live[i] : 0;
       nlev_old = nlev;
       nlev = 0;
       lb = le = count;
@@ -83,8 +111,7 @@ void rcm_order(int dim, const std::vector<int> &start, const std::vector<int> &n
             for (int k = le; k < count; k++) {
               const int u = lv[k].node;
               int d2 = 0;
-              for (int j = start[u]; j < start[u + 1]; j++)
-                if (marks[neigh[j]]) d2 += live[neigh[j]];
+              for (int j = start[u]; j < start[u + 1]; j++) d2 += lum[neigh[j]];
               lv[k].deg = live[u];
               lv[k].deg2 = d2;
             }
@@ -997,25 +1024,34 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
                     [&](int x, int y) { return ent_dst[x] < ent_dst[y]; });
     }
     TMARK("10");
+    // (random gathers over 10^6..10^8 entries: cache misses are what they cost, so spread them over threads)
     auto apply_i = [&](std::vector<int> &v) {
       std::vector<int> t(nent);
-      for (int k = 0; k < nent; k++) t[k] = v[perm[k]];
+      parallel_for(nent, [&](long long lo, long long hi) {
+        for (long long k = lo; k < hi; k++) t[k] = v[perm[k]];
+      });
       v.swap(t);
     };
-    std::vector<int> new_ptr(1, 0);
-    std::vector<Term> new_terms;
-    new_terms.reserve(terms.size());
-    for (int k = 0; k < nent; k++) {
-      for (int t = term_ptr[perm[k]]; t < term_ptr[perm[k] + 1]; t++) new_terms.push_back(terms[t]);
-      new_ptr.push_back((int)new_terms.size());
-    }
+    std::vector<int> new_ptr((size_t)nent + 1, 0);
+    for (int k = 0; k < nent; k++) new_ptr[k + 1] = new_ptr[k] + (term_ptr[perm[k] + 1] - term_ptr[perm[k]]);
+    std::vector<Term> new_terms(terms.size());
+    parallel_for(nent, [&](long long lo, long long hi) {
+      for (long long k = lo; k < hi; k++) {
+        int o = new_ptr[k];
+        for (int t = term_ptr[perm[k]]; t < term_ptr[perm[k] + 1]; t++) new_terms[o++] = terms[t];
+      }
+    });
     term_ptr.swap(new_ptr), terms.swap(new_terms);
     std::vector<long long> nd(nent);
-    for (int k = 0; k < nent; k++) nd[k] = ent_dst[perm[k]];
+    parallel_for(nent, [&](long long lo, long long hi) {
+      for (long long k = lo; k < hi; k++) nd[k] = ent_dst[perm[k]];
+    });
     ent_dst.swap(nd);
     apply_i(ent_a), apply_i(ent_b), apply_i(ent_er), apply_i(ent_ec);
     std::vector<int> inv(nent);
-    for (int k = 0; k < nent; k++) inv[perm[k]] = k;
+    parallel_for(nent, [&](long long lo, long long hi) {
+      for (long long k = lo; k < hi; k++) inv[perm[k]] = (int)k;
+    });
     for (int i = 0; i < n; i++)
       if (diag_ent[i] >= 0) diag_ent[i] = inv[diag_ent[i]];
   }
