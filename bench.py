@@ -385,6 +385,7 @@ def bench_c4(args):
     t0 = time.perf_counter()
     mat.init_dense(dq)
     t_init = time.perf_counter() - t0
+    dq.norm_A = max(float(blk.abs().sum(1).max()) + 1.0 for blk in dq.F)  # for the interior-point run below
     dq.F = None  # the engine holds its own copy of the blocks
     torch.cuda.empty_cache()
     g = torch.Generator(device="cuda").manual_seed(100 + (0 if one else rank))
@@ -488,6 +489,26 @@ def bench_c4(args):
                          if st["ms_factor"] else None},
         "roofline": roofline,
     }
+    if world == 1 and not args.no_ip:
+        # second half of BASELINE.json's metric: interior-point iterations per second on the SAME 10^6-variable DOCP,
+        # the whole Mehrotra loop device-resident (hqpkkt_mehrotra: per iteration 1 factorisation, 2 solves, the
+        # right-hand sides incl. the dense products with the dynamics rows); QP data: c ~ U(-0.5, 0.5), x_0 ~ U(-1, 1), -1 <= u <= 1
+        try:
+            gq = torch.Generator(device="cuda").manual_seed(7)
+            dq.c = torch.empty(n, dtype=torch.float64, device="cuda").uniform_(-0.5, 0.5, generator=gq)  # some bounds end active
+            dq.b = torch.zeros(me, dtype=torch.float64, device="cuda")
+            dq.b[me - nx:] = torch.empty(nx, dtype=torch.float64, device="cuda").uniform_(-1.0, 1.0, generator=gq)
+            dq.d = torch.ones(m, dtype=torch.float64, device="cuda")
+            t0 = time.perf_counter()
+            _x, _y, _z, _w, info = mat.mehrotra(dq)
+            wall = time.perf_counter() - t0
+            out["ip_iterations_c4"] = {"solver": "hqpkkt_mehrotra (device-resident restatement of Hqp_IpsMehrotra), plugin LQDOCP / STAGED",
+                                       "iters": info["iters"], "result": info["result"], "factorisations": info["n_factor"],
+                                       "solves": info["n_solve"], "seconds": info["ms_total"] * 1e-3, "wall_s": wall,
+                                       "ip_iters_per_s": info["iters"] / (info["ms_total"] * 1e-3) if info["ms_total"] else None,
+                                       "gap": info["gap"]}
+        except Exception as e:  # never let the secondary measurement break the bench line
+            out["ip_iterations_c4"] = {"error": str(e)}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c4(K, nx, nu)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
@@ -519,6 +540,7 @@ def parse_args():
     ap.add_argument("--band", type=int, default=80, help="semi-bandwidth of Q / row width of A (C2: 80)")
     ap.add_argument("--mode", default="SpBKP", choices=["SpBKP", "RedSpBKP"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ip", action="store_true", help="c4: skip the interior-point run on the same problem")
     ap.add_argument("--host-vectors", action="store_true",
                     help="z,w,r*,d* as host pointers (the shim's mode): PCIe-inclusive, never the headline value")
     ap.add_argument("--replicas", action="store_true",

@@ -6,7 +6,7 @@ O=gpurun_out/prof2; rm -rf $O; mkdir -p $O
 # counter passes first (separate runs, --kernel-trace only): bench.py copies k_dgemm_tn's HBM bytes per
 # launch from profiles/r02_pmc_traffic_c4.json into roofline.traffic.  40 stages: per-launch figures do
 # not depend on the number of stages
-B="python3 bench.py --stages 40 --steps 1 --warmup 1 --no-cpu-baseline"
+B="python3 bench.py --stages 40 --steps 1 --warmup 1 --no-cpu-baseline --no-ip"
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch -- $B > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write -- $B > /dev/null 2>&1
 python tools/pmc_summary.py $O/pmc_fetch $O/pmc_write $O r02
@@ -16,7 +16,7 @@ rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --kernel
 python tools/pmc_busy.py $O/pmc_mfma > $O/r02_pmc_mfma_busy.txt 2>&1
 # the bench line (driver's command) and its kernel statistics
 python bench.py --steps 20 --warmup 3 2>$O/r02_bench.err | grep '^{' | tail -1 > $O/r02_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 > $O/r02_bench_under_rocprof.json
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-ip 2>/dev/null | grep '^{' | tail -1 > $O/r02_bench_under_rocprof.json
 cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/r02_kernel_stats.csv
 # other sizes of the same structure (K = 200) and round 1's headline workload
 for nx in 1000 2000 3000; do python tools/c4_bench.py 200 $nx 50 3 --profile 2>/dev/null | grep '^{' | tail -1 >> $O/r02_c4_sizes.jsonl; done

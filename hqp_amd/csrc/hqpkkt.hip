@@ -1263,8 +1263,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     if (!h || !res) return HQPKKT_E_NULL;
     if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
     if (opts && opts->max_iters < 0) return HQPKKT_E_RANGE;
-    if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
-    if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
+      if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
     hqpkkt_ip_opts o;
     if (opts)
       o = *opts;
@@ -1311,6 +1310,15 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     } restore{h, saved_loc};
     h->opts.loc = HQPKKT_LOC_DEVICE;
     h->lazy = true;  // no host round trip where the loop does not need the answer at once
+    // STAGED with dense dynamics: their share of A x and A'y for the right-hand sides (k_ip_rhs)
+    const double *dx1 = nullptr, *dx2 = nullptr;
+    int dndyn = 0;
+    auto dyn_products = [&]() -> int {
+      if (h->opts.mode != HQPKKT_MODE_STAGED) return 0;
+      Vecs vv{};
+      vv.dx = C.x, vv.dy = C.y;
+      return staged_dense_products(h, vv, &dx1, &dx2, &dndyn);
+    };
     hipEvent_t t0 = h->ev0;  // total time: own pair of events (the plugin calls reuse the handle's)
     const hipEvent_t tb = h->evt0, te = h->evt1;  // owned by the handle: no early return can leak them
     (void)t0;
@@ -1465,14 +1473,15 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       bool redo = false;  // the second corrector replaced the step: same step() call, new right-hand sides
       do {
       // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
+      if ((e = dyn_products())) return e;
       if (h->short_rows)
         k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
                                               h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
-                                              C.part);
+                                              C.part, dx1, dx2, dndyn);
       else
         k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
                                                h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
-                                               C.part);
+                                               C.part, dx1, dx2, dndyn);
       if (m == 0) {  // equality-constrained QP: one Newton step (:364-413)
         if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
           if (e == HQPKKT_E_SING) return finish(4);
@@ -1641,8 +1650,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     if (!h || !res) return HQPKKT_E_NULL;
     if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
     if (opts && opts->max_iters < 0) return HQPKKT_E_RANGE;
-    if (h->sd && h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // the loop's SpMVs read the CSR blocks only
-    if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
+      if (h->an.shard_count > 1) return HQPKKT_E_INTERN;
     hqpkkt_ip_opts o;
     if (opts)
       o = *opts;
@@ -1686,6 +1694,15 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     } restore{h, saved_loc};
     h->opts.loc = HQPKKT_LOC_DEVICE;
     h->lazy = true;
+    // STAGED with dense dynamics: their share of A x and A'y for the right-hand sides (k_ip_rhs)
+    const double *dx1 = nullptr, *dx2 = nullptr;
+    int dndyn = 0;
+    auto dyn_products = [&]() -> int {
+      if (h->opts.mode != HQPKKT_MODE_STAGED) return 0;
+      Vecs vv{};
+      vv.dx = C.x, vv.dy = C.y;
+      return staged_dense_products(h, vv, &dx1, &dx2, &dndyn);
+    };
     const hipEvent_t tb = h->evt0, te = h->evt1;  // owned by the handle: no early return can leak them
     HIPCHK(hipEventRecord(tb, s));
     std::memset(res, 0, sizeof(*res));
@@ -1717,12 +1734,13 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       // hot_start (:222-266): x, y, z, w of the last solve, w += 1e-10, the slack vectors a1..a3
       // of that point - which are the right-hand sides r1..r3 of Mehrotra's loop
       k_ip_shift<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, 0.0, 1e-10, C.z, C.w);
+      if ((e = dyn_products())) return e;
       if (h->short_rows)
         k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                              h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
+                                              h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part, dx1, dx2, dndyn);
       else
         k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                               h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part);
+                                               h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.r4, C.part, dx1, dx2, dndyn);
       if ((e = C.reduce(OPS_SUM, 3))) return e;
       gap = C.hout[2] + 1.0;  // in_prod(z, w) + 1 (:248)
       if (rhomin == 0.0) rhomin = h->fr_rhomin;

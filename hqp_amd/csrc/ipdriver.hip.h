@@ -130,7 +130,10 @@ k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev 
          const double *__restrict__ d, const double *__restrict__ x, const double *__restrict__ y,
          const double *__restrict__ z, const double *__restrict__ w, double *__restrict__ r1,
          double *__restrict__ r2, double *__restrict__ r3, double *__restrict__ r4,
-         double *__restrict__ part) {
+         double *__restrict__ part,
+         // STAGED with dense dynamics: x1 = A_dyn' y (n), x2 = A_dyn x (the first ndyn rows of A, empty in
+         // the CSR block), from k_st_dyn_aty / k_st_dyn_ax
+         const double *__restrict__ x1 = nullptr, const double *__restrict__ x2 = nullptr, int ndyn = 0) {
   __shared__ double red[4];
   const int sub = threadIdx.x & (LPR - 1);
   constexpr int RPB = 256 / LPR;
@@ -140,7 +143,7 @@ k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev 
     if (q < n) {
       const double qx = row_dot<LPR>(Q, vals, x, q, sub);
       const double g = qx + c[q];
-      const double s = g - row_dot<LPR>(AT, vals, y, q, sub) - row_dot<LPR>(CT, vals, z, q, sub);
+      const double s = g - row_dot<LPR>(AT, vals, y, q, sub) - row_dot<LPR>(CT, vals, z, q, sub) - (x1 ? x1[q] : 0.0);
       if (sub == 0) {
         r1[q] = s;
         gap += x[q] * g, pc += x[q] * (0.5 * qx + c[q]);
@@ -148,7 +151,7 @@ k_ip_rhs(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDev 
       }
     } else if (q < n + me) {
       const int i = q - n;
-      const double s = -(row_dot<LPR>(A, vals, x, i, sub) + b[i]);
+      const double s = -(row_dot<LPR>(A, vals, x, i, sub) + (i < ndyn ? x2[i] : 0.0) + b[i]);
       if (sub == 0) {
         r2[i] = s;
         gap += y[i] * b[i];

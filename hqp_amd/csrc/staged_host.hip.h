@@ -18,9 +18,10 @@ struct StagedDev {
   int sk_tiles = 0;             // most tiles a product of this handle has (size of the counter array)
   // order of the tiles of a lower-triangular product with T tile rows (GemmArgs::tile_map), by T
   std::vector<std::pair<int, DBuf<int> *>> tri_maps;
-  const int *tri_map(int T) {
+  const int *tri_map(int T, bool create = false) {
     for (auto &e : tri_maps)
       if (e.first == T) return e.second->p;
+    if (!create) return nullptr;  // (made at upload time: no allocation inside a captured sequence)
     std::vector<int> m;
     m.reserve((size_t)T * (T + 1) / 2);
     const int S = 8;  // super-blocks of 8 x 8 tiles, row by row; inside a block column by column
@@ -232,6 +233,16 @@ static int staged_upload(hqpkkt_t *h) {
     if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
       d.sk_grid = 2 * cus;
       if ((e = d.sk_ws.alloc((size_t)d.sk_grid * 2 * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_tiles + 4))) return e;
+    }
+  }
+  // orders of the tiles of the triangular products (G, V; their column slices when sharded)
+  for (int k = 0; k < P.K; k++) {
+    std::vector<int> sizes = {P.nk[k] + P.mk[k], P.nk[k]};
+    if (P.sharded)
+      for (int p = 0; p < P.shard_count; p++) sizes.push_back(P.xcut[(size_t)k * (P.shard_count + 1) + p + 1] - P.xcut[(size_t)k * (P.shard_count + 1) + p]);
+    for (int sz : sizes) {
+      const int T = (sz + 127) / 128;
+      if (T >= 16) (void)d.tri_map(T, true);
     }
   }
   d.lds_small = 0;

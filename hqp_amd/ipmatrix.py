@@ -273,17 +273,26 @@ class Hqp_IpMatrix:
                                          np.asarray(p[:-1], dtype=np.int64))[np.diff(p) > 0].max(initial=0.0))
 
         def ninf(v):
+            if hasattr(v, "data_ptr"):  # torch tensor (device-resident problem data)
+                return float(v.abs().max()) if v.numel() else 0.0
             return float(np.abs(v).max()) if len(v) else 0.0
 
         o.norm_Q, o.norm_C, o.norm_d = rowsum(qp.Q, qp.n), rowsum(qp.C, qp.m), ninf(qp.d)
-        o.norm_data = max(o.norm_Q, rowsum(qp.A, qp.me), o.norm_C, ninf(qp.c), ninf(qp.b), o.norm_d)
+        if getattr(qp, "norm_A", None) is not None:  # (the caller has released the blocks)
+            norm_A = float(qp.norm_A)
+        elif hasattr(qp, "F"):  # problems.DenseDocp: the dynamics rows are [fx fu | -1], the others are in E
+            norm_A = max([float(abs(blk).sum(1).max()) + 1.0 for blk in qp.F] + [rowsum(qp.E, qp.me_rest)])
+        else:
+            norm_A = rowsum(qp.A, qp.me)
+        o.norm_data = max(o.norm_Q, norm_A, o.norm_C, ninf(qp.c), ninf(qp.b), o.norm_d)
         res = _lib.IpResult()
         self._tmp = []
         if self._device_vectors:
             import torch
             dev = torch.device("cuda", self._dev)
             mk = lambda k: torch.zeros(k, dtype=torch.float64, device=dev)
-            cin = [torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64)).to(dev) for v in (qp.c, qp.b, qp.d)]
+            cin = [v.to(dev) if hasattr(v, "data_ptr") else torch.as_tensor(np.ascontiguousarray(v, dtype=np.float64)).to(dev)
+                   for v in (qp.c, qp.b, qp.d)]
         else:
             mk = lambda k: np.zeros(k)
             cin = [np.ascontiguousarray(v, dtype=np.float64) for v in (qp.c, qp.b, qp.d)]

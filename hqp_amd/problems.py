@@ -203,13 +203,16 @@ class DenseDocp:
     ``E`` = the other equality rows (me_rest x n CSR).  Vectors of length ``me`` keep the
     reference's order: dynamics rows first."""
 
-    def __init__(self, nx, nu, Q, E, C, F, me_rest, m):
+    def __init__(self, nx, nu, Q, E, C, F, me_rest, m, c=None, b=None, d=None):
         self.nx, self.nu = [int(v) for v in nx], [int(v) for v in nu]
         self.K = len(self.nu)
         self.n = sum(self.nx) + sum(self.nu)
         self.ndyn = sum(self.nx[1:])
         self.me_rest, self.me, self.m = int(me_rest), self.ndyn + int(me_rest), int(m)
         self.Q, self.E, self.C, self.F = Q, E, C, F
+        self.c = np.zeros(self.n) if c is None else c
+        self.b = np.zeros(self.me) if b is None else b
+        self.d = np.zeros(self.m) if d is None else d
 
     @property
     def dims(self):
@@ -235,7 +238,7 @@ def dense_docp_from_program(prog, nx, nu):
     ndyn = row
     Ep = (p[ndyn:] - p[ndyn]).astype(np.int32)
     E = (Ep, i[p[ndyn]:].astype(np.int32), x[p[ndyn]:].copy())
-    return DenseDocp(nx, nu, prog.Q, E, prog.C, F, prog.me - ndyn, prog.m)
+    return DenseDocp(nx, nu, prog.Q, E, prog.C, F, prog.me - ndyn, prog.m, c=prog.c, b=prog.b, d=prog.d)
 
 
 def random_sparse_qp(n, me, m, row_nnz=4, seed=7):

@@ -225,8 +225,11 @@ def test_dense_handover_equals_csr_handover(device_vectors):
         r1 = A.residuum(prog, *st, *da)
         r2 = B.residuum(None, *st, *da)
         assert abs(r1 - r2) <= 1e-13
-        with pytest.raises(ipmatrix.KktError):
-            B.mehrotra(prog)
+        # the device-resident interior-point loop on both hand-overs: same optimiser
+        xa, _ya, _za, _wa, ia = A.mehrotra(prog)
+        xb, _yb, _zb, _wb, ib = B.mehrotra(dq)
+        assert ia["result"] == 0 and ib["result"] == 0 and abs(ia["iters"] - ib["iters"]) <= 1
+        assert np.abs(xa - xb).max() <= 1e-7 * max(1.0, np.abs(xa).max())
 
 
 def test_dgemm_kernel_against_exact_products():
