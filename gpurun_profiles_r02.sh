@@ -22,5 +22,6 @@ cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/r02_kernel_stats.csv
 for nx in 1000 2000 3000; do python tools/c4_bench.py 200 $nx 50 3 --profile 2>/dev/null | grep '^{' | tail -1 >> $O/r02_c4_sizes.jsonl; done
 python bench.py --workload c2 --steps 20 --warmup 3 2>/dev/null | grep '^{' | tail -1 > $O/r02_bench_c2.json
 python tools/staged_probe.py gemm 2>/dev/null > $O/r02_dgemm_sizes.txt
+python tools/update_time.py 2>/dev/null | grep '^{' | tail -1 > $O/r02_update_time.json
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 ls -la $O

@@ -28,6 +28,7 @@ SYMBOLS = [
     "hqpkkt_default_ip_opts", "hqpkkt_mehrotra", "hqpkkt_franke",
     "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm",
     "hqpkkt_analyze_staged", "hqpkkt_set_values_staged", "hqpkkt_set_shard_stream",
+    "hqpkkt_values_staging",
 ]
 RCCL_LIB_PATH = os.path.join(_HERE, "libhqpkkt_rccl.so")
 RCCL_SYMBOLS = ["hqpkkt_rccl_unique_id", "hqpkkt_rccl_create", "hqpkkt_rccl_create_from_env",
@@ -132,6 +133,7 @@ def lib():
     L.hqpkkt_debug_stage_ranks.argtypes = [vp, vp, C.c_int]
     L.hqpkkt_analyze_staged.argtypes = [vp, C.c_int, vp, vp, C.c_int, C.c_int, C.c_int] + [vp] * 6
     L.hqpkkt_set_values_staged.argtypes = [vp, dp, vp, vp, dp, dp]
+    L.hqpkkt_values_staging.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.hqpkkt_set_shard_stream.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.hqpkkt_debug_dgemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)] * 2
     _lib = L

@@ -186,6 +186,7 @@ struct hqpkkt {
   double *hpin = nullptr;  // 128 doubles: 0..63 status words (as ints), 64.. the IP loop's scalars
   // host vectors of a small system: packed into / out of pinned memory by the CPU, ONE
   // transfer each way instead of six + four staged copies from pageable memory
+  double *hvals = nullptr;   // pinned host staging of Qx | Ax | Cx (hqpkkt_values_staging), nq + na + nc doubles
   double *hstage = nullptr;
   size_t hstage_in = 0, hstage_out = 0;  // doubles; 0 = system too large, copy vector by vector
   const double *out_pending = nullptr;   // results wait in hstage + hstage_in for unstage()
@@ -254,6 +255,7 @@ struct hqpkkt {
     terms.release(), esign.release(), bits.p = nullptr;
     if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr;
     if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
+    if (hvals) (void)hipHostFree(hvals), hvals = nullptr;
     hstage_in = hstage_out = 0;
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
     if (sd) staged_release(sd, false);
@@ -1915,6 +1917,17 @@ int hqpkkt_set_shard_stream(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_st
   if (h->analyzed && (rank != h->shard_rank || count != h->shard_count)) return HQPKKT_E_INTERN;
   h->shard_rank = rank, h->shard_count = count;
   h->xchg_fn = nullptr, h->xchg_sfn = fn, h->xchg_ctx = ctx;
+  return 0;
+}
+
+int hqpkkt_values_staging(hqpkkt_t *h, double **Qx, double **Ax, double **Cx) {
+  if (!h || !Qx || !Ax || !Cx) return HQPKKT_E_NULL;
+  if (!h->analyzed) return HQPKKT_E_INTERN;
+  int e = ensure_device(h);
+  if (e) return e;
+  const Analysis &an = h->an;
+  if (!h->hvals) HIPCHK(hipHostMalloc((void **)&h->hvals, sizeof(double) * ((size_t)an.nq + an.na + an.nc + 1), hipHostMallocDefault));
+  *Qx = h->hvals, *Ax = h->hvals + an.nq, *Cx = h->hvals + an.nq + an.na;
   return 0;
 }
 

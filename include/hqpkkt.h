@@ -157,6 +157,15 @@ int hqpkkt_analyze(hqpkkt_t *h, int n, int me, int m,
 int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax,
                       const double *Cx);
 
+/* Pinned host buffers of the handle for the three value arrays (after hqpkkt_analyze; nnz(Q), nnz(A),
+ * nnz(C) doubles; they live until the next hqpkkt_analyze / hqpkkt_destroy).  A host whose matrices are
+ * row lists (Meschach SPMAT: one heap array per row) writes the values of an update() straight into
+ * them - several threads, no intermediate copy - and passes the same pointers to hqpkkt_set_values:
+ * the transfer is then ONE DMA per block from page-locked memory (opts.loc = HQPKKT_LOC_HOST).  The
+ * shim does this when the pattern is unchanged (the reference's PARDISO plugin re-walks its matrices per
+ * update as well, hqp/Hqp_IpPARDISO.C:240-330). */
+int hqpkkt_values_staging(hqpkkt_t *h, double **Qx, double **Ax, double **Cx);
+
 /* Hqp_IpSpBKP::factor / Hqp_IpRedSpBKP::factor (hqp/Hqp_IpSpBKP.C:139-180,
  * hqp/Hqp_IpRedSpBKP.C:281-320) including spBKPfactor (hqp/spBKP.C:369-645):
  * insert w/z (resp. C'ZW^-1C), symmetric scaling, LDL' with 1x1/2x2 pivots.

@@ -95,6 +95,51 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
   return err;
 }
 
+// Time of Hqp_Solver::update() (= plugin update(): new values on the same pattern, once per SQP
+// iteration, hqp/Hqp_SqpSolver.C:285-296) with the plugin `mat_solver`: out[0] = median seconds of
+// `reps` updates (values scaled a little in between), out[1] = seconds of init + first update.
+int hqpip_time_update(const char *mat_solver, int n, int me, int m, const int *Qp, const int *Qi,
+                      const double *Qx, const int *Ap, const int *Ai, const double *Ax, const int *Cp,
+                      const int *Ci, const double *Cx, int reps, double *out) {
+  if (hqpref_startup() != 0) return -1;
+  Hqp_Solver *S = new Hqp_IpsMehrotra;
+  if (If_SetString("qp_mat_solver", mat_solver) != IF_OK) {
+    delete S;
+    return -2;
+  }
+  Hqp_Program *qp = new Hqp_Program;
+  qp->resize(n, me, m);
+  fill(qp->Q, n, Qp, Qi, Qx);
+  fill(qp->A, me, Ap, Ai, Ax);
+  fill(qp->C, m, Cp, Ci, Cx);
+  S->qp(qp);
+  int err = 0;
+  double ts[64];
+  if (reps > 64) reps = 64;
+  double t0 = now_s(), t1 = t0;
+  m_catchall(S->init(); S->update(); t1 = now_s();
+             for (int r = 0; r < reps; r++) {
+               for (int i = 0; i < n; i++) {
+                 SPROW *row = qp->Q->row + i;
+                 for (int j = 0; j < row->len; j++) row->elt[j].val *= 1.0009765625;
+               }
+               const double a = now_s();
+               S->update();
+               ts[r] = now_s() - a;
+             },
+             err = _err_num);
+  if (!err) {
+    for (int a = 0; a < reps; a++)
+      for (int b = a + 1; b < reps; b++)
+        if (ts[b] < ts[a]) { const double t = ts[a]; ts[a] = ts[b], ts[b] = t; }
+    out[0] = reps ? ts[reps / 2] : 0.0;
+    out[1] = t1 - t0;
+  }
+  delete S;
+  delete qp;
+  return err;
+}
+
 // Two QPs in a row with the same matrices, as an SQP iteration makes them: (c, b, d) solved
 // from a cold start, then (c2, b2, d2) after update() + hot_start()
 // (hqp/Hqp_SqpSolver.C:285-296, hqp/Hqp_IpsMehrotra.C:330-352, 696-733).  x, y, z and out

@@ -276,3 +276,19 @@ def sqp_did(kmax, qp_solver="Mehrotra", mat_solver="SpBKP", host="ref", sqp_eps=
         raise RefError(e, f"sqp_did[{qp_solver},{mat_solver}]")
     return dict(f=out[0], sqp_iters=int(out[1]), qp_iters=int(out[2]), seconds=out[3], norm_inf=out[4],
                 norm_grd_L=out[5], rc=e)
+
+
+def time_update(prog, mat_solver="SpBKP", host="ref", reps=7):
+    """(median seconds of Hqp_Solver::update() with new values on the same pattern, seconds of init +
+    first update) with the reference's Hqp_IpsMehrotra and the plugin ``mat_solver``."""
+    lib = _host(host)
+    out = np.zeros(4)
+    args = []
+    for (p, i, x) in (prog.Q, prog.A, prog.C):
+        args += [np.ascontiguousarray(p, dtype=np.int32),
+                 np.ascontiguousarray(i, dtype=np.int32) if len(i) else np.zeros(1, np.int32), _pad(x)]
+    lib.hqpip_time_update.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int] + [_ip, _ip, _dp] * 3 + [C.c_int, _dp]
+    e = lib.hqpip_time_update(mat_solver.encode(), prog.n, prog.me, prog.m, *args, reps, out)
+    if e:
+        raise RefError(e, "time_update")
+    return float(out[0]), float(out[1])

@@ -8,6 +8,10 @@
  * No C++ object with a non-trivial destructor is alive across a possible
  * m_error(): everything the shim owns hangs off `this` as Meschach objects.
  */
+// (standard headers first: hqp/Meschach.h defines min / max macros, hqp/Meschach.h:38-43)
+#include <thread>
+#include <vector>
+
 #include "Hqp_IpSpBKPHip.h"
 
 #include <If_Int.h>
@@ -51,6 +55,11 @@ Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
   // the same deterministic SQP iteration); the plugins of the processes form an RCCL communicator
   // (libhqpkkt_rccl.so, include/hqpkkt_rccl.h) and share every factorisation
   _ifList.append(new If_Int("mat_ngpu", &_ngpu));
+  // host threads that walk the row lists in update() (0: the single-threaded re-extraction)
+  _update_threads = (int)std::thread::hardware_concurrency();
+  if (_update_threads > 16) _update_threads = 16;
+  if (_update_threads < 1) _update_threads = 1;
+  _ifList.append(new If_Int("mat_update_threads", &_update_threads));
 }
 
 //--------------------------------------------------------------------------
@@ -126,6 +135,53 @@ static void extract_block(const SPMAT *M, bool upper,
   if (ptr->ive[m] != k)
     changed = true;
   ptr->ive[m] = k;
+}
+
+//--------------------------------------------------------------------------
+// update() on an unchanged pattern: the values of one block straight from the SPROW
+// arrays into `val` (pinned staging of the library), rows dealt to `nthr` threads; the
+// column indices are compared on the way (the entry is in the cache line just read;
+// the reference's PARDISO plugin compares them too, hqp/Hqp_IpPARDISO.C:286-296).
+// Returns true if the pattern is no longer the analysed one.
+static bool refresh_block(const SPMAT *M, bool upper, const IVEC *ptr, const IVEC *idx,
+                          double *val, int nthr)
+{
+  const int m = M->m;
+  if (!ptr || (int)ptr->dim != m + 1)
+    return true;
+  std::vector<char> bad(nthr, 0);
+  auto work = [&](int t) {
+    const int lo = (int)((long long)m * t / nthr), hi = (int)((long long)m * (t + 1) / nthr);
+    for (int i = lo; i < hi; i++) {
+      const SPROW *row = M->row + i;
+      const row_elt *elt = row->elt;
+      int k = ptr->ive[i];
+      const int kend = ptr->ive[i + 1];
+      for (int j = 0; j < row->len; j++, elt++) {
+        if (upper && elt->col < i)
+          continue;
+        if (k >= kend || idx->ive[k] != elt->col) {
+          bad[t] = 1;
+          return;
+        }
+        val[k++] = elt->val;
+      }
+      if (k != kend) {
+        bad[t] = 1;
+        return;
+      }
+    }
+  };
+  if (nthr <= 1 || m < 4096)
+    for (int t = 0; t < nthr; t++) work(t);
+  else {
+    std::vector<std::thread> th;
+    for (int t = 0; t < nthr; t++) th.emplace_back(work, t);
+    for (size_t t = 0; t < th.size(); t++) th[t].join();
+  }
+  for (int t = 0; t < nthr; t++)
+    if (bad[t]) return true;
+  return false;
 }
 
 void Hqp_IpMatrixHip::extract(const Hqp_Program *qp, bool &pattern_changed)
@@ -210,6 +266,24 @@ void Hqp_IpMatrixHip::update(const Hqp_Program *qp)
 {
   bool changed;
   int e;
+  // fast path: same pattern as analysed -> values straight into the library's pinned staging
+  // (no C++ object with a destructor is alive when check() may longjmp: the vectors of
+  // refresh_block are gone by then)
+  double *sq = NULL, *sa = NULL, *sc = NULL;
+  if (_h && _Qp && _update_threads > 0 && hqpkkt_values_staging(_h, &sq, &sa, &sc) == HQPKKT_OK) {
+    bool ch = refresh_block(qp->Q, true, _Qp, _Qi, sq, _update_threads);
+    ch = ch || refresh_block(qp->A, false, _Ap, _Ai, sa, _update_threads);
+    ch = ch || refresh_block(qp->C, false, _Cp, _Ci, sc, _update_threads);
+    if (!ch) {
+      e = hqpkkt_set_values(_h, sq, sa, sc);
+      if (_mode_used == HQPKKT_MODE_STAGED && (e == HQPKKT_E_FORMAT || e == HQPKKT_E_SIZES)) {
+        extract(qp, changed);
+        e = open(HQPKKT_MODE_FULL);
+      }
+      check(e, "Hqp_IpMatrixHip::update");
+      return;
+    }
+  }
   extract(qp, changed);
   if (changed) {
     // structure changed behind our back: analyse again (the reference's own

@@ -33,6 +33,7 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   void *_rccl;        // communicator context of libhqpkkt_rccl.so (include/hqpkkt_rccl.h)
   void *_rccl_lib;    // its dlopen handle
   int _rank;
+  int _update_threads; // mat_update_threads: host threads of update()'s walk over the row lists
   struct hqpkkt *_h;
   // CSR copies of the pattern the handle was analysed for (pattern-change
   // detection like hqp/Hqp_IpPARDISO.C:247-248,293-296) and value staging
