@@ -373,6 +373,23 @@ def bench_c4(args):
     n, me, m = dq.dims
     shard, transport = None, None
     if one:
+        # every rank must hold the SAME system: the device generators should agree (same seed, same kind of
+        # GPU); if a checksum says otherwise, rank 0's blocks are broadcast
+        import torch.distributed as tdist
+        chk = torch.stack([blk.sum() for blk in dq.F]).sum().reshape(1)
+        lo, hi = chk.clone(), chk.clone()
+        if args.backend != "nccl":
+            lo, hi = lo.cpu(), hi.cpu()
+        tdist.all_reduce(lo, op=tdist.ReduceOp.MIN)
+        tdist.all_reduce(hi, op=tdist.ReduceOp.MAX)
+        if float(lo) != float(hi):
+            for blk in dq.F:
+                if args.backend == "nccl":
+                    tdist.broadcast(blk, src=0)
+                else:
+                    t = blk.cpu()
+                    tdist.broadcast(t, src=0)
+                    blk.copy_(t)
         if args.backend == "nccl" and args.transport == "rccl":
             try:  # libhqpkkt_rccl.so: ncclAllGather in the handle's stream
                 shard, transport = kdist.RcclShard(rank, world, local_rank), "libhqpkkt_rccl (RCCL, stream-ordered)"
