@@ -424,6 +424,23 @@ def bench_c4(args):
     kdist.fence()
     elapsed = kdist.max_over_ranks(time.perf_counter() - t0)
     st = mat.stats()
+    # the same step as a host with its vectors in (pinned) host memory sees it - SURVEY.md 8(d): z, w, r1..r4 go
+    # to the device and dx..dw come back per call; extra information, never `value`
+    host_rate = None
+    if world == 1:
+        hin = [t.cpu().pin_memory() for t in [z, w] + r]
+        hout = [torch.empty_like(t, device="cpu").pin_memory() for t in d]
+        nh = max(1, min(args.steps, 3))
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(nh):
+            for src, dst in zip(hin, [z, w] + r):
+                dst.copy_(src, non_blocking=True)
+            step()
+            for src, dst in zip(d, hout):
+                dst.copy_(src, non_blocking=True)
+            torch.cuda.synchronize()
+        host_rate = nh / (time.perf_counter() - t0)
     # per-kernel-class device time: HIP events on the library's stream around every launch,
     # in a separate untimed pass over the same workload
     mat.set_profile(True)
@@ -484,6 +501,7 @@ def bench_c4(args):
         "dtype": "f64",
         "data": "synthetic",
         "vectors": "resident in HBM",
+        "value_with_host_vectors": host_rate,  # PCIe per call (33 MB each way in all): what the shim's host sees
         "shard": {"ranks": world, "transport": transport, "bytes_allgather_per_factor": st["bytes_exchange_factor"],
                   "flops_rank0": st["flops_local"], "allgathers_per_factor": st["n_exchange_blocks"]} if one else None,
         "config": {"workload": f"C4 = BASELINE configs[3], the metric's 10^6-variable DOCP: multistage LQ optimal control QP, K={K} stages, "

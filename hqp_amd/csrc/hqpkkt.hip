@@ -2091,7 +2091,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
     if (r == 0) (void)hipEventRecord(e0, 0);
     if (use_sk) {
       (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (tiles + 4), 0);
-      stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, stg::StreamK{skws, skcnt, (int)tiles, std::max(0, (int)(tiles / skg) - 1)});
+      stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, stg::StreamK{skws, skcnt, (int)tiles, stg::gemm_streamk_dp_rounds(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)});
     } else if (big)
       stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
     else

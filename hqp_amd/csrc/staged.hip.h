@@ -75,6 +75,14 @@ static inline int gemm_streamk_grid(int M, int N, int K, int lower, int grid) {
   return (int)gl;
 }
 
+// whole data-parallel rounds in front of the shared part: as many as leave every workgroup a share of at
+// least 96 k-slabs of the rest (a shorter share costs more in parked partial sums than it balances)
+static inline int gemm_streamk_dp_rounds(long long tiles, long long nslab, int grid) {
+  long long dp = tiles / grid;
+  if (dp > 0 && (tiles - dp * grid) * nslab / grid < 96) dp--;
+  return (int)dp;
+}
+
 // blockIdx -> position in a sequence in which the workgroups of one XCD (blockIdx % 8) are
 // neighbours (each XCD has its own L2; neighbouring tiles share operand panels)
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {

@@ -84,7 +84,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM) {
   if (skg > 0 && tiles <= d->sk_tiles) {
     // tile count that does not fill the chip evenly: even shares of the (tile, k-slab) units (k_dgemm_tn_sk)
     HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
-    stg::StreamK sk{d->sk_ws.p, d->sk_cnt.p, (int)tiles, std::max(0, (int)(tiles / skg) - 1)};
+    stg::StreamK sk{d->sk_ws.p, d->sk_cnt.p, (int)tiles, stg::gemm_streamk_dp_rounds(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)};
     KLAUNCH(h, cls, stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
     return 0;
   }
