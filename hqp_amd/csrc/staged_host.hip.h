@@ -16,6 +16,12 @@ struct StagedDev {
   DBuf<unsigned> sk_cnt;
   int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
   int sk_tiles = 0;             // most tiles a product of this handle has (size of the counter array)
+  // second stream: the control-sized chain of a stage (G_u strip, H's control part, carried rows, K^-1, Y, Rm)
+  // runs beside the large product G_xx = fx'W_x instead of behind it (fork / join by events; inside a
+  // captured sequence these are parallel branches of the graph)
+  hipStream_t stream2 = nullptr;
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  bool overlap = false;
   // order of the tiles of a lower-triangular product with T tile rows (GemmArgs::tile_map), by T
   std::vector<std::pair<int, DBuf<int> *>> tri_maps;
   const int *tri_map(int T, bool create = false) {
@@ -45,6 +51,9 @@ struct StagedDev {
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release();
     for (auto &e : tri_maps) e.second->release(), delete e.second;
     tri_maps.clear();
+    if (stream2) (void)hipStreamDestroy(stream2), stream2 = nullptr;
+    if (ev_fork) (void)hipEventDestroy(ev_fork), ev_fork = nullptr;
+    if (ev_join) (void)hipEventDestroy(ev_join), ev_join = nullptr;
   }
 };
 
@@ -72,10 +81,11 @@ inline StagePtr stage_ptr(StagedDev &d, int k) {
 }
 
 // C = alpha A'B + beta Cin on the handle's stream; 128 x 128 tiles for large products, 64 x 64 below
-int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM) {
+int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = true) {
   if (g.M <= 0 || g.N <= 0) return 0;
   StagedDev *d = h->sd;
-  const int skg = d ? stg::gemm_streamk_grid(g.M, g.N, g.K, g.lower, d->sk_grid) : 0;
+  // (allow_sk false: launches of the second stream - the stream-K workspace belongs to the first)
+  const int skg = d && allow_sk ? stg::gemm_streamk_grid(g.M, g.N, g.K, g.lower, d->sk_grid) : 0;
   const bool big = skg > 0 || stg::gemm_big_tiles(g.M, g.N, g.lower);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
@@ -235,6 +245,15 @@ static int staged_upload(hqpkkt_t *h) {
       if ((e = d.sk_ws.alloc((size_t)d.sk_grid * 2 * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_tiles + 4))) return e;
     }
   }
+  // (measured on one MI355X at C4 size: 142 ms against 136 ms per 20 stages WITH the second stream - the
+  // separate product for the control rows of G and the contention cost more than the hidden chain; so it is
+  // off unless HQPKKT_OVERLAP is set.  When sharded the separate product exists anyway.)
+  if (!d.stream2 && getenv("HQPKKT_OVERLAP")) {
+    HIPCHK(hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking));
+    HIPCHK(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
+  }
+  d.overlap = d.stream2 != nullptr;
   // orders of the tiles of the triangular products (G, V; their column slices when sharded)
   for (int k = 0; k < P.K; k++) {
     std::vector<int> sizes = {P.nk[k] + P.mk[k], P.nk[k]};
@@ -353,45 +372,83 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     const int *cut = P.sharded ? &P.xcut[(size_t)k * (NR + 1)] : nullptr;
     const int c0 = cut ? cut[RK] : 0, c1 = cut ? cut[RK + 1] : nn, wd = c1 - c0;
     const long long ldf = P.ldf[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1];
+    // The control-sized chain of the stage on the second stream, beside the large product G_xx (needs the
+    // control columns to start at an even column: 16-byte loads of W + n)
+    const bool ovl = d.overlap && mm > 0 && (nn % 2 == 0);
+    hipStream_t sA = h->stream, sB = ovl ? d.stream2 : h->stream;
+    struct StreamGuard {  // launches go to h->stream: back to the first stream on every way out
+      hqpkkt_t *h;
+      hipStream_t s;
+      ~StreamGuard() { h->stream = s; }
+    } guard{h, sA};
+    auto on_b = [&]() { h->stream = sB; };
+    auto on_a = [&]() { h->stream = sA; };
+    const int ne_x = P.h_mid[k] - P.h_ptr[k], ne_u = P.h_ptr[k + 1] - P.h_mid[k];
+    auto add_h = [&](int first, int count) {
+      if (count)
+        KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(count), 256, 0, h->stream>>>(count, d.h_dst.p + first, d.h_tptr.p + first, d.h_terms.p,
+                                                                                   h->vals.p, h->wt.p, G, 1));
+    };
+    // ---- W
     if (!P.sharded) {
-      // W = V+ F ; G = F'W (lower tiles) + H
       if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldf, nullptr, 0, W, ldf, np, nz, np, 1.0, 0.0, 0, 0}))) return e;
-      if ((e = st_gemm(h, stg::GemmArgs{sp.F, ldf, W, ldf, nullptr, 0, G, ldg, nz, nz, np, 1.0, 0.0, 1, 0}))) return e;
     } else {
-      // own columns of W and of the lower triangle of Gxx (diagonal block + the rows below it) ...
+      // own columns of W, and on every rank its control columns
       if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + c0, ldf, nullptr, 0, W + c0, ldf, np, wd, np, 1.0, 0.0, 0, 0})))
         return e;
-      if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + c0 * ldg + c0, ldg, wd, wd, np, 1.0, 0.0, 1, 0})))
-        return e;
-      if (wd > 0 && nn > c1 &&
-          (e = st_gemm(h, stg::GemmArgs{sp.F + c1, ldf, W + c0, ldf, nullptr, 0, G + c1 * ldg + c0, ldg, nn - c1, wd, np, 1.0, 0.0, 0, 0})))
-        return e;
-      // ... and, on every rank, the control columns of W and the control rows of G (Gux, Guu)
       if (mm > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + nn, ldf, nullptr, 0, W + nn, ldf, np, mm, np, 1.0, 0.0, 0, 0})))
         return e;
-      if (mm > 0 && (e = st_gemm(h, stg::GemmArgs{W + nn, ldf, sp.F, ldf, nullptr, 0, G + nn * ldg, ldg, mm, nz, np, 1.0, 0.0, 0, 0})))
-        return e;
     }
-    const int ne = P.h_ptr[k + 1] - P.h_ptr[k];
-    if (ne)
-      KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(ne), 256, 0, s>>>(ne, d.h_dst.p + P.h_ptr[k], d.h_tptr.p + P.h_ptr[k], d.h_terms.p,
-                                                                       h->vals.p, h->wt.p, G, 1));
+    if (ovl) {
+      HIPCHK(hipEventRecord(d.ev_fork, sA));
+      HIPCHK(hipStreamWaitEvent(sB, d.ev_fork, 0));
+    }
+    // ---- G: the state part (large) on the first stream ...
+    if (!P.sharded && !ovl) {
+      // G = F'W (lower tiles of the whole (n+m) x (n+m) block)
+      if ((e = st_gemm(h, stg::GemmArgs{sp.F, ldf, W, ldf, nullptr, 0, G, ldg, nz, nz, np, 1.0, 0.0, 1, 0}))) return e;
+      add_h(P.h_ptr[k], ne_x + ne_u);
+    } else {
+      if (!P.sharded) {
+        if ((e = st_gemm(h, stg::GemmArgs{sp.F, ldf, W, ldf, nullptr, 0, G, ldg, nn, nn, np, 1.0, 0.0, 1, 0}))) return e;
+      } else {
+        // own columns of the lower triangle of Gxx: diagonal block + the rows below it
+        if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + c0 * ldg + c0, ldg, wd, wd, np, 1.0, 0.0, 1, 0})))
+          return e;
+        if (wd > 0 && nn > c1 &&
+            (e = st_gemm(h, stg::GemmArgs{sp.F + c1, ldf, W + c0, ldf, nullptr, 0, G + c1 * ldg + c0, ldg, nn - c1, wd, np, 1.0, 0.0, 0, 0})))
+          return e;
+      }
+      add_h(P.h_ptr[k], ne_x);
+      // ... the control rows of G (Gux, Guu) = W_u' F and H's control part on the second
+      on_b();
+      if (mm > 0 && (e = st_gemm(h, stg::GemmArgs{W + nn, ldf, sp.F, ldf, nullptr, 0, G + nn * ldg, ldg, mm, nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !ovl)))
+        return e;
+      add_h(P.h_mid[k], ne_u);
+    }
+    on_b();
     // carried rows: N_k[e..] = B+ F
     if (P.cap[k + 1] > 0 &&
         (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, P.ldf[k], nullptr, 0, sp.N + (size_t)ek * P.ldn[k], P.ldn[k],
-                                      P.cap[k + 1], nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD)))
+                                      P.cap[k + 1], nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
       return e;
     stg::SmallArgs sa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
                       P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.T, P.ldt[k], sp.dyn, h->flags.p};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<<<1, 256, d.lds_small, s>>>(sa));
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,
                      sp.Y, P.ldy[k], sp.BT, P.ldb[k]};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, s>>>(wa));
-    // Rm = K^-1 Y ; V = Gxx - Y'Rm (lower tiles, mirrored)
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
+    // Rm = K^-1 Y
     if (P.qmax[k] > 0 &&
         (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, P.ldy[k], nullptr, 0, sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
-                                      1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD)))
+                                      1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
       return e;
+    on_a();
+    if (ovl) {
+      HIPCHK(hipEventRecord(d.ev_join, sB));
+      HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
+    }
+    // V = Gxx - Y'Rm (lower tiles, mirrored)
     if (!P.sharded) {
       if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1},
                        KC_ST_GEMM_UPD)))

@@ -285,7 +285,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   // ------------------------------------------------------------------ H term lists
   {
     struct Raw {
-      long long key;  // stage << 44 | li * ld + lj
+      long long key;  // stage << 45 | (touches a control row / column) << 44 | li * ld + lj
       Term t;
     };
     std::vector<Raw> raw;
@@ -293,7 +293,8 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     const int ONE = nq + na + nc, WONE = m;
     auto ldof = [&](int k) { return k < K ? ldg[k] : ldv[K]; };
     auto push = [&](int k, int li, int lj, Term t) {
-      raw.push_back({((long long)k << 44) | ((long long)li * ldof(k) + lj), t});
+      const long long ctl = (li >= nk[k] || lj >= nk[k]) ? 1 : 0;
+      raw.push_back({((long long)k << 45) | (ctl << 44) | ((long long)li * ldof(k) + lj), t});
     };
     for (int i = 0; i < n; i++)
       for (int p = Qp[i]; p < Qp[i + 1]; p++) {
@@ -311,19 +312,23 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     }
     std::stable_sort(raw.begin(), raw.end(), [](const Raw &a, const Raw &b) { return a.key < b.key; });
     h_ptr.assign(K + 2, 0), h_tptr.assign(1, 0), h_dst.clear(), h_terms.clear();
+    std::vector<int> nstate(K + 1, 0);
     h_terms.reserve(raw.size());
     long long prev = -1;
     for (const Raw &e : raw) {
       if (e.key != prev) {
         h_dst.push_back(e.key & ((1LL << 44) - 1));
         h_tptr.push_back(h_tptr.back());
-        h_ptr[(int)(e.key >> 44) + 1]++;
+        h_ptr[(int)(e.key >> 45) + 1]++;
+        if (!((e.key >> 44) & 1)) nstate[(int)(e.key >> 45)]++;
         prev = e.key;
       }
       h_terms.push_back(e.t);
       h_tptr.back()++;
     }
     for (int k = 0; k <= K; k++) h_ptr[k + 1] += h_ptr[k];
+    h_mid.assign(K + 1, 0);
+    for (int k = 0; k <= K; k++) h_mid[k] = h_ptr[k] + nstate[k];
   }
 
   // ------------------------------------------------------------------ work counts

@@ -48,6 +48,7 @@ struct StagedPlan {
     int s1, s2, wi;
   };
   std::vector<int> h_ptr, h_tptr;
+  std::vector<int> h_mid;  // per stage: first entry that touches a control row / column (the state part comes first)
   std::vector<long long> h_dst;
   std::vector<Term> h_terms;
 
