@@ -214,6 +214,7 @@ struct hqpkkt {
   // residual of the solve that follows), solve() leaves its result in the stream
   bool lazy = false, factor_unchecked = false;
   bool soft_singular = false;  // the factorisation perturbed an exactly zero pivot (counters[3])
+  bool soft_tiny = false;      // ... or met a pivot below 1e-13 max|K| on a multiplier-type row (counters[4])
   double refine_target = 0.0;  // > 0: the refinement of hqpkkt_solve aims below mat_eps (set by hqpkkt_franke)
   // hqpkkt_mehrotra left x, y and the hot-start candidates of z, w in ipv (same dimensions)
   bool ip_hot_valid = false;
@@ -817,6 +818,7 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
     std::memcpy(&h->st.kmax, &kb, sizeof(kb));
     h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
     h->soft_singular = hs[4] != 0;
+    h->soft_tiny = hs[5] != 0;
     if (flags[0] || std::isinf(h->st.kmax)) {
       h->factored = false;
       return flags[0] ? flags[0] : HQPKKT_E_SING;
@@ -1100,6 +1102,7 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   }
   h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
   h->soft_singular = hs[4] != 0;
+  h->soft_tiny = hs[5] != 0;
   if (flags[0]) return flags[0];
   if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
   h->factored = true;
@@ -1225,6 +1228,9 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if (res != res) return HQPKKT_E_SING;
   // an exactly zero pivot outside a root front was perturbed: singular if the refinement failed
   if (h->soft_singular && !(res <= h->opts.eps)) return HQPKKT_E_SING;
+  // a multiplier-type pivot below 1e-13 max|K| and a solve that ends nowhere near a solution: the
+  // rank-deficient equality block the reference reports as E_SING (hqp/spBKP.C:699-700)
+  if (h->soft_tiny && !(res <= 1e-4)) return HQPKKT_E_SING;
   return 0;
 }
 

@@ -150,6 +150,16 @@ struct TermDev {
 // was absorbed by c^2/Q_ii = 1 and cancelled again, its coupling to an ancestor's x still to
 // come) the pivot is perturbed like a tiny one and only counters[3] is marked: hqpkkt_solve
 // reports E_SING if the refinement then does not reach mat_eps.
+// A rank-deficient equality block does not always end in an EXACT zero here (the reference's search over
+// the whole remaining column finds one, hqp/spBKP.C:699-700: E_SING): with the search restricted to the
+// pivot block the second of two identical rows can be left with a pivot of 1e-17.  A pivot of a variable
+// without a diagonal of its own (equality multiplier, x without Q_ii) that is below 1e-13 max|K| marks the
+// factorisation (counters[4]) without changing it: hqpkkt_solve reports E_SING if its refinement then ends
+// with a residual above 1e-4 (a solution that is garbage, not one that is a few digits short of mat_eps as
+// in the last iterations of an interior-point run), and nothing changes for the systems that still solve.
+__device__ __forceinline__ double soft_pivot_limit(const unsigned long long *kmax_bits) {
+  return 1e-13 * __longlong_as_double((long long)*kmax_bits);
+}
 __device__ __forceinline__ int zero_pivot_slot(int sg1, int sg2, int b) {
   return (b == 0 || sg1 == 2 || sg1 == -2 || sg2 == 2 || sg2 == -2) ? -1 : 3;
 }
@@ -575,6 +585,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tid & 31, ty = tid >> 5;
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
+  const double softlim = soft_pivot_limit(kmax_bits);
 
   STAMP(0);
   stage_lower8(P, F, p, ld, a, wave, lane, T, upd, node);
@@ -731,6 +742,10 @@ int dn;
       for (int n = 0; n < 4; n++) cj[n] = cur[tx + 32 * n];
       double d = cur[k];
       bool pertd = false;
+      if (fabs(d) < softlim) {
+        const int sgs = esign[e0 + lp[k]];
+        if (sgs == 2 || sgs == -2) counters[4] = 1;  // see soft_pivot_limit
+      }
       if (!(fabs(d) >= pert)) {
         const int sg = esign[e0 + lp[k]];
         if (d == 0.0) counters[zero_pivot_slot(sg, sg, b)] = 4;
@@ -991,6 +1006,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   const bool row_on = i < p;
   FSTAMP(0);
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
+  const double softlim = soft_pivot_limit(kmax_bits);
   // The columns in groups of 16 (most fronts have one), eight loads per lane and group in
   // flight.  Every unrolled slot sits behind a uniform test of p or b: a front of four
   // pivots executes a quarter of the instructions of one with sixteen (one wavefront per
@@ -1165,6 +1181,10 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
     if (kind != 2) {
       double d = rdlane(ck, k);
       bool pertd = false;
+      if (fabs(d) < softlim) {
+        const int sgs = esign[e0 + lp[k]];
+        if (sgs == 2 || sgs == -2) counters[4] = 1;  // see soft_pivot_limit
+      }
       if (!(fabs(d) >= pert)) {
         const int sg = esign[e0 + lp[k]];
         if (d == 0.0) counters[zero_pivot_slot(sg, sg, b)] = 4;

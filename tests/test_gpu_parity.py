@@ -411,3 +411,29 @@ def test_weak_hessian_test_runs_on_every_update():
     assert M.solve(weak, *st, *d) <= 1e-10
     M.update(strong)
     assert M.debug(30)[1] == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["SpBKP", "RedSpBKP"])
+def test_duplicated_equality_row_is_e_sing_like_the_reference(kind):
+    """A rank-deficient equality block: the reference's search over the whole remaining column ends in an
+    exactly zero pivot -> E_SING in solve (hqp/spBKP.C:699-700) for both plugins.  Here the full plugin is
+    left with a pivot of ~1e-17 on the second multiplier (no exact zero inside the pivot block): marked
+    soft-singular, and the solve whose refinement cannot reach mat_eps reports E_SING as well."""
+    prog = problems.banded_qp(1500, 12)
+    p, i, x = prog.A
+    r = 1500 // 8
+    i, x = i.copy(), x.copy()
+    i[p[r + 1]:p[r + 2]], x[p[r + 1]:p[r + 2]] = i[p[r]:p[r + 1]], x[p[r]:p[r + 1]]
+    bad = problems.Program(prog.n, prog.me, prog.m, prog.Q, (p, i, x), prog.C)
+    st = problems.ip_state(bad, 7, 1.0)
+    O = oracleapi.OracleIpMatrix(kind)
+    O.init(bad)
+    with pytest.raises(Exception):
+        O.factor(st[0], st[1])
+        O.solve(*st)
+    M = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP}[kind]()
+    M.init(bad)
+    with pytest.raises(ipmatrix.SingularError):
+        M.factor(bad, st[0], st[1])
+        M.solve(bad, *st, *new_d(bad))
