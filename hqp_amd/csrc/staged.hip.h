@@ -609,6 +609,7 @@ struct SmallArgs {
   double ge_tol;
   double *Kinv;
   long long ldq;        // qmax x qmax, zero padded
+  double *Kmat;         // K itself (same shape): the products with K^-1 are refined against it
   double *t;
   long long ldt;        // cap x ldt : t[li][s]
   int *dyn;             // [0] r, [1] number of leftover rows, [2..2+capn) R, [2+capn..2+2capn) L
@@ -713,6 +714,10 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
       Km[i * ld + j] = v;
     }
     __syncthreads();
+    for (int e = tid; e < a.qmax * a.qmax; e += nt) {
+      const int i = e / a.qmax, j = e - i * a.qmax;
+      a.Kmat[(long long)i * a.ldq + j] = (i < q && j < q) ? Km[i * ld + j] : 0.0;
+    }
     // scaling: u rows 1/sqrt(K_ii) where K_ii > 1 (hqp/Hqp_IpLQDOCP.C:1851-1858), constraint rows
     // by their largest entry
     for (int i = tid; i < q; i += nt) {
@@ -743,7 +748,8 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
       a.Kinv[(long long)i * a.ldq + j] = v;
     }
   } else {
-    for (int e = tid; e < a.qmax * a.qmax; e += nt) a.Kinv[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0;
+    for (int e = tid; e < a.qmax * a.qmax; e += nt)
+      a.Kinv[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0, a.Kmat[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0;
   }
 }
 static size_t st_small_lds(int m, int capn) {
@@ -805,7 +811,8 @@ __global__ void k_st_check_fixed(const int *__restrict__ dyn0, int *__restrict__
 __global__ void __launch_bounds__(256) k_st_init_factor(int n0, int cap, const double *__restrict__ V, long long ldv,
                                                         const double *__restrict__ BT, long long ldb,
                                                         const int *__restrict__ dyn0, double *__restrict__ K0inv,
-                                                        long long ldq, int qmax, int *__restrict__ status) {
+                                                        double *__restrict__ K0mat, long long ldq, int qmax,
+                                                        int *__restrict__ status) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ ArgMax red[4];
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -824,6 +831,10 @@ __global__ void __launch_bounds__(256) k_st_init_factor(int n0, int cap, const d
     Km[i * ld + j] = v;
   }
   __syncthreads();
+  for (int e = tid; e < qmax * qmax; e += nt) {
+    const int i = e / qmax, j = e - i * qmax;
+    K0mat[(long long)i * ldq + j] = (i < q && j < q) ? Km[i * ld + j] : 0.0;
+  }
   for (int i = tid; i < q; i += nt) {
     double d = 1.0;
     if (i < n0) {
@@ -952,7 +963,9 @@ __global__ void k_st_q(int n, const int *__restrict__ CTp, const int *__restrict
 }
 
 // backward sweep, the small part of a stage (one workgroup):
-//   nu = [a_k ; beta+ + B+ f],  y0 = [gam_u ; nu_R],  rho = K^-1 y0,  beta = nu_L - t nu_R
+//   nu = [a_k ; beta+ + B+ f],  y0 = [gam_u ; nu_R],  rho = K^-1 y0 (+ one round of refinement against K:
+//   the product with an explicit inverse alone has a residual of cond(K) eps, a solve by factors has not),
+//   beta = nu_L - t nu_R
 struct BwdSmall {
   int n, m, np, e, capn, cap, qmax;
   const int *eq_rows;        // QP row index of the own equality rows
@@ -964,6 +977,7 @@ struct BwdSmall {
   const double *f;           // r2 + first dynamics row of the stage
   const double *gam;         // n + m
   const double *Kinv;
+  const double *Kmat;
   long long ldq;
   const double *t;
   long long ldt;
@@ -990,10 +1004,25 @@ __global__ void __launch_bounds__(256) k_st_bwd_small(BwdSmall a) {
   const int q = a.m + r;
   for (int i = tid; i < q; i += nt) y0[i] = i < a.m ? a.gam[a.n + i] : nu[Rl[i - a.m]];
   __syncthreads();
+  double *rh = y0 + a.qmax, *rs = rh + a.qmax;
+  for (int i = tid; i < q; i += nt) {
+    double s = 0.0;  // K^-1 and K are stored symmetric: column i, so that neighbouring threads read neighbouring words
+    for (int j = 0; j < q; j++) s += a.Kinv[(long long)j * a.ldq + i] * y0[j];
+    rh[i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < q; i += nt) {
+    double s = y0[i];
+    for (int j = 0; j < q; j++) s -= a.Kmat[(long long)j * a.ldq + i] * rh[j];
+    rs[i] = s;
+  }
+  __syncthreads();
   for (int i = tid; i < a.qmax; i += nt) {
     double s = 0.0;
-    if (i < q)  // K^-1 is stored symmetric: column i, so that neighbouring threads read neighbouring words
-      for (int j = 0; j < q; j++) s += a.Kinv[(long long)j * a.ldq + i] * y0[j];
+    if (i < q) {
+      for (int j = 0; j < q; j++) s += a.Kinv[(long long)j * a.ldq + i] * rs[j];
+      s += rh[i];
+    }
     a.rho[i] = s;
   }
   for (int li = tid; li < a.cap; li += nt) {
@@ -1057,14 +1086,33 @@ __global__ void k_st_y_fixed(int n0, const int *__restrict__ fix_rows, const int
   if (i < n0) dy[fix_rows[i]] = -tmp[i] / vals[fix_src[i]];
 }
 __global__ void __launch_bounds__(256) k_st_x0_free(int n0, int cap0, int qmax, const double *__restrict__ K0inv,
-                                                    long long ldq, const int *__restrict__ dyn0,
-                                                    const double *__restrict__ v0, const double *__restrict__ beta0,
-                                                    double *__restrict__ x0, double *__restrict__ eta0) {
-  const int c = dyn0[1], q = n0 + c;
-  for (int i = threadIdx.x; i < n0 + cap0; i += blockDim.x) {
+                                                    const double *__restrict__ K0mat, long long ldq,
+                                                    const int *__restrict__ dyn0, const double *__restrict__ v0,
+                                                    const double *__restrict__ beta0, double *__restrict__ x0,
+                                                    double *__restrict__ eta0) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int c = dyn0[1], q = n0 + c, tid = threadIdx.x, nt = blockDim.x;
+  double *b = sm, *y = sm + qmax, *rs = y + qmax;
+  for (int i = tid; i < q; i += nt) b[i] = i < n0 ? v0[i] : beta0[i - n0];
+  __syncthreads();
+  for (int i = tid; i < q; i += nt) {
     double s = 0.0;
-    if (i < q)
-      for (int j = 0; j < q; j++) s += K0inv[(long long)i * ldq + j] * (j < n0 ? v0[j] : beta0[j - n0]);
+    for (int j = 0; j < q; j++) s += K0inv[(long long)j * ldq + i] * b[j];
+    y[i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < q; i += nt) {  // one round of refinement against K0 (see k_st_bwd_small)
+    double s = b[i];
+    for (int j = 0; j < q; j++) s -= K0mat[(long long)j * ldq + i] * y[j];
+    rs[i] = s;
+  }
+  __syncthreads();
+  for (int i = tid; i < n0 + cap0; i += nt) {
+    double s = 0.0;
+    if (i < q) {
+      for (int j = 0; j < q; j++) s += K0inv[(long long)j * ldq + i] * rs[j];
+      s += y[i];
+    }
     if (i < n0)
       x0[i] = -s;
     else

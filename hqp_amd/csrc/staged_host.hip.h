@@ -61,7 +61,7 @@ namespace {
 
 // per-stage pointers into the arenas
 struct StagePtr {
-  double *F, *V, *Y, *Rm, *Kinv, *N, *BT, *T, *v, *beta, *eta, *rho;
+  double *F, *V, *Y, *Rm, *Kinv, *Kmat, *N, *BT, *T, *v, *beta, *eta, *rho;
   int *dyn;
 };
 inline StagePtr stage_ptr(StagedDev &d, int k) {
@@ -75,7 +75,7 @@ inline StagePtr stage_ptr(StagedDev &d, int k) {
   s.dyn = d.dyn.p + P.dyn_off[k];
   if (k < P.K) {
     s.F = d.F.p + P.oF[k];
-    s.Y = M + P.oY[k], s.Rm = M + P.oR[k], s.Kinv = M + P.oK[k], s.T = M + P.oT[k];
+    s.Y = M + P.oY[k], s.Rm = M + P.oR[k], s.Kinv = M + P.oK[k], s.Kmat = M + P.oKm[k], s.T = M + P.oT[k];
   }
   return s;
 }
@@ -433,7 +433,7 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
                                       P.cap[k + 1], nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
       return e;
     stg::SmallArgs sa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
-                      P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.T, P.ldt[k], sp.dyn, h->flags.p};
+                      P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p};
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,
                      sp.Y, P.ldy[k], sp.BT, P.ldb[k]};
@@ -443,6 +443,18 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
         (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, P.ldy[k], nullptr, 0, sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
                                       1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
       return e;
+    // one round of refinement against K: Rm += K^-1 (Y - K Rm).  The product with an explicit inverse alone
+    // leaves a residual of cond(K) eps |Y| where the reference's solve by Bunch-Kaufman factors
+    // (hqp/Hqp_IpLQDOCP.C:1866-1869, 1911-1924) leaves eps |K| |Rm|; stiff stages need the latter
+    if (P.qmax[k] > 0) {
+      double *Res = d.misc.p + P.oRes;
+      if ((e = st_gemm(h, stg::GemmArgs{sp.Kmat, P.ldq[k], sp.Rm, P.ldy[k], sp.Y, P.ldy[k], Res, P.ldy[k], P.qmax[k], nn, P.qmax[k],
+                                        -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
+        return e;
+      if ((e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], Res, P.ldy[k], sp.Rm, P.ldy[k], sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
+                                        1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
+        return e;
+    }
     on_a();
     if (ovl) {
       HIPCHK(hipEventRecord(d.ev_join, sB));
@@ -489,7 +501,7 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_check_fixed<<<1, 64, 0, s>>>(s0.dyn, h->flags.p));
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<<<1, 256, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
-                                                                             d.misc.p + P.oK0, P.ldq0, P.q0max, h->flags.p));
+                                                                             d.misc.p + P.oK0, d.misc.p + P.oK0m, P.ldq0, P.q0max, h->flags.p));
   }
   if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
   HIPCHK(hipGetLastError());
@@ -522,9 +534,9 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     if ((e = st_gemv_rows(h, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, f, sn.v, nullptr, 0, nullptr, nullptr, tt, 1.0}))) return e;
     if ((e = st_gemv_cols(h, d, sp.F, P.ldf[k], np, nz, tt, qv + P.nmk[k], 1.0, gam))) return e;
     stg::BwdSmall ba{nn, mm, np, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], d.eq_rows.p + P.eq_ptr[k], v.r2,
-                     P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr, sn.beta, sn.BT, P.ldb[k + 1], f, gam, sp.Kinv, P.ldq[k], sp.T, P.ldt[k],
+                     P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr, sn.beta, sn.BT, P.ldb[k + 1], f, gam, sp.Kinv, sp.Kmat, P.ldq[k], sp.T, P.ldt[k],
                      sp.dyn, sp.rho, sp.beta};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_bwd_small<<<1, 256, sizeof(double) * (P.capn[k] + P.qmax[k] + 4), s>>>(ba));
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_bwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 3 * P.qmax[k] + 4), s>>>(ba));
     // v_k = gam_x - Y' rho
     if ((e = st_gemv_cols(h, d, sp.Y, P.ldy[k], P.qmax[k], nn, sp.rho, gam, -1.0, sp.v))) return e;
   }
@@ -535,7 +547,7 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
       KLAUNCH(h, KC_ST_VEC, stg::k_st_x0_fixed<<<nblk(std::max(n0, P.cap[0])), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, v.r2, S,
                                                                                          s0.eta, P.cap[0]));
     else
-      KLAUNCH(h, KC_ST_SMALL, stg::k_st_x0_free<<<1, 256, 0, s>>>(n0, P.cap[0], P.q0max, M + P.oK0, P.ldq0, s0.dyn, s0.v,
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_x0_free<<<1, 256, sizeof(double) * (3 * P.q0max + 4), s>>>(n0, P.cap[0], P.q0max, M + P.oK0, M + P.oK0m, P.ldq0, s0.dyn, s0.v,
                                                                 s0.beta, S, s0.eta));
   }
   for (int k = 0; k < K; k++) {

@@ -152,6 +152,8 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     // would carry more than CARRY_MAX rows reports HQPKKT_E_SIZES at run time
     cap[k] = std::min(capn[k], CARRY_MAX);
     qmax[k] = mk[k] + std::min(mk[k], capn[k]);
+    // at most mk[k] rows can be consumed by this stage's controls: more than CARRY_MAX are left for sure
+    if (capn[k] - mk[k] > CARRY_MAX) return 1;
   }
   q0max = fixed_x0 ? 0 : nk[0] + cap[0];
   // what the one-workgroup kernels hold in LDS (~150 KB)
@@ -170,10 +172,10 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   ldf.assign(K + 1, 8), ldv.assign(K + 1, 8), ldy.assign(K + 1, 8), ldn.assign(K + 1, 8);
   ldb.assign(K + 1, 8), ldq.assign(K + 1, 8), ldt.assign(K + 1, 8), ldg.assign(K + 1, 8);
   oF.assign(K + 1, 0), oV.assign(K + 1, 0);
-  oY.assign(K + 1, 0), oR.assign(K + 1, 0), oK.assign(K + 1, 0), oN.assign(K + 1, 0);
+  oY.assign(K + 1, 0), oR.assign(K + 1, 0), oK.assign(K + 1, 0), oKm.assign(K + 1, 0), oN.assign(K + 1, 0);
   oBT.assign(K + 1, 0), oT.assign(K + 1, 0), oVec.assign(K + 1, 0);
   long long fo = 0, vo = 0, mo = 0;
-  long long wmax = 0, gmax = 0;
+  long long wmax = 0, gmax = 0, resmax = 0;
   int nzmax = 0, nmax = 0;
   for (int k = 0; k <= K; k++) {
     const int nz = k < K ? nk[k] + mk[k] : nk[k];
@@ -192,6 +194,8 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       oY[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldy[k]);
       oR[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldy[k]);
       oK[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldq[k]);
+      oKm[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldq[k]);
+      resmax = std::max(resmax, (long long)std::max(qmax[k], 1) * ldy[k]);
       oT[k] = mo, mo += up16((long long)std::max(cap[k], 1) * ldt[k]);
       wmax = std::max(wmax, (long long)nk[k + 1] * ldf[k]);
       gmax = std::max(gmax, (long long)nz * ldg[k]);
@@ -201,6 +205,8 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   oG = mo, mo += up16(gmax);
   ldq0 = up8(std::max(q0max, 1));
   oK0 = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
+  oK0m = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
+  oRes = mo, mo += up16(resmax);
   oGam = mo, mo += up16(nzmax + 8);
   {
     int qm = 1;

@@ -301,11 +301,22 @@ void Hqp_IpMatrixHip::update(const Hqp_Program *qp)
 }
 
 //--------------------------------------------------------------------------
-void Hqp_IpMatrixHip::factor(const Hqp_Program *, const VEC *z, const VEC *w)
+void Hqp_IpMatrixHip::factor(const Hqp_Program *qp, const VEC *z, const VEC *w)
 {
+  int e;
   assert((int)z->dim == _m && (int)w->dim == _m);
   hqpkkt_set_tol(_h, _tol);
-  check(hqpkkt_factor(_h, z->ve, w->ve), "Hqp_IpMatrixHip::factor");
+  e = hqpkkt_factor(_h, z->ve, w->ve);
+  if (_mode_used == HQPKKT_MODE_STAGED && e == HQPKKT_E_SIZES) {
+    // a stage is left with more constraint rows to carry back than the STAGED kernels hold (decided
+    // by the values: the ranks of the stage constraints): from now on the full-system engine
+    bool changed;
+    extract(qp, changed);
+    e = open(HQPKKT_MODE_FULL);
+    if (!e)
+      e = hqpkkt_factor(_h, z->ve, w->ve);
+  }
+  check(e, "Hqp_IpMatrixHip::factor");
 }
 
 //--------------------------------------------------------------------------

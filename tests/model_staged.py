@@ -212,10 +212,11 @@ class StagedModel:
             Y = np.vstack([G[n:, :n], Nx[R, :]])
             Kinv = inv_complete(Kmat)
             Rm = Kinv @ Y
+            Rm = Rm + Kinv @ (Y - Kmat @ Rm)  # one round of refinement, as the kernels do
             Vk = G[:n, :n] - Y.T @ Rm
             V[k] = 0.5 * (Vk + Vk.T)
             B[k] = Nx[L, :] - t @ Nx[R, :]
-            st[k] = dict(R=R, L=L, t=t, Kinv=Kinv, Y=Y, Rm=Rm, c=c)
+            st[k] = dict(R=R, L=L, t=t, Kinv=Kinv, Kmat=Kmat, Y=Y, Rm=Rm, c=c)
         self.V, self.B, self.st = V, B, st
         if S["fixed_x0"]:
             if B[0].shape[0] and np.abs(B[0]).max() > GE_TOL:
@@ -227,6 +228,7 @@ class StagedModel:
             K0[:n0, :n0] = V[0]
             K0[n0:, :n0] = B[0]
             K0[:n0, n0:] = B[0].T
+            self.K0 = K0
             self.K0inv = inv_complete(K0)
 
     # -------------------------------------------------------------------- step
@@ -256,6 +258,7 @@ class StagedModel:
             s = st[k]
             y0 = np.concatenate([gam[n:], nu[s["R"]]])
             rho[k] = s["Kinv"] @ y0
+            rho[k] = rho[k] + s["Kinv"] @ (y0 - s["Kmat"] @ rho[k])
             v[k] = gam[:n] - s["Y"].T @ rho[k]
             beta[k] = nu[s["L"]] - s["t"] @ nu[s["R"]]
         sx = np.zeros(nvar)
@@ -268,7 +271,9 @@ class StagedModel:
             eta = np.zeros(B[0].shape[0])
             lam[fr] = -(V[0] @ x + v[0] + B[0].T @ eta) / val
         else:
-            sol = -self.K0inv @ np.concatenate([v[0], beta[0]])
+            b0 = np.concatenate([v[0], beta[0]])
+            sol = self.K0inv @ b0
+            sol = -(sol + self.K0inv @ (b0 - self.K0 @ sol))
             x, eta = sol[:n0], sol[n0:]
         for k in range(K):
             n, mu = nk[k], mk[k]

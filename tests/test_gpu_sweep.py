@@ -84,3 +84,32 @@ def test_random_qps_through_the_mehrotra_loop(block):
         assert abs(f(x) - f(ref["x"])) <= 1e-6 * max(1.0, abs(f(ref["x"]))), tag
         agreed += 1
     assert agreed >= 20
+
+
+@pytest.mark.parametrize("block", range(4))
+def test_random_multistage_qps_against_the_reference_lqdocp(block):
+    """A fixed slice of tools/fuzz_staged.py: the STAGED engine (plugin LQDOCP) against the reference's own
+    Hqp_IpLQDOCP (oracle/_ref) where it is built, the CPU oracle of the full system otherwise."""
+    import fuzz_staged
+    ok = 0
+    for case in range(60 * block, 60 * block + 60):
+        s, detail = fuzz_staged.check(case)
+        assert s != "BAD", detail
+        ok += s == "ok"
+    assert ok >= 45
+
+
+def test_stiff_stage_where_the_explicit_inverse_needs_its_refinement():
+    """Sweep case 672: path equalities that consume both controls with a nearly dependent pair of columns make
+    the cost-to-go stiff (|V| ~ 2e9 next to 1e3); products with the explicit inverse of the stage matrix alone left
+    a first-pass residual of 0.45 where the reference's solve by factors has 4e-6 - with one round of refinement
+    against K itself (k_st_bwd_small, staged_run_factor) the two agree."""
+    import fuzz_staged
+    prog, st, tag = fuzz_staged.make_case(672)
+    M = ipmatrix.IpLQDOCP()
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    M.step(prog, *st, *d)
+    assert M.residuum(prog, *st, *d) < 1e-4, tag
+    assert M.solve(prog, *st, *d) < 1e-10, tag
