@@ -44,7 +44,7 @@ class Opts(C.Structure):
                 ("eps", C.c_double), ("pivot_eps", C.c_double), ("leaf_size", C.c_int),
                 ("max_pivots", C.c_int), ("zd_policy", C.c_int), ("slack_policy", C.c_int),
                 ("no_small_fronts", C.c_int), ("upd_pingpong_mb", C.c_int), ("amalgamation", C.c_int),
-                ("reserved", C.c_int * 1)]
+                ("ordering", C.c_int)]
 
 
 class Stats(C.Structure):

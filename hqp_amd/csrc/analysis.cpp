@@ -10,6 +10,7 @@
 #include "analysis.hpp"
 
 #include <algorithm>
+#include <functional>
 #include <cstring>
 #include <numeric>
 #include <thread>
@@ -329,7 +330,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   // are not coupled across the cut (e.g. slack rows whose x sits on the right)
   // stay in the right part, so a separator is usually well below sbw rows.  Each
   // logical node becomes a chain of supernodes of <= max_pivots pivots below.
-  if (leaf_size <= 0) leaf_size = std::max(3 * std::max(sbw, 1) / 2, 32);
+  if (leaf_size <= 0) leaf_size = ordering == 1 ? 64 : std::max(3 * std::max(sbw, 1) / 2, 32);
   struct Tmp {
     std::vector<int> verts;  // band positions
     std::vector<int> kids;
@@ -348,11 +349,123 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       if (!taken[r]) v.push_back(r);
     return v;
   };
+  std::vector<int> roots;
+  if (ordering == 1) {
+    // ---- general graphs: nested dissection by level structures (George's automatic nested
+    // dissection).  Per connected piece: breadth-first levels from a pseudo-peripheral vertex, the
+    // thinnest level of the middle half is the separator (only its vertices that touch the next
+    // level: the others join the near side), both sides recursively.  A mesh-like sparsity
+    // (discretised problems, the CUTE collection's typical structure) gets separators that shrink
+    // with the piece; the cut of the RCM band above keeps them at the band width on every level.
+    const int leaf = std::max(leaf_size, 8);
+    std::vector<int> in_set(dim, -1), lvl(dim, -1), queue;
+    int set_id = 0;
+    // breadth-first levels of the piece that holds `start` inside set `sid`; returns the level count
+    auto bfs = [&](int start, int sid, std::vector<int> &order, std::vector<int> &lptr) {
+      order.clear(), lptr.clear();
+      order.push_back(start), lvl[start] = 0;
+      lptr.push_back(0);
+      size_t head = 0;
+      int cur = 0;
+      while (head < order.size()) {
+        const int q = order[head];
+        if (lvl[q] != cur) cur = lvl[q], lptr.push_back((int)head);
+        head++;
+        for (int k = gstart[q]; k < gstart[q + 1]; k++) {
+          const int x = gneigh[k];
+          if (in_set[x] == sid && lvl[x] < 0) lvl[x] = cur + 1, order.push_back(x);
+        }
+      }
+      lptr.push_back((int)order.size());
+      return (int)lptr.size() - 1;
+    };
+    std::function<std::vector<int>(std::vector<int> &)> dissect = [&](std::vector<int> &S) -> std::vector<int> {
+      std::vector<int> out;
+      const int sid = set_id++;
+      for (int q : S) in_set[q] = sid, lvl[q] = -1;
+      std::vector<int> order, lptr, best_order, best_lptr;
+      for (int q0 : S) {
+        if (lvl[q0] >= 0) continue;  // piece already handled
+        // pseudo-peripheral start: repeat from a minimum-degree vertex of the last level while the depth grows
+        int start = q0, depth = bfs(start, sid, order, lptr);
+        for (int round = 0; round < 4; round++) {
+          int cand = -1, cdeg = 0x7fffffff;
+          for (int t = lptr[depth - 1]; t < lptr[depth]; t++) {
+            const int q = order[t], dg = gstart[q + 1] - gstart[q];
+            if (dg < cdeg) cdeg = dg, cand = q;
+          }
+          best_order = order, best_lptr = lptr;
+          for (int q : order) lvl[q] = -1;
+          const int d2 = bfs(cand, sid, order, lptr);
+          if (d2 <= depth) {  // no deeper: keep the previous structure
+            for (int q : order) lvl[q] = -1;
+            order = best_order, lptr = best_lptr;
+            for (int l = 0; l < depth; l++)
+              for (int t = lptr[l]; t < lptr[l + 1]; t++) lvl[order[t]] = l;
+            break;
+          }
+          depth = d2, start = cand;
+        }
+        const int len = (int)order.size();
+        auto as_leaf = [&]() {
+          std::vector<int> v;
+          for (int q : order) v.push_back(qp2j[q]);
+          std::sort(v.begin(), v.end());
+          out.push_back(make(std::move(v), {}));
+        };
+        if (len <= leaf || depth < 3) {
+          as_leaf();
+          continue;
+        }
+        // thinnest level with at least a quarter of the piece on either side; none: the one next to the median
+        int cut = -1;
+        long long bestw = 0;
+        for (int l = 1; l + 1 < depth; l++) {
+          const int before = lptr[l], after = len - lptr[l + 1], w = lptr[l + 1] - lptr[l];
+          if (4LL * before >= len && 4LL * after >= len && (cut < 0 || w < bestw)) cut = l, bestw = w;
+        }
+        if (cut < 0) {
+          long long bestd = 0;
+          for (int l = 1; l + 1 < depth; l++) {
+            const long long dd = std::llabs(2LL * lptr[l] + (lptr[l + 1] - lptr[l]) - len);
+            if (cut < 0 || dd < bestd) cut = l, bestd = dd;
+          }
+        }
+        std::vector<int> sep, left, right;
+        for (int t = lptr[cut]; t < lptr[cut + 1]; t++) {
+          const int q = order[t];
+          bool touches = false;
+          for (int k = gstart[q]; k < gstart[q + 1] && !touches; k++)
+            touches = in_set[gneigh[k]] == sid && lvl[gneigh[k]] == cut + 1;
+          (touches ? sep : left).push_back(q);
+        }
+        if (3LL * (long long)sep.size() >= len) {
+          as_leaf();
+          continue;
+        }
+        left.insert(left.end(), order.begin(), order.begin() + lptr[cut]);
+        right.assign(order.begin() + lptr[cut + 1], order.end());
+        std::vector<int> sv;
+        for (int q : sep) sv.push_back(qp2j[q]);
+        std::sort(sv.begin(), sv.end());
+        // (the recursion re-labels in_set / lvl of its vertices: nothing of this piece is read afterwards)
+        std::vector<int> kids = dissect(left);
+        std::vector<int> kr = dissect(right);
+        kids.insert(kids.end(), kr.begin(), kr.end());
+        // mark the piece as handled for the loop over S (lvl >= 0) under this frame's set id again
+        for (int q : order) in_set[q] = -2, lvl[q] = 0;
+        out.push_back(make(std::move(sv), std::move(kids)));
+      }
+      return out;
+    };
+    std::vector<int> all(dim);
+    for (int q = 0; q < dim; q++) all[q] = q;
+    roots = dissect(all);
+  } else {
   struct Frame {
     int lo, hi, stage, mid;
     std::vector<int> sep, left, right;
   };
-  std::vector<int> roots;
   {
     std::vector<Frame> st;
     std::vector<std::vector<int>> ret;  // return values stack
@@ -416,6 +529,8 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       st.pop_back();
     }
     roots = ret.back();
+  }
+
   }
 
   // postorder of the logical nodes

@@ -59,7 +59,7 @@ class Hqp_IpMatrix:
 
     def __init__(self, device=0, device_vectors=False, mat_tol=1.0, mat_eps=1e-10,
                  pivot_eps=None, leaf_size=0, max_pivots=0, zd_policy=None, shard=None, slack_policy=None, small_fronts=True, upd_pingpong_mb=0,
-                 amalgamation=False):
+                 amalgamation=False, ordering=0):
         L = _lib.lib()
         o = _lib.Opts()
         L.hqpkkt_default_opts(C.byref(o))
@@ -77,6 +77,7 @@ class Hqp_IpMatrix:
         o.no_small_fronts = 0 if small_fronts else 1
         o.upd_pingpong_mb = upd_pingpong_mb
         o.amalgamation = 1 if amalgamation else 0
+        o.ordering = int(ordering)
         self._L = L
         self._h = C.c_void_p()
         self._device_vectors = bool(device_vectors)

@@ -270,6 +270,44 @@ def random_sparse_qp(n, me, m, row_nnz=4, seed=7):
                    b=rng.uniform(-1, 1, me), d=rng.uniform(0.5, 1.5, m))
 
 
+def grid_sparse_qp(gx, gy, seed=11, eq_every=3, bound_frac=0.5, long_range=0):
+    """Mesh-structured QP, the sparsity of a discretised control problem (what the CUTE collection's
+    large programs look like, BASELINE configs[4]): one variable per cell of a gx x gy grid, Q couples
+    a cell with its right and lower neighbour (diagonally dominant), every eq_every-th cell has an
+    equality row over the cell and those two neighbours, a fraction of the cells is bounded (one-entry
+    inequality rows).  long_range > 0 adds that many random far couplings to Q (irregular part)."""
+    rng = np.random.default_rng(seed)
+    n = gx * gy
+    idx = np.arange(n).reshape(gy, gx)
+    right = np.stack([idx[:, :-1].ravel(), idx[:, 1:].ravel()])
+    down = np.stack([idx[:-1, :].ravel(), idx[1:, :].ravel()])
+    lo = np.concatenate([right[0], down[0]])
+    hi = np.concatenate([right[1], down[1]])
+    if long_range:
+        a, b = rng.integers(0, n, long_range), rng.integers(0, n, long_range)
+        keep = a != b
+        key = np.unique(np.minimum(a, b)[keep].astype(np.int64) * n + np.maximum(a, b)[keep])
+        near = set((lo.astype(np.int64) * n + hi).tolist())
+        key = np.array([k for k in key.tolist() if k not in near], dtype=np.int64)
+        lo, hi = np.concatenate([lo, key // n]), np.concatenate([hi, key % n])
+    v = rng.uniform(-0.5, 0.5, size=lo.size)
+    rowsum = np.zeros(n)
+    np.add.at(rowsum, lo, np.abs(v))
+    np.add.at(rowsum, hi, np.abs(v))
+    Q = _csr(np.concatenate([np.arange(n), lo]), np.concatenate([np.arange(n), hi]),
+             np.concatenate([1.0 + rowsum, v]), n)
+    cells = idx[:-1, :-1].ravel()
+    cells = cells[(cells // gx + cells % gx) % eq_every == 0]
+    me = cells.size
+    rr = np.repeat(np.arange(me), 3)
+    cc = np.stack([cells, cells + 1, cells + gx], axis=1).ravel()
+    A = _csr(rr, cc, rng.uniform(0.5, 1.5, size=rr.size) * rng.choice([-1.0, 1.0], size=rr.size), me)
+    bounded = np.flatnonzero(rng.random(n) < bound_frac)
+    m = bounded.size
+    Cm = _csr(np.arange(m), bounded, np.ones(m), m)
+    return Program(n, me, m, Q, A, Cm, c=rng.uniform(-1, 1, n), b=rng.uniform(-1, 1, me), d=rng.uniform(0.5, 1.5, m))
+
+
 def ip_state(prog, seed=1, spread=0.0):
     """Strictly positive (z, w) and right-hand sides r1..r4 as an interior-point
     iteration would pass them (hqp/Hqp_IpsMehrotra.C:425-445, 527-530).

@@ -98,7 +98,12 @@ typedef struct hqpkkt_opts {
                         latency there, not arithmetic: +7..10 % interior-point iterations/s on
                         the Prg_DID structure, same iteration counts.  Default 0 (DESIGN.md
                         section 4)                                                              */
-  int reserved[1];
+  int ordering;      /* elimination tree: 0 = nested dissection of the RCM band (default: banded and
+                        multistage systems, mat_sbw wide separators on every level), 1 = nested
+                        dissection of the graph itself by breadth-first level structures, for
+                        irregular sparsity (discretised / CUTE-style programs, hqp_cute/hqp_cute.tcl:
+                        22-46 selects RedSpBKP for them): separators shrink with the piece.  mat_sbw
+                        and the RCM permutation are reported as before either way                  */
 } hqpkkt_opts;
 
 typedef struct hqpkkt_stats {

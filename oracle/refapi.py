@@ -278,6 +278,24 @@ def sqp_did(kmax, qp_solver="Mehrotra", mat_solver="SpBKP", host="ref", sqp_eps=
                 norm_grd_L=out[5], rc=e)
 
 
+def sqp_grid(gx, gy, qp_solver="Mehrotra", mat_solver="RedSpBKP", host="ref", seed=1, eq_every=3, bound_frac=0.5, hela=1,
+             ordering=0, sqp_eps=1e-6, sqp_max_iters=200):
+    """BASELINE.json configs[4] stand-in: Prg_GridNLP (oracle/ref_sqpdrive.cc, our program class with the sparsity
+    of a discretised control problem) through the reference's Hqp_SqpPowell with the QP solver / KKT plugin given
+    by name.  Returns dict(f, sqp_iters, qp_iters, seconds, norm_inf, norm_grd_L, n, me, m, rc) - rc 0 = optimal."""
+    lib = _host(host)
+    lib.hqpsqp_grid.restype = C.c_int
+    lib.hqpsqp_grid.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_int,
+                                C.c_double, C.c_int, _dp]
+    out = np.zeros(12)
+    e = lib.hqpsqp_grid(int(gx), int(gy), int(seed), int(eq_every), float(bound_frac), int(hela), qp_solver.encode(),
+                        mat_solver.encode(), int(ordering), float(sqp_eps), int(sqp_max_iters), out)
+    if e > 0:
+        raise RefError(e, f"sqp_grid[{qp_solver},{mat_solver}]")
+    return dict(f=out[0], sqp_iters=int(out[1]), qp_iters=int(out[2]), seconds=out[3], norm_inf=out[4],
+                norm_grd_L=out[5], n=int(out[6]), me=int(out[7]), m=int(out[8]), rc=e)
+
+
 def time_update(prog, mat_solver="SpBKP", host="ref", reps=7):
     """(median seconds of Hqp_Solver::update() with new values on the same pattern, seconds of init +
     first update) with the reference's Hqp_IpsMehrotra and the plugin ``mat_solver``."""

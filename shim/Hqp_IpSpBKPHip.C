@@ -60,6 +60,10 @@ Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
   if (_update_threads > 16) _update_threads = 16;
   if (_update_threads < 1) _update_threads = 1;
   _ifList.append(new If_Int("mat_update_threads", &_update_threads));
+  // 1: nested dissection of the graph itself instead of the RCM band (irregular sparsity, e.g. what
+  // hqp_cute/hqp_cute.tcl:22-46 runs through RedSpBKP); takes effect at the next init()
+  _ordering = 0;
+  _ifList.append(new If_Int("mat_ordering", &_ordering));
 }
 
 //--------------------------------------------------------------------------
@@ -209,6 +213,7 @@ int Hqp_IpMatrixHip::open(int mode)
   opts.loc = HQPKKT_LOC_HOST;   // Meschach VEC::ve pointers
   opts.tol = _tol;
   opts.eps = _eps;
+  opts.ordering = _ordering;
   if (_ngpu > 1 && !_rccl) {
     // the communicator is made once per plugin object (it outlives re-inits)
     typedef int (*create_t)(void **, int *, int *, int *);

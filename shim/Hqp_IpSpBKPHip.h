@@ -33,6 +33,7 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   void *_rccl;        // communicator context of libhqpkkt_rccl.so (include/hqpkkt_rccl.h)
   void *_rccl_lib;    // its dlopen handle
   int _rank;
+  int _ordering;      // mat_ordering: 0 nested dissection of the RCM band, 1 of the graph itself
   int _update_threads; // mat_update_threads: host threads of update()'s walk over the row lists
   struct hqpkkt *_h;
   // CSR copies of the pattern the handle was analysed for (pattern-change
