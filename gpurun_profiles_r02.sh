@@ -23,5 +23,10 @@ for nx in 1000 2000 3000; do python tools/c4_bench.py 200 $nx 50 3 --profile 2>/
 python bench.py --workload c2 --steps 20 --warmup 3 2>/dev/null | grep '^{' | tail -1 > $O/r02_bench_c2.json
 python tools/staged_probe.py gemm 2>/dev/null > $O/r02_dgemm_sizes.txt
 python tools/update_time.py 2>/dev/null | grep '^{' | tail -1 > $O/r02_update_time.json
+# configs[4] stand-in: the sparse NLP through the reference's SQP host (reference's RedSpBKP up to 150 x 150 cells)
+python tools/c5_bench.py 150 60 100 150 200 300 500 700 1000 2>/dev/null | grep '^{' > $O/r02_c5_grid_sqp.jsonl
+# the randomised sweep of the STAGED engine against the reference's Hqp_IpLQDOCP, in chunks (the reference's
+# Meschach error counter ends the process after 100 caught errors)
+for s0 in 0 400 800 1200 1600 2000 2400 2800; do python tools/fuzz_staged.py 400 $s0 2>/dev/null | grep -v amdgpu.ids | tail -12; done > $O/r02_fuzz_staged.txt
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 ls -la $O

@@ -58,6 +58,11 @@ def main():
                 line[f"kkt_ordering{o}"] = kkt_rate(g, o)
             except ipmatrix.KktError as e:
                 line[f"kkt_ordering{o}"] = {"error": str(e)}
+        try:  # our device-resident Mehrotra loop (shim/Hqp_IpsMehrotraHip.C) under the same SQP host
+            r = refapi.sqp_grid(g, g, "MehrotraHip", "RedSpBKPHip", host="hip", ordering=1)
+            line["MehrotraHip_RedSpBKPHip_ordering1"] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in r.items()}
+        except refapi.RefError as e:
+            line["MehrotraHip_RedSpBKPHip_ordering1"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
 
 
