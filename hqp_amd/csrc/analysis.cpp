@@ -137,6 +137,33 @@ void rcm_order(int dim, const std::vector<int> &start, const std::vector<int> &n
   for (int i = 0; i < dim; i++) order[lv[i].node] = dim - 1 - i;
 }
 
+// Plain reverse Cuthill-McKee (one breadth-first pass per component from its first node, the new
+// neighbours of a node in the order of their degrees): ordering 2 does not report the reference's
+// permutation, and the reference-faithful pass above re-sorts a whole level after every parent, which is
+// quadratic in the level width (seconds for a 10^6-node mesh)
+void cm_order_plain(int dim, const std::vector<int> &start, const std::vector<int> &neigh, std::vector<int> &order) {
+  std::vector<int> seq;
+  seq.reserve(dim);
+  std::vector<char> seen(dim, 0);
+  std::vector<int> nb;
+  for (int root = 0; root < dim; root++) {
+    if (seen[root]) continue;
+    seen[root] = 1;
+    size_t head = seq.size();
+    seq.push_back(root);
+    while (head < seq.size()) {
+      const int v = seq[head++];
+      nb.clear();
+      for (int k = start[v]; k < start[v + 1]; k++)
+        if (!seen[neigh[k]]) seen[neigh[k]] = 1, nb.push_back(neigh[k]);
+      std::stable_sort(nb.begin(), nb.end(), [&](int a, int b) { return start[a + 1] - start[a] < start[b + 1] - start[b]; });
+      seq.insert(seq.end(), nb.begin(), nb.end());
+    }
+  }
+  order.assign(dim, 0);
+  for (int i = 0; i < dim; i++) order[seq[i]] = dim - 1 - i;
+}
+
 bool csr_ok(int rows, int cols, const int *p, const int *ix) {
   if (!p) return rows == 0;
   if (p[0] != 0) return false;
@@ -311,7 +338,10 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     for (int r = 0; r < m; r++)
       for (int k = Cp[r]; k < Cp[r + 1]; k++) link(n + me + r, Ci[k]);
 
-  rcm_order(dim, gstart, gneigh, qp2j);
+  if (ordering == 2)
+    cm_order_plain(dim, gstart, gneigh, qp2j);
+  else
+    rcm_order(dim, gstart, gneigh, qp2j);
   sbw = 0;
   std::vector<int> reach(dim);  // by band position: farthest coupled position
   for (int v = 0; v < dim; v++) {
@@ -330,7 +360,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   // are not coupled across the cut (e.g. slack rows whose x sits on the right)
   // stay in the right part, so a separator is usually well below sbw rows.  Each
   // logical node becomes a chain of supernodes of <= max_pivots pivots below.
-  if (leaf_size <= 0) leaf_size = ordering == 1 ? 64 : std::max(3 * std::max(sbw, 1) / 2, 32);
+  if (leaf_size <= 0) leaf_size = ordering >= 1 ? 64 : std::max(3 * std::max(sbw, 1) / 2, 32);
   struct Tmp {
     std::vector<int> verts;  // band positions
     std::vector<int> kids;
@@ -350,7 +380,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     return v;
   };
   std::vector<int> roots;
-  if (ordering == 1) {
+  if (ordering >= 1) {
     // ---- general graphs: nested dissection by level structures (George's automatic nested
     // dissection).  Per connected piece: breadth-first levels from a pseudo-peripheral vertex, the
     // thinnest level of the middle half is the separator (only its vertices that touch the next

@@ -67,7 +67,7 @@ struct Analysis {
   std::vector<long long> upd_level_off, upd_level_len;  // ping-pong: the range a level's blocks occupy
   bool small_fronts = true;  // fused one-wavefront kernels for fronts with few pivots and few border rows
   bool amalgamation = false;  // separators absorb their child separators while they stay small fronts
-  int ordering = 0;  // 0: nested dissection of the RCM band, 1: nested dissection of the graph itself (irregular sparsity)
+  int ordering = 0;  // 0: nested dissection of the RCM band, 1: nested dissection of the graph itself (irregular sparsity), 2: the same without the reference's RCM pass
   int slack_policy = 2;  // FULL mode, slack rows inside a node: 0 band order, 1 behind all x, 2 behind their own x
   std::vector<int> node_owner;  // owning rank per supernode, -1 = replicated top of the tree
   std::vector<int> xroots;      // subtree roots whose update / contribution blocks are exchanged

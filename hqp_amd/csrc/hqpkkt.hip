@@ -973,7 +973,7 @@ static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd) {
   h->an.slack_policy = h->opts.slack_policy;
   h->an.small_fronts = !h->opts.no_small_fronts;
   h->an.amalgamation = h->opts.amalgamation != 0;
-  h->an.ordering = h->opts.ordering == 1 ? 1 : 0;
+  h->an.ordering = (h->opts.ordering == 1 || h->opts.ordering == 2) ? h->opts.ordering : 0;
   if (h->opts.upd_pingpong_mb > 0) h->an.upd_pingpong_bytes = (long long)h->opts.upd_pingpong_mb << 20;
   if (h->opts.upd_pingpong_mb < 0) h->an.upd_pingpong_bytes = 0;
   int e = h->an.run(h->opts.mode, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),

@@ -103,7 +103,10 @@ typedef struct hqpkkt_opts {
                         dissection of the graph itself by breadth-first level structures, for
                         irregular sparsity (discretised / CUTE-style programs, hqp_cute/hqp_cute.tcl:
                         22-46 selects RedSpBKP for them): separators shrink with the piece.  mat_sbw
-                        and the RCM permutation are reported as before either way                  */
+                        and the RCM permutation are reported as before either way; 2 = as 1 without the
+                        reference-faithful RCM pass (hqp/sprcm.C:226-384 re-sorts a level after every
+                        parent: quadratic in the level width, seconds for a 10^6-node mesh): mat_sbw
+                        and hqpkkt_get_perm then describe a plain reverse Cuthill-McKee numbering       */
 } hqpkkt_opts;
 
 typedef struct hqpkkt_stats {

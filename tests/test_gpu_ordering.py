@@ -24,16 +24,20 @@ CASES = {
 @pytest.mark.parametrize("kind", ["SpBKP", "RedSpBKP"])
 @pytest.mark.parametrize("case", sorted(CASES))
 @pytest.mark.parametrize("spread", [0.0, 2.0])
-def test_graph_dissection_against_the_oracle(kind, case, spread):
+@pytest.mark.parametrize("ordering", [1, 2])
+def test_graph_dissection_against_the_oracle(kind, case, spread, ordering):
     prog = CASES[case]()
     st = problems.ip_state(prog, 3, spread)
     O = oracleapi.OracleIpMatrix(kind)
     O.init(prog)
     O.factor(st[0], st[1])
     osol, ores = O.solve(*st)
-    M = CLS[kind](ordering=1)
+    M = CLS[kind](ordering=ordering)
     M.init(prog)
-    assert M.mat_sbw == O.sbw and np.array_equal(M.perm(), O.perm())  # reported as before
+    if ordering == 1:  # reported as before; 2 numbers the graph by a plain reverse Cuthill-McKee pass
+        assert M.mat_sbw == O.sbw and np.array_equal(M.perm(), O.perm())
+    else:
+        assert sorted(M.perm()) == list(range(prog.n + prog.me + (prog.m if kind == "SpBKP" else 0)))
     d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
     M.factor(prog, st[0], st[1])
     res = M.solve(prog, *st, *d)

@@ -48,7 +48,7 @@ def main():
         if g <= ref_max:
             r = refapi.sqp_grid(g, g, "Mehrotra", "RedSpBKP", host="hip")
             line["reference_RedSpBKP_cpu"] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in r.items()}
-        for o in ((0, 1) if g <= 300 else (1,)):  # the band's tree beyond 300 x 300: tens of GB of factor
+        for o in ((0, 1, 2) if g <= 300 else (2,)):  # the band's tree beyond 300 x 300: tens of GB of factor
             try:
                 r = refapi.sqp_grid(g, g, "Mehrotra", "RedSpBKPHip", host="hip", ordering=o)
                 line[f"RedSpBKPHip_ordering{o}"] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in r.items()}
@@ -59,10 +59,10 @@ def main():
             except ipmatrix.KktError as e:
                 line[f"kkt_ordering{o}"] = {"error": str(e)}
         try:  # our device-resident Mehrotra loop (shim/Hqp_IpsMehrotraHip.C) under the same SQP host
-            r = refapi.sqp_grid(g, g, "MehrotraHip", "RedSpBKPHip", host="hip", ordering=1)
-            line["MehrotraHip_RedSpBKPHip_ordering1"] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in r.items()}
+            r = refapi.sqp_grid(g, g, "MehrotraHip", "RedSpBKPHip", host="hip", ordering=2)
+            line["MehrotraHip_RedSpBKPHip_ordering2"] = {k: (float(v) if isinstance(v, (float, np.floating)) else v) for k, v in r.items()}
         except refapi.RefError as e:
-            line["MehrotraHip_RedSpBKPHip_ordering1"] = {"error": str(e)}
+            line["MehrotraHip_RedSpBKPHip_ordering2"] = {"error": str(e)}
         print(json.dumps(line), flush=True)
 
 
