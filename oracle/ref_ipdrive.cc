@@ -43,7 +43,7 @@ void hqpip_set_init_method(int v) { g_init_method = v; }
 // solver: 0 = Mehrotra, 1 = Franke, 2 = MehrotraHip, 3 = FrankeHip (our Hqp_Solver plugins).  Returns 0, or the Meschach error number,
 // or -1 (setup) / -2 (unknown plugin name).
 // out[0] = iterations, out[1] = Hqp_Result (0 optimal), out[2] = seconds in
-// cold_start + solve, out[3] = seconds in init + update.
+// cold_start + solve, out[3] = seconds in init + update, out[4] = mat_sbw after the solve.
 int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const int *Qp,
                 const int *Qi, const double *Qx, const double *c, const int *Ap,
                 const int *Ai, const double *Ax, const double *b, const int *Cp,
@@ -89,6 +89,9 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
     out[1] = (double)S->result();
     out[2] = t2 - t1;
     out[3] = t1 - t0;
+    int sbw = -2;
+    (void)If_GetInt("mat_sbw", &sbw);
+    out[4] = sbw;   // the plugin's read-only member (our STAGED engine reports -1: no band)
   }
   delete S;
   delete qp;

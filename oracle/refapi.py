@@ -235,13 +235,13 @@ def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-
                  np.ascontiguousarray(i, dtype=np.int32) if len(i) else np.zeros(1, np.int32),
                  _pad(x), _pad(vec)]
     x, y, z = np.zeros(max(n, 1)), np.zeros(max(me, 1)), np.zeros(max(m, 1))
-    out = np.zeros(4)
+    out = np.zeros(5)
     e = lib.hqpip_solve({"Mehrotra": 0, "Franke": 1, "MehrotraHip": 2, "FrankeHip": 3}[solver], mat_solver.encode(), n, me, m, *args,
                         qp_eps, max_iters, x, y, z, out)
     if e:
         raise RefError(e, f"ip_solve[{solver},{mat_solver}]")
     return dict(x=x[:n], y=y[:me], z=z[:m], iters=int(out[0]), result=int(out[1]), seconds=out[2],
-                setup_seconds=out[3])
+                setup_seconds=out[3], mat_sbw=int(out[4]))
 
 
 def ip_solve_hot(prog, c2, b2, d2, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250):

@@ -64,6 +64,12 @@ Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
   // hqp_cute/hqp_cute.tcl:22-46 runs through RedSpBKP); takes effect at the next init()
   _ordering = 0;
   _ifList.append(new If_Int("mat_ordering", &_ordering));
+  // LQDOCPHip: a DOCP whose widest stage front (nx_k + nu_k + nx_k+1) is below this goes to the tree engine -
+  // the stage-by-stage chain of dense products pays from a few hundred states per stage on (K = 200, nu = 10:
+  // nx = 50 takes 15 ms staged against 2.1 ms through the tree, nx = 400 30 against 25)
+  _staged_min_front = 800;
+  if (getenv("HQPKKT_STAGED_MIN_FRONT")) _staged_min_front = atoi(getenv("HQPKKT_STAGED_MIN_FRONT"));
+  _ifList.append(new If_Int("mat_staged_min_front", &_staged_min_front));
 }
 
 //--------------------------------------------------------------------------
@@ -262,6 +268,10 @@ void Hqp_IpMatrixHip::init(const Hqp_Program *qp)
     // constraint rows than the STAGED kernels hold: the same KKT system through
     // the full-system engine
     e = open(HQPKKT_MODE_FULL);
+  } else if (_mode == HQPKKT_MODE_STAGED && !e) {
+    hqpkkt_stats st;
+    if (hqpkkt_get_stats(_h, &st) == HQPKKT_OK && st.max_front < _staged_min_front)
+      e = open(HQPKKT_MODE_FULL);   // small stages: see mat_staged_min_front
   }
   check(e, "Hqp_IpMatrixHip::init");
 }

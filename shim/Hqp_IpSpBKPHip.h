@@ -34,6 +34,7 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   void *_rccl_lib;    // its dlopen handle
   int _rank;
   int _ordering;      // mat_ordering: 0 nested dissection of the RCM band, 1 of the graph itself
+  int _staged_min_front; // mat_staged_min_front: LQDOCPHip uses the STAGED engine from this stage width on
   int _update_threads; // mat_update_threads: host threads of update()'s walk over the row lists
   struct hqpkkt *_h;
   // CSR copies of the pattern the handle was analysed for (pattern-change
@@ -80,7 +81,8 @@ class Hqp_IpRedSpBKPHip : public Hqp_IpMatrixHip {
 // odc/crane.tcl:58: qp_mat_solver LQDOCP).  Like Hqp_IpLQDOCP (hqp/Hqp_IpLQDOCP.C:693-976)
 // it finds the stages from the -1.0 staircase of A, keeps fx, fu and the cost-to-go
 // Hessians as dense per-stage blocks and runs the extended Riccati recursion over them
-// (HQPKKT_MODE_STAGED: fp64 MFMA products on the device).  Where the reference asserts
+// (HQPKKT_MODE_STAGED: fp64 MFMA products on the device) - from mat_staged_min_front (default 800) rows per
+// stage front on; narrower stages are faster through the tree engine.  Where the reference asserts
 // (no DOCP structure) or a stage is beyond the STAGED kernels (> ~64 controls, > 48
 // carried constraint rows) the same KKT system goes to the full-system engine.
 class Hqp_IpLQDOCPHip : public Hqp_IpMatrixHip {

@@ -47,12 +47,34 @@ def test_hip_plugin_fails_loudly_without_gpu():
 
 
 @pytest.mark.gpu
+def test_lqdocp_plugin_routes_narrow_stages_to_the_tree_engine(monkeypatch):
+    """mat_staged_min_front (default 800): a DOCP with narrow stages is solved by the tree engine (mat_sbw is a band
+    width), a wide one or mat_staged_min_front 0 by the STAGED engine (mat_sbw -1); same optimiser either way."""
+    if not refapi.host_available("hip"):
+        pytest.skip("oracle/_ref/libhqphost_hip.so not present")
+    prog = problems.did_like_qp(400)
+    monkeypatch.delenv("HQPKKT_STAGED_MIN_FRONT", raising=False)
+    routed = refapi.ip_solve(prog, "Mehrotra", "LQDOCPHip", host="hip")
+    monkeypatch.setenv("HQPKKT_STAGED_MIN_FRONT", "0")
+    staged = refapi.ip_solve(prog, "Mehrotra", "LQDOCPHip", host="hip")
+    assert routed["mat_sbw"] > 0 and staged["mat_sbw"] == -1
+    assert routed["result"] == staged["result"] == 0 and abs(routed["iters"] - staged["iters"]) <= 2
+    assert np.abs(routed["x"] - staged["x"]).max() <= 1e-6 * max(1.0, np.abs(staged["x"]).max())
+    wide = problems.lq_docp(6, 420, 4, seed=2)
+    monkeypatch.delenv("HQPKKT_STAGED_MIN_FRONT", raising=False)
+    assert refapi.ip_solve(wide, "Mehrotra", "LQDOCPHip", host="hip")["mat_sbw"] == -1
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["Mehrotra", "Franke"])
 @pytest.mark.parametrize("pair", [("SpBKP", "SpBKPHip"), ("RedSpBKP", "RedSpBKPHip"), ("LQDOCP", "LQDOCPHip")])
 @pytest.mark.parametrize("case", ["did50", "did400", "banded"])
-def test_reference_ip_solver_drives_hip_plugin(solver, pair, case):
+def test_reference_ip_solver_drives_hip_plugin(solver, pair, case, monkeypatch):
     if not refapi.host_available("hip"):
         pytest.skip("oracle/_ref/libhqphost_hip.so not present")
+    # LQDOCPHip: the STAGED engine also for these narrow stages (the default routes them to the tree engine,
+    # test_lqdocp_plugin_routes_narrow_stages_to_the_tree_engine)
+    monkeypatch.setenv("HQPKKT_STAGED_MIN_FRONT", "0")
     if pair[0] == "LQDOCP" and case == "banded":
         pytest.skip("Hqp_IpLQDOCP asserts DOCP structure (hqp/Hqp_IpLQDOCP.C:701,706,730)")
     prog = {"did50": lambda: problems.did_like_qp(50), "did400": lambda: problems.did_like_qp(400),
