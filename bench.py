@@ -322,6 +322,37 @@ def cpu_baseline_c4(K, nx, nu):
     return out
 
 
+def mesh_kkt_sizes(local_rank):
+    """Extra information: BASELINE configs[4]'s stand-in (mesh-structured sparse QP, plugin RedSpBKP, the tree of the
+    graph's own dissection: hqpkkt_opts.ordering 2): KKT factor+solve at 9e4 and 1e6 variables."""
+    import torch
+    from hqp_amd import ipmatrix, problems
+    out = {}
+    try:
+        for g in (300, 1000):
+            prog = problems.grid_sparse_qp(g, g)
+            st = [torch.as_tensor(a).cuda() for a in problems.ip_state(prog, 1, 1.0)]
+            M = ipmatrix.IpRedSpBKP(device=local_rank, device_vectors=True, ordering=2)
+            t0 = time.perf_counter()
+            M.init(prog)
+            init_s = time.perf_counter() - t0
+            d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
+            ts = []
+            for _ in range(6):
+                torch.cuda.synchronize()
+                t0 = time.perf_counter()
+                M.factor(prog, st[0], st[1])
+                res = M.solve(prog, *st, *d)
+                ts.append(time.perf_counter() - t0)
+            s = M.stats()
+            out[f"{g}x{g}"] = {"variables": prog.n, "kkt_dim": s["dim"], "ms_per_factor_solve": 1e3 * float(np.median(ts[1:])),
+                               "residual": res, "init_s": init_s, "flops_factor": s["flops_factor"], "tree_levels": s["n_levels"]}
+            del M
+    except Exception as e:
+        out["error"] = str(e)
+    return out
+
+
 def staged_small_sizes(local_rank):
     """Extra information: the STAGED engine at the sizes the reference's Hqp_IpLQDOCP is timed at in
     SURVEY.md section 6 (K=200, nu=10, CSR hand-over), next to the full-system engine on the same QPs."""
@@ -556,6 +587,7 @@ def bench_c4(args):
         c2 = bench_c2(a2, extras=False)
         out["c2_banded_kkt"] = {k: c2[k] for k in ("value", "unit", "ms_per_step", "residual", "roofline", "init_s")} if c2 else None
         out["ip_iterations"] = ip_iterations(2000)
+        out["mesh_kkt_configs4_standin"] = mesh_kkt_sizes(local_rank)
     return out
 
 

@@ -62,14 +62,17 @@ def main():
             prog = problems.banded_qp(case[1], case[2])
         elif case[0] == "docp":
             prog = problems.lq_docp(case[1], case[2], case[3])
+        elif case[0] == "grid":  # mesh QP through the tree of the graph's own dissection (opts.ordering)
+            prog = problems.grid_sparse_qp(case[1], case[2])
         else:
             prog = problems.did_like_qp(case[1])
         st = problems.ip_state(prog, 7, 1.0)
         cls = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP, "LQDOCP": ipmatrix.IpLQDOCP}[kind]
+        kw = dict(ordering=case[3]) if case[0] == "grid" else {}
         if os.environ.get("SHARD_TRANSPORT") == "rccl":  # libhqpkkt_rccl.so: stream-ordered collectives
-            M = cls(device=dev, shard=dist.RcclShard(rank, world, dev))
+            M = cls(device=dev, shard=dist.RcclShard(rank, world, dev), **kw)
         else:
-            M = cls(device=dev, shard=(rank, world, dist.make_exchange(rank, dev)))
+            M = cls(device=dev, shard=(rank, world, dist.make_exchange(rank, dev)), **kw)
         M.init(prog)
         d = new_d(prog)
         for rep in range(2):  # second round replays the captured graphs
@@ -87,7 +90,7 @@ def main():
                        owned=int((owner == rank).sum()), top=int((owner < 0).sum()),
                        bytes_factor=s["bytes_exchange_factor"], bytes_step=s["bytes_exchange_step"])
         if rank == 0:
-            R = cls(device=dev)
+            R = cls(device=dev, **kw)
             R.init(prog)
             R.factor(prog, st[0], st[1])
             d0 = new_d(prog)

@@ -13,7 +13,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 CASES = [["banded", 1500, 12, "SpBKP"], ["banded", 1500, 12, "RedSpBKP"], ["docp", 24, 6, 3, "SpBKP"],
-         ["did", 400, "RedSpBKP"]]
+         ["did", 400, "RedSpBKP"], ["grid", 40, 40, 1, "RedSpBKP"]]
 
 
 @pytest.mark.parametrize("world,port", [(2, 29561), (3, 29562), (4, 29563)])

@@ -42,6 +42,8 @@ def make_case(case):
         kw = dict(leaf_size=int(rng.choice([8, 24, 40, 100])), max_pivots=int(rng.choice([4, 16, 48, 128])))
     if rng.random() < 0.3:
         kw["amalgamation"] = True
+    if os.environ.get("FUZZ_ORDERING"):  # every case through the tree of the graph's own dissection (opts.ordering 1)
+        kw["ordering"] = 1
     st = problems.ip_state(prog, case, spread)
     return prog, st, kind, kw, f"case {case}: {what}{args} {kind} spread {spread} {kw}"
 
