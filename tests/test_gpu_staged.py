@@ -5,6 +5,9 @@ against the full-system HIP engine, on multistage QPs with and without stage equ
 (fixed / free initial state, final-state constraints that are carried back through the
 stages, path equalities, state bounds), and at K = 200 through size-independent properties.
 """
+import os
+import sys
+
 import numpy as np
 import pytest
 
@@ -254,3 +257,43 @@ def test_staged_mehrotra_loop():
         out.append((x, info))
     assert abs(out[0][1]["iters"] - out[1][1]["iters"]) <= 1
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-6 * max(1.0, np.abs(out[1][0]).max())
+
+
+def test_full_size_c4_properties():
+    """BASELINE configs[3] at its stated size - K = 200 stages, nx = 5000, nu = 50: 1 015 000 variables, the KKT system
+    of dimension 2.04e6 - through size-independent properties (the reference needs ~20 minutes per factorisation there):
+    residual of the reference's 4-block system <= 1e-10 without a refinement round, residuum() of the solution equal
+    to what solve() returned, linearity in the right-hand side, a second factorisation bit-identical."""
+    import torch
+    free, _total = torch.cuda.mem_get_info()
+    if free < 150e9:
+        pytest.skip("needs ~110 GB of HBM")
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    K, nx, nu = 200, 5000, 50
+    dq = bench.c4_dense(K, nx, nu, seed=3)
+    n, me, m = dq.dims
+    assert n == 1015000 and me == 1005000 and m == 20000
+    M = ipmatrix.IpLQDOCP(device_vectors=True)
+    M.init_dense(dq)
+    dq.F = None
+    torch.cuda.empty_cache()
+    g = torch.Generator(device="cuda").manual_seed(5)
+    rnd = lambda k, lo, hi: torch.empty(k, dtype=torch.float64, device="cuda").uniform_(lo, hi, generator=g)
+    z, w = rnd(m, 0.1, 1.1), rnd(m, 0.1, 1.1)
+    r = [rnd(k, -0.5, 0.5) for k in (n, me, m, m)]
+    new = lambda: [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (n, me, m, m)]
+    M.factor(dq, z, w)
+    d1 = new()
+    res = M.solve(dq, z, w, *r, *d1)
+    assert res <= 1e-10 and M.stats()["refine_rounds"] == 0
+    assert abs(M.residuum(dq, z, w, *r, *d1) - res) <= 1e-13
+    r2 = [2.0 * v for v in r]
+    d2 = new()
+    assert M.solve(dq, z, w, *r2, *d2) <= 1e-10
+    scale = max(float(v.abs().max()) for v in d1)
+    assert max(float((b - 2.0 * a).abs().max()) for a, b in zip(d1, d2)) <= 1e-9 * scale
+    M.factor(dq, z, w)
+    d3 = new()
+    M.solve(dq, z, w, *r, *d3)
+    assert all(bool(torch.equal(a, b)) for a, b in zip(d1, d3))
