@@ -360,7 +360,7 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   // are not coupled across the cut (e.g. slack rows whose x sits on the right)
   // stay in the right part, so a separator is usually well below sbw rows.  Each
   // logical node becomes a chain of supernodes of <= max_pivots pivots below.
-  if (leaf_size <= 0) leaf_size = ordering >= 1 ? 64 : std::max(3 * std::max(sbw, 1) / 2, 32);
+  if (leaf_size <= 0) leaf_size = ordering >= 1 ? 32 : std::max(3 * std::max(sbw, 1) / 2, 32);
   struct Tmp {
     std::vector<int> verts;  // band positions
     std::vector<int> kids;

@@ -81,3 +81,29 @@ def test_reference_sqp_solver_over_a_sparse_nlp(g, pair, ordering):
     assert abs(got["qp_iters"] - ref["qp_iters"]) <= 2
     assert abs(got["f"] - ref["f"]) <= 1e-6 * abs(ref["f"])
     assert got["norm_inf"] < 1e-6 and got["norm_grd_L"] < 1e-5
+
+
+def test_full_size_mesh_properties():
+    """The stand-in for configs[4] at 10^6 variables (1000 x 1000 cells, reduced KKT dimension 1.33e6, ordering 2)
+    through size-independent properties: residual <= 1e-10, residuum() of the solution equal to what solve()
+    returned, linear in the right-hand side, a second factorisation bit-identical."""
+    prog = problems.grid_sparse_qp(1000, 1000)
+    assert prog.n == 1000000
+    st = problems.ip_state(prog, 2, 1.0)
+    M = ipmatrix.IpRedSpBKP(ordering=2)
+    M.init(prog)
+    new = lambda: [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    M.factor(prog, st[0], st[1])
+    d1 = new()
+    res = M.solve(prog, *st, *d1)
+    assert res <= 1e-10
+    assert abs(M.residuum(prog, *st, *d1) - res) <= 1e-13
+    st2 = (st[0], st[1]) + tuple(2.0 * v for v in st[2:])
+    d2 = new()
+    assert M.solve(prog, *st2, *d2) <= 1e-10
+    scale = max(np.abs(v).max() for v in d1)
+    assert max(np.abs(b - 2.0 * a).max() for a, b in zip(d1, d2)) <= 1e-9 * scale
+    M.factor(prog, st[0], st[1])
+    d3 = new()
+    M.solve(prog, *st, *d3)
+    assert all(np.array_equal(a, b) for a, b in zip(d1, d3))
