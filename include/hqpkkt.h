@@ -298,8 +298,9 @@ int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu);
  * hqpkkt_set_values_staged replaces hqpkkt_set_values: F[k] points to the row-major
  * nx[k+1] x (nx[k] + nu[k]) block [fx_k fu_k] with leading dimension ldF[k] (the -1.0 of the
  * staircase is implied); pointers per opts.loc (the array F itself is a host array).  The
- * blocks are copied: the caller may release them afterwards.  hqpkkt_mehrotra / _franke do not
- * take this form (HQPKKT_E_INTERN). */
+ * blocks are copied: the caller may release them afterwards.  hqpkkt_mehrotra / _franke run on this
+ * form too (their products with the dynamics rows go through the dense blocks; b / y in the same row
+ * order as r2 / dy). */
 int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int n_total, int me_rest, int m, const int *Qp,
                           const int *Qi, const int *Ep, const int *Ei, const int *Cp, const int *Ci);
 int hqpkkt_set_values_staged(hqpkkt_t *h, const double *Qx, const double *const *F, const long long *ldF,

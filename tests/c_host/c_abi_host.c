@@ -88,5 +88,62 @@ int main(void) {
   printf("C_ABI ok sbw %d dim %d res %.3e res2 %.3e ip_result %d ip_iters %d mu %.3e zmin %.3e cmin %.3e\n", sbw,
          s.dim, res, res2, ir.result, ir.iters, ir.mu, zmin, cmin);
   hqpkkt_destroy(h);
+
+  /* ---- the multistage plugin's dense hand-over (Hqp_IpLQDOCP semantics, HQPKKT_MODE_STAGED): K stages of nx states
+   * and nu controls, the dynamics as K row-major blocks [fx fu], x_0 fixed by nx one-entry equality rows, -1 <= u <= 1 */
+  {
+    enum { K = 6, NX = 40, NU = 3, NZ = NX + NU };
+    const int nt = K * NZ + NX, me_rest = NX, mm = 2 * K * NU, met = K * NX + me_rest;
+    int nxs[K + 1], nus[K];
+    for (int k = 0; k <= K; k++) nxs[k] = NX;
+    for (int k = 0; k < K; k++) nus[k] = NU;
+    int *qp = malloc(sizeof(int) * (nt + 1)), *qi = malloc(sizeof(int) * nt);
+    double *qx = malloc(sizeof(double) * nt);
+    for (int i = 0; i < nt; i++) qp[i] = i, qi[i] = i, qx[i] = (i < K * NZ && i % NZ >= NX) ? 0.1 : 1.0;
+    qp[nt] = nt;
+    int ep[NX + 1], ei[NX];
+    double ex[NX];
+    for (int i = 0; i < NX; i++) ep[i] = i, ei[i] = i, ex[i] = 1.0;
+    ep[NX] = NX;
+    int *cp = malloc(sizeof(int) * (mm + 1)), *ci = malloc(sizeof(int) * mm);
+    double *cx = malloc(sizeof(double) * mm);
+    for (int r = 0; r < mm; r++) {
+      const int u = r % (K * NU);
+      cp[r] = r, ci[r] = (u / NU) * NZ + NX + u % NU, cx[r] = r < K * NU ? 1.0 : -1.0;
+    }
+    cp[mm] = mm;
+    double *Fb = malloc(sizeof(double) * K * NX * NZ);
+    const double *Fp[K];
+    long long ldF[K];
+    for (int k = 0; k < K; k++) {
+      Fp[k] = Fb + (size_t)k * NX * NZ, ldF[k] = NZ;
+      for (int i = 0; i < NX * NZ; i++) Fb[(size_t)k * NX * NZ + i] = (urand(&seed) - 0.5) * ((i % NZ) < NX ? 0.25 : 1.0);
+    }
+    hqpkkt_t *hs = NULL;
+    hqpkkt_default_opts(&o);
+    o.mode = HQPKKT_MODE_STAGED;
+    if ((st = hqpkkt_create(&o, &hs)) ||
+        (st = hqpkkt_analyze_staged(hs, K, nxs, nus, nt, me_rest, mm, qp, qi, ep, ei, cp, ci)) ||
+        (st = hqpkkt_set_values_staged(hs, qx, Fp, ldF, ex, cx))) {
+      printf("C_ABI status %d in the staged hand-over: %s\n", st, hqpkkt_strerror(st));
+      return 2;
+    }
+    double *zs = malloc(sizeof(double) * mm), *ws = malloc(sizeof(double) * mm), *s3 = malloc(sizeof(double) * mm),
+           *s4 = malloc(sizeof(double) * mm), *s1 = malloc(sizeof(double) * nt), *s2 = malloc(sizeof(double) * met);
+    double *ex1 = calloc(nt, sizeof(double)), *ey = calloc(met, sizeof(double)), *ez = calloc(mm, sizeof(double)),
+           *ew = calloc(mm, sizeof(double));
+    for (int i = 0; i < mm; i++) zs[i] = 0.1 + urand(&seed), ws[i] = 0.1 + urand(&seed), s3[i] = urand(&seed) - 0.5, s4[i] = urand(&seed) - 0.5;
+    for (int i = 0; i < nt; i++) s1[i] = urand(&seed) - 0.5;
+    for (int i = 0; i < met; i++) s2[i] = urand(&seed) - 0.5;
+    double sres = -1.0, sres2 = -1.0;
+    if ((st = hqpkkt_factor(hs, zs, ws)) || (st = hqpkkt_solve(hs, zs, ws, s1, s2, s3, s4, ex1, ey, ez, ew, &sres)) ||
+        (st = hqpkkt_residual(hs, zs, ws, s1, s2, s3, s4, ex1, ey, ez, ew, &sres2))) {
+      printf("C_ABI status %d in the staged factor/solve: %s\n", st, hqpkkt_strerror(st));
+      return 2;
+    }
+    hqpkkt_get_stats(hs, &s);
+    printf("C_ABI staged ok stages %d dim %d res %.3e res2 %.3e\n", s.n_levels - 1, s.dim, sres, sres2);
+    hqpkkt_destroy(hs);
+  }
   return 0;
 }

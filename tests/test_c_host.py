@@ -43,3 +43,8 @@ def test_c_host_runs_on_the_gpu(tmp_path):
     assert float(f["res"]) <= 1e-10 and abs(float(f["res"]) - float(f["res2"])) <= 1e-12
     assert int(f["ip_result"]) == 0 and 1 <= int(f["ip_iters"]) <= 40
     assert float(f["mu"]) <= 1e-9 and float(f["zmin"]) > 0 and float(f["cmin"]) > -1e-8
+    # the multistage plugin's dense hand-over (hqpkkt_analyze_staged / hqpkkt_set_values_staged) from plain C
+    line = [l for l in out.stdout.splitlines() if l.startswith("C_ABI staged ok")][-1]
+    g = dict(re.findall(r"(\w+) (-?[\d.e+-]+)", line))
+    assert int(g["stages"]) == 6 and int(g["dim"]) == 6 * 43 + 40 + 6 * 40 + 40
+    assert float(g["res"]) <= 1e-10 and abs(float(g["res"]) - float(g["res2"])) <= 1e-12
