@@ -9,10 +9,13 @@ from hqp_amd import problems
 GOLDEN_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
 GOLDEN = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(GOLDEN_DIR, "*.npz")))
 KINDS = ("SpBKP", "RedSpBKP")
+# multistage QPs with the results of the reference's own Hqp_IpLQDOCP (tests/golden_lqdocp/make_golden.py)
+GOLDEN_LQDOCP_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_lqdocp")
+GOLDEN_LQDOCP = sorted(os.path.splitext(os.path.basename(f))[0] for f in glob.glob(os.path.join(GOLDEN_LQDOCP_DIR, "*.npz")))
 
 
-def load_golden(name):
-    g = dict(np.load(os.path.join(GOLDEN_DIR, name + ".npz")))
+def load_golden(name, directory=None):
+    g = dict(np.load(os.path.join(directory or GOLDEN_DIR, name + ".npz")))
     n, me, m = int(g["n"]), int(g["me"]), int(g["m"])
     prog = problems.Program(n, me, m, (g["Qp"], g["Qi"], g["Qx"]), (g["Ap"], g["Ai"], g["Ax"]),
                             (g["Cp"], g["Ci"], g["Cx"]))

@@ -297,3 +297,24 @@ def test_full_size_c4_properties():
     d3 = new()
     M.solve(dq, z, w, *r, *d3)
     assert all(bool(torch.equal(a, b)) for a, b in zip(d1, d3))
+
+
+@pytest.mark.parametrize("name", __import__("common").GOLDEN_LQDOCP)
+def test_against_the_reference_lqdocp_golden(name):
+    """Committed fixtures: what the reference's own Hqp_IpLQDOCP returned on seven multistage QPs (plain, final-state
+    and path equalities with state bounds, free initial state, the Prg_DID structure, stages wider than an MFMA tile,
+    the stiff sweep case 672) - the STAGED engine through the C ABI: residual of solve() <= the reference's + 1e-10,
+    solution to 1e-8, residuum() of the reference's own step result to 1e-12 (relative to the solution)."""
+    from common import GOLDEN_LQDOCP_DIR, load_golden
+    prog, st, g = load_golden(name, GOLDEN_LQDOCP_DIR)
+    M = ipmatrix.IpLQDOCP()
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    gold = [g[f"LQDOCP_solve_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    scale = max(1.0, max(np.abs(v).max() for v in gold if len(v)))
+    assert res <= float(g["LQDOCP_res"]) + 1e-10 * scale, (res, float(g["LQDOCP_res"]))
+    assert rel_err(d, gold) <= 1e-8, rel_err(d, gold)
+    gstep = [g[f"LQDOCP_step_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    assert abs(M.residuum(prog, *st, *gstep) - float(g["LQDOCP_res_of_step"])) <= 1e-12 * scale + 1e-13

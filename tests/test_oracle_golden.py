@@ -50,3 +50,19 @@ def test_oracle_update_changes_values():
     O.factor(st[0], st[1])
     b, res = O.solve(*st)
     assert res < 1e-10 and rel_err(a, b) > 1e-3
+
+
+@pytest.mark.parametrize("name", __import__("common").GOLDEN_LQDOCP)
+def test_oracle_solves_the_lqdocp_fixtures_like_the_reference(name):
+    """The multistage fixtures (results of the reference's Hqp_IpLQDOCP): the CPU oracle of the reduced system
+    reaches the same solution - two different eliminations of the same KKT system."""
+    from common import GOLDEN_LQDOCP_DIR, load_golden, rel_err
+    prog, st, g = load_golden(name, GOLDEN_LQDOCP_DIR)
+    O = oracleapi.OracleIpMatrix("RedSpBKP")
+    O.init(prog)
+    O.factor(st[0], st[1])
+    sol, res = O.solve(*st)
+    gold = [g[f"LQDOCP_solve_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    scale = max(1.0, max(np.abs(v).max() for v in gold if len(v)))
+    assert res <= 1e-10 * scale
+    assert rel_err(sol, gold) <= 1e-7, rel_err(sol, gold)
