@@ -819,6 +819,9 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
     h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
     h->soft_singular = hs[4] != 0;
     h->soft_tiny = hs[5] != 0;
+    if (getenv("HQPKKT_TRACE_SOLVE") && (flags[0] || hs[4] || hs[5]))
+      fprintf(stderr, "factor (checked with the solve): status %d, perturbed %d, zero pivot perturbed %d, tiny multiplier pivot %d\n", flags[0],
+              flags[2], hs[4], hs[5]);
     if (flags[0] || std::isinf(h->st.kmax)) {
       h->factored = false;
       return flags[0] ? flags[0] : HQPKKT_E_SING;
@@ -1104,6 +1107,9 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   h->st.n_2x2 = flags[1], h->st.n_perturbed = flags[2], h->st.n_slow_pivots = flags[3];
   h->soft_singular = hs[4] != 0;
   h->soft_tiny = hs[5] != 0;
+  if (getenv("HQPKKT_TRACE_SOLVE") && (flags[0] || hs[4] || hs[5]))
+    fprintf(stderr, "factor: status %d, 2x2 %d, perturbed %d, zero pivot perturbed %d, tiny multiplier pivot %d, kmax %.3e\n", flags[0],
+            flags[1], flags[2], hs[4], hs[5], h->st.kmax);
   if (flags[0]) return flags[0];
   if (!(h->st.kmax == h->st.kmax) || std::isinf(h->st.kmax)) return HQPKKT_E_SING;
   h->factored = true;
@@ -1181,6 +1187,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   const double target = h->refine_target > 0.0 ? std::fmin(h->opts.eps, h->refine_target) : h->opts.eps;
   const bool refined = res > target;  // otherwise the caller's copy is already complete
   const double res_first = res;
+  double res_acc = res;  // residual of the solution as it stands (res is the last TRIAL's when that one was rejected, as in the reference)
   // correction solve: rhs = residual vectors, result = vcor
   Vecs c = v;
   c.r1 = h->vres.p, c.r2 = c.r1 + n, c.r3 = c.r2 + me, c.r4 = c.r3 + m;
@@ -1203,6 +1210,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
       }
     } while (res > res_last && alpha > 0.0);
     if (alpha <= 0.0) break;
+    res_acc = res;
   }
   if (!(res <= h->opts.eps) && h->zd_weak && h->zd_used == 2 && h->an.shard_count <= 1) {
     // the refinement did not reach mat_eps: weak Hessian diagonals and every multiplier behind
@@ -1229,9 +1237,17 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if (res != res) return HQPKKT_E_SING;
   // an exactly zero pivot outside a root front was perturbed: singular if the refinement failed
   if (h->soft_singular && !(res <= h->opts.eps)) return HQPKKT_E_SING;
-  // a multiplier-type pivot below 1e-13 max|K| and a solve that ends nowhere near a solution: the
-  // rank-deficient equality block the reference reports as E_SING (hqp/spBKP.C:699-700)
-  if (h->soft_tiny && !(res <= 1e-4)) return HQPKKT_E_SING;
+  // a multiplier-type pivot below 1e-13 max|K| and a solve that ends no nearer to a solution than the zero
+  // vector is: the rank-deficient equality block the reference reports as E_SING (hqp/spBKP.C:699-700).
+  // (Not: a late interior-point system whose refinement stalls at 1e-4 - the reference goes on there.)
+  if (h->soft_tiny && !(res_acc <= 1e-4)) {
+    double rnorm = 0.0;
+    Vecs vz = v;
+    vz.dx = h->vcor.p, vz.dy = vz.dx + n, vz.dz = vz.dy + me, vz.dw = vz.dz + m;
+    HIPCHK(hipMemsetAsync(h->vcor.p, 0, sizeof(double) * (size_t)ntot, s));
+    if ((e = run_residual(h, vz, &rnorm))) return e;
+    if (!(res_acc < rnorm)) return HQPKKT_E_SING;
+  }
   return 0;
 }
 

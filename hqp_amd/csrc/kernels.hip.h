@@ -153,13 +153,14 @@ struct TermDev {
 // A rank-deficient equality block does not always end in an EXACT zero here (the reference's search over
 // the whole remaining column finds one, hqp/spBKP.C:699-700: E_SING): with the search restricted to the
 // pivot block the second of two identical rows can be left with a pivot of 1e-17.  A pivot of a variable
-// without a diagonal of its own (equality multiplier, x without Q_ii) that is below 1e-13 max|K| marks the
+// without a diagonal of its own (equality multiplier, x without Q_ii) that is below SOFT_PIVOT_REL times the scale of its row (below) marks the
 // factorisation (counters[4]) without changing it: hqpkkt_solve reports E_SING if its refinement then ends
 // with a residual above 1e-4 (a solution that is garbage, not one that is a few digits short of mat_eps as
 // in the last iterations of an interior-point run), and nothing changes for the systems that still solve.
-__device__ __forceinline__ double soft_pivot_limit(const unsigned long long *kmax_bits) {
-  return 1e-13 * __longlong_as_double((long long)*kmax_bits);
-}
+// ... relative to the largest entry of the pivot's row in the block as it was assembled: a pivot that
+// cancelled (-c + c for the second of two identical equality rows) is 1e-16 of it, the multiplier pivots
+// of a late interior-point iteration are of its order whatever max|K| = z/w has grown to
+#define SOFT_PIVOT_REL 1e-13
 __device__ __forceinline__ int zero_pivot_slot(int sg1, int sg2, int b) {
   return (b == 0 || sg1 == 2 || sg1 == -2 || sg2 == 2 || sg2 == -2) ? -1 : 3;
 }
@@ -575,7 +576,7 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   // 128-entry vectors (the patch is zero padded beyond p, so they are written and
   // read without bounds predicates)
   double *cbuf0 = a + max(ld * p, 2 * FD_PLD * FD_PANEL);  // behind the staging image / panel
-  double *cbuf1 = cbuf0 + 128;      // (spare)
+  double *cbuf1 = cbuf0 + 128;      // row maxima of the block as assembled (rm0 below)
   double *cbr = cbuf1 + 128;        // column r (second column of a 2x2)
   double *xb0 = cbr + 128, *xb1 = xb0 + 128;  // row / column exchange
   double *dv = xb1 + 128;           // 2p: inverse pivot data per position
@@ -585,7 +586,6 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int tx = tid & 31, ty = tid >> 5;
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
-  const double softlim = soft_pivot_limit(kmax_bits);
 
   STAMP(0);
   stage_lower8(P, F, p, ld, a, wave, lane, T, upd, node);
@@ -600,6 +600,19 @@ k_factor_diag(DevTree T, const int *__restrict__ level_nodes, double *__restrict
       A[m][n] = (i < p && j < p) ? (i >= j ? a[i + j * ld] : a[j + i * ld]) : 0.0;
     }
   patch_put_col(A, 0, tx, ty, p, cbuf0);
+  // largest entry of every row of the block as assembled (children included): what a pivot of a row without a
+  // diagonal of its own is measured against (SOFT_PIVOT_REL).  Non-negative doubles order like their bit patterns.
+  double *rm0 = cbuf1;
+#pragma unroll
+  for (int m = 0; m < 8; m++) {  // a row's 128 columns sit in the 32 lanes of one half of a wavefront: DPP max over them
+    double v = fmax(fmax(fabs(A[m][0]), fabs(A[m][1])), fmax(fabs(A[m][2]), fabs(A[m][3])));
+    v = fmax(v, dpp_move<0xb1, 0xf>(v));   // quad_perm [1,0,3,2]
+    v = fmax(v, dpp_move<0x4e, 0xf>(v));   // quad_perm [2,3,0,1]
+    v = fmax(v, dpp_move<0x124, 0xf>(v));  // row_ror 4
+    v = fmax(v, dpp_move<0x128, 0xf>(v));  // row_ror 8: every lane of a row of 16 holds the row's maximum
+    v = fmax(v, dpp_move<0x142, 0xa>(v));  // row_bcast 15 into rows 1 and 3: maximum of the half
+    if (tx == 16) rm0[ty + 16 * m] = v;
+  }
   __syncthreads();
 
   // LDS panel of the fast path (aliases the staging image, which is idle in the loop):
@@ -742,9 +755,9 @@ int dn;
       for (int n = 0; n < 4; n++) cj[n] = cur[tx + 32 * n];
       double d = cur[k];
       bool pertd = false;
-      if (fabs(d) < softlim) {
+      if (fabs(d) < SOFT_PIVOT_REL * rm0[lp[k]]) {
         const int sgs = esign[e0 + lp[k]];
-        if (sgs == 2 || sgs == -2) counters[4] = 1;  // see soft_pivot_limit
+        if (sgs == 2 || sgs == -2) counters[4] = 1;  // see SOFT_PIVOT_REL
       }
       if (!(fabs(d) >= pert)) {
         const int sg = esign[e0 + lp[k]];
@@ -1006,7 +1019,6 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   const bool row_on = i < p;
   FSTAMP(0);
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
-  const double softlim = soft_pivot_limit(kmax_bits);
   // The columns in groups of 16 (most fronts have one), eight loads per lane and group in
   // flight.  Every unrolled slot sits behind a uniform test of p or b: a front of four
   // pivots executes a quarter of the instructions of one with sixteen (one wavefront per
@@ -1132,6 +1144,12 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
     }
   }
   __syncthreads();
+  // largest entry of every row of the block as assembled (children included): the scale a pivot of a row without
+  // a diagonal of its own is measured against (SOFT_PIVOT_REL)
+  double rowmax0 = 0.0;
+  if (row_on)
+    for (int j = h; j < p; j += 2) rowmax0 = fmax(rowmax0, fabs(a[i + j * ldp]));
+  rowmax0 = fmax(rowmax0, __shfl_xor(rowmax0, 32));
   FSTAMP(2);
   int k = 0, n2x2 = 0, npert = 0;  // statistics: one atomic per front, not one per pivot (thousands of
                                    // fronts of a level would queue up on the same address)
@@ -1181,9 +1199,9 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
     if (kind != 2) {
       double d = rdlane(ck, k);
       bool pertd = false;
-      if (fabs(d) < softlim) {
+      if (fabs(d) < SOFT_PIVOT_REL * rdlane(rowmax0, lp[k])) {
         const int sgs = esign[e0 + lp[k]];
-        if (sgs == 2 || sgs == -2) counters[4] = 1;  // see soft_pivot_limit
+        if (sgs == 2 || sgs == -2) counters[4] = 1;  // see SOFT_PIVOT_REL
       }
       if (!(fabs(d) >= pert)) {
         const int sg = esign[e0 + lp[k]];
