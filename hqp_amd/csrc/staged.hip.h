@@ -582,8 +582,89 @@ __device__ int gj_inverse_reg(double *a, int q, int ld, int *ip, int *pc_of_row,
   (void)ip;
   return bad;
 }
+// The same for a matrix that is positive definite after its scaling (K = G_uu of a stage without consumed
+// constraint rows): pivots in the natural order down the diagonal - no search, two barriers per step instead of
+// four.  Elimination without pivoting is backward stable on such a matrix.  Returns 2 without having touched `a`
+// when a pivot is not safely positive (G_uu indefinite or nearly singular): the caller then runs the search.
+template <int NB>
+__device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double *rowv) {
+  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  double m[NB][2 * NB];
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int r = ty + 16 * i;
+#pragma unroll
+    for (int j = 0; j < NB; j++) {
+      const int c = tx + 16 * j;
+      m[i][j] = (r < q && c < q) ? a[r * ld + c] : 0.0;
+      m[i][NB + j] = (r == c && r < q) ? 1.0 : 0.0;
+    }
+  }
+  __syncthreads();
+  int bad = 0;
+  for (int s = 0; s < q; s++) {
+    if ((s & 15) == ty) {
+      const int i = s >> 4;
+#pragma unroll
+      for (int ii = 0; ii < NB; ii++)
+        if (ii == i) {
+#pragma unroll
+          for (int j = 0; j < 2 * NB; j++) rowv[tx + 16 * j] = m[ii][j];
+        }
+    }
+    if ((s & 15) == tx) {
+      const int j = s >> 4;
+#pragma unroll
+      for (int jj = 0; jj < NB; jj++)
+        if (jj == j) {
+#pragma unroll
+          for (int i = 0; i < NB; i++) colv[ty + 16 * i] = m[i][jj];
+        }
+    }
+    __syncthreads();
+    const double piv = rowv[(s & 15) + 16 * (s >> 4)];
+    if (!(piv > 1e-10)) bad = 2;  // uniform: every thread reads the same value (the matrix is scaled: diagonal <= 1)
+    const double pinv = bad ? 1.0 : 1.0 / piv;
+    double rv[2 * NB];
+#pragma unroll
+    for (int j = 0; j < 2 * NB; j++) rv[j] = rowv[tx + 16 * j] * pinv;
+#pragma unroll
+    for (int i = 0; i < NB; i++) {
+      const int r = ty + 16 * i;
+      const double f = colv[r];
+      if (r == s) {
+#pragma unroll
+        for (int j = 0; j < 2 * NB; j++) m[i][j] = rv[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 2 * NB; j++) m[i][j] -= f * rv[j];
+      }
+    }
+    __syncthreads();  // rowv / colv are rewritten in the next step
+  }
+  if (bad) return bad;  // (uniform) `a` still holds the matrix
+#pragma unroll
+  for (int i = 0; i < NB; i++) {
+    const int r = ty + 16 * i;
+    if (r < q) {
+#pragma unroll
+      for (int j = 0; j < NB; j++) {
+        const int c = tx + 16 * j;
+        if (c < q) a[r * ld + c] = m[i][NB + j];
+      }
+    }
+  }
+  __syncthreads();
+  return 0;
+}
 // dispatch: registers up to order 64, LDS above
-__device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red) {
+__device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red,
+                              bool spd = false) {
+  if (spd && q <= 64) {
+    const int e = q <= 16 ? gj_inverse_reg_spd<1>(a, q, ld, colv, rowv)
+                : q <= 32 ? gj_inverse_reg_spd<2>(a, q, ld, colv, rowv) : gj_inverse_reg_spd<4>(a, q, ld, colv, rowv);
+    if (e == 0) return 0;
+  }
   if (q <= 16) return gj_inverse_reg<1>(a, q, ld, ip, ir, colv, rowv, red);
   if (q <= 32) return gj_inverse_reg<2>(a, q, ld, ip, ir, colv, rowv, red);
   if (q <= 64) return gj_inverse_reg<4>(a, q, ld, ip, ir, colv, rowv, red);
@@ -738,7 +819,7 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
       Km[i * ld + j] *= dsc[i] * dsc[j];
     }
     __syncthreads();
-    const int bad = gj_inverse_any(Km, q, ld, ip, ir, ic, colv, rowv, red);
+    const int bad = gj_inverse_any(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
     if (bad && tid == 0) atomicExch(a.status, 4);
     __syncthreads();
     for (int e = tid; e < a.qmax * a.qmax; e += nt) {
