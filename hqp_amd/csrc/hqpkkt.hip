@@ -1057,6 +1057,7 @@ int hqpkkt_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const dou
 // on every multiplier right behind a matched neighbour (policy 0).  Symbolic phase, upload and
 // values again (hqpkkt_mehrotra's vectors stay); the caller factorises and solves once more.
 static int switch_to_policy0(hqpkkt_t *h) {
+  if (getenv("HQPKKT_TRACE_SOLVE")) fprintf(stderr, "solve: refinement failed with weak Hessian diagonals: zero-diagonal placement 2 -> 0, factorising again\n");
   HIPCHK(hipSetDevice(h->opts.device));
   HIPCHK(hipStreamSynchronize(h->stream));
   const bool lazy = h->lazy, hot = h->ip_hot_valid;
@@ -1212,7 +1213,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
     if (alpha <= 0.0) break;
     res_acc = res;
   }
-  if (!(res <= h->opts.eps) && h->zd_weak && h->zd_used == 2 && h->an.shard_count <= 1) {
+  if (!(res <= h->opts.eps) && h->zd_weak && h->zd_used == 2) {  // (sharded: every rank sees the same residual and switches)
     // the refinement did not reach mat_eps: weak Hessian diagonals and every multiplier behind
     // ALL its neighbours is the placement that loses accuracy when z/w spreads (hqpkkt_opts.
     // zd_policy); switch the handle to the matching rule and do this factor + solve again

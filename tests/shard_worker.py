@@ -64,9 +64,11 @@ def main():
             prog = problems.lq_docp(case[1], case[2], case[3])
         elif case[0] == "grid":  # mesh QP through the tree of the graph's own dissection (opts.ordering)
             prog = problems.grid_sparse_qp(case[1], case[2])
+        elif case[0] == "did_spread":  # w/z over 12 decades on weak Hessian diagonals: the refinement fails and the
+            prog = problems.did_like_qp(case[1])  # handle switches its zero-diagonal placement (every rank must)
         else:
             prog = problems.did_like_qp(case[1])
-        st = problems.ip_state(prog, 7, 1.0)
+        st = problems.ip_state(prog, case[2], case[3]) if case[0] == "did_spread" else problems.ip_state(prog, 7, 1.0)
         cls = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP, "LQDOCP": ipmatrix.IpLQDOCP}[kind]
         kw = dict(ordering=case[3]) if case[0] == "grid" else {}
         if os.environ.get("SHARD_TRANSPORT") == "rccl":  # libhqpkkt_rccl.so: stream-ordered collectives

@@ -41,6 +41,25 @@ def test_sharded_system_matches_single(world, port):
         assert r0["xblocks"] >= world - 1
 
 
+def test_sharded_system_switches_the_zero_diagonal_placement_on_every_rank():
+    """zd_policy -1 on weak Hessian diagonals (Prg_DID, qx = 1e-4) with w/z over 12 decades: the refinement of the first
+    solve fails and the handle re-analyses with the other placement (hqpkkt_opts.zd_policy) - sharded too: every rank
+    sees the same residual, switches and factorises again; same solution as the unsharded handle."""
+    cases = [["did_spread", 200, 1, 6.0, "RedSpBKP"]]
+    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_CASES=json.dumps(cases), MASTER_ADDR="127.0.0.1", HQPKKT_TRACE_SOLVE="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29567", os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    assert out.stderr.count("zero-diagonal placement 2 -> 0") >= 3  # both ranks and the unsharded partner
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
+    per_rank = json.loads(line[len("SHARD_RESULT "):])
+    r0 = per_rank[0][0]
+    assert r0["diff"] < 1e-7, r0
+    for r in per_rank:
+        assert r[0]["same_as_rank0"] and r[0]["res"] <= 10 * r0["res_single"] + 1e-10, r[0]
+
+
 STAGED_CASES = [["docp", 5, 300, 6, "LQDOCP"], ["docp", 3, 520, 20, "LQDOCP"]]
 
 
