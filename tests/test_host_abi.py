@@ -120,3 +120,37 @@ def test_large_structure_counts():
     st = M.stats()
     assert st["sbw"] == 50 and st["dim"] == 10000
     assert st["n_levels"] <= 12 and st["max_front"] <= 96 + 3 * 50
+
+
+@pytest.mark.parametrize("case", ["grid", "grid_far", "random", "banded"])
+@pytest.mark.parametrize("kind", KINDS)
+@pytest.mark.parametrize("ordering", [1, 2])
+def test_graph_dissection_tree_is_valid_and_factorisable(case, kind, ordering):
+    """hqpkkt_opts.ordering 1 / 2 (nested dissection of the KKT graph itself, hqp_amd/csrc/analysis.cpp) on the host:
+    the exported tree is a postorder, nothing couples outside the symbolic fronts and the numpy model of the kernels'
+    algorithm solves the scaled system on it; ordering 1 still reports the reference's mat_sbw (RCM)."""
+    prog = {"grid": lambda: problems.grid_sparse_qp(14, 11, seed=2),
+            "grid_far": lambda: problems.grid_sparse_qp(12, 12, seed=3, long_range=25),
+            "random": lambda: problems.random_sparse_qp(150, 40, 90, row_nnz=3, seed=4),
+            "banded": lambda: problems.banded_qp(200, 6, 5)}[case]()
+    st = problems.ip_state(prog, 5, 1.0)
+    M = analyzed(CLS[kind], prog, ordering=ordering, leaf_size=16)
+    s = M.structure()
+    dim = M.stats()["dim"]
+    e = s["elim"]
+    assert sorted(e) == list(range(dim)) and int(s["npiv"].sum()) == dim
+    par = s["parent"]
+    assert all(par[k] > k or par[k] < 0 for k in range(len(par)))
+    if ordering == 1:
+        assert M.mat_sbw == analyzed(CLS[kind], prog).mat_sbw
+    mode = 0 if kind == "SpBKP" else 1
+    K, _sc = model.scaled_kkt(prog, st[0], st[1], mode)
+    mdl = model.Model(s)
+    mdl.factor(K, prog.n)
+    assert mdl.struct_violation == 0.0
+    rhs = np.random.default_rng(1).uniform(-1, 1, dim)
+    rhs_e = np.zeros(dim)
+    rhs_e[e] = rhs
+    x = mdl.solve(rhs_e)[e]
+    tol = 1e-3 if mdl.npert else 1e-7
+    assert np.abs(K @ x - rhs).max() <= tol * max(1.0, np.abs(K).max() * np.abs(x).max())
