@@ -402,7 +402,7 @@ def bench_c4(args):
     one = world > 1 and not args.replicas
     dq = c4_dense(K, nx, nu, seed=0 if one else rank)
     n, me, m = dq.dims
-    shard, transport = None, None
+    shard, transport, comm_ranks = None, None, None
     if one:
         # every rank must hold the SAME system: the device generators should agree (same seed, same kind of
         # GPU); if a checksum says otherwise, rank 0's blocks are broadcast
@@ -424,11 +424,14 @@ def bench_c4(args):
         if args.backend == "nccl" and args.transport == "rccl":
             try:  # libhqpkkt_rccl.so: ncclAllGather in the handle's stream
                 shard, transport = kdist.RcclShard(rank, world, local_rank), "libhqpkkt_rccl (RCCL, stream-ordered)"
+                comm_ranks = shard.comm_ranks  # ncclCommCount of the communicator the collectives run on
             except Exception as e:  # fall back to torch.distributed's collectives behind the callback
                 print(f"bench: RcclShard failed ({e}); using the torch.distributed callback", file=sys.stderr)
         if shard is None:
             shard = (rank, world, kdist.make_exchange(rank, local_rank))
             transport = f"torch.distributed ({args.backend}) behind the exchange callback"
+            import torch.distributed as tdist
+            comm_ranks = tdist.get_world_size()
     mat = ipmatrix.IpLQDOCP(device=local_rank, device_vectors=True, shard=shard)
     t0 = time.perf_counter()
     mat.init_dense(dq)
@@ -455,6 +458,11 @@ def bench_c4(args):
     kdist.fence()
     elapsed = kdist.max_over_ranks(time.perf_counter() - t0)
     st = mat.stats()
+    all_devices = None
+    if one:  # which GPU every rank computed on (the bench line shows that N ranks meant N GPUs)
+        import torch.distributed as tdist
+        all_devices = [None] * world
+        tdist.all_gather_object(all_devices, f"{os.uname().nodename}:cuda:{torch.cuda.current_device()}")
     # the same step as a host with its vectors in (pinned) host memory sees it - SURVEY.md 8(d): z, w, r1..r4 go
     # to the device and dx..dw come back per call; extra information, never `value`
     host_rate = None
@@ -533,7 +541,9 @@ def bench_c4(args):
         "data": "synthetic",
         "vectors": "resident in HBM",
         "value_with_host_vectors": host_rate,  # PCIe per call (33 MB each way in all): what the shim's host sees
-        "shard": {"ranks": world, "transport": transport, "bytes_allgather_per_factor": st["bytes_exchange_factor"],
+        "shard": {"ranks": world, "transport": transport, "comm_ranks": comm_ranks,
+                  "devices": sorted(set(all_devices)) if all_devices else None,
+                  "bytes_allgather_per_factor": st["bytes_exchange_factor"],
                   "flops_rank0": st["flops_local"], "allgathers_per_factor": st["n_exchange_blocks"]} if one else None,
         "config": {"workload": f"C4 = BASELINE configs[3], the metric's 10^6-variable DOCP: multistage LQ optimal control QP, K={K} stages, "
                                f"nx={nx} states, nu={nu} controls -> n={n} me={me} m={m}, dense fx/fu handed over as blocks, x_0 fixed, "
@@ -597,7 +607,7 @@ def parse_args():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", default="c4", choices=["c4", "c2"],
+    ap.add_argument("--workload", default="c4", choices=["c4", "c2", "launchcheck"],
                     help="c4: 10^6-variable multistage DOCP, STAGED engine (the metric's own configuration); "
                          "c2: banded KKT system of dim 10^5, full-system engine")
     ap.add_argument("--stages", type=int, default=200, help="c4: K")
@@ -616,19 +626,36 @@ def parse_args():
                     help="c4, N>1, one system: libhqpkkt_rccl.so (collectives in the handle's stream) or the "
                          "torch.distributed callback")
     ap.add_argument("--one-system", action="store_true",
-                    help="N>1: all ranks factor and solve ONE system together (subtrees of the assembly tree per "
-                         "rank, one all-gather per factor, all-gather + all-reduce per solve over RCCL; strong "
-                         "scaling) instead of one independent system per GPU")
+                    help="c2, N>1: all ranks factor and solve ONE banded system together (tree engine: subtrees of the "
+                         "assembly tree per rank, one all-gather per factor, all-gather + all-reduce per solve; strong "
+                         "scaling) instead of one independent system per GPU.  (c4 shards ONE system by default: "
+                         "the STAGED engine's column split with one gather of V_k per stage; --replicas for one each)")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: functional check of the N>1 paths on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0")
     ap.add_argument("--leaf-size", type=int, default=0)
     ap.add_argument("--max-pivots", type=int, default=0)
     args = ap.parse_args()
-    if args.gpus > 1 and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} needs one process per GPU: launch with python -m torch.distributed.run "
-                         f"--nnodes=1 --nproc-per-node {args.gpus} --master-addr 127.0.0.1 bench.py --gpus {args.gpus} ...")
+    if args.gpus > 1 and "RANK" in os.environ and int(os.environ.get("WORLD_SIZE", "1")) != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but this process was started as one of WORLD_SIZE={os.environ.get('WORLD_SIZE')} ranks")
     return args
+
+
+def launch_ranks(gpus):
+    """`python bench.py --gpus N` outside a launcher: start N FRESH rank processes (one per GPU) with
+    torch.distributed.run and hand their output through.  This parent has imported neither torch nor anything
+    that touches HIP, and it does not replace itself: the ranks are children, their exit status is ours."""
+    import socket
+    import subprocess
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env, cwd=ROOT)
 
 
 def bench_c2(args, extras=True):
@@ -778,7 +805,19 @@ def bench_c2(args, extras=True):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "RANK" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     from hqp_amd import dist as kdist
+    if args.workload == "launchcheck":
+        # the N > 1 plumbing alone, no GPU needed (tests/test_dist_gloo.py): rendezvous over gloo, the fence and
+        # the max-over-ranks of the timing contract; rank 0 prints what it saw
+        rank, _lr, world = kdist.init(backend="gloo")
+        kdist.fence(device_sync=False)
+        t = kdist.max_over_ranks(float(rank))
+        if rank == 0:
+            print(json.dumps({"launchcheck": True, "world": world, "max_rank": t, "gpus": args.gpus}))
+        kdist.finalize()
+        return
     out = bench_c4(args) if args.workload == "c4" else bench_c2(args)
     if out is not None:
         print(json.dumps(out))

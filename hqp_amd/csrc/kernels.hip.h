@@ -2406,7 +2406,9 @@ __global__ void k_zero_ranges(double *__restrict__ base, const long long *__rest
 }
 // sharded mode: the status words of a factorisation as doubles for one all-reduce (sum): [0] ranks
 // with E_SING (or an infinite / NaN max|K|), [1] ranks with another error, [2] ranks that perturbed an
-// exactly zero pivot (soft singular), [3] unused; and back: every rank ends with the same words
+// exactly zero pivot (soft singular), [3] ranks that met a tiny multiplier-type pivot (SOFT_PIVOT_REL, flags[5]:
+// seen by the owner of the subtree only, and hqpkkt_solve turns it into E_SING when the refinement fails - on
+// every rank or on none); and back: every rank ends with the same words
 __global__ void k_status_pack(const int *__restrict__ flags, const unsigned long long *__restrict__ bits,
                               double *__restrict__ out) {
   if (threadIdx.x != 0) return;
@@ -2415,7 +2417,7 @@ __global__ void k_status_pack(const int *__restrict__ flags, const unsigned long
   out[0] = (flags[0] == 4 || badk) ? 1.0 : 0.0;
   out[1] = (flags[0] != 0 && flags[0] != 4) ? 1.0 : 0.0;
   out[2] = flags[4] != 0 ? 1.0 : 0.0;
-  out[3] = 0.0;
+  out[3] = flags[5] != 0 ? 1.0 : 0.0;
 }
 __global__ void k_status_unpack(const double *__restrict__ in, int *__restrict__ flags,
                                 unsigned long long *__restrict__ bits) {
@@ -2425,6 +2427,7 @@ __global__ void k_status_unpack(const double *__restrict__ in, int *__restrict__
   else if (in[0] > 0.0)
     flags[0] = 4;
   if (in[2] > 0.0) flags[4] = 1;
+  if (in[3] > 0.0) flags[5] = 1;
   (void)bits;
 }
 // sharded mode: keep only the entries this rank contributes to the all-reduce

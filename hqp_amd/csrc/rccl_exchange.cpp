@@ -1,10 +1,15 @@
 // libhqpkkt_rccl.so: see include/hqpkkt_rccl.h.
 #include "../../include/hqpkkt_rccl.h"
 
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
+#include <sys/stat.h>
+#include <sys/types.h>
+#include <time.h>
 #include <unistd.h>
 
+#include <cerrno>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -15,6 +20,7 @@ namespace {
 struct Ctx {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1, device = 0;
+  bool group_open = false;  // inside the broadcast sequence of one gather (root 0 .. nranks-1)
 };
 static_assert(sizeof(ncclUniqueId) <= HQPKKT_RCCL_ID_BYTES, "ncclUniqueId does not fit");
 int env_int(const char *a, const char *b, const char *c, int dflt) {
@@ -23,6 +29,34 @@ int env_int(const char *a, const char *b, const char *c, int dflt) {
     if (v && *v) return atoi(v);
   }
   return dflt;
+}
+// an open group must be closed on every way out: otherwise each later RCCL call of this thread is queued
+// and never launched
+int close_group(Ctx *c, ncclResult_t r) {
+  if (c->group_open) {
+    c->group_open = false;
+    const ncclResult_t g = ncclGroupEnd();
+    if (r == ncclSuccess) r = g;
+  }
+  return r == ncclSuccess ? 0 : (int)r;
+}
+// the file that carries the ncclUniqueId of hqpkkt_rccl_create_from_env: HQPKKT_ID_FILE, or a name made of
+// the launcher's rendezvous port inside a directory only this user can write
+std::string id_file_path() {
+  if (const char *f = getenv("HQPKKT_ID_FILE"))
+    if (*f) return f;
+  std::string dir;
+  if (const char *x = getenv("XDG_RUNTIME_DIR"))
+    if (*x) dir = x;
+  if (dir.empty()) {
+    dir = "/tmp/hqpkkt-" + std::to_string((long)getuid());
+    if (mkdir(dir.c_str(), 0700) != 0 && errno != EEXIST) return std::string();
+    struct stat st;
+    if (lstat(dir.c_str(), &st) != 0 || !S_ISDIR(st.st_mode) || st.st_uid != getuid() || (st.st_mode & 022)) return std::string();
+  }
+  const char *port = getenv("MASTER_PORT");
+  const char *run = getenv("TORCHELASTIC_RUN_ID");
+  return dir + "/rccl_id." + (port && *port ? port : "0") + "." + (run && *run ? run : "none");
 }
 }  // namespace
 
@@ -62,30 +96,45 @@ int hqpkkt_rccl_create_from_env(void **ctx, int *rank_out, int *nranks_out, int 
   const int rank = env_int("HQPKKT_RANK", "RANK", "OMPI_COMM_WORLD_RANK", 0);
   const int nranks = env_int("HQPKKT_WORLD_SIZE", "WORLD_SIZE", "OMPI_COMM_WORLD_SIZE", 1);
   const int device = env_int("HQPKKT_DEVICE", "LOCAL_RANK", "OMPI_COMM_WORLD_LOCAL_RANK", rank);
-  std::string path = getenv("HQPKKT_ID_FILE") ? getenv("HQPKKT_ID_FILE")
-                                              : std::string("/tmp/hqpkkt_rccl_id.") + (getenv("MASTER_PORT") ? getenv("MASTER_PORT") : "0");
+  const std::string path = id_file_path();
+  if (path.empty()) return -3;
+  // A file left by an earlier run (same port) must never be taken for this run's: rank 0 removes the
+  // path before it makes the id and again once the communicator is up (every rank has read it by
+  // then); the others accept only a file that is not older than their own start (minus the skew a
+  // launcher may put between its ranks)
+  const time_t started = time(nullptr);
   char id[HQPKKT_RCCL_ID_BYTES];
   if (rank == 0) {
+    (void)unlink(path.c_str());
     int e = hqpkkt_rccl_unique_id(id);
     if (e) return e;
-    const std::string tmp = path + ".tmp";
-    FILE *f = std::fopen(tmp.c_str(), "wb");
-    if (!f) return -3;
-    const size_t k = std::fwrite(id, 1, sizeof(id), f);
-    std::fclose(f);
-    if (k != sizeof(id) || std::rename(tmp.c_str(), path.c_str()) != 0) return -3;
-  } else {
-    FILE *f = nullptr;
-    for (int tries = 0; tries < 6000 && !f; tries++) {  // up to ten minutes
-      f = std::fopen(path.c_str(), "rb");
-      if (!f) usleep(100000);
+    const std::string tmp = path + ".tmp." + std::to_string((long)getpid());
+    (void)unlink(tmp.c_str());
+    const int fd = open(tmp.c_str(), O_WRONLY | O_CREAT | O_EXCL | O_NOFOLLOW, 0600);
+    if (fd < 0) return -3;
+    const ssize_t k = write(fd, id, sizeof(id));
+    close(fd);
+    if (k != (ssize_t)sizeof(id) || std::rename(tmp.c_str(), path.c_str()) != 0) {
+      (void)unlink(tmp.c_str());
+      return -3;
     }
-    if (!f) return -4;
-    const size_t k = std::fread(id, 1, sizeof(id), f);
-    std::fclose(f);
-    if (k != sizeof(id)) return -4;
+  } else {
+    bool got = false;
+    for (int tries = 0; tries < 6000 && !got; tries++) {  // up to ten minutes
+      const int fd = open(path.c_str(), O_RDONLY | O_NOFOLLOW);
+      if (fd >= 0) {
+        struct stat st;
+        if (fstat(fd, &st) == 0 && st.st_uid == getuid() && st.st_mtime + 120 >= started &&
+            read(fd, id, sizeof(id)) == (ssize_t)sizeof(id))
+          got = true;
+        close(fd);
+      }
+      if (!got) usleep(100000);
+    }
+    if (!got) return -4;
   }
   const int e = hqpkkt_rccl_create(id, nranks, rank, device, ctx);
+  if (rank == 0) (void)unlink(path.c_str());
   if (e) return e;
   if (rank_out) *rank_out = rank;
   if (nranks_out) *nranks_out = nranks;
@@ -93,33 +142,54 @@ int hqpkkt_rccl_create_from_env(void **ctx, int *rank_out, int *nranks_out, int 
   return 0;
 }
 
+int hqpkkt_rccl_comm_info(void *ctx, int *nranks, int *rank, int *device) {
+  Ctx *c = (Ctx *)ctx;
+  if (!c || !c->comm) return -1;
+  int n = 0, r = 0, d = 0;
+  ncclResult_t e = ncclCommCount(c->comm, &n);
+  if (e == ncclSuccess) e = ncclCommUserRank(c->comm, &r);
+  if (e == ncclSuccess) e = ncclCommCuDevice(c->comm, &d);
+  if (e != ncclSuccess) return (int)e;
+  if (nranks) *nranks = n;
+  if (rank) *rank = r;
+  if (device) *device = d;
+  return 0;
+}
+
 int hqpkkt_rccl_exchange(void *ctx, int op, double *buf, long long slot_elems, int nslots, void *hip_stream) {
   Ctx *c = (Ctx *)ctx;
-  if (!c || !buf || slot_elems < 0) return -1;
+  if (!c) return -1;
+  if (!buf || slot_elems < 0) return close_group(c, ncclInvalidArgument);
   hipStream_t s = (hipStream_t)hip_stream;
   ncclResult_t r;
   if (op == 0) {  // HQPKKT_XCHG_ALLGATHER, in place: the send part is this rank's slot of the receive buffer
-    if (nslots != c->nranks) return -1;
+    if (c->group_open || nslots != c->nranks) return close_group(c, ncclInvalidArgument);
     r = ncclAllGather(buf + (size_t)c->rank * slot_elems, buf, (size_t)slot_elems, ncclDouble, c->comm, s);
   } else if (op == 1) {  // HQPKKT_XCHG_ALLREDUCE_SUM
+    if (c->group_open) return close_group(c, ncclInvalidArgument);
     r = ncclAllReduce(buf, buf, (size_t)slot_elems, ncclDouble, ncclSum, c->comm, s);
   } else if (op >= 16 && op < 16 + c->nranks) {  // HQPKKT_XCHG_BCAST_BASE + root
-    // the broadcasts of one gather come back to back: the first opens a group, the last (root = nranks-1) closes it
+    // the broadcasts of one gather come back to back, roots 0 .. nranks-1 in this order: the first opens a
+    // group, the last closes it; anything out of sequence, or any error, closes the group before returning
     const int root = op - 16;
-    if (root == 0) (void)ncclGroupStart();
+    if (root == 0) {
+      if (c->group_open) return close_group(c, ncclInvalidUsage);
+      r = ncclGroupStart();
+      if (r != ncclSuccess) return (int)r;
+      c->group_open = true;
+    } else if (!c->group_open)
+      return (int)ncclInvalidUsage;
     r = slot_elems > 0 ? ncclBroadcast(buf, buf, (size_t)slot_elems, ncclDouble, root, c->comm, s) : ncclSuccess;
-    if (root == c->nranks - 1) {
-      const ncclResult_t g = ncclGroupEnd();
-      if (r == ncclSuccess) r = g;
-    }
+    if (r != ncclSuccess || root == c->nranks - 1) return close_group(c, r);
   } else
-    return -1;
+    return close_group(c, ncclInvalidArgument);
   return r == ncclSuccess ? 0 : (int)r;
 }
 
 int hqpkkt_rccl_destroy(void *ctx) {
   Ctx *c = (Ctx *)ctx;
   if (!c) return 0;
+  (void)close_group(c, ncclSuccess);
   if (c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
   return 0;

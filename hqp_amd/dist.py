@@ -169,6 +169,13 @@ class RcclShard:
             raise RuntimeError(f"hqpkkt_rccl_create: {e}")
         self._R, self.rank, self.world = R, rank, world
         self.fn = C.cast(R.hqpkkt_rccl_exchange, C.c_void_p)
+        # what the communicator itself says (ncclCommCount / UserRank / CuDevice): a bench line quotes it
+        nr, ur, dv = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+        if R.hqpkkt_rccl_comm_info(self._ctx, C.byref(nr), C.byref(ur), C.byref(dv)):
+            raise RuntimeError("hqpkkt_rccl_comm_info failed")
+        self.comm_ranks, self.comm_rank, self.comm_device = nr.value, ur.value, dv.value
+        if (self.comm_ranks, self.comm_rank) != (world, rank):
+            raise RuntimeError(f"RCCL communicator reports rank {ur.value} of {nr.value}, expected {rank} of {world}")
         # self-test of the three collectives on 8 values per rank (wrong data here must not reach a solve)
         import torch
         dev = torch.device("cuda", device)

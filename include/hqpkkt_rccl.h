@@ -24,11 +24,17 @@ int hqpkkt_rccl_create(const char id[HQPKKT_RCCL_ID_BYTES], int nranks, int rank
 /* the same from the environment, for hosts without a transport of their own (the C++ HQP host with
  * mat_ngpu > 1, started once per GPU): HQPKKT_RANK / HQPKKT_WORLD_SIZE (default: RANK / WORLD_SIZE of
  * torchrun, OMPI_COMM_WORLD_RANK / _SIZE of mpirun), device = HQPKKT_DEVICE or LOCAL_RANK or the rank;
- * rank 0 writes the id to the file HQPKKT_ID_FILE (default /tmp/hqpkkt_rccl_id.<MASTER_PORT or 0>), the
- * others wait for it */
+ * rank 0 writes the id to the file HQPKKT_ID_FILE (default: rccl_id.<MASTER_PORT or 0>.<TORCHELASTIC_RUN_ID or
+ * none> inside $XDG_RUNTIME_DIR, or inside /tmp/hqpkkt-<uid>, mode 0700), the others wait for it.  Rank 0
+ * removes the file before it writes the new id and again once the communicator is up; the others take only a
+ * file of their own user that is not older than their own start: the file of an earlier run is never used */
 int hqpkkt_rccl_create_from_env(void **ctx, int *rank, int *nranks, int *device);
+/* what the communicator itself reports: ncclCommCount / ncclCommUserRank / ncclCommCuDevice (any may be null) */
+int hqpkkt_rccl_comm_info(void *ctx, int *nranks, int *rank, int *device);
 /* hqpkkt_exchange_stream_fn: HQPKKT_XCHG_ALLGATHER in place (slot `rank` of `buf` is the send part),
- * HQPKKT_XCHG_ALLREDUCE_SUM in place; returns 0 or the ncclResult_t */
+ * HQPKKT_XCHG_ALLREDUCE_SUM in place, HQPKKT_XCHG_BCAST_BASE + root: the broadcasts of one gather, roots
+ * 0 .. nranks-1 in this order, form ONE RCCL group (opened by root 0, closed by the last root, and closed on
+ * any error before the call returns); returns 0 or the ncclResult_t */
 int hqpkkt_rccl_exchange(void *ctx, int op, double *buf, long long slot_elems, int nslots, void *hip_stream);
 int hqpkkt_rccl_destroy(void *ctx);
 

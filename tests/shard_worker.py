@@ -11,6 +11,54 @@ import numpy as np
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def c4dense_case(case, rank, world, dev):
+    """BASELINE configs[3]'s structure at FULL stage width through the dense hand-over (bench.c4_dense:
+    K stages of nx states, nu controls, everything on the device): the sharded handle against an
+    unsharded one on rank 0, identical vectors on every rank."""
+    import torch
+    import torch.distributed as tdist
+    import bench
+    from hqp_amd import dist, ipmatrix
+    _, K, nx, nu, _kind = case
+    dq = bench.c4_dense(K, nx, nu, seed=0, device=f"cuda:{dev}")
+    n, me, m = dq.dims
+    g = torch.Generator(device=f"cuda:{dev}").manual_seed(100)
+    rnd = lambda k, lo, hi: torch.empty(k, dtype=torch.float64, device=f"cuda:{dev}").uniform_(lo, hi, generator=g)
+    z, w = rnd(m, 0.1, 1.1), rnd(m, 0.1, 1.1)
+    r = [rnd(k, -0.5, 0.5) for k in (n, me, m, m)]
+    if os.environ.get("SHARD_TRANSPORT") == "rccl":
+        shard = dist.RcclShard(rank, world, dev)
+    else:
+        shard = (rank, world, dist.make_exchange(rank, dev))
+    M = ipmatrix.IpLQDOCP(device=dev, device_vectors=True, shard=shard)
+    M.init_dense(dq)
+    d = [torch.zeros(k, dtype=torch.float64, device=f"cuda:{dev}") for k in (n, me, m, m)]
+    for _rep in range(2):
+        M.factor(None, z, w)
+        res = M.solve(None, z, w, *r, *d)
+    s = M.stats()
+    cuts = M.debug(27).reshape(-1, world + 1)
+    rec = dict(case=case, rank=rank, res=res, staged=True, cuts=cuts[0].tolist(), flops_local=s["flops_local"],
+               bytes_factor=s["bytes_exchange_factor"], ranks=s["shard_count"], refine_rounds=s["refine_rounds"])
+    del M
+    torch.cuda.empty_cache()
+    tdist.barrier()  # (the unsharded partner below needs the memory the other ranks have just released)
+    if rank == 0:
+        R = ipmatrix.IpLQDOCP(device=dev, device_vectors=True)
+        R.init_dense(dq)
+        d0 = [torch.zeros_like(t) for t in d]
+        R.factor(None, z, w)
+        rec["res_single"] = R.solve(None, z, w, *r, *d0)
+        rec["diff"] = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-300)) for a, b in zip(d, d0) if b.numel())
+        del R
+    t = torch.cat(d).cpu()
+    ref = t.clone()
+    tdist.broadcast(ref, src=0)
+    rec["same_as_rank0"] = bool(torch.equal(t, ref))
+    return rec
 
 
 def main():
@@ -31,6 +79,9 @@ def main():
     cases = json.loads(os.environ.get("SHARD_CASES", '[["banded", 1500, 12, "SpBKP"]]'))
     for case in cases:
         kind = case[-1]
+        if case[0] == "c4dense":
+            out.append(c4dense_case(case, rank, world, dev))
+            continue
         if case[0] == "singular":
             # a duplicated equality row: the zero pivot turns up inside ONE rank's subtree (or in the top);
             # every rank must return the same status - nobody may be left waiting in a collective

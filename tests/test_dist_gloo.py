@@ -1,6 +1,8 @@
 """CPU, world_size 2 over gloo: the N>1 plumbing bench.py uses (unit sharding,
-fence, max / sum over ranks).  The KKT path shards by system with no data-path
-collective, so this is all the multi-process logic there is."""
+fence, max / sum over ranks) and bench.py's own launcher (`python bench.py --gpus N`
+starts its N ranks itself).  The collectives of ONE system that is sharded over the
+ranks are covered by tests/test_shard_cpu.py (gloo, numpy model of the kernels) and
+tests/test_gpu_shard.py (the kernels themselves, ranks sharing the test box's GPU)."""
 import os
 import subprocess
 import sys
@@ -48,3 +50,21 @@ def test_shard_units_cover_exactly_once():
     for world in (1, 2, 3, 8):
         owned = sorted(u for r in range(world) for u in dist.shard_units(11, r, world))
         assert owned == list(range(11))
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` outside a launcher (no RANK / WORLD_SIZE in the environment) starts two fresh
+    rank processes itself, hands rank 0's line through and returns their exit status."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "launchcheck"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d == {"launchcheck": True, "world": 2, "max_rank": 1.0, "gpus": 2}
+    # a failing rank's status comes back (here: a world size that contradicts --gpus)
+    bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "launchcheck"],
+                         capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, RANK="0", WORLD_SIZE="3"))
+    assert bad.returncode != 0

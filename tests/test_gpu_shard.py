@@ -86,6 +86,44 @@ def test_sharded_staged_system_matches_single(world, port):
             assert r["res"] <= 1e-10 and r["same_as_rank0"] and r["ranks"] == world, (case, r)
 
 
+def test_sharded_staged_system_at_full_stage_width():
+    """configs[3]'s stage width (nx = 5000, nu = 50, K = 20 stages, dense hand-over) over two ranks that share
+    the one GPU of the test box: the stream-K column slices, the pack / unpack of the strips of V_k and the
+    exact-size broadcast sequence at the size the multi-GPU bench runs them.  Same solution as the unsharded
+    handle to 1e-9, identical vectors on both ranks, no refinement round needed."""
+    case = ["c4dense", 20, 5000, 50, "LQDOCP"]
+    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_CASES=json.dumps([case]), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
+    recs = [r[0] for r in json.loads(line[len("SHARD_RESULT "):])]
+    assert recs[0]["diff"] < 1e-9, recs[0]
+    cuts = recs[0]["cuts"]
+    assert cuts[0] == 0 and cuts[-1] == 5000 and 0 < cuts[1] < 5000 and cuts[1] % 128 == 0
+    for r in recs:
+        assert r["res"] <= 1e-10 and r["same_as_rank0"] and r["ranks"] == 2, r
+    # both ranks do about half of the products
+    f0, f1 = recs[0]["flops_local"], recs[1]["flops_local"]
+    assert abs(f0 - f1) <= 0.1 * max(f0, f1), (f0, f1)
+
+
+def test_bench_launches_its_own_ranks():
+    """`python bench.py --gpus 2` outside a launcher starts its ranks itself (fresh child processes) and prints
+    ONE strong-scaling line; here two ranks on the one GPU with the exchange staged through gloo."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--backend", "gloo", "--share-gpu", "--stages", "6",
+           "--nx", "1024", "--steps", "2", "--warmup", "1", "--no-ip", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, lines
+    rec = json.loads(lines[0])
+    assert rec["scaling"] == "strong" and rec["n_gpus"] == 2 and rec["residual"] <= 1e-10
+    assert rec["shard"]["ranks"] == 2 and rec["shard"]["comm_ranks"] == 2 and "gloo" in rec["shard"]["transport"]
+
+
 def test_rccl_transport_single_rank():
     """libhqpkkt_rccl.so on the one GPU of the test box: a communicator of one rank, the STAGED
     engine's exchange path with the collectives in the handle's stream (hqpkkt_set_shard_stream).
@@ -106,7 +144,10 @@ def test_sharded_singular_system_same_status_on_all_ranks(world, port):
     """A rank-deficient equality block: the exactly zero pivot appears in one rank's subtree only; the
     status words are agreed by an all-reduce, so every rank raises E_SING (none hangs in the next
     collective)."""
-    cases = [["singular", 1500, 12, "RedSpBKP"], ["banded", 1500, 12, "RedSpBKP"]]
+    # (the full plugin is left with a multiplier pivot of ~1e-17 instead of an exact zero: the "tiny pivot"
+    # mark, flags[5], set on the owner of that subtree only - it travels with the agreed status words too)
+    cases = [["singular", 1500, 12, "RedSpBKP"], ["banded", 1500, 12, "RedSpBKP"], ["singular", 1500, 12, "SpBKP"],
+             ["banded", 1500, 12, "SpBKP"]]
     env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_CASES=json.dumps(cases), MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
            "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "shard_worker.py")]
@@ -114,8 +155,10 @@ def test_sharded_singular_system_same_status_on_all_ranks(world, port):
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
     per_rank = json.loads(line[len("SHARD_RESULT "):])
-    codes = [r[0]["code"] for r in per_rank]
-    assert codes == [4] * world, codes
+    for ci in (0, 2):
+        codes = [r[ci]["code"] for r in per_rank]
+        assert codes == [4] * world, (cases[ci], codes)
     # ... and the ranks go on together: the next (regular) system is solved as usual
     for r in per_rank:
-        assert r[1]["res"] <= 1e-10 and r[1]["same_as_rank0"]
+        for ci in (1, 3):
+            assert r[ci]["res"] <= 1e-10 and r[ci]["same_as_rank0"]
