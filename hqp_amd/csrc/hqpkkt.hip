@@ -2075,9 +2075,9 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return HQPKKT_E_DEVICE;
   HIPCHK(hipSetDevice(device));
   const long long lda = (M + 7) / 8 * 8, ldb = (N + 7) / 8 * 8, ldc = ldb;
-  double *A = nullptr, *B = nullptr, *Cm = nullptr, *err = nullptr;
+  double *A = nullptr, *B = nullptr, *Cm = nullptr, *err = nullptr, *zr = nullptr;
   auto fin = [&](int rc) {
-    (void)hipFree(A), (void)hipFree(B), (void)hipFree(Cm), (void)hipFree(err);
+    (void)hipFree(A), (void)hipFree(B), (void)hipFree(Cm), (void)hipFree(err), (void)hipFree(zr);
     return rc;
   };
   const size_t kk = K > 0 ? K : 1;
@@ -2088,7 +2088,12 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   k_fill_rand<<<nblk((long long)kk * ldb), 256>>>(B, (long long)kk * ldb, 2);
   (void)hipMemset(err, 0, 8);
   (void)hipMemset(Cm, 0, sizeof(double) * (size_t)std::max(M, N) * ldc);
-  stg::GemmArgs g{A, lda, B, ldb, nullptr, 0, Cm, ldc, M, N, K, 1.0, 0.0, lower, mirror, nullptr};
+  stg::GemmArgs g{A, lda, B, ldb, nullptr, 0, Cm, ldc, M, N, K, 1.0, 0.0, lower, mirror, nullptr, nullptr};
+  if (!getenv("HQPKKT_NO_LDSDMA")) {
+    if (hipMalloc((void **)&zr, sizeof(double) * 256) != hipSuccess) return fin(HQPKKT_E_MEM);
+    (void)hipMemset(zr, 0, sizeof(double) * 256);
+    g.zeros = zr;
+  }
   int cus = 0;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
   const int skg = getenv("HQPKKT_NO_STREAMK") ? 0 : stg::gemm_streamk_grid(M, N, K, lower, 2 * cus);
@@ -2097,12 +2102,14 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   const int b = big ? 128 : 64;
   const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
   (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(128, 128));
+  (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(128, 128));
   (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(64, 64));
   // stream-K form where the engine would use it (staged_host.hip.h, st_gemm)
   double *skws = nullptr;
   unsigned *skcnt = nullptr;
   if (use_sk) {
-    (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_sk_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_sk_lds_bytes());
+    (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_sk_lds_bytes());
     if (hipMalloc((void **)&skws, sizeof(double) * (size_t)(skg + 1) * 2 * 128 * 128) != hipSuccess ||
         hipMalloc((void **)&skcnt, sizeof(unsigned) * (tiles + 4)) != hipSuccess) {
       (void)hipFree(skws), (void)hipFree(skcnt);
@@ -2115,8 +2122,14 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
     if (r == 0) (void)hipEventRecord(e0, 0);
     if (use_sk) {
       (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (tiles + 4), 0);
-      stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, stg::StreamK{skws, skcnt, (int)tiles, stg::gemm_streamk_dp_rounds(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)});
-    } else if (big)
+      const stg::StreamK skk{skws, skcnt, (int)tiles, stg::gemm_streamk_dp_rounds(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)};
+      if (g.zeros)
+        stg::k_dgemm_tn_sk<true><<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, skk);
+      else
+        stg::k_dgemm_tn_sk<false><<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, skk);
+    } else if (big && g.zeros)
+      stg::k_dgemm_tn<128, 128, true><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
+    else if (big)
       stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
     else
       stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64)>>>(g);

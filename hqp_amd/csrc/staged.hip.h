@@ -44,6 +44,8 @@ struct GemmArgs {
   const int *tile_map;  // lower, 128 x 128 tiles: tile index -> tile row << 16 | tile column, in blocks of
                         // 8 x 8 tiles (neighbours in the launch order share operand panels in their XCD's L2);
                         // null: row by row
+  const double *zeros;  // >= 128 zero doubles (16-byte aligned): the source of the operand rows k >= K when the
+                        // 128 x 128 kernels stage their operands by LDS-DMA; null: staging through registers
 };
 
 static const int GEMM_BK = 16;
@@ -204,6 +206,71 @@ struct GemmTile {
     }
   }
 
+  // The same with the operand slabs brought global -> LDS by the DMA path (global_load_lds_dwordx4: no
+  // staging registers, no ds_write, no vector ALU work besides the address of a row), 128-wide tiles only: a
+  // k-row of a panel is 128 doubles = the 1 KiB one wave-instruction writes (lane l -> bytes 16 l .. 16 l + 15
+  // behind a wave-uniform LDS address), so padded LDS rows are no obstacle.  Wave w brings the rows w, w + 4,
+  // w + 8, w + 12 of both panels: 8 instructions per wave and slab, issued BETWEEN the first 16 multiplications
+  // of the slab before (one per two v_mfma_f64_16x16x4, which take 64 cycles each), into the buffer the
+  // barrier at the end of the slab before has released; they have the rest of the slab (~4000 cycles) to land
+  // and are waited for (vmcnt(0)) in front of the barrier that ends the slab.  Rows k >= K come from g.zeros,
+  // so the last, partial slab needs no masking; behind the last slab of the range the same 8 instructions
+  // copy zero rows into the buffer nobody reads any more (no branch in the loop).
+  // Per slab a wave is outside its MFMA stream only for the barrier and the latency of its first fragment
+  // reads: the register-staged loop above spends ~150 vector instructions per slab on addresses, masks and
+  // ds_write_b128 behind the last MFMA, during which the matrix pipe has nothing from this wave (two
+  // workgroups per CU that started together stay in step, so the partner wave is in the same phase).
+  static __device__ __forceinline__ void glds16(const double *src, double *lds_row) {
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
+                                     (__attribute__((address_space(3))) void *)lds_row, 16, 0, 0);
+  }
+  static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
+                                                        double4_t (&acc)[TM][TN], double *As, double *Bs) {
+    static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int lr = lane & 15, lk = lane >> 4;
+    // a 16-byte load is inside its row when its first column is < ld (ld even)
+    const double *pa = g.A + ((i0 + 2 * lane < g.lda) ? i0 + 2 * lane : 0);
+    const double *pb = g.B + ((j0 + 2 * lane < g.ldb) ? j0 + 2 * lane : 0);
+    const double *zr = g.zeros + 2 * lane;
+    // piece p of the slab that starts at row k0 -> buffer buf: rows wave + 4 (p & 3) of A (p < 4) or B
+    auto dma = [&](int buf, int k0, int p) {
+      const int r = wave + 4 * (p & 3), k = k0 + r;
+      if (p < 4)
+        glds16(k < g.K ? pa + (long long)k * g.lda : zr, As + (buf * BK + r) * LDA);
+      else
+        glds16(k < g.K ? pb + (long long)k * g.ldb : zr, Bs + (buf * BK + r) * LDB);
+    };
+    if (s1 > s0) {
+#pragma unroll
+      for (int p = 0; p < 8; p++) dma(0, s0 * BK, p);
+    }
+    __syncthreads();  // (waits for the DMA: vmcnt(0))
+    for (int s = s0; s < s1; s++) {
+      const int buf = (s - s0) & 1;
+      const int knext = s + 1 < s1 ? (s + 1) * BK : g.K;  // behind the last slab: zero rows
+      const double *Ab = As + buf * BK * LDA + wm * WM + lr;
+      const double *Bb = Bs + buf * BK * LDB + wn * WN + lr;
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ks++) {
+        double af[TM], bf[TN];
+#pragma unroll
+        for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * LDA + 16 * x];
+#pragma unroll
+        for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * LDB + 16 * y];
+#pragma unroll
+        for (int x = 0; x < TM; x++)
+#pragma unroll
+          for (int y = 0; y < TN; y++) {
+            acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            if (ks == 0 && (y & 1)) dma(buf ^ 1, knext, x * 2 + (y >> 1));
+          }
+      }
+      __syncthreads();
+    }
+  }
+
   static __device__ __forceinline__ void epilogue(const GemmArgs &g, int tm, int tn, const double4_t (&acc)[TM][TN]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
@@ -227,7 +294,7 @@ struct GemmTile {
   }
 };
 
-template <int BM, int BN>
+template <int BM, int BN, bool DMA = false>
 __global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
   using T = GemmTile<BM, BN>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 * BK * (LDA + LDB) doubles
@@ -239,7 +306,10 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
   for (int x = 0; x < T::TM; x++)
 #pragma unroll
     for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  T::accumulate(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
+  if constexpr (DMA)
+    T::accumulate_dma(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
+  else
+    T::accumulate(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
   T::epilogue(g, tm, tn, acc);
 }
 
@@ -259,6 +329,7 @@ struct StreamK {
   int tiles;
   int dp_rounds;
 };
+template <bool DMA>
 __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) {
   constexpr int BM = 128, BN = 128;
   using T = GemmTile<BM, BN>;
@@ -275,7 +346,10 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) 
     for (int x = 0; x < T::TM; x++)
 #pragma unroll
       for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    T::accumulate(g, tm * BM, tn * BN, 0, nslab, acc, As, Bs);
+    if constexpr (DMA)
+      T::accumulate_dma(g, tm * BM, tn * BN, 0, nslab, acc, As, Bs);
+    else
+      T::accumulate(g, tm * BM, tn * BN, 0, nslab, acc, As, Bs);
     T::epilogue(g, tm, tn, acc);
   }
   const int t_first = sk.dp_rounds * G;
@@ -296,7 +370,10 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) 
     for (int x = 0; x < T::TM; x++)
 #pragma unroll
       for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
+    if constexpr (DMA)
+      T::accumulate_dma(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
+    else
+      T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
     bool finish = true;
     if (s0 > 0 || s1 < nslab) {
       // shared tile: the workgroups that own its first and its last unit, and everybody between them

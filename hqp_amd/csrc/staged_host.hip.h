@@ -12,6 +12,7 @@ struct StagedDev {
   DBuf<stg::HTerm> h_terms;
   DBuf<stg::DynDesc> dyn_desc;  // dense dynamics: per stage (K+1) what k_st_dyn_ax / _aty need
   DBuf<double> dyn_x1, dyn_x2;  // A_dyn' dy (n), A_dyn dx (ndyn)
+  DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   DBuf<double> sk_ws;           // stream-K dgemm: two partial tiles per workgroup
   DBuf<unsigned> sk_cnt;
   int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
@@ -48,7 +49,7 @@ struct StagedDev {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
-    dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release();
+    dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
     for (auto &e : tri_maps) e.second->release(), delete e.second;
     tri_maps.clear();
     if (stream2) (void)hipStreamDestroy(stream2), stream2 = nullptr;
@@ -91,14 +92,20 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
   const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
   if (g.lower && big && d && tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
+  if (d && d->zeros.p) g.zeros = d->zeros.p;
   if (skg > 0 && tiles <= d->sk_tiles) {
     // tile count that does not fill the chip evenly: even shares of the (tile, k-slab) units (k_dgemm_tn_sk)
     HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
     stg::StreamK sk{d->sk_ws.p, d->sk_cnt.p, (int)tiles, stg::gemm_streamk_dp_rounds(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)};
-    KLAUNCH(h, cls, stg::k_dgemm_tn_sk<<<skg, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
+    if (g.zeros)
+      KLAUNCH(h, cls, stg::k_dgemm_tn_sk<true><<<skg, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
+    else
+      KLAUNCH(h, cls, stg::k_dgemm_tn_sk<false><<<skg, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
     return 0;
   }
-  if (big)
+  if (big && g.zeros)
+    KLAUNCH(h, cls, stg::k_dgemm_tn<128, 128, true><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
+  else if (big)
     KLAUNCH(h, cls, stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
   else
     KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
@@ -227,6 +234,11 @@ static int staged_upload(hqpkkt_t *h) {
     }
     if ((e = d.dyn_desc.upload(dd)) || (e = d.dyn_x1.alloc(n)) || (e = d.dyn_x2.alloc(P.ndyn))) return e;
   }
+  if (!getenv("HQPKKT_NO_LDSDMA")) {  // (the register-staged loop stays selectable for comparisons)
+    if ((e = d.zeros.alloc(256))) return e;
+    HIPCHK(hipMemset(d.zeros.p, 0, sizeof(double) * 256));
+  } else
+    d.zeros.release();
   HIPCHK(hipMemset(d.F.p, 0, sizeof(double) * std::max<long long>(P.f_elems, 1)));
   HIPCHK(hipMemset(d.V.p, 0, sizeof(double) * std::max<long long>(P.v_elems, 1)));
   HIPCHK(hipMemset(d.misc.p, 0, sizeof(double) * std::max<long long>(P.misc_elems, 1)));
@@ -280,7 +292,11 @@ static int staged_upload(hqpkkt_t *h) {
                                  (int)stg::gemm_lds_bytes(128, 128)));
       HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)stg::gemm_lds_bytes(64, 64)));
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)stg::gemm_lds_bytes(128, 128)));
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)stg::gemm_sk_lds_bytes()));
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)stg::gemm_sk_lds_bytes()));
       attr_gemm = true;
     }
