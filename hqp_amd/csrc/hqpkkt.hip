@@ -2089,28 +2089,25 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipMemset(err, 0, 8);
   (void)hipMemset(Cm, 0, sizeof(double) * (size_t)std::max(M, N) * ldc);
   stg::GemmArgs g{A, lda, B, ldb, nullptr, 0, Cm, ldc, M, N, K, 1.0, 0.0, lower, mirror, nullptr, nullptr};
-  if (!getenv("HQPKKT_NO_LDSDMA")) {
+  const int variant = stg::gemm_variant_from_env();
+  if (variant != stg::GEMM_REG4) {
     if (hipMalloc((void **)&zr, sizeof(double) * 256) != hipSuccess) return fin(HQPKKT_E_MEM);
     (void)hipMemset(zr, 0, sizeof(double) * 256);
     g.zeros = zr;
   }
   int cus = 0;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  const int skg = getenv("HQPKKT_NO_STREAMK") ? 0 : stg::gemm_streamk_grid(M, N, K, lower, 2 * cus);
-  const bool use_sk = skg > 0;
+  const int skg = 2 * cus;
+  const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && stg::gemm_use_split(M, N, K, lower, skg);
   const bool big = use_sk || stg::gemm_big_tiles(M, N, lower);
   const int b = big ? 128 : 64;
   const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
-  (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(128, 128));
-  (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(128, 128));
-  (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_lds_bytes(64, 64));
+  (void)stg::gemm_set_attributes();
   // stream-K form where the engine would use it (staged_host.hip.h, st_gemm)
   double *skws = nullptr;
   unsigned *skcnt = nullptr;
   if (use_sk) {
-    (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_sk_lds_bytes());
-    (void)hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::gemm_sk_lds_bytes());
-    if (hipMalloc((void **)&skws, sizeof(double) * (size_t)(skg + 1) * 2 * 128 * 128) != hipSuccess ||
+    if (hipMalloc((void **)&skws, sizeof(double) * (size_t)(16 * tiles + 8) * 128 * 128) != hipSuccess ||
         hipMalloc((void **)&skcnt, sizeof(unsigned) * (tiles + 4)) != hipSuccess) {
       (void)hipFree(skws), (void)hipFree(skcnt);
       return fin(HQPKKT_E_MEM);
@@ -2122,15 +2119,11 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
     if (r == 0) (void)hipEventRecord(e0, 0);
     if (use_sk) {
       (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (tiles + 4), 0);
-      const stg::StreamK skk{skws, skcnt, (int)tiles, stg::gemm_streamk_dp_rounds(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)};
-      if (g.zeros)
-        stg::k_dgemm_tn_sk<true><<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, skk);
-      else
-        stg::k_dgemm_tn_sk<false><<<skg, 256, stg::gemm_sk_lds_bytes()>>>(g, skk);
-    } else if (big && g.zeros)
-      stg::k_dgemm_tn<128, 128, true><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
-    else if (big)
-      stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128)>>>(g);
+      stg::SplitPlan skk = stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
+      skk.ws = skws, skk.cnt = skcnt;
+      stg::gemm_launch_split(variant, skg, 0, g, skk);
+    } else if (big)
+      stg::gemm_launch_plain(variant, (unsigned)tiles, 0, g);
     else
       stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64)>>>(g);
   }
@@ -2141,6 +2134,71 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipEventElapsedTime(&t, e0, e1);
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   if (se != hipSuccess) return fin(HQPKKT_E_DEVICE);
+  if (getenv("HQPKKT_DGEMM_STAMPS") && use_sk) {
+    // the split form with time stamps: per workgroup its start and, per round / split phase, the end of the k
+    // loop, of the parking / summing of partial tiles and of the epilogue (us after the first start)
+    unsigned long long *st = nullptr;
+    double *ws2 = nullptr;
+    unsigned *cnt2 = nullptr;
+    if (hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * skg) == hipSuccess &&
+        hipMalloc((void **)&ws2, sizeof(double) * (size_t)(16 * tiles + 8) * 128 * 128) == hipSuccess &&
+        hipMalloc((void **)&cnt2, sizeof(unsigned) * (tiles + 4)) == hipSuccess) {
+      (void)hipMemset(st, 0, sizeof(unsigned long long) * 16 * skg);
+      (void)hipMemset(cnt2, 0, sizeof(unsigned) * (tiles + 4));
+      stg::GemmArgs gs = g;
+      gs.stamps = st;
+      stg::SplitPlan skk = stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
+      skk.ws = ws2, skk.cnt = cnt2;
+      stg::gemm_launch_split(variant, skg, 0, gs, skk);
+      std::vector<unsigned long long> hs(16 * (size_t)skg);
+      if (hipMemcpy(hs.data(), st, sizeof(unsigned long long) * 16 * skg, hipMemcpyDeviceToHost) == hipSuccess) {
+        unsigned long long tmin = ~0ULL;
+        for (int w = 0; w < skg; w++) tmin = std::min(tmin, hs[16 * (size_t)w]);
+        fprintf(stderr, "split plan: %d whole tiles", skk.whole);
+        for (int q = 0; q < skk.nphase; q++) fprintf(stderr, ", %d tiles x %d pieces", skk.count[q], skk.split[q]);
+        fprintf(stderr, "; stamps of every %dth workgroup (us): start | per round: k loop end, parked / summed, epilogue end\n", std::max(1, skg / 32));
+        for (int w = 0; w < skg; w += std::max(1, skg / 32)) {
+          fprintf(stderr, "  wg %4d: %7.2f |", w, (hs[16 * (size_t)w] - tmin) * 0.01);
+          for (int r = 0; r < std::min(5, skk.dp_rounds + skk.nphase); r++) {
+            for (int c = 1; c <= 3; c++) {
+              const unsigned long long x = hs[16 * (size_t)w + 3 * r + c];
+              if (x) fprintf(stderr, " %8.2f", (x - tmin) * 0.01); else fprintf(stderr, "        -");
+            }
+            fprintf(stderr, " |");
+          }
+          fprintf(stderr, "\n");
+        }
+      }
+    }
+    (void)hipFree(st), (void)hipFree(ws2), (void)hipFree(cnt2);
+  }
+  if (getenv("HQPKKT_DGEMM_STAMPS") && !use_sk && big) {
+    // one more launch with time stamps per workgroup (100 MHz constant clock): when it started, when its k loop
+    // ended, when its epilogue ended - relative to the first start; printed as a histogram over the workgroups
+    unsigned long long *st = nullptr;
+    if (hipMalloc((void **)&st, sizeof(unsigned long long) * 4 * tiles) == hipSuccess) {
+      stg::GemmArgs gs = g;
+      gs.stamps = st;
+      stg::gemm_launch_plain(variant, (unsigned)tiles, 0, gs);
+      std::vector<unsigned long long> hs(4 * tiles);
+      if (hipMemcpy(hs.data(), st, sizeof(unsigned long long) * 4 * tiles, hipMemcpyDeviceToHost) == hipSuccess) {
+        unsigned long long tmin = ~0ULL;
+        for (long long t = 0; t < tiles; t++) tmin = std::min(tmin, hs[4 * t]);
+        // workgroups in the order of their start
+        std::vector<long long> ord(tiles);
+        for (long long t = 0; t < tiles; t++) ord[t] = t;
+        std::sort(ord.begin(), ord.end(), [&](long long a, long long b) { return hs[4 * a] < hs[4 * b]; });
+        fprintf(stderr, "stamps (us after the first start; %lld workgroups, every %lldth in start order): start, k loop end, epilogue end, xcc, blockIdx\n", tiles,
+                std::max<long long>(1, tiles / 64));
+        for (long long q = 0; q < tiles; q += std::max<long long>(1, tiles / 64)) {
+          const long long t = ord[q];
+          fprintf(stderr, "  %8.2f %8.2f %8.2f  xcc %llu  wg %lld\n", (hs[4 * t] - tmin) * 0.01, (hs[4 * t + 2] - tmin) * 0.01, (hs[4 * t + 3] - tmin) * 0.01,
+                  hs[4 * t + 1], t);
+        }
+      }
+      (void)hipFree(st);
+    }
+  }
   k_gemm_check<<<16, 256>>>(g, 4096, err);
   double he = 0.0;
   if (hipMemcpy(&he, err, 8, hipMemcpyDeviceToHost) != hipSuccess) return fin(HQPKKT_E_DEVICE);

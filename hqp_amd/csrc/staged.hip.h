@@ -46,6 +46,9 @@ struct GemmArgs {
                         // null: row by row
   const double *zeros;  // >= 128 zero doubles (16-byte aligned): the source of the operand rows k >= K when the
                         // 128 x 128 kernels stage their operands by LDS-DMA; null: staging through registers
+  unsigned long long *stamps;  // diagnostic builds of the plain kernel only (hqpkkt_debug_dgemm): 4 constant-clock
+                               // (100 MHz) time stamps per workgroup: start, operands of the first slab in LDS, end of
+                               // the k loop, end of the epilogue; null in every product of the engine
 };
 
 static const int GEMM_BK = 16;
@@ -58,33 +61,12 @@ static inline bool gemm_big_tiles(int M, int N, int lower) {
   return (lower ? tm * (tm + 1) / 2 : tm * tn) >= 384;
 }
 
-// The stream-K form (k_dgemm_tn_sk) pays where whole rounds of 128 x 128 tiles would leave slots idle
-// and the product is deep enough to be worth sharing.  Returns the grid to launch (0: use the plain
-// kernels): all `grid` workgroups when there are more tiles than that; for fewer tiles at most 8
-// workgroups per tile (the last arriver reads the others' partial sums one after the other) and at
-// least 96 k-slabs per workgroup (parking and adding the partial sums costs as much as ~20 slabs:
-// measured, shares of 8 .. 40 slabs were slower than the plain 64 x 64 tiles).
-static inline int gemm_streamk_grid(int M, int N, int K, int lower, int grid) {
-  if (grid <= 0 || (long long)M * N < 256LL * 256) return 0;
-  const long long tm = (M + 127) / 128, tn = (N + 127) / 128, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
-  const long long nslab = (K + GEMM_BK - 1) / GEMM_BK;
-  if (tiles % grid == 0 || tiles >= 8LL * grid) return 0;  // even, or the tail does not matter
-  if (nslab < 64) return 0;  // shallow products (the rank-q update of V): sharing a tile costs more than it saves
-  if (tiles > grid) return grid;
-  const long long gl = std::min<long long>(std::min<long long>(grid, tiles * 8), tiles * nslab / 96);
-  // worth it only with clearly more workgroups than tiles
-  if (gl * 2 < tiles * 3) return 0;
-  return (int)gl;
-}
-
-// whole data-parallel rounds in front of the shared part: as many as leave every workgroup a share of at
-// least 96 k-slabs of the rest (a shorter share costs more in parked partial sums than it balances)
-static inline int gemm_streamk_dp_rounds(long long tiles, long long nslab, int grid) {
-  long long dp = tiles / grid;
-  if (dp > 0 && (tiles - dp * grid) * nslab / grid < 96) dp--;
-  return (int)dp;
-}
-
+// The split form (k_dgemm_tn_sk, below) pays where whole rounds of 128 x 128 tiles would leave slots idle
+// and the product is deep enough to be cut.  Returns true when the launch should use it with the whole
+// `grid` (two workgroups per CU): more than one tile, not a multiple of the grid, and either more tiles
+// than half the grid or a plan that puts at least a quarter of the grid to work (below that the 64 x 64
+// tiles fill the chip better).
+static inline bool gemm_use_split(int M, int N, int K, int lower, int grid);
 // blockIdx -> position in a sequence in which the workgroups of one XCD (blockIdx % 8) are
 // neighbours (each XCD has its own L2; neighbouring tiles share operand panels)
 __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
@@ -96,11 +78,17 @@ __device__ __forceinline__ int xcd_swizzle(int bid, int nwg) {
 // of both operands go global -> registers -> LDS (two buffers: the loads of slab t+1 are in
 // flight while slab t is multiplied), fragments LDS -> registers with ds_read_b64, conflict
 // free because an LDS row is BM + 16 doubles (rows k, k+1 of a fragment: banks 32 apart).
-template <int BM, int BN>
+// WGM x WGN wavefronts per workgroup (2 x 2: 64 x 64 per wave, 16 accumulator tiles = 128 registers, two waves
+// per SIMD; 2 x 4: 64 x 32 per wave, 8 accumulator tiles, under 128 registers, FOUR waves per SIMD with two
+// workgroups per CU - one wave issues a v_mfma_f64_16x16x4 only every ~140 cycles (stamps of the 2 x 2 kernel:
+// every workgroup proceeds at that pace whoever its partner is, profiles/r03_dgemm_stamps.txt), the pipe takes
+// one per 64, so two waves per SIMD top out near 90 % of the peak and it takes three or four to fill it)
+template <int BM, int BN, int WGM = 2, int WGN = 2>
 struct GemmTile {
   static constexpr int BK = GEMM_BK;
+  static constexpr int NW = WGM * WGN, NT = 64 * NW;
   static constexpr int LDA = BM + 16, LDB = BN + 16;
-  static constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 16, TN = WN / 16;
+  static constexpr int WM = BM / WGM, WN = BN / WGN, TM = WM / 16, TN = WN / 16;
   static constexpr int LA = BK * BM / 2 / 256, LB = BK * BN / 2 / 256;  // 16-byte loads per thread and slab
   static constexpr int RA = 256 / (BM / 2), RB = 256 / (BN / 2);        // slab rows covered by one pass
 
@@ -128,8 +116,9 @@ struct GemmTile {
   // acc += sum over the slabs [s0, s1) of the tile at (i0, j0); ends with a barrier (LDS free again)
   static __device__ __forceinline__ void accumulate(const GemmArgs &g, int i0, int j0, int s0, int s1,
                                                     double4_t (&acc)[TM][TN], double *As, double *Bs) {
+    static_assert(NT == 256, "the register-staged loop is written for 256 threads");
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lk = lane >> 4;
     // global -> register staging: thread covers columns ca, ca+1 of rows ra + p*RA
     const int ca = 2 * (tid % (BM / 2)), ra = tid / (BM / 2);
@@ -227,26 +216,29 @@ struct GemmTile {
   static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
                                                         double4_t (&acc)[TM][TN], double *As, double *Bs) {
     static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
+    constexpr int RPW = BK / NW;  // rows of each panel per wave and slab
+    static_assert(RPW * NW == BK && TM * TN >= 2 * RPW, "pieces are issued behind the multiplications of the first k-step");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lk = lane >> 4;
     // a 16-byte load is inside its row when its first column is < ld (ld even)
     const double *pa = g.A + ((i0 + 2 * lane < g.lda) ? i0 + 2 * lane : 0);
     const double *pb = g.B + ((j0 + 2 * lane < g.ldb) ? j0 + 2 * lane : 0);
     const double *zr = g.zeros + 2 * lane;
-    // piece p of the slab that starts at row k0 -> buffer buf: rows wave + 4 (p & 3) of A (p < 4) or B
+    // piece p of the slab that starts at row k0 -> buffer buf: row wave + NW (p % RPW) of A (p < RPW) or B
     auto dma = [&](int buf, int k0, int p) {
-      const int r = wave + 4 * (p & 3), k = k0 + r;
-      if (p < 4)
+      const int r = wave + NW * (p % RPW), k = k0 + r;
+      if (p < RPW)
         glds16(k < g.K ? pa + (long long)k * g.lda : zr, As + (buf * BK + r) * LDA);
       else
         glds16(k < g.K ? pb + (long long)k * g.ldb : zr, Bs + (buf * BK + r) * LDB);
     };
     if (s1 > s0) {
 #pragma unroll
-      for (int p = 0; p < 8; p++) dma(0, s0 * BK, p);
+      for (int p = 0; p < 2 * RPW; p++) dma(0, s0 * BK, p);
     }
     __syncthreads();  // (waits for the DMA: vmcnt(0))
+    constexpr int GAP = TM * TN / (2 * RPW);  // multiplications between two pieces
     for (int s = s0; s < s1; s++) {
       const int buf = (s - s0) & 1;
       const int knext = s + 1 < s1 ? (s + 1) * BK : g.K;  // behind the last slab: zero rows
@@ -264,7 +256,7 @@ struct GemmTile {
 #pragma unroll
           for (int y = 0; y < TN; y++) {
             acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
-            if (ks == 0 && (y & 1)) dma(buf ^ 1, knext, x * 2 + (y >> 1));
+            if (ks == 0 && (x * TN + y) % GAP == GAP - 1) dma(buf ^ 1, knext, (x * TN + y) / GAP);
           }
       }
       __syncthreads();
@@ -273,7 +265,7 @@ struct GemmTile {
 
   static __device__ __forceinline__ void epilogue(const GemmArgs &g, int tm, int tn, const double4_t (&acc)[TM][TN]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lk = lane >> 4;
     const int i0 = tm * BM, j0 = tn * BN;
     const bool diag = g.lower && tm == tn;
@@ -294,12 +286,13 @@ struct GemmTile {
   }
 };
 
-template <int BM, int BN, bool DMA = false>
-__global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
-  using T = GemmTile<BM, BN>;
+template <int BM, int BN, bool DMA = false, int WGM = 2, int WGN = 2>
+__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn(GemmArgs g) {
+  using T = GemmTile<BM, BN, WGM, WGN>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 * BK * (LDA + LDB) doubles
   double *As = lds, *Bs = lds + 2 * T::BK * T::LDA;
   int tm, tn;
+  const unsigned long long t0 = g.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   T::tile_of(g, xcd_swizzle(blockIdx.x, gridDim.x), tm, tn);
   double4_t acc[T::TM][T::TN];
 #pragma unroll
@@ -310,59 +303,156 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn(GemmArgs g) {
     T::accumulate_dma(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
   else
     T::accumulate(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
+  const unsigned long long t2 = g.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   T::epilogue(g, tm, tn, acc);
+  if (g.stamps && threadIdx.x == 0) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    unsigned xcc;
+    asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+    g.stamps[4 * blockIdx.x + 0] = t0, g.stamps[4 * blockIdx.x + 1] = (unsigned long long)(xcc & 15);
+    g.stamps[4 * blockIdx.x + 2] = t2, g.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
+  }
 }
 
 // The same product for tile counts that do not fill the chip evenly (1600 tiles on 512 workgroup
 // slots: the last of four rounds would be an eighth full; 100 tiles of a column slice: a fifth of
-// the slots busy for a whole tile time).  A fixed grid of workgroups first runs `dp_rounds` rounds
-// of whole tiles (one per workgroup and round, all at the same k: neighbours share their operand
-// panels in L2), then shares the (tile, k-slab) units of the remaining tiles evenly: every
-// workgroup gets a contiguous range of them in tile order, i.e. at most the tail of one tile, whole
-// tiles and the head of another one.  The workgroups that share a tile park their partial sums
-// (plain stores, then an agent-scope release and one counter add); the one that arrives last adds
-// all of them in the order of the k ranges (its own from registers) and writes the tile: the result
-// does not depend on the order of arrival, and nobody waits for anybody.
-struct StreamK {
-  double *ws;     // 2 slots of 128 x 128 doubles per workgroup: [0] its first, [1] its second partial tile
-  unsigned *cnt;  // per tile (zeroed before every launch)
-  int tiles;
-  int dp_rounds;
+// the slots busy for a whole tile time).  A fixed grid of G workgroups (two per CU) runs
+//   * `dp_rounds` rounds of whole tiles, then
+//   * up to three SPLIT phases: phase q takes count[q] tiles and cuts the k range of each into split[q]
+//     equal pieces: the last whole round as halves, the rest of the tiles floor(G / rest) ways.
+// In every phase the workgroups that run side by side (neighbours in w: the same XCD after the swizzle)
+// work on neighbouring tiles at the SAME k, so they share their operand panels in that XCD's L2 -
+// round 2's form of this kernel gave every workgroup a contiguous range of (tile, k-slab) units, which
+// balances as well but leaves the 512 workgroups at 512 different k: 3 GB of operand reads in 0.7 ms
+// that no cache level could share (the Infinity Cache holds 256 MB, F and W are 200 MB each), and the
+// shared part of a launch ran at the speed of those reads, not of the matrix pipes.
+// The pieces of a tile park their partial sums (plain stores, then an agent-scope release and one
+// counter add); the workgroup that arrives last adds all of them in the order of the k ranges (its
+// own comes back from memory too: one code path, one order) and writes the tile: the result does not
+// depend on the order of arrival, and nobody waits for anybody.
+struct SplitPlan {
+  double *ws;     // partial tiles: piece p (numbered through the split phases) -> ws + p * 128 * 128 (gemm_split_plan_pieces)
+  unsigned *cnt;  // arrival counter per tile, and at [queue] the head of the unit list (all zeroed before every launch)
+  int queue;      // = number of tiles
+  int dp_rounds;  // (whole / G, informative)
+  int whole;      // the first `whole` tiles are computed whole
+  int dynamic;    // 0: workgroup w does unit w of every round and phase; 1: units after the first from a queue
+  int nphase;
+  int begin[3], count[3], split[3];
 };
-template <bool DMA>
-__global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) {
+
+// Host: the plan for `tiles` tiles of `nslab` k-slabs on `grid` workgroups.  The remainder R of the whole
+// rounds is cut floor(grid / R) ways; a remainder of more than half a round first gives grid / 2 tiles to
+// two workgroups each (a full phase of half the depth) and cuts the rest after that.  A piece holds at
+// least 16 slabs (below that the pipeline fill of a piece and the parked partial sums cost more than the
+// balance gains) and a tile has at most 16 pieces (the last arriver reads them one after the other).
+static inline SplitPlan gemm_split_plan(long long tiles, long long nslab, int grid) {
+  SplitPlan sp{};
+  sp.queue = (int)tiles;
+  const long long smax = std::max<long long>(1, std::min<long long>(16, nslab / 16));
+  if (const char *e = getenv("HQPKKT_SPLIT_PLAN")) {
+    // experiments (tools/split_sweep.sh): units taken from a queue; "% whole, % up to which halves, pieces of the rest,
+    // whole rounds only".  Measured at the C4 shapes: no setting beats the fixed assignment below (78-80 % against 80 %
+    // for W, 64-74 % against 74 % for G): workgroups that take whole tiles at their own times work at 512 different k
+    // and stop sharing operand panels in L2
+    int PW = 45, PH = 80, SR = 8, whole_rounds_only = 1;
+    sscanf(e, "%d,%d,%d,%d", &PW, &PH, &SR, &whole_rounds_only);
+    sp.dynamic = 1;
+    long long a = tiles * PW / 100;
+    if (whole_rounds_only) a = a / grid * grid;
+    sp.dp_rounds = (int)(a / grid), sp.whole = (int)a;
+    const long long b = std::max(a, tiles * PH / 100), sr = std::max<long long>(1, std::min<long long>(SR, smax));
+    if (b > a) sp.begin[sp.nphase] = (int)a, sp.count[sp.nphase] = (int)(b - a), sp.split[sp.nphase] = (int)std::min<long long>(2, smax), sp.nphase++;
+    if (tiles > b) sp.begin[sp.nphase] = (int)b, sp.count[sp.nphase] = (int)(tiles - b), sp.split[sp.nphase] = (int)sr, sp.nphase++;
+    return sp;
+  }
+  sp.dp_rounds = (int)(tiles / grid);
+  long long R = tiles - (long long)sp.dp_rounds * grid, begin = (long long)sp.dp_rounds * grid;
+  sp.whole = (int)begin;
+  while (R > 0 && sp.nphase < 2) {
+    long long s = std::min<long long>(smax, grid / R), r = R;
+    if (s <= 1) {
+      s = 1;
+      if (sp.nphase == 0 && smax >= 2 && R > grid / 2) s = 2, r = grid / 2;
+    }
+    sp.begin[sp.nphase] = (int)begin, sp.count[sp.nphase] = (int)r, sp.split[sp.nphase] = (int)s;
+    sp.nphase++, begin += r, R -= r;
+  }
+  return sp;
+}
+static inline long long gemm_split_plan_pieces(const SplitPlan &sp) {
+  long long n = 0;
+  for (int q = 0; q < sp.nphase; q++) n += (long long)sp.count[q] * sp.split[q];
+  return n;
+}
+// time of the plan in units of one k-slab of one workgroup (what the launch heuristics compare)
+static inline long long gemm_split_plan_depth(const SplitPlan &sp, long long nslab) {
+  long long d = (long long)sp.dp_rounds * nslab;
+  for (int q = 0; q < sp.nphase; q++) d += (nslab + sp.split[q] - 1) / sp.split[q];
+  return d;
+}
+static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
+  if (grid <= 0 || (long long)M * N < 256LL * 256) return false;
+  const long long tm = (M + 127) / 128, tn = (N + 127) / 128, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
+  const long long nslab = (K + GEMM_BK - 1) / GEMM_BK;
+  if (tiles % grid == 0 || tiles >= 16LL * grid) return false;  // even, or the tail does not matter
+  if (nslab < 32) return false;                                 // too shallow to cut
+  // (a CU with one workgroup reaches 92 % of what it does with two: up to 5/8 of the grid one plain round of one
+  // or two workgroups per CU is as fast as cut pieces, without their parked partial sums)
+  return tiles > grid * 5 / 8;
+}
+template <bool DMA, int WGM = 2, int WGN = 2>
+__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn_sk(GemmArgs g, SplitPlan sk) {
   constexpr int BM = 128, BN = 128;
-  using T = GemmTile<BM, BN>;
+  using T = GemmTile<BM, BN, WGM, WGN>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // tiles + one word for the arrival order
   double *As = lds, *Bs = lds + 2 * T::BK * T::LDA;
   unsigned *s_old = (unsigned *)(lds + 2 * T::BK * (T::LDA + T::LDB));
   const int G = gridDim.x, v = xcd_swizzle(blockIdx.x, G);
   const int nslab = (g.K + T::BK - 1) / T::BK;
-  for (int r = 0; r < sk.dp_rounds; r++) {
-    int tm, tn;
-    T::tile_of(g, r * G + v, tm, tn);
-    double4_t acc[T::TM][T::TN];
-#pragma unroll
-    for (int x = 0; x < T::TM; x++)
-#pragma unroll
-      for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
-    if constexpr (DMA)
-      T::accumulate_dma(g, tm * BM, tn * BN, 0, nslab, acc, As, Bs);
-    else
-      T::accumulate(g, tm * BM, tn * BN, 0, nslab, acc, As, Bs);
-    T::epilogue(g, tm, tn, acc);
-  }
-  const int t_first = sk.dp_rounds * G;
-  const long long U = (long long)(sk.tiles - t_first) * nslab, per = U / G, rem = U % G;
-  // workgroup w owns the units [start(w), start(w + 1)); owner(u) is its inverse
-  auto start = [&](long long w) { return w * per + (w < rem ? w : rem); };
-  auto owner = [&](long long uu) { return uu < rem * (per + 1) ? uu / (per + 1) : rem + (uu - rem * (per + 1)) / per; };
-  long long u = start(v);
-  const long long u0 = u, u1 = start(v + 1);
   constexpr int SLOT = BM * BN;
-  while (u < u1) {
-    const int tl = (int)(u / nslab), s0 = (int)(u - (long long)tl * nslab), t = t_first + tl;
-    const int s1 = (int)((long long)nslab < s0 + (u1 - u) ? nslab : s0 + (u1 - u));
+  unsigned long long *stamp = g.stamps ? g.stamps + 16 * (long long)blockIdx.x : nullptr;  // (diagnostic launches only)
+  if (stamp && threadIdx.x == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
+  // Units of work: the whole tiles of the rounds (unit u = tile u), then the pieces of the split phases (phase q:
+  // unit = piece j of tile ti at j * count[q] + ti).  Workgroup w does unit w of every round and phase: its
+  // neighbours in the XCD work on the neighbouring tiles at the same k.  (sk.dynamic: every unit after the first
+  // from ONE counter instead - of the two workgroups of a CU the one that was dispatched first wins the arbitration
+  // for the matrix pipe and runs 1.7 - 2 times as fast as its partner (stamps: profiles/r03_dgemm_stamps.txt), and a
+  // queue lets it take more units; measured, it does not pay: see gemm_split_plan.)  The result does not depend on who
+  // computes what: a tile's pieces are fixed k ranges, summed in their order.
+  const int n_whole = sk.whole;
+  int n_units = n_whole;
+  for (int q = 0; q < sk.nphase; q++) n_units += sk.count[q] * sk.split[q];
+  int r = 0;
+  for (int u = v; u < n_units; r++) {
+    int q = -1;
+    int t = u, s0 = 0, s1 = nslab, cnt = G, pieces = 1, ti = 0, pbase = 0;
+    if (u >= n_whole) {
+      int rel = u - n_whole;
+      q = 0;
+      while (q + 1 < sk.nphase && rel >= sk.count[q] * sk.split[q]) rel -= sk.count[q] * sk.split[q], pbase += sk.count[q] * sk.split[q], q++;
+      cnt = sk.count[q], pieces = sk.split[q];
+      ti = rel % cnt;
+      const int L = (nslab + pieces - 1) / pieces, j = rel / cnt;
+      t = sk.begin[q] + ti, s0 = min(nslab, j * L), s1 = min(nslab, s0 + L);
+    }
+    const int u_now = u;
+    if (sk.dynamic) {  // the next unit, fetched while this one is computed
+      if (threadIdx.x == 0) s_old[1] = (unsigned)G + __hip_atomic_fetch_add(sk.cnt + sk.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {  // unit w of the next round / phase (the plan's phases hold at most G units each)
+      int nu = n_units;
+      if (u + G < n_whole)
+        nu = u + G;
+      else {
+        int base = n_whole, qq = 0;
+        if (u >= n_whole) base += pbase + cnt * pieces, qq = q + 1;
+        for (; qq < sk.nphase && nu == n_units; qq++) {
+          if (v < sk.count[qq] * sk.split[qq]) nu = base + v;
+          base += sk.count[qq] * sk.split[qq];
+        }
+      }
+      if (threadIdx.x == 0) s_old[1] = (unsigned)nu;
+    }
     int tm, tn;
     T::tile_of(g, t, tm, tn);
     double4_t acc[T::TM][T::TN];
@@ -375,16 +465,15 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) 
     else
       T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
     bool finish = true;
-    if (s0 > 0 || s1 < nslab) {
-      // shared tile: the workgroups that own its first and its last unit, and everybody between them
-      const int w_first = (int)owner((long long)tl * nslab), w_last = (int)owner((long long)(tl + 1) * nslab - 1);
-      double *mine = sk.ws + ((long long)v * 2 + (u == u0 ? 0 : 1)) * SLOT;
+    if (stamp && threadIdx.x == 0 && r < 5) stamp[1 + 3 * r] = __builtin_amdgcn_s_memrealtime();
+    if (pieces > 1) {
+      double *mine = sk.ws + (long long)(u_now - n_whole) * SLOT;
 #pragma unroll
       for (int x = 0; x < T::TM; x++)
 #pragma unroll
         for (int y = 0; y < T::TN; y++)
 #pragma unroll
-          for (int rg = 0; rg < 4; rg++) mine[((x * T::TN + y) * 4 + rg) * 256 + threadIdx.x] = acc[x][y][rg];
+          for (int rg = 0; rg < 4; rg++) mine[((x * T::TN + y) * 4 + rg) * T::NT + threadIdx.x] = acc[x][y][rg];
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (threadIdx.x == 0) {
@@ -393,37 +482,81 @@ __global__ void __launch_bounds__(256, 2) k_dgemm_tn_sk(GemmArgs g, StreamK sk) 
         *s_old = __hip_atomic_fetch_add(sk.cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       }
       __syncthreads();
-      finish = *s_old == (unsigned)(w_last - w_first);
+      finish = *s_old == (unsigned)(pieces - 1);
       if (finish) {
         if (threadIdx.x == 0) {
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }
         __syncthreads();
-        // (the own partial comes back from memory as well: one code path, one order)
 #pragma unroll
         for (int x = 0; x < T::TM; x++)
 #pragma unroll
           for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
-        for (int w = w_first; w <= w_last; w++) {
-          // workgroup w's partial of this tile is its first one iff its range starts inside the tile
-          const int slot = start(w) >= (long long)tl * nslab ? 0 : 1;
-          const double *theirs = sk.ws + ((long long)w * 2 + slot) * SLOT;
+        for (int jj = 0; jj < pieces; jj++) {
+          const double *theirs = sk.ws + (long long)(pbase + jj * cnt + ti) * SLOT;
 #pragma unroll
           for (int x = 0; x < T::TM; x++)
 #pragma unroll
             for (int y = 0; y < T::TN; y++)
 #pragma unroll
-              for (int rg = 0; rg < 4; rg++) acc[x][y][rg] += theirs[((x * T::TN + y) * 4 + rg) * 256 + threadIdx.x];
+              for (int rg = 0; rg < 4; rg++) acc[x][y][rg] += theirs[((x * T::TN + y) * 4 + rg) * T::NT + threadIdx.x];
         }
       }
       __syncthreads();  // s_old is rewritten at the next shared tile
     }
+    if (stamp && threadIdx.x == 0 && r < 5) stamp[2 + 3 * r] = __builtin_amdgcn_s_memrealtime();
     if (finish) T::epilogue(g, tm, tn, acc);
-    u += s1 - s0;
+    if (stamp && threadIdx.x == 0 && r < 5) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      stamp[3 + 3 * r] = __builtin_amdgcn_s_memrealtime();
+    }
+    __syncthreads();
+    u = (int)s_old[1];
+    __syncthreads();  // (s_old[1] is rewritten at the top of the next unit)
   }
 }
-static inline size_t gemm_sk_lds_bytes() { return gemm_lds_bytes(128, 128) + 16; }
+static inline size_t gemm_sk_lds_bytes() { return gemm_lds_bytes(128, 128) + 16; }  // + two words: arrival order, next unit
+
+// Host: the variants of the 128 x 128 product.  0: operands staged through registers, 4 waves (round 2's loop, kept
+// for comparisons: HQPKKT_NO_LDSDMA); 1: LDS-DMA, 2 x 2 waves of 64 x 64; 2: LDS-DMA, 2 x 4 waves of 64 x 32 (default)
+enum { GEMM_REG4 = 0, GEMM_DMA4 = 1, GEMM_DMA8 = 2 };
+static inline void gemm_launch_plain(int variant, unsigned tiles, hipStream_t s, const GemmArgs &g) {
+  if (variant == GEMM_DMA8)
+    k_dgemm_tn<128, 128, true, 2, 4><<<tiles, 512, gemm_lds_bytes(128, 128), s>>>(g);
+  else if (variant == GEMM_DMA4)
+    k_dgemm_tn<128, 128, true><<<tiles, 256, gemm_lds_bytes(128, 128), s>>>(g);
+  else
+    k_dgemm_tn<128, 128><<<tiles, 256, gemm_lds_bytes(128, 128), s>>>(g);
+}
+static inline void gemm_launch_split(int variant, int grid, hipStream_t s, const GemmArgs &g, const SplitPlan &sk) {
+  if (variant == GEMM_DMA8)
+    k_dgemm_tn_sk<true, 2, 4><<<grid, 512, gemm_sk_lds_bytes(), s>>>(g, sk);
+  else if (variant == GEMM_DMA4)
+    k_dgemm_tn_sk<true><<<grid, 256, gemm_sk_lds_bytes(), s>>>(g, sk);
+  else
+    k_dgemm_tn_sk<false><<<grid, 256, gemm_sk_lds_bytes(), s>>>(g, sk);
+}
+static inline hipError_t gemm_set_attributes() {
+  hipError_t e = hipSuccess;
+  auto set = [&](const void *f, size_t bytes) {
+    const hipError_t r = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e == hipSuccess) e = r;
+  };
+  set((const void *)k_dgemm_tn<128, 128>, gemm_lds_bytes(128, 128));
+  set((const void *)k_dgemm_tn<128, 128, true>, gemm_lds_bytes(128, 128));
+  set((const void *)k_dgemm_tn<128, 128, true, 2, 4>, gemm_lds_bytes(128, 128));
+  set((const void *)k_dgemm_tn<64, 64>, gemm_lds_bytes(64, 64));
+  set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());
+  set((const void *)k_dgemm_tn_sk<true>, gemm_sk_lds_bytes());
+  set((const void *)k_dgemm_tn_sk<true, 2, 4>, gemm_sk_lds_bytes());
+  return e;
+}
+static inline int gemm_variant_from_env() {
+  if (getenv("HQPKKT_NO_LDSDMA")) return GEMM_REG4;
+  const char *w = getenv("HQPKKT_DGEMM_WAVES");
+  return (w && atoi(w) == 4) ? GEMM_DMA4 : GEMM_DMA8;
+}
 
 // ---------------------------------------------------------------------------------------
 // H = Q + C'(Z/W)C of one stage added into the dense block (term lists as in the REDUCED

@@ -13,6 +13,7 @@ struct StagedDev {
   DBuf<stg::DynDesc> dyn_desc;  // dense dynamics: per stage (K+1) what k_st_dyn_ax / _aty need
   DBuf<double> dyn_x1, dyn_x2;  // A_dyn' dy (n), A_dyn dx (ndyn)
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
+  int gemm_variant = stg::GEMM_DMA8;
   DBuf<double> sk_ws;           // stream-K dgemm: two partial tiles per workgroup
   DBuf<unsigned> sk_cnt;
   int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
@@ -85,28 +86,24 @@ inline StagePtr stage_ptr(StagedDev &d, int k) {
 int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = true) {
   if (g.M <= 0 || g.N <= 0) return 0;
   StagedDev *d = h->sd;
-  // (allow_sk false: launches of the second stream - the stream-K workspace belongs to the first)
-  const int skg = d && allow_sk ? stg::gemm_streamk_grid(g.M, g.N, g.K, g.lower, d->sk_grid) : 0;
-  const bool big = skg > 0 || stg::gemm_big_tiles(g.M, g.N, g.lower);
+  // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
+  const bool split = d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid);
+  const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
   const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
   if (g.lower && big && d && tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
   if (d && d->zeros.p) g.zeros = d->zeros.p;
-  if (skg > 0 && tiles <= d->sk_tiles) {
-    // tile count that does not fill the chip evenly: even shares of the (tile, k-slab) units (k_dgemm_tn_sk)
+  if (split && tiles <= d->sk_tiles) {
+    // tile count that does not fill the chip evenly: whole rounds, then the k ranges of the rest cut (k_dgemm_tn_sk)
     HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
-    stg::StreamK sk{d->sk_ws.p, d->sk_cnt.p, (int)tiles, stg::gemm_streamk_dp_rounds(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)};
-    if (g.zeros)
-      KLAUNCH(h, cls, stg::k_dgemm_tn_sk<true><<<skg, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
-    else
-      KLAUNCH(h, cls, stg::k_dgemm_tn_sk<false><<<skg, 256, stg::gemm_sk_lds_bytes(), h->stream>>>(g, sk));
+    stg::SplitPlan sk = stg::gemm_split_plan(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid);
+    sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
+    KLAUNCH(h, cls, stg::gemm_launch_split(d->gemm_variant, d->sk_grid, h->stream, g, sk));
     return 0;
   }
-  if (big && g.zeros)
-    KLAUNCH(h, cls, stg::k_dgemm_tn<128, 128, true><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
-  else if (big)
-    KLAUNCH(h, cls, stg::k_dgemm_tn<128, 128><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(128, 128), h->stream>>>(g));
+  if (big)
+    KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g));
   else
     KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
   return 0;
@@ -234,7 +231,8 @@ static int staged_upload(hqpkkt_t *h) {
     }
     if ((e = d.dyn_desc.upload(dd)) || (e = d.dyn_x1.alloc(n)) || (e = d.dyn_x2.alloc(P.ndyn))) return e;
   }
-  if (!getenv("HQPKKT_NO_LDSDMA")) {  // (the register-staged loop stays selectable for comparisons)
+  d.gemm_variant = stg::gemm_variant_from_env();
+  if (d.gemm_variant != stg::GEMM_REG4) {  // (the register-staged loop stays selectable for comparisons)
     if ((e = d.zeros.alloc(256))) return e;
     HIPCHK(hipMemset(d.zeros.p, 0, sizeof(double) * 256));
   } else
@@ -246,15 +244,20 @@ static int staged_upload(hqpkkt_t *h) {
   {  // stream-K grid: two workgroups per CU, if some product of the recursion has more tiles than that
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->opts.device));
-    long long tmax = 0;
+    long long tmax = 0, pmax = 0;  // most tiles / most cut pieces of a product of this handle (column slices have fewer)
     for (int k = 0; k < P.K; k++) {
       const long long t1 = (P.nk[k + 1] + 127) / 128, t2 = (P.nk[k] + P.mk[k] + 127) / 128;
       tmax = std::max(tmax, t1 * t2);
+      if (cus > 0)
+        for (long long t : {t1 * t2, t2 * (t2 + 1) / 2, t1 * (t1 + 1) / 2})
+          pmax = std::max(pmax, stg::gemm_split_plan_pieces(stg::gemm_split_plan(t, (std::max(P.nk[k + 1], P.nk[k]) + stg::GEMM_BK - 1) / stg::GEMM_BK, 2 * cus)));
     }
+    pmax = pmax * 5 / 4 + 64;  // (plans of smaller products of the same stage: never more pieces than 8 per tile of tmax)
+    pmax = std::max(pmax, 16 * tmax);
     d.sk_grid = 0, d.sk_tiles = (int)tmax;
     if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
       d.sk_grid = 2 * cus;
-      if ((e = d.sk_ws.alloc((size_t)d.sk_grid * 2 * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_tiles + 4))) return e;
+      if ((e = d.sk_ws.alloc((size_t)std::max<long long>(pmax, 1) * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_tiles + 4))) return e;
     }
   }
   // (measured on one MI355X at C4 size: 142 ms against 136 ms per 20 stages WITH the second stream - the
@@ -288,16 +291,7 @@ static int staged_upload(hqpkkt_t *h) {
   {
     std::lock_guard<std::mutex> lk(attr_mutex);
     if (!attr_gemm) {
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)stg::gemm_lds_bytes(128, 128)));
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<64, 64>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)stg::gemm_lds_bytes(64, 64)));
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn<128, 128, true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)stg::gemm_lds_bytes(128, 128)));
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)stg::gemm_sk_lds_bytes()));
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_dgemm_tn_sk<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                 (int)stg::gemm_sk_lds_bytes()));
+      HIPCHK(stg::gemm_set_attributes());
       attr_gemm = true;
     }
     if (d.lds_small > attr_small) {

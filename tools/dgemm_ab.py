@@ -10,6 +10,7 @@ for (M, N, K, lo) in [(1024,1024,1024,0),(2048,2048,2048,0),(4096,4096,4096,0),(
     ms, tf, err = ipmatrix.bench_dgemm(M, N, K, lo, lo, reps=5)
     print(f"dgemm M={M} N={N} K={K} lower={lo}: {ms:.3f} ms  {tf:.2f} TFLOP/s  ({tf/78.6*100:.1f}%% of 78.6)  err {err:.1e}", flush=True)
 ''' % ROOT
-for name, env in (("lds-dma", {}), ("register-staged", {"HQPKKT_NO_LDSDMA": "1"})):
+for name, env in (("lds-dma, 2 x 4 waves of 64 x 32 (4 waves per SIMD)", {}), ("lds-dma, 2 x 2 waves of 64 x 64 (2 waves per SIMD)", {"HQPKKT_DGEMM_WAVES": "4"}),
+                  ("register-staged, 2 x 2 waves", {"HQPKKT_NO_LDSDMA": "1"})):
     print("==", name, flush=True)
     subprocess.run([sys.executable, "-c", CODE], env=dict(os.environ, **env))
