@@ -28,6 +28,15 @@ using kktdev::mfma_f64;
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
+// One system over several ranks: where the strips of a stage's G_xx lie in the exchange buffer.  Rank p owns the
+// state columns [cut[p], cut[p+1]) (multiples of 128, so a tile lies inside one strip) and delivers the rows
+// i >= cut[p] of them, row-major with leading dimension cut[p+1] - cut[p], at xbuf + off[p].
+struct StripTab {
+  int nranks;
+  int cut[17];
+  long long off[17];
+};
+
 struct GemmArgs {
   const double *A;
   long long lda;  // K x M, row-major (k-major)
@@ -46,6 +55,8 @@ struct GemmArgs {
                         // null: row by row
   const double *zeros;  // >= 128 zero doubles (16-byte aligned): the source of the operand rows k >= K when the
                         // 128 x 128 kernels stage their operands by LDS-DMA; null: staging through registers
+  const StripTab *strips;      // with beta != 0: Cin(i, j), i >= j, is read from the strips of the exchange buffer `Cin`
+                               // (the rank-q update of a sharded stage takes G_xx straight from what the ranks sent)
   unsigned long long *stamps;  // diagnostic builds of the plain kernel only (hqpkkt_debug_dgemm): 4 constant-clock
                                // (100 MHz) time stamps per workgroup: start, operands of the first slab in LDS, end of
                                // the k loop, end of the epilogue; null in every product of the engine
@@ -269,6 +280,15 @@ struct GemmTile {
     const int lr = lane & 15, lk = lane >> 4;
     const int i0 = tm * BM, j0 = tn * BN;
     const bool diag = g.lower && tm == tn;
+    const double *cin = g.Cin;
+    long long ldcin = g.ldcin;
+    if (g.strips && g.beta != 0.0) {  // the strip that holds the columns of this tile
+      int p = 0;
+      while (p + 1 < g.strips->nranks && g.strips->cut[p + 1] <= j0) p++;
+      const int c0 = g.strips->cut[p];
+      ldcin = g.strips->cut[p + 1] - c0;
+      cin = g.Cin + g.strips->off[p] - ((long long)c0 * ldcin + c0);
+    }
 #pragma unroll
     for (int x = 0; x < TM; x++)
 #pragma unroll
@@ -279,7 +299,7 @@ struct GemmTile {
           if (i >= g.M || j >= g.N) continue;
           if (diag && g.mirror && i < j) continue;
           double v = g.alpha * acc[x][y][rg];
-          if (g.beta != 0.0) v += g.beta * g.Cin[(long long)i * g.ldcin + j];
+          if (g.beta != 0.0) v += g.beta * cin[(long long)i * ldcin + j];
           g.C[(long long)i * g.ldc + j] = v;
           if (g.mirror && i != j) g.C[(long long)j * g.ldc + i] = v;
         }
@@ -1429,36 +1449,15 @@ __global__ void k_st_copy(int n, const double *__restrict__ s, double *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// One system over several ranks: rank p computes the columns [c0, c1) of the lower triangle of V_k
-// (rows c0 .. n-1: a strip (n - c0) x (c1 - c0), row-major in its slot of the exchange buffer); after
-// the all-gather every rank writes all strips, and their mirror images, into its V_k.
+// One system over several ranks: rank p computes the columns [c0, c1) of the lower triangle of G_xx (rows c0 ..
+// n-1: a strip (n - c0) x (c1 - c0), row-major in its part of the exchange buffer); after the exchange every rank
+// forms V_k = G_xx - Y' Rm from all strips (GemmArgs::strips: unpack, rank-q update and mirror in one pass).
 __global__ void __launch_bounds__(256) k_st_pack(const double *__restrict__ V, long long ldv, int n, int c0, int c1,
                                                  double *__restrict__ slot) {
   const int w = c1 - c0;
   for (int i = c0 + blockIdx.x; i < n; i += gridDim.x)
     for (int jj = threadIdx.x; jj < w; jj += blockDim.x) slot[(long long)(i - c0) * w + jj] = V[(long long)i * ldv + c0 + jj];
 }
-struct UnpackArgs {
-  double *V;
-  long long ldv;
-  int n, nranks;
-  const double *xbuf;
-  long long off[17];  // start of every rank's strip in xbuf
-  int cut[17];        // nranks + 1 column cuts (nranks <= 16)
-};
-__global__ void __launch_bounds__(256) k_st_unpack(UnpackArgs a) {
-  const int p = blockIdx.y, c0 = a.cut[p], c1 = a.cut[p + 1], w = c1 - c0;
-  const double *slot = a.xbuf + a.off[p];
-  for (int i = c0 + blockIdx.x; i < a.n; i += gridDim.x)
-    for (int jj = threadIdx.x; jj < w; jj += blockDim.x) {
-      const int j = c0 + jj;
-      if (i < j) continue;  // upper part of the diagonal block: not computed
-      const double v = slot[(long long)(i - c0) * w + jj];
-      a.V[(long long)i * a.ldv + j] = v;
-      if (i != j) a.V[(long long)j * a.ldv + i] = v;
-    }
-}
-
 // ---------------------------------------------------------------------------------------
 // Dense dynamics (hqpkkt_set_values_staged): the products with the dynamics rows of A that
 // residuum() needs, all stages in one launch (blockIdx.y = stage)

@@ -12,6 +12,7 @@ struct StagedDev {
   DBuf<stg::HTerm> h_terms;
   DBuf<stg::DynDesc> dyn_desc;  // dense dynamics: per stage (K+1) what k_st_dyn_ax / _aty need
   DBuf<double> dyn_x1, dyn_x2;  // A_dyn' dy (n), A_dyn dx (ndyn)
+  DBuf<stg::StripTab> strip_tabs;  // sharded: per stage where the ranks' strips of G_xx lie in the exchange buffer
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
   DBuf<double> sk_ws;           // stream-K dgemm: two partial tiles per workgroup
@@ -51,6 +52,7 @@ struct StagedDev {
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
+    strip_tabs.release();
     for (auto &e : tri_maps) e.second->release(), delete e.second;
     tri_maps.clear();
     if (stream2) (void)hipStreamDestroy(stream2), stream2 = nullptr;
@@ -169,7 +171,9 @@ static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = fa
       const int *cut = &P.xcut[(size_t)k * (P.shard_count + 1)];
       const long long wd = cut[P.shard_rank + 1] - cut[P.shard_rank], c0 = cut[P.shard_rank];
       const long long np = P.nk[k + 1], nz = P.nk[k] + P.mk[k], mm = P.mk[k], nn = P.nk[k], q = P.qmax[k];
-      fl += 2 * np * np * (wd + mm) + 2 * np * wd * (nz - c0) - np * wd * wd + 2 * np * mm * nz + 2 * q * wd * (nn - c0);
+      // own columns of W and of the lower triangle of G_xx; replicated: the control columns of W, the control rows of
+      // G and the rank-q update of the whole block
+      fl += 2 * np * np * wd + 2 * np * wd * (nn - c0) - np * wd * wd + 2 * np * np * mm + 2 * np * mm * nz + q * nn * nn;
     }
     h->st.bytes_exchange_factor = bytes, h->st.flops_local = fl, h->st.n_exchange_blocks = P.K;
   }
@@ -263,12 +267,28 @@ static int staged_upload(hqpkkt_t *h) {
   // (measured on one MI355X at C4 size: 142 ms against 136 ms per 20 stages WITH the second stream - the
   // separate product for the control rows of G and the contention cost more than the hidden chain; so it is
   // off unless HQPKKT_OVERLAP is set.  When sharded the separate product exists anyway.)
-  if (!d.stream2 && getenv("HQPKKT_OVERLAP")) {
+  if (!d.stream2 && (getenv("HQPKKT_OVERLAP") || P.sharded)) {
     HIPCHK(hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking));
     HIPCHK(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
     HIPCHK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
   }
-  d.overlap = d.stream2 != nullptr;
+  d.overlap = d.stream2 != nullptr && getenv("HQPKKT_OVERLAP") != nullptr;
+  if (P.sharded) {
+    // (exact strip sizes behind the stream-ordered transport, slots padded to the largest strip behind the callback)
+    const bool exact = h->xchg_sfn != nullptr;
+    std::vector<stg::StripTab> tabs(P.K + 1);
+    for (int k = 0; k < P.K; k++) {
+      const int *cut = &P.xcut[(size_t)k * (P.shard_count + 1)];
+      stg::StripTab &t = tabs[k];
+      t.nranks = P.shard_count;
+      long long off = 0;
+      for (int p = 0; p <= P.shard_count; p++) {
+        t.cut[p] = cut[p];
+        if (p < P.shard_count) t.off[p] = exact ? off : (long long)p * P.xslot[k], off += (long long)(P.nk[k] - cut[p]) * (cut[p + 1] - cut[p]);
+      }
+    }
+    if ((e = d.strip_tabs.upload(tabs))) return e;
+  }
   // orders of the tiles of the triangular products (G, V; their column slices when sharded)
   for (int k = 0; k < P.K; k++) {
     std::vector<int> sizes = {P.nk[k] + P.mk[k], P.nk[k]};
@@ -347,17 +367,117 @@ static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, co
   return 0;
 }
 
+// One stage of the backward recursion when ONE system is sharded over several ranks.
+// Rank p owns the state columns [c0, c1) of the two large products; everything control-sized is computed by every
+// rank on identical data.  Two streams:
+//   sA (the handle's): W[:, c0:c1) = V+ F[:, c0:c1)  ->  the strip of the lower triangle of G_xx = fx' W_x below its
+//       first column (+ H_xx)  ->  pack  ->  the strips of all ranks are exchanged (stream-ordered broadcasts of the
+//       exact sizes, or one all-gather of padded slots behind the drained-stream callback)
+//   sB: W_u = V+ f_u  ->  the control rows of G (G_ux, G_uu) = W_u' F (+ H's control part)  ->  carried rows N = B+ F
+//       ->  rank decision, K^-1 (k_st_small), Y and the carried rows (k_st_wide)  ->  Rm = K^-1 Y, refined against K
+// and, joined: V_k = G_xx - Y' Rm over the WHOLE lower triangle, mirrored, with G_xx read straight from the strips in
+// the exchange buffer (GemmArgs::strips) - one pass that is unpack, rank-q update and mirror at once.  The gather
+// (n^2 / 2 doubles per stage) therefore runs beside the control-sized chain of the same stage instead of between
+// two stages, and nothing of that chain is on the path of the large products.
+static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots);
+static int staged_stage_sharded(hqpkkt_t *h, int k) {
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  const int NR = P.shard_count, RK = P.shard_rank;
+  StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
+  const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
+  const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k], q = P.qmax[k];
+  const int *cut = &P.xcut[(size_t)k * (NR + 1)];
+  const int c0 = cut[RK], c1 = cut[RK + 1], wd = c1 - c0;
+  const long long ldf = P.ldf[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k];
+  double *G = d.misc.p + P.oG, *W = d.misc.p + P.oW, *xb = d.misc.p + P.oX;
+  hipStream_t sA = h->stream, sB = d.stream2 ? d.stream2 : h->stream;
+  struct StreamGuard {  // launches go to h->stream: back to the first stream on every way out
+    hqpkkt_t *h;
+    hipStream_t s;
+    ~StreamGuard() { h->stream = s; }
+  } guard{h, sA};
+  const bool two = sB != sA;
+  int e;
+  if (two) {
+    HIPCHK(hipEventRecord(d.ev_fork, sA));
+    HIPCHK(hipStreamWaitEvent(sB, d.ev_fork, 0));
+  }
+  const int ne_x = P.h_mid[k] - P.h_ptr[k], ne_u = P.h_ptr[k + 1] - P.h_mid[k];
+  auto add_h = [&](int first, int count) {
+    if (count)
+      KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(count), 256, 0, h->stream>>>(count, d.h_dst.p + first, d.h_tptr.p + first, d.h_terms.p,
+                                                                                 h->vals.p, h->wt.p, G, 1));
+  };
+  // ---- sB: the control-sized chain (the workspace of the cut products belongs to sA: plain kernels here)
+  h->stream = sB;
+  if (mm > 0) {
+    if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + nn, ldf, nullptr, 0, W + nn, ldf, np, mm, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two))) return e;
+    if ((e = st_gemm(h, stg::GemmArgs{W + nn, ldf, sp.F, ldf, nullptr, 0, G + (long long)nn * ldg, ldg, mm, nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)))
+      return e;
+    add_h(P.h_mid[k], ne_u);
+  }
+  if (P.cap[k + 1] > 0 &&
+      (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, ldf, nullptr, 0, sp.N + (size_t)ek * P.ldn[k], P.ldn[k], P.cap[k + 1], nz, np,
+                                    1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !two)))
+    return e;
+  {
+    stg::SmallArgs sa{G, ldg, nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
+                      P.capn[k], P.cap[k], q, h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<<<1, 256, d.lds_small, h->stream>>>(sa));
+    stg::WideArgs wa{G, ldg, nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], q, sp.T, P.ldt[k], sp.dyn, sp.Y, ldy, sp.BT, P.ldb[k]};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
+  }
+  if (q > 0) {  // Rm = K^-1 Y and one round of refinement against K (see staged_run_factor)
+    double *Res = d.misc.p + P.oRes;
+    if ((e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, ldy, nullptr, 0, sp.Rm, ldy, q, nn, q, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !two)) ||
+        (e = st_gemm(h, stg::GemmArgs{sp.Kmat, P.ldq[k], sp.Rm, ldy, sp.Y, ldy, Res, ldy, q, nn, q, -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !two)) ||
+        (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], Res, ldy, sp.Rm, ldy, sp.Rm, ldy, q, nn, q, 1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !two)))
+      return e;
+  }
+  if (two) HIPCHK(hipEventRecord(d.ev_join, sB));
+  // ---- sA: the large products of this rank's columns, and the exchange
+  h->stream = sA;
+  if (wd > 0) {
+    if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + c0, ldf, nullptr, 0, W + c0, ldf, np, wd, np, 1.0, 0.0, 0, 0}))) return e;
+    // diagonal block (lower tiles) and the rows below it
+    if ((e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + (long long)c0 * ldg + c0, ldg, wd, wd, np, 1.0, 0.0, 1, 0}))) return e;
+    if (nn > c1 &&
+        (e = st_gemm(h, stg::GemmArgs{sp.F + c1, ldf, W + c0, ldf, nullptr, 0, G + (long long)c1 * ldg + c0, ldg, nn - c1, wd, np, 1.0, 0.0, 0, 0})))
+      return e;
+  }
+  add_h(P.h_ptr[k], ne_x);  // (entries outside this rank's strip land in parts of G nobody reads)
+  const stg::StripTab *tab = d.strip_tabs.p + k;
+  const bool exact = h->xchg_sfn != nullptr;
+  long long off_mine = 0;
+  for (int p = 0; p < RK; p++) off_mine += (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]);
+  if (!exact) off_mine = (long long)RK * P.xslot[k];
+  if (wd > 0)
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_pack<<<std::min(nn - c0, 4096), 256, 0, sA>>>(G, ldg, nn, c0, c1, xb + off_mine));
+  if (exact) {
+    long long off = 0;
+    for (int p = 0; p < NR; p++) {
+      const long long len = (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]);
+      if ((e = exchange(h, HQPKKT_XCHG_BCAST_BASE + p, xb + off, len, 1))) return e;
+      off += len;
+    }
+  } else if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR)))
+    return e;
+  if (two) HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
+  // V_k = G_xx - Y' Rm: lower tiles, mirrored; G_xx from the strips
+  stg::GemmArgs gu{sp.Y, ldy, sp.Rm, ldy, xb, 0, sp.V, ldv, nn, nn, q, -1.0, 1.0, 1, 1};
+  gu.strips = tab;
+  return st_gemm(h, gu, KC_ST_GEMM_UPD);  // (q = 0, a stage without controls: V_k = G_xx, the k loop is empty)
+}
+
 // Hqp_IpLQDOCP::factor (hqp/Hqp_IpLQDOCP.C:796-862): W^-1 Z, C'(W^-1 Z)C, then the backward
 // recursion over the stages (ExRiccatiFactorSc, :1794-1999)
-static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots);
-
 static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
   Analysis &an = h->an;
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;
   hipStream_t s = h->stream;
   const int m = an.m, K = P.K;
-  const int NR = P.shard_count, RK = P.shard_rank;
   int e;
   HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 128, s));
   if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
@@ -375,12 +495,13 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_last<<<nblk(std::max(nK, 1)), 256, 0, s>>>(nK, eK, P.cap[K], sp.N, P.ldn[K], sp.BT, P.ldb[K], sp.dyn));
   }
   for (int k = K - 1; k >= 0; k--) {
+    if (P.sharded) {
+      if ((e = staged_stage_sharded(h, k))) return e;
+      continue;
+    }
     StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
     const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
     const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k];
-    // this rank's state columns [c0, c1) of the products (everything when not sharded)
-    const int *cut = P.sharded ? &P.xcut[(size_t)k * (NR + 1)] : nullptr;
-    const int c0 = cut ? cut[RK] : 0, c1 = cut ? cut[RK + 1] : nn, wd = c1 - c0;
     const long long ldf = P.ldf[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1];
     // The control-sized chain of the stage on the second stream, beside the large product G_xx (needs the
     // control columns to start at an even column: 16-byte loads of W + n)
@@ -400,35 +521,18 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
                                                                                    h->vals.p, h->wt.p, G, 1));
     };
     // ---- W
-    if (!P.sharded) {
-      if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldf, nullptr, 0, W, ldf, np, nz, np, 1.0, 0.0, 0, 0}))) return e;
-    } else {
-      // own columns of W, and on every rank its control columns
-      if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + c0, ldf, nullptr, 0, W + c0, ldf, np, wd, np, 1.0, 0.0, 0, 0})))
-        return e;
-      if (mm > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + nn, ldf, nullptr, 0, W + nn, ldf, np, mm, np, 1.0, 0.0, 0, 0})))
-        return e;
-    }
+    if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldf, nullptr, 0, W, ldf, np, nz, np, 1.0, 0.0, 0, 0}))) return e;
     if (ovl) {
       HIPCHK(hipEventRecord(d.ev_fork, sA));
       HIPCHK(hipStreamWaitEvent(sB, d.ev_fork, 0));
     }
     // ---- G: the state part (large) on the first stream ...
-    if (!P.sharded && !ovl) {
+    if (!ovl) {
       // G = F'W (lower tiles of the whole (n+m) x (n+m) block)
       if ((e = st_gemm(h, stg::GemmArgs{sp.F, ldf, W, ldf, nullptr, 0, G, ldg, nz, nz, np, 1.0, 0.0, 1, 0}))) return e;
       add_h(P.h_ptr[k], ne_x + ne_u);
     } else {
-      if (!P.sharded) {
-        if ((e = st_gemm(h, stg::GemmArgs{sp.F, ldf, W, ldf, nullptr, 0, G, ldg, nn, nn, np, 1.0, 0.0, 1, 0}))) return e;
-      } else {
-        // own columns of the lower triangle of Gxx: diagonal block + the rows below it
-        if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + c0 * ldg + c0, ldg, wd, wd, np, 1.0, 0.0, 1, 0})))
-          return e;
-        if (wd > 0 && nn > c1 &&
-            (e = st_gemm(h, stg::GemmArgs{sp.F + c1, ldf, W + c0, ldf, nullptr, 0, G + c1 * ldg + c0, ldg, nn - c1, wd, np, 1.0, 0.0, 0, 0})))
-          return e;
-      }
+      if ((e = st_gemm(h, stg::GemmArgs{sp.F, ldf, W, ldf, nullptr, 0, G, ldg, nn, nn, np, 1.0, 0.0, 1, 0}))) return e;
       add_h(P.h_ptr[k], ne_x);
       // ... the control rows of G (Gux, Guu) = W_u' F and H's control part on the second
       on_b();
@@ -471,39 +575,9 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
       HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
     }
     // V = Gxx - Y'Rm (lower tiles, mirrored)
-    if (!P.sharded) {
-      if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1},
-                       KC_ST_GEMM_UPD)))
-        return e;
-    } else {
-      const long long ldy = P.ldy[k], ldv = P.ldv[k];
-      if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sp.Y + c0, ldy, sp.Rm + c0, ldy, G + c0 * ldg + c0, ldg, sp.V + c0 * ldv + c0, ldv, wd, wd,
-                                                 P.qmax[k], -1.0, 1.0, 1, 0}, KC_ST_GEMM_UPD)))
-        return e;
-      if (wd > 0 && nn > c1 &&
-          (e = st_gemm(h, stg::GemmArgs{sp.Y + c1, ldy, sp.Rm + c0, ldy, G + c1 * ldg + c0, ldg, sp.V + c1 * ldv + c0, ldv, nn - c1, wd,
-                                        P.qmax[k], -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD)))
-        return e;
-      // the strips of V_k: pack, gather, unpack + mirror.  With the stream-ordered transport one broadcast
-      // per rank with the strip's own size (back to back: one RCCL group); behind the drained-stream callback
-      // ONE all-gather of slots padded to the largest strip
-      double *xb = d.misc.p + P.oX;
-      stg::UnpackArgs ua{sp.V, ldv, nn, NR, xb, {0}, {0}};
-      const bool exact = h->xchg_sfn != nullptr;
-      long long off = 0;
-      for (int p = 0; p <= NR; p++) {
-        ua.cut[p] = cut[p];
-        if (p < NR) ua.off[p] = exact ? off : (long long)p * P.xslot[k], off += (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]);
-      }
-      if (wd > 0)
-        KLAUNCH(h, KC_ST_VEC, stg::k_st_pack<<<std::min(nn - c0, 4096), 256, 0, s>>>(sp.V, ldv, nn, c0, c1, xb + ua.off[RK]));
-      if (exact) {
-        for (int p = 0; p < NR; p++)
-          if ((e = exchange(h, HQPKKT_XCHG_BCAST_BASE + p, xb + ua.off[p], (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]), 1))) return e;
-      } else if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR)))
-        return e;
-      KLAUNCH(h, KC_ST_VEC, stg::k_st_unpack<<<dim3(std::min(nn, 4096), NR), 256, 0, s>>>(ua));
-    }
+    if ((e = st_gemm(h, stg::GemmArgs{sp.Y, P.ldy[k], sp.Rm, P.ldy[k], G, P.ldg[k], sp.V, P.ldv[k], nn, nn, P.qmax[k], -1.0, 1.0, 1, 1},
+                     KC_ST_GEMM_UPD)))
+      return e;
   }
   {
     StagePtr s0 = stage_ptr(d, 0);

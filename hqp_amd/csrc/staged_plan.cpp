@@ -232,7 +232,10 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       double tot = 0.0;
       for (int b = 0; b < nb; b++) {
         const double c0 = 128.0 * b, wdt = std::min<double>(128.0, nn - c0);
-        cost[b] = wdt * (2.0 * np * np + 2.0 * np * (nz - c0) + 2.0 * q * (nn - c0));
+        // W strip (all rows of V+) and the strip of the lower triangle of G_xx below its first column (the rank-q
+        // update is applied after the gather, to the whole block, by every rank)
+        cost[b] = wdt * (2.0 * np * np + 2.0 * np * (nn - c0));
+        (void)q, (void)nz;
         tot += cost[b];
       }
       int *cut = &xcut[(size_t)k * (shard_count + 1)];
