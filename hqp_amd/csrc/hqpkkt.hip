@@ -2070,7 +2070,7 @@ __global__ void k_gemm_check(stg::GemmArgs g, int nsample, double *err) {
 }  // namespace
 int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, int reps, double *ms, double *max_err) {
   if (M <= 0 || N <= 0 || K < 0 || reps <= 0) return HQPKKT_E_RANGE;
-  if (lower && M != N) return HQPKKT_E_RANGE;
+  if (lower && M < N) return HQPKKT_E_RANGE;  // (M > N: the column strip of a lower triangle)
   int ndev = 0;
   if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return HQPKKT_E_DEVICE;
   HIPCHK(hipSetDevice(device));
@@ -2101,7 +2101,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && stg::gemm_use_split(M, N, K, lower, skg);
   const bool big = use_sk || stg::gemm_big_tiles(M, N, lower);
   const int b = big ? 128 : 64;
-  const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
+  const long long tiles = stg::gemm_tiles(M, N, b, lower);
   (void)stg::gemm_set_attributes();
   // stream-K form where the engine would use it (staged_host.hip.h, st_gemm)
   double *skws = nullptr;

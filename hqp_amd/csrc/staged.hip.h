@@ -63,14 +63,17 @@ struct GemmArgs {
 };
 
 static const int GEMM_BK = 16;
+// number of b x b tiles of an M x N product; lower: only tiles with tile row >= tile column (M >= N: a triangle of
+// ceil(N / b) tile columns on top of a rectangle - the column strip of a lower triangle that one rank computes)
+static inline long long gemm_tiles(int M, int N, int b, int lower) {
+  const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b;
+  return lower ? tn * (tn + 1) / 2 + (tm > tn ? (tm - tn) * tn : 0) : tm * tn;
+}
 static inline size_t gemm_lds_bytes(int bm, int bn) { return sizeof(double) * 2 * GEMM_BK * (size_t)(bm + 16 + bn + 16); }
 
 // 128 x 128 tiles (16 flop per operand byte) once they fill the chip: 256 CUs x 2 workgroups;
 // 64 x 64 tiles (four times as many workgroups) below
-static inline bool gemm_big_tiles(int M, int N, int lower) {
-  const long long tm = (M + 127) / 128, tn = (N + 127) / 128;
-  return (lower ? tm * (tm + 1) / 2 : tm * tn) >= 384;
-}
+static inline bool gemm_big_tiles(int M, int N, int lower) { return gemm_tiles(M, N, 128, lower) >= 384; }
 
 // The split form (k_dgemm_tn_sk, below) pays where whole rounds of 128 x 128 tiles would leave slots idle
 // and the product is deep enough to be cut.  Returns true when the launch should use it with the whole
@@ -109,10 +112,16 @@ struct GemmTile {
       const int e = g.tile_map[t];
       tm = e >> 16, tn = e & 0xffff;
     } else if (g.lower) {
-      tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
-      while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
-      while (tm * (tm + 1) / 2 > t) tm--;
-      tn = t - tm * (tm + 1) / 2;
+      const int tcols = (g.N + BN - 1) / BN, tri = tcols * (tcols + 1) / 2;
+      if (t < tri) {
+        tm = (int)((sqrtf(8.0f * (float)t + 1.0f) - 1.0f) * 0.5f);
+        while ((tm + 1) * (tm + 2) / 2 <= t) tm++;
+        while (tm * (tm + 1) / 2 > t) tm--;
+        tn = t - tm * (tm + 1) / 2;
+      } else {  // (M > N: the rectangle below the triangle, row by row)
+        tm = tcols + (t - tri) / tcols;
+        tn = (t - tri) % tcols;
+      }
     } else {
       const int tiles_n = (g.N + BN - 1) / BN, tiles_m = (g.M + BM - 1) / BM;
       constexpr int GM = 8;  // tile rows walked together: their A panels stay in L2
@@ -413,10 +422,11 @@ static inline long long gemm_split_plan_depth(const SplitPlan &sp, long long nsl
 }
 static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
   if (grid <= 0 || (long long)M * N < 256LL * 256) return false;
-  const long long tm = (M + 127) / 128, tn = (N + 127) / 128, tiles = lower ? tm * (tm + 1) / 2 : tm * tn;
+  const long long tiles = gemm_tiles(M, N, 128, lower);
   const long long nslab = (K + GEMM_BK - 1) / GEMM_BK;
-  if (tiles % grid == 0 || tiles >= 16LL * grid) return false;  // even, or the tail does not matter
   if (nslab < 32) return false;                                 // too shallow to cut
+  if (getenv("HQPKKT_FORCE_SPLIT")) return true;                // (experiments: tools/slice_sweep.sh)
+  if (tiles % grid == 0 || tiles >= 16LL * grid) return false;  // even, or the tail does not matter
   // (a CU with one workgroup reaches 92 % of what it does with two: up to 5/8 of the grid one plain round of one
   // or two workgroups per CU is as fast as cut pieces, without their parked partial sums)
   return tiles > grid * 5 / 8;

@@ -92,9 +92,10 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   const bool split = d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid);
   const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower);
   const int b = big ? 128 : 64;
-  const long long tm = (g.M + b - 1) / b, tn = (g.N + b - 1) / b;
-  const long long tiles = g.lower ? tm * (tm + 1) / 2 : tm * tn;
-  if (g.lower && big && d && tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
+  const long long tm = (g.M + b - 1) / b;
+  const long long tiles = stg::gemm_tiles(g.M, g.N, b, g.lower);
+  if (g.lower && g.M < g.N) return HQPKKT_E_INTERN;  // (lower: a triangle, or the column strip of one)
+  if (g.lower && g.M == g.N && big && d && tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
   if (d && d->zeros.p) g.zeros = d->zeros.p;
   if (split && tiles <= d->sk_tiles) {
     // tile count that does not fill the chip evenly: whole rounds, then the k ranges of the rest cut (k_dgemm_tn_sk)
@@ -440,10 +441,8 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
   h->stream = sA;
   if (wd > 0) {
     if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + c0, ldf, nullptr, 0, W + c0, ldf, np, wd, np, 1.0, 0.0, 0, 0}))) return e;
-    // diagonal block (lower tiles) and the rows below it
-    if ((e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + (long long)c0 * ldg + c0, ldg, wd, wd, np, 1.0, 0.0, 1, 0}))) return e;
-    if (nn > c1 &&
-        (e = st_gemm(h, stg::GemmArgs{sp.F + c1, ldf, W + c0, ldf, nullptr, 0, G + (long long)c1 * ldg + c0, ldg, nn - c1, wd, np, 1.0, 0.0, 0, 0})))
+    // the strip of the lower triangle of G_xx: diagonal block (lower tiles) and the rows below it, one launch
+    if ((e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + (long long)c0 * ldg + c0, ldg, nn - c0, wd, np, 1.0, 0.0, 1, 0})))
       return e;
   }
   add_h(P.h_ptr[k], ne_x);  // (entries outside this rank's strip land in parts of G nobody reads)
