@@ -28,7 +28,7 @@ SYMBOLS = [
     "hqpkkt_default_ip_opts", "hqpkkt_mehrotra", "hqpkkt_franke",
     "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm",
     "hqpkkt_analyze_staged", "hqpkkt_set_values_staged", "hqpkkt_set_shard_stream",
-    "hqpkkt_values_staging",
+    "hqpkkt_values_staging", "hqpkkt_detect_stages", "hqpkkt_stage_staging", "hqpkkt_set_stage_block",
 ]
 RCCL_LIB_PATH = os.path.join(_HERE, "libhqpkkt_rccl.so")
 RCCL_SYMBOLS = ["hqpkkt_rccl_unique_id", "hqpkkt_rccl_create", "hqpkkt_rccl_create_from_env",

@@ -2015,8 +2015,80 @@ int hqpkkt_set_values_staged(hqpkkt_t *h, const double *Qx, const double *const 
     if (!h) return HQPKKT_E_NULL;
     if (!h->analyzed || h->opts.mode != HQPKKT_MODE_STAGED || !h->sd) return HQPKKT_E_INTERN;
     Analysis &an = h->an;
-    if ((an.nq && !Qx) || (an.na && !Ex) || (an.nc && !Cx) || !F || !ldF) return HQPKKT_E_NULL;
-    return staged_set_values(h, Qx, Ex, Cx, F, ldF);
+    if ((an.nq && !Qx) || (an.na && !Ex) || (an.nc && !Cx) || (F && !ldF)) return HQPKKT_E_NULL;
+    if (!h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;  // analysed for the CSR hand-over
+    if (!F) {  // the blocks came one by one (hqpkkt_set_stage_block): every one of them, since the analysis
+      const std::vector<char> &bs = h->sd->blocks_set;
+      if ((int)bs.size() != h->sd->plan.K || std::find(bs.begin(), bs.end(), 0) != bs.end()) return HQPKKT_E_INTERN;
+    }
+    return staged_set_values(h, Qx, Ex, Cx, F, ldF, true);
+  });
+}
+
+int hqpkkt_detect_stages(int n, int rows, const int *row_len, const int *last_col, const int *prev_col, int cap, int *K,
+                         int *nx, int *nu, int *dyn_rows) {
+  return guarded([&]() -> int {
+    if (!row_len || !last_col || !prev_col || !K || !nx || !nu || !dyn_rows) return HQPKKT_E_NULL;
+    if (n < 1 || rows < 1) return HQPKKT_E_FORMAT;
+    std::vector<int> st, ct, fc;
+    int nd = 0;
+    if (kktdev::stages_from_staircase(n, rows, row_len, last_col, prev_col, st, ct, fc, nd)) return HQPKKT_E_FORMAT;
+    const int k = (int)ct.size();
+    if (k > cap) return HQPKKT_E_SIZES;
+    *K = k, *dyn_rows = nd;
+    for (int i = 0; i <= k; i++) nx[i] = st[i];
+    for (int i = 0; i < k; i++) nu[i] = ct[i];
+    return 0;
+  });
+}
+
+int hqpkkt_stage_staging(hqpkkt_t *h, int which, double **buf, long long *elems) {
+  return guarded([&]() -> int {
+    if (!h || !buf || !elems || which < 0 || which > 1) return HQPKKT_E_NULL;
+    if (!h->analyzed || h->opts.mode != HQPKKT_MODE_STAGED || !h->sd || !h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;
+    int e = ensure_device(h);
+    if (e) return e;
+    StagedDev &d = *h->sd;
+    const kktdev::StagedPlan &P = d.plan;
+    long long mx = 1;
+    for (int k = 0; k < P.K; k++) mx = std::max(mx, (long long)P.nk[k + 1] * (P.nk[k] + P.mk[k]));
+    for (int b = 0; b < 2; b++)
+      if (!d.hblk[b] || d.hblk_elems < mx) {
+        if (d.hblk[b]) (void)hipHostFree(d.hblk[b]), d.hblk[b] = nullptr;
+        HIPCHK(hipHostMalloc((void **)&d.hblk[b], sizeof(double) * (size_t)mx, hipHostMallocDefault));
+      }
+    d.hblk_elems = mx;
+    // the copy that last read this buffer must be over before the caller refills it
+    if (d.hblk_ev[which]) HIPCHK(hipEventSynchronize(d.hblk_ev[which]));
+    *buf = d.hblk[which], *elems = mx;
+    return 0;
+  });
+}
+
+int hqpkkt_set_stage_block(hqpkkt_t *h, int k, const double *F, long long ldF) {
+  return guarded([&]() -> int {
+    if (!h || !F) return HQPKKT_E_NULL;
+    if (!h->analyzed || h->opts.mode != HQPKKT_MODE_STAGED || !h->sd || !h->sd->plan.dense_dyn) return HQPKKT_E_INTERN;
+    int e;
+    if (!h->uploaded && (e = staged_upload(h))) return e;
+    StagedDev &d = *h->sd;
+    const kktdev::StagedPlan &P = d.plan;
+    if (k < 0 || k >= P.K) return HQPKKT_E_RANGE;
+    const int nz = P.nk[k] + P.mk[k];
+    if (ldF < nz) return HQPKKT_E_SIZES;
+    HIPCHK(hipSetDevice(h->opts.device));
+    const hipMemcpyKind kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
+    HIPCHK(hipMemcpy2DAsync(d.F.p + P.oF[k], sizeof(double) * P.ldf[k], F, sizeof(double) * ldF, sizeof(double) * nz, P.nk[k + 1], kind,
+                            h->stream));
+    for (int b = 0; b < 2; b++)
+      if (F == d.hblk[b]) {  // the library's own staging buffer: remember when it is free again
+        if (!d.hblk_ev[b]) HIPCHK(hipEventCreateWithFlags(&d.hblk_ev[b], hipEventDisableTiming));
+        HIPCHK(hipEventRecord(d.hblk_ev[b], h->stream));
+      }
+    if ((int)d.blocks_set.size() != P.K) d.blocks_set.assign(P.K, 0);
+    d.blocks_set[k] = 1;
+    h->factored = false;
+    return 0;
   });
 }
 

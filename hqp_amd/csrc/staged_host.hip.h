@@ -12,6 +12,10 @@ struct StagedDev {
   DBuf<stg::HTerm> h_terms;
   DBuf<stg::DynDesc> dyn_desc;  // dense dynamics: per stage (K+1) what k_st_dyn_ax / _aty need
   DBuf<double> dyn_x1, dyn_x2;  // A_dyn' dy (n), A_dyn dx (ndyn)
+  double *hblk[2] = {nullptr, nullptr};  // pinned staging of one stage block each (hqpkkt_stage_staging)
+  long long hblk_elems = 0;
+  hipEvent_t hblk_ev[2] = {nullptr, nullptr};
+  std::vector<char> blocks_set;         // dense hand-over block by block: which stages have arrived since the analysis
   DBuf<stg::StripTab> strip_tabs;  // sharded: per stage where the ranks' strips of G_xx lie in the exchange buffer
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
@@ -53,6 +57,11 @@ struct StagedDev {
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
     strip_tabs.release();
+    for (int b = 0; b < 2; b++) {
+      if (hblk[b]) (void)hipHostFree(hblk[b]), hblk[b] = nullptr;
+      if (hblk_ev[b]) (void)hipEventDestroy(hblk_ev[b]), hblk_ev[b] = nullptr;
+    }
+    hblk_elems = 0, blocks_set.clear();
     for (auto &e : tri_maps) e.second->release(), delete e.second;
     tri_maps.clear();
     if (stream2) (void)hipStreamDestroy(stream2), stream2 = nullptr;
@@ -331,13 +340,13 @@ static int staged_upload(hqpkkt_t *h) {
 }
 
 static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const double *Cx,
-                             const double *const *Fblk = nullptr, const long long *ldF = nullptr) {
+                             const double *const *Fblk = nullptr, const long long *ldF = nullptr, bool dense = false) {
   Analysis &an = h->an;
   int e;
   if (!h->uploaded && (e = staged_upload(h))) return e;
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;
-  if (P.dense_dyn != (Fblk != nullptr)) return HQPKKT_E_INTERN;  // analysed for the other hand-over
+  if (P.dense_dyn != (dense || Fblk != nullptr)) return HQPKKT_E_INTERN;  // analysed for the other hand-over
   HIPCHK(hipSetDevice(h->opts.device));
   hipStream_t s = h->stream;
   hipMemcpyKind kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;

@@ -13,6 +13,50 @@ inline int up8(long long x) { return (int)((x + 7) / 8 * 8); }
 inline long long up16(long long x) { return (x + 15) / 16 * 16; }
 }  // namespace
 
+// Stage sizes of a DOCP from the staircase its dynamics rows form in A: what Hqp_IpLQDOCP::Get_Dim reads off
+// the same rows (hqp/Hqp_IpLQDOCP.C:201-287).  Per row only its length, the column of its last entry (the -1.0
+// that multiplies a component of x_{k+1}) and of the entry before it are looked at, so a caller that keeps A
+// as row lists (the reference-side binding: shim/) hands over three ints per row and never a CSR copy of the
+// dynamics.  The walk: every dynamics row ends one column further right than the row before it while it
+// belongs to the same stage; a stage ends where that column jumps (the controls of the next stage lie
+// between) or where a row's other entries no longer reach back behind the states this stage has produced
+// so far (stages without controls).  The walk is over when a row ends in the last column of A.
+// Returns 0 and states[K+1], controls[K], first_col[K+1], dyn_rows, or 6 (HQPKKT_E_FORMAT).
+int stages_from_staircase(int n, int rows, const int *row_len, const int *last_col, const int *prev_col,
+                          std::vector<int> &states, std::vector<int> &controls, std::vector<int> &first_col, int &dyn_rows) {
+  struct Stage {
+    int first_target;  // column of the first state this stage produces (= first column of the NEXT stage's block)
+    int produced;      // dynamics rows of this stage = states of the next one
+  };
+  std::vector<Stage> found;
+  int target = -1;  // column the previous row ended in
+  dyn_rows = -1;
+  for (int i = 0; i < rows && dyn_rows < 0; i++) {
+    if (row_len[i] < 2) return 6;
+    const int end = last_col[i], reach = prev_col[i];
+    if (end <= target || end >= n) return 6;
+    const bool contiguous = end == target + 1;
+    const bool same_stage = !found.empty() && contiguous && end - reach >= found.back().produced;
+    if (same_stage)
+      found.back().produced++;
+    else
+      found.push_back(Stage{end, 1});
+    target = end;
+    if (end == n - 1) dyn_rows = i + 1;
+  }
+  if (dyn_rows < 0 || found.empty()) return 6;
+  const int K = (int)found.size();
+  states.assign(K + 1, 0), controls.assign(K, 0), first_col.assign(K + 1, 0);
+  for (int k = 0; k < K; k++) states[k + 1] = found[k].produced, first_col[k + 1] = found[k].first_target;
+  // x_0: as many states as the first stage produces, unless its block is narrower (hqp/Hqp_IpLQDOCP.C:265)
+  states[0] = std::min(states[1], first_col[1]);
+  for (int k = 0; k < K; k++) {
+    controls[k] = first_col[k + 1] - first_col[k] - states[k];
+    if (controls[k] < 0) return 6;
+  }
+  return 0;
+}
+
 int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const int *Ap, const int *Ai,
                     const int *Cp, const int *Ci) {
   n = n_, m = m_;
@@ -43,39 +87,16 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     } else if (Ap[ndyn] != 0)
       return 6;  // dense dynamics: their rows of A are empty
   } else {
-    // the -1.0 staircase (values are checked when they arrive: chk_idx): a new stage starts
-    // where the last column jumps by more than one or the row reaches back into the block of
-    // states the current stage produces
+    // the -1.0 staircase (values are checked when they arrive: chk_idx)
     if (dense_dyn || arows == 0) return 6;
-    nk.push_back(0), nmk.push_back(0);
-    int cur = 0, last = -1;
-    ndyn = -1;
+    std::vector<int> len(arows), tail(arows), before(arows);
     for (int i = 0; i < arows; i++) {
-      const int len = Ap[i + 1] - Ap[i];
-      if (len <= 1) return 6;
-      const int icl = Ai[Ap[i + 1] - 1], icl1 = Ai[Ap[i + 1] - 2];
-      if (icl <= last) return 6;
-      if (icl - last > 1 || icl - icl1 < cur) {
-        if (nk.size() > 1) nk.back() = cur;
-        nk.push_back(0), nmk.push_back(icl);
-        cur = 1;
-      } else
-        cur++;
-      last = icl;
-      if (icl == n - 1) {
-        nk.back() = cur;
-        ndyn = i + 1;
-        break;
-      }
+      len[i] = Ap[i + 1] - Ap[i];
+      tail[i] = len[i] > 0 ? Ai[Ap[i + 1] - 1] : -1;
+      before[i] = len[i] > 1 ? Ai[Ap[i + 1] - 2] : -1;
     }
-    if (ndyn < 0 || nk.size() < 2) return 6;
+    if (stages_from_staircase(n, arows, len.data(), tail.data(), before.data(), nk, mk, nmk, ndyn)) return 6;
     K = (int)nk.size() - 1;
-    nk[0] = std::min(nk[1], nmk[1]);  // hqp/Hqp_IpLQDOCP.C:265
-    mk.assign(K, 0);
-    for (int k = 0; k < K; k++) {
-      mk[k] = nmk[k + 1] - nmk[k] - nk[k];
-      if (mk[k] < 0) return 6;
-    }
     nks.assign(K + 1, 0);
     for (int k = 0; k < K; k++) nks[k + 1] = nks[k] + nk[k + 1];
     if (nks[K] != ndyn) return 6;

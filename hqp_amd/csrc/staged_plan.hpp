@@ -16,6 +16,9 @@ inline long long gj_lds_bytes(long long q) {
   return q * (q | 1) * 8 + (q + cv + rv) * 8 + 3 * q * 4 + 64;
 }
 
+int stages_from_staircase(int n, int rows, const int *row_len, const int *last_col, const int *prev_col,
+                          std::vector<int> &states, std::vector<int> &controls, std::vector<int> &first_col, int &dyn_rows);
+
 struct StagedPlan {
   int n = 0, me = 0, m = 0, K = 0;
   int nq = 0, na = 0, nc = 0;

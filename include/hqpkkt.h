@@ -301,8 +301,24 @@ int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu);
  * blocks are copied: the caller may release them afterwards.  hqpkkt_mehrotra / _franke run on this
  * form too (their products with the dynamics rows go through the dense blocks; b / y in the same row
  * order as r2 / dy). */
+/* Stage sizes from the staircase of the dynamics rows, for hosts that keep A as row lists and must never make a CSR
+ * copy of the dynamics (the reference-side binding, shim/Hqp_IpSpBKPHip.C: 5*10^9 entries at K = 200, nx = 5000):
+ * per row of A its length, the column of its last entry and of the one before it (three ints per row).  What
+ * Hqp_IpLQDOCP::Get_Dim reads off the same rows (hqp/Hqp_IpLQDOCP.C:201-287).  nx holds cap + 1, nu cap entries;
+ * returns K, nx[0..K], nu[0..K-1] and the number of dynamics rows (the first rows of A); HQPKKT_E_FORMAT: not a
+ * staircase, HQPKKT_E_SIZES: more than cap stages.  Host-only, no handle, no device. */
+int hqpkkt_detect_stages(int n, int rows, const int *row_len, const int *last_col, const int *prev_col, int cap, int *K,
+                         int *nx, int *nu, int *dyn_rows);
 int hqpkkt_analyze_staged(hqpkkt_t *h, int K, const int *nx, const int *nu, int n_total, int me_rest, int m, const int *Qp,
                           const int *Qi, const int *Ep, const int *Ei, const int *Cp, const int *Ci);
+/* The dense blocks one at a time, for hosts that extract them from row lists stage by stage (two stage-sized pinned
+ * buffers instead of K of them): hqpkkt_stage_staging returns pinned buffer `which` (0 / 1; large enough for the
+ * largest block; it waits until the copy that last read the buffer is over), hqpkkt_set_stage_block copies block k =
+ * [fx_k fu_k] (nx[k+1] x (nx[k] + nu[k]), row-major, leading dimension ldF; any pointer per opts.loc) into the engine's
+ * arena, asynchronously in the handle's stream.  hqpkkt_set_values_staged with F = NULL then takes the other values
+ * and ends the hand-over (HQPKKT_E_INTERN unless every block has been set since the analysis). */
+int hqpkkt_stage_staging(hqpkkt_t *h, int which, double **buf, long long *elems);
+int hqpkkt_set_stage_block(hqpkkt_t *h, int k, const double *F, long long ldF);
 int hqpkkt_set_values_staged(hqpkkt_t *h, const double *Qx, const double *const *F, const long long *ldF,
                              const double *Ex, const double *Cx);
 /* tests: rank and number of carried rows per stage (2 ints each, K+1 stages) of the last factor */

@@ -22,6 +22,7 @@
 #include "Hqp_Program.h"
 #include "hqpkkt.h"
 #include "hqpkkt_rccl.h"
+#include "stage_extract.h"
 
 IF_CLASS_DEFINE("SpBKPHip", Hqp_IpSpBKPHip, Hqp_IpMatrix);
 IF_CLASS_DEFINE("RedSpBKPHip", Hqp_IpRedSpBKPHip, Hqp_IpMatrix);
@@ -44,6 +45,17 @@ Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
   _h = NULL;
   _Qp = _Qi = _Ap = _Ai = _Cp = _Ci = IVNULL;
   _Qx = _Ax = _Cx = VNULL;
+  _dense = false;
+  _K = _ndyn = 0;
+  _nx = _nu = IVNULL;
+  _wz_tol = HUGE_VAL;
+  _a_sparse = 0;
+  _logging = getenv("HQPKKT_SHIM_LOGGING") ? atoi(getenv("HQPKKT_SHIM_LOGGING")) : 0;
+  if (mode == HQPKKT_MODE_STAGED) {
+    _ifList.append(new If_Real("mat_wz_tol", &_wz_tol));
+    _ifList.append(new If_Int("mat_a_sparse", &_a_sparse));
+    _ifList.append(new If_Int("mat_logging", &_logging));
+  }
 
   // same Tcl-visible members as hqp/Hqp_IpSpBKP.C:58-59, plus the device knobs
   _ifList.append(new If_Int("mat_sbw", &_sbw));
@@ -82,6 +94,7 @@ Hqp_IpMatrixHip::~Hqp_IpMatrixHip()
     if (f) f(_rccl);
   }
   iv_free(_Qp); iv_free(_Qi); iv_free(_Ap); iv_free(_Ai); iv_free(_Cp); iv_free(_Ci);
+  iv_free(_nx); iv_free(_nu);
   v_free(_Qx); v_free(_Ax); v_free(_Cx);
 }
 
@@ -109,25 +122,30 @@ void Hqp_IpMatrixHip::check(int status, const char *where)
 //--------------------------------------------------------------------------
 // one block: SPMAT -> (ptr, idx, val); upper = keep col >= row only
 // (the reference reads only that part of Q, meschach/addon2_hqp.c:1078-1086)
-static void extract_block(const SPMAT *M, bool upper,
-                          IVEC *&ptr, IVEC *&idx, VEC *&val, bool &changed)
+// rows [row0, M->m) only (the equality rows behind the dynamics rows of a DOCP).  Returns false when the block
+// has more entries than int32 CSR holds (the caller reports HQPKKT_E_SIZES; the dynamics rows of a large DOCP
+// never come this way: open_dense)
+static bool extract_block(const SPMAT *M, bool upper,
+                          IVEC *&ptr, IVEC *&idx, VEC *&val, bool &changed, int row0 = 0)
 {
-  int i, j, k, m = M->m;
-  int nnz = 0;
+  int i, j, k, m = M->m - row0;
+  long long nnz = 0;
   for (i = 0; i < m; i++) {
-    const SPROW *row = M->row + i;
+    const SPROW *row = M->row + row0 + i;
     for (j = 0; j < row->len; j++)
       if (!upper || row->elt[j].col >= i)
         nnz++;
   }
-  if (!ptr || (int)ptr->dim != m + 1 || !idx || (int)idx->dim != nnz)
+  if (nnz > 0x7fffffffLL)
+    return false;
+  if (!ptr || (int)ptr->dim != m + 1 || !idx || (long long)idx->dim != nnz)
     changed = true;
   ptr = iv_resize(ptr, m + 1);
-  idx = iv_resize(idx, nnz);
-  val = v_resize(val, nnz);
+  idx = iv_resize(idx, (int)nnz);
+  val = v_resize(val, (int)nnz);
   k = 0;
   for (i = 0; i < m; i++) {
-    const SPROW *row = M->row + i;
+    const SPROW *row = M->row + row0 + i;
     if (ptr->ive[i] != k)
       changed = true;
     ptr->ive[i] = k;
@@ -145,6 +163,7 @@ static void extract_block(const SPMAT *M, bool upper,
   if (ptr->ive[m] != k)
     changed = true;
   ptr->ive[m] = k;
+  return true;
 }
 
 //--------------------------------------------------------------------------
@@ -196,17 +215,117 @@ static bool refresh_block(const SPMAT *M, bool upper, const IVEC *ptr, const IVE
 
 void Hqp_IpMatrixHip::extract(const Hqp_Program *qp, bool &pattern_changed)
 {
-  pattern_changed = false;
-  extract_block(qp->Q, true, _Qp, _Qi, _Qx, pattern_changed);
-  extract_block(qp->A, false, _Ap, _Ai, _Ax, pattern_changed);
-  extract_block(qp->C, false, _Cp, _Ci, _Cx, pattern_changed);
+  pattern_changed = _dense;  // (the CSR copies held the rows behind the dynamics only)
+  _dense = false;
+  bool ok = extract_block(qp->Q, true, _Qp, _Qi, _Qx, pattern_changed);
+  ok = extract_block(qp->A, false, _Ap, _Ai, _Ax, pattern_changed) && ok;
+  ok = extract_block(qp->C, false, _Cp, _Ci, _Cx, pattern_changed) && ok;
+  if (!ok)
+    check(HQPKKT_E_SIZES, "Hqp_IpMatrixHip: more than 2^31 entries in a block (only LQDOCPHip's dense stage blocks go beyond)");
+}
+
+//--------------------------------------------------------------------------
+// the row lists of an SPMAT as shim/stage_extract.h wants them
+namespace {
+struct SpmatRows {
+  const SPMAT *M;
+  int len(long long i) const { return M->row[i].len; }
+  int col(long long i, int j) const { return M->row[i].elt[j].col; }
+  double val(long long i, int j) const { return M->row[i].elt[j].val; }
+};
+}  // namespace
+
+//--------------------------------------------------------------------------
+// The values of a DOCP whose structure open_dense() has analysed: every stage's dense block [fx_k fu_k] walked out
+// of the row lists of A into one of the library's two pinned stage buffers (rows dealt to the update threads) and
+// copied into the engine's arena while the next stage is walked - what Hqp_IpLQDOCP::update does with
+// sp_extract_mat (hqp/Hqp_IpLQDOCP.C:748-755) -, then the values of Q, of the other equality rows and of C.
+int Hqp_IpMatrixHip::dense_values(const Hqp_Program *qp)
+{
+  int e = HQPKKT_OK;
+  const SpmatRows A = {qp->A};
+  long long row0 = 0;
+  int col0 = 0;
+  for (int k = 0; k < _K && !e; k++) {
+    const int np = _nx->ive[k + 1], nz = _nx->ive[k] + _nu->ive[k], next0 = col0 + nz;
+    double *buf = NULL;
+    long long cap = 0;
+    if ((e = hqpkkt_stage_staging(_h, k & 1, &buf, &cap)))
+      break;
+    if ((long long)np * nz > cap) {
+      e = HQPKKT_E_INTERN;
+      break;
+    }
+    int nthr = _update_threads < 1 ? 1 : _update_threads;
+    if ((long long)np * nz < (1LL << 18)) nthr = 1;
+    std::vector<long long> got(nthr, 0);
+    auto work = [&](int t) {
+      const int lo = (int)((long long)np * t / nthr), hi = (int)((long long)np * (t + 1) / nthr);
+      for (long long x = (long long)lo * nz; x < (long long)hi * nz; x++) buf[x] = 0.0;
+      hqpshim::DenseSink sink = {buf, (long long)nz};
+      got[t] = hqpshim::stage_rows(A, row0, lo, hi, col0, nz, next0, sink);
+    };
+    if (nthr == 1)
+      work(0);
+    else {
+      std::vector<std::thread> th;
+      for (int t = 0; t < nthr; t++) th.emplace_back(work, t);
+      for (size_t t = 0; t < th.size(); t++) th[t].join();
+    }
+    for (int t = 0; t < nthr; t++)
+      if (got[t] < 0) e = HQPKKT_E_FORMAT;  // an entry outside its stage / not the -1.0 staircase
+    if (!e)
+      e = hqpkkt_set_stage_block(_h, k, buf, nz);
+    row0 += np, col0 = next0;
+  }
+  if (!e)
+    e = hqpkkt_set_values_staged(_h, _Qx->ve, NULL, NULL, _Ax->ve, _Cx->ve);
+  return e;
+}
+
+//--------------------------------------------------------------------------
+// LQDOCPHip: stage sizes from the staircase (three ints per row of A), CSR of Q, of the equality rows behind the
+// dynamics and of C, the dynamics as dense blocks.  Returns HQPKKT_E_FORMAT where Hqp_IpLQDOCP::init asserts (no
+// DOCP staircase) and HQPKKT_E_SIZES where a stage is beyond the STAGED kernels: init() then routes the same
+// system to the full-system engine.
+int Hqp_IpMatrixHip::open_dense(const Hqp_Program *qp)
+{
+  const int rows = qp->A->m;
+  int e, K = 0, ndyn = 0;
+  bool changed = false;
+  if (rows < 1 || _n < 1)
+    return HQPKKT_E_FORMAT;
+  {
+    std::vector<int> len(rows), last(rows), prev(rows), nx(rows + 1), nu(rows);
+    const SpmatRows A = {qp->A};
+    hqpshim::staircase_keys(A, rows, len.data(), last.data(), prev.data());
+    if ((e = hqpkkt_detect_stages(_n, rows, len.data(), last.data(), prev.data(), rows, &K, nx.data(), nu.data(), &ndyn)))
+      return e;
+    _nx = iv_resize(_nx, K + 1);
+    _nu = iv_resize(_nu, K);
+    for (int k = 0; k <= K; k++) _nx->ive[k] = nx[k];
+    for (int k = 0; k < K; k++) _nu->ive[k] = nu[k];
+  }
+  _K = K, _ndyn = ndyn;
+  if (!extract_block(qp->Q, true, _Qp, _Qi, _Qx, changed) ||
+      !extract_block(qp->A, false, _Ap, _Ai, _Ax, changed, ndyn) ||
+      !extract_block(qp->C, false, _Cp, _Ci, _Cx, changed))
+    return HQPKKT_E_SIZES;
+  if ((e = create_handle(HQPKKT_MODE_STAGED)))
+    return e;
+  _sbw = -1;
+  if ((e = hqpkkt_analyze_staged(_h, K, _nx->ive, _nu->ive, _n, _me - ndyn, _m, _Qp->ive, _Qi->ive,
+                                 _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive)))
+    return e;
+  _dense = true;
+  return dense_values(qp);
 }
 
 //--------------------------------------------------------------------------
 // (re)create the handle for `mode` and hand the structure and the values over.
 // Returns the status of the first call that fails (the handle then stays
 // created, but not analysed).
-int Hqp_IpMatrixHip::open(int mode)
+int Hqp_IpMatrixHip::create_handle(int mode)
 {
   hqpkkt_opts opts;
   int e;
@@ -242,6 +361,15 @@ int Hqp_IpMatrixHip::open(int mode)
       return e ? e : HQPKKT_E_DEVICE;
   }
   _mode_used = mode;
+  return HQPKKT_OK;
+}
+
+int Hqp_IpMatrixHip::open(int mode)
+{
+  int e;
+  if ((e = create_handle(mode)))
+    return e;
+  _dense = false;
   if ((e = hqpkkt_analyze(_h, _n, _me, _m,
                           _Qp->ive, _Qi->ive, _Ap->ive, _Ai->ive, _Cp->ive, _Ci->ive,
                           &_sbw)))
@@ -260,19 +388,38 @@ void Hqp_IpMatrixHip::init(const Hqp_Program *qp)
   _m = qp->d->dim;
 
   // the handle is created here: mat_tol / mat_eps / mat_device may have been set
+  if (_mode == HQPKKT_MODE_STAGED) {
+    // the dynamics as dense stage blocks straight from the row lists (no CSR copy of them: open_dense)
+    e = open_dense(qp);
+    const char *why = NULL;
+    if (e == HQPKKT_E_FORMAT || e == HQPKKT_E_SIZES) {
+      // not the staircase of a DOCP (where Hqp_IpLQDOCP::init asserts, hqp/Hqp_IpLQDOCP.C:700-707), or a stage with
+      // more controls / carried constraint rows than the STAGED kernels hold: the same KKT system through the
+      // full-system engine
+      why = e == HQPKKT_E_FORMAT ? "no DOCP staircase" : "a stage beyond the STAGED kernels";
+      extract(qp, changed);
+      e = open(HQPKKT_MODE_FULL);
+    } else if (!e) {
+      hqpkkt_stats st;
+      if (hqpkkt_get_stats(_h, &st) == HQPKKT_OK && st.max_front < _staged_min_front) {
+        why = "stages below mat_staged_min_front";   // small stages are faster through the tree engine
+        extract(qp, changed);
+        e = open(HQPKKT_MODE_FULL);
+      }
+    }
+    if (_logging > 0) {
+      fprintf(stderr, "LQDOCPHip: n %d me %d m %d", _n, _me, _m);
+      if (_dense)
+        fprintf(stderr, ", %d stages (x_0: %d states; widest stage %d states + %d controls), %d dynamics rows as dense "
+                "blocks: STAGED engine\n", _K, _nx->ive[0], _nx->ive[_K], _K ? _nu->ive[0] : 0, _ndyn);
+      else
+        fprintf(stderr, ": full-system engine (%s), mat_sbw %d\n", why ? why : "", _sbw);
+    }
+    check(e, "Hqp_IpMatrixHip::init");
+    return;
+  }
   extract(qp, changed);
   e = open(_mode);
-  if (_mode == HQPKKT_MODE_STAGED && (e == HQPKKT_E_FORMAT || e == HQPKKT_E_SIZES)) {
-    // not the staircase of a DOCP (where Hqp_IpLQDOCP::init asserts,
-    // hqp/Hqp_IpLQDOCP.C:700-707), or a stage with more controls / carried
-    // constraint rows than the STAGED kernels hold: the same KKT system through
-    // the full-system engine
-    e = open(HQPKKT_MODE_FULL);
-  } else if (_mode == HQPKKT_MODE_STAGED && !e) {
-    hqpkkt_stats st;
-    if (hqpkkt_get_stats(_h, &st) == HQPKKT_OK && st.max_front < _staged_min_front)
-      e = open(HQPKKT_MODE_FULL);   // small stages: see mat_staged_min_front
-  }
   check(e, "Hqp_IpMatrixHip::init");
 }
 
@@ -285,6 +432,39 @@ void Hqp_IpMatrixHip::update(const Hqp_Program *qp)
   // (no C++ object with a destructor is alive when check() may longjmp: the vectors of
   // refresh_block are gone by then)
   double *sq = NULL, *sa = NULL, *sc = NULL;
+  if (_dense) {
+    // same stage structure (three ints per row of A are enough to see it) -> new values block by block
+    const int rows = qp->A->m;
+    bool same = false;
+    int st = HQPKKT_OK;
+    {
+      std::vector<int> len(rows), last(rows), prev(rows), nx(rows + 1), nu(rows);
+      const SpmatRows A = {qp->A};
+      int K = 0, ndyn = 0;
+      hqpshim::staircase_keys(A, rows, len.data(), last.data(), prev.data());
+      st = hqpkkt_detect_stages(_n, rows, len.data(), last.data(), prev.data(), rows, &K, nx.data(), nu.data(), &ndyn);
+      same = !st && K == _K && ndyn == _ndyn;
+      for (int k = 0; same && k <= K; k++) same = nx[k] == _nx->ive[k] && (k == K || nu[k] == _nu->ive[k]);
+    }
+    changed = false;
+    if (same) {
+      if (!extract_block(qp->Q, true, _Qp, _Qi, _Qx, changed) ||
+          !extract_block(qp->A, false, _Ap, _Ai, _Ax, changed, _ndyn) ||
+          !extract_block(qp->C, false, _Cp, _Ci, _Cx, changed))
+        check(HQPKKT_E_SIZES, "Hqp_IpMatrixHip::update");
+    }
+    if (same && !changed) {
+      e = dense_values(qp);
+      if (e == HQPKKT_E_FORMAT || e == HQPKKT_E_SIZES) {
+        extract(qp, changed);
+        e = open(HQPKKT_MODE_FULL);
+      }
+      check(e, "Hqp_IpMatrixHip::update");
+      return;
+    }
+    init(qp);  // another structure: as a new program
+    return;
+  }
   if (_h && _Qp && _update_threads > 0 && hqpkkt_values_staging(_h, &sq, &sa, &sc) == HQPKKT_OK) {
     bool ch = refresh_block(qp->Q, true, _Qp, _Qi, sq, _update_threads);
     ch = ch || refresh_block(qp->A, false, _Ap, _Ai, sa, _update_threads);

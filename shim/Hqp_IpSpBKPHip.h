@@ -36,14 +36,28 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   int _ordering;      // mat_ordering: 0 nested dissection of the RCM band, 1 of the graph itself
   int _staged_min_front; // mat_staged_min_front: LQDOCPHip uses the STAGED engine from this stage width on
   int _update_threads; // mat_update_threads: host threads of update()'s walk over the row lists
+  // LQDOCPHip (hqp/Hqp_IpLQDOCP.C:177-179 registers the same three): mat_wz_tol and mat_a_sparse are accepted and
+  // not used (the first selects the reference's other recursion, off by default: HUGE_VAL, :111, 850-853; the
+  // second its sparse products with fx, fu, which have no counterpart on dense MFMA blocks), mat_logging > 0 prints
+  // the stage structure and the engine chosen at init()
+  Real _wz_tol;
+  int _a_sparse, _logging;
   struct hqpkkt *_h;
+  // STAGED engine with the dynamics handed over as dense blocks (hqpkkt_analyze_staged): stage sizes, the number of
+  // dynamics rows, CSR of the OTHER equality rows only - the dynamics rows of A are never copied into a CSR
+  bool _dense;
+  int _K, _ndyn;
+  IVEC *_nx, *_nu;
   // CSR copies of the pattern the handle was analysed for (pattern-change
   // detection like hqp/Hqp_IpPARDISO.C:247-248,293-296) and value staging
   IVEC *_Qp, *_Qi, *_Ap, *_Ai, *_Cp, *_Ci;
   VEC *_Qx, *_Ax, *_Cx;
 
   void extract(const Hqp_Program *qp, bool &pattern_changed);
+  int create_handle(int mode);
   int open(int mode);
+  int open_dense(const Hqp_Program *qp);
+  int dense_values(const Hqp_Program *qp);
   void check(int status, const char *where);
 
  public:

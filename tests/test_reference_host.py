@@ -66,6 +66,37 @@ def test_lqdocp_plugin_routes_narrow_stages_to_the_tree_engine(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_lqdocp_plugin_takes_wide_stages_as_dense_blocks(monkeypatch, capfd):
+    """LQDOCPHip reaches the STAGED engine through the DENSE hand-over: stage sizes from three ints per row of A
+    (hqpkkt_detect_stages), every [fx_k fu_k] walked out of the row lists into a pinned stage buffer
+    (hqpkkt_stage_staging / hqpkkt_set_stage_block) - no CSR copy of the dynamics rows, whose entry count passes 2^31
+    at the headline size (tests/c_host/stage_extract_test.cc walks that size on the CPU).  A DOCP with 1000 states per
+    stage under the reference's own Hqp_IpsMehrotra: same iterations, result and objective as with the reference's
+    Hqp_IpLQDOCP; then update() with other values on the same structure (two QPs in a row, hot start)."""
+    if not refapi.host_available("hip"):
+        pytest.skip("oracle/_ref/libhqphost_hip.so not present")
+    monkeypatch.delenv("HQPKKT_STAGED_MIN_FRONT", raising=False)
+    monkeypatch.setenv("HQPKKT_SHIM_LOGGING", "1")  # (mat_logging of the plugin: the host of these tests has no Tcl prompt)
+    prog = problems.lq_docp(2, 1000, 4, seed=3)
+    ref = refapi.ip_solve(prog, "Mehrotra", "LQDOCP", host="hip")
+    hip = refapi.ip_solve(prog, "Mehrotra", "LQDOCPHip", host="hip")
+    err = capfd.readouterr().err
+    assert "2 stages" in err and "dense blocks: STAGED engine" in err, err[-500:]
+    assert hip["mat_sbw"] == -1
+    fr, fh = objective(prog, ref["x"]), objective(prog, hip["x"])
+    assert hip["result"] == ref["result"] == 0 and hip["iters"] == ref["iters"], (ref["iters"], hip["iters"])
+    assert abs(fr - fh) <= 1e-6 * max(1.0, abs(fr))
+    assert np.abs(hip["x"] - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
+    # update(): the same structure with a perturbed c (what an SQP iteration hands to the QP solver)
+    rng = np.random.default_rng(5)
+    c2 = prog.c + 1e-2 * rng.standard_normal(prog.n)
+    h2 = refapi.ip_solve_hot(prog, c2, prog.b, prog.d, "Mehrotra", "LQDOCPHip", host="hip")
+    t2 = refapi.ip_solve_hot(prog, c2, prog.b, prog.d, "Mehrotra", "RedSpBKPHip", host="hip")
+    assert h2["result"] == t2["result"] == 0
+    assert np.abs(h2["x"] - t2["x"]).max() <= 1e-6 * max(1.0, np.abs(t2["x"]).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["Mehrotra", "Franke"])
 @pytest.mark.parametrize("pair", [("SpBKP", "SpBKPHip"), ("RedSpBKP", "RedSpBKPHip"), ("LQDOCP", "LQDOCPHip")])
 @pytest.mark.parametrize("case", ["did50", "did400", "banded"])
