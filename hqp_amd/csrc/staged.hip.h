@@ -662,13 +662,13 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax *red) {
 __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv,
                           ArgMax *red) {
   const int tid = threadIdx.x, nt = blockDim.x;
-  const int ty = tid >> 4, tx = tid & 15;
+  const int ty = tid >> 4, tx = tid & 15, RS = nt >> 4;  // (ty, tx): rows ty + RS i, columns tx + 16 j
   const double INF = __longlong_as_double(0x7ff0000000000000LL);
   for (int j = tid; j < q; j += nt) ip[j] = 0;
   __syncthreads();
   int bad = 0;
   ArgMax best{-1.0, 0x7fffffff};
-  for (int r = ty; r < q; r += 16)
+  for (int r = ty; r < q; r += RS)
     for (int c = tx; c < q; c += 16) {
       const double v = fabs(a[r * ld + c]);
       best = better(best, ArgMax{v == v ? v : INF, r * q + c});
@@ -694,7 +694,7 @@ __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, d
     }
     __syncthreads();
     best = ArgMax{-1.0, 0x7fffffff};
-    for (int r = ty; r < q; r += 16) {
+    for (int r = ty; r < q; r += RS) {
       const double cr = colv[r];
       const bool rfree = ip[r] == 0;
       for (int c = tx; c < q; c += 16) {
@@ -900,6 +900,7 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
 // dispatch: registers up to order 64, LDS above
 __device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red,
                               bool spd = false) {
+  if (blockDim.x != 256) return gj_inverse(a, q, ld, ip, ir, ic, colv, rowv, red);  // (the register forms are laid out for 256 threads)
   if (spd && q <= 64) {
     const int e = q <= 16 ? gj_inverse_reg_spd<1>(a, q, ld, colv, rowv)
                 : q <= 32 ? gj_inverse_reg_spd<2>(a, q, ld, colv, rowv) : gj_inverse_reg_spd<4>(a, q, ld, colv, rowv);
@@ -935,10 +936,13 @@ struct SmallArgs {
   long long ldt;        // cap x ldt : t[li][s]
   int *dyn;             // [0] r, [1] number of leftover rows, [2..2+capn) R, [2+capn..2+2capn) L
   int *status;          // set to 4 (E_SING) on a singular K
+  double *scratch;      // null: the matrices of (A) and (B) live in LDS; else in this global area (stages with hundreds of
+                        // controls / carried rows: StagedPlan::big) and LDS holds the flags and vectors only
 };
-__global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_st_small(SmallArgs a) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ ArgMax red[4];
+  __shared__ ArgMax red[16];
   __shared__ int s_r, s_stop;
   const int tid = threadIdx.x, nt = blockDim.x;
   const int m = a.m, n = a.n;
@@ -948,8 +952,8 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
   int r = 0;
   if (c > 0 && m > 0) {
     const int ld = m + c;
-    double *aug = sm;
-    int *rfree = (int *)(sm + (size_t)c * ld);
+    double *aug = a.scratch ? a.scratch : sm;
+    int *rfree = (int *)(a.scratch ? sm : sm + (size_t)c * ld);
     int *cfree = rfree + c;
     for (int e = tid; e < c * ld; e += nt) {
       const int i = e / ld, j = e - i * ld;
@@ -1016,8 +1020,8 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
   const int q = m + r;
   if (q > 0) {
     const int ld = q | 1;
-    double *Km = sm;
-    double *dsc = Km + (size_t)q * ld;
+    double *Km = a.scratch ? a.scratch : sm;
+    double *dsc = a.scratch ? sm : Km + (size_t)q * ld;
     double *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
     int *ip = (int *)(rowv + (q > 128 ? q : 128)), *ir = ip + q, *ic = ir + q;
     for (int e = tid; e < q * q; e += nt) {
@@ -1073,10 +1077,11 @@ __global__ void __launch_bounds__(256) k_st_small(SmallArgs a) {
       a.Kinv[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0, a.Kmat[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0;
   }
 }
-static size_t st_small_lds(int m, int capn) {
+static size_t st_small_lds(int m, int capn, bool big = false) {
   const size_t q = (size_t)m + (size_t)(capn < m ? capn : m);
-  const size_t a = (size_t)capn * (m + capn) * 8 + (size_t)(capn + m + 2) * 4 + (size_t)capn * 8 + 16;
-  const size_t b = (size_t)kktdev::gj_lds_bytes((long long)q);
+  // big: the matrices are in global memory, LDS holds flags, multipliers, scalings, pivot row / column, index arrays
+  const size_t a = (big ? 0 : (size_t)capn * (m + capn) * 8) + (size_t)(capn + m + 2) * 4 + (size_t)capn * 8 + 16;
+  const size_t b = big ? (size_t)kktdev::gj_lds_bytes((long long)q) - q * (q | 1) * 8 : (size_t)kktdev::gj_lds_bytes((long long)q);
   return (a > b ? a : b) + 64;
 }
 
@@ -1129,16 +1134,17 @@ __global__ void k_st_check_fixed(const int *__restrict__ dyn0, int *__restrict__
 }
 
 // free initial state: inverse of [V_0 B_0'; B_0 0]  (hqp/Hqp_IpLQDOCP.C:1972-1996)
-__global__ void __launch_bounds__(256) k_st_init_factor(int n0, int cap, const double *__restrict__ V, long long ldv,
-                                                        const double *__restrict__ BT, long long ldb,
-                                                        const int *__restrict__ dyn0, double *__restrict__ K0inv,
-                                                        double *__restrict__ K0mat, long long ldq, int qmax,
-                                                        int *__restrict__ status) {
+template <int NT>
+__global__ void __launch_bounds__(NT) k_st_init_factor(int n0, int cap, const double *__restrict__ V, long long ldv,
+                                                       const double *__restrict__ BT, long long ldb,
+                                                       const int *__restrict__ dyn0, double *__restrict__ K0inv,
+                                                       double *__restrict__ K0mat, long long ldq, int qmax,
+                                                       int *__restrict__ status, double *scratch) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  __shared__ ArgMax red[4];
+  __shared__ ArgMax red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int c = dyn0[1], q = n0 + c, ld = q | 1;
-  double *Km = sm, *dsc = Km + (size_t)q * ld, *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
+  double *Km = scratch ? scratch : sm, *dsc = scratch ? sm : Km + (size_t)q * ld, *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
   int *ip = (int *)(rowv + (q > 128 ? q : 128)), *ir = ip + q, *ic = ir + q;
   for (int e = tid; e < q * q; e += nt) {
     const int i = e / q, j = e - i * q;

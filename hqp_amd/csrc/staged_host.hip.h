@@ -50,7 +50,7 @@ struct StagedDev {
     tri_maps.push_back({T, b});
     return b->p;
   }
-  size_t lds_small = 0, lds_init = 0;
+  size_t lds_small = 0, lds_small_big = 0, lds_init = 0;
   void release() {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
@@ -309,14 +309,19 @@ static int staged_upload(hqpkkt_t *h) {
       if (T >= 16) (void)d.tri_map(T, true);
     }
   }
-  d.lds_small = 0;
-  for (int k = 0; k < P.K; k++) d.lds_small = std::max(d.lds_small, stg::st_small_lds(P.mk[k], P.capn[k]));
+  d.lds_small = 0, d.lds_small_big = 0;
+  for (int k = 0; k < P.K; k++) {
+    if (P.big[k])
+      d.lds_small_big = std::max(d.lds_small_big, stg::st_small_lds(P.mk[k], P.capn[k], true));
+    else
+      d.lds_small = std::max(d.lds_small, stg::st_small_lds(P.mk[k], P.capn[k]));
+  }
   {
     const size_t q = (size_t)P.q0max;
-    d.lds_init = (size_t)kktdev::gj_lds_bytes((long long)q);
+    d.lds_init = (size_t)kktdev::gj_lds_bytes((long long)q) - (P.big0 ? q * (q | 1) * 8 : 0);
   }
   static std::mutex attr_mutex;  // function attributes are process state, shared by all handles
-  static size_t attr_small = 0, attr_init = 0;
+  static size_t attr_small = 0, attr_small_big = 0, attr_init = 0, attr_init_big = 0;
   static bool attr_gemm = false;
   {
     std::lock_guard<std::mutex> lk(attr_mutex);
@@ -325,14 +330,24 @@ static int staged_upload(hqpkkt_t *h) {
       attr_gemm = true;
     }
     if (d.lds_small > attr_small) {
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_small, hipFuncAttributeMaxDynamicSharedMemorySize,
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)d.lds_small));
       attr_small = d.lds_small;
     }
-    if (d.lds_init > attr_init) {
-      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_init_factor, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (d.lds_small_big > attr_small_big) {
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_small<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)d.lds_small_big));
+      attr_small_big = d.lds_small_big;
+    }
+    if (!P.big0 && d.lds_init > attr_init) {
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_init_factor<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)d.lds_init));
       attr_init = d.lds_init;
+    }
+    if (P.big0 && d.lds_init > attr_init_big) {
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_init_factor<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)d.lds_init));
+      attr_init_big = d.lds_init;
     }
   }
   h->uploaded = true;
@@ -433,8 +448,12 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     return e;
   {
     stg::SmallArgs sa{G, ldg, nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
-                      P.capn[k], P.cap[k], q, h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<<<1, 256, d.lds_small, h->stream>>>(sa));
+                      P.capn[k], P.cap[k], q, h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p,
+                      P.big[k] ? d.misc.p + P.oScr : nullptr};
+    if (P.big[k])
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
+    else
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, ldg, nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], q, sp.T, P.ldt[k], sp.dyn, sp.Y, ldy, sp.BT, P.ldb[k]};
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
   }
@@ -555,8 +574,12 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
                                       P.cap[k + 1], nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
       return e;
     stg::SmallArgs sa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
-                      P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<<<1, 256, d.lds_small, h->stream>>>(sa));
+                      P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p,
+                      P.big[k] ? d.misc.p + P.oScr : nullptr};
+    if (P.big[k])
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
+    else
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,
                      sp.Y, P.ldy[k], sp.BT, P.ldb[k]};
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
@@ -591,9 +614,13 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     StagePtr s0 = stage_ptr(d, 0);
     if (P.fixed_x0)
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_check_fixed<<<1, 64, 0, s>>>(s0.dyn, h->flags.p));
+    else if (P.big0)
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<1024><<<1, 1024, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
+                                                                                    d.misc.p + P.oK0, d.misc.p + P.oK0m, P.ldq0, P.q0max, h->flags.p,
+                                                                                    d.misc.p + P.oScr));
     else
-      KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<<<1, 256, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
-                                                                             d.misc.p + P.oK0, d.misc.p + P.oK0m, P.ldq0, P.q0max, h->flags.p));
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<256><<<1, 256, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
+                                                                                  d.misc.p + P.oK0, d.misc.p + P.oK0m, P.ldq0, P.q0max, h->flags.p, nullptr));
   }
   if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
   HIPCHK(hipGetLastError());

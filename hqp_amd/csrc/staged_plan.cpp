@@ -8,7 +8,8 @@
 namespace kktdev {
 
 namespace {
-const int CARRY_MAX = 48;
+const int CARRY_MAX = 256;   // carried constraint rows a stage may hand to the one before it
+const int CONTROLS_MAX = 512;  // controls per stage
 inline int up8(long long x) { return (int)((x + 7) / 8 * 8); }
 inline long long up16(long long x) { return (x + 15) / 16 * 16; }
 }  // namespace
@@ -167,6 +168,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   // ------------------------------------------------------------------ capacities
   cap.assign(K + 1, 0), capn.assign(K + 1, 0), qmax.assign(K + 1, 0);
   cap[K] = capn[K] = (int)eq[K].size();
+  if (cap[K] > CARRY_MAX) return 1;
   for (int k = K - 1; k >= 0; k--) {
     capn[k] = (int)eq[k].size() + cap[k + 1];
     // structural bound (nothing consumed), cut at what the kernels are built for: a stage that
@@ -174,19 +176,34 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     cap[k] = std::min(capn[k], CARRY_MAX);
     qmax[k] = mk[k] + std::min(mk[k], capn[k]);
     // at most mk[k] rows can be consumed by this stage's controls: more than CARRY_MAX are left for sure
-    if (capn[k] - mk[k] > CARRY_MAX) return 1;
+    if (capn[k] - mk[k] > CARRY_MAX || mk[k] > CONTROLS_MAX) return 1;
   }
   q0max = fixed_x0 ? 0 : nk[0] + cap[0];
-  // what the one-workgroup kernels hold in LDS (~150 KB)
+  // Stages whose control-sized work fits the LDS of one CU (~150 KB) run it there; the others ("big": some
+  // hundreds of controls or carried rows) run the same elimination with their matrices in a scratch area of
+  // the misc arena (k_st_small with SmallArgs::scratch, 1024 threads)
+  big.assign(K + 1, 0);
+  scratch_elems = 0;
   for (int k = 0; k < K; k++) {
     const long long q = qmax[k];
     const long long a = (long long)capn[k] * (mk[k] + capn[k]) * 8 + (capn[k] + mk[k] + 2) * 4LL + capn[k] * 8LL;
     const long long b = gj_lds_bytes(q);
-    if (std::max(a, b) + 256 > 150 * 1024) return 1;
+    if (std::max(a, b) + 256 > 150 * 1024) {
+      big[k] = 1;
+      scratch_elems = std::max(scratch_elems, std::max((long long)capn[k] * (mk[k] + capn[k]), q * (q | 1)) + 64);
+    }
   }
+  big0 = 0;
   if (!fixed_x0) {
     const long long q = q0max;
-    if (gj_lds_bytes(q) + 256 > 150 * 1024) return 1;
+    if (gj_lds_bytes(q) + 256 > 150 * 1024) {
+      // a free initial state of many components: [V_0 B_0'; B_0 0] of order n_0 + carried rows is inverted by ONE
+      // workgroup out of global memory - up to order 1024; beyond that HQPKKT_E_SIZES (a blocked factorisation
+      // of V_0 is what it would take)
+      if (q > 1024) return 1;
+      big0 = 1;
+      scratch_elems = std::max(scratch_elems, q * (q | 1) + 64);
+    }
   }
 
   // ------------------------------------------------------------------ storage
@@ -240,6 +257,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   oPart = mo, mo += up16((long long)part_chunks * (nzmax + 8));
   oS = mo, mo += up16(n + 8);
   oQv = mo, mo += up16(n + 8);
+  oScr = mo, mo += up16(scratch_elems);
   // ------------------------------------------------------------------ column ranges of the ranks
   xcut.clear(), xslot.assign(K + 1, 0), oX = 0;
   if (sharded) {

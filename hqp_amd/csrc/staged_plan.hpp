@@ -33,6 +33,9 @@ struct StagedPlan {
   // static bounds: cap[k] carried rows leaving stage k, capn[k] rows of N_k, qmax[k] order of K_k
   std::vector<int> cap, capn, qmax;
   int q0max = 0, ldq0 = 8;  // free initial state: order of [V_0 B_0'; B_0 0]
+  std::vector<char> big;    // per stage: its control-sized matrices do not fit LDS (scratch in the misc arena instead)
+  int big0 = 0;             // the same for the free initial state
+  long long scratch_elems = 0, oScr = 0;
 
   // dense storage (element offsets; leading dimensions are multiples of 8)
   std::vector<int> ldf, ldv, ldy, ldn, ldb, ldq, ldt, ldg;

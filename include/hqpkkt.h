@@ -284,8 +284,12 @@ int hqpkkt_set_shard_stream(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_st
  * of A exactly as Hqp_IpLQDOCP::Get_Dim does (:201-287) unless hqpkkt_set_stages has given
  * them (K stages, nx[K+1] states, nu[K] controls; K <= 0 returns to the detection);
  * HQPKKT_E_FORMAT: the pattern / the values are not such a staircase (the reference
- * asserts), HQPKKT_E_SIZES: a stage has more controls or carries more constraint rows
- * than the one-workgroup kernels hold (about 64 controls + 48 carried rows).  mat_sbw is -1. */
+ * asserts), HQPKKT_E_SIZES: a stage with more than 512 controls, more than 256 constraint rows
+ * carried from one stage to the one before it, or a FREE initial state with more than 1024 components
+ * + carried rows (a fixed x_0 has no limit).  Up to ~64 controls and ~130 for the order of a stage's
+ * [G_uu N_u'; N_u 0] the control-sized work of a stage runs in the LDS of one CU; beyond that the same
+ * elimination runs out of global memory (one workgroup: correct and slow, ~20 ms per stage at 300
+ * controls).  mat_sbw is -1. */
 int hqpkkt_set_stages(hqpkkt_t *h, int K, const int *nx, const int *nu);
 /* The same with the dynamics handed over as DENSE blocks instead of CSR rows - what a DOCP of
  * 10^6 variables needs (K = 200 stages of 5000 states: the CSR form of fx alone would hold

@@ -235,6 +235,31 @@ def test_dense_handover_equals_csr_handover(device_vectors):
         assert np.abs(xa - xb).max() <= 1e-7 * max(1.0, np.abs(xa).max())
 
 
+@pytest.mark.parametrize("case", ["nu200", "final140", "final100_nu50", "free_x0_250", "nu300_path40", "nu512"])
+def test_stages_beyond_one_cu_of_lds(case):
+    """Stages whose control-sized matrices do not fit the LDS of one CU (round 2: HQPKKT_E_SIZES and the tree engine):
+    hundreds of controls, more than a hundred constraint rows carried back through the stages, a free initial state
+    of 250 components - the same elimination with its matrices in global memory (StagedPlan::big).  Against the
+    full-system engine: same solution, residual of the refined solve below mat_eps."""
+    prog = {"nu200": lambda: problems.lq_docp(4, 260, 200, seed=2),
+            "final140": lambda: problems.lq_docp(10, 160, 20, final_eq=140, seed=3),
+            "final100_nu50": lambda: problems.lq_docp(5, 120, 50, final_eq=100, seed=3),
+            "nu512": lambda: problems.lq_docp(2, 520, 512, seed=6),
+            "free_x0_250": lambda: problems.lq_docp(3, 250, 6, x0_fixed=False, final_eq=3, seed=4),
+            "nu300_path40": lambda: problems.lq_docp(3, 200, 300, path_eq=40, seed=5)}[case]()
+    st = problems.ip_state(prog, 6, 1.0)
+    S, F = ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()
+    ds, rs = _solve(S, prog, st)
+    df, rf = _solve(F, prog, st)
+    assert rs <= RES_TOL and rf <= RES_TOL, (rs, rf)
+    assert rel_err(ds, df) <= SOL_TOL
+    ranks = S.stage_ranks()
+    if case == "final140":  # the 140 final-state rows are consumed twenty per stage on their way back
+        assert ranks[-1, 1] == 140 and ranks[0, 1] == 0 and ranks[:, 0].max() == 20 and (ranks[:, 0] == 20).sum() == 7
+    if case == "nu300_path40":
+        assert (ranks[:-1, 0] == 40).all()
+
+
 def test_dgemm_kernel_against_exact_products():
     """k_dgemm_tn (both tile sizes, ragged edges, lower / mirrored output, K not a multiple
     of the slab) against exactly accumulated sample entries."""
