@@ -251,14 +251,15 @@ def c4_program(K, nx, nu, seed=0):
     return problems.Program(n, K * nx + nx, cols.size, Q, A, C)
 
 
-def _ref_lqdocp_time(args):
-    """One process: median factor+solve time of the reference's Hqp_IpLQDOCP on c4_program(K, nx, nu)."""
-    K, nx, nu, reps = args
+def _ref_time(args):
+    """One process: median factor+solve time of a reference plugin (Hqp_IpLQDOCP / Hqp_IpSpBKP) on c4_program(K, nx, nu)."""
+    K, nx, nu, reps = args[:4]
+    kind = args[4] if len(args) > 4 else "LQDOCP"
     from hqp_amd import problems
     from oracle import refapi
     prog = c4_program(K, nx, nu, seed=1)
     st = problems.ip_state(prog, 1)
-    R = refapi.RefIpMatrix("LQDOCP")
+    R = refapi.RefIpMatrix(kind)
     R.init(prog)
     ts, res = [], None
     for _ in range(reps):
@@ -268,13 +269,19 @@ def _ref_lqdocp_time(args):
     return float(np.median(ts)), float(res)
 
 
+_ref_lqdocp_time = _ref_time
+
+
 def cpu_baseline_c4(K, nx, nu):
-    """The reference's own multistage plugin Hqp_IpLQDOCP (oracle/_ref, built from the reference's
-    sources) timed on this box's host cores on a BOUNDED sample of the workload: the same QP family
-    at K stages with nx = 100 and 200 states (the full nx = 5000 needs ~10^14 flops of Meschach's
-    triple-loop m_mlt: about half a day on one core), extrapolated with the exponent the two samples
-    give (SURVEY.md 8(d) C4 prescribes this).  One core (the path is single-threaded) plus the
-    aggregate of 8 instances on 8 cores."""
+    """The reference's own plugins (oracle/_ref, built from the reference's sources) timed on this box's host cores on a
+    BOUNDED sample of the workload, as SURVEY.md 8(d) C4 prescribes: the same QP family at K stages with nx = 50, 100,
+    200 and 400 states for the multistage plugin Hqp_IpLQDOCP (the full nx = 5000 needs ~10^14 flops of Meschach's
+    triple-loop m_mlt: about half a day on one core) and nx = 50, 100 for Hqp_IpSpBKP, the plugin north_star names as
+    the comparator (its band grows with nx: 13.7 s per factorisation at nx = 200 already).  Extrapolated to nx two ways:
+    with the exponent fitted over the samples (least squares in log-log; it still grows towards 3 over them, so this
+    flatters the CPU) and with nx^3 from the largest sample.  `value` uses the fitted exponent of Hqp_IpLQDOCP - the
+    faster plugin and the smaller extrapolation, i.e. the most favourable reading for the CPU.  One core (the path is
+    single-threaded) plus the aggregate of 8 instances on 8 cores."""
     try:
         from oracle import refapi
         have_ref = refapi.available()
@@ -295,19 +302,37 @@ def cpu_baseline_c4(K, nx, nu):
         return {"value": 1.0 / t, "unit": "KKT factor+solve/s", "cores": 1, "kind": "port", "host_cores": cores,
                 "sample": "1 x factor+solve of a REDUCED-SIZE multistage QP (K=12, nx=12, nu=3) with the dense-storage C oracle of "
                           "the full system; oracle/_ref not loadable on this box; NOT extrapolated"}
-    t100, r100 = _ref_lqdocp_time((K, 100, nu, 5))
-    t200, r200 = _ref_lqdocp_time((K, 200, nu, 5))
-    expo = float(np.log(t200 / t100) / np.log(2.0))
-    t_full = t200 * (nx / 200.0) ** expo
-    out = {"value": 1.0 / t_full, "unit": "KKT factor+solve/s", "cores": 1, "kind": "reference", "host_cores": cores,
-           "sample": f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve, median of 5 after one init, same QP family at K={K}, nu={nu}: "
-                     f"nx=100 {t100:.3f} s, nx=200 {t200:.3f} s (residuals {r100:.1e}, {r200:.1e}); EXTRAPOLATED to nx={nx} with the "
-                     f"measured exponent {expo:.2f}: {t_full:.0f} s per factor+solve",
-           "measured": {"nx100_s": t100, "nx200_s": t200, "exponent": expo}, "extrapolated_s": t_full}
+
+    def fit(sizes, times):
+        lx, lt = np.log(np.asarray(sizes, float)), np.log(np.asarray(times, float))
+        expo = float(np.polyfit(lx, lt, 1)[0])
+        local = float(np.log(times[-1] / times[-2]) / np.log(sizes[-1] / sizes[-2])) if len(sizes) > 1 else expo
+        return {"sizes": list(sizes), "seconds": [float(t) for t in times], "exponent_fit": expo, "exponent_last_two": local,
+                "extrapolated_fit_s": float(times[-1] * (nx / sizes[-1]) ** expo),
+                "extrapolated_cubic_s": float(times[-1] * (nx / sizes[-1]) ** 3)}
+
+    sizes_l, reps_l = (50, 100, 200, 400), (5, 5, 3, 2)
+    tl = [_ref_time((K, s_, nu, r_))[0] for s_, r_ in zip(sizes_l, reps_l)]
+    lq = fit(sizes_l, tl)
+    out = {"value": 1.0 / lq["extrapolated_fit_s"], "unit": "KKT factor+solve/s", "cores": 1, "kind": "reference", "host_cores": cores,
+           "sample": f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve, median after one init, same QP family at K={K}, nu={nu}: "
+                     + ", ".join(f"nx={s_} {t_:.3f} s" for s_, t_ in zip(sizes_l, tl))
+                     + f"; EXTRAPOLATED to nx={nx}: fitted exponent {lq['exponent_fit']:.2f} -> {lq['extrapolated_fit_s']:.0f} s (used for `value`), "
+                       f"nx^3 from nx=400 -> {lq['extrapolated_cubic_s']:.0f} s per factor+solve",
+           "lqdocp": lq, "measured": {"nx100_s": tl[1], "nx200_s": tl[2], "exponent": lq["exponent_fit"]},
+           "extrapolated_s": lq["extrapolated_fit_s"]}
+    try:  # Hqp_IpSpBKP, the comparator north_star names (full KKT system, RCM band of ~3 nx)
+        sizes_s = (50, 100)
+        ts_ = [_ref_time((K, s_, nu, 2, "SpBKP"))[0] for s_ in sizes_s]
+        out["spbkp"] = fit(sizes_s, ts_)
+        out["spbkp"]["note"] = ("Hqp_IpSpBKP::factor + solve on the same QPs; its work grows ~nx^3 (band ~3 nx), memory ~N*band: the nx=5000 system "
+                                "would need ~340 GB of factor (SURVEY.md 6) - extrapolation only")
+    except Exception as e:
+        out["spbkp"] = {"error": str(e)}
     try:  # 8 independent instances on the host's cores: aggregate rate at the nx=100 sample
         import subprocess
         inst = min(8, cores or 1)
-        code = ("import sys; sys.path.insert(0, %r); import bench; t, r = bench._ref_lqdocp_time((%d, 100, %d, 3)); print(t)"
+        code = ("import sys; sys.path.insert(0, %r); import bench; t, r = bench._ref_time((%d, 100, %d, 3)); print(t)"
                 % (ROOT, K, nu))
         t0 = time.perf_counter()
         procs = [subprocess.Popen([sys.executable, "-c", code], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True)
@@ -315,8 +340,8 @@ def cpu_baseline_c4(K, nx, nu):
         ts = [float(p.communicate(timeout=300)[0].strip().splitlines()[-1]) for p in procs]
         wall = time.perf_counter() - t0
         tm = float(np.median(ts))
-        out["aggregate_instances"] = {"instances": inst, "median_s_per_instance_nx100": tm, "slowdown_vs_alone": tm / t100,
-                                      "aggregate_value_extrapolated": inst / (t_full * tm / t100), "wall_s": wall}
+        out["aggregate_instances"] = {"instances": inst, "median_s_per_instance_nx100": tm, "slowdown_vs_alone": tm / tl[1],
+                                      "aggregate_value_extrapolated": inst / (lq["extrapolated_fit_s"] * tm / tl[1]), "wall_s": wall}
     except Exception as e:
         out["aggregate_instances"] = {"error": str(e)}
     return out
@@ -588,6 +613,12 @@ def bench_c4(args):
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline_c4(K, nx, nu)
         out["speedup_vs_cpu_baseline"] = out["value"] / out["cpu_baseline"]["value"]
+        cb = out["cpu_baseline"]
+        if "lqdocp" in cb:  # the same ratio under the other readings of the extrapolation (all of them extrapolations)
+            out["speedup_vs_cpu_baseline_readings"] = {
+                "Hqp_IpLQDOCP, fitted exponent": out["value"] * cb["lqdocp"]["extrapolated_fit_s"],
+                "Hqp_IpLQDOCP, nx^3 from nx=400": out["value"] * cb["lqdocp"]["extrapolated_cubic_s"],
+                "Hqp_IpSpBKP, nx^3 from nx=100": out["value"] * cb["spbkp"]["extrapolated_cubic_s"] if "extrapolated_cubic_s" in cb.get("spbkp", {}) else None}
         del mat
         torch.cuda.empty_cache()
         out["staged_small_sizes"] = staged_small_sizes(local_rank)
