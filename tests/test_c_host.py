@@ -98,3 +98,19 @@ def test_detect_stages_matches_the_plan():
     assert p[2] - p[1] == p[3] - p[2]
     i[r0], i[r1] = i[r1].copy(), i[r0].copy()
     assert detect(problems.Program(prog.n, prog.me, prog.m, prog.Q, (p, i, x), prog.C))[0] == 6
+
+
+def test_host_side_cpp_under_address_and_ub_sanitizers(tmp_path):
+    """SURVEY.md section 5 (sanitizers on the CPU side): analysis.cpp and staged_plan.cpp, the product's host-side C++,
+    built with -fsanitize=address,undefined and run over banded, Prg_DID-like and multistage structures (orderings,
+    shard plans for 1 / 3 / 8 ranks, big stages, dense hand-over, a non-staircase): no report, exit status 0."""
+    exe = str(tmp_path / "sanitize_host")
+    src = [os.path.join(ROOT, "tests", "c_host", "sanitize_host.cc"), os.path.join(ROOT, "hqp_amd", "csrc", "analysis.cpp"),
+           os.path.join(ROOT, "hqp_amd", "csrc", "staged_plan.cpp")]
+    out = subprocess.run(["g++", "-O1", "-g0", "-std=c++17", "-fsanitize=address,undefined", "-fno-sanitize-recover=all", "-o", exe] + src,
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    run = subprocess.run([exe], capture_output=True, text=True, timeout=300,
+                         env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:abort_on_error=0", UBSAN_OPTIONS="print_stacktrace=1"))
+    assert run.returncode == 0, (run.returncode, run.stdout[-500:], run.stderr[-3000:])
+    assert "sanitize_host ok" in run.stdout
