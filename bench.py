@@ -528,12 +528,14 @@ def bench_c4(args):
     gemm_ms, gemm_launch = per_step.get("staged_gemm", 0.0), launches.get("staged_gemm", 1.0)
     achieved = flops_big / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
     traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_c4.json")
+    pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic_c4.json")
+    if not os.path.exists(pmc):
+        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_c4.json")
     if os.path.exists(pmc) and (nx, nu) == (5000, 50) and not one:
         # HBM bytes per launch of the stream-K dgemm from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
         # workload (separate runs, gfx950 correction applied: profiles/README.md)
         traffic = json.load(open(pmc)).get("k_dgemm_tn_sk", {}).get("hbm_bytes_per_launch")
-    roofline = {"kernel": "k_dgemm_tn_sk / k_dgemm_tn<128,128> (W = V+ F, G = F'W)", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+    roofline = {"kernel": "k_dgemm_tn_sk<lds-dma, 2x4 waves> / k_dgemm_tn<128,128> (W = V+ F, G = F'W)", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS if achieved else None, "traffic": traffic,
                 "launches_per_step": gemm_launch, "avg_launch_ms": gemm_ms / gemm_launch if gemm_launch else None,
                 "algorithmic_flops_per_launch": flops_big / gemm_launch if gemm_launch else None,

@@ -187,6 +187,7 @@ struct hqpkkt {
   // host vectors of a small system: packed into / out of pinned memory by the CPU, ONE
   // transfer each way instead of six + four staged copies from pageable memory
   double *hvals = nullptr;   // pinned host staging of Qx | Ax | Cx (hqpkkt_values_staging), nq + na + nc doubles
+  size_t hvals_elems = 0;    // ... as allocated: a new analysis with another pattern allocates again
   double *hstage = nullptr;
   size_t hstage_in = 0, hstage_out = 0;  // doubles; 0 = system too large, copy vector by vector
   const double *out_pending = nullptr;   // results wait in hstage + hstage_in for unstage()
@@ -256,7 +257,9 @@ struct hqpkkt {
     terms.release(), esign.release(), bits.p = nullptr;
     if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr;
     if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
-    if (hvals) (void)hipHostFree(hvals), hvals = nullptr;
+    // (keep_ip = the re-analysis inside hqpkkt_solve, switch_to_policy0: the pattern and with it the sizes of the
+    // pinned value staging stay, and a host may hold the pointers of hqpkkt_values_staging)
+    if (hvals && !keep_ip) (void)hipHostFree(hvals), hvals = nullptr, hvals_elems = 0;
     hstage_in = hstage_out = 0;
     Qf.release(), A.release(), AT.release(), C.release(), CT.release();
     if (sd) staged_release(sd, false);
@@ -1950,7 +1953,12 @@ int hqpkkt_values_staging(hqpkkt_t *h, double **Qx, double **Ax, double **Cx) {
   int e = ensure_device(h);
   if (e) return e;
   const Analysis &an = h->an;
-  if (!h->hvals) HIPCHK(hipHostMalloc((void **)&h->hvals, sizeof(double) * ((size_t)an.nq + an.na + an.nc + 1), hipHostMallocDefault));
+  const size_t need = (size_t)an.nq + an.na + an.nc + 1;
+  if (h->hvals && h->hvals_elems != need) (void)hipHostFree(h->hvals), h->hvals = nullptr;  // (analysed again for another pattern)
+  if (!h->hvals) {
+    HIPCHK(hipHostMalloc((void **)&h->hvals, sizeof(double) * need, hipHostMallocDefault));
+    h->hvals_elems = need;
+  }
   *Qx = h->hvals, *Ax = h->hvals + an.nq, *Cx = h->hvals + an.nq + an.na;
   return 0;
 }
