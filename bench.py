@@ -626,7 +626,9 @@ def bench_c4(args):
         out["staged_small_sizes"] = staged_small_sizes(local_rank)
         # round 1's headline workload (BASELINE configs[1]) through the full-system engine
         a2 = argparse.Namespace(**vars(args))
-        a2.steps, a2.warmup = min(args.steps, 10), min(args.warmup, 2)
+        # (the GPU has idled through the CPU baseline above - about a minute of host work: enough warm-up steps for its
+        # clocks to be back before the 10 timed ones, a step takes 3 ms)
+        a2.steps, a2.warmup = min(args.steps, 10), 50
         c2 = bench_c2(a2, extras=False)
         out["c2_banded_kkt"] = {k: c2[k] for k in ("value", "unit", "ms_per_step", "residual", "roofline", "init_s")} if c2 else None
         out["ip_iterations"] = ip_iterations(2000)

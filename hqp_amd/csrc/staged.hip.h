@@ -283,7 +283,13 @@ struct GemmTile {
     }
   }
 
-  static __device__ __forceinline__ void epilogue(const GemmArgs &g, int tm, int tn, const double4_t (&acc)[TM][TN]) {
+  // `lds`: the workgroup's LDS (free after accumulate's last barrier), used to write the MIRROR image of an
+  // off-diagonal tile in whole rows: the values of 64 tile columns at a time go to LDS transposed ([column][row],
+  // leading dimension BM + 2: conflict-free), and every wave then writes rows of the mirrored block in 1-KiB (BM = 128)
+  // pieces - written element by element the image costs one 32-byte sector per value (the rank-q update V = G_xx -
+  // Y'Rm of a C4 stage, which is nothing but reading G and writing V and its image: 158 us, 1.9 TB/s).  All threads
+  // of the workgroup must call (barriers inside when g.mirror is set).
+  static __device__ __forceinline__ void epilogue(const GemmArgs &g, int tm, int tn, const double4_t (&acc)[TM][TN], double *lds) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lk = lane >> 4;
@@ -298,6 +304,9 @@ struct GemmTile {
       ldcin = g.strips->cut[p + 1] - c0;
       cin = g.Cin + g.strips->off[p] - ((long long)c0 * ldcin + c0);
     }
+    constexpr int HC = BN < 64 ? BN : 64, LDT = BM + 2;  // columns per pass of the mirrored write
+    const bool via_lds = g.mirror && !diag && lds != nullptr;
+    double4_t val[TM][TN];
 #pragma unroll
     for (int x = 0; x < TM; x++)
 #pragma unroll
@@ -305,13 +314,46 @@ struct GemmTile {
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) {
           const int i = i0 + wm * WM + 16 * x + lk + 4 * rg, j = j0 + wn * WN + 16 * y + lr;
-          if (i >= g.M || j >= g.N) continue;
-          if (diag && g.mirror && i < j) continue;
-          double v = g.alpha * acc[x][y][rg];
-          if (g.beta != 0.0) v += g.beta * cin[(long long)i * ldcin + j];
-          g.C[(long long)i * g.ldc + j] = v;
-          if (g.mirror && i != j) g.C[(long long)j * g.ldc + i] = v;
+          double v = 0.0;
+          if (i < g.M && j < g.N && !(diag && g.mirror && i < j)) {
+            v = g.alpha * acc[x][y][rg];
+            if (g.beta != 0.0) v += g.beta * cin[(long long)i * ldcin + j];
+            g.C[(long long)i * g.ldc + j] = v;
+            if (g.mirror && i != j && !via_lds) g.C[(long long)j * g.ldc + i] = v;
+          }
+          val[x][y][rg] = v;
         }
+    if (via_lds) {  // (uniform for the workgroup)
+#pragma unroll
+      for (int h = 0; h < BN / HC; h++) {
+        if ((wn * WN) / HC == h) {
+#pragma unroll
+          for (int x = 0; x < TM; x++)
+#pragma unroll
+            for (int y = 0; y < TN; y++)
+#pragma unroll
+              for (int rg = 0; rg < 4; rg++)
+                lds[(wn * WN - h * HC + 16 * y + lr) * LDT + wm * WM + 16 * x + lk + 4 * rg] = val[x][y][rg];
+        }
+        __syncthreads();
+        // row jj of the image = column j0 + h HC + jj of the tile: BM values, two per lane and row
+        for (int jj = wave; jj < HC; jj += NW) {
+          const int j = j0 + h * HC + jj;
+          if (j >= g.N) break;
+          for (int ii = 2 * lane; ii < BM; ii += 128) {
+            const int i = i0 + ii;
+            double *dst = g.C + (long long)j * g.ldc + i;
+            if (i + 1 < g.M && (((size_t)dst) & 15) == 0)
+              *(double2_t *)dst = *(const double2_t *)(lds + jj * LDT + ii);
+            else {
+              if (i < g.M) dst[0] = lds[jj * LDT + ii];
+              if (i + 1 < g.M) dst[1] = lds[jj * LDT + ii + 1];
+            }
+          }
+        }
+        __syncthreads();
+      }
+    }
   }
 };
 
@@ -333,7 +375,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn(Gemm
   else
     T::accumulate(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
   const unsigned long long t2 = g.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
-  T::epilogue(g, tm, tn, acc);
+  T::epilogue(g, tm, tn, acc, lds);
   if (g.stamps && threadIdx.x == 0) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     unsigned xcc;
@@ -429,7 +471,14 @@ static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
   if (tiles % grid == 0 || tiles >= 16LL * grid) return false;  // even, or the tail does not matter
   // (a CU with one workgroup reaches 92 % of what it does with two: up to 5/8 of the grid one plain round of one
   // or two workgroups per CU is as fast as cut pieces, without their parked partial sums)
-  return tiles > grid * 5 / 8;
+  if (tiles > grid * 5 / 8) return true;
+  // few tiles (a stage of ~1000 states: 72): cut every tile's k range so that about half of the CUs get a piece -
+  // against 64 x 64 tiles on the register-staged loop (1000 x 1050 x 1000: 91 us)
+  if (tiles <= grid / 4 && !getenv("HQPKKT_NO_SMALL_SPLIT")) {
+    const SplitPlan sp = gemm_split_plan(tiles, nslab, grid);
+    return sp.nphase == 1 && sp.split[0] >= 2 && (long long)sp.count[0] * sp.split[0] >= grid / 4;
+  }
+  return false;
 }
 template <bool DMA, int WGM = 2, int WGN = 2>
 __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn_sk(GemmArgs g, SplitPlan sk) {
@@ -536,7 +585,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn_sk(G
       __syncthreads();  // s_old is rewritten at the next shared tile
     }
     if (stamp && threadIdx.x == 0 && r < 5) stamp[2 + 3 * r] = __builtin_amdgcn_s_memrealtime();
-    if (finish) T::epilogue(g, tm, tn, acc);
+    if (finish) T::epilogue(g, tm, tn, acc, lds);  // (uniform: the whole workgroup)
     if (stamp && threadIdx.x == 0 && r < 5) {
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       stamp[3 + 3 * r] = __builtin_amdgcn_s_memrealtime();
@@ -1259,15 +1308,41 @@ struct GemvCols {
   int rows_per_chunk;
 };
 __global__ void __launch_bounds__(256) k_st_gemv_cols(GemvCols g) {
-  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  // two neighbouring columns per thread (one 16-byte load per row; rows 16-byte aligned when lda is even and the
+  // block starts aligned), four rows in flight
+  const int j = 2 * (blockIdx.x * blockDim.x + threadIdx.x);
   if (j >= g.N) return;
   const int k0 = blockIdx.y * g.rows_per_chunk, k1 = min(g.K, k0 + g.rows_per_chunk);
-  double s = 0.0;
-  for (int k = k0; k < k1; k++) s += g.A[(long long)k * g.lda + j] * g.x[k];
-  if (gridDim.y == 1)
-    g.y[j] = (g.add ? g.add[j] : 0.0) + g.alpha * s;
-  else
-    g.part[(long long)blockIdx.y * g.N + j] = s;
+  double s0 = 0.0, s1 = 0.0;
+  const double *a = g.A + (long long)k0 * g.lda + j;
+  if (j + 1 < g.N && (((size_t)a) & 15) == 0 && (g.lda & 1) == 0) {
+    double t0 = 0.0, t1 = 0.0, u0 = 0.0, u1 = 0.0, w0 = 0.0, w1 = 0.0;
+    int k = k0;
+    for (; k + 3 < k1; k += 4, a += 4 * g.lda) {
+      const double2_t v0 = *(const double2_t *)a, v1 = *(const double2_t *)(a + g.lda), v2 = *(const double2_t *)(a + 2 * g.lda),
+                      v3 = *(const double2_t *)(a + 3 * g.lda);
+      const double x0 = g.x[k], x1 = g.x[k + 1], x2 = g.x[k + 2], x3 = g.x[k + 3];
+      s0 += v0.x * x0, s1 += v0.y * x0, t0 += v1.x * x1, t1 += v1.y * x1;
+      u0 += v2.x * x2, u1 += v2.y * x2, w0 += v3.x * x3, w1 += v3.y * x3;
+    }
+    for (; k < k1; k++, a += g.lda) {
+      const double2_t v0 = *(const double2_t *)a;
+      s0 += v0.x * g.x[k], s1 += v0.y * g.x[k];
+    }
+    s0 = (s0 + t0) + (u0 + w0), s1 = (s1 + t1) + (u1 + w1);
+  } else {
+    for (int k = k0; k < k1; k++, a += g.lda) {
+      s0 += a[0] * g.x[k];
+      if (j + 1 < g.N) s1 += a[1] * g.x[k];
+    }
+  }
+  if (gridDim.y == 1) {
+    g.y[j] = (g.add ? g.add[j] : 0.0) + g.alpha * s0;
+    if (j + 1 < g.N) g.y[j + 1] = (g.add ? g.add[j + 1] : 0.0) + g.alpha * s1;
+  } else {
+    g.part[(long long)blockIdx.y * g.N + j] = s0;
+    if (j + 1 < g.N) g.part[(long long)blockIdx.y * g.N + j + 1] = s1;
+  }
 }
 __global__ void k_st_cols_finish(int N, int nchunk, const double *__restrict__ part, const double *__restrict__ add,
                                  double alpha, double *__restrict__ y) {

@@ -133,7 +133,7 @@ int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int 
   const kktdev::StagedPlan &P = d.plan;
   int chunks = std::max(1, std::min(P.part_chunks, K / 64));
   stg::GemvCols g{A, lda, K, N, x, add, alpha, y, d.misc.p + P.oPart, (K + chunks - 1) / chunks};
-  KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_cols<<<dim3((N + 255) / 256, chunks), 256, 0, h->stream>>>(g));
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_cols<<<dim3((N + 511) / 512, chunks), 256, 0, h->stream>>>(g));
   if (chunks > 1)
     KLAUNCH(h, KC_ST_VEC, stg::k_st_cols_finish<<<(N + 255) / 256, 256, 0, h->stream>>>(N, chunks, d.misc.p + P.oPart, add,
                                                                                        alpha, y));

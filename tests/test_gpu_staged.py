@@ -260,6 +260,21 @@ def test_stages_beyond_one_cu_of_lds(case):
         assert (ranks[:-1, 0] == 40).all()
 
 
+@pytest.mark.parametrize("nx,nu,K", [(1000, 8, 3), (1500, 40, 2), (2304, 16, 2)])
+def test_staged_mid_size_stages_against_the_tree_engine(nx, nu, K):
+    """Stage widths between the small cases (nx <= 400: reference, oracle) and the headline (nx = 5000: properties):
+    72 ... 324 tiles of 128 x 128 per product - the cut few-tile launches, plain rounds and the 64 x 64 kernel all
+    occur - against the full-system (tree) engine on the same QP: same solution to 1e-8, residual of the refined
+    solve below mat_eps on both."""
+    prog = problems.lq_docp(K, nx, nu, final_eq=2, seed=21)
+    st = problems.ip_state(prog, 8, 1.0)
+    S, F = ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()
+    ds, rs = _solve(S, prog, st)
+    df, rf = _solve(F, prog, st)
+    assert rs <= RES_TOL and rf <= RES_TOL, (rs, rf)
+    assert rel_err(ds, df) <= SOL_TOL
+
+
 def test_dgemm_kernel_against_exact_products():
     """k_dgemm_tn (both tile sizes, ragged edges, lower / mirrored output, K not a multiple
     of the slab) against exactly accumulated sample entries."""
