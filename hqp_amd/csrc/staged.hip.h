@@ -474,7 +474,9 @@ static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
   if (tiles > grid * 5 / 8) return true;
   // few tiles (a stage of ~1000 states: 72): cut every tile's k range so that about half of the CUs get a piece -
   // against 64 x 64 tiles on the register-staged loop (1000 x 1050 x 1000: 91 us)
-  if (tiles <= grid / 4 && !getenv("HQPKKT_NO_SMALL_SPLIT")) {
+  // (measured: 0.149 ms against 0.091 - three pieces of 21 slabs cost more in pipeline fill, parked partial sums and their
+  // summation than the fuller grid gains; kept as an experiment: HQPKKT_SMALL_SPLIT)
+  if (tiles <= grid / 4 && getenv("HQPKKT_SMALL_SPLIT")) {
     const SplitPlan sp = gemm_split_plan(tiles, nslab, grid);
     return sp.nphase == 1 && sp.split[0] >= 2 && (long long)sp.count[0] * sp.split[0] >= grid / 4;
   }
@@ -946,10 +948,11 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
   __syncthreads();
   return 0;
 }
-// dispatch: registers up to order 64, LDS above
+// dispatch: registers up to order 64 (the register forms are laid out for 256 threads), LDS / global memory above
+template <int NT>
 __device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red,
                               bool spd = false) {
-  if (blockDim.x != 256) return gj_inverse(a, q, ld, ip, ir, ic, colv, rowv, red);  // (the register forms are laid out for 256 threads)
+  if constexpr (NT != 256) return gj_inverse(a, q, ld, ip, ir, ic, colv, rowv, red);
   if (spd && q <= 64) {
     const int e = q <= 16 ? gj_inverse_reg_spd<1>(a, q, ld, colv, rowv)
                 : q <= 32 ? gj_inverse_reg_spd<2>(a, q, ld, colv, rowv) : gj_inverse_reg_spd<4>(a, q, ld, colv, rowv);
@@ -989,7 +992,7 @@ struct SmallArgs {
                         // controls / carried rows: StagedPlan::big) and LDS holds the flags and vectors only
 };
 template <int NT>
-__global__ void __launch_bounds__(NT) k_st_small(SmallArgs a) {
+__global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (one workgroup: no occupancy to protect, all registers)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ ArgMax red[16];
   __shared__ int s_r, s_stop;
@@ -1112,7 +1115,7 @@ __global__ void __launch_bounds__(NT) k_st_small(SmallArgs a) {
       Km[i * ld + j] *= dsc[i] * dsc[j];
     }
     __syncthreads();
-    const int bad = gj_inverse_any(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
+    const int bad = gj_inverse_any<NT>(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
     if (bad && tid == 0) atomicExch(a.status, 4);
     __syncthreads();
     for (int e = tid; e < a.qmax * a.qmax; e += nt) {
@@ -1184,7 +1187,7 @@ __global__ void k_st_check_fixed(const int *__restrict__ dyn0, int *__restrict__
 
 // free initial state: inverse of [V_0 B_0'; B_0 0]  (hqp/Hqp_IpLQDOCP.C:1972-1996)
 template <int NT>
-__global__ void __launch_bounds__(NT) k_st_init_factor(int n0, int cap, const double *__restrict__ V, long long ldv,
+__global__ void __launch_bounds__(NT, NT / 256) k_st_init_factor(int n0, int cap, const double *__restrict__ V, long long ldv,
                                                        const double *__restrict__ BT, long long ldb,
                                                        const int *__restrict__ dyn0, double *__restrict__ K0inv,
                                                        double *__restrict__ K0mat, long long ldq, int qmax,
@@ -1222,7 +1225,7 @@ __global__ void __launch_bounds__(NT) k_st_init_factor(int n0, int cap, const do
   __syncthreads();
   for (int e = tid; e < q * q; e += nt) Km[(e / q) * ld + e % q] *= dsc[e / q] * dsc[e % q];
   __syncthreads();
-  const int bad = gj_inverse_any(Km, q, ld, ip, ir, ic, colv, rowv, red);
+  const int bad = gj_inverse_any<NT>(Km, q, ld, ip, ir, ic, colv, rowv, red);
   if (bad && tid == 0) atomicExch(status, 4);
   __syncthreads();
   for (int e = tid; e < qmax * qmax; e += nt) {
