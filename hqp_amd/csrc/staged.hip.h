@@ -233,18 +233,17 @@ struct GemmTile {
     __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)src,
                                      (__attribute__((address_space(3))) void *)lds_row, 16, 0, 0);
   }
-  static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
-                                                        double4_t (&acc)[TM][TN], double *As, double *Bs) {
-    static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
+  // `skip_upper`: the tile lies on the diagonal of a lower-triangular product - its 16 x 16 blocks strictly above the
+  // diagonal are not needed.  Blocks of 16 rows / columns beyond M / N (the ragged last tile row and column: 5000 = 39 x
+  // 128 + 8) and those blocks are left out of the multiplications: a wave whose blocks are all wanted runs the plain
+  // loop, the others a copy of it with a (wave-uniform, scalar) test in front of every MFMA.  The operands are staged
+  // and the barriers kept as always; what is saved is the matrix pipe's time, which the partner workgroup of the CU
+  // gets (3.8 % of W's and 5.3 % of G's multiplications at the C4 shapes).
+  template <bool MASKED>
+  static __device__ __forceinline__ void slabs_dma(const GemmArgs &g, const double *pa, const double *pb, const double *zr, int wave,
+                                                   int wm, int wn, int lr, int lk, int s0, int s1, unsigned mask,
+                                                   double4_t (&acc)[TM][TN], double *As, double *Bs) {
     constexpr int RPW = BK / NW;  // rows of each panel per wave and slab
-    static_assert(RPW * NW == BK && TM * TN >= 2 * RPW, "pieces are issued behind the multiplications of the first k-step");
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int lr = lane & 15, lk = lane >> 4;
-    // a 16-byte load is inside its row when its first column is < ld (ld even)
-    const double *pa = g.A + ((i0 + 2 * lane < g.lda) ? i0 + 2 * lane : 0);
-    const double *pb = g.B + ((j0 + 2 * lane < g.ldb) ? j0 + 2 * lane : 0);
-    const double *zr = g.zeros + 2 * lane;
     // piece p of the slab that starts at row k0 -> buffer buf: row wave + NW (p % RPW) of A (p < RPW) or B
     auto dma = [&](int buf, int k0, int p) {
       const int r = wave + NW * (p % RPW), k = k0 + r;
@@ -275,12 +274,39 @@ struct GemmTile {
         for (int x = 0; x < TM; x++)
 #pragma unroll
           for (int y = 0; y < TN; y++) {
-            acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            if (!MASKED || ((mask >> (x * TN + y)) & 1u)) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
             if (ks == 0 && (x * TN + y) % GAP == GAP - 1) dma(buf ^ 1, knext, (x * TN + y) / GAP);
           }
       }
       __syncthreads();
     }
+  }
+  static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
+                                                        double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper = false) {
+    static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
+    static_assert((BK / NW) * NW == BK && TM * TN >= 2 * (BK / NW) && TM * TN <= 32,
+                  "pieces are issued behind the multiplications of the first k-step");
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 15, lk = lane >> 4;
+    // a 16-byte load is inside its row when its first column is < ld (ld even)
+    const double *pa = g.A + ((i0 + 2 * lane < g.lda) ? i0 + 2 * lane : 0);
+    const double *pb = g.B + ((j0 + 2 * lane < g.ldb) ? j0 + 2 * lane : 0);
+    const double *zr = g.zeros + 2 * lane;
+    unsigned mask = 0;
+#pragma unroll
+    for (int x = 0; x < TM; x++)
+#pragma unroll
+      for (int y = 0; y < TN; y++) {
+        const int rb = wm * TM + x, cb = wn * TN + y;  // 16 x 16 block of the tile
+        const bool want = i0 + 16 * rb < g.M && j0 + 16 * cb < g.N && !(skip_upper && cb > rb);
+        mask |= (want ? 1u : 0u) << (x * TN + y);
+      }
+    mask = __builtin_amdgcn_readfirstlane(mask);
+    if (mask == (TM * TN == 32 ? 0xffffffffu : (1u << (TM * TN)) - 1u))
+      slabs_dma<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+    else
+      slabs_dma<true>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
   }
 
   // `lds`: the workgroup's LDS (free after accumulate's last barrier), used to write the MIRROR image of an
@@ -315,7 +341,7 @@ struct GemmTile {
         for (int rg = 0; rg < 4; rg++) {
           const int i = i0 + wm * WM + 16 * x + lk + 4 * rg, j = j0 + wn * WN + 16 * y + lr;
           double v = 0.0;
-          if (i < g.M && j < g.N && !(diag && g.mirror && i < j)) {
+          if (i < g.M && j < g.N && !(diag && i < j)) {
             v = g.alpha * acc[x][y][rg];
             if (g.beta != 0.0) v += g.beta * cin[(long long)i * ldcin + j];
             g.C[(long long)i * g.ldc + j] = v;
@@ -371,7 +397,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn(Gemm
 #pragma unroll
     for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
   if constexpr (DMA)
-    T::accumulate_dma(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
+    T::accumulate_dma(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs, g.lower && tm == tn);
   else
     T::accumulate(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
   const unsigned long long t2 = g.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -542,7 +568,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn_sk(G
 #pragma unroll
       for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
     if constexpr (DMA)
-      T::accumulate_dma(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
+      T::accumulate_dma(g, tm * BM, tn * BN, s0, s1, acc, As, Bs, g.lower && tm == tn);
     else
       T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
     bool finish = true;
