@@ -354,8 +354,9 @@ def mesh_kkt_sizes(local_rank):
     from hqp_amd import ipmatrix, problems
     out = {}
     try:
-        for g in (300, 1000):
-            prog = problems.grid_sparse_qp(g, g)
+        for g in (300, 1000, -1):
+            # (-1: no mesh - 10^5 variables, 21 entries per row of Q, 1000 random far couplings: problems.banded_long_range_qp)
+            prog = problems.grid_sparse_qp(g, g) if g > 0 else problems.banded_long_range_qp(100000, 10, 1000)
             st = [torch.as_tensor(a).cuda() for a in problems.ip_state(prog, 1, 1.0)]
             M = ipmatrix.IpRedSpBKP(device=local_rank, device_vectors=True, ordering=2)
             t0 = time.perf_counter()
@@ -370,8 +371,9 @@ def mesh_kkt_sizes(local_rank):
                 res = M.solve(prog, *st, *d)
                 ts.append(time.perf_counter() - t0)
             s = M.stats()
-            out[f"{g}x{g}"] = {"variables": prog.n, "kkt_dim": s["dim"], "ms_per_factor_solve": 1e3 * float(np.median(ts[1:])),
-                               "residual": res, "init_s": init_s, "flops_factor": s["flops_factor"], "tree_levels": s["n_levels"]}
+            out[f"{g}x{g}" if g > 0 else "band21_far1000_n1e5"] = {"variables": prog.n, "kkt_dim": s["dim"], "ms_per_factor_solve": 1e3 * float(np.median(ts[1:])),
+                               "residual": res, "init_s": init_s, "flops_factor": s["flops_factor"], "tree_levels": s["n_levels"],
+                               "max_front": s["max_front"]}
             del M
     except Exception as e:
         out["error"] = str(e)

@@ -996,8 +996,11 @@ __device__ __forceinline__ double rdlane(double v, int l) {
 // dependent chains.  Global loads are issued in predicated, fully unrolled batches
 // (one memory latency per batch, not one per loop trip), the LDS updates of a pivot
 // step likewise, and the registers are capped at 128 so that 16 fronts share a CU.
+#ifndef HQPKKT_FDS_WAVES
+#define HQPKKT_FDS_WAVES 4
+#endif
 template <bool FRONT>
-__global__ void __launch_bounds__(64, 4)
+__global__ void __launch_bounds__(64, HQPKKT_FDS_WAVES)
 k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
                     double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
                     const signed char *__restrict__ esign, double *__restrict__ linv,

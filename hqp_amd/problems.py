@@ -308,6 +308,26 @@ def grid_sparse_qp(gx, gy, seed=11, eq_every=3, bound_frac=0.5, long_range=0):
     return Program(n, me, m, Q, A, Cm, c=rng.uniform(-1, 1, n), b=rng.uniform(-1, 1, me), d=rng.uniform(0.5, 1.5, m))
 
 
+def banded_long_range_qp(n, band, far, seed=7, min_dist=1000):
+    """Irregular sparsity without a mesh behind it (BASELINE configs[4], SURVEY 8(d) C5: "row density" instead of
+    0.1 % fill): the banded QP of `banded_qp` (2 band + 1 entries per row of Q, band-wide rows of A) plus `far` random
+    couplings Q_ij between variables at least `min_dist` apart - every one of them ties two distant parts of the band
+    together, so a band ordering sees a bandwidth of ~n while a dissection of the graph itself only has to put one end of
+    each crossing coupling into a separator."""
+    rng = np.random.default_rng(seed)
+    prog = banded_qp(n, band, seed)
+    p, i, x = prog.Q
+    rows = np.repeat(np.arange(n), np.diff(p))
+    a, b = rng.integers(0, n, far), rng.integers(0, n, far)
+    keep = np.abs(a - b) >= min(min_dist, n // 4)
+    lo, hi = np.minimum(a, b)[keep], np.maximum(a, b)[keep]
+    key = np.unique(lo.astype(np.int64) * n + hi)
+    lo, hi = key // n, key % n
+    v = rng.uniform(-0.05, 0.05, lo.size)  # (small against the diagonal: Q stays positive definite)
+    Q = _csr(np.concatenate([rows, lo]), np.concatenate([i, hi]), np.concatenate([x, v]), n)
+    return Program(n, prog.me, prog.m, Q, prog.A, prog.C, c=prog.c, b=prog.b, d=prog.d)
+
+
 def ip_state(prog, seed=1, spread=0.0):
     """Strictly positive (z, w) and right-hand sides r1..r4 as an interior-point
     iteration would pass them (hqp/Hqp_IpsMehrotra.C:425-445, 527-530).
