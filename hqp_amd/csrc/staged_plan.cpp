@@ -285,7 +285,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
         for (int p = 0; p < shard_count; p++) {
           if (out) out[p] = (int)std::min<long long>(128LL * b, nn);
           double acc = 0.0;
-          while (b < nb && (acc + cost[b] <= bound || (acc == 0.0 && p == shard_count - 1 && false))) acc += cost[b++];
+          while (b < nb && acc + cost[b] <= bound) acc += cost[b++];
         }
         return b == nb;
       };
