@@ -42,10 +42,10 @@ def test_stage_plan_equals_the_model(case):
     assert list(S["eq_rows"]) == [r for rows in R["eq_rows"] for r in rows]
     assert list(S["fix_rows"]) == R["fix_rows"]
     assert list(np.diff(S["eq_ptr"])) == [len(r) for r in R["eq_rows"]]
-    # capacity of carried rows: own rows + what the next stage may hand back, at most 48
+    # capacity of carried rows: own rows + what the next stage may hand back, at most 256
     e_k = [len(r) for r in R["eq_rows"]]
     cap = list(S["cap"])
-    assert cap[-1] == e_k[-1] and all(cap[k] == min(e_k[k] + cap[k + 1], 48) for k in range(len(cap) - 1))
+    assert cap[-1] == e_k[-1] and all(cap[k] == min(e_k[k] + cap[k + 1], 256) for k in range(len(cap) - 1))
 
 
 def test_not_a_staircase_is_e_format():
