@@ -2177,9 +2177,9 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   }
   int cus = 0;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
-  const int skg = 2 * cus;
+  const int skg = stg::gemm_wgs_per_cu(variant) * cus;
   const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && stg::gemm_use_split(M, N, K, lower, skg);
-  const bool big = use_sk || stg::gemm_big_tiles(M, N, lower);
+  const bool big = use_sk || stg::gemm_big_tiles(M, N, lower, K);
   const int b = big ? 128 : 64;
   const long long tiles = stg::gemm_tiles(M, N, b, lower);
   (void)stg::gemm_set_attributes();
@@ -2203,7 +2203,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
       skk.ws = skws, skk.cnt = skcnt;
       stg::gemm_launch_split(variant, skg, 0, g, skk);
     } else if (big)
-      stg::gemm_launch_plain(variant, (unsigned)tiles, 0, g);
+      stg::gemm_launch_plain(variant, (unsigned)tiles, 0, g, cus);
     else
       stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64)>>>(g);
   }

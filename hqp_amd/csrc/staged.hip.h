@@ -63,17 +63,25 @@ struct GemmArgs {
 };
 
 static const int GEMM_BK = 16;
+
 // number of b x b tiles of an M x N product; lower: only tiles with tile row >= tile column (M >= N: a triangle of
 // ceil(N / b) tile columns on top of a rectangle - the column strip of a lower triangle that one rank computes)
 static inline long long gemm_tiles(int M, int N, int b, int lower) {
   const long long tm = (M + b - 1) / b, tn = (N + b - 1) / b;
   return lower ? tn * (tn + 1) / 2 + (tm > tn ? (tm - tn) * tn : 0) : tm * tn;
 }
-static inline size_t gemm_lds_bytes(int bm, int bn) { return sizeof(double) * 2 * GEMM_BK * (size_t)(bm + 16 + bn + 16); }
+static inline size_t gemm_lds_bytes(int bm, int bn, int nbuf = 2) { return sizeof(double) * nbuf * GEMM_BK * (size_t)(bm + 16 + bn + 16); }
 
-// 128 x 128 tiles (16 flop per operand byte) once they fill the chip: 256 CUs x 2 workgroups;
-// 64 x 64 tiles (four times as many workgroups) below
-static inline bool gemm_big_tiles(int M, int N, int lower) { return gemm_tiles(M, N, 128, lower) >= 384; }
+// 128 x 128 tiles from 384 tiles on (the grid of 2 x 256 workgroups three quarters full).  Below that the 64 x 64
+// kernel with four times the tiles is faster (same-box comparisons, tools/ab_env.sh HQPKKT_OLD_BIG: 2000 x 2050 x 2000
+// 0.41 against 0.50 ms, 1500 x 1540 x 1500 0.19 against 0.21) with one exception: a deep rectangular product of 160 -
+// 256 tiles - the column strip of W when a C4 system is sharded over 8 ranks, 5000 x 640 x 5000 - as ONE round of one
+// workgroup per CU (gemm_launch_plain): 0.71 against 0.83 ms.
+static inline bool gemm_big_tiles(int M, int N, int lower, int K = 0) {
+  const long long t = gemm_tiles(M, N, 128, lower);
+  static const bool old_rule = getenv("HQPKKT_OLD_BIG") != nullptr;  // (comparisons)
+  return t >= 384 || (!old_rule && !lower && t >= 160 && t <= 256 && K >= 256 * GEMM_BK);
+}
 
 // The split form (k_dgemm_tn_sk, below) pays where whole rounds of 128 x 128 tiles would leave slots idle
 // and the product is deep enough to be cut.  Returns true when the launch should use it with the whole
@@ -258,6 +266,8 @@ struct GemmTile {
     }
     __syncthreads();  // (waits for the DMA: vmcnt(0))
     constexpr int GAP = TM * TN / (2 * RPW);  // multiplications between two pieces
+    // (measured and dropped: the waves w and w + 4, which share a SIMD, issuing their pieces two k-steps apart: 8192^3
+    // 90.8 -> 88.3 % of peak)
     for (int s = s0; s < s1; s++) {
       const int buf = (s - s0) & 1;
       const int knext = s + 1 < s1 ? (s + 1) * BK : g.K;  // behind the last slab: zero rows
@@ -281,8 +291,66 @@ struct GemmTile {
       __syncthreads();
     }
   }
+  // The same loop over THREE LDS buffers (110 KB: one workgroup per CU): the DMA of slab s + 2 is issued during slab s
+  // and has two slab times to land - with two buffers the DMA of slab s + 1, issued at the start of slab s, is waited
+  // for at its end, and under load (every CU streaming its panels out of L2) its 1-2 us do not always fit into the
+  // 1.7 us a slab takes a workgroup that has the CU to itself.  Counted wait: vmcnt(2 RPW) leaves the newest slab's
+  // pieces in flight across the barrier (raw s_barrier: __syncthreads() would drain them).  As / Bs: 3 BK rows each.
+  template <bool MASKED>
+  static __device__ __forceinline__ void slabs_dma3(const GemmArgs &g, const double *pa, const double *pb, const double *zr, int wave,
+                                                    int wm, int wn, int lr, int lk, int s0, int s1, unsigned mask,
+                                                    double4_t (&acc)[TM][TN], double *As, double *Bs) {
+    constexpr int RPW = BK / NW;
+    static_assert(2 * RPW == 4 || 2 * RPW == 8, "the counted waits below are written for 4 or 8 pieces per wave and slab");
+    auto dma = [&](int buf, int k0, int p) {
+      const int r = wave + NW * (p % RPW), k = k0 + r;
+      if (p < RPW)
+        glds16(k < g.K ? pa + (long long)k * g.lda : zr, As + (buf * BK + r) * LDA);
+      else
+        glds16(k < g.K ? pb + (long long)k * g.ldb : zr, Bs + (buf * BK + r) * LDB);
+    };
+    auto wait_all_but_newest_slab = [&]() {
+      if constexpr (2 * RPW == 4)
+        asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else
+        asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    };
+    // slabs s0 and s0 + 1 (zero rows where the range is shorter) -> buffers 0 and 1
+#pragma unroll
+    for (int p = 0; p < 2 * RPW; p++) dma(0, s1 > s0 ? s0 * BK : g.K, p);
+#pragma unroll
+    for (int p = 0; p < 2 * RPW; p++) dma(1, s0 + 1 < s1 ? (s0 + 1) * BK : g.K, p);
+    wait_all_but_newest_slab();
+    constexpr int GAP = TM * TN / (2 * RPW);
+    int buf = 0;
+    for (int s = s0; s < s1; s++) {
+      const int bnext = buf >= 1 ? buf - 1 : 2;  // (buf + 2) % 3
+      const int knext = s + 2 < s1 ? (s + 2) * BK : g.K;
+      const double *Ab = As + buf * BK * LDA + wm * WM + lr;
+      const double *Bb = Bs + buf * BK * LDB + wn * WN + lr;
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ks++) {
+        double af[TM], bf[TN];
+#pragma unroll
+        for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * LDA + 16 * x];
+#pragma unroll
+        for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * LDB + 16 * y];
+#pragma unroll
+        for (int x = 0; x < TM; x++)
+#pragma unroll
+          for (int y = 0; y < TN; y++) {
+            if (!MASKED || ((mask >> (x * TN + y)) & 1u)) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+            if (ks == 0 && (x * TN + y) % GAP == GAP - 1) dma(bnext, knext, (x * TN + y) / GAP);
+          }
+      }
+      wait_all_but_newest_slab();
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero rows behind the range: LDS is reused after this)
+    __syncthreads();
+  }
   static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
-                                                        double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper = false) {
+                                                        double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper = false, int nbuf = 2) {
     static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
     static_assert((BK / NW) * NW == BK && TM * TN >= 2 * (BK / NW) && TM * TN <= 32,
                   "pieces are issued behind the multiplications of the first k-step");
@@ -303,7 +371,13 @@ struct GemmTile {
         mask |= (want ? 1u : 0u) << (x * TN + y);
       }
     mask = __builtin_amdgcn_readfirstlane(mask);
-    if (mask == (TM * TN == 32 ? 0xffffffffu : (1u << (TM * TN)) - 1u))
+    const bool all = mask == (TM * TN == 32 ? 0xffffffffu : (1u << (TM * TN)) - 1u);
+    if (nbuf == 3) {
+      if (all)
+        slabs_dma3<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+      else
+        slabs_dma3<true>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+    } else if (all)
       slabs_dma<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
     else
       slabs_dma<true>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
@@ -383,11 +457,11 @@ struct GemmTile {
   }
 };
 
-template <int BM, int BN, bool DMA = false, int WGM = 2, int WGN = 2>
-__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn(GemmArgs g) {
+template <int BM, int BN, bool DMA = false, int WGM = 2, int WGN = 2, int NBUF = 2>
+__global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WGM * WGN / 2) k_dgemm_tn(GemmArgs g) {
   using T = GemmTile<BM, BN, WGM, WGN>;
-  extern __shared__ __attribute__((aligned(16))) double lds[];  // 2 * BK * (LDA + LDB) doubles
-  double *As = lds, *Bs = lds + 2 * T::BK * T::LDA;
+  extern __shared__ __attribute__((aligned(16))) double lds[];  // NBUF * BK * (LDA + LDB) doubles
+  double *As = lds, *Bs = lds + NBUF * T::BK * T::LDA;
   int tm, tn;
   const unsigned long long t0 = g.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   T::tile_of(g, xcd_swizzle(blockIdx.x, gridDim.x), tm, tn);
@@ -397,7 +471,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn(Gemm
 #pragma unroll
     for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
   if constexpr (DMA)
-    T::accumulate_dma(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs, g.lower && tm == tn);
+    T::accumulate_dma(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs, g.lower && tm == tn, NBUF);
   else
     T::accumulate(g, tm * BM, tn * BN, 0, (g.K + T::BK - 1) / T::BK, acc, As, Bs);
   const unsigned long long t2 = g.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
@@ -508,13 +582,13 @@ static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
   }
   return false;
 }
-template <bool DMA, int WGM = 2, int WGN = 2>
-__global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn_sk(GemmArgs g, SplitPlan sk) {
+template <bool DMA, int WGM = 2, int WGN = 2, int NBUF = 2>
+__global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WGM * WGN / 2) k_dgemm_tn_sk(GemmArgs g, SplitPlan sk) {
   constexpr int BM = 128, BN = 128;
   using T = GemmTile<BM, BN, WGM, WGN>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // tiles + one word for the arrival order
-  double *As = lds, *Bs = lds + 2 * T::BK * T::LDA;
-  unsigned *s_old = (unsigned *)(lds + 2 * T::BK * (T::LDA + T::LDB));
+  double *As = lds, *Bs = lds + NBUF * T::BK * T::LDA;
+  unsigned *s_old = (unsigned *)(lds + NBUF * T::BK * (T::LDA + T::LDB));
   const int G = gridDim.x, v = xcd_swizzle(blockIdx.x, G);
   const int nslab = (g.K + T::BK - 1) / T::BK;
   constexpr int SLOT = BM * BN;
@@ -568,7 +642,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn_sk(G
 #pragma unroll
       for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
     if constexpr (DMA)
-      T::accumulate_dma(g, tm * BM, tn * BN, s0, s1, acc, As, Bs, g.lower && tm == tn);
+      T::accumulate_dma(g, tm * BM, tn * BN, s0, s1, acc, As, Bs, g.lower && tm == tn, NBUF);
     else
       T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
     bool finish = true;
@@ -623,13 +697,20 @@ __global__ void __launch_bounds__(64 * WGM * WGN, WGM * WGN / 2) k_dgemm_tn_sk(G
     __syncthreads();  // (s_old[1] is rewritten at the top of the next unit)
   }
 }
-static inline size_t gemm_sk_lds_bytes() { return gemm_lds_bytes(128, 128) + 16; }  // + two words: arrival order, next unit
+static inline size_t gemm_sk_lds_bytes(int nbuf = 2) { return gemm_lds_bytes(128, 128, nbuf) + 16; }  // + two words: arrival order, next unit
 
 // Host: the variants of the 128 x 128 product.  0: operands staged through registers, 4 waves (round 2's loop, kept
 // for comparisons: HQPKKT_NO_LDSDMA); 1: LDS-DMA, 2 x 2 waves of 64 x 64; 2: LDS-DMA, 2 x 4 waves of 64 x 32 (default)
-enum { GEMM_REG4 = 0, GEMM_DMA4 = 1, GEMM_DMA8 = 2 };
-static inline void gemm_launch_plain(int variant, unsigned tiles, hipStream_t s, const GemmArgs &g) {
-  if (variant == GEMM_DMA8)
+enum { GEMM_REG4 = 0, GEMM_DMA4 = 1, GEMM_DMA8 = 2, GEMM_DMA8X3 = 3 };  // X3: three LDS buffers, one workgroup per CU
+static inline int gemm_wgs_per_cu(int variant) { return variant == GEMM_DMA8X3 ? 1 : 2; }
+// cus > 0: a launch of at most that many tiles takes the three-buffer kernel, whose 110 KB of LDS admit ONE workgroup
+// per CU - the dispatcher otherwise puts two workgroups on some CUs and none on others, and a pair takes twice as long
+// as a workgroup alone (the column strip 5000 x 640 x 5000 of a system sharded over 8 ranks: 0.75 -> 0.62 ms)
+static inline void gemm_launch_plain(int variant, unsigned tiles, hipStream_t s, const GemmArgs &g, int cus = 0) {
+  if (variant == GEMM_DMA8 && cus > 0 && (int)tiles <= cus) variant = GEMM_DMA8X3;
+  if (variant == GEMM_DMA8X3)
+    k_dgemm_tn<128, 128, true, 2, 4, 3><<<tiles, 512, gemm_lds_bytes(128, 128, 3), s>>>(g);
+  else if (variant == GEMM_DMA8)
     k_dgemm_tn<128, 128, true, 2, 4><<<tiles, 512, gemm_lds_bytes(128, 128), s>>>(g);
   else if (variant == GEMM_DMA4)
     k_dgemm_tn<128, 128, true><<<tiles, 256, gemm_lds_bytes(128, 128), s>>>(g);
@@ -637,7 +718,9 @@ static inline void gemm_launch_plain(int variant, unsigned tiles, hipStream_t s,
     k_dgemm_tn<128, 128><<<tiles, 256, gemm_lds_bytes(128, 128), s>>>(g);
 }
 static inline void gemm_launch_split(int variant, int grid, hipStream_t s, const GemmArgs &g, const SplitPlan &sk) {
-  if (variant == GEMM_DMA8)
+  if (variant == GEMM_DMA8X3)
+    k_dgemm_tn_sk<true, 2, 4, 3><<<grid, 512, gemm_sk_lds_bytes(3), s>>>(g, sk);
+  else if (variant == GEMM_DMA8)
     k_dgemm_tn_sk<true, 2, 4><<<grid, 512, gemm_sk_lds_bytes(), s>>>(g, sk);
   else if (variant == GEMM_DMA4)
     k_dgemm_tn_sk<true><<<grid, 256, gemm_sk_lds_bytes(), s>>>(g, sk);
@@ -657,12 +740,16 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true, 2, 4>, gemm_sk_lds_bytes());
+  set((const void *)k_dgemm_tn<128, 128, true, 2, 4, 3>, gemm_lds_bytes(128, 128, 3));
+  set((const void *)k_dgemm_tn_sk<true, 2, 4, 3>, gemm_sk_lds_bytes(3));
   return e;
 }
 static inline int gemm_variant_from_env() {
   if (getenv("HQPKKT_NO_LDSDMA")) return GEMM_REG4;
   const char *w = getenv("HQPKKT_DGEMM_WAVES");
-  return (w && atoi(w) == 4) ? GEMM_DMA4 : GEMM_DMA8;
+  if (w && atoi(w) == 4) return GEMM_DMA4;
+  if (getenv("HQPKKT_DGEMM_3BUF")) return GEMM_DMA8X3;
+  return GEMM_DMA8;
 }
 
 // ---------------------------------------------------------------------------------------

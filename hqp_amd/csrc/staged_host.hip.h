@@ -19,6 +19,7 @@ struct StagedDev {
   DBuf<stg::StripTab> strip_tabs;  // sharded: per stage where the ranks' strips of G_xx lie in the exchange buffer
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
+  int cus = 0;
   DBuf<double> sk_ws;           // stream-K dgemm: two partial tiles per workgroup
   DBuf<unsigned> sk_cnt;
   int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
@@ -99,7 +100,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   StagedDev *d = h->sd;
   // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
   const bool split = d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid);
-  const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower);
+  const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower, g.K);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b;
   const long long tiles = stg::gemm_tiles(g.M, g.N, b, g.lower);
@@ -115,7 +116,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
     return 0;
   }
   if (big)
-    KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g));
+    KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g, d ? d->cus : 0));
   else
     KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
   return 0;
@@ -258,6 +259,7 @@ static int staged_upload(hqpkkt_t *h) {
   {  // stream-K grid: two workgroups per CU, if some product of the recursion has more tiles than that
     int cus = 0;
     HIPCHK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, h->opts.device));
+    d.cus = cus;
     long long tmax = 0, pmax = 0;  // most tiles / most cut pieces of a product of this handle (column slices have fewer)
     for (int k = 0; k < P.K; k++) {
       const long long t1 = (P.nk[k + 1] + 127) / 128, t2 = (P.nk[k] + P.mk[k] + 127) / 128;
@@ -270,7 +272,7 @@ static int staged_upload(hqpkkt_t *h) {
     pmax = std::max(pmax, 16 * tmax);
     d.sk_grid = 0, d.sk_tiles = (int)tmax;
     if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
-      d.sk_grid = 2 * cus;
+      d.sk_grid = stg::gemm_wgs_per_cu(stg::gemm_variant_from_env()) * cus;
       if ((e = d.sk_ws.alloc((size_t)std::max<long long>(pmax, 1) * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_tiles + 4))) return e;
     }
   }
