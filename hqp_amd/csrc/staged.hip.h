@@ -1077,6 +1077,67 @@ __device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *i
   return gj_inverse(a, q, ld, ip, ir, ic, colv, rowv, red);
 }
 
+// LU factors of the q x q matrix a (LDS or global memory, leading dimension ld) in place - unit lower L below the
+// diagonal, U on and above it - with complete pivoting; rows and columns are exchanged physically, pr[s] / pc[s]
+// record the row / column that came to position s.  Returns 0, or 1 when a pivot is exactly zero / NaN.  The pivot
+// search of step s+1 rides on the update sweep of step s (thread grid 16 columns x nt/16 rows, as in gj_inverse).
+// Used where the factors are applied by substitution (k_st_x0_free): a solve by factors leaves a residual of
+// eps |K| |x| where the product with an explicit inverse leaves cond(K) eps |b|.
+__device__ int lu_complete(double *a, int q, int ld, int *pr, int *pc, double *colv, double *rowv, ArgMax *red) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int ty = tid >> 4, tx = tid & 15, RS = nt >> 4;
+  const double INF = __longlong_as_double(0x7ff0000000000000LL);
+  int bad = 0;
+  ArgMax best{-1.0, 0x7fffffff};
+  for (int r = ty; r < q; r += RS)
+    for (int c = tx; c < q; c += 16) {
+      const double v = fabs(a[r * ld + c]);
+      best = better(best, ArgMax{v == v ? v : INF, r * q + c});
+    }
+  for (int s = 0; s < q; s++) {
+    best = block_argmax(best, red);
+    const int irow = best.i / q, icol = best.i - irow * q;
+    if (!(best.v > 0.0) || best.v == INF) {
+      bad = 1;
+      break;
+    }
+    if (irow != s)
+      for (int c = tid; c < q; c += nt) {
+        const double x = a[irow * ld + c];
+        a[irow * ld + c] = a[s * ld + c];
+        a[s * ld + c] = x;
+      }
+    __syncthreads();
+    if (icol != s)
+      for (int r = tid; r < q; r += nt) {
+        const double x = a[r * ld + icol];
+        a[r * ld + icol] = a[r * ld + s];
+        a[r * ld + s] = x;
+      }
+    if (tid == 0) pr[s] = irow, pc[s] = icol;
+    __syncthreads();
+    const double pinv = 1.0 / a[s * ld + s];
+    for (int c = s + 1 + tid; c < q; c += nt) {
+      colv[c] = a[c * ld + s] * pinv;
+      rowv[c] = a[s * ld + c];
+    }
+    __syncthreads();
+    best = ArgMax{-1.0, 0x7fffffff};
+    for (int r = s + 1 + ty; r < q; r += RS) {
+      const double cr = colv[r];
+      if (tx == 0) a[r * ld + s] = cr;
+      for (int c = s + 1 + tx; c < q; c += 16) {
+        const double v = a[r * ld + c] - cr * rowv[c];
+        a[r * ld + c] = v;
+        const double av = fabs(v);
+        best = better(best, ArgMax{av == av ? av : INF, r * q + c});
+      }
+    }
+  }
+  __syncthreads();
+  return bad;
+}
+
 // Per stage, one workgroup: (A) rank-revealing elimination of the control part N_u of the
 // stage's constraint rows (own equalities, then the rows carried back from stage k+1) with
 // complete pivoting: consumed rows R (they determine controls), leftover rows L (free of u
@@ -1284,6 +1345,51 @@ __global__ void k_st_wide(WideArgs a) {
     a.BT[(long long)j * a.ldb + li] = v;
   }
 }
+// Rm = K^-1 Y with one round of refinement against K (Rm += K^-1 (Y - K Rm), see staged_run_factor) for stages whose K
+// has order <= 64, in ONE launch instead of three products with a 50-deep k loop: a workgroup takes 32 columns of Y;
+// K^-1 and K (symmetric, so a row is read as a column: broadcast reads) and the three q x 32 panels live in LDS;
+// thread (row group g of 8, column c) computes the rows g, g + 8, ... of its column.
+struct RmArgs {
+  const double *Kinv, *Kmat;
+  long long ldq;
+  const double *Y;
+  double *Rm;
+  long long ldy;
+  int q, n;
+};
+static const int RM_COLS = 32;
+static inline size_t st_rm_lds(int q) { return sizeof(double) * ((size_t)2 * q * (q | 1) + (size_t)3 * q * RM_COLS); }
+__global__ void __launch_bounds__(256) k_st_rm(RmArgs a) {
+  extern __shared__ __attribute__((aligned(16))) double sm[];
+  const int q = a.q, ldk = q | 1, tid = threadIdx.x, c = tid & (RM_COLS - 1), g = tid / RM_COLS;
+  double *Ki = sm, *Km = Ki + (size_t)q * ldk, *Ys = Km + (size_t)q * ldk, *Rs = Ys + (size_t)q * RM_COLS, *Es = Rs + (size_t)q * RM_COLS;
+  const int j = blockIdx.x * RM_COLS + c;
+  for (int e = tid; e < q * q; e += 256) {
+    const int i = e / q, l = e - i * q;
+    Ki[i * ldk + l] = a.Kinv[(long long)i * a.ldq + l];
+    Km[i * ldk + l] = a.Kmat[(long long)i * a.ldq + l];
+  }
+  for (int i = g; i < q; i += 8) Ys[i * RM_COLS + c] = j < a.n ? a.Y[(long long)i * a.ldy + j] : 0.0;
+  __syncthreads();
+  for (int i = g; i < q; i += 8) {
+    double s = 0.0;
+    for (int l = 0; l < q; l++) s += Ki[l * ldk + i] * Ys[l * RM_COLS + c];
+    Rs[i * RM_COLS + c] = s;
+  }
+  __syncthreads();
+  for (int i = g; i < q; i += 8) {
+    double s = Ys[i * RM_COLS + c];
+    for (int l = 0; l < q; l++) s -= Km[l * ldk + i] * Rs[l * RM_COLS + c];
+    Es[i * RM_COLS + c] = s;
+  }
+  __syncthreads();
+  for (int i = g; i < q; i += 8) {
+    double s = Rs[i * RM_COLS + c];
+    for (int l = 0; l < q; l++) s += Ki[l * ldk + i] * Es[l * RM_COLS + c];
+    if (j < a.n) a.Rm[(long long)i * a.ldy + j] = s;
+  }
+}
+
 // last stage K: all its equality rows are carried (no control): BT_K = E_K', count = e
 __global__ void k_st_last(int n, int e, int cap, const double *__restrict__ N, long long ldn, double *__restrict__ BT,
                           long long ldb, int *__restrict__ dyn) {
@@ -1298,19 +1404,21 @@ __global__ void k_st_check_fixed(const int *__restrict__ dyn0, int *__restrict__
   if (threadIdx.x == 0 && blockIdx.x == 0 && dyn0[1] > 0) atomicExch(status, 4);
 }
 
-// free initial state: inverse of [V_0 B_0'; B_0 0]  (hqp/Hqp_IpLQDOCP.C:1972-1996)
+// free initial state: LU factors (complete pivoting) of the diagonally scaled [V_0 B_0'; B_0 0]; the reference
+// factorises the same scaled matrix by Bunch-Kaufman-Parlett (hqp/Hqp_IpLQDOCP.C:1972-1996) and solves by
+// substitution.  K0lu: the factors; K0s: 3 q doubles - the scaling, the row and the column exchanges.
 template <int NT>
 __global__ void __launch_bounds__(NT, NT / 256) k_st_init_factor(int n0, int cap, const double *__restrict__ V, long long ldv,
                                                        const double *__restrict__ BT, long long ldb,
-                                                       const int *__restrict__ dyn0, double *__restrict__ K0inv,
-                                                       double *__restrict__ K0mat, long long ldq, int qmax,
+                                                       const int *__restrict__ dyn0, double *__restrict__ K0lu,
+                                                       double *__restrict__ K0mat, double *__restrict__ K0s, long long ldq, int qmax,
                                                        int *__restrict__ status, double *scratch) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ ArgMax red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int c = dyn0[1], q = n0 + c, ld = q | 1;
   double *Km = scratch ? scratch : sm, *dsc = scratch ? sm : Km + (size_t)q * ld, *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
-  int *ip = (int *)(rowv + (q > 128 ? q : 128)), *ir = ip + q, *ic = ir + q;
+  int *pr = (int *)(rowv + (q > 128 ? q : 128)), *pc = pr + q;
   for (int e = tid; e < q * q; e += nt) {
     const int i = e / q, j = e - i * q;
     double v;
@@ -1338,13 +1446,14 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_init_factor(int n0, int cap
   __syncthreads();
   for (int e = tid; e < q * q; e += nt) Km[(e / q) * ld + e % q] *= dsc[e / q] * dsc[e % q];
   __syncthreads();
-  const int bad = gj_inverse_any<NT>(Km, q, ld, ip, ir, ic, colv, rowv, red);
+  const int bad = lu_complete(Km, q, ld, pr, pc, colv, rowv, red);
   if (bad && tid == 0) atomicExch(status, 4);
   __syncthreads();
   for (int e = tid; e < qmax * qmax; e += nt) {
     const int i = e / qmax, j = e - i * qmax;
-    K0inv[(long long)i * ldq + j] = (i < q && j < q) ? 0.5 * (Km[i * ld + j] + Km[j * ld + i]) * dsc[i] * dsc[j] : 0.0;
+    K0lu[(long long)i * ldq + j] = (i < q && j < q) ? Km[i * ld + j] : 0.0;
   }
+  for (int i = tid; i < q; i += nt) K0s[i] = dsc[i], K0s[qmax + i] = (double)pr[i], K0s[2 * qmax + i] = (double)pc[i];
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1603,34 +1712,93 @@ __global__ void k_st_y_fixed(int n0, const int *__restrict__ fix_rows, const int
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n0) dy[fix_rows[i]] = -tmp[i] / vals[fix_src[i]];
 }
-__global__ void __launch_bounds__(256) k_st_x0_free(int n0, int cap0, int qmax, const double *__restrict__ K0inv,
-                                                    const double *__restrict__ K0mat, long long ldq,
+// t <- (D K D)^-1 t by the factors of k_st_init_factor (t in LDS, already scaled by D): row exchanges, L, U, column
+// exchanges.  Blocks of 64 unknowns: the part of a block's rows outside its diagonal block is one dot product per
+// row (a wavefront per row, coalesced), the diagonal block is solved by one wavefront out of LDS.
+__device__ void x0_lu_solve(const double *__restrict__ LU, long long ldq, const double *__restrict__ perm, int qmax, int q,
+                            double *t, double *T) {
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
+  if (tid == 0)
+    for (int s = 0; s < q; s++) {
+      const int r = (int)perm[qmax + s];
+      const double x = t[s];
+      t[s] = t[r], t[r] = x;
+    }
+  __syncthreads();
+  for (int b0 = 0; b0 < q; b0 += 64) {  // L y = t
+    const int nb = min(64, q - b0);
+    for (int i = wave; i < nb; i += nw) {
+      double sum = 0.0;
+      for (int j = lane; j < b0; j += 64) sum += LU[(long long)(b0 + i) * ldq + j] * t[j];
+      sum = kktdev::wave_sum(sum);
+      if (lane == 0) t[b0 + i] -= sum;
+    }
+    for (int e = tid; e < nb * nb; e += blockDim.x) T[(e / nb) * 65 + e % nb] = LU[(long long)(b0 + e / nb) * ldq + b0 + e % nb];
+    __syncthreads();
+    if (wave == 0) {
+      double y = lane < nb ? t[b0 + lane] : 0.0;
+      for (int s = 0; s < nb; s++) {
+        const double ys = __shfl(y, s);
+        if (lane > s && lane < nb) y -= T[lane * 65 + s] * ys;
+      }
+      if (lane < nb) t[b0 + lane] = y;
+    }
+    __syncthreads();
+  }
+  for (int b0 = ((q - 1) / 64) * 64; b0 >= 0; b0 -= 64) {  // U z = y
+    const int nb = min(64, q - b0);
+    for (int i = wave; i < nb; i += nw) {
+      double sum = 0.0;
+      for (int j = b0 + nb + lane; j < q; j += 64) sum += LU[(long long)(b0 + i) * ldq + j] * t[j];
+      sum = kktdev::wave_sum(sum);
+      if (lane == 0) t[b0 + i] -= sum;
+    }
+    for (int e = tid; e < nb * nb; e += blockDim.x) T[(e / nb) * 65 + e % nb] = LU[(long long)(b0 + e / nb) * ldq + b0 + e % nb];
+    __syncthreads();
+    if (wave == 0) {
+      double y = lane < nb ? t[b0 + lane] : 0.0;
+      for (int s = nb - 1; s >= 0; s--) {
+        if (lane == s) y /= T[s * 65 + s];
+        const double ys = __shfl(y, s);
+        if (lane < s) y -= T[lane * 65 + s] * ys;
+      }
+      if (lane < nb) t[b0 + lane] = y;
+    }
+    __syncthreads();
+  }
+  if (tid == 0)
+    for (int s = q - 1; s >= 0; s--) {
+      const int r = (int)perm[2 * qmax + s];
+      const double x = t[s];
+      t[s] = t[r], t[r] = x;
+    }
+  __syncthreads();
+}
+__global__ void __launch_bounds__(256) k_st_x0_free(int n0, int cap0, int qmax, const double *__restrict__ K0lu,
+                                                    const double *__restrict__ K0mat, const double *__restrict__ K0s, long long ldq,
                                                     const int *__restrict__ dyn0, const double *__restrict__ v0,
                                                     const double *__restrict__ beta0, double *__restrict__ x0,
                                                     double *__restrict__ eta0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   const int c = dyn0[1], q = n0 + c, tid = threadIdx.x, nt = blockDim.x;
-  double *b = sm, *y = sm + qmax, *rs = y + qmax;
-  for (int i = tid; i < q; i += nt) b[i] = i < n0 ? v0[i] : beta0[i - n0];
-  __syncthreads();
+  double *b = sm, *y = sm + qmax, *t = y + qmax, *T = t + qmax;
   for (int i = tid; i < q; i += nt) {
-    double s = 0.0;
-    for (int j = 0; j < q; j++) s += K0inv[(long long)j * ldq + i] * b[j];
-    y[i] = s;
+    b[i] = i < n0 ? v0[i] : beta0[i - n0];
+    t[i] = K0s[i] * b[i];
   }
   __syncthreads();
-  for (int i = tid; i < q; i += nt) {  // one round of refinement against K0 (see k_st_bwd_small)
+  x0_lu_solve(K0lu, ldq, K0s, qmax, q, t, T);
+  for (int i = tid; i < q; i += nt) y[i] = K0s[i] * t[i];
+  __syncthreads();
+  for (int i = tid; i < q; i += nt) {  // one round of refinement against K0 itself (symmetric: column i read as row i)
     double s = b[i];
     for (int j = 0; j < q; j++) s -= K0mat[(long long)j * ldq + i] * y[j];
-    rs[i] = s;
+    t[i] = K0s[i] * s;
   }
   __syncthreads();
+  x0_lu_solve(K0lu, ldq, K0s, qmax, q, t, T);
   for (int i = tid; i < n0 + cap0; i += nt) {
-    double s = 0.0;
-    if (i < q) {
-      for (int j = 0; j < q; j++) s += K0inv[(long long)j * ldq + i] * rs[j];
-      s += y[i];
-    }
+    const double s = i < q ? y[i] + K0s[i] * t[i] : 0.0;
     if (i < n0)
       x0[i] = -s;
     else

@@ -51,7 +51,7 @@ struct StagedDev {
     tri_maps.push_back({T, b});
     return b->p;
   }
-  size_t lds_small = 0, lds_small_big = 0, lds_init = 0;
+  size_t lds_small = 0, lds_small_big = 0, lds_init = 0, lds_x0 = 0;
   void release() {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
@@ -142,6 +142,29 @@ int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int 
 }
 
 }  // namespace
+
+// Rm = K^-1 Y, refined against K: one launch for K of order <= 64 (k_st_rm), three products above
+static int st_rm(hqpkkt_t *h, StagedDev &d, const StagePtr &sp, int k, bool allow_sk) {
+  const kktdev::StagedPlan &P = d.plan;
+  const int q = P.qmax[k], nn = P.nk[k];
+  const long long ldy = P.ldy[k];
+  if (q <= 0) return 0;
+  if (q <= 64 && !getenv("HQPKKT_NO_FUSED_RM")) {
+    stg::RmArgs ra{sp.Kinv, sp.Kmat, P.ldq[k], sp.Y, sp.Rm, ldy, q, nn};
+    KLAUNCH(h, KC_ST_GEMM_UPD, stg::k_st_rm<<<(nn + stg::RM_COLS - 1) / stg::RM_COLS, 256, stg::st_rm_lds(q), h->stream>>>(ra));
+    return 0;
+  }
+  // one round of refinement against K: Rm += K^-1 (Y - K Rm).  The product with an explicit inverse alone
+  // leaves a residual of cond(K) eps |Y| where the reference's solve by Bunch-Kaufman factors
+  // (hqp/Hqp_IpLQDOCP.C:1866-1869, 1911-1924) leaves eps |K| |Rm|; stiff stages need the latter
+  double *Res = d.misc.p + P.oRes;
+  int e;
+  if ((e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, ldy, nullptr, 0, sp.Rm, ldy, q, nn, q, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)) ||
+      (e = st_gemm(h, stg::GemmArgs{sp.Kmat, P.ldq[k], sp.Rm, ldy, sp.Y, ldy, Res, ldy, q, nn, q, -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)) ||
+      (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], Res, ldy, sp.Rm, ldy, sp.Rm, ldy, q, nn, q, 1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)))
+    return e;
+  return 0;
+}
 
 static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = false) {
   if (!h->sd) h->sd = new (std::nothrow) StagedDev;
@@ -321,14 +344,16 @@ static int staged_upload(hqpkkt_t *h) {
   {
     const size_t q = (size_t)P.q0max;
     d.lds_init = (size_t)kktdev::gj_lds_bytes((long long)q) - (P.big0 ? q * (q | 1) * 8 : 0);
+    d.lds_x0 = sizeof(double) * (3 * q + 64 * 65 + 8);
   }
   static std::mutex attr_mutex;  // function attributes are process state, shared by all handles
-  static size_t attr_small = 0, attr_small_big = 0, attr_init = 0, attr_init_big = 0;
+  static size_t attr_small = 0, attr_small_big = 0, attr_init = 0, attr_init_big = 0, attr_x0 = 0;
   static bool attr_gemm = false;
   {
     std::lock_guard<std::mutex> lk(attr_mutex);
     if (!attr_gemm) {
       HIPCHK(stg::gemm_set_attributes());
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_rm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::st_rm_lds(64)));
       attr_gemm = true;
     }
     if (d.lds_small > attr_small) {
@@ -345,6 +370,10 @@ static int staged_upload(hqpkkt_t *h) {
       HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_init_factor<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)d.lds_init));
       attr_init = d.lds_init;
+    }
+    if (d.lds_x0 > attr_x0) {
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_x0_free, hipFuncAttributeMaxDynamicSharedMemorySize, (int)d.lds_x0));
+      attr_x0 = d.lds_x0;
     }
     if (P.big0 && d.lds_init > attr_init_big) {
       HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_init_factor<1024>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -459,13 +488,7 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     stg::WideArgs wa{G, ldg, nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], q, sp.T, P.ldt[k], sp.dyn, sp.Y, ldy, sp.BT, P.ldb[k]};
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
   }
-  if (q > 0) {  // Rm = K^-1 Y and one round of refinement against K (see staged_run_factor)
-    double *Res = d.misc.p + P.oRes;
-    if ((e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, ldy, nullptr, 0, sp.Rm, ldy, q, nn, q, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !two)) ||
-        (e = st_gemm(h, stg::GemmArgs{sp.Kmat, P.ldq[k], sp.Rm, ldy, sp.Y, ldy, Res, ldy, q, nn, q, -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !two)) ||
-        (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], Res, ldy, sp.Rm, ldy, sp.Rm, ldy, q, nn, q, 1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !two)))
-      return e;
-  }
+  if ((e = st_rm(h, d, sp, k, !two))) return e;
   if (two) HIPCHK(hipEventRecord(d.ev_join, sB));
   // ---- sA: the large products of this rank's columns, and the exchange
   h->stream = sA;
@@ -585,23 +608,7 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,
                      sp.Y, P.ldy[k], sp.BT, P.ldb[k]};
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
-    // Rm = K^-1 Y
-    if (P.qmax[k] > 0 &&
-        (e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], sp.Y, P.ldy[k], nullptr, 0, sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
-                                      1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
-      return e;
-    // one round of refinement against K: Rm += K^-1 (Y - K Rm).  The product with an explicit inverse alone
-    // leaves a residual of cond(K) eps |Y| where the reference's solve by Bunch-Kaufman factors
-    // (hqp/Hqp_IpLQDOCP.C:1866-1869, 1911-1924) leaves eps |K| |Rm|; stiff stages need the latter
-    if (P.qmax[k] > 0) {
-      double *Res = d.misc.p + P.oRes;
-      if ((e = st_gemm(h, stg::GemmArgs{sp.Kmat, P.ldq[k], sp.Rm, P.ldy[k], sp.Y, P.ldy[k], Res, P.ldy[k], P.qmax[k], nn, P.qmax[k],
-                                        -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
-        return e;
-      if ((e = st_gemm(h, stg::GemmArgs{sp.Kinv, P.ldq[k], Res, P.ldy[k], sp.Rm, P.ldy[k], sp.Rm, P.ldy[k], P.qmax[k], nn, P.qmax[k],
-                                        1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, !ovl)))
-        return e;
-    }
+    if ((e = st_rm(h, d, sp, k, !ovl))) return e;
     on_a();
     if (ovl) {
       HIPCHK(hipEventRecord(d.ev_join, sB));
@@ -618,11 +625,11 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_check_fixed<<<1, 64, 0, s>>>(s0.dyn, h->flags.p));
     else if (P.big0)
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<1024><<<1, 1024, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
-                                                                                    d.misc.p + P.oK0, d.misc.p + P.oK0m, P.ldq0, P.q0max, h->flags.p,
+                                                                                    d.misc.p + P.oK0, d.misc.p + P.oK0m, d.misc.p + P.oK0s, P.ldq0, P.q0max, h->flags.p,
                                                                                     d.misc.p + P.oScr));
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<256><<<1, 256, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
-                                                                                  d.misc.p + P.oK0, d.misc.p + P.oK0m, P.ldq0, P.q0max, h->flags.p, nullptr));
+                                                                                  d.misc.p + P.oK0, d.misc.p + P.oK0m, d.misc.p + P.oK0s, P.ldq0, P.q0max, h->flags.p, nullptr));
   }
   if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
   HIPCHK(hipGetLastError());
@@ -668,7 +675,7 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
       KLAUNCH(h, KC_ST_VEC, stg::k_st_x0_fixed<<<nblk(std::max(n0, P.cap[0])), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, v.r2, S,
                                                                                          s0.eta, P.cap[0]));
     else
-      KLAUNCH(h, KC_ST_SMALL, stg::k_st_x0_free<<<1, 256, sizeof(double) * (3 * P.q0max + 4), s>>>(n0, P.cap[0], P.q0max, M + P.oK0, M + P.oK0m, P.ldq0, s0.dyn, s0.v,
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_x0_free<<<1, 256, d.lds_x0, s>>>(n0, P.cap[0], P.q0max, M + P.oK0, M + P.oK0m, M + P.oK0s, P.ldq0, s0.dyn, s0.v,
                                                                 s0.beta, S, s0.eta));
   }
   for (int k = 0; k < K; k++) {

@@ -244,6 +244,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   ldq0 = up8(std::max(q0max, 1));
   oK0 = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
   oK0m = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
+  oK0s = mo, mo += up16(3LL * std::max(q0max, 1));
   oRes = mo, mo += up16(resmax);
   oGam = mo, mo += up16(nzmax + 8);
   {

@@ -159,6 +159,23 @@ def inv_complete(Kmat):
     return np.linalg.inv(Kmat)
 
 
+class ScaledSolve:
+    """[V_0 B_0'; B_0 0] of a free initial state: factors of the diagonally scaled matrix applied by substitution (the
+    kernels: LU with complete pivoting, k_st_init_factor / k_st_x0_free; the reference: BKPfactor of the same scaled
+    matrix, hqp/Hqp_IpLQDOCP.C:1984-1996).  A product with an explicit inverse is not backward stable and loses the
+    solution when V_0 is ill-conditioned (unstable closed loops)."""
+
+    def __init__(self, K0, n0):
+        import scipy.linalg as sla
+        d = np.ones(K0.shape[0])
+        dg = np.diag(K0)[:n0]
+        d[:n0] = np.where(dg > 1.0, 1.0 / np.sqrt(np.where(dg > 1.0, dg, 1.0)), 1.0)
+        self.d, self.lu, self._solve = d, sla.lu_factor(K0 * d[:, None] * d[None, :]), sla.lu_solve
+
+    def __matmul__(self, b):
+        return self.d * self._solve(self.lu, self.d * b)
+
+
 class StagedModel:
     def __init__(self, prog):
         self.prog = prog
@@ -229,7 +246,7 @@ class StagedModel:
             K0[n0:, :n0] = B[0]
             K0[:n0, n0:] = B[0].T
             self.K0 = K0
-            self.K0inv = inv_complete(K0)
+            self.K0inv = ScaledSolve(K0, n0)
 
     # -------------------------------------------------------------------- step
     def step(self, r1, r2, r3, r4):

@@ -260,6 +260,33 @@ def test_stages_beyond_one_cu_of_lds(case):
         assert (ranks[:-1, 0] == 40).all()
 
 
+@pytest.mark.parametrize("K,nx,nu,seed,state", [(12, 8, 1, 417, 5597), (32, 3, 2, 748, 7983)])
+def test_unstable_closed_loops_reach_the_reference_residual(K, nx, nu, seed, state):
+    """The two finds of round 2's campaign (profiles/r02_fuzz_big.txt): a free initial state and path equalities that
+    consume every control, so the closed loop is whatever the constraints make it - here unstable, V_0 of size 1e15 and
+    cond ~1e29.  The reference ends at 3e-8 / 2e-10; with [V_0 B_0'; B_0 0] applied as an explicit inverse this engine
+    ended at 1e-5 / 3e-5.  Its factors applied by substitution (k_st_x0_free), as the reference does with its
+    Bunch-Kaufman factors (hqp/Hqp_IpLQDOCP.C:1984-1996), reach the reference's residual."""
+    from oracle import oracleapi, refapi
+    prog = problems.lq_docp(K, nx, nu, seed=seed, x0_fixed=False, final_eq=0, path_eq=nu, path_eq_every=1, x_bounds=0)
+    st = problems.ip_state(prog, state, 1.0)
+    O = oracleapi.OracleIpMatrix("RedSpBKP")
+    O.init(prog)
+    O.factor(st[0], st[1])
+    osol, _ = O.solve(*st)
+    scale = max(1.0, max(np.abs(v).max() for v in osol if len(v)))
+    d, _res = _solve(ipmatrix.IpLQDOCP(), prog, st)
+    r = O.residuum(*st, *d)
+    bound = 1e-7 * scale
+    if refapi.available():
+        L = refapi.RefIpMatrix("LQDOCP")
+        L.init(prog)
+        L.factor(st[0], st[1])
+        _ls, lres = L.solve(*st)
+        bound = lres + 1e-10 * scale
+    assert r <= bound, (r, bound)
+
+
 @pytest.mark.parametrize("nx,nu,K", [(1000, 8, 3), (1500, 40, 2), (2304, 16, 2)])
 def test_staged_mid_size_stages_against_the_tree_engine(nx, nu, K):
     """Stage widths between the small cases (nx <= 400: reference, oracle) and the headline (nx = 5000: properties):
