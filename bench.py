@@ -454,6 +454,14 @@ def bench_c4(args):
                 comm_ranks = shard.comm_ranks  # ncclCommCount of the communicator the collectives run on
             except Exception as e:  # fall back to torch.distributed's collectives behind the callback
                 print(f"bench: RcclShard failed ({e}); using the torch.distributed callback", file=sys.stderr)
+                shard = None
+            # the choice of transport is one decision of ALL ranks: a rank that fell back alone would wait in a
+            # collective the others never enter
+            okf = torch.tensor([1.0 if shard is not None else 0.0], device="cuda")
+            tdist.all_reduce(okf, op=tdist.ReduceOp.MIN)
+            if float(okf) == 0.0 and shard is not None:
+                shard.close()
+                shard = None
         if shard is None:
             shard = (rank, world, kdist.make_exchange(rank, local_rank))
             transport = f"torch.distributed ({args.backend}) behind the exchange callback"

@@ -823,6 +823,10 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax *red) {
 // ip, ir, ic: int work arrays of q entries; colv, rowv: double work arrays of q entries.
 // 256 threads as a 16 x 16 grid: thread (ty, tx) owns the entries (ty + 16 i, tx + 16 j); the
 // pivot search of step s+1 rides on the update sweep of step s.
+#ifndef HQPKKT_GJ_RB
+#define HQPKKT_GJ_RB 2  // rows per trip of the sweeps whose matrix is in global memory (1024 threads: 128 registers each)
+#endif
+template <int RB = 1>  // RB rows x 8 columns of loads in flight per thread
 __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv,
                           ArgMax *red) {
   const int tid = threadIdx.x, nt = blockDim.x;
@@ -858,19 +862,41 @@ __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, d
     }
     __syncthreads();
     best = ArgMax{-1.0, 0x7fffffff};
-    for (int r = ty; r < q; r += RS) {
-      const double cr = colv[r];
-      const bool rfree = ip[r] == 0;
-      for (int c = tx; c < q; c += 16) {
-        double v;
-        if (r == icol)
-          v = rowv[c];
-        else
-          v = (c == icol ? 0.0 : a[r * ld + c]) - rowv[c] * cr;
-        a[r * ld + c] = v;
-        if (rfree && ip[c] == 0) {
-          const double av = fabs(v);
-          best = better(best, ArgMax{av == av ? av : INF, r * q + c});
+    // RB x 8 entries per trip: what depends on the column alone (pivot row, flags) is read once per trip, the entries'
+    // loads are issued together from clamped addresses (no branch between them) - the matrix may live in global memory
+    // (stages with hundreds of controls), and in LDS too a wait per entry costs more than the arithmetic
+    for (int c0 = tx; c0 < q; c0 += 128) {
+      double rv[8];
+      int cc[8];
+      bool cfree[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int c = c0 + 16 * u;
+        cc[u] = c < q ? c : q - 1;
+        rv[u] = rowv[cc[u]];
+        cfree[u] = c < q && ip[cc[u]] == 0;
+      }
+      for (int r0 = ty; r0 < q; r0 += RS * RB) {
+        double x[RB][8];
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+          const int r = min(r0 + k * RS, q - 1);
+#pragma unroll
+          for (int u = 0; u < 8; u++) x[k][u] = a[r * ld + cc[u]];
+        }
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+          const int r = r0 + k * RS, rr = min(r, q - 1);
+          const double cr = colv[rr];
+          const bool rfree = r < q && ip[rr] == 0, prow = r == icol;
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int c = c0 + 16 * u;
+            const double v = prow ? rv[u] : (c == icol ? 0.0 : x[k][u]) - rv[u] * cr;
+            if (r < q && c < q) a[r * ld + c] = v;
+            const double av = fabs(v);
+            if (rfree && cfree[u]) best = better(best, ArgMax{av == av ? av : INF, r * q + c});
+          }
         }
       }
     }
@@ -1065,7 +1091,7 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
 template <int NT>
 __device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red,
                               bool spd = false) {
-  if constexpr (NT != 256) return gj_inverse(a, q, ld, ip, ir, ic, colv, rowv, red);
+  if constexpr (NT != 256) return gj_inverse<HQPKKT_GJ_RB>(a, q, ld, ip, ir, ic, colv, rowv, red);
   if (spd && q <= 64) {
     const int e = q <= 16 ? gj_inverse_reg_spd<1>(a, q, ld, colv, rowv)
                 : q <= 32 ? gj_inverse_reg_spd<2>(a, q, ld, colv, rowv) : gj_inverse_reg_spd<4>(a, q, ld, colv, rowv);
@@ -1083,6 +1109,7 @@ __device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *i
 // search of step s+1 rides on the update sweep of step s (thread grid 16 columns x nt/16 rows, as in gj_inverse).
 // Used where the factors are applied by substitution (k_st_x0_free): a solve by factors leaves a residual of
 // eps |K| |x| where the product with an explicit inverse leaves cond(K) eps |b|.
+template <int RB = 1>
 __device__ int lu_complete(double *a, int q, int ld, int *pr, int *pc, double *colv, double *rowv, ArgMax *red) {
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ty = tid >> 4, tx = tid & 15, RS = nt >> 4;
@@ -1123,16 +1150,40 @@ __device__ int lu_complete(double *a, int q, int ld, int *pr, int *pc, double *c
     }
     __syncthreads();
     best = ArgMax{-1.0, 0x7fffffff};
-    for (int r = s + 1 + ty; r < q; r += RS) {
-      const double cr = colv[r];
-      if (tx == 0) a[r * ld + s] = cr;
-      for (int c = s + 1 + tx; c < q; c += 16) {
-        const double v = a[r * ld + c] - cr * rowv[c];
-        a[r * ld + c] = v;
-        const double av = fabs(v);
-        best = better(best, ArgMax{av == av ? av : INF, r * q + c});
+    for (int c0 = s + 1 + tx; c0 < q; c0 += 128) {  // (as in gj_inverse: column data once per trip, RB x 8 loads in flight)
+      double rv[8];
+      int cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        cc[u] = min(c0 + 16 * u, q - 1);
+        rv[u] = rowv[cc[u]];
+      }
+      for (int r0 = s + 1 + ty; r0 < q; r0 += RS * RB) {
+        double x[RB][8];
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+          const int r = min(r0 + k * RS, q - 1);
+#pragma unroll
+          for (int u = 0; u < 8; u++) x[k][u] = a[r * ld + cc[u]];
+        }
+#pragma unroll
+        for (int k = 0; k < RB; k++) {
+          const int r = r0 + k * RS;
+          const double cr = colv[min(r, q - 1)];
+#pragma unroll
+          for (int u = 0; u < 8; u++) {
+            const int c = c0 + 16 * u;
+            const double v = x[k][u] - cr * rv[u];
+            if (r < q && c < q) {
+              a[r * ld + c] = v;
+              const double av = fabs(v);
+              best = better(best, ArgMax{av == av ? av : INF, r * q + c});
+            }
+          }
+        }
       }
     }
+    for (int r = s + 1 + tid; r < q; r += nt) a[r * ld + s] = colv[r];  // the multipliers
   }
   __syncthreads();
   return bad;
@@ -1171,6 +1222,7 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
   __shared__ ArgMax red[16];
   __shared__ int s_r, s_stop;
   const int tid = threadIdx.x, nt = blockDim.x;
+  constexpr bool BIG = NT != 256;  // the matrices of (A) and (B) in a.scratch (global memory) instead of LDS
   const int m = a.m, n = a.n;
   const int c = a.e + (a.cnt_next ? *a.cnt_next : 0);
   int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
@@ -1178,8 +1230,14 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
   int r = 0;
   if (c > 0 && m > 0) {
     const int ld = m + c;
-    double *aug = a.scratch ? a.scratch : sm;
-    int *rfree = (int *)(a.scratch ? sm : sm + (size_t)c * ld);
+    // (the kind of memory is fixed by the instantiation, so that the accesses are LDS / global instructions and not
+    // flat ones: with a pointer chosen at run time every load also waits for the stores in front of it)
+    double *aug;
+    int *rfree;
+    if constexpr (BIG)
+      aug = a.scratch, rfree = (int *)sm;
+    else
+      aug = sm, rfree = (int *)(sm + (size_t)c * ld);
     int *cfree = rfree + c;
     for (int e = tid; e < c * ld; e += nt) {
       const int i = e / ld, j = e - i * ld;
@@ -1210,9 +1268,27 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
       __syncthreads();
       for (int i = tid; i < c; i += nt) fac[i] = (rfree[i]) ? aug[i * ld + pj] / piv : 0.0;
       __syncthreads();
-      for (int e = tid; e < c * ld; e += nt) {
-        const int i = e / ld, j = e - i * ld;
-        if (rfree[i] && fac[i] != 0.0) aug[e] = (j == pj) ? 0.0 : aug[e] - fac[i] * aug[pi * ld + j];
+      {  // (thread grid 16 columns x nt/16 rows; the pivot row's entries once per trip, eight loads in flight)
+        const int ty = tid >> 4, tx = tid & 15, RS = nt >> 4;
+        for (int j0 = tx; j0 < ld; j0 += 128) {
+          double pv[8];
+          int jj[8];
+#pragma unroll
+          for (int u = 0; u < 8; u++) jj[u] = min(j0 + 16 * u, ld - 1), pv[u] = aug[pi * ld + jj[u]];
+          for (int i = ty; i < c; i += RS) {
+            const double f = fac[i];  // (zero for the rows that are not free)
+            if (f != 0.0) {
+              double x[8];
+#pragma unroll
+              for (int u = 0; u < 8; u++) x[u] = aug[i * ld + jj[u]];
+#pragma unroll
+              for (int u = 0; u < 8; u++) {
+                const int j = j0 + 16 * u;
+                if (j < ld) aug[i * ld + j] = (j == pj) ? 0.0 : x[u] - f * pv[u];
+              }
+            }
+          }
+        }
       }
       __syncthreads();
     }
@@ -1246,8 +1322,11 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
   const int q = m + r;
   if (q > 0) {
     const int ld = q | 1;
-    double *Km = a.scratch ? a.scratch : sm;
-    double *dsc = a.scratch ? sm : Km + (size_t)q * ld;
+    double *Km, *dsc;
+    if constexpr (BIG)
+      Km = a.scratch, dsc = sm;
+    else
+      Km = sm, dsc = sm + (size_t)q * ld;
     double *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
     int *ip = (int *)(rowv + (q > 128 ? q : 128)), *ir = ip + q, *ic = ir + q;
     for (int e = tid; e < q * q; e += nt) {
@@ -1417,7 +1496,13 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_init_factor(int n0, int cap
   __shared__ ArgMax red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
   const int c = dyn0[1], q = n0 + c, ld = q | 1;
-  double *Km = scratch ? scratch : sm, *dsc = scratch ? sm : Km + (size_t)q * ld, *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
+  constexpr bool BIG = NT != 256;  // (the kind of memory fixed by the instantiation: see k_st_small)
+  double *Km, *dsc;
+  if constexpr (BIG)
+    Km = scratch, dsc = sm;
+  else
+    Km = sm, dsc = sm + (size_t)q * ld;
+  double *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
   int *pr = (int *)(rowv + (q > 128 ? q : 128)), *pc = pr + q;
   for (int e = tid; e < q * q; e += nt) {
     const int i = e / q, j = e - i * q;
@@ -1446,7 +1531,7 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_init_factor(int n0, int cap
   __syncthreads();
   for (int e = tid; e < q * q; e += nt) Km[(e / q) * ld + e % q] *= dsc[e / q] * dsc[e % q];
   __syncthreads();
-  const int bad = lu_complete(Km, q, ld, pr, pc, colv, rowv, red);
+  const int bad = lu_complete<BIG ? HQPKKT_GJ_RB : 1>(Km, q, ld, pr, pc, colv, rowv, red);
   if (bad && tid == 0) atomicExch(status, 4);
   __syncthreads();
   for (int e = tid; e < qmax * qmax; e += nt) {

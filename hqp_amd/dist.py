@@ -50,6 +50,11 @@ def fence(device_sync=True):
     """barrier + device synchronise, the bracket of the timed region."""
     import torch
     import torch.distributed as dist
+    # the device is drained BEFORE the barrier too: the barrier of an RCCL process group is itself a kernel, and it
+    # must never meet this library's own collectives (another communicator, libhqpkkt_rccl.so) in flight - kernels of
+    # two communicators queued in different orders on different ranks can wait for each other for ever
+    if device_sync and torch.cuda.is_available():
+        torch.cuda.synchronize()
     if dist.is_available() and dist.is_initialized():
         dist.barrier()
     if device_sync and torch.cuda.is_available():

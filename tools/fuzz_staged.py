@@ -92,12 +92,16 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
     cnt = {"ok": 0, "skip": 0, "BAD": 0}
+    why = {}  # skipped cases by reason (E_SIZES must stay at 0: every generated stage size has an engine)
     for case in range(seed0, seed0 + ncases):
         s, detail = check(case)
         cnt[s] += 1
+        if s == "skip":
+            reason = "E_SIZES" if "E_SIZES" in detail else detail.rsplit("} ", 1)[-1].split(" (")[0]
+            why[reason] = why.get(reason, 0) + 1
         if s == "BAD":
             print(detail, flush=True)
-    print(f"fuzz_staged: {ncases} cases from {seed0}: {cnt} in {time.time() - t0:.0f} s", flush=True)
+    print(f"fuzz_staged: {ncases} cases from {seed0}: {cnt} in {time.time() - t0:.0f} s; skipped because: {why}", flush=True)
 
 
 if __name__ == "__main__":
