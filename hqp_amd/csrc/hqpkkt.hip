@@ -2379,6 +2379,11 @@ int hqpkkt_debug_stamps(hqpkkt_t *h, int *out) {
   HIPCHK(hipMemcpy(out, h->flags.p, sizeof(int) * 64, hipMemcpyDeviceToHost));
   return 0;
 }
+int hqpkkt_debug_gj_stamps(int *out) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(stg::g_gj_stamps), sizeof(int) * 32));
+  return 0;
+}
 #endif
 
 int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long cap, long long *len) {

@@ -823,6 +823,15 @@ __device__ __forceinline__ ArgMax block_argmax(ArgMax a, ArgMax *red) {
 // ip, ir, ic: int work arrays of q entries; colv, rowv: double work arrays of q entries.
 // 256 threads as a 16 x 16 grid: thread (ty, tx) owns the entries (ty + 16 i, tx + 16 j); the
 // pivot search of step s+1 rides on the update sweep of step s.
+#ifdef HQPKKT_STAMPS
+__device__ int g_gj_stamps[32];
+#define GSTAMP(slot)                                                                              \
+  do {                                                                                            \
+    if (threadIdx.x == 0 && s == 10) g_gj_stamps[slot] = (int)__builtin_amdgcn_s_memtime();       \
+  } while (0)
+#else
+#define GSTAMP(slot)
+#endif
 #ifndef HQPKKT_GJ_RB
 #define HQPKKT_GJ_RB 2  // rows per trip of the sweeps whose matrix is in global memory (1024 threads: 128 registers each)
 #endif
@@ -832,17 +841,25 @@ __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, d
   const int tid = threadIdx.x, nt = blockDim.x;
   const int ty = tid >> 4, tx = tid & 15, RS = nt >> 4;  // (ty, tx): rows ty + RS i, columns tx + 16 j
   const double INF = __longlong_as_double(0x7ff0000000000000LL);
+  const long long ABS = 0x7fffffffffffffffLL, INFB = 0x7ff0000000000000LL;
   for (int j = tid; j < q; j += nt) ip[j] = 0;
   __syncthreads();
   int bad = 0;
-  ArgMax best{-1.0, 0x7fffffff};
+  // this thread's largest |entry| among the free rows and columns as its BIT PATTERN: for non-negative doubles the
+  // order of the patterns is the order of the values, and a NaN lies above infinity - one integer comparison per
+  // entry.  Ties: the first entry in this thread's fixed order, then the first lane, then the first wavefront - the
+  // same pivot sequence in every run.
+  long long bb = -1;
+  int bi = 0x7fffffff;
   for (int r = ty; r < q; r += RS)
     for (int c = tx; c < q; c += 16) {
-      const double v = fabs(a[r * ld + c]);
-      best = better(best, ArgMax{v == v ? v : INF, r * q + c});
+      const long long bits = __double_as_longlong(a[r * ld + c]) & ABS;
+      if (bits > bb) bb = bits, bi = r * q + c;
     }
   for (int s = 0; s < q; s++) {
-    best = block_argmax(best, red);
+    GSTAMP(0);
+    ArgMax best = block_argmax(ArgMax{bb < 0 ? -1.0 : (bb > INFB ? INF : __longlong_as_double(bb)), bi}, red);
+    GSTAMP(1);
     const int irow = best.i / q, icol = best.i - irow * q;
     if (!(best.v > 0.0) || best.v == INF) bad = 1;
     if (irow != icol)
@@ -853,15 +870,22 @@ __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, d
       }
     if (tid == 0) ip[icol] = 1, ir[s] = irow, ic[s] = icol;
     __syncthreads();
-    const double piv = a[icol * ld + icol];
-    const double pinv = bad ? 1.0 : 1.0 / piv;
-    __syncthreads();
+    GSTAMP(2);
+    const double pinv = bad ? 1.0 : 1.0 / a[icol * ld + icol];
     for (int c = tid; c < q; c += nt) {
       colv[c] = (c == icol) ? 0.0 : a[c * ld + icol];
       rowv[c] = (c == icol ? 1.0 : a[icol * ld + c]) * pinv;
     }
     __syncthreads();
-    best = ArgMax{-1.0, 0x7fffffff};
+    // the pivot column is cleared and the pivot row scaled in place, so that the sweep has no special rows or columns:
+    // every entry becomes a - colv[r] rowv[c] (colv is zero in the pivot row)
+    for (int c = tid; c < q; c += nt) {
+      if (c != icol) a[c * ld + icol] = 0.0;
+      a[icol * ld + c] = rowv[c];
+    }
+    __syncthreads();
+    GSTAMP(3);
+    bb = -1, bi = 0x7fffffff;
     // RB x 8 entries per trip: what depends on the column alone (pivot row, flags) is read once per trip, the entries'
     // loads are issued together from clamped addresses (no branch between them) - the matrix may live in global memory
     // (stages with hundreds of controls), and in LDS too a wait per entry costs more than the arithmetic
@@ -888,18 +912,19 @@ __device__ int gj_inverse(double *a, int q, int ld, int *ip, int *ir, int *ic, d
         for (int k = 0; k < RB; k++) {
           const int r = r0 + k * RS, rr = min(r, q - 1);
           const double cr = colv[rr];
-          const bool rfree = r < q && ip[rr] == 0, prow = r == icol;
+          const bool rfree = r < q && ip[rr] == 0;
 #pragma unroll
           for (int u = 0; u < 8; u++) {
             const int c = c0 + 16 * u;
-            const double v = prow ? rv[u] : (c == icol ? 0.0 : x[k][u]) - rv[u] * cr;
+            const double v = fma(-rv[u], cr, x[k][u]);
             if (r < q && c < q) a[r * ld + c] = v;
-            const double av = fabs(v);
-            if (rfree && cfree[u]) best = better(best, ArgMax{av == av ? av : INF, r * q + c});
+            const long long bits = __double_as_longlong(v) & ABS;
+            if (rfree && cfree[u] && bits > bb) bb = bits, bi = r * q + c;
           }
         }
       }
     }
+    GSTAMP(4);
   }
   __syncthreads();
   for (int s = q - 1; s >= 0; s--) {
@@ -1088,10 +1113,10 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
   return 0;
 }
 // dispatch: registers up to order 64 (the register forms are laid out for 256 threads), LDS / global memory above
-template <int NT>
+template <int NT, bool BIG = (NT != 256)>
 __device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red,
                               bool spd = false) {
-  if constexpr (NT != 256) return gj_inverse<HQPKKT_GJ_RB>(a, q, ld, ip, ir, ic, colv, rowv, red);
+  if constexpr (NT != 256) return gj_inverse<BIG ? HQPKKT_GJ_RB : 1>(a, q, ld, ip, ir, ic, colv, rowv, red);
   if (spd && q <= 64) {
     const int e = q <= 16 ? gj_inverse_reg_spd<1>(a, q, ld, colv, rowv)
                 : q <= 32 ? gj_inverse_reg_spd<2>(a, q, ld, colv, rowv) : gj_inverse_reg_spd<4>(a, q, ld, colv, rowv);
@@ -1216,13 +1241,25 @@ struct SmallArgs {
   double *scratch;      // null: the matrices of (A) and (B) live in LDS; else in this global area (stages with hundreds of
                         // controls / carried rows: StagedPlan::big) and LDS holds the flags and vectors only
 };
-template <int NT>
+#ifdef HQPKKT_STAMPS
+#define SSTAMP(slot)                                                                          \
+  do {                                                                                        \
+    if (threadIdx.x == 0) a.status[9 + (slot)] = (int)__builtin_amdgcn_s_memtime();           \
+  } while (0)
+#else
+#define SSTAMP(slot)
+#endif
+// <256, false>: K of order <= 64, register-resident inverse; <1024, false>: up to what LDS holds (order ~136), sixteen
+// wavefronts on the sweeps (measured: the sweep of the LDS inverse is bound by instruction issue, not by LDS);
+// <1024, true>: matrices in global memory.
+template <int NT, bool BIG = (NT != 256)>
 __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (one workgroup: no occupancy to protect, all registers)
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ ArgMax red[16];
   __shared__ int s_r, s_stop;
   const int tid = threadIdx.x, nt = blockDim.x;
-  constexpr bool BIG = NT != 256;  // the matrices of (A) and (B) in a.scratch (global memory) instead of LDS
+  // BIG: the matrices of (A) and (B) in a.scratch (global memory) instead of LDS
+  SSTAMP(0);
   const int m = a.m, n = a.n;
   const int c = a.e + (a.cnt_next ? *a.cnt_next : 0);
   int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
@@ -1319,6 +1356,7 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
     __syncthreads();
   }
   // ---------------- (B)
+  SSTAMP(1);
   const int q = m + r;
   if (q > 0) {
     const int ld = q | 1;
@@ -1344,10 +1382,12 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
       Km[i * ld + j] = v;
     }
     __syncthreads();
+    SSTAMP(2);
     for (int e = tid; e < a.qmax * a.qmax; e += nt) {
       const int i = e / a.qmax, j = e - i * a.qmax;
       a.Kmat[(long long)i * a.ldq + j] = (i < q && j < q) ? Km[i * ld + j] : 0.0;
     }
+    SSTAMP(3);
     // scaling: u rows 1/sqrt(K_ii) where K_ii > 1 (hqp/Hqp_IpLQDOCP.C:1851-1858), constraint rows
     // by their largest entry
     for (int i = tid; i < q; i += nt) {
@@ -1368,15 +1408,18 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
       Km[i * ld + j] *= dsc[i] * dsc[j];
     }
     __syncthreads();
-    const int bad = gj_inverse_any<NT>(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
+    SSTAMP(4);
+    const int bad = gj_inverse_any<NT, BIG>(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
     if (bad && tid == 0) atomicExch(a.status, 4);
     __syncthreads();
+    SSTAMP(5);
     for (int e = tid; e < a.qmax * a.qmax; e += nt) {
       const int i = e / a.qmax, j = e - i * a.qmax;
       double v = 0.0;
       if (i < q && j < q) v = 0.5 * (Km[i * ld + j] + Km[j * ld + i]) * dsc[i] * dsc[j];
       a.Kinv[(long long)i * a.ldq + j] = v;
     }
+    SSTAMP(6);
   } else {
     for (int e = tid; e < a.qmax * a.qmax; e += nt)
       a.Kinv[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0, a.Kmat[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0;

@@ -359,6 +359,8 @@ static int staged_upload(hqpkkt_t *h) {
     if (d.lds_small > attr_small) {
       HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_small<256>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                  (int)d.lds_small));
+      HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_small<1024, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                 (int)d.lds_small));
       attr_small = d.lds_small;
     }
     if (d.lds_small_big > attr_small_big) {
@@ -483,6 +485,8 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
                       P.big[k] ? d.misc.p + P.oScr : nullptr};
     if (P.big[k])
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
+    else if (P.qmax[k] > 64)
+      KLAUNCH(h, KC_ST_SMALL, (stg::k_st_small<1024, false><<<1, 1024, d.lds_small, h->stream>>>(sa)));
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, ldg, nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], q, sp.T, P.ldt[k], sp.dyn, sp.Y, ldy, sp.BT, P.ldb[k]};
@@ -603,6 +607,8 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
                       P.big[k] ? d.misc.p + P.oScr : nullptr};
     if (P.big[k])
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
+    else if (P.qmax[k] > 64)
+      KLAUNCH(h, KC_ST_SMALL, (stg::k_st_small<1024, false><<<1, 1024, d.lds_small, h->stream>>>(sa)));
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,
