@@ -17,7 +17,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.p
 cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/r03_kernel_stats.csv
 # other sizes of the same structure (K = 200), a stage with 200 controls at full width, round 1's headline workload
 for nx in 1000 2000 3000; do python tools/c4_bench.py 200 $nx 50 3 --profile 2>/dev/null | grep '^{' | tail -1 >> $O/r03_c4_sizes.jsonl; done
+python tools/c4_bench.py 200 5000 100 2 2>/dev/null | grep '^{' | tail -1 > $O/r03_c4_nu100.json
 python tools/c4_bench.py 200 5000 200 2 2>/dev/null | grep '^{' | tail -1 > $O/r03_c4_nu200.json
+python tools/bigstage_time.py 2>&1 | grep -v amdgpu.ids > $O/r03_bigstage_time.txt
 python bench.py --workload c2 --steps 20 --warmup 3 2>/dev/null | grep '^{' | tail -1 > $O/r03_bench_c2.json
 # the fp64 product on its own: rates by shape (three staging variants), time stamps per workgroup
 python tools/dgemm_ab.py 2>&1 | grep -v amdgpu.ids > $O/r03_dgemm_sizes.txt
@@ -27,6 +29,6 @@ python bench.py --gpus 2 --backend gloo --share-gpu --stages 20 --steps 3 --warm
 # single-GPU pieces of the multi-GPU model: the column-slice products of 2 / 4 / 8 ranks
 python tools/dgemm_shapes.py 5000x2560x5000x0 5000x2560x5000x1 5000x1280x5000x0 4360x1280x5000x1 3720x1280x5000x1 5000x640x5000x0 5000x640x5000x1 2440x640x5000x1 5000x5000x50x1x1 5000x50x5000x0 50x5050x5000x0 2>&1 | grep dgemm > $O/r03_slice_products.txt
 # the randomised sweep of the STAGED engine against the reference's Hqp_IpLQDOCP, in chunks
-for s0 in 0 400 800 1200 1600; do python tools/fuzz_staged.py 400 $s0 2>/dev/null | grep -v amdgpu.ids | tail -12; done > $O/r03_fuzz_staged.txt
+for s0 in $(seq 0 400 9600); do python tools/fuzz_staged.py 400 $s0 2>/dev/null | grep -v amdgpu.ids | tail -12; done > $O/r03_fuzz_staged.txt
 rm -rf $O/kt $O/pmc_fetch $O/pmc_write $O/pmc_mfma
 ls -la $O

@@ -100,6 +100,28 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   StagedDev *d = h->sd;
   // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
   const bool split = d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid);
+  // Between half a round and three quarters of the full grid of 128 x 128 tiles (stages of ~1500 .. 2700 states): whole
+  // tiles on ONE workgroup per CU, the remainder's k ranges cut - against 64 x 64 tiles on the register-staged loop
+  const long long t128 = stg::gemm_tiles(g.M, g.N, 128, g.lower);
+  static const int mid_mode = getenv("HQPKKT_MID_SPLIT") ? atoi(getenv("HQPKKT_MID_SPLIT")) : 0;
+  bool mid = (mid_mode & 1) && !split && d && allow_sk && d->sk_grid > 0 && d->cus > 0 && d->gemm_variant == stg::GEMM_DMA8 &&
+             t128 > d->cus / 2 && t128 < 384 && t128 % d->cus != 0 && g.K >= 64 * stg::GEMM_BK && t128 <= d->sk_tiles &&
+             !stg::gemm_big_tiles(g.M, g.N, g.lower, g.K);
+  // (experiment, bit 2: the triangular products of the split form on one workgroup per CU too)
+  if ((mid_mode & 2) && split && g.lower && d->cus > 0 && d->gemm_variant == stg::GEMM_DMA8 && t128 % d->cus != 0 && t128 <= d->sk_tiles) mid = true;
+  if (mid) {
+    if (g.lower && g.M < g.N) return HQPKKT_E_INTERN;
+    if (g.lower && g.M == g.N) {
+      const long long tm = (g.M + 127) / 128;
+      if (tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
+    }
+    if (d->zeros.p) g.zeros = d->zeros.p;
+    HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
+    stg::SplitPlan sk = stg::gemm_split_plan(t128, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->cus);
+    sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
+    KLAUNCH(h, cls, stg::gemm_launch_split(stg::GEMM_DMA8X3, d->cus, h->stream, g, sk));
+    return 0;
+  }
   const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower, g.K);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b;
@@ -289,7 +311,8 @@ static int staged_upload(hqpkkt_t *h) {
       tmax = std::max(tmax, t1 * t2);
       if (cus > 0)
         for (long long t : {t1 * t2, t2 * (t2 + 1) / 2, t1 * (t1 + 1) / 2})
-          pmax = std::max(pmax, stg::gemm_split_plan_pieces(stg::gemm_split_plan(t, (std::max(P.nk[k + 1], P.nk[k]) + stg::GEMM_BK - 1) / stg::GEMM_BK, 2 * cus)));
+          for (int grid : {2 * cus, cus})
+            pmax = std::max(pmax, stg::gemm_split_plan_pieces(stg::gemm_split_plan(t, (std::max(P.nk[k + 1], P.nk[k]) + stg::GEMM_BK - 1) / stg::GEMM_BK, grid)));
     }
     pmax = pmax * 5 / 4 + 64;  // (plans of smaller products of the same stage: never more pieces than 8 per tile of tmax)
     pmax = std::max(pmax, 16 * tmax);
