@@ -2366,6 +2366,14 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       v = &h->sd->plan.xcut;
       break;
     }
+    case 28: {  // STAGED: [0] stages whose blocked elimination ran, [1] those of them that fell back to the one-workgroup form
+      if (!h->sd) return HQPKKT_E_INTERN;
+      tmp.assign(2, 0);
+      if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(tmp.data(), h->flags.p + 6, sizeof(int) * 2, hipMemcpyDeviceToHost) != hipSuccess)
+        return HQPKKT_E_DEVICE;
+      v = &tmp;
+      break;
+    }
     default: return HQPKKT_E_RANGE;
   }
   *len = (long long)v->size();

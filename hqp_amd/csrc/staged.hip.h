@@ -1240,7 +1240,23 @@ struct SmallArgs {
   int *status;          // set to 4 (E_SING) on a singular K
   double *scratch;      // null: the matrices of (A) and (B) live in LDS; else in this global area (stages with hundreds of
                         // controls / carried rows: StagedPlan::big) and LDS holds the flags and vectors only
+  int mode;             // global-memory form only.  0: everything; 1: (A) and the scaled K, no inverse (the blocked
+                        // elimination k_blk_* follows); 2: the inverse by this kernel only if the blocked one gave up
 };
+// layout of SmallArgs::scratch in the global-memory form (qmax = SmallArgs::qmax, ldk = up8(qmax)):
+// scaled K | its scaling | panel T0 (64 x ldk) | panel R (64 x ldk) | block P (64 x 64) | flags (ints)
+struct BigScratch {
+  double *Ks, *dsc, *T0, *R, *Pb;
+  int *flags;
+  long long ldk;
+};
+__host__ __device__ inline BigScratch big_scratch(double *base, int qmax) {
+  BigScratch b;
+  b.ldk = (qmax + 7) / 8 * 8;
+  b.Ks = base, b.dsc = b.Ks + (long long)qmax * b.ldk, b.T0 = b.dsc + b.ldk, b.R = b.T0 + 64 * b.ldk, b.Pb = b.R + 64 * b.ldk;
+  b.flags = (int *)(b.Pb + 64 * 64);
+  return b;
+}
 #ifdef HQPKKT_STAMPS
 #define SSTAMP(slot)                                                                          \
   do {                                                                                        \
@@ -1265,7 +1281,13 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
   int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
   // ---------------- (A)
   int r = 0;
-  if (c > 0 && m > 0) {
+  if (BIG && a.mode == 2) {
+    // (second call for this stage: the ranks stand in dyn, and the area of (A) now holds K's scaling and the flags)
+    if (tid == 0) atomicAdd(a.status + 6, 1);
+    if (big_scratch(a.scratch, a.qmax).flags[0] == 0) return;  // (uniform)
+    if (tid == 0) atomicAdd(a.status + 7, 1);
+    r = a.dyn[0];
+  } else if (c > 0 && m > 0) {
     const int ld = m + c;
     // (the kind of memory is fixed by the instantiation, so that the accesses are LDS / global instructions and not
     // flat ones: with a pointer chosen at run time every load also waits for the stores in front of it)
@@ -1359,14 +1381,26 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
   SSTAMP(1);
   const int q = m + r;
   if (q > 0) {
-    const int ld = q | 1;
-    double *Km, *dsc;
-    if constexpr (BIG)
-      Km = a.scratch, dsc = sm;
-    else
-      Km = sm, dsc = sm + (size_t)q * ld;
-    double *colv = dsc + q, *rowv = colv + (q > 64 ? q : 64);
+    int ld = q | 1;
+    double *Km, *dsc, *colv;
+    if constexpr (BIG) {
+      const BigScratch bs = big_scratch(a.scratch, a.qmax);
+      Km = bs.Ks, dsc = bs.dsc, ld = (int)bs.ldk, colv = sm;
+    } else
+      Km = sm, dsc = sm + (size_t)q * ld, colv = dsc + q;
+    double *rowv = colv + (q > 64 ? q : 64);
     int *ip = (int *)(rowv + (q > 128 ? q : 128)), *ir = ip + q, *ic = ir + q;
+    if (BIG && a.mode == 2) {
+      // the blocked elimination gave up (a diagonal block without a safe pivot, or its result failed the check
+      // against K): K is scaled again from its copy and inverted here, with the search over the whole matrix
+      const BigScratch bs = big_scratch(a.scratch, a.qmax);
+      if (bs.flags[0] == 0) return;  // (uniform)
+      for (int e = tid; e < q * q; e += nt) {
+        const int i = e / q, j = e - i * q;
+        Km[i * ld + j] = a.Kmat[(long long)i * a.ldq + j] * dsc[i] * dsc[j];
+      }
+      __syncthreads();
+    } else {
     for (int e = tid; e < q * q; e += nt) {
       const int i = e / q, j = e - i * q;
       double v;
@@ -1408,6 +1442,18 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
       Km[i * ld + j] *= dsc[i] * dsc[j];
     }
     __syncthreads();
+    if (BIG && a.mode == 1) {
+      // identity padding up to qmax (the ranks are decided here, the launches behind this one were sized by the host)
+      const BigScratch bs = big_scratch(a.scratch, a.qmax);
+      for (int e = tid; e < a.qmax * a.qmax; e += nt) {
+        const int i = e / a.qmax, j = e - i * a.qmax;
+        if (i >= q || j >= q) Km[i * ld + j] = i == j ? 1.0 : 0.0;
+      }
+      for (int i = q + tid; i < a.qmax; i += nt) dsc[i] = 0.0;
+      if (tid == 0) bs.flags[0] = 0;
+      return;
+    }
+    }
     SSTAMP(4);
     const int bad = gj_inverse_any<NT, BIG>(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
     if (bad && tid == 0) atomicExch(a.status, 4);
@@ -1421,10 +1467,108 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
     }
     SSTAMP(6);
   } else {
+    if (BIG && a.mode == 2) return;
     for (int e = tid; e < a.qmax * a.qmax; e += nt)
       a.Kinv[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0, a.Kmat[(long long)(e / a.qmax) * a.ldq + e % a.qmax] = 0.0;
+    if constexpr (BIG) {
+      if (a.mode == 1) {
+        const BigScratch bs = big_scratch(a.scratch, a.qmax);
+        for (int e = tid; e < a.qmax * a.qmax; e += nt) bs.Ks[(long long)(e / a.qmax) * bs.ldk + e % a.qmax] = e / a.qmax == e % a.qmax ? 1.0 : 0.0;
+        for (int i = tid; i < a.qmax; i += nt) bs.dsc[i] = 0.0;
+        if (tid == 0) bs.flags[0] = 0;
+      }
+    }
   }
 }
+
+// ---- Blocked elimination of a stage's K where it does not fit the LDS of one CU (order up to 768): the symmetric
+// sweep operator with pivot BLOCKS of 64 down the diagonal - per block one workgroup inverts the 64 x 64 diagonal block
+// (complete pivoting inside it, registers), two small products on the whole chip form the block row P K_j: and the
+// update K - K_:j P K_j:, one kernel puts the block row, its mirror image and -P in place.  After the last block the
+// area holds -K^-1.  No pivoting ACROSS blocks: that is safe where the control Hessian of the stage is positive definite
+// and the consumed constraint rows come behind it (the quasidefinite order); a diagonal block without a safe pivot, or a
+// result that fails the check K K^-1 = I, raises flags[0] and the one-workgroup elimination with the search over the
+// whole matrix runs instead (k_st_small mode 2).  200 controls: 3 ms -> ~0.5 ms per stage, 512: 34 -> ~1 ms.
+struct BlkArgs {
+  double *scratch;
+  int qmax, j;
+};
+__global__ void __launch_bounds__(256) k_blk_pivot(BlkArgs a) {
+  __shared__ double A[64 * 65], colv[64], rowv[128];
+  __shared__ int ip[64], pcr[64];
+  __shared__ ArgMax red[16];
+  const BigScratch bs = big_scratch(a.scratch, a.qmax);
+  if (bs.flags[0]) return;  // (uniform) an earlier block gave up
+  const int tid = threadIdx.x, j0 = a.j * 64, b = min(64, a.qmax - j0);
+  ArgMax am{0.0, 0};
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const double v = (r < b && c < b) ? bs.Ks[(long long)(j0 + r) * bs.ldk + j0 + c] : 0.0;
+    A[r * 65 + c] = v;
+    const double av = fabs(v);
+    if (!(av <= am.v)) am.v = av == av ? av : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  for (int e = tid; e < 64 * a.qmax; e += 256) {
+    const int r = e / a.qmax, c = e - r * a.qmax;
+    bs.T0[(long long)r * bs.ldk + c] = r < b ? bs.Ks[(long long)(j0 + r) * bs.ldk + c] : 0.0;
+  }
+  am = block_argmax(am, red);
+  __syncthreads();
+  const int bad = gj_inverse_reg<4>(A, b, 65, ip, pcr, colv, rowv, red);
+  ArgMax pm{0.0, 0};
+  for (int e = tid; e < 64 * 64; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const double v = (r < b && c < b) ? 0.5 * (A[r * 65 + c] + A[c * 65 + r]) : 0.0;
+    bs.Pb[e] = v;
+    const double av = fabs(v);
+    if (!(av <= pm.v)) pm.v = av == av ? av : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  pm = block_argmax(pm, red);
+  // |K_jj| |K_jj^-1| beyond 1e12: no safe pivot inside this block
+  if (tid == 0 && (bad || !(am.v * pm.v < 1e12))) bs.flags[0] = 1;
+}
+__global__ void k_blk_fixup(BlkArgs a) {
+  const BigScratch bs = big_scratch(a.scratch, a.qmax);
+  if (bs.flags[0]) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= 64 * a.qmax) return;
+  const int r = e / a.qmax, c = e - r * a.qmax, j0 = a.j * 64, b = min(64, a.qmax - j0);
+  if (r >= b) return;
+  if (c >= j0 && c < j0 + b) {
+    bs.Ks[(long long)(j0 + r) * bs.ldk + c] = -bs.Pb[r * 64 + c - j0];
+  } else {
+    const double v = bs.R[(long long)r * bs.ldk + c];
+    bs.Ks[(long long)(j0 + r) * bs.ldk + c] = v;
+    bs.Ks[(long long)c * bs.ldk + j0 + r] = v;
+  }
+}
+// Kinv = -(swept area), unscaled, symmetrised, zero beyond the live order q = m + r
+__global__ void k_blk_final(SmallArgs a) {
+  const BigScratch bs = big_scratch(a.scratch, a.qmax);
+  if (bs.flags[0]) return;
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= a.qmax * a.qmax) return;
+  const int i = e / a.qmax, l = e - i * a.qmax, q = a.m + a.dyn[0];
+  double v = 0.0;
+  if (i < q && l < q) v = -0.5 * (bs.Ks[(long long)i * bs.ldk + l] + bs.Ks[(long long)l * bs.ldk + i]) * bs.dsc[i] * bs.dsc[l];
+  a.Kinv[(long long)i * a.ldq + l] = v;
+}
+// E = K Kinv (in the area of the swept matrix) against the identity of order q
+__global__ void __launch_bounds__(1024) k_blk_check(SmallArgs a, double tol) {
+  __shared__ ArgMax red[16];
+  const BigScratch bs = big_scratch(a.scratch, a.qmax);
+  if (bs.flags[0]) return;
+  const int q = a.m + a.dyn[0];
+  ArgMax am{0.0, 0};
+  for (int e = threadIdx.x; e < a.qmax * a.qmax; e += blockDim.x) {
+    const int i = e / a.qmax, l = e - i * a.qmax;
+    const double d = fabs(bs.Ks[(long long)i * bs.ldk + l] - ((i == l && i < q) ? 1.0 : 0.0));
+    if (!(d <= am.v)) am.v = d == d ? d : __longlong_as_double(0x7ff0000000000000LL);
+  }
+  am = block_argmax(am, red);
+  if (threadIdx.x == 0 && !(am.v <= tol)) bs.flags[0] = 1;
+}
+
 static size_t st_small_lds(int m, int capn, bool big = false) {
   const size_t q = (size_t)m + (size_t)(capn < m ? capn : m);
   // big: the matrices are in global memory, LDS holds flags, multipliers, scalings, pivot row / column, index arrays

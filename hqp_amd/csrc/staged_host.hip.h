@@ -165,6 +165,39 @@ int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int 
 
 }  // namespace
 
+// The control-sized elimination of a stage whose matrices live in global memory: phase (A) and the scaled K by the
+// one-workgroup kernel, the inverse by the blocked sweep on the whole chip (k_blk_*, staged.hip.h), its check against
+// K, and the one-workgroup inverse behind it in case the blocked one gave up (decided on the device: flags[0]).
+static int st_small_big(hqpkkt_t *h, StagedDev &d, stg::SmallArgs sa, bool allow_sk) {
+  static const bool legacy = getenv("HQPKKT_NO_BLOCK_GJ") != nullptr;
+  static const double tol = getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
+  if (legacy) {
+    sa.mode = 0;
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
+    return 0;
+  }
+  int e;
+  sa.mode = 1;
+  KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
+  const stg::BigScratch bs = stg::big_scratch(sa.scratch, sa.qmax);
+  const int q = sa.qmax, nb = (q + 63) / 64;
+  for (int j = 0; j < nb; j++) {
+    const stg::BlkArgs ba{sa.scratch, q, j};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_blk_pivot<<<1, 256, 0, h->stream>>>(ba));
+    if ((e = st_gemm(h, stg::GemmArgs{bs.Pb, 64, bs.T0, bs.ldk, nullptr, 0, bs.R, bs.ldk, 64, q, 64, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)) ||
+        (e = st_gemm(h, stg::GemmArgs{bs.T0, bs.ldk, bs.R, bs.ldk, bs.Ks, bs.ldk, bs.Ks, bs.ldk, q, q, 64, -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)))
+      return e;
+    KLAUNCH(h, KC_ST_SMALL, stg::k_blk_fixup<<<nblk(64LL * q), 256, 0, h->stream>>>(ba));
+  }
+  KLAUNCH(h, KC_ST_SMALL, stg::k_blk_final<<<nblk((long long)q * q), 256, 0, h->stream>>>(sa));
+  if ((e = st_gemm(h, stg::GemmArgs{sa.Kmat, sa.ldq, sa.Kinv, sa.ldq, nullptr, 0, bs.Ks, bs.ldk, q, q, q, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)))
+    return e;
+  KLAUNCH(h, KC_ST_SMALL, stg::k_blk_check<<<1, 1024, 0, h->stream>>>(sa, tol));
+  sa.mode = 2;
+  KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
+  return 0;
+}
+
 // Rm = K^-1 Y, refined against K: one launch for K of order <= 64 (k_st_rm), three products above
 static int st_rm(hqpkkt_t *h, StagedDev &d, const StagePtr &sp, int k, bool allow_sk) {
   const kktdev::StagedPlan &P = d.plan;
@@ -506,9 +539,9 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     stg::SmallArgs sa{G, ldg, nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
                       P.capn[k], P.cap[k], q, h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p,
                       P.big[k] ? d.misc.p + P.oScr : nullptr};
-    if (P.big[k])
-      KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
-    else if (P.qmax[k] > 64)
+    if (P.big[k]) {
+      if ((e = st_small_big(h, d, sa, !two))) return e;
+    } else if (P.qmax[k] > 64)
       KLAUNCH(h, KC_ST_SMALL, (stg::k_st_small<1024, false><<<1, 1024, d.lds_small, h->stream>>>(sa)));
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
@@ -628,9 +661,9 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     stg::SmallArgs sa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
                       P.capn[k], P.cap[k], P.qmax[k], h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p,
                       P.big[k] ? d.misc.p + P.oScr : nullptr};
-    if (P.big[k])
-      KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
-    else if (P.qmax[k] > 64)
+    if (P.big[k]) {
+      if ((e = st_small_big(h, d, sa, !ovl))) return e;
+    } else if (P.qmax[k] > 64)
       KLAUNCH(h, KC_ST_SMALL, (stg::k_st_small<1024, false><<<1, 1024, d.lds_small, h->stream>>>(sa)));
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));

@@ -190,7 +190,10 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     const long long b = gj_lds_bytes(q);
     if (std::max(a, b) + 256 > 150 * 1024) {
       big[k] = 1;
-      scratch_elems = std::max(scratch_elems, std::max((long long)capn[k] * (mk[k] + capn[k]), q * (q | 1)) + 64);
+      // the scaled K (rows of up8(q) doubles), its scaling, and for the blocked elimination (k_blk_*) two panels of 64
+      // rows, one 64 x 64 block and a few flags; the constraint rows of phase (A) use the same area before K is built
+      const long long ldk = (q + 7) / 8 * 8;
+      scratch_elems = std::max(scratch_elems, std::max((long long)capn[k] * (mk[k] + capn[k]), q * ldk + ldk + 2 * 64 * ldk + 64 * 64 + 16) + 64);
     }
   }
   big0 = 0;

@@ -253,11 +253,39 @@ def test_stages_beyond_one_cu_of_lds(case):
     df, rf = _solve(F, prog, st)
     assert rs <= RES_TOL and rf <= RES_TOL, (rs, rf)
     assert rel_err(ds, df) <= SOL_TOL
+    # the inverse of K by the blocked sweep over the whole chip (k_blk_*): used by every such stage, and on these QPs -
+    # positive definite control Hessians, constraint rows behind them - without falling back to the one-workgroup form
+    used, fell_back = S.debug(28)
+    assert fell_back == 0 and (used > 0) == (case in ("nu200", "nu512", "nu300_path40", "final140")), (used, fell_back)
     ranks = S.stage_ranks()
     if case == "final140":  # the 140 final-state rows are consumed twenty per stage on their way back
         assert ranks[-1, 1] == 140 and ranks[0, 1] == 0 and ranks[:, 0].max() == 20 and (ranks[:, 0] == 20).sum() == 7
     if case == "nu300_path40":
         assert (ranks[:-1, 0] == 40).all()
+
+
+def test_blocked_elimination_falls_back_to_the_pivoted_one(monkeypatch):
+    """The device-side decision behind the blocked sweep: with a tolerance no result can meet (HQPKKT_BLOCK_GJ_TOL < 0)
+    every stage's check fails, the one-workgroup elimination with the search over the whole matrix runs instead, and the
+    solution is the same."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np
+        from hqp_amd import problems, ipmatrix
+        from common import new_d, rel_err
+        prog = problems.lq_docp(3, 200, 300, path_eq=40, seed=5); st = problems.ip_state(prog, 6, 1.0)
+        out = []
+        for M in (ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()):
+            M.init(prog); M.factor(prog, st[0], st[1]); d = new_d(prog); res = M.solve(prog, *st, *d); out.append((d, res, M))
+        used, fell = out[0][2].debug(28)
+        assert used == 3 and fell == 3, (used, fell)
+        assert out[0][1] <= 1e-10 and rel_err(out[0][0], out[1][0]) <= 1e-8, (out[0][1], rel_err(out[0][0], out[1][0]))
+        print("OK")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HQPKKT_BLOCK_GJ_TOL="-1")
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
 
 
 @pytest.mark.parametrize("K,nx,nu,seed,state", [(12, 8, 1, 417, 5597), (32, 3, 2, 748, 7983)])

@@ -97,6 +97,27 @@ def test_lqdocp_plugin_takes_wide_stages_as_dense_blocks(monkeypatch, capfd):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("case", ["nu150", "free_x0_path"])
+def test_lqdocp_plugin_on_stages_beyond_round_twos_limits(case, monkeypatch):
+    """Stage sizes round 2's kernels refused (HQPKKT_E_SIZES, then the tree engine): 150 controls per stage (the
+    control-sized elimination out of global memory), and a free initial state of 300 components (solved by LU factors
+    and substitution) with path equalities - LQDOCPHip on the STAGED engine under the reference's own Hqp_IpsMehrotra
+    against the reference's Hqp_IpLQDOCP: same iterations, result, objective and optimiser."""
+    if not refapi.host_available("hip"):
+        pytest.skip("oracle/_ref/libhqphost_hip.so not present")
+    monkeypatch.setenv("HQPKKT_STAGED_MIN_FRONT", "0")
+    prog = {"nu150": lambda: problems.lq_docp(3, 200, 150, seed=7),
+            "free_x0_path": lambda: problems.lq_docp(4, 300, 6, x0_fixed=False, path_eq=2, final_eq=3, seed=8)}[case]()
+    ref = refapi.ip_solve(prog, "Mehrotra", "LQDOCP", host="hip")
+    hip = refapi.ip_solve(prog, "Mehrotra", "LQDOCPHip", host="hip")
+    assert hip["mat_sbw"] == -1  # the STAGED engine, not the fall-back
+    fr, fh = objective(prog, ref["x"]), objective(prog, hip["x"])
+    assert hip["result"] == ref["result"] == 0 and hip["iters"] == ref["iters"], (ref["result"], ref["iters"], hip["result"], hip["iters"])
+    assert abs(fr - fh) <= 1e-6 * max(1.0, abs(fr))
+    assert np.abs(hip["x"] - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("solver", ["Mehrotra", "Franke"])
 @pytest.mark.parametrize("pair", [("SpBKP", "SpBKPHip"), ("RedSpBKP", "RedSpBKPHip"), ("LQDOCP", "LQDOCPHip")])
 @pytest.mark.parametrize("case", ["did50", "did400", "banded"])
