@@ -264,6 +264,30 @@ def test_stages_beyond_one_cu_of_lds(case):
         assert (ranks[:-1, 0] == 40).all()
 
 
+@pytest.mark.parametrize("seed", range(10))
+def test_random_stages_with_many_controls_against_the_tree_engine(seed):
+    """Random stage shapes in the range the campaigns of tools/fuzz_staged.py do not reach (they stop at 9 controls):
+    66 ... 280 controls, path equalities that consume a part of them, final-state rows carried back, fixed / free initial
+    state - K of order 65 ... 136 in LDS with sixteen wavefronts, beyond that the blocked elimination - against the
+    tree engine on the same QP."""
+    rng = np.random.default_rng(900 + seed)
+    nu = int(rng.integers(66, 281))
+    nx = int(rng.integers(40, 220))
+    K = int(rng.integers(2, 4))
+    path_eq = int(rng.integers(0, min(nu, 60))) if rng.random() < 0.6 else 0
+    final_eq = int(rng.integers(1, min(nx, 40))) if rng.random() < 0.5 else 0
+    x0_fixed = bool(rng.random() < 0.7)
+    prog = problems.lq_docp(K, nx, nu, seed=int(rng.integers(1, 999)), x0_fixed=x0_fixed, path_eq=path_eq, final_eq=final_eq)
+    st = problems.ip_state(prog, 40 + seed, float(rng.choice([0.0, 1.0, 2.0])))
+    S, F = ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()
+    ds, rs = _solve(S, prog, st)
+    df, rf = _solve(F, prog, st)
+    tag = dict(K=K, nx=nx, nu=nu, path_eq=path_eq, final_eq=final_eq, x0_fixed=x0_fixed)
+    assert rs <= RES_TOL and rf <= RES_TOL, (tag, rs, rf)
+    assert rel_err(ds, df) <= SOL_TOL, (tag, rel_err(ds, df))
+    assert S.debug(28)[1] == 0, tag  # (the blocked form, where it ran, did not have to fall back)
+
+
 def test_blocked_elimination_falls_back_to_the_pivoted_one(monkeypatch):
     """The device-side decision behind the blocked sweep: with a tolerance no result can meet (HQPKKT_BLOCK_GJ_TOL < 0)
     every stage's check fails, the one-workgroup elimination with the search over the whole matrix runs instead, and the
