@@ -1618,10 +1618,12 @@ __global__ void k_st_wide(WideArgs a) {
 struct RmArgs {
   const double *Kinv, *Kmat;
   long long ldq;
-  const double *Y;
+  double *Y;
   double *Rm;
   long long ldy;
   int q, n;
+  int wide;  // 1: Y and the carried rows B_k are formed here too, from w (k_st_wide's work: one launch less)
+  WideArgs w;
 };
 static const int RM_COLS = 32;
 static inline size_t st_rm_lds(int q) { return sizeof(double) * ((size_t)2 * q * (q | 1) + (size_t)3 * q * RM_COLS); }
@@ -1635,7 +1637,32 @@ __global__ void __launch_bounds__(256) k_st_rm(RmArgs a) {
     Ki[i * ldk + l] = a.Kinv[(long long)i * a.ldq + l];
     Km[i * ldk + l] = a.Kmat[(long long)i * a.ldq + l];
   }
-  for (int i = g; i < q; i += 8) Ys[i * RM_COLS + c] = j < a.n ? a.Y[(long long)i * a.ldy + j] : 0.0;
+  if (a.wide) {
+    const WideArgs &w = a.w;
+    const int r = w.dyn[0], nl = w.dyn[1];
+    const int *Rl = w.dyn + 2, *Ll = w.dyn + 2 + w.capn;
+    for (int i = g; i < q; i += 8) {
+      double v = 0.0;
+      if (j < a.n) {
+        if (i < w.m)
+          v = w.G[(long long)(w.n + i) * w.ldg + j];
+        else if (i - w.m < r)
+          v = w.N[(long long)Rl[i - w.m] * w.ldn + j];
+        a.Y[(long long)i * a.ldy + j] = v;
+      }
+      Ys[i * RM_COLS + c] = v;
+    }
+    if (j < a.n)
+      for (int li = g; li < w.cap; li += 8) {
+        double v = 0.0;
+        if (li < nl) {
+          v = w.N[(long long)Ll[li] * w.ldn + j];
+          for (int s = 0; s < r; s++) v -= w.t[(long long)li * w.ldt + s] * w.N[(long long)Rl[s] * w.ldn + j];
+        }
+        w.BT[(long long)j * w.ldb + li] = v;
+      }
+  } else
+    for (int i = g; i < q; i += 8) Ys[i * RM_COLS + c] = j < a.n ? a.Y[(long long)i * a.ldy + j] : 0.0;
   __syncthreads();
   for (int i = g; i < q; i += 8) {
     double s = 0.0;

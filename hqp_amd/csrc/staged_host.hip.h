@@ -199,16 +199,19 @@ static int st_small_big(hqpkkt_t *h, StagedDev &d, stg::SmallArgs sa, bool allow
 }
 
 // Rm = K^-1 Y, refined against K: one launch for K of order <= 64 (k_st_rm), three products above
-static int st_rm(hqpkkt_t *h, StagedDev &d, const StagePtr &sp, int k, bool allow_sk) {
+// (wa: the arguments of k_st_wide - Y and the carried rows B_k; with K of order 1 .. 64 they are formed inside k_st_rm)
+static int st_rm(hqpkkt_t *h, StagedDev &d, const StagePtr &sp, int k, bool allow_sk, const stg::WideArgs &wa) {
   const kktdev::StagedPlan &P = d.plan;
   const int q = P.qmax[k], nn = P.nk[k];
   const long long ldy = P.ldy[k];
-  if (q <= 0) return 0;
-  if (q <= 64 && !getenv("HQPKKT_NO_FUSED_RM")) {
-    stg::RmArgs ra{sp.Kinv, sp.Kmat, P.ldq[k], sp.Y, sp.Rm, ldy, q, nn};
+  static const bool fused = getenv("HQPKKT_NO_FUSED_RM") == nullptr;
+  if (q > 0 && q <= 64 && fused) {
+    stg::RmArgs ra{sp.Kinv, sp.Kmat, P.ldq[k], sp.Y, sp.Rm, ldy, q, nn, 1, wa};
     KLAUNCH(h, KC_ST_GEMM_UPD, stg::k_st_rm<<<(nn + stg::RM_COLS - 1) / stg::RM_COLS, 256, stg::st_rm_lds(q), h->stream>>>(ra));
     return 0;
   }
+  KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
+  if (q <= 0) return 0;
   // one round of refinement against K: Rm += K^-1 (Y - K Rm).  The product with an explicit inverse alone
   // leaves a residual of cond(K) eps |Y| where the reference's solve by Bunch-Kaufman factors
   // (hqp/Hqp_IpLQDOCP.C:1866-1869, 1911-1924) leaves eps |K| |Rm|; stiff stages need the latter
@@ -546,9 +549,8 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, ldg, nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], q, sp.T, P.ldt[k], sp.dyn, sp.Y, ldy, sp.BT, P.ldb[k]};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
+    if ((e = st_rm(h, d, sp, k, !two, wa))) return e;
   }
-  if ((e = st_rm(h, d, sp, k, !two))) return e;
   if (two) HIPCHK(hipEventRecord(d.ev_join, sB));
   // ---- sA: the large products of this rank's columns, and the exchange
   h->stream = sA;
@@ -669,8 +671,7 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,
                      sp.Y, P.ldy[k], sp.BT, P.ldb[k]};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_wide<<<nblk(nn), 256, 0, h->stream>>>(wa));
-    if ((e = st_rm(h, d, sp, k, !ovl))) return e;
+    if ((e = st_rm(h, d, sp, k, !ovl, wa))) return e;
     on_a();
     if (ovl) {
       HIPCHK(hipEventRecord(d.ev_join, sB));
