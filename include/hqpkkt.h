@@ -407,8 +407,8 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
  * 8 entry_row, 9 entry_col (elimination indices, nnz_kkt each), 10 node_owner
  * (rank per supernode, -1 = replicated top), 11 exchanged subtree roots; STAGED: 20 states
  * per stage, 21 controls, 22 first column, 23 / 24 own equality rows (ptr / rows), 25 rows
- * that fix x_0, 26 capacity of carried rows, 27 column cuts of the ranks ((K+1) x (ranks+1)), 28 two counters since
- * the last set_values: stages whose K was inverted by the blocked elimination, and those of them that fell back to the
+ * that fix x_0, 26 capacity of carried rows, 27 column cuts of the ranks ((K+1) x (ranks+1)), 28 two counters of
+ * the last factorisation: stages whose K was inverted by the blocked elimination, and those of them that fell back to the
  * one-workgroup elimination (device -> host copy); 30 (zero-diagonal policy in use, last
  * values have weak Hessian diagonals).
  * *len receives the element count; out may be NULL to query it. */
