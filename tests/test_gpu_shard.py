@@ -60,7 +60,8 @@ def test_sharded_system_switches_the_zero_diagonal_placement_on_every_rank():
         assert r[0]["same_as_rank0"] and r[0]["res"] <= 10 * r0["res_single"] + 1e-10, r[0]
 
 
-STAGED_CASES = [["docp", 5, 300, 6, "LQDOCP"], ["docp", 3, 520, 20, "LQDOCP"]]
+# (the third: 200 controls per stage - the blocked elimination of K on the second stream, beside the strips' products)
+STAGED_CASES = [["docp", 5, 300, 6, "LQDOCP"], ["docp", 3, 520, 20, "LQDOCP"], ["docp", 3, 400, 200, "LQDOCP"]]
 
 
 @pytest.mark.parametrize("world,port", [(2, 29571), (3, 29572)])
@@ -128,15 +129,15 @@ def test_rccl_transport_single_rank():
     """libhqpkkt_rccl.so on the one GPU of the test box: a communicator of one rank, the STAGED
     engine's exchange path with the collectives in the handle's stream (hqpkkt_set_shard_stream).
     The several-rank form of the same code runs in bench.py --one-system."""
-    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_TRANSPORT="rccl", SHARD_CASES=json.dumps(STAGED_CASES[:1]),
-               MASTER_ADDR="127.0.0.1")
+    cases = [STAGED_CASES[0], STAGED_CASES[2]]
+    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_TRANSPORT="rccl", SHARD_CASES=json.dumps(cases), MASTER_ADDR="127.0.0.1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
            "--master-addr", "127.0.0.1", "--master-port", "29575", os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
-    rec = json.loads(line[len("SHARD_RESULT "):])[0][0]
-    assert rec["diff"] < 1e-9 and rec["res"] <= 1e-10
+    for rec in json.loads(line[len("SHARD_RESULT "):])[0]:
+        assert rec["diff"] < 1e-9 and rec["res"] <= 1e-10, rec
 
 
 @pytest.mark.parametrize("world,port", [(2, 29577), (3, 29578)])
