@@ -1043,16 +1043,17 @@ __device__ int gj_inverse_reg(double *a, int q, int ld, int *ip, int *pc_of_row,
 // when a pivot is not safely positive (G_uu indefinite or nearly singular): the caller then runs the search.
 template <int NB>
 __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double *rowv) {
+  // in place (no identity beside the matrix: half the multiply-adds and LDS reads of the form with the search): step s
+  // replaces the pivot by 1/p, its row by row/p, its column by -column/p and every other entry by a_ij - a_is a_sj / p
   const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
-  double m[NB][2 * NB];
+  double m[NB][NB];
 #pragma unroll
   for (int i = 0; i < NB; i++) {
     const int r = ty + 16 * i;
 #pragma unroll
     for (int j = 0; j < NB; j++) {
       const int c = tx + 16 * j;
-      m[i][j] = (r < q && c < q) ? a[r * ld + c] : 0.0;
-      m[i][NB + j] = (r == c && r < q) ? 1.0 : 0.0;
+      m[i][j] = (r < q && c < q) ? a[r * ld + c] : (r == c ? 1.0 : 0.0);
     }
   }
   __syncthreads();
@@ -1064,7 +1065,7 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
       for (int ii = 0; ii < NB; ii++)
         if (ii == i) {
 #pragma unroll
-          for (int j = 0; j < 2 * NB; j++) rowv[tx + 16 * j] = m[ii][j];
+          for (int j = 0; j < NB; j++) rowv[tx + 16 * j] = m[ii][j];
         }
     }
     if ((s & 15) == tx) {
@@ -1077,22 +1078,20 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
         }
     }
     __syncthreads();
-    const double piv = rowv[(s & 15) + 16 * (s >> 4)];
+    const double piv = rowv[s];
     if (!(piv > 1e-10)) bad = 2;  // uniform: every thread reads the same value (the matrix is scaled: diagonal <= 1)
     const double pinv = bad ? 1.0 : 1.0 / piv;
-    double rv[2 * NB];
+    double rv[NB];
 #pragma unroll
-    for (int j = 0; j < 2 * NB; j++) rv[j] = rowv[tx + 16 * j] * pinv;
+    for (int j = 0; j < NB; j++) rv[j] = (tx + 16 * j == s ? 1.0 : rowv[tx + 16 * j]) * pinv;
 #pragma unroll
     for (int i = 0; i < NB; i++) {
       const int r = ty + 16 * i;
       const double f = colv[r];
-      if (r == s) {
 #pragma unroll
-        for (int j = 0; j < 2 * NB; j++) m[i][j] = rv[j];
-      } else {
-#pragma unroll
-        for (int j = 0; j < 2 * NB; j++) m[i][j] -= f * rv[j];
+      for (int j = 0; j < NB; j++) {
+        const double old = tx + 16 * j == s ? 0.0 : m[i][j];
+        m[i][j] = r == s ? rv[j] : fma(-f, rv[j], old);
       }
     }
     __syncthreads();  // rowv / colv are rewritten in the next step
@@ -1105,7 +1104,7 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
 #pragma unroll
       for (int j = 0; j < NB; j++) {
         const int c = tx + 16 * j;
-        if (c < q) a[r * ld + c] = m[i][NB + j];
+        if (c < q) a[r * ld + c] = m[i][j];
       }
     }
   }
@@ -1626,31 +1625,67 @@ struct RmArgs {
   WideArgs w;
 };
 static const int RM_COLS = 32;
-static inline size_t st_rm_lds(int q) { return sizeof(double) * ((size_t)2 * q * (q | 1) + (size_t)3 * q * RM_COLS); }
+// K^-1 and K zero-padded to a multiple of 16 (rows of QP + 1 doubles), three QP x 32 panels
+static inline size_t st_rm_lds(int q) {
+  const size_t QP = ((size_t)q + 15) & ~(size_t)15;
+  return sizeof(double) * (2 * QP * (QP + 1) + 3 * QP * RM_COLS);
+}
+#ifdef HQPKKT_STAMPS
+#define RSTAMP(slot)                                                                                     \
+  do {                                                                                                   \
+    if (threadIdx.x == 0 && blockIdx.x == 0) g_gj_stamps[16 + (slot)] = (int)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define RSTAMP(slot)
+#endif
+// The three products are (q x q)' (q x 32) each: on the matrix pipe (v_mfma_f64_16x16x4: wavefront w takes the rows
+// 16 w .. 16 w + 15 of the result, both halves of the 32 columns) - as scalar sums out of LDS they had been bound by the
+// LDS issue rate (nine reads per eight multiply-adds; 14 us of a 22-us kernel at q = 50, tools/stamps_stsmall.py).
 __global__ void __launch_bounds__(256) k_st_rm(RmArgs a) {
+  typedef double d4 __attribute__((ext_vector_type(4)));
   extern __shared__ __attribute__((aligned(16))) double sm[];
-  const int q = a.q, ldk = q | 1, tid = threadIdx.x, c = tid & (RM_COLS - 1), g = tid / RM_COLS;
-  double *Ki = sm, *Km = Ki + (size_t)q * ldk, *Ys = Km + (size_t)q * ldk, *Rs = Ys + (size_t)q * RM_COLS, *Es = Rs + (size_t)q * RM_COLS;
+  RSTAMP(0);
+  const int q = a.q, QP = (q + 15) & ~15, LDK = QP + 1, tid = threadIdx.x, c = tid & (RM_COLS - 1), g = tid / RM_COLS;
+  double *Ki = sm, *Km = Ki + (size_t)QP * LDK, *Ys = Km + (size_t)QP * LDK, *Rs = Ys + (size_t)QP * RM_COLS, *Es = Rs + (size_t)QP * RM_COLS;
   const int j = blockIdx.x * RM_COLS + c;
-  for (int e = tid; e < q * q; e += 256) {
-    const int i = e / q, l = e - i * q;
-    Ki[i * ldk + l] = a.Kinv[(long long)i * a.ldq + l];
-    Km[i * ldk + l] = a.Kmat[(long long)i * a.ldq + l];
+  {  // (lane = column, the wavefronts take the rows in turn; the loads of a thread in flight together)
+    const int l = tid & 63;
+    double vi[16], vm[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = (tid >> 6) + 4 * u;
+      const bool in = i < q && l < q;
+      vi[u] = in ? a.Kinv[(long long)i * a.ldq + l] : 0.0;
+      vm[u] = in ? a.Kmat[(long long)i * a.ldq + l] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int i = (tid >> 6) + 4 * u;
+      if (i < QP && l < QP) Ki[i * LDK + l] = vi[u], Km[i * LDK + l] = vm[u];
+    }
   }
+  RSTAMP(1);
   if (a.wide) {
     const WideArgs &w = a.w;
     const int r = w.dyn[0], nl = w.dyn[1];
     const int *Rl = w.dyn + 2, *Ll = w.dyn + 2 + w.capn;
-    for (int i = g; i < q; i += 8) {
-      double v = 0.0;
-      if (j < a.n) {
+    double yv[8];  // (all loads before the first store: Y may alias G and N as far as the compiler knows)
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = g + 8 * u;
+      yv[u] = 0.0;
+      if (j < a.n && i < q) {
         if (i < w.m)
-          v = w.G[(long long)(w.n + i) * w.ldg + j];
+          yv[u] = w.G[(long long)(w.n + i) * w.ldg + j];
         else if (i - w.m < r)
-          v = w.N[(long long)Rl[i - w.m] * w.ldn + j];
-        a.Y[(long long)i * a.ldy + j] = v;
+          yv[u] = w.N[(long long)Rl[i - w.m] * w.ldn + j];
       }
-      Ys[i * RM_COLS + c] = v;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int i = g + 8 * u;
+      if (j < a.n && i < q) a.Y[(long long)i * a.ldy + j] = yv[u];
+      if (i < QP) Ys[i * RM_COLS + c] = yv[u];
     }
     if (j < a.n)
       for (int li = g; li < w.cap; li += 8) {
@@ -1662,25 +1697,55 @@ __global__ void __launch_bounds__(256) k_st_rm(RmArgs a) {
         w.BT[(long long)j * w.ldb + li] = v;
       }
   } else
-    for (int i = g; i < q; i += 8) Ys[i * RM_COLS + c] = j < a.n ? a.Y[(long long)i * a.ldy + j] : 0.0;
+    for (int i = g; i < QP; i += 8) Ys[i * RM_COLS + c] = (j < a.n && i < q) ? a.Y[(long long)i * a.ldy + j] : 0.0;
   __syncthreads();
-  for (int i = g; i < q; i += 8) {
-    double s = 0.0;
-    for (int l = 0; l < q; l++) s += Ki[l * ldk + i] * Ys[l * RM_COLS + c];
-    Rs[i * RM_COLS + c] = s;
-  }
+  RSTAMP(2);
+  const int wave = tid >> 6, lane = tid & 63, lr = lane & 15, lk = lane >> 4, m0 = 16 * wave;
+  const int kend = (q + 3) & ~3;
+  // out = init + sign * Kx' X for this wavefront's 16 rows (operand layout of the instruction: A[m = lr][k = lk],
+  // B[k = lk][n = lr], result rows lk + 4 rg)
+  auto product = [&](const double *Kx, const double *X, double sign, const double *init, double *out, bool global) {
+    if (m0 >= QP) return;  // (wave-uniform)
+    d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+    if (init) {
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        acc0[rg] = init[(m0 + lk + 4 * rg) * RM_COLS + lr];
+        acc1[rg] = init[(m0 + lk + 4 * rg) * RM_COLS + 16 + lr];
+      }
+    }
+    double av[16], b0[16], b1[16];  // all fragments of the k loop first (QP <= 64: 16 steps at most), then the chain
+#pragma unroll
+    for (int st = 0; st < 16; st++)
+      if (4 * st < kend) {  // (wave-uniform)
+        av[st] = Kx[(4 * st + lk) * LDK + m0 + lr];
+        b0[st] = sign * X[(4 * st + lk) * RM_COLS + lr], b1[st] = sign * X[(4 * st + lk) * RM_COLS + 16 + lr];
+      }
+#pragma unroll
+    for (int st = 0; st < 16; st++)
+      if (4 * st < kend) {
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], b0[st], acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av[st], b1[st], acc1, 0, 0, 0);
+      }
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int m = m0 + lk + 4 * rg;
+      if (global) {
+        const int jj = blockIdx.x * RM_COLS + lr;
+        if (m < q && jj < a.n) out[(long long)m * a.ldy + jj] = acc0[rg];
+        if (m < q && jj + 16 < a.n) out[(long long)m * a.ldy + jj + 16] = acc1[rg];
+      } else {
+        out[m * RM_COLS + lr] = acc0[rg];
+        out[m * RM_COLS + 16 + lr] = acc1[rg];
+      }
+    }
+  };
+  product(Ki, Ys, 1.0, nullptr, Rs, false);  // Rs = K^-1 Y
   __syncthreads();
-  for (int i = g; i < q; i += 8) {
-    double s = Ys[i * RM_COLS + c];
-    for (int l = 0; l < q; l++) s -= Km[l * ldk + i] * Rs[l * RM_COLS + c];
-    Es[i * RM_COLS + c] = s;
-  }
+  product(Km, Rs, -1.0, Ys, Es, false);  // Es = Y - K Rs
   __syncthreads();
-  for (int i = g; i < q; i += 8) {
-    double s = Rs[i * RM_COLS + c];
-    for (int l = 0; l < q; l++) s += Ki[l * ldk + i] * Es[l * RM_COLS + c];
-    if (j < a.n) a.Rm[(long long)i * a.ldy + j] = s;
-  }
+  product(Ki, Es, 1.0, Rs, a.Rm, true);  // Rm = Rs + K^-1 Es
+  RSTAMP(3);
 }
 
 // last stage K: all its equality rows are carried (no control): BT_K = E_K', count = e
@@ -1918,6 +1983,21 @@ __global__ void __launch_bounds__(256) k_st_bwd_small(BwdSmall a) {
   const int r = a.dyn[0], nl = a.dyn[1];
   const int *Rl = a.dyn + 2, *Ll = a.dyn + 2 + a.capn;
   double *nu = sm, *y0 = sm + a.capn + 1;
+  // K of order <= 64: this thread's 16 entries of column (tid & 63) of K^-1 and of K are requested before anything else
+  // (they come from HBM: the factorisation wrote them long ago) and the three products below run out of registers,
+  // four partial sums per entry meeting in LDS.  (Both are stored zero-padded to qmax and symmetric.)
+  const bool fastq = a.qmax <= 64 && nt == 256;
+  const int ci = tid & 63, part = tid >> 6;
+  double ki[16], km[16];
+  if (fastq) {
+#pragma unroll
+    for (int u = 0; u < 16; u++) {
+      const int j = part * 16 + u;
+      const bool ok = j < a.qmax && ci < a.qmax;
+      ki[u] = ok ? a.Kinv[(long long)j * a.ldq + ci] : 0.0;
+      km[u] = ok ? a.Kmat[(long long)j * a.ldq + ci] : 0.0;
+    }
+  }
   for (int i = tid; i < a.e; i += nt) nu[i] = a.r2[a.eq_rows[i]];
   // carried rows: beta+ + B+ f, one wavefront per row
   for (int li = tid >> 6; li < cn; li += nt >> 6) {
@@ -1931,6 +2011,29 @@ __global__ void __launch_bounds__(256) k_st_bwd_small(BwdSmall a) {
   for (int i = tid; i < q; i += nt) y0[i] = i < a.m ? a.gam[a.n + i] : nu[Rl[i - a.m]];
   __syncthreads();
   double *rh = y0 + a.qmax, *rs = rh + a.qmax;
+  if (fastq) {
+    double *P = rs + a.qmax;  // 4 x 64 partial sums
+    auto col_times = [&](const double(&kk)[16], const double *x) {
+      double s = 0.0;
+#pragma unroll
+      for (int u = 0; u < 16; u++) {
+        const int j = part * 16 + u;
+        s = fma(kk[u], j < q ? x[j] : 0.0, s);
+      }
+      P[part * 64 + ci] = s;
+    };
+    col_times(ki, y0);
+    __syncthreads();
+    if (tid < q) rh[tid] = (P[tid] + P[64 + tid]) + (P[128 + tid] + P[192 + tid]);
+    __syncthreads();
+    col_times(km, rh);
+    __syncthreads();
+    if (tid < q) rs[tid] = y0[tid] - ((P[tid] + P[64 + tid]) + (P[128 + tid] + P[192 + tid]));
+    __syncthreads();
+    col_times(ki, rs);
+    __syncthreads();
+    if (tid < a.qmax) a.rho[tid] = tid < q ? rh[tid] + ((P[tid] + P[64 + tid]) + (P[128 + tid] + P[192 + tid])) : 0.0;
+  } else {
   for (int i = tid; i < q; i += nt) {
     double s = 0.0;  // K^-1 and K are stored symmetric: column i, so that neighbouring threads read neighbouring words
     for (int j = 0; j < q; j++) s += a.Kinv[(long long)j * a.ldq + i] * y0[j];
@@ -1950,6 +2053,7 @@ __global__ void __launch_bounds__(256) k_st_bwd_small(BwdSmall a) {
       s += rh[i];
     }
     a.rho[i] = s;
+  }
   }
   for (int li = tid; li < a.cap; li += nt) {
     double s = 0.0;

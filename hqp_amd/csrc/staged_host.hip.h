@@ -727,7 +727,7 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     stg::BwdSmall ba{nn, mm, np, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], d.eq_rows.p + P.eq_ptr[k], v.r2,
                      P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr, sn.beta, sn.BT, P.ldb[k + 1], f, gam, sp.Kinv, sp.Kmat, P.ldq[k], sp.T, P.ldt[k],
                      sp.dyn, sp.rho, sp.beta};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_st_bwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 3 * P.qmax[k] + 4), s>>>(ba));
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_bwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 3 * P.qmax[k] + 4 + 256), s>>>(ba));
     // v_k = gam_x - Y' rho
     if ((e = st_gemv_cols(h, d, sp.Y, P.ldy[k], P.qmax[k], nn, sp.rho, gam, -1.0, sp.v))) return e;
   }

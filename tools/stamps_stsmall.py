@@ -18,3 +18,4 @@ for rep in range(3):
     g = (C.c_int * 32)()
     if _lib.lib().hqpkkt_debug_gj_stamps(g) == 0:
         print("   step 10 of the LDS / global inverse (cycles): argmax, exchange, pivot row/col, sweep:", np.diff(np.array(g[0:5], dtype=np.int64)).tolist())
+        print("   k_st_rm, workgroup 0 (cycles): K^-1 and K to LDS, Y (and carried rows), three products, store:", np.diff(np.array(g[16:20], dtype=np.int64)).tolist())
