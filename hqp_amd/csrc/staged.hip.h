@@ -154,56 +154,46 @@ struct GemmTile {
     // a 16-byte load is inside its row when its first column is < ld (ld even)
     const long long acol = (i0 + ca < g.lda) ? i0 + ca : 0;
     const long long bcol = (j0 + cb < g.ldb) ? j0 + cb : 0;
-    double2_t sa[LA], sb[LB];
-    // The loads of a slab are issued BEFORE the multiplications of the previous one and consumed
-    // (masked for k >= K, stored to LDS) AFTER them: nothing between the two touches the staging
-    // registers, so that the wait for the loads comes behind the MFMA block.
-    const double *pa = g.A + (long long)(s0 * BK + ra) * g.lda + acol;
-    const double *pb = g.B + (long long)(s0 * BK + rb) * g.ldb + bcol;
-    const long long stepa = (long long)RA * g.lda, stepb = (long long)RB * g.ldb;
-    auto gload = [&](int k0) {
-      if (k0 + BK <= g.K) {  // whole slab inside the operands (uniform)
-#pragma unroll
-        for (int p = 0; p < LA; p++) sa[p] = *(const double2_t *)(pa + p * stepa);
-#pragma unroll
-        for (int p = 0; p < LB; p++) sb[p] = *(const double2_t *)(pb + p * stepb);
-      } else {  // last, partial slab: rows beyond K are read from row K-1 and zeroed in lstore
-#pragma unroll
-        for (int p = 0; p < LA; p++) {
-          const int k = k0 + ra + p * RA, kc = k < g.K ? k : g.K - 1;
-          sa[p] = *(const double2_t *)(g.A + (long long)kc * g.lda + acol);
-        }
-#pragma unroll
-        for (int p = 0; p < LB; p++) {
-          const int k = k0 + rb + p * RB, kc = k < g.K ? k : g.K - 1;
-          sb[p] = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
-        }
-      }
-      pa += (long long)BK * g.lda, pb += (long long)BK * g.ldb;
-    };
-    auto lstore = [&](int buf, int k0) {
-      const bool tail = k0 + BK > g.K;
+    // D register sets: the loads of slab t + D are issued before the multiplications of slab t and consumed (masked
+    // for k >= K, stored to LDS) after those of slab t + D - 1.  With 64 x 64 tiles a slab is 16 multiplications per
+    // wavefront (0.4 us) and a load from L2 takes 1.4: one set (round 2) left the loop waiting for its loads - 1.44 us
+    // per slab (profiles: 272 tiles of a 1000-state stage in 91 us); the 128 x 128 form of this loop keeps one set
+    // (its slab is four times the work, its sets four times the registers).
+    constexpr int D = (BM == 64 && BN == 64) ? 4 : 1;
+    double2_t sa[D][LA], sb[D][LB];
+    // (no branch anywhere in the loop: rows k >= K are read from row K - 1 and zeroed on their way to LDS, slabs
+    // behind the last one are the last one again and go to a buffer nobody reads - with branches between the loads and
+    // their use the compiler waits for ALL loads in flight at every join, also those just issued)
+    const int last = s1 - 1;
+    auto gload = [&](double2_t(&xa)[LA], double2_t(&xb)[LB], int slab) {
+      const int k0 = (slab < last ? slab : last) * BK;
 #pragma unroll
       for (int p = 0; p < LA; p++) {
-        double2_t v = sa[p];
-        if (tail && k0 + ra + p * RA >= g.K) v = (double2_t){0.0, 0.0};
+        const int k = k0 + ra + p * RA, kc = k < g.K ? k : g.K - 1;
+        xa[p] = *(const double2_t *)(g.A + (long long)kc * g.lda + acol);
+      }
+#pragma unroll
+      for (int p = 0; p < LB; p++) {
+        const int k = k0 + rb + p * RB, kc = k < g.K ? k : g.K - 1;
+        xb[p] = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
+      }
+    };
+    auto lstore = [&](int buf, const double2_t(&xa)[LA], const double2_t(&xb)[LB], int slab) {
+      const int k0 = (slab < last ? slab : last) * BK;
+#pragma unroll
+      for (int p = 0; p < LA; p++) {
+        double2_t v = xa[p];
+        if (k0 + ra + p * RA >= g.K) v = (double2_t){0.0, 0.0};
         *(double2_t *)(As + (buf * BK + ra + p * RA) * LDA + ca) = v;
       }
 #pragma unroll
       for (int p = 0; p < LB; p++) {
-        double2_t v = sb[p];
-        if (tail && k0 + rb + p * RB >= g.K) v = (double2_t){0.0, 0.0};
+        double2_t v = xb[p];
+        if (k0 + rb + p * RB >= g.K) v = (double2_t){0.0, 0.0};
         *(double2_t *)(Bs + (buf * BK + rb + p * RB) * LDB + cb) = v;
       }
     };
-    if (s1 > s0) {
-      gload(s0 * BK);
-      lstore(0, s0 * BK);
-    }
-    __syncthreads();
-    for (int s = s0; s < s1; s++) {
-      const int buf = (s - s0) & 1;
-      if (s + 1 < s1) gload((s + 1) * BK);
+    auto multiply = [&](int buf) {
       const double *Ab = As + buf * BK * LDA + wm * WM + lr;
       const double *Bb = Bs + buf * BK * LDB + wn * WN + lr;
 #pragma unroll
@@ -218,8 +208,32 @@ struct GemmTile {
 #pragma unroll
           for (int y = 0; y < TN; y++) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
       }
-      if (s + 1 < s1) lstore(buf ^ 1, (s + 1) * BK);
-      __syncthreads();
+    };
+    if (s1 <= s0) return;  // (uniform)
+#pragma unroll
+    for (int d = 0; d < D; d++) gload(sa[d], sb[d], s0 + d);
+    lstore(0, sa[0], sb[0], s0);
+    __syncthreads();
+    // whole groups of D slabs (D even or 1: the LDS buffer of a step is its position in the group, mod 2), straight-line
+    int s = s0;
+    for (; s + D <= s1; s += D) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int buf = d & 1;
+        gload(sa[d], sb[d], s + d + D);  // set d: its slab went to LDS one step ago
+        multiply(D == 1 ? ((s - s0) & 1) : buf);
+        lstore(D == 1 ? (((s - s0) & 1) ^ 1) : (buf ^ 1), sa[(d + 1) % D], sb[(d + 1) % D], s + d + 1);
+        __syncthreads();
+      }
+    }
+    // the remaining 0 .. D - 1 slabs one by one (set (s - s0) % D holds slab s + 1 ... the sets rotate as above)
+#pragma unroll
+    for (int d = 0; d < D - 1; d++) {
+      if (s + d < s1) {  // (uniform)
+        multiply((D == 1 ? (s + d - s0) : d) & 1);
+        if (s + d + 1 < s1) lstore(((D == 1 ? (s + d - s0) : d) & 1) ^ 1, sa[(d + 1) % D], sb[(d + 1) % D], s + d + 1);
+        __syncthreads();
+      }
     }
   }
 
@@ -582,9 +596,8 @@ static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
   }
   return false;
 }
-template <bool DMA, int WGM = 2, int WGN = 2, int NBUF = 2>
+template <bool DMA, int WGM = 2, int WGN = 2, int NBUF = 2, int BM = 128, int BN = 128>
 __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WGM * WGN / 2) k_dgemm_tn_sk(GemmArgs g, SplitPlan sk) {
-  constexpr int BM = 128, BN = 128;
   using T = GemmTile<BM, BN, WGM, WGN>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // tiles + one word for the arrival order
   double *As = lds, *Bs = lds + NBUF * T::BK * T::LDA;
@@ -727,6 +740,12 @@ static inline void gemm_launch_split(int variant, int grid, hipStream_t s, const
   else
     k_dgemm_tn_sk<false><<<grid, 256, gemm_sk_lds_bytes(), s>>>(g, sk);
 }
+// 64 x 64 tiles (register-staged loop) with their k ranges cut: products of a few hundred small tiles, where one
+// workgroup per CU leaves the matrix pipe two thirds idle (a stage of ~1000 states: 272 tiles of 63 slabs, 91 us)
+static const int GEMM_SPLIT64_WGS_PER_CU = 4;
+static inline void gemm_launch_split64(int grid, hipStream_t s, const GemmArgs &g, const SplitPlan &sk) {
+  k_dgemm_tn_sk<false, 2, 2, 2, 64, 64><<<grid, 256, gemm_lds_bytes(64, 64) + 16, s>>>(g, sk);
+}
 static inline hipError_t gemm_set_attributes() {
   hipError_t e = hipSuccess;
   auto set = [&](const void *f, size_t bytes) {
@@ -737,6 +756,7 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn<128, 128, true>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<128, 128, true, 2, 4>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<64, 64>, gemm_lds_bytes(64, 64));
+  set((const void *)k_dgemm_tn_sk<false, 2, 2, 2, 64, 64>, gemm_lds_bytes(64, 64) + 16);
   set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true, 2, 4>, gemm_sk_lds_bytes());

@@ -52,6 +52,7 @@ struct StagedDev {
     return b->p;
   }
   size_t lds_small = 0, lds_small_big = 0, lds_init = 0, lds_x0 = 0;
+  long long sk_ws_elems = 0, sk_cnt_elems = 0;
   void release() {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
@@ -139,8 +140,27 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   }
   if (big)
     KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g, d ? d->cus : 0));
-  else
+  else {
+    // few small tiles of a deep product: cut the k ranges so that every CU holds several workgroups.  Measured (K = 100,
+    // nx = 700 / 1000 / 1500 / 2000): 27.0 / 27.6 / 42.4 / 73.5 ms per factorisation against 15.2 / 21.6 / 38.4 / 69.9 without -
+    // the loop was waiting for its loads, not for workgroups (GemmTile::accumulate now keeps four slabs in flight);
+    // an experiment behind HQPKKT_SPLIT64
+    static const bool no64 = getenv("HQPKKT_SPLIT64") == nullptr;
+    const long long nslab = (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK;
+    if (!no64 && d && allow_sk && d->sk_grid > 0 && d->cus > 0 && nslab >= 32 && tiles >= 16 &&
+        tiles < (long long)stg::GEMM_SPLIT64_WGS_PER_CU * d->cus * 3 / 4 && tiles + 4 <= d->sk_cnt_elems) {
+      const int grid = stg::GEMM_SPLIT64_WGS_PER_CU * d->cus;
+      stg::SplitPlan sk = stg::gemm_split_plan(tiles, nslab, grid);
+      const long long pieces = stg::gemm_split_plan_pieces(sk);
+      if (pieces > 0 && pieces * 64 * 64 <= d->sk_ws_elems) {
+        HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (tiles + 4), h->stream));
+        sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
+        KLAUNCH(h, cls, stg::gemm_launch_split64(grid, h->stream, g, sk));
+        return 0;
+      }
+    }
     KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
+  }
   return 0;
 }
 
@@ -355,7 +375,10 @@ static int staged_upload(hqpkkt_t *h) {
     d.sk_grid = 0, d.sk_tiles = (int)tmax;
     if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
       d.sk_grid = stg::gemm_wgs_per_cu(stg::gemm_variant_from_env()) * cus;
-      if ((e = d.sk_ws.alloc((size_t)std::max<long long>(pmax, 1) * 128 * 128)) || (e = d.sk_cnt.alloc(d.sk_tiles + 4))) return e;
+      // (the cut form of the 64 x 64 tiles: at most two phases of one unit per workgroup, up to 3/4 of its grid in tiles)
+      d.sk_ws_elems = std::max<long long>(std::max<long long>(pmax, 1) * 128 * 128, 2LL * stg::GEMM_SPLIT64_WGS_PER_CU * cus * 64 * 64);
+      d.sk_cnt_elems = std::max<long long>(d.sk_tiles, (long long)stg::GEMM_SPLIT64_WGS_PER_CU * cus) + 4;
+      if ((e = d.sk_ws.alloc((size_t)d.sk_ws_elems)) || (e = d.sk_cnt.alloc((size_t)d.sk_cnt_elems))) return e;
     }
   }
   // (measured on one MI355X at C4 size: 142 ms against 136 ms per 20 stages WITH the second stream - the
