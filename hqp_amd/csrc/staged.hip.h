@@ -363,8 +363,96 @@ struct GemmTile {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero rows behind the range: LDS is reused after this)
     __syncthreads();
   }
+  // ---- 64 x 64 tiles by LDS-DMA (products of a few hundred to a few thousand small tiles: stages of 500 .. 2700
+  // states).  A k-row of a 64-wide panel is HALF a wave-instruction of the DMA (64 lanes x 16 bytes = 1 KiB = two
+  // rows), and the DMA writes its 1 KiB contiguously: LDS rows are unpadded, 64 doubles.  What keeps the fragment reads
+  // free of bank conflicts instead of padding: the DMA takes a GLOBAL address per lane, so the odd k-rows are stored
+  // with their 16-column groups exchanged pairwise (column ^ 16) and read back the same way - lanes lk = 0, 1 (one half
+  // of a ds_read_b64) then cover all 64 banks.  Three buffers of 16 KB, counted waits as in slabs_dma3; wave w issues the
+  // row pairs w and w + 4 of both panels, one piece behind every fourth multiplication.  As / Bs: 3 x 16 x 64 doubles.
+  template <bool MASKED>
+  static __device__ __forceinline__ void slabs_dma64(const GemmArgs &g, const double *pa, const double *pb, const double *zr, int half,
+                                                     int wave, int wm, int wn, int lr, int lk, int s0, int s1, unsigned mask,
+                                                     double4_t (&acc)[TM][TN], double *As, double *Bs) {
+    static_assert(BM == 64 && BN == 64 && NW == 4 && BK == 16 && TM == 2 && TN == 2, "written for 2 x 2 waves of 32 x 32");
+    // piece p (0..3) of this wave for the slab at row k0: A pairs wave, wave + 4, then B pairs wave, wave + 4
+    auto dma = [&](int buf, int k0, int p) {
+      const int rp = wave + 4 * (p & 1), k = k0 + 2 * rp + half;  // this lane's row of the pair
+      if (p < 2)
+        glds16(k < g.K ? pa + (long long)k * g.lda : zr, As + (buf * BK + 2 * rp) * 64);
+      else
+        glds16(k < g.K ? pb + (long long)k * g.ldb : zr, Bs + (buf * BK + 2 * rp) * 64);
+    };
+    auto wait_all_but_newest_slab = [&]() { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+#pragma unroll
+    for (int p = 0; p < 4; p++) dma(0, s1 > s0 ? s0 * BK : g.K, p);
+#pragma unroll
+    for (int p = 0; p < 4; p++) dma(1, s0 + 1 < s1 ? (s0 + 1) * BK : g.K, p);
+    wait_all_but_newest_slab();
+    // fragment columns of this lane: rows k = 4 ks + lk, odd rows swizzled
+    const int sw = 16 * (lk & 1);
+    int ca[TM], cb[TN];
+#pragma unroll
+    for (int x = 0; x < TM; x++) ca[x] = (wm * WM + 16 * x + lr) ^ sw;
+#pragma unroll
+    for (int y = 0; y < TN; y++) cb[y] = (wn * WN + 16 * y + lr) ^ sw;
+    int buf = 0;
+    for (int s = s0; s < s1; s++) {
+      const int bnext = buf >= 1 ? buf - 1 : 2;  // (buf + 2) % 3
+      const int knext = s + 2 < s1 ? (s + 2) * BK : g.K;
+      const double *Ab = As + buf * BK * 64, *Bb = Bs + buf * BK * 64;
+#pragma unroll
+      for (int ks = 0; ks < BK / 4; ks++) {
+        double af[TM], bf[TN];
+#pragma unroll
+        for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * 64 + ca[x]];
+#pragma unroll
+        for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * 64 + cb[y]];
+#pragma unroll
+        for (int x = 0; x < TM; x++)
+#pragma unroll
+          for (int y = 0; y < TN; y++)
+            if (!MASKED || ((mask >> (x * TN + y)) & 1u)) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
+        dma(bnext, knext, ks);  // (four k-steps, four pieces)
+      }
+      wait_all_but_newest_slab();
+      buf = buf == 2 ? 0 : buf + 1;
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero rows behind the range: LDS is reused after this)
+    __syncthreads();
+  }
+  static __device__ __forceinline__ void accumulate_dma64(const GemmArgs &g, int i0, int j0, int s0, int s1,
+                                                          double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WGN, wn = wave % WGN;
+    const int lr = lane & 15, lk = lane >> 4;
+    // this lane's 16 bytes of a row pair: row `half` of the pair, LDS columns 2 (lane % 32), + 1; they hold the
+    // operand columns (2 (lane % 32)) ^ (16 half), + 1 (the exchange keeps pairs of columns together)
+    const int half = lane >> 5, col = (2 * (lane & 31)) ^ (16 * half);
+    const double *pa = g.A + ((i0 + col < g.lda) ? i0 + col : 0);
+    const double *pb = g.B + ((j0 + col < g.ldb) ? j0 + col : 0);
+    const double *zr = g.zeros + 2 * (lane & 31);
+    unsigned mask = 0;
+#pragma unroll
+    for (int x = 0; x < TM; x++)
+#pragma unroll
+      for (int y = 0; y < TN; y++) {
+        const int rb = wm * TM + x, cbk = wn * TN + y;  // 16 x 16 block of the tile
+        const bool want = i0 + 16 * rb < g.M && j0 + 16 * cbk < g.N && !(skip_upper && cbk > rb);
+        mask |= (want ? 1u : 0u) << (x * TN + y);
+      }
+    mask = __builtin_amdgcn_readfirstlane(mask);
+    if (mask == (1u << (TM * TN)) - 1u)
+      slabs_dma64<false>(g, pa, pb, zr, half, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+    else
+      slabs_dma64<true>(g, pa, pb, zr, half, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+  }
   static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
                                                         double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper = false, int nbuf = 2) {
+    if constexpr (BM == 64 && BN == 64) {
+      accumulate_dma64(g, i0, j0, s0, s1, acc, As, Bs, skip_upper);
+      return;
+    } else {
     static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
     static_assert((BK / NW) * NW == BK && TM * TN >= 2 * (BK / NW) && TM * TN <= 32,
                   "pieces are issued behind the multiplications of the first k-step");
@@ -395,6 +483,7 @@ struct GemmTile {
       slabs_dma<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
     else
       slabs_dma<true>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+    }
   }
 
   // `lds`: the workgroup's LDS (free after accumulate's last barrier), used to write the MIRROR image of an
@@ -475,7 +564,7 @@ template <int BM, int BN, bool DMA = false, int WGM = 2, int WGN = 2, int NBUF =
 __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WGM * WGN / 2) k_dgemm_tn(GemmArgs g) {
   using T = GemmTile<BM, BN, WGM, WGN>;
   extern __shared__ __attribute__((aligned(16))) double lds[];  // NBUF * BK * (LDA + LDB) doubles
-  double *As = lds, *Bs = lds + NBUF * T::BK * T::LDA;
+  double *As = lds, *Bs = lds + NBUF * T::BK * ((DMA && BM == 64) ? 64 : T::LDA);  // (the 64 x 64 DMA form: unpadded rows)
   int tm, tn;
   const unsigned long long t0 = g.stamps ? __builtin_amdgcn_s_memrealtime() : 0;
   T::tile_of(g, xcd_swizzle(blockIdx.x, gridDim.x), tm, tn);
@@ -746,6 +835,8 @@ static const int GEMM_SPLIT64_WGS_PER_CU = 4;
 static inline void gemm_launch_split64(int grid, hipStream_t s, const GemmArgs &g, const SplitPlan &sk) {
   k_dgemm_tn_sk<false, 2, 2, 2, 64, 64><<<grid, 256, gemm_lds_bytes(64, 64) + 16, s>>>(g, sk);
 }
+// LDS of the 64 x 64 LDS-DMA kernel: three buffers of two unpadded 16 x 64 panels (the mirrored epilogue needs 34 KB)
+static const size_t GEMM_DMA64_LDS = sizeof(double) * 3 * GEMM_BK * 128;
 static inline hipError_t gemm_set_attributes() {
   hipError_t e = hipSuccess;
   auto set = [&](const void *f, size_t bytes) {
@@ -756,6 +847,7 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn<128, 128, true>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<128, 128, true, 2, 4>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<64, 64>, gemm_lds_bytes(64, 64));
+  set((const void *)k_dgemm_tn<64, 64, true, 2, 2, 3>, GEMM_DMA64_LDS);
   set((const void *)k_dgemm_tn_sk<false, 2, 2, 2, 64, 64>, gemm_lds_bytes(64, 64) + 16);
   set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true>, gemm_sk_lds_bytes());

@@ -159,7 +159,16 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
         return 0;
       }
     }
-    KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
+    // The same tiles with their operands by LDS-DMA, three buffers, swizzled unpadded rows (accumulate_dma64): exact, and
+    // SLOWER than the register-staged loop with four slabs in flight (W of a 1000-state stage 96.7 against 81.4 us,
+    // G 63.5 against 48.6; K = 100: nx = 1000 / 2000 / 3000 factor in 22.4 / 73.1 / 165.0 ms against 20.0 / 68.9 / 160.2) - a
+    // workgroup alone on its CU idles the matrix pipe around every barrier whatever stages its operands.  Behind
+    // HQPKKT_DMA64.
+    static const bool no_dma64 = getenv("HQPKKT_DMA64") == nullptr;
+    if (!no_dma64 && d && g.zeros && d->gemm_variant != stg::GEMM_REG4 && g.K >= 4 * stg::GEMM_BK && (g.lda % 2) == 0 && (g.ldb % 2) == 0)
+      KLAUNCH(h, cls, (stg::k_dgemm_tn<64, 64, true, 2, 2, 3><<<(unsigned)tiles, 256, stg::GEMM_DMA64_LDS, h->stream>>>(g)));
+    else
+      KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
   }
   return 0;
 }
