@@ -159,7 +159,7 @@ struct GemmTile {
     // wavefront (0.4 us) and a load from L2 takes 1.4: one set (round 2) left the loop waiting for its loads - 1.44 us
     // per slab (profiles: 272 tiles of a 1000-state stage in 91 us); the 128 x 128 form of this loop keeps one set
     // (its slab is four times the work, its sets four times the registers).
-    constexpr int D = (BM == 64 && BN == 64) ? 4 : 1;
+    constexpr int D = (BM * BN <= 64 * 64) ? 4 : 1;
     double2_t sa[D][LA], sb[D][LB];
     // (no branch anywhere in the loop: rows k >= K are read from row K - 1 and zeroed on their way to LDS, slabs
     // behind the last one are the last one again and go to a buffer nobody reads - with branches between the loads and
@@ -835,6 +835,10 @@ static const int GEMM_SPLIT64_WGS_PER_CU = 4;
 static inline void gemm_launch_split64(int grid, hipStream_t s, const GemmArgs &g, const SplitPlan &sk) {
   k_dgemm_tn_sk<false, 2, 2, 2, 64, 64><<<grid, 256, gemm_lds_bytes(64, 64) + 16, s>>>(g, sk);
 }
+// the rule for 64 x 32 tiles (st_gemm, hqpkkt_debug_dgemm): a rectangular product of at most two 64 x 64 tiles per CU, deep
+static inline bool gemm_tiles_6432(int M, int N, int K, int lower, int mirror, int cus) {
+  return cus > 0 && !lower && !mirror && gemm_tiles(M, N, 64, 0) <= 2LL * cus && K >= 16 * GEMM_BK;
+}
 // LDS of the 64 x 64 LDS-DMA kernel: three buffers of two unpadded 16 x 64 panels (the mirrored epilogue needs 34 KB)
 static const size_t GEMM_DMA64_LDS = sizeof(double) * 3 * GEMM_BK * 128;
 static inline hipError_t gemm_set_attributes() {
@@ -847,6 +851,7 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn<128, 128, true>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<128, 128, true, 2, 4>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<64, 64>, gemm_lds_bytes(64, 64));
+  set((const void *)k_dgemm_tn<64, 32>, gemm_lds_bytes(64, 32));
   set((const void *)k_dgemm_tn<64, 64, true, 2, 2, 3>, GEMM_DMA64_LDS);
   set((const void *)k_dgemm_tn_sk<false, 2, 2, 2, 64, 64>, gemm_lds_bytes(64, 64) + 16);
   set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());

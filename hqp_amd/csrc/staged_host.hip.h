@@ -159,6 +159,14 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
         return 0;
       }
     }
+    // few tiles of a deep rectangular product (W of a stage of ~1000 states: 272): 64 x 32 tiles, so that a CU holds two
+    // workgroups and one multiplies while the other waits at its barrier: 81 -> 73 us (HQPKKT_NO_TILE6432: off)
+    static const bool t6432 = getenv("HQPKKT_NO_TILE6432") == nullptr;
+    if (t6432 && stg::gemm_tiles_6432(g.M, g.N, g.K, g.lower, g.mirror, d ? d->cus : 0)) {
+      const long long t2 = ((g.M + 63) / 64) * (long long)((g.N + 31) / 32);
+      KLAUNCH(h, cls, (stg::k_dgemm_tn<64, 32><<<(unsigned)t2, 256, stg::gemm_lds_bytes(64, 32), h->stream>>>(g)));
+      return 0;
+    }
     // The same tiles with their operands by LDS-DMA, three buffers, swizzled unpadded rows (accumulate_dma64): exact, and
     // SLOWER than the register-staged loop with four slabs in flight (W of a 1000-state stage 96.7 against 81.4 us,
     // G 63.5 against 48.6; K = 100: nx = 1000 / 2000 / 3000 factor in 22.4 / 73.1 / 165.0 ms against 20.0 / 68.9 / 160.2) - a

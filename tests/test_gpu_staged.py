@@ -365,7 +365,7 @@ def test_dgemm_kernel_against_exact_products(dma64, monkeypatch):
                                      (640, 520, 300, 0, 0), (700, 700, 129, 1, 1), (513, 1100, 1, 0, 0), (48, 2000, 48, 0, 0),
                                      # the 64 x 64 tiles at the shapes of a 1000-state stage, ragged ones, four slabs + 1 row
                                      (1000, 1050, 1000, 0, 0), (1050, 1050, 1000, 1, 0), (1000, 1000, 64, 1, 1), (333, 777, 65, 0, 0),
-                                     (1500, 1540, 1500, 0, 0)]:
+                                     (1500, 1540, 1500, 0, 0), (1000, 1050, 256, 0, 0), (130, 70, 300, 0, 0)]:  # (the last two: 64 x 32 tiles)
         ms, tf, err = ipmatrix.bench_dgemm(M, N, K, lower, mirror, reps=1)
         assert err <= 1e-14, (M, N, K, lower, mirror, err)
 
