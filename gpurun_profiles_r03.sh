@@ -17,6 +17,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt -- python3 bench.p
 cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/r03_kernel_stats.csv
 # other sizes of the same structure (K = 200), a stage with 200 controls at full width, round 1's headline workload
 for nx in 1000 2000 3000; do python tools/c4_bench.py 200 $nx 50 3 --profile 2>/dev/null | grep '^{' | tail -1 >> $O/r03_c4_sizes.jsonl; done
+# (the same without the per-launch events of --profile: the rates DESIGN.md quotes)
+for nx in 400 700 1000 1500 2000 2500 3000; do python tools/c4_bench.py 200 $nx 50 3 2>/dev/null | grep '^{' | tail -1 >> $O/r03_c4_sizes_plain.jsonl; done
+./tools/mid_trace.sh 1000 > $O/r03_stage_timeline_nx1000.txt 2>&1
 python tools/c4_bench.py 200 5000 100 2 2>/dev/null | grep '^{' | tail -1 > $O/r03_c4_nu100.json
 python tools/c4_bench.py 200 5000 200 2 2>/dev/null | grep '^{' | tail -1 > $O/r03_c4_nu200.json
 python tools/bigstage_time.py 2>&1 | grep -v amdgpu.ids > $O/r03_bigstage_time.txt
