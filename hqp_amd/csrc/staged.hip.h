@@ -1228,6 +1228,46 @@ __device__ int gj_inverse_reg_spd(double *a, int q, int ld, double *colv, double
   __syncthreads();
   return 0;
 }
+// The inverse of a matrix that is positive definite after its scaling, in place in LDS (order 65 .. 136, sixteen
+// wavefronts): pivots down the diagonal, no search - per step one broadcast of the pivot row / column and the sweep.
+// Returns 2 at the first pivot that is not safely positive; the matrix is then partly eliminated (the caller builds
+// it again and runs the search).
+__device__ int gj_inverse_spd(double *a, int q, int ld, double *colv, double *rowv) {
+  const int tid = threadIdx.x, nt = blockDim.x;
+  const int ty = tid >> 4, tx = tid & 15, RS = nt >> 4;
+  for (int s = 0; s < q; s++) {
+    const double piv = a[s * ld + s];
+    if (!(piv > 1e-10)) return 2;  // (uniform: every thread reads the same entry)
+    const double pinv = 1.0 / piv;
+    for (int c = tid; c < q; c += nt) {
+      colv[c] = (c == s) ? 0.0 : a[c * ld + s];
+      rowv[c] = (c == s ? 1.0 : a[s * ld + c]) * pinv;
+    }
+    __syncthreads();
+    for (int c = tid; c < q; c += nt) {
+      if (c != s) a[c * ld + s] = 0.0;
+      a[s * ld + c] = rowv[c];
+    }
+    __syncthreads();
+    for (int c0 = tx; c0 < q; c0 += 128) {
+      double rv[8];
+      int cc[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) cc[u] = min(c0 + 16 * u, q - 1), rv[u] = rowv[cc[u]];
+      for (int r = ty; r < q; r += RS) {
+        double x[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) x[u] = a[r * ld + cc[u]];
+        const double cr = colv[r];
+#pragma unroll
+        for (int u = 0; u < 8; u++)
+          if (c0 + 16 * u < q) a[r * ld + c0 + 16 * u] = fma(-rv[u], cr, x[u]);
+      }
+    }
+    __syncthreads();
+  }
+  return 0;
+}
 // dispatch: registers up to order 64 (the register forms are laid out for 256 threads), LDS / global memory above
 template <int NT, bool BIG = (NT != 256)>
 __device__ int gj_inverse_any(double *a, int q, int ld, int *ip, int *ir, int *ic, double *colv, double *rowv, ArgMax *red,
@@ -1356,7 +1396,7 @@ struct SmallArgs {
   int *status;          // set to 4 (E_SING) on a singular K
   double *scratch;      // null: the matrices of (A) and (B) live in LDS; else in this global area (stages with hundreds of
                         // controls / carried rows: StagedPlan::big) and LDS holds the flags and vectors only
-  int mode;             // global-memory form only.  0: everything; 1: (A) and the scaled K, no inverse (the blocked
+  int mode;             // (LDS form: 100 = test hook, see k_st_small)  global-memory form:  0: everything; 1: (A) and the scaled K, no inverse (the blocked
                         // elimination k_blk_* follows); 2: the inverse by this kernel only if the blocked one gave up
 };
 // layout of SmallArgs::scratch in the global-memory form (qmax = SmallArgs::qmax, ldk = up8(qmax)):
@@ -1571,7 +1611,23 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_small(SmallArgs a) {  // (o
     }
     }
     SSTAMP(4);
-    const int bad = gj_inverse_any<NT, BIG>(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
+    int bad = -1;
+    if constexpr (NT == 1024 && !BIG) {
+      if (r == 0) {  // no consumed constraint rows: K = G_uu, positive definite unless the problem is not convex in u
+        bad = gj_inverse_spd(Km, q, ld, colv, rowv);
+        if (a.mode == 100) bad = 2;  // (test hook, HQPKKT_SPD_TEST_FAIL: the way back from a pivot that was refused)
+        if (bad) {  // (uniform) scaled again from the copy, then with the search
+          __syncthreads();
+          for (int e = tid; e < q * q; e += nt) {
+            const int i = e / q, j = e - i * q;
+            Km[i * ld + j] = a.Kmat[(long long)i * a.ldq + j] * dsc[i] * dsc[j];
+          }
+          __syncthreads();
+          bad = -1;
+        }
+      }
+    }
+    if (bad < 0) bad = gj_inverse_any<NT, BIG>(Km, q, ld, ip, ir, ic, colv, rowv, red, r == 0);
     if (bad && tid == 0) atomicExch(a.status, 4);
     __syncthreads();
     SSTAMP(5);

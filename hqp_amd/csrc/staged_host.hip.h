@@ -584,8 +584,11 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
                       P.big[k] ? d.misc.p + P.oScr : nullptr};
     if (P.big[k]) {
       if ((e = st_small_big(h, d, sa, !two))) return e;
-    } else if (P.qmax[k] > 64)
+    } else if (P.qmax[k] > 64) {
+      static const bool spd_test_fail = getenv("HQPKKT_SPD_TEST_FAIL") != nullptr;
+      if (spd_test_fail) sa.mode = 100;
       KLAUNCH(h, KC_ST_SMALL, (stg::k_st_small<1024, false><<<1, 1024, d.lds_small, h->stream>>>(sa)));
+    }
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, ldg, nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], q, sp.T, P.ldt[k], sp.dyn, sp.Y, ldy, sp.BT, P.ldb[k]};
@@ -705,8 +708,11 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
                       P.big[k] ? d.misc.p + P.oScr : nullptr};
     if (P.big[k]) {
       if ((e = st_small_big(h, d, sa, !ovl))) return e;
-    } else if (P.qmax[k] > 64)
+    } else if (P.qmax[k] > 64) {
+      static const bool spd_test_fail = getenv("HQPKKT_SPD_TEST_FAIL") != nullptr;
+      if (spd_test_fail) sa.mode = 100;
       KLAUNCH(h, KC_ST_SMALL, (stg::k_st_small<1024, false><<<1, 1024, d.lds_small, h->stream>>>(sa)));
+    }
     else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<256><<<1, 256, d.lds_small, h->stream>>>(sa));
     stg::WideArgs wa{G, P.ldg[k], nn, mm, sp.N, P.ldn[k], P.capn[k], P.cap[k], P.qmax[k], sp.T, P.ldt[k], sp.dyn,

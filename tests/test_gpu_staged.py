@@ -288,6 +288,27 @@ def test_random_stages_with_many_controls_against_the_tree_engine(seed):
     assert S.debug(28)[1] == 0, tag  # (the blocked form, where it ran, did not have to fall back)
 
 
+def test_refused_diagonal_pivot_goes_back_to_the_search():
+    """K of order 65 .. 136 without consumed constraint rows is inverted down its diagonal, no search (gj_inverse_spd);
+    a pivot that is not safely positive sends the stage back: K scaled again from its copy, then the elimination with
+    complete pivoting.  HQPKKT_SPD_TEST_FAIL refuses after the whole elimination has run - the worst state to come back
+    from - and the solution must be the one of the tree engine."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from hqp_amd import problems, ipmatrix
+        from common import new_d, rel_err
+        prog = problems.lq_docp(3, 200, 100, seed=2); st = problems.ip_state(prog, 6, 1.0)
+        out = []
+        for M in (ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()):
+            M.init(prog); M.factor(prog, st[0], st[1]); d = new_d(prog); res = M.solve(prog, *st, *d); out.append((d, res))
+        assert out[0][1] <= 1e-10 and rel_err(out[0][0], out[1][0]) <= 1e-8, (out[0][1], rel_err(out[0][0], out[1][0]))
+        print("OK")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-c", code], env=dict(os.environ, HQPKKT_SPD_TEST_FAIL="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
 def test_blocked_elimination_falls_back_to_the_pivoted_one(monkeypatch):
     """The device-side decision behind the blocked sweep: with a tolerance no result can meet (HQPKKT_BLOCK_GJ_TOL < 0)
     every stage's check fails, the one-workgroup elimination with the search over the whole matrix runs instead, and the
