@@ -1686,7 +1686,10 @@ __global__ void __launch_bounds__(256) k_blk_pivot(BlkArgs a) {
   }
   am = block_argmax(am, red);
   __syncthreads();
-  const int bad = gj_inverse_reg<4>(A, b, 65, ip, pcr, colv, rowv, red);
+  // (a positive definite block - the control Hessian's blocks and their Schur complements - down its diagonal first;
+  // the register form leaves A untouched when it refuses a pivot, the search takes over)
+  int bad = gj_inverse_reg_spd<4>(A, b, 65, colv, rowv);
+  if (bad) bad = gj_inverse_reg<4>(A, b, 65, ip, pcr, colv, rowv, red);
   ArgMax pm{0.0, 0};
   for (int e = tid; e < 64 * 64; e += 256) {
     const int r = e >> 6, c = e & 63;
