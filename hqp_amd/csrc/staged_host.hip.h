@@ -30,6 +30,7 @@ struct StagedDev {
   hipStream_t stream2 = nullptr;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
   bool overlap = false;
+  int overlap_mode = 0;  // 0 never, 1 every stage, 2 stages of 1280 .. 4096 states
   // order of the tiles of a lower-triangular product with T tile rows (GemmArgs::tile_map), by T
   std::vector<std::pair<int, DBuf<int> *>> tri_maps;
   const int *tri_map(int T, bool create = false) {
@@ -398,15 +399,24 @@ static int staged_upload(hqpkkt_t *h) {
       if ((e = d.sk_ws.alloc((size_t)d.sk_ws_elems)) || (e = d.sk_cnt.alloc((size_t)d.sk_cnt_elems))) return e;
     }
   }
-  // (measured on one MI355X at C4 size: 142 ms against 136 ms per 20 stages WITH the second stream - the
-  // separate product for the control rows of G and the contention cost more than the hidden chain; so it is
-  // off unless HQPKKT_OVERLAP is set.  When sharded the separate product exists anyway.)
-  if (!d.stream2 && (getenv("HQPKKT_OVERLAP") || P.sharded)) {
-    HIPCHK(hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking));
-    HIPCHK(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
-    HIPCHK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
+  // The control-sized chain of a stage on a second stream beside its large product G_xx.  Measured on one MI355X (same
+  // box, tools/c4_bench.py): stages of 1500 / 2000 / 2500 / 3000 states + 2.7 / 2.5 / 3.5 / 2.7 %, 5000 states - 1.1 % (the
+  // separate skinny product for the control rows of G and the contention cost more than the hidden chain), 1000 states
+  // - 13 %.  So: on for stages of 1280 .. 4096 states; HQPKKT_OVERLAP=1 everywhere, =0 nowhere.  When sharded the
+  // separate product exists anyway (staged_stage_sharded).
+  {
+    const char *ov = getenv("HQPKKT_OVERLAP");
+    d.overlap_mode = ov ? (atoi(ov) != 0 ? 1 : 0) : 2;  // 2: by stage width
+    bool any = d.overlap_mode == 1 || P.sharded;
+    if (d.overlap_mode == 2)
+      for (int k = 0; k < P.K; k++) any = any || (P.nk[k] >= 1280 && P.nk[k] <= 4096);
+    if (!d.stream2 && any) {
+      HIPCHK(hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking));
+      HIPCHK(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
+      HIPCHK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
+    }
+    d.overlap = d.stream2 != nullptr && d.overlap_mode != 0;
   }
-  d.overlap = d.stream2 != nullptr && getenv("HQPKKT_OVERLAP") != nullptr;
   if (P.sharded) {
     // (exact strip sizes behind the stream-ordered transport, slots padded to the largest strip behind the callback)
     const bool exact = h->xchg_sfn != nullptr;
@@ -662,7 +672,7 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     const long long ldf = P.ldf[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1];
     // The control-sized chain of the stage on the second stream, beside the large product G_xx (needs the
     // control columns to start at an even column: 16-byte loads of W + n)
-    const bool ovl = d.overlap && mm > 0 && (nn % 2 == 0);
+    const bool ovl = d.overlap && mm > 0 && (nn % 2 == 0) && (d.overlap_mode == 1 || (nn >= 1280 && nn <= 4096));
     hipStream_t sA = h->stream, sB = ovl ? d.stream2 : h->stream;
     struct StreamGuard {  // launches go to h->stream: back to the first stream on every way out
       hqpkkt_t *h;
