@@ -768,6 +768,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WG
       finish = *s_old == (unsigned)(pieces - 1);
       if (finish) {
         if (threadIdx.x == 0) {
+          sk.cnt[t] = 0;  // (every piece of the tile has arrived: the counter is ready for the next launch - no memset between launches)
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         }

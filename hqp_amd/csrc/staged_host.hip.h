@@ -118,8 +118,8 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
       if (tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
     }
     if (d->zeros.p) g.zeros = d->zeros.p;
-    HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
     stg::SplitPlan sk = stg::gemm_split_plan(t128, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->cus);
+    if (sk.dynamic) HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));  // (the queue's head)
     sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
     KLAUNCH(h, cls, stg::gemm_launch_split(stg::GEMM_DMA8X3, d->cus, h->stream, g, sk));
     return 0;
@@ -133,8 +133,9 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   if (d && d->zeros.p) g.zeros = d->zeros.p;
   if (split && tiles <= d->sk_tiles) {
     // tile count that does not fill the chip evenly: whole rounds, then the k ranges of the rest cut (k_dgemm_tn_sk)
-    HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));
+    // (the arrival counters are zero between launches: the last arriver of a tile resets its counter)
     stg::SplitPlan sk = stg::gemm_split_plan(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid);
+    if (sk.dynamic) HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));  // (the queue's head)
     sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
     KLAUNCH(h, cls, stg::gemm_launch_split(d->gemm_variant, d->sk_grid, h->stream, g, sk));
     return 0;
@@ -154,7 +155,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
       stg::SplitPlan sk = stg::gemm_split_plan(tiles, nslab, grid);
       const long long pieces = stg::gemm_split_plan_pieces(sk);
       if (pieces > 0 && pieces * 64 * 64 <= d->sk_ws_elems) {
-        HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (tiles + 4), h->stream));
+        if (sk.dynamic) HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (tiles + 4), h->stream));
         sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
         KLAUNCH(h, cls, stg::gemm_launch_split64(grid, h->stream, g, sk));
         return 0;
@@ -397,6 +398,7 @@ static int staged_upload(hqpkkt_t *h) {
       d.sk_ws_elems = std::max<long long>(std::max<long long>(pmax, 1) * 128 * 128, 2LL * stg::GEMM_SPLIT64_WGS_PER_CU * cus * 64 * 64);
       d.sk_cnt_elems = std::max<long long>(d.sk_tiles, (long long)stg::GEMM_SPLIT64_WGS_PER_CU * cus) + 4;
       if ((e = d.sk_ws.alloc((size_t)d.sk_ws_elems)) || (e = d.sk_cnt.alloc((size_t)d.sk_cnt_elems))) return e;
+      HIPCHK(hipMemset(d.sk_cnt.p, 0, sizeof(unsigned) * (size_t)d.sk_cnt_elems));
     }
   }
   // The control-sized chain of a stage on a second stream beside its large product G_xx.  Measured on one MI355X (same
