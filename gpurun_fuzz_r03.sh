@@ -9,4 +9,6 @@ echo "## FUZZ_ORDERING=1 tools/fuzz.py 3000" >> $F
 FUZZ_ORDERING=1 python tools/fuzz.py 3000 2>/dev/null | grep -v amdgpu.ids | tail -8 >> $F
 echo "## tools/fuzz_ip.py, 6000 QPs in chunks of 400 (device loops against the reference's solvers)" >> $F
 for s0 in $(seq 0 400 5600); do python tools/fuzz_ip.py 400 $s0 2>/dev/null | grep -v amdgpu.ids | tail -4 >> $F; done
+echo "## tools/fuzz_bigstage.py, 1000 QPs in chunks of 100 (stages of 10 ... 300 controls against the tree engine)" >> $F
+for s0 in $(seq 0 100 900); do python tools/fuzz_bigstage.py 100 $s0 2>/dev/null | grep -v amdgpu.ids | tail -6 >> $F; done
 tail -5 $F
