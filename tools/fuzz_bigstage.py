@@ -3,7 +3,7 @@
 fixed / free initial state, w/z spreads - K of order <= 64 in registers, 65 ... 136 in LDS (diagonal-first or with the
 search), beyond that the blocked elimination - against the tree engine (Hqp_IpLQDOCPFull) on the same QP: residual of
 the refined solve <= 1e-10, same solution to 1e-8; the blocked elimination must not have fallen back.
-Usage: python tools/fuzz_bigstage.py [cases] [seed0]"""
+Usage: [FUZZ_LARGE=1] python tools/fuzz_bigstage.py [cases] [seed0]"""
 import os
 import sys
 import time
@@ -18,9 +18,10 @@ from common import new_d, rel_err
 
 def make_case(case):
     rng = np.random.default_rng(77000 + case)
-    nu = int(rng.choice([rng.integers(10, 65), rng.integers(65, 137), rng.integers(137, 301)]))
-    nx = int(rng.integers(20, 260))
-    K = int(rng.integers(2, 5))
+    large = bool(os.environ.get("FUZZ_LARGE"))  # up to the engine's limits: 512 controls, x_0 systems of ~1000
+    nu = int(rng.choice([rng.integers(10, 65), rng.integers(65, 137), rng.integers(137, 513 if large else 301)]))
+    nx = int(rng.integers(20, 900 if large else 260))
+    K = int(rng.integers(2, 4 if large else 5))
     path_eq = int(rng.integers(1, max(2, min(nu, 70)))) if rng.random() < 0.6 else 0
     final_eq = int(rng.integers(1, max(2, min(nx, 60)))) if rng.random() < 0.5 else 0
     x0_fixed = bool(rng.random() < 0.7)
