@@ -847,10 +847,20 @@ static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, 
   int nzmax = 1, npmax = 1;
   for (int k = 0; k < P.K; k++) nzmax = std::max(nzmax, P.nk[k] + P.mk[k]), npmax = std::max(npmax, P.nk[k + 1]);
   nzmax = std::max(nzmax, P.nk[P.K]);
-  KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_ax<<<dim3(std::min((npmax + 3) / 4, 2048), P.K), 256, 0, h->stream>>>(d.dyn_desc.p, d.F.p, v.dx,
-                                                                                                        d.dyn_x2.p));
-  KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_aty<<<dim3((nzmax + 255) / 256, P.K + 1), 256, 0, h->stream>>>(d.dyn_desc.p, d.F.p, v.dy,
-                                                                                                 d.dyn_x1.p));
+  static const bool two_passes = getenv("HQPKKT_RESIDUAL_TWO_PASSES") != nullptr;
+  const int nbc = (nzmax + 255) / 256;
+  if (!two_passes && d.dyn_part.p && d.dyn_part_cols == nbc) {
+    // one pass over F for both products (k_st_dyn_both), then the row sums' column blocks
+    KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_both<<<dim3(nbc, P.K + 1), 256, 0, h->stream>>>(d.dyn_desc.p, d.F.p, v.dx, v.dy, d.dyn_x1.p,
+                                                                                        d.dyn_part.p, nbc));
+    KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_ax_finish<<<dim3((npmax + 255) / 256, P.K), 256, 0, h->stream>>>(d.dyn_desc.p, d.dyn_part.p, nbc,
+                                                                                                     v.dx, d.dyn_x2.p));
+  } else {
+    KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_ax<<<dim3(std::min((npmax + 3) / 4, 2048), P.K), 256, 0, h->stream>>>(d.dyn_desc.p, d.F.p, v.dx,
+                                                                                                          d.dyn_x2.p));
+    KLAUNCH(h, KC_RESIDUAL, stg::k_st_dyn_aty<<<dim3((nzmax + 255) / 256, P.K + 1), 256, 0, h->stream>>>(d.dyn_desc.p, d.F.p, v.dy,
+                                                                                                   d.dyn_x1.p));
+  }
   *x1 = d.dyn_x1.p, *x2 = d.dyn_x2.p, *ndyn = P.ndyn;
   return 0;
 }

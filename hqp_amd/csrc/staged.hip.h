@@ -2443,6 +2443,84 @@ __global__ void __launch_bounds__(256) k_st_dyn_ax(const DynDesc *__restrict__ d
 }
 // out1[c] = sum_li F_k[li][lc] dy[row0 + li] - dy[row of x_k's dynamics equation]   (c in stage k;
 // the last stage has no F: np = 0)
+// Both products of residuum() with the dense dynamics rows in ONE pass over the F blocks (two passes: 80 GB at the
+// headline size, 14.5 ms): workgroup (bx, k) takes 256 columns of stage k's block, thread = column.  Down the rows it
+// accumulates its column of A_dyn' dy; the row sums of A_dyn dx over the workgroup's 256 columns go, 64 rows at a time,
+// through a wavefront sum and LDS into `part` (one value per row and column block); k_st_dyn_ax_finish adds the
+// column blocks in their order and the -x_{k+1} of the dynamics rows.
+__global__ void __launch_bounds__(256) k_st_dyn_both(const DynDesc *__restrict__ desc, const double *__restrict__ F,
+                                                     const double *__restrict__ dx, const double *__restrict__ dy,
+                                                     double *__restrict__ out1, double *__restrict__ part, int nblk_cols) {
+  // wavefront w takes the rows w, w + 4, ... of the block; lane l the columns l, l + 64, l + 128, l + 192 of the
+  // workgroup's 256: a row's sum over those columns is ONE wavefront sum (eight rows' sums side by side), a column's
+  // sum over the rows meets the other three wavefronts' in LDS at the end
+  __shared__ double cs[4][256];
+  const DynDesc d = desc[blockIdx.y];
+  const int ncols = d.np > 0 ? d.nz : d.ncur;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c0 = blockIdx.x * 256;
+  if (c0 >= ncols) return;  // (uniform)
+  bool in[4];
+  double xj[4], s[4];
+  const double *fc[4];
+#pragma unroll
+  for (int g = 0; g < 4; g++) {
+    const int lc = c0 + lane + 64 * g;
+    in[g] = lc < ncols;
+    xj[g] = (in[g] && lc < d.nz) ? dx[d.col0 + lc] : 0.0;
+    fc[g] = F + d.oF + (in[g] ? lc : 0);
+    s[g] = 0.0;
+  }
+  for (int li0 = wave; li0 < d.np; li0 += 32) {  // eight rows of this wavefront per trip: li0, li0 + 4, ...
+    double v[8][4], p[8];
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int li = li0 + 4 * u;
+#pragma unroll
+      for (int g = 0; g < 4; g++) v[u][g] = (in[g] && li < d.np) ? fc[g][(long long)li * d.ldf] : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; u++) {
+      const int li = li0 + 4 * u;
+      const double yv = li < d.np ? dy[d.row0 + li] : 0.0;
+      p[u] = 0.0;
+#pragma unroll
+      for (int g = 0; g < 4; g++) {
+        s[g] = fma(v[u][g], yv, s[g]);
+        p[u] = fma(v[u][g], xj[g], p[u]);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1)
+#pragma unroll
+      for (int u = 0; u < 8; u++) p[u] += __shfl_xor(p[u], o);
+    if (lane == 0) {
+#pragma unroll
+      for (int u = 0; u < 8; u++)
+        if (li0 + 4 * u < d.np) part[(long long)(d.row0 + li0 + 4 * u) * nblk_cols + blockIdx.x] = p[u];
+    }
+  }
+#pragma unroll
+  for (int g = 0; g < 4; g++) cs[wave][lane + 64 * g] = s[g];
+  __syncthreads();
+  const int lc = c0 + tid;
+  if (lc < ncols) {
+    double t = (cs[0][tid] + cs[1][tid]) + (cs[2][tid] + cs[3][tid]);
+    // x_k is the state the previous stage's dynamics produce: -1.0 in that row
+    if (blockIdx.y > 0 && lc < d.ncur) t -= dy[d.row0 - d.ncur + lc];
+    out1[d.col0 + lc] = t;
+  }
+}
+__global__ void k_st_dyn_ax_finish(const DynDesc *__restrict__ desc, const double *__restrict__ part, int nblk_cols,
+                                   const double *__restrict__ dx, double *__restrict__ out2) {
+  const DynDesc d = desc[blockIdx.y];
+  const int li = blockIdx.x * blockDim.x + threadIdx.x;
+  if (li >= d.np) return;
+  const int nb = (d.nz + 255) / 256;
+  double s = 0.0;
+  for (int b = 0; b < nb; b++) s += part[(long long)(d.row0 + li) * nblk_cols + b];
+  out2[d.row0 + li] = s - dx[d.col0 + d.nz + li];
+}
 __global__ void __launch_bounds__(256) k_st_dyn_aty(const DynDesc *__restrict__ desc, const double *__restrict__ F,
                                                     const double *__restrict__ dy, double *__restrict__ out1) {
   const DynDesc d = desc[blockIdx.y];

@@ -12,6 +12,8 @@ struct StagedDev {
   DBuf<stg::HTerm> h_terms;
   DBuf<stg::DynDesc> dyn_desc;  // dense dynamics: per stage (K+1) what k_st_dyn_ax / _aty need
   DBuf<double> dyn_x1, dyn_x2;  // A_dyn' dy (n), A_dyn dx (ndyn)
+  DBuf<double> dyn_part;        // row sums of A_dyn dx per block of 256 columns (k_st_dyn_both): ndyn x dyn_part_cols
+  int dyn_part_cols = 0;
   double *hblk[2] = {nullptr, nullptr};  // pinned staging of one stage block each (hqpkkt_stage_staging)
   long long hblk_elems = 0;
   hipEvent_t hblk_ev[2] = {nullptr, nullptr};
@@ -58,7 +60,7 @@ struct StagedDev {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
-    dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
+    dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), dyn_part.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
     strip_tabs.release();
     for (int b = 0; b < 2; b++) {
       if (hblk[b]) (void)hipHostFree(hblk[b]), hblk[b] = nullptr;
@@ -365,6 +367,13 @@ static int staged_upload(hqpkkt_t *h) {
       dd[k].col0 = P.nmk[k], dd[k].row0 = k < P.K ? P.nks[k] : P.ndyn, dd[k].ncur = P.nk[k];
     }
     if ((e = d.dyn_desc.upload(dd)) || (e = d.dyn_x1.alloc(n)) || (e = d.dyn_x2.alloc(P.ndyn))) return e;
+    {
+      int nzmax = 1;
+      for (int k = 0; k < P.K; k++) nzmax = std::max(nzmax, P.nk[k] + P.mk[k]);
+      nzmax = std::max(nzmax, P.nk[P.K]);
+      d.dyn_part_cols = (nzmax + 255) / 256;
+      if ((e = d.dyn_part.alloc((size_t)std::max(P.ndyn, 1) * d.dyn_part_cols))) return e;
+    }
   }
   d.gemm_variant = stg::gemm_variant_from_env();
   if (d.gemm_variant != stg::GEMM_REG4) {  // (the register-staged loop stays selectable for comparisons)
