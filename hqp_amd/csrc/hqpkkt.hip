@@ -16,6 +16,7 @@
 #include "analysis.hpp"
 #include "staged_plan.hpp"
 #include "kernels.hip.h"
+#include "factor_blk.hip.h"
 #include "ipdriver.hip.h"
 #include "staged.hip.h"
 
@@ -199,6 +200,10 @@ struct hqpkkt {
   DBuf<double> tz;    // REDUCED temporary (m)
   DBuf<double> ipv;   // interior-point driver: x y z w | r1..r4 | dxa..dwa | dx..dw | c b d | partials | scalars
   size_t lds_diag = 0, lds_panel = 0, lds_bwdb = 0;
+  // pivot blocks of the general fronts: k_factor_blk (round 4) unless HQPKKT_OLD_FD asks for k_factor_diag;
+  // per schedule and tree level the largest pivot count among the general fronts of the level
+  bool old_fd = false;
+  std::vector<int> level_maxp[2];
   // captured kernel sequences (factor; step on the caller's vectors; step on the
   // refinement's residual vectors): replayed with hipGraphLaunch
   struct GraphSlot {
@@ -407,14 +412,29 @@ static int upload(hqpkkt_t *h) {
                 2 * mp * sizeof(int) + 16;
   h->lds_panel = (32 * mp + 2 * mp) * sizeof(double) + mp * sizeof(int);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
-  if (h->lds_diag > 160 * 1024 || h->lds_bwdb > 160 * 1024) return HQPKKT_E_MEM;
+  h->old_fd = getenv("HQPKKT_OLD_FD") != nullptr && mp <= 128;
+  if (!h->old_fd) h->lds_diag = 0;
+  const size_t lds_blk = fb_lds_bytes((int)mp);
+  if (h->lds_diag > 160 * 1024 || h->lds_bwdb > 160 * 1024 || lds_blk > 160 * 1024) return HQPKKT_E_MEM;
+  for (int w = 0; w < 2; w++) {
+    const Analysis::Sched &S = an.sched[w];
+    h->level_maxp[w].assign(an.nlevels, 0);
+    for (int l = 0; l < an.nlevels && S.nnodes; l++)
+      for (int q = S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l]; q < S.level_ptr[l + 1]; q++)
+        h->level_maxp[w][l] = std::max(h->level_maxp[w][l], an.npiv[S.level_nodes[q]]);
+  }
   {
     // the attribute is state of the PROCESS, not of the handle: a second handle with smaller fronts must
     // not lower the limit under one that still launches with more (several plugins in one host, the
     // bench's concurrent systems): keep the largest value ever asked for, under a mutex
     static std::mutex attr_mutex;
-    static size_t a_diag = 0, a_panel = 0, a_bwdb = 0;
+    static size_t a_diag = 0, a_panel = 0, a_bwdb = 0, a_blk = 0;
     std::lock_guard<std::mutex> lk(attr_mutex);
+    if (lds_blk > a_blk) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 6, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
+      a_blk = lds_blk;
+    }
     if (h->lds_diag > a_diag) {
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_diag));
       a_diag = h->lds_diag;
@@ -574,10 +594,23 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p, h->xar.p, ldp, 1));
       }
-      if (nn > nfs + nsm)
+      if (nn > nfs + nsm && h->old_fd)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nfs - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p));
+      else if (nn > nfs + nsm) {
+        // the pivot blocks on the matrix pipe: 8 wavefronts (two workgroups per CU) for levels of <= 128 pivots,
+        // 16 wavefronts for up to 256
+        const int lmp = h->level_maxp[which][l];
+        if (lmp <= 128)
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<8, 6, 144, 4><<<nn - nfs - nsm, 512, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->flags.p + 1, h->upd.p)));
+        else
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<16, 6, 208, 4><<<nn - nfs - nsm, 1024, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->flags.p + 1, h->upd.p)));
+      }
       const int ns = S.slab_ptr[l + 1] - S.slab_ptr[l];
       if (ns > 0)
         KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, D.slabs.p + 2 * (size_t)S.slab_ptr[l],
@@ -2429,6 +2462,95 @@ int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long ca
   HIPCHK(hipSetDevice(h->opts.device));
   HIPCHK(hipStreamSynchronize(h->stream));
   if (n) HIPCHK(hipMemcpy(out, src, sizeof(double) * n, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// One dense symmetric p x p block through the pivot-block kernel on its own (tests, tools): A row-major;
+// variant 0 = k_factor_blk (8 wavefronts for p <= 128, 16 beyond), 1 = k_factor_diag (p <= 128),
+// 2 = k_factor_blk with 16 wavefronts whatever p.  Out: the block's panel (p x p column-major: unit lower L11
+// below the diagonal), D^-1 (2 p), pivot types, pivot order, M = L11^-1 (p x p column-major), the counters
+// (2x2 pivots, perturbed, slow pivots, ...), and the average time of `reps` launches of one workgroup.
+int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, double pivot_eps, int variant,
+                              int reps, double *Lout, double *dinv_out, int *ptype_out, int *lperm_out,
+                              double *Wout, int *counters_out, double *ms_out) {
+  if (!A || p < 1 || p > 192 || (variant == 1 && p > 128)) return HQPKKT_E_RANGE;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= device) return HQPKKT_E_DEVICE;
+  HIPCHK(hipSetDevice(device));
+  if (reps < 1) reps = 1;
+  const size_t pp2 = (size_t)p * p;
+  std::vector<double> P(pp2 * reps);
+  double kmax = 0.0;
+  for (int j = 0; j < p; j++)
+    for (int i = 0; i < p; i++) {
+      P[(size_t)j * p + i] = i >= j ? A[(size_t)i * p + j] : 0.0;
+      kmax = std::fmax(kmax, std::fabs(A[(size_t)i * p + j]));
+    }
+  for (int rp = 1; rp < reps; rp++) std::memcpy(P.data() + pp2 * rp, P.data(), sizeof(double) * pp2);
+  std::vector<int> piv_start(reps), npiv(reps, p), nbor(reps, 0), parent(reps, -1), child_ptr(reps + 1, 0), nodes(reps);
+  std::vector<long long> zeros(reps + 1, 0), poff(reps), loff(reps);
+  std::vector<signed char> sg((size_t)p * reps);
+  for (int rp = 0; rp < reps; rp++) {
+    piv_start[rp] = rp * p, nodes[rp] = rp, poff[rp] = (long long)pp2 * rp, loff[rp] = (long long)pp2 * rp;
+    for (int i = 0; i < p; i++) sg[(size_t)rp * p + i] = A[(size_t)i * p + i] < 0.0 ? -1 : 1;
+  }
+  DBuf<int> d_ps, d_np, d_nb, d_par, d_cp, d_nodes, d_pt, d_lp, d_flags, d_one;
+  DBuf<long long> d_zero, d_poff, d_loff;
+  DBuf<double> d_P, d_dinv, d_W, d_upd;
+  DBuf<signed char> d_sg;
+  std::vector<int> fl(128, 0), onei(4, 0);
+  std::memcpy(fl.data() + 120, &kmax, sizeof(double));
+  int e;
+  if ((e = d_ps.upload(piv_start)) || (e = d_np.upload(npiv)) || (e = d_nb.upload(nbor)) || (e = d_par.upload(parent)) ||
+      (e = d_cp.upload(child_ptr)) || (e = d_nodes.upload(nodes)) || (e = d_zero.upload(zeros)) || (e = d_poff.upload(poff)) ||
+      (e = d_loff.upload(loff)) || (e = d_P.upload(P)) || (e = d_sg.upload(sg)) || (e = d_flags.upload(fl)) ||
+      (e = d_one.upload(onei)) || (e = d_dinv.alloc(2 * (size_t)p * reps)) || (e = d_W.alloc(pp2 * reps)) ||
+      (e = d_upd.alloc(8)) || (e = d_pt.alloc((size_t)p * reps)) || (e = d_lp.alloc((size_t)p * reps)))
+    return e;
+  HIPCHK(hipMemset(d_W.p, 0, sizeof(double) * pp2 * reps));
+  DevTree T{d_ps.p, d_np.p, d_nb.p, d_par.p, d_zero.p, d_one.p, d_one.p, d_poff.p, d_zero.p, d_zero.p, d_zero.p,
+            d_cp.p, d_one.p, d_one.p, d_zero.p};
+  const double alpha = tol * 0.6403882032022076;
+  const unsigned long long *kb = (const unsigned long long *)(d_flags.p + 120);
+  const size_t mpd = p, ldm = mpd | 1;
+  const size_t lds_old = (std::max<size_t>(ldm * mpd, 2 * FD_PLD * FD_PANEL) + 5 * 128 + 2 * mpd) * sizeof(double) + 2 * mpd * sizeof(int) + 16;
+  if (variant == 1)
+    HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_old, 64 * 1024)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(128)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 6, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
+  hipEvent_t e0, e1;
+  HIPCHK(hipEventCreate(&e0));
+  HIPCHK(hipEventCreate(&e1));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipEventRecord(e0, 0));
+  for (int rp = 0; rp < reps; rp++) {
+    if (variant == 1)
+      k_factor_diag<<<1, FD_THREADS, lds_old, 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p, d_loff.p,
+                                                  alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
+    else if (variant == 0 && p <= 128)
+      k_factor_blk<8, 6, 144, 4><<<1, 512, fb_lds_bytes(p), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+                                                        d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
+    else
+      k_factor_blk<16, 6, 208, 4><<<1, 1024, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+                                                          d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
+  }
+  HIPCHK(hipEventRecord(e1, 0));
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipGetLastError());
+  float ms = 0.f;
+  HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+  (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
+  if (ms_out) *ms_out = ms / reps;
+  const size_t last = (size_t)(reps - 1);
+  if (Lout) HIPCHK(hipMemcpy(Lout, d_P.p + pp2 * last, sizeof(double) * pp2, hipMemcpyDeviceToHost));
+  if (Wout) HIPCHK(hipMemcpy(Wout, d_W.p + pp2 * last, sizeof(double) * pp2, hipMemcpyDeviceToHost));
+  if (dinv_out) HIPCHK(hipMemcpy(dinv_out, d_dinv.p + 2 * (size_t)p * last, sizeof(double) * 2 * p, hipMemcpyDeviceToHost));
+  if (ptype_out) HIPCHK(hipMemcpy(ptype_out, d_pt.p + (size_t)p * last, sizeof(int) * p, hipMemcpyDeviceToHost));
+  if (lperm_out) HIPCHK(hipMemcpy(lperm_out, d_lp.p + (size_t)p * last, sizeof(int) * p, hipMemcpyDeviceToHost));
+  if (counters_out) HIPCHK(hipMemcpy(counters_out, d_flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost));
+  DBuf<int> *ib[] = {&d_ps, &d_np, &d_nb, &d_par, &d_cp, &d_nodes, &d_pt, &d_lp, &d_flags, &d_one};
+  for (auto b : ib) b->release();
+  d_zero.release(), d_poff.release(), d_loff.release(), d_P.release(), d_dinv.release(), d_W.release(), d_upd.release(), d_sg.release();
   return 0;
 }
 

@@ -425,6 +425,19 @@ int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long ca
  * asymmetric 16x16x16 operands; *max_err is max |C - exact|. */
 int hqpkkt_selftest_mfma(int device, double *max_err);
 
+/* The pivot-block kernel on ONE dense symmetric p x p block (1 <= p <= 192; A row-major), without a tree:
+ * what the tests check P A P' = L D L' and M L = I with, for every pivot count and for blocks that need
+ * interchanges and 2x2 pivots (hqp/spBKP.C:392, 431-438, 471, 480 restricted to the block).
+ * variant 0: k_factor_blk as the library launches it (8 wavefronts up to 128 pivots, 16 beyond);
+ * 1: k_factor_diag of rounds 1-3 (p <= 128); 2: k_factor_blk with 16 wavefronts whatever p.
+ * Out (each may be NULL): L (p x p column-major, unit lower factor below the diagonal), dinv (2 p: D^-1, for a
+ * 2x2 pivot i11 i21 | i22 i21), ptype (0 / 1 / 2), lperm (row of A at every pivot position), W = L^-1 (p x p
+ * column-major), counters (128 ints: status, 2x2 pivots, perturbed, slow steps, ...; instrumented builds: time stamps from [9] on), ms (average of `reps`
+ * launches of one workgroup). */
+int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, double pivot_eps, int variant,
+                              int reps, double *L, double *dinv, int *ptype, int *lperm, double *W,
+                              int *counters, double *ms);
+
 #ifdef __cplusplus
 }
 #endif
