@@ -45,8 +45,8 @@ namespace kktdev {
 __host__ __device__ inline int fb_ld_of(int p) { return p <= 128 ? 144 : 208; }
 __host__ __device__ inline size_t fb_lds_bytes(int p) {
   const int pp = ((p + 15) / 16) * 16, ld = fb_ld_of(p);
-  // Op, Lb, Yb (two) | Tb, Ld (two each), Gb | dvals, dinvs, cmaxf, flags (two each) | rm0 | dv | lp, pt (ints)
-  return sizeof(double) * ((size_t)64 * ld + 5 * 272 + 96 + (size_t)pp + 2 * (size_t)pp + (size_t)pp + 16);
+  // Op, Lb, Yb, Xq | Tb, Ld (two each), Gb | Ab, G2 | dvals, dinvs, cmaxf, flags (two each) | rm0 | dv | lp, pt (ints)
+  return sizeof(double) * ((size_t)64 * ld + 5 * 272 + 512 + 96 + (size_t)pp + 2 * (size_t)pp + (size_t)pp + 16);
 }
 
 // Barrier of the panel loop: waits for this wavefront's LDS operations only.  __syncthreads() also waits for the
@@ -221,7 +221,10 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
              const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters,
              const double *__restrict__ upd) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  constexpr int NT = 64 * NW, NWK = NW - 1;  // the last wavefront eliminates the diagonal blocks and holds no block
+  // The last wavefront eliminates the diagonal blocks and holds no block.  The fp64 multiply-adds of its chain and
+  // the fp64 matrix products of the others run on the same units of a SIMD: the wavefronts that share its SIMD
+  // (every fourth) hold no block either.
+  constexpr int NT = 64 * NW, NWK = NW - NW / 4;
   constexpr int ld = LD;
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
@@ -232,12 +235,15 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   const int nb = (p + 15) >> 4, pp = nb << 4;
   double *Op = lds;                 // 16 x ld: the pivot rows of [M | U] (k-major)
   double *Lb = Op + 16 * ld;        // 16 x ld: -L of the panel (k-major)
-  double *Yb = Lb + 16 * ld;        // two of 16 x ld: the rows of M of a panel's pivots as they stand (k-major), and
-                                    // in the columns of the panel's own block N of its diagonal block
-  double *Tb = Yb + 32 * ld;        // two of 16 x 17: the eliminated diagonal block (rows of [N | U])
+  double *Yb = Lb + 16 * ld;        // 16 x ld: the rows of M of the next panel's pivots as they stand (k-major)
+  double *Xq = Yb + 16 * ld;        // 16 x ld, columns 0..63: what the elimination of a diagonal block leaves as
+                                    // operand images, for two panels in turn: -L of the block (columns 16 par ..),
+                                    // N of the block (columns 32 + 16 par ..)
+  double *Tb = Xq + 16 * ld;        // two of 16 x 17: the eliminated diagonal block (rows of [N | U])
   double *Ldg = Tb + 2 * 272;       // two of 16 x 17: -L inside the diagonal block, [pivot][row]
   double *Gb = Ldg + 2 * 272;       // 16 x 17: the diagonal block to eliminate
-  double *dvals = Gb + 272, *dinvs = dvals + 32;  // two of 16 each
+  double *Ab = Gb + 272, *G2 = Ab + 256;  // register images of the two blocks the next elimination starts from
+  double *dvals = G2 + 256, *dinvs = dvals + 32;  // two of 16 each
   float *cmaxf = (float *)(dinvs + 32);           // two of 16 column maxima (fp32 bits order like the values)
   int *badin = (int *)(dinvs + 48);               // two: pivots that failed inside their own block (bit mask)
   float *rm0 = (float *)(dinvs + 64);  // pp: largest entry of every row of the block as assembled (fp32)
@@ -247,20 +253,22 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_ge = wave == NW - 1;
+  const bool is_worker = (wave & 3) != 3;
+  const int wrank = wave - (wave >> 2);  // rank among the wavefronts that hold blocks
   if (is_ge) __builtin_amdgcn_s_setprio(3);  // its chain of dependent operations is the critical path of a panel
   const int ln0 = lane & 15, lg0 = lane >> 4;
   int ln = ln0, lg = lg0;
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
   const int nslots = nb * (nb + 1) / 2;
 
-  // ---- this wavefront's blocks: slot t = wave + NWK s, block rows from the last one up
+  // ---- this wavefront's blocks: slot t = wrank + NWK s, block rows from the last one up
   int sI[NS], sJ[NS];
 #pragma unroll
   for (int s = 0; s < NS; s++) {
-    const int t = wave + NWK * s;
+    const int t = wrank + NWK * s;
     int I = nb - 1, base = 0;
     while (I >= 0 && t >= base + I + 1) base += I + 1, I--;
-    const bool have = !is_ge && t < nslots;
+    const bool have = is_worker && t < nslots;
     sI[s] = have ? I : -1;
     sJ[s] = have ? t - base : -1;
   }
@@ -323,23 +331,42 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   }
   __syncthreads();
 
-  // the diagonal block of block row `row` to Gb, its rows of M (as they stand) to Yb
-  auto publish_pivot_rows = [&](int row, double *Yd) {
+  // Block row `row`: its rows of M (as they stand) to Yb; diag: its diagonal block as rows to Gb (the
+  // elimination reads it next)
+  auto publish_block_row = [&](int row, bool diag) {
+#pragma unroll
+    for (int s = 0; s < NS; s++) {
+      if (sI[s] != row) continue;
+      if (sJ[s] == row) {
+        if (diag) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) Gb[ln * 17 + lg + 4 * q] = R[s][q];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < 4; q++) Yb[ln * ld + 16 * sJ[s] + lg + 4 * q] = R[s][q];
+      }
+    }
+  };
+  // the two blocks of block row `row` the elimination wavefront starts its next block from (register images)
+  auto publish_start_blocks = [&](int row) {
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       if (sI[s] != row) continue;
       if (sJ[s] == row) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) Gb[ln * 17 + lg + 4 * q] = R[s][q];
-      } else {
+        for (int q = 0; q < 4; q++) G2[64 * q + lane] = R[s][q];
+      } else if (sJ[s] == row - 1) {
 #pragma unroll
-        for (int q = 0; q < 4; q++) Yd[ln * ld + 16 * sJ[s] + lg + 4 * q] = R[s][q];
+        for (int q = 0; q < 4; q++) Ab[64 * q + lane] = R[s][q];
       }
     }
   };
 
   int k = 0, par = 0;
-  bool prologue = true;  // the diagonal block of the panel is not eliminated yet (first panel, after a slow step)
+  // hot: the diagonal block of the panel is eliminated already (by the look-ahead of the panel before) and the
+  // start blocks of the next block row are published; false for the first panel and after a slow step
+  bool hot = false;
   [[maybe_unused]] int npan = 0;
   FBSTAMP(1);
   while (k < p) {
@@ -352,13 +379,13 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     for (int s = 0; s < NS; s++) asm volatile("" : "+s"(sI[s]), "+s"(sJ[s]));
     const int kb = k >> 4, off = k & 15, kend = min(16, p - 16 * kb);
     // ================= panel: pivots off .. 15 of block kb without interchanges =============
-    double *Yc = Yb + 16 * ld * par, *Yn = Yb + 16 * ld * (par ^ 1);
-    if (prologue) {
-      publish_pivot_rows(kb, Yc);
+    if (!hot) {
+      publish_block_row(kb, true);
+      if (kb + 1 < nb) publish_start_blocks(kb + 1);
       fb_barrier();
       if (is_ge) {
         if (lane < 16) cmaxf[16 * par + lane] = 0.0f;
-        fb_eliminate_block<LD>(Gb, Tb + 272 * par, Ldg + 272 * par, Yc + 16 * kb, Lb + 16 * kb, dvals + 16 * par,
+        fb_eliminate_block<LD>(Gb, Tb + 272 * par, Ldg + 272 * par, Xq + 32 + 16 * par, Xq + 16 * par, dvals + 16 * par,
                                dinvs + 16 * par, badin + par, alpha, pert, off, lane);
         // (this wavefront holds no block: telling the compiler so frees the registers of R for the elimination)
 #pragma unroll
@@ -368,10 +395,12 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     }
     FBSTAMP(2 + 5 * npan);
     const double *Tp = Tb + 272 * par, *Lp = Ldg + 272 * par, *dvp = dvals + 16 * par, *dip = dinvs + 16 * par;
+    const double *Tnq = Xq + 32 + 16 * par, *Ldq = Xq + 16 * par;
     float *cmp = cmaxf + 16 * par;
-    // ---- C' = N A' for the blocks below the diagonal block, M rows <- N (M rows).  N (row ln, columns lg + 4 q:
-    // the A operand of the first product, the B operand of the second) and D^-1 once per wavefront.
-    if (!is_ge) {
+    // ---- C' = N A' for the blocks below the diagonal block, M rows <- N (M rows); the elimination wavefront:
+    // the next diagonal block as this panel leaves it.  N (row ln, columns lg + 4 q: the A operand of the first
+    // product, the B operand of the second) and D^-1 once per wavefront.
+    {
       double tn[4], tna[4], dvi[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
@@ -381,39 +410,56 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         tna[q] = ln >= off ? tn[q] : 0.0;
         dvi[q] = dip[c];                                        // (0 in front of `off`)
       }
+      if (is_ge) {
+        if (kb + 1 < nb) {
+          // Ahead of the test: with the whole panel accepted the block (kb+1, kb+1) becomes G - L C' with
+          // C' = N (block (kb+1, kb))', both in registers as the accumulator layout of the products wants them
+          double4_t A_, G_;
 #pragma unroll
-      for (int s = 0; s < NS; s++) {
-        if (sJ[s] == kb && sI[s] > kb) {
+          for (int q = 0; q < 4; q++) A_[q] = Ab[64 * q + lane], G_[q] = G2[64 * q + lane];
           double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int q = 0; q < 4; q++) acc = mfma_f64(tna[q], R[s][q], acc);
-          const int row = 16 * sI[s] + ln;
-          double *o = Op + (lg * ld + row), *l = Lb + (lg * ld + row);
-          double *pc = P + ((long long)(16 * kb + lg) * F + row);  // L11 column 16 kb + lg (+ 4 q), this row
+          for (int q = 0; q < 4; q++) acc = mfma_f64(tna[q], A_[q], acc);
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            // acc[q] = C(row ln of block I, pivot lg + 4 q); zero for the pivots in front of `off`
-            const double lq = acc[q] * dvi[q];
-            o[4 * q * ld] = acc[q];
-            l[4 * q * ld] = -lq;
-            // (ahead of the test: the column of a pivot that is rejected is written again when it is eliminated)
-            if (lg + 4 * q >= off && 16 * kb + lg + 4 * q < p && row < p) pc[4 * q * F] = lq;
-            // column maxima in fp32 (a NaN counts as infinite)
-            const float av = (acc[q] == acc[q]) ? fabsf((float)acc[q]) : __int_as_float(0x7f800000);
-            const float v = row16_max_f(av);
-            if (ln == 0) atomicMax((unsigned int *)&cmp[lg + 4 * q], (unsigned int)__float_as_int(v));
+          for (int q = 0; q < 4; q++) G_ = mfma_f64(acc[q], -(acc[q] * dvi[q]), G_);
+#pragma unroll
+          for (int q = 0; q < 4; q++) Gb[ln * 17 + lg + 4 * q] = G_[q];
+        }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NS; s++) {
+          if (sJ[s] == kb && sI[s] > kb) {
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = mfma_f64(tna[q], R[s][q], acc);
+            const int row = 16 * sI[s] + ln;
+            double *o = Op + (lg * ld + row), *l = Lb + (lg * ld + row);
+            double *pc = P + ((long long)(16 * kb + lg) * F + row);  // L11 column 16 kb + lg (+ 4 q), this row
+#pragma unroll
+            for (int q = 0; q < 4; q++) {
+              // acc[q] = C(row ln of block I, pivot lg + 4 q); zero for the pivots in front of `off`
+              const double lq = acc[q] * dvi[q];
+              o[4 * q * ld] = acc[q];
+              l[4 * q * ld] = -lq;
+              // (ahead of the test: the column of a pivot that is rejected is written again when it is eliminated)
+              if (lg + 4 * q >= off && 16 * kb + lg + 4 * q < p && row < p) pc[4 * q * F] = lq;
+              // column maxima in fp32 (a NaN counts as infinite)
+              const float av = (acc[q] == acc[q]) ? fabsf((float)acc[q]) : __int_as_float(0x7f800000);
+              const float v = row16_max_f(av);
+              if (ln == 0) atomicMax((unsigned int *)&cmp[lg + 4 * q], (unsigned int)__float_as_int(v));
+            }
+          } else if (sI[s] == kb && sJ[s] >= 0 && sJ[s] < kb) {
+            const double *y = Yb + (lg * ld + 16 * sJ[s] + ln);
+            double a[4];
+#pragma unroll
+            for (int q = 0; q < 4; q++) a[q] = y[4 * q * ld];  // A operand: m = ln (column of block j), k = lg + 4 q
+            double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int q = 0; q < 4; q++) acc = mfma_f64(a[q], tn[q], acc);
+            double *o = Op + (ln * ld + 16 * sJ[s] + lg);
+#pragma unroll
+            for (int q = 0; q < 4; q++) o[4 * q] = acc[q];
           }
-        } else if (sI[s] == kb && sJ[s] >= 0 && sJ[s] < kb) {
-          const double *y = Yc + (lg * ld + 16 * sJ[s] + ln);
-          double a[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) a[q] = y[4 * q * ld];  // A operand: m = ln (column of block j), k = lg + 4 q
-          double4_t acc = {0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-          for (int q = 0; q < 4; q++) acc = mfma_f64(a[q], tn[q], acc);
-          double *o = Op + (ln * ld + 16 * sJ[s] + lg);
-#pragma unroll
-          for (int q = 0; q < 4; q++) o[4 * q] = acc[q];
         }
       }
     }
@@ -430,57 +476,42 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       done = __builtin_amdgcn_readfirstlane(done);
     }
     FBWSTAMP(0);
-    // Look-ahead: with the whole block accepted, the next block row is updated first and published, and the
-    // elimination of its diagonal block runs beside the update of everything else.
+    // Look-ahead: with the whole block accepted the elimination of the next diagonal block (prepared above)
+    // runs beside the update.
     const bool la = done == 16 && kb + 1 < nb;
-    if (done == 16) {
+    if (la && is_ge) {
+      if (lane < 16) cmaxf[16 * (par ^ 1) + lane] = 0.0f;
+      fb_eliminate_block<LD>(Gb, Tb + 272 * (par ^ 1), Ldg + 272 * (par ^ 1), Xq + 32 + 16 * (par ^ 1), Xq + 16 * (par ^ 1),
+                             dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1), badin + (par ^ 1), alpha, pert, 0, lane);
+#pragma unroll
+      for (int s = 0; s < NS; s++) R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
+      FBWSTAMP(1);
+    } else if (done == 16) {
       // ---- update with a whole panel: every live block (block rows >= kb) -= (its rows of L) (the 16 pivot rows).
-      // Both operands are 16 k-rows of stride ld: the pivot rows from Op (the panel's own block column: N, from
-      // the Y image), -L from Lb (the panel's own block row: the part the elimination wrote).
-#pragma unroll 1
-      for (int pass = 0; pass < 2; pass++) {
-        asm volatile("" : "+v"(ln), "+v"(lg), "+v"(tid), "+v"(lane));  // (as at the top of the panel loop)
+      // Both operands are 16 k-rows of stride ld: the pivot rows from Op (the panel's own block column: N), -L
+      // from Lb (the panel's own block row: what the elimination left).
 #pragma unroll
-        for (int s = 0; s < NS; s++) asm volatile("" : "+s"(sI[s]), "+s"(sJ[s]));
+      for (int s = 0; s < NS; s++) {
+        if (sI[s] < kb) continue;  // (also the empty slots: -1)
+        const double *ab = sJ[s] == kb ? Tnq + (lg * ld + ln) : Op + (lg * ld + 16 * sJ[s] + ln);
+        const double *lb = sI[s] == kb ? Ldq + (lg * ld + ln) : Lb + (lg * ld + 16 * sI[s] + ln);
+        double a[4], l[4];
 #pragma unroll
-        for (int s = 0; s < NS; s++) {
-          if (sI[s] < kb) continue;  // (also the empty slots: -1)
-          if (la ? ((sI[s] == kb + 1) != (pass == 0)) : (pass != 0)) continue;
-          const double *ab = (sJ[s] == kb ? Yc : Op) + (lg * ld + 16 * sJ[s] + ln);
-          const double *lb = Lb + (lg * ld + 16 * sI[s] + ln);
-          double a[4], l[4];
+        for (int q = 0; q < 4; q++) a[q] = ab[4 * q * ld], l[q] = lb[4 * q * ld];
+        double4_t acc = R[s];
+        if (sJ[s] == kb) {  // the eliminated columns of the panel's own block turn into columns of M: from zero
 #pragma unroll
-          for (int q = 0; q < 4; q++) a[q] = ab[4 * q * ld], l[q] = lb[4 * q * ld];
-#ifdef HQPKKT_STAMPS
-          if (pass == 1 && s < 2) { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); FBWSTAMP2(2 * s, a[0] + l[0] + a[3] + l[3]); }
-#endif
-          double4_t acc = R[s];
-          if (sJ[s] == kb) {  // the eliminated columns of the panel's own block turn into columns of M: from zero
-#pragma unroll
-            for (int q = 0; q < 4; q++) acc[q] = (lg + 4 * q < off) ? acc[q] : 0.0;
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++) acc = mfma_f64(a[q], l[q], acc);
-          R[s] = acc;
-#ifdef HQPKKT_STAMPS
-          if (pass == 1 && s < 2) FBWSTAMP2(2 * s + 1, acc[0] + acc[3]);
-#endif
+          for (int q = 0; q < 4; q++) acc[q] = (lg + 4 * q < off) ? acc[q] : 0.0;
         }
-        if (pass == 0 && la) {
-          FBWSTAMP(1);
-          publish_pivot_rows(kb + 1, Yn);
-          FBWSTAMP(2);
-          fb_barrier();
-          FBWSTAMP(3);
-          FBSTAMP(4 + 5 * npan);
-          if (is_ge) {
-            if (lane < 16) cmaxf[16 * (par ^ 1) + lane] = 0.0f;
-            fb_eliminate_block<LD>(Gb, Tb + 272 * (par ^ 1), Ldg + 272 * (par ^ 1), Yn + 16 * (kb + 1), Lb + 16 * (kb + 1),
-                                   dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1), badin + (par ^ 1), alpha, pert, 0, lane);
 #pragma unroll
-            for (int s = 0; s < NS; s++) R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
-          }
-        }
+        for (int q = 0; q < 4; q++) acc = mfma_f64(a[q], l[q], acc);
+        R[s] = acc;
+      }
+      FBWSTAMP(1);
+      // what the next panel and the elimination behind it start from
+      if (la) {
+        publish_block_row(kb + 1, false);
+        if (kb + 2 < nb) publish_start_blocks(kb + 2);
       }
     } else if (done > off) {
       // ---- update with the pivots off .. done - 1 only (the rest of the panel goes to the slow step): operands
@@ -526,14 +557,16 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       if (tid >= off && tid < done) dv[2 * (16 * kb + tid)] = dip[tid], dv[2 * (16 * kb + tid) + 1] = 0.0, pt[16 * kb + tid] = 0;
     }
     FBSTAMP(5 + 5 * npan);
+    FBWSTAMP(2);
     if (done < kend)
       __syncthreads();  // the slow step reads L11 columns back
     else
       fb_barrier();
+    FBWSTAMP(3);
     FBSTAMP(6 + 5 * npan);
     npan++;
     k = 16 * kb + done;
-    prologue = !la;
+    hot = la;
     if (la) par ^= 1;
     if (done < kend) {
       // ================= slow step: one pivot with the complete test =========================

@@ -432,7 +432,7 @@ static int upload(hqpkkt_t *h) {
     std::lock_guard<std::mutex> lk(attr_mutex);
     if (lds_blk > a_blk) {
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
-      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 6, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 7, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
       a_blk = lds_blk;
     }
     if (h->lds_diag > a_diag) {
@@ -607,7 +607,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
         else
-          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<16, 6, 208, 4><<<nn - nfs - nsm, 1024, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<16, 7, 208, 4><<<nn - nfs - nsm, 1024, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
       }
@@ -2517,7 +2517,7 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
   if (variant == 1)
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_old, 64 * 1024)));
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(128)));
-  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 6, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 7, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -2531,7 +2531,7 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
       k_factor_blk<8, 6, 144, 4><<<1, 512, fb_lds_bytes(p), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                         d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
     else
-      k_factor_blk<16, 6, 208, 4><<<1, 1024, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+      k_factor_blk<16, 7, 208, 4><<<1, 1024, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                           d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
   }
   HIPCHK(hipEventRecord(e1, 0));

@@ -21,8 +21,8 @@ for p in [int(a) for a in sys.argv[1:]] or [80, 128, 160]:
             print(f"   panel {k}: prologue {a[0] - prev}  solve {a[1] - a[0]}  test + next block row {a[2] - a[1]}  rest of the update | next elimination {a[3] - a[2]}  sync {a[4] - a[3]}")
         w = out["counters"][63:63 + 64].astype(np.int64).reshape(16, 4)
         t0 = s[3 + 5 * 3]  # thread 0 behind the barrier in front of the test of panel 3
-        print("   panel 3 per wavefront (test done, next block row updated, published, behind the barrier), relative to thread 0's stamp:")
-        for wv in range(8):
+        print("   panel 3 per wavefront (test done, update / elimination done, published, behind the barrier), relative to thread 0 behind the barrier in front of the test:")
+        for wv in range(16):
             if w[wv].any():
                 print(f"      wave {wv:2d}: " + "  ".join(str(int(x - t0)) for x in w[wv]))
         w2 = out["counters"][95:95 + 32].astype(np.int64).reshape(8, 4)
