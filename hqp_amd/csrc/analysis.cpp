@@ -249,7 +249,8 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   TMARK("0");
   if (int e0 = setup_blocks(mode_, n_, me_, m_, Qp, Qi, Ap, Ai, Cp, Ci)) return e0;
   const int ONE = nq + na + nc, WONE = m;
-  if (max_pivots <= 0 || max_pivots > 128) max_pivots = 128;
+  if (max_pivots <= 0) max_pivots = 128;
+  if (max_pivots > 192) max_pivots = 192;  // k_factor_blk: 12 blocks of 16 (k_factor_diag of rounds 1-3: 128)
   if (leaf_size <= 0) leaf_size = 0;  // decided below from sbw
 
   TMARK("1");

@@ -193,20 +193,14 @@ __device__ __forceinline__ void fb_eliminate_block(const double *Gb, double *Tb,
   do {                                                                                   \
     if (blockIdx.x == 0 && threadIdx.x == 0 && (slot) < 54) counters[8 + (slot)] = (int)__builtin_amdgcn_s_memtime(); \
   } while (0)
-// per-wavefront stamps of panel 3 (four per wavefront, counters[62 + 4 wave + j])
+// per-wavefront stamps of panel 3 (sixteen per wavefront) in a symbol of their own (hqpkkt_debug_fb_stamps)
+__device__ int g_fb_stamps[16 * 16];
 #define FBWSTAMP(j)                                                                      \
   do {                                                                                   \
     if (blockIdx.x == 0 && npan == 3 && (threadIdx.x & 63) == 0)                         \
-      counters[62 + 4 * (threadIdx.x >> 6) + (j)] = (int)__builtin_amdgcn_s_memtime();  \
+      g_fb_stamps[16 * (threadIdx.x >> 6) + (j)] = (int)__builtin_amdgcn_s_memtime();    \
   } while (0)
-// (value: something the stamped point must have computed, so that the stamp waits for it)
-#define FBWSTAMP2(j, value)                                                              \
-  do {                                                                                   \
-    double vv_ = (value);                                                                \
-    asm volatile("" : "+v"(vv_));                                                        \
-    if (blockIdx.x == 0 && npan == 3 && (threadIdx.x & 63) == 0)                         \
-      counters[94 + 4 * (threadIdx.x >> 6) + (j)] = (int)__builtin_amdgcn_s_memtime();   \
-  } while (0)
+#define FBWSTAMP2(j, value) do { } while (0)
 #else
 #define FBSTAMP(slot)
 #define FBWSTAMP(j)
@@ -394,6 +388,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       fb_barrier();
     }
     FBSTAMP(2 + 5 * npan);
+    FBWSTAMP(0);
     const double *Tp = Tb + 272 * par, *Lp = Ldg + 272 * par, *dvp = dvals + 16 * par, *dip = dinvs + 16 * par;
     const double *Tnq = Xq + 32 + 16 * par, *Ldq = Xq + 16 * par;
     float *cmp = cmaxf + 16 * par;
@@ -410,6 +405,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         tna[q] = ln >= off ? tn[q] : 0.0;
         dvi[q] = dip[c];                                        // (0 in front of `off`)
       }
+      FBWSTAMP(1);
       if (is_ge) {
         if (kb + 1 < nb) {
           // Ahead of the test: with the whole panel accepted the block (kb+1, kb+1) becomes G - L C' with
@@ -463,7 +459,9 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         }
       }
     }
+    FBWSTAMP(2);
     fb_barrier();
+    FBWSTAMP(3);
     FBSTAMP(3 + 5 * npan);
     // ---- the test of all pivots of the panel: the pivots in front of the first failure are accepted
     int done;
@@ -475,17 +473,19 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       done = badm ? (int)__builtin_ctz(badm) : kend;
       done = __builtin_amdgcn_readfirstlane(done);
     }
-    FBWSTAMP(0);
+    FBWSTAMP(4);
     // Look-ahead: with the whole block accepted the elimination of the next diagonal block (prepared above)
     // runs beside the update.
     const bool la = done == 16 && kb + 1 < nb;
     if (la && is_ge) {
       if (lane < 16) cmaxf[16 * (par ^ 1) + lane] = 0.0f;
+#ifndef FB_SKIP_GE  // (timing experiments only: wrong results)
       fb_eliminate_block<LD>(Gb, Tb + 272 * (par ^ 1), Ldg + 272 * (par ^ 1), Xq + 32 + 16 * (par ^ 1), Xq + 16 * (par ^ 1),
                              dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1), badin + (par ^ 1), alpha, pert, 0, lane);
+#endif
 #pragma unroll
       for (int s = 0; s < NS; s++) R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
-      FBWSTAMP(1);
+      FBWSTAMP(5);
     } else if (done == 16) {
       // ---- update with a whole panel: every live block (block rows >= kb) -= (its rows of L) (the 16 pivot rows).
       // Both operands are 16 k-rows of stride ld: the pivot rows from Op (the panel's own block column: N), -L
@@ -503,11 +503,15 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
 #pragma unroll
           for (int q = 0; q < 4; q++) acc[q] = (lg + 4 * q < off) ? acc[q] : 0.0;
         }
+#ifndef FB_SKIP_UPD  // (timing experiments only: wrong results)
 #pragma unroll
         for (int q = 0; q < 4; q++) acc = mfma_f64(a[q], l[q], acc);
+#else
+        acc[0] += a[0] + l[0] + a[3] + l[3];
+#endif
         R[s] = acc;
       }
-      FBWSTAMP(1);
+      FBWSTAMP(5);
       // what the next panel and the elimination behind it start from
       if (la) {
         publish_block_row(kb + 1, false);
@@ -547,6 +551,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         R[s] = acc;
       }
     }
+    FBWSTAMP(6);
     if (done > off && !is_ge) {
       // L11 inside the diagonal block, pivot data of the accepted pivots
       if (tid < 256) {
@@ -557,12 +562,12 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       if (tid >= off && tid < done) dv[2 * (16 * kb + tid)] = dip[tid], dv[2 * (16 * kb + tid) + 1] = 0.0, pt[16 * kb + tid] = 0;
     }
     FBSTAMP(5 + 5 * npan);
-    FBWSTAMP(2);
+    FBWSTAMP(7);
     if (done < kend)
       __syncthreads();  // the slow step reads L11 columns back
     else
       fb_barrier();
-    FBWSTAMP(3);
+    FBWSTAMP(8);
     FBSTAMP(6 + 5 * npan);
     npan++;
     k = 16 * kb + done;

@@ -1025,8 +1025,13 @@ static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd) {
   h->an.ordering = (h->opts.ordering == 1 || h->opts.ordering == 2) ? h->opts.ordering : 0;
   if (h->opts.upd_pingpong_mb > 0) h->an.upd_pingpong_bytes = (long long)h->opts.upd_pingpong_mb << 20;
   if (h->opts.upd_pingpong_mb < 0) h->an.upd_pingpong_bytes = 0;
+  // pivots per supernode: the caller's number, or 192 (what k_factor_blk takes; HQPKKT_MAX_PIVOTS for same-box
+  // comparisons; k_factor_diag of rounds 1-3, HQPKKT_OLD_FD, takes 128)
+  int maxp = h->opts.max_pivots;
+  if (maxp <= 0) maxp = getenv("HQPKKT_MAX_PIVOTS") ? std::atoi(getenv("HQPKKT_MAX_PIVOTS")) : 192;
+  if (getenv("HQPKKT_OLD_FD")) maxp = std::min(maxp, 128);
   int e = h->an.run(h->opts.mode, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),
-                    h->pCp.data(), h->pCi.data(), h->opts.leaf_size, h->opts.max_pivots, zd);
+                    h->pCp.data(), h->pCi.data(), h->opts.leaf_size, maxp, zd);
   if (e) return e;
   h->zd_used = zd;
   h->analyzed = true;
@@ -2432,6 +2437,11 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
 int hqpkkt_debug_stamps(hqpkkt_t *h, int *out) {
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpy(out, h->flags.p, sizeof(int) * 64, hipMemcpyDeviceToHost));
+  return 0;
+}
+int hqpkkt_debug_fb_stamps(int *out) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(kktdev::g_fb_stamps), sizeof(int) * 256));
   return 0;
 }
 int hqpkkt_debug_gj_stamps(int *out) {

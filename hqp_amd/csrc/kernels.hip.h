@@ -1661,22 +1661,22 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
   // permutation, so that the epilogue has no dependent global loads
   double *pd = s + 32 * p;        // 2 p
   int *pty = (int *)(pd + 2 * p);  // p
-  if (tid < p) {
+  if (tid < p) {  // (256 threads: fronts of up to 256 pivots)
     pty[tid] = ptype[e0 + tid];
     pd[2 * tid] = dinv[2 * (e0 + tid)];
     pd[2 * tid + 1] = dinv[2 * (e0 + tid) + 1];
   }
-  {
-    int lc[16];  // p <= 128: 16 columns per thread, loads batched
+  for (int c0 = 0; c0 < p; c0 += 128) {  // 128 columns per trip (fronts of up to 256 pivots: two trips)
+    int lc[16];  // 16 columns per thread and trip, loads batched
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      const int kcol = g + 8 * u;
+      const int kcol = c0 + g + 8 * u;
       lc[u] = kcol < p ? lperm[e0 + kcol] : 0;
     }
     double v[16];
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      const int kcol = g + 8 * u;
+      const int kcol = c0 + g + 8 * u;
       v[u] = (live && kcol < p) ? P[(long long)lc[u] * F + p + r0 + r] : 0.0;
     }
     // + the children's update blocks at (border row, pivot column)
@@ -1687,7 +1687,7 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
       const int ci = live ? iv[p + r0 + r] : -1;
       int cj[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) cj[u] = (g + 8 * u < p) ? iv[lc[u]] : -1;
+      for (int u = 0; u < 16; u++) cj[u] = (c0 + g + 8 * u < p) ? iv[lc[u]] : -1;
       double gv[16];
 #pragma unroll
       for (int u = 0; u < 16; u++) gv[u] = (ci >= 0 && cj[u] >= 0) ? Uc[(long long)cj[u] * bc + ci] : 0.0;
@@ -1696,19 +1696,19 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
     }
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      const int kcol = g + 8 * u;
+      const int kcol = c0 + g + 8 * u;
       if (kcol < p) s[r + 32 * kcol] = v[u];
     }
   }
   __syncthreads();
   const int nbc = (p + 15) >> 4;
   const int ml = lane & 15, kl = lane >> 4;
-  double4_t acc[2][2];  // [column tile of this wave][row half]
-  int ctile[2];
+  double4_t acc[4][2];  // [column tile of this wave][row half]
+  int ctile[4];
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
-    // column tiles from the most expensive down, dealt 0 1 2 3 3 2 1 0 to the waves
-    const int idx = u == 0 ? wave : 7 - wave;
+  for (int u = 0; u < 4; u++) {
+    // column tiles from the most expensive down, dealt 0 1 2 3 3 2 1 0 0 1 2 3 3 2 1 0 to the waves
+    const int idx = 8 * (u >> 1) + ((u & 1) == 0 ? wave : 7 - wave);
     const int ct = nbc - 1 - idx;
     ctile[u] = ct;
     acc[u][0] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -1716,11 +1716,11 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
     if (ct < 0) continue;  // wave-uniform
     const int c0 = 16 * ct, tend = min(p, c0 + 16);
     const bool con = c0 + ml < p;
-    // the tile's M operands in two batches of 16 k-steps (64 pivots): all loads of a
+    // the tile's M operands in batches of 16 k-steps (64 pivots): all loads of a
     // batch are in flight together, then the products with the slab in LDS
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-      if (64 * half >= tend) continue;  // wave-uniform
+#pragma unroll 1
+    for (int half = 0; half < 4; half++) {
+      if (64 * half >= tend) break;  // wave-uniform
       double bv[16];
 #pragma unroll
       for (int q = 0; q < 16; q++) {
@@ -1742,7 +1742,7 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
   }
   __syncthreads();  // everybody has read s
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
+  for (int u = 0; u < 4; u++) {
     const int ct = ctile[u];
     if (ct < 0) continue;
     const int c = 16 * ct + ml;
@@ -1894,25 +1894,28 @@ __global__ void k_mfma_selftest(const double *A, const double *B, double *C) {
 __device__ __forceinline__ void mfma_lower_times_vec(const double *__restrict__ W, int p, const double *tp,
                                                      double *y, int wave, int lane) {
   const int nb = (p + DB - 1) / DB, ml = lane & 15, kl = lane >> 4;
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int ib = nb - 1 - (u == 0 ? wave : 7 - wave);
+#pragma unroll 1
+  for (int u = 0; u < 4; u++) {  // (fronts of up to 256 pivots: 16 row blocks, four per wave)
+    const int ib = nb - 1 - (8 * (u >> 1) + ((u & 1) == 0 ? wave : 7 - wave));
     if (ib < 0) continue;  // wave-uniform
     const int i0 = DB * ib, tend = min(p, i0 + DB);
     const bool ron = i0 + ml < p;
-    double av[32];
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-      const int t = 4 * q + kl;
-      av[q] = (ron && t < tend) ? W[(long long)t * p + i0 + ml] : 0.0;
-    }
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int t0 = 0; t0 < tend; t0 += 128) {  // 32 k-steps (128 pivots) of operands in flight together
+      double av[32];
 #pragma unroll
-    for (int q = 0; q < 32; q++) {
-      if (4 * q < tend) {  // wave-uniform
-        const int t = 4 * q + kl;
-        const double bv = (ml == 0 && t < tend) ? tp[t] : 0.0;
-        acc = mfma_f64(av[q], bv, acc);
+      for (int q = 0; q < 32; q++) {
+        const int t = t0 + 4 * q + kl;
+        av[q] = (ron && t < tend) ? W[(long long)t * p + i0 + ml] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 32; q++) {
+        if (t0 + 4 * q < tend) {  // wave-uniform
+          const int t = t0 + 4 * q + kl;
+          const double bv = (ml == 0 && t < tend) ? tp[t] : 0.0;
+          acc = mfma_f64(av[q], bv, acc);
+        }
       }
     }
     if (ml == 0) {
@@ -1928,25 +1931,28 @@ __device__ __forceinline__ void mfma_lower_times_vec(const double *__restrict__ 
 __device__ __forceinline__ void mfma_lower_trans_times_vec(const double *__restrict__ W, int p,
                                                            const double *v, double *z, int wave, int lane) {
   const int nb = (p + DB - 1) / DB, ml = lane & 15, kl = lane >> 4;
-#pragma unroll
-  for (int u = 0; u < 2; u++) {
-    const int tb = u == 0 ? wave : 7 - wave;  // column block 0 is the longest
-    if (tb >= nb) continue;                   // wave-uniform
+#pragma unroll 1
+  for (int u = 0; u < 4; u++) {
+    const int tb = 8 * (u >> 1) + ((u & 1) == 0 ? wave : 7 - wave);  // column block 0 is the longest
+    if (tb >= nb) continue;                                            // wave-uniform
     const int t0 = DB * tb;
     const bool con = t0 + ml < p;
-    double bv[32];
-#pragma unroll
-    for (int q = 0; q < 32; q++) {
-      const int i = t0 + 4 * q + kl;
-      bv[q] = (con && i < p) ? W[(long long)(t0 + ml) * p + i] : 0.0;
-    }
     double4_t acc = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 1
+    for (int i0 = t0; i0 < p; i0 += 128) {
+      double bv[32];
 #pragma unroll
-    for (int q = 0; q < 32; q++) {
-      if (t0 + 4 * q < p) {  // wave-uniform
-        const int i = t0 + 4 * q + kl;
-        const double av = (ml == 0 && i < p) ? v[i] : 0.0;
-        acc = mfma_f64(av, bv[q], acc);
+      for (int q = 0; q < 32; q++) {
+        const int i = i0 + 4 * q + kl;
+        bv[q] = (con && i < p) ? W[(long long)(t0 + ml) * p + i] : 0.0;
+      }
+#pragma unroll
+      for (int q = 0; q < 32; q++) {
+        if (i0 + 4 * q < p) {  // wave-uniform
+          const int i = i0 + 4 * q + kl;
+          const double av = (ml == 0 && i < p) ? v[i] : 0.0;
+          acc = mfma_f64(av, bv[q], acc);
+        }
       }
     }
     if (kl == 0 && con) z[t0 + ml] = acc[0];
@@ -1961,7 +1967,7 @@ k_solve_fwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__re
               const int *__restrict__ ptype, const int *__restrict__ lperm,
               const double *__restrict__ rhs, double *__restrict__ xsol, double *__restrict__ ytmp,
               double *__restrict__ cb) {
-  __shared__ double t1[128], tp[128], y[128];
+  __shared__ double t1[256], tp[256], y[256];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
   const int e0 = T.piv_start[node];
@@ -2009,7 +2015,7 @@ __global__ void __launch_bounds__(256)
 k_solve_fwd_b(DevTree T, const int *__restrict__ gslabs, const double *__restrict__ panel,
               const double *__restrict__ ytmp, double *__restrict__ cb) {
   __shared__ double part[4][64];
-  __shared__ double ysh[128];
+  __shared__ double ysh[256];
   const int node = gslabs[2 * blockIdx.x], slab = gslabs[2 * blockIdx.x + 1];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
@@ -2096,7 +2102,7 @@ __global__ void __launch_bounds__(256)
 k_solve_bwd_a(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ linv,
               const long long *__restrict__ linv_off, const int *__restrict__ lperm,
               const double *__restrict__ vtmp, double *__restrict__ xsol) {
-  __shared__ double v[128], z[128];
+  __shared__ double v[256], z[256];
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node];
   const int e0 = T.piv_start[node];
@@ -2122,7 +2128,7 @@ k_solve_fwd(DevTree T, const int *__restrict__ gslabs, const double *__restrict_
             const double *__restrict__ dinv, const int *__restrict__ ptype, const int *__restrict__ lperm,
             const double *__restrict__ rhs, double *__restrict__ xsol, double *__restrict__ ytmp,
             double *__restrict__ cb) {
-  __shared__ double t1[128], tp[128], y[128], cbs[64], part[4][64];
+  __shared__ double t1[256], tp[256], y[256], cbs[64], part[4][64];
   const int node = gslabs[2 * blockIdx.x], slab = gslabs[2 * blockIdx.x + 1];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
@@ -2131,7 +2137,7 @@ k_solve_fwd(DevTree T, const int *__restrict__ gslabs, const double *__restrict_
   const double *L = panel + T.panel_off[node] + p;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int i = slab * 64 + lane;
-  double l[32];  // L21(i, wave + 4u), p <= 128
+  double l[32];  // L21(i, wave + 4u) of the first 128 pivots (requested before anything else)
 #pragma unroll
   for (int u = 0; u < 32; u++) {
     const int k = wave + 4 * u;
@@ -2175,6 +2181,19 @@ k_solve_fwd(DevTree T, const int *__restrict__ gslabs, const double *__restrict_
   for (int u = 0; u < 32; u++) {
     const int k = wave + 4 * u;
     if (4 * u < p) a4[u & 3] += (i < b && k < p) ? l[u] * y[k] : 0.0;
+  }
+  if (p > 128) {  // block-uniform: the pivots behind the first 128
+    double l2[32];
+#pragma unroll
+    for (int u = 0; u < 32; u++) {
+      const int k = 128 + wave + 4 * u;
+      l2[u] = L[(i < b && k < p) ? (long long)k * F + i : -(long long)p];
+    }
+#pragma unroll
+    for (int u = 0; u < 32; u++) {
+      const int k = 128 + wave + 4 * u;
+      if (128 + 4 * u < p) a4[u & 3] += (i < b && k < p) ? l2[u] * y[k] : 0.0;
+    }
   }
   part[wave][lane] = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   __syncthreads();

@@ -19,15 +19,13 @@ for p in [int(a) for a in sys.argv[1:]] or [80, 128, 160]:
             a = s[2 + 5 * k: 7 + 5 * k]
             prev = s[1] if k == 0 else s[6 + 5 * (k - 1)]
             print(f"   panel {k}: prologue {a[0] - prev}  solve {a[1] - a[0]}  test + next block row {a[2] - a[1]}  rest of the update | next elimination {a[3] - a[2]}  sync {a[4] - a[3]}")
-        w = out["counters"][63:63 + 64].astype(np.int64).reshape(16, 4)
-        t0 = s[3 + 5 * 3]  # thread 0 behind the barrier in front of the test of panel 3
-        print("   panel 3 per wavefront (test done, update / elimination done, published, behind the barrier), relative to thread 0 behind the barrier in front of the test:")
+        import ctypes as C
+        from hqp_amd import _lib
+        buf = (C.c_int * 256)()
+        _lib.lib().hqpkkt_debug_fb_stamps(buf)
+        w = np.array(buf[:], dtype=np.int64).reshape(16, 16)[:, :9]
+        names = "top | operands of the wavefront | solve / next diagonal block | barrier | test | update / elimination | published | L, pivot data | barrier"
+        print("   panel 3 per wavefront, cycles between: " + names)
         for wv in range(16):
             if w[wv].any():
-                print(f"      wave {wv:2d}: " + "  ".join(str(int(x - t0)) for x in w[wv]))
-        w2 = out["counters"][95:95 + 32].astype(np.int64).reshape(8, 4)
-        t4 = s[4 + 5 * 3]
-        print("   panel 3, second pass, slots 0 and 1 per wavefront (operands there, products done), relative to the barrier:")
-        for wv in range(8):
-            if w2[wv].any():
-                print(f"      wave {wv:2d}: " + "  ".join(str(int(x - t4)) for x in w2[wv]))
+                print(f"      wave {wv:2d}: " + "  ".join(f"{int(w[wv][j + 1] - w[wv][j]):6d}" for j in range(8)))
