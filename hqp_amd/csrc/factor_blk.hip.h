@@ -63,6 +63,16 @@ __device__ __forceinline__ float row16_max_f(float v) {
   v = fmaxf(v, dpp_move_f<0x128, 0xf>(v));
   return v;
 }
+// max over the 16 lanes of a DPP row of an unsigned (the bits of a non-negative float: a NaN is the largest);
+// the DPP operand inside the max itself (the nops: a DPP read behind a VALU write of the same register)
+__device__ __forceinline__ unsigned row16_max_u(unsigned v) {
+  asm volatile("s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+               "s_nop 1\n\tv_max_u32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf"
+               : "+v"(v));
+  return v;
+}
 // max over the 16 lanes of a DPP row; every lane of the row ends with it
 __device__ __forceinline__ double row16_max(double v) {
   v = fmax(v, dpp_move<0xb1, 0xf>(v));   // quad_perm [1,0,3,2]
@@ -117,16 +127,14 @@ __device__ __forceinline__ void lds_max_pos(double *addr, double v) {
     __builtin_amdgcn_sched_barrier(0);                                                    \
     const bool act = (r > (S)) & ((S) >= off);                                            \
     const double nl = act ? -(g[S] * di) : 0.0;                                           \
-    myd = (r == (S)) ? d : myd, mydi = (r == (S)) ? ((S) >= off ? di : 0.0) : mydi;       \
-    /* the test inside the block (hqp/spBKP.C:431-438), off the chain: lane-local compares, one ballot */ \
-    badm |= __any((int)(act & !(fabs(d) >= alpha * fabs(g[S]))) | (int)(((S) >= off) & !(fabs(d) >= pert))) ? (1u << (S)) : 0u; \
+    /* the test inside the block (hqp/spBKP.C:431-438): |d| >= alpha |column| <=> |multiplier| <= 1 / alpha */ \
+    badm |= __any(!(fabs(nl) <= ialpha)) ? (1u << (S)) : 0u;                              \
     if ((S) < 15) {                                                                       \
       asm volatile("s_nop 1" ::: "memory");                                               \
       FB_FMAC(((S) + 1) & 15, S, nl);                                                     \
       asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" FB_STR(FB_NEXT(S)) " row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(g[((S) + 1) & 15])); \
     }                                                                                     \
     g[S] = act ? nl : g[S];                                                               \
-    Ldg[(S)*17 + r] = nl;                                                                 \
     Lbk[(S)*LD + r] = nl;                                                                 \
     nlp = nl;                                                                             \
   }
@@ -156,14 +164,15 @@ __device__ __forceinline__ void lds_max_pos(double *addr, double v) {
 // triangle is used for the part that is still to be eliminated, columns < off hold
 // entries of M).  Leaves: Tb[s][c] = row s after the elimination (c < s: N resp. the M
 // columns < off, c == s: 1, c > s: U), identity rows for s < off; -L of the block in
-// Ldg[s * 17 + r]; the pivots and their inverses (0 for the pivots in front of `off`); the pivots that failed
+// Lbk[s * LD + r]; the pivots and their inverses (0 for the pivots in front of `off`); the pivots that failed
 // |d| >= alpha |column| against the rows of the block itself or |d| >= pert.  Tn (16 rows of stride LD): N alone,
 // Lbk (likewise): -L, both where the update's operand images keep the columns of this block.
 template <int LD>
-__device__ __forceinline__ void fb_eliminate_block(const double *Gb, double *Tb, double *Ldg, double *Tn, double *Lbk,
+__device__ __forceinline__ void fb_eliminate_block(const double *Gb, double *Tb, double *Tn, double *Lbk,
                                                    double *dvals, double *dinvs, int *bad_in, double alpha,
                                                    double pert, int off, int lane) {
   const int r = lane & 15, grp = lane >> 4;
+  const double ialpha = 1.0 / alpha;
   unsigned int badm = 0;
   double g[16];
 #pragma unroll
@@ -171,13 +180,25 @@ __device__ __forceinline__ void fb_eliminate_block(const double *Gb, double *Tb,
     const int hi = max(r, c), lo = min(r, c);
     g[c] = Gb[(c < off) ? r * 17 + c : hi * 17 + lo];
   }
-  double d, nlp = 0.0, myd = 0.0, mydi = 0.0;
+  double d, nlp = 0.0;
   asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(g[0]));
   FB_STEP(0, -1) FB_STEP(1, 0) FB_STEP(2, 1) FB_STEP(3, 2) FB_STEP(4, 3) FB_STEP(5, 4) FB_STEP(6, 5) FB_STEP(7, 6)
   FB_STEP(8, 7) FB_STEP(9, 8) FB_STEP(10, 9) FB_STEP(11, 10) FB_STEP(12, 11) FB_STEP(13, 12) FB_STEP(14, 13) FB_STEP(15, 14)
   // (step 15 has no row below it: nothing pending)
-  if (grp == 0) dvals[r] = myd, dinvs[r] = mydi;
-  if (lane == 0) *bad_in = (int)badm;  // bit s: pivot s failed against a row of its own block (or is tiny)
+  // the pivot of row r is still the diagonal entry of its own lane; its inverse as the steps computed it
+  double myd = g[0];
+#pragma unroll
+  for (int c = 1; c < 16; c++) myd = (r == c) ? g[c] : myd;
+  double mydi;
+  {
+    const double x = __builtin_amdgcn_rcp(myd);
+    const double e = fma(-myd, x, 1.0);
+    const double e2 = fma(e, e, e);
+    mydi = fma(x, e2, x);
+  }
+  if (grp == 0) dvals[r] = myd, dinvs[r] = r >= off ? mydi : 0.0;
+  badm |= (unsigned int)(__ballot(r >= off && !(fabs(myd) >= pert)) & 0xffffull);
+  if (lane == 0) *bad_in = (int)badm;  // bit s: pivot s failed against a row of its own block, or is tiny
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const double v = (c == r) ? 1.0 : (r < off ? 0.0 : g[c]);
@@ -206,7 +227,7 @@ __device__ int g_fb_stamps[16 * 16];
 #define FBWSTAMP(j)
 #endif
 
-template <int NW, int NS, int LD, int WPE>
+template <int NW, int NS, int LD, int WPE, bool OWNSIMD>
 __global__ void __launch_bounds__(64 * NW, WPE)
 k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
              double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
@@ -218,11 +239,12 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   // The last wavefront eliminates the diagonal blocks and holds no block.  The fp64 multiply-adds of its chain and
   // the fp64 matrix products of the others run on the same units of a SIMD: the wavefronts that share its SIMD
   // (every fourth) hold no block either.
-  constexpr int NT = 64 * NW, NWK = NW - NW / 4;
+  constexpr int NT = 64 * NW, NWK = OWNSIMD ? NW - NW / 4 : NW - 1;
   constexpr int ld = LD;
   const int node = level_nodes[blockIdx.x];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
+  const int Fi = p + b;
   const int e0 = T.piv_start[node];
   double *P = panel + T.panel_off[node];
   double *W = linv + linv_off[node];  // p x p column-major
@@ -247,25 +269,31 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const bool is_ge = wave == NW - 1;
-  const bool is_worker = (wave & 3) != 3;
-  const int wrank = wave - (wave >> 2);  // rank among the wavefronts that hold blocks
+  const bool is_worker = OWNSIMD ? (wave & 3) != 3 : !is_ge;
+  const int wrank = OWNSIMD ? wave - (wave >> 2) : wave;  // rank among the wavefronts that hold blocks
   if (is_ge) __builtin_amdgcn_s_setprio(3);  // its chain of dependent operations is the critical path of a panel
   const int ln0 = lane & 15, lg0 = lane >> 4;
   int ln = ln0, lg = lg0;
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
   const int nslots = nb * (nb + 1) / 2;
 
-  // ---- this wavefront's blocks: slot t = wrank + NWK s, block rows from the last one up
-  int sI[NS], sJ[NS];
-#pragma unroll
-  for (int s = 0; s < NS; s++) {
-    const int t = wrank + NWK * s;
-    int I = nb - 1, base = 0;
-    while (I >= 0 && t >= base + I + 1) base += I + 1, I--;
-    const bool have = is_worker && t < nslots;
-    sI[s] = have ? I : -1;
-    sJ[s] = have ? t - base : -1;
+  // ---- this wavefront's blocks: slot t = wrank + NWK s, block rows from the last one up.  Lane s of the
+  // wavefront keeps (block row, block column) of slot s: which slots a step concerns is one ballot (a list of NS
+  // pairs in scalar registers, compared slot by slot in every step of every panel, cost more instructions than
+  // the work itself), the pair of a slot that takes part comes by v_readlane.
+  int myI = -1, myJ = -1;
+  {
+    const int t = wrank + NWK * lane;
+    if (is_worker && lane < NS && t < nslots) {
+      int I = nb - 1, base = 0;
+      while (t >= base + I + 1) base += I + 1, I--;
+      myI = I, myJ = t - base;
+    }
   }
+#define SLOT_I(s) __builtin_amdgcn_readlane(myI, (s))
+#define SLOT_J(s) __builtin_amdgcn_readlane(myJ, (s))
+#define SLOT_IN(mask, s) (((mask) >> (s)) & 1u)
+  const unsigned m_all = (unsigned)__ballot(myI >= 0);
   FBSTAMP(0);
   double4_t R[NS];
   // ---- load: lower triangle of the block (+ the mirror image inside the diagonal
@@ -273,13 +301,13 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
 #pragma unroll
   for (int s = 0; s < NS; s++) {
     R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
-    if (sI[s] < 0) continue;
-    const int i = 16 * sI[s] + ln;
+    if (!SLOT_IN(m_all, s)) continue;
+    const int i = 16 * SLOT_I(s) + ln, c0 = 16 * SLOT_J(s) + lg;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int c = 16 * sJ[s] + lg + 4 * q;
+      const int c = c0 + 4 * q;
       const int hi = max(i, c), lo = min(i, c);
-      const double v = P[hi < p ? (long long)lo * F + hi : 0];
+      const double v = P[hi < p ? lo * Fi + hi : 0];  // (32-bit offsets: a front has fewer than 2^31 entries)
       R[s][q] = hi < p ? v : (hi == lo ? 1.0 : 0.0);
     }
   }
@@ -289,19 +317,19 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     const double *Uc = upd + T.upd_off[ch];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-      if (sI[s] < 0) continue;
-      const int i = 16 * sI[s] + ln;
+      if (!SLOT_IN(m_all, s)) continue;
+      const int i = 16 * SLOT_I(s) + ln, c0 = 16 * SLOT_J(s) + lg;
       const int ci = i < p ? iv[i] : -1;
       int cj[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const int c = 16 * sJ[s] + lg + 4 * q;
+        const int c = c0 + 4 * q;
         cj[q] = c < p ? iv[c] : -1;
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const bool ok = ci >= 0 && cj[q] >= 0;
-        const double v = Uc[ok ? (long long)min(ci, cj[q]) * bc + max(ci, cj[q]) : 0];
+        const double v = Uc[ok ? min(ci, cj[q]) * bc + max(ci, cj[q]) : 0];
         R[s][q] += ok ? v : 0.0;
       }
     }
@@ -312,48 +340,47 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   // against, SOFT_PIVOT_REL; fp32 is plenty for that): non-negative floats order like their bits
 #pragma unroll
   for (int s = 0; s < NS; s++) {
-    if (sI[s] < 0) continue;
+    if (!SLOT_IN(m_all, s)) continue;
+    const int I_ = SLOT_I(s), J_ = SLOT_J(s);
     float vi = 0.0f;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const float a = fabsf((float)R[s][q]);
       vi = fmaxf(vi, a);
       const float vc = row16_max_f(a);
-      if (ln == 0) atomicMax((unsigned int *)&rm0[16 * sJ[s] + lg + 4 * q], (unsigned int)__float_as_int(vc));
+      if (ln == 0) atomicMax((unsigned int *)&rm0[16 * J_ + lg + 4 * q], (unsigned int)__float_as_int(vc));
     }
-    atomicMax((unsigned int *)&rm0[16 * sI[s] + ln], (unsigned int)__float_as_int(vi));
+    atomicMax((unsigned int *)&rm0[16 * I_ + ln], (unsigned int)__float_as_int(vi));
   }
   __syncthreads();
 
   // Block row `row`: its rows of M (as they stand) to Yb; diag: its diagonal block as rows to Gb (the
   // elimination reads it next)
   auto publish_block_row = [&](int row, bool diag) {
+    const unsigned m = (unsigned)__ballot(myI == row && (diag || myJ != row));
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-      if (sI[s] != row) continue;
-      if (sJ[s] == row) {
-        if (diag) {
+      if (!SLOT_IN(m, s)) continue;
+      const int J_ = SLOT_J(s);
+      if (J_ == row) {
 #pragma unroll
-          for (int q = 0; q < 4; q++) Gb[ln * 17 + lg + 4 * q] = R[s][q];
-        }
+        for (int q = 0; q < 4; q++) Gb[ln * 17 + lg + 4 * q] = R[s][q];
       } else {
+        double *y = Yb + (ln * ld + 16 * J_ + lg);
 #pragma unroll
-        for (int q = 0; q < 4; q++) Yb[ln * ld + 16 * sJ[s] + lg + 4 * q] = R[s][q];
+        for (int q = 0; q < 4; q++) y[4 * q] = R[s][q];
       }
     }
   };
   // the two blocks of block row `row` the elimination wavefront starts its next block from (register images)
   auto publish_start_blocks = [&](int row) {
+    const unsigned m = (unsigned)__ballot(myI == row && myJ >= row - 1);
 #pragma unroll
     for (int s = 0; s < NS; s++) {
-      if (sI[s] != row) continue;
-      if (sJ[s] == row) {
+      if (!SLOT_IN(m, s)) continue;
+      double *d = SLOT_J(s) == row ? G2 : Ab;
 #pragma unroll
-        for (int q = 0; q < 4; q++) G2[64 * q + lane] = R[s][q];
-      } else if (sJ[s] == row - 1) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) Ab[64 * q + lane] = R[s][q];
-      }
+      for (int q = 0; q < 4; q++) d[64 * q + lane] = R[s][q];
     }
   };
 
@@ -369,9 +396,12 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     // block list is computed in front of the loop and kept - hundreds of values, spilt)
     ln = ln0, lg = lg0;
     asm volatile("" : "+v"(ln), "+v"(lg), "+v"(tid), "+v"(lane));
-#pragma unroll
-    for (int s = 0; s < NS; s++) asm volatile("" : "+s"(sI[s]), "+s"(sJ[s]));
+    asm volatile("" : "+v"(myI), "+v"(myJ));
     const int kb = k >> 4, off = k & 15, kend = min(16, p - 16 * kb);
+    // which slots the steps of this panel concern
+    const unsigned m_solve = (unsigned)__ballot(myJ == kb && myI > kb);            // blocks below the diagonal block
+    const unsigned m_mrow = (unsigned)__ballot(myI == kb && myJ < kb && myJ >= 0);  // the pivot rows of M
+    const unsigned m_live = (unsigned)__ballot(myI >= kb);
     // ================= panel: pivots off .. 15 of block kb without interchanges =============
     if (!hot) {
       publish_block_row(kb, true);
@@ -379,7 +409,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       fb_barrier();
       if (is_ge) {
         if (lane < 16) cmaxf[16 * par + lane] = 0.0f;
-        fb_eliminate_block<LD>(Gb, Tb + 272 * par, Ldg + 272 * par, Xq + 32 + 16 * par, Xq + 16 * par, dvals + 16 * par,
+        fb_eliminate_block<LD>(Gb, Tb + 272 * par, Xq + 32 + 16 * par, Xq + 16 * par, dvals + 16 * par,
                                dinvs + 16 * par, badin + par, alpha, pert, off, lane);
         // (this wavefront holds no block: telling the compiler so frees the registers of R for the elimination)
 #pragma unroll
@@ -389,33 +419,33 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     }
     FBSTAMP(2 + 5 * npan);
     FBWSTAMP(0);
-    const double *Tp = Tb + 272 * par, *Lp = Ldg + 272 * par, *dvp = dvals + 16 * par, *dip = dinvs + 16 * par;
+    const double *Tp = Tb + 272 * par, *dvp = dvals + 16 * par, *dip = dinvs + 16 * par;
     const double *Tnq = Xq + 32 + 16 * par, *Ldq = Xq + 16 * par;
     float *cmp = cmaxf + 16 * par;
     // ---- C' = N A' for the blocks below the diagonal block, M rows <- N (M rows); the elimination wavefront:
     // the next diagonal block as this panel leaves it.  N (row ln, columns lg + 4 q: the A operand of the first
     // product, the B operand of the second) and D^-1 once per wavefront.
-    {
-      double tn[4], tna[4], dvi[4];
+    if (is_ge || (m_solve | m_mrow)) {
+      double tn[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = lg + 4 * q;
         const double t = Tp[ln * 17 + c];
         tn[q] = (c <= ln && (c >= off || c == ln)) ? t : 0.0;  // (rows in front of `off` are rows of the identity)
-        tna[q] = ln >= off ? tn[q] : 0.0;
-        dvi[q] = dip[c];                                        // (0 in front of `off`)
       }
+      const bool rowon = ln >= off;  // (as the A operand of C' = N A': no pivot in front of `off`)
       FBWSTAMP(1);
       if (is_ge) {
         if (kb + 1 < nb) {
           // Ahead of the test: with the whole panel accepted the block (kb+1, kb+1) becomes G - L C' with
           // C' = N (block (kb+1, kb))', both in registers as the accumulator layout of the products wants them
           double4_t A_, G_;
+          double dvi[4];
 #pragma unroll
-          for (int q = 0; q < 4; q++) A_[q] = Ab[64 * q + lane], G_[q] = G2[64 * q + lane];
+          for (int q = 0; q < 4; q++) A_[q] = Ab[64 * q + lane], G_[q] = G2[64 * q + lane], dvi[q] = dip[lg + 4 * q];
           double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-          for (int q = 0; q < 4; q++) acc = mfma_f64(tna[q], A_[q], acc);
+          for (int q = 0; q < 4; q++) acc = mfma_f64(rowon ? tn[q] : 0.0, A_[q], acc);
 #pragma unroll
           for (int q = 0; q < 4; q++) G_ = mfma_f64(acc[q], -(acc[q] * dvi[q]), G_);
 #pragma unroll
@@ -424,35 +454,34 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       } else {
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-          if (sJ[s] == kb && sI[s] > kb) {
+          if (SLOT_IN(m_solve, s)) {
+            double dvi[4];  // D^-1 (0 in front of `off`)
+#pragma unroll
+            for (int q = 0; q < 4; q++) dvi[q] = dip[lg + 4 * q];
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-            for (int q = 0; q < 4; q++) acc = mfma_f64(tna[q], R[s][q], acc);
-            const int row = 16 * sI[s] + ln;
+            for (int q = 0; q < 4; q++) acc = mfma_f64(rowon ? tn[q] : 0.0, R[s][q], acc);
+            const int row = 16 * SLOT_I(s) + ln;
             double *o = Op + (lg * ld + row), *l = Lb + (lg * ld + row);
-            double *pc = P + ((long long)(16 * kb + lg) * F + row);  // L11 column 16 kb + lg (+ 4 q), this row
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               // acc[q] = C(row ln of block I, pivot lg + 4 q); zero for the pivots in front of `off`
-              const double lq = acc[q] * dvi[q];
               o[4 * q * ld] = acc[q];
-              l[4 * q * ld] = -lq;
-              // (ahead of the test: the column of a pivot that is rejected is written again when it is eliminated)
-              if (lg + 4 * q >= off && 16 * kb + lg + 4 * q < p && row < p) pc[4 * q * F] = lq;
-              // column maxima in fp32 (a NaN counts as infinite)
-              const float av = (acc[q] == acc[q]) ? fabsf((float)acc[q]) : __int_as_float(0x7f800000);
-              const float v = row16_max_f(av);
-              if (ln == 0) atomicMax((unsigned int *)&cmp[lg + 4 * q], (unsigned int)__float_as_int(v));
+              l[4 * q * ld] = -(acc[q] * dvi[q]);
+              // column maxima in fp32, compared as bit patterns (a NaN is the largest)
+              const unsigned v = row16_max_u(__float_as_uint((float)acc[q]) & 0x7fffffffu);
+              if (ln == 0) atomicMax((unsigned int *)&cmp[lg + 4 * q], v);
             }
-          } else if (sI[s] == kb && sJ[s] >= 0 && sJ[s] < kb) {
-            const double *y = Yb + (lg * ld + 16 * sJ[s] + ln);
+          } else if (SLOT_IN(m_mrow, s)) {
+            const int J_ = SLOT_J(s);
+            const double *y = Yb + (lg * ld + 16 * J_ + ln);
             double a[4];
 #pragma unroll
             for (int q = 0; q < 4; q++) a[q] = y[4 * q * ld];  // A operand: m = ln (column of block j), k = lg + 4 q
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 4; q++) acc = mfma_f64(a[q], tn[q], acc);
-            double *o = Op + (ln * ld + 16 * sJ[s] + lg);
+            double *o = Op + (ln * ld + 16 * J_ + lg);
 #pragma unroll
             for (int q = 0; q < 4; q++) o[4 * q] = acc[q];
           }
@@ -480,7 +509,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     if (la && is_ge) {
       if (lane < 16) cmaxf[16 * (par ^ 1) + lane] = 0.0f;
 #ifndef FB_SKIP_GE  // (timing experiments only: wrong results)
-      fb_eliminate_block<LD>(Gb, Tb + 272 * (par ^ 1), Ldg + 272 * (par ^ 1), Xq + 32 + 16 * (par ^ 1), Xq + 16 * (par ^ 1),
+      fb_eliminate_block<LD>(Gb, Tb + 272 * (par ^ 1), Xq + 32 + 16 * (par ^ 1), Xq + 16 * (par ^ 1),
                              dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1), badin + (par ^ 1), alpha, pert, 0, lane);
 #endif
 #pragma unroll
@@ -492,16 +521,23 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       // from Lb (the panel's own block row: what the elimination left).
 #pragma unroll
       for (int s = 0; s < NS; s++) {
-        if (sI[s] < kb) continue;  // (also the empty slots: -1)
-        const double *ab = sJ[s] == kb ? Tnq + (lg * ld + ln) : Op + (lg * ld + 16 * sJ[s] + ln);
-        const double *lb = sI[s] == kb ? Ldq + (lg * ld + ln) : Lb + (lg * ld + 16 * sI[s] + ln);
+        if (!SLOT_IN(m_live, s)) continue;
+        const int I_ = SLOT_I(s), J_ = SLOT_J(s);
+        const double *ab = J_ == kb ? Tnq + (lg * ld + ln) : Op + (lg * ld + 16 * J_ + ln);
+        const double *lb = I_ == kb ? Ldq + (lg * ld + ln) : Lb + (lg * ld + 16 * I_ + ln);
         double a[4], l[4];
 #pragma unroll
         for (int q = 0; q < 4; q++) a[q] = ab[4 * q * ld], l[q] = lb[4 * q * ld];
         double4_t acc = R[s];
-        if (sJ[s] == kb) {  // the eliminated columns of the panel's own block turn into columns of M: from zero
+        if (J_ == kb) {  // the eliminated columns of the panel's own block turn into columns of M: from zero
 #pragma unroll
           for (int q = 0; q < 4; q++) acc[q] = (lg + 4 * q < off) ? acc[q] : 0.0;
+          if (I_ > kb && 16 * I_ + ln < p) {  // and its B operand is the block's part of the L11 columns of the panel
+            double *pc = P + ((16 * kb + lg) * Fi + 16 * I_ + ln);
+#pragma unroll
+            for (int q = 0; q < 4; q++)
+              if (lg + 4 * q >= off && 16 * kb + lg + 4 * q < p) pc[4 * q * Fi] = -l[q];
+          }
         }
 #ifndef FB_SKIP_UPD  // (timing experiments only: wrong results)
 #pragma unroll
@@ -528,22 +564,25 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         km[q] = sp >= off && sp < done;
         const double t = Tp[sp * 17 + ln];
         town[q] = (!km[q] || (ln > sp && ln < done)) ? 0.0 : t;
-        ldg[q] = km[q] ? Lp[sp * 17 + ln] : 0.0;
+        ldg[q] = km[q] ? Ldq[sp * ld + ln] : 0.0;
       }
 #pragma unroll
       for (int s = 0; s < NS; s++) {
-        if (sI[s] < kb) continue;
-        const bool own = sJ[s] == kb, dgr = sI[s] == kb;
-        const double *o = Op + (lg * ld + 16 * sJ[s] + ln);
-        const double *lb = Lb + (lg * ld + 16 * sI[s] + ln);
+        if (!SLOT_IN(m_live, s)) continue;
+        const int I_ = SLOT_I(s), J_ = SLOT_J(s);
+        const bool own = J_ == kb, dgr = I_ == kb;
+        const double *o = Op + (lg * ld + 16 * J_ + ln);
+        const double *lb = Lb + (lg * ld + 16 * I_ + ln);
         double4_t acc = R[s];
         if (own) {  // the columns of the accepted pivots turn into columns of M: from zero
 #pragma unroll
           for (int q = 0; q < 4; q++) acc[q] = km[q] ? 0.0 : acc[q];
         }
+        double *pc = P + ((16 * kb + lg) * Fi + 16 * I_ + ln);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const double ta = o[4 * q * ld], tl = lb[4 * q * ld];
+          if (own && !dgr && km[q] && 16 * I_ + ln < p) pc[4 * q * Fi] = -tl;  // L11 columns of the accepted pivots
           const double a = own ? town[q] : (km[q] ? ta : 0.0);
           const double l = dgr ? ldg[q] : (km[q] ? tl : 0.0);
           acc = mfma_f64(a, l, acc);
@@ -557,7 +596,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       if (tid < 256) {
         const int sp = tid >> 4, rr = tid & 15;
         if (sp >= off && sp < done && rr > sp && 16 * kb + rr < p)
-          P[(long long)(16 * kb + sp) * F + 16 * kb + rr] = -Lp[sp * 17 + rr];
+          P[(16 * kb + sp) * Fi + 16 * kb + rr] = -Ldq[sp * ld + rr];
       }
       if (tid >= off && tid < done) dv[2 * (16 * kb + tid)] = dip[tid], dv[2 * (16 * kb + tid) + 1] = 0.0, pt[16 * kb + tid] = 0;
     }
@@ -584,11 +623,11 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       auto publish_rows = [&](double *vec1, int g1, double *vec2, int g2) {
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-          if (sI[s] >= kb) {
-            const int i = 16 * sI[s] + ln;
+          if (SLOT_IN(m_live, s)) {
+            const int i = 16 * SLOT_I(s) + ln, c0 = 16 * SLOT_J(s) + lg;
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              const int c = 16 * sJ[s] + lg + 4 * q;
+              const int c = c0 + 4 * q;
               const double v = R[s][q];
               // (the mirror image inside a diagonal block is not used; entry ld - 1 of a vector is nobody's:
               // stores without a match go there instead of behind a branch each)
@@ -734,12 +773,12 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         const double *Vp1 = (p1 == k) ? V0 : V2;
 #pragma unroll
         for (int s = 0; s < NS; s++) {
-          if (sI[s] >= kb) {
-            const int i = 16 * sI[s] + ln;
+          if (SLOT_IN(m_live, s)) {
+            const int i = 16 * SLOT_I(s) + ln, c0 = 16 * SLOT_J(s) + lg;
             const double l1 = V5[i], l2 = V6[i];
 #pragma unroll
             for (int q = 0; q < 4; q++) {
-              const int c = 16 * sJ[s] + lg + 4 * q;
+              const int c = c0 + 4 * q;
               double v = R[s][q];
               if (swp) {
                 if (c < k) {
@@ -777,14 +816,15 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   // ---- M = L11^-1: every block row is complete (zeros above the diagonal inside the diagonal blocks)
 #pragma unroll
   for (int s = 0; s < NS; s++) {
-    if (sI[s] < 0) continue;
-    const int row = 16 * sI[s] + ln;
+    if (!SLOT_IN(m_all, s)) continue;
+    const int I_ = SLOT_I(s), J_ = SLOT_J(s);
+    const int row = 16 * I_ + ln;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const int cl = lg + 4 * q, col = 16 * sJ[s] + cl;
+      const int cl = lg + 4 * q, col = 16 * J_ + cl;
       double v = R[s][q];
-      if (sJ[s] == sI[s]) v = cl < ln ? v : (cl == ln ? 1.0 : 0.0);
-      if (row < p && col < p) W[(long long)col * p + row] = v;
+      if (J_ == I_) v = cl < ln ? v : (cl == ln ? 1.0 : 0.0);
+      if (row < p && col < p) W[col * p + row] = v;
     }
   }
   __syncthreads();

@@ -17,6 +17,9 @@
 #include "staged_plan.hpp"
 #include "kernels.hip.h"
 #include "factor_blk.hip.h"
+#ifndef FB_OWNSIMD
+#define FB_OWNSIMD false  // true: the elimination wavefront of k_factor_blk shares its SIMD with no block-holding wavefront (measured slower)
+#endif
 #include "ipdriver.hip.h"
 #include "staged.hip.h"
 
@@ -431,8 +434,8 @@ static int upload(hqpkkt_t *h) {
     static size_t a_diag = 0, a_panel = 0, a_bwdb = 0, a_blk = 0;
     std::lock_guard<std::mutex> lk(attr_mutex);
     if (lds_blk > a_blk) {
-      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
-      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 7, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
       a_blk = lds_blk;
     }
     if (h->lds_diag > a_diag) {
@@ -603,11 +606,11 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
         // 16 wavefronts for up to 256
         const int lmp = h->level_maxp[which][l];
         if (lmp <= 128)
-          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<8, 6, 144, 4><<<nn - nfs - nsm, 512, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<8, 6, 144, 2, FB_OWNSIMD><<<nn - nfs - nsm, 512, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
         else
-          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<16, 7, 208, 4><<<nn - nfs - nsm, 1024, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<12, 8, 208, 3, FB_OWNSIMD><<<nn - nfs - nsm, 768, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
       }
@@ -2526,8 +2529,8 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
   const size_t lds_old = (std::max<size_t>(ldm * mpd, 2 * FD_PLD * FD_PANEL) + 5 * 128 + 2 * mpd) * sizeof(double) + 2 * mpd * sizeof(int) + 16;
   if (variant == 1)
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_old, 64 * 1024)));
-  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(128)));
-  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<16, 7, 208, 4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(128)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -2538,10 +2541,10 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
       k_factor_diag<<<1, FD_THREADS, lds_old, 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p, d_loff.p,
                                                   alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
     else if (variant == 0 && p <= 128)
-      k_factor_blk<8, 6, 144, 4><<<1, 512, fb_lds_bytes(p), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+      k_factor_blk<8, 6, 144, 2, FB_OWNSIMD><<<1, 512, fb_lds_bytes(p), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                         d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
     else
-      k_factor_blk<16, 7, 208, 4><<<1, 1024, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+      k_factor_blk<12, 8, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                           d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
   }
   HIPCHK(hipEventRecord(e1, 0));

@@ -24,7 +24,7 @@ __global__ void ge_probe(const double *G, double *out, unsigned long long *st, i
   const bool ge = threadIdx.x >= blockDim.x - 64;
   T0();
   for (int it = 0; it < iters; it++) {
-    if (ge) fb_eliminate_block<208>(Gb, Tb, Ldg, Xq + 32, Xq, dv, di, bad, 0.64, 1e-300, 0, threadIdx.x & 63);
+    if (ge) fb_eliminate_block<208>(Gb, Tb, Xq + 32, Xq, dv, di, bad, 0.64, 1e-300, 0, threadIdx.x & 63);
     fb_barrier();
   }
   T1(slot);
