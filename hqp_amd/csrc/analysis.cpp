@@ -1069,6 +1069,13 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     // systems) is processed by one wavefront per supernode that does extend-add,
     // pivot block, panel and update in one kernel (and the solves likewise)
     auto fsmall = [&](int id) { return small_fronts && npiv[id] <= SMALL_PIVOTS && nbor[id] <= SMALL_BORDER; };
+    // The one-wavefront pivot-block kernel pays where a level holds many blocks of a few pivots; a handful of them
+    // (the remainder pieces of a cut separator next to blocks of 150 pivots) would be a launch of their own on the
+    // critical path: they go with the general blocks of the level.
+    std::vector<int> nsmall_level(nlevels, 0);
+    for (int id = 0; id < nnodes; id++)
+      if (keep(id) && !fsmall(id) && npiv[id] <= SMALL_PIVOTS) nsmall_level[level[id]]++;
+    auto smallblk = [&](int id) { return !fsmall(id) && npiv[id] <= SMALL_PIVOTS && nsmall_level[level[id]] >= 64; };
     {
       // order inside a level: small fronts, then the other supernodes with at most
       // SMALL_PIVOTS pivots (one-wavefront pivot-block kernel), then the rest
@@ -1078,18 +1085,18 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       S.level_fsmall.assign(nlevels, 0);
       for (int l = 0; l < nlevels; l++) S.level_fsmall[l] = fill[l] - S.level_ptr[l];
       for (int id = 0; id < nnodes; id++)
-        if (keep(id) && !fsmall(id) && npiv[id] <= SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
+        if (keep(id) && smallblk(id)) S.level_nodes[fill[level[id]]++] = id;
       S.level_small.assign(nlevels, 0);
       for (int l = 0; l < nlevels; l++) S.level_small[l] = fill[l] - S.level_ptr[l] - S.level_fsmall[l];
       for (int id = 0; id < nnodes; id++)
-        if (keep(id) && npiv[id] > SMALL_PIVOTS) S.level_nodes[fill[level[id]]++] = id;
+        if (keep(id) && !fsmall(id) && !smallblk(id)) S.level_nodes[fill[level[id]]++] = id;
       S.level_fs_p.assign(nlevels, 1), S.level_fs_b.assign(nlevels, 1), S.level_sm_p.assign(nlevels, 1);
       for (int id = 0; id < nnodes; id++) {
         if (!keep(id) || npiv[id] > SMALL_PIVOTS) continue;
         const int l = level[id];
         if (fsmall(id))
           S.level_fs_p[l] = std::max(S.level_fs_p[l], npiv[id]), S.level_fs_b[l] = std::max(S.level_fs_b[l], nbor[id]);
-        else
+        else if (smallblk(id))
           S.level_sm_p[l] = std::max(S.level_sm_p[l], npiv[id]);
       }
     }

@@ -342,15 +342,15 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   for (int s = 0; s < NS; s++) {
     if (!SLOT_IN(m_all, s)) continue;
     const int I_ = SLOT_I(s), J_ = SLOT_J(s);
-    float vi = 0.0f;
+    unsigned vi = 0u;  // (bit patterns of the fp32 magnitudes: they order like the values)
 #pragma unroll
     for (int q = 0; q < 4; q++) {
-      const float a = fabsf((float)R[s][q]);
-      vi = fmaxf(vi, a);
-      const float vc = row16_max_f(a);
-      if (ln == 0) atomicMax((unsigned int *)&rm0[16 * J_ + lg + 4 * q], (unsigned int)__float_as_int(vc));
+      const unsigned a = __float_as_uint((float)R[s][q]) & 0x7fffffffu;
+      vi = max(vi, a);
+      const unsigned vc = row16_max_u(a);
+      if (ln == 0) atomicMax((unsigned int *)&rm0[16 * J_ + lg + 4 * q], vc);
     }
-    atomicMax((unsigned int *)&rm0[16 * I_ + ln], (unsigned int)__float_as_int(vi));
+    atomicMax((unsigned int *)&rm0[16 * I_ + ln], vi);
   }
   __syncthreads();
 
