@@ -39,6 +39,33 @@ FP64_PEAK_TFLOPS = 78.6   # MI355X fp64 vector == fp64 MFMA peak (SURVEY.md 7, 8
 HBM_PEAK_GBS = 8000.0     # /opt/skills/guides/MI355X_MICROARCH.md
 
 
+class Watchdog:
+    """N > 1: every phase that can wait for another rank (rendezvous, communicator creation, the first collectives)
+    runs under a deadline.  A rank that is still inside when it expires says where and leaves with status 86:
+    torchrun then ends the other ranks, so that a hang becomes a failed run with a message within minutes (the
+    parent in launch_ranks may then try once more with the other transport).  Never re-execs anything."""
+
+    def __init__(self, rank):
+        self.rank, self._t = rank, None
+
+    def arm(self, seconds, what):
+        import threading
+        self.disarm()
+
+        def fire():
+            print(f"bench: rank {self.rank} still in '{what}' after {seconds} s - giving up (exit 86)", file=sys.stderr, flush=True)
+            os._exit(86)
+
+        self._t = threading.Timer(seconds, fire)
+        self._t.daemon = True
+        self._t.start()
+
+    def disarm(self):
+        if self._t is not None:
+            self._t.cancel()
+            self._t = None
+
+
 def class_work(struct, rank=None):
     """Algorithmic work per numeric factorisation, split by kernel class, from the
     symbolic structure (p pivots, b border rows per supernode); flops count a
@@ -417,12 +444,16 @@ def bench_c4(args):
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dog = Watchdog(rank)
+    if world > 1:
+        dog.arm(args.watchdog, "process group rendezvous")
     if args.share_gpu and world > 1:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group(args.backend)
     else:
         kdist.init(args.backend)
+    dog.disarm()
     from hqp_amd import ipmatrix
     K, nx, nu = args.stages, args.nx, args.nu
     # N > 1: ONE system over the ranks (strong scaling) unless --replicas
@@ -434,6 +465,7 @@ def bench_c4(args):
         # every rank must hold the SAME system: the device generators should agree (same seed, same kind of
         # GPU); if a checksum says otherwise, rank 0's blocks are broadcast
         import torch.distributed as tdist
+        dog.arm(args.watchdog, "first collectives / communicator of the sharded system")
         chk = torch.stack([blk.sum() for blk in dq.F]).sum().reshape(1)
         lo, hi = chk.clone(), chk.clone()
         if args.backend != "nccl":
@@ -467,6 +499,7 @@ def bench_c4(args):
             transport = f"torch.distributed ({args.backend}) behind the exchange callback"
             import torch.distributed as tdist
             comm_ranks = tdist.get_world_size()
+        dog.disarm()
     mat = ipmatrix.IpLQDOCP(device=local_rank, device_vectors=True, shard=shard)
     t0 = time.perf_counter()
     mat.init_dense(dq)
@@ -484,6 +517,8 @@ def bench_c4(args):
         mat.factor(None, z, w)
         return mat.solve(None, z, w, *r, *d)
 
+    if world > 1:  # (a C4 step takes about a second: minutes mean a rank is waiting for one that is not coming)
+        dog.arm(max(args.watchdog, 60 + 20 * (args.warmup + args.steps)), "warm-up and timed steps")
     for _ in range(args.warmup):
         step()
     kdist.fence()
@@ -492,6 +527,7 @@ def bench_c4(args):
         res = step()
     kdist.fence()
     elapsed = kdist.max_over_ranks(time.perf_counter() - t0)
+    dog.disarm()
     st = mat.stats()
     all_devices = None
     if one:  # which GPU every rank computed on (the bench line shows that N ranks meant N GPUs)
@@ -523,6 +559,48 @@ def bench_c4(args):
         step()
     prof = mat.profile()
     mat.set_profile(False)
+    per_rank, replicas = None, None
+    if one:
+        # One SCALE run should yield the curve AND its explanation: per rank the device time of the products and of
+        # the exchange (its place in the stream to its completion = the wait for the slowest rank + the transfer) ...
+        import torch.distributed as tdist
+        mine = {"rank": rank, "ms_products": (prof.get("staged_gemm", (0, 0))[0] + prof.get("staged_gemm_upd", (0, 0))[0]) / nprof,
+                "ms_exchange_wait": prof.get("exchange", (0, 0))[0] / nprof,
+                "ms_control_sized_chain": prof.get("staged_small", (0, 0))[0] / nprof,
+                "ms_factor": st["ms_factor"], "ms_solve": st["ms_solve"]}
+        per_rank = [None] * world
+        tdist.all_gather_object(per_rank, mine)
+        # ... and, from a second timed pass, the aggregate of N independent systems, one per GPU (the metric's literal
+        # "factor+solve/sec @ N GPU": no exchange at all, scaling "weak")
+        if not args.no_replicas_pass:
+            dog.arm(max(args.watchdog, 240), "replicas pass")
+            del mat
+            if hasattr(shard, "close"):
+                shard.close()
+            torch.cuda.empty_cache()
+            dq2 = c4_dense(K, nx, nu, seed=rank)
+            mat2 = ipmatrix.IpLQDOCP(device=local_rank, device_vectors=True)
+            mat2.init_dense(dq2)
+            dq2.F = None
+            torch.cuda.empty_cache()
+            nrep = max(1, min(args.steps, 5))
+
+            def step2():
+                mat2.factor(None, z, w)
+                return mat2.solve(None, z, w, *r, *d)
+
+            step2()
+            kdist.fence()
+            t0 = time.perf_counter()
+            for _ in range(nrep):
+                res2 = step2()
+            kdist.fence()
+            el2 = kdist.max_over_ranks(time.perf_counter() - t0)
+            replicas = {"value": world * nrep / el2, "unit": "KKT factor+solve/s", "steps": nrep, "ms_per_step": 1e3 * el2 / nrep,
+                        "scaling": "weak", "residual_rank0": res2,
+                        "what": f"{world} independent C4 systems, one per GPU, no collective in the data path"}
+            del mat2
+            dog.disarm()
     if rank != 0:
         return None
     per_step = {k: v[0] / nprof for k, v in prof.items() if v[1]}
@@ -581,7 +659,10 @@ def bench_c4(args):
         "shard": {"ranks": world, "transport": transport, "comm_ranks": comm_ranks,
                   "devices": sorted(set(all_devices)) if all_devices else None,
                   "bytes_allgather_per_factor": st["bytes_exchange_factor"],
-                  "flops_rank0": st["flops_local"], "allgathers_per_factor": st["n_exchange_blocks"]} if one else None,
+                  "flops_rank0": st["flops_local"], "allgathers_per_factor": st["n_exchange_blocks"],
+                  "per_rank": per_rank} if one else None,
+        "replicas_value": replicas["value"] if replicas else None,
+        "replicas": replicas,
         "config": {"workload": f"C4 = BASELINE configs[3], the metric's 10^6-variable DOCP: multistage LQ optimal control QP, K={K} stages, "
                                f"nx={nx} states, nu={nu} controls -> n={n} me={me} m={m}, dense fx/fu handed over as blocks, x_0 fixed, "
                                f"box bounds on u; plugin LQDOCP (STAGED engine), "
@@ -678,6 +759,12 @@ def parse_args():
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
                     help="gloo + --share-gpu: functional check of the N>1 paths on a one-GPU box (not a measurement)")
     ap.add_argument("--share-gpu", action="store_true", help="all ranks use cuda:0")
+    ap.add_argument("--watchdog", type=int, default=120,
+                    help="N>1: seconds a rank may spend in the rendezvous / communicator creation / first collectives "
+                         "before it gives up with exit status 86")
+    ap.add_argument("--no-replicas-pass", action="store_true",
+                    help="c4, N>1, one system: skip the second timed pass (N independent systems, `replicas_value`)")
+    ap.add_argument("--no-retry", action="store_true", help="N>1: do not start the ranks a second time with --transport torch")
     ap.add_argument("--leaf-size", type=int, default=0)
     ap.add_argument("--max-pivots", type=int, default=0)
     args = ap.parse_args()
@@ -689,18 +776,44 @@ def parse_args():
 def launch_ranks(gpus):
     """`python bench.py --gpus N` outside a launcher: start N FRESH rank processes (one per GPU) with
     torch.distributed.run and hand their output through.  This parent has imported neither torch nor anything
-    that touches HIP, and it does not replace itself: the ranks are children, their exit status is ours."""
+    that touches HIP, and it does not replace itself: the ranks are children, their exit status is ours.
+    If the set fails or exceeds its limit (a rank's watchdog fired, a communicator could not be made), ONE fresh
+    set is started with --transport torch (torch.distributed's own collectives behind the exchange callback)."""
+    import signal
     import socket
     import subprocess
-    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    env = dict(os.environ)
-    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    env.setdefault("OMP_NUM_THREADS", "8")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
-    return subprocess.call(cmd, env=env, cwd=ROOT)
+
+    def run_once(extra, limit_s):
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        env = dict(os.environ)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.setdefault("OMP_NUM_THREADS", "8")
+        env["HQPKKT_RUN_NONCE"] = f"{os.getpid()}.{port}"  # part of the name of the RCCL id file, if one is used
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus),
+               "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:] + extra
+        p = subprocess.Popen(cmd, env=env, cwd=ROOT, start_new_session=True)
+        try:
+            return p.wait(timeout=limit_s)
+        except subprocess.TimeoutExpired:
+            print(f"bench: the {gpus} ranks did not finish within {limit_s} s - ending them", file=sys.stderr, flush=True)
+            try:
+                os.killpg(p.pid, signal.SIGTERM)  # the process group this parent started, nothing else
+                p.wait(timeout=20)
+            except Exception:
+                try:
+                    os.killpg(p.pid, signal.SIGKILL)
+                except Exception:
+                    pass
+            return 124
+
+    limit = int(os.environ.get("HQPKKT_BENCH_LIMIT_S", "1500"))
+    rc = run_once([], limit)
+    if rc != 0 and "--no-retry" not in sys.argv and "--transport" not in sys.argv:
+        print(f"bench: the ranks ended with status {rc}; one more set with --transport torch", file=sys.stderr, flush=True)
+        rc = run_once(["--transport", "torch", "--no-retry"], limit)
+    return rc
 
 
 def bench_c2(args, extras=True):
@@ -714,12 +827,16 @@ def bench_c2(args, extras=True):
     if args.share_gpu:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dog = Watchdog(rank)
+    if world > 1:
+        dog.arm(getattr(args, "watchdog", 120), "process group rendezvous")
     if args.share_gpu and world > 1:
         import torch.distributed as tdist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         tdist.init_process_group(args.backend)
     else:
         kdist.init(args.backend)
+    dog.disarm()
 
     from hqp_amd import ipmatrix, problems
 
@@ -856,11 +973,23 @@ def main():
     if args.workload == "launchcheck":
         # the N > 1 plumbing alone, no GPU needed (tests/test_dist_gloo.py): rendezvous over gloo, the fence and
         # the max-over-ranks of the timing contract; rank 0 prints what it saw
+        # (HQPKKT_LAUNCHCHECK=hang: rank 1 never reaches the rendezvous and rank 0's watchdog must end the run;
+        # =fail_rccl: the first set of ranks fails unless it was started with --transport torch - the launcher's retry)
+        mode = os.environ.get("HQPKKT_LAUNCHCHECK", "")
+        rank0, _l, _w = kdist.env_world()
+        dog = Watchdog(rank0)
+        dog.arm(args.watchdog, "process group rendezvous")
+        if mode == "hang" and rank0 == 1:
+            time.sleep(3600)
+        if mode == "fail_rccl" and args.transport != "torch":
+            sys.exit(7)
         rank, _lr, world = kdist.init(backend="gloo")
+        dog.disarm()
         kdist.fence(device_sync=False)
         t = kdist.max_over_ranks(float(rank))
         if rank == 0:
-            print(json.dumps({"launchcheck": True, "world": world, "max_rank": t, "gpus": args.gpus}))
+            print(json.dumps({"launchcheck": True, "world": world, "max_rank": t, "gpus": args.gpus} |
+                             ({"transport": args.transport} if mode else {})))
         kdist.finalize()
         return
     out = bench_c4(args) if args.workload == "c4" else bench_c2(args)

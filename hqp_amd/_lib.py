@@ -33,7 +33,7 @@ SYMBOLS = [
 ]
 RCCL_LIB_PATH = os.path.join(_HERE, "libhqpkkt_rccl.so")
 RCCL_SYMBOLS = ["hqpkkt_rccl_unique_id", "hqpkkt_rccl_create", "hqpkkt_rccl_create_from_env",
-                "hqpkkt_rccl_comm_info", "hqpkkt_rccl_exchange", "hqpkkt_rccl_destroy"]
+                "hqpkkt_rccl_comm_info", "hqpkkt_rccl_exchange", "hqpkkt_rccl_destroy", "hqpkkt_rccl_origin"]
 
 XCHG_ALLGATHER, XCHG_ALLREDUCE_SUM, XCHG_BCAST_BASE = 0, 1, 16
 # int fn(void *ctx, int op, double *buf, long long slot_elems, int nslots)
@@ -156,6 +156,7 @@ def rccl_lib():
         R.hqpkkt_rccl_exchange.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_longlong, C.c_int, C.c_void_p]
         R.hqpkkt_rccl_destroy.argtypes = [C.c_void_p]
         R.hqpkkt_rccl_comm_info.argtypes = [C.c_void_p, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
+        R.hqpkkt_rccl_origin.restype = C.c_char_p
         _rccl = R
     return _rccl
 

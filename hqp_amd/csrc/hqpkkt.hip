@@ -85,10 +85,11 @@ struct CsrBuf {
 // per-kernel-class device timing (hqpkkt_set_profile): HIP events on the
 // handle's stream around every launch, summed per class after the call
 enum { KC_ASSEMBLE = 0, KC_FACTOR_DIAG, KC_PANEL_SOLVE, KC_SCHUR_UPDATE,
-       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_ST_GEMM, KC_ST_SMALL, KC_ST_VEC, KC_ST_GEMM_UPD, KC_COUNT };
+       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_ST_GEMM, KC_ST_SMALL, KC_ST_VEC, KC_ST_GEMM_UPD, KC_XCHG, KC_COUNT };
 static const char *const kc_names[KC_COUNT] = {"assemble", "factor_diag", "panel_solve",
                                                "schur_update", "solve_fwd", "solve_bwd", "vector",
-                                               "residual", "staged_gemm", "staged_small", "staged_gemv", "staged_gemm_upd"};
+                                               "residual", "staged_gemm", "staged_small", "staged_gemv", "staged_gemm_upd",
+                                               "exchange"};
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;
@@ -761,11 +762,19 @@ static int graphed(hqpkkt_t *h, hqpkkt::GraphSlot &slot, F body) {
 // The exchange steps of a sharded system: the handle's stream is
 // drained, the caller's collective runs, and the next phase starts afterwards.
 static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots) {
-  if (h->xchg_sfn)  // the collective is put into the handle's stream behind the kernels that fill `buf`
-    return h->xchg_sfn(h->xchg_ctx, op, buf, slot, nslots, (void *)h->stream) ? HQPKKT_E_DEVICE : 0;
+  // (profiled as the class "exchange": in the stream-ordered form the time between the collective's place in
+  // the stream and its completion - the wait for the slowest rank and the transfer)
+  if (h->xchg_sfn) {  // the collective is put into the handle's stream behind the kernels that fill `buf`
+    h->prof.begin(KC_XCHG, h->stream);
+    const int rc = h->xchg_sfn(h->xchg_ctx, op, buf, slot, nslots, (void *)h->stream);
+    h->prof.end(h->stream);
+    return rc ? HQPKKT_E_DEVICE : 0;
+  }
   if (!h->xchg_fn) return HQPKKT_E_INTERN;
+  h->prof.begin(KC_XCHG, h->stream);
   HIPCHK(hipStreamSynchronize(h->stream));
   const int rc = h->xchg_fn(h->xchg_ctx, op, buf, slot, nslots);
+  h->prof.end(h->stream);
   return rc ? HQPKKT_E_DEVICE : 0;
 }
 

@@ -1,9 +1,10 @@
 // libhqpkkt_rccl.so: see include/hqpkkt_rccl.h.
 #include "../../include/hqpkkt_rccl.h"
 
+#include <dlfcn.h>
 #include <fcntl.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
+#include <rccl/rccl.h>  // types only: the entry points are resolved at run time (see rccl_api below)
 #include <sys/stat.h>
 #include <sys/types.h>
 #include <time.h>
@@ -17,6 +18,56 @@
 #include <string>
 
 namespace {
+// RCCL's entry points, taken from the RCCL that is ALREADY in the process when there is one (PyTorch's wheel
+// ships its own librccl.so: a second copy from /opt/rocm in the same process would mean two independent
+// communicator runtimes on the same GPUs), otherwise from the system's librccl.so.1 (a C++ host without
+// PyTorch).  This library is therefore not linked against librccl.
+struct RcclApi {
+  void *lib = nullptr;
+  const char *origin = "";
+  ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*CommCount)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommUserRank)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*CommCuDevice)(const ncclComm_t, int *) = nullptr;
+  ncclResult_t (*AllGather)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Broadcast)(const void *, void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  bool ok = false;
+};
+const RcclApi &rccl_api() {
+  static RcclApi a = [] {
+    RcclApi r;
+    const char *names[] = {"librccl.so.1", "librccl.so"};
+    if (const char *f = getenv("HQPKKT_RCCL_LIB"))  // an explicit path wins
+      if (*f) r.lib = dlopen(f, RTLD_NOW | RTLD_LOCAL), r.origin = "HQPKKT_RCCL_LIB";
+    for (const char *n : names)
+      if (!r.lib && (r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD))) r.origin = "already loaded in the process";
+    for (const char *n : names)
+      if (!r.lib && (r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL))) r.origin = "loaded from the library path";
+    if (!r.lib) return r;
+#define HQPKKT_SYM(field, name) r.field = (decltype(r.field))dlsym(r.lib, name)
+    HQPKKT_SYM(GetUniqueId, "ncclGetUniqueId");
+    HQPKKT_SYM(CommInitRank, "ncclCommInitRank");
+    HQPKKT_SYM(CommDestroy, "ncclCommDestroy");
+    HQPKKT_SYM(CommCount, "ncclCommCount");
+    HQPKKT_SYM(CommUserRank, "ncclCommUserRank");
+    HQPKKT_SYM(CommCuDevice, "ncclCommCuDevice");
+    HQPKKT_SYM(AllGather, "ncclAllGather");
+    HQPKKT_SYM(AllReduce, "ncclAllReduce");
+    HQPKKT_SYM(Broadcast, "ncclBroadcast");
+    HQPKKT_SYM(GroupStart, "ncclGroupStart");
+    HQPKKT_SYM(GroupEnd, "ncclGroupEnd");
+#undef HQPKKT_SYM
+    r.ok = r.GetUniqueId && r.CommInitRank && r.CommDestroy && r.CommCount && r.CommUserRank && r.CommCuDevice &&
+           r.AllGather && r.AllReduce && r.Broadcast && r.GroupStart && r.GroupEnd;
+    return r;
+  }();
+  return a;
+}
 struct Ctx {
   ncclComm_t comm = nullptr;
   int rank = 0, nranks = 1, device = 0;
@@ -35,7 +86,7 @@ int env_int(const char *a, const char *b, const char *c, int dflt) {
 int close_group(Ctx *c, ncclResult_t r) {
   if (c->group_open) {
     c->group_open = false;
-    const ncclResult_t g = ncclGroupEnd();
+    const ncclResult_t g = rccl_api().GroupEnd();
     if (r == ncclSuccess) r = g;
   }
   return r == ncclSuccess ? 0 : (int)r;
@@ -56,7 +107,11 @@ std::string id_file_path() {
   }
   const char *port = getenv("MASTER_PORT");
   const char *run = getenv("TORCHELASTIC_RUN_ID");
-  return dir + "/rccl_id." + (port && *port ? port : "0") + "." + (run && *run ? run : "none");
+  // ... and of the process that started the ranks (their common parent under torchrun / mpirun), so that a file a
+  // crashed run left behind on the same port is never this run's
+  const char *nonce = getenv("HQPKKT_RUN_NONCE");
+  return dir + "/rccl_id." + (port && *port ? port : "0") + "." + (run && *run ? run : "none") + "." +
+         (nonce && *nonce ? std::string(nonce) : std::to_string((long)getppid()));
 }
 }  // namespace
 
@@ -64,9 +119,10 @@ extern "C" {
 
 int hqpkkt_rccl_unique_id(char id[HQPKKT_RCCL_ID_BYTES]) {
   if (!id) return -1;
+  if (!rccl_api().ok) return -5;  // no usable librccl in the process or on the library path
   ncclUniqueId u;
   std::memset(id, 0, HQPKKT_RCCL_ID_BYTES);
-  const ncclResult_t r = ncclGetUniqueId(&u);
+  const ncclResult_t r = rccl_api().GetUniqueId(&u);
   if (r != ncclSuccess) return (int)r;
   std::memcpy(id, &u, sizeof(u));
   return 0;
@@ -74,6 +130,7 @@ int hqpkkt_rccl_unique_id(char id[HQPKKT_RCCL_ID_BYTES]) {
 
 int hqpkkt_rccl_create(const char id[HQPKKT_RCCL_ID_BYTES], int nranks, int rank, int device, void **ctx) {
   if (!id || !ctx || nranks < 1 || rank < 0 || rank >= nranks) return -1;
+  if (!rccl_api().ok) return -5;
   Ctx *c = new (std::nothrow) Ctx;
   if (!c) return -1;
   c->rank = rank, c->nranks = nranks, c->device = device;
@@ -83,7 +140,7 @@ int hqpkkt_rccl_create(const char id[HQPKKT_RCCL_ID_BYTES], int nranks, int rank
   }
   ncclUniqueId u;
   std::memcpy(&u, id, sizeof(u));
-  const ncclResult_t r = ncclCommInitRank(&c->comm, nranks, u, rank);
+  const ncclResult_t r = rccl_api().CommInitRank(&c->comm, nranks, u, rank);
   if (r != ncclSuccess) {
     delete c;
     return (int)r;
@@ -146,9 +203,9 @@ int hqpkkt_rccl_comm_info(void *ctx, int *nranks, int *rank, int *device) {
   Ctx *c = (Ctx *)ctx;
   if (!c || !c->comm) return -1;
   int n = 0, r = 0, d = 0;
-  ncclResult_t e = ncclCommCount(c->comm, &n);
-  if (e == ncclSuccess) e = ncclCommUserRank(c->comm, &r);
-  if (e == ncclSuccess) e = ncclCommCuDevice(c->comm, &d);
+  ncclResult_t e = rccl_api().CommCount(c->comm, &n);
+  if (e == ncclSuccess) e = rccl_api().CommUserRank(c->comm, &r);
+  if (e == ncclSuccess) e = rccl_api().CommCuDevice(c->comm, &d);
   if (e != ncclSuccess) return (int)e;
   if (nranks) *nranks = n;
   if (rank) *rank = r;
@@ -164,33 +221,35 @@ int hqpkkt_rccl_exchange(void *ctx, int op, double *buf, long long slot_elems, i
   ncclResult_t r;
   if (op == 0) {  // HQPKKT_XCHG_ALLGATHER, in place: the send part is this rank's slot of the receive buffer
     if (c->group_open || nslots != c->nranks) return close_group(c, ncclInvalidArgument);
-    r = ncclAllGather(buf + (size_t)c->rank * slot_elems, buf, (size_t)slot_elems, ncclDouble, c->comm, s);
+    r = rccl_api().AllGather(buf + (size_t)c->rank * slot_elems, buf, (size_t)slot_elems, ncclDouble, c->comm, s);
   } else if (op == 1) {  // HQPKKT_XCHG_ALLREDUCE_SUM
     if (c->group_open) return close_group(c, ncclInvalidArgument);
-    r = ncclAllReduce(buf, buf, (size_t)slot_elems, ncclDouble, ncclSum, c->comm, s);
+    r = rccl_api().AllReduce(buf, buf, (size_t)slot_elems, ncclDouble, ncclSum, c->comm, s);
   } else if (op >= 16 && op < 16 + c->nranks) {  // HQPKKT_XCHG_BCAST_BASE + root
     // the broadcasts of one gather come back to back, roots 0 .. nranks-1 in this order: the first opens a
     // group, the last closes it; anything out of sequence, or any error, closes the group before returning
     const int root = op - 16;
     if (root == 0) {
       if (c->group_open) return close_group(c, ncclInvalidUsage);
-      r = ncclGroupStart();
+      r = rccl_api().GroupStart();
       if (r != ncclSuccess) return (int)r;
       c->group_open = true;
     } else if (!c->group_open)
       return (int)ncclInvalidUsage;
-    r = slot_elems > 0 ? ncclBroadcast(buf, buf, (size_t)slot_elems, ncclDouble, root, c->comm, s) : ncclSuccess;
+    r = slot_elems > 0 ? rccl_api().Broadcast(buf, buf, (size_t)slot_elems, ncclDouble, root, c->comm, s) : ncclSuccess;
     if (r != ncclSuccess || root == c->nranks - 1) return close_group(c, r);
   } else
     return close_group(c, ncclInvalidArgument);
   return r == ncclSuccess ? 0 : (int)r;
 }
 
+const char *hqpkkt_rccl_origin(void) { return rccl_api().ok ? rccl_api().origin : "no librccl found"; }
+
 int hqpkkt_rccl_destroy(void *ctx) {
   Ctx *c = (Ctx *)ctx;
   if (!c) return 0;
   (void)close_group(c, ncclSuccess);
-  if (c->comm) (void)ncclCommDestroy(c->comm);
+  if (c->comm) (void)rccl_api().CommDestroy(c->comm);
   delete c;
   return 0;
 }

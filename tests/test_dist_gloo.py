@@ -5,6 +5,7 @@ ranks are covered by tests/test_shard_cpu.py (gloo, numpy model of the kernels) 
 tests/test_gpu_shard.py (the kernels themselves, ranks sharing the test box's GPU)."""
 import os
 import subprocess
+import time
 import sys
 import textwrap
 
@@ -68,3 +69,22 @@ def test_bench_starts_its_own_ranks():
     bad = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "launchcheck"],
                          capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, RANK="0", WORLD_SIZE="3"))
     assert bad.returncode != 0
+
+
+def test_bench_watchdog_and_retry():
+    """N > 1 must never hang: a rank that waits for one that is not coming gives up after --watchdog seconds
+    (exit status 86, the launcher ends the others and returns non-zero); a first set of ranks that fails is
+    replaced ONCE by a fresh set with --transport torch."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "launchcheck"]
+    t0 = time.time()
+    hang = subprocess.run(cmd + ["--watchdog", "10", "--no-retry"], capture_output=True, text=True, timeout=300, cwd=ROOT,
+                          env=dict(env, HQPKKT_LAUNCHCHECK="hang"))
+    assert hang.returncode != 0 and time.time() - t0 < 200
+    assert "giving up (exit 86)" in hang.stderr, hang.stderr[-2000:]
+    retry = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT, env=dict(env, HQPKKT_LAUNCHCHECK="fail_rccl"))
+    assert retry.returncode == 0, retry.stderr[-2000:]
+    assert "one more set with --transport torch" in retry.stderr
+    d = json.loads([l for l in retry.stdout.splitlines() if l.startswith("{")][0])
+    assert d["world"] == 2 and d["transport"] == "torch"
