@@ -647,7 +647,9 @@ static inline SplitPlan gemm_split_plan(long long tiles, long long nslab, int gr
     long long s = std::min<long long>(smax, grid / R), r = R;
     if (s <= 1) {
       s = 1;
-      if (sp.nphase == 0 && smax >= 2 && R > grid / 2) s = 2, r = grid / 2;
+      // (the half round needs an even grid: with an odd one workgroup grid - 1 would start on the next phase's first
+      // unit, which workgroup 0 takes as well)
+      if (sp.nphase == 0 && smax >= 2 && R > grid / 2 && grid % 2 == 0) s = 2, r = grid / 2;
     }
     sp.begin[sp.nphase] = (int)begin, sp.count[sp.nphase] = (int)r, sp.split[sp.nphase] = (int)s;
     sp.nphase++, begin += r, R -= r;

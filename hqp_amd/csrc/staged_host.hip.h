@@ -102,6 +102,9 @@ inline StagePtr stage_ptr(StagedDev &d, int k) {
 int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = true) {
   if (g.M <= 0 || g.N <= 0) return 0;
   StagedDev *d = h->sd;
+  // operands by LDS-DMA (global_load_lds_dwordx4) only from 16-byte aligned rows: an operand that starts at an odd
+  // column (the control columns F + nn of a stage with an odd number of states) is staged through registers
+  const bool al16 = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
   // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
   const bool split = d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid);
   // Between half a round and three quarters of the full grid of 128 x 128 tiles (stages of ~1500 .. 2700 states): whole
@@ -119,7 +122,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
       const long long tm = (g.M + 127) / 128;
       if (tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
     }
-    if (d->zeros.p) g.zeros = d->zeros.p;
+    if (d->zeros.p && al16) g.zeros = d->zeros.p;
     stg::SplitPlan sk = stg::gemm_split_plan(t128, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->cus);
     if (sk.dynamic) HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));  // (the queue's head)
     sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
@@ -132,7 +135,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   const long long tiles = stg::gemm_tiles(g.M, g.N, b, g.lower);
   if (g.lower && g.M < g.N) return HQPKKT_E_INTERN;  // (lower: a triangle, or the column strip of one)
   if (g.lower && g.M == g.N && big && d && tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
-  if (d && d->zeros.p) g.zeros = d->zeros.p;
+  if (d && d->zeros.p && al16) g.zeros = d->zeros.p;
   if (split && tiles <= d->sk_tiles) {
     // tile count that does not fill the chip evenly: whole rounds, then the k ranges of the rest cut (k_dgemm_tn_sk)
     // (the arrival counters are zero between launches: the last arriver of a tile resets its counter)
@@ -577,9 +580,18 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
   } guard{h, sA};
   const bool two = sB != sA;
   int e;
+  struct JoinGuard {  // an error between fork and join must not leave the second stream forked
+    bool armed = false;
+    hipStream_t a, b;
+    hipEvent_t ev;
+    ~JoinGuard() {
+      if (armed && hipEventRecord(ev, b) == hipSuccess) (void)hipStreamWaitEvent(a, ev, 0);
+    }
+  } join{false, sA, sB, d.ev_join};
   if (two) {
     HIPCHK(hipEventRecord(d.ev_fork, sA));
     HIPCHK(hipStreamWaitEvent(sB, d.ev_fork, 0));
+    join.armed = true;
   }
   const int ne_x = P.h_mid[k] - P.h_ptr[k], ne_u = P.h_ptr[k + 1] - P.h_mid[k];
   auto add_h = [&](int first, int count) {
@@ -641,7 +653,10 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     }
   } else if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR)))
     return e;
-  if (two) HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
+  if (two) {
+    HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
+    join.armed = false;
+  }
   // V_k = G_xx - Y' Rm: lower tiles, mirrored; G_xx from the strips
   stg::GemmArgs gu{sp.Y, ldy, sp.Rm, ldy, xb, 0, sp.V, ldv, nn, nn, q, -1.0, 1.0, 1, 1};
   gu.strips = tab;

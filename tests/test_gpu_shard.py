@@ -94,8 +94,12 @@ def test_sharded_staged_system_at_full_stage_width():
     handle to 1e-9, identical vectors on both ranks, no refinement round needed."""
     case = ["c4dense", 20, 5000, 50, "LQDOCP"]
     env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_CASES=json.dumps([case]), MASTER_ADDR="127.0.0.1")
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free port (concurrent runs must not collide)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
-           "--master-addr", "127.0.0.1", "--master-port", "29573", os.path.join(ROOT, "tests", "shard_worker.py")]
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "shard_worker.py")]
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
     line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]

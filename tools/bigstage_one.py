@@ -1,5 +1,6 @@
+import os
 """One big-stage case under rocprofv3 (per-kernel durations).  Usage: python tools/bigstage_one.py nu controls [path_eq]"""
-import sys; sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 from hqp_amd import problems, ipmatrix
 from common import new_d
 nx, nu = int(sys.argv[1]), int(sys.argv[2])

@@ -1,6 +1,7 @@
+import os
 """Time of the control-sized elimination (k_st_small / k_st_init_factor) of stages whose matrices live in global
 memory (StagedPlan::big): per launch, from the per-class event profile.  Usage: python tools/bigstage_time.py"""
-import sys; sys.path.insert(0, "/root/repo"); sys.path.insert(0, "/root/repo/tests")
+import sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np
 from hqp_amd import problems, ipmatrix
 from common import new_d, rel_err
