@@ -253,6 +253,50 @@ def c4_dense(K, nx, nu, seed=0, device="cuda"):
     return problems.DenseDocp([nx] * (K + 1), [nu] * K, Q, E, C, F, nx, cols.size)
 
 
+def c4_qp_vectors(dq, nx, nu, seed=7):
+    """c, b, d of the interior-point run on the C4 structure.  The state cost reaches every control through the dense
+    f_u (effective control Hessian ~ nx / 3), so with unit bounds no bound is ever active and the QP is solved in three
+    iterations; the bounds |u| <= 1.2 / (nx / 3) are of the size of the unconstrained controls instead: a third to a
+    half of the controls end at a bound (the bench line and the test report the fraction they found)."""
+    import torch
+    n, me, m = dq.dims
+    gq = torch.Generator(device="cuda").manual_seed(seed)
+    dq.c = torch.empty(n, dtype=torch.float64, device="cuda").uniform_(-0.5, 0.5, generator=gq)
+    dq.b = torch.zeros(me, dtype=torch.float64, device="cuda")
+    dq.b[me - nx:] = torch.empty(nx, dtype=torch.float64, device="cuda").uniform_(-1.0, 1.0, generator=gq)
+    dq.d = torch.full((m,), 1.2 / (nx / 3.0), dtype=torch.float64, device="cuda")
+    return dq
+
+
+def c4_kkt_norms(F, K, nx, nu, c, b, d, x, y, z, w):
+    """Max-norms of the KKT conditions of the C4 QP (Q = diag(1 on states, 0.1 on controls), dynamics blocks F, x_0 fixed,
+    |u| <= d) at (x, y, z, w): stationarity Q x + c - A'y - C'z, equalities A x + b, inequalities C x + d - w,
+    complementarity z .* w, smallest z / w.  Conventions of hqp/Hqp_IpsMehrotra.C:27-31."""
+    import torch
+    nz = nx + nu
+    X = x[:K * nz].view(K, nz)
+    xs = torch.cat([X[:, :nx], x[K * nz:].view(1, nx)])      # x_0 .. x_K
+    ydyn, yE = y[:K * nx].view(K, nx), y[K * nx:]
+    qd = torch.ones_like(x)
+    qd[:K * nz].view(K, nz)[:, nx:] = 0.1
+    stat = qd * x + c
+    ax = torch.empty_like(y)
+    for k in range(K):
+        ax[k * nx:(k + 1) * nx] = F[k] @ X[k] - xs[k + 1]
+        stat[k * nz:(k + 1) * nz] -= F[k].T @ ydyn[k]
+        stat[(k + 1) * nz:(k + 1) * nz + nx] += ydyn[k]      # the -1 of row block k in column block x_{k+1}
+    ax[K * nx:] = xs[0]
+    stat[:nx] -= yE
+    ku = K * nu
+    U = X[:, nx:].reshape(-1)
+    Su = stat[:K * nz].view(K, nz)[:, nx:]
+    Su -= (z[:ku] - z[ku:]).view(K, nu)
+    cxd = torch.cat([U, -U]) + d
+    return {"stationarity": float(stat.abs().max()), "equalities": float((ax + b).abs().max()),
+            "inequalities": float((cxd - w).abs().max()), "complementarity": float((z * w).abs().max()),
+            "min_z": float(z.min()), "min_w": float(w.min()), "active_fraction": float((w < z).double().mean())}
+
+
 def c4_program(K, nx, nu, seed=0):
     """The same QP family in CSR form (Hqp_Docp's layout) for the CPU reference: what
     Hqp_IpLQDOCP::init / factor / step are timed on."""
@@ -688,19 +732,20 @@ def bench_c4(args):
         # the whole Mehrotra loop device-resident (hqpkkt_mehrotra: per iteration 1 factorisation, 2 solves, the
         # right-hand sides incl. the dense products with the dynamics rows); QP data: c ~ U(-0.5, 0.5), x_0 ~ U(-1, 1), -1 <= u <= 1
         try:
-            gq = torch.Generator(device="cuda").manual_seed(7)
-            dq.c = torch.empty(n, dtype=torch.float64, device="cuda").uniform_(-0.5, 0.5, generator=gq)  # some bounds end active
-            dq.b = torch.zeros(me, dtype=torch.float64, device="cuda")
-            dq.b[me - nx:] = torch.empty(nx, dtype=torch.float64, device="cuda").uniform_(-1.0, 1.0, generator=gq)
-            dq.d = torch.ones(m, dtype=torch.float64, device="cuda")
+            c4_qp_vectors(dq, nx, nu)
             t0 = time.perf_counter()
             _x, _y, _z, _w, info = mat.mehrotra(dq)
             wall = time.perf_counter() - t0
+            # the KKT conditions of what came back, with the dynamics blocks generated once more (the engine holds its own copy)
+            Fk = c4_dense(K, nx, nu, seed=0).F
+            kkt = c4_kkt_norms(Fk, K, nx, nu, dq.c, dq.b, dq.d, _x, _y, _z, _w)
+            del Fk
             out["ip_iterations_c4"] = {"solver": "hqpkkt_mehrotra (device-resident restatement of Hqp_IpsMehrotra), plugin LQDOCP / STAGED",
                                        "iters": info["iters"], "result": info["result"], "factorisations": info["n_factor"],
                                        "solves": info["n_solve"], "seconds": info["ms_total"] * 1e-3, "wall_s": wall,
                                        "ip_iters_per_s": info["iters"] / (info["ms_total"] * 1e-3) if info["ms_total"] else None,
-                                       "gap": info["gap"]}
+                                       "gap": info["gap"], "kkt": kkt,
+                                       "bounds": f"|u| <= {1.2 / (nx / 3.0):.3e}; {100 * kkt['active_fraction'] / 1.0:.1f} % of the 2 K nu bound rows active at the result"}
         except Exception as e:  # never let the secondary measurement break the bench line
             out["ip_iterations_c4"] = {"error": str(e)}
     if world == 1 and not args.no_cpu_baseline:

@@ -114,6 +114,27 @@ def test_sharded_staged_system_at_full_stage_width():
     assert abs(f0 - f1) <= 0.1 * max(f0, f1), (f0, f1)
 
 
+def test_sharded_staged_system_with_an_odd_number_of_states_is_refused():
+    """with an odd number of states per stage the control columns F + nn of the dynamics would start 8, not
+    16 bytes aligned under the column split.  The plan of a SHARDED system refuses such a stage (staged_plan.cpp: status
+    E_SIZES, on every rank alike - nobody is left in a collective); the unsharded engine takes it (operands that are
+    not 16-byte aligned are staged through registers, st_gemm)."""
+    import socket
+    import bench
+    mat = ipmatrix.IpLQDOCP(device_vectors=True)
+    mat.init_dense(bench.c4_dense(3, 1001, 40, seed=1))  # unsharded: accepted
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    case = ["c4dense", 3, 1001, 40, "LQDOCP"]
+    env = dict(os.environ, SHARD_BACKEND="gloo", SHARD_CASES=json.dumps([case]), MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert out.returncode != 0
+    assert out.stderr.count("hqpkkt status 1 in init_dense") == 2, out.stderr[-3000:]
+
+
 def test_bench_launches_its_own_ranks():
     """`python bench.py --gpus 2` outside a launcher starts its ranks itself (fresh child processes) and prints
     ONE strong-scaling line; here two ranks on the one GPU with the exchange staged through gloo."""

@@ -427,6 +427,57 @@ def test_staged_mehrotra_loop():
     assert np.abs(out[0][0] - out[1][0]).max() <= 1e-6 * max(1.0, np.abs(out[1][0]).max())
 
 
+def test_mehrotra_on_wide_stages_satisfies_the_kkt_conditions():
+    """the interior-point half of the metric on the C4 structure.  hqpkkt_mehrotra on a DOCP of 1000
+    states per stage (dense hand-over, bounds of the size of the unconstrained controls, so that a good part of them
+    is active at the optimum): the result satisfies the KKT conditions of the QP (hqp/Hqp_IpsMehrotra.C:27-31) and the
+    loop needed a real number of iterations."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    K, nx, nu = 24, 1000, 20
+    dq = bench.c4_dense(K, nx, nu, seed=3)
+    F = dq.F
+    mat = ipmatrix.IpLQDOCP(device_vectors=True)
+    mat.init_dense(dq)
+    dq.norm_A = max(float(blk.abs().sum(1).max()) + 1.0 for blk in F)
+    bench.c4_qp_vectors(dq, nx, nu, seed=11)
+    x, y, z, w, info = mat.mehrotra(dq)
+    kkt = bench.c4_kkt_norms(F, K, nx, nu, dq.c, dq.b, dq.d, x, y, z, w)
+    print(info, kkt)
+    assert info["result"] == 0 and info["iters"] >= 8, info
+    assert 0.05 < kkt["active_fraction"] < 0.95, kkt
+    assert kkt["min_z"] >= 0.0 and kkt["min_w"] >= 0.0
+    assert kkt["stationarity"] <= 1e-8 and kkt["equalities"] <= 1e-8 and kkt["inequalities"] <= 1e-8, kkt
+    assert kkt["complementarity"] <= 1e-8, kkt
+
+
+def test_mehrotra_iterations_equal_the_references_on_the_c4_structure():
+    """... and at a width the reference finishes in seconds (60 states per stage, CSR hand-over) the device-resident
+    loop on the STAGED engine needs the iterations of the reference's own Hqp_IpsMehrotra with its Hqp_IpLQDOCP,
+    and ends at the same point."""
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    from oracle import refapi
+    if not refapi.available():
+        pytest.skip("reference build not on this box")
+    K, nx, nu = 12, 60, 4
+    prog = bench.c4_program(K, nx, nu, seed=5)
+    rng = np.random.default_rng(6)
+    prog.c = rng.uniform(-0.5, 0.5, prog.n)
+    prog.b = np.zeros(prog.me)
+    prog.b[prog.me - nx:] = rng.uniform(-1.0, 1.0, nx)
+    prog.d = np.full(prog.m, 1.2 / (nx / 3.0))
+    ref = refapi.ip_solve(prog, "Mehrotra", "LQDOCP")
+    mat = ipmatrix.IpLQDOCP()
+    mat.init(prog)
+    x, y, z, w, info = mat.mehrotra(prog)
+    print(ref["iters"], info)
+    assert ref["result"] == 0 and info["result"] == 0
+    assert ref["iters"] >= 6 and abs(info["iters"] - ref["iters"]) <= 1, (ref["iters"], info["iters"])
+    assert np.abs(x - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
+    assert 0.05 < float((w < z).mean()) < 0.95
+
+
 def test_full_size_c4_properties():
     """BASELINE configs[3] at its stated size - K = 200 stages, nx = 5000, nu = 50: 1 015 000 variables, the KKT system
     of dimension 2.04e6 - through size-independent properties (the reference needs ~20 minutes per factorisation there):
