@@ -120,7 +120,9 @@ def test_sharded_staged_system_with_an_odd_number_of_states_is_refused():
     E_SIZES, on every rank alike - nobody is left in a collective); the unsharded engine takes it (operands that are
     not 16-byte aligned are staged through registers, st_gemm)."""
     import socket
+    sys.path.insert(0, ROOT)
     import bench
+    from hqp_amd import ipmatrix
     mat = ipmatrix.IpLQDOCP(device_vectors=True)
     mat.init_dense(bench.c4_dense(3, 1001, 40, seed=1))  # unsharded: accepted
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
