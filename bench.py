@@ -66,6 +66,17 @@ class Watchdog:
             self._t = None
 
 
+def kernel_source_sha16():
+    """Fingerprint of the STAGED engine's kernel sources: a counter-derived figure (roofline.traffic) is quoted only
+    when the profile it comes from was collected on the same sources."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("staged.hip.h", "staged_host.hip.h"):
+        with open(os.path.join(ROOT, "hqp_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
 def class_work(struct, rank=None):
     """Algorithmic work per numeric factorisation, split by kernel class, from the
     symbolic structure (p pivots, b border rows per supernode); flops count a
@@ -659,16 +670,23 @@ def bench_c4(args):
     bytes_gemv = K * 8.0 * (2.0 * np1 * np1 + 2.0 * np1 * nz + 2.0 * q * nx) * (1 + st["refine_rounds"])
     gemm_ms, gemm_launch = per_step.get("staged_gemm", 0.0), launches.get("staged_gemm", 1.0)
     achieved = flops_big / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "r03_pmc_traffic_c4.json")
-    if not os.path.exists(pmc):
-        pmc = os.path.join(ROOT, "profiles", "r02_pmc_traffic_c4.json")
+    traffic, traffic_note = None, None
+    pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_c4.json")
     if os.path.exists(pmc) and (nx, nu) == (5000, 50) and not one:
         # HBM bytes per launch of the stream-K dgemm from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-        # workload (separate runs, gfx950 correction applied: profiles/README.md)
-        traffic = json.load(open(pmc)).get("k_dgemm_tn_sk", {}).get("hbm_bytes_per_launch")
+        # workload (separate runs, gfx950 correction applied: profiles/README.md) - only if those passes ran on the
+        # kernel sources of this checkout
+        rec = json.load(open(pmc))
+        if rec.get("_kernel_source_sha16") == kernel_source_sha16():
+            traffic = rec.get("k_dgemm_tn_sk", {}).get("hbm_bytes_per_launch")
+        else:
+            traffic_note = ("profiles/r04_pmc_traffic_c4.json was collected on other kernel sources "
+                            f"({rec.get('_kernel_source_sha16')} != {kernel_source_sha16()}): not quoted")
+    elif (nx, nu) == (5000, 50) and not one:
+        traffic_note = "no counter passes of this round (profiles/r04_pmc_traffic_c4.json)"
     roofline = {"kernel": "k_dgemm_tn_sk<lds-dma, 2x4 waves> / k_dgemm_tn<128,128> (W = V+ F, G = F'W)", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS if achieved else None, "traffic": traffic,
+                "traffic_note": traffic_note,
                 "launches_per_step": gemm_launch, "avg_launch_ms": gemm_ms / gemm_launch if gemm_launch else None,
                 "algorithmic_flops_per_launch": flops_big / gemm_launch if gemm_launch else None,
                 "algorithmic_flops_per_step": flops_big,

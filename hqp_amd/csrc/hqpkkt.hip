@@ -2266,8 +2266,6 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
       stg::gemm_launch_plain(variant, (unsigned)tiles, 0, g, cus);
     else if (!getenv("HQPKKT_NO_TILE6432") && stg::gemm_tiles_6432(M, N, K, lower, mirror, cus))  // (as st_gemm chooses)
       stg::k_dgemm_tn<64, 32><<<(unsigned)(((M + 63) / 64) * (long long)((N + 31) / 32)), 256, stg::gemm_lds_bytes(64, 32)>>>(g);
-    else if (getenv("HQPKKT_DMA64") && g.zeros && K >= 4 * stg::GEMM_BK)
-      stg::k_dgemm_tn<64, 64, true, 2, 2, 3><<<(unsigned)tiles, 256, stg::GEMM_DMA64_LDS>>>(g);
     else
       stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64)>>>(g);
   }

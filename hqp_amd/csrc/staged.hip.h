@@ -73,14 +73,13 @@ static inline long long gemm_tiles(int M, int N, int b, int lower) {
 static inline size_t gemm_lds_bytes(int bm, int bn, int nbuf = 2) { return sizeof(double) * nbuf * GEMM_BK * (size_t)(bm + 16 + bn + 16); }
 
 // 128 x 128 tiles from 384 tiles on (the grid of 2 x 256 workgroups three quarters full).  Below that the 64 x 64
-// kernel with four times the tiles is faster (same-box comparisons, tools/ab_env.sh HQPKKT_OLD_BIG: 2000 x 2050 x 2000
+// kernel with four times the tiles is faster (same-box comparisons of round 3: 2000 x 2050 x 2000
 // 0.41 against 0.50 ms, 1500 x 1540 x 1500 0.19 against 0.21) with one exception: a deep rectangular product of 160 -
 // 256 tiles - the column strip of W when a C4 system is sharded over 8 ranks, 5000 x 640 x 5000 - as ONE round of one
 // workgroup per CU (gemm_launch_plain): 0.71 against 0.83 ms.
 static inline bool gemm_big_tiles(int M, int N, int lower, int K = 0) {
   const long long t = gemm_tiles(M, N, 128, lower);
-  static const bool old_rule = getenv("HQPKKT_OLD_BIG") != nullptr;  // (comparisons)
-  return t >= 384 || (!old_rule && !lower && t >= 160 && t <= 256 && K >= 256 * GEMM_BK);
+  return t >= 384 || (!lower && t >= 160 && t <= 256 && K >= 256 * GEMM_BK);
 }
 
 // The split form (k_dgemm_tn_sk, below) pays where whole rounds of 128 x 128 tiles would leave slots idle
@@ -363,96 +362,8 @@ struct GemmTile {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero rows behind the range: LDS is reused after this)
     __syncthreads();
   }
-  // ---- 64 x 64 tiles by LDS-DMA (products of a few hundred to a few thousand small tiles: stages of 500 .. 2700
-  // states).  A k-row of a 64-wide panel is HALF a wave-instruction of the DMA (64 lanes x 16 bytes = 1 KiB = two
-  // rows), and the DMA writes its 1 KiB contiguously: LDS rows are unpadded, 64 doubles.  What keeps the fragment reads
-  // free of bank conflicts instead of padding: the DMA takes a GLOBAL address per lane, so the odd k-rows are stored
-  // with their 16-column groups exchanged pairwise (column ^ 16) and read back the same way - lanes lk = 0, 1 (one half
-  // of a ds_read_b64) then cover all 64 banks.  Three buffers of 16 KB, counted waits as in slabs_dma3; wave w issues the
-  // row pairs w and w + 4 of both panels, one piece behind every fourth multiplication.  As / Bs: 3 x 16 x 64 doubles.
-  template <bool MASKED>
-  static __device__ __forceinline__ void slabs_dma64(const GemmArgs &g, const double *pa, const double *pb, const double *zr, int half,
-                                                     int wave, int wm, int wn, int lr, int lk, int s0, int s1, unsigned mask,
-                                                     double4_t (&acc)[TM][TN], double *As, double *Bs) {
-    static_assert(BM == 64 && BN == 64 && NW == 4 && BK == 16 && TM == 2 && TN == 2, "written for 2 x 2 waves of 32 x 32");
-    // piece p (0..3) of this wave for the slab at row k0: A pairs wave, wave + 4, then B pairs wave, wave + 4
-    auto dma = [&](int buf, int k0, int p) {
-      const int rp = wave + 4 * (p & 1), k = k0 + 2 * rp + half;  // this lane's row of the pair
-      if (p < 2)
-        glds16(k < g.K ? pa + (long long)k * g.lda : zr, As + (buf * BK + 2 * rp) * 64);
-      else
-        glds16(k < g.K ? pb + (long long)k * g.ldb : zr, Bs + (buf * BK + 2 * rp) * 64);
-    };
-    auto wait_all_but_newest_slab = [&]() { asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
-#pragma unroll
-    for (int p = 0; p < 4; p++) dma(0, s1 > s0 ? s0 * BK : g.K, p);
-#pragma unroll
-    for (int p = 0; p < 4; p++) dma(1, s0 + 1 < s1 ? (s0 + 1) * BK : g.K, p);
-    wait_all_but_newest_slab();
-    // fragment columns of this lane: rows k = 4 ks + lk, odd rows swizzled
-    const int sw = 16 * (lk & 1);
-    int ca[TM], cb[TN];
-#pragma unroll
-    for (int x = 0; x < TM; x++) ca[x] = (wm * WM + 16 * x + lr) ^ sw;
-#pragma unroll
-    for (int y = 0; y < TN; y++) cb[y] = (wn * WN + 16 * y + lr) ^ sw;
-    int buf = 0;
-    for (int s = s0; s < s1; s++) {
-      const int bnext = buf >= 1 ? buf - 1 : 2;  // (buf + 2) % 3
-      const int knext = s + 2 < s1 ? (s + 2) * BK : g.K;
-      const double *Ab = As + buf * BK * 64, *Bb = Bs + buf * BK * 64;
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ks++) {
-        double af[TM], bf[TN];
-#pragma unroll
-        for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * 64 + ca[x]];
-#pragma unroll
-        for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * 64 + cb[y]];
-#pragma unroll
-        for (int x = 0; x < TM; x++)
-#pragma unroll
-          for (int y = 0; y < TN; y++)
-            if (!MASKED || ((mask >> (x * TN + y)) & 1u)) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
-        dma(bnext, knext, ks);  // (four k-steps, four pieces)
-      }
-      wait_all_but_newest_slab();
-      buf = buf == 2 ? 0 : buf + 1;
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero rows behind the range: LDS is reused after this)
-    __syncthreads();
-  }
-  static __device__ __forceinline__ void accumulate_dma64(const GemmArgs &g, int i0, int j0, int s0, int s1,
-                                                          double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper) {
-    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave / WGN, wn = wave % WGN;
-    const int lr = lane & 15, lk = lane >> 4;
-    // this lane's 16 bytes of a row pair: row `half` of the pair, LDS columns 2 (lane % 32), + 1; they hold the
-    // operand columns (2 (lane % 32)) ^ (16 half), + 1 (the exchange keeps pairs of columns together)
-    const int half = lane >> 5, col = (2 * (lane & 31)) ^ (16 * half);
-    const double *pa = g.A + ((i0 + col < g.lda) ? i0 + col : 0);
-    const double *pb = g.B + ((j0 + col < g.ldb) ? j0 + col : 0);
-    const double *zr = g.zeros + 2 * (lane & 31);
-    unsigned mask = 0;
-#pragma unroll
-    for (int x = 0; x < TM; x++)
-#pragma unroll
-      for (int y = 0; y < TN; y++) {
-        const int rb = wm * TM + x, cbk = wn * TN + y;  // 16 x 16 block of the tile
-        const bool want = i0 + 16 * rb < g.M && j0 + 16 * cbk < g.N && !(skip_upper && cbk > rb);
-        mask |= (want ? 1u : 0u) << (x * TN + y);
-      }
-    mask = __builtin_amdgcn_readfirstlane(mask);
-    if (mask == (1u << (TM * TN)) - 1u)
-      slabs_dma64<false>(g, pa, pb, zr, half, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
-    else
-      slabs_dma64<true>(g, pa, pb, zr, half, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
-  }
   static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
                                                         double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper = false, int nbuf = 2) {
-    if constexpr (BM == 64 && BN == 64) {
-      accumulate_dma64(g, i0, j0, s0, s1, acc, As, Bs, skip_upper);
-      return;
-    } else {
     static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
     static_assert((BK / NW) * NW == BK && TM * TN >= 2 * (BK / NW) && TM * TN <= 32,
                   "pieces are issued behind the multiplications of the first k-step");
@@ -483,7 +394,6 @@ struct GemmTile {
       slabs_dma<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
     else
       slabs_dma<true>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
-    }
   }
 
   // `lds`: the workgroup's LDS (free after accumulate's last barrier), used to write the MIRROR image of an
@@ -606,11 +516,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WG
 // depend on the order of arrival, and nobody waits for anybody.
 struct SplitPlan {
   double *ws;     // partial tiles: piece p (numbered through the split phases) -> ws + p * 128 * 128 (gemm_split_plan_pieces)
-  unsigned *cnt;  // arrival counter per tile, and at [queue] the head of the unit list (all zeroed before every launch)
-  int queue;      // = number of tiles
+  unsigned *cnt;  // arrival counter per tile (zero between launches: the last arriver of a tile resets it)
   int dp_rounds;  // (whole / G, informative)
   int whole;      // the first `whole` tiles are computed whole
-  int dynamic;    // 0: workgroup w does unit w of every round and phase; 1: units after the first from a queue
   int nphase;
   int begin[3], count[3], split[3];
 };
@@ -622,24 +530,7 @@ struct SplitPlan {
 // balance gains) and a tile has at most 16 pieces (the last arriver reads them one after the other).
 static inline SplitPlan gemm_split_plan(long long tiles, long long nslab, int grid) {
   SplitPlan sp{};
-  sp.queue = (int)tiles;
   const long long smax = std::max<long long>(1, std::min<long long>(16, nslab / 16));
-  if (const char *e = getenv("HQPKKT_SPLIT_PLAN")) {
-    // experiments (tools/split_sweep.sh): units taken from a queue; "% whole, % up to which halves, pieces of the rest,
-    // whole rounds only".  Measured at the C4 shapes: no setting beats the fixed assignment below (78-80 % against 80 %
-    // for W, 64-74 % against 74 % for G): workgroups that take whole tiles at their own times work at 512 different k
-    // and stop sharing operand panels in L2
-    int PW = 45, PH = 80, SR = 8, whole_rounds_only = 1;
-    sscanf(e, "%d,%d,%d,%d", &PW, &PH, &SR, &whole_rounds_only);
-    sp.dynamic = 1;
-    long long a = tiles * PW / 100;
-    if (whole_rounds_only) a = a / grid * grid;
-    sp.dp_rounds = (int)(a / grid), sp.whole = (int)a;
-    const long long b = std::max(a, tiles * PH / 100), sr = std::max<long long>(1, std::min<long long>(SR, smax));
-    if (b > a) sp.begin[sp.nphase] = (int)a, sp.count[sp.nphase] = (int)(b - a), sp.split[sp.nphase] = (int)std::min<long long>(2, smax), sp.nphase++;
-    if (tiles > b) sp.begin[sp.nphase] = (int)b, sp.count[sp.nphase] = (int)(tiles - b), sp.split[sp.nphase] = (int)sr, sp.nphase++;
-    return sp;
-  }
   sp.dp_rounds = (int)(tiles / grid);
   long long R = tiles - (long long)sp.dp_rounds * grid, begin = (long long)sp.dp_rounds * grid;
   sp.whole = (int)begin;
@@ -672,19 +563,11 @@ static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
   const long long tiles = gemm_tiles(M, N, 128, lower);
   const long long nslab = (K + GEMM_BK - 1) / GEMM_BK;
   if (nslab < 32) return false;                                 // too shallow to cut
-  if (getenv("HQPKKT_FORCE_SPLIT")) return true;                // (experiments: tools/slice_sweep.sh)
   if (tiles % grid == 0 || tiles >= 16LL * grid) return false;  // even, or the tail does not matter
   // (a CU with one workgroup reaches 92 % of what it does with two: up to 5/8 of the grid one plain round of one
   // or two workgroups per CU is as fast as cut pieces, without their parked partial sums)
   if (tiles > grid * 5 / 8) return true;
-  // few tiles (a stage of ~1000 states: 72): cut every tile's k range so that about half of the CUs get a piece -
-  // against 64 x 64 tiles on the register-staged loop (1000 x 1050 x 1000: 91 us)
-  // (measured: 0.149 ms against 0.091 - three pieces of 21 slabs cost more in pipeline fill, parked partial sums and their
-  // summation than the fuller grid gains; kept as an experiment: HQPKKT_SMALL_SPLIT)
-  if (tiles <= grid / 4 && getenv("HQPKKT_SMALL_SPLIT")) {
-    const SplitPlan sp = gemm_split_plan(tiles, nslab, grid);
-    return sp.nphase == 1 && sp.split[0] >= 2 && (long long)sp.count[0] * sp.split[0] >= grid / 4;
-  }
+  // (few tiles - a stage of ~1000 states: 72 - run on 64 x 64 tiles; cut pieces for them were measured slower)
   return false;
 }
 template <bool DMA, int WGM = 2, int WGN = 2, int NBUF = 2, int BM = 128, int BN = 128>
@@ -700,11 +583,9 @@ __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WG
   if (stamp && threadIdx.x == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
   // Units of work: the whole tiles of the rounds (unit u = tile u), then the pieces of the split phases (phase q:
   // unit = piece j of tile ti at j * count[q] + ti).  Workgroup w does unit w of every round and phase: its
-  // neighbours in the XCD work on the neighbouring tiles at the same k.  (sk.dynamic: every unit after the first
-  // from ONE counter instead - of the two workgroups of a CU the one that was dispatched first wins the arbitration
-  // for the matrix pipe and runs 1.7 - 2 times as fast as its partner (stamps: profiles/r03_dgemm_stamps.txt), and a
-  // queue lets it take more units; measured, it does not pay: see gemm_split_plan.)  The result does not depend on who
-  // computes what: a tile's pieces are fixed k ranges, summed in their order.
+  // neighbours in the XCD work on the neighbouring tiles at the same k.  (A queue of units was measured in round 3
+  // and does not pay: profiles/NOTES.md.)  The result does not depend on who computes what: a tile's pieces are fixed
+  // k ranges, summed in their order.
   const int n_whole = sk.whole;
   int n_units = n_whole;
   for (int q = 0; q < sk.nphase; q++) n_units += sk.count[q] * sk.split[q];
@@ -722,9 +603,7 @@ __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WG
       t = sk.begin[q] + ti, s0 = min(nslab, j * L), s1 = min(nslab, s0 + L);
     }
     const int u_now = u;
-    if (sk.dynamic) {  // the next unit, fetched while this one is computed
-      if (threadIdx.x == 0) s_old[1] = (unsigned)G + __hip_atomic_fetch_add(sk.cnt + sk.queue, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else {  // unit w of the next round / phase (the plan's phases hold at most G units each)
+    {  // unit w of the next round / phase (the plan's phases hold at most G units each)
       int nu = n_units;
       if (u + G < n_whole)
         nu = u + G;
@@ -834,16 +713,10 @@ static inline void gemm_launch_split(int variant, int grid, hipStream_t s, const
 }
 // 64 x 64 tiles (register-staged loop) with their k ranges cut: products of a few hundred small tiles, where one
 // workgroup per CU leaves the matrix pipe two thirds idle (a stage of ~1000 states: 272 tiles of 63 slabs, 91 us)
-static const int GEMM_SPLIT64_WGS_PER_CU = 4;
-static inline void gemm_launch_split64(int grid, hipStream_t s, const GemmArgs &g, const SplitPlan &sk) {
-  k_dgemm_tn_sk<false, 2, 2, 2, 64, 64><<<grid, 256, gemm_lds_bytes(64, 64) + 16, s>>>(g, sk);
-}
 // the rule for 64 x 32 tiles (st_gemm, hqpkkt_debug_dgemm): a rectangular product of at most two 64 x 64 tiles per CU, deep
 static inline bool gemm_tiles_6432(int M, int N, int K, int lower, int mirror, int cus) {
   return cus > 0 && !lower && !mirror && gemm_tiles(M, N, 64, 0) <= 2LL * cus && K >= 16 * GEMM_BK;
 }
-// LDS of the 64 x 64 LDS-DMA kernel: three buffers of two unpadded 16 x 64 panels (the mirrored epilogue needs 34 KB)
-static const size_t GEMM_DMA64_LDS = sizeof(double) * 3 * GEMM_BK * 128;
 static inline hipError_t gemm_set_attributes() {
   hipError_t e = hipSuccess;
   auto set = [&](const void *f, size_t bytes) {
@@ -855,8 +728,6 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn<128, 128, true, 2, 4>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<64, 64>, gemm_lds_bytes(64, 64));
   set((const void *)k_dgemm_tn<64, 32>, gemm_lds_bytes(64, 32));
-  set((const void *)k_dgemm_tn<64, 64, true, 2, 2, 3>, GEMM_DMA64_LDS);
-  set((const void *)k_dgemm_tn_sk<false, 2, 2, 2, 64, 64>, gemm_lds_bytes(64, 64) + 16);
   set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true, 2, 4>, gemm_sk_lds_bytes());

@@ -107,28 +107,6 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   const bool al16 = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
   // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
   const bool split = d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid);
-  // Between half a round and three quarters of the full grid of 128 x 128 tiles (stages of ~1500 .. 2700 states): whole
-  // tiles on ONE workgroup per CU, the remainder's k ranges cut - against 64 x 64 tiles on the register-staged loop
-  const long long t128 = stg::gemm_tiles(g.M, g.N, 128, g.lower);
-  static const int mid_mode = getenv("HQPKKT_MID_SPLIT") ? atoi(getenv("HQPKKT_MID_SPLIT")) : 0;
-  bool mid = (mid_mode & 1) && !split && d && allow_sk && d->sk_grid > 0 && d->cus > 0 && d->gemm_variant == stg::GEMM_DMA8 &&
-             t128 > d->cus / 2 && t128 < 384 && t128 % d->cus != 0 && g.K >= 64 * stg::GEMM_BK && t128 <= d->sk_tiles &&
-             !stg::gemm_big_tiles(g.M, g.N, g.lower, g.K);
-  // (experiment, bit 2: the triangular products of the split form on one workgroup per CU too)
-  if ((mid_mode & 2) && split && g.lower && d->cus > 0 && d->gemm_variant == stg::GEMM_DMA8 && t128 % d->cus != 0 && t128 <= d->sk_tiles) mid = true;
-  if (mid) {
-    if (g.lower && g.M < g.N) return HQPKKT_E_INTERN;
-    if (g.lower && g.M == g.N) {
-      const long long tm = (g.M + 127) / 128;
-      if (tm >= 16 && tm < 32768) g.tile_map = d->tri_map((int)tm);
-    }
-    if (d->zeros.p && al16) g.zeros = d->zeros.p;
-    stg::SplitPlan sk = stg::gemm_split_plan(t128, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->cus);
-    if (sk.dynamic) HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));  // (the queue's head)
-    sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
-    KLAUNCH(h, cls, stg::gemm_launch_split(stg::GEMM_DMA8X3, d->cus, h->stream, g, sk));
-    return 0;
-  }
   const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower, g.K);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b;
@@ -140,7 +118,6 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
     // tile count that does not fill the chip evenly: whole rounds, then the k ranges of the rest cut (k_dgemm_tn_sk)
     // (the arrival counters are zero between launches: the last arriver of a tile resets its counter)
     stg::SplitPlan sk = stg::gemm_split_plan(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid);
-    if (sk.dynamic) HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (d->sk_tiles + 4), h->stream));  // (the queue's head)
     sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
     KLAUNCH(h, cls, stg::gemm_launch_split(d->gemm_variant, d->sk_grid, h->stream, g, sk));
     return 0;
@@ -148,24 +125,6 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   if (big)
     KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g, d ? d->cus : 0));
   else {
-    // few small tiles of a deep product: cut the k ranges so that every CU holds several workgroups.  Measured (K = 100,
-    // nx = 700 / 1000 / 1500 / 2000): 27.0 / 27.6 / 42.4 / 73.5 ms per factorisation against 15.2 / 21.6 / 38.4 / 69.9 without -
-    // the loop was waiting for its loads, not for workgroups (GemmTile::accumulate now keeps four slabs in flight);
-    // an experiment behind HQPKKT_SPLIT64
-    static const bool no64 = getenv("HQPKKT_SPLIT64") == nullptr;
-    const long long nslab = (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK;
-    if (!no64 && d && allow_sk && d->sk_grid > 0 && d->cus > 0 && nslab >= 32 && tiles >= 16 &&
-        tiles < (long long)stg::GEMM_SPLIT64_WGS_PER_CU * d->cus * 3 / 4 && tiles + 4 <= d->sk_cnt_elems) {
-      const int grid = stg::GEMM_SPLIT64_WGS_PER_CU * d->cus;
-      stg::SplitPlan sk = stg::gemm_split_plan(tiles, nslab, grid);
-      const long long pieces = stg::gemm_split_plan_pieces(sk);
-      if (pieces > 0 && pieces * 64 * 64 <= d->sk_ws_elems) {
-        if (sk.dynamic) HIPCHK(hipMemsetAsync(d->sk_cnt.p, 0, sizeof(unsigned) * (tiles + 4), h->stream));
-        sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
-        KLAUNCH(h, cls, stg::gemm_launch_split64(grid, h->stream, g, sk));
-        return 0;
-      }
-    }
     // few tiles of a deep rectangular product (W of a stage of ~1000 states: 272): 64 x 32 tiles, so that a CU holds two
     // workgroups and one multiplies while the other waits at its barrier: 81 -> 73 us (HQPKKT_NO_TILE6432: off)
     static const bool t6432 = getenv("HQPKKT_NO_TILE6432") == nullptr;
@@ -174,16 +133,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
       KLAUNCH(h, cls, (stg::k_dgemm_tn<64, 32><<<(unsigned)t2, 256, stg::gemm_lds_bytes(64, 32), h->stream>>>(g)));
       return 0;
     }
-    // The same tiles with their operands by LDS-DMA, three buffers, swizzled unpadded rows (accumulate_dma64): exact, and
-    // SLOWER than the register-staged loop with four slabs in flight (W of a 1000-state stage 96.7 against 81.4 us,
-    // G 63.5 against 48.6; K = 100: nx = 1000 / 2000 / 3000 factor in 22.4 / 73.1 / 165.0 ms against 20.0 / 68.9 / 160.2) - a
-    // workgroup alone on its CU idles the matrix pipe around every barrier whatever stages its operands.  Behind
-    // HQPKKT_DMA64.
-    static const bool no_dma64 = getenv("HQPKKT_DMA64") == nullptr;
-    if (!no_dma64 && d && g.zeros && d->gemm_variant != stg::GEMM_REG4 && g.K >= 4 * stg::GEMM_BK && (g.lda % 2) == 0 && (g.ldb % 2) == 0)
-      KLAUNCH(h, cls, (stg::k_dgemm_tn<64, 64, true, 2, 2, 3><<<(unsigned)tiles, 256, stg::GEMM_DMA64_LDS, h->stream>>>(g)));
-    else
-      KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
+    KLAUNCH(h, cls, stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g));
   }
   return 0;
 }
@@ -407,8 +357,8 @@ static int staged_upload(hqpkkt_t *h) {
     if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
       d.sk_grid = stg::gemm_wgs_per_cu(stg::gemm_variant_from_env()) * cus;
       // (the cut form of the 64 x 64 tiles: at most two phases of one unit per workgroup, up to 3/4 of its grid in tiles)
-      d.sk_ws_elems = std::max<long long>(std::max<long long>(pmax, 1) * 128 * 128, 2LL * stg::GEMM_SPLIT64_WGS_PER_CU * cus * 64 * 64);
-      d.sk_cnt_elems = std::max<long long>(d.sk_tiles, (long long)stg::GEMM_SPLIT64_WGS_PER_CU * cus) + 4;
+      d.sk_ws_elems = std::max<long long>(pmax, 1) * 128 * 128;
+      d.sk_cnt_elems = d.sk_tiles + 4;
       if ((e = d.sk_ws.alloc((size_t)d.sk_ws_elems)) || (e = d.sk_cnt.alloc((size_t)d.sk_cnt_elems))) return e;
       HIPCHK(hipMemset(d.sk_cnt.p, 0, sizeof(unsigned) * (size_t)d.sk_cnt_elems));
     }

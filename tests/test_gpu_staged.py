@@ -375,13 +375,9 @@ def test_staged_mid_size_stages_against_the_tree_engine(nx, nu, K):
     assert rel_err(ds, df) <= SOL_TOL
 
 
-@pytest.mark.parametrize("dma64", [False, True])
-def test_dgemm_kernel_against_exact_products(dma64, monkeypatch):
+def test_dgemm_kernel_against_exact_products():
     """k_dgemm_tn (both tile sizes, ragged edges, lower / mirrored output, K not a multiple
-    of the slab) against exactly accumulated sample entries.  dma64: the 64 x 64 tiles on the LDS-DMA loop (an experiment
-    that stays in the library behind HQPKKT_DMA64; the default is the register-staged loop)."""
-    if dma64:
-        monkeypatch.setenv("HQPKKT_DMA64", "1")
+    of the slab) against exactly accumulated sample entries."""
     for (M, N, K, lower, mirror) in [(64, 64, 16, 0, 0), (100, 37, 53, 0, 0), (130, 130, 70, 1, 0), (130, 130, 70, 1, 1),
                                      (640, 520, 300, 0, 0), (700, 700, 129, 1, 1), (513, 1100, 1, 0, 0), (48, 2000, 48, 0, 0),
                                      # the 64 x 64 tiles at the shapes of a 1000-state stage, ragged ones, four slabs + 1 row

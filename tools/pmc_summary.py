@@ -45,6 +45,10 @@ def main():
         res[k] = {"launches": fn, "FETCH_SIZE_KB_per_launch": ft / max(fn, 1),
                   "WRITE_SIZE_KB_per_launch": wt / max(wn, 1),
                   "hbm_bytes_per_launch": (2 * ft / max(fn, 1) + wt / max(wn, 1)) * 1024}
+    # which kernel sources these figures belong to (bench.py quotes them only for the same sources)
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    res["_kernel_source_sha16"] = bench.kernel_source_sha16()
     json.dump(res, open(os.path.join(out, "pmc_traffic.json"), "w"), indent=1)
 
 
