@@ -69,7 +69,7 @@ class IpOpts(C.Structure):
     _fields_ = [("eps", C.c_double), ("max_iters", C.c_int), ("gammaf", C.c_double),
                 ("norm_data", C.c_double), ("hot_start", C.c_int), ("max_warm_iters", C.c_int),
                 ("init_method", C.c_int), ("reserved", C.c_int * 1),
-                ("norm_Q", C.c_double), ("norm_C", C.c_double), ("norm_d", C.c_double)]
+                ("norm_Q", C.c_double), ("norm_C", C.c_double), ("norm_d", C.c_double), ("qp_mu0", C.c_double)]
 
 
 class IpResult(C.Structure):

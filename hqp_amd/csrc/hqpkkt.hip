@@ -17,6 +17,7 @@
 #include "staged_plan.hpp"
 #include "kernels.hip.h"
 #include "factor_blk.hip.h"
+#include "solve_top.hip.h"
 #ifndef FB_OWNSIMD
 #define FB_OWNSIMD false  // true: the elimination wavefront of k_factor_blk shares its SIMD with no block-holding wavefront (measured slower)
 #endif
@@ -85,11 +86,11 @@ struct CsrBuf {
 // per-kernel-class device timing (hqpkkt_set_profile): HIP events on the
 // handle's stream around every launch, summed per class after the call
 enum { KC_ASSEMBLE = 0, KC_FACTOR_DIAG, KC_PANEL_SOLVE, KC_SCHUR_UPDATE,
-       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_ST_GEMM, KC_ST_SMALL, KC_ST_VEC, KC_ST_GEMM_UPD, KC_XCHG, KC_COUNT };
+       KC_SOLVE_FWD, KC_SOLVE_BWD, KC_VECTOR, KC_RESIDUAL, KC_ST_GEMM, KC_ST_SMALL, KC_ST_VEC, KC_ST_GEMM_UPD, KC_XCHG, KC_SOLVE_TOP, KC_COUNT };
 static const char *const kc_names[KC_COUNT] = {"assemble", "factor_diag", "panel_solve",
                                                "schur_update", "solve_fwd", "solve_bwd", "vector",
                                                "residual", "staged_gemm", "staged_small", "staged_gemv", "staged_gemm_upd",
-                                               "exchange"};
+                                               "exchange", "solve_top"};
 struct Prof {
   bool on = false;
   std::vector<hipEvent_t> pool;
@@ -208,6 +209,10 @@ struct hqpkkt {
   // per schedule and tree level the largest pivot count among the general fronts of the level
   bool old_fd = false;
   std::vector<int> level_maxp[2];
+  // the top levels of the tree solved in one launch (solve_top.hip.h): fronts of the levels >= top_lt, root first
+  int top_n = 0, top_lt = 1 << 30;
+  size_t top_lds = 0;
+  DBuf<int> top_nodes, top_idx, top_sync;
   // captured kernel sequences (factor; step on the caller's vectors; step on the
   // refinement's residual vectors): replayed with hipGraphLaunch
   struct GraphSlot {
@@ -223,6 +228,9 @@ struct hqpkkt {
   // inside hqpkkt_mehrotra: factor() returns without waiting for its status (read with the
   // residual of the solve that follows), solve() leaves its result in the stream
   bool lazy = false, factor_unchecked = false;
+  // hqpkkt_franke: the first residual of a solve is not waited for - it comes back with the scalars of the iteration
+  // (one read-back per iteration); residual_pending: such a residual is in the stream, collect_residual() reads it
+  bool defer_residual = false, residual_pending = false;
   bool soft_singular = false;  // the factorisation perturbed an exactly zero pivot (counters[3])
   bool soft_tiny = false;      // ... or met a pivot below 1e-13 max|K| on a multiplier-type row (counters[4])
   double refine_target = 0.0;  // > 0: the refinement of hqpkkt_solve aims below mat_eps (set by hqpkkt_franke)
@@ -253,7 +261,8 @@ struct hqpkkt {
   }
   void release_device(bool keep_ip = false) {  // keep_ip: hqpkkt_mehrotra's vectors and the pinned words stay
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
-                       &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags};
+                       &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags,
+                       &top_nodes, &top_idx, &top_sync};
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release(), simple_src.release(), simple_wi.release();
     DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off, &pinv_off,
@@ -427,13 +436,44 @@ static int upload(hqpkkt_t *h) {
       for (int q = S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l]; q < S.level_ptr[l + 1]; q++)
         h->level_maxp[w][l] = std::max(h->level_maxp[w][l], an.npiv[S.level_nodes[q]]);
   }
+  // the fused top of the solve sweeps: the highest levels whose fronts all fit k_solve_top, at most ST_MAXFRONTS fronts
+  // (single rank: with a sharded tree the forward and backward sweeps of a schedule are not adjacent)
+  h->top_n = 0, h->top_lt = 1 << 30, h->top_lds = 0;
+  if (!getenv("HQPKKT_NO_SOLVE_TOP") && an.shard_count == 1 && an.sched[0].nnodes > 0) {
+    const Analysis::Sched &S = an.sched[0];
+    int lt = an.nlevels, cnt = 0, maxp = 0;
+    for (int l = an.nlevels - 1; l >= 0; l--) {
+      const int nn = S.level_ptr[l + 1] - S.level_ptr[l];
+      bool fits = cnt + nn <= ST_MAXFRONTS;
+      int mp2 = maxp;
+      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1] && fits; q++) {
+        const int v = S.level_nodes[q];
+        fits = an.npiv[v] <= ST_MAXP && an.nbor[v] <= ST_MAXB;
+        mp2 = std::max(mp2, an.npiv[v]);
+      }
+      if (!fits) break;
+      cnt += nn, lt = l, maxp = mp2;
+    }
+    if (an.nlevels - lt >= 2 && cnt >= 2) {
+      std::vector<int> nodes, idx(an.nnodes, -1);
+      for (int l = an.nlevels - 1; l >= lt; l--)
+        for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) idx[S.level_nodes[q]] = (int)nodes.size(), nodes.push_back(S.level_nodes[q]);
+      std::vector<int> zero(2 * nodes.size(), 0);
+      if ((e = h->top_nodes.upload(nodes)) || (e = h->top_idx.upload(idx)) || (e = h->top_sync.upload(zero))) return e;
+      h->top_n = (int)nodes.size(), h->top_lt = lt, h->top_lds = st_top_lds_bytes(maxp);
+    }
+  }
   {
     // the attribute is state of the PROCESS, not of the handle: a second handle with smaller fronts must
     // not lower the limit under one that still launches with more (several plugins in one host, the
     // bench's concurrent systems): keep the largest value ever asked for, under a mutex
     static std::mutex attr_mutex;
-    static size_t a_diag = 0, a_panel = 0, a_bwdb = 0, a_blk = 0;
+    static size_t a_diag = 0, a_panel = 0, a_bwdb = 0, a_blk = 0, a_top = 0;
     std::lock_guard<std::mutex> lk(attr_mutex);
+    if (h->top_lds > a_top) {
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->top_lds));
+      a_top = h->top_lds;
+    }
     if (lds_blk > a_blk) {
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
@@ -642,7 +682,8 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   auto forward = [&](int which) -> int {
     const Analysis::Sched &S = an.sched[which];
     const hqpkkt::DevSched &D = h->ds[which];
-    for (int l = 0; l < an.nlevels && S.nnodes; l++) {
+    const int lend = which == 0 && h->top_n > 0 ? h->top_lt : an.nlevels;  // (the levels above: k_solve_top)
+    for (int l = 0; l < lend && S.nnodes; l++) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l];
       if (nfs > 0)
         KLAUNCH(h, KC_SOLVE_FWD,
@@ -670,7 +711,8 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   auto backward = [&](int which) -> int {
     const Analysis::Sched &S = an.sched[which];
     const hqpkkt::DevSched &D = h->ds[which];
-    for (int l = an.nlevels - 1; l >= 0 && S.nnodes; l--) {
+    const int lbeg = which == 0 && h->top_n > 0 ? h->top_lt - 1 : an.nlevels - 1;
+    for (int l = lbeg; l >= 0 && S.nnodes; l--) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l];
       const int ncb = S.cblk_ptr[l + 1] - S.cblk_ptr[l];
       if (nn <= 0) continue;
@@ -703,6 +745,10 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   }
   if (phases & 2) {
     forward(1);
+    if (h->top_n > 0)  // the top levels, up and down, in one launch
+      KLAUNCH(h, KC_SOLVE_TOP, k_solve_top<<<h->top_n, ST_THREADS, h->top_lds, s>>>(T, h->top_nodes.p, h->top_idx.p, h->top_sync.p, h->top_n,
+                                                       h->panel.p, h->linv.p, h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p,
+                                                       h->rhs.p, h->xsol.p, h->cb.p, h->flags.p));
     backward(1);
     backward(0);
     if (an.shard_count > 1)  // leave only this rank's share for the all-reduce
@@ -826,6 +872,7 @@ struct OutPtrs {
 };
 static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, const double **x2, int *ndyn);
 
+static int collect_residual(hqpkkt_t *h, double *res);
 static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *out = nullptr) {
   Analysis &an = h->an;
   hipStream_t s = h->stream;
@@ -851,11 +898,29 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
     if (e2) return e2;
   }
   // one copy: the residual maximum and the status of the factorisation this solve belongs to
+  HIPCHK(hipMemcpyAsync((int *)h->hpin, h->flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost, s));
+  if (h->defer_residual && !out) {  // the caller queues more work and waits once (collect_residual)
+    h->residual_pending = true;
+    *res = 0.0;
+    return 0;
+  }
+  HIPCHK(hipStreamSynchronize(s));
+  return collect_residual(h, res);
+}
+
+// the words run_residual copied to the pinned buffer, after the stream has been waited for
+static int collect_residual(hqpkkt_t *h, double *res) {
+  hipStream_t s = h->stream;
+  h->residual_pending = false;
   const bool check = h->factor_unchecked;
   int *hs = (int *)h->hpin;
-  HIPCHK(hipMemcpyAsync(hs, h->flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost, s));
-  HIPCHK(hipStreamSynchronize(s));
   int flags[4] = {hs[0], hs[1], hs[2], hs[3]};
+  if (hs[ST_GAVE_UP]) {  // k_solve_top gave up waiting for a front: clear its protocol words, report, do not hang
+    (void)hipMemsetAsync(h->top_sync.p, 0, sizeof(int) * 2 * h->top_n, s);
+    (void)hipMemsetAsync(h->flags.p + ST_GAVE_UP, 0, sizeof(int), s);
+    (void)hipStreamSynchronize(s);
+    return HQPKKT_E_DEVICE;
+  }
   unsigned long long kb, bits;
   std::memcpy(&kb, hs + 120, sizeof(kb)), std::memcpy(&bits, hs + 122, sizeof(bits));
   double r;
@@ -1230,6 +1295,8 @@ int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w, const double 
   return e;
 }
 
+static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
+                      const double *r4, double *dx, double *dy, double *dz, double *dw, double res, double *res_out);
 // Hqp_IpMatrix::solve (hqp/Hqp_IpMatrix.C:65-128)
 int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1,
                  const double *r2, const double *r3, const double *r4, double *dx, double *dy,
@@ -1237,7 +1304,6 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if (!h) return HQPKKT_E_NULL;
   if (!h->factored) return HQPKKT_E_INTERN;
   HIPCHK(hipSetDevice(h->opts.device));
-  const int n = h->an.n, me = h->an.me, m = h->an.m;
   hipStream_t s = h->stream;
   Vecs v{};
   int e = stage_in(h, z, w, r1, r2, r3, r4, v);
@@ -1245,9 +1311,23 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   stage_out_ptrs(h, v);
   HIPCHK(hipEventRecord(h->ev0, s));
   if ((e = do_step(h, v, 0))) return e;
-  double res = 0.0, res_last;
+  double res = 0.0;
   const OutPtrs outp{dx, dy, dz, dw};
   if ((e = run_residual(h, v, &res, h->lazy ? nullptr : &outp))) return e;
+  if (h->residual_pending) {  // (hqpkkt_franke: solve_tail follows if the residual, once read, asks for it)
+    if (res_out) *res_out = 0.0;
+    return stage_out(h, v, dx, dy, dz, dw);
+  }
+  return solve_tail(h, v, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res, res_out);
+}
+
+// refinement and the checks of hqpkkt_solve, from the residual `res` of the first solution on
+static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
+                      const double *r4, double *dx, double *dy, double *dz, double *dw, double res, double *res_out) {
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  hipStream_t s = h->stream;
+  int e;
+  double res_last;
   const double target = h->refine_target > 0.0 ? std::fmin(h->opts.eps, h->refine_target) : h->opts.eps;
   const bool refined = res > target;  // otherwise the caller's copy is already complete
   const double res_first = res;
@@ -1752,7 +1832,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     hipStream_t s = h->stream;
     const size_t nv = (size_t)n + me + 2 * (size_t)m;
     // same arena as hqpkkt_mehrotra (its hot-start data does not survive this call)
-    const size_t need = 4 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;
+    const size_t need = 5 * nv + (size_t)n + me + m + (size_t)IP_BLOCKS * IP_SLOTS + 64 + 2 * (size_t)m;  // (+ nv: the iterate before a step)
     int e;
     if (h->ipv.count < need) {
       if ((e = h->ipv.alloc(need))) return e;
@@ -1770,6 +1850,8 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     C.dx = take(n), C.dy = take(me), C.dz = take(m), C.dw = take(m);
     C.c = take(n), C.b = take(me), C.d = take(m);
     C.part = take((size_t)IP_BLOCKS * IP_SLOTS), C.out = take(64);
+    (void)take(2 * (size_t)m);
+    double *const keep = take(nv);  // x, y, z, w before the step of an iteration (see below)
     const hipMemcpyKind in_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
     const hipMemcpyKind out_kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     if (n) HIPCHK(hipMemcpyAsync(C.c, c, sizeof(double) * n, in_kind, s));
@@ -1779,7 +1861,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     struct Restore {
       hqpkkt_t *h;
       int loc;
-      ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
+      ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false, h->defer_residual = false, h->residual_pending = false; }
     } restore{h, saved_loc};
     h->opts.loc = HQPKKT_LOC_DEVICE;
     h->lazy = true;
@@ -1841,8 +1923,14 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       const int opsd[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
       if ((e = C.reduce(opsd, 3))) return e;
       const double min_d = C.hout[0], norm_d = C.hout[1];
-      Ltilde = std::fmax(norm_d, -min_d);  // "according Wright" (qp_mu0 = 0)
-      Ltilde = std::fmax(Ltilde, 1e2 * m);
+      if (o.qp_mu0 > 0.0) {  // "choose Ltilde according _mu0" (:167-173)
+        const double mean_d_h = 0.5 * C.hout[2] / (double)m;
+        Ltilde = -mean_d_h + std::sqrt(mean_d_h * mean_d_h + (double)m * rhomin * o.qp_mu0);
+        Ltilde = std::fmax(Ltilde, -min_d);
+      } else {  // "according Wright" (:175-182)
+        Ltilde = std::fmax(norm_d, -min_d);
+        Ltilde = std::fmax(Ltilde, 1e2 * m);
+      }
     }
     if (h->short_rows)
       k_fr_cold<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->CT.dev(), Ltilde, C.c, C.b, C.d, C.x, C.y, C.z, C.w, a1, a2, a3, C.part);
@@ -1873,8 +1961,55 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       // far below without refinement, lets that noise block the step near the solution (the loop
       // then creeps on with alpha -> 0).  Ask the solve for a residual below the slacks.
       h->refine_target = m > 0 ? std::fmax(0.05 * gap / (double)m, 2e-12) : 0.0;
+      // One read-back per iteration: the solve leaves its first residual (and the status of the factorisation) in
+      // the stream, the step length is computed and consumed on the device, and residual, status, step length and
+      // the new gap come back together.  When the words then say that the solve was not finished (refinement wanted,
+      // a perturbed pivot to judge, an error), the iterate of before the step is put back, the solve is finished as
+      // hqpkkt_solve would have, and the step is taken again.
+      double *const Sfr = C.out + 32;
+      auto take_step = [&]() -> int {
+        if (m > 0) {
+          k_fr_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
+          IpOps orat;
+          orat.op[0] = IP_MIN;
+          for (int k = 1; k < IP_SLOTS; k++) orat.op[k] = IP_SUM;
+          k_ip_final<<<1, 256, 0, s>>>(C.part, orat, C.out, IpEpi{3, m, 0.0, 0.0, beta, nullptr, Sfr});
+        }
+        k_fr_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, m > 0 ? Sfr + IPS_ALPHA : nullptr, C.x, C.y, C.z, C.w, C.dx,
+                                              C.dy, C.dz, C.dw, C.part);
+        IpOps ou;
+        for (int k = 0; k < IP_SLOTS; k++) ou.op[k] = IP_SUM;
+        ou.op[1] = IP_MAX;
+        k_ip_final<<<1, 256, 0, s>>>(C.part, ou, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
+        HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        return 0;
+      };
+      const double target = std::fmin(h->opts.eps, h->refine_target);
+      h->defer_residual = !getenv("HQPKKT_FRANKE_TWO_READS");
       e = hqpkkt_factor(h, C.z, C.w);
       if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
+      h->defer_residual = false;
+      if (!e && h->residual_pending) {
+        CopyList L{{C.x, C.y, C.z, C.w, nullptr, nullptr}, {keep, keep + n, keep + n + me, keep + n + me + m, nullptr, nullptr}, {n, me, m, m, 0, 0}};
+        k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 4);
+        if ((e = take_step())) return e;
+        e = collect_residual(h, &resid);
+        const bool unfinished = e || !(resid <= target) || h->soft_singular || h->soft_tiny;
+        if (unfinished) {
+          CopyList B{{keep, keep + n, keep + n + me, keep + n + me + m, nullptr, nullptr}, {C.x, C.y, C.z, C.w, nullptr, nullptr}, {n, me, m, m, 0, 0}};
+          k_copy_vectors<<<copy_blocks(B), 256, 0, s>>>(B, 4);
+          if (!e) {
+            Vecs v{};
+            if ((e = stage_in(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, v))) return e;
+            stage_out_ptrs(h, v);
+            e = solve_tail(h, v, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, resid, &resid);
+          }
+          if (!e && (e = take_step())) return e;
+        }
+      } else if (!e) {
+        if ((e = take_step())) return e;
+      }
       h->refine_target = 0.0;
       if (e == HQPKKT_E_SING && hot) {  // Hqp_Degenerate inside a hot start: thrown away (:405-411)
         result = 4;
@@ -1883,25 +2018,6 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       if (e) {
         if (e == HQPKKT_E_SING) return finish(4);  // Hqp_Degenerate (:308-310)
         return e;
-      }
-      // the step length is computed and consumed on the device; it comes back with the new gap
-      double *const Sfr = C.out + 32;
-      if (m > 0) {
-        k_fr_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
-        IpOps orat;
-        orat.op[0] = IP_MIN;
-        for (int k = 1; k < IP_SLOTS; k++) orat.op[k] = IP_SUM;
-        k_ip_final<<<1, 256, 0, s>>>(C.part, orat, C.out, IpEpi{3, m, 0.0, 0.0, beta, nullptr, Sfr});
-      }
-      k_fr_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 1.0, m > 0 ? Sfr + IPS_ALPHA : nullptr, C.x, C.y, C.z, C.w, C.dx,
-                                            C.dy, C.dz, C.dw, C.part);
-      {
-        IpOps ou;
-        for (int k = 0; k < IP_SLOTS; k++) ou.op[k] = IP_SUM;
-        ou.op[1] = IP_MAX;
-        k_ip_final<<<1, 256, 0, s>>>(C.part, ou, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-        HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
       }
       alpha = m > 0 ? C.hout[32 + IPS_ALPHA] : std::fmin(1.0, 2.0 * beta);
       alphabar = 0.5 * alphabar + 0.5 * alpha;
@@ -2421,6 +2537,10 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
     }
     case 30:  // zero-diagonal placement in use, and whether the last values have weak Hessian diagonals
       tmp = {h->zd_used, h->zd_weak ? 1 : 0};
+      v = &tmp;
+      break;
+    case 31:  // the solve's fused top (k_solve_top): number of fronts, first fused level, LDS bytes
+      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds};
       v = &tmp;
       break;
     case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)

@@ -250,13 +250,14 @@ class Hqp_IpMatrix:
         _check(self._L.hqpkkt_debug_get(self._h, what, C.c_void_p(out.ctypes.data), C.byref(k)), "debug_get")
         return out[: k.value]
 
-    def franke(self, qp, eps=1e-10, max_iters=200, hot_start=0):
+    def franke(self, qp, eps=1e-10, max_iters=200, hot_start=0, qp_mu0=0.0):
         """Device-resident run of the reference's other interior-point solver, Hqp_IpsFranke
         (``hqpkkt_franke``): returns (x, y, z, w, info).  ``hot_start`` 1: Hqp_IpsFranke::hot_start
-        from the iterate this handle's previous franke() call ended with."""
-        return self.mehrotra(qp, eps, max_iters, hot_start, _entry="hqpkkt_franke")
+        from the iterate this handle's previous franke() call ended with.  ``qp_mu0``: the reference's
+        interface variable of that name (cold start, hqp/Hqp_IpsFranke.C:167-173)."""
+        return self.mehrotra(qp, eps, max_iters, hot_start, _entry="hqpkkt_franke", qp_mu0=qp_mu0)
 
-    def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0, init_method=0, _entry="hqpkkt_mehrotra"):
+    def mehrotra(self, qp, eps=1e-10, max_iters=200, hot_start=0, init_method=0, _entry="hqpkkt_mehrotra", qp_mu0=0.0):
         """Device-resident Mehrotra predictor-corrector solve of the QP, the restatement of
         hqp/Hqp_IpsMehrotra.C behind ``hqpkkt_mehrotra``: returns (x, y, z, w, info).
         init()/update() must have been called with ``qp``.  ``hot_start``: 0 cold start,
@@ -265,6 +266,7 @@ class Hqp_IpMatrix:
         o = _lib.IpOpts()
         self._L.hqpkkt_default_ip_opts(C.byref(o))
         o.eps, o.max_iters, o.hot_start, o.init_method = eps, max_iters, int(hot_start), int(init_method)
+        o.qp_mu0 = float(qp_mu0)
 
         def rowsum(csr, rows):  # sp_norm_inf (meschach/addon2_hqp.c:723-743)
             p, _i, x = csr

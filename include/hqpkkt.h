@@ -376,6 +376,8 @@ typedef struct hqpkkt_ip_opts {
                        |C| / max(|d|,1e-10) / |Q|; 3 as 0 with r4 = -z.*w and dz, dw added to z, w */
   int reserved[1];
   double norm_Q, norm_C, norm_d; /* inf-norms of Q, C (largest absolute row sum) and d: init_method 1, 2 */
+  double qp_mu0;    /* hqpkkt_franke: qp_mu0 (hqp/Hqp_IpsFranke.C:77,87): > 0 chooses the cold start's Ltilde
+                       from it (:167-173), 0 (default) "according Wright" (:175-182)                    */
 } hqpkkt_ip_opts;
 typedef struct hqpkkt_ip_result {
   int result, iters;     /* Hqp_Result, iterations                                    */
@@ -394,7 +396,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
  * hqpkkt_mehrotra; of hqpkkt_ip_opts it reads eps, max_iters, hot_start (1 = Hqp_IpsFranke::
  * hot_start, :222-266, from the iterate the previous hqpkkt_franke call on this handle ended with;
  * thrown away as in :388-411) and max_warm_iters (0 = 15); qp_beta 0.995 and qp_mu0 0 are the
- * reference's defaults.  res->result: 0 optimal, 3 suboptimal, 4
+ * reference's defaults (qp_mu0: hqpkkt_ip_opts.qp_mu0).  res->result: 0 optimal, 3 suboptimal, 4
  * degenerate, 1 feasible / 2 infeasible when max_iters ends the run. */
 int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
                   const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res);
@@ -410,7 +412,8 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
  * that fix x_0, 26 capacity of carried rows, 27 column cuts of the ranks ((K+1) x (ranks+1)), 28 two counters of
  * the last factorisation: stages whose K was inverted by the blocked elimination, and those of them that fell back to the
  * one-workgroup elimination (device -> host copy); 30 (zero-diagonal policy in use, last
- * values have weak Hessian diagonals).
+ * values have weak Hessian diagonals), 31 (fronts of the tree's top that the solve handles in one launch, first
+ * such level, LDS bytes of that launch).
  * *len receives the element count; out may be NULL to query it. */
 int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len);
 

@@ -39,6 +39,9 @@ extern "C" {
 // reference's own Tcl variable after the solver exists
 static int g_init_method = 0;
 void hqpip_set_init_method(int v) { g_init_method = v; }
+// qp_mu0 of the Franke solvers created below (hqp/Hqp_IpsFranke.C:77,87), set the same way
+static double g_mu0 = 0.0;
+void hqpip_set_mu0(double v) { g_mu0 = v; }
 
 // solver: 0 = Mehrotra, 1 = Franke, 2 = MehrotraHip, 3 = FrankeHip (our Hqp_Solver plugins).  Returns 0, or the Meschach error number,
 // or -1 (setup) / -2 (unknown plugin name).
@@ -77,6 +80,7 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
   S->eps(qp_eps);
   S->max_iters(max_iters);
   if (solver == 0 || solver == 2) (void)If_SetInt("qp_init_method", g_init_method);
+  if (solver == 1 || solver == 3) (void)If_SetReal("qp_mu0", g_mu0);
   int err = 0;
   double t0 = now_s(), t1 = t0, t2 = t0;
   m_catchall(S->init(); S->update(); t1 = now_s(); S->cold_start(); S->solve(); t2 = now_s(),
@@ -176,6 +180,7 @@ int hqpip_solve_hot(int solver, const char *mat_solver, int n, int me, int m, co
   S->eps(qp_eps);
   S->max_iters(max_iters);
   if (solver == 0 || solver == 2) (void)If_SetInt("qp_init_method", g_init_method);
+  if (solver == 1 || solver == 3) (void)If_SetReal("qp_mu0", g_mu0);
   int err = 0, it1 = 0;
   double t1 = now_s(), t2 = t1;
   m_catchall(S->init(); S->update(); S->cold_start(); S->solve(); it1 = S->iter();

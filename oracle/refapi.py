@@ -223,11 +223,16 @@ def host_available(host="ref"):
         return False
 
 
-def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250, init_method=0):
+def ip_solve(prog, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250, init_method=0, qp_mu0=0.0):
     """Run Hqp_IpsMehrotra / Hqp_IpsFranke of the reference on ``prog`` with the KKT
     plugin ``mat_solver``.  Returns dict(x, y, z, iters, result, seconds)."""
     lib = _host(host)
     lib.hqpip_set_init_method(int(init_method))
+    if hasattr(lib, "hqpip_set_mu0"):
+        lib.hqpip_set_mu0.argtypes = [C.c_double]
+        lib.hqpip_set_mu0(float(qp_mu0))
+    elif qp_mu0:
+        raise RefError(-1, "this oracle/_ref build has no hqpip_set_mu0")
     n, me, m = prog.dims
     args = []
     for (p, i, x), vec in zip((prog.Q, prog.A, prog.C), (prog.c, prog.b, prog.d)):

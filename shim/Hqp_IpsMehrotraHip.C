@@ -25,6 +25,7 @@ Hqp_IpsMehrotraHip::Hqp_IpsMehrotraHip()
   _hot = 2;
   _max_warm_iters = 25;  // hqp/Hqp_IpsMehrotra.C:111
   _init_method = 0;      // hqp/Hqp_IpsMehrotra.C:112
+  _mu0 = 0.0;            // hqp/Hqp_IpsFranke.C:77
   _n_factor = _n_solve = 0;
   _ms_total = 0.0;
   _matrix = new Hqp_IpRedSpBKPHip;
@@ -94,7 +95,13 @@ void Hqp_IpsMehrotraHip::solve()
   run(false);
 }
 
-// hqp/Hqp_IpsFranke.C on the device (hqpkkt_franke; cold start, qp_beta 0.995, qp_mu0 0)
+// hqp/Hqp_IpsFranke.C on the device (hqpkkt_franke; qp_beta 0.995, qp_mu0 as the reference's interface variable)
+Hqp_IpsFrankeHip::Hqp_IpsFrankeHip()
+{
+  _max_warm_iters = 15;
+  _ifList.append(new If_Real("qp_mu0", &_mu0));
+}
+
 void Hqp_IpsFrankeHip::solve()
 {
   run(true);
@@ -115,6 +122,7 @@ void Hqp_IpsMehrotraHip::run(bool franke)
   opts.hot_start = _hot;
   opts.max_warm_iters = _max_warm_iters;
   opts.init_method = _init_method;
+  opts.qp_mu0 = franke ? _mu0 : 0.0;
   opts.norm_Q = sp_norm_inf(_qp->Q), opts.norm_C = sp_norm_inf(_qp->C), opts.norm_d = v_norm_inf(_qp->d);
   // hqp/Hqp_IpsMehrotra.C:462-464
   opts.norm_data = max(max(max(max(max(opts.norm_Q, sp_norm_inf(_qp->A)), opts.norm_C), v_norm_inf(_qp->c)),

@@ -31,6 +31,7 @@ class Hqp_IpsMehrotraHip : public Hqp_Solver {
   int _hot;                 // how the next solve() starts: hqpkkt_ip_opts.hot_start
   int _max_warm_iters;      // qp_max_warm_iters (hqp/Hqp_IpsMehrotra.C:111,122)
   int _init_method;         // qp_init_method (hqp/Hqp_IpsMehrotra.C:112,124)
+  Real _mu0;                // FrankeHip: qp_mu0 (hqp/Hqp_IpsFranke.C:77,87)
   Hqp_IpMatrix *_matrix;
 
  public:
@@ -55,7 +56,7 @@ class Hqp_IpsMehrotraHip : public Hqp_Solver {
 // hqp/Hqp_IpsFranke.C:81)
 class Hqp_IpsFrankeHip : public Hqp_IpsMehrotraHip {
  public:
-  Hqp_IpsFrankeHip() { _max_warm_iters = 15; }
+  Hqp_IpsFrankeHip();
   void solve();
   const char *name() { return "FrankeHip"; }
 };

@@ -1,0 +1,26 @@
+"""GPU (-m gpu): hqpkkt_franke with one read-back per iteration (the first residual of the solve comes back with the
+scalars of the step; an unfinished solve puts the iterate back, refines and takes the step again) against the same
+loop waiting for the residual before the step (HQPKKT_FRANKE_TWO_READS): the same arithmetic, so the same iterates."""
+import numpy as np
+import pytest
+
+from hqp_amd import ipmatrix, problems
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("case", ["banded", "did400", "did2000", "lq"])
+def test_franke_one_read_back_gives_the_same_iterates(case, monkeypatch):
+    prog = {"banded": lambda: problems.banded_qp(300, 8, 5), "did400": lambda: problems.did_like_qp(400),
+            "did2000": lambda: problems.did_like_qp(2000), "lq": lambda: problems.lq_docp(40, 6, 2, final_eq=2)}[case]()
+    A = ipmatrix.IpRedSpBKP()
+    A.init(prog)
+    xa, ya, za, wa, ia = A.franke(prog, max_iters=300)
+    monkeypatch.setenv("HQPKKT_FRANKE_TWO_READS", "1")
+    B = ipmatrix.IpRedSpBKP()
+    B.init(prog)
+    xb, yb, zb, wb, ib = B.franke(prog, max_iters=300)
+    assert (ia["result"], ia["iters"]) == (ib["result"], ib["iters"]), (ia, ib)
+    assert ia["result"] == 0
+    for u, v in ((xa, xb), (ya, yb), (za, zb), (wa, wb)):
+        assert np.array_equal(u, v)

@@ -1,0 +1,80 @@
+"""GPU (-m gpu): the top levels of the tree solve in one launch (k_solve_top, hqp_amd/csrc/solve_top.hip.h) against
+the per-level kernels on the same factorisation data, against the CPU oracle, and repeated (the protocol words of
+the launch reset themselves)."""
+import numpy as np
+import pytest
+
+from hqp_amd import ipmatrix, problems
+from oracle import oracleapi
+
+pytestmark = pytest.mark.gpu
+
+
+def _solve(cls, prog, st, **kw):
+    M = cls(**kw)
+    M.init(prog)
+    d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    M.factor(prog, st[0], st[1])
+    res = M.solve(prog, *st, *d)
+    return M, d, res
+
+
+@pytest.mark.parametrize("n,band,cls", [(3000, 20, ipmatrix.IpRedSpBKP), (6000, 40, ipmatrix.IpSpBKP),
+                                        (12000, 80, ipmatrix.IpRedSpBKP), (9000, 85, ipmatrix.IpSpBKP)])
+def test_fused_top_against_the_per_level_sweeps(n, band, cls, monkeypatch):
+    """Same system, same factorisation kernels; the solve with the fused top and with HQPKKT_NO_SOLVE_TOP: both below
+    the residual tolerance, solutions equal to rounding (the order of summation differs), and the fused launch is
+    really in use (introspection 31)."""
+    prog = problems.banded_qp(n, band, seed=7)
+    st = problems.ip_state(prog, seed=3)
+    A, da, ra = _solve(cls, prog, st)
+    top = A.debug(31)
+    assert top[0] >= 3 and top[1] < A.stats()["n_levels"], top
+    monkeypatch.setenv("HQPKKT_NO_SOLVE_TOP", "1")
+    B, db, rb = _solve(cls, prog, st)
+    assert B.debug(31)[0] == 0
+    assert ra <= 1e-10 and rb <= 1e-10, (ra, rb)
+    for x, yv in zip(da, db):
+        if len(x):
+            assert np.abs(x - yv).max() <= 1e-9 * max(1.0, np.abs(yv).max())
+    # repeated solves on one handle: the protocol words are back to zero after every launch
+    for _ in range(5):
+        d2 = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+        r2 = A.solve(prog, *st, *d2)
+        assert r2 == ra
+        for x, yv in zip(d2, da):
+            assert np.array_equal(x, yv)  # reproducible from run to run
+
+
+def test_fused_top_against_the_oracle():
+    prog = problems.banded_qp(1600, 32, seed=11)
+    st = problems.ip_state(prog, seed=5)
+    O = oracleapi.OracleIpMatrix("SpBKP")
+    O.init(prog)
+    O.factor(st[0], st[1])
+    osol, ores = O.solve(*st)
+    M, d, res = _solve(ipmatrix.IpSpBKP, prog, st)
+    assert M.debug(31)[0] >= 3
+    assert res <= 1e-10
+    assert O.residuum(*st, *d) <= ores + 1e-10 * max(1.0, max(np.abs(v).max() for v in d if len(v)))
+
+
+def test_fused_top_on_deep_trees_of_small_fronts():
+    """Double-integrator DOCP (fronts of a few pivots, a tree of a dozen levels): the fused launch holds the top
+    levels; device-resident Mehrotra loop with it and without: same iteration count, same optimiser."""
+    import os
+    prog = problems.did_like_qp(400)
+    A = ipmatrix.IpRedSpBKP()
+    A.init(prog)
+    assert A.debug(31)[0] >= 3
+    xa = A.mehrotra(prog)
+    os.environ["HQPKKT_NO_SOLVE_TOP"] = "1"
+    try:
+        B = ipmatrix.IpRedSpBKP()
+        B.init(prog)
+        assert B.debug(31)[0] == 0
+        xb = B.mehrotra(prog)
+    finally:
+        del os.environ["HQPKKT_NO_SOLVE_TOP"]
+    assert xa[-1]["iters"] == xb[-1]["iters"] and xa[-1]["result"] == 0
+    assert np.abs(xa[0] - xb[0]).max() <= 1e-7 * max(1.0, np.abs(xb[0]).max())

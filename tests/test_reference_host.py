@@ -489,6 +489,31 @@ def test_device_resident_franke_follows_the_reference(case, kind):
         assert np.abs(hh["x"] - x).max() <= 1e-9 * max(1.0, np.abs(x).max())
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("mu0", [1e-3, 1.0, 50.0])
+@pytest.mark.parametrize("case", ["banded", "did400"])
+def test_device_resident_franke_with_qp_mu0(case, mu0):
+    """qp_mu0 > 0 (hqp/Hqp_IpsFranke.C:167-173: the cold start's Ltilde from the mean of d, m, rhomin and mu0 instead
+    of "according Wright"): the reference's Hqp_IpsFranke with that interface variable set against hqpkkt_franke with
+    hqpkkt_ip_opts.qp_mu0 - same result, iteration counts as in the test above, same x; and the variable changes
+    the run (another iteration count than qp_mu0 = 0 for at least one of the values, on the reference's side too)."""
+    from hqp_amd import ipmatrix
+    if not refapi.host_available("ref") or not hasattr(refapi._host("ref"), "hqpip_set_mu0"):
+        pytest.skip("oracle/_ref not present (or built before hqpip_set_mu0)")
+    prog = problems.banded_qp(300, 8, 5) if case == "banded" else problems.did_like_qp(400)
+    ref = refapi.ip_solve(prog, "Franke", "RedSpBKP", max_iters=300, qp_mu0=mu0)
+    M = ipmatrix.IpRedSpBKP()
+    M.init(prog)
+    x, _y, _z, _w, info = M.franke(prog, max_iters=300, qp_mu0=mu0)
+    assert info["result"] == ref["result"], (info, ref["result"], ref["iters"])
+    slack = max(2, ref["iters"] // 10) if case.startswith("did") else 0
+    assert abs(info["iters"] - ref["iters"]) <= slack, (info["iters"], ref["iters"])
+    assert np.abs(x - ref["x"]).max() <= (1e-4 if case.startswith("did") else 1e-6) * max(1.0, np.abs(ref["x"]).max())
+    if refapi.host_available("hip"):
+        hh = refapi.ip_solve(prog, "FrankeHip", "RedSpBKPHip", host="hip", max_iters=300, qp_mu0=mu0)
+        assert (hh["result"], hh["iters"]) == (info["result"], info["iters"])
+
+
 @needs_ref
 def test_reference_sqp_demo_reproduces_the_survey_pins():
     """BASELINE.json configs[0] (plumbing, no GPU): the reference's hqp_docp demo - Prg_DID with
