@@ -29,7 +29,7 @@ SYMBOLS = [
     "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm",
     "hqpkkt_analyze_staged", "hqpkkt_set_values_staged", "hqpkkt_set_shard_stream",
     "hqpkkt_values_staging", "hqpkkt_detect_stages", "hqpkkt_stage_staging", "hqpkkt_set_stage_block",
-    "hqpkkt_debug_factor_block",
+    "hqpkkt_debug_factor_block", "hqpkkt_debug_solve_top_stamps",
 ]
 RCCL_LIB_PATH = os.path.join(_HERE, "libhqpkkt_rccl.so")
 RCCL_SYMBOLS = ["hqpkkt_rccl_unique_id", "hqpkkt_rccl_create", "hqpkkt_rccl_create_from_env",
@@ -137,6 +137,7 @@ def lib():
     L.hqpkkt_values_staging.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.hqpkkt_set_shard_stream.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.hqpkkt_debug_dgemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)] * 2
+    L.hqpkkt_debug_solve_top_stamps.argtypes = [vp, vp, C.c_int]
     L.hqpkkt_debug_factor_block.argtypes = [C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_int, C.c_int] + [vp] * 7
     _lib = L
     return L

@@ -210,9 +210,11 @@ struct hqpkkt {
   bool old_fd = false;
   std::vector<int> level_maxp[2];
   // the top levels of the tree solved in one launch (solve_top.hip.h): fronts of the levels >= top_lt, root first
-  int top_n = 0, top_lt = 1 << 30;
+  int top_n = 0, top_lt = 1 << 30, top_ns = 3;  // top_ns: 3 = k_solve_top<3, 11>, 4 = <4, 10>
   size_t top_lds = 0;
-  DBuf<int> top_nodes, top_idx, top_sync;
+  DBuf<int> top_nodes, top_idx, top_bpos, top_words;
+  unsigned long long *top_stamps = nullptr;  // (hqpkkt_debug_solve_top_stamps)
+  DBuf<double> top_x;  // the exchange arrays of the launch: 2 x top_n x ST_CS contributions, then 2 x top_n x ST_XS solution
   // captured kernel sequences (factor; step on the caller's vectors; step on the
   // refinement's residual vectors): replayed with hipGraphLaunch
   struct GraphSlot {
@@ -262,14 +264,14 @@ struct hqpkkt {
   void release_device(bool keep_ip = false) {  // keep_ip: hqpkkt_mehrotra's vectors and the pinned words stay
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
                        &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags,
-                       &top_nodes, &top_idx, &top_sync};
+                       &top_nodes, &top_idx, &top_bpos, &top_words};
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release(), simple_src.release(), simple_wi.release();
     DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off, &pinv_off,
                              &zero_panel};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &top_x};
     for (auto b : db) b->release();
     if (!keep_ip) ipv.release();
     terms.release(), esign.release(), bits.p = nullptr;
@@ -312,6 +314,17 @@ static int ensure_device(hqpkkt_t *h) {
     HIPCHK(hipEventCreate(&h->evt1));
   }
   if (!h->stream) h->stream = h->own_stream;
+  return 0;
+}
+
+// the exchange arrays of k_solve_top in their idle state: every word the sentinel, counters zero
+static int reset_solve_top(hqpkkt_t *h) {
+  if (h->top_n <= 0) return 0;
+  std::vector<double> fill(2 * (size_t)h->top_n * (ST_CS + ST_XS));
+  for (auto &x : fill) std::memcpy(&x, &ST_SENTINEL, sizeof(double));
+  HIPCHK(hipStreamSynchronize(h->stream));
+  HIPCHK(hipMemcpy(h->top_x.p, fill.data(), sizeof(double) * fill.size(), hipMemcpyHostToDevice));
+  HIPCHK(hipMemset(h->top_words.p, 0, sizeof(int) * 2));
   return 0;
 }
 
@@ -436,31 +449,46 @@ static int upload(hqpkkt_t *h) {
       for (int q = S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l]; q < S.level_ptr[l + 1]; q++)
         h->level_maxp[w][l] = std::max(h->level_maxp[w][l], an.npiv[S.level_nodes[q]]);
   }
-  // the fused top of the solve sweeps: the highest levels whose fronts all fit k_solve_top, at most ST_MAXFRONTS fronts
-  // (single rank: with a sharded tree the forward and backward sweeps of a schedule are not adjacent)
+  // the fused top of the solve sweeps: the highest levels whose fronts all fit one instance of k_solve_top, at most
+  // ST_MAXFRONTS fronts (single rank: with a sharded tree the two sweeps of a schedule are not adjacent)
   h->top_n = 0, h->top_lt = 1 << 30, h->top_lds = 0;
   if (!getenv("HQPKKT_NO_SOLVE_TOP") && an.shard_count == 1 && an.sched[0].nnodes > 0) {
     const Analysis::Sched &S = an.sched[0];
     int lt = an.nlevels, cnt = 0, maxp = 0;
+    bool ok3 = true, ok4 = true;  // the instances <3, 11> and <4, 10>
     for (int l = an.nlevels - 1; l >= 0; l--) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l];
-      bool fits = cnt + nn <= ST_MAXFRONTS;
+      bool f3 = ok3, f4 = ok4;
       int mp2 = maxp;
-      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1] && fits; q++) {
+      for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) {
         const int v = S.level_nodes[q];
-        fits = an.npiv[v] <= ST_MAXP && an.nbor[v] <= ST_MAXB;
+        f3 = f3 && st_top_fits(an.npiv[v], an.nbor[v], 3, 11), f4 = f4 && st_top_fits(an.npiv[v], an.nbor[v], 4, 10);
         mp2 = std::max(mp2, an.npiv[v]);
       }
-      if (!fits) break;
-      cnt += nn, lt = l, maxp = mp2;
+      // (levels of small fronts stay with their one-wavefront kernels: a step of k_solve_top costs 16 wavefronts'
+      // worth of barriers and reductions whatever the size of the front - measured slower on the DID tree)
+      if (cnt + nn > ST_MAXFRONTS || !(f3 || f4) || S.level_fsmall[l] > 0) break;
+      cnt += nn, lt = l, maxp = mp2, ok3 = f3, ok4 = f4;
     }
     if (an.nlevels - lt >= 2 && cnt >= 2) {
-      std::vector<int> nodes, idx(an.nnodes, -1);
+      std::vector<int> nodes, idx(an.nnodes, -1), owner(an.dim, -1);
       for (int l = an.nlevels - 1; l >= lt; l--)
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) idx[S.level_nodes[q]] = (int)nodes.size(), nodes.push_back(S.level_nodes[q]);
-      std::vector<int> zero(2 * nodes.size(), 0);
-      if ((e = h->top_nodes.upload(nodes)) || (e = h->top_idx.upload(idx)) || (e = h->top_sync.upload(zero))) return e;
-      h->top_n = (int)nodes.size(), h->top_lt = lt, h->top_lds = st_top_lds_bytes(maxp);
+      for (size_t t = 0; t < nodes.size(); t++)
+        for (int k = 0; k < an.npiv[nodes[t]]; k++) owner[an.piv_start[nodes[t]] + k] = (int)t;
+      std::vector<int> bpos(nodes.size() * ST_CS, 0);
+      for (size_t t = 0; t < nodes.size(); t++)
+        for (int i = 0; i < an.nbor[nodes[t]]; i++) {
+          const int ei = an.bidx[an.bptr[nodes[t]] + i], o = owner[ei];
+          if (o < 0) return HQPKKT_E_INTERN;  // (a border row of a fused front belongs to a fused ancestor)
+          bpos[t * ST_CS + i] = o * ST_XS + (ei - an.piv_start[nodes[o]]);
+        }
+      std::vector<int> words(2, 0);
+      if ((e = h->top_nodes.upload(nodes)) || (e = h->top_idx.upload(idx)) || (e = h->top_bpos.upload(bpos)) || (e = h->top_words.upload(words)) ||
+          (e = h->top_x.alloc(2 * nodes.size() * (size_t)(ST_CS + ST_XS))))
+        return e;
+      h->top_n = (int)nodes.size(), h->top_lt = lt, h->top_ns = ok3 ? 3 : 4, h->top_lds = st_top_lds_bytes(maxp, h->top_ns);
+      if ((e = reset_solve_top(h))) return e;
     }
   }
   {
@@ -471,7 +499,8 @@ static int upload(hqpkkt_t *h) {
     static size_t a_diag = 0, a_panel = 0, a_bwdb = 0, a_blk = 0, a_top = 0;
     std::lock_guard<std::mutex> lk(attr_mutex);
     if (h->top_lds > a_top) {
-      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->top_lds));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<3, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(h->top_lds, st_top_lds_bytes(176, 3))));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(h->top_lds, st_top_lds_bytes(160, 4))));
       a_top = h->top_lds;
     }
     if (lds_blk > a_blk) {
@@ -745,10 +774,15 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   }
   if (phases & 2) {
     forward(1);
-    if (h->top_n > 0)  // the top levels, up and down, in one launch
-      KLAUNCH(h, KC_SOLVE_TOP, k_solve_top<<<h->top_n, ST_THREADS, h->top_lds, s>>>(T, h->top_nodes.p, h->top_idx.p, h->top_sync.p, h->top_n,
-                                                       h->panel.p, h->linv.p, h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p,
-                                                       h->rhs.p, h->xsol.p, h->cb.p, h->flags.p));
+    if (h->top_n > 0) {  // the top levels, up and down, in one launch
+      const TopArgs ta{h->top_nodes.p, h->top_idx.p, h->top_bpos.p, h->top_x.p, h->top_x.p + 2 * (size_t)h->top_n * ST_CS, h->top_words.p, h->top_n, h->top_stamps};
+      if (h->top_ns == 3)
+        KLAUNCH(h, KC_SOLVE_TOP, (k_solve_top<3, 11><<<h->top_n, ST_THREADS, h->top_lds, s>>>(T, ta, h->panel.p, h->linv.p, h->linv_off.p, h->dinv.p, h->ptype.p,
+                                                                 h->lperm.p, h->rhs.p, h->xsol.p, h->cb.p, h->flags.p)));
+      else
+        KLAUNCH(h, KC_SOLVE_TOP, (k_solve_top<4, 10><<<h->top_n, ST_THREADS, h->top_lds, s>>>(T, ta, h->panel.p, h->linv.p, h->linv_off.p, h->dinv.p, h->ptype.p,
+                                                                 h->lperm.p, h->rhs.p, h->xsol.p, h->cb.p, h->flags.p)));
+    }
     backward(1);
     backward(0);
     if (an.shard_count > 1)  // leave only this rank's share for the all-reduce
@@ -915,8 +949,8 @@ static int collect_residual(hqpkkt_t *h, double *res) {
   const bool check = h->factor_unchecked;
   int *hs = (int *)h->hpin;
   int flags[4] = {hs[0], hs[1], hs[2], hs[3]};
-  if (hs[ST_GAVE_UP]) {  // k_solve_top gave up waiting for a front: clear its protocol words, report, do not hang
-    (void)hipMemsetAsync(h->top_sync.p, 0, sizeof(int) * 2 * h->top_n, s);
+  if (hs[ST_GAVE_UP]) {  // k_solve_top gave up waiting for a word: rebuild its exchange arrays, report, do not hang
+    (void)reset_solve_top(h);
     (void)hipMemsetAsync(h->flags.p + ST_GAVE_UP, 0, sizeof(int), s);
     (void)hipStreamSynchronize(s);
     return HQPKKT_E_DEVICE;
@@ -2501,6 +2535,45 @@ const char *hqpkkt_strerror(int status) {
   }
 }
 
+// diagnostics: run the solve `reps` times with time stamps inside k_solve_top (eager launches) and return, per fused
+// front, level and six times in microseconds after the launch's first stamp: start, static data in, children arrived,
+// forward done, border solution arrived, backward done (out: top_n x 8 doubles, [0] = tree level, [1..6] the times)
+int hqpkkt_debug_solve_top_stamps(hqpkkt_t *h, double *out, int cap) {
+  if (!h || !out) return HQPKKT_E_NULL;
+  if (!h->factored || h->top_n <= 0) return HQPKKT_E_INTERN;
+  if (cap < h->top_n * 8) return HQPKKT_E_SIZES;
+  HIPCHK(hipSetDevice(h->opts.device));
+  unsigned long long *st = nullptr;
+  HIPCHK(hipMalloc((void **)&st, sizeof(unsigned long long) * 8 * h->top_n));
+  (void)hipMemset(st, 0, sizeof(unsigned long long) * 8 * h->top_n);
+  const bool graphs = h->use_graphs;
+  h->use_graphs = false, h->top_stamps = st;
+  Vecs v{};
+  {  // the staged vectors of the last solve (the layout of stage_in)
+    const int n = h->an.n, me = h->an.me, m = h->an.m;
+    double *b = h->vin.p;
+    v.z = b, v.w = b + m, v.r1 = b + 2 * (size_t)m, v.r2 = v.r1 + n, v.r3 = v.r2 + me, v.r4 = v.r3 + m;
+  }
+  stage_out_ptrs(h, v);
+  int e = do_step(h, v, 0);
+  if (!e && hipStreamSynchronize(h->stream) != hipSuccess) e = HQPKKT_E_DEVICE;
+  h->use_graphs = graphs, h->top_stamps = nullptr;
+  std::vector<unsigned long long> hs(8 * (size_t)h->top_n);
+  if (!e && hipMemcpy(hs.data(), st, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost) != hipSuccess) e = HQPKKT_E_DEVICE;
+  (void)hipFree(st);
+  if (e) return e;
+  std::vector<int> nodes(h->top_n);
+  HIPCHK(hipMemcpy(nodes.data(), h->top_nodes.p, sizeof(int) * h->top_n, hipMemcpyDeviceToHost));
+  unsigned long long t0 = ~0ULL;
+  for (int t = 0; t < h->top_n; t++) t0 = std::min(t0, hs[8 * (size_t)t]);
+  for (int t = 0; t < h->top_n; t++) {
+    out[8 * t] = h->an.level[nodes[t]];
+    for (int k = 0; k < 6; k++) out[8 * t + 1 + k] = (double)(hs[8 * (size_t)t + k] - t0) * 0.01;  // 100 MHz
+    out[8 * t + 7] = 0.0;
+  }
+  return 0;
+}
+
 int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
   if (!h || !len) return HQPKKT_E_NULL;
   if (!h->analyzed) return HQPKKT_E_INTERN;
@@ -2540,7 +2613,7 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       v = &tmp;
       break;
     case 31:  // the solve's fused top (k_solve_top): number of fronts, first fused level, LDS bytes
-      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds};
+      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds, h->top_ns};
       v = &tmp;
       break;
     case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)

@@ -416,6 +416,10 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
  * such level, LDS bytes of that launch).
  * *len receives the element count; out may be NULL to query it. */
 int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len);
+/* diagnostics of the solve's fused top (k_solve_top): one solve on the vectors of the last one with time stamps inside
+ * the launch; out (cap >= 8 x fronts doubles) receives per front its tree level and six times in microseconds: start,
+ * static data in, children arrived, forward done, border solution arrived, backward done. */
+int hqpkkt_debug_solve_top_stamps(hqpkkt_t *h, double *out, int cap);
 
 /* Numeric blocks of one supernode after factor (device -> host copy, tests only):
  * what 0 = panel ((p+b) x p, column-major: L11 below the diagonal, L21), 1 = the

@@ -59,22 +59,12 @@ def test_fused_top_against_the_oracle():
     assert O.residuum(*st, *d) <= ores + 1e-10 * max(1.0, max(np.abs(v).max() for v in d if len(v)))
 
 
-def test_fused_top_on_deep_trees_of_small_fronts():
-    """Double-integrator DOCP (fronts of a few pivots, a tree of a dozen levels): the fused launch holds the top
-    levels; device-resident Mehrotra loop with it and without: same iteration count, same optimiser."""
-    import os
+def test_trees_of_small_fronts_keep_their_one_wavefront_kernels():
+    """Double-integrator DOCP (fronts of a few pivots): a step of the fused launch costs more than a launch of the
+    one-wavefront kernels there, so such levels are not fused."""
     prog = problems.did_like_qp(400)
     A = ipmatrix.IpRedSpBKP()
     A.init(prog)
-    assert A.debug(31)[0] >= 3
-    xa = A.mehrotra(prog)
-    os.environ["HQPKKT_NO_SOLVE_TOP"] = "1"
-    try:
-        B = ipmatrix.IpRedSpBKP()
-        B.init(prog)
-        assert B.debug(31)[0] == 0
-        xb = B.mehrotra(prog)
-    finally:
-        del os.environ["HQPKKT_NO_SOLVE_TOP"]
-    assert xa[-1]["iters"] == xb[-1]["iters"] and xa[-1]["result"] == 0
-    assert np.abs(xa[0] - xb[0]).max() <= 1e-7 * max(1.0, np.abs(xb[0]).max())
+    assert A.debug(31)[0] == 0
+    x, _y, _z, _w, info = A.mehrotra(prog)
+    assert info["result"] == 0
