@@ -214,6 +214,11 @@ struct hqpkkt {
   size_t top_lds = 0;
   DBuf<int> top_nodes, top_idx, top_bpos, top_words;
   unsigned long long *top_stamps = nullptr;  // (hqpkkt_debug_solve_top_stamps)
+  // trees of small fronts only (the double-integrator structure): each sweep of the solve is ONE launch over all levels
+  // (k_solve_fwd_small<true> / k_solve_bwd_small<true>); tree_x: the exchange arrays (2 x cb_elems, then 2 x dim)
+  bool small_tree = false;
+  DBuf<double> tree_x;
+  DBuf<int> tree_words, tree_down;  // [0] solves so far; the fronts root first
   DBuf<double> top_x;  // the exchange arrays of the launch: 2 x top_n x ST_CS contributions, then 2 x top_n x ST_XS solution
   // captured kernel sequences (factor; step on the caller's vectors; step on the
   // refinement's residual vectors): replayed with hipGraphLaunch
@@ -264,14 +269,14 @@ struct hqpkkt {
   void release_device(bool keep_ip = false) {  // keep_ip: hqpkkt_mehrotra's vectors and the pinned words stay
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
                        &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags,
-                       &top_nodes, &top_idx, &top_bpos, &top_words};
+                       &top_nodes, &top_idx, &top_bpos, &top_words, &tree_words, &tree_down};
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release(), simple_src.release(), simple_wi.release();
     DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off, &pinv_off,
                              &zero_panel};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &top_x};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &top_x, &tree_x};
     for (auto b : db) b->release();
     if (!keep_ip) ipv.release();
     terms.release(), esign.release(), bits.p = nullptr;
@@ -319,12 +324,22 @@ static int ensure_device(hqpkkt_t *h) {
 
 // the exchange arrays of k_solve_top in their idle state: every word the sentinel, counters zero
 static int reset_solve_top(hqpkkt_t *h) {
-  if (h->top_n <= 0) return 0;
-  std::vector<double> fill(2 * (size_t)h->top_n * (ST_CS + ST_XS));
-  for (auto &x : fill) std::memcpy(&x, &ST_SENTINEL, sizeof(double));
   HIPCHK(hipStreamSynchronize(h->stream));
-  HIPCHK(hipMemcpy(h->top_x.p, fill.data(), sizeof(double) * fill.size(), hipMemcpyHostToDevice));
-  HIPCHK(hipMemset(h->top_words.p, 0, sizeof(int) * 2));
+  auto fill = [&](DBuf<double> &buf, size_t count) -> int {
+    std::vector<double> f(count);
+    for (auto &x : f) std::memcpy(&x, &XW_SENTINEL, sizeof(double));
+    HIPCHK(hipMemcpy(buf.p, f.data(), sizeof(double) * count, hipMemcpyHostToDevice));
+    return 0;
+  };
+  int e;
+  if (h->top_n > 0) {
+    if ((e = fill(h->top_x, 2 * (size_t)h->top_n * (ST_CS + ST_XS)))) return e;
+    HIPCHK(hipMemset(h->top_words.p, 0, sizeof(int) * 2));
+  }
+  if (h->small_tree) {
+    if ((e = fill(h->tree_x, 2 * (size_t)(h->an.cb_elems + h->an.dim)))) return e;
+    HIPCHK(hipMemset(h->tree_words.p, 0, sizeof(int)));
+  }
   return 0;
 }
 
@@ -448,6 +463,21 @@ static int upload(hqpkkt_t *h) {
     for (int l = 0; l < an.nlevels && S.nnodes; l++)
       for (int q = S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l]; q < S.level_ptr[l + 1]; q++)
         h->level_maxp[w][l] = std::max(h->level_maxp[w][l], an.npiv[S.level_nodes[q]]);
+  }
+  // a tree of small fronts only: whole-tree sweeps
+  h->small_tree = false;
+  if (!getenv("HQPKKT_NO_TREE_SWEEPS") && an.shard_count == 1 && an.sched[0].nnodes > 1 && an.sched[1].nnodes == 0) {
+    const Analysis::Sched &S = an.sched[0];
+    bool all = true;
+    for (int l = 0; l < an.nlevels && all; l++) all = S.level_fsmall[l] == S.level_ptr[l + 1] - S.level_ptr[l];
+    if (all) {
+      std::vector<int> down, one(1, 0);
+      for (int l = an.nlevels - 1; l >= 0; l--)
+        for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) down.push_back(S.level_nodes[q]);
+      if ((e = h->tree_down.upload(down)) || (e = h->tree_words.upload(one)) || (e = h->tree_x.alloc(2 * (size_t)(an.cb_elems + an.dim)))) return e;
+      h->small_tree = true;
+      if ((e = reset_solve_top(h))) return e;
+    }
   }
   // the fused top of the solve sweeps: the highest levels whose fronts all fit one instance of k_solve_top, at most
   // ST_MAXFRONTS fronts (single rank: with a sharded tree the two sweeps of a schedule are not adjacent)
@@ -711,14 +741,21 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   auto forward = [&](int which) -> int {
     const Analysis::Sched &S = an.sched[which];
     const hqpkkt::DevSched &D = h->ds[which];
+    const TreeXchg tx{h->tree_x.p, h->tree_x.p + 2 * an.cb_elems, an.cb_elems, an.dim, h->tree_words.p, h->flags.p};
+    if (which == 0 && h->small_tree) {  // all levels in one launch
+      KLAUNCH(h, KC_SOLVE_FWD,
+              k_solve_fwd_small<true><<<S.nnodes, 64, 0, s>>>(T, D.level_nodes.p, h->panel.p, h->linv.p, h->linv_off.p, h->dinv.p, h->ptype.p,
+                                                              h->lperm.p, h->rhs.p, h->xsol.p, h->ytmp.p, h->cb.p, tx));
+      return 0;
+    }
     const int lend = which == 0 && h->top_n > 0 ? h->top_lt : an.nlevels;  // (the levels above: k_solve_top)
     for (int l = 0; l < lend && S.nnodes; l++) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l];
       if (nfs > 0)
         KLAUNCH(h, KC_SOLVE_FWD,
-                k_solve_fwd_small<<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
+                k_solve_fwd_small<false><<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
                                                      h->linv_off.p, h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p,
-                                                     h->xsol.p, h->ytmp.p, h->cb.p));
+                                                     h->xsol.p, h->ytmp.p, h->cb.p, tx));
       const int ng = S.gslab_ptr[l + 1] - S.gslab_ptr[l];  // (front, 64-row slab), at least one per front
       if (ng > 0 && ng <= FWD_FUSED_MAX_SLABS)  // a handful of fronts: the launch is what costs
         KLAUNCH(h, KC_SOLVE_FWD,
@@ -740,6 +777,12 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   auto backward = [&](int which) -> int {
     const Analysis::Sched &S = an.sched[which];
     const hqpkkt::DevSched &D = h->ds[which];
+    const TreeXchg tx{h->tree_x.p, h->tree_x.p + 2 * an.cb_elems, an.cb_elems, an.dim, h->tree_words.p, h->flags.p};
+    if (which == 0 && h->small_tree) {
+      KLAUNCH(h, KC_SOLVE_BWD, k_solve_bwd_small<true><<<S.nnodes, 64, 0, s>>>(T, h->tree_down.p, h->panel.p, h->linv.p, h->linv_off.p, h->lperm.p,
+                                                                               h->xsol.p, tx));
+      return 0;
+    }
     const int lbeg = which == 0 && h->top_n > 0 ? h->top_lt - 1 : an.nlevels - 1;
     for (int l = lbeg; l >= 0 && S.nnodes; l--) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l];
@@ -747,8 +790,8 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
       if (nn <= 0) continue;
       if (nfs > 0)
         KLAUNCH(h, KC_SOLVE_BWD,
-                k_solve_bwd_small<<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
-                                                     h->linv_off.p, h->lperm.p, h->xsol.p));
+                k_solve_bwd_small<false><<<nfs, 64, 0, s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p, h->linv.p,
+                                                     h->linv_off.p, h->lperm.p, h->xsol.p, tx));
       if (nn <= nfs) continue;
       // (one workgroup per front doing both steps was measured slower: L21' x needs the
       // column blocks spread over the chip)
@@ -764,11 +807,12 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   if (phases & 1) {
     if (an.mode == 0) {
       KLAUNCH(h, KC_VECTOR, k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
-                                           h->rhs.p));
+                                           h->rhs.p, h->small_tree ? h->tree_words.p : nullptr));
     } else {
       if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
       KLAUNCH(h, KC_VECTOR, k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
-                                          h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p));
+                                          h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p,
+                                          h->small_tree ? h->tree_words.p : nullptr));
     }
     forward(0);
   }
@@ -2613,7 +2657,7 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       v = &tmp;
       break;
     case 31:  // the solve's fused top (k_solve_top): number of fronts, first fused level, LDS bytes
-      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds, h->top_ns};
+      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds, h->top_ns, h->small_tree ? 1 : 0};
       v = &tmp;
       break;
     case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)

@@ -1495,18 +1495,67 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   FSTAMP(9);
 }
 
+// ---- data words as signals (used by the whole-tree sweeps below and by k_solve_top, solve_top.hip.h): a producer
+// writes its results with agent-scope atomic stores into an exchange array whose words hold a sentinel (a NaN payload
+// no arithmetic produces) until then; the consumer's lanes poll exactly the words they need.  No flags, no cache
+// maintenance: one memory round trip per tree level.  The arrays exist twice: solve e uses copy e & 1 and every front
+// puts the sentinel back into ITS words of the other copy, which nobody reads during this solve.
+static const unsigned long long XW_SENTINEL = 0x7ff8dead0badc0deULL;
+static const int XW_GAVE_UP = 110;  // index into the handle's flags buffer: a poll gave up (~2^20 tries)
+__device__ __forceinline__ unsigned long long xw_peek(const double *p) {
+  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xw_post(double *p, double v) {
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xw_clear(double *p) {
+  __hip_atomic_store((unsigned long long *)p, XW_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xw_take(const double *p, int *flags) {
+  unsigned long long v = xw_peek(p);
+  for (int n = 0; v == XW_SENTINEL; n++) {
+    if (n > (1 << 20)) {
+      __hip_atomic_store(flags + XW_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 0.0;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    v = xw_peek(p);
+  }
+  return __longlong_as_double((long long)v);
+}
+// exchange arrays of the whole-tree sweeps of small fronts: contribution vectors (the layout of cb) and solution
+// (elimination indices), two copies each; epoch: solves so far (k_rhs_* counts)
+struct TreeXchg {
+  double *cb, *x;
+  long long cb_elems;
+  int dim;
+  const int *epoch;
+  int *flags;
+};
+
 // ---- tree solves of the small fronts: one wavefront per supernode does what the
 // A and B kernels below do for the general fronts (two launches per level, not four).
 // Like the factorisation above they are latency chains: every load that depends on the
 // node alone (M, L21) is issued before anything else.
+// TREE: ALL levels in one launch (trees of small fronts only: the double-integrator structure has a dozen levels
+// of thousands of fronts of a few pivots, and a level's launch costs more than its work).  The fronts come in the
+// order of the levels, leaves first; a front's lanes wait for the words of its children's contribution vectors in
+// the exchange array and post their own.  With more fronts than the chip holds this relies on workgroups being
+// dispatched in the order of their index (a waiting front only waits for fronts before it).
+template <bool TREE>
 __global__ void __launch_bounds__(64)
 k_solve_fwd_small(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
                   const double *__restrict__ linv, const long long *__restrict__ linv_off,
                   const double *__restrict__ dinv, const int *__restrict__ ptype,
                   const int *__restrict__ lperm, const double *__restrict__ rhs, double *__restrict__ xsol,
-                  double *__restrict__ ytmp, double *__restrict__ cb) {
+                  double *__restrict__ ytmp, double *__restrict__ cb, TreeXchg X) {
   __shared__ double t1[FS_MAXP], tp[FS_MAXP], y[FS_MAXP], cbs[FS_MAXB];
   const int node = level_nodes[blockIdx.x];
+  const int par = TREE ? (*X.epoch & 1) : 0;
+  if constexpr (TREE) {
+    cb = X.cb + (long long)par * X.cb_elems;
+    if ((int)threadIdx.x < T.nbor[node]) xw_clear(X.cb + (long long)(par ^ 1) * X.cb_elems + T.cb_off[node] + threadIdx.x);
+  }
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
   const int e0 = T.piv_start[node];
@@ -1545,7 +1594,12 @@ k_solve_fwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
     const int *rel0 = T.rel + T.bptr[ch0], *rel1 = T.rel + T.bptr[ch1];
     const double *cb0 = cb + T.cb_off[ch0], *cb1 = cb + T.cb_off[ch1];
     const int ri0 = lane < bc0 ? rel0[lane] : -1, ri1 = lane < bc1 ? rel1[lane] : -1;
-    const double v0 = lane < bc0 ? cb0[lane] : 0.0, v1 = lane < bc1 ? cb1[lane] : 0.0;
+    double v0, v1;
+    if constexpr (TREE) {
+      v0 = lane < bc0 ? xw_take(cb0 + lane, X.flags) : 0.0, v1 = lane < bc1 ? xw_take(cb1 + lane, X.flags) : 0.0;
+    } else {
+      v0 = lane < bc0 ? cb0[lane] : 0.0, v1 = lane < bc1 ? cb1[lane] : 0.0;
+    }
     if (ri0 >= 0) {
       if (ri0 < p)
         t1[ri0] += v0;
@@ -1579,15 +1633,26 @@ k_solve_fwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
   for (int u = 0; u < FS_MAXP / 4; u++) s = fma(lv[u], y[4 * u + cq], s);
   s += __shfl_xor(s, 16);
   s += __shfl_xor(s, 32);
-  if (lane < b) cb[T.cb_off[node] + lane] = cbs[lane] - s;
+  if constexpr (TREE) {
+    if (lane < b) xw_post(cb + T.cb_off[node] + lane, cbs[lane] - s);
+  } else {
+    if (lane < b) cb[T.cb_off[node] + lane] = cbs[lane] - s;
+  }
 }
 
+// TREE: all levels in one launch, root first; the lanes wait for the solution at their border rows (pivots of
+// ancestors) in the exchange array and post their own part of it
+template <bool TREE>
 __global__ void __launch_bounds__(64)
 k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *__restrict__ panel,
                   const double *__restrict__ linv, const long long *__restrict__ linv_off,
-                  const int *__restrict__ lperm, double *__restrict__ xsol) {
+                  const int *__restrict__ lperm, double *__restrict__ xsol, TreeXchg X) {
   __shared__ double x2[FS_MAXB], v[FS_MAXP];
   const int node = level_nodes[blockIdx.x];
+  const int par = TREE ? (*X.epoch & 1) : 0;
+  if constexpr (TREE) {
+    if ((int)threadIdx.x < T.npiv[node]) xw_clear(X.x + (long long)(par ^ 1) * X.dim + T.piv_start[node] + threadIdx.x);
+  }
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
   const int e0 = T.piv_start[node];
@@ -1610,9 +1675,14 @@ k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
     const double w = W[ok ? (long long)i * p + r : 0];
     wv[u] = ok ? w : 0.0;
   }
-  if (lane < FS_MAXB) x2[lane] = lane < b ? xsol[bi[lane]] : 0.0;
+  const int bil = lane < b ? bi[lane] : 0;
   const int lpk = i < p ? lperm[e0 + i] : 0;
   const double xv = i < p ? xsol[e0 + i] : 0.0;
+  if constexpr (TREE) {
+    if (lane < FS_MAXB) x2[lane] = lane < b ? xw_take(X.x + (long long)par * X.dim + bil, X.flags) : 0.0;
+  } else {
+    if (lane < FS_MAXB) x2[lane] = lane < b ? xsol[bil] : 0.0;
+  }
   __syncthreads();
   double acc = 0.0;  // v = yd - L21' x(border)
 #pragma unroll
@@ -1625,6 +1695,9 @@ k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
   for (int u = 0; u < FS_MAXP / 2; u++) z = fma(wv[u], v[2 * u + h], z);
   z += __shfl_xor(z, 32);
   if (lane < p) xsol[e0 + lpk] = z;
+  if constexpr (TREE) {
+    if (lane < p && T.child_ptr[node + 1] > T.child_ptr[node]) xw_post(X.x + (long long)par * X.dim + e0 + lpk, z);
+  }
 }
 
 // --------------------------------------------------- panel solve (border rows)
@@ -2207,8 +2280,9 @@ __global__ void k_rhs_full(int n, int me, int m, const int *__restrict__ q2e,
                            const double *__restrict__ sc, const double *__restrict__ z,
                            const double *__restrict__ r1, const double *__restrict__ r2,
                            const double *__restrict__ r3, const double *__restrict__ r4,
-                           double *__restrict__ rhs) {
+                           double *__restrict__ rhs, int *__restrict__ epoch) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0 && epoch) *epoch += 1;  // the solve counter of the whole-tree sweeps (solve_top.hip.h)
   if (q >= n + me + m) return;
   double v;
   if (q < n)
@@ -2279,8 +2353,9 @@ __global__ void k_rhs_red(int n, int me, const int *__restrict__ q2e, const doub
                           const int *__restrict__ CTp, const int *__restrict__ CTc,
                           const int *__restrict__ CTs, const double *__restrict__ vals,
                           const double *__restrict__ tz, const double *__restrict__ r1,
-                          const double *__restrict__ r2, double *__restrict__ rhs) {
+                          const double *__restrict__ r2, double *__restrict__ rhs, int *__restrict__ epoch) {
   int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0 && epoch) *epoch += 1;  // the solve counter of the whole-tree sweeps (solve_top.hip.h)
   if (q >= n + me) return;
   double v;
   if (q < n)

@@ -29,8 +29,8 @@ namespace kktdev {
 
 static const int ST_THREADS = 1024, ST_MAXFRONTS = 128;
 static const int ST_XS = 192, ST_CS = 256;  // words per front in the exchange arrays: solution (pivots), contribution (border rows)
-static const int ST_GAVE_UP = 110;          // index into the handle's flags buffer
-static const unsigned long long ST_SENTINEL = 0x7ff8dead0badc0deULL;
+static const int ST_GAVE_UP = XW_GAVE_UP;    // index into the handle's flags buffer
+static const unsigned long long ST_SENTINEL = XW_SENTINEL;
 
 // the two instances: <3, 11> fronts of up to 176 pivots and 192 border rows, <4, 10> up to 160 pivots and 256 border rows
 static inline bool st_top_fits(int p, int b, int ns, int nu) { return p <= 16 * nu && b <= 64 * ns; }
@@ -38,26 +38,8 @@ static inline size_t st_top_lds_bytes(int maxp, int ns) {
   const size_t mlen = ((size_t)maxp * (maxp + 1) / 2 + 1) & ~(size_t)1;
   return sizeof(double) * (mlen + 8 * 64 * ns + 16 * 64 * ns);
 }
-
-__device__ __forceinline__ unsigned long long st_peek(const double *p) {
-  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void st_post(double *p, double v) {
-  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-// wait for a word of an exchange array
-__device__ __forceinline__ double st_take(const double *p, int *flags) {
-  unsigned long long v = st_peek(p);
-  for (int n = 0; v == ST_SENTINEL; n++) {
-    if (n > (1 << 20)) {
-      __hip_atomic_store(flags + ST_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return 0.0;
-    }
-    __builtin_amdgcn_s_sleep(1);
-    v = st_peek(p);
-  }
-  return __longlong_as_double((long long)v);
-}
+__device__ __forceinline__ void st_post(double *p, double v) { xw_post(p, v); }
+__device__ __forceinline__ double st_take(const double *p, int *flags) { return xw_take(p, flags); }
 
 struct TopArgs {
   const int *nodes;    // fronts of the fused levels, root first

@@ -59,12 +59,28 @@ def test_fused_top_against_the_oracle():
     assert O.residuum(*st, *d) <= ores + 1e-10 * max(1.0, max(np.abs(v).max() for v in d if len(v)))
 
 
-def test_trees_of_small_fronts_keep_their_one_wavefront_kernels():
-    """Double-integrator DOCP (fronts of a few pivots): a step of the fused launch costs more than a launch of the
-    one-wavefront kernels there, so such levels are not fused."""
-    prog = problems.did_like_qp(400)
-    A = ipmatrix.IpRedSpBKP()
-    A.init(prog)
-    assert A.debug(31)[0] == 0
-    x, _y, _z, _w, info = A.mehrotra(prog)
-    assert info["result"] == 0
+@pytest.mark.parametrize("K", [60, 400, 2000])
+def test_whole_tree_sweeps_on_trees_of_small_fronts(K, monkeypatch):
+    """Double-integrator DOCP (fronts of a few pivots, a tree of a dozen levels): each sweep of the solve is one
+    launch over all levels (k_solve_fwd_small<true> / k_solve_bwd_small<true>, contributions and solution travel as
+    polled words).  Same arithmetic as the per-level launches: the solve and a whole device-resident Mehrotra run give
+    the same bits; repeated solves too (the exchange arrays are back in their idle state after every solve)."""
+    prog = problems.did_like_qp(K)
+    st = problems.ip_state(prog, seed=3)
+    A, da, ra = _solve(ipmatrix.IpRedSpBKP, prog, st)
+    assert A.debug(31)[0] == 0 and A.debug(31)[4] == 1
+    for _ in range(4):
+        d2 = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+        assert A.solve(prog, *st, *d2) == ra
+        for x, yv in zip(d2, da):
+            assert np.array_equal(x, yv)
+    xa = A.mehrotra(prog)
+    monkeypatch.setenv("HQPKKT_NO_TREE_SWEEPS", "1")
+    B, db, rb = _solve(ipmatrix.IpRedSpBKP, prog, st)
+    assert B.debug(31)[4] == 0
+    assert ra == rb and ra <= 1e-10
+    for x, yv in zip(da, db):
+        assert np.array_equal(x, yv)
+    xb = B.mehrotra(prog)
+    assert xa[-1]["iters"] == xb[-1]["iters"] and xa[-1]["result"] == 0
+    assert np.array_equal(xa[0], xb[0])
