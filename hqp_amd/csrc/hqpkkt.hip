@@ -216,9 +216,9 @@ struct hqpkkt {
   unsigned long long *top_stamps = nullptr;  // (hqpkkt_debug_solve_top_stamps)
   // trees of small fronts only (the double-integrator structure): each sweep of the solve is ONE launch over all levels
   // (k_solve_fwd_small<true> / k_solve_bwd_small<true>); tree_x: the exchange arrays (2 x cb_elems, then 2 x dim)
-  bool small_tree = false;
-  DBuf<double> tree_x;
-  DBuf<int> tree_words, tree_down;  // [0] solves so far; the fronts root first
+  bool small_tree = false, tree_factor = false;  // tree_factor: ... and the factorisation too (k_factor_diag_small<true, true>)
+  DBuf<double> tree_x, tree_u;   // tree_u: the exchange copies of the update arena (2 x upd_elems)
+  DBuf<int> tree_words, tree_down;  // [0] solves so far, [1] factorisations so far; the fronts root first
   DBuf<double> top_x;  // the exchange arrays of the launch: 2 x top_n x ST_CS contributions, then 2 x top_n x ST_XS solution
   // captured kernel sequences (factor; step on the caller's vectors; step on the
   // refinement's residual vectors): replayed with hipGraphLaunch
@@ -276,7 +276,7 @@ struct hqpkkt {
                              &zero_panel};
     for (auto b : lb) b->release();
     DBuf<double> *db[] = {&vals, &wt, &sc, &ent_val, &panel, &upd, &xar, &dinv, &rhs, &xsol,
-                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &top_x, &tree_x};
+                          &cb, &vin, &vout, &vres, &vcor, &tz, &ytmp, &vtmp, &linv, &top_x, &tree_x, &tree_u};
     for (auto b : db) b->release();
     if (!keep_ip) ipv.release();
     terms.release(), esign.release(), bits.p = nullptr;
@@ -338,7 +338,8 @@ static int reset_solve_top(hqpkkt_t *h) {
   }
   if (h->small_tree) {
     if ((e = fill(h->tree_x, 2 * (size_t)(h->an.cb_elems + h->an.dim)))) return e;
-    HIPCHK(hipMemset(h->tree_words.p, 0, sizeof(int)));
+    if (h->tree_factor && (e = fill(h->tree_u, 2 * (size_t)std::max<long long>(h->an.upd_elems, 1)))) return e;
+    HIPCHK(hipMemset(h->tree_words.p, 0, sizeof(int) * 2));
   }
   return 0;
 }
@@ -465,17 +466,19 @@ static int upload(hqpkkt_t *h) {
         h->level_maxp[w][l] = std::max(h->level_maxp[w][l], an.npiv[S.level_nodes[q]]);
   }
   // a tree of small fronts only: whole-tree sweeps
-  h->small_tree = false;
+  h->small_tree = false, h->tree_factor = false;
   if (!getenv("HQPKKT_NO_TREE_SWEEPS") && an.shard_count == 1 && an.sched[0].nnodes > 1 && an.sched[1].nnodes == 0) {
     const Analysis::Sched &S = an.sched[0];
     bool all = true;
     for (int l = 0; l < an.nlevels && all; l++) all = S.level_fsmall[l] == S.level_ptr[l + 1] - S.level_ptr[l];
     if (all) {
-      std::vector<int> down, one(1, 0);
+      std::vector<int> down, one(2, 0);
       for (int l = an.nlevels - 1; l >= 0; l--)
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) down.push_back(S.level_nodes[q]);
       if ((e = h->tree_down.upload(down)) || (e = h->tree_words.upload(one)) || (e = h->tree_x.alloc(2 * (size_t)(an.cb_elems + an.dim)))) return e;
       h->small_tree = true;
+      h->tree_factor = !an.upd_pingpong && !getenv("HQPKKT_NO_TREE_FACTOR");
+      if (h->tree_factor && (e = h->tree_u.alloc(2 * (size_t)std::max<long long>(an.upd_elems, 1)))) return e;
       if ((e = reset_solve_top(h))) return e;
     }
   }
@@ -666,10 +669,10 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
     if (h->simple_src.count) {  // FULL: one pass
       KLAUNCH(h, KC_ASSEMBLE, k_assemble_simple<<<std::min(nblk(nent), 2048), 256, 0, s>>>(
                                   nent, h->simple_src.p, h->simple_wi.p, h->ent_a.p, h->ent_b.p, h->ent_dst.p,
-                                  h->vals.p, h->wt.p, h->sc.p, h->panel.p, h->bits.p));
+                                  h->vals.p, h->wt.p, h->sc.p, h->panel.p, h->bits.p, h->tree_factor ? h->tree_words.p + 1 : nullptr));
     } else {
       KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
-                                                h->ent_val.p));
+                                                h->ent_val.p, h->tree_factor ? h->tree_words.p + 1 : nullptr));
       if (an.mode == 1 && an.n > 0)
         KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
       KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
@@ -683,19 +686,28 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
     const Analysis::Sched &S = an.sched[which];
     const hqpkkt::DevSched &D = h->ds[which];
     if (S.nnodes == 0) continue;
+    const TreeXchgF txf{h->tree_u.p, an.upd_elems, h->tree_words.p + 1};
+    if (which == 0 && h->tree_factor) {  // a tree of small fronts: all levels in one launch
+      int ldp = 1, ldb = 1;
+      for (int l = 0; l < an.nlevels; l++) ldp = std::max(ldp, S.level_fs_p[l] | 1), ldb = std::max(ldb, S.level_fs_b[l]);
+      KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_diag_small<true, true><<<S.nnodes, 64, fs_lds_bytes(true, ldp, ldb), s>>>(T, D.level_nodes.p, h->panel.p,
+                                               h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                               h->flags.p + 1, h->upd.p, h->xar.p, ldp, ldb, txf)));
+      continue;
+    }
     for (int l = 0; l < an.nlevels; l++) {
       const int nn = S.level_ptr[l + 1] - S.level_ptr[l], nfs = S.level_fsmall[l], nsm = S.level_small[l];
       if (nfs > 0) {  // small fronts: extend-add, pivot block, panel and update in one kernel
         const int ldp = S.level_fs_p[l] | 1, ldb = S.level_fs_b[l];
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<true><<<nfs, 64, fs_lds_bytes(true, ldp, ldb), s>>>(T, D.level_nodes.p + S.level_ptr[l], h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                                 h->flags.p + 1, h->upd.p, h->xar.p, ldp, ldb));
+                                                 h->flags.p + 1, h->upd.p, h->xar.p, ldp, ldb, txf));
       }
       if (nsm > 0) {
         const int ldp = S.level_sm_p[l] | 1;
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag_small<false><<<nsm, 64, fs_lds_bytes(false, ldp, 1), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
-                                                 h->flags.p + 1, h->upd.p, h->xar.p, ldp, 1));
+                                                 h->flags.p + 1, h->upd.p, h->xar.p, ldp, 1, txf));
       }
       if (nn > nfs + nsm && h->old_fd)
         KLAUNCH(h, KC_FACTOR_DIAG, k_factor_diag<<<nn - nfs - nsm, FD_THREADS, h->lds_diag, s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
@@ -2657,7 +2669,7 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       v = &tmp;
       break;
     case 31:  // the solve's fused top (k_solve_top): number of fronts, first fused level, LDS bytes
-      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds, h->top_ns, h->small_tree ? 1 : 0};
+      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds, h->top_ns, h->small_tree ? 1 : 0, h->tree_factor ? 1 : 0};
       v = &tmp;
       break;
     case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)
@@ -2718,7 +2730,15 @@ int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long ca
   if (cap < n) return HQPKKT_E_SIZES;
   HIPCHK(hipSetDevice(h->opts.device));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (what == 3 && h->tree_factor) {  // the block is in the exchange copy of the last factorisation (lower triangle; the rest idle)
+    int ep = 0;
+    HIPCHK(hipMemcpy(&ep, h->tree_words.p + 1, sizeof(int), hipMemcpyDeviceToHost));
+    src = h->tree_u.p + (long long)(ep & 1) * an.upd_elems + an.upd_off[node];
+  }
   if (n) HIPCHK(hipMemcpy(out, src, sizeof(double) * n, hipMemcpyDeviceToHost));
+  if (what == 3 && h->tree_factor)
+    for (long long t = 0; t < n; t++)
+      if (std::memcmp(out + t, &XW_SENTINEL, sizeof(double)) == 0) out[t] = 0.0;
   return 0;
 }
 

@@ -169,8 +169,9 @@ __device__ __forceinline__ int zero_pivot_slot(int sg1, int sg2, int b) {
 __global__ void k_entry_values(int nent, const int *__restrict__ term_ptr,
                                const TermDev *__restrict__ terms,
                                const double *__restrict__ vals, const double *__restrict__ wt,
-                               double *__restrict__ ent_val) {
+                               double *__restrict__ ent_val, int *__restrict__ epoch) {
   int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0 && epoch) *epoch += 1;  // the factorisation counter of the whole-tree launch (k_factor_diag_small<true, true>)
   if (e >= nent) return;
   double v = 0.0;
   for (int t = term_ptr[e]; t < term_ptr[e + 1]; t++) {
@@ -222,9 +223,10 @@ k_assemble_simple(int nent, const int *__restrict__ src, const int *__restrict__
                   const int *__restrict__ ent_a, const int *__restrict__ ent_b,
                   const long long *__restrict__ ent_dst, const double *__restrict__ vals,
                   const double *__restrict__ wt, const double *__restrict__ sc, double *__restrict__ panel,
-                  unsigned long long *__restrict__ kmax) {
+                  unsigned long long *__restrict__ kmax, int *__restrict__ epoch) {
   __shared__ double red[4];
   double mx = 0.0;
+  if (blockIdx.x == 0 && threadIdx.x == 0 && epoch) *epoch += 1;  // (see k_entry_values)
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nent; e += gridDim.x * blockDim.x) {
     const int sg = src[e];
     const double raw = vals[sg & 0x7fffffff] * wt[wi[e]];
@@ -962,6 +964,51 @@ int dn;
   STAMP(48);
 }
 
+// ---- data words as signals (used by the whole-tree sweeps below and by k_solve_top, solve_top.hip.h): a producer
+// writes its results with agent-scope atomic stores into an exchange array whose words hold a sentinel (a NaN payload
+// no arithmetic produces) until then; the consumer's lanes poll exactly the words they need.  No flags, no cache
+// maintenance: one memory round trip per tree level.  The arrays exist twice: solve e uses copy e & 1 and every front
+// puts the sentinel back into ITS words of the other copy, which nobody reads during this solve.
+static const unsigned long long XW_SENTINEL = 0x7ff8dead0badc0deULL;
+static const int XW_GAVE_UP = 110;  // index into the handle's flags buffer: a poll gave up (~2^20 tries)
+__device__ __forceinline__ unsigned long long xw_peek(const double *p) {
+  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xw_post(double *p, double v) {
+  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void xw_clear(double *p) {
+  __hip_atomic_store((unsigned long long *)p, XW_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double xw_take(const double *p, int *flags) {
+  unsigned long long v = xw_peek(p);
+  for (int n = 0; v == XW_SENTINEL; n++) {
+    if (n > (1 << 20)) {
+      __hip_atomic_store(flags + XW_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 0.0;
+    }
+    __builtin_amdgcn_s_sleep(1);
+    v = xw_peek(p);
+  }
+  return __longlong_as_double((long long)v);
+}
+// exchange arrays of the whole-tree sweeps of small fronts: contribution vectors (the layout of cb) and solution
+// (elimination indices), two copies each; epoch: solves so far (k_rhs_* counts)
+struct TreeXchg {
+  double *cb, *x;
+  long long cb_elems;
+  int dim;
+  const int *epoch;
+  int *flags;
+};
+// ... and of the whole-tree factorisation of small fronts: the update blocks (layout of the update arena), two
+// copies; epoch: factorisations so far (the assembly kernel counts)
+struct TreeXchgF {
+  double *u;
+  long long upd_elems;
+  const int *epoch;
+};
+
 // ---------------------------------------- pivot block of a small supernode
 // Narrow-band systems (Prg_DID: sbw 5) have thousands of supernodes with a
 // handful of pivots each; the 512-thread kernel above would spend its time in
@@ -999,14 +1046,24 @@ __device__ __forceinline__ double rdlane(double v, int l) {
 #ifndef HQPKKT_FDS_WAVES
 #define HQPKKT_FDS_WAVES 4
 #endif
-template <bool FRONT>
+// TREE (with FRONT): ALL levels of a tree of small fronts in one launch, leaves first; a front's lanes wait for
+// the words of its children's update blocks in the exchange array and post their own (see "data words as signals").
+template <bool FRONT, bool TREE = false>
 __global__ void __launch_bounds__(64, HQPKKT_FDS_WAVES)
 k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__restrict__ panel,
                     double *__restrict__ dinv, int *__restrict__ ptype, int *__restrict__ lperm,
                     const signed char *__restrict__ esign, double *__restrict__ linv,
                     const long long *__restrict__ linv_off, double alpha, double pivot_eps,
                     const unsigned long long *__restrict__ kmax_bits, int *__restrict__ counters,
-                    double *__restrict__ upd, double *__restrict__ xar, int ldp, int ldb) {
+                    double *__restrict__ upd, double *__restrict__ xar, int ldp, int ldb, TreeXchgF XF) {
+  static_assert(FRONT || !TREE, "whole-tree launches are for small fronts");
+  if constexpr (TREE) {
+    const int par = *XF.epoch & 1;
+    upd = XF.u + (long long)par * XF.upd_elems;
+    double *other = XF.u + (long long)(par ^ 1) * XF.upd_elems + T.upd_off[level_nodes[blockIdx.x]];
+    const int bb = T.nbor[level_nodes[blockIdx.x]];
+    for (int t = threadIdx.x; t < bb * bb; t += 64) xw_clear(other + t);
+  }
   extern __shared__ __attribute__((aligned(16))) double fsm[];
   double *a = fsm;               // ldp x ldp: full symmetric image of the pivot block
   double *dv = a + ldp * ldp;    // 2 ldp
@@ -1112,6 +1169,35 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
         for (int ib = jb; ib < bcm; ib += 16) {
           const int ii = ib + r16;
           double v0[4], v1[4];
+          if constexpr (TREE) {
+            // all words of the tile requested together, again while one this lane needs still holds the sentinel
+            unsigned long long w0[4], w1[4];
+            bool wait = true;
+            for (int tries = 0; wait; tries++) {
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                if (jb + 4 * u < bcm) {
+                  const int j = jb + 4 * u + cq;
+                  w0[u] = xw_peek(U0 + ((j < bc0 && ii < bc0 && ii >= j) ? (long long)j * bc0 + ii : 0));
+                  w1[u] = xw_peek(U1 + ((j < bc1 && ii < bc1 && ii >= j) ? (long long)j * bc1 + ii : 0));
+                }
+              wait = false;
+#pragma unroll
+              for (int u = 0; u < 4; u++)
+                if (jb + 4 * u < bcm) {
+                  const int j = jb + 4 * u + cq;
+                  wait = wait || (j < bc0 && ii < bc0 && ii >= j && w0[u] == XW_SENTINEL) ||
+                         (j < bc1 && ii < bc1 && ii >= j && w1[u] == XW_SENTINEL);
+                }
+              if (wait && tries > (1 << 20)) {
+                __hip_atomic_store(counters - 1 + XW_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                wait = false;
+              }
+              if (wait) __builtin_amdgcn_s_sleep(1);
+            }
+#pragma unroll
+            for (int u = 0; u < 4; u++) v0[u] = __longlong_as_double((long long)w0[u]), v1[u] = __longlong_as_double((long long)w1[u]);
+          } else {
 #pragma unroll
           for (int u = 0; u < 4; u++)
             if (jb + 4 * u < bcm) {
@@ -1119,6 +1205,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
               v0[u] = U0[(j < bc0 && ii < bc0 && ii >= j) ? (long long)j * bc0 + ii : 0];
               v1[u] = U1[(j < bc1 && ii < bc1 && ii >= j) ? (long long)j * bc1 + ii : 0];
             }
+          }
 #pragma unroll
           for (int w = 0; w < 2; w++) {
             const int bc = w ? bc1 : bc0;
@@ -1488,50 +1575,16 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
           for (int q = 0; q < 4; q++)
             if (tb + q < p) acc = fma(-lq[q], xq[q], acc);
         }
-        if (ron && c2 < b && r16 >= c2) U[(long long)c2 * b + r16] = acc;
+        if constexpr (TREE) {
+          if (ron && c2 < b && r16 >= c2) xw_post(U + (long long)c2 * b + r16, acc);
+        } else {
+          if (ron && c2 < b && r16 >= c2) U[(long long)c2 * b + r16] = acc;
+        }
       }
     }
   }
   FSTAMP(9);
 }
-
-// ---- data words as signals (used by the whole-tree sweeps below and by k_solve_top, solve_top.hip.h): a producer
-// writes its results with agent-scope atomic stores into an exchange array whose words hold a sentinel (a NaN payload
-// no arithmetic produces) until then; the consumer's lanes poll exactly the words they need.  No flags, no cache
-// maintenance: one memory round trip per tree level.  The arrays exist twice: solve e uses copy e & 1 and every front
-// puts the sentinel back into ITS words of the other copy, which nobody reads during this solve.
-static const unsigned long long XW_SENTINEL = 0x7ff8dead0badc0deULL;
-static const int XW_GAVE_UP = 110;  // index into the handle's flags buffer: a poll gave up (~2^20 tries)
-__device__ __forceinline__ unsigned long long xw_peek(const double *p) {
-  return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void xw_post(double *p, double v) {
-  __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void xw_clear(double *p) {
-  __hip_atomic_store((unsigned long long *)p, XW_SENTINEL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ double xw_take(const double *p, int *flags) {
-  unsigned long long v = xw_peek(p);
-  for (int n = 0; v == XW_SENTINEL; n++) {
-    if (n > (1 << 20)) {
-      __hip_atomic_store(flags + XW_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      return 0.0;
-    }
-    __builtin_amdgcn_s_sleep(1);
-    v = xw_peek(p);
-  }
-  return __longlong_as_double((long long)v);
-}
-// exchange arrays of the whole-tree sweeps of small fronts: contribution vectors (the layout of cb) and solution
-// (elimination indices), two copies each; epoch: solves so far (k_rhs_* counts)
-struct TreeXchg {
-  double *cb, *x;
-  long long cb_elems;
-  int dim;
-  const int *epoch;
-  int *flags;
-};
 
 // ---- tree solves of the small fronts: one wavefront per supernode does what the
 // A and B kernels below do for the general fronts (two launches per level, not four).

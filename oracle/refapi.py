@@ -254,6 +254,9 @@ def ip_solve_hot(prog, c2, b2, d2, solver="Mehrotra", mat_solver="SpBKP", host="
     matrices with (c2, b2, d2) after update() + hot_start() (hqp/Hqp_IpsMehrotra.C:330-352,
     696-733).  Returns the SECOND solve: dict(x, y, z, iters, result, seconds, first_iters)."""
     lib = _host(host)
+    if hasattr(lib, "hqpip_set_mu0"):  # (process-wide in the driver: back to the reference's default)
+        lib.hqpip_set_mu0.argtypes = [C.c_double]
+        lib.hqpip_set_mu0(0.0)
     n, me, m = prog.dims
     args = []
     for (p, i, x), vec in zip((prog.Q, prog.A, prog.C), (prog.c, prog.b, prog.d)):

@@ -68,7 +68,7 @@ def test_whole_tree_sweeps_on_trees_of_small_fronts(K, monkeypatch):
     prog = problems.did_like_qp(K)
     st = problems.ip_state(prog, seed=3)
     A, da, ra = _solve(ipmatrix.IpRedSpBKP, prog, st)
-    assert A.debug(31)[0] == 0 and A.debug(31)[4] == 1
+    assert A.debug(31)[0] == 0 and A.debug(31)[4] == 1 and A.debug(31)[5] == 1
     for _ in range(4):
         d2 = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
         assert A.solve(prog, *st, *d2) == ra
