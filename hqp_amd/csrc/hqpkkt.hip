@@ -238,6 +238,7 @@ struct hqpkkt {
   // hqpkkt_franke: the first residual of a solve is not waited for - it comes back with the scalars of the iteration
   // (one read-back per iteration); residual_pending: such a residual is in the stream, collect_residual() reads it
   bool defer_residual = false, residual_pending = false;
+  int res_slot = 0, res_read = 122;  // which of the two residual words the next residual kernel uses / the last one used
   bool soft_singular = false;  // the factorisation perturbed an exactly zero pivot (counters[3])
   bool soft_tiny = false;      // ... or met a pivot below 1e-13 max|K| on a multiplier-type row (counters[4])
   double refine_target = 0.0;  // > 0: the refinement of hqpkkt_solve aims below mat_eps (set by hqpkkt_franke)
@@ -431,6 +432,8 @@ static int upload(hqpkkt_t *h) {
       (e = h->vcor.alloc((size_t)n + me + 2 * (size_t)m)) || (e = h->tz.alloc(m)))
     return e;
   h->bits.p = (unsigned long long *)(h->flags.p + 120);
+  HIPCHK(hipMemset(h->flags.p, 0, sizeof(int) * 128));
+  h->res_slot = 0, h->res_read = 122;
   if (!h->hpin) HIPCHK(hipHostMalloc((void **)&h->hpin, sizeof(double) * 128, hipHostMallocDefault));
   if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr;
   h->hstage_in = h->hstage_out = 0;
@@ -968,7 +971,11 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
   hipStream_t s = h->stream;
   const int n = an.n, me = an.me, m = an.m;
   double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
-  HIPCHK(hipMemsetAsync(h->bits.p + 1, 0, sizeof(unsigned long long), s));
+  // the maximum is accumulated in one of two words (ints 122-123 / 118-119 of the flags buffer) in turn; a residual
+  // kernel zeroes the word of the next one.  (Both are zero after a factorisation: it clears the flags buffer.)
+  unsigned long long *const rb_now = h->bits.p + (h->res_slot ? -1 : 1), *const rb_next = h->bits.p + (h->res_slot ? 1 : -1);
+  h->res_read = h->res_slot ? 118 : 122;
+  h->res_slot ^= 1;
   const double *x1 = nullptr, *x2 = nullptr;  // STAGED, dense dynamics: their share of A dx and A'dy
   int ndyn = 0;
   if (h->opts.mode == HQPKKT_MODE_STAGED) {
@@ -978,11 +985,11 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
   if (h->short_rows)
     KLAUNCH(h, KC_RESIDUAL, k_residual<4><<<std::min(nblk(4LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
-        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1, x1, x2, ndyn));
+        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, rb_now, rb_next, x1, x2, ndyn));
   else
     KLAUNCH(h, KC_RESIDUAL, k_residual<16><<<std::min(nblk(16LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
-        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, h->bits.p + 1, x1, x2, ndyn));
+        v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, rb_now, rb_next, x1, x2, ndyn));
   if (out) {
     int e2 = stage_out(h, v, out->dx, out->dy, out->dz, out->dw);
     if (e2) return e2;
@@ -1012,7 +1019,7 @@ static int collect_residual(hqpkkt_t *h, double *res) {
     return HQPKKT_E_DEVICE;
   }
   unsigned long long kb, bits;
-  std::memcpy(&kb, hs + 120, sizeof(kb)), std::memcpy(&bits, hs + 122, sizeof(bits));
+  std::memcpy(&kb, hs + 120, sizeof(kb)), std::memcpy(&bits, hs + h->res_read, sizeof(bits));
   double r;
   std::memcpy(&r, &bits, sizeof(r));
   *res = r;
@@ -2463,7 +2470,14 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
   for (int r = -1; r < reps; r++) {
     if (r == 0) (void)hipEventRecord(e0, 0);
-    if (use_sk) {
+    const char *t256 = getenv("HQPKKT_DGEMM_TILE256");  // (experiment: 256 x 128 tiles, "2" / "3" LDS buffers; full products only)
+    if (t256 && !lower && !mirror && g.zeros) {
+      const unsigned nt = (unsigned)(((M + 255) / 256) * (long long)((N + 127) / 128));
+      if (t256[0] == '3')
+        stg::k_dgemm_tn<256, 128, true, 4, 4, 3><<<nt, 1024, stg::gemm_lds_bytes(256, 128, 3)>>>(g);
+      else
+        stg::k_dgemm_tn<256, 128, true, 4, 4, 2><<<nt, 1024, stg::gemm_lds_bytes(256, 128)>>>(g);
+    } else if (use_sk) {
       (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (tiles + 4), 0);
       stg::SplitPlan skk = stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
       skk.ws = skws, skk.cnt = skcnt;

@@ -2501,11 +2501,13 @@ k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDe
            const double *__restrict__ dy, const double *__restrict__ dz,
            const double *__restrict__ dw, double *__restrict__ o1, double *__restrict__ o2,
            double *__restrict__ o3, double *__restrict__ o4,
-           unsigned long long *__restrict__ resbits,
+           unsigned long long *__restrict__ resbits, unsigned long long *__restrict__ resbits_next,
+           // (resbits_next: the word the NEXT residual accumulates into, zeroed here - no memset between residuals)
            // STAGED with dense dynamics: x1 = A_dyn' dy (n), x2 = A_dyn dx (first ndyn rows of A,
            // which are empty in the CSR block), computed by the dense kernels of staged.hip.h
            const double *__restrict__ x1 = nullptr, const double *__restrict__ x2 = nullptr, int ndyn = 0) {
   __shared__ double red[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) *resbits_next = 0ULL;
   const int sub = threadIdx.x & (LPR - 1);
   const int total = n + me + m;
   double mag = 0.0;
