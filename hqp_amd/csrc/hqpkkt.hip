@@ -2470,14 +2470,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
   for (int r = -1; r < reps; r++) {
     if (r == 0) (void)hipEventRecord(e0, 0);
-    const char *t256 = getenv("HQPKKT_DGEMM_TILE256");  // (experiment: 256 x 128 tiles, "2" / "3" LDS buffers; full products only)
-    if (t256 && !lower && !mirror && g.zeros) {
-      const unsigned nt = (unsigned)(((M + 255) / 256) * (long long)((N + 127) / 128));
-      if (t256[0] == '3')
-        stg::k_dgemm_tn<256, 128, true, 4, 4, 3><<<nt, 1024, stg::gemm_lds_bytes(256, 128, 3)>>>(g);
-      else
-        stg::k_dgemm_tn<256, 128, true, 4, 4, 2><<<nt, 1024, stg::gemm_lds_bytes(256, 128)>>>(g);
-    } else if (use_sk) {
+    if (use_sk) {
       (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (tiles + 4), 0);
       stg::SplitPlan skk = stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
       skk.ws = skws, skk.cnt = skcnt;

@@ -362,69 +362,9 @@ struct GemmTile {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the zero rows behind the range: LDS is reused after this)
     __syncthreads();
   }
-  // 256 x 128 tiles, 4 x 4 wavefronts (one workgroup per CU, the same 64 x 32 per wavefront as the 2 x 4 form of the
-  // 128 x 128 tile): 48 one-KiB pieces per slab for twice the multiplications of 32 - a quarter less operand traffic
-  // L2 -> LDS per flop.  Wave w brings row w of the slab: the two halves of A's row and B's row, issued behind the
-  // multiplications 1, 3 and 5 of the slab before.  NB LDS buffers (2: 104 KB, 3: 156 KB).
-  template <bool MASKED, int NB>
-  static __device__ __forceinline__ void slabs_dma_wide(const GemmArgs &g, const double *pa, const double *pa2, const double *pb,
-                                                        const double *zr, int wave, int wm, int wn, int lr, int lk, int s0, int s1,
-                                                        unsigned mask, double4_t (&acc)[TM][TN], double *As, double *Bs) {
-    static_assert(BM == 256 && BN == 128 && NW == 16 && TM * TN == 8, "written for 256 x 128 tiles on 4 x 4 wavefronts");
-    auto dma = [&](int buf, int k0, int p) {
-      const int k = k0 + wave;
-      if (p == 0)
-        glds16(k < g.K ? pa + (long long)k * g.lda : zr, As + (buf * BK + wave) * LDA);
-      else if (p == 1)
-        glds16(k < g.K ? pa2 + (long long)k * g.lda : zr, As + (buf * BK + wave) * LDA + 128);
-      else
-        glds16(k < g.K ? pb + (long long)k * g.ldb : zr, Bs + (buf * BK + wave) * LDB);
-    };
-    auto wait_older = [&]() {  // everything but the newest slab's three pieces has landed; then the barrier
-      if constexpr (NB == 3)
-        asm volatile("s_waitcnt vmcnt(3) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      else
-        __syncthreads();
-    };
-#pragma unroll
-    for (int p = 0; p < 3; p++) dma(0, s1 > s0 ? s0 * BK : g.K, p);
-    if constexpr (NB == 3) {
-#pragma unroll
-      for (int p = 0; p < 3; p++) dma(1, s0 + 1 < s1 ? (s0 + 1) * BK : g.K, p);
-    }
-    wait_older();
-    int buf = 0;
-    for (int s = s0; s < s1; s++) {
-      const int bnext = NB == 3 ? (buf >= 1 ? buf - 1 : 2) : (buf ^ 1);
-      const int knext = s + (NB - 1) < s1 ? (s + (NB - 1)) * BK : g.K;  // behind the range: zero rows into a buffer nobody reads
-      const double *Ab = As + buf * BK * LDA + wm * WM + lr;
-      const double *Bb = Bs + buf * BK * LDB + wn * WN + lr;
-#pragma unroll
-      for (int ks = 0; ks < BK / 4; ks++) {
-        double af[TM], bf[TN];
-#pragma unroll
-        for (int x = 0; x < TM; x++) af[x] = Ab[(ks * 4 + lk) * LDA + 16 * x];
-#pragma unroll
-        for (int y = 0; y < TN; y++) bf[y] = Bb[(ks * 4 + lk) * LDB + 16 * y];
-#pragma unroll
-        for (int x = 0; x < TM; x++)
-#pragma unroll
-          for (int y = 0; y < TN; y++) {
-            if (!MASKED || ((mask >> (x * TN + y)) & 1u)) acc[x][y] = mfma_f64(af[x], bf[y], acc[x][y]);
-            if (ks == 0 && (x * TN + y) % 2 == 1 && (x * TN + y) / 2 < 3) dma(bnext, knext, (x * TN + y) / 2);
-          }
-      }
-      wait_older();
-      buf = NB == 3 ? (buf == 2 ? 0 : buf + 1) : (buf ^ 1);
-    }
-    if constexpr (NB == 3) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
-    }
-  }
   static __device__ __forceinline__ void accumulate_dma(const GemmArgs &g, int i0, int j0, int s0, int s1,
                                                         double4_t (&acc)[TM][TN], double *As, double *Bs, bool skip_upper = false, int nbuf = 2) {
-    static_assert((BM == 128 || BM == 256) && BN == 128, "one k-row of a panel must be one or two 1-KiB wave-instructions");
+    static_assert(BM == 128 && BN == 128, "one k-row of a panel must be one 1-KiB wave-instruction");
     static_assert((BK / NW) * NW == BK && TM * TN >= 2 * (BK / NW) && TM * TN <= 32,
                   "pieces are issued behind the multiplications of the first k-step");
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -445,19 +385,6 @@ struct GemmTile {
       }
     mask = __builtin_amdgcn_readfirstlane(mask);
     const bool all = mask == (TM * TN == 32 ? 0xffffffffu : (1u << (TM * TN)) - 1u);
-    if constexpr (BM == 256) {
-      const double *pa2 = g.A + ((i0 + 128 + 2 * lane < g.lda) ? i0 + 128 + 2 * lane : 0);
-      if (nbuf == 3) {
-        if (all)
-          slabs_dma_wide<false, 3>(g, pa, pa2, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
-        else
-          slabs_dma_wide<true, 3>(g, pa, pa2, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
-      } else if (all)
-        slabs_dma_wide<false, 2>(g, pa, pa2, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
-      else
-        slabs_dma_wide<true, 2>(g, pa, pa2, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
-      return;
-    } else
     if (nbuf == 3) {
       if (all)
         slabs_dma3<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
@@ -543,8 +470,11 @@ struct GemmTile {
   }
 };
 
-// wavefronts per SIMD the launch is compiled for: two workgroups per CU (one with three LDS buffers, one of 16 wavefronts)
-constexpr int gemm_waves_per_simd(int nw, int nbuf) { return nw >= 16 ? 4 : (nbuf == 3 ? nw / 4 : nw / 2); }
+// wavefronts per SIMD the launch is compiled for: two workgroups per CU (one with three LDS buffers)
+// (A 256 x 128 tile on 4 x 4 wavefronts, one workgroup per CU, was written and measured in round 4 - commit 44e8e46,
+// profiles/r04_tile256_ab.txt: 88.4 % of the peak at 8192^3 against 89.7 % of the 2 x 4 form, 64 % against 79.5 % on
+// the 800 tiles of a C4 stage's W - and taken out again.)
+constexpr int gemm_waves_per_simd(int nw, int nbuf) { return nbuf == 3 ? nw / 4 : nw / 2; }
 template <int BM, int BN, bool DMA = false, int WGM = 2, int WGN = 2, int NBUF = 2>
 __global__ void __launch_bounds__(64 * WGM * WGN, gemm_waves_per_simd(WGM * WGN, NBUF)) k_dgemm_tn(GemmArgs g) {
   using T = GemmTile<BM, BN, WGM, WGN>;
@@ -801,8 +731,6 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn<128, 128>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<128, 128, true>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<128, 128, true, 2, 4>, gemm_lds_bytes(128, 128));
-  set((const void *)k_dgemm_tn<256, 128, true, 4, 4, 2>, gemm_lds_bytes(256, 128));
-  set((const void *)k_dgemm_tn<256, 128, true, 4, 4, 3>, gemm_lds_bytes(256, 128, 3));
   set((const void *)k_dgemm_tn<64, 64>, gemm_lds_bytes(64, 64));
   set((const void *)k_dgemm_tn<64, 32>, gemm_lds_bytes(64, 32));
   set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());
