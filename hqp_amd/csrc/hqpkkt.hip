@@ -212,7 +212,8 @@ struct hqpkkt {
   // the top levels of the tree solved in one launch (solve_top.hip.h): fronts of the levels >= top_lt, root first
   int top_n = 0, top_lt = 1 << 30, top_ns = 3;  // top_ns: 3 = k_solve_top<3, 11>, 4 = <4, 10>
   size_t top_lds = 0;
-  DBuf<int> top_nodes, top_idx, top_bpos, top_words;
+  DBuf<int> top_nodes, top_idx, top_bpos, top_up;  // top_up: the fronts leaves first (top_split)
+  bool top_split = false;  // more fronts than one launch may hold at once: the two sweeps as launches of their own
   unsigned long long *top_stamps = nullptr;  // (hqpkkt_debug_solve_top_stamps)
   // trees of small fronts only (the double-integrator structure): each sweep of the solve is ONE launch over all levels
   // (k_solve_fwd_small<true> / k_solve_bwd_small<true>); tree_x: the exchange arrays (2 x cb_elems, then 2 x dim)
@@ -270,7 +271,7 @@ struct hqpkkt {
   void release_device(bool keep_ip = false) {  // keep_ip: hqpkkt_mehrotra's vectors and the pinned words stay
     DBuf<int> *ib[] = {&piv_start, &npiv, &nbor, &parent, &bidx, &rel, &child_ptr, &child_idx,
                        &ent_a, &ent_b, &term_ptr, &diag_ent, &q2e, &pinv, &ptype, &lperm, &flags,
-                       &top_nodes, &top_idx, &top_bpos, &top_words, &tree_words, &tree_down};
+                       &top_nodes, &top_idx, &top_bpos, &top_up, &tree_words, &tree_down};
     for (auto b : ib) b->release();
     ds[0].release(), ds[1].release(), keep_e.release(), simple_src.release(), simple_wi.release();
     DBuf<long long> *lb[] = {&bptr, &panel_off, &upd_off, &x_off, &cb_off, &ent_dst, &linv_off, &pinv_off,
@@ -326,6 +327,7 @@ static int ensure_device(hqpkkt_t *h) {
 // the exchange arrays of k_solve_top in their idle state: every word the sentinel, counters zero
 static int reset_solve_top(hqpkkt_t *h) {
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (h->tree_words.p) HIPCHK(hipMemset(h->tree_words.p, 0, sizeof(int) * 2));
   auto fill = [&](DBuf<double> &buf, size_t count) -> int {
     std::vector<double> f(count);
     for (auto &x : f) std::memcpy(&x, &XW_SENTINEL, sizeof(double));
@@ -335,12 +337,11 @@ static int reset_solve_top(hqpkkt_t *h) {
   int e;
   if (h->top_n > 0) {
     if ((e = fill(h->top_x, 2 * (size_t)h->top_n * (ST_CS + ST_XS)))) return e;
-    HIPCHK(hipMemset(h->top_words.p, 0, sizeof(int) * 2));
   }
   if (h->small_tree) {
     if ((e = fill(h->tree_x, 2 * (size_t)(h->an.cb_elems + h->an.dim)))) return e;
     if (h->tree_factor && (e = fill(h->tree_u, 2 * (size_t)std::max<long long>(h->an.upd_elems, 1)))) return e;
-    HIPCHK(hipMemset(h->tree_words.p, 0, sizeof(int) * 2));
+
   }
   return 0;
 }
@@ -468,6 +469,10 @@ static int upload(hqpkkt_t *h) {
       for (int q = S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l]; q < S.level_ptr[l + 1]; q++)
         h->level_maxp[w][l] = std::max(h->level_maxp[w][l], an.npiv[S.level_nodes[q]]);
   }
+  {  // the counters of the polled exchanges: [0] solves, [1] factorisations so far (k_rhs_*, the assembly kernels count)
+    std::vector<int> two(2, 0);
+    if ((e = h->tree_words.upload(two))) return e;
+  }
   // a tree of small fronts only: whole-tree sweeps
   h->small_tree = false, h->tree_factor = false;
   if (!getenv("HQPKKT_NO_TREE_SWEEPS") && an.shard_count == 1 && an.sched[0].nnodes > 1 && an.sched[1].nnodes == 0) {
@@ -478,7 +483,7 @@ static int upload(hqpkkt_t *h) {
       std::vector<int> down, one(2, 0);
       for (int l = an.nlevels - 1; l >= 0; l--)
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) down.push_back(S.level_nodes[q]);
-      if ((e = h->tree_down.upload(down)) || (e = h->tree_words.upload(one)) || (e = h->tree_x.alloc(2 * (size_t)(an.cb_elems + an.dim)))) return e;
+      if ((e = h->tree_down.upload(down)) || (e = h->tree_x.alloc(2 * (size_t)(an.cb_elems + an.dim)))) return e;
       h->small_tree = true;
       h->tree_factor = !an.upd_pingpong && !getenv("HQPKKT_NO_TREE_FACTOR");
       if (h->tree_factor && (e = h->tree_u.alloc(2 * (size_t)std::max<long long>(an.upd_elems, 1)))) return e;
@@ -503,7 +508,7 @@ static int upload(hqpkkt_t *h) {
       }
       // (levels of small fronts stay with their one-wavefront kernels: a step of k_solve_top costs 16 wavefronts'
       // worth of barriers and reductions whatever the size of the front - measured slower on the DID tree)
-      if (cnt + nn > ST_MAXFRONTS || !(f3 || f4) || S.level_fsmall[l] > 0) break;
+      if (cnt + nn > ST_MAXSPLIT || !(f3 || f4) || S.level_fsmall[l] > 0) break;
       cnt += nn, lt = l, maxp = mp2, ok3 = f3, ok4 = f4;
     }
     if (an.nlevels - lt >= 2 && cnt >= 2) {
@@ -519,8 +524,9 @@ static int upload(hqpkkt_t *h) {
           if (o < 0) return HQPKKT_E_INTERN;  // (a border row of a fused front belongs to a fused ancestor)
           bpos[t * ST_CS + i] = o * ST_XS + (ei - an.piv_start[nodes[o]]);
         }
-      std::vector<int> words(2, 0);
-      if ((e = h->top_nodes.upload(nodes)) || (e = h->top_idx.upload(idx)) || (e = h->top_bpos.upload(bpos)) || (e = h->top_words.upload(words)) ||
+      std::vector<int> up(nodes.rbegin(), nodes.rend());  // (level by level, leaves first)
+      h->top_split = (int)nodes.size() > ST_MAXFRONTS || getenv("HQPKKT_SOLVE_TOP_SPLIT") != nullptr;
+      if ((e = h->top_nodes.upload(nodes)) || (e = h->top_idx.upload(idx)) || (e = h->top_bpos.upload(bpos)) || (e = h->top_up.upload(up)) ||
           (e = h->top_x.alloc(2 * nodes.size() * (size_t)(ST_CS + ST_XS))))
         return e;
       h->top_n = (int)nodes.size(), h->top_lt = lt, h->top_ns = ok3 ? 3 : 4, h->top_lds = st_top_lds_bytes(maxp, h->top_ns);
@@ -535,8 +541,13 @@ static int upload(hqpkkt_t *h) {
     static size_t a_diag = 0, a_panel = 0, a_bwdb = 0, a_blk = 0, a_top = 0;
     std::lock_guard<std::mutex> lk(attr_mutex);
     if (h->top_lds > a_top) {
-      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<3, 11>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(h->top_lds, st_top_lds_bytes(176, 3))));
-      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<4, 10>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(h->top_lds, st_top_lds_bytes(160, 4))));
+      const int l3 = (int)std::min(h->top_lds, st_top_lds_bytes(176, 3)), l4 = (int)std::min(h->top_lds, st_top_lds_bytes(160, 4));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<3, 11, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<3, 11, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<3, 11, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<4, 10, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<4, 10, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
+      HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<4, 10, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, l4));
       a_top = h->top_lds;
     }
     if (lds_blk > a_blk) {
@@ -672,10 +683,10 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
     if (h->simple_src.count) {  // FULL: one pass
       KLAUNCH(h, KC_ASSEMBLE, k_assemble_simple<<<std::min(nblk(nent), 2048), 256, 0, s>>>(
                                   nent, h->simple_src.p, h->simple_wi.p, h->ent_a.p, h->ent_b.p, h->ent_dst.p,
-                                  h->vals.p, h->wt.p, h->sc.p, h->panel.p, h->bits.p, h->tree_factor ? h->tree_words.p + 1 : nullptr));
+                                  h->vals.p, h->wt.p, h->sc.p, h->panel.p, h->bits.p, h->tree_words.p + 1));
     } else {
       KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
-                                                h->ent_val.p, h->tree_factor ? h->tree_words.p + 1 : nullptr));
+                                                h->ent_val.p, h->tree_words.p + 1));
       if (an.mode == 1 && an.n > 0)
         KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
       KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
@@ -822,25 +833,31 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
   if (phases & 1) {
     if (an.mode == 0) {
       KLAUNCH(h, KC_VECTOR, k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
-                                           h->rhs.p, h->small_tree ? h->tree_words.p : nullptr));
+                                           h->rhs.p, h->tree_words.p));
     } else {
       if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
       KLAUNCH(h, KC_VECTOR, k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
                                           h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p,
-                                          h->small_tree ? h->tree_words.p : nullptr));
+                                          h->tree_words.p));
     }
     forward(0);
   }
   if (phases & 2) {
     forward(1);
-    if (h->top_n > 0) {  // the top levels, up and down, in one launch
-      const TopArgs ta{h->top_nodes.p, h->top_idx.p, h->top_bpos.p, h->top_x.p, h->top_x.p + 2 * (size_t)h->top_n * ST_CS, h->top_words.p, h->top_n, h->top_stamps};
-      if (h->top_ns == 3)
-        KLAUNCH(h, KC_SOLVE_TOP, (k_solve_top<3, 11><<<h->top_n, ST_THREADS, h->top_lds, s>>>(T, ta, h->panel.p, h->linv.p, h->linv_off.p, h->dinv.p, h->ptype.p,
-                                                                 h->lperm.p, h->rhs.p, h->xsol.p, h->cb.p, h->flags.p)));
-      else
-        KLAUNCH(h, KC_SOLVE_TOP, (k_solve_top<4, 10><<<h->top_n, ST_THREADS, h->top_lds, s>>>(T, ta, h->panel.p, h->linv.p, h->linv_off.p, h->dinv.p, h->ptype.p,
-                                                                 h->lperm.p, h->rhs.p, h->xsol.p, h->cb.p, h->flags.p)));
+    if (h->top_n > 0) {  // the top levels, up and down: one launch, or one per sweep (k_solve_top)
+      TopArgs ta{h->top_nodes.p, h->top_idx.p, h->top_bpos.p, h->top_x.p, h->top_x.p + 2 * (size_t)h->top_n * ST_CS, h->tree_words.p, h->top_n, h->top_stamps};
+#define TOP_LAUNCH(NS, NU, MODE)                                                                                                          \
+  KLAUNCH(h, KC_SOLVE_TOP, (k_solve_top<NS, NU, MODE><<<h->top_n, ST_THREADS, h->top_lds, s>>>(T, ta, h->panel.p, h->linv.p, h->linv_off.p, \
+                                                            h->dinv.p, h->ptype.p, h->lperm.p, h->rhs.p, h->xsol.p, h->cb.p, h->flags.p)))
+      if (!h->top_split) {
+        if (h->top_ns == 3) TOP_LAUNCH(3, 11, 0); else TOP_LAUNCH(4, 10, 0);
+      } else {
+        ta.nodes = h->top_up.p;
+        if (h->top_ns == 3) TOP_LAUNCH(3, 11, 1); else TOP_LAUNCH(4, 10, 1);
+        ta.nodes = h->top_nodes.p;
+        if (h->top_ns == 3) TOP_LAUNCH(3, 11, 2); else TOP_LAUNCH(4, 10, 2);
+      }
+#undef TOP_LAUNCH
     }
     backward(1);
     backward(0);
@@ -1199,10 +1216,13 @@ static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd) {
   h->an.ordering = (h->opts.ordering == 1 || h->opts.ordering == 2) ? h->opts.ordering : 0;
   if (h->opts.upd_pingpong_mb > 0) h->an.upd_pingpong_bytes = (long long)h->opts.upd_pingpong_mb << 20;
   if (h->opts.upd_pingpong_mb < 0) h->an.upd_pingpong_bytes = 0;
-  // pivots per supernode: the caller's number, or 192 (what k_factor_blk takes; HQPKKT_MAX_PIVOTS for same-box
-  // comparisons; k_factor_diag of rounds 1-3, HQPKKT_OLD_FD, takes 128)
+  // pivots per supernode: the caller's number (k_factor_blk takes up to 192), or 160 - ten blocks of 16, the widest
+  // front whose M = L11^-1 stays in LDS next to L21 in registers for both sweeps of k_solve_top, so that ALL levels of
+  // a banded system's tree go through its two launches (C2: 2.27 ms per factor + solve against 2.33 with 192, where
+  // the leaf level stays outside).  HQPKKT_MAX_PIVOTS for same-box comparisons; k_factor_diag of rounds 1-3
+  // (HQPKKT_OLD_FD) takes 128.
   int maxp = h->opts.max_pivots;
-  if (maxp <= 0) maxp = getenv("HQPKKT_MAX_PIVOTS") ? std::atoi(getenv("HQPKKT_MAX_PIVOTS")) : 192;
+  if (maxp <= 0) maxp = getenv("HQPKKT_MAX_PIVOTS") ? std::atoi(getenv("HQPKKT_MAX_PIVOTS")) : 160;
   if (getenv("HQPKKT_OLD_FD")) maxp = std::min(maxp, 128);
   int e = h->an.run(h->opts.mode, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),
                     h->pCp.data(), h->pCi.data(), h->opts.leaf_size, maxp, zd);
@@ -2676,7 +2696,7 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       v = &tmp;
       break;
     case 31:  // the solve's fused top (k_solve_top): number of fronts, first fused level, LDS bytes
-      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds, h->top_ns, h->small_tree ? 1 : 0, h->tree_factor ? 1 : 0};
+      tmp = {h->top_n, h->top_n ? h->top_lt : h->an.nlevels, (int)h->top_lds, h->top_ns, h->small_tree ? 1 : 0, h->tree_factor ? 1 : 0, h->top_split ? 1 : 0};
       v = &tmp;
       break;
     case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)

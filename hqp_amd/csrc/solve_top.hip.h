@@ -27,7 +27,7 @@
 
 namespace kktdev {
 
-static const int ST_THREADS = 1024, ST_MAXFRONTS = 128;
+static const int ST_THREADS = 1024, ST_MAXFRONTS = 128, ST_MAXSPLIT = 1 << 15;  // fronts of one fused launch / of the split form
 static const int ST_XS = 192, ST_CS = 256;  // words per front in the exchange arrays: solution (pivots), contribution (border rows)
 static const int ST_GAVE_UP = XW_GAVE_UP;    // index into the handle's flags buffer
 static const unsigned long long ST_SENTINEL = XW_SENTINEL;
@@ -46,22 +46,25 @@ struct TopArgs {
   const int *top_idx;  // supernode -> index into nodes, -1 below the fused levels
   const int *bpos;     // [front][border row] -> word of the solution exchange array
   double *xcb, *xx;    // exchange arrays: 2 x ntop x ST_CS contributions, 2 x ntop x ST_XS solution
-  int *words;          // [0] launch counter, [1] workgroups of this launch that have read it
+  const int *epoch;    // solves so far (k_rhs_* counts): this solve uses copy epoch & 1 of the exchange arrays
   int ntop;
   unsigned long long *stamps;  // diagnostics (hqpkkt_debug_solve_top_stamps): 8 times per front, or null
 };
 #define ST_STAMP(k) \
   if (A.stamps && tid == 0) A.stamps[8 * me + (k)] = __builtin_amdgcn_s_memrealtime()
 
-template <int NS, int NU>
+// MODE 0: both sweeps in one launch (all fronts resident at once: at most ST_MAXFRONTS); 1 / 2: the forward sweep
+// (`nodes` leaves first) and the backward sweep (root first) as launches of their own, for any number of fronts - a
+// waiting front only waits for fronts before it in the launch, which relies on workgroups being dispatched in index
+// order when the chip does not hold them all.
+template <int NS, int NU, int MODE>
 __global__ void __launch_bounds__(ST_THREADS)
 k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double *__restrict__ linv,
             const long long *__restrict__ linv_off, const double *__restrict__ dinv, const int *__restrict__ ptype,
             const int *__restrict__ lperm, const double *__restrict__ rhs, double *__restrict__ xsol,
             const double *__restrict__ cb, int *__restrict__ flags) {
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  __shared__ int s_par;
-  const int me = blockIdx.x, node = A.nodes[me];
+  const int node = A.nodes[blockIdx.x], me = A.top_idx[node];  // me: the front's slot in the exchange arrays
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
   const int e0 = T.piv_start[node];
@@ -70,11 +73,7 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   constexpr int VEC = 64 * NS;  // length of the vectors in LDS (pivots, border rows) and stride of the partial sums
   ST_STAMP(0);
-  if (tid == 0) {
-    s_par = __hip_atomic_load(A.words, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the counter has been READ before this workgroup reports it
-    __hip_atomic_fetch_add(A.words + 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  const int par = *A.epoch & 1;
   const size_t mlen = ((size_t)p * (p + 1) / 2 + 1) & ~(size_t)1;
   double *Ms = lds;  // column t of M from its diagonal down: Ms[t p - t (t - 1) / 2 + (i - t)]
   double *t1 = Ms + mlen, *tp = t1 + VEC, *y = tp + VEC, *xd = y + VEC, *vv = xd + VEC, *cbs = vv + VEC,
@@ -116,17 +115,17 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
   const bool has_parent = parent >= 0;  // (inside this launch: the fused levels are closed upwards)
   if (tid < VEC) t1[tid] = rv, cbs[tid] = 0.0;
   __syncthreads();
-  const int par = s_par;
   double *xcb = A.xcb + (size_t)par * A.ntop * ST_CS, *xx = A.xx + (size_t)par * A.ntop * ST_XS;
   {  // this front's words of the other copy: back to the sentinel for the next launch
     double *ocb = A.xcb + (size_t)(par ^ 1) * A.ntop * ST_CS, *ox = A.xx + (size_t)(par ^ 1) * A.ntop * ST_XS;
-    if (tid < ST_CS) st_post(ocb + me * ST_CS + tid, __longlong_as_double((long long)ST_SENTINEL));
-    if (tid < ST_XS) st_post(ox + me * ST_XS + tid, __longlong_as_double((long long)ST_SENTINEL));
+    if (MODE != 2 && tid < ST_CS) st_post(ocb + me * ST_CS + tid, __longlong_as_double((long long)ST_SENTINEL));
+    if (MODE != 1 && tid < ST_XS) st_post(ox + me * ST_XS + tid, __longlong_as_double((long long)ST_SENTINEL));
   }
 
   ST_STAMP(1);  // static data requested / in LDS
-  // ---- forward: t = rhs + children, y = M P t, yd = D^-1 y, contribution = c - L21 y
   int nfc = 0;  // children inside the fused levels
+  if constexpr (MODE != 2) {
+  // ---- forward: t = rhs + children, y = M P t, yd = D^-1 y, contribution = c - L21 y
   for (int cc = c0; cc < c1; cc++) {
     const int c = T.child_idx[cc];
     const int bc = T.nbor[c], ci = A.top_idx[c];
@@ -196,6 +195,14 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
     }
   }
 
+  if constexpr (MODE == 1) {  // yd for the backward launch
+    if (tid < p) xsol[e0 + tid] = xd[tid];
+    return;
+  }
+  } else {  // (backward launch: yd from the forward one; the fused children are counted for the posting below)
+    if (tid < p) xd[tid] = xsol[e0 + tid];
+    for (int cc = c0; cc < c1; cc++) nfc += A.top_idx[T.child_idx[cc]] >= 0 ? 1 : 0;
+  }
   ST_STAMP(3);  // forward step done
   // ---- backward: v = yd - L21' x(border), x = P' M' v
   if (tid < VEC) x2[tid] = tid < b && has_parent ? st_take(xx + bpos, flags) : 0.0;
@@ -237,17 +244,6 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
     xsol[e0 + lpk] = z;  // (for the levels below, after this launch)
   }
   ST_STAMP(5);
-  if (me == A.ntop - 1 && tid == 0) {  // every workgroup of this launch has read the counter: the next launch uses the other copy
-    for (int n = 0; __hip_atomic_load(A.words + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < A.ntop; n++) {
-      if (n > (1 << 20)) {
-        __hip_atomic_store(flags + ST_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        break;
-      }
-      __builtin_amdgcn_s_sleep(4);
-    }
-    __hip_atomic_store(A.words + 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_fetch_add(A.words, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
 }
 
 }  // namespace kktdev
