@@ -525,7 +525,12 @@ static int upload(hqpkkt_t *h) {
           bpos[t * ST_CS + i] = o * ST_XS + (ei - an.piv_start[nodes[o]]);
         }
       std::vector<int> up(nodes.rbegin(), nodes.rend());  // (level by level, leaves first)
-      h->top_split = (int)nodes.size() > ST_MAXFRONTS || getenv("HQPKKT_SOLVE_TOP_SPLIT") != nullptr;
+      // One launch for both sweeps needs ALL its fronts resident at once (the forward sweep of a front waits for
+      // fronts behind it in the launch): safe only while nothing else competes for the CUs.  Several systems in flight
+      // on one GPU (bench.py's concurrent systems, scenario trees) could starve each other, so the form in use is the
+      // split one - a front waits only for fronts before it - and the fused launch is an option (HQPKKT_SOLVE_TOP_FUSED,
+      // 17 us less per solve: M and L21 are read once).
+      h->top_split = (int)nodes.size() > ST_MAXFRONTS || getenv("HQPKKT_SOLVE_TOP_FUSED") == nullptr;
       if ((e = h->top_nodes.upload(nodes)) || (e = h->top_idx.upload(idx)) || (e = h->top_bpos.upload(bpos)) || (e = h->top_up.upload(up)) ||
           (e = h->top_x.alloc(2 * nodes.size() * (size_t)(ST_CS + ST_XS))))
         return e;

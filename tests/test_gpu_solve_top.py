@@ -48,14 +48,14 @@ def test_fused_top_against_the_per_level_sweeps(n, band, cls, monkeypatch):
 
 @pytest.mark.parametrize("n,band,cls", [(6000, 40, ipmatrix.IpSpBKP), (20000, 60, ipmatrix.IpRedSpBKP)])
 def test_split_sweeps_give_the_bits_of_the_fused_launch(n, band, cls, monkeypatch):
-    """The two sweeps as launches of their own (forward leaves first, backward root first: the form for more fronts than
-    the chip holds at once; forced here by HQPKKT_SOLVE_TOP_SPLIT) against both sweeps in one launch: same arithmetic,
-    same bits; repeated solves too."""
+    """The two sweeps as launches of their own (forward leaves first, backward root first: the form in use, for any
+    number of fronts) against both sweeps in one launch (HQPKKT_SOLVE_TOP_FUSED, at most 128 fronts, all resident):
+    same arithmetic, same bits; repeated solves too."""
     prog = problems.banded_qp(n, band, seed=8)
     st = problems.ip_state(prog, seed=2)
-    A, da, ra = _solve(cls, prog, st)
-    monkeypatch.setenv("HQPKKT_SOLVE_TOP_SPLIT", "1")
     B, db, rb = _solve(cls, prog, st)
+    monkeypatch.setenv("HQPKKT_SOLVE_TOP_FUSED", "1")
+    A, da, ra = _solve(cls, prog, st)
     assert B.debug(31)[6] == 1 and B.debug(31)[0] == A.debug(31)[0] >= 3
     if A.debug(31)[6] == 0:  # (the larger system is split anyway)
         assert ra == rb
