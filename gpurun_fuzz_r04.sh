@@ -1,10 +1,10 @@
 #!/bin/bash
-# Round-4 randomised campaign of the tree engine on the new pivot-block kernel (outputs under gpurun_out/fuzz4/).
+# Round-4 randomised campaign of the tree engine on the final code of the round (k_factor_blk, k_solve_top, whole-tree launches of small fronts) (outputs under gpurun_out/fuzz4/).
 cd $GRAFT_REPO_ROOT; O=gpurun_out/fuzz4; mkdir -p $O; F=$O/r04_fuzz_tree.txt; : > $F
 echo "## tools/fuzz.py 12000 (tree engine, k_factor_blk, fronts of up to 192 pivots, against the CPU oracle)" >> $F
 timeout 1500 python tools/fuzz.py 12000 2>/dev/null | grep -v amdgpu.ids | tail -8 >> $F
-echo "## FUZZ_SCALE=30 tools/fuzz.py 150 (banded systems up to n = 45 000, band 120: fronts of 100 .. 192 pivots)" >> $F
-FUZZ_SCALE=30 timeout 1500 python tools/fuzz.py 150 2>/dev/null | grep -v amdgpu.ids | tail -8 >> $F
+echo "## FUZZ_SCALE=30 tools/fuzz.py 60 (banded systems up to n = 45 000, band 120: fronts of 100 .. 192 pivots)" >> $F
+FUZZ_SCALE=30 timeout 1500 python tools/fuzz.py 60 2>/dev/null | grep -v amdgpu.ids | tail -8 >> $F
 echo "## FUZZ_ORDERING=1 tools/fuzz.py 3000" >> $F
 FUZZ_ORDERING=1 timeout 900 python tools/fuzz.py 3000 2>/dev/null | grep -v amdgpu.ids | tail -8 >> $F
 echo "## tools/fuzz_ip.py, 6000 QPs in chunks of 400 (device loops against the reference's solvers)" >> $F

@@ -2656,8 +2656,10 @@ int hqpkkt_debug_solve_top_stamps(hqpkkt_t *h, double *out, int cap) {
   for (int t = 0; t < h->top_n; t++) t0 = std::min(t0, hs[8 * (size_t)t]);
   for (int t = 0; t < h->top_n; t++) {
     out[8 * t] = h->an.level[nodes[t]];
+    // split form: the backward launch has its own start (slot 6) and static-data (slot 7) stamps; they are returned in
+    // place of nothing - out[7] = start of the backward launch of this front
     for (int k = 0; k < 6; k++) out[8 * t + 1 + k] = (double)(hs[8 * (size_t)t + k] - t0) * 0.01;  // 100 MHz
-    out[8 * t + 7] = 0.0;
+    out[8 * t + 7] = hs[8 * (size_t)t + 6] ? (double)(hs[8 * (size_t)t + 6] - t0) * 0.01 : 0.0;
   }
   return 0;
 }

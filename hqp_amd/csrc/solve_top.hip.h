@@ -72,7 +72,7 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
   const double *W = linv + linv_off[node];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   constexpr int VEC = 64 * NS;  // length of the vectors in LDS (pivots, border rows) and stride of the partial sums
-  ST_STAMP(0);
+  ST_STAMP(MODE == 2 ? 6 : 0);  // (slots 6, 7: start and static data of the backward launch of the split form)
   const int par = *A.epoch & 1;
   const size_t mlen = ((size_t)p * (p + 1) / 2 + 1) & ~(size_t)1;
   double *Ms = lds;  // column t of M from its diagonal down: Ms[t p - t (t - 1) / 2 + (i - t)]
@@ -122,7 +122,7 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
     if (MODE != 1 && tid < ST_XS) st_post(ox + me * ST_XS + tid, __longlong_as_double((long long)ST_SENTINEL));
   }
 
-  ST_STAMP(1);  // static data requested / in LDS
+  ST_STAMP(MODE == 2 ? 7 : 1);  // static data requested / in LDS
   int nfc = 0;  // children inside the fused levels
   if constexpr (MODE != 2) {
   // ---- forward: t = rhs + children, y = M P t, yd = D^-1 y, contribution = c - L21 y

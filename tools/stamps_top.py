@@ -28,8 +28,10 @@ for rep in range(3):
     rc = _lib.lib().hqpkkt_debug_solve_top_stamps(M._h, out.ctypes.data, len(out))
     assert rc == 0, rc
 o = out.reshape(-1, 8)
-print("level fronts |   start  static-in  children   fwd-done  border-in  bwd-done   (mean us; max in brackets for fwd/bwd done)")
+print("level fronts |   start  static-in  children   fwd-done | bwd-start border-in  bwd-done   (mean us after the first start; max in brackets for fwd / bwd done;")
+print("             |  split form: the backward sweep is a launch of its own and loads its static data again)")
 for lv in sorted(set(o[:, 0].astype(int))):
     m = o[:, 0].astype(int) == lv
-    mean = o[m, 1:7].mean(0)
-    print(f"{lv:5d} {m.sum():6d} | " + " ".join(f"{x:9.2f}" for x in mean) + f"   [{o[m, 4].max():.2f} {o[m, 6].max():.2f}]")
+    mean = o[m, 1:8].mean(0)
+    print(f"{lv:5d} {m.sum():6d} | " + " ".join(f"{x:9.2f}" for x in mean[:4]) + " | " + " ".join(f"{x:9.2f}" for x in (mean[6], mean[4], mean[5])) +
+          f"   [{o[m, 4].max():.2f} {o[m, 6].max():.2f}]")
