@@ -953,8 +953,19 @@ def bench_c2(args, extras=True):
         per_step = {k: v[0] / nprof for k, v in prof.items()}
         launches = {k: v[1] / nprof for k, v in prof.items()}
         solves_per_step = 1 + st["refine_rounds"]
-        for k in ("solve_fwd", "solve_bwd"):  # the sweeps run once per solve of the step
-            work[k] = {q: v * solves_per_step for q, v in work[k].items()}
+        # the fronts whose sweeps run inside k_solve_top (hqp_amd/csrc/solve_top.hip.h: all levels of this tree, in two
+        # launches) count under that class, the others under the per-level kernels
+        top = mat.debug(31)
+        if top[0] > 0 and not one:
+            lev = np.asarray(struct["level"])
+            p_, b_ = struct["npiv"].astype(np.float64), struct["nborder"].astype(np.float64)
+            fused = lev >= top[1]
+            sweep = lambda m: {"flops": float((p_[m] ** 2 + 2 * b_[m] * p_[m]).sum()), "bytes": float((8 * (p_[m] ** 2 / 2 + b_[m] * p_[m])).sum())}
+            work["solve_fwd"], work["solve_bwd"] = sweep(~fused), sweep(~fused)
+            work["solve_top"] = {q: 2 * v for q, v in sweep(fused).items()}
+        for k in ("solve_fwd", "solve_bwd", "solve_top"):  # the sweeps run once per solve of the step
+            if k in work:
+                work[k] = {q: v * solves_per_step for q, v in work[k].items()}
         # every kernel class against both ceilings (algorithmic flops / bytes per step)
         kernels = {k: {"ms_per_step": per_step.get(k, 0.0), "launches_per_step": launches.get(k, 0.0),
                        "tflops": w["flops"] / (per_step[k] * 1e-3) / 1e12 if per_step.get(k) else None,
@@ -967,13 +978,8 @@ def bench_c2(args, extras=True):
         dom_launch_ms = dom_ms / max(launches[dom], 1.0)
         flops_per_launch = work[dom]["flops"] / max(launches[dom], 1.0)
         achieved = flops_per_launch / (dom_launch_ms * 1e-3) / 1e12
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-        if os.path.exists(pmc) and prog.n == 40000 and args.band == 80 and args.mode == "SpBKP":
-            # HBM bytes per launch of the dominant kernel from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of
-            # this same command (separate runs, gfx950 corrections applied; see profiles/README.md)
-            traffic = json.load(open(pmc)).get("k_" + dom, {}).get("hbm_bytes_per_launch")
-        roofline = {"kernel": "k_" + dom, "bound": "latency" if dom == "factor_diag" else "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
+        traffic = None  # (no counter passes of the tree engine's kernels since round 1: profiles/pmc_traffic.json is k_factor_diag's)
+        roofline = {"kernel": "k_factor_blk" if dom == "factor_diag" else "k_" + dom, "bound": "latency" if dom == "factor_diag" else "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                     "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS, "traffic": traffic,
                     "launches_per_step": launches[dom], "avg_launch_ms": dom_launch_ms,
                     "algorithmic_flops_per_step": work[dom]["flops"]}

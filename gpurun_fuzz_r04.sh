@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round-4 randomised campaign of the tree engine on the final code of the round (k_factor_blk, k_solve_top, whole-tree launches of small fronts) (outputs under gpurun_out/fuzz4/).
 cd $GRAFT_REPO_ROOT; O=gpurun_out/fuzz4; mkdir -p $O; F=$O/r04_fuzz_tree.txt; : > $F
-echo "## tools/fuzz.py 12000 (tree engine, k_factor_blk, fronts of up to 192 pivots, against the CPU oracle)" >> $F
+echo "## tools/fuzz.py 12000 (tree engine, k_factor_blk, supernodes of up to 160 pivots by default, the cases with their own max_pivots up to 192; against the CPU oracle)" >> $F
 timeout 1500 python tools/fuzz.py 12000 2>/dev/null | grep -v amdgpu.ids | tail -8 >> $F
 echo "## FUZZ_SCALE=30 tools/fuzz.py 60 (banded systems up to n = 45 000, band 120: fronts of 100 .. 192 pivots)" >> $F
 FUZZ_SCALE=30 timeout 1500 python tools/fuzz.py 60 2>/dev/null | grep -v amdgpu.ids | tail -8 >> $F

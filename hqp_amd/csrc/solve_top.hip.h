@@ -1,28 +1,32 @@
-// ---- the top of the assembly tree in ONE launch: forward sweep up to the root and backward sweep down again
+// ---- the solve sweeps of the general fronts across tree levels: one launch per sweep (or one for both)
 //
-// Above the level where a tree level is a handful of fronts, a level of the solve is a latency chain (gather the
-// children's contributions, y = M P t, c - L21 y; then v = yd - L21' x, x = P' M' v) and its cost is the launch, the
-// first-touch memory latency of M and L21 and the dependent index loads: 22 + 19 us per level on the C2 tree against
-// 1 - 2 us of arithmetic.  k_solve_top gives every front of the top levels (at most ST_MAXFRONTS, all resident at
-// once) ONE workgroup of 16 wavefronts for the whole solve:
+// Where a tree level is a handful of fronts, a level of the solve is a latency chain (gather the children's
+// contributions, y = M P t, c - L21 y; then v = yd - L21' x, x = P' M' v) and its cost is the launch, the first-touch
+// memory latency of M and L21 and the dependent index loads: 22 + 19 us per level on the C2 tree against 1 - 2 us of
+// arithmetic.  k_solve_top gives every front ONE workgroup of 16 wavefronts:
 //   - before anything else it loads what depends on the front alone: the lower triangle of M = L11^-1 into LDS
 //     (packed by columns), L21 into registers (lane = border row within a 64-row slab, wavefront w holds the columns
 //     k = w (mod 16): NS slabs x NU columns per lane), permutation, pivot data, index lists;
 //   - forward step when its children's contributions have arrived, backward step when the solution at its border
-//     rows has; M and L21 stay on chip between the two: the top of the tree reads them once per solve.
-// Data between fronts travels WITHOUT flags and without cache maintenance: the words themselves are the signal.  A
-// front writes its contribution vector (forward) and its part of the solution (backward) with agent-scope atomic
-// stores into small exchange arrays whose words hold a sentinel (a NaN payload no arithmetic produces) until then; the
-// consumer's lanes poll exactly the words they need with agent-scope loads.  One memory round trip per level, where a
-// flag protocol pays release (L2 write-back), flag, acquire (invalidate), data.  The arrays exist twice: launch e
-// uses copy e & 1 and every front puts the sentinel back into ITS words of the other copy, which nobody reads during
-// this launch; e lives in device memory (the launch is replayed from a graph) and is advanced by the last workgroup
-// once all workgroups of the launch have read it.
+//     rows has.
+// Data between fronts travels WITHOUT flags and without cache maintenance: the words themselves are the signal
+// (kernels.hip.h, "data words as signals").  A front writes its contribution vector (forward) and its part of the
+// solution (backward) with agent-scope atomic stores into small exchange arrays whose words hold a sentinel until then;
+// the consumer's lanes poll exactly the words they need.  One memory round trip per level, where a flag protocol pays
+// release (L2 write-back), flag, acquire (invalidate), data (measured: 13 us per level and direction).  The arrays exist
+// twice: solve e uses copy e & 1 and every front puts the sentinel back into ITS words of the other copy, which nobody
+// reads during this solve; e is the device counter k_rhs_* bumps at the start of every solve (the launches are replayed
+// from a graph).
+// MODE 1 / 2 - the form in use: the forward sweep (`nodes` leaves first) and the backward sweep (root first) as launches
+// of their own, for any number of fronts: a waiting front only waits for fronts before it in the launch, which relies on
+// workgroups being dispatched in index order when the chip does not hold them all.  MODE 0: both sweeps in one launch,
+// M and L21 read once; all fronts (at most ST_MAXFRONTS) must be resident at once, so it is an option
+// (HQPKKT_SOLVE_TOP_FUSED), not the default: several systems in flight on one GPU could starve each other.
 // A poll gives up after ~2^20 tries (about a second) and raises flags[ST_GAVE_UP]: hqpkkt_solve then rebuilds the
 // exchange arrays and reports HQPKKT_E_DEVICE instead of hanging the device.
 // Arithmetic: plain FMA sums in a fixed order (thread-local over k, then the 16 / 4 partial sums in index order; the
-// backward column sums by the wavefront reduction) - reproducible from run to run, not bit-identical to the
-// per-level kernels (different order of summation).
+// backward column sums by the wavefront reduction) - reproducible from run to run and the same in all three modes, not
+// bit-identical to the per-level kernels (different order of summation).
 #pragma once
 
 namespace kktdev {

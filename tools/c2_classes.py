@@ -1,6 +1,8 @@
+"""C2 system: tree levels (fronts, pivots, border rows), what the solve fuses (introspection 31) and the device time per
+kernel class of a factor + solve (events around every launch), for the default and for 160 pivots per supernode."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from hqp_amd import ipmatrix, problems
 prog = problems.banded_qp(40000, 80, seed=12345)

@@ -1,5 +1,7 @@
+"""Device-resident Mehrotra loop on the double-integrator QP (C3 structure): IP iterations per second, with and without
+amalgamation; the tree options in use (introspection 31).  python tools/did_rate.py [K]"""
 import os, sys, json
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 from hqp_amd import ipmatrix, problems
 K = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
