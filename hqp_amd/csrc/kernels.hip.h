@@ -80,6 +80,28 @@ __device__ __forceinline__ double wave_max_dpp(double v) {
   return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
 
+// sum over the 64 lanes the same way (lanes a DPP step does not reach contribute zero); broadcast to every lane
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_move0(double v) {
+  const long long b = __double_as_longlong(v);
+  int lo = (int)(b & 0xffffffffLL), hi = (int)(b >> 32);
+  lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xf, false);
+  hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xf, false);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+__device__ __forceinline__ double wave_sum_dpp(double v) {
+  v += dpp_move0<0xb1, 0xf>(v);   // quad_perm [1,0,3,2]
+  v += dpp_move0<0x4e, 0xf>(v);   // quad_perm [2,3,0,1]
+  v += dpp_move0<0x124, 0xf>(v);  // row_ror 4
+  v += dpp_move0<0x128, 0xf>(v);  // row_ror 8: every lane of a row has the row's sum
+  v += dpp_move0<0x142, 0xa>(v);  // row_bcast 15: rows 1 and 3 add the sum of the row before
+  v += dpp_move0<0x143, 0xc>(v);  // row_bcast 31: rows 2 and 3 add lane 31 -> lane 63 holds the total
+  const long long b = __double_as_longlong(v);
+  const int lo = __builtin_amdgcn_readlane((int)(b & 0xffffffffLL), 63);
+  const int hi = __builtin_amdgcn_readlane((int)(b >> 32), 63);
+  return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
+
 // same for a float (the arg-max search of the pivot column runs in fp32: an fp64
 // max costs ~40 cycles of latency per step on gfx950, an fp32 one a few)
 template <int CTRL, int ROW_MASK>

@@ -160,20 +160,27 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
   if (tid < p) tp[tid] = t1[lpk];
   __syncthreads();
   {
-    const int i = tid & 255, c = tid >> 8;
-    double a0 = 0.0, a1 = 0.0;
-    if (i < p) {
-      int t = c;
-      for (; t + 4 <= i; t += 8) {
-        a0 = fma(Ms[t * p - (t * (t - 1)) / 2 - t + i], tp[t], a0);
-        a1 = fma(Ms[(t + 4) * p - ((t + 4) * (t + 3)) / 2 - (t + 4) + i], tp[t + 4], a1);
+    // y = M tp (M lower): row r and row p - 1 - r in one thread (the triangle's work balances), eight column classes
+    // t = c (mod 8); the packed index of (i, t) steps by 8 p - 8 t - 36 from t to t + 8
+    const int r = tid & 127, c = tid >> 7;
+    const int iA = r, iB = p - 1 - r;
+    double aA = 0.0, aB = 0.0;
+    if (2 * r < p) {
+      int idx = c * p - (c * (c - 1)) / 2 - c, step = 8 * p - 8 * c - 36;
+      for (int t = c; t <= iB; t += 8) {
+        const double x = tp[t];
+        if (t <= iA) aA = fma(Ms[idx + iA], x, aA);
+        aB = fma(Ms[idx + iB], x, aB);
+        idx += step, step -= 64;
       }
-      if (t <= i) a0 = fma(Ms[t * p - (t * (t - 1)) / 2 - t + i], tp[t], a0);
+      part[256 * c + iA] = aA;
+      if (iB != iA) part[256 * c + iB] = aB;
     }
-    part[256 * c + i] = a0 + a1;
   }
   __syncthreads();
-  if (tid < p) y[tid] = (part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid]);
+  if (tid < p)
+    y[tid] = ((part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid])) +
+             ((part[1024 + tid] + part[1280 + tid]) + (part[1536 + tid] + part[1792 + tid]));
   __syncthreads();
   if (tid < p) {
     const int kp = pty == 2 ? tid - 1 : min(tid + 1, p - 1);  // partner of a 2x2 pivot
@@ -221,29 +228,29 @@ k_solve_top(DevTree T, TopArgs A, const double *__restrict__ panel, const double
       double a = 0.0;
 #pragma unroll
       for (int s = 0; s < NS; s++) a = fma(l[s][u], xs[s], a);
-      a = wave_sum(a);
+      a = wave_sum_dpp(a);  // (every lane has the sum)
       const int k = wave + 16 * u;
       if (lane == 0 && k < p) vv[k] = xd[k] - a;
     }
   }
   __syncthreads();
   {
-    const int t = tid & 255, c = tid >> 8;
-    double a0 = 0.0, a1 = 0.0;
-    if (t < p) {
-      const double *col = Ms + (t * p - (t * (t - 1)) / 2 - t);
-      int i = t + c;
-      for (; i + 4 < p; i += 8) {
-        a0 = fma(col[i], vv[i], a0);
-        a1 = fma(col[i + 4], vv[i + 4], a1);
-      }
-      if (i < p) a0 = fma(col[i], vv[i], a0);
+    // z = M' v: columns r and p - 1 - r in one thread, eight row classes i = t + c (mod 8)
+    const int r = tid & 127, c = tid >> 7;
+    const int tA = r, tB = p - 1 - r;
+    double aA = 0.0, aB = 0.0;
+    if (2 * r < p) {
+      const double *colA = Ms + (tA * p - (tA * (tA - 1)) / 2 - tA), *colB = Ms + (tB * p - (tB * (tB - 1)) / 2 - tB);
+      for (int i = tA + c; i < p; i += 8) aA = fma(colA[i], vv[i], aA);
+      for (int i = tB + c; i < p; i += 8) aB = fma(colB[i], vv[i], aB);
+      part[256 * c + tA] = aA;
+      if (tB != tA) part[256 * c + tB] = aB;
     }
-    part[256 * c + t] = a0 + a1;
   }
   __syncthreads();
   if (tid < p) {
-    const double z = (part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid]);
+    const double z = ((part[tid] + part[256 + tid]) + (part[512 + tid] + part[768 + tid])) +
+                     ((part[1024 + tid] + part[1280 + tid]) + (part[1536 + tid] + part[1792 + tid]));
     if (nfc > 0) st_post(xx + me * ST_XS + lpk, z);
     xsol[e0 + lpk] = z;  // (for the levels below, after this launch)
   }
