@@ -311,26 +311,30 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       R[s][q] = hi < p ? v : (hi == lo ? 1.0 : 0.0);
     }
   }
-  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
-    const int ch = T.child_idx[cc], bc = T.nbor[ch];
-    const int *iv = T.pinv + T.pinv_off[ch];
-    const double *Uc = upd + T.upd_off[ch];
+  // two children at a time: their index maps travel together, then their values (one round trip each instead of two)
+  for (int cc0 = T.child_ptr[node], cc1 = T.child_ptr[node + 1], cc = cc0; cc < cc1; cc += 2) {
+    const bool two = cc + 1 < cc1;
+    const int chA = T.child_idx[cc], chB = T.child_idx[two ? cc + 1 : cc];
+    const int bcA = T.nbor[chA], bcB = T.nbor[chB];
+    const int *ivA = T.pinv + T.pinv_off[chA], *ivB = T.pinv + T.pinv_off[chB];
+    const double *UA = upd + T.upd_off[chA], *UB = upd + T.upd_off[chB];
 #pragma unroll
     for (int s = 0; s < NS; s++) {
       if (!SLOT_IN(m_all, s)) continue;
       const int i = 16 * SLOT_I(s) + ln, c0 = 16 * SLOT_J(s) + lg;
-      const int ci = i < p ? iv[i] : -1;
-      int cj[4];
+      const int ciA = i < p ? ivA[i] : -1, ciB = (i < p && two) ? ivB[i] : -1;
+      int cjA[4], cjB[4];
 #pragma unroll
       for (int q = 0; q < 4; q++) {
         const int c = c0 + 4 * q;
-        cj[q] = c < p ? iv[c] : -1;
+        cjA[q] = c < p ? ivA[c] : -1, cjB[q] = (c < p && two) ? ivB[c] : -1;
       }
 #pragma unroll
       for (int q = 0; q < 4; q++) {
-        const bool ok = ci >= 0 && cj[q] >= 0;
-        const double v = Uc[ok ? min(ci, cj[q]) * bc + max(ci, cj[q]) : 0];
-        R[s][q] += ok ? v : 0.0;
+        const bool okA = ciA >= 0 && cjA[q] >= 0, okB = ciB >= 0 && cjB[q] >= 0;
+        const double vA = UA[okA ? min(ciA, cjA[q]) * bcA + max(ciA, cjA[q]) : 0];
+        const double vB = UB[okB ? min(ciB, cjB[q]) * bcB + max(ciB, cjB[q]) : 0];
+        R[s][q] = (R[s][q] + (okA ? vA : 0.0)) + (okB ? vB : 0.0);
       }
     }
   }

@@ -1786,7 +1786,7 @@ k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
 // MFMA operand layout (verified by hqpkkt_selftest_mfma): A: lane l holds
 // A[l&15][l>>4]; B: B[l>>4][l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
 
-__global__ void __launch_bounds__(256, 4)
+__global__ void __launch_bounds__(256, 3)
 k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ panel,
               double *__restrict__ xar, const double *__restrict__ dinv,
               const int *__restrict__ ptype, const int *__restrict__ lperm,
@@ -1809,6 +1809,9 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
   // permutation, so that the epilogue has no dependent global loads
   double *pd = s + 32 * p;        // 2 p
   int *pty = (int *)(pd + 2 * p);  // p
+  // the children list and the first two children (a dependent chain of scalar loads: requested before everything else)
+  const int cc0 = T.child_ptr[node], cc1 = T.child_ptr[node + 1];
+  const int chA = T.child_idx[cc0 < cc1 ? cc0 : 0], chB = T.child_idx[cc0 + 1 < cc1 ? cc0 + 1 : 0];
   if (tid < p) {  // (256 threads: fronts of up to 256 pivots)
     pty[tid] = ptype[e0 + tid];
     pd[2 * tid] = dinv[2 * (e0 + tid)];
@@ -1827,20 +1830,29 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
       const int kcol = c0 + g + 8 * u;
       v[u] = (live && kcol < p) ? P[(long long)lc[u] * F + p + r0 + r] : 0.0;
     }
-    // + the children's update blocks at (border row, pivot column)
-    for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
-      const int c = T.child_idx[cc], bc = T.nbor[c];
-      const int *iv = T.pinv + T.pinv_off[c];
-      const double *Uc = upd + T.upd_off[c];
-      const int ci = live ? iv[p + r0 + r] : -1;
-      int cj[16];
+    // + the children's update blocks at (border row, pivot column): two children at a time - their index maps
+    // travel together, then their values (a front of a dissection tree has two: one round trip each instead of two)
+    for (int cc = cc0; cc < cc1; cc += 2) {
+      const bool two = cc + 1 < cc1;
+      const int cA = cc == cc0 ? chA : T.child_idx[cc], cB = two ? (cc == cc0 ? chB : T.child_idx[cc + 1]) : cA;
+      const int bcA = T.nbor[cA], bcB = T.nbor[cB];
+      const int *ivA = T.pinv + T.pinv_off[cA], *ivB = T.pinv + T.pinv_off[cB];
+      const double *UA = upd + T.upd_off[cA], *UB = upd + T.upd_off[cB];
+      const int ciA = live ? ivA[p + r0 + r] : -1, ciB = (live && two) ? ivB[p + r0 + r] : -1;
+      int cjA[16], cjB[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) cj[u] = (c0 + g + 8 * u < p) ? iv[lc[u]] : -1;
-      double gv[16];
+      for (int u = 0; u < 16; u++) {
+        const bool on = c0 + g + 8 * u < p;
+        cjA[u] = on ? ivA[lc[u]] : -1, cjB[u] = (on && two) ? ivB[lc[u]] : -1;
+      }
+      double gA[16], gB[16];
 #pragma unroll
-      for (int u = 0; u < 16; u++) gv[u] = (ci >= 0 && cj[u] >= 0) ? Uc[(long long)cj[u] * bc + ci] : 0.0;
+      for (int u = 0; u < 16; u++) {
+        gA[u] = (ciA >= 0 && cjA[u] >= 0) ? UA[(long long)cjA[u] * bcA + ciA] : 0.0;
+        gB[u] = (ciB >= 0 && cjB[u] >= 0) ? UB[(long long)cjB[u] * bcB + ciB] : 0.0;
+      }
 #pragma unroll
-      for (int u = 0; u < 16; u++) v[u] += gv[u];
+      for (int u = 0; u < 16; u++) v[u] = (v[u] + gA[u]) + gB[u];  // (children in slot order, as one by one)
     }
 #pragma unroll
     for (int u = 0; u < 16; u++) {
@@ -1866,6 +1878,7 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
     const bool con = c0 + ml < p;
     // the tile's M operands in batches of 16 k-steps (64 pivots): all loads of a
     // batch are in flight together, then the products with the slab in LDS
+    // (batches of 32 were measured slower: 0.50 against 0.47 ms over the C2 levels)
 #pragma unroll 1
     for (int half = 0; half < 4; half++) {
       if (64 * half >= tend) break;  // wave-uniform
