@@ -473,7 +473,9 @@ struct GemmTile {
 // wavefronts per SIMD the launch is compiled for: two workgroups per CU (one with three LDS buffers)
 // (A 256 x 128 tile on 4 x 4 wavefronts, one workgroup per CU, was written and measured in round 4 - commit 44e8e46,
 // profiles/r04_tile256_ab.txt: 88.4 % of the peak at 8192^3 against 89.7 % of the 2 x 4 form, 64 % against 79.5 % on
-// the 800 tiles of a C4 stage's W - and taken out again.)
+// the 800 tiles of a C4 stage's W - and taken out again; in the split form (whole rounds + cut remainder) it reaches
+// 80.7 % on W against 81.0 % of the form in use: the shape's ceiling - 313 slabs per tile, ragged last tile row and
+// column - not the pairing of workgroups, is what holds W at 81 %.)
 constexpr int gemm_waves_per_simd(int nw, int nbuf) { return nbuf == 3 ? nw / 4 : nw / 2; }
 template <int BM, int BN, bool DMA = false, int WGM = 2, int WGN = 2, int NBUF = 2>
 __global__ void __launch_bounds__(64 * WGM * WGN, gemm_waves_per_simd(WGM * WGN, NBUF)) k_dgemm_tn(GemmArgs g) {
