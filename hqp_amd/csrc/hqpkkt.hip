@@ -558,6 +558,7 @@ static int upload(hqpkkt_t *h) {
     if (lds_blk > a_blk) {
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 6, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(176))));
       a_blk = lds_blk;
     }
     if (h->lds_diag > a_diag) {
@@ -738,6 +739,10 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
         const int lmp = h->level_maxp[which][l];
         if (lmp <= 128)
           KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<8, 6, 144, 2, FB_OWNSIMD><<<nn - nfs - nsm, 512, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->flags.p + 1, h->upd.p)));
+        else if (lmp <= 176)  // (66 blocks of the triangle on 11 wavefronts: six per wavefront - 16 registers fewer than with eight, no scratch)
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<12, 6, 208, 3, FB_OWNSIMD><<<nn - nfs - nsm, 768, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
         else
@@ -2777,8 +2782,9 @@ int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long ca
 }
 
 // One dense symmetric p x p block through the pivot-block kernel on its own (tests, tools): A row-major;
-// variant 0 = k_factor_blk (8 wavefronts for p <= 128, 16 beyond), 1 = k_factor_diag (p <= 128),
-// 2 = k_factor_blk with 16 wavefronts whatever p.  Out: the block's panel (p x p column-major: unit lower L11
+// variant 0 = k_factor_blk as run_factor launches it (8 wavefronts for p <= 128, 12 beyond: six blocks per wavefront up to
+// 176 pivots, eight up to 192), 1 = k_factor_diag (p <= 128), 2 = the 12-wavefront instance with eight blocks whatever p,
+// 3 = the 12-wavefront instance with six blocks (p <= 176).  Out: the block's panel (p x p column-major: unit lower L11
 // below the diagonal), D^-1 (2 p), pivot types, pivot order, M = L11^-1 (p x p column-major), the counters
 // (2x2 pivots, perturbed, slow pivots, ...), and the average time of `reps` launches of one workgroup.
 int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, double pivot_eps, int variant,
@@ -2829,6 +2835,7 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
     HIPCHK(hipFuncSetAttribute((const void *)k_factor_diag, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::max<size_t>(lds_old, 64 * 1024)));
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(128)));
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 6, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -2841,6 +2848,9 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
     else if (variant == 0 && p <= 128)
       k_factor_blk<8, 6, 144, 2, FB_OWNSIMD><<<1, 512, fb_lds_bytes(p), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                         d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
+    else if ((variant == 0 || variant == 3) && p <= 176)  // (as run_factor chooses: six blocks per wavefront up to 176 pivots)
+      k_factor_blk<12, 6, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+                                                          d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
     else
       k_factor_blk<12, 8, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                           d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
