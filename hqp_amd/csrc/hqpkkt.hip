@@ -559,6 +559,7 @@ static int upload(hqpkkt_t *h) {
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 6, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(176))));
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 5, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(160))));
       a_blk = lds_blk;
     }
     if (h->lds_diag > a_diag) {
@@ -734,11 +735,15 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p));
       else if (nn > nfs + nsm) {
-        // the pivot blocks on the matrix pipe: 8 wavefronts (two workgroups per CU) for levels of <= 128 pivots,
-        // 16 wavefronts for up to 256
+        // the pivot blocks on the matrix pipe: 8 wavefronts (two workgroups per CU) for levels of <= 128 pivots, 12
+        // wavefronts beyond, each holding as many 16 x 16 blocks of the triangle as the level's largest front needs
         const int lmp = h->level_maxp[which][l];
         if (lmp <= 128)
           KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<8, 6, 144, 2, FB_OWNSIMD><<<nn - nfs - nsm, 512, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+                                                 h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
+                                                 h->flags.p + 1, h->upd.p)));
+        else if (lmp <= 160)  // (55 blocks on 11 wavefronts: five per wavefront)
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<12, 5, 208, 3, FB_OWNSIMD><<<nn - nfs - nsm, 768, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
         else if (lmp <= 176)  // (66 blocks of the triangle on 11 wavefronts: six per wavefront - 16 registers fewer than with eight, no scratch)
@@ -2782,8 +2787,8 @@ int hqpkkt_debug_read(hqpkkt_t *h, int what, int node, double *out, long long ca
 }
 
 // One dense symmetric p x p block through the pivot-block kernel on its own (tests, tools): A row-major;
-// variant 0 = k_factor_blk as run_factor launches it (8 wavefronts for p <= 128, 12 beyond: six blocks per wavefront up to
-// 176 pivots, eight up to 192), 1 = k_factor_diag (p <= 128), 2 = the 12-wavefront instance with eight blocks whatever p,
+// variant 0 = k_factor_blk as run_factor launches it (8 wavefronts for p <= 128, 12 beyond: five blocks per wavefront up to
+// 160 pivots, six up to 176, eight up to 192), 1 = k_factor_diag (p <= 128), 2 = the 12-wavefront instance with eight blocks whatever p,
 // 3 = the 12-wavefront instance with six blocks (p <= 176).  Out: the block's panel (p x p column-major: unit lower L11
 // below the diagonal), D^-1 (2 p), pivot types, pivot order, M = L11^-1 (p x p column-major), the counters
 // (2x2 pivots, perturbed, slow pivots, ...), and the average time of `reps` launches of one workgroup.
@@ -2836,6 +2841,7 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(128)));
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 6, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 5, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -2848,7 +2854,10 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
     else if (variant == 0 && p <= 128)
       k_factor_blk<8, 6, 144, 2, FB_OWNSIMD><<<1, 512, fb_lds_bytes(p), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                         d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
-    else if ((variant == 0 || variant == 3) && p <= 176)  // (as run_factor chooses: six blocks per wavefront up to 176 pivots)
+    else if (variant == 0 && p <= 160)  // (as run_factor chooses: five blocks per wavefront up to 160 pivots, six up to 176)
+      k_factor_blk<12, 5, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+                                                          d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
+    else if ((variant == 0 || variant == 3) && p <= 176)
       k_factor_blk<12, 6, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                           d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
     else

@@ -54,13 +54,15 @@ def test_sixteen_wavefront_variant_on_small_blocks():
 
 @pytest.mark.parametrize("kind", ["qd", "indef", "kkt0", "tiny"])
 def test_the_instances_of_twelve_wavefronts_agree(kind):
-    """Six blocks per wavefront (fronts of up to 176 pivots, what run_factor launches for them) against eight (up to
-    192): the same pivot sequence and the same factor to the last bit - the blocks are dealt to the wavefronts
+    """Five / six blocks per wavefront (fronts of up to 160 / 176 pivots, what run_factor launches for them) against eight
+    (up to 192): the same pivot sequence and the same factor to the last bit - the blocks are dealt to the wavefronts
     differently, the arithmetic of a block is the same."""
     for p in (129, 144, 160, 176):
         A = bc.make_block(kind, p, 7 * p)
-        a, b = bc.factor_block(A, variant=3), bc.factor_block(A, variant=2)
-        err, inv, ok, growth = bc.check_block(A, a)
-        assert ok and err < 1e-11 * growth ** 2 and inv < 1e-11 * growth ** 2, (kind, p, err, inv)
-        assert (a["lperm"] == b["lperm"]).all() and (a["ptype"] == b["ptype"]).all(), (kind, p)
-        assert np.array_equal(a["L"], b["L"]) and np.array_equal(a["W"], b["W"]), (kind, p)
+        b = bc.factor_block(A, variant=2)
+        for variant in (0, 3):  # (0: five blocks per wavefront up to 160 pivots, six beyond; 3: six)
+            a = bc.factor_block(A, variant=variant)
+            err, inv, ok, growth = bc.check_block(A, a)
+            assert ok and err < 1e-11 * growth ** 2 and inv < 1e-11 * growth ** 2, (kind, p, variant, err, inv)
+            assert (a["lperm"] == b["lperm"]).all() and (a["ptype"] == b["ptype"]).all(), (kind, p, variant)
+            assert np.array_equal(a["L"], b["L"]) and np.array_equal(a["W"], b["W"]), (kind, p, variant)
