@@ -1090,6 +1090,11 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       for (int l = 0; l < nlevels; l++) S.level_small[l] = fill[l] - S.level_ptr[l] - S.level_fsmall[l];
       for (int id = 0; id < nnodes; id++)
         if (keep(id) && !fsmall(id) && !smallblk(id)) S.level_nodes[fill[level[id]]++] = id;
+      // the general fronts of a level by falling number of pivots: a level with more fronts than the chip has CUs (one
+      // pivot-block workgroup per CU) then starts its largest fronts first and fills up with the small ones
+      for (int l = 0; l < nlevels; l++)
+        std::stable_sort(S.level_nodes.begin() + S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l], S.level_nodes.begin() + S.level_ptr[l + 1],
+                         [&](int a, int b) { return npiv[a] != npiv[b] ? npiv[a] > npiv[b] : nbor[a] > nbor[b]; });
       S.level_fs_p.assign(nlevels, 1), S.level_fs_b.assign(nlevels, 1), S.level_sm_p.assign(nlevels, 1);
       for (int id = 0; id < nnodes; id++) {
         if (!keep(id) || npiv[id] > SMALL_PIVOTS) continue;
