@@ -524,7 +524,9 @@ static int upload(hqpkkt_t *h) {
           if (o < 0) return HQPKKT_E_INTERN;  // (a border row of a fused front belongs to a fused ancestor)
           bpos[t * ST_CS + i] = o * ST_XS + (ei - an.piv_start[nodes[o]]);
         }
-      std::vector<int> up(nodes.rbegin(), nodes.rend());  // (level by level, leaves first)
+      std::vector<int> up;  // level by level, leaves first; inside a level the largest fronts first, as in `nodes`
+      for (int l = lt; l < an.nlevels; l++)
+        for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) up.push_back(S.level_nodes[q]);
       // One launch for both sweeps needs ALL its fronts resident at once (the forward sweep of a front waits for
       // fronts behind it in the launch): safe only while nothing else competes for the CUs.  Several systems in flight
       // on one GPU (bench.py's concurrent systems, scenario trees) could starve each other, so the form in use is the
