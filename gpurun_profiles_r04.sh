@@ -20,7 +20,7 @@ cp $(ls $O/kt/*/*kernel_stats.csv | tail -1) $O/r04_kernel_stats.csv
 timeout 300 python bench.py --workload c2 --steps 30 --warmup 5 2>/dev/null | grep '^{' | tail -1 > $O/r04_bench_c2.json
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d $O/kt2 -- python3 bench.py --workload c2 --steps 20 --warmup 3 --no-cpu-baseline --no-ip 2>/dev/null | grep '^{' | tail -1 > $O/r04_bench_c2_under_rocprof.json
 cp $(ls $O/kt2/*/*kernel_stats.csv | tail -1) $O/r04_kernel_stats_c2.csv
-timeout 300 bash tools/c2_trace.sh 0 > $O/r04_c2_timeline.txt 2>&1
+timeout 300 bash tools/c2_trace.sh 160 > $O/r04_c2_timeline.txt 2>&1
 timeout 300 python tools/stamps_top.py 2>&1 | grep -v amdgpu.ids > $O/r04_solve_top_stamps.txt
 timeout 300 python tools/tree_levels.py 2>&1 | grep -v amdgpu.ids > $O/r04_c2_tree_levels.txt
 timeout 300 python tools/block_time.py 2>&1 | grep -v amdgpu.ids > $O/r04_block_time.txt
