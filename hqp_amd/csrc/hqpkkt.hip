@@ -232,6 +232,24 @@ struct hqpkkt {
       ge = nullptr, g = nullptr;
     }
   } gfactor[2], gstep[2][3];  // [phase], [caller's / refinement's vectors][phase]
+  // The device-resident interior-point loops hand over the same device vectors in every iteration: their sequences are
+  // captured ON those vectors (no copies into and out of the handle's staging buffers), one graph per set of pointers.
+  struct DirectGraph {
+    const void *key[10];
+    GraphSlot g;
+  };
+  std::vector<DirectGraph> gdirect_step, gdirect_factor;
+  GraphSlot &direct_slot(std::vector<DirectGraph> &cache, const void *const (&key)[10]) {
+    for (auto &d : cache)
+      if (std::memcmp(d.key, key, sizeof(key)) == 0) return d.g;
+    if (cache.size() >= 6) {  // (Mehrotra's loop has two sets + the refinement's, Franke's one + the refinement's)
+      cache.front().g.drop();
+      cache.erase(cache.begin());
+    }
+    cache.emplace_back();
+    std::memcpy(cache.back().key, key, sizeof(key));
+    return cache.back().g;
+  }
   bool use_graphs = true, capturing = false;
   // inside hqpkkt_mehrotra: factor() returns without waiting for its status (read with the
   // residual of the solve that follows), solve() leaves its result in the stream
@@ -262,6 +280,9 @@ struct hqpkkt {
     for (auto &g : gfactor) g.drop();
     for (auto &gs : gstep)
       for (auto &g : gs) g.drop();
+    for (auto &d : gdirect_step) d.g.drop();
+    for (auto &d : gdirect_factor) d.g.drop();
+    gdirect_step.clear(), gdirect_factor.clear();
   }
 
   DevTree tree() const {
@@ -962,7 +983,13 @@ static int do_factor(hqpkkt_t *h, const Vecs &v) {
     if (staged_is_sharded(h)) return staged_run_factor(h, v.z, v.w);  // an exchange per stage: not captured
     return graphed(h, h->gfactor[0], [&]() { return staged_run_factor(h, v.z, v.w); });
   }
-  if (an.shard_count <= 1) return graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 3); });
+  if (an.shard_count <= 1) {
+    if (an.m > 0 && v.z != h->vin.p) {  // the caller's device vectors themselves (direct_vectors)
+      const void *key[10] = {v.z, v.w};
+      return graphed(h, h->direct_slot(h->gdirect_factor, key), [&]() { return run_factor(h, v.z, v.w, 3); });
+    }
+    return graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 3); });
+  }
   if ((e = graphed(h, h->gfactor[0], [&]() { return run_factor(h, v.z, v.w, 1); }))) return e;
   if (an.upd_x_slot > 0 &&
       (e = exchange(h, HQPKKT_XCHG_ALLGATHER, h->upd.p + an.upd_x_off, an.upd_x_slot, an.shard_count)))
@@ -981,7 +1008,15 @@ static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
   int e;
   if (h->opts.mode == HQPKKT_MODE_STAGED)
     return graphed(h, h->gstep[which][0], [&]() { return staged_run_step(h, v); });
-  if (an.shard_count <= 1) return graphed(h, h->gstep[which][0], [&]() { return run_step(h, v, 7); });
+  if (an.shard_count <= 1) {
+    // the caller's device vectors themselves (direct_vectors): also the refinement's sequence (which == 1: residual and
+    // correction vectors are the handle's, z and w the caller's)
+    if ((which == 0 && v.dx != h->vout.p) || (an.m > 0 && v.z != h->vin.p)) {
+      const void *key[10] = {v.z, v.w, v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw};
+      return graphed(h, h->direct_slot(h->gdirect_step, key), [&]() { return run_step(h, v, 7); });
+    }
+    return graphed(h, h->gstep[which][0], [&]() { return run_step(h, v, 7); });
+  }
   if ((e = graphed(h, h->gstep[which][0], [&]() { return run_step(h, v, 1); }))) return e;
   if (an.cb_x_slot > 0 &&
       (e = exchange(h, HQPKKT_XCHG_ALLGATHER, h->cb.p + an.cb_x_off, an.cb_x_slot, an.shard_count)))
@@ -1335,14 +1370,35 @@ static int switch_to_policy0(hqpkkt_t *h) {
   return e;
 }
 
+// inside the device-resident loops (lazy) of the tree engine on one GPU: no staging copies, the sequences are captured
+// on the caller's device vectors (hqpkkt_t::DirectGraph)
+static bool direct_vectors(const hqpkkt_t *h) {
+  return getenv("HQPKKT_NO_DIRECT_VECTORS") == nullptr && h->lazy && h->opts.loc == HQPKKT_LOC_DEVICE && h->opts.mode != HQPKKT_MODE_STAGED && h->an.shard_count <= 1 && h->use_graphs;
+}
+// the vectors a solve works on: the caller's (direct_vectors) or the staging buffers, filled
+static int solve_vecs(hqpkkt_t *h, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
+                      const double *r4, double *dx, double *dy, double *dz, double *dw, Vecs &v) {
+  if (direct_vectors(h)) {
+    v.z = z, v.w = w, v.r1 = r1, v.r2 = r2, v.r3 = r3, v.r4 = r4, v.dx = dx, v.dy = dy, v.dz = dz, v.dw = dw;
+    return 0;
+  }
+  int e = stage_in(h, z, w, r1, r2, r3, r4, v);
+  if (e) return e;
+  stage_out_ptrs(h, v);
+  return 0;
+}
+
 int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   if (!h) return HQPKKT_E_NULL;
   if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
   if (h->an.m > 0 && (!z || !w)) return HQPKKT_E_NULL;
   HIPCHK(hipSetDevice(h->opts.device));
   Vecs v{};
-  int e = stage_in(h, z, w, nullptr, nullptr, nullptr, nullptr, v);
-  if (e) return e;
+  int e = 0;
+  if (direct_vectors(h))
+    v.z = z, v.w = w;
+  else if ((e = stage_in(h, z, w, nullptr, nullptr, nullptr, nullptr, v)))
+    return e;
   h->factored = false;
   HIPCHK(hipEventRecord(h->ev0, h->stream));
   if ((e = do_factor(h, v))) return e;
@@ -1440,9 +1496,8 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   HIPCHK(hipSetDevice(h->opts.device));
   hipStream_t s = h->stream;
   Vecs v{};
-  int e = stage_in(h, z, w, r1, r2, r3, r4, v);
+  int e = solve_vecs(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, v);
   if (e) return e;
-  stage_out_ptrs(h, v);
   HIPCHK(hipEventRecord(h->ev0, s));
   if ((e = do_step(h, v, 0))) return e;
   double res = 0.0;
@@ -1450,7 +1505,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if ((e = run_residual(h, v, &res, h->lazy ? nullptr : &outp))) return e;
   if (h->residual_pending) {  // (hqpkkt_franke: solve_tail follows if the residual, once read, asks for it)
     if (res_out) *res_out = 0.0;
-    return stage_out(h, v, dx, dy, dz, dw);
+    return v.dx == dx ? 0 : stage_out(h, v, dx, dy, dz, dw);
   }
   return solve_tail(h, v, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res, res_out);
 }
@@ -1499,7 +1554,7 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
   }
   HIPCHK(hipEventRecord(h->ev1, s));
   if (h->lazy) {
-    if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
+    if (v.dx != dx && (e = stage_out(h, v, dx, dy, dz, dw))) return e;
   } else {
     if (refined) {
       if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
@@ -2135,8 +2190,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
           k_copy_vectors<<<copy_blocks(B), 256, 0, s>>>(B, 4);
           if (!e) {
             Vecs v{};
-            if ((e = stage_in(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, v))) return e;
-            stage_out_ptrs(h, v);
+            if ((e = solve_vecs(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, v))) return e;
             e = solve_tail(h, v, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, resid, &resid);
           }
           if (!e && (e = take_step())) return e;

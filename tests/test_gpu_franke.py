@@ -24,3 +24,27 @@ def test_franke_one_read_back_gives_the_same_iterates(case, monkeypatch):
     assert ia["result"] == 0
     for u, v in ((xa, xb), (ya, yb), (za, zb), (wa, wb)):
         assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("case", ["banded", "did400", "lq"])
+def test_loops_on_the_callers_vectors_give_the_same_iterates(case, monkeypatch):
+    """The device-resident loops capture the factorisation and the solve ON their own device vectors (no copies into
+    and out of the handle's staging buffers, one graph per set of pointers) - against the staged form
+    (HQPKKT_NO_DIRECT_VECTORS): the same kernels on the same values, so the same iterates, Mehrotra and Franke."""
+    prog = {"banded": lambda: problems.banded_qp(300, 8, 5), "did400": lambda: problems.did_like_qp(400),
+            "lq": lambda: problems.lq_docp(40, 6, 2, final_eq=2)}[case]()
+    A = ipmatrix.IpRedSpBKP()
+    A.init(prog)
+    ma, fa = A.mehrotra(prog), A.franke(prog, max_iters=300)
+    ma2 = A.mehrotra(prog)  # (again on the same handle: the graphs of the first run are replayed)
+    monkeypatch.setenv("HQPKKT_NO_DIRECT_VECTORS", "1")
+    B = ipmatrix.IpRedSpBKP()
+    B.init(prog)
+    mb, fb = B.mehrotra(prog), B.franke(prog, max_iters=300)
+    mb2 = B.mehrotra(prog)
+    # (the same sequence of calls on both handles: a handle's first solve may re-place zero diagonals once the values
+    # are known - zd_policy -1 - so its first run and its later ones follow slightly different pivot orders)
+    for a, b in ((ma, mb), (fa, fb), (ma2, mb2)):
+        assert (a[-1]["result"], a[-1]["iters"]) == (b[-1]["result"], b[-1]["iters"]) and a[-1]["result"] == 0
+        for u, v in zip(a[:4], b[:4]):
+            assert np.array_equal(u, v)
