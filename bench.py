@@ -667,7 +667,14 @@ def bench_c4(args):
         flops_big = float(st["flops_local"])
     q = nu
     flops_upd = K * (2.0 * q * q * nx + 1.0 * q * nx * nx)                 # Rm = K^-1 Y ; V = Gxx - Y'Rm (lower half)
-    bytes_gemv = K * 8.0 * (2.0 * np1 * np1 + 2.0 * np1 * nz + 2.0 * q * nx) * (1 + st["refine_rounds"])
+    # bytes of the solve's matrix-vector products per stage: V+ twice, F twice, Y and Rm once.  V is symmetric and from
+    # 2048 states on only its tiles (64 x 512) on and below the diagonal are read (k_st_symv_tiles): those are the
+    # algorithmic bytes then; the rate over the whole matrix is kept beside it for comparison with earlier rounds
+    v_full = 1.0 * np1 * np1
+    sym = np1 >= 2048 and not os.environ.get("HQPKKT_NO_SYMV")
+    v_read = float(sum((bi // 8 + 1) * 64 * 512 for bi in range((np1 + 63) // 64))) if sym else v_full
+    bytes_gemv = K * 8.0 * (2.0 * v_read + 2.0 * np1 * nz + 2.0 * q * nx) * (1 + st["refine_rounds"])
+    bytes_gemv_full = K * 8.0 * (2.0 * v_full + 2.0 * np1 * nz + 2.0 * q * nx) * (1 + st["refine_rounds"])
     gemm_ms, gemm_launch = per_step.get("staged_gemm", 0.0), launches.get("staged_gemm", 1.0)
     achieved = flops_big / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
     traffic, traffic_note = None, None
@@ -698,7 +705,9 @@ def bench_c4(args):
                             "tflops": flops_upd / (per_step["staged_gemm_upd"] * 1e-3) / 1e12 if per_step.get("staged_gemm_upd") else None},
         "staged_gemv": {"ms_per_step": per_step.get("staged_gemv"), "launches_per_step": launches.get("staged_gemv"),
                         "gbs": bytes_gemv / (per_step["staged_gemv"] * 1e-3) / 1e9 if per_step.get("staged_gemv") else None,
-                        "frac_hbm_peak": bytes_gemv / (per_step["staged_gemv"] * 1e-3) / 1e9 / HBM_PEAK_GBS if per_step.get("staged_gemv") else None},
+                        "frac_hbm_peak": bytes_gemv / (per_step["staged_gemv"] * 1e-3) / 1e9 / HBM_PEAK_GBS if per_step.get("staged_gemv") else None,
+                        "gbs_counting_all_of_v": bytes_gemv_full / (per_step["staged_gemv"] * 1e-3) / 1e9 if per_step.get("staged_gemv") else None,
+                        "v_read": "tiles on and below the diagonal" if sym else "whole matrix"},
         "staged_small": {"ms_per_step": per_step.get("staged_small"), "launches_per_step": launches.get("staged_small")},
         "residual": {"ms_per_step": per_step.get("residual"), "launches_per_step": launches.get("residual")},
     }

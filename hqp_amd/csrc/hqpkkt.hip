@@ -2785,6 +2785,15 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
       v = &tmp;
       break;
     }
+    case 32: {  // STAGED, free initial state of many components: [0] blocked inverse ran, [1] fell back to the LU factors
+      if (!h->sd) return HQPKKT_E_INTERN;
+      tmp.assign(2, 0);
+      if (hipDeviceSynchronize() != hipSuccess ||
+          hipMemcpy(tmp.data(), h->flags.p + stg::X0_BLOCKED, sizeof(int) * 2, hipMemcpyDeviceToHost) != hipSuccess)
+        return HQPKKT_E_DEVICE;
+      v = &tmp;
+      break;
+    }
     default: return HQPKKT_E_RANGE;
   }
   *len = (long long)v->size();

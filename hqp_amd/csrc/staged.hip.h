@@ -1819,6 +1819,7 @@ __global__ void k_st_check_fixed(const int *__restrict__ dyn0, int *__restrict__
   if (threadIdx.x == 0 && blockIdx.x == 0 && dyn0[1] > 0) atomicExch(status, 4);
 }
 
+constexpr int X0_BLOCKED = 40, X0_FELL_BACK = 41;  // counters in the status words: blocked inverse of K0 ran / gave up
 // free initial state: LU factors (complete pivoting) of the diagonally scaled [V_0 B_0'; B_0 0]; the reference
 // factorises the same scaled matrix by Bunch-Kaufman-Parlett (hqp/Hqp_IpLQDOCP.C:1972-1996) and solves by
 // substitution.  K0lu: the factors; K0s: 3 q doubles - the scaling, the row and the column exchanges.
@@ -1827,10 +1828,15 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_init_factor(int n0, int cap
                                                        const double *__restrict__ BT, long long ldb,
                                                        const int *__restrict__ dyn0, double *__restrict__ K0lu,
                                                        double *__restrict__ K0mat, double *__restrict__ K0s, long long ldq, int qmax,
-                                                       int *__restrict__ status, double *scratch) {
+                                                       int *__restrict__ status, double *scratch, const int *only_if) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
   __shared__ ArgMax red[16];
   const int tid = threadIdx.x, nt = blockDim.x;
+  // (only_if: the flag of the blocked inverse, k_x0_*; zero = its result stands, nothing to do here)
+  if (only_if) {
+    if (*only_if == 0) return;  // (uniform)
+    if (tid == 0) atomicAdd(status + X0_FELL_BACK, 1);
+  }
   const int c = dyn0[1], q = n0 + c, ld = q | 1;
   constexpr bool BIG = NT != 256;  // (the kind of memory fixed by the instantiation: see k_st_small)
   double *Km, *dsc;
@@ -1875,6 +1881,118 @@ __global__ void __launch_bounds__(NT, NT / 256) k_st_init_factor(int n0, int cap
     K0lu[(long long)i * ldq + j] = (i < q && j < q) ? Km[i * ld + j] : 0.0;
   }
   for (int i = tid; i < q; i += nt) K0s[i] = dsc[i], K0s[qmax + i] = (double)pr[i], K0s[2 * qmax + i] = (double)pc[i];
+  if (tid == 0) K0s[3 * qmax] = 0.0;  // the area K0lu holds LU factors
+}
+
+// The same matrix of a free initial state with hundreds of components, inverted by the blocked sweep on the whole chip
+// (k_blk_pivot / two products / k_blk_fixup per block of 64, as for a stage's K): k_x0_prepare writes the scaled matrix
+// (identity beyond the live order n0 + carried rows), k_x0_final the inverse, unscaled and symmetrised, into the area
+// of the factors, k_x0_check compares K0 K0^-1 with the identity and leaves the verdict in K0s[3 qmax] (1: the area
+// holds the inverse; 0: LU factors - written by k_st_init_factor behind it, which runs only where the sweep gave up or
+// failed the check).  1000 components: 99 ms -> a few ms.  hqp/Hqp_IpLQDOCP.C:1972-1996 factorises the same matrix.
+struct X0Args {
+  int n0, qmax;
+  const double *V;
+  long long ldv;
+  const double *BT;
+  long long ldb;
+  const int *dyn0;
+  double *K0inv, *K0mat, *K0s;
+  long long ldq;
+  double *scratch;
+  int *status;
+};
+__global__ void k_x0_prepare(X0Args a) {
+  const BigScratch bs = big_scratch(a.scratch, a.qmax);
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)a.qmax * a.qmax) return;
+  const int i = (int)(e / a.qmax), j = (int)(e - (long long)i * a.qmax), q = a.n0 + a.dyn0[1];
+  double v = 0.0, sc = 1.0;
+  if (i < q && j < q) {
+    if (i < a.n0 && j < a.n0)
+      v = a.V[(long long)i * a.ldv + j];
+    else if (i < a.n0 || j < a.n0)
+      v = a.BT[(long long)(i < a.n0 ? i : j) * a.ldb + (i < a.n0 ? j : i) - a.n0];
+    if (i < a.n0) {
+      const double kii = a.V[(long long)i * a.ldv + i];
+      if (kii > 1.0) sc = 1.0 / sqrt(kii);
+    }
+    if (j < a.n0) {
+      const double kjj = a.V[(long long)j * a.ldv + j];
+      if (kjj > 1.0) sc *= 1.0 / sqrt(kjj);
+    }
+  }
+  a.K0mat[(long long)i * a.ldq + j] = v;
+  bs.Ks[(long long)i * bs.ldk + j] = (i < q && j < q) ? v * sc : (i == j ? 1.0 : 0.0);
+  if (j == 0) {
+    double d = 0.0;
+    if (i < q) {
+      d = 1.0;
+      if (i < a.n0) {
+        const double kii = a.V[(long long)i * a.ldv + i];
+        if (kii > 1.0) d = 1.0 / sqrt(kii);
+      }
+    }
+    bs.dsc[i] = d;
+  }
+  if (e == 0) bs.flags[0] = 0, atomicAdd(a.status + X0_BLOCKED, 1);
+}
+__global__ void k_x0_final(X0Args a) {
+  const BigScratch bs = big_scratch(a.scratch, a.qmax);
+  if (bs.flags[0]) return;
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= (long long)a.qmax * a.qmax) return;
+  const int i = (int)(e / a.qmax), l = (int)(e - (long long)i * a.qmax), q = a.n0 + a.dyn0[1];
+  double v = 0.0;
+  if (i < q && l < q) v = -0.5 * (bs.Ks[(long long)i * bs.ldk + l] + bs.Ks[(long long)l * bs.ldk + i]) * bs.dsc[i] * bs.dsc[l];
+  a.K0inv[(long long)i * a.ldq + l] = v;
+}
+// E = K0 K0inv (in the area of the swept matrix) against the identity of the live order; the verdict
+__global__ void __launch_bounds__(1024) k_x0_check(X0Args a, double tol) {
+  __shared__ ArgMax red[16];
+  const BigScratch bs = big_scratch(a.scratch, a.qmax);
+  if (bs.flags[0] == 0) {
+    const int q = a.n0 + a.dyn0[1];
+    ArgMax am{0.0, 0};
+    for (long long e = threadIdx.x; e < (long long)a.qmax * a.qmax; e += blockDim.x) {
+      const int i = (int)(e / a.qmax), l = (int)(e - (long long)i * a.qmax);
+      const double d = fabs(bs.Ks[(long long)i * bs.ldk + l] - ((i == l && i < q) ? 1.0 : 0.0));
+      if (!(d <= am.v)) am.v = d == d ? d : __longlong_as_double(0x7ff0000000000000LL);
+    }
+    am = block_argmax(am, red);
+    if (threadIdx.x == 0 && !(am.v <= tol)) bs.flags[0] = 1;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) a.K0s[3 * a.qmax] = bs.flags[0] ? 0.0 : 1.0;
+}
+// the solve with the inverse: rhs (nb = -b, pb = b with b = [v_0 ; beta_0], zero beyond the live order), three products
+// by k_st_gemv_rows (y = K0inv nb; r = -(pb + K0 y); z = y + K0inv r: one round of refinement against K0), the result
+struct X0Vec {
+  int n0, cap0, qmax;
+  const int *dyn0;
+  const double *K0s;
+  const double *v0, *beta0;
+  double *nb, *pb;
+  const double *z;
+  double *x0, *eta0;
+};
+__global__ void k_x0_rhs(X0Vec a) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.qmax) return;
+  const int q = a.n0 + a.dyn0[1];
+  const double b = i < q ? (i < a.n0 ? a.v0[i] : a.beta0[i - a.n0]) : 0.0;
+  a.nb[i] = -b, a.pb[i] = b;
+}
+__global__ void k_x0_out(X0Vec a) {
+  if (a.K0s[3 * a.qmax] != 1.0) return;  // (the factors are in use: k_st_x0_free writes the result)
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= a.n0 + a.cap0) return;
+  const int q = a.n0 + a.dyn0[1];
+  const double s = i < q ? a.z[i] : 0.0;
+  if (i < a.n0)
+    a.x0[i] = s;
+  else
+    a.eta0[i - a.n0] = s;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -1926,6 +2044,136 @@ __global__ void __launch_bounds__(256) k_st_gemv_rows(GemvRows g) {
   }
   s = kktdev::wave_sum(s);
   if (lane == 0) g.y[row] = g.scale * ((g.add ? g.add[row] : 0.0) + s);
+}
+// The same product with a SYMMETRIC matrix stored in full (V of a stage: the lower tiles and their mirror images, exactly
+// symmetric), reading only the tiles on and below the diagonal: a tile of SV_R rows x SV_C columns gives the partial dot
+// products of its rows (rowpart[column tile][row]) and, from the same registers, the partial products of the mirrored
+// elements (colpart[row tile][column]: sum over the tile's rows i of V[i][j] x[i], elements strictly below the
+// diagonal).  k_st_symv_finish adds the partials of a row in a fixed order (reproducible from run to run), the carried
+// rows' term and `add`.  HBM traffic: half the matrix plus (N / SV_R + N / SV_C) N / 2 doubles of partials, twice.
+constexpr int SV_R = 64, SV_P = 4, SV_C = 128 * SV_P, SV_U = 4;  // rows, 16-byte loads per lane and row, columns of a tile; rows in flight
+struct SymvArgs {
+  const double *V;
+  long long ldv;
+  int N;
+  const double *x;
+  double *rowpart;  // [ceil(N / SV_C)][N]
+  double *colpart;  // [ceil(N / SV_R)][N]
+};
+// (measured on the 5000 x 5000 V of the headline, tools/symv_probe.hip: 22.8 us for the 113 MB of the triangle's tiles
+// against 37.1 us for the rows form over the whole matrix; tiles of 64 x 256, 32 x 512, 96 x 512, 128 x 512 and 2 / 8
+// rows in flight: 22.2 - 32 us; the row sums by DPP, 1 us less than by ds_bpermute)
+__global__ void __launch_bounds__(256) k_st_symv_tiles(SymvArgs g) {
+  __shared__ double red[4][SV_C];
+  // tile number -> (row tile bi, column tile bj) over the tiles on and below the diagonal: the RT = SV_C / SV_R row tiles
+  // RT g .. RT g + RT - 1 have g + 1 column tiles each, RT g (g + 1) / 2 tiles stand before them
+  constexpr int RT = SV_C / SV_R;
+  const int t = blockIdx.x;
+  int gq = (int)((sqrt(1.0 + 8.0 * t / RT) - 1.0) * 0.5);
+  while (RT * gq * (gq + 1) / 2 > t) gq--;
+  while (RT * (gq + 1) * (gq + 2) / 2 <= t) gq++;
+  const int rem = t - RT * gq * (gq + 1) / 2, bi = RT * gq + rem / (gq + 1), bj = rem % (gq + 1), r0 = bi * SV_R, c0 = bj * SV_C;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool diag = c0 + SV_C - 1 >= r0;  // the tile meets the diagonal: element masks
+  int jj[SV_P];                           // this lane's column pairs (jj, jj + 1)
+  double xa[SV_P], xb[SV_P], ca[SV_P], cb[SV_P];
+#pragma unroll
+  for (int p = 0; p < SV_P; p++) {
+    jj[p] = c0 + 2 * lane + 128 * p;
+    xa[p] = jj[p] < g.N ? g.x[jj[p]] : 0.0, xb[p] = jj[p] + 1 < g.N ? g.x[jj[p] + 1] : 0.0;
+    ca[p] = cb[p] = 0.0;
+  }
+  const int ra = r0 + wave * (SV_R / 4), rb = min(g.N, ra + SV_R / 4);
+  const double *row = g.V + (long long)ra * g.ldv;
+  double *rp = g.rowpart + (long long)bj * g.N;
+  for (int i = ra; i < rb; i += SV_U) {
+    double2_t v[SV_U][SV_P];
+    double xi[SV_U];
+#pragma unroll
+    for (int u = 0; u < SV_U; u++) {
+      const bool live = i + u < rb;
+#pragma unroll
+      for (int p = 0; p < SV_P; p++)
+        v[u][p] = (live && jj[p] < g.N) ? *(const double2_t *)(row + (long long)u * g.ldv + jj[p]) : double2_t{0.0, 0.0};
+      xi[u] = live ? g.x[i + u] : 0.0;
+    }
+    row += SV_U * g.ldv;
+#pragma unroll
+    for (int u = 0; u < SV_U; u++) {
+      const int ii = i + u;
+      double s = 0.0;
+#pragma unroll
+      for (int p = 0; p < SV_P; p++) {
+        double a = v[u][p].x, b = jj[p] + 1 < g.N ? v[u][p].y : 0.0;
+        if (diag) {  // row part: columns <= ii
+          if (jj[p] > ii) a = 0.0;
+          if (jj[p] + 1 > ii) b = 0.0;
+        }
+        s += a * xa[p] + b * xb[p];
+        if (diag) {  // mirrored part: columns < ii
+          if (jj[p] == ii) a = 0.0;
+          if (jj[p] + 1 == ii) b = 0.0;
+        }
+        ca[p] += a * xi[u], cb[p] += b * xi[u];
+      }
+      s = kktdev::wave_sum_dpp(s);
+      if (lane == 0 && ii < rb) rp[ii] = s;
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < SV_P; p++) red[wave][128 * p + 2 * lane] = ca[p], red[wave][128 * p + 2 * lane + 1] = cb[p];
+  __syncthreads();
+  for (int c = threadIdx.x; c < SV_C; c += 256)
+    if (c0 + c < g.N) g.colpart[(long long)bi * g.N + c0 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
+}
+struct SymvFinish {
+  int N;
+  const double *rowpart, *colpart;
+  const double *add;  // may be null
+  const double *A2;   // optional block of carried rows (as GemvRows)
+  long long lda2;
+  const int *n2;
+  const double *x2;
+  double *y;
+  double scale;
+};
+__global__ void __launch_bounds__(256) k_st_symv_finish(SymvFinish g) {
+  // 64 columns per workgroup, four threads per column: thread group q adds every fourth partial of the mirrored part
+  // (eight loads in flight), group 0 the row parts and the carried rows' term; fixed order throughout
+  __shared__ double red[4][64];
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + cl;
+  double s = 0.0;
+  if (j < g.N) {
+    const int bi = j / SV_R, nrt = (g.N + SV_R - 1) / SV_R, ct = (bi * SV_R + SV_R - 1) / SV_C;
+    int b = bi + q;
+    for (; b + 28 < nrt; b += 32) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) v[u] = g.colpart[(long long)(b + 4 * u) * g.N + j];
+#pragma unroll
+      for (int u = 0; u < 8; u++) s += v[u];
+    }
+    for (; b < nrt; b += 4) s += g.colpart[(long long)b * g.N + j];
+    {  // the row parts: every fourth one per group, up to eight loads in flight
+      double v[8];
+      for (int t0 = q; t0 <= ct; t0 += 32) {
+#pragma unroll
+        for (int u = 0; u < 8; u++) v[u] = t0 + 4 * u <= ct ? g.rowpart[(long long)(t0 + 4 * u) * g.N + j] : 0.0;
+#pragma unroll
+        for (int u = 0; u < 8; u++) s += v[u];
+      }
+    }
+    if (q == 0) {
+      if (g.A2) {
+        const int k2 = *g.n2;
+        const double *br = g.A2 + (long long)j * g.lda2;
+        for (int l = 0; l < k2; l++) s += br[l] * g.x2[l];
+      }
+    }
+  }
+  red[q][cl] = s;
+  __syncthreads();
+  if (q == 0 && j < g.N) g.y[j] = g.scale * ((g.add ? g.add[j] : 0.0) + ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])));
 }
 // the same for few, long rows (Rm x with a handful of controls and thousands of states): one
 // workgroup per row, so that a row's bytes are in flight from 256 threads
@@ -2248,6 +2496,7 @@ __global__ void __launch_bounds__(256) k_st_x0_free(int n0, int cap0, int qmax, 
                                                     const double *__restrict__ beta0, double *__restrict__ x0,
                                                     double *__restrict__ eta0) {
   extern __shared__ __attribute__((aligned(16))) double sm[];
+  if (K0s[3 * qmax] == 1.0) return;  // (uniform) the area holds the inverse: k_x0_rhs ... k_x0_out have done it
   const int c = dyn0[1], q = n0 + c, tid = threadIdx.x, nt = blockDim.x;
   double *b = sm, *y = sm + qmax, *t = y + qmax, *T = t + qmax;
   for (int i = tid; i < q; i += nt) {

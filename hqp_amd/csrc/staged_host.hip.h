@@ -143,6 +143,23 @@ int st_gemv_rows(hqpkkt_t *h, stg::GemvRows g) {
   KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_rows<<<(g.M + 3) / 4, 256, 0, h->stream>>>(g));
   return 0;
 }
+// y = scale (add + V x + A2 x2) with the symmetric V of a stage: from 2048 states on only the tiles on and below the
+// diagonal are read (k_st_symv_tiles + k_st_symv_finish; HQPKKT_NO_SYMV: the rows form throughout)
+int st_symv(hqpkkt_t *h, StagedDev &d, stg::GemvRows g) {
+  static const bool off = getenv("HQPKKT_NO_SYMV") != nullptr;
+  static const int from = getenv("HQPKKT_SYMV_FROM") ? atoi(getenv("HQPKKT_SYMV_FROM")) : 2048;
+  if (off || g.M != g.N || g.N < from || (g.lda & 1) || (((size_t)g.A) & 15)) return st_gemv_rows(h, g);
+  const kktdev::StagedPlan &P = d.plan;
+  const int N = g.N, nct = (N + stg::SV_C - 1) / stg::SV_C, nrt = (N + stg::SV_R - 1) / stg::SV_R;
+  double *rowpart = d.misc.p + P.oSym, *colpart = rowpart + (long long)nct * N;
+  static_assert(stg::SV_R == 64 && stg::SV_C == 512, "StagedPlan::oSym is sized for these tiles");
+  long long tiles = 0;
+  for (int bi = 0; bi < nrt; bi++) tiles += bi / (stg::SV_C / stg::SV_R) + 1;
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_symv_tiles<<<(unsigned)tiles, 256, 0, h->stream>>>(stg::SymvArgs{g.A, g.lda, N, g.x, rowpart, colpart}));
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_symv_finish<<<(N + 63) / 64, 256, 0, h->stream>>>(
+                            stg::SymvFinish{N, rowpart, colpart, g.add, g.A2, g.lda2, g.n2, g.x2, g.y, g.scale}));
+  return 0;
+}
 // y = add + alpha A'x over a K x N row-major block
 int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int K, int N, const double *x,
                  const double *add, double alpha, double *y) {
@@ -162,6 +179,21 @@ int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int 
 // The control-sized elimination of a stage whose matrices live in global memory: phase (A) and the scaled K by the
 // one-workgroup kernel, the inverse by the blocked sweep on the whole chip (k_blk_*, staged.hip.h), its check against
 // K, and the one-workgroup inverse behind it in case the blocked one gave up (decided on the device: flags[0]).
+// the sweep over the pivot blocks of 64 down the diagonal of the scaled matrix in `scratch` (layout: stg::big_scratch)
+static int st_blk_sweep(hqpkkt_t *h, double *scratch, int q, bool allow_sk) {
+  const stg::BigScratch bs = stg::big_scratch(scratch, q);
+  const int nb = (q + 63) / 64;
+  int e;
+  for (int j = 0; j < nb; j++) {
+    const stg::BlkArgs ba{scratch, q, j};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_blk_pivot<<<1, 256, 0, h->stream>>>(ba));
+    if ((e = st_gemm(h, stg::GemmArgs{bs.Pb, 64, bs.T0, bs.ldk, nullptr, 0, bs.R, bs.ldk, 64, q, 64, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)) ||
+        (e = st_gemm(h, stg::GemmArgs{bs.T0, bs.ldk, bs.R, bs.ldk, bs.Ks, bs.ldk, bs.Ks, bs.ldk, q, q, 64, -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)))
+      return e;
+    KLAUNCH(h, KC_ST_SMALL, stg::k_blk_fixup<<<nblk(64LL * q), 256, 0, h->stream>>>(ba));
+  }
+  return 0;
+}
 static int st_small_big(hqpkkt_t *h, StagedDev &d, stg::SmallArgs sa, bool allow_sk) {
   static const bool legacy = getenv("HQPKKT_NO_BLOCK_GJ") != nullptr;
   static const double tol = getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
@@ -174,15 +206,8 @@ static int st_small_big(hqpkkt_t *h, StagedDev &d, stg::SmallArgs sa, bool allow
   sa.mode = 1;
   KLAUNCH(h, KC_ST_SMALL, stg::k_st_small<1024><<<1, 1024, d.lds_small_big, h->stream>>>(sa));
   const stg::BigScratch bs = stg::big_scratch(sa.scratch, sa.qmax);
-  const int q = sa.qmax, nb = (q + 63) / 64;
-  for (int j = 0; j < nb; j++) {
-    const stg::BlkArgs ba{sa.scratch, q, j};
-    KLAUNCH(h, KC_ST_SMALL, stg::k_blk_pivot<<<1, 256, 0, h->stream>>>(ba));
-    if ((e = st_gemm(h, stg::GemmArgs{bs.Pb, 64, bs.T0, bs.ldk, nullptr, 0, bs.R, bs.ldk, 64, q, 64, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)) ||
-        (e = st_gemm(h, stg::GemmArgs{bs.T0, bs.ldk, bs.R, bs.ldk, bs.Ks, bs.ldk, bs.Ks, bs.ldk, q, q, 64, -1.0, 1.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)))
-      return e;
-    KLAUNCH(h, KC_ST_SMALL, stg::k_blk_fixup<<<nblk(64LL * q), 256, 0, h->stream>>>(ba));
-  }
+  const int q = sa.qmax;
+  if ((e = st_blk_sweep(h, sa.scratch, q, allow_sk))) return e;
   KLAUNCH(h, KC_ST_SMALL, stg::k_blk_final<<<nblk((long long)q * q), 256, 0, h->stream>>>(sa));
   if ((e = st_gemm(h, stg::GemmArgs{sa.Kmat, sa.ldq, sa.Kinv, sa.ldq, nullptr, 0, bs.Ks, bs.ldk, q, q, q, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, allow_sk)))
     return e;
@@ -718,13 +743,30 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
     StagePtr s0 = stage_ptr(d, 0);
     if (P.fixed_x0)
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_check_fixed<<<1, 64, 0, s>>>(s0.dyn, h->flags.p));
-    else if (P.big0)
+    else if (P.big0) {
+      // the inverse by the blocked sweep on the whole chip, checked against K0; the LU factorisation by one workgroup
+      // behind it runs only where the sweep gave up (decided on the device).  HQPKKT_NO_BLOCK_X0: the LU form only
+      static const bool legacy0 = getenv("HQPKKT_NO_BLOCK_X0") != nullptr;
+      static const double tol0 = getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
+      double *scr = d.misc.p + P.oScr;
+      const int q = P.q0max;
+      if (!legacy0) {
+        const stg::X0Args xa{P.nk[0], q, s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn, d.misc.p + P.oK0, d.misc.p + P.oK0m, d.misc.p + P.oK0s,
+                             P.ldq0, scr, h->flags.p};
+        KLAUNCH(h, KC_ST_SMALL, stg::k_x0_prepare<<<nblk((long long)q * q), 256, 0, s>>>(xa));
+        if ((e = st_blk_sweep(h, scr, q, true))) return e;
+        KLAUNCH(h, KC_ST_SMALL, stg::k_x0_final<<<nblk((long long)q * q), 256, 0, s>>>(xa));
+        const stg::BigScratch bs = stg::big_scratch(scr, q);
+        if ((e = st_gemm(h, stg::GemmArgs{xa.K0mat, P.ldq0, xa.K0inv, P.ldq0, nullptr, 0, bs.Ks, bs.ldk, q, q, q, 1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, true)))
+          return e;
+        KLAUNCH(h, KC_ST_SMALL, stg::k_x0_check<<<1, 1024, 0, s>>>(xa, tol0));
+      }
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<1024><<<1, 1024, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
                                                                                     d.misc.p + P.oK0, d.misc.p + P.oK0m, d.misc.p + P.oK0s, P.ldq0, P.q0max, h->flags.p,
-                                                                                    d.misc.p + P.oScr));
-    else
+                                                                                    scr, legacy0 ? nullptr : stg::big_scratch(scr, q).flags));
+    } else
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_init_factor<256><<<1, 256, d.lds_init, s>>>(P.nk[0], P.cap[0], s0.V, P.ldv[0], s0.BT, P.ldb[0], s0.dyn,
-                                                                                  d.misc.p + P.oK0, d.misc.p + P.oK0m, d.misc.p + P.oK0s, P.ldq0, P.q0max, h->flags.p, nullptr));
+                                                                                  d.misc.p + P.oK0, d.misc.p + P.oK0m, d.misc.p + P.oK0s, P.ldq0, P.q0max, h->flags.p, nullptr, nullptr));
   }
   if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
   HIPCHK(hipGetLastError());
@@ -754,7 +796,7 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
     const double *f = v.r2 + P.nks[k];
     // tt = v+ + V+ f ; gam = q_k + F' tt
-    if ((e = st_gemv_rows(h, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, f, sn.v, nullptr, 0, nullptr, nullptr, tt, 1.0}))) return e;
+    if ((e = st_symv(h, d, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, f, sn.v, nullptr, 0, nullptr, nullptr, tt, 1.0}))) return e;
     if ((e = st_gemv_cols(h, d, sp.F, P.ldf[k], np, nz, tt, qv + P.nmk[k], 1.0, gam))) return e;
     stg::BwdSmall ba{nn, mm, np, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], d.eq_rows.p + P.eq_ptr[k], v.r2,
                      P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr, sn.beta, sn.BT, P.ldb[k + 1], f, gam, sp.Kinv, sp.Kmat, P.ldq[k], sp.T, P.ldt[k],
@@ -769,9 +811,23 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     if (P.fixed_x0)
       KLAUNCH(h, KC_ST_VEC, stg::k_st_x0_fixed<<<nblk(std::max(n0, P.cap[0])), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, v.r2, S,
                                                                                          s0.eta, P.cap[0]));
-    else
+    else {
+      if (P.big0) {
+        // with the inverse of the blocked sweep (K0s[3 q]: which form the area holds; decided on the device): three
+        // products over the whole chip; k_st_x0_free behind them works only where the factors are in use
+        const int q = P.q0max, l8 = (q + 7) / 8 * 8;
+        double *vec = M + P.oK0s + 3 * (long long)q + 8, *nb = vec, *pb = vec + l8, *y = vec + 2 * l8, *r = vec + 3 * l8;
+        const stg::X0Vec xv{n0, P.cap[0], q, s0.dyn, M + P.oK0s, s0.v, s0.beta, nb, pb, pb, S, s0.eta};
+        KLAUNCH(h, KC_ST_VEC, stg::k_x0_rhs<<<nblk(q), 256, 0, s>>>(xv));
+        if ((e = st_gemv_rows(h, stg::GemvRows{M + P.oK0, P.ldq0, q, q, nb, nullptr, nullptr, 0, nullptr, nullptr, y, 1.0})) ||
+            (e = st_gemv_rows(h, stg::GemvRows{M + P.oK0m, P.ldq0, q, q, y, pb, nullptr, 0, nullptr, nullptr, r, -1.0})) ||
+            (e = st_gemv_rows(h, stg::GemvRows{M + P.oK0, P.ldq0, q, q, r, y, nullptr, 0, nullptr, nullptr, pb, 1.0})))
+          return e;
+        KLAUNCH(h, KC_ST_VEC, stg::k_x0_out<<<nblk(n0 + P.cap[0]), 256, 0, s>>>(xv));
+      }
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_x0_free<<<1, 256, d.lds_x0, s>>>(n0, P.cap[0], P.q0max, M + P.oK0, M + P.oK0m, M + P.oK0s, P.ldq0, s0.dyn, s0.v,
                                                                 s0.beta, S, s0.eta));
+    }
   }
   for (int k = 0; k < K; k++) {
     StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
@@ -789,7 +845,7 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     // x+ = F s + f ; p = V+ x+ + v+ + B+' eta+
     if ((e = st_gemv_rows(h, stg::GemvRows{sp.F, P.ldf[k], np, nz, xk, v.r2 + P.nks[k], nullptr, 0, nullptr, nullptr, S + P.nmk[k + 1], 1.0})))
       return e;
-    if ((e = st_gemv_rows(h, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, S + P.nmk[k + 1], sn.v, P.cap[k + 1] > 0 ? sn.BT : nullptr,
+    if ((e = st_symv(h, d, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, S + P.nmk[k + 1], sn.v, P.cap[k + 1] > 0 ? sn.BT : nullptr,
                                            P.ldb[k + 1], sn.dyn + 1, sn.eta, v.dy + P.nks[k], 1.0})))
       return e;
   }
@@ -799,7 +855,7 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     if (eK) KLAUNCH(h, KC_ST_VEC, stg::k_st_y_last<<<nblk(eK), 256, 0, s>>>(eK, d.eq_rows.p + P.eq_ptr[K], sK.eta, v.dy));
     if (P.fixed_x0) {
       const int n0 = P.nk[0];
-      if ((e = st_gemv_rows(h, stg::GemvRows{s0.V, P.ldv[0], n0, n0, S, s0.v, nullptr, 0, nullptr, nullptr, tmp, 1.0}))) return e;
+      if ((e = st_symv(h, d, stg::GemvRows{s0.V, P.ldv[0], n0, n0, S, s0.v, nullptr, 0, nullptr, nullptr, tmp, 1.0}))) return e;
       KLAUNCH(h, KC_ST_VEC, stg::k_st_y_fixed<<<nblk(n0), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, tmp, v.dy));
     }
   }

@@ -200,12 +200,15 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   if (!fixed_x0) {
     const long long q = q0max;
     if (gj_lds_bytes(q) + 256 > 150 * 1024) {
-      // a free initial state of many components: [V_0 B_0'; B_0 0] of order n_0 + carried rows is inverted by ONE
-      // workgroup out of global memory - up to order 1024; beyond that HQPKKT_E_SIZES (a blocked factorisation
-      // of V_0 is what it would take)
-      if (q > 1024) return 1;
+      // a free initial state of many components: [V_0 B_0'; B_0 0] of order n_0 + carried rows is inverted by the
+      // blocked sweep on the whole chip, with the LU factorisation by ONE workgroup out of global memory behind it
+      // where the sweep gives up - up to order 4096 (the LDS vectors of that workgroup); beyond that HQPKKT_E_SIZES
+      if (q > 4096) return 1;
       big0 = 1;
-      scratch_elems = std::max(scratch_elems, q * (q | 1) + 64);
+      // (the blocked inverse, k_x0_*: the scaled matrix in rows of up8(q), scaling, two panels, one block, flags;
+      // the one-workgroup LU behind it: q rows of q | 1)
+      const long long ldk = (q + 7) / 8 * 8;
+      scratch_elems = std::max(scratch_elems, std::max(q * (q | 1), q * ldk + ldk + 2 * 64 * ldk + 64 * 64 + 16) + 64);
     }
   }
 
@@ -247,7 +250,8 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   ldq0 = up8(std::max(q0max, 1));
   oK0 = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
   oK0m = mo, mo += up16((long long)std::max(q0max, 1) * ldq0);
-  oK0s = mo, mo += up16(3LL * std::max(q0max, 1));
+  // scaling and the two permutations | which form the area K0 holds | four vectors of the solve with the inverse
+  oK0s = mo, mo += up16(3LL * std::max(q0max, 1) + 8 + 4LL * up8(std::max(q0max, 1)));
   oRes = mo, mo += up16(resmax);
   oGam = mo, mo += up16(nzmax + 8);
   {
@@ -259,6 +263,8 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   oTmp = mo, mo += up16(nmax + 8);
   part_chunks = std::max(1, std::min(64, nmax / 64));
   oPart = mo, mo += up16((long long)part_chunks * (nzmax + 8));
+  // partial sums of the symmetric products with V (k_st_symv_tiles: 64-row and 512-column tiles)
+  oSym = mo, mo += up16(((long long)(nmax + 63) / 64 + (nmax + 511) / 512) * (nmax + 8));
   oS = mo, mo += up16(n + 8);
   oQv = mo, mo += up16(n + 8);
   oScr = mo, mo += up16(scratch_elems);

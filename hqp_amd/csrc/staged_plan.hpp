@@ -42,7 +42,7 @@ struct StagedPlan {
   std::vector<long long> oF, oV;                      // F arena, V arena
   std::vector<long long> oY, oR, oK, oKm, oN, oBT, oT;  // misc arena (oKm: K itself, next to its inverse oK)
   std::vector<long long> oVec;                        // per stage: v(n) beta(cap) rho(qmax) eta(cap)
-  long long oW = 0, oG = 0, oK0 = 0, oK0m = 0, oK0s = 0, oRes = 0, oGam = 0, oTT = 0, oPart = 0, oS = 0, oQv = 0, oTmp = 0, oUy = 0;
+  long long oW = 0, oG = 0, oK0 = 0, oK0m = 0, oK0s = 0, oRes = 0, oGam = 0, oTT = 0, oPart = 0, oS = 0, oQv = 0, oTmp = 0, oUy = 0, oSym = 0;
   long long f_elems = 0, v_elems = 0, misc_elems = 0;
   int part_chunks = 1;
   std::vector<int> dyn_off;  // int arena: per stage [r, nl, R(capn), L(capn)]

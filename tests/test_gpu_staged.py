@@ -257,6 +257,8 @@ def test_stages_beyond_one_cu_of_lds(case):
     # positive definite control Hessians, constraint rows behind them - without falling back to the one-workgroup form
     used, fell_back = S.debug(28)
     assert fell_back == 0 and (used > 0) == (case in ("nu200", "nu512", "nu300_path40", "final140")), (used, fell_back)
+    if case == "free_x0_250":  # [V_0 B_0'; B_0 0] of order 253: inverted by the same sweep (k_x0_*), the LU form not needed
+        assert list(S.debug(32)) == [1, 0], S.debug(32)
     ranks = S.stage_ranks()
     if case == "final140":  # the 140 final-state rows are consumed twenty per stage on their way back
         assert ranks[-1, 1] == 140 and ranks[0, 1] == 0 and ranks[:, 0].max() == 20 and (ranks[:, 0] == 20).sum() == 7
@@ -331,6 +333,71 @@ def test_blocked_elimination_falls_back_to_the_pivoted_one(monkeypatch):
     env = dict(os.environ, HQPKKT_BLOCK_GJ_TOL="-1")
     r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+@pytest.mark.parametrize("nx,final_eq,tol", [(1000, 0, None), (700, 5, None), (1900, 3, None), (600, 4, "-1")])
+def test_free_initial_state_of_many_components(nx, final_eq, tol):
+    """[V_0 B_0'; B_0 0] of a free initial state with hundreds to thousands of components (order up to 4096): inverted
+    by the blocked sweep over the whole chip and checked against the matrix (k_x0_prepare, k_blk_*, k_x0_final,
+    k_x0_check), applied by three products with one round of refinement; the reference factorises the same matrix by
+    Bunch-Kaufman (hqp/Hqp_IpLQDOCP.C:1972-1996).  Against the full-system engine.  With a tolerance no result can meet
+    the check fails and the LU factors of one workgroup (k_st_init_factor, applied by k_st_x0_free) take over - decided
+    on the device."""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+        from hqp_amd import problems, ipmatrix
+        from common import new_d, rel_err
+        prog = problems.lq_docp(2, %d, 4, x0_fixed=False, final_eq=%d, seed=4); st = problems.ip_state(prog, 6, 1.0)
+        out = []
+        for M in (ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()):
+            M.init(prog); M.factor(prog, st[0], st[1]); d = new_d(prog); res = M.solve(prog, *st, *d); out.append((d, res, M))
+        ran, fell = out[0][2].debug(32)
+        assert ran == 1 and fell == %d, (ran, fell)
+        assert out[0][1] <= 1e-10 and rel_err(out[0][0], out[1][0]) <= 1e-8, (out[0][1], rel_err(out[0][0], out[1][0]))
+        d2 = new_d(prog); assert out[0][2].solve(prog, *st, *d2) == out[0][1]
+        print("OK")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)), nx, final_eq,
+            1 if tol else 0)
+    env = dict(os.environ)
+    if tol:
+        env["HQPKKT_BLOCK_GJ_TOL"] = tol
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_symmetric_products_of_the_solve_read_one_triangle():
+    """From 2048 states on the products with V in the two sweeps of the solve read the tiles on and below the diagonal
+    only (k_st_symv_tiles, k_st_symv_finish).  Same stage matrices, same solve with HQPKKT_NO_SYMV (the rows form): equal
+    to rounding, both below the residual tolerance, and reproducible from run to run.  (With HQPKKT_SYMV_FROM=16 the
+    whole of this file runs through the triangle form; profiles/r04_symv.txt.)"""
+    import subprocess, sys, os, textwrap
+    code = textwrap.dedent("""
+        import sys; sys.path.insert(0, %r); sys.path.insert(0, %r)
+        import numpy as np
+        from hqp_amd import problems, ipmatrix
+        from common import new_d, rel_err
+        prog = problems.lq_docp(3, 2100, 6, final_eq=2, seed=3); st = problems.ip_state(prog, 6, 1.0)
+        M = ipmatrix.IpLQDOCP(); M.init(prog); M.factor(prog, st[0], st[1])
+        d = new_d(prog); res = M.solve(prog, *st, *d)
+        d2 = new_d(prog); res2 = M.solve(prog, *st, *d2)
+        assert res == res2 and all(np.array_equal(a, b) for a, b in zip(d, d2))
+        np.savez(sys.argv[1], res=res, *d)
+        print("OK")
+    """) % (os.path.dirname(os.path.dirname(os.path.abspath(__file__))), os.path.dirname(os.path.abspath(__file__)))
+    import tempfile
+    import numpy as np
+    out = []
+    with tempfile.TemporaryDirectory() as tmp:
+        for tag, env in (("tri", {}), ("rows", {"HQPKKT_NO_SYMV": "1"})):
+            path = os.path.join(tmp, tag + ".npz")
+            r = subprocess.run([sys.executable, "-c", code, path], env=dict(os.environ, **env), capture_output=True, text=True, timeout=900)
+            assert r.returncode == 0 and "OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+            z = np.load(path)
+            out.append((float(z["res"]), [z["arr_%d" % i] for i in range(4)]))
+    assert out[0][0] <= 1e-10 and out[1][0] <= 1e-10, (out[0][0], out[1][0])
+    assert not all(np.array_equal(a, b) for a, b in zip(out[0][1], out[1][1]))  # (the triangle form was really in use)
+    assert rel_err(out[0][1], out[1][1]) <= 1e-9
 
 
 @pytest.mark.parametrize("K,nx,nu,seed,state", [(12, 8, 1, 417, 5597), (32, 3, 2, 748, 7983)])
