@@ -26,6 +26,18 @@ timeout 300 python tools/tree_levels.py 2>&1 | grep -v amdgpu.ids > $O/r04_c2_tr
 timeout 300 python tools/block_time.py 2>&1 | grep -v amdgpu.ids > $O/r04_block_time.txt
 # C3 (double-integrator QP, K = 2000): the device-resident Mehrotra loop per kernel
 timeout 300 bash tools/ipprof.sh 2000 > $O/r04_ip_did_kstat.txt 2>&1
+# STAGED engine, control-sized paths: stages beyond one CU of LDS and free initial states of 250 / 1000 components; the
+# symmetric products of the solve (micro-benchmark of the tile forms, and the solve's kernels on ten stages of the headline)
+timeout 300 python tools/bigstage_time.py 2>&1 | grep -v amdgpu.ids > $O/r04_bigstage_time.txt
+hipcc --offload-arch=gfx950 -O3 -std=c++17 -w -o /tmp/symv_probe tools/symv_probe.hip && timeout 100 /tmp/symv_probe > $O/r04_symv.txt 2>&1
+for t in tri rows; do
+  if [ $t = rows ]; then export HQPKKT_NO_SYMV=1; fi
+  rm -rf /tmp/p
+  timeout 200 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p -- python3 tools/c4_bench.py 10 5000 50 2 > /tmp/p.log 2>&1
+  echo "== the solve's product kernels, ten stages of the headline, two factor+solve: $t" >> $O/r04_symv.txt
+  grep -i "gemv\|symv\|cols_finish\|\"Name\"" $(find /tmp/p -name '*kernel_stats.csv' | head -1) | cut -d, -f1-4,6,7 >> $O/r04_symv.txt
+done
+unset HQPKKT_NO_SYMV
 # N > 1 path: bench.py starting its own two ranks on the one GPU (exchange staged through gloo: functional, not a measurement)
 timeout 600 python bench.py --gpus 2 --backend gloo --share-gpu --stages 20 --steps 3 --warmup 1 --no-ip 2>/dev/null | grep '^{' | tail -1 > $O/r04_bench_2rank_shared.json
 rm -rf $O/kt $O/kt2 $O/pmc_fetch $O/pmc_write $O/pmc_mfma gpurun_out/c2trace/kt gpurun_out/prof_ip/ip_results.db

@@ -285,7 +285,7 @@ int hqpkkt_set_shard_stream(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_st
  * them (K stages, nx[K+1] states, nu[K] controls; K <= 0 returns to the detection);
  * HQPKKT_E_FORMAT: the pattern / the values are not such a staircase (the reference
  * asserts), HQPKKT_E_SIZES: a stage with more than 512 controls, more than 256 constraint rows
- * carried from one stage to the one before it, or a FREE initial state with more than 1024 components
+ * carried from one stage to the one before it, or a FREE initial state with more than 4096 components
  * + carried rows (a fixed x_0 has no limit).  Up to ~64 controls and ~130 for the order of a stage's
  * [G_uu N_u'; N_u 0] the control-sized work of a stage runs in the LDS of one CU; beyond that the same
  * elimination runs out of global memory (one workgroup: correct and slow, ~20 ms per stage at 300

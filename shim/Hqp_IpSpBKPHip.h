@@ -98,7 +98,7 @@ class Hqp_IpRedSpBKPHip : public Hqp_IpMatrixHip {
 // (HQPKKT_MODE_STAGED: fp64 MFMA products on the device) - from mat_staged_min_front (default 800) rows per
 // stage front on; narrower stages are faster through the tree engine.  Where the reference asserts
 // (no DOCP structure) or a stage is beyond the STAGED kernels (> 512 controls, > 256
-// carried constraint rows, a free x_0 of > 1024 components) the same KKT system goes to the full-system engine.
+// carried constraint rows, a free x_0 of > 4096 components) the same KKT system goes to the full-system engine.
 class Hqp_IpLQDOCPHip : public Hqp_IpMatrixHip {
  public:
   Hqp_IpLQDOCPHip() : Hqp_IpMatrixHip(2) {}

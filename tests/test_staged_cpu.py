@@ -67,7 +67,8 @@ def test_not_a_staircase_is_e_format():
 def test_size_limits_of_the_staged_engine():
     """Round 3: 150 controls per stage are accepted (the control-sized elimination then runs out of global memory,
     StagedPlan::big); beyond 512 controls, beyond 256 carried constraint rows, or with a free initial state of more than
-    1024 components: HQPKKT_E_SIZES (the shim's fall-back to the tree engine)."""
+    4096 components (round 4: the blocked inverse of [V_0 B_0'; B_0 0]; 1024 before): HQPKKT_E_SIZES (the shim's
+    fall-back to the tree engine)."""
     M = ipmatrix.IpLQDOCP()
     e, _ = _analyze(M, problems.lq_docp(2, 4, 150))
     assert e == 0
@@ -76,6 +77,8 @@ def test_size_limits_of_the_staged_engine():
     e, _ = _analyze(ipmatrix.IpLQDOCP(), problems.lq_docp(2, 300, 2, final_eq=280))
     assert e == _lib.E_SIZES
     e, _ = _analyze(ipmatrix.IpLQDOCP(), problems.lq_docp(2, 1100, 2, x0_fixed=False))
+    assert e == 0
+    e, _ = _analyze(ipmatrix.IpLQDOCP(), problems.lq_docp(2, 4100, 1, x0_fixed=False))
     assert e == _lib.E_SIZES
     e, _ = _analyze(ipmatrix.IpLQDOCP(), problems.lq_docp(2, 1100, 2))  # fixed x_0: no limit on the states
     assert e == 0

@@ -3,7 +3,9 @@
 fixed / free initial state, w/z spreads - K of order <= 64 in registers, 65 ... 136 in LDS (diagonal-first or with the
 search), beyond that the blocked elimination - against the tree engine (Hqp_IpLQDOCPFull) on the same QP: residual of
 the refined solve <= 1e-10, same solution to 1e-8; the blocked elimination must not have fallen back.
-Usage: [FUZZ_LARGE=1] python tools/fuzz_bigstage.py [cases] [seed0]"""
+FUZZ_X0=1: free initial states of 140 ... 1600 components with few controls (the blocked inverse of [V_0 B_0'; B_0 0],
+k_x0_*; counted separately: ran / fell back to the LU factors of one workgroup).
+Usage: [FUZZ_LARGE=1 | FUZZ_X0=1] python tools/fuzz_bigstage.py [cases] [seed0]"""
 import os
 import sys
 import time
@@ -19,6 +21,14 @@ from common import new_d, rel_err
 def make_case(case):
     rng = np.random.default_rng(77000 + case)
     large = bool(os.environ.get("FUZZ_LARGE"))  # up to the engine's limits: 512 controls, x_0 systems of ~1000
+    if os.environ.get("FUZZ_X0"):
+        nx, nu, K = int(rng.integers(140, 1601)), int(rng.integers(1, 9)), int(rng.integers(2, 4))
+        kw = dict(seed=int(rng.integers(1, 999)), x0_fixed=False, final_eq=int(rng.integers(0, 8)) if rng.random() < 0.6 else 0,
+                  path_eq=int(rng.integers(1, nu + 1)) if rng.random() < 0.3 else 0, path_eq_every=int(rng.integers(1, 3)),
+                  x_bounds=int(rng.integers(0, nx + 1)) if rng.random() < 0.5 else 0)
+        prog = problems.lq_docp(K, nx, nu, **kw)
+        st = problems.ip_state(prog, case, float(rng.choice([0.0, 1.0, 2.0, 3.0])))
+        return prog, st, f"case {case}: K={K} nx={nx} nu={nu} {kw}"
     nu = int(rng.choice([rng.integers(10, 65), rng.integers(65, 137), rng.integers(137, 513 if large else 301)]))
     nx = int(rng.integers(20, 900 if large else 260))
     K = int(rng.integers(2, 4 if large else 5))
@@ -45,7 +55,7 @@ def main():
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
     cnt = {"ok": 0, "skip": 0, "BAD": 0}
-    blocked = fell = 0
+    blocked = fell = x0_ran = x0_fell = 0
     for case in range(seed0, seed0 + ncases):
         prog, st, tag = make_case(case)
         try:
@@ -83,6 +93,9 @@ def main():
         u, f = S.debug(28)
         blocked += int(u)
         fell += int(f)
+        u0, f0 = S.debug(32)
+        x0_ran += int(u0)
+        x0_fell += int(f0)
         if not (rf <= 1e-10):
             cnt["skip"] += 1
             continue
@@ -92,7 +105,7 @@ def main():
             cnt["BAD"] += 1
             print(tag, f"residual {rs:.2e} (tree engine {rf:.2e}), relative difference {rel_err(ds, df):.2e}", flush=True)
     print(f"fuzz_bigstage: {ncases} cases from {seed0}: {cnt}; stages through the blocked elimination {blocked}, fallen back {fell}; "
-          f"{time.time() - t0:.0f} s", flush=True)
+          f"free initial states through the blocked inverse {x0_ran}, fallen back {x0_fell}; {time.time() - t0:.0f} s", flush=True)
 
 
 if __name__ == "__main__":
