@@ -747,7 +747,8 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
       // the inverse by the blocked sweep on the whole chip, checked against K0; the LU factorisation by one workgroup
       // behind it runs only where the sweep gave up (decided on the device).  HQPKKT_NO_BLOCK_X0: the LU form only
       static const bool legacy0 = getenv("HQPKKT_NO_BLOCK_X0") != nullptr;
-      static const double tol0 = getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
+      static const double tol0 = getenv("HQPKKT_BLOCK_X0_TOL") ? atof(getenv("HQPKKT_BLOCK_X0_TOL"))
+                                 : getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
       double *scr = d.misc.p + P.oScr;
       const int q = P.q0max;
       if (!legacy0) {
