@@ -48,6 +48,9 @@ __device__ __forceinline__ double gather_children(const DevTree &T, const double
 }
 
 // order-preserving max for non-negative doubles through their bit pattern
+// (the read-modify-writes of a launch's workgroups on ONE word are served one after the other, ~6 ns each: launches that
+// end in this keep their grids at a thousand or two workgroups; a look at the word first - an agent-scope load - cost
+// k_assemble_simple more than it saved k_residual)
 __device__ __forceinline__ void atomic_max_pos(unsigned long long *addr, double v) {
   atomicMax(addr, (unsigned long long)__double_as_longlong(v));
 }
@@ -2519,10 +2522,18 @@ __device__ __forceinline__ double row_sum(double v) {
 template <int LPR>
 __device__ __forceinline__ double row_dot(const CsrDev M, const double *__restrict__ vals,
                                           const double *__restrict__ x, int row, int sub) {
-  double s = 0.0;
+  // (two entries per lane in flight: the loop is a chain of index -> value round trips, 80 - 160 entries per row on
+  // the banded systems)
+  double s = 0.0, t = 0.0;
   const int e = M.ptr[row + 1];
-  for (int k = M.ptr[row] + sub; k < e; k += LPR) s += M.val[k] * x[M.col[k]];
-  return row_sum<LPR>(s);
+  int k = M.ptr[row] + sub;
+  for (; k + LPR < e; k += 2 * LPR) {
+    const int c0 = M.col[k], c1 = M.col[k + LPR];
+    const double v0 = M.val[k], v1 = M.val[k + LPR];
+    s += v0 * x[c0], t += v1 * x[c1];
+  }
+  if (k < e) s += M.val[k] * x[M.col[k]];
+  return row_sum<LPR>(s + t);
 }
 // LPR lanes per CSR row: 16 for the banded systems, 4 when the rows hold a handful of
 // entries (DOCP / Prg_DID matrices: 1-3 per row)
