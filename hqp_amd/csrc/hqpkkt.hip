@@ -2787,9 +2787,15 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
     }
     case 32: {  // STAGED, free initial state of many components: [0] blocked inverse ran, [1] fell back to the LU factors
       if (!h->sd) return HQPKKT_E_INTERN;
-      tmp.assign(2, 0);
+      // ... [2] the pivot block that gave up (1-based, 0: none), [3], [4] |K_jj|, |K_jj^-1| of that block, [5] max |K0 K0^-1 - I|
+      // (floats as their bit patterns; the words of the blocked sweep's scratch area as the LAST factorisation left them)
+      tmp.assign(6, 0);
       if (hipDeviceSynchronize() != hipSuccess ||
           hipMemcpy(tmp.data(), h->flags.p + stg::X0_BLOCKED, sizeof(int) * 2, hipMemcpyDeviceToHost) != hipSuccess)
+        return HQPKKT_E_DEVICE;
+      if (h->sd->plan.big0 &&
+          hipMemcpy(tmp.data() + 2, stg::big_scratch(h->sd->misc.p + h->sd->plan.oScr, h->sd->plan.q0max).flags + 1, sizeof(int) * 4,
+                    hipMemcpyDeviceToHost) != hipSuccess)
         return HQPKKT_E_DEVICE;
       v = &tmp;
       break;

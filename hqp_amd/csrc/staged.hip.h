@@ -1581,7 +1581,11 @@ __global__ void __launch_bounds__(256) k_blk_pivot(BlkArgs a) {
   }
   pm = block_argmax(pm, red);
   // |K_jj| |K_jj^-1| beyond 1e12: no safe pivot inside this block
-  if (tid == 0 && (bad || !(am.v * pm.v < 1e12))) bs.flags[0] = 1;
+  if (tid == 0 && (bad || !(am.v * pm.v < 1e12))) {
+    bs.flags[0] = 1;
+    // (introspection: the block that gave up, and |K_jj|, |K_jj^-1| as floats)
+    bs.flags[1] = a.j + 1, bs.flags[2] = __float_as_int((float)am.v), bs.flags[3] = __float_as_int((float)pm.v);
+  }
 }
 __global__ void k_blk_fixup(BlkArgs a) {
   const BigScratch bs = big_scratch(a.scratch, a.qmax);
@@ -1935,7 +1939,7 @@ __global__ void k_x0_prepare(X0Args a) {
     }
     bs.dsc[i] = d;
   }
-  if (e == 0) bs.flags[0] = 0, atomicAdd(a.status + X0_BLOCKED, 1);
+  if (e == 0) bs.flags[0] = bs.flags[1] = bs.flags[2] = bs.flags[3] = bs.flags[4] = 0, atomicAdd(a.status + X0_BLOCKED, 1);
 }
 __global__ void k_x0_final(X0Args a) {
   const BigScratch bs = big_scratch(a.scratch, a.qmax);
@@ -1960,7 +1964,10 @@ __global__ void __launch_bounds__(1024) k_x0_check(X0Args a, double tol) {
       if (!(d <= am.v)) am.v = d == d ? d : __longlong_as_double(0x7ff0000000000000LL);
     }
     am = block_argmax(am, red);
-    if (threadIdx.x == 0 && !(am.v <= tol)) bs.flags[0] = 1;
+    if (threadIdx.x == 0) {
+      bs.flags[4] = __float_as_int((float)am.v);  // (introspection: max |K0 K0^-1 - I|)
+      if (!(am.v <= tol)) bs.flags[0] = 1;
+    }
   }
   __syncthreads();
   if (threadIdx.x == 0) a.K0s[3 * a.qmax] = bs.flags[0] ? 0.0 : 1.0;

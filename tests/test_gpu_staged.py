@@ -258,7 +258,7 @@ def test_stages_beyond_one_cu_of_lds(case):
     used, fell_back = S.debug(28)
     assert fell_back == 0 and (used > 0) == (case in ("nu200", "nu512", "nu300_path40", "final140")), (used, fell_back)
     if case == "free_x0_250":  # [V_0 B_0'; B_0 0] of order 253: inverted by the same sweep (k_x0_*), the LU form not needed
-        assert list(S.debug(32)) == [1, 0], S.debug(32)
+        assert list(S.debug(32))[:2] == [1, 0], S.debug(32)
     ranks = S.stage_ranks()
     if case == "final140":  # the 140 final-state rows are consumed twenty per stage on their way back
         assert ranks[-1, 1] == 140 and ranks[0, 1] == 0 and ranks[:, 0].max() == 20 and (ranks[:, 0] == 20).sum() == 7
@@ -352,7 +352,7 @@ def test_free_initial_state_of_many_components(nx, final_eq, tol):
         out = []
         for M in (ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()):
             M.init(prog); M.factor(prog, st[0], st[1]); d = new_d(prog); res = M.solve(prog, *st, *d); out.append((d, res, M))
-        ran, fell = out[0][2].debug(32)
+        ran, fell = out[0][2].debug(32)[:2]
         assert ran == 1 and fell == %d, (ran, fell)
         assert out[0][1] <= 1e-10 and rel_err(out[0][0], out[1][0]) <= 1e-8, (out[0][1], rel_err(out[0][0], out[1][0]))
         d2 = new_d(prog); assert out[0][2].solve(prog, *st, *d2) == out[0][1]

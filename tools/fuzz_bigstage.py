@@ -93,7 +93,7 @@ def main():
         u, f = S.debug(28)
         blocked += int(u)
         fell += int(f)
-        u0, f0 = S.debug(32)
+        u0, f0 = S.debug(32)[:2]
         x0_ran += int(u0)
         x0_fell += int(f0)
         if not (rf <= 1e-10):
