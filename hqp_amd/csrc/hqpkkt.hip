@@ -254,6 +254,12 @@ struct hqpkkt {
   // inside hqpkkt_mehrotra: factor() returns without waiting for its status (read with the
   // residual of the solve that follows), solve() leaves its result in the stream
   bool lazy = false, factor_unchecked = false;
+  // hqpkkt_factor / hqpkkt_solve of a caller with DEVICE vectors: the second call in a row with the same pointers works
+  // on the caller's vectors themselves (no staging copies; the sequences are captured on them, DirectGraph) - set for
+  // the duration of that call.  last_f / last_s: the pointers of the previous call of either kind
+  bool direct_now = false;
+  bool panel_cleared = false;  // do_factor has cleared the panel arena in front of the factorisation's graph
+  const void *last_f[2] = {nullptr, nullptr}, *last_s[10] = {};
   // hqpkkt_franke: the first residual of a solve is not waited for - it comes back with the scalars of the iteration
   // (one read-back per iteration); residual_pending: such a residual is in the stream, collect_residual() reads it
   bool defer_residual = false, residual_pending = false;
@@ -700,13 +706,15 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
   const int m = an.m, nent = (int)an.ent_a.size();
   DevTree T = h->tree();
   if (phases & 1) {
-    if (an.shard_count <= 1) {
-      HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, s));
+    if (an.shard_count <= 1 && h->panel_cleared) {  // (a large arena: cleared by do_factor in front of the graph)
+      k_clear<<<1, 256, 0, s>>>(nullptr, 0, h->flags.p);
+    } else if (an.shard_count <= 1) {  // the panel arena, and the status words, counters and the two maxima
+      k_clear<<<(int)std::max<long long>(1, std::min<long long>(4096, (an.panel_elems / 2 + 1023) / 1024)), 256, 0, s>>>(h->panel.p, an.panel_elems, h->flags.p);
     } else {  // only the blocks this rank writes
       const int np = (int)an.zero_panel.size() / 2;
       if (np) k_zero_ranges<<<dim3(512, np), 256, 0, s>>>(h->panel.p, h->zero_panel.p);
+      k_clear<<<1, 256, 0, s>>>(nullptr, 0, h->flags.p);
     }
-    HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 128, s));  // status, counters and the two maxima
     if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
     if (m > 0)
       KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
@@ -984,6 +992,12 @@ static int do_factor(hqpkkt_t *h, const Vecs &v) {
     return graphed(h, h->gfactor[0], [&]() { return staged_run_factor(h, v.z, v.w); });
   }
   if (an.shard_count <= 1) {
+    // A large panel arena (C2: 0.21 GB) is cleared by the runtime's fill IN FRONT of the graph - 17 us faster than k_clear
+    // at that size, and not a memset NODE (see k_clear); small arenas (the trees of the interior-point loops) inside it.
+    // HQPKKT_CLEAR_IN_GRAPH: always inside
+    static const bool inside = getenv("HQPKKT_CLEAR_IN_GRAPH") != nullptr;
+    h->panel_cleared = !inside && an.panel_elems >= (4LL << 20) && h->use_graphs && !h->prof.on;
+    if (h->panel_cleared) HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, h->stream));
     if (an.m > 0 && v.z != h->vin.p) {  // the caller's device vectors themselves (direct_vectors)
       const void *key[10] = {v.z, v.w};
       return graphed(h, h->direct_slot(h->gdirect_factor, key), [&]() { return run_factor(h, v.z, v.w, 3); });
@@ -1373,8 +1387,29 @@ static int switch_to_policy0(hqpkkt_t *h) {
 // inside the device-resident loops (lazy) of the tree engine on one GPU: no staging copies, the sequences are captured
 // on the caller's device vectors (hqpkkt_t::DirectGraph)
 static bool direct_vectors(const hqpkkt_t *h) {
-  return getenv("HQPKKT_NO_DIRECT_VECTORS") == nullptr && h->lazy && h->opts.loc == HQPKKT_LOC_DEVICE && h->opts.mode != HQPKKT_MODE_STAGED && h->an.shard_count <= 1 && h->use_graphs;
+  return getenv("HQPKKT_NO_DIRECT_VECTORS") == nullptr && (h->lazy || h->direct_now) && h->opts.loc == HQPKKT_LOC_DEVICE &&
+         h->opts.mode != HQPKKT_MODE_STAGED && h->an.shard_count <= 1 && h->use_graphs;
 }
+// A caller's own factor / solve calls (not the device-resident loops): direct from the SECOND call in a row with the same
+// set of pointers (a caller that passes fresh vectors every time would pay a graph capture per call), and only if no
+// two of the vectors overlap (the staging copies read every input before any output is written; the sequences do not).
+// HQPKKT_NO_DIRECT_CALLS: off.
+struct DirectCall {
+  hqpkkt_t *h;
+  DirectCall(hqpkkt_t *h_, const void *const *ptr, const int *len, int count, const void **last) : h(h_) {
+    static const bool off = getenv("HQPKKT_NO_DIRECT_CALLS") != nullptr;
+    bool same = !off && !h->lazy && h->an.m > 0;
+    for (int i = 0; i < count; i++) same = same && ptr[i] == last[i] && (ptr[i] != nullptr || len[i] == 0);
+    for (int i = 0; i < count; i++) last[i] = ptr[i];
+    for (int i = 0; same && i < count; i++)
+      for (int j = i + 1; j < count; j++) {
+        const char *a = (const char *)ptr[i], *b = (const char *)ptr[j];
+        if (len[i] > 0 && len[j] > 0 && a < b + sizeof(double) * (size_t)len[j] && b < a + sizeof(double) * (size_t)len[i]) same = false;
+      }
+    h->direct_now = same;
+  }
+  ~DirectCall() { h->direct_now = false; }
+};
 // the vectors a solve works on: the caller's (direct_vectors) or the staging buffers, filled
 static int solve_vecs(hqpkkt_t *h, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
                       const double *r4, double *dx, double *dy, double *dz, double *dw, Vecs &v) {
@@ -1393,6 +1428,9 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
   if (h->an.m > 0 && (!z || !w)) return HQPKKT_E_NULL;
   HIPCHK(hipSetDevice(h->opts.device));
+  const void *const fp[2] = {z, w};
+  const int fl[2] = {h->an.m, h->an.m};
+  DirectCall direct_call(h, fp, fl, 2, h->last_f);
   Vecs v{};
   int e = 0;
   if (direct_vectors(h))
@@ -1495,6 +1533,9 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if (!h->factored) return HQPKKT_E_INTERN;
   HIPCHK(hipSetDevice(h->opts.device));
   hipStream_t s = h->stream;
+  const void *const sp[10] = {z, w, r1, r2, r3, r4, dx, dy, dz, dw};
+  const int sl[10] = {h->an.m, h->an.m, h->an.n, h->an.me, h->an.m, h->an.m, h->an.n, h->an.me, h->an.m, h->an.m};
+  DirectCall direct_call(h, sp, sl, 10, h->last_s);
   Vecs v{};
   int e = solve_vecs(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, v);
   if (e) return e;
@@ -1502,7 +1543,7 @@ int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1
   if ((e = do_step(h, v, 0))) return e;
   double res = 0.0;
   const OutPtrs outp{dx, dy, dz, dw};
-  if ((e = run_residual(h, v, &res, h->lazy ? nullptr : &outp))) return e;
+  if ((e = run_residual(h, v, &res, (h->lazy || v.dx == dx) ? nullptr : &outp))) return e;
   if (h->residual_pending) {  // (hqpkkt_franke: solve_tail follows if the residual, once read, asks for it)
     if (res_out) *res_out = 0.0;
     return v.dx == dx ? 0 : stage_out(h, v, dx, dy, dz, dw);
@@ -1556,7 +1597,7 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
   if (h->lazy) {
     if (v.dx != dx && (e = stage_out(h, v, dx, dy, dz, dw))) return e;
   } else {
-    if (refined) {
+    if (refined && v.dx != dx) {
       if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
     }
     HIPCHK(hipStreamSynchronize(s));  // (returns at once when nothing was queued after the read-back)

@@ -2594,6 +2594,24 @@ k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDe
 
 // several vectors moved by one launch (staging of caller pointers into the
 // handle's fixed buffers, so that the numeric sequences can be replayed as graphs)
+// the panel arena and the 128 status words of a factorisation cleared by ONE kernel of the captured sequence (no memset
+// nodes in the graphs: a graph whose memset nodes had run a few times was seen to clear with the arguments of a later
+// copy of the caller's on another stream - status "6000", tests/test_gpu_parity.py::test_repeated_calls_...)
+__global__ void __launch_bounds__(256) k_clear(double *__restrict__ p, long long n, int *__restrict__ words) {
+  typedef double d2 __attribute__((ext_vector_type(2)));
+  if (blockIdx.x == 0 && threadIdx.x < 128) words[threadIdx.x] = 0;
+  const long long n2 = n >> 1, stride = (long long)gridDim.x * blockDim.x;
+  d2 *q = (d2 *)p;
+  long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const d2 zero{0.0, 0.0};
+  // (streaming stores: nothing of this is read before the assembly has scattered into it)
+  for (; i + 3 * stride < n2; i += 4 * stride) {
+    __builtin_nontemporal_store(zero, q + i), __builtin_nontemporal_store(zero, q + i + stride);
+    __builtin_nontemporal_store(zero, q + i + 2 * stride), __builtin_nontemporal_store(zero, q + i + 3 * stride);
+  }
+  for (; i < n2; i += stride) __builtin_nontemporal_store(zero, q + i);
+  if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
+}
 // sharded mode: clear the (offset, length) ranges of an arena this rank writes
 __global__ void k_zero_ranges(double *__restrict__ base, const long long *__restrict__ ranges) {
   const long long off = ranges[2 * blockIdx.y], len = ranges[2 * blockIdx.y + 1];

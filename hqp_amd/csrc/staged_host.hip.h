@@ -647,7 +647,10 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
   hipStream_t s = h->stream;
   const int m = an.m, K = P.K;
   int e;
-  HIPCHK(hipMemsetAsync(h->flags.p, 0, sizeof(int) * 128, s));
+  {  // the status words and V_K cleared by one kernel (no memset nodes in the captured sequence: kernels.hip.h, k_clear)
+    const long long vk = (long long)P.nk[K] * P.ldv[K];
+    kktdev::k_clear<<<(int)std::max<long long>(1, std::min<long long>(4096, (vk / 2 + 1023) / 1024)), 256, 0, s>>>(stage_ptr(d, K).V, vk, h->flags.p);
+  }
   if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
   if (m > 0) KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(1, m, an.n + an.me, z, w, h->wt.p, nullptr, h->flags.p));
   if (!h->capturing) HIPCHK(hipEventRecord(h->ev1, s));
@@ -655,7 +658,6 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
   {  // last stage: V_K = H_K, all its equality rows are carried
     StagePtr sp = stage_ptr(d, K);
     const int nK = P.nk[K], eK = P.eq_ptr[K + 1] - P.eq_ptr[K];
-    HIPCHK(hipMemsetAsync(sp.V, 0, sizeof(double) * (size_t)nK * P.ldv[K], s));
     const int ne = P.h_ptr[K + 1] - P.h_ptr[K];
     if (ne)
       KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(ne), 256, 0, s>>>(ne, d.h_dst.p + P.h_ptr[K], d.h_tptr.p + P.h_ptr[K], d.h_terms.p,

@@ -51,6 +51,11 @@ extern "C" {
 /* where the vectors z,w,r1..r4,dx..dw (and Qx,Ax,Cx) live */
 #define HQPKKT_LOC_HOST 0   /* Meschach VEC::ve pointers; copied H2D / D2H per call */
 #define HQPKKT_LOC_DEVICE 1 /* device pointers on opts.device, used in place */
+/* Device vectors are read and written by the handle's own (non-blocking) stream: whatever the caller has queued on
+ * other streams for these vectors - producers of the inputs, but also writes to the OUTPUT vectors such as clearing
+ * them - must be complete before a call; every call returns with its results complete.  hqpkkt_factor / hqpkkt_solve
+ * stage the vectors through buffers of the handle on the first call; from the second call in a row with the same
+ * pointers (none of them overlapping another) they work on the caller's vectors themselves. */
 
 typedef struct hqpkkt hqpkkt_t;
 

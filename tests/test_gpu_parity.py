@@ -133,6 +133,63 @@ def test_device_vectors_torch(kind):
     assert rel_err([t.cpu().numpy() for t in d], gold) <= SOL_TOL
 
 
+@pytest.mark.parametrize("kind,n,band", [("SpBKP", 3000, 20), ("RedSpBKP", 6000, 40)])
+def test_repeated_calls_on_the_same_device_vectors_skip_the_staging_copies(kind, n, band):
+    """hqpkkt_factor / hqpkkt_solve of a caller with device vectors: the first call stages the vectors into the handle's
+    buffers, from the second call in a row with the same pointers on the sequences run on the caller's vectors themselves
+    (captured on them; hqpkkt.hip DirectCall).  Same kernels on the same numbers: every call gives the bits of the first
+    one; new right-hand sides in the same tensors are seen; a call whose result aliases an input (dx = r1) stays on the
+    staging path and gives the same solution; new tensors go back to staging."""
+    import torch
+    prog = problems.banded_qp(n, band, seed=5)
+    st = problems.ip_state(prog, seed=2)
+    M = CLS[kind](device_vectors=True)
+    M.init(prog)
+    dev = [torch.as_tensor(a).cuda() for a in st]
+    d = [torch.zeros(k, dtype=torch.float64, device="cuda") for k in (prog.n, prog.me, prog.m, prog.m)]
+    out = []
+    for _ in range(4):
+        M.factor(prog, dev[0], dev[1])
+        for t in d:
+            t.zero_()
+        torch.cuda.synchronize()  # (the handle has a stream of its own: the caller's writes must be complete, hqpkkt.h)
+        res = M.solve(prog, *dev, *d)
+        out.append((res, [t.cpu().numpy().copy() for t in d]))
+    assert out[0][0] <= 1e-10
+    for res, sol in out[1:]:
+        assert res == out[0][0]
+        for a, b in zip(sol, out[0][1]):
+            assert np.array_equal(a, b)
+    # twice the right-hand side, written into the same tensors: twice the solution
+    for t in dev[2:]:
+        t.mul_(2.0)
+    torch.cuda.synchronize()
+    M.solve(prog, *dev, *d)
+    assert rel_err([t.cpu().numpy() for t in d], [2.0 * v for v in out[0][1]]) <= 1e-9
+    for t in dev[2:]:
+        t.mul_(0.5)
+    torch.cuda.synchronize()
+    # the result written over r1 (same length as dx): inputs are read before outputs are written, twice in a row
+    r1 = torch.empty_like(dev[2])
+    for _ in range(2):
+        r1.copy_(dev[2])
+        alias = [r1, d[1], d[2], d[3]]
+        torch.cuda.synchronize()
+        res = M.solve(prog, dev[0], dev[1], r1, dev[3], dev[4], dev[5], *alias)
+        assert res <= 1e-10
+        assert rel_err([t.cpu().numpy() for t in alias], out[0][1]) <= 1e-9
+    # fresh tensors every call
+    for _ in range(2):
+        dev2 = [t.clone() for t in dev]
+        d2 = [torch.zeros_like(t) for t in d]
+        torch.cuda.synchronize()
+        M.factor(prog, dev2[0], dev2[1])
+        res = M.solve(prog, *dev2, *d2)
+        assert res == out[0][0]
+        for a, b in zip(d2, out[0][1]):
+            assert np.array_equal(a.cpu().numpy(), b)
+
+
 def test_full_size_c2_properties():
     """Config C2 of BASELINE.json (n=40000, b=80: KKT dim 1e5, mat_sbw 200) at full
     size through size-independent properties: the refined KKT residual reaches
