@@ -258,7 +258,6 @@ struct hqpkkt {
   // on the caller's vectors themselves (no staging copies; the sequences are captured on them, DirectGraph) - set for
   // the duration of that call.  last_f / last_s: the pointers of the previous call of either kind
   bool direct_now = false;
-  bool panel_cleared = false;  // do_factor has cleared the panel arena in front of the factorisation's graph
   const void *last_f[2] = {nullptr, nullptr}, *last_s[10] = {};
   // hqpkkt_franke: the first residual of a solve is not waited for - it comes back with the scalars of the iteration
   // (one read-back per iteration); residual_pending: such a residual is in the stream, collect_residual() reads it
@@ -706,10 +705,8 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
   const int m = an.m, nent = (int)an.ent_a.size();
   DevTree T = h->tree();
   if (phases & 1) {
-    if (an.shard_count <= 1 && h->panel_cleared) {  // (a large arena: cleared by do_factor in front of the graph)
-      k_clear<<<1, 256, 0, s>>>(nullptr, 0, h->flags.p);
-    } else if (an.shard_count <= 1) {  // the panel arena, and the status words, counters and the two maxima
-      k_clear<<<(int)std::max<long long>(1, std::min<long long>(4096, (an.panel_elems / 2 + 1023) / 1024)), 256, 0, s>>>(h->panel.p, an.panel_elems, h->flags.p);
+    if (an.shard_count <= 1) {  // the panel arena, and the status words, counters and the two maxima
+      k_clear<<<(int)std::max<long long>(1, std::min<long long>(2048, (an.panel_elems / 2 + 1023) / 1024)), 256, 0, s>>>(h->panel.p, an.panel_elems, h->flags.p);
     } else {  // only the blocks this rank writes
       const int np = (int)an.zero_panel.size() / 2;
       if (np) k_zero_ranges<<<dim3(512, np), 256, 0, s>>>(h->panel.p, h->zero_panel.p);
@@ -992,12 +989,6 @@ static int do_factor(hqpkkt_t *h, const Vecs &v) {
     return graphed(h, h->gfactor[0], [&]() { return staged_run_factor(h, v.z, v.w); });
   }
   if (an.shard_count <= 1) {
-    // A large panel arena (C2: 0.21 GB) is cleared by the runtime's fill IN FRONT of the graph - 17 us faster than k_clear
-    // at that size, and not a memset NODE (see k_clear); small arenas (the trees of the interior-point loops) inside it.
-    // HQPKKT_CLEAR_IN_GRAPH: always inside
-    static const bool inside = getenv("HQPKKT_CLEAR_IN_GRAPH") != nullptr;
-    h->panel_cleared = !inside && an.panel_elems >= (4LL << 20) && h->use_graphs && !h->prof.on;
-    if (h->panel_cleared) HIPCHK(hipMemsetAsync(h->panel.p, 0, sizeof(double) * an.panel_elems, h->stream));
     if (an.m > 0 && v.z != h->vin.p) {  // the caller's device vectors themselves (direct_vectors)
       const void *key[10] = {v.z, v.w};
       return graphed(h, h->direct_slot(h->gdirect_factor, key), [&]() { return run_factor(h, v.z, v.w, 3); });
