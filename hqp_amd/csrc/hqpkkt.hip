@@ -706,7 +706,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
   DevTree T = h->tree();
   if (phases & 1) {
     if (an.shard_count <= 1) {  // the panel arena, and the status words, counters and the two maxima
-      k_clear<<<(int)std::max<long long>(1, std::min<long long>(2048, (an.panel_elems / 2 + 1023) / 1024)), 256, 0, s>>>(h->panel.p, an.panel_elems, h->flags.p);
+      KLAUNCH(h, KC_ASSEMBLE, k_clear<<<(int)std::max<long long>(1, std::min<long long>(2048, (an.panel_elems / 2 + 1023) / 1024)), 256, 0, s>>>(h->panel.p, an.panel_elems, h->flags.p));
     } else {  // only the blocks this rank writes
       const int np = (int)an.zero_panel.size() / 2;
       if (np) k_zero_ranges<<<dim3(512, np), 256, 0, s>>>(h->panel.p, h->zero_panel.p);
