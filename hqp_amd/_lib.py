@@ -59,7 +59,8 @@ class Stats(C.Structure):
                 ("shard_rank", C.c_int), ("shard_count", C.c_int), ("n_top", C.c_int),
                 ("n_exchange_blocks", C.c_int), ("flops_local", C.c_longlong),
                 ("flops_top", C.c_longlong), ("bytes_exchange_factor", C.c_longlong),
-                ("bytes_exchange_step", C.c_longlong), ("n_slow_pivots", C.c_int)]
+                ("bytes_exchange_step", C.c_longlong), ("n_slow_pivots", C.c_int),
+                ("n_poll_fallbacks", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -263,6 +263,7 @@ struct hqpkkt {
   // (one read-back per iteration); residual_pending: such a residual is in the stream, collect_residual() reads it
   bool defer_residual = false, residual_pending = false;
   int res_slot = 0, res_read = 122;  // which of the two residual words the next residual kernel uses / the last one used
+  bool no_polled = false;      // a polled launch gave up once: per-level launches for the rest of the handle's life (poll_fallback)
   bool soft_singular = false;  // the factorisation perturbed an exactly zero pivot (counters[3])
   bool soft_tiny = false;      // ... or met a pivot below 1e-13 max|K| on a multiplier-type row (counters[4])
   double refine_target = 0.0;  // > 0: the refinement of hqpkkt_solve aims below mat_eps (set by hqpkkt_franke)
@@ -370,6 +371,23 @@ static int reset_solve_top(hqpkkt_t *h) {
 
   }
   return 0;
+}
+
+// A polled launch gave up (flags[XW_GAVE_UP] in the words `hs` read back from the device): the exchange arrays go back
+// to their idle state and the handle switches - for good - to the per-level launches, which wait for nothing inside a
+// launch (the polled launches rest on workgroups being dispatched in index order, which HIP does not promise:
+// DESIGN.md section 2a).  Returns true when that happened: the caller's operation has to be run again.
+static const int HQPKKT_E_POLL = -7001;  // internal: never leaves the library (the entry points run the call again)
+static bool poll_fallback(hqpkkt_t *h, const int *hs) {
+  if (!hs[XW_GAVE_UP]) return false;
+  (void)reset_solve_top(h);
+  (void)hipMemsetAsync(h->flags.p + XW_GAVE_UP, 0, sizeof(int), h->stream);
+  (void)hipStreamSynchronize(h->stream);
+  h->top_n = 0, h->small_tree = false, h->tree_factor = false, h->no_polled = true;  // (no_polled: a later upload stays there)
+  h->drop_graphs();
+  h->st.n_poll_fallbacks++;
+  if (getenv("HQPKKT_TRACE_SOLVE")) fprintf(stderr, "a polled launch gave up: per-level launches from now on\n");
+  return true;
 }
 
 static int upload(hqpkkt_t *h) {
@@ -499,9 +517,14 @@ static int upload(hqpkkt_t *h) {
     std::vector<int> two(2, 0);
     if ((e = h->tree_words.upload(two))) return e;
   }
+  {  // tries before a poll gives up (HQPKKT_POLL_LIMIT: a test hook that forces the fall-back of poll_fallback)
+    const char *pl = getenv("HQPKKT_POLL_LIMIT");
+    const int lim = pl ? atoi(pl) : 1 << 20;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(xw_poll_limit), &lim, sizeof(int)));
+  }
   // a tree of small fronts only: whole-tree sweeps
   h->small_tree = false, h->tree_factor = false;
-  if (!getenv("HQPKKT_NO_TREE_SWEEPS") && an.shard_count == 1 && an.sched[0].nnodes > 1 && an.sched[1].nnodes == 0) {
+  if (!getenv("HQPKKT_NO_TREE_SWEEPS") && !h->no_polled && an.shard_count == 1 && an.sched[0].nnodes > 1 && an.sched[1].nnodes == 0) {
     const Analysis::Sched &S = an.sched[0];
     bool all = true;
     for (int l = 0; l < an.nlevels && all; l++) all = S.level_fsmall[l] == S.level_ptr[l + 1] - S.level_ptr[l];
@@ -519,7 +542,7 @@ static int upload(hqpkkt_t *h) {
   // the fused top of the solve sweeps: the highest levels whose fronts all fit one instance of k_solve_top, at most
   // ST_MAXFRONTS fronts (single rank: with a sharded tree the two sweeps of a schedule are not adjacent)
   h->top_n = 0, h->top_lt = 1 << 30, h->top_lds = 0;
-  if (!getenv("HQPKKT_NO_SOLVE_TOP") && an.shard_count == 1 && an.sched[0].nnodes > 0) {
+  if (!getenv("HQPKKT_NO_SOLVE_TOP") && !h->no_polled && an.shard_count == 1 && an.sched[0].nnodes > 0) {
     const Analysis::Sched &S = an.sched[0];
     int lt = an.nlevels, cnt = 0, maxp = 0;
     bool ok3 = true, ok4 = true;  // the instances <3, 11> and <4, 10>
@@ -570,9 +593,14 @@ static int upload(hqpkkt_t *h) {
     // the attribute is state of the PROCESS, not of the handle: a second handle with smaller fronts must
     // not lower the limit under one that still launches with more (several plugins in one host, the
     // bench's concurrent systems): keep the largest value ever asked for, under a mutex
+    // ... and hipFuncSetAttribute acts on the CURRENT device: the largest values are kept per device
     static std::mutex attr_mutex;
-    static size_t a_diag = 0, a_panel = 0, a_bwdb = 0, a_blk = 0, a_top = 0;
+    struct PerDev { size_t diag = 0, panel = 0, bwdb = 0, blk = 0, top = 0; };
+    static PerDev per_dev[64];
+    if (h->opts.device < 0 || h->opts.device >= 64) return HQPKKT_E_RANGE;
     std::lock_guard<std::mutex> lk(attr_mutex);
+    size_t &a_diag = per_dev[h->opts.device].diag, &a_panel = per_dev[h->opts.device].panel, &a_bwdb = per_dev[h->opts.device].bwdb,
+           &a_blk = per_dev[h->opts.device].blk, &a_top = per_dev[h->opts.device].top;
     if (h->top_lds > a_top) {
       const int l3 = (int)std::min(h->top_lds, st_top_lds_bytes(176, 3)), l4 = (int)std::min(h->top_lds, st_top_lds_bytes(160, 4));
       HIPCHK(hipFuncSetAttribute((const void *)k_solve_top<3, 11, 0>, hipFuncAttributeMaxDynamicSharedMemorySize, l3));
@@ -1011,8 +1039,10 @@ static int do_factor(hqpkkt_t *h, const Vecs &v) {
 static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
   Analysis &an = h->an;
   int e;
-  if (h->opts.mode == HQPKKT_MODE_STAGED)
+  if (h->opts.mode == HQPKKT_MODE_STAGED) {
+    if (staged_is_sharded(h)) return staged_run_step(h, v);  // exchanges inside the sweeps: not captured
     return graphed(h, h->gstep[which][0], [&]() { return staged_run_step(h, v); });
+  }
   if (an.shard_count <= 1) {
     // the caller's device vectors themselves (direct_vectors): also the refinement's sequence (which == 1: residual and
     // correction vectors are the handle's, z and w the caller's)
@@ -1081,16 +1111,13 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
 
 // the words run_residual copied to the pinned buffer, after the stream has been waited for
 static int collect_residual(hqpkkt_t *h, double *res) {
-  hipStream_t s = h->stream;
   h->residual_pending = false;
   const bool check = h->factor_unchecked;
   int *hs = (int *)h->hpin;
   int flags[4] = {hs[0], hs[1], hs[2], hs[3]};
-  if (hs[ST_GAVE_UP]) {  // k_solve_top gave up waiting for a word: rebuild its exchange arrays, report, do not hang
-    (void)reset_solve_top(h);
-    (void)hipMemsetAsync(h->flags.p + ST_GAVE_UP, 0, sizeof(int), s);
-    (void)hipStreamSynchronize(s);
-    return HQPKKT_E_DEVICE;
+  if (poll_fallback(h, hs)) {  // a polled launch gave up waiting for a word: no result, and per-level launches from now on
+    if (h->factor_unchecked) h->factor_unchecked = false, h->factored = false;  // (the factorisation may be the one that gave up)
+    return HQPKKT_E_POLL;
   }
   unsigned long long kb, bits;
   std::memcpy(&kb, hs + 120, sizeof(kb)), std::memcpy(&bits, hs + h->res_read, sizeof(bits));
@@ -1128,6 +1155,18 @@ static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, 
   int nzmax = 1, npmax = 1;
   for (int k = 0; k < P.K; k++) nzmax = std::max(nzmax, P.nk[k] + P.mk[k]), npmax = std::max(npmax, P.nk[k + 1]);
   nzmax = std::max(nzmax, P.nk[P.K]);
+  if (P.sharded) {
+    // the rank's share of both products from its local blocks (staged.hip.h, DynLoc), summed over the ranks
+    const long long tot = d.dyn_sum_x2 + P.ndyn;
+    KLAUNCH(h, KC_RESIDUAL, stg::k_st_zero<<<nblk(tot), 256, 0, h->stream>>>(tot, d.dyn_sum.p));
+    KLAUNCH(h, KC_RESIDUAL, stg::k_st_dynloc_ax<<<dim3(std::min((npmax + 3) / 4, 2048), P.K), 256, 0, h->stream>>>(d.dyn_loc.p, d.F.p, v.dx,
+                                                                                                           d.dyn_sum.p + d.dyn_sum_x2));
+    KLAUNCH(h, KC_RESIDUAL, stg::k_st_dynloc_aty<<<dim3((nzmax + 255) / 256, P.K + 1), 256, 0, h->stream>>>(d.dyn_loc.p, d.F.p, v.dy, d.dyn_sum.p));
+    int e = exchange(h, HQPKKT_XCHG_ALLREDUCE_SUM, d.dyn_sum.p, tot, 1);
+    if (e) return e;
+    *x1 = d.dyn_sum.p, *x2 = d.dyn_sum.p + d.dyn_sum_x2, *ndyn = P.ndyn;
+    return 0;
+  }
   static const bool two_passes = getenv("HQPKKT_RESIDUAL_TWO_PASSES") != nullptr;
   const int nbc = (nzmax + 255) / 256;
   if (!two_passes && d.dyn_part.p && d.dyn_part_cols == nbc) {
@@ -1414,7 +1453,14 @@ static int solve_vecs(hqpkkt_t *h, const double *z, const double *w, const doubl
   return 0;
 }
 
+static int factor_once(hqpkkt_t *h, const double *z, const double *w);
+// (a polled launch that gave up has switched the handle to the per-level launches: once more, then)
 int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
+  int e = factor_once(h, z, w);
+  if (e == HQPKKT_E_POLL) e = factor_once(h, z, w);
+  return e == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : e;
+}
+static int factor_once(hqpkkt_t *h, const double *z, const double *w) {
   if (!h) return HQPKKT_E_NULL;
   if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
   if (h->an.m > 0 && (!z || !w)) return HQPKKT_E_NULL;
@@ -1442,6 +1488,7 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   int *hs = (int *)h->hpin;
   HIPCHK(hipMemcpyAsync(hs, h->flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (poll_fallback(h, hs)) return HQPKKT_E_POLL;  // (factored stays false)
   const int flags[4] = {hs[0], hs[1], hs[2], hs[3]};
   std::memcpy(&h->st.kmax, hs + 120, sizeof(double));
   h->prof.collect();
@@ -1464,9 +1511,17 @@ int hqpkkt_factor(hqpkkt_t *h, const double *z, const double *w) {
   return 0;
 }
 
+static int step_once(hqpkkt_t *h, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
+                     const double *r4, double *dx, double *dy, double *dz, double *dw);
 int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w, const double *r1,
                 const double *r2, const double *r3, const double *r4, double *dx, double *dy,
                 double *dz, double *dw) {
+  int e = step_once(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw);
+  if (e == HQPKKT_E_POLL) e = step_once(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw);
+  return e == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : e;
+}
+static int step_once(hqpkkt_t *h, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
+                     const double *r4, double *dx, double *dy, double *dz, double *dw) {
   if (!h) return HQPKKT_E_NULL;
   if (!h->factored) return HQPKKT_E_INTERN;
   HIPCHK(hipSetDevice(h->opts.device));
@@ -1478,7 +1533,10 @@ int hqpkkt_step(hqpkkt_t *h, const double *z, const double *w, const double *r1,
   if ((e = do_step(h, v, 0))) return e;
   HIPCHK(hipEventRecord(h->evs1, h->stream));
   if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
+  int *hs = (int *)h->hpin;  // the give-up word of the polled sweeps comes back with the result
+  HIPCHK(hipMemcpyAsync(hs + XW_GAVE_UP, h->flags.p + XW_GAVE_UP, sizeof(int), hipMemcpyDeviceToHost, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
+  if (poll_fallback(h, hs)) return HQPKKT_E_POLL;
   unstage(h, dx, dy, dz, dw);
   h->prof.collect();
   h->st.ms_step = elapsed(h->evs0, h->evs1);
@@ -1507,6 +1565,7 @@ int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w, const double 
   }
   HIPCHK(hipEventRecord(h->evs0, h->stream));
   e = run_residual(h, v, res);
+  if (e == HQPKKT_E_POLL) e = HQPKKT_E_DEVICE;  // (a stale word: the residual kernels poll nothing)
   HIPCHK(hipEventRecord(h->evs1, h->stream));
   HIPCHK(hipStreamSynchronize(h->stream));
   h->prof.collect();
@@ -1517,9 +1576,19 @@ int hqpkkt_residual(hqpkkt_t *h, const double *z, const double *w, const double 
 static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
                       const double *r4, double *dx, double *dy, double *dz, double *dw, double res, double *res_out);
 // Hqp_IpMatrix::solve (hqp/Hqp_IpMatrix.C:65-128)
+static int solve_once(hqpkkt_t *h, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
+                      const double *r4, double *dx, double *dy, double *dz, double *dw, double *res_out);
 int hqpkkt_solve(hqpkkt_t *h, const double *z, const double *w, const double *r1,
                  const double *r2, const double *r3, const double *r4, double *dx, double *dy,
                  double *dz, double *dw, double *res_out) {
+  int e = solve_once(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res_out);
+  // a polled sweep gave up: the factors are those of the per-level kernels as well (bit-identical), the solve runs again
+  // on the per-level launches.  (Inside the device-resident loops - lazy - the loop itself is run again.)
+  if (e == HQPKKT_E_POLL && h->factored && !h->lazy) e = solve_once(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res_out);
+  return e == HQPKKT_E_POLL && !h->lazy ? HQPKKT_E_DEVICE : e;
+}
+static int solve_once(hqpkkt_t *h, const double *z, const double *w, const double *r1, const double *r2, const double *r3,
+                      const double *r4, double *dx, double *dy, double *dz, double *dw, double *res_out) {
   if (!h) return HQPKKT_E_NULL;
   if (!h->factored) return HQPKKT_E_INTERN;
   HIPCHK(hipSetDevice(h->opts.device));
@@ -1649,7 +1718,7 @@ int hqpkkt_default_ip_opts(hqpkkt_ip_opts *o) {
 
 int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
                     const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
-  return guarded([&]() -> int {
+  auto loop = [&]() -> int {
     if (!h || !res) return HQPKKT_E_NULL;
     if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
     if (opts && opts->max_iters < 0) return HQPKKT_E_RANGE;
@@ -2027,7 +2096,11 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     iter += fail_iters;
     if (m > 0) h->ip_hot_valid = keep_hot;
     return finish(result);
-  });
+  };
+  // (a polled launch that gave up has switched the handle to the per-level launches: the loop runs once more)
+  int rc = guarded(loop);
+  if (rc == HQPKKT_E_POLL) rc = guarded(loop);
+  return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
 }
 
 // ---- device-resident Franke loop ----------------------------------------------
@@ -2036,7 +2109,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
 // the gap and rhomin, the step length, zeta) live on the host as in the reference.
 int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,
                   const double *d, double *x, double *y, double *z, double *w, hqpkkt_ip_result *res) {
-  return guarded([&]() -> int {
+  auto loop = [&]() -> int {
     if (!h || !res) return HQPKKT_E_NULL;
     if (!h->analyzed || !h->have_values) return HQPKKT_E_INTERN;
     if (opts && opts->max_iters < 0) return HQPKKT_E_RANGE;
@@ -2206,7 +2279,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
         HIPCHK(hipStreamSynchronize(s));
         return 0;
       };
-      const double target = std::fmin(h->opts.eps, h->refine_target);
+      const double target = h->refine_target > 0.0 ? std::fmin(h->opts.eps, h->refine_target) : h->opts.eps;  // (as solve_tail)
       h->defer_residual = !getenv("HQPKKT_FRANKE_TWO_READS");
       e = hqpkkt_factor(h, C.z, C.w);
       if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
@@ -2284,7 +2357,11 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     h->fr_hot_valid = m > 0 && result != 4;
     h->fr_rhomin = rhomin;
     return finish(result);
-  });
+  };
+  // (a polled launch that gave up has switched the handle to the per-level launches: the loop runs once more)
+  int rc = guarded(loop);
+  if (rc == HQPKKT_E_POLL) rc = guarded(loop);
+  return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
 }
 
 int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {
@@ -2482,8 +2559,7 @@ int hqpkkt_set_stage_block(hqpkkt_t *h, int k, const double *F, long long ldF) {
     if (ldF < nz) return HQPKKT_E_SIZES;
     HIPCHK(hipSetDevice(h->opts.device));
     const hipMemcpyKind kind = h->opts.loc == HQPKKT_LOC_DEVICE ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice;
-    HIPCHK(hipMemcpy2DAsync(d.F.p + P.oF[k], sizeof(double) * P.ldf[k], F, sizeof(double) * ldF, sizeof(double) * nz, P.nk[k + 1], kind,
-                            h->stream));
+    if ((e = staged_copy_block(h, k, F, ldF, kind))) return e;
     for (int b = 0; b < 2; b++)
       if (F == d.hblk[b]) {  // the library's own staging buffer: remember when it is free again
         if (!d.hblk_ev[b]) HIPCHK(hipEventCreateWithFlags(&d.hblk_ev[b], hipEventDisableTiming));
@@ -2744,6 +2820,10 @@ int hqpkkt_debug_solve_top_stamps(hqpkkt_t *h, double *out, int cap) {
   int e = do_step(h, v, 0);
   if (!e && hipStreamSynchronize(h->stream) != hipSuccess) e = HQPKKT_E_DEVICE;
   h->use_graphs = graphs, h->top_stamps = nullptr;
+  if (!e) {  // stamps of a sweep that gave up on a poll mean nothing
+    int gave_up[XW_GAVE_UP + 1] = {};
+    if (hipMemcpy(gave_up + XW_GAVE_UP, h->flags.p + XW_GAVE_UP, sizeof(int), hipMemcpyDeviceToHost) != hipSuccess || poll_fallback(h, gave_up)) e = HQPKKT_E_DEVICE;
+  }
   std::vector<unsigned long long> hs(8 * (size_t)h->top_n);
   if (!e && hipMemcpy(hs.data(), st, sizeof(unsigned long long) * hs.size(), hipMemcpyDeviceToHost) != hipSuccess) e = HQPKKT_E_DEVICE;
   (void)hipFree(st);

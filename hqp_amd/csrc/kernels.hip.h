@@ -996,6 +996,9 @@ int dn;
 // puts the sentinel back into ITS words of the other copy, which nobody reads during this solve.
 static const unsigned long long XW_SENTINEL = 0x7ff8dead0badc0deULL;
 static const int XW_GAVE_UP = 110;  // index into the handle's flags buffer: a poll gave up (~2^20 tries)
+// tries before a poll gives up.  A device global so that a test can shorten it (HQPKKT_POLL_LIMIT, read when a handle
+// uploads its tree): with 0 every poll that has to wait gives up, which forces the fall-back to the per-level launches.
+__device__ int xw_poll_limit = 1 << 20;
 __device__ __forceinline__ unsigned long long xw_peek(const double *p) {
   return __hip_atomic_load((const unsigned long long *)p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
@@ -1008,7 +1011,7 @@ __device__ __forceinline__ void xw_clear(double *p) {
 __device__ __forceinline__ double xw_take(const double *p, int *flags) {
   unsigned long long v = xw_peek(p);
   for (int n = 0; v == XW_SENTINEL; n++) {
-    if (n > (1 << 20)) {
+    if (n >= xw_poll_limit) {
       __hip_atomic_store(flags + XW_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return 0.0;
     }
@@ -1214,7 +1217,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
                   wait = wait || (j < bc0 && ii < bc0 && ii >= j && w0[u] == XW_SENTINEL) ||
                          (j < bc1 && ii < bc1 && ii >= j && w1[u] == XW_SENTINEL);
                 }
-              if (wait && tries > (1 << 20)) {
+              if (wait && tries >= xw_poll_limit) {
                 __hip_atomic_store(counters - 1 + XW_GAVE_UP, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 wait = false;
               }

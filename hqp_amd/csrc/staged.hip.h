@@ -28,14 +28,31 @@ using kktdev::mfma_f64;
 
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
-// One system over several ranks: where the strips of a stage's G_xx lie in the exchange buffer.  Rank p owns the
-// state columns [cut[p], cut[p+1]) (multiples of 128, so a tile lies inside one strip) and delivers the rows
-// i >= cut[p] of them, row-major with leading dimension cut[p+1] - cut[p], at xbuf + off[p].
+// One system over several ranks (staged_plan.hpp): rank p owns the state columns [cut[p], cut[p+1]) of a stage
+// (multiples of 128, so a tile lies inside one strip).  StripTab: where the ranks' strips of W lie after the first
+// exchange of a stage - strip p = n+ rows of cut[p+1] - cut[p] columns, row-major, at xw + off[p].
 struct StripTab {
   int nranks;
   int cut[17];
   long long off[17];
 };
+// ... and where the blocks of G_xx lie after the second: block (a, b), a >= b, = rows of strip a x columns of strip b in
+// one part, or in two cut at row rsplit (the pairs half the ring apart, staged_plan.cpp); part t row-major with leading
+// dimension cut[b+1] - cut[b] at x + off[t]
+struct RectTab {
+  int nranks;
+  int cut[17];
+  struct Block {
+    long long off[2];
+    int rsplit;  // first row of the second part (a large number: one part)
+    int pad;
+  } blk[16 * 16];  // [a * 16 + b]
+};
+static __device__ __forceinline__ int strip_of(const int *cut, int nranks, int j) {
+  int p = 0;
+  while (p + 1 < nranks && cut[p + 1] <= j) p++;
+  return p;
+}
 
 struct GemmArgs {
   const double *A;
@@ -50,13 +67,15 @@ struct GemmArgs {
   double alpha, beta;
   int lower;   // only tiles with tile row >= tile column (M == N)
   int mirror;  // with lower: C[j][i] = C[i][j] as well (exactly symmetric result)
-  const int *tile_map;  // lower, 128 x 128 tiles: tile index -> tile row << 16 | tile column, in blocks of
+  const int *tile_map;  // 128 x 128 tiles: tile index -> tile row << 16 | tile column.  Lower: in blocks of
                         // 8 x 8 tiles (neighbours in the launch order share operand panels in their XCD's L2);
-                        // null: row by row
+                        // not lower: the tiles of a launch that computes a part of the product only (the blocks of G_xx
+                        // one rank owns, bstrips); null: row by row
   const double *zeros;  // >= 128 zero doubles (16-byte aligned): the source of the operand rows k >= K when the
                         // 128 x 128 kernels stage their operands by LDS-DMA; null: staging through registers
-  const StripTab *strips;      // with beta != 0: Cin(i, j), i >= j, is read from the strips of the exchange buffer `Cin`
+  const RectTab *rects;        // with beta != 0: Cin(i, j), i >= j, is read from the blocks in the exchange buffer `Cin`
                                // (the rank-q update of a sharded stage takes G_xx straight from what the ranks sent)
+  const StripTab *bstrips;     // the columns of B come from the ranks' strips in the exchange buffer `B` (128-wide tiles)
   unsigned long long *stamps;  // diagnostic builds of the plain kernel only (hqpkkt_debug_dgemm): 4 constant-clock
                                // (100 MHz) time stamps per workgroup: start, operands of the first slab in LDS, end of
                                // the k loop, end of the epilogue; null in every product of the engine
@@ -115,7 +134,7 @@ struct GemmTile {
 
   // tile index -> (tile row, tile column)
   static __device__ __forceinline__ void tile_of(const GemmArgs &g, int t, int &tm, int &tn) {
-    if (g.lower && g.tile_map && BM == 128) {
+    if (g.tile_map && BM == 128) {
       const int e = g.tile_map[t];
       tm = e >> 16, tn = e & 0xffff;
     } else if (g.lower) {
@@ -152,7 +171,14 @@ struct GemmTile {
     const int cb = 2 * (tid % (BN / 2)), rb = tid / (BN / 2);
     // a 16-byte load is inside its row when its first column is < ld (ld even)
     const long long acol = (i0 + ca < g.lda) ? i0 + ca : 0;
-    const long long bcol = (j0 + cb < g.ldb) ? j0 + cb : 0;
+    const double *Bp = g.B;
+    long long ldb = g.ldb;
+    int jb = j0;  // first column of the tile inside its B block
+    if (g.bstrips) {
+      const int q = strip_of(g.bstrips->cut, g.bstrips->nranks, j0);
+      Bp = g.B + g.bstrips->off[q], ldb = g.bstrips->cut[q + 1] - g.bstrips->cut[q], jb = j0 - g.bstrips->cut[q];
+    }
+    const long long bcol = (jb + cb < ldb) ? jb + cb : 0;
     // D register sets: the loads of slab t + D are issued before the multiplications of slab t and consumed (masked
     // for k >= K, stored to LDS) after those of slab t + D - 1.  With 64 x 64 tiles a slab is 16 multiplications per
     // wavefront (0.4 us) and a load from L2 takes 1.4: one set (round 2) left the loop waiting for its loads - 1.44 us
@@ -174,7 +200,7 @@ struct GemmTile {
 #pragma unroll
       for (int p = 0; p < LB; p++) {
         const int k = k0 + rb + p * RB, kc = k < g.K ? k : g.K - 1;
-        xb[p] = *(const double2_t *)(g.B + (long long)kc * g.ldb + bcol);
+        xb[p] = *(const double2_t *)(Bp + (long long)kc * ldb + bcol);
       }
     };
     auto lstore = [&](int buf, const double2_t(&xa)[LA], const double2_t(&xb)[LB], int slab) {
@@ -371,8 +397,14 @@ struct GemmTile {
     const int wm = wave / WGN, wn = wave % WGN;
     const int lr = lane & 15, lk = lane >> 4;
     // a 16-byte load is inside its row when its first column is < ld (ld even)
+    GemmArgs gl = g;  // (B and its leading dimension: the strip of the tile's columns)
+    int jb = j0;
+    if (g.bstrips) {
+      const int q = strip_of(g.bstrips->cut, g.bstrips->nranks, j0);
+      gl.B = g.B + g.bstrips->off[q], gl.ldb = g.bstrips->cut[q + 1] - g.bstrips->cut[q], jb = j0 - g.bstrips->cut[q];
+    }
     const double *pa = g.A + ((i0 + 2 * lane < g.lda) ? i0 + 2 * lane : 0);
-    const double *pb = g.B + ((j0 + 2 * lane < g.ldb) ? j0 + 2 * lane : 0);
+    const double *pb = gl.B + ((jb + 2 * lane < gl.ldb) ? jb + 2 * lane : 0);
     const double *zr = g.zeros + 2 * lane;
     unsigned mask = 0;
 #pragma unroll
@@ -387,13 +419,13 @@ struct GemmTile {
     const bool all = mask == (TM * TN == 32 ? 0xffffffffu : (1u << (TM * TN)) - 1u);
     if (nbuf == 3) {
       if (all)
-        slabs_dma3<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+        slabs_dma3<false>(gl, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
       else
-        slabs_dma3<true>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+        slabs_dma3<true>(gl, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
     } else if (all)
-      slabs_dma<false>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+      slabs_dma<false>(gl, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
     else
-      slabs_dma<true>(g, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
+      slabs_dma<true>(gl, pa, pb, zr, wave, wm, wn, lr, lk, s0, s1, mask, acc, As, Bs);
   }
 
   // `lds`: the workgroup's LDS (free after accumulate's last barrier), used to write the MIRROR image of an
@@ -410,12 +442,13 @@ struct GemmTile {
     const bool diag = g.lower && tm == tn;
     const double *cin = g.Cin;
     long long ldcin = g.ldcin;
-    if (g.strips && g.beta != 0.0) {  // the strip that holds the columns of this tile
-      int p = 0;
-      while (p + 1 < g.strips->nranks && g.strips->cut[p + 1] <= j0) p++;
-      const int c0 = g.strips->cut[p];
-      ldcin = g.strips->cut[p + 1] - c0;
-      cin = g.Cin + g.strips->off[p] - ((long long)c0 * ldcin + c0);
+    if (g.rects && g.beta != 0.0) {  // the block (part) that holds this tile
+      const RectTab &R = *g.rects;
+      const int a = strip_of(R.cut, R.nranks, i0), b = strip_of(R.cut, R.nranks, j0);
+      const RectTab::Block &blk = R.blk[a * 16 + b];
+      const int t = i0 >= blk.rsplit ? 1 : 0, r0 = t ? blk.rsplit : R.cut[a], c0 = R.cut[b];
+      ldcin = R.cut[b + 1] - c0;
+      cin = g.Cin + blk.off[t] - ((long long)r0 * ldcin + c0);
     }
     constexpr int HC = BN < 64 ? BN : 64, LDT = BM + 2;  // columns per pass of the mirrored write
     const bool via_lds = g.mirror && !diag && lds != nullptr;
@@ -2582,14 +2615,75 @@ __global__ void k_st_copy(int n, const double *__restrict__ s, double *__restric
 }
 
 // ---------------------------------------------------------------------------------------
-// One system over several ranks: rank p computes the columns [c0, c1) of the lower triangle of G_xx (rows c0 ..
-// n-1: a strip (n - c0) x (c1 - c0), row-major in its part of the exchange buffer); after the exchange every rank
-// forms V_k = G_xx - Y' Rm from all strips (GemmArgs::strips: unpack, rank-q update and mirror in one pass).
-__global__ void __launch_bounds__(256) k_st_pack(const double *__restrict__ V, long long ldv, int n, int c0, int c1,
-                                                 double *__restrict__ slot) {
-  const int w = c1 - c0;
-  for (int i = c0 + blockIdx.x; i < n; i += gridDim.x)
-    for (int jj = threadIdx.x; jj < w; jj += blockDim.x) slot[(long long)(i - c0) * w + jj] = V[(long long)i * ldv + c0 + jj];
+// One system over several ranks (staged_plan.hpp).  The blocks of G_xx this rank has computed in its row strip of the
+// work block G go into its slot of the second exchange buffer in LOWER orientation: a block of its own rows as it is,
+// a block it computed for the partner's rows (rows = its own columns) transposed.  blockIdx.y = block.
+struct PackRect {
+  int r0, c0, rows, cols;  // where the block lies in G (work orientation) and its size there
+  int transpose;           // the slot holds it transposed: cols x rows, leading dimension rows
+  int pad;
+  long long off;           // into this rank's slot
+};
+__global__ void __launch_bounds__(256) k_st_pack_rects(const PackRect *__restrict__ rects, const double *__restrict__ G, long long ldg,
+                                                       double *__restrict__ slot) {
+  __shared__ double t[32][33];
+  const PackRect r = rects[blockIdx.y];
+  double *dst = slot + r.off;
+  if (!r.transpose) {
+    for (int i = blockIdx.x; i < r.rows; i += gridDim.x) {
+      const double *src = G + (long long)(r.r0 + i) * ldg + r.c0;
+      for (int j = threadIdx.x; j < r.cols; j += blockDim.x) dst[(long long)i * r.cols + j] = src[j];
+    }
+    return;
+  }
+  // 32 x 32 tiles through LDS: rows of G are read, rows of the transposed block written
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+  const int tr = (r.rows + 31) / 32, tc = (r.cols + 31) / 32;
+  for (int tile = blockIdx.x; tile < tr * tc; tile += gridDim.x) {
+    const int i0 = (tile / tc) * 32, j0 = (tile % tc) * 32;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int i = i0 + ty + 8 * u, j = j0 + tx;
+      t[ty + 8 * u][tx] = (i < r.rows && j < r.cols) ? G[(long long)(r.r0 + i) * ldg + r.c0 + j] : 0.0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      const int j = j0 + ty + 8 * u, i = i0 + tx;
+      if (i < r.rows && j < r.cols) dst[(long long)j * r.rows + i] = t[tx][ty + 8 * u];
+    }
+    __syncthreads();
+  }
+}
+// The first exchange of a stage carries, behind the n+ rows of every rank's W strip, its columns of the control rows of
+// G (W_u' F_p: m rows) and of the carried rows (B+ F_p: capx rows): into their places in G and N.  blockIdx.y = rank.
+__global__ void __launch_bounds__(256) k_st_unpack_extra(const StripTab *__restrict__ tab, const double *__restrict__ xw, int np, int m, int capx,
+                                                         double *__restrict__ Gu, long long ldg, double *__restrict__ Nc, long long ldn) {
+  const int q = blockIdx.y, c0 = tab->cut[q], w = tab->cut[q + 1] - c0;
+  const double *src = xw + tab->off[q] + (long long)np * w;
+  for (int i = blockIdx.x; i < m + capx; i += gridDim.x) {
+    double *dst = i < m ? Gu + (long long)i * ldg + c0 : Nc + (long long)(i - m) * ldn + c0;
+    for (int j = threadIdx.x; j < w; j += blockDim.x) dst[j] = src[(long long)i * w + j];
+  }
+}
+// rows x cols block copy (the own row strip of V_k out of the transient full block)
+__global__ void __launch_bounds__(256) k_st_copy2d(const double *__restrict__ src, long long lds_, double *__restrict__ dst, long long ldd, int rows,
+                                                   int cols) {
+  for (int i = blockIdx.x; i < rows; i += gridDim.x)
+    for (int j = threadIdx.x; j < cols; j += blockDim.x) dst[(long long)i * ldd + j] = src[(long long)i * lds_ + j];
+}
+// y = add + the ranks' partial vectors in their order (x+ = F s + f over the column strips)
+__global__ void k_st_sum_slots(int n, int nslots, const double *__restrict__ slots, long long stride, const double *__restrict__ add,
+                               double *__restrict__ y) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  double s = add ? add[i] : 0.0;
+  for (int p = 0; p < nslots; p++) s += slots[(long long)p * stride + i];
+  y[i] = s;
+}
+__global__ void k_st_zero(long long n, double *__restrict__ y) {
+  const long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = 0.0;
 }
 // ---------------------------------------------------------------------------------------
 // Dense dynamics (hqpkkt_set_values_staged): the products with the dynamics rows of A that
@@ -2702,6 +2796,45 @@ __global__ void __launch_bounds__(256) k_st_dyn_aty(const DynDesc *__restrict__ 
     // x_k is the state the previous stage's dynamics produce: -1.0 in that row
     if (blockIdx.y > 0 && lc < d.ncur) s -= dy[d.row0 - d.ncur + lc];
     out1[d.col0 + lc] = s;
+  }
+}
+
+// The same two products when the F blocks are the LOCAL ones of a rank (Floc_k = [F_p | F_u], staged_plan.hpp): the rank
+// adds what its state columns contribute; the control columns, the -x_{k+1} of the dynamics rows and the -dy of the
+// rows that produce x_k are added once, by the rank that owns them (control columns: rank 0).  Both outputs start at
+// zero and are summed over the ranks afterwards.
+struct DynLoc {
+  long long oF;
+  int ldf, np, nz, col0, row0, ncur;  // as DynDesc (nz, ncur: of the whole stage)
+  int c0, wd, m;                      // own state columns [c0, c0 + wd), controls of the stage
+  int with_controls;                  // this rank adds the control columns' share
+};
+__global__ void __launch_bounds__(256) k_st_dynloc_ax(const DynLoc *__restrict__ desc, const double *__restrict__ F,
+                                                      const double *__restrict__ dx, double *__restrict__ out2) {
+  const DynLoc d = desc[blockIdx.y];
+  const int lane = threadIdx.x & 63;
+  const int nloc = d.wd + (d.with_controls ? d.m : 0);
+  for (int li = blockIdx.x * 4 + (threadIdx.x >> 6); li < d.np; li += gridDim.x * 4) {
+    const double *fr = F + d.oF + (long long)li * d.ldf;
+    double s = 0.0;
+    for (int j = lane; j < nloc; j += 64) s += fr[j] * dx[d.col0 + (j < d.wd ? d.c0 + j : d.ncur + (j - d.wd))];
+    s = kktdev::wave_sum(s);
+    // -x_{k+1}[li]: by the rank that owns row li of the next stage's states ... which only the host knows: rank 0 here
+    if (lane == 0) out2[d.row0 + li] = s - (d.with_controls ? dx[d.col0 + d.nz + li] : 0.0);
+  }
+}
+__global__ void __launch_bounds__(256) k_st_dynloc_aty(const DynLoc *__restrict__ desc, const double *__restrict__ F,
+                                                       const double *__restrict__ dy, double *__restrict__ out1) {
+  const DynLoc d = desc[blockIdx.y];
+  const int nloc = d.wd + (d.with_controls && d.np > 0 ? d.m : 0);
+  for (int lc = blockIdx.x * blockDim.x + threadIdx.x; lc < nloc; lc += gridDim.x * blockDim.x) {
+    const int gc = lc < d.wd ? d.c0 + lc : d.ncur + (lc - d.wd);
+    double s = 0.0;
+    const double *fc = F + d.oF + lc;
+    for (int li = 0; li < d.np; li++) s += fc[(long long)li * d.ldf] * dy[d.row0 + li];
+    // x_k is the state the previous stage's dynamics produce: -1.0 in that row
+    if (blockIdx.y > 0 && gc < d.ncur) s -= dy[d.row0 - d.ncur + gc];
+    out1[d.col0 + gc] = s;
   }
 }
 

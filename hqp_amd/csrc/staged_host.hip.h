@@ -18,7 +18,18 @@ struct StagedDev {
   long long hblk_elems = 0;
   hipEvent_t hblk_ev[2] = {nullptr, nullptr};
   std::vector<char> blocks_set;         // dense hand-over block by block: which stages have arrived since the analysis
-  DBuf<stg::StripTab> strip_tabs;  // sharded: per stage where the ranks' strips of G_xx lie in the exchange buffer
+  // one system over several ranks (staged_plan.hpp): per stage where the ranks' strips of W / blocks of G_xx lie in the
+  // exchange buffers, this rank's tiles of its blocks' products and its blocks to pack; the local dynamics blocks of
+  // residuum()'s products and their summed results (A_dyn' dy: n, A_dyn dx: ndyn)
+  DBuf<stg::StripTab> wtabs;
+  DBuf<stg::RectTab> rtabs;
+  DBuf<int> gtile;
+  DBuf<stg::PackRect> prects;
+  std::vector<int> prect_ptr;
+  DBuf<stg::DynLoc> dyn_loc;
+  DBuf<double> dyn_sum;
+  long long dyn_sum_x2 = 0;  // offset of A_dyn dx in dyn_sum
+  hipEvent_t ev_wu = nullptr, ev_x1 = nullptr;
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
   int cus = 0;
@@ -61,7 +72,9 @@ struct StagedDev {
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), dyn_part.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
-    strip_tabs.release();
+    wtabs.release(), rtabs.release(), gtile.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
+    if (ev_wu) (void)hipEventDestroy(ev_wu), ev_wu = nullptr;
+    if (ev_x1) (void)hipEventDestroy(ev_x1), ev_x1 = nullptr;
     for (int b = 0; b < 2; b++) {
       if (hblk[b]) (void)hipHostFree(hblk[b]), hblk[b] = nullptr;
       if (hblk_ev[b]) (void)hipEventDestroy(hblk_ev[b]), hblk_ev[b] = nullptr;
@@ -81,18 +94,20 @@ namespace {
 struct StagePtr {
   double *F, *V, *Y, *Rm, *Kinv, *Kmat, *N, *BT, *T, *v, *beta, *eta, *rho;
   int *dyn;
+  double *Vs;  // sharded: this rank's row strip of V_k (V: the transient full block; F: the local block [F_p | F_u])
 };
 inline StagePtr stage_ptr(StagedDev &d, int k) {
   const kktdev::StagedPlan &P = d.plan;
   StagePtr s{};
   double *M = d.misc.p;
-  s.V = d.V.p + P.oV[k];
+  s.V = P.sharded ? M + P.oVf[k & 1] : d.V.p + P.oV[k];
+  s.Vs = P.sharded ? d.V.p + P.oVs[k] : nullptr;
   s.BT = M + P.oBT[k], s.N = M + P.oN[k];
   const int capx = std::max(P.cap[k], 1);
   s.v = M + P.oVec[k], s.beta = s.v + P.nk[k], s.eta = s.beta + capx, s.rho = s.eta + capx;
   s.dyn = d.dyn.p + P.dyn_off[k];
   if (k < P.K) {
-    s.F = d.F.p + P.oF[k];
+    s.F = d.F.p + (P.sharded ? P.oFl[k] : P.oF[k]);
     s.Y = M + P.oY[k], s.Rm = M + P.oR[k], s.Kinv = M + P.oK[k], s.Kmat = M + P.oKm[k], s.T = M + P.oT[k];
   }
   return s;
@@ -277,16 +292,22 @@ static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = fa
   h->st.shard_rank = P.shard_rank, h->st.shard_count = P.shard_count;
   if (P.sharded) {
     long long bytes = 0, fl = 0;
+    const int NR = P.shard_count, RK = P.shard_rank;
     for (int k = 0; k < P.K; k++) {
-      bytes += (long long)sizeof(double) * P.xslot[k] * P.shard_count;
-      const int *cut = &P.xcut[(size_t)k * (P.shard_count + 1)];
-      const long long wd = cut[P.shard_rank + 1] - cut[P.shard_rank], c0 = cut[P.shard_rank];
-      const long long np = P.nk[k + 1], nz = P.nk[k] + P.mk[k], mm = P.mk[k], nn = P.nk[k], q = P.qmax[k];
-      // own columns of W and of the lower triangle of G_xx; replicated: the control columns of W, the control rows of
-      // G and the rank-q update of the whole block
-      fl += 2 * np * np * wd + 2 * np * wd * (nn - c0) - np * wd * wd + 2 * np * np * mm + 2 * np * mm * nz + q * nn * nn;
+      bytes += (long long)sizeof(double) * (P.xwslot[k] + P.xslot[k]) * NR;
+      const int *cut = &P.xcut[(size_t)k * (NR + 1)];
+      const long long wd = cut[RK + 1] - cut[RK];
+      const long long np = P.nk[k + 1], mm = P.mk[k], nn = P.nk[k], q = P.qmax[k], cx = P.cap[k + 1];
+      // own: the strip of W, its columns of the control rows of G and of the carried rows, the tiles of its blocks of
+      // G_xx; by every rank: the control columns, the rank-q update of the whole block
+      fl += 2 * np * np * wd + 2 * np * (mm + cx) * wd + 2 * np * 128LL * 128 * (P.gtile_ptr[k + 1] - P.gtile_ptr[k]);
+      fl += 2 * np * np * mm + 2 * np * mm * mm + q * nn * nn;
     }
-    h->st.bytes_exchange_factor = bytes, h->st.flops_local = fl, h->st.n_exchange_blocks = P.K;
+    h->st.bytes_exchange_factor = bytes, h->st.flops_local = fl, h->st.n_exchange_blocks = 2 * P.K;
+    // per solve: a state-sized vector per stage and direction, the partial sums of x+, the dynamics rows' multipliers
+    long long sb = 0;
+    for (int k = 0; k < P.K; k++) sb += (long long)sizeof(double) * (2LL * P.nk[k + 1] + (long long)NR * P.nk[k + 1]);
+    h->st.bytes_exchange_step = sb + (long long)sizeof(double) * P.ndyn;
   }
   return 0;
 }
@@ -337,7 +358,21 @@ static int staged_upload(hqpkkt_t *h) {
     for (size_t k = 0; k < t.size(); k++) t[k] = stg::HTerm{P.h_terms[k].s1, P.h_terms[k].s2, P.h_terms[k].wi};
     if ((e = d.h_terms.upload(t))) return e;
   }
-  if (P.dense_dyn) {
+  if (P.dense_dyn && P.sharded) {
+    // the local blocks: own state columns [c0, c0 + wd) and the control columns; rank 0 adds what belongs to nobody's strip
+    const int NR = P.shard_count, RK = P.shard_rank;
+    std::vector<stg::DynLoc> dl(P.K + 1);
+    for (int k = 0; k <= P.K; k++) {
+      stg::DynLoc &x = dl[k];
+      x.oF = k < P.K ? P.oFl[k] : 0, x.ldf = k < P.K ? P.ldfl[k] : 0;
+      x.np = k < P.K ? P.nk[k + 1] : 0, x.nz = k < P.K ? P.nk[k] + P.mk[k] : P.nk[k];
+      x.col0 = P.nmk[k], x.row0 = k < P.K ? P.nks[k] : P.ndyn, x.ncur = P.nk[k];
+      x.c0 = P.xcut[(size_t)k * (NR + 1) + RK], x.wd = P.xcut[(size_t)k * (NR + 1) + RK + 1] - x.c0;
+      x.m = k < P.K ? P.mk[k] : 0, x.with_controls = RK == 0;
+    }
+    d.dyn_sum_x2 = ((long long)n + 15) / 16 * 16;
+    if ((e = d.dyn_loc.upload(dl)) || (e = d.dyn_sum.alloc((size_t)(d.dyn_sum_x2 + P.ndyn + 16)))) return e;
+  } else if (P.dense_dyn) {
     std::vector<stg::DynDesc> dd(P.K + 1);
     for (int k = 0; k <= P.K; k++) {
       dd[k].oF = k < P.K ? P.oF[k] : 0, dd[k].ldf = k < P.K ? P.ldf[k] : 0;
@@ -376,6 +411,8 @@ static int staged_upload(hqpkkt_t *h) {
           for (int grid : {2 * cus, cus})
             pmax = std::max(pmax, stg::gemm_split_plan_pieces(stg::gemm_split_plan(t, (std::max(P.nk[k + 1], P.nk[k]) + stg::GEMM_BK - 1) / stg::GEMM_BK, grid)));
     }
+    if (P.sharded)
+      for (int k = 0; k < P.K; k++) tmax = std::max<long long>(tmax, P.gtile_ptr[k + 1] - P.gtile_ptr[k]);
     pmax = pmax * 5 / 4 + 64;  // (plans of smaller products of the same stage: never more pieces than 8 per tile of tmax)
     pmax = std::max(pmax, 16 * tmax);
     d.sk_grid = 0, d.sk_tiles = (int)tmax;
@@ -407,31 +444,55 @@ static int staged_upload(hqpkkt_t *h) {
     d.overlap = d.stream2 != nullptr && d.overlap_mode != 0;
   }
   if (P.sharded) {
-    // (exact strip sizes behind the stream-ordered transport, slots padded to the largest strip behind the callback)
-    const bool exact = h->xchg_sfn != nullptr;
-    std::vector<stg::StripTab> tabs(P.K + 1);
+    const int NR = P.shard_count, RK = P.shard_rank;
+    std::vector<stg::StripTab> wt(P.K + 1);
+    std::vector<stg::RectTab> rt(P.K + 1);
+    std::vector<stg::PackRect> pr;
+    d.prect_ptr.assign(P.K + 1, 0);
     for (int k = 0; k < P.K; k++) {
-      const int *cut = &P.xcut[(size_t)k * (P.shard_count + 1)];
-      stg::StripTab &t = tabs[k];
-      t.nranks = P.shard_count;
-      long long off = 0;
-      for (int p = 0; p <= P.shard_count; p++) {
-        t.cut[p] = cut[p];
-        if (p < P.shard_count) t.off[p] = exact ? off : (long long)p * P.xslot[k], off += (long long)(P.nk[k] - cut[p]) * (cut[p + 1] - cut[p]);
+      const int *cut = &P.xcut[(size_t)k * (NR + 1)];
+      stg::StripTab &t = wt[k];
+      stg::RectTab &r = rt[k];
+      t.nranks = r.nranks = NR;
+      for (int p = 0; p <= NR; p++) {
+        t.cut[p] = r.cut[p] = cut[p];
+        if (p < NR) t.off[p] = (long long)p * P.xwslot[k];
+      }
+      for (auto &b : r.blk) b.off[0] = b.off[1] = 0, b.rsplit = 1 << 30, b.pad = 0;
+      d.prect_ptr[k] = (int)pr.size();
+      for (int q = P.xrect_ptr[k]; q < P.xrect_ptr[k + 1]; q++) {
+        const kktdev::StagedPlan::XRect &x = P.xrects[q];
+        stg::RectTab::Block &b = r.blk[x.a * 16 + x.b];
+        const long long off = (long long)x.owner * P.xslot[k] + x.off;
+        if (x.r0 == cut[x.a])
+          b.off[0] = off;
+        else
+          b.off[1] = off, b.rsplit = x.r0;
+        if (x.owner == RK) {
+          stg::PackRect pk{};
+          if (x.mine_rows)
+            pk.r0 = x.r0, pk.c0 = x.c0, pk.rows = x.r1 - x.r0, pk.cols = x.c1 - x.c0, pk.transpose = 0;
+          else  // computed for the partner's rows in the own row strip of G: rows = own columns
+            pk.r0 = x.c0, pk.c0 = x.r0, pk.rows = x.c1 - x.c0, pk.cols = x.r1 - x.r0, pk.transpose = 1;
+          pk.off = x.off;
+          pr.push_back(pk);
+        }
       }
     }
-    if ((e = d.strip_tabs.upload(tabs))) return e;
+    d.prect_ptr[P.K] = (int)pr.size();
+    if (pr.empty()) pr.push_back(stg::PackRect{});
+    std::vector<int> gt = P.gtile;
+    if (gt.empty()) gt.push_back(0);
+    if ((e = d.wtabs.upload(wt)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt))) return e;
+    if (!d.ev_wu) HIPCHK(hipEventCreateWithFlags(&d.ev_wu, hipEventDisableTiming));
+    if (!d.ev_x1) HIPCHK(hipEventCreateWithFlags(&d.ev_x1, hipEventDisableTiming));
   }
-  // orders of the tiles of the triangular products (G, V; their column slices when sharded)
-  for (int k = 0; k < P.K; k++) {
-    std::vector<int> sizes = {P.nk[k] + P.mk[k], P.nk[k]};
-    if (P.sharded)
-      for (int p = 0; p < P.shard_count; p++) sizes.push_back(P.xcut[(size_t)k * (P.shard_count + 1) + p + 1] - P.xcut[(size_t)k * (P.shard_count + 1) + p]);
-    for (int sz : sizes) {
+  // orders of the tiles of the triangular products (G, V)
+  for (int k = 0; k < P.K; k++)
+    for (int sz : {P.nk[k] + P.mk[k], P.nk[k]}) {
       const int T = (sz + 127) / 128;
       if (T >= 16) (void)d.tri_map(T, true);
     }
-  }
   d.lds_small = 0, d.lds_small_big = 0;
   for (int k = 0; k < P.K; k++) {
     if (P.big[k])
@@ -444,11 +505,15 @@ static int staged_upload(hqpkkt_t *h) {
     d.lds_init = (size_t)kktdev::gj_lds_bytes((long long)q) - (P.big0 ? q * (q | 1) * 8 : 0);
     d.lds_x0 = sizeof(double) * (3 * q + 64 * 65 + 8);
   }
-  static std::mutex attr_mutex;  // function attributes are process state, shared by all handles
-  static size_t attr_small = 0, attr_small_big = 0, attr_init = 0, attr_init_big = 0, attr_x0 = 0;
-  static bool attr_gemm = false;
+  static std::mutex attr_mutex;  // function attributes are process state, shared by all handles - per DEVICE
+  struct PerDev { size_t small = 0, small_big = 0, init = 0, init_big = 0, x0 = 0; bool gemm = false; };
+  static PerDev per_dev[64];
+  if (h->opts.device < 0 || h->opts.device >= 64) return HQPKKT_E_RANGE;
   {
     std::lock_guard<std::mutex> lk(attr_mutex);
+    PerDev &pd = per_dev[h->opts.device];
+    size_t &attr_small = pd.small, &attr_small_big = pd.small_big, &attr_init = pd.init, &attr_init_big = pd.init_big, &attr_x0 = pd.x0;
+    bool &attr_gemm = pd.gemm;
     if (!attr_gemm) {
       HIPCHK(stg::gemm_set_attributes());
       HIPCHK(hipFuncSetAttribute((const void *)stg::k_st_rm, hipFuncAttributeMaxDynamicSharedMemorySize, (int)stg::st_rm_lds(64)));
@@ -485,6 +550,26 @@ static int staged_upload(hqpkkt_t *h) {
   return 0;
 }
 
+// the dynamics block of stage k from the caller's F (n+ rows of n_k + m_k values) into the F arena: the whole block,
+// or - one system over several ranks - this rank's state columns and the control columns
+static int staged_copy_block(hqpkkt_t *h, int k, const double *F, long long ldF, hipMemcpyKind kind) {
+  StagedDev &d = *h->sd;
+  const kktdev::StagedPlan &P = d.plan;
+  const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1];
+  if (np <= 0) return 0;
+  if (!P.sharded) {
+    if (nn + mm > 0)
+      HIPCHK(hipMemcpy2DAsync(d.F.p + P.oF[k], sizeof(double) * P.ldf[k], F, sizeof(double) * ldF, sizeof(double) * (nn + mm), np, kind, h->stream));
+    return 0;
+  }
+  const int *cut = &P.xcut[(size_t)k * (P.shard_count + 1)];
+  const int c0 = cut[P.shard_rank], wd = cut[P.shard_rank + 1] - c0;
+  double *dst = d.F.p + P.oFl[k];
+  if (wd > 0) HIPCHK(hipMemcpy2DAsync(dst, sizeof(double) * P.ldfl[k], F + c0, sizeof(double) * ldF, sizeof(double) * wd, np, kind, h->stream));
+  if (mm > 0) HIPCHK(hipMemcpy2DAsync(dst + wd, sizeof(double) * P.ldfl[k], F + nn, sizeof(double) * ldF, sizeof(double) * mm, np, kind, h->stream));
+  return 0;
+}
+
 static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, const double *Cx,
                              const double *const *Fblk = nullptr, const long long *ldF = nullptr, bool dense = false) {
   Analysis &an = h->an;
@@ -500,8 +585,7 @@ static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, co
     for (int k = 0; k < P.K; k++) {
       const int nz = P.nk[k] + P.mk[k];
       if (!Fblk[k] || ldF[k] < nz) return HQPKKT_E_SIZES;
-      HIPCHK(hipMemcpy2DAsync(d.F.p + P.oF[k], sizeof(double) * P.ldf[k], Fblk[k], sizeof(double) * ldF[k],
-                              sizeof(double) * nz, P.nk[k + 1], kind, s));
+      if ((e = staged_copy_block(h, k, Fblk[k], ldF[k], kind))) return e;
     }
   if (an.nq) HIPCHK(hipMemcpyAsync(h->vals.p, Qx, sizeof(double) * an.nq, kind, s));
   if (an.na) HIPCHK(hipMemcpyAsync(h->vals.p + an.nq, Ax, sizeof(double) * an.na, kind, s));
@@ -523,30 +607,52 @@ static int staged_set_values(hqpkkt_t *h, const double *Qx, const double *Ax, co
   return 0;
 }
 
-// One stage of the backward recursion when ONE system is sharded over several ranks.
-// Rank p owns the state columns [c0, c1) of the two large products; everything control-sized is computed by every
-// rank on identical data.  Two streams:
-//   sA (the handle's): W[:, c0:c1) = V+ F[:, c0:c1)  ->  the strip of the lower triangle of G_xx = fx' W_x below its
-//       first column (+ H_xx)  ->  pack  ->  the strips of all ranks are exchanged (stream-ordered broadcasts of the
-//       exact sizes, or one all-gather of padded slots behind the drained-stream callback)
-//   sB: W_u = V+ f_u  ->  the control rows of G (G_ux, G_uu) = W_u' F (+ H's control part)  ->  carried rows N = B+ F
-//       ->  rank decision, K^-1 (k_st_small), Y and the carried rows (k_st_wide)  ->  Rm = K^-1 Y, refined against K
-// and, joined: V_k = G_xx - Y' Rm over the WHOLE lower triangle, mirrored, with G_xx read straight from the strips in
-// the exchange buffer (GemmArgs::strips) - one pass that is unpack, rank-q update and mirror at once.  The gather
-// (n^2 / 2 doubles per stage) therefore runs beside the control-sized chain of the same stage instead of between
-// two stages, and nothing of that chain is on the path of the large products.
+// the tiles g.tile_map[0 .. ntiles) of a product (128 x 128 tiles; the blocks of G_xx one rank owns): their k ranges
+// cut when they do not fill the chip (k_dgemm_tn_sk), one plain round otherwise
+static int st_gemm_tiles(hqpkkt_t *h, stg::GemmArgs g, int ntiles, int cls) {
+  if (ntiles <= 0 || g.M <= 0 || g.N <= 0) return 0;
+  StagedDev *d = h->sd;
+  const bool al16 = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && ((g.lda & 1) == 0);
+  if (d->zeros.p && al16) g.zeros = d->zeros.p;
+  const int variant = g.zeros ? d->gemm_variant : stg::GEMM_REG4;
+  const long long nslab = (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK;
+  if (d->sk_grid > 0 && ntiles % d->sk_grid != 0 && ntiles < 16LL * d->sk_grid && nslab >= 32 && ntiles <= d->sk_tiles) {
+    stg::SplitPlan sk = stg::gemm_split_plan(ntiles, nslab, d->sk_grid);
+    if (stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
+      sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
+      KLAUNCH(h, cls, stg::gemm_launch_split(variant, d->sk_grid, h->stream, g, sk));
+      return 0;
+    }
+  }
+  KLAUNCH(h, cls, stg::gemm_launch_plain(variant, (unsigned)ntiles, h->stream, g, d->cus));
+  return 0;
+}
+
+// One stage of the backward recursion when ONE system is sharded over several ranks (DESIGN.md section 7,
+// staged_plan.hpp).  Rank p owns the state columns [c0, c1) of the stage: its memory holds those columns of F_k (and the
+// control columns), its products are the strip W_p = V+ F_p and the blocks of G_xx the plan gives it; everything
+// control-sized is computed by every rank on identical data.  Two streams:
+//   sA (the handle's): W_p = V+ F_p, then - behind W_u of sB - its columns of the control rows of G (W_u' F_p) and of
+//       the carried rows (B+ F_p), all three into its slot  ->  EXCHANGE 1 (gather of the slots)  ->  its blocks of
+//       G_xx = F_p' W_q in ONE launch (the B operand from the ranks' slots, the tiles of the plan's list), + H_xx  ->
+//       pack (lower orientation)  ->  EXCHANGE 2
+//   sB: W_u = V+ f_u, G_uu, the control columns of the carried rows; behind exchange 1: the control rows of G and the
+//       carried rows into their places, rank decision, K^-1 (k_st_small), Y (k_st_wide), Rm = K^-1 Y
+// and, joined: V_k = G_xx - Y' Rm over the WHOLE lower triangle, mirrored, with G_xx read straight from the blocks in
+// the exchange buffer (GemmArgs::rects) into the transient full block; the rank keeps its row strip for the solve.
 static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots);
 static int staged_stage_sharded(hqpkkt_t *h, int k) {
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;
   const int NR = P.shard_count, RK = P.shard_rank;
   StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
-  const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
-  const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k], q = P.qmax[k];
+  const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1];
+  const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k], q = P.qmax[k], cx = P.cap[k + 1];
   const int *cut = &P.xcut[(size_t)k * (NR + 1)];
   const int c0 = cut[RK], c1 = cut[RK + 1], wd = c1 - c0;
-  const long long ldf = P.ldf[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k];
-  double *G = d.misc.p + P.oG, *W = d.misc.p + P.oW, *xb = d.misc.p + P.oX;
+  const long long ldfl = P.ldfl[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k], ldwu = P.ldwu;
+  double *G = d.misc.p + P.oG, *Wu = d.misc.p + P.oWu, *xw = d.misc.p + P.oXW, *xb = d.misc.p + P.oX;
+  double *slot = xw + (long long)RK * P.xwslot[k];
   hipStream_t sA = h->stream, sB = d.stream2 ? d.stream2 : h->stream;
   struct StreamGuard {  // launches go to h->stream: back to the first stream on every way out
     hqpkkt_t *h;
@@ -574,18 +680,40 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
       KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(count), 256, 0, h->stream>>>(count, d.h_dst.p + first, d.h_tptr.p + first, d.h_terms.p,
                                                                                  h->vals.p, h->wt.p, G, 1));
   };
-  // ---- sB: the control-sized chain (the workspace of the cut products belongs to sA: plain kernels here)
+  const double *Fu = sp.F + wd;  // the control columns of the local block
+  // ---- sB, first part: what needs the control columns only (the workspace of the cut products belongs to sA: plain kernels)
   h->stream = sB;
   if (mm > 0) {
-    if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + nn, ldf, nullptr, 0, W + nn, ldf, np, mm, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two))) return e;
-    if ((e = st_gemm(h, stg::GemmArgs{W + nn, ldf, sp.F, ldf, nullptr, 0, G + (long long)nn * ldg, ldg, mm, nz, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)))
+    if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, Fu, ldfl, nullptr, 0, Wu, ldwu, np, mm, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)) ||
+        (e = st_gemm(h, stg::GemmArgs{Wu, ldwu, Fu, ldfl, nullptr, 0, G + (long long)nn * ldg + nn, ldg, mm, mm, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)))
       return e;
-    add_h(P.h_mid[k], ne_u);
+    if (cx > 0 && (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], Fu, ldfl, nullptr, 0, sp.N + (size_t)ek * P.ldn[k] + nn, P.ldn[k], cx, mm, np,
+                                                1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !two)))
+      return e;
   }
-  if (P.cap[k + 1] > 0 &&
-      (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, ldf, nullptr, 0, sp.N + (size_t)ek * P.ldn[k], P.ldn[k], P.cap[k + 1], nz, np,
-                                    1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !two)))
+  if (two) HIPCHK(hipEventRecord(d.ev_wu, sB));
+  // ---- sA: the strip of W and the rank's columns of the control-sized rows, into its slot
+  h->stream = sA;
+  if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldfl, nullptr, 0, slot, wd, np, wd, np, 1.0, 0.0, 0, 0}))) return e;
+  if (two) HIPCHK(hipStreamWaitEvent(sA, d.ev_wu, 0));
+  if (wd > 0 && mm > 0 &&
+      (e = st_gemm(h, stg::GemmArgs{Wu, ldwu, sp.F, ldfl, nullptr, 0, slot + (long long)np * wd, wd, mm, wd, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)))
     return e;
+  if (wd > 0 && cx > 0 &&
+      (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, ldfl, nullptr, 0, slot + (long long)(np + mm) * wd, wd, cx, wd, np, 1.0, 0.0, 0, 0},
+                   KC_ST_GEMM_UPD, !two)))
+    return e;
+  if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xw, P.xwslot[k], NR))) return e;
+  if (two) {
+    HIPCHK(hipEventRecord(d.ev_x1, sA));
+    HIPCHK(hipStreamWaitEvent(sB, d.ev_x1, 0));
+  }
+  // ---- sB, second part: the control-sized chain
+  h->stream = sB;
+  if (mm + cx > 0)
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_unpack_extra<<<dim3(std::min(mm + cx, 1024), NR), 256, 0, h->stream>>>(
+                              d.wtabs.p + k, xw, np, mm, cx, G + (long long)nn * ldg, ldg, sp.N + (size_t)ek * P.ldn[k], P.ldn[k]));
+  add_h(P.h_mid[k], ne_u);
   {
     stg::SmallArgs sa{G, ldg, nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
                       P.capn[k], P.cap[k], q, h->ge_tol, sp.Kinv, P.ldq[k], sp.Kmat, sp.T, P.ldt[k], sp.dyn, h->flags.p,
@@ -603,39 +731,30 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     if ((e = st_rm(h, d, sp, k, !two, wa))) return e;
   }
   if (two) HIPCHK(hipEventRecord(d.ev_join, sB));
-  // ---- sA: the large products of this rank's columns, and the exchange
+  // ---- sA: the rank's blocks of G_xx (rows = its strip) in one launch, H_xx, pack, exchange 2
   h->stream = sA;
-  if (wd > 0) {
-    if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F + c0, ldf, nullptr, 0, W + c0, ldf, np, wd, np, 1.0, 0.0, 0, 0}))) return e;
-    // the strip of the lower triangle of G_xx: diagonal block (lower tiles) and the rows below it, one launch
-    if ((e = st_gemm(h, stg::GemmArgs{sp.F + c0, ldf, W + c0, ldf, nullptr, 0, G + (long long)c0 * ldg + c0, ldg, nn - c0, wd, np, 1.0, 0.0, 1, 0})))
-      return e;
+  const int ntile = P.gtile_ptr[k + 1] - P.gtile_ptr[k];
+  if (wd > 0 && ntile > 0) {
+    stg::GemmArgs gg{sp.F, ldfl, xw, 0, nullptr, 0, G + (long long)c0 * ldg, ldg, wd, nn, np, 1.0, 0.0, 0, 0};
+    gg.tile_map = d.gtile.p + P.gtile_ptr[k], gg.bstrips = d.wtabs.p + k;
+    if ((e = st_gemm_tiles(h, gg, ntile, KC_ST_GEMM))) return e;
   }
-  add_h(P.h_ptr[k], ne_x);  // (entries outside this rank's strip land in parts of G nobody reads)
-  const stg::StripTab *tab = d.strip_tabs.p + k;
-  const bool exact = h->xchg_sfn != nullptr;
-  long long off_mine = 0;
-  for (int p = 0; p < RK; p++) off_mine += (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]);
-  if (!exact) off_mine = (long long)RK * P.xslot[k];
-  if (wd > 0)
-    KLAUNCH(h, KC_ST_VEC, stg::k_st_pack<<<std::min(nn - c0, 4096), 256, 0, sA>>>(G, ldg, nn, c0, c1, xb + off_mine));
-  if (exact) {
-    long long off = 0;
-    for (int p = 0; p < NR; p++) {
-      const long long len = (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]);
-      if ((e = exchange(h, HQPKKT_XCHG_BCAST_BASE + p, xb + off, len, 1))) return e;
-      off += len;
-    }
-  } else if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR)))
-    return e;
+  add_h(P.h_ptr[k], ne_x);  // (entries outside this rank's blocks land in parts of G nobody reads)
+  const int npk = d.prect_ptr[k + 1] - d.prect_ptr[k];
+  if (npk > 0)
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_pack_rects<<<dim3(512, npk), 256, 0, sA>>>(d.prects.p + d.prect_ptr[k], G, ldg, xb + (long long)RK * P.xslot[k]));
+  if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR))) return e;
   if (two) {
     HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
     join.armed = false;
   }
-  // V_k = G_xx - Y' Rm: lower tiles, mirrored; G_xx from the strips
+  // V_k = G_xx - Y' Rm: lower tiles, mirrored; G_xx from the blocks
   stg::GemmArgs gu{sp.Y, ldy, sp.Rm, ldy, xb, 0, sp.V, ldv, nn, nn, q, -1.0, 1.0, 1, 1};
-  gu.strips = tab;
-  return st_gemm(h, gu, KC_ST_GEMM_UPD);  // (q = 0, a stage without controls: V_k = G_xx, the k loop is empty)
+  gu.rects = d.rtabs.p + k;
+  if ((e = st_gemm(h, gu, KC_ST_GEMM_UPD))) return e;  // (q = 0, a stage without controls: V_k = G_xx, the k loop is empty)
+  if (wd > 0)
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_copy2d<<<std::min(wd, 2048), 256, 0, sA>>>(sp.V + (long long)c0 * ldv, ldv, sp.Vs, ldv, wd, nn));
+  return 0;
 }
 
 // Hqp_IpLQDOCP::factor (hqp/Hqp_IpLQDOCP.C:796-862): W^-1 Z, C'(W^-1 Z)C, then the backward
@@ -663,6 +782,11 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
       KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(ne), 256, 0, s>>>(ne, d.h_dst.p + P.h_ptr[K], d.h_tptr.p + P.h_ptr[K], d.h_terms.p,
                                                                        h->vals.p, h->wt.p, sp.V, 0));
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_last<<<nblk(std::max(nK, 1)), 256, 0, s>>>(nK, eK, P.cap[K], sp.N, P.ldn[K], sp.BT, P.ldb[K], sp.dyn));
+    if (P.sharded) {  // this rank's rows of V_K for the solve
+      const int c0 = P.xcut[(size_t)K * (P.shard_count + 1) + P.shard_rank], wd = P.xcut[(size_t)K * (P.shard_count + 1) + P.shard_rank + 1] - c0;
+      if (wd > 0)
+        KLAUNCH(h, KC_ST_VEC, stg::k_st_copy2d<<<std::min(wd, 2048), 256, 0, s>>>(sp.V + (long long)c0 * P.ldv[K], P.ldv[K], sp.Vs, P.ldv[K], wd, nK));
+    }
   }
   for (int k = K - 1; k >= 0; k--) {
     if (P.sharded) {
@@ -776,8 +900,128 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
   return 0;
 }
 
+// The same sweeps when ONE system is sharded over several ranks (staged_plan.hpp): the products with V_k run on the
+// rank's ROW strip, those with F_k on its COLUMN strip (and the control columns); everything control-sized is computed
+// by every rank.  Per stage one gather of a state-sized vector in the backward sweep (tt = v+ + V+ f, by rows) and one
+// of the ranks' partial sums in the forward sweep (x+ = F s + f, by columns); the multipliers of the dynamics rows
+// (V+ x+ + v+ + B+' eta+, by rows) are summed over the ranks once, at the end.  Not captured: the exchanges are calls.
+static int staged_run_step_sharded(hqpkkt_t *h, const Vecs &v) {
+  Analysis &an = h->an;
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  hipStream_t s = h->stream;
+  const int n = an.n, m = an.m, K = P.K, NR = P.shard_count, RK = P.shard_rank;
+  double *M = d.misc.p;
+  double *S = M + P.oS, *qv = M + P.oQv, *gam = M + P.oGam, *tt = M + P.oTT, *xv = M + P.oXV, *xp = M + P.oXP, *dyx = M + P.oDyx;
+  auto cut0 = [&](int k) { return P.xcut[(size_t)k * (NR + 1) + RK]; };
+  auto width = [&](int k) { return P.xcut[(size_t)k * (NR + 1) + RK + 1] - P.xcut[(size_t)k * (NR + 1) + RK]; };
+  int e;
+  const long long ndx = (long long)P.ndyn + (P.fixed_x0 ? P.nk[0] : 0);
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_zero<<<nblk(std::max<long long>(ndx, 1)), 256, 0, s>>>(ndx, dyx));
+  if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
+  KLAUNCH(h, KC_VECTOR, stg::k_st_q<<<nblk(n), 256, 0, s>>>(n, h->CT.ptr.p, h->CT.col.p, h->CT.src.p, h->vals.p, h->tz.p, v.r1, qv));
+  {  // last stage
+    StagePtr sp = stage_ptr(d, K);
+    const int nK = P.nk[K], eK = P.eq_ptr[K + 1] - P.eq_ptr[K];
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(nK), 256, 0, s>>>(nK, qv + P.nmk[K], sp.v));
+    if (eK) KLAUNCH(h, KC_ST_VEC, stg::k_st_gather<<<nblk(eK), 256, 0, s>>>(eK, d.eq_rows.p + P.eq_ptr[K], v.r2, sp.beta));
+  }
+  for (int k = K - 1; k >= 0; k--) {
+    StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
+    const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1];
+    const int c0 = cut0(k), wd = width(k), c0n = cut0(k + 1), wdn = width(k + 1);
+    const double *f = v.r2 + P.nks[k];
+    // tt = v+ + V+ f by rows: the ranks' strips side by side (strip p starts at p xw), gathered
+    if (wdn > 0 && (e = st_gemv_rows(h, stg::GemvRows{sn.Vs, P.ldv[k + 1], wdn, np, f, sn.v + c0n, nullptr, 0, nullptr, nullptr,
+                                                        xv + (long long)RK * P.xw[k + 1], 1.0})))
+      return e;
+    if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xv, P.xw[k + 1], NR))) return e;
+    // gam = q_k + F' tt: the own state columns and the control columns
+    if (wd > 0 && (e = st_gemv_cols(h, d, sp.F, P.ldfl[k], np, wd, xv, qv + P.nmk[k] + c0, 1.0, gam + c0))) return e;
+    if (mm > 0 && (e = st_gemv_cols(h, d, sp.F + wd, P.ldfl[k], np, mm, xv, qv + P.nmk[k] + nn, 1.0, gam + nn))) return e;
+    stg::BwdSmall ba{nn, mm, np, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], d.eq_rows.p + P.eq_ptr[k], v.r2,
+                     P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr, sn.beta, sn.BT, P.ldb[k + 1], f, gam, sp.Kinv, sp.Kmat, P.ldq[k], sp.T, P.ldt[k],
+                     sp.dyn, sp.rho, sp.beta};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_bwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 3 * P.qmax[k] + 4 + 256), s>>>(ba));
+    // v_k = gam_x - Y' rho: the own entries (all a later product needs)
+    if (wd > 0 && (e = st_gemv_cols(h, d, sp.Y + c0, P.ldy[k], P.qmax[k], wd, sp.rho, gam + c0, -1.0, sp.v + c0))) return e;
+  }
+  {
+    StagePtr s0 = stage_ptr(d, 0);
+    const int n0 = P.nk[0];
+    if (P.fixed_x0)
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_x0_fixed<<<nblk(std::max(n0, P.cap[0])), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, v.r2, S,
+                                                                                         s0.eta, P.cap[0]));
+    else {
+      // the free initial state needs v_0 in full: gathered
+      const int c0 = cut0(0), wd = width(0);
+      if (wd > 0) KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(wd), 256, 0, s>>>(wd, s0.v + c0, xv + (long long)RK * P.xw[0]));
+      if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xv, P.xw[0], NR))) return e;
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(n0), 256, 0, s>>>(n0, xv, s0.v));
+      if (P.big0) {
+        const int q = P.q0max, l8 = (q + 7) / 8 * 8;
+        double *vec = M + P.oK0s + 3 * (long long)q + 8, *nb = vec, *pb = vec + l8, *y = vec + 2 * l8, *r = vec + 3 * l8;
+        const stg::X0Vec xv0{n0, P.cap[0], q, s0.dyn, M + P.oK0s, s0.v, s0.beta, nb, pb, pb, S, s0.eta};
+        KLAUNCH(h, KC_ST_VEC, stg::k_x0_rhs<<<nblk(q), 256, 0, s>>>(xv0));
+        if ((e = st_gemv_rows(h, stg::GemvRows{M + P.oK0, P.ldq0, q, q, nb, nullptr, nullptr, 0, nullptr, nullptr, y, 1.0})) ||
+            (e = st_gemv_rows(h, stg::GemvRows{M + P.oK0m, P.ldq0, q, q, y, pb, nullptr, 0, nullptr, nullptr, r, -1.0})) ||
+            (e = st_gemv_rows(h, stg::GemvRows{M + P.oK0, P.ldq0, q, q, r, y, nullptr, 0, nullptr, nullptr, pb, 1.0})))
+          return e;
+        KLAUNCH(h, KC_ST_VEC, stg::k_x0_out<<<nblk(n0 + P.cap[0]), 256, 0, s>>>(xv0));
+      }
+      KLAUNCH(h, KC_ST_SMALL, stg::k_st_x0_free<<<1, 256, d.lds_x0, s>>>(n0, P.cap[0], P.q0max, M + P.oK0, M + P.oK0m, M + P.oK0s, P.ldq0, s0.dyn, s0.v,
+                                                                s0.beta, S, s0.eta));
+    }
+  }
+  for (int k = 0; k < K; k++) {
+    StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
+    const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1];
+    const int c0 = cut0(k), wd = width(k), c0n = cut0(k + 1), wdn = width(k + 1);
+    double *xk = S + P.nmk[k];
+    // [u ; yhat] = -(Rm x + rho)
+    double *uy = M + P.oUy;
+    if (P.qmax[k] > 0) {
+      stg::GemvRows gr{sp.Rm, P.ldy[k], P.qmax[k], nn, xk, sp.rho, nullptr, 0, nullptr, nullptr, uy, -1.0};
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_wide<<<P.qmax[k], 256, 0, s>>>(gr));
+    }
+    stg::FwdSmall fa{nn, mm, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], uy, sp.T, P.ldt[k],
+                     sp.dyn, sp.eta, d.eq_rows.p + P.eq_ptr[k], xk + nn, v.dy, sn.eta, P.cap[k + 1]};
+    KLAUNCH(h, KC_ST_SMALL, stg::k_st_fwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 4), s>>>(fa));
+    // x+ = F s + f: the own columns' share of every row, gathered, and added in the order of the ranks to f_u u + f
+    if ((e = st_gemv_rows(h, stg::GemvRows{sp.F, P.ldfl[k], np, wd, xk + c0, nullptr, nullptr, 0, nullptr, nullptr, xp + (long long)RK * P.xpslot, 1.0})))
+      return e;
+    if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xp, P.xpslot, NR))) return e;
+    if ((e = st_gemv_rows(h, stg::GemvRows{sp.F + wd, P.ldfl[k], np, mm, xk + nn, v.r2 + P.nks[k], nullptr, 0, nullptr, nullptr, tt, 1.0}))) return e;
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_sum_slots<<<nblk(np), 256, 0, s>>>(np, NR, xp, P.xpslot, tt, S + P.nmk[k + 1]));
+    // p = V+ x+ + v+ + B+' eta+: the own rows
+    if (wdn > 0 &&
+        (e = st_gemv_rows(h, stg::GemvRows{sn.Vs, P.ldv[k + 1], wdn, np, S + P.nmk[k + 1], sn.v + c0n,
+                                           P.cap[k + 1] > 0 ? sn.BT + (long long)c0n * P.ldb[k + 1] : nullptr, P.ldb[k + 1], sn.dyn + 1, sn.eta,
+                                           dyx + P.nks[k] + c0n, 1.0})))
+      return e;
+  }
+  {
+    StagePtr sK = stage_ptr(d, K), s0 = stage_ptr(d, 0);
+    const int eK = P.eq_ptr[K + 1] - P.eq_ptr[K], n0 = P.nk[0];
+    if (eK) KLAUNCH(h, KC_ST_VEC, stg::k_st_y_last<<<nblk(eK), 256, 0, s>>>(eK, d.eq_rows.p + P.eq_ptr[K], sK.eta, v.dy));
+    if (P.fixed_x0 && width(0) > 0 &&
+        (e = st_gemv_rows(h, stg::GemvRows{s0.Vs, P.ldv[0], width(0), n0, S, s0.v + cut0(0), nullptr, 0, nullptr, nullptr, dyx + P.ndyn + cut0(0), 1.0})))
+      return e;
+    if (ndx > 0 && (e = exchange(h, HQPKKT_XCHG_ALLREDUCE_SUM, dyx, ndx, 1))) return e;
+    if (P.ndyn > 0) KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(P.ndyn), 256, 0, s>>>(P.ndyn, dyx, v.dy));
+    if (P.fixed_x0) KLAUNCH(h, KC_ST_VEC, stg::k_st_y_fixed<<<nblk(n0), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, dyx + P.ndyn, v.dy));
+  }
+  KLAUNCH(h, KC_VECTOR, stg::k_st_negate<<<nblk(n), 256, 0, s>>>(n, S, v.dx));
+  if (m > 0)
+    KLAUNCH(h, KC_VECTOR, k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, h->wt.p, h->tz.p,
+                                                             v.r3, v.dz, v.dw));
+  HIPCHK(hipGetLastError());
+  return 0;
+}
+
 // Hqp_IpLQDOCP::step (hqp/Hqp_IpLQDOCP.C:869-976) with ExRiccatiSolveSc (:2007-2182)
 static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
+  if (h->sd->plan.sharded) return staged_run_step_sharded(h, v);
   Analysis &an = h->an;
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;

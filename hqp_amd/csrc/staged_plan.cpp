@@ -241,7 +241,7 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       oKm[k] = mo, mo += up16((long long)std::max(qmax[k], 1) * ldq[k]);
       resmax = std::max(resmax, (long long)std::max(qmax[k], 1) * ldy[k]);
       oT[k] = mo, mo += up16((long long)std::max(cap[k], 1) * ldt[k]);
-      wmax = std::max(wmax, (long long)nk[k + 1] * ldf[k]);
+      if (!sharded) wmax = std::max(wmax, (long long)nk[k + 1] * ldf[k]);  // (sharded: W_p goes straight into its exchange slot)
       gmax = std::max(gmax, (long long)nz * ldg[k]);
     }
   }
@@ -268,54 +268,91 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   oS = mo, mo += up16(n + 8);
   oQv = mo, mo += up16(n + 8);
   oScr = mo, mo += up16(scratch_elems);
-  // ------------------------------------------------------------------ column ranges of the ranks
-  xcut.clear(), xslot.assign(K + 1, 0), oX = 0;
+  // ------------------------------------------------------------------ one system over several ranks (staged_plan.hpp)
+  xcut.clear(), xw.clear(), ldfl.clear(), oFl.clear(), oVs.clear(), xwslot.clear(), xslot.clear();
+  xrects.clear(), xrect_ptr.clear(), gtile.clear(), gtile_ptr.clear();
+  oX = oXW = oXV = oXP = oWu = oDyx = 0, xvslot = xpslot = 0, oVf[0] = oVf[1] = 0;
   if (sharded) {
-    long long xmax = 0;
-    xcut.assign((size_t)(K + 1) * (shard_count + 1), 0);
+    const int P = shard_count, me_ = shard_rank;
+    if (P < 1 || P > 16 || me_ < 0 || me_ >= P) return 1;
+    xcut.assign((size_t)(K + 1) * (P + 1), 0), xw.assign(K + 1, 0);
+    ldfl.assign(K + 1, 8), oFl.assign(K + 1, 0), oVs.assign(K + 1, 0), xwslot.assign(K + 1, 0), xslot.assign(K + 1, 0);
+    long long flo = 0, vso = 0, vfmax = 0, xwmax = 0, xmax = 0, wumax = 0;
+    int mmax = 1;
+    for (int k = 0; k <= K; k++) {
+      const long long nn = nk[k];
+      if (k < K && (nn & 1)) return 1;  // the control columns of Floc start behind the strip: 16-byte loads need it even
+      const long long T = (nn + 127) / 128;
+      xw[k] = (int)(128 * ((T + P - 1) / P));
+      int *cut = &xcut[(size_t)k * (P + 1)];
+      for (int p = 0; p <= P; p++) cut[p] = (int)std::min<long long>(nn, (long long)p * xw[k]);
+      const long long wd = cut[me_ + 1] - cut[me_];
+      oVs[k] = vso, vso += up16(wd * ldv[k]);
+      vfmax = std::max(vfmax, up16(nn * ldv[k]));
+      xvslot = std::max<long long>(xvslot, up16(xw[k]));
+      if (k < K) {
+        ldfl[k] = up8(wd + mk[k]);
+        oFl[k] = flo, flo += up16((long long)nk[k + 1] * ldfl[k]);
+        xwslot[k] = up16(((long long)nk[k + 1] + mk[k] + cap[k + 1]) * xw[k]);
+        xwmax = std::max(xwmax, xwslot[k]);
+        mmax = std::max(mmax, mk[k]);
+        wumax = std::max(wumax, (long long)nk[k + 1] * up8(std::max(mk[k], 1)));
+      }
+    }
+    // the blocks of G_xx: who computes which
+    xrect_ptr.assign(K + 1, 0), gtile_ptr.assign(K + 1, 0);
+    const int D = (P - 1) / 2;
     for (int k = 0; k < K; k++) {
-      const long long nn = nk[k], nz = nk[k] + mk[k], np = nk[k + 1], q = qmax[k];
-      if (nn & 1) return 1;  // the control columns start at column n_k: 16-byte loads need it even
-      const int nb = (int)((nn + 127) / 128);
-      std::vector<double> cost(nb);
-      double tot = 0.0;
-      for (int b = 0; b < nb; b++) {
-        const double c0 = 128.0 * b, wdt = std::min<double>(128.0, nn - c0);
-        // W strip (all rows of V+) and the strip of the lower triangle of G_xx below its first column (the rank-q
-        // update is applied after the gather, to the whole block, by every rank)
-        cost[b] = wdt * (2.0 * np * np + 2.0 * np * (nn - c0));
-        (void)q, (void)nz;
-        tot += cost[b];
-      }
-      int *cut = &xcut[(size_t)k * (shard_count + 1)];
-      // contiguous ranges of 128-column blocks with the smallest possible largest share: bisection on
-      // the bound, greedy filling for a given bound
-      auto fill = [&](double bound, int *out) {
-        int b = 0;
-        for (int p = 0; p < shard_count; p++) {
-          if (out) out[p] = (int)std::min<long long>(128LL * b, nn);
-          double acc = 0.0;
-          while (b < nb && acc + cost[b] <= bound) acc += cost[b++];
-        }
-        return b == nb;
+      const int *cut = &xcut[(size_t)k * (P + 1)];
+      xrect_ptr[k] = (int)xrects.size(), gtile_ptr[k] = (int)gtile.size();
+      std::vector<long long> fill(P, 0);
+      auto add = [&](int a, int b, int r0, int r1, int owner) {
+        if (r1 <= r0 || cut[b + 1] <= cut[b]) return;
+        XRect r{a, b, r0, r1, cut[b], cut[b + 1], owner, owner == a, fill[owner]};
+        fill[owner] += up16((long long)(r1 - r0) * (cut[b + 1] - cut[b]));
+        xrects.push_back(r);
       };
-      double lo = tot / shard_count, hi = tot;
-      for (int b2 = 0; b2 < nb; b2++) lo = std::max(lo, cost[b2]);
-      for (int it = 0; it < 60 && hi - lo > 1e-9 * tot; it++) {
-        const double mid = 0.5 * (lo + hi);
-        if (fill(mid, nullptr))
-          hi = mid;
-        else
-          lo = mid;
-      }
-      fill(hi, cut);
-      cut[shard_count] = (int)nn;
-      for (int p = 0; p < shard_count; p++)
-        xslot[k] = std::max(xslot[k], (long long)(nn - cut[p]) * (cut[p + 1] - cut[p]));
+      for (int a = 0; a < P; a++)
+        for (int b = 0; b <= a; b++) {
+          const int d = a - b;
+          if (d == 0 || d <= D)
+            add(a, b, cut[a], cut[a + 1], d == 0 ? a : b);
+          else if (P - d <= D)
+            add(a, b, cut[a], cut[a + 1], a);
+          else {  // P even, the two blocks P / 2 apart: the upper rows to b, the rest to a
+            const int h = cut[a + 1] - cut[a], rs = cut[a] + ((h / 2 + 127) / 128) * 128;
+            add(a, b, cut[a], std::min(rs, cut[a + 1]), b);
+            add(a, b, std::min(rs, cut[a + 1]), cut[a + 1], a);
+          }
+        }
+      for (int p = 0; p < P; p++) xslot[k] = std::max(xslot[k], fill[p]);
       xslot[k] = up16(xslot[k]);
       xmax = std::max(xmax, xslot[k]);
+      // this rank's tiles, in its row strip of the work block: (tile row in the strip) << 16 | global tile column
+      for (int q = xrect_ptr[k]; q < (int)xrects.size(); q++) {
+        const XRect &r = xrects[q];
+        if (r.owner != me_) continue;
+        // work rectangle: the block itself, or its transpose (rows = own columns)
+        const int R0 = r.mine_rows ? r.r0 : r.c0, R1 = r.mine_rows ? r.r1 : r.c1, C0 = r.mine_rows ? r.c0 : r.r0,
+                  C1 = r.mine_rows ? r.c1 : r.r1;
+        for (int tn = C0 / 128; tn < (C1 + 127) / 128; tn++)
+          for (int tm = R0 / 128; tm < (R1 + 127) / 128; tm++) {
+            if (r.a == r.b && tn > tm) continue;  // diagonal block: lower tiles
+            gtile.push_back(((tm - cut[me_] / 128) << 16) | tn);
+          }
+      }
     }
-    oX = mo, mo += up16(xmax * shard_count);
+    xrect_ptr[K] = (int)xrects.size(), gtile_ptr[K] = (int)gtile.size();
+    ldwu = up8(mmax);
+    oWu = mo, mo += up16(wumax + 8);
+    oXW = mo, mo += up16(xwmax * P);
+    oX = mo, mo += up16(xmax * P);
+    oXV = mo, mo += up16(xvslot * P);
+    xpslot = up16(nmax + 8);
+    oXP = mo, mo += up16(xpslot * P);
+    oDyx = mo, mo += up16((long long)ndyn + nk[0] + 8);
+    oVf[0] = mo, mo += vfmax, oVf[1] = mo, mo += vfmax;  // (work blocks, like W and G)
+    fo = flo, vo = vso;
   }
   f_elems = fo, v_elems = vo, misc_elems = mo;
   dyn_off.assign(K + 1, 0);
@@ -329,8 +366,18 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
     for (int k = 0; k < K; k++)
       for (int i = nks[k]; i < nks[k + 1]; i++) {
         const int li = i - nks[k];
-        for (int p = Ap[i]; p < Ap[i + 1] - 1; p++)
-          a_dst[p] = oF[k] + (long long)li * ldf[k] + (Ai[p] - nmk[k]);
+        for (int p = Ap[i]; p < Ap[i + 1] - 1; p++) {
+          const int lc = Ai[p] - nmk[k];
+          if (!sharded)
+            a_dst[p] = oF[k] + (long long)li * ldf[k] + lc;
+          else {  // the local block: own state columns, then the control columns
+            const int c0 = xcut[(size_t)k * (shard_count + 1) + shard_rank], c1 = xcut[(size_t)k * (shard_count + 1) + shard_rank + 1];
+            if (lc >= nk[k])
+              a_dst[p] = oFl[k] + (long long)li * ldfl[k] + (c1 - c0) + (lc - nk[k]);
+            else if (lc >= c0 && lc < c1)
+              a_dst[p] = oFl[k] + (long long)li * ldfl[k] + (lc - c0);
+          }
+        }
         chk_idx.push_back(nq + Ap[i + 1] - 1), chk_kind.push_back(0);
       }
   for (int k = 0; k <= K; k++)

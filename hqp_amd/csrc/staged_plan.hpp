@@ -65,16 +65,52 @@ struct StagedPlan {
   long long flops_factor = 0;  // as implemented (dense products of the recursion)
   long long bytes_step = 0;    // dense bytes one step streams
 
-  // one system over several ranks (hqpkkt_set_shard): every rank holds all blocks; the state columns
-  // of a stage's products W = V+ F, G = F'W and V = Gxx - Y'Rm are cut into one contiguous range per
-  // rank (multiples of 128, balanced by the work of the three products together: the ranges differ in
-  // height in the triangular ones), the control columns and everything small are computed by all;
-  // ONE all-gather per stage brings the strips of V_k (lower part) together.
+  // One system over several ranks (hqpkkt_set_shard), DESIGN.md section 7: the STATE COLUMNS of every stage are cut into one
+  // contiguous range per rank - the same width for every rank but the last, a multiple of 128 - and the memory goes
+  // with them: rank p keeps the columns [cut[p], cut[p+1]) of F_k next to the control columns (Floc_k = [F_p | F_u],
+  // n+ x ldfl) and, for the solve, the ROWS [cut[p], cut[p+1]) of V_k.  Per stage of the factorisation:
+  //   W_p = V+ F_p                                   local (V+ in full: the transient result of the stage before)
+  //   exchange 1: [W_p ; W_u' F_p ; B+ F_p]          n+ + m + cap+ rows of the rank's width (gather of the slots)
+  //   G_xx block (a, b), a >= b                      by rank a (F_a' W_b) or rank b (W_a' F_b): pair {a, b} belongs to
+  //                                                  b if a - b <= (P - 1) / 2 else to a; with P even the pairs P / 2
+  //                                                  apart are cut in two by rows; diagonal blocks: lower tiles
+  //   exchange 2: the blocks (lower orientation)     n^2 / 2 doubles in all
+  //   V_k = G_xx - Y' Rm in full (every rank), its row strip kept
+  // The control-sized chain is computed by every rank on identical data.  The solve's products run on the strips with
+  // one gather of a state-sized vector per stage and direction.
   int shard_rank = 0, shard_count = 1;
   bool sharded = false;          // several ranks, or one rank with a transport set (tests the exchange path)
-  std::vector<int> xcut;         // (K+1) x (shard_count+1): first column of rank p's range in stage k
-  std::vector<long long> xslot;  // per stage: elements of one slot of the exchange buffer (largest strip)
-  long long oX = 0;              // exchange buffer in the misc arena: shard_count slots
+  std::vector<int> xcut;         // (K+1) x (shard_count+1): first state column of rank p in stage k (k = K: rows of V_K)
+  std::vector<int> xw;           // per stage (K+1): the common strip width (all ranks but the last)
+  std::vector<int> ldfl;         // per stage: leading dimension of Floc_k (own strip + control columns)
+  std::vector<long long> oFl, oVs;  // local F blocks (F arena), own row strips of V_k (V arena, ld = ldv[k])
+  long long oVf[2] = {0, 0};     // the two full-size transient V blocks (misc arena): V_k lives in oVf[k & 1]
+  long long oWu = 0;             // W_u = V+ F_u, n+ x ldwu (misc)
+  int ldwu = 8;
+  long long oXW = 0;             // exchange 1: shard_count slots of xwslot[k] doubles (misc)
+  std::vector<long long> xwslot;
+  long long oX = 0;              // exchange 2: shard_count slots of xslot[k] doubles (misc)
+  std::vector<long long> xslot;
+  long long oXV = 0;             // gathers of the solve: the ranks' strips of a state-sized vector, side by side (misc)
+  long long xvslot = 0;
+  long long oXP = 0;             // ... and shard_count whole state-sized vectors (the partial sums of x+ = F s + f)
+  long long xpslot = 0;
+  long long oDyx = 0;            // the dynamics rows' multipliers (+ V_0 x_0 + v_0 with a fixed x_0): summed over the ranks
+  // a block (part) of G_xx in the exchange buffer 2, lower orientation: rows [r0, r1) x columns [c0, c1) of G_xx,
+  // row-major with leading dimension c1 - c0 at slot `owner`, offset `off`; how the owner computes it: `mine_rows`
+  // (A = its own F strip: the block is the rows of its strip) or not (A = W of the row block's owner, B = its own F strip:
+  // computed transposed in its row strip of the work block, packed with a transposition)
+  struct XRect {
+    int a, b;            // block row / column (ranks)
+    int r0, r1, c0, c1;
+    int owner;
+    bool mine_rows;
+    long long off;       // inside the owner's slot
+  };
+  std::vector<XRect> xrects;      // all stages, all ranks: stage k holds xrect_ptr[k] .. xrect_ptr[k+1]
+  std::vector<int> xrect_ptr;
+  std::vector<int> gtile;         // this rank's tiles of its blocks' products: (tile row in the strip) << 16 | global tile column
+  std::vector<int> gtile_ptr;     // per stage
 
   // explicit stage sizes (hqpkkt_set_stages): K, nx[K+1], nu[K]; empty: detect from A
   std::vector<int> given_nx, given_nu;

@@ -143,6 +143,9 @@ typedef struct hqpkkt_stats {
   int n_slow_pivots;      /* pivots of the last factor that failed the cheap test
                              |a_kk| >= alpha max|column| and took the complete
                              Bunch-Kaufman decision (k_factor_diag's slow path)   */
+  int n_poll_fallbacks;   /* times a launch that spans tree levels gave up waiting for
+                             another workgroup's words since the handle was created; it
+                             has run on per-level launches from the first one on        */
 } hqpkkt_stats;
 
 /* Fill *opts with the defaults (mode FULL, device 0, host pointers, tol 1.0,

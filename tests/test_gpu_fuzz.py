@@ -1,0 +1,103 @@
+"""GPU (-m gpu): deterministic subsets of the randomised campaigns under tools/ (fixed seeds, the case generators and
+checks of the campaigns themselves), so that the driver's GPU test run repeats them - the large campaigns
+(profiles/r0*_fuzz_*.txt) are builder-run.  About half a minute in total:
+
+* tools/fuzz.py          tree engine (both plugins, tree options, update()) against the CPU oracle, 300 + 40 cases
+* tools/fuzz_staged.py   STAGED engine against the reference's own Hqp_IpLQDOCP, 200 cases + the historic finds
+* tools/fuzz_bigstage.py STAGED engine on stages of 10 ... 300 controls against the tree engine, 100 cases
+* tools/fuzz_ip.py       the device-resident Mehrotra / Franke loops against the reference's solvers, 100 cases + the
+                         finds of rounds 1-4 (the three that still differ are listed as such, not hidden)
+"""
+import os
+import sys
+
+import pytest
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+
+from oracle import refapi  # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(check, cases):
+    bad, cnt = [], {}
+    for case in cases:
+        status, detail = check(case)
+        cnt[status] = cnt.get(status, 0) + 1
+        if status == "BAD":
+            bad.append(detail)
+    return bad, cnt
+
+
+def test_tree_engine_campaign_subset():
+    """tools/fuzz.py cases 0-299: random banded / DID-like / multistage / unstructured systems, both plugins, tree
+    options, w/z spreads; mat_sbw and the RCM permutation equal to the oracle's, the oracle's residual of OUR solution
+    within 1e-10 of its own, again after update() - and systems the reference does not solve are not solved here either."""
+    import fuzz
+    bad, cnt = _run(fuzz.check, range(300))
+    assert not bad, bad
+    assert cnt.get("ok", 0) >= 270, cnt  # (a few per hundred are singular on both sides)
+
+
+def test_tree_engine_campaign_subset_with_graph_dissection(monkeypatch):
+    """... 40 cases through the tree of the graph's own dissection (hqpkkt_opts.ordering 1)"""
+    import fuzz
+    monkeypatch.setenv("FUZZ_ORDERING", "1")
+    bad, cnt = _run(fuzz.check, range(3000, 3040))
+    assert not bad, bad
+    assert cnt.get("ok", 0) >= 34, cnt
+
+
+def test_staged_engine_campaign_subset_against_the_reference():
+    """tools/fuzz_staged.py cases 0-199 and the finds of round 2 (5597, 7983: free initial states whose path
+    equalities consume the controls) and of the first sweep (672: a stiff stage) against the REFERENCE's Hqp_IpLQDOCP
+    (oracle/_ref): the oracle's residual of our refined solution within 1e-10 of the reference's."""
+    import fuzz_staged
+    if not refapi.available():
+        pytest.skip("oracle/_ref not present")
+    bad, cnt = _run(fuzz_staged.check, list(range(200)) + [672, 5597, 7983])
+    assert not bad, bad
+    assert cnt.get("ok", 0) >= 180, cnt  # (the rest: the reference itself fails or ends above 1e-8)
+
+
+def test_large_stage_campaign_subset():
+    """tools/fuzz_bigstage.py cases 0-99: stages of 10 ... 300 controls (K in registers, in LDS, by the blocked
+    elimination), carried final-state rows, free initial states - against the tree engine on the same QP."""
+    import fuzz_bigstage
+    tally = {}
+    bad, cnt = _run(lambda c: fuzz_bigstage.check(c, tally), range(100))
+    assert not bad, bad
+    assert cnt.get("ok", 0) >= 95, cnt
+    assert tally["blocked"] >= 100 and tally["fell"] <= 3, tally  # the blocked elimination ran, and did not fall back
+
+
+# finds of tools/fuzz_ip.py in rounds 1-4 (profiles/r02_fuzz_big.txt: 12 000 cases, r04_fuzz_tree.txt: 6 000); those that
+# still differ from the reference are reported as expected failures, not hidden (all hqpkkt_franke on the
+# double-integrator structure: pivoting confined to the supernode's pivot block)
+IP_FINDS = [193, 2536, 5533, 5975, 6258, 7018, 7260, 7511, 8650, 10246]
+
+
+def test_ip_loop_campaign_subset():
+    """tools/fuzz_ip.py cases 0-99: hqpkkt_mehrotra / hqpkkt_franke against the reference's
+    Hqp_IpsMehrotra / Hqp_IpsFranke with its own plugin - same result code, objective to 1e-6, iteration counts
+    within 2 (Mehrotra) / 10 % (Franke), or spread as the reference's own two plugins are."""
+    import fuzz_ip
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    bad, cnt = _run(fuzz_ip.check, range(100))
+    assert not bad, bad
+    assert cnt.get("ok", 0) >= 95, cnt
+
+
+@pytest.mark.parametrize("case", IP_FINDS)
+def test_ip_loop_finds_of_the_campaigns(case):
+    """The QPs on which the campaigns of rounds 1-4 found hqpkkt_franke / hqpkkt_mehrotra to differ from the
+    reference's solvers (iteration counts apart by more than 10 %, or "degenerate" within 3 iterations of the
+    reference's "optimal"): pass where they now agree, expected failure where they still differ."""
+    import fuzz_ip
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    status, line = fuzz_ip.check(case)
+    if status == "BAD":
+        pytest.xfail("known difference (pivoting confined to the supernode's pivot block): " + line)

@@ -107,3 +107,43 @@ def test_whole_tree_sweeps_on_trees_of_small_fronts(K, monkeypatch):
     xb = B.mehrotra(prog)
     assert xa[-1]["iters"] == xb[-1]["iters"] and xa[-1]["result"] == 0
     assert np.array_equal(xa[0], xb[0])
+
+
+@pytest.mark.parametrize("make,cls,what", [(lambda: problems.banded_qp(6000, 40, seed=7), ipmatrix.IpSpBKP, "top"),
+                                           (lambda: problems.did_like_qp(400), ipmatrix.IpRedSpBKP, "tree")])
+def test_a_poll_that_gives_up_falls_back_to_the_per_level_launches(make, cls, what, monkeypatch):
+    """HQPKKT_POLL_LIMIT=0 (test hook): every poll of a launch that spans tree levels gives up as soon as it has to
+    wait.  The call must not return a wrong result: the handle switches to the per-level launches, runs the operation
+    again and counts the event (hqpkkt_stats.n_poll_fallbacks); the results are those of the per-level launches, and
+    later calls on the handle stay there.  (the polled launches rest on index-ordered dispatch.)"""
+    prog = make()
+    st = problems.ip_state(prog, seed=3)
+    monkeypatch.setenv("HQPKKT_NO_SOLVE_TOP", "1")
+    monkeypatch.setenv("HQPKKT_NO_TREE_SWEEPS", "1")
+    R, dr, rr = _solve(cls, prog, st)  # the per-level launches, chosen up front
+    monkeypatch.delenv("HQPKKT_NO_SOLVE_TOP")
+    monkeypatch.delenv("HQPKKT_NO_TREE_SWEEPS")
+    monkeypatch.setenv("HQPKKT_POLL_LIMIT", "0")
+    A, da, ra = _solve(cls, prog, st)
+    monkeypatch.delenv("HQPKKT_POLL_LIMIT")
+    assert A.stats()["n_poll_fallbacks"] >= 1
+    assert A.debug(31)[0] == 0 and A.debug(31)[4] == 0  # neither k_solve_top nor the whole-tree sweeps any more
+    assert ra == rr and ra <= 1e-10
+    for x, yv in zip(da, dr):
+        assert np.array_equal(x, yv)
+    d2 = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    A.factor(prog, st[0], st[1])
+    assert A.solve(prog, *st, *d2) == rr
+    if what == "tree":  # the device-resident loop on the switched handle, and on one that has to switch inside the loop
+        xa = A.mehrotra(prog)
+        monkeypatch.setenv("HQPKKT_POLL_LIMIT", "0")
+        B = cls()
+        B.init(prog)
+        xb = B.mehrotra(prog)
+        monkeypatch.delenv("HQPKKT_POLL_LIMIT")
+        assert B.stats()["n_poll_fallbacks"] >= 1
+        assert xa[-1]["iters"] == xb[-1]["iters"] and xb[-1]["result"] == 0
+        assert np.array_equal(xa[0], xb[0])
+    # a handle made afterwards polls with the normal limit again
+    C, dc, rc = _solve(cls, prog, st)
+    assert C.stats()["n_poll_fallbacks"] == 0 and (C.debug(31)[0] >= 3 or C.debug(31)[4] == 1)

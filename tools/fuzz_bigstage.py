@@ -50,62 +50,62 @@ def solve(M, prog, st):
     return d, M.solve(prog, *st, *d)
 
 
+def check(case, tally=None):
+    """-> (status, detail) of case number ``case``: 'ok', 'skip' (nothing to compare with: the tree engine or the
+    reference does not solve it either) or 'BAD'; tally: dict that collects which engines the stages went through"""
+    prog, st, tag = make_case(case)
+    try:
+        S, F = ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()
+        df, rf = solve(F, prog, st)
+    except ipmatrix.KktError as e:
+        return "skip", tag + " the tree engine does not solve it"
+    try:
+        ds, rs = solve(S, prog, st)
+    except ipmatrix.KktError as e:
+        if e.code == 1:
+            return "skip", tag + " E_SIZES"
+        # E_SING: e.g. more final-state rows than the controls of all stages can absorb and a FIXED x_0 - the
+        # recursion cannot solve that, the reference's Hqp_IpLQDOCP neither (hqp/Hqp_IpLQDOCP.C:2097-2108); the
+        # tree engine factorises the whole system and may.  Not a difference if the reference fails as well.
+        ref_fails = False
+        try:
+            from oracle import refapi
+            if refapi.available():
+                L = refapi.RefIpMatrix("LQDOCP")
+                L.init(prog)
+                L.factor(st[0], st[1])
+                _ls, lres = L.solve(*st)
+                ref_fails = not (lres <= 1e-8)
+        except Exception:
+            ref_fails = True
+        if ref_fails:
+            return "skip", tag + " the reference fails as well"
+        return "BAD", f"{tag} raised {e} where the reference solves"
+    if tally is not None:
+        u, f = S.debug(28)
+        u0, f0 = S.debug(32)[:2]
+        for key, val in (("blocked", u), ("fell", f), ("x0_ran", u0), ("x0_fell", f0)):
+            tally[key] = tally.get(key, 0) + int(val)
+    if not (rf <= 1e-10):
+        return "skip", tag + " tree engine above 1e-10"
+    if rs <= 1e-10 and rel_err(ds, df) <= 1e-8:
+        return "ok", tag
+    return "BAD", f"{tag} residual {rs:.2e} (tree engine {rf:.2e}), relative difference {rel_err(ds, df):.2e}"
+
+
 def main():
     ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
     seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
     t0 = time.time()
     cnt = {"ok": 0, "skip": 0, "BAD": 0}
-    blocked = fell = x0_ran = x0_fell = 0
+    t = {"blocked": 0, "fell": 0, "x0_ran": 0, "x0_fell": 0}
     for case in range(seed0, seed0 + ncases):
-        prog, st, tag = make_case(case)
-        try:
-            S, F = ipmatrix.IpLQDOCP(), ipmatrix.IpLQDOCPFull()
-            df, rf = solve(F, prog, st)
-        except ipmatrix.KktError as e:
-            cnt["skip"] += 1  # the tree engine does not solve it: nothing to compare with
-            continue
-        try:
-            ds, rs = solve(S, prog, st)
-        except ipmatrix.KktError as e:
-            if e.code == 1:
-                cnt["skip"] += 1
-                continue
-            # E_SING: e.g. more final-state rows than the controls of all stages can absorb and a FIXED x_0 - the
-            # recursion cannot solve that, the reference's Hqp_IpLQDOCP neither (hqp/Hqp_IpLQDOCP.C:2097-2108); the
-            # tree engine factorises the whole system and may.  Not a difference if the reference fails as well.
-            ref_fails = False
-            try:
-                from oracle import refapi
-                if refapi.available():
-                    L = refapi.RefIpMatrix("LQDOCP")
-                    L.init(prog)
-                    L.factor(st[0], st[1])
-                    _ls, lres = L.solve(*st)
-                    ref_fails = not (lres <= 1e-8)
-            except Exception:
-                ref_fails = True
-            if ref_fails:
-                cnt["skip"] += 1
-                continue
-            cnt["BAD"] += 1
-            print(tag, "raised", e, "where the reference solves", flush=True)
-            continue
-        u, f = S.debug(28)
-        blocked += int(u)
-        fell += int(f)
-        u0, f0 = S.debug(32)[:2]
-        x0_ran += int(u0)
-        x0_fell += int(f0)
-        if not (rf <= 1e-10):
-            cnt["skip"] += 1
-            continue
-        if rs <= 1e-10 and rel_err(ds, df) <= 1e-8:
-            cnt["ok"] += 1
-        else:
-            cnt["BAD"] += 1
-            print(tag, f"residual {rs:.2e} (tree engine {rf:.2e}), relative difference {rel_err(ds, df):.2e}", flush=True)
-    print(f"fuzz_bigstage: {ncases} cases from {seed0}: {cnt}; stages through the blocked elimination {blocked}, fallen back {fell}; "
-          f"free initial states through the blocked inverse {x0_ran}, fallen back {x0_fell}; {time.time() - t0:.0f} s", flush=True)
+        status, detail = check(case, t)
+        cnt[status] += 1
+        if status == "BAD":
+            print(detail, flush=True)
+    print(f"fuzz_bigstage: {ncases} cases from {seed0}: {cnt}; stages through the blocked elimination {t['blocked']}, fallen back {t['fell']}; "
+          f"free initial states through the blocked inverse {t['x0_ran']}, fallen back {t['x0_fell']}; {time.time() - t0:.0f} s", flush=True)
 
 
 if __name__ == "__main__":

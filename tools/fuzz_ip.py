@@ -19,11 +19,11 @@ def objective(prog, x):
 HOT = os.environ.get("FUZZ_HOT", "") == "1"  # 1: hot starts (two QPs in a row) instead of cold starts
 SHIM = os.environ.get("FUZZ_SHIM", "") == "1"  # 1: Hqp_IpsMehrotra / Hqp_IpsFranke + SpBKPHip / RedSpBKPHip instead of the device loops
 OPTS = eval(os.environ.get("FUZZ_OPTS", "{}"))  # plugin options for every case, e.g. "dict(slack_policy=1)"
-ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
-seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-bad = odd = 0
-t0 = time.time()
-for case in range(seed0, seed0 + ncases):
+
+
+def check(case):
+    """-> (status, line) of fuzz case number ``case``: 'ok', 'odd' (explained: the reference itself is not optimal / the
+    final test missed by a hair on one side / counts spread like the reference's own two plugins) or 'BAD'"""
     rng = np.random.default_rng(5000 + case)
     what = str(rng.choice(["banded", "did", "docp"]))
     if what == "banded":
@@ -74,36 +74,43 @@ for case in range(seed0, seed0 + ncases):
             M.init(prog)
             x, y, z, w, info = M.franke(prog, max_iters=250)
     except Exception as e:
-        bad += 1
-        print("EXCEPTION", tag, repr(e)[:120], flush=True)
-        continue
+        return "BAD", f"EXCEPTION {tag} {repr(e)[:120]}"
     fr, fd = objective(prog, ref["x"]), objective(prog, x)
     same_f = abs(fr - fd) <= 1e-6 * max(1.0, abs(fr))
     slack = 2 if solver == "Mehrotra" else max(2, ref["iters"] // 10)
     same_it = abs(info["iters"] - ref["iters"]) <= slack
     line = f"{tag}: result {info['result']}/{ref['result']} iters {info['iters']}/{ref['iters']} f {fd:.10g}/{fr:.10g}"
     if info["result"] == ref["result"] and same_it and (same_f or ref["result"] != 0):
-        continue
+        return "ok", line
     if ref["result"] != 0 and info["result"] in (0, 3, 4):
-        odd += 1  # the reference does not end "optimal" itself: stall / E_SING next to the solution
-        print("reference not optimal:", line, flush=True)
-        continue
+        # the reference does not end "optimal" itself: stall / E_SING next to the solution
+        return "odd", "reference not optimal: " + line
     if {info["result"], ref["result"]} == {0, 3} and same_it and same_f:
-        odd += 1
-        print("final test missed by a hair on one side:", line, flush=True)
-        continue
+        return "odd", "final test missed by a hair on one side: " + line
     # how far apart are the reference's own two plugins on this QP?
     if HOT:
-        bad += 1
-        print("MISMATCH", line, flush=True)
-        continue
+        return "BAD", "MISMATCH " + line
     other = refapi.ip_solve(prog, solver, "RedSpBKP" if kind == "SpBKP" else "SpBKP", init_method=im)
     if info["result"] == ref["result"] == other["result"] and same_f and \
             abs(info["iters"] - ref["iters"]) <= 2 * abs(other["iters"] - ref["iters"]) + slack:
-        odd += 1
-        print(f"counts spread like the reference's own plugins ({other['iters']} with the other one):", line, flush=True)
-        continue
-    bad += 1
-    print("MISMATCH", line, f"(reference with its other plugin: {other['result']}, {other['iters']})", flush=True)
-print(f"{ncases} cases from {seed0}: {bad} bad, {odd} odd, {time.time() - t0:.0f} s")
-sys.exit(1 if bad else 0)
+        return "odd", f"counts spread like the reference's own plugins ({other['iters']} with the other one): " + line
+    return "BAD", f"MISMATCH {line} (reference with its other plugin: {other['result']}, {other['iters']})"
+
+
+def main():
+    ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+    seed0 = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+    bad = odd = 0
+    t0 = time.time()
+    for case in range(seed0, seed0 + ncases):
+        status, line = check(case)
+        bad += status == "BAD"
+        odd += status == "odd"
+        if status != "ok":
+            print(line, flush=True)
+    print(f"{ncases} cases from {seed0}: {bad} bad, {odd} odd, {time.time() - t0:.0f} s")
+    sys.exit(1 if bad else 0)
+
+
+if __name__ == "__main__":
+    main()
