@@ -30,10 +30,12 @@ typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // One system over several ranks (staged_plan.hpp): rank p owns the state columns [cut[p], cut[p+1]) of a stage
 // (multiples of 128, so a tile lies inside one strip).  StripTab: where the ranks' strips of W lie after the first
-// exchange of a stage - strip p = n+ rows of cut[p+1] - cut[p] columns, row-major, at xw + off[p].
+// exchange of a stage - strip p = n+ rows of cut[p+1] - cut[p] columns (and the control columns behind them), row-major
+// with leading dimension ld[p], at xw + off[p].
 struct StripTab {
   int nranks;
   int cut[17];
+  int ld[17];  // leading dimension of strip p (its width + the control columns, a multiple of 8)
   long long off[17];
 };
 // ... and where the blocks of G_xx lie after the second: block (a, b), a >= b, = rows of strip a x columns of strip b in
@@ -176,7 +178,7 @@ struct GemmTile {
     int jb = j0;  // first column of the tile inside its B block
     if (g.bstrips) {
       const int q = strip_of(g.bstrips->cut, g.bstrips->nranks, j0);
-      Bp = g.B + g.bstrips->off[q], ldb = g.bstrips->cut[q + 1] - g.bstrips->cut[q], jb = j0 - g.bstrips->cut[q];
+      Bp = g.B + g.bstrips->off[q], ldb = g.bstrips->ld[q], jb = j0 - g.bstrips->cut[q];
     }
     const long long bcol = (jb + cb < ldb) ? jb + cb : 0;
     // D register sets: the loads of slab t + D are issued before the multiplications of slab t and consumed (masked
@@ -401,7 +403,7 @@ struct GemmTile {
     int jb = j0;
     if (g.bstrips) {
       const int q = strip_of(g.bstrips->cut, g.bstrips->nranks, j0);
-      gl.B = g.B + g.bstrips->off[q], gl.ldb = g.bstrips->cut[q + 1] - g.bstrips->cut[q], jb = j0 - g.bstrips->cut[q];
+      gl.B = g.B + g.bstrips->off[q], gl.ldb = g.bstrips->ld[q], jb = j0 - g.bstrips->cut[q];
     }
     const double *pa = g.A + ((i0 + 2 * lane < g.lda) ? i0 + 2 * lane : 0);
     const double *pb = gl.B + ((jb + 2 * lane < gl.ldb) ? jb + 2 * lane : 0);
@@ -536,6 +538,48 @@ __global__ void __launch_bounds__(64 * WGM * WGN, gemm_waves_per_simd(WGM * WGN,
     g.stamps[4 * blockIdx.x + 0] = t0, g.stamps[4 * blockIdx.x + 1] = (unsigned long long)(xcc & 15);
     g.stamps[4 * blockIdx.x + 2] = t2, g.stamps[4 * blockIdx.x + 3] = __builtin_amdgcn_s_memrealtime();
   }
+}
+
+// A THIN product - a handful of tiles, thousands of k (the control rows of G: 50 x 690 x 5000; the carried rows) - is a
+// chain of 313 slabs in each of its few workgroups: 330 us for 0.3 GFlop.  Cut in k: workgroup (tile, y) sums the slabs
+// of piece y into part[y] (M x N, raw sums), k_dgemm_ks_finish adds the pieces in their order (reproducible) and applies
+// alpha / beta.  Not lower, not mirrored; register-staged 64-wide tiles.
+template <int BM, int BN>
+__global__ void __launch_bounds__(256) k_dgemm_tn_ks(GemmArgs g, double *__restrict__ part, int nsplit) {
+  using T = GemmTile<BM, BN, 2, 2>;
+  extern __shared__ __attribute__((aligned(16))) double lds[];
+  double *As = lds, *Bs = lds + 2 * T::BK * T::LDA;
+  int tm, tn;
+  T::tile_of(g, blockIdx.x, tm, tn);
+  const int nslab = (g.K + T::BK - 1) / T::BK, L = (nslab + nsplit - 1) / nsplit;
+  const int s0 = min(nslab, (int)blockIdx.y * L), s1 = min(nslab, s0 + L);
+  double4_t acc[T::TM][T::TN];
+#pragma unroll
+  for (int x = 0; x < T::TM; x++)
+#pragma unroll
+    for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, wm = wave / 2, wn = wave % 2, lr = lane & 15, lk = lane >> 4;
+  double *out = part + (long long)blockIdx.y * g.M * g.N;
+#pragma unroll
+  for (int x = 0; x < T::TM; x++)
+#pragma unroll
+    for (int y = 0; y < T::TN; y++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int i = tm * BM + wm * T::WM + 16 * x + lk + 4 * rg, j = tn * BN + wn * T::WN + 16 * y + lr;
+        if (i < g.M && j < g.N) out[(long long)i * g.N + j] = acc[x][y][rg];
+      }
+}
+__global__ void k_dgemm_ks_finish(GemmArgs g, const double *__restrict__ part, int nsplit) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x, tot = (long long)g.M * g.N;
+  if (e >= tot) return;
+  double s = 0.0;
+  for (int y = 0; y < nsplit; y++) s += part[(long long)y * tot + e];
+  const int i = (int)(e / g.N), j = (int)(e % g.N);
+  double v = g.alpha * s;
+  if (g.beta != 0.0) v += g.beta * g.Cin[(long long)i * g.ldcin + j];
+  g.C[(long long)i * g.ldc + j] = v;
 }
 
 // The same product for tile counts that do not fill the chip evenly (1600 tiles on 512 workgroup
@@ -768,6 +812,7 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn<128, 128, true, 2, 4>, gemm_lds_bytes(128, 128));
   set((const void *)k_dgemm_tn<64, 64>, gemm_lds_bytes(64, 64));
   set((const void *)k_dgemm_tn<64, 32>, gemm_lds_bytes(64, 32));
+  set((const void *)k_dgemm_tn_ks<64, 64>, gemm_lds_bytes(64, 64));
   set((const void *)k_dgemm_tn_sk<false>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true>, gemm_sk_lds_bytes());
   set((const void *)k_dgemm_tn_sk<true, 2, 4>, gemm_sk_lds_bytes());
@@ -2655,15 +2700,18 @@ __global__ void __launch_bounds__(256) k_st_pack_rects(const PackRect *__restric
     __syncthreads();
   }
 }
-// The first exchange of a stage carries, behind the n+ rows of every rank's W strip, its columns of the control rows of
-// G (W_u' F_p: m rows) and of the carried rows (B+ F_p: capx rows): into their places in G and N.  blockIdx.y = rank.
+// The first exchange of a stage carries, behind the n+ rows of every rank's [W_p | W_u], the same columns of the control
+// rows of G (W_u' Floc: m rows) and of the carried rows (B+ Floc: capx rows): the state columns of all ranks and the
+// control columns of rank `own`'s slot into their places in G and N.  blockIdx.y = rank.
 __global__ void __launch_bounds__(256) k_st_unpack_extra(const StripTab *__restrict__ tab, const double *__restrict__ xw, int np, int m, int capx,
-                                                         double *__restrict__ Gu, long long ldg, double *__restrict__ Nc, long long ldn) {
-  const int q = blockIdx.y, c0 = tab->cut[q], w = tab->cut[q + 1] - c0;
-  const double *src = xw + tab->off[q] + (long long)np * w;
+                                                         int nn, int own, double *__restrict__ Gu, long long ldg, double *__restrict__ Nc,
+                                                         long long ldn) {
+  const int q = blockIdx.y, c0 = tab->cut[q], w = tab->cut[q + 1] - c0, ld = tab->ld[q];
+  const int ncol = w + (q == own ? m : 0);
+  const double *src = xw + tab->off[q] + (long long)np * ld;
   for (int i = blockIdx.x; i < m + capx; i += gridDim.x) {
-    double *dst = i < m ? Gu + (long long)i * ldg + c0 : Nc + (long long)(i - m) * ldn + c0;
-    for (int j = threadIdx.x; j < w; j += blockDim.x) dst[j] = src[(long long)i * w + j];
+    double *dst = i < m ? Gu + (long long)i * ldg : Nc + (long long)(i - m) * ldn;
+    for (int j = threadIdx.x; j < ncol; j += blockDim.x) dst[j < w ? c0 + j : nn + (j - w)] = src[(long long)i * ld + j];
   }
 }
 // rows x cols block copy (the own row strip of V_k out of the transient full block)

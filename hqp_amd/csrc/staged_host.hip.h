@@ -29,7 +29,7 @@ struct StagedDev {
   DBuf<stg::DynLoc> dyn_loc;
   DBuf<double> dyn_sum;
   long long dyn_sum_x2 = 0;  // offset of A_dyn dx in dyn_sum
-  hipEvent_t ev_wu = nullptr, ev_x1 = nullptr;
+  hipEvent_t ev_x1 = nullptr;
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
   int cus = 0;
@@ -73,7 +73,6 @@ struct StagedDev {
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), dyn_part.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
     wtabs.release(), rtabs.release(), gtile.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
-    if (ev_wu) (void)hipEventDestroy(ev_wu), ev_wu = nullptr;
     if (ev_x1) (void)hipEventDestroy(ev_x1), ev_x1 = nullptr;
     for (int b = 0; b < 2; b++) {
       if (hblk[b]) (void)hipHostFree(hblk[b]), hblk[b] = nullptr;
@@ -139,7 +138,15 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   }
   if (big)
     KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g, d ? d->cus : 0));
-  else {
+  else if (d && allow_sk && d->cus > 0 && !g.lower && !g.mirror && g.K >= 1024 && tiles * 4 <= d->cus &&
+           (long long)g.M * g.N * 8 <= d->sk_ws_elems && !getenv("HQPKKT_NO_KSPLIT")) {
+    // a thin, deep product: its k range cut over the chip (k_dgemm_tn_ks), the pieces added in their order
+    const int nslab = (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK;
+    int nsplit = (int)std::min<long long>(nslab / 4, std::max<long long>(1, (2LL * d->cus) / tiles));
+    nsplit = (int)std::min<long long>(nsplit, d->sk_ws_elems / std::max<long long>(1, (long long)g.M * g.N));
+    KLAUNCH(h, cls, (stg::k_dgemm_tn_ks<64, 64><<<dim3((unsigned)tiles, nsplit), 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g, d->sk_ws.p, nsplit)));
+    KLAUNCH(h, cls, stg::k_dgemm_ks_finish<<<nblk((long long)g.M * g.N), 256, 0, h->stream>>>(g, d->sk_ws.p, nsplit));
+  } else {
     // few tiles of a deep rectangular product (W of a stage of ~1000 states: 272): 64 x 32 tiles, so that a CU holds two
     // workgroups and one multiplies while the other waits at its barrier: 81 -> 73 us (HQPKKT_NO_TILE6432: off)
     static const bool t6432 = getenv("HQPKKT_NO_TILE6432") == nullptr;
@@ -456,7 +463,7 @@ static int staged_upload(hqpkkt_t *h) {
       t.nranks = r.nranks = NR;
       for (int p = 0; p <= NR; p++) {
         t.cut[p] = r.cut[p] = cut[p];
-        if (p < NR) t.off[p] = (long long)p * P.xwslot[k];
+        if (p < NR) t.off[p] = (long long)p * P.xwslot[k], t.ld[p] = (cut[p + 1] - cut[p] + P.mk[k] + 7) / 8 * 8;
       }
       for (auto &b : r.blk) b.off[0] = b.off[1] = 0, b.rsplit = 1 << 30, b.pad = 0;
       d.prect_ptr[k] = (int)pr.size();
@@ -484,7 +491,6 @@ static int staged_upload(hqpkkt_t *h) {
     std::vector<int> gt = P.gtile;
     if (gt.empty()) gt.push_back(0);
     if ((e = d.wtabs.upload(wt)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt))) return e;
-    if (!d.ev_wu) HIPCHK(hipEventCreateWithFlags(&d.ev_wu, hipEventDisableTiming));
     if (!d.ev_x1) HIPCHK(hipEventCreateWithFlags(&d.ev_x1, hipEventDisableTiming));
   }
   // orders of the tiles of the triangular products (G, V)
@@ -632,12 +638,12 @@ static int st_gemm_tiles(hqpkkt_t *h, stg::GemmArgs g, int ntiles, int cls) {
 // staged_plan.hpp).  Rank p owns the state columns [c0, c1) of the stage: its memory holds those columns of F_k (and the
 // control columns), its products are the strip W_p = V+ F_p and the blocks of G_xx the plan gives it; everything
 // control-sized is computed by every rank on identical data.  Two streams:
-//   sA (the handle's): W_p = V+ F_p, then - behind W_u of sB - its columns of the control rows of G (W_u' F_p) and of
-//       the carried rows (B+ F_p), all three into its slot  ->  EXCHANGE 1 (gather of the slots)  ->  its blocks of
-//       G_xx = F_p' W_q in ONE launch (the B operand from the ranks' slots, the tiles of the plan's list), + H_xx  ->
-//       pack (lower orientation)  ->  EXCHANGE 2
-//   sB: W_u = V+ f_u, G_uu, the control columns of the carried rows; behind exchange 1: the control rows of G and the
-//       carried rows into their places, rank decision, K^-1 (k_st_small), Y (k_st_wide), Rm = K^-1 Y
+//   sA (the handle's): [W_p | W_u] = V+ Floc, its columns of the control rows of G (W_u' Floc) and of the carried rows
+//       (B+ Floc), all three into its slot  ->  EXCHANGE 1 (gather of the slots)  ->  its blocks of G_xx = F_p' W_q in
+//       ONE launch (the B operand from the ranks' slots, the tiles of the plan's list), + H_xx  ->  pack (lower
+//       orientation)  ->  EXCHANGE 2
+//   sB, behind exchange 1: the control rows of G and the carried rows into their places, rank decision, K^-1
+//       (k_st_small), Y (k_st_wide), Rm = K^-1 Y - beside the blocks of G_xx
 // and, joined: V_k = G_xx - Y' Rm over the WHOLE lower triangle, mirrored, with G_xx read straight from the blocks in
 // the exchange buffer (GemmArgs::rects) into the transient full block; the rank keeps its row strip for the solve.
 static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots);
@@ -650,9 +656,9 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
   const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k], q = P.qmax[k], cx = P.cap[k + 1];
   const int *cut = &P.xcut[(size_t)k * (NR + 1)];
   const int c0 = cut[RK], c1 = cut[RK + 1], wd = c1 - c0;
-  const long long ldfl = P.ldfl[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k], ldwu = P.ldwu;
-  double *G = d.misc.p + P.oG, *Wu = d.misc.p + P.oWu, *xw = d.misc.p + P.oXW, *xb = d.misc.p + P.oX;
-  double *slot = xw + (long long)RK * P.xwslot[k];
+  const long long ldfl = P.ldfl[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k];
+  double *G = d.misc.p + P.oG, *xw = d.misc.p + P.oXW, *xb = d.misc.p + P.oX;
+  double *slot = xw + (long long)RK * P.xwslot[k];  // [W_p | W_u] (n+ rows), the control rows of G (m), the carried rows (cx): ld = ldfl
   hipStream_t sA = h->stream, sB = d.stream2 ? d.stream2 : h->stream;
   struct StreamGuard {  // launches go to h->stream: back to the first stream on every way out
     hqpkkt_t *h;
@@ -669,50 +675,37 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
       if (armed && hipEventRecord(ev, b) == hipSuccess) (void)hipStreamWaitEvent(a, ev, 0);
     }
   } join{false, sA, sB, d.ev_join};
-  if (two) {
-    HIPCHK(hipEventRecord(d.ev_fork, sA));
-    HIPCHK(hipStreamWaitEvent(sB, d.ev_fork, 0));
-    join.armed = true;
-  }
   const int ne_x = P.h_mid[k] - P.h_ptr[k], ne_u = P.h_ptr[k + 1] - P.h_mid[k];
   auto add_h = [&](int first, int count) {
     if (count)
       KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(count), 256, 0, h->stream>>>(count, d.h_dst.p + first, d.h_tptr.p + first, d.h_terms.p,
                                                                                  h->vals.p, h->wt.p, G, 1));
   };
-  const double *Fu = sp.F + wd;  // the control columns of the local block
-  // ---- sB, first part: what needs the control columns only (the workspace of the cut products belongs to sA: plain kernels)
-  h->stream = sB;
-  if (mm > 0) {
-    if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, Fu, ldfl, nullptr, 0, Wu, ldwu, np, mm, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)) ||
-        (e = st_gemm(h, stg::GemmArgs{Wu, ldwu, Fu, ldfl, nullptr, 0, G + (long long)nn * ldg + nn, ldg, mm, mm, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)))
-      return e;
-    if (cx > 0 && (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], Fu, ldfl, nullptr, 0, sp.N + (size_t)ek * P.ldn[k] + nn, P.ldn[k], cx, mm, np,
-                                                1.0, 0.0, 0, 0}, KC_ST_GEMM_UPD, !two)))
-      return e;
-  }
-  if (two) HIPCHK(hipEventRecord(d.ev_wu, sB));
-  // ---- sA: the strip of W and the rank's columns of the control-sized rows, into its slot
-  h->stream = sA;
-  if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldfl, nullptr, 0, slot, wd, np, wd, np, 1.0, 0.0, 0, 0}))) return e;
-  if (two) HIPCHK(hipStreamWaitEvent(sA, d.ev_wu, 0));
-  if (wd > 0 && mm > 0 &&
-      (e = st_gemm(h, stg::GemmArgs{Wu, ldwu, sp.F, ldfl, nullptr, 0, slot + (long long)np * wd, wd, mm, wd, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two)))
+  // ---- sA: [W_p | W_u] = V+ Floc in one product, then - thin and deep: cut in k - the same columns of the control rows of
+  // G (W_u' Floc) and of the carried rows (B+ Floc), all into the rank's slot
+  const int nloc = wd + mm;
+  if (nloc > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldfl, nullptr, 0, slot, ldfl, np, nloc, np, 1.0, 0.0, 0, 0}))) return e;
+  if (mm > 0 &&
+      (e = st_gemm(h, stg::GemmArgs{slot + wd, ldfl, sp.F, ldfl, nullptr, 0, slot + (long long)np * ldfl, ldfl, mm, nloc, np, 1.0, 0.0, 0, 0})))
     return e;
-  if (wd > 0 && cx > 0 &&
-      (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, ldfl, nullptr, 0, slot + (long long)(np + mm) * wd, wd, cx, wd, np, 1.0, 0.0, 0, 0},
-                   KC_ST_GEMM_UPD, !two)))
+  if (cx > 0 && nloc > 0 &&
+      (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, ldfl, nullptr, 0, slot + (long long)(np + mm) * ldfl, ldfl, cx, nloc, np, 1.0, 0.0, 0, 0},
+                   KC_ST_GEMM_UPD)))
     return e;
   if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xw, P.xwslot[k], NR))) return e;
   if (two) {
     HIPCHK(hipEventRecord(d.ev_x1, sA));
     HIPCHK(hipStreamWaitEvent(sB, d.ev_x1, 0));
+    join.armed = true;
   }
   // ---- sB, second part: the control-sized chain
   h->stream = sB;
   if (mm + cx > 0)
     KLAUNCH(h, KC_ST_VEC, stg::k_st_unpack_extra<<<dim3(std::min(mm + cx, 1024), NR), 256, 0, h->stream>>>(
-                              d.wtabs.p + k, xw, np, mm, cx, G + (long long)nn * ldg, ldg, sp.N + (size_t)ek * P.ldn[k], P.ldn[k]));
+                              d.wtabs.p + k, xw, np, mm, cx, nn, 0, G + (long long)nn * ldg, ldg, sp.N + (size_t)ek * P.ldn[k], P.ldn[k]));
+  // (the control columns from rank 0's slot on EVERY rank: the ranks' own copies of W_u come out of products of different
+  // shapes - other cut plans, another order of the k pieces - and differ in their last bits; the control-sized chain must
+  // see identical data everywhere, or the ranks' rank decisions and refinement loops could part ways)
   add_h(P.h_mid[k], ne_u);
   {
     stg::SmallArgs sa{G, ldg, nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,

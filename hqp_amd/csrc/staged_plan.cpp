@@ -271,14 +271,13 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   // ------------------------------------------------------------------ one system over several ranks (staged_plan.hpp)
   xcut.clear(), xw.clear(), ldfl.clear(), oFl.clear(), oVs.clear(), xwslot.clear(), xslot.clear();
   xrects.clear(), xrect_ptr.clear(), gtile.clear(), gtile_ptr.clear();
-  oX = oXW = oXV = oXP = oWu = oDyx = 0, xvslot = xpslot = 0, oVf[0] = oVf[1] = 0;
+  oX = oXW = oXV = oXP = oDyx = 0, xvslot = xpslot = 0, oVf[0] = oVf[1] = 0;
   if (sharded) {
     const int P = shard_count, me_ = shard_rank;
     if (P < 1 || P > 16 || me_ < 0 || me_ >= P) return 1;
     xcut.assign((size_t)(K + 1) * (P + 1), 0), xw.assign(K + 1, 0);
     ldfl.assign(K + 1, 8), oFl.assign(K + 1, 0), oVs.assign(K + 1, 0), xwslot.assign(K + 1, 0), xslot.assign(K + 1, 0);
-    long long flo = 0, vso = 0, vfmax = 0, xwmax = 0, xmax = 0, wumax = 0;
-    int mmax = 1;
+    long long flo = 0, vso = 0, vfmax = 0, xwmax = 0, xmax = 0;
     for (int k = 0; k <= K; k++) {
       const long long nn = nk[k];
       if (k < K && (nn & 1)) return 1;  // the control columns of Floc start behind the strip: 16-byte loads need it even
@@ -293,10 +292,8 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       if (k < K) {
         ldfl[k] = up8(wd + mk[k]);
         oFl[k] = flo, flo += up16((long long)nk[k + 1] * ldfl[k]);
-        xwslot[k] = up16(((long long)nk[k + 1] + mk[k] + cap[k + 1]) * xw[k]);
+        xwslot[k] = up16(((long long)nk[k + 1] + mk[k] + cap[k + 1]) * up8(xw[k] + mk[k]));
         xwmax = std::max(xwmax, xwslot[k]);
-        mmax = std::max(mmax, mk[k]);
-        wumax = std::max(wumax, (long long)nk[k + 1] * up8(std::max(mk[k], 1)));
       }
     }
     // the blocks of G_xx: who computes which
@@ -343,8 +340,6 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       }
     }
     xrect_ptr[K] = (int)xrects.size(), gtile_ptr[K] = (int)gtile.size();
-    ldwu = up8(mmax);
-    oWu = mo, mo += up16(wumax + 8);
     oXW = mo, mo += up16(xwmax * P);
     oX = mo, mo += up16(xmax * P);
     oXV = mo, mo += up16(xvslot * P);

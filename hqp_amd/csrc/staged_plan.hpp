@@ -69,11 +69,13 @@ struct StagedPlan {
   // contiguous range per rank - the same width for every rank but the last, a multiple of 128 - and the memory goes
   // with them: rank p keeps the columns [cut[p], cut[p+1]) of F_k next to the control columns (Floc_k = [F_p | F_u],
   // n+ x ldfl) and, for the solve, the ROWS [cut[p], cut[p+1]) of V_k.  Per stage of the factorisation:
-  //   W_p = V+ F_p                                   local (V+ in full: the transient result of the stage before)
-  //   exchange 1: [W_p ; W_u' F_p ; B+ F_p]          n+ + m + cap+ rows of the rank's width (gather of the slots)
-  //   G_xx block (a, b), a >= b                      by rank a (F_a' W_b) or rank b (W_a' F_b): pair {a, b} belongs to
-  //                                                  b if a - b <= (P - 1) / 2 else to a; with P even the pairs P / 2
-  //                                                  apart are cut in two by rows; diagonal blocks: lower tiles
+  //   Wloc = V+ Floc = [W_p | W_u]                  local (V+ in full: the transient result of the stage before)
+  //   exchange 1: [Wloc ; W_u' Floc ; B+ Floc]       n+ + m + cap+ rows of the rank's local width (gather of the slots)
+  //   G_xx block (a, b), a >= b                      by one of the two ranks, as F_p' W_q in its row strip of the work
+  //                                                  block (the owner of the columns computes the transpose): pair
+  //                                                  {a, b} belongs to b if a - b <= (P - 1) / 2 else to a; with P even
+  //                                                  the pairs P / 2 apart are cut in two by rows; diagonal blocks:
+  //                                                  lower tiles
   //   exchange 2: the blocks (lower orientation)     n^2 / 2 doubles in all
   //   V_k = G_xx - Y' Rm in full (every rank), its row strip kept
   // The control-sized chain is computed by every rank on identical data.  The solve's products run on the strips with
@@ -85,8 +87,6 @@ struct StagedPlan {
   std::vector<int> ldfl;         // per stage: leading dimension of Floc_k (own strip + control columns)
   std::vector<long long> oFl, oVs;  // local F blocks (F arena), own row strips of V_k (V arena, ld = ldv[k])
   long long oVf[2] = {0, 0};     // the two full-size transient V blocks (misc arena): V_k lives in oVf[k & 1]
-  long long oWu = 0;             // W_u = V+ F_u, n+ x ldwu (misc)
-  int ldwu = 8;
   long long oXW = 0;             // exchange 1: shard_count slots of xwslot[k] doubles (misc)
   std::vector<long long> xwslot;
   long long oX = 0;              // exchange 2: shard_count slots of xslot[k] doubles (misc)

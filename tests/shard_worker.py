@@ -42,7 +42,8 @@ def c4dense_case(case, rank, world, dev):
     s = M.stats()
     cuts = M.debug(27).reshape(-1, world + 1)
     rec = dict(case=case, rank=rank, res=res, staged=True, cuts=cuts[0].tolist(), flops_local=s["flops_local"],
-               bytes_factor=s["bytes_exchange_factor"], ranks=s["shard_count"], refine_rounds=s["refine_rounds"])
+               bytes_factor=s["bytes_exchange_factor"], ranks=s["shard_count"], refine_rounds=s["refine_rounds"],
+               bytes_panels=s["bytes_panels"])
     del M
     torch.cuda.empty_cache()
     tdist.barrier()  # (the unsharded partner below needs the memory the other ranks have just released)
@@ -52,6 +53,7 @@ def c4dense_case(case, rank, world, dev):
         d0 = [torch.zeros_like(t) for t in d]
         R.factor(None, z, w)
         rec["res_single"] = R.solve(None, z, w, *r, *d0)
+        rec["bytes_panels_single"] = R.stats()["bytes_panels"]
         rec["diff"] = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-300)) for a, b in zip(d, d0) if b.numel())
         del R
     t = torch.cat(d).cpu()
@@ -113,13 +115,15 @@ def main():
             prog = problems.banded_qp(case[1], case[2])
         elif case[0] == "docp":
             prog = problems.lq_docp(case[1], case[2], case[3])
+        elif case[0] == "docpx":  # ["docpx", K, nx, nu, {options of problems.lq_docp}, spread, kind]
+            prog = problems.lq_docp(case[1], case[2], case[3], **case[4])
         elif case[0] == "grid":  # mesh QP through the tree of the graph's own dissection (opts.ordering)
             prog = problems.grid_sparse_qp(case[1], case[2])
         elif case[0] == "did_spread":  # w/z over 12 decades on weak Hessian diagonals: the refinement fails and the
             prog = problems.did_like_qp(case[1])  # handle switches its zero-diagonal placement (every rank must)
         else:
             prog = problems.did_like_qp(case[1])
-        st = problems.ip_state(prog, case[2], case[3]) if case[0] == "did_spread" else problems.ip_state(prog, 7, 1.0)
+        st = problems.ip_state(prog, case[2], case[3]) if case[0] == "did_spread" else problems.ip_state(prog, 7, case[5] if case[0] == "docpx" else 1.0)
         cls = {"SpBKP": ipmatrix.IpSpBKP, "RedSpBKP": ipmatrix.IpRedSpBKP, "LQDOCP": ipmatrix.IpLQDOCP}[kind]
         kw = dict(ordering=case[3]) if case[0] == "grid" else {}
         if os.environ.get("SHARD_TRANSPORT") == "rccl":  # libhqpkkt_rccl.so: stream-ordered collectives
@@ -135,7 +139,7 @@ def main():
         if kind == "LQDOCP":
             cuts = M.debug(27).reshape(-1, world + 1)
             rec = dict(case=case, rank=rank, res=res, staged=True, cuts=cuts[0].tolist(), flops_local=s["flops_local"],
-                       bytes_factor=s["bytes_exchange_factor"], ranks=s["shard_count"])
+                       bytes_factor=s["bytes_exchange_factor"], ranks=s["shard_count"], bytes_panels=s["bytes_panels"])
         else:
             owner = M.debug(10)
             rec = dict(case=case, rank=rank, res=res, n_top=s["n_top"], xblocks=s["n_exchange_blocks"],
@@ -149,6 +153,7 @@ def main():
             d0 = new_d(prog)
             res0 = R.solve(prog, *st, *d0)
             rec["res_single"] = res0
+            rec["bytes_panels_single"] = R.stats()["bytes_panels"]
             rec["diff"] = max(float(np.abs(a - b).max() / max(np.abs(b).max(), 1e-300))
                               for a, b in zip(d, d0) if len(b))
         # all ranks must hold the same full solution

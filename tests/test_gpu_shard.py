@@ -12,6 +12,31 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
+
+def _transport(world):
+    """Environment of the ranks: with at least `world` GPUs in the box every rank takes its own and the exchange is
+    libhqpkkt_rccl.so's (RCCL over xGMI, collectives in the handle's stream); on the one-GPU test box the ranks share
+    cuda:0 and the exchange is staged through gloo."""
+    import torch
+    if torch.cuda.device_count() >= world and world > 1:  # (counting devices does not initialise the GPU)
+        return dict(SHARD_BACKEND="nccl", SHARD_TRANSPORT="rccl")
+    return dict(SHARD_BACKEND="gloo")
+
+
+def _run_workers(world, cases, extra_env=None, timeout=900):
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:  # a free port (concurrent runs must not collide)
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ, SHARD_CASES=json.dumps(cases), MASTER_ADDR="127.0.0.1", **_transport(world))
+    env.update(extra_env or {})
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(world),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "tests", "shard_worker.py")]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT, env=env)
+    assert out.returncode == 0, (out.stdout[-2000:], out.stderr[-3000:])
+    line = [l for l in out.stdout.splitlines() if l.startswith("SHARD_RESULT ")][-1]
+    return json.loads(line[len("SHARD_RESULT "):])
+
 CASES = [["banded", 1500, 12, "SpBKP"], ["banded", 1500, 12, "RedSpBKP"], ["docp", 24, 6, 3, "SpBKP"],
          ["did", 400, "RedSpBKP"], ["grid", 40, 40, 1, "RedSpBKP"]]
 
@@ -87,6 +112,43 @@ def test_sharded_staged_system_matches_single(world, port):
             assert r["res"] <= 1e-10 and r["same_as_rank0"] and r["ranks"] == world, (case, r)
 
 
+# the stage shapes of the recursion: final-state rows carried back through the stages (the carried rows' columns travel
+# with the first exchange), path equalities that consume controls, a FREE initial state (v_0 gathered), state bounds,
+# w/z spread over decades; the last with more ranks than 128-column blocks (empty strips)
+STAGED_SHAPES = [["docpx", 6, 300, 5, dict(x0_fixed=True, final_eq=7), 1.0, "LQDOCP"],
+                 ["docpx", 5, 280, 6, dict(x0_fixed=False, final_eq=4, path_eq=2), 2.0, "LQDOCP"],
+                 ["docpx", 4, 520, 12, dict(x0_fixed=False, path_eq=3, path_eq_every=2, x_bounds=40), 1.0, "LQDOCP"],
+                 ["docpx", 7, 140, 4, dict(x0_fixed=True, final_eq=3, x_bounds=10), 3.0, "LQDOCP"]]
+
+
+@pytest.mark.parametrize("world", [2, 3, 4])
+def test_memory_sharded_stages_on_every_stage_shape(world):
+    """the memory-sharded partition (every rank holds its column strip of F_k and its row strip of
+    V_k only) with 2, 3 and 4 ranks against the unsharded handle on the same system: solutions equal to 1e-9, the
+    residual bound on every rank, identical vectors on all ranks.  Two ranks: the pair of blocks half the ring apart is
+    cut in two; three: every pair has one owner; four: both kinds."""
+    per_rank = _run_workers(world, STAGED_SHAPES)
+    for ci, case in enumerate(STAGED_SHAPES):
+        recs = [r[ci] for r in per_rank]
+        assert recs[0]["diff"] < 1e-9, (case, recs[0])
+        for r in recs:
+            assert r["res"] <= 1e-10 and r["same_as_rank0"] and r["ranks"] == world, (case, r)
+
+
+@pytest.mark.parametrize("world", [3, 4])
+def test_memory_sharded_dense_hand_over(world):
+    """The dense hand-over (hqpkkt_set_values_staged: every rank copies its columns of the caller's blocks) and the
+    products of residuum() with the local blocks (summed over the ranks), stages of 1024 states: same solution as the
+    unsharded handle, and the rank's arenas hold about 1 / P of the unsharded ones (strips are whole 128-column blocks:
+    8 blocks over 3 ranks = 3 + 3 + 2, so 12.5 % more than a third here; the 10 % bound is checked at full stage width)."""
+    case = ["c4dense", 12, 1024, 16, "LQDOCP"]
+    recs = [r[0] for r in _run_workers(world, [case])]
+    assert recs[0]["diff"] < 1e-9, recs[0]
+    for r in recs:
+        assert r["res"] <= 1e-10 and r["same_as_rank0"] and r["ranks"] == world, r
+        assert r["bytes_panels"] <= recs[0]["bytes_panels_single"] * (1.0 / world) * 1.20, (r["bytes_panels"], recs[0]["bytes_panels_single"])
+
+
 def test_sharded_staged_system_at_full_stage_width():
     """configs[3]'s stage width (nx = 5000, nu = 50, K = 20 stages, dense hand-over) over two ranks that share
     the one GPU of the test box: the stream-K column slices, the pack / unpack of the strips of V_k and the
@@ -112,6 +174,9 @@ def test_sharded_staged_system_at_full_stage_width():
     # both ranks do about half of the products
     f0, f1 = recs[0]["flops_local"], recs[1]["flops_local"]
     assert abs(f0 - f1) <= 0.1 * max(f0, f1), (f0, f1)
+    # ... and hold about half of the stage blocks (<= 1 / P + 10 %)
+    for r in recs:
+        assert r["bytes_panels"] <= recs[0]["bytes_panels_single"] * 0.5 * 1.10, (r["bytes_panels"], recs[0]["bytes_panels_single"])
 
 
 def test_sharded_staged_system_with_an_odd_number_of_states_is_refused():
