@@ -988,13 +988,14 @@ static int graphed(hqpkkt_t *h, hqpkkt::GraphSlot &slot, F body) {
 
 // The exchange steps of a sharded system: the handle's stream is
 // drained, the caller's collective runs, and the next phase starts afterwards.
-static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots) {
+static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots, hipStream_t on = nullptr) {
   // (profiled as the class "exchange": in the stream-ordered form the time between the collective's place in
   // the stream and its completion - the wait for the slowest rank and the transfer)
-  if (h->xchg_sfn) {  // the collective is put into the handle's stream behind the kernels that fill `buf`
-    h->prof.begin(KC_XCHG, h->stream);
-    const int rc = h->xchg_sfn(h->xchg_ctx, op, buf, slot, nslots, (void *)h->stream);
-    h->prof.end(h->stream);
+  if (h->xchg_sfn) {  // the collective is put into the handle's stream (or `on`) behind the kernels that fill `buf`
+    hipStream_t st = on ? on : h->stream;
+    h->prof.begin(KC_XCHG, st);
+    const int rc = h->xchg_sfn(h->xchg_ctx, op, buf, slot, nslots, (void *)st);
+    h->prof.end(st);
     return rc ? HQPKKT_E_DEVICE : 0;
   }
   if (!h->xchg_fn) return HQPKKT_E_INTERN;
@@ -2650,7 +2651,8 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   int cus = 0;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
   const int skg = stg::gemm_wgs_per_cu(variant) * cus;
-  const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && stg::gemm_use_split(M, N, K, lower, skg);
+  // (HQPKKT_DGEMM_FORCE_SPLIT: the cut form whatever the launch rules say - same-box comparisons of the two forms)
+  const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && (stg::gemm_use_split(M, N, K, lower, skg) || getenv("HQPKKT_DGEMM_FORCE_SPLIT"));
   const bool big = use_sk || stg::gemm_big_tiles(M, N, lower, K);
   const int b = big ? 128 : 64;
   const long long tiles = stg::gemm_tiles(M, N, b, lower);

@@ -21,7 +21,7 @@ struct StagedDev {
   // one system over several ranks (staged_plan.hpp): per stage where the ranks' strips of W / blocks of G_xx lie in the
   // exchange buffers, this rank's tiles of its blocks' products and its blocks to pack; the local dynamics blocks of
   // residuum()'s products and their summed results (A_dyn' dy: n, A_dyn dx: ndyn)
-  DBuf<stg::StripTab> wtabs;
+  DBuf<stg::StripTab> wtabs, wtabs2;  // (the two parts of the first exchange: upper rows of W, the rest)
   DBuf<stg::RectTab> rtabs;
   DBuf<int> gtile;
   DBuf<stg::PackRect> prects;
@@ -29,7 +29,11 @@ struct StagedDev {
   DBuf<stg::DynLoc> dyn_loc;
   DBuf<double> dyn_sum;
   long long dyn_sum_x2 = 0;  // offset of A_dyn dx in dyn_sum
-  hipEvent_t ev_x1 = nullptr;
+  // the exchanges of a stage in the stream-ordered form (RCCL) go to a stream of their own, so that the first part of
+  // exchange 1 travels beside the products of the second: ev_w[i] "part i of the slot is complete" (first stream),
+  // ev_x[i] "exchange i has arrived" (i = 0, 1: the parts of exchange 1, 2: exchange 2)
+  hipStream_t stream_x = nullptr;
+  hipEvent_t ev_x1 = nullptr, ev_w[3] = {nullptr, nullptr, nullptr}, ev_x[3] = {nullptr, nullptr, nullptr};
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
   int cus = 0;
@@ -72,7 +76,10 @@ struct StagedDev {
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), dyn_part.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
-    wtabs.release(), rtabs.release(), gtile.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
+    wtabs.release(), wtabs2.release(), rtabs.release(), gtile.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
+    if (stream_x) (void)hipStreamDestroy(stream_x), stream_x = nullptr;
+    for (hipEvent_t *ev : {&ev_w[0], &ev_w[1], &ev_w[2], &ev_x[0], &ev_x[1], &ev_x[2]})
+      if (*ev) (void)hipEventDestroy(*ev), *ev = nullptr;
     if (ev_x1) (void)hipEventDestroy(ev_x1), ev_x1 = nullptr;
     for (int b = 0; b < 2; b++) {
       if (hblk[b]) (void)hipHostFree(hblk[b]), hblk[b] = nullptr;
@@ -301,7 +308,7 @@ static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = fa
     long long bytes = 0, fl = 0;
     const int NR = P.shard_count, RK = P.shard_rank;
     for (int k = 0; k < P.K; k++) {
-      bytes += (long long)sizeof(double) * (P.xwslot[k] + P.xslot[k]) * NR;
+      bytes += (long long)sizeof(double) * (P.xwslot[k] + P.xwslot2[k] + P.xslot[k]) * NR;
       const int *cut = &P.xcut[(size_t)k * (NR + 1)];
       const long long wd = cut[RK + 1] - cut[RK];
       const long long np = P.nk[k + 1], mm = P.mk[k], nn = P.nk[k], q = P.qmax[k], cx = P.cap[k + 1];
@@ -444,7 +451,13 @@ static int staged_upload(hqpkkt_t *h) {
     if (d.overlap_mode == 2)
       for (int k = 0; k < P.K; k++) any = any || (P.nk[k] >= 1280 && P.nk[k] <= 4096);
     if (!d.stream2 && any) {
-      HIPCHK(hipStreamCreateWithFlags(&d.stream2, hipStreamNonBlocking));
+      {
+        // (the control-sized chain ahead of the large products' waiting workgroups: a chain of a few small kernels behind
+        // a launch that fills every CU otherwise waits a whole tile time for each of its launches)
+        int lo = 0, hi = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        HIPCHK(hipStreamCreateWithPriority(&d.stream2, hipStreamNonBlocking, hi));
+      }
       HIPCHK(hipEventCreateWithFlags(&d.ev_fork, hipEventDisableTiming));
       HIPCHK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
     }
@@ -452,7 +465,7 @@ static int staged_upload(hqpkkt_t *h) {
   }
   if (P.sharded) {
     const int NR = P.shard_count, RK = P.shard_rank;
-    std::vector<stg::StripTab> wt(P.K + 1);
+    std::vector<stg::StripTab> wt(P.K + 1), wt2(P.K + 1);
     std::vector<stg::RectTab> rt(P.K + 1);
     std::vector<stg::PackRect> pr;
     d.prect_ptr.assign(P.K + 1, 0);
@@ -465,6 +478,8 @@ static int staged_upload(hqpkkt_t *h) {
         t.cut[p] = r.cut[p] = cut[p];
         if (p < NR) t.off[p] = (long long)p * P.xwslot[k], t.ld[p] = (cut[p + 1] - cut[p] + P.mk[k] + 7) / 8 * 8;
       }
+      wt2[k] = t;  // the second part: the same strips in the second buffer (offsets relative to its start)
+      for (int p = 0; p < NR; p++) wt2[k].off[p] = (long long)p * P.xwslot2[k];
       for (auto &b : r.blk) b.off[0] = b.off[1] = 0, b.rsplit = 1 << 30, b.pad = 0;
       d.prect_ptr[k] = (int)pr.size();
       for (int q = P.xrect_ptr[k]; q < P.xrect_ptr[k + 1]; q++) {
@@ -490,8 +505,14 @@ static int staged_upload(hqpkkt_t *h) {
     if (pr.empty()) pr.push_back(stg::PackRect{});
     std::vector<int> gt = P.gtile;
     if (gt.empty()) gt.push_back(0);
-    if ((e = d.wtabs.upload(wt)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt))) return e;
+    if ((e = d.wtabs.upload(wt)) || (e = d.wtabs2.upload(wt2)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt)))
+      return e;
     if (!d.ev_x1) HIPCHK(hipEventCreateWithFlags(&d.ev_x1, hipEventDisableTiming));
+    if (h->xchg_sfn && !d.stream_x && !getenv("HQPKKT_NO_XCHG_STREAM")) {
+      HIPCHK(hipStreamCreateWithFlags(&d.stream_x, hipStreamNonBlocking));
+      for (hipEvent_t *ev : {&d.ev_w[0], &d.ev_w[1], &d.ev_w[2], &d.ev_x[0], &d.ev_x[1], &d.ev_x[2]})
+        HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
+    }
   }
   // orders of the tiles of the triangular products (G, V)
   for (int k = 0; k < P.K; k++)
@@ -646,7 +667,7 @@ static int st_gemm_tiles(hqpkkt_t *h, stg::GemmArgs g, int ntiles, int cls) {
 //       (k_st_small), Y (k_st_wide), Rm = K^-1 Y - beside the blocks of G_xx
 // and, joined: V_k = G_xx - Y' Rm over the WHOLE lower triangle, mirrored, with G_xx read straight from the blocks in
 // the exchange buffer (GemmArgs::rects) into the transient full block; the rank keeps its row strip for the solve.
-static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots);
+static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots, hipStream_t on);
 static int staged_stage_sharded(hqpkkt_t *h, int k) {
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;
@@ -658,7 +679,7 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
   const int c0 = cut[RK], c1 = cut[RK + 1], wd = c1 - c0;
   const long long ldfl = P.ldfl[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k];
   double *G = d.misc.p + P.oG, *xw = d.misc.p + P.oXW, *xb = d.misc.p + P.oX;
-  double *slot = xw + (long long)RK * P.xwslot[k];  // [W_p | W_u] (n+ rows), the control rows of G (m), the carried rows (cx): ld = ldfl
+  double *slot = xw + (long long)RK * P.xwslot[k];  // the upper rows of [W_p | W_u], ld = ldfl (the rest: slot2, below)
   hipStream_t sA = h->stream, sB = d.stream2 ? d.stream2 : h->stream;
   struct StreamGuard {  // launches go to h->stream: back to the first stream on every way out
     hqpkkt_t *h;
@@ -681,28 +702,56 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
       KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(count), 256, 0, h->stream>>>(count, d.h_dst.p + first, d.h_tptr.p + first, d.h_terms.p,
                                                                                  h->vals.p, h->wt.p, G, 1));
   };
-  // ---- sA: [W_p | W_u] = V+ Floc in one product, then - thin and deep: cut in k - the same columns of the control rows of
-  // G (W_u' Floc) and of the carried rows (B+ Floc), all into the rank's slot
-  const int nloc = wd + mm;
-  if (nloc > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldfl, nullptr, 0, slot, ldfl, np, nloc, np, 1.0, 0.0, 0, 0}))) return e;
-  if (mm > 0 &&
-      (e = st_gemm(h, stg::GemmArgs{slot + wd, ldfl, sp.F, ldfl, nullptr, 0, slot + (long long)np * ldfl, ldfl, mm, nloc, np, 1.0, 0.0, 0, 0})))
-    return e;
+  // ---- sA: [W_p | W_u] = V+ Floc - the upper rows first: they travel (first part of exchange 1) while the lower rows are
+  // computed - then, thin and deep (cut in k), the same columns of the control rows of G (W_u' Floc) and of the carried
+  // rows (B+ Floc) behind the lower rows: the second part
+  const int nloc = wd + mm, hr = P.xwrows[k];
+  double *xw2 = d.misc.p + P.oXW2, *slot2 = xw2 + (long long)RK * P.xwslot2[k], *ext = slot2 + (long long)(np - hr) * ldfl;
+  hipStream_t sX = (h->xchg_sfn && d.stream_x) ? d.stream_x : nullptr;  // the exchanges' own stream (stream-ordered transport)
+  auto xchg = [&](int i, double *buf, long long slot_elems) -> int {
+    if (slot_elems <= 0) return 0;
+    if (!sX) return exchange(h, HQPKKT_XCHG_ALLGATHER, buf, slot_elems, NR, nullptr);
+    HIPCHK(hipEventRecord(d.ev_w[i], sA));
+    HIPCHK(hipStreamWaitEvent(sX, d.ev_w[i], 0));
+    const int rc = exchange(h, HQPKKT_XCHG_ALLGATHER, buf, slot_elems, NR, sX);
+    if (rc) return rc;
+    HIPCHK(hipEventRecord(d.ev_x[i], sX));
+    return 0;
+  };
+  auto arrived = [&](int i, hipStream_t on) -> int {  // `on` goes on when exchange i has arrived
+    if (sX) HIPCHK(hipStreamWaitEvent(on, d.ev_x[i], 0));
+    return 0;
+  };
+  if (hr > 0) {  // (every rank makes every exchange, whatever it has to contribute)
+    if (nloc > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldfl, nullptr, 0, slot, ldfl, hr, nloc, np, 1.0, 0.0, 0, 0}))) return e;
+    if ((e = xchg(0, xw, P.xwslot[k]))) return e;
+  }
+  if (nloc > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V + hr, ldvn, sp.F, ldfl, nullptr, 0, slot2, ldfl, np - hr, nloc, np, 1.0, 0.0, 0, 0}))) return e;
+  // (W_u, the A operand of the thin products, lies in both parts: two products over the two row ranges, the second added)
+  auto thin = [&](const double *A1, long long lda1, const double *A2, long long lda2, int M, double *C, int cls) -> int {
+    int e2;
+    if (hr > 0 && (e2 = st_gemm(h, stg::GemmArgs{A1, lda1, sp.F, ldfl, nullptr, 0, C, ldfl, M, nloc, hr, 1.0, 0.0, 0, 0}, cls))) return e2;
+    return st_gemm(h, stg::GemmArgs{A2, lda2, sp.F + (long long)hr * ldfl, ldfl, C, ldfl, C, ldfl, M, nloc, np - hr, 1.0, hr > 0 ? 1.0 : 0.0, 0, 0}, cls);
+  };
+  if (mm > 0 && nloc > 0 && (e = thin(slot + wd, ldfl, slot2 + wd, ldfl, mm, ext, KC_ST_GEMM))) return e;
   if (cx > 0 && nloc > 0 &&
-      (e = st_gemm(h, stg::GemmArgs{sn.BT, P.ldb[k + 1], sp.F, ldfl, nullptr, 0, slot + (long long)(np + mm) * ldfl, ldfl, cx, nloc, np, 1.0, 0.0, 0, 0},
-                   KC_ST_GEMM_UPD)))
+      (e = thin(sn.BT, P.ldb[k + 1], sn.BT + (long long)hr * P.ldb[k + 1], P.ldb[k + 1], cx, ext + (long long)mm * ldfl, KC_ST_GEMM_UPD)))
     return e;
-  if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xw, P.xwslot[k], NR))) return e;
+  if ((e = xchg(1, xw2, P.xwslot2[k]))) return e;
   if (two) {
-    HIPCHK(hipEventRecord(d.ev_x1, sA));
-    HIPCHK(hipStreamWaitEvent(sB, d.ev_x1, 0));
+    if (sX)
+      HIPCHK(hipStreamWaitEvent(sB, d.ev_x[1], 0));
+    else {
+      HIPCHK(hipEventRecord(d.ev_x1, sA));
+      HIPCHK(hipStreamWaitEvent(sB, d.ev_x1, 0));
+    }
     join.armed = true;
   }
   // ---- sB, second part: the control-sized chain
   h->stream = sB;
   if (mm + cx > 0)
     KLAUNCH(h, KC_ST_VEC, stg::k_st_unpack_extra<<<dim3(std::min(mm + cx, 1024), NR), 256, 0, h->stream>>>(
-                              d.wtabs.p + k, xw, np, mm, cx, nn, 0, G + (long long)nn * ldg, ldg, sp.N + (size_t)ek * P.ldn[k], P.ldn[k]));
+                              d.wtabs2.p + k, xw2, np - hr, mm, cx, nn, 0, G + (long long)nn * ldg, ldg, sp.N + (size_t)ek * P.ldn[k], P.ldn[k]));
   // (the control columns from rank 0's slot on EVERY rank: the ranks' own copies of W_u come out of products of different
   // shapes - other cut plans, another order of the k pieces - and differ in their last bits; the control-sized chain must
   // see identical data everywhere, or the ranks' rank decisions and refinement loops could part ways)
@@ -728,15 +777,25 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
   h->stream = sA;
   const int ntile = P.gtile_ptr[k + 1] - P.gtile_ptr[k];
   if (wd > 0 && ntile > 0) {
-    stg::GemmArgs gg{sp.F, ldfl, xw, 0, nullptr, 0, G + (long long)c0 * ldg, ldg, wd, nn, np, 1.0, 0.0, 0, 0};
-    gg.tile_map = d.gtile.p + P.gtile_ptr[k], gg.bstrips = d.wtabs.p + k;
-    if ((e = st_gemm_tiles(h, gg, ntile, KC_ST_GEMM))) return e;
-  }
+    // over the rows of the first part as soon as it has arrived, the rest added when the second has
+    double *Gs = G + (long long)c0 * ldg;
+    if (hr > 0) {
+      if ((e = arrived(0, sA))) return e;
+      stg::GemmArgs g1{sp.F, ldfl, xw, 0, nullptr, 0, Gs, ldg, wd, nn, hr, 1.0, 0.0, 0, 0};
+      g1.tile_map = d.gtile.p + P.gtile_ptr[k], g1.bstrips = d.wtabs.p + k;
+      if ((e = st_gemm_tiles(h, g1, ntile, KC_ST_GEMM))) return e;
+    }
+    if ((e = arrived(1, sA))) return e;
+    stg::GemmArgs g2{sp.F + (long long)hr * ldfl, ldfl, xw2, 0, Gs, ldg, Gs, ldg, wd, nn, np - hr, 1.0, hr > 0 ? 1.0 : 0.0, 0, 0};
+    g2.tile_map = d.gtile.p + P.gtile_ptr[k], g2.bstrips = d.wtabs2.p + k;
+    if ((e = st_gemm_tiles(h, g2, ntile, KC_ST_GEMM))) return e;
+  } else if ((e = arrived(0, sA)) || (e = arrived(1, sA)))
+    return e;
   add_h(P.h_ptr[k], ne_x);  // (entries outside this rank's blocks land in parts of G nobody reads)
   const int npk = d.prect_ptr[k + 1] - d.prect_ptr[k];
   if (npk > 0)
     KLAUNCH(h, KC_ST_VEC, stg::k_st_pack_rects<<<dim3(512, npk), 256, 0, sA>>>(d.prects.p + d.prect_ptr[k], G, ldg, xb + (long long)RK * P.xslot[k]));
-  if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR))) return e;
+  if ((e = xchg(2, xb, P.xslot[k])) || (e = arrived(2, sA))) return e;
   if (two) {
     HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
     join.armed = false;
@@ -928,7 +987,7 @@ static int staged_run_step_sharded(hqpkkt_t *h, const Vecs &v) {
     if (wdn > 0 && (e = st_gemv_rows(h, stg::GemvRows{sn.Vs, P.ldv[k + 1], wdn, np, f, sn.v + c0n, nullptr, 0, nullptr, nullptr,
                                                         xv + (long long)RK * P.xw[k + 1], 1.0})))
       return e;
-    if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xv, P.xw[k + 1], NR))) return e;
+    if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xv, P.xw[k + 1], NR, nullptr))) return e;
     // gam = q_k + F' tt: the own state columns and the control columns
     if (wd > 0 && (e = st_gemv_cols(h, d, sp.F, P.ldfl[k], np, wd, xv, qv + P.nmk[k] + c0, 1.0, gam + c0))) return e;
     if (mm > 0 && (e = st_gemv_cols(h, d, sp.F + wd, P.ldfl[k], np, mm, xv, qv + P.nmk[k] + nn, 1.0, gam + nn))) return e;
@@ -949,7 +1008,7 @@ static int staged_run_step_sharded(hqpkkt_t *h, const Vecs &v) {
       // the free initial state needs v_0 in full: gathered
       const int c0 = cut0(0), wd = width(0);
       if (wd > 0) KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(wd), 256, 0, s>>>(wd, s0.v + c0, xv + (long long)RK * P.xw[0]));
-      if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xv, P.xw[0], NR))) return e;
+      if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xv, P.xw[0], NR, nullptr))) return e;
       KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(n0), 256, 0, s>>>(n0, xv, s0.v));
       if (P.big0) {
         const int q = P.q0max, l8 = (q + 7) / 8 * 8;
@@ -983,7 +1042,7 @@ static int staged_run_step_sharded(hqpkkt_t *h, const Vecs &v) {
     // x+ = F s + f: the own columns' share of every row, gathered, and added in the order of the ranks to f_u u + f
     if ((e = st_gemv_rows(h, stg::GemvRows{sp.F, P.ldfl[k], np, wd, xk + c0, nullptr, nullptr, 0, nullptr, nullptr, xp + (long long)RK * P.xpslot, 1.0})))
       return e;
-    if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xp, P.xpslot, NR))) return e;
+    if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xp, P.xpslot, NR, nullptr))) return e;
     if ((e = st_gemv_rows(h, stg::GemvRows{sp.F + wd, P.ldfl[k], np, mm, xk + nn, v.r2 + P.nks[k], nullptr, 0, nullptr, nullptr, tt, 1.0}))) return e;
     KLAUNCH(h, KC_ST_VEC, stg::k_st_sum_slots<<<nblk(np), 256, 0, s>>>(np, NR, xp, P.xpslot, tt, S + P.nmk[k + 1]));
     // p = V+ x+ + v+ + B+' eta+: the own rows
@@ -1000,7 +1059,7 @@ static int staged_run_step_sharded(hqpkkt_t *h, const Vecs &v) {
     if (P.fixed_x0 && width(0) > 0 &&
         (e = st_gemv_rows(h, stg::GemvRows{s0.Vs, P.ldv[0], width(0), n0, S, s0.v + cut0(0), nullptr, 0, nullptr, nullptr, dyx + P.ndyn + cut0(0), 1.0})))
       return e;
-    if (ndx > 0 && (e = exchange(h, HQPKKT_XCHG_ALLREDUCE_SUM, dyx, ndx, 1))) return e;
+    if (ndx > 0 && (e = exchange(h, HQPKKT_XCHG_ALLREDUCE_SUM, dyx, ndx, 1, nullptr))) return e;
     if (P.ndyn > 0) KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(P.ndyn), 256, 0, s>>>(P.ndyn, dyx, v.dy));
     if (P.fixed_x0) KLAUNCH(h, KC_ST_VEC, stg::k_st_y_fixed<<<nblk(n0), 256, 0, s>>>(n0, d.fix_rows.p, d.fix_src.p, h->vals.p, dyx + P.ndyn, v.dy));
   }

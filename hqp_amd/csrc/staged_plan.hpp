@@ -70,7 +70,8 @@ struct StagedPlan {
   // with them: rank p keeps the columns [cut[p], cut[p+1]) of F_k next to the control columns (Floc_k = [F_p | F_u],
   // n+ x ldfl) and, for the solve, the ROWS [cut[p], cut[p+1]) of V_k.  Per stage of the factorisation:
   //   Wloc = V+ Floc = [W_p | W_u]                  local (V+ in full: the transient result of the stage before)
-  //   exchange 1: [Wloc ; W_u' Floc ; B+ Floc]       n+ + m + cap+ rows of the rank's local width (gather of the slots)
+  //   exchange 1: [Wloc ; W_u' Floc ; B+ Floc]       n+ + m + cap+ rows of the rank's local width (gather of the slots),
+  //                                                  the upper half of the rows of Wloc while the lower half is computed
   //   G_xx block (a, b), a >= b                      by one of the two ranks, as F_p' W_q in its row strip of the work
   //                                                  block (the owner of the columns computes the transpose): pair
   //                                                  {a, b} belongs to b if a - b <= (P - 1) / 2 else to a; with P even
@@ -87,8 +88,12 @@ struct StagedPlan {
   std::vector<int> ldfl;         // per stage: leading dimension of Floc_k (own strip + control columns)
   std::vector<long long> oFl, oVs;  // local F blocks (F arena), own row strips of V_k (V arena, ld = ldv[k])
   long long oVf[2] = {0, 0};     // the two full-size transient V blocks (misc arena): V_k lives in oVf[k & 1]
-  long long oXW = 0;             // exchange 1: shard_count slots of xwslot[k] doubles (misc)
-  std::vector<long long> xwslot;
+  // exchange 1 in two parts, so that the first travels while the second is computed: the rows [0, xwrows[k]) of every
+  // rank's [W_p | W_u] (slots of xwslot[k] doubles at oXW), then the remaining rows with the control rows of G and the
+  // carried rows behind them (slots of xwslot2[k] doubles at oXW2)
+  long long oXW = 0, oXW2 = 0;
+  std::vector<long long> xwslot, xwslot2;
+  std::vector<int> xwrows;
   long long oX = 0;              // exchange 2: shard_count slots of xslot[k] doubles (misc)
   std::vector<long long> xslot;
   long long oXV = 0;             // gathers of the solve: the ranks' strips of a state-sized vector, side by side (misc)
