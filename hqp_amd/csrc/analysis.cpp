@@ -410,6 +410,19 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       lptr.push_back((int)order.size());
       return (int)lptr.size() - 1;
     };
+    // the caller's numbering as a linear order of ALL vertices: x_i at i; a multiplier or slack at the mean index of the
+    // x variables it is coupled to (scaled by 2, so that it falls between them)
+    std::vector<long long> natkey(dim);
+    for (int q = 0; q < dim; q++) {
+      if (q < n) {
+        natkey[q] = 2LL * q;
+        continue;
+      }
+      long long sum = 0, cnt = 0;
+      for (int k = gstart[q]; k < gstart[q + 1]; k++)
+        if (gneigh[k] < n) sum += gneigh[k], cnt++;
+      natkey[q] = cnt ? 2 * sum / cnt + 1 : 2LL * q;
+    }
     std::function<std::vector<int>(std::vector<int> &)> dissect = [&](std::vector<int> &S) -> std::vector<int> {
       std::vector<int> out;
       const int sid = set_id++;
@@ -470,12 +483,74 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
             touches = in_set[gneigh[k]] == sid && lvl[gneigh[k]] == cut + 1;
           (touches ? sep : left).push_back(q);
         }
+        left.insert(left.end(), order.begin(), order.begin() + lptr[cut]);
+        right.assign(order.begin() + lptr[cut + 1], order.end());
+        {
+          // Further candidates: the piece cut in two halves by a linear ORDER of its vertices, the separator a vertex
+          // cover of the edges that cross (greedy: the vertex with the most crossing edges first).  A level structure is
+          // the wrong tool where a few far couplings tie distant parts of a band or mesh together - every level then
+          // reaches across the whole piece (a band of 10^5 variables with 1000 far couplings: separators of thousands, a
+          // root front of 11 724 rows) - while a cut of the right order pays one end of each crossing coupling and the
+          // band width.  Two orders are tried: the Cuthill-McKee numbering (itself a breadth-first order: good for
+          // meshes, scrambled by far couplings) and the caller's own numbering of the variables (multipliers and slacks
+          // at the mean index of their x: programs from discretisations and multistage problems come banded in it).
+          // The smallest separator of the three wins.
+          // (only the two halves are needed, not the order inside them: nth_element, linear in the piece - two full sorts
+          // per piece doubled the time of the symbolic phase of a 10^6-cell mesh.  Not tried where the level structure's
+          // separator is as small as a planar mesh's: below the square root of the piece's size.)
+          static const bool levels_only = getenv("HQPKKT_ND_LEVELS_ONLY") != nullptr;  // (round 4's separators: comparisons)
+          const bool suspicious = !levels_only && (double)sep.size() * sep.size() > 1.0 * len;
+          std::vector<int> saved(suspicious ? len : 0), byp, best_sep, best_left, best_right;
+          if (suspicious) byp = order;
+          for (int t = 0; t < len && suspicious; t++) saved[t] = lvl[order[t]];
+          std::vector<int> &side = lvl;  // scratch marks for this piece: -3 left, -4 right, -5 in the cover (in_set stays sid)
+          for (int pass = 0; pass < 2 && suspicious; pass++) {
+            const int half = len / 2;
+            if (pass == 0)
+              std::nth_element(byp.begin(), byp.begin() + half, byp.end(), [&](int a, int b) { return qp2j[a] < qp2j[b]; });
+            else
+              std::nth_element(byp.begin(), byp.begin() + half, byp.end(),
+                               [&](int a, int b) { return natkey[a] != natkey[b] ? natkey[a] < natkey[b] : a < b; });
+            for (int t = 0; t < len; t++) side[byp[t]] = t < half ? -3 : -4;
+            std::vector<std::pair<int, int>> cand;  // (crossing degree, vertex)
+            for (int q : byp) {
+              int c = 0;
+              for (int k = gstart[q]; k < gstart[q + 1]; k++) {
+                const int x = gneigh[k];
+                c += in_set[x] == sid && side[x] != side[q];
+              }
+              if (c) cand.push_back({c, q});
+            }
+            std::sort(cand.begin(), cand.end(), [&](const std::pair<int, int> &a, const std::pair<int, int> &b) {
+              return a.first != b.first ? a.first > b.first : a.second < b.second;
+            });
+            std::vector<int> sep2;
+            for (auto &cq : cand) {  // taken if one of its crossing edges is still uncovered
+              const int q = cq.second;
+              bool open = false;
+              for (int k = gstart[q]; k < gstart[q + 1] && !open; k++) {
+                const int x = gneigh[k];
+                open = in_set[x] == sid && (side[x] == -3 || side[x] == -4) && side[x] != side[q];
+              }
+              if (open) side[q] = -5, sep2.push_back(q);
+            }
+            if (sep2.size() < (best_sep.empty() ? sep.size() : best_sep.size())) {
+              best_sep = sep2;
+              best_left.clear(), best_right.clear();
+              for (int t = 0; t < len; t++) {
+                const int q = byp[t];
+                if (side[q] == -3) best_left.push_back(q);
+                if (side[q] == -4) best_right.push_back(q);
+              }
+            }
+          }
+          if (!best_sep.empty() && best_sep.size() < sep.size()) sep.swap(best_sep), left.swap(best_left), right.swap(best_right);
+          for (int t = 0; t < len && suspicious; t++) lvl[order[t]] = saved[t];
+        }
         if (3LL * (long long)sep.size() >= len) {
           as_leaf();
           continue;
         }
-        left.insert(left.end(), order.begin(), order.begin() + lptr[cut]);
-        right.assign(order.begin() + lptr[cut + 1], order.end());
         std::vector<int> sv;
         for (int q : sep) sv.push_back(qp2j[q]);
         std::sort(sv.begin(), sv.end());
@@ -584,6 +659,14 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
         }
       }
     }
+  }
+  if (getenv("HQPKKT_TRACE_ND")) {
+    std::vector<size_t> sz;
+    for (auto &t : tmp) sz.push_back(t.verts.size());
+    std::sort(sz.rbegin(), sz.rend());
+    fprintf(stderr, "dissection: %d logical nodes, %zu roots; largest:", nlog, roots.size());
+    for (size_t i = 0; i < std::min<size_t>(12, sz.size()); i++) fprintf(stderr, " %zu", sz[i]);
+    fprintf(stderr, "\n");
   }
   std::vector<std::vector<int>> lverts(nlog);  // pivot sets by band position
   std::vector<int> lnode_of_pos(dim);

@@ -101,8 +101,12 @@ static int hqp_solve_loop(double sqp_eps, int &qp_iters) {
 //   f(x)  = sum_i a_i/2 (x_i - t_i)^2 + g/4 x_i^4 + sum_{i~j} k_ij/2 (x_i - x_j)^2   (right / lower neighbours)
 //   g_c(x)= x_c x_{c+1} + x_{c+gx} - beta_c = 0          for every eq_every-th cell c
 //   lo <= x_i <= hi                                      for a fraction of the cells
+// far > 0 adds that many couplings k/2 (x_i - x_j)^2 between random cells i < j far apart in the numbering (the
+// irregular part: "1 % far couplings" on top of the mesh's five entries per row)
 class Prg_GridNLP : public Hqp_SqpProgram {
-  int _gx, _gy, _n, _me, _nb, _hela;
+  int _gx, _gy, _n, _me, _nb, _hela, _nfar;
+  IVEC *_fi, *_fj;
+  VEC *_kf;
   unsigned long long _rs;
   VEC *_a, *_t, *_kr, *_kd, *_beta;
   IVEC *_cells, *_bnd;
@@ -113,8 +117,8 @@ class Prg_GridNLP : public Hqp_SqpProgram {
   }
 
  public:
-  Prg_GridNLP(int gx, int gy, int seed, int eq_every, double bound_frac, int hela)
-      : _gx(gx), _gy(gy), _n(gx * gy), _me(0), _nb(0), _hela(hela), _rs(88172645463325252ULL + 7919ULL * (unsigned)seed),
+  Prg_GridNLP(int gx, int gy, int seed, int eq_every, double bound_frac, int hela, int far = 0)
+      : _gx(gx), _gy(gy), _n(gx * gy), _me(0), _nb(0), _hela(hela), _nfar(0), _rs(88172645463325252ULL + 7919ULL * (unsigned)seed),
         _gam(0.5), _lo(-1.2), _hi(1.2) {
     _a = v_get(_n), _t = v_get(_n), _kr = v_get(_n), _kd = v_get(_n);
     for (int i = 0; i < _n; i++)
@@ -127,8 +131,18 @@ class Prg_GridNLP : public Hqp_SqpProgram {
     for (int k = 0; k < _me; k++) _beta->ve[k] = 0.4 * rnd() - 0.2;
     for (int i = 0; i < _n; i++)
       if (rnd() < bound_frac) _bnd->ive[_nb++] = i;
+    _fi = iv_get(far > 0 ? far : 1), _fj = iv_get(far > 0 ? far : 1), _kf = v_get(far > 0 ? far : 1);
+    for (int k = 0; k < far; k++) {  // (drawn last: the mesh part is the same program with and without them)
+      int i = (int)(rnd() * _n), j = (int)(rnd() * _n);
+      if (i > j) { const int t = i; i = j; j = t; }
+      if (j - i < _n / 8 || j >= _n) continue;  // far apart in the numbering, and not a mesh neighbour
+      _fi->ive[_nfar] = i, _fj->ive[_nfar] = j, _kf->ve[_nfar] = 0.05 + 0.1 * rnd(), _nfar++;
+    }
   }
-  ~Prg_GridNLP() { v_free(_a), v_free(_t), v_free(_kr), v_free(_kd), v_free(_beta), iv_free(_cells), iv_free(_bnd); }
+  ~Prg_GridNLP() {
+    v_free(_a), v_free(_t), v_free(_kr), v_free(_kd), v_free(_beta), iv_free(_cells), iv_free(_bnd);
+    iv_free(_fi), iv_free(_fj), v_free(_kf);
+  }
   const char *name() { return "GridNLP"; }
   int n() const { return _n; }
   int me() const { return _me; }
@@ -144,6 +158,8 @@ class Prg_GridNLP : public Hqp_SqpProgram {
         if (i / _gx + 1 < _gy) sp_set_val(_qp->Q, i, i + _gx, 0.0);
       }
     }
+    if (_hela)
+      for (int k = 0; k < _nfar; k++) sp_set_val(_qp->Q, _fi->ive[k], _fj->ive[k], 0.0);
     for (int k = 0; k < _me; k++) {
       const int c = _cells->ive[k];
       sp_set_val(_qp->A, k, c, 0.0), sp_set_val(_qp->A, k, c + 1, 0.0), sp_set_val(_qp->A, k, c + _gx, 1.0);
@@ -163,6 +179,10 @@ class Prg_GridNLP : public Hqp_SqpProgram {
       f += 0.5 * _a->ve[i] * e * e + 0.25 * _gam * x[i] * x[i] * x[i] * x[i];
       if (i % _gx + 1 < _gx) f += 0.5 * _kr->ve[i] * (x[i] - x[i + 1]) * (x[i] - x[i + 1]);
       if (i / _gx + 1 < _gy) f += 0.5 * _kd->ve[i] * (x[i] - x[i + _gx]) * (x[i] - x[i + _gx]);
+    }
+    for (int k = 0; k < _nfar; k++) {
+      const double e = x[_fi->ive[k]] - x[_fj->ive[k]];
+      f += 0.5 * _kf->ve[k] * e * e;
     }
     _f = f;
     for (int k = 0; k < _me; k++) {
@@ -189,6 +209,10 @@ class Prg_GridNLP : public Hqp_SqpProgram {
         g[i] += e, g[i + _gx] -= e;
       }
     }
+    for (int k = 0; k < _nfar; k++) {
+      const double e = _kf->ve[k] * (x[_fi->ive[k]] - x[_fj->ive[k]]);
+      g[_fi->ive[k]] += e, g[_fj->ive[k]] -= e;
+    }
     for (int k = 0; k < _me; k++) {
       const int c = _cells->ive[k];
       sp_set_val(_qp->A, k, c, x[c + 1]), sp_set_val(_qp->A, k, c + 1, x[c]);
@@ -201,6 +225,12 @@ class Prg_GridNLP : public Hqp_SqpProgram {
         if (i % _gx > 0) dii += _kr->ve[i - 1];
         if (i / _gx > 0) dii += _kd->ve[i - _gx];
         sp_set_val(_qp->Q, i, i, dii);
+      }
+      for (int k = 0; k < _nfar; k++) {  // (several couplings may share an end: the diagonals are added up)
+        const int i = _fi->ive[k], j = _fj->ive[k];
+        sp_set_val(_qp->Q, i, j, -_kf->ve[k]);
+        sp_set_val(_qp->Q, i, i, sp_get_val(_qp->Q, i, i) + _kf->ve[k]);
+        sp_set_val(_qp->Q, j, j, sp_get_val(_qp->Q, j, j) + _kf->ve[k]);
       }
       if ((const VEC *)y)
         for (int k = 0; k < _me; k++) {
@@ -248,15 +278,22 @@ int hqpsqp_did(int kmax, const char *qp_solver, const char *mat_solver, double s
 // BASELINE.json configs[4] stand-in (Prg_GridNLP above) through the reference's Hqp_SqpPowell.  hela 1: analytic
 // Lagrangian Hessian + sqp_hela Gerschgorin; 0: sqp_hela DScale (hqp_cute/hqp_cute.tcl:36-42).  ordering is
 // handed to mat_ordering where the plugin has it (ours).  out as hqpsqp_did plus out[6..8] = n, me, m.
+int hqpsqp_gridfar(int gx, int gy, int far, int seed, int eq_every, double bound_frac, int hela, const char *qp_solver,
+                   const char *mat_solver, int ordering, double sqp_eps, int sqp_max_iters, double *out);
 int hqpsqp_grid(int gx, int gy, int seed, int eq_every, double bound_frac, int hela, const char *qp_solver,
                 const char *mat_solver, int ordering, double sqp_eps, int sqp_max_iters, double *out) {
+  return hqpsqp_gridfar(gx, gy, 0, seed, eq_every, bound_frac, hela, qp_solver, mat_solver, ordering, sqp_eps, sqp_max_iters, out);
+}
+// ... with `far` couplings between distant cells (Prg_GridNLP above)
+int hqpsqp_gridfar(int gx, int gy, int far, int seed, int eq_every, double bound_frac, int hela, const char *qp_solver,
+                   const char *mat_solver, int ordering, double sqp_eps, int sqp_max_iters, double *out) {
   if (hqpref_startup() != 0) return -1;
   int err = 0, rc = 0;
   double t0 = 0.0, t1 = 0.0;
   int qp_iters = 0;
   m_catchall(
       theSqpProgram = NULL; theSqpSolver = new Hqp_SqpPowell;
-      Prg_GridNLP *prg = new Prg_GridNLP(gx, gy, seed, eq_every, bound_frac, hela); theSqpProgram = prg;
+      Prg_GridNLP *prg = new Prg_GridNLP(gx, gy, seed, eq_every, bound_frac, hela, far); theSqpProgram = prg;
       if (If_SetString("sqp_qp_solver", qp_solver) != IF_OK) rc = -2;
       if (!rc && If_SetString("qp_mat_solver", mat_solver) != IF_OK) rc = -2;
       if (!rc) {

@@ -287,17 +287,18 @@ def sqp_did(kmax, qp_solver="Mehrotra", mat_solver="SpBKP", host="ref", sqp_eps=
 
 
 def sqp_grid(gx, gy, qp_solver="Mehrotra", mat_solver="RedSpBKP", host="ref", seed=1, eq_every=3, bound_frac=0.5, hela=1,
-             ordering=0, sqp_eps=1e-6, sqp_max_iters=200):
+             ordering=0, sqp_eps=1e-6, sqp_max_iters=200, far=0):
     """BASELINE.json configs[4] stand-in: Prg_GridNLP (oracle/ref_sqpdrive.cc, our program class with the sparsity
     of a discretised control problem) through the reference's Hqp_SqpPowell with the QP solver / KKT plugin given
     by name.  Returns dict(f, sqp_iters, qp_iters, seconds, norm_inf, norm_grd_L, n, me, m, rc) - rc 0 = optimal."""
     lib = _host(host)
-    lib.hqpsqp_grid.restype = C.c_int
-    lib.hqpsqp_grid.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_int,
-                                C.c_double, C.c_int, _dp]
+    lib.hqpsqp_gridfar.restype = C.c_int
+    lib.hqpsqp_gridfar.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_double, C.c_int, C.c_char_p, C.c_char_p, C.c_int,
+                                   C.c_double, C.c_int, _dp]
     out = np.zeros(12)
-    e = lib.hqpsqp_grid(int(gx), int(gy), int(seed), int(eq_every), float(bound_frac), int(hela), qp_solver.encode(),
-                        mat_solver.encode(), int(ordering), float(sqp_eps), int(sqp_max_iters), out)
+    # (far > 0: that many couplings between distant cells on top of the mesh - the irregular part)
+    e = lib.hqpsqp_gridfar(int(gx), int(gy), int(far), int(seed), int(eq_every), float(bound_frac), int(hela), qp_solver.encode(),
+                           mat_solver.encode(), int(ordering), float(sqp_eps), int(sqp_max_iters), out)
     if e > 0:
         raise RefError(e, f"sqp_grid[{qp_solver},{mat_solver}]")
     return dict(f=out[0], sqp_iters=int(out[1]), qp_iters=int(out[2]), seconds=out[3], norm_inf=out[4],

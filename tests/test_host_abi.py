@@ -154,3 +154,21 @@ def test_graph_dissection_tree_is_valid_and_factorisable(case, kind, ordering):
     x = mdl.solve(rhs_e)[e]
     tol = 1e-3 if mdl.npert else 1e-7
     assert np.abs(K @ x - rhs).max() <= tol * max(1.0, np.abs(K).max() * np.abs(x).max())
+
+
+def test_dissection_of_a_band_with_far_couplings():
+    """Host-only (hqpkkt_analyze touches no device): the symbolic phase on the irregular stand-in of BASELINE configs[4] -
+    10^5 variables, 21 entries per row of Q, 1000 couplings between distant variables - through the dissection of the
+    graph itself (ordering 2).  Level structures alone gave a root separator of 6154 vertices and fronts of 11 724 rows
+    (round 4); with the cuts by linear order among the candidates the largest separator has ~500 vertices
+    (max_front <= 4000)."""
+    from hqp_amd import ipmatrix, problems
+    prog = problems.banded_long_range_qp(100000, 10, 1000)
+    M = ipmatrix.IpRedSpBKP(ordering=2)
+    try:
+        M.init(prog)
+    except ipmatrix.KktError as e:  # no device here: the analysis has run, the upload of the values fails
+        assert e.code == 100
+    s = M.stats()
+    assert s["dim"] == 150000
+    assert s["max_front"] <= 4000 and s["flops_factor"] < 5e10, s
