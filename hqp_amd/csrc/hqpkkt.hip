@@ -500,7 +500,7 @@ static int upload(hqpkkt_t *h) {
   const size_t mp = an.max_npiv, ldm = mp | 1;
   h->lds_diag = (std::max<size_t>(ldm * mp, 2 * FD_PLD * FD_PANEL) + 5 * 128 + 2 * mp) * sizeof(double) +
                 2 * mp * sizeof(int) + 16;
-  h->lds_panel = (32 * mp + 2 * mp) * sizeof(double) + mp * sizeof(int);
+  h->lds_panel = (PS_LD * mp + 1 + 2 * mp) * sizeof(double) + mp * sizeof(int);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
   h->old_fd = getenv("HQPKKT_OLD_FD") != nullptr && mp <= 128;
   if (!h->old_fd) h->lds_diag = 0;
@@ -521,6 +521,9 @@ static int upload(hqpkkt_t *h) {
     const char *pl = getenv("HQPKKT_POLL_LIMIT");
     const int lim = pl ? atoi(pl) : 1 << 20;
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(xw_poll_limit), &lim, sizeof(int)));
+    const char *tp = getenv("HQPKKT_TINY_PERTURB");
+    const double spp = tp ? atof(tp) : 1e-6;
+    HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(soft_pivot_pert), &spp, sizeof(double)));
   }
   // a tree of small fronts only: whole-tree sweeps
   h->small_tree = false, h->tree_factor = false;
@@ -1623,13 +1626,22 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
   const bool refined = res > target;  // otherwise the caller's copy is already complete
   const double res_first = res;
   double res_acc = res;  // residual of the solution as it stands (res is the last TRIAL's when that one was rejected, as in the reference)
+  double res_acc_prev = HUGE_VAL;  // ... and before the last round
   // correction solve: rhs = residual vectors, result = vcor
   Vecs c = v;
   c.r1 = h->vres.p, c.r2 = c.r1 + n, c.r3 = c.r2 + me, c.r4 = c.r3 + m;
   c.dx = h->vcor.p, c.dy = c.dx + n, c.dz = c.dy + me, c.dw = c.dz + m;
   const int ntot = n + me + 2 * m;
   int rounds = 0;
-  for (int it = 0; it < 5 && res > target; it++) {
+  // (the reference makes at most five rounds, hqp/Hqp_IpMatrix.C:84: its factors come from a pivot search over the whole
+  // remaining column.  Where THIS factorisation had to perturb a pivot, or met a multiplier pivot at rounding level -
+  // the pivot search is confined to the supernode's block - the factors are those of a nearby matrix and the rounds
+  // contract more slowly: up to fifteen then, as long as they still gain, so that solve() returns what the caller's
+  // optimality test expects of an accurate factorisation - Hqp_IpsFranke compares the returned residual with its
+  // eps, hqp/Hqp_IpsFranke.C:372)
+  const int max_rounds = (h->st.n_perturbed > 0 || h->soft_tiny || h->soft_singular) && !getenv("HQPKKT_FIVE_ROUNDS") ? 15 : 5;
+  for (int it = 0; it < max_rounds && res > target; it++) {
+    if (it >= 5 && !(res < 0.5 * res_acc_prev)) break;  // beyond the reference's five: only while a round still halves the residual
     res_last = res;
     if ((e = do_step(h, c, 1))) return e;
     rounds++;
@@ -1645,7 +1657,7 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
       }
     } while (res > res_last && alpha > 0.0);
     if (alpha <= 0.0) break;
-    res_acc = res;
+    res_acc_prev = res_acc, res_acc = res;
   }
   if (!(res <= h->opts.eps) && h->zd_weak && h->zd_used == 2) {  // (sharded: every rank sees the same residual and switches)
     // the refinement did not reach mat_eps: weak Hessian diagonals and every multiplier behind

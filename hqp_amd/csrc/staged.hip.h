@@ -29,9 +29,9 @@ using kktdev::mfma_f64;
 typedef double double2_t __attribute__((ext_vector_type(2)));
 
 // One system over several ranks (staged_plan.hpp): rank p owns the state columns [cut[p], cut[p+1]) of a stage
-// (multiples of 128, so a tile lies inside one strip).  StripTab: where the ranks' strips of W lie after the first
-// exchange of a stage - strip p = n+ rows of cut[p+1] - cut[p] columns (and the control columns behind them), row-major
-// with leading dimension ld[p], at xw + off[p].
+// (multiples of 128, so a tile lies inside one strip).  StripTab: where the ranks' local blocks of F lie once they are
+// gathered - strip p = n+ rows of cut[p+1] - cut[p] columns (and the control columns behind them), row-major with
+// leading dimension ld[p], at fg + off[p].
 struct StripTab {
   int nranks;
   int cut[17];
@@ -2698,20 +2698,6 @@ __global__ void __launch_bounds__(256) k_st_pack_rects(const PackRect *__restric
       if (i < r.rows && j < r.cols) dst[(long long)j * r.rows + i] = t[tx][ty + 8 * u];
     }
     __syncthreads();
-  }
-}
-// The first exchange of a stage carries, behind the n+ rows of every rank's [W_p | W_u], the same columns of the control
-// rows of G (W_u' Floc: m rows) and of the carried rows (B+ Floc: capx rows): the state columns of all ranks and the
-// control columns of rank `own`'s slot into their places in G and N.  blockIdx.y = rank.
-__global__ void __launch_bounds__(256) k_st_unpack_extra(const StripTab *__restrict__ tab, const double *__restrict__ xw, int np, int m, int capx,
-                                                         int nn, int own, double *__restrict__ Gu, long long ldg, double *__restrict__ Nc,
-                                                         long long ldn) {
-  const int q = blockIdx.y, c0 = tab->cut[q], w = tab->cut[q + 1] - c0, ld = tab->ld[q];
-  const int ncol = w + (q == own ? m : 0);
-  const double *src = xw + tab->off[q] + (long long)np * ld;
-  for (int i = blockIdx.x; i < m + capx; i += gridDim.x) {
-    double *dst = i < m ? Gu + (long long)i * ldg : Nc + (long long)(i - m) * ldn;
-    for (int j = threadIdx.x; j < ncol; j += blockDim.x) dst[j < w ? c0 + j : nn + (j - w)] = src[(long long)i * ld + j];
   }
 }
 // rows x cols block copy (the own row strip of V_k out of the transient full block)

@@ -21,7 +21,7 @@ struct StagedDev {
   // one system over several ranks (staged_plan.hpp): per stage where the ranks' strips of W / blocks of G_xx lie in the
   // exchange buffers, this rank's tiles of its blocks' products and its blocks to pack; the local dynamics blocks of
   // residuum()'s products and their summed results (A_dyn' dy: n, A_dyn dx: ndyn)
-  DBuf<stg::StripTab> wtabs, wtabs2;  // (the two parts of the first exchange: upper rows of W, the rest)
+  DBuf<stg::StripTab> wtabs;  // (the strips of the gathered F: offsets inside one of the two buffers)
   DBuf<stg::RectTab> rtabs;
   DBuf<int> gtile;
   DBuf<stg::PackRect> prects;
@@ -29,14 +29,16 @@ struct StagedDev {
   DBuf<stg::DynLoc> dyn_loc;
   DBuf<double> dyn_sum;
   long long dyn_sum_x2 = 0;  // offset of A_dyn dx in dyn_sum
-  // the exchanges of a stage in the stream-ordered form (RCCL) go to a stream of their own, so that the first part of
-  // exchange 1 travels beside the products of the second: ev_w[i] "part i of the slot is complete" (first stream),
-  // ev_x[i] "exchange i has arrived" (i = 0, 1: the parts of exchange 1, 2: exchange 2)
+  // the exchanges of a stage in the stream-ordered form (RCCL) go to a stream of their own, so that the gather of the
+  // NEXT stage's F blocks travels beside this stage's products: ev_w[i] "the first stream is ready for exchange i",
+  // ev_x[i] "exchange i has arrived" (i = 0, 1: the gathered F in buffer i, 2: the blocks of G_xx)
   hipStream_t stream_x = nullptr;
   hipEvent_t ev_x1 = nullptr, ev_w[3] = {nullptr, nullptr, nullptr}, ev_x[3] = {nullptr, nullptr, nullptr};
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
   int cus = 0;
+  DBuf<double> ks_ws2;          // the pieces of a thin product cut in k (k_dgemm_tn_ks) launched on the SECOND stream
+  long long ks_ws2_elems = 0;
   DBuf<double> sk_ws;           // stream-K dgemm: two partial tiles per workgroup
   DBuf<unsigned> sk_cnt;
   int sk_grid = 0;              // workgroups of the stream-K grid (2 per CU); 0: not used
@@ -75,8 +77,8 @@ struct StagedDev {
     F.release(), V.release(), misc.release();
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
-    dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), dyn_part.release(), sk_ws.release(), sk_cnt.release(), zeros.release();
-    wtabs.release(), wtabs2.release(), rtabs.release(), gtile.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
+    dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), dyn_part.release(), sk_ws.release(), ks_ws2.release(), sk_cnt.release(), zeros.release();
+    wtabs.release(), rtabs.release(), gtile.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
     if (stream_x) (void)hipStreamDestroy(stream_x), stream_x = nullptr;
     for (hipEvent_t *ev : {&ev_w[0], &ev_w[1], &ev_w[2], &ev_x[0], &ev_x[1], &ev_x[2]})
       if (*ev) (void)hipEventDestroy(*ev), *ev = nullptr;
@@ -145,14 +147,17 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   }
   if (big)
     KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g, d ? d->cus : 0));
-  else if (d && allow_sk && d->cus > 0 && !g.lower && !g.mirror && g.K >= 1024 && tiles * 4 <= d->cus &&
-           (long long)g.M * g.N * 8 <= d->sk_ws_elems && !getenv("HQPKKT_NO_KSPLIT")) {
-    // a thin, deep product: its k range cut over the chip (k_dgemm_tn_ks), the pieces added in their order
+  else if (d && d->cus > 0 && !g.lower && !g.mirror && g.K >= 1024 && tiles * 2 <= d->cus && !getenv("HQPKKT_NO_KSPLIT") &&
+           (long long)g.M * g.N * 4 <= (allow_sk ? d->sk_ws_elems : d->ks_ws2_elems)) {
+    // a thin, deep product: its k range cut over the chip (k_dgemm_tn_ks), the pieces added in their order (the
+    // launches of the second stream have a workspace of their own)
+    double *ws = allow_sk ? d->sk_ws.p : d->ks_ws2.p;
+    const long long wse = allow_sk ? d->sk_ws_elems : d->ks_ws2_elems;
     const int nslab = (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK;
     int nsplit = (int)std::min<long long>(nslab / 4, std::max<long long>(1, (2LL * d->cus) / tiles));
-    nsplit = (int)std::min<long long>(nsplit, d->sk_ws_elems / std::max<long long>(1, (long long)g.M * g.N));
-    KLAUNCH(h, cls, (stg::k_dgemm_tn_ks<64, 64><<<dim3((unsigned)tiles, nsplit), 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g, d->sk_ws.p, nsplit)));
-    KLAUNCH(h, cls, stg::k_dgemm_ks_finish<<<nblk((long long)g.M * g.N), 256, 0, h->stream>>>(g, d->sk_ws.p, nsplit));
+    nsplit = (int)std::max<long long>(1, std::min<long long>(nsplit, wse / std::max<long long>(1, (long long)g.M * g.N)));
+    KLAUNCH(h, cls, (stg::k_dgemm_tn_ks<64, 64><<<dim3((unsigned)tiles, nsplit), 256, stg::gemm_lds_bytes(64, 64), h->stream>>>(g, ws, nsplit)));
+    KLAUNCH(h, cls, stg::k_dgemm_ks_finish<<<nblk((long long)g.M * g.N), 256, 0, h->stream>>>(g, ws, nsplit));
   } else {
     // few tiles of a deep rectangular product (W of a stage of ~1000 states: 272): 64 x 32 tiles, so that a CU holds two
     // workgroups and one multiplies while the other waits at its barrier: 81 -> 73 us (HQPKKT_NO_TILE6432: off)
@@ -308,14 +313,14 @@ static int staged_analyze(hqpkkt_t *h, int n, int me, int m, bool dense_dyn = fa
     long long bytes = 0, fl = 0;
     const int NR = P.shard_count, RK = P.shard_rank;
     for (int k = 0; k < P.K; k++) {
-      bytes += (long long)sizeof(double) * (P.xwslot[k] + P.xwslot2[k] + P.xslot[k]) * NR;
+      bytes += (long long)sizeof(double) * (P.fgslot[k] + P.xslot[k]) * NR;  // (the gathered F: static, requested a stage ahead)
       const int *cut = &P.xcut[(size_t)k * (NR + 1)];
       const long long wd = cut[RK + 1] - cut[RK];
       const long long np = P.nk[k + 1], mm = P.mk[k], nn = P.nk[k], q = P.qmax[k], cx = P.cap[k + 1];
       // own: the strip of W, its columns of the control rows of G and of the carried rows, the tiles of its blocks of
       // G_xx; by every rank: the control columns, the rank-q update of the whole block
-      fl += 2 * np * np * wd + 2 * np * (mm + cx) * wd + 2 * np * 128LL * 128 * (P.gtile_ptr[k + 1] - P.gtile_ptr[k]);
-      fl += 2 * np * np * mm + 2 * np * mm * mm + q * nn * nn;
+      fl += 2 * np * np * wd + 2 * np * 128LL * 128 * (P.gtile_ptr[k + 1] - P.gtile_ptr[k]);
+      fl += 2 * np * np * mm + 2 * np * (mm + cx) * (nn + mm) + q * nn * nn;
     }
     h->st.bytes_exchange_factor = bytes, h->st.flops_local = fl, h->st.n_exchange_blocks = 2 * P.K;
     // per solve: a state-sized vector per stage and direction, the partial sums of x+, the dynamics rows' multipliers
@@ -462,10 +467,15 @@ static int staged_upload(hqpkkt_t *h) {
       HIPCHK(hipEventCreateWithFlags(&d.ev_join, hipEventDisableTiming));
     }
     d.overlap = d.stream2 != nullptr && d.overlap_mode != 0;
+    d.ks_ws2_elems = 0;
+    if (d.stream2 && d.cus > 0) {
+      d.ks_ws2_elems = 8LL << 20;
+      if ((e = d.ks_ws2.alloc((size_t)d.ks_ws2_elems))) return e;
+    }
   }
   if (P.sharded) {
     const int NR = P.shard_count, RK = P.shard_rank;
-    std::vector<stg::StripTab> wt(P.K + 1), wt2(P.K + 1);
+    std::vector<stg::StripTab> wt(P.K + 1);
     std::vector<stg::RectTab> rt(P.K + 1);
     std::vector<stg::PackRect> pr;
     d.prect_ptr.assign(P.K + 1, 0);
@@ -476,10 +486,8 @@ static int staged_upload(hqpkkt_t *h) {
       t.nranks = r.nranks = NR;
       for (int p = 0; p <= NR; p++) {
         t.cut[p] = r.cut[p] = cut[p];
-        if (p < NR) t.off[p] = (long long)p * P.xwslot[k], t.ld[p] = (cut[p + 1] - cut[p] + P.mk[k] + 7) / 8 * 8;
+        if (p < NR) t.off[p] = (long long)p * P.fgslot[k], t.ld[p] = (cut[p + 1] - cut[p] + P.mk[k] + 7) / 8 * 8;
       }
-      wt2[k] = t;  // the second part: the same strips in the second buffer (offsets relative to its start)
-      for (int p = 0; p < NR; p++) wt2[k].off[p] = (long long)p * P.xwslot2[k];
       for (auto &b : r.blk) b.off[0] = b.off[1] = 0, b.rsplit = 1 << 30, b.pad = 0;
       d.prect_ptr[k] = (int)pr.size();
       for (int q = P.xrect_ptr[k]; q < P.xrect_ptr[k + 1]; q++) {
@@ -505,7 +513,7 @@ static int staged_upload(hqpkkt_t *h) {
     if (pr.empty()) pr.push_back(stg::PackRect{});
     std::vector<int> gt = P.gtile;
     if (gt.empty()) gt.push_back(0);
-    if ((e = d.wtabs.upload(wt)) || (e = d.wtabs2.upload(wt2)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt)))
+    if ((e = d.wtabs.upload(wt)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt)))
       return e;
     if (!d.ev_x1) HIPCHK(hipEventCreateWithFlags(&d.ev_x1, hipEventDisableTiming));
     if (h->xchg_sfn && !d.stream_x && !getenv("HQPKKT_NO_XCHG_STREAM")) {
@@ -657,17 +665,40 @@ static int st_gemm_tiles(hqpkkt_t *h, stg::GemmArgs g, int ntiles, int cls) {
 
 // One stage of the backward recursion when ONE system is sharded over several ranks (DESIGN.md section 7,
 // staged_plan.hpp).  Rank p owns the state columns [c0, c1) of the stage: its memory holds those columns of F_k (and the
-// control columns), its products are the strip W_p = V+ F_p and the blocks of G_xx the plan gives it; everything
-// control-sized is computed by every rank on identical data.  Two streams:
-//   sA (the handle's): [W_p | W_u] = V+ Floc, its columns of the control rows of G (W_u' Floc) and of the carried rows
-//       (B+ Floc), all three into its slot  ->  EXCHANGE 1 (gather of the slots)  ->  its blocks of G_xx = F_p' W_q in
-//       ONE launch (the B operand from the ranks' slots, the tiles of the plan's list), + H_xx  ->  pack (lower
-//       orientation)  ->  EXCHANGE 2
-//   sB, behind exchange 1: the control rows of G and the carried rows into their places, rank decision, K^-1
-//       (k_st_small), Y (k_st_wide), Rm = K^-1 Y - beside the blocks of G_xx
+// control columns), its products are the strip W_p = V+ F_p and the blocks of G_xx the plan gives it - as W_p' F_q, with
+// the other rank's F_q out of the GATHERED local blocks, which are static data and were requested a stage ago; W is not
+// exchanged.  Everything control-sized is computed by every rank on identical data by launches of identical shape.
+//   sA (the handle's): request the gather of stage k - 1's F  ->  W_p = V+ F_p  ->  its blocks of G_xx = W_p' F_q in ONE
+//       launch (B from the gathered strips, the tiles of the plan's list), + H_xx  ->  pack (lower orientation)  ->
+//       the GATHER OF THE BLOCKS: the one exchange on the critical path
+//   sB: W_u = V+ f_u, the control rows of G = W_u' [F_x | F_u] and the carried rows B+ F (thin, deep products over the
+//       gathered strips, cut in k), rank decision, K^-1 (k_st_small), Y (k_st_wide), Rm = K^-1 Y - beside the large products
 // and, joined: V_k = G_xx - Y' Rm over the WHOLE lower triangle, mirrored, with G_xx read straight from the blocks in
 // the exchange buffer (GemmArgs::rects) into the transient full block; the rank keeps its row strip for the solve.
 static int exchange(hqpkkt_t *h, int op, double *buf, long long slot, int nslots, hipStream_t on);
+// the gather of the ranks' local blocks of stage k into buffer k & 1: stream-ordered transport: on the exchanges' own
+// stream behind `after` (the first stream's position when the buffer's last readers are done); otherwise here and now
+static int staged_gather_f(hqpkkt_t *h, int k) {
+  StagedDev &d = *h->sd;
+  kktdev::StagedPlan &P = d.plan;
+  const int NR = P.shard_count, RK = P.shard_rank, i = k & 1;
+  const int wd = P.xcut[(size_t)k * (NR + 1) + RK + 1] - P.xcut[(size_t)k * (NR + 1) + RK], nloc = wd + P.mk[k], np = P.nk[k + 1];
+  double *fg = d.misc.p + P.oFg[i], *mine = fg + (long long)RK * P.fgslot[k];
+  hipStream_t sA = h->stream, sX = (h->xchg_sfn && d.stream_x) ? d.stream_x : nullptr;
+  hipStream_t on = sX ? sX : sA;
+  if (sX) {
+    HIPCHK(hipEventRecord(d.ev_w[i], sA));
+    HIPCHK(hipStreamWaitEvent(sX, d.ev_w[i], 0));
+  }
+  if (nloc > 0 && np > 0)
+    KLAUNCH(h, KC_ST_VEC, stg::k_st_copy2d<<<std::min(np, 2048), 256, 0, on>>>(stage_ptr(d, k).F, P.ldfl[k], mine, P.ldfl[k], np, nloc));
+  if (P.fgslot[k] > 0) {
+    const int e = exchange(h, HQPKKT_XCHG_ALLGATHER, fg, P.fgslot[k], NR, sX);
+    if (e) return e;
+  }
+  if (sX) HIPCHK(hipEventRecord(d.ev_x[i], sX));
+  return 0;
+}
 static int staged_stage_sharded(hqpkkt_t *h, int k) {
   StagedDev &d = *h->sd;
   kktdev::StagedPlan &P = d.plan;
@@ -677,10 +708,11 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
   const int ek = P.eq_ptr[k + 1] - P.eq_ptr[k], q = P.qmax[k], cx = P.cap[k + 1];
   const int *cut = &P.xcut[(size_t)k * (NR + 1)];
   const int c0 = cut[RK], c1 = cut[RK + 1], wd = c1 - c0;
-  const long long ldfl = P.ldfl[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k];
-  double *G = d.misc.p + P.oG, *xw = d.misc.p + P.oXW, *xb = d.misc.p + P.oX;
-  double *slot = xw + (long long)RK * P.xwslot[k];  // the upper rows of [W_p | W_u], ld = ldfl (the rest: slot2, below)
+  const long long ldfl = P.ldfl[k], ldg = P.ldg[k], ldvn = P.ldv[k + 1], ldy = P.ldy[k], ldv = P.ldv[k], ldwl = P.ldwl[k], ldwu = P.ldwu;
+  double *G = d.misc.p + P.oG, *Wl = d.misc.p + P.oWl, *Wu = d.misc.p + P.oWu, *xb = d.misc.p + P.oX;
+  double *fg = d.misc.p + P.oFg[k & 1];  // the gathered local blocks of THIS stage (requested a stage ago)
   hipStream_t sA = h->stream, sB = d.stream2 ? d.stream2 : h->stream;
+  hipStream_t sX = (h->xchg_sfn && d.stream_x) ? d.stream_x : nullptr;  // the exchanges' own stream (stream-ordered transport)
   struct StreamGuard {  // launches go to h->stream: back to the first stream on every way out
     hqpkkt_t *h;
     hipStream_t s;
@@ -702,59 +734,44 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
       KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h<<<nblk(count), 256, 0, h->stream>>>(count, d.h_dst.p + first, d.h_tptr.p + first, d.h_terms.p,
                                                                                  h->vals.p, h->wt.p, G, 1));
   };
-  // ---- sA: [W_p | W_u] = V+ Floc - the upper rows first: they travel (first part of exchange 1) while the lower rows are
-  // computed - then, thin and deep (cut in k), the same columns of the control rows of G (W_u' Floc) and of the carried
-  // rows (B+ Floc) behind the lower rows: the second part
-  const int nloc = wd + mm, hr = P.xwrows[k];
-  double *xw2 = d.misc.p + P.oXW2, *slot2 = xw2 + (long long)RK * P.xwslot2[k], *ext = slot2 + (long long)(np - hr) * ldfl;
-  hipStream_t sX = (h->xchg_sfn && d.stream_x) ? d.stream_x : nullptr;  // the exchanges' own stream (stream-ordered transport)
-  auto xchg = [&](int i, double *buf, long long slot_elems) -> int {
-    if (slot_elems <= 0) return 0;
-    if (!sX) return exchange(h, HQPKKT_XCHG_ALLGATHER, buf, slot_elems, NR, nullptr);
-    HIPCHK(hipEventRecord(d.ev_w[i], sA));
-    HIPCHK(hipStreamWaitEvent(sX, d.ev_w[i], 0));
-    const int rc = exchange(h, HQPKKT_XCHG_ALLGATHER, buf, slot_elems, NR, sX);
-    if (rc) return rc;
-    HIPCHK(hipEventRecord(d.ev_x[i], sX));
-    return 0;
-  };
-  auto arrived = [&](int i, hipStream_t on) -> int {  // `on` goes on when exchange i has arrived
-    if (sX) HIPCHK(hipStreamWaitEvent(on, d.ev_x[i], 0));
-    return 0;
-  };
-  if (hr > 0) {  // (every rank makes every exchange, whatever it has to contribute)
-    if (nloc > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldfl, nullptr, 0, slot, ldfl, hr, nloc, np, 1.0, 0.0, 0, 0}))) return e;
-    if ((e = xchg(0, xw, P.xwslot[k]))) return e;
-  }
-  if (nloc > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V + hr, ldvn, sp.F, ldfl, nullptr, 0, slot2, ldfl, np - hr, nloc, np, 1.0, 0.0, 0, 0}))) return e;
-  // (W_u, the A operand of the thin products, lies in both parts: two products over the two row ranges, the second added)
-  auto thin = [&](const double *A1, long long lda1, const double *A2, long long lda2, int M, double *C, int cls) -> int {
-    int e2;
-    if (hr > 0 && (e2 = st_gemm(h, stg::GemmArgs{A1, lda1, sp.F, ldfl, nullptr, 0, C, ldfl, M, nloc, hr, 1.0, 0.0, 0, 0}, cls))) return e2;
-    return st_gemm(h, stg::GemmArgs{A2, lda2, sp.F + (long long)hr * ldfl, ldfl, C, ldfl, C, ldfl, M, nloc, np - hr, 1.0, hr > 0 ? 1.0 : 0.0, 0, 0}, cls);
-  };
-  if (mm > 0 && nloc > 0 && (e = thin(slot + wd, ldfl, slot2 + wd, ldfl, mm, ext, KC_ST_GEMM))) return e;
-  if (cx > 0 && nloc > 0 &&
-      (e = thin(sn.BT, P.ldb[k + 1], sn.BT + (long long)hr * P.ldb[k + 1], P.ldb[k + 1], cx, ext + (long long)mm * ldfl, KC_ST_GEMM_UPD)))
-    return e;
-  if ((e = xchg(1, xw2, P.xwslot2[k]))) return e;
+  // the next stage's F blocks travel while this stage is computed (its buffer's last readers, the stage before this one,
+  // are behind us in the first stream)
+  if (k > 0 && (e = staged_gather_f(h, k - 1))) return e;
   if (two) {
-    if (sX)
-      HIPCHK(hipStreamWaitEvent(sB, d.ev_x[1], 0));
-    else {
-      HIPCHK(hipEventRecord(d.ev_x1, sA));
-      HIPCHK(hipStreamWaitEvent(sB, d.ev_x1, 0));
-    }
+    HIPCHK(hipEventRecord(d.ev_fork, sA));
+    HIPCHK(hipStreamWaitEvent(sB, d.ev_fork, 0));
     join.armed = true;
   }
-  // ---- sB, second part: the control-sized chain
+  // ---- the control-sized chain, from the gathered F (identical on all ranks: the control columns out of rank 0's slot).
+  // Its thin products are launches of hundreds of small workgroups: beside a product that fills every workgroup slot of
+  // the chip (the cut form: strips of >= 1024 columns, up to four ranks at the headline width) each of them waits for
+  // slots - measured: 1.6 ms for a 20 us kernel, the chain became the critical path - so they go FIRST on the first
+  // stream there (0.2 ms), and beside the strip's product only where that one leaves CUs idle (one round of <= 256 tiles).
+  const bool thin_first = wd >= 1024;
+  h->stream = thin_first ? sA : sB;
+  if (sX) HIPCHK(hipStreamWaitEvent(h->stream, d.ev_x[k & 1], 0));
+  {
+    const stg::StripTab *tab = d.wtabs.p + k;
+    const long long ld0 = (cut[1] - cut[0] + mm + 7) / 8 * 8;  // rank 0's local block: [F_0 | F_u]
+    const double *Fu = fg + (cut[1] - cut[0]);
+    auto thin = [&](const double *A, long long lda, int M, double *C, long long ldc, int cls) -> int {  // C = A' [F_x | F_u]
+      int e2;
+      stg::GemmArgs gx{A, lda, fg, 0, nullptr, 0, C, ldc, M, nn, np, 1.0, 0.0, 0, 0};
+      gx.bstrips = tab;
+      if (nn > 0 && (e2 = st_gemm(h, gx, cls, !two || thin_first))) return e2;
+      return mm > 0 ? st_gemm(h, stg::GemmArgs{A, lda, Fu, ld0, nullptr, 0, C + nn, ldc, M, mm, np, 1.0, 0.0, 0, 0}, cls, !two || thin_first) : 0;
+    };
+    if (mm > 0) {
+      if ((e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, Fu, ld0, nullptr, 0, Wu, ldwu, np, mm, np, 1.0, 0.0, 0, 0}, KC_ST_GEMM, !two || thin_first))) return e;
+      if ((e = thin(Wu, ldwu, mm, G + (long long)nn * ldg, ldg, KC_ST_GEMM))) return e;
+    }
+    if (cx > 0 && (e = thin(sn.BT, P.ldb[k + 1], cx, sp.N + (size_t)ek * P.ldn[k], P.ldn[k], KC_ST_GEMM_UPD))) return e;
+  }
+  if (thin_first && two) {  // the rest of the chain beside the large products
+    HIPCHK(hipEventRecord(d.ev_x1, sA));
+    HIPCHK(hipStreamWaitEvent(sB, d.ev_x1, 0));
+  }
   h->stream = sB;
-  if (mm + cx > 0)
-    KLAUNCH(h, KC_ST_VEC, stg::k_st_unpack_extra<<<dim3(std::min(mm + cx, 1024), NR), 256, 0, h->stream>>>(
-                              d.wtabs2.p + k, xw2, np - hr, mm, cx, nn, 0, G + (long long)nn * ldg, ldg, sp.N + (size_t)ek * P.ldn[k], P.ldn[k]));
-  // (the control columns from rank 0's slot on EVERY rank: the ranks' own copies of W_u come out of products of different
-  // shapes - other cut plans, another order of the k pieces - and differ in their last bits; the control-sized chain must
-  // see identical data everywhere, or the ranks' rank decisions and refinement loops could part ways)
   add_h(P.h_mid[k], ne_u);
   {
     stg::SmallArgs sa{G, ldg, nn, mm, sp.N, P.ldn[k], ek, P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr,
@@ -773,29 +790,31 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     if ((e = st_rm(h, d, sp, k, !two, wa))) return e;
   }
   if (two) HIPCHK(hipEventRecord(d.ev_join, sB));
-  // ---- sA: the rank's blocks of G_xx (rows = its strip) in one launch, H_xx, pack, exchange 2
+  // ---- sA: the strip of W, the rank's blocks of G_xx (rows = its strip) in one launch, H_xx, pack, the gather of the blocks
   h->stream = sA;
+  if (wd > 0 && (e = st_gemm(h, stg::GemmArgs{sn.V, ldvn, sp.F, ldfl, nullptr, 0, Wl, ldwl, np, wd, np, 1.0, 0.0, 0, 0}))) return e;
+  if (sX) HIPCHK(hipStreamWaitEvent(sA, d.ev_x[k & 1], 0));
   const int ntile = P.gtile_ptr[k + 1] - P.gtile_ptr[k];
   if (wd > 0 && ntile > 0) {
-    // over the rows of the first part as soon as it has arrived, the rest added when the second has
-    double *Gs = G + (long long)c0 * ldg;
-    if (hr > 0) {
-      if ((e = arrived(0, sA))) return e;
-      stg::GemmArgs g1{sp.F, ldfl, xw, 0, nullptr, 0, Gs, ldg, wd, nn, hr, 1.0, 0.0, 0, 0};
-      g1.tile_map = d.gtile.p + P.gtile_ptr[k], g1.bstrips = d.wtabs.p + k;
-      if ((e = st_gemm_tiles(h, g1, ntile, KC_ST_GEMM))) return e;
-    }
-    if ((e = arrived(1, sA))) return e;
-    stg::GemmArgs g2{sp.F + (long long)hr * ldfl, ldfl, xw2, 0, Gs, ldg, Gs, ldg, wd, nn, np - hr, 1.0, hr > 0 ? 1.0 : 0.0, 0, 0};
-    g2.tile_map = d.gtile.p + P.gtile_ptr[k], g2.bstrips = d.wtabs2.p + k;
-    if ((e = st_gemm_tiles(h, g2, ntile, KC_ST_GEMM))) return e;
-  } else if ((e = arrived(0, sA)) || (e = arrived(1, sA)))
-    return e;
+    stg::GemmArgs gg{Wl, ldwl, fg, 0, nullptr, 0, G + (long long)c0 * ldg, ldg, wd, nn, np, 1.0, 0.0, 0, 0};
+    gg.tile_map = d.gtile.p + P.gtile_ptr[k], gg.bstrips = d.wtabs.p + k;
+    if ((e = st_gemm_tiles(h, gg, ntile, KC_ST_GEMM))) return e;
+  }
   add_h(P.h_ptr[k], ne_x);  // (entries outside this rank's blocks land in parts of G nobody reads)
   const int npk = d.prect_ptr[k + 1] - d.prect_ptr[k];
   if (npk > 0)
     KLAUNCH(h, KC_ST_VEC, stg::k_st_pack_rects<<<dim3(512, npk), 256, 0, sA>>>(d.prects.p + d.prect_ptr[k], G, ldg, xb + (long long)RK * P.xslot[k]));
-  if ((e = xchg(2, xb, P.xslot[k])) || (e = arrived(2, sA))) return e;
+  if (P.xslot[k] > 0) {
+    if (sX) {
+      HIPCHK(hipEventRecord(d.ev_w[2], sA));
+      HIPCHK(hipStreamWaitEvent(sX, d.ev_w[2], 0));
+    }
+    if ((e = exchange(h, HQPKKT_XCHG_ALLGATHER, xb, P.xslot[k], NR, sX))) return e;
+    if (sX) {
+      HIPCHK(hipEventRecord(d.ev_x[2], sX));
+      HIPCHK(hipStreamWaitEvent(sA, d.ev_x[2], 0));
+    }
+  }
   if (two) {
     HIPCHK(hipStreamWaitEvent(sA, d.ev_join, 0));
     join.armed = false;
@@ -840,6 +859,7 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
         KLAUNCH(h, KC_ST_VEC, stg::k_st_copy2d<<<std::min(wd, 2048), 256, 0, s>>>(sp.V + (long long)c0 * P.ldv[K], P.ldv[K], sp.Vs, P.ldv[K], wd, nK));
     }
   }
+  if (P.sharded && K > 0 && (e = staged_gather_f(h, K - 1))) return e;  // (stage k requests stage k - 1's)
   for (int k = K - 1; k >= 0; k--) {
     if (P.sharded) {
       if ((e = staged_stage_sharded(h, k))) return e;

@@ -269,16 +269,17 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   oQv = mo, mo += up16(n + 8);
   oScr = mo, mo += up16(scratch_elems);
   // ------------------------------------------------------------------ one system over several ranks (staged_plan.hpp)
-  xcut.clear(), xw.clear(), ldfl.clear(), oFl.clear(), oVs.clear(), xwslot.clear(), xwslot2.clear(), xwrows.clear(), xslot.clear();
+  xcut.clear(), xw.clear(), ldfl.clear(), oFl.clear(), oVs.clear(), fgslot.clear(), ldwl.clear(), xslot.clear();
   xrects.clear(), xrect_ptr.clear(), gtile.clear(), gtile_ptr.clear();
-  oX = oXW = oXW2 = oXV = oXP = oDyx = 0, xvslot = xpslot = 0, oVf[0] = oVf[1] = 0;
+  oX = oXV = oXP = oDyx = oWl = oWu = 0, xvslot = xpslot = 0, oVf[0] = oVf[1] = 0, oFg[0] = oFg[1] = 0;
   if (sharded) {
     const int P = shard_count, me_ = shard_rank;
     if (P < 1 || P > 16 || me_ < 0 || me_ >= P) return 1;
     xcut.assign((size_t)(K + 1) * (P + 1), 0), xw.assign(K + 1, 0);
-    ldfl.assign(K + 1, 8), oFl.assign(K + 1, 0), oVs.assign(K + 1, 0), xwslot.assign(K + 1, 0), xslot.assign(K + 1, 0);
-    xwslot2.assign(K + 1, 0), xwrows.assign(K + 1, 0);
-    long long flo = 0, vso = 0, vfmax = 0, xwmax = 0, xwmax2 = 0, xmax = 0;
+    ldfl.assign(K + 1, 8), oFl.assign(K + 1, 0), oVs.assign(K + 1, 0), fgslot.assign(K + 1, 0), xslot.assign(K + 1, 0);
+    ldwl.assign(K + 1, 8);
+    long long flo = 0, vso = 0, vfmax = 0, fgmax = 0, xmax = 0, wlmax = 0, wumax = 0;
+    int mmax = 1;
     for (int k = 0; k <= K; k++) {
       const long long nn = nk[k];
       if (k < K && (nn & 1)) return 1;  // the control columns of Floc start behind the strip: 16-byte loads need it even
@@ -293,15 +294,13 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       if (k < K) {
         ldfl[k] = up8(wd + mk[k]);
         oFl[k] = flo, flo += up16((long long)nk[k + 1] * ldfl[k]);
-        // the upper half of the rows of W: whole 128-row tiles; stages of fewer than 512 rows travel in one piece
         const long long np = nk[k + 1];
-        // - where the halves are still products that fill the chip (strips of >= 1024 columns: up to four ranks at the
-        // headline width; measured on one MI355X, tools/shard_pieces.py: two half products cost 4 % more than the whole
-        // one at 1280 columns, 23 % more at 640 - more than the travel time they hide)
-        xwrows[k] = (np >= 512 && xw[k] >= 1024) ? (int)(128 * (((np + 127) / 128 + 1) / 2)) : 0;
-        xwslot[k] = up16((long long)xwrows[k] * up8(xw[k] + mk[k]));
-        xwslot2[k] = up16((np - xwrows[k] + mk[k] + cap[k + 1]) * up8(xw[k] + mk[k]));
-        xwmax = std::max(xwmax, xwslot[k]), xwmax2 = std::max(xwmax2, xwslot2[k]);
+        fgslot[k] = up16(np * up8(xw[k] + mk[k]));  // (every rank's local block: its strip and the control columns)
+        fgmax = std::max(fgmax, fgslot[k]);
+        ldwl[k] = up8(std::max<long long>(wd, 1));
+        wlmax = std::max(wlmax, np * ldwl[k]);
+        mmax = std::max(mmax, mk[k]);
+        wumax = std::max(wumax, np * up8(std::max(mk[k], 1)));
       }
     }
     // the blocks of G_xx: who computes which
@@ -348,8 +347,11 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
       }
     }
     xrect_ptr[K] = (int)xrects.size(), gtile_ptr[K] = (int)gtile.size();
-    oXW = mo, mo += up16(xwmax * P);
-    oXW2 = mo, mo += up16(xwmax2 * P);
+    oFg[0] = mo, mo += up16(fgmax * P);
+    oFg[1] = mo, mo += up16(fgmax * P);
+    ldwu = up8(mmax);
+    oWl = mo, mo += up16(wlmax + 8);
+    oWu = mo, mo += up16(wumax + 8);
     oX = mo, mo += up16(xmax * P);
     oXV = mo, mo += up16(xvslot * P);
     xpslot = up16(nmax + 8);

@@ -69,18 +69,20 @@ struct StagedPlan {
   // contiguous range per rank - the same width for every rank but the last, a multiple of 128 - and the memory goes
   // with them: rank p keeps the columns [cut[p], cut[p+1]) of F_k next to the control columns (Floc_k = [F_p | F_u],
   // n+ x ldfl) and, for the solve, the ROWS [cut[p], cut[p+1]) of V_k.  Per stage of the factorisation:
-  //   Wloc = V+ Floc = [W_p | W_u]                  local (V+ in full: the transient result of the stage before)
-  //   exchange 1: [Wloc ; W_u' Floc ; B+ Floc]       n+ + m + cap+ rows of the rank's local width (gather of the slots),
-  //                                                  the upper half of the rows of Wloc while the lower half is computed
-  //   G_xx block (a, b), a >= b                      by one of the two ranks, as F_p' W_q in its row strip of the work
-  //                                                  block (the owner of the columns computes the transpose): pair
-  //                                                  {a, b} belongs to b if a - b <= (P - 1) / 2 else to a; with P even
-  //                                                  the pairs P / 2 apart are cut in two by rows; diagonal blocks:
-  //                                                  lower tiles
-  //   exchange 2: the blocks (lower orientation)     n^2 / 2 doubles in all
+  //   W_p = V+ F_p                                   local (V+ in full: the transient result of the stage before); W is
+  //                                                  NOT exchanged
+  //   gather of the ranks' Floc_k                    STATIC data: requested a stage ahead (stage k - 1's while stage k is
+  //                                                  computed), into one of two buffers - off the critical path
+  //   G_xx block (a, b), a >= b                      by one of the two ranks, as W_p' F_q = (V+ F_p)' F_q in its row strip
+  //                                                  of the work block (the owner of the block's columns computes the
+  //                                                  transpose): pair {a, b} belongs to b if a - b <= (P - 1) / 2 else to
+  //                                                  a; with P even the pairs P / 2 apart are cut in two by rows;
+  //                                                  diagonal blocks: lower tiles
+  //   gather of the blocks (lower orientation)       n^2 / 2 doubles in all: the one exchange on the critical path
   //   V_k = G_xx - Y' Rm in full (every rank), its row strip kept
-  // The control-sized chain is computed by every rank on identical data.  The solve's products run on the strips with
-  // one gather of a state-sized vector per stage and direction.
+  // The control-sized chain (W_u = V+ F_u, the control rows of G = W_u' F, the carried rows B+ F, K^-1, Y, Rm) is
+  // computed by every rank from the gathered F - by launches of the same shape everywhere, so that all ranks see
+  // identical bits.  The solve's products run on the strips with one gather of a state-sized vector per stage and direction.
   int shard_rank = 0, shard_count = 1;
   bool sharded = false;          // several ranks, or one rank with a transport set (tests the exchange path)
   std::vector<int> xcut;         // (K+1) x (shard_count+1): first state column of rank p in stage k (k = K: rows of V_K)
@@ -88,13 +90,12 @@ struct StagedPlan {
   std::vector<int> ldfl;         // per stage: leading dimension of Floc_k (own strip + control columns)
   std::vector<long long> oFl, oVs;  // local F blocks (F arena), own row strips of V_k (V arena, ld = ldv[k])
   long long oVf[2] = {0, 0};     // the two full-size transient V blocks (misc arena): V_k lives in oVf[k & 1]
-  // exchange 1 in two parts, so that the first travels while the second is computed: the rows [0, xwrows[k]) of every
-  // rank's [W_p | W_u] (slots of xwslot[k] doubles at oXW), then the remaining rows with the control rows of G and the
-  // carried rows behind them (slots of xwslot2[k] doubles at oXW2)
-  long long oXW = 0, oXW2 = 0;
-  std::vector<long long> xwslot, xwslot2;
-  std::vector<int> xwrows;
-  long long oX = 0;              // exchange 2: shard_count slots of xslot[k] doubles (misc)
+  long long oFg[2] = {0, 0};     // the gathered local F blocks: stage k's in oFg[k & 1], shard_count slots of fgslot[k] doubles (misc)
+  std::vector<long long> fgslot;
+  long long oWl = 0, oWu = 0;    // W_p = V+ F_p (n+ x ldwl[k]) and W_u = V+ F_u (n+ x ldwu) of the stage in work (misc)
+  std::vector<int> ldwl;
+  int ldwu = 8;
+  long long oX = 0;              // the gather of the blocks of G_xx: shard_count slots of xslot[k] doubles (misc)
   std::vector<long long> xslot;
   long long oXV = 0;             // gathers of the solve: the ranks' strips of a state-sized vector, side by side (misc)
   long long xvslot = 0;
