@@ -729,7 +729,7 @@ def bench_c4(args):
         "value_with_host_vectors": host_rate,  # PCIe per call (33 MB each way in all): what the shim's host sees
         "shard": {"ranks": world, "transport": transport, "comm_ranks": comm_ranks,
                   "devices": sorted(set(all_devices)) if all_devices else None,
-                  "bytes_allgather_per_factor": st["bytes_exchange_factor"],
+                  "bytes_allgather_per_factor": st["bytes_exchange_factor"], "bytes_panels_this_rank": st["bytes_panels"],
                   "flops_rank0": st["flops_local"], "allgathers_per_factor": st["n_exchange_blocks"],
                   "per_rank": per_rank} if one else None,
         "replicas_value": replicas["value"] if replicas else None,
@@ -737,7 +737,8 @@ def bench_c4(args):
         "config": {"workload": f"C4 = BASELINE configs[3], the metric's 10^6-variable DOCP: multistage LQ optimal control QP, K={K} stages, "
                                f"nx={nx} states, nu={nu} controls -> n={n} me={me} m={m}, dense fx/fu handed over as blocks, x_0 fixed, "
                                f"box bounds on u; plugin LQDOCP (STAGED engine), "
-                               + (f"ONE system over {world} GPUs (state columns of every stage's products per rank, one all-gather per stage)"
+                               + (f"ONE system over {world} GPUs (memory sharded: every rank holds its column strip of every F_k and its row strip of every V_k; "
+                                  f"per stage the gather of the F blocks, requested a stage ahead, and ONE gather of the blocks of G_xx)"
                                   if one else "one system per GPU"),
                    "stages": K, "nx": nx, "nu": nu, "n": n, "me": me, "m": m, "plugin": "LQDOCP",
                    "kkt_dim_full": n + me + m, "hbm_gb": (st["bytes_panels"] + st["bytes_updates"]) / 1e9},

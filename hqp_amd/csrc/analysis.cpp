@@ -660,14 +660,6 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
       }
     }
   }
-  if (getenv("HQPKKT_TRACE_ND")) {
-    std::vector<size_t> sz;
-    for (auto &t : tmp) sz.push_back(t.verts.size());
-    std::sort(sz.rbegin(), sz.rend());
-    fprintf(stderr, "dissection: %d logical nodes, %zu roots; largest:", nlog, roots.size());
-    for (size_t i = 0; i < std::min<size_t>(12, sz.size()); i++) fprintf(stderr, " %zu", sz[i]);
-    fprintf(stderr, "\n");
-  }
   std::vector<std::vector<int>> lverts(nlog);  // pivot sets by band position
   std::vector<int> lnode_of_pos(dim);
   for (int id = 0; id < nlog; id++) {

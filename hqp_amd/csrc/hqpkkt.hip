@@ -537,7 +537,7 @@ static int upload(hqpkkt_t *h) {
         for (int q = S.level_ptr[l]; q < S.level_ptr[l + 1]; q++) down.push_back(S.level_nodes[q]);
       if ((e = h->tree_down.upload(down)) || (e = h->tree_x.alloc(2 * (size_t)(an.cb_elems + an.dim)))) return e;
       h->small_tree = true;
-      h->tree_factor = !an.upd_pingpong && !getenv("HQPKKT_NO_TREE_FACTOR");
+      h->tree_factor = !an.upd_pingpong;
       if (h->tree_factor && (e = h->tree_u.alloc(2 * (size_t)std::max<long long>(an.upd_elems, 1)))) return e;
       if ((e = reset_solve_top(h))) return e;
     }
@@ -1171,7 +1171,7 @@ static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, 
     *x1 = d.dyn_sum.p, *x2 = d.dyn_sum.p + d.dyn_sum_x2, *ndyn = P.ndyn;
     return 0;
   }
-  static const bool two_passes = getenv("HQPKKT_RESIDUAL_TWO_PASSES") != nullptr;
+  const bool two_passes = false;  // (one pass over F for both products; the two-pass kernels stay for blocks the fused one does not take)
   const int nbc = (nzmax + 255) / 256;
   if (!two_passes && d.dyn_part.p && d.dyn_part_cols == nbc) {
     // one pass over F for both products (k_st_dyn_both), then the row sums' column blocks
@@ -1639,7 +1639,7 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
   // contract more slowly: up to fifteen then, as long as they still gain, so that solve() returns what the caller's
   // optimality test expects of an accurate factorisation - Hqp_IpsFranke compares the returned residual with its
   // eps, hqp/Hqp_IpsFranke.C:372)
-  const int max_rounds = (h->st.n_perturbed > 0 || h->soft_tiny || h->soft_singular) && !getenv("HQPKKT_FIVE_ROUNDS") ? 15 : 5;
+  const int max_rounds = (h->st.n_perturbed > 0 || h->soft_tiny || h->soft_singular) ? 15 : 5;
   for (int it = 0; it < max_rounds && res > target; it++) {
     if (it >= 5 && !(res < 0.5 * res_acc_prev)) break;  // beyond the reference's five: only while a round still halves the residual
     res_last = res;
@@ -2690,7 +2690,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
       stg::gemm_launch_split(variant, skg, 0, g, skk);
     } else if (big)
       stg::gemm_launch_plain(variant, (unsigned)tiles, 0, g, cus);
-    else if (!getenv("HQPKKT_NO_TILE6432") && stg::gemm_tiles_6432(M, N, K, lower, mirror, cus))  // (as st_gemm chooses)
+    else if (stg::gemm_tiles_6432(M, N, K, lower, mirror, cus))  // (as st_gemm chooses)
       stg::k_dgemm_tn<64, 32><<<(unsigned)(((M + 63) / 64) * (long long)((N + 31) / 32)), 256, stg::gemm_lds_bytes(64, 32)>>>(g);
     else
       stg::k_dgemm_tn<64, 64><<<(unsigned)tiles, 256, stg::gemm_lds_bytes(64, 64)>>>(g);
@@ -2901,6 +2901,28 @@ int hqpkkt_debug_get(const hqpkkt_t *h, int what, int *out, long long *len) {
     case 27: {  // STAGED over several ranks: column cuts, (K+1) x (ranks+1)
       if (!h->sd) return HQPKKT_E_INTERN;
       v = &h->sd->plan.xcut;
+      break;
+    }
+    case 33: {  // STAGED over several ranks: the blocks of G_xx, 10 ints each: stage, block row, block column, r0, r1, c0,
+                // c1, owner, computed in the owner's own rows (1) or transposed (0), offset inside the owner's slot
+      if (!h->sd) return HQPKKT_E_INTERN;
+      const kktdev::StagedPlan &P = h->sd->plan;
+      for (int k = 0; k < P.K && !P.xrect_ptr.empty(); k++)
+        for (int q = P.xrect_ptr[k]; q < P.xrect_ptr[k + 1]; q++) {
+          const kktdev::StagedPlan::XRect &x = P.xrects[q];
+          for (int val : {k, x.a, x.b, x.r0, x.r1, x.c0, x.c1, x.owner, x.mine_rows ? 1 : 0, (int)x.off}) tmp.push_back(val);
+        }
+      v = &tmp;
+      break;
+    }
+    case 34: {  // ... and this rank's tiles of its blocks' products: per stage a count, then the tiles (tile row in the strip << 16 | tile column)
+      if (!h->sd) return HQPKKT_E_INTERN;
+      const kktdev::StagedPlan &P = h->sd->plan;
+      for (int k = 0; k < P.K && !P.gtile_ptr.empty(); k++) {
+        tmp.push_back(P.gtile_ptr[k + 1] - P.gtile_ptr[k]);
+        for (int q = P.gtile_ptr[k]; q < P.gtile_ptr[k + 1]; q++) tmp.push_back(P.gtile[q]);
+      }
+      v = &tmp;
       break;
     }
     case 28: {  // STAGED: [0] stages whose blocked elimination ran, [1] those of them that fell back to the one-workgroup form

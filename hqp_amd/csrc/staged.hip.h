@@ -824,7 +824,6 @@ static inline int gemm_variant_from_env() {
   if (getenv("HQPKKT_NO_LDSDMA")) return GEMM_REG4;
   const char *w = getenv("HQPKKT_DGEMM_WAVES");
   if (w && atoi(w) == 4) return GEMM_DMA4;
-  if (getenv("HQPKKT_DGEMM_3BUF")) return GEMM_DMA8X3;
   return GEMM_DMA8;
 }
 

@@ -147,7 +147,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   }
   if (big)
     KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g, d ? d->cus : 0));
-  else if (d && d->cus > 0 && !g.lower && !g.mirror && g.K >= 1024 && tiles * 2 <= d->cus && !getenv("HQPKKT_NO_KSPLIT") &&
+  else if (d && d->cus > 0 && !g.lower && !g.mirror && g.K >= 1024 && tiles * 2 <= d->cus &&
            (long long)g.M * g.N * 4 <= (allow_sk ? d->sk_ws_elems : d->ks_ws2_elems)) {
     // a thin, deep product: its k range cut over the chip (k_dgemm_tn_ks), the pieces added in their order (the
     // launches of the second stream have a workspace of their own)
@@ -160,9 +160,8 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
     KLAUNCH(h, cls, stg::k_dgemm_ks_finish<<<nblk((long long)g.M * g.N), 256, 0, h->stream>>>(g, ws, nsplit));
   } else {
     // few tiles of a deep rectangular product (W of a stage of ~1000 states: 272): 64 x 32 tiles, so that a CU holds two
-    // workgroups and one multiplies while the other waits at its barrier: 81 -> 73 us (HQPKKT_NO_TILE6432: off)
-    static const bool t6432 = getenv("HQPKKT_NO_TILE6432") == nullptr;
-    if (t6432 && stg::gemm_tiles_6432(g.M, g.N, g.K, g.lower, g.mirror, d ? d->cus : 0)) {
+    // workgroups and one multiplies while the other waits at its barrier: 81 -> 73 us
+    if (stg::gemm_tiles_6432(g.M, g.N, g.K, g.lower, g.mirror, d ? d->cus : 0)) {
       const long long t2 = ((g.M + 63) / 64) * (long long)((g.N + 31) / 32);
       KLAUNCH(h, cls, (stg::k_dgemm_tn<64, 32><<<(unsigned)t2, 256, stg::gemm_lds_bytes(64, 32), h->stream>>>(g)));
       return 0;
@@ -257,8 +256,7 @@ static int st_rm(hqpkkt_t *h, StagedDev &d, const StagePtr &sp, int k, bool allo
   const kktdev::StagedPlan &P = d.plan;
   const int q = P.qmax[k], nn = P.nk[k];
   const long long ldy = P.ldy[k];
-  static const bool fused = getenv("HQPKKT_NO_FUSED_RM") == nullptr;
-  if (q > 0 && q <= 64 && fused) {
+  if (q > 0 && q <= 64) {
     stg::RmArgs ra{sp.Kinv, sp.Kmat, P.ldq[k], sp.Y, sp.Rm, ldy, q, nn, 1, wa};
     KLAUNCH(h, KC_ST_GEMM_UPD, stg::k_st_rm<<<(nn + stg::RM_COLS - 1) / stg::RM_COLS, 256, stg::st_rm_lds(q), h->stream>>>(ra));
     return 0;
@@ -516,7 +514,7 @@ static int staged_upload(hqpkkt_t *h) {
     if ((e = d.wtabs.upload(wt)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt)))
       return e;
     if (!d.ev_x1) HIPCHK(hipEventCreateWithFlags(&d.ev_x1, hipEventDisableTiming));
-    if (h->xchg_sfn && !d.stream_x && !getenv("HQPKKT_NO_XCHG_STREAM")) {
+    if (h->xchg_sfn && !d.stream_x) {
       HIPCHK(hipStreamCreateWithFlags(&d.stream_x, hipStreamNonBlocking));
       for (hipEvent_t *ev : {&d.ev_w[0], &d.ev_w[1], &d.ev_w[2], &d.ev_x[0], &d.ev_x[1], &d.ev_x[2]})
         HIPCHK(hipEventCreateWithFlags(ev, hipEventDisableTiming));
