@@ -269,11 +269,15 @@ int hqpkkt_set_shard(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_fn fn, vo
  * handle's stream, behind the kernels that fill `buf`) and returns at once; nothing is drained, the
  * kernels that follow wait in the stream.  hqpkkt_rccl_exchange of libhqpkkt_rccl.so
  * (include/hqpkkt_rccl.h: ncclAllGather / ncclAllReduce of RCCL over xGMI) has this signature.
- * STAGED mode over several ranks: every rank holds all stage blocks; the state columns of the three
- * products of a stage (W = V+ F, G = F'W, V = Gxx - Y'Rm) are cut into one range per rank, the
- * control columns and all small work are done by every rank; ONE all-gather per stage (the strips
- * of the lower triangle of V_k: n^2/2 doubles in all) brings the cost-to-go Hessian together; the
- * solves run replicated, without communication.  Needs an even number of states per stage. */
+ * STAGED mode over several ranks: the state columns of every stage are cut into one range per rank
+ * and the memory goes with them - a rank keeps its columns of every F_k (every rank is handed the
+ * same blocks and copies its share) and its rows of every V_k: bytes_panels per rank <= 1 / P of the
+ * single-rank figure + 10 %.  Per stage of a factorisation: W_p = V+ F_p (local), the gather of the
+ * ranks' F blocks (static data, requested a stage ahead), the blocks of G_xx = F'V+F dealt out in a
+ * ring and computed as W_p' F_q, ONE gather of those blocks (n^2/2 doubles in all) on the critical
+ * path, V_k = G_xx - Y'Rm by every rank; the control-sized work is done by every rank on identical
+ * data.  The solve gathers one state-sized vector per stage and direction.  Needs an even number of
+ * states per stage. */
 typedef int (*hqpkkt_exchange_stream_fn)(void *ctx, int op, double *buf, long long slot_elems, int nslots,
                                          void *hip_stream);
 int hqpkkt_set_shard_stream(hqpkkt_t *h, int rank, int count, hqpkkt_exchange_stream_fn fn, void *ctx);
