@@ -678,19 +678,25 @@ def bench_c4(args):
     gemm_ms, gemm_launch = per_step.get("staged_gemm", 0.0), launches.get("staged_gemm", 1.0)
     achieved = flops_big / (gemm_ms * 1e-3) / 1e12 if gemm_ms else None
     traffic, traffic_note = None, None
-    pmc = os.path.join(ROOT, "profiles", "r04_pmc_traffic_c4.json")
-    if os.path.exists(pmc) and (nx, nu) == (5000, 50) and not one:
+    import glob
+    pmcs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0*_pmc_traffic_c4.json")), reverse=True)  # newest round first
+    if pmcs and (nx, nu) == (5000, 50) and not one:
         # HBM bytes per launch of the stream-K dgemm from rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this
-        # workload (separate runs, gfx950 correction applied: profiles/README.md) - only if those passes ran on the
+        # workload (separate runs, gfx950 correction applied: profiles/README.md) - only from passes that ran on the
         # kernel sources of this checkout
-        rec = json.load(open(pmc))
-        if rec.get("_kernel_source_sha16") == kernel_source_sha16():
-            traffic = rec.get("k_dgemm_tn_sk", {}).get("hbm_bytes_per_launch")
-        else:
-            traffic_note = ("profiles/r04_pmc_traffic_c4.json was collected on other kernel sources "
-                            f"({rec.get('_kernel_source_sha16')} != {kernel_source_sha16()}): not quoted")
+        seen = []
+        for pmc in pmcs:
+            rec = json.load(open(pmc))
+            if rec.get("_kernel_source_sha16") == kernel_source_sha16():
+                traffic = rec.get("k_dgemm_tn_sk", {}).get("hbm_bytes_per_launch")
+                traffic_note = "rocprofv3 counter passes: profiles/" + os.path.basename(pmc)
+                break
+            seen.append(f"{os.path.basename(pmc)}: {rec.get('_kernel_source_sha16')}")
+        if traffic is None:
+            traffic_note = ("the counter passes under profiles/ were collected on other kernel sources "
+                            f"({'; '.join(seen)} != {kernel_source_sha16()}): not quoted")
     elif (nx, nu) == (5000, 50) and not one:
-        traffic_note = "no counter passes of this round (profiles/r04_pmc_traffic_c4.json)"
+        traffic_note = "no counter passes (profiles/r0*_pmc_traffic_c4.json)"
     roofline = {"kernel": "k_dgemm_tn_sk<lds-dma, 2x4 waves> / k_dgemm_tn<128,128> (W = V+ F, G = F'W)", "bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS,
                 "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS if achieved else None, "traffic": traffic,
                 "traffic_note": traffic_note,

@@ -1639,7 +1639,9 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
   // contract more slowly: up to fifteen then, as long as they still gain, so that solve() returns what the caller's
   // optimality test expects of an accurate factorisation - Hqp_IpsFranke compares the returned residual with its
   // eps, hqp/Hqp_IpsFranke.C:372)
-  const int max_rounds = (h->st.n_perturbed > 0 || h->soft_tiny || h->soft_singular) ? 15 : 5;
+  // (not behind a cancelled pivot that was USED as it was - soft_tiny alone: five rounds leave such factors at a residual
+  // that says "singular", fifteen can drag a consistent singular system below mat_eps, and the reference reports it)
+  const int max_rounds = h->st.n_perturbed > 0 ? 15 : 5;
   for (int it = 0; it < max_rounds && res > target; it++) {
     if (it >= 5 && !(res < 0.5 * res_acc_prev)) break;  // beyond the reference's five: only while a round still halves the residual
     res_last = res;
@@ -1778,7 +1780,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     struct Restore {
       hqpkkt_t *h;
       int loc;
-      ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false; }
+      ~Restore() {
+        h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false;
+        (void)hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 0, sizeof(int), h->stream);  // (kernels.hip.h: cancelled pivots are replaced inside the loop only)
+      }
     } restore{h, saved_loc};
     h->opts.loc = HQPKKT_LOC_DEVICE;
     h->lazy = true;  // no host round trip where the loop does not need the answer at once
@@ -1939,6 +1944,9 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         k_ip_fill<<<nblk(m), 256, 0, s>>>(m, 1.0, C.wh);
       }
     }
+    // the cold start's factorisation has succeeded (or a hot start carries on): the matrix is regular, cancelled multiplier
+    // pivots are replaced from here on (kernels.hip.h, TINY_REPLACE_WORD)
+    HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));
     bool restart_cold = false;
     while (true) {
       double phi = 0.0;
@@ -2168,7 +2176,10 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     struct Restore {
       hqpkkt_t *h;
       int loc;
-      ~Restore() { h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false, h->defer_residual = false, h->residual_pending = false; }
+      ~Restore() {
+        h->opts.loc = loc, h->lazy = false, h->factor_unchecked = false, h->defer_residual = false, h->residual_pending = false;
+        (void)hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 0, sizeof(int), h->stream);
+      }
     } restore{h, saved_loc};
     h->opts.loc = HQPKKT_LOC_DEVICE;
     h->lazy = true;
@@ -2253,6 +2264,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     // ---- iterations (:381-416 around :271-378)
     while (true) {
       if (iter == 0) alphabar = 1.0;
+      if (iter == 1) HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));  // (the first factorisation + solve has succeeded: kernels.hip.h)
       double mu;
       if (1.0 / gap < rhomin || alpha < 1.0) {
         mu = alphabar * gap / rhomin;             // potential reduction

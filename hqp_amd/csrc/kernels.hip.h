@@ -194,6 +194,16 @@ struct TermDev {
 // handle uploads its tree (HQPKKT_TINY_PERTURB, 0: off; default 1e-6: with 1e-8 two of the ten finds stay - a smaller
 // replacement amplifies the rounding errors of its row more than the refinement gains from the smaller change)
 __device__ double soft_pivot_pert = 1e-6;
+// ... but only where the caller has said that the matrix is known to be regular: a cancelled multiplier pivot is ALSO what
+// a rank-deficient equality block leaves behind (two identical rows), which the reference reports as E_SING / "degenerate"
+// at the first factorisation - a replaced pivot would solve the consistent singular system and go on.  Word
+// TINY_REPLACE_WORD of the handle's flags (k_clear leaves it alone) switches the replacement on: the device-resident
+// interior-point loops set it once their first factorisation + solve has succeeded (hqpkkt_mehrotra: behind the cold
+// start; hqpkkt_franke: from the second iteration on) and clear it when they return; the plugin entry points
+// (hqpkkt_factor on its own, the reference's solvers through the shim) never replace.  An EXACTLY zero pivot is never
+// replaced: it stays the reference's E_SING (zero_pivot_slot above).
+static const int TINY_REPLACE_WORD = 112;
+__device__ __forceinline__ bool tiny_replace(const int *counters) { return counters[TINY_REPLACE_WORD - 1] != 0 && soft_pivot_pert > 0.0; }
 // (The replacement cures the runs that ended early on garbage factors - all ten finds of the campaigns of rounds 1-4 - and
 // breaks about as many others, where the pivot used as it was had been good enough: six of the 12 000 cases of
 // profiles/r05_fuzz_tree.txt against seven without it.  Trying both treatments per solve and keeping the better one was
@@ -798,7 +808,7 @@ int dn;
         const int sgs = esign[e0 + lp[k]];
         if (sgs == 2 || sgs == -2) {
           counters[4] = 1;  // see SOFT_PIVOT_REL
-          if (soft_pivot_pert > 0.0) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rm0[lp[k]], pert), pertd = true;
+          if (d != 0.0 && tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rm0[lp[k]], pert), pertd = true;
         }
       }
       if (!(fabs(d) >= pert)) {
@@ -1336,7 +1346,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
         const int sgs = esign[e0 + lp[k]];
         if (sgs == 2 || sgs == -2) {
           counters[4] = 1;  // see SOFT_PIVOT_REL
-          if (soft_pivot_pert > 0.0) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rdlane(rowmax0, lp[k]), pert), pertd = true;
+          if (d != 0.0 && tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rdlane(rowmax0, lp[k]), pert), pertd = true;
         }
       }
       if (!(fabs(d) >= pert)) {
@@ -2627,7 +2637,7 @@ k_residual(int n, int me, int m, CsrDev Q, CsrDev AT, CsrDev CT, CsrDev A, CsrDe
 // stores 40 - 46 us (tools/clear_probe.hip).
 __global__ void __launch_bounds__(256) k_clear(double *__restrict__ p, long long n, int *__restrict__ words) {
   typedef double d2 __attribute__((ext_vector_type(2)));
-  if (blockIdx.x == 0 && threadIdx.x < 128) words[threadIdx.x] = 0;
+  if (blockIdx.x == 0 && threadIdx.x < 128 && threadIdx.x != TINY_REPLACE_WORD) words[threadIdx.x] = 0;  // (that word is the caller's)
   const long long n2 = n >> 1, per = (n2 + gridDim.x - 1) / gridDim.x;
   const long long b0 = (long long)blockIdx.x * per, b1 = b0 + per < n2 ? b0 + per : n2;
   d2 *q = (d2 *)p;
