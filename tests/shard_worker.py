@@ -84,6 +84,45 @@ def main():
         if case[0] == "c4dense":
             out.append(c4dense_case(case, rank, world, dev))
             continue
+        if case[0] == "fuzzst":  # ["fuzzst", first, count, "LQDOCP"]: cases of tools/fuzz_staged.py, sharded against unsharded
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import fuzz_staged
+            worst, ncmp, codes = 0.0, 0, []
+            for c in range(case[1], case[1] + case[2]):
+                prog, st, tag = fuzz_staged.make_case(c)
+                res = []
+                for sh in (True, False):
+                    if not sh and rank != 0:
+                        res.append(None)
+                        continue
+                    kw = dict(shard=(rank, world, dist.make_exchange(rank, dev))) if sh else {}
+                    M = ipmatrix.IpLQDOCP(device=dev, **kw)
+                    try:
+                        M.init(prog)
+                        M.factor(prog, st[0], st[1])
+                        d = new_d(prog)
+                        r = M.solve(prog, *st, *d)
+                        res.append((0, r, d))
+                    except ipmatrix.KktError as err:
+                        res.append((err.code, None, None))
+                    del M
+                code = torch.tensor([res[0][0]])
+                ref = code.clone()
+                tdist.broadcast(ref, src=0)
+                codes.append(bool(torch.equal(code, ref)))  # every rank ends with the same status
+                if rank == 0:
+                    (cs, rs, ds), (cu, ru, du) = res
+                    if cs == 1:
+                        continue  # E_SIZES: an odd number of states - the sharded plan refuses such stages, by design (staged_plan.cpp)
+                    if cs != cu:
+                        worst = max(worst, 1.0 if (cs == 0) != (cu == 0) and not (cu == 0 and ru is not None and not ru <= 1e-8) else 0.0)
+                        continue
+                    if cs == 0 and ru <= 1e-10:
+                        ncmp += 1
+                        scale = max(1.0, max(np.abs(v).max() for v in du if len(v)))
+                        worst = max(worst, max(float(np.abs(a - b).max()) for a, b in zip(ds, du) if len(b)) / scale)
+            out.append(dict(case=case, rank=rank, worst=worst, compared=ncmp, same_status=all(codes)))
+            continue
         if case[0] == "singular":
             # a duplicated equality row: the zero pivot turns up inside ONE rank's subtree (or in the top);
             # every rank must return the same status - nobody may be left waiting in a collective

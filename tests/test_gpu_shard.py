@@ -135,6 +135,17 @@ def test_memory_sharded_stages_on_every_stage_shape(world):
             assert r["res"] <= 1e-10 and r["same_as_rank0"] and r["ranks"] == world, (case, r)
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_memory_sharded_stages_on_random_multistage_qps(world):
+    """60 cases of tools/fuzz_staged.py (random stages, states, controls, fixed / free x_0, carried final-state rows, path
+    equalities, state bounds, w/z spreads) through the sharded handle and the unsharded one: the same status on every
+    rank, and where both solve, the same solution to 1e-8 (stages with an odd number of states are refused by the sharded
+    plan: E_SIZES on every rank)."""
+    recs = [r[0] for r in _run_workers(world, [["fuzzst", 0, 60, "LQDOCP"]])]
+    assert all(r["same_status"] for r in recs), recs
+    assert recs[0]["worst"] <= 1e-8 and recs[0]["compared"] >= 15, recs[0]
+
+
 @pytest.mark.parametrize("world", [3, 4])
 def test_memory_sharded_dense_hand_over(world):
     """The dense hand-over (hqpkkt_set_values_staged: every rank copies its columns of the caller's blocks) and the
