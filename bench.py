@@ -436,9 +436,11 @@ def mesh_kkt_sizes(local_rank):
     from hqp_amd import ipmatrix, problems
     out = {}
     try:
-        for g in (300, 1000, -1):
-            # (-1: no mesh - 10^5 variables, 21 entries per row of Q, 1000 random far couplings: problems.banded_long_range_qp)
-            prog = problems.grid_sparse_qp(g, g) if g > 0 else problems.banded_long_range_qp(100000, 10, 1000)
+        for g in (300, 1000, -1, -2):
+            # (-1: no mesh - 10^5 variables, 21 entries per row of Q, 1000 random far couplings: problems.banded_long_range_qp;
+            # -2: the 10^6-cell mesh with 1 % = 10 000 couplings between distant cells: configs[4]'s "random sparse" at full size)
+            prog = (problems.grid_sparse_qp(g, g) if g > 0 else problems.banded_long_range_qp(100000, 10, 1000) if g == -1
+                    else problems.grid_sparse_qp(1000, 1000, seed=5, long_range=10000))
             st = [torch.as_tensor(a).cuda() for a in problems.ip_state(prog, 1, 1.0)]
             M = ipmatrix.IpRedSpBKP(device=local_rank, device_vectors=True, ordering=2)
             t0 = time.perf_counter()
@@ -453,7 +455,7 @@ def mesh_kkt_sizes(local_rank):
                 res = M.solve(prog, *st, *d)
                 ts.append(time.perf_counter() - t0)
             s = M.stats()
-            out[f"{g}x{g}" if g > 0 else "band21_far1000_n1e5"] = {"variables": prog.n, "kkt_dim": s["dim"], "ms_per_factor_solve": 1e3 * float(np.median(ts[1:])),
+            out[f"{g}x{g}" if g > 0 else "band21_far1000_n1e5" if g == -1 else "1000x1000_far10000_n1e6"] = {"variables": prog.n, "kkt_dim": s["dim"], "ms_per_factor_solve": 1e3 * float(np.median(ts[1:])),
                                "residual": res, "init_s": init_s, "flops_factor": s["flops_factor"], "tree_levels": s["n_levels"],
                                "max_front": s["max_front"]}
             del M

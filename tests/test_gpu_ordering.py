@@ -210,6 +210,37 @@ def test_random_sparse_system_with_far_couplings_against_the_oracle():
             assert max(np.abs(a - b).max() for a, b in zip(d, osol)) <= 1e-8 * scale
 
 
+def test_full_size_irregular_sqp_loop_and_properties():
+    """BASELINE configs[4] at FULL size on the irregular generator: 10^6 variables (1000 x 1000 cells, five entries per
+    row) with 1 % = 10 000 couplings between distant cells.  (i) The full SQP loop: the reference's unmodified
+    Hqp_SqpPowell over Prg_GridNLP with the device-resident MehrotraHip driving RedSpBKPHip (mat_ordering 2) ends optimal
+    with the KKT conditions of the NLP met (round 4's separators would have needed fronts of 1.4e5 rows and 660 GB here:
+    tools/c5_irregular.py, profiles/r05_c5_irregular.jsonl).  (ii) The KKT system of the QP of the same structure through
+    size-independent properties: residual <= 1e-10, residuum() of the solution equal to what solve() returned, linear
+    in the right-hand side."""
+    if refapi.host_available("hip"):
+        r = refapi.sqp_grid(1000, 1000, "MehrotraHip", "RedSpBKPHip", host="hip", ordering=2, far=10000)
+        assert r["n"] == 1000000 and r["rc"] == 0, r
+        assert r["norm_inf"] < 1e-6 and r["norm_grd_L"] < 1e-5, r
+    prog = problems.grid_sparse_qp(1000, 1000, seed=5, long_range=10000)
+    st = problems.ip_state(prog, 2, 1.0)
+    M = ipmatrix.IpRedSpBKP(ordering=2)
+    M.init(prog)
+    s = M.stats()
+    assert s["max_front"] <= 20000 and s["bytes_panels"] + s["bytes_updates"] < 30e9, s
+    new = lambda: [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    M.factor(prog, st[0], st[1])
+    d1 = new()
+    res = M.solve(prog, *st, *d1)
+    assert res <= 1e-10
+    assert abs(M.residuum(prog, *st, *d1) - res) <= 1e-13
+    st2 = (st[0], st[1]) + tuple(2.0 * v for v in st[2:])
+    d2 = new()
+    assert M.solve(prog, *st2, *d2) <= 1e-10
+    scale = max(np.abs(v).max() for v in d1)
+    assert max(np.abs(b - 2.0 * a).max() for a, b in zip(d1, d2)) <= 1e-9 * scale
+
+
 def test_full_size_mesh_properties():
     """The stand-in for configs[4] at 10^6 variables (1000 x 1000 cells, reduced KKT dimension 1.33e6, ordering 2)
     through size-independent properties: residual <= 1e-10, residuum() of the solution equal to what solve()
