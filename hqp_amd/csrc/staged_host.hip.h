@@ -141,13 +141,15 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
     // tile count that does not fill the chip evenly: whole rounds, then the k ranges of the rest cut (k_dgemm_tn_sk)
     // (the arrival counters are zero between launches: the last arriver of a tile resets its counter)
     stg::SplitPlan sk = stg::gemm_split_plan(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid);
-    sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
-    KLAUNCH(h, cls, stg::gemm_launch_split(d->gemm_variant, d->sk_grid, h->stream, g, sk));
-    return 0;
+    if (stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
+      sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
+      KLAUNCH(h, cls, stg::gemm_launch_split(d->gemm_variant, d->sk_grid, h->stream, g, sk));
+      return 0;
+    }
   }
   if (big)
     KLAUNCH(h, cls, stg::gemm_launch_plain(d ? d->gemm_variant : stg::GEMM_REG4, (unsigned)tiles, h->stream, g, d ? d->cus : 0));
-  else if (d && d->cus > 0 && !g.lower && !g.mirror && g.K >= 1024 && tiles * 2 <= d->cus &&
+  else if (d && d->cus > 0 && !g.lower && !g.mirror && g.K >= 512 && tiles * 2 <= d->cus &&
            (long long)g.M * g.N * 4 <= (allow_sk ? d->sk_ws_elems : d->ks_ws2_elems)) {
     // a thin, deep product: its k range cut over the chip (k_dgemm_tn_ks), the pieces added in their order (the
     // launches of the second stream have a workspace of their own)
@@ -430,8 +432,10 @@ static int staged_upload(hqpkkt_t *h) {
     }
     if (P.sharded)
       for (int k = 0; k < P.K; k++) tmax = std::max<long long>(tmax, P.gtile_ptr[k + 1] - P.gtile_ptr[k]);
-    pmax = pmax * 5 / 4 + 64;  // (plans of smaller products of the same stage: never more pieces than 8 per tile of tmax)
-    pmax = std::max(pmax, 16 * tmax);
+    // (a plan has at most two cut phases of at most one unit per workgroup of the grid each: gemm_split_plan; every launch
+    // checks its pieces against the workspace.  Until round 5 the workspace was sized 16 pieces per tile of the largest
+    // product - 3.4 GB at the headline width, per handle, sharded or not)
+    pmax = std::max(pmax * 5 / 4 + 64, 4LL * cus + 64);
     d.sk_grid = 0, d.sk_tiles = (int)tmax;
     if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
       d.sk_grid = stg::gemm_wgs_per_cu(stg::gemm_variant_from_env()) * cus;

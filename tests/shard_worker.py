@@ -33,17 +33,25 @@ def c4dense_case(case, rank, world, dev):
         shard = dist.RcclShard(rank, world, dev)
     else:
         shard = (rank, world, dist.make_exchange(rank, dev))
+    d = [torch.zeros(k, dtype=torch.float64, device=f"cuda:{dev}") for k in (n, me, m, m)]
+    torch.cuda.synchronize()
+    tdist.barrier()
+    free0 = torch.cuda.mem_get_info(dev)[0]
     M = ipmatrix.IpLQDOCP(device=dev, device_vectors=True, shard=shard)
     M.init_dense(dq)
-    d = [torch.zeros(k, dtype=torch.float64, device=f"cuda:{dev}") for k in (n, me, m, m)]
     for _rep in range(2):
         M.factor(None, z, w)
         res = M.solve(None, z, w, *r, *d)
+    torch.cuda.synchronize()
+    tdist.barrier()
+    # device memory the handles of ALL ranks on this device took (the ranks of the test box share one GPU)
+    hbm_all_ranks = free0 - torch.cuda.mem_get_info(dev)[0]
+    tdist.barrier()
     s = M.stats()
     cuts = M.debug(27).reshape(-1, world + 1)
     rec = dict(case=case, rank=rank, res=res, staged=True, cuts=cuts[0].tolist(), flops_local=s["flops_local"],
                bytes_factor=s["bytes_exchange_factor"], ranks=s["shard_count"], refine_rounds=s["refine_rounds"],
-               bytes_panels=s["bytes_panels"])
+               bytes_panels=s["bytes_panels"], hbm_all_ranks=int(hbm_all_ranks), bytes_updates=s["bytes_updates"])
     del M
     torch.cuda.empty_cache()
     tdist.barrier()  # (the unsharded partner below needs the memory the other ranks have just released)
@@ -54,6 +62,8 @@ def c4dense_case(case, rank, world, dev):
         R.factor(None, z, w)
         rec["res_single"] = R.solve(None, z, w, *r, *d0)
         rec["bytes_panels_single"] = R.stats()["bytes_panels"]
+        torch.cuda.synchronize()
+        rec["hbm_single"] = int(free0 - torch.cuda.mem_get_info(dev)[0])
         rec["diff"] = max(float((a - b).abs().max() / b.abs().max().clamp_min(1e-300)) for a, b in zip(d, d0) if b.numel())
         del R
     t = torch.cat(d).cpu()

@@ -188,6 +188,11 @@ def test_sharded_staged_system_at_full_stage_width():
     # ... and hold about half of the stage blocks (<= 1 / P + 10 %)
     for r in recs:
         assert r["bytes_panels"] <= recs[0]["bytes_panels_single"] * 0.5 * 1.10, (r["bytes_panels"], recs[0]["bytes_panels_single"])
+    # ... as the allocator sees it: the handles of BOTH ranks together (they share the test box's one GPU) take what the
+    # one unsharded handle takes for its stage blocks, plus their work blocks (two whole V, two gathered-F buffers, W, G,
+    # exchange slots each: 1.3 GB per rank at this width, whatever the number of stages)
+    both, single = recs[0]["hbm_all_ranks"], recs[0]["hbm_single"]
+    assert both <= single + 2 * 1.6e9, (both, single)
 
 
 def test_sharded_staged_system_with_an_odd_number_of_states_is_refused():
