@@ -27,6 +27,8 @@ timeout 300 bash tools/ipprof.sh 2000 > $O/r05_ip_did_kstat.txt 2>&1
 # configs[4] stand-ins (mesh 300 x 300, 1000 x 1000, band of 21 with 1000 far couplings at 10^5 variables)
 timeout 300 python tools/mesh_bench.py 2>/dev/null | grep '^{' | tail -1 > $O/r05_mesh_bench.json
 HQPKKT_ND_LEVELS_ONLY=1 timeout 300 python tools/mesh_bench.py 2>/dev/null | grep '^{' | tail -1 > $O/r05_mesh_bench_levels_only.json
+# configs[4] at full size on the irregular generator: the SQP loop at 10^6 variables with 1 % far couplings
+timeout 600 python tools/c5_irregular.py 2>/dev/null | grep '^{' > $O/r05_c5_irregular.jsonl
 # mid-size stages
 for nx in 1000 2000 3000; do timeout 300 python tools/c4_bench.py 200 $nx 50 3 2>/dev/null | grep '^{' | tail -1 >> $O/r05_c4_sizes.jsonl; done
 # N > 1 path: bench.py starting its own two ranks on the one GPU (exchange staged through gloo: functional, not a measurement)
