@@ -869,7 +869,10 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
   for (int id = 0; id < nlog; id++) {
     if (absorbed[id]) continue;
     const std::vector<int> &v = lverts[id];
-    const int len = (int)v.size(), parts = std::max(1, (len + max_pivots - 1) / max_pivots);
+    // (separators in the high hundreds and beyond - the top of an irregular graph's tree - in longer pieces: every piece rewrites the
+    //  whole update block of its front, 8 bytes per entry each way for 2 * pivots flops)
+    const int len = (int)v.size(), mp = (long_chain_pivots > 0 && len >= LONG_CHAIN_VERTS) ? long_chain_pivots : max_pivots;
+    const int parts = std::max(1, (len + mp - 1) / mp);
     const int size = (len + parts - 1) / parts;
     int top = -1;
     for (int s = 0; s < len || (len == 0 && s == 0); s += std::max(size, 1)) {
@@ -1182,12 +1185,24 @@ int Analysis::run(int mode_, int n_, int me_, int m_, const int *Qp, const int *
     }
     S.upd_tile_ptr.assign(nlevels + 1, 0), S.slab_ptr.assign(nlevels + 1, 0);
     S.gslab_ptr.assign(nlevels + 1, 0), S.cblk_ptr.assign(nlevels + 1, 0);
+    S.upd_big_ptr.assign(nlevels, 0);
+    // (HQPKKT_SCHUR_BIG_B: a test hook - 1 sends every front through k_schur_update_big)
+    const int big_b = getenv("HQPKKT_SCHUR_BIG_B") ? atoi(getenv("HQPKKT_SCHUR_BIG_B")) : UPD_BIG_BORDER;
     for (int l = 0; l < nlevels; l++) {
+      // the level's 64-tiles first, then the 128-tiles of its fronts with large borders
+      for (int big = 0; big < 2; big++) {
+        if (big) S.upd_big_ptr[l] = (int)S.upd_tiles.size() / 3;
+        for (int t = S.level_ptr[l] + S.level_fsmall[l]; t < S.level_ptr[l + 1]; t++) {
+          int id = S.level_nodes[t], b = nbor[id];
+          if ((b >= big_b) != (big == 1)) continue;
+          const int edge = big ? 2 * UPD_TILE : UPD_TILE;
+          int nt = (b + edge - 1) / edge;
+          for (int ti = 0; ti < nt; ti++)
+            for (int tj = 0; tj <= ti; tj++) S.upd_tiles.insert(S.upd_tiles.end(), {id, ti, tj});
+        }
+      }
       for (int t = S.level_ptr[l] + S.level_fsmall[l]; t < S.level_ptr[l + 1]; t++) {
         int id = S.level_nodes[t], b = nbor[id];
-        int nt = (b + UPD_TILE - 1) / UPD_TILE;
-        for (int ti = 0; ti < nt; ti++)
-          for (int tj = 0; tj <= ti; tj++) S.upd_tiles.insert(S.upd_tiles.end(), {id, ti, tj});
         int ns = (b + SLAB_ROWS - 1) / SLAB_ROWS;
         for (int sl = 0; sl < ns; sl++) S.slabs.insert(S.slabs.end(), {id, sl});
         for (int sl = 0; sl < std::max(1, (b + 63) / 64); sl++) S.gslabs.insert(S.gslabs.end(), {id, sl});

@@ -54,6 +54,7 @@ struct Analysis {
     std::vector<int> level_sm_p;              // per level: largest npiv of the other small supernodes
     // tiles of the Schur update and slabs of the panel solve, grouped by level
     std::vector<int> upd_tile_ptr, upd_tiles;  // triples (node, ti, tj)
+    std::vector<int> upd_big_ptr;              // per level: where its 128 x 128 tiles start (fronts with borders >= UPD_BIG_BORDER)
     std::vector<int> slab_ptr, slabs;          // pairs (node, slab): 32 border rows
     std::vector<int> gslab_ptr, gslabs;        // pairs (node, slab): 64 border rows (solve)
     std::vector<int> cblk_ptr, cblks;          // pairs (node, block of 16 pivot columns)
@@ -65,6 +66,7 @@ struct Analysis {
   long long upd_pingpong_bytes = 16LL << 30;  // update blocks beyond this: two alternating half-arenas
   bool upd_pingpong = false;
   std::vector<long long> upd_level_off, upd_level_len;  // ping-pong: the range a level's blocks occupy
+  int long_chain_pivots = 0;  // > 0: pivots per supernode in the chains of separators of >= LONG_CHAIN_VERTS vertices
   bool small_fronts = true;  // fused one-wavefront kernels for fronts with few pivots and few border rows
   bool amalgamation = false;  // separators absorb their child separators while they stay small fronts
   int ordering = 0;  // 0: nested dissection of the RCM band, 1: nested dissection of the graph itself (irregular sparsity), 2: the same without the reference's RCM pass
@@ -100,6 +102,8 @@ struct Analysis {
 };
 
 static const int UPD_TILE = 64;   // Schur-update tile edge (rows/cols per workgroup)
+static const int LONG_CHAIN_VERTS = 768;
+static const int UPD_BIG_BORDER = 2048;  // fronts with at least this many border rows: tiles of twice the edge (k_schur_update_big)
 static const int SLAB_ROWS = 32;  // border rows per panel-solve workgroup
 static const int SMALL_PIVOTS = 32;  // supernodes up to this size use k_factor_diag_small
 static const int SMALL_BORDER = 16;  // ... and with at most this many border rows are "small fronts"

@@ -819,10 +819,13 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
         KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, D.slabs.p + 2 * (size_t)S.slab_ptr[l],
                                                     h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
                                                     h->lperm.p, h->linv.p, h->linv_off.p, h->upd.p));
-      const int nt = S.upd_tile_ptr[l + 1] - S.upd_tile_ptr[l];
+      const int nt = S.upd_big_ptr[l] - S.upd_tile_ptr[l], ntb = S.upd_tile_ptr[l + 1] - S.upd_big_ptr[l];
       if (nt > 0)
         KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_tile_ptr[l],
                                           h->panel.p, h->xar.p, h->upd.p));
+      if (ntb > 0)
+        KLAUNCH(h, KC_SCHUR_UPDATE, (k_schur_update_big<2, 2, 4, 4, 2, 2><<<ntb, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_big_ptr[l],
+                                          h->panel.p, h->xar.p, h->upd.p)));
     }
   }
   if (!h->capturing) HIPCHK(hipEventRecord(h->evs1, s));
@@ -1321,7 +1324,11 @@ static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd) {
   // a banded system's tree go through its two launches (C2: 2.27 ms per factor + solve against 2.33 with 192, where
   // the leaf level stays outside).  HQPKKT_MAX_PIVOTS for same-box comparisons; k_factor_diag of rounds 1-3
   // (HQPKKT_OLD_FD) takes 128.
+  // Separators of >= LONG_CHAIN_VERTS vertices (irregular graphs) are cut into pieces of 192 all the same: their fronts go
+  // through the per-level kernels anyway, and the update blocks are rewritten 17 % less often (1e6-cell mesh with far
+  // couplings: 154 ms per factor + solve against 162).
   int maxp = h->opts.max_pivots;
+  h->an.long_chain_pivots = (maxp <= 0 && !getenv("HQPKKT_MAX_PIVOTS")) ? 192 : 0;
   if (maxp <= 0) maxp = getenv("HQPKKT_MAX_PIVOTS") ? std::atoi(getenv("HQPKKT_MAX_PIVOTS")) : 160;
   if (getenv("HQPKKT_OLD_FD")) maxp = std::min(maxp, 128);
   int e = h->an.run(h->opts.mode, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),

@@ -2068,6 +2068,117 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
       }
 }
 
+// The same update on 128x128 tiles for fronts with borders in the thousands (the top of the tree of an
+// irregular graph: the separators of a mesh with far couplings): each wave holds a 64x64 block = 4x4
+// MFMA tiles, so an operand fragment fetched from L2 feeds four products instead of two - this kernel
+// is bound by the operand traffic, not by HBM (the panel of 160 pivots gives 20 flop per byte of U).
+// The operands of the next eight pivots travel while the products of these eight run (two register
+// sets); the children's contributions are gathered after the products, straight into the accumulators.
+// WX x WY wavefronts, each holding TX x TY MFMA tiles (16 x 16): a workgroup tile of 16 WX TX rows x 16 WY TY columns
+// (128 x 128); KT k-steps (of four pivots) per register set; OCC wavefronts per SIMD.  The instance in use is
+// <2, 2, 4, 4, 2, 2>: with eight wavefronts of 64 x 32 at four per SIMD the registers spill inside the loop (114 ms
+// against 104 on the 1e6-cell mesh with far couplings; the products alone run at 66 TFLOP/s, the blocks' traffic -
+// 197 GB there - at 3.9 TB/s, and two workgroups per CU overlap the two by about a third).
+template <int WX, int WY, int TX, int TY, int KT, int OCC>
+__global__ void __launch_bounds__(64 * WX * WY, OCC)
+k_schur_update_big(DevTree T, const int *__restrict__ tiles, const double *__restrict__ panel,
+                   const double *__restrict__ xar, double *__restrict__ upd) {
+  static_assert(WX * TX == 8 && WY * TY == 8, "128 x 128 tiles (Analysis::run lists them)");
+  const int node = tiles[3 * blockIdx.x], ti = tiles[3 * blockIdx.x + 1],
+            tj = tiles[3 * blockIdx.x + 2];
+  const int p = T.npiv[node], b = T.nbor[node];
+  const long long F = p + b;
+  const double *L = panel + T.panel_off[node] + p;  // L21(i,k) = L[k*F + i]
+  const double *X = xar + T.x_off[node];            // X(j,k)   = X[k*b + j]
+  double *U = upd + T.upd_off[node];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int i0 = ti * 128 + (wave / WY) * (16 * TX), j0 = tj * 128 + (wave % WY) * (16 * TY);
+  if (i0 >= b || j0 >= b || i0 + 16 * TX - 1 < j0) return;  // wave-uniform
+  const int lr = lane & 15, lk = lane >> 4;
+  double4_t acc[TX][TY];
+#pragma unroll
+  for (int x = 0; x < TX; x++)
+#pragma unroll
+    for (int y = 0; y < TY; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // rows / columns beyond the border read the last one (never written back) and pivots beyond the last one read
+  // it again (zeroed by a select; whole k-steps beyond it are skipped): no predicated loads in the loop
+  const double *La[TX], *Xb[TY];
+#pragma unroll
+  for (int x = 0; x < TX; x++) La[x] = L + min(i0 + 16 * x + lr, b - 1);
+#pragma unroll
+  for (int y = 0; y < TY; y++) Xb[y] = X + min(j0 + 16 * y + lr, b - 1);
+  double av[2][KT][TX], bv[2][KT][TY];
+  auto load = [&](int set, int k0) {
+#pragma unroll
+    for (int q = 0; q < KT; q++) {
+      const int k = k0 + 4 * q + lk, kc = min(k, p - 1);
+      const long long ka = (long long)kc * F, kb = (long long)kc * b;
+#pragma unroll
+      for (int x = 0; x < TX; x++) {
+        const double v = La[x][ka];
+        av[set][q][x] = k < p ? v : 0.0;
+      }
+#pragma unroll
+      for (int y = 0; y < TY; y++) {
+        const double v = Xb[y][kb];
+        bv[set][q][y] = k < p ? v : 0.0;
+      }
+    }
+  };
+  auto products = [&](int set, int k0) {
+#pragma unroll
+    for (int q = 0; q < KT; q++)
+      if (k0 + 4 * q < p) {  // wave-uniform
+#pragma unroll
+        for (int x = 0; x < TX; x++)
+#pragma unroll
+          for (int y = 0; y < TY; y++) acc[x][y] = mfma_f64(bv[set][q][y], av[set][q][x], acc[x][y]);
+      }
+  };
+  load(0, 0);
+  for (int k0 = 0; k0 < p; k0 += 8 * KT) {
+    load(1, k0 + 4 * KT);
+    products(0, k0);
+    load(0, k0 + 8 * KT);
+    products(1, k0 + 4 * KT);
+  }
+  // acc <- acc - (children's contributions); U = -acc
+  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+    const int c = T.child_idx[cc], bc = T.nbor[c];
+    const int *iv = T.pinv + T.pinv_off[c] + p;  // border part of the parent's front
+    const double *Uc = upd + T.upd_off[c];
+    int ci[TX], cj[TY][4];
+#pragma unroll
+    for (int x = 0; x < TX; x++) ci[x] = (i0 + 16 * x + lr < b) ? iv[i0 + 16 * x + lr] : -1;
+#pragma unroll
+    for (int y = 0; y < TY; y++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) cj[y][rg] = (j0 + 16 * y + lk + 4 * rg < b) ? iv[j0 + 16 * y + lk + 4 * rg] : -1;
+#pragma unroll
+    for (int x = 0; x < TX; x++) {
+      double gv[TY][4];
+#pragma unroll
+      for (int y = 0; y < TY; y++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++)
+          gv[y][rg] = (ci[x] >= 0 && cj[y][rg] >= 0 && ci[x] >= cj[y][rg]) ? Uc[(long long)cj[y][rg] * bc + ci[x]] : 0.0;
+#pragma unroll
+      for (int y = 0; y < TY; y++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) acc[x][y][rg] -= gv[y][rg];
+    }
+  }
+#pragma unroll
+  for (int x = 0; x < TX; x++)
+#pragma unroll
+    for (int y = 0; y < TY; y++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        const int i = i0 + 16 * x + lr, j = j0 + 16 * y + lk + 4 * rg;
+        if (i < b && j < b && i >= j) U[(long long)j * b + i] = -acc[x][y][rg];
+      }
+}
+
 // MFMA layout self-test: C(16x16) = A(16x16) * B(16x16), all row-major
 __global__ void k_mfma_selftest(const double *A, const double *B, double *C) {
   const int lane = threadIdx.x & 63, lr = lane & 15, lk = lane >> 4;

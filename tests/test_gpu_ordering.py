@@ -210,6 +210,33 @@ def test_random_sparse_system_with_far_couplings_against_the_oracle():
             assert max(np.abs(a - b).max() for a, b in zip(d, osol)) <= 1e-8 * scale
 
 
+def test_update_blocks_on_128_tiles_against_the_oracle(monkeypatch):
+    """k_schur_update_big (fronts with >= 2048 border rows: the top of an irregular graph's tree) on EVERY front
+    (HQPKKT_SCHUR_BIG_B=1, the test hook of Analysis::run): banded, double-integrator and irregular systems, borders
+    from a handful to several hundred rows - residuals within 1e-10 of the CPU oracle's, solutions to 1e-8."""
+    monkeypatch.setenv("HQPKKT_SCHUR_BIG_B", "1")
+    cases = [("RedSpBKP", problems.banded_long_range_qp(4000, 5, 40, seed=11, min_dist=500), dict(ordering=2)),
+             ("SpBKP", problems.banded_qp(3000, 30, 7), {}),
+             ("RedSpBKP", problems.banded_qp(2000, 60, 3), dict(max_pivots=48)),
+             ("SpBKP", problems.did_like_qp(300), {}),
+             ("RedSpBKP", problems.grid_sparse_qp(60, 50, seed=2, long_range=40), dict(ordering=1))]
+    for kind, prog, kw in cases:
+        st = problems.ip_state(prog, 3, 1.0)
+        O = oracleapi.OracleIpMatrix(kind)
+        O.init(prog)
+        O.factor(st[0], st[1])
+        osol, ores = O.solve(*st)
+        scale = max(1.0, max(np.abs(v).max() for v in osol))
+        M = CLS[kind](**kw)
+        M.init(prog)
+        M.factor(prog, st[0], st[1])
+        d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+        res = M.solve(prog, *st, *d)
+        assert res <= ores + 1e-10 * scale, (kind, kw, res, ores)
+        assert O.residuum(*st, *d) <= ores + 1e-10 * scale
+        assert max(np.abs(a - b).max() for a, b in zip(d, osol)) <= 1e-8 * scale
+
+
 def test_full_size_irregular_sqp_loop_and_properties():
     """BASELINE configs[4] at FULL size on the irregular generator: 10^6 variables (1000 x 1000 cells, five entries per
     row) with 1 % = 10 000 couplings between distant cells.  (i) The full SQP loop: the reference's unmodified
