@@ -2147,12 +2147,10 @@ struct SymvArgs {
 // (measured on the 5000 x 5000 V of the headline, tools/symv_probe.hip: 22.8 us for the 113 MB of the triangle's tiles
 // against 37.1 us for the rows form over the whole matrix; tiles of 64 x 256, 32 x 512, 96 x 512, 128 x 512 and 2 / 8
 // rows in flight: 22.2 - 32 us; the row sums by DPP, 1 us less than by ds_bpermute)
-__global__ void __launch_bounds__(256) k_st_symv_tiles(SymvArgs g) {
-  __shared__ double red[4][SV_C];
+__device__ __forceinline__ void symv_tile(const SymvArgs &g, const int t, double (*red)[SV_C]) {
   // tile number -> (row tile bi, column tile bj) over the tiles on and below the diagonal: the RT = SV_C / SV_R row tiles
   // RT g .. RT g + RT - 1 have g + 1 column tiles each, RT g (g + 1) / 2 tiles stand before them
   constexpr int RT = SV_C / SV_R;
-  const int t = blockIdx.x;
   int gq = (int)((sqrt(1.0 + 8.0 * t / RT) - 1.0) * 0.5);
   while (RT * gq * (gq + 1) / 2 > t) gq--;
   while (RT * (gq + 1) * (gq + 2) / 2 <= t) gq++;
@@ -2210,6 +2208,10 @@ __global__ void __launch_bounds__(256) k_st_symv_tiles(SymvArgs g) {
   for (int c = threadIdx.x; c < SV_C; c += 256)
     if (c0 + c < g.N) g.colpart[(long long)bi * g.N + c0 + c] = (red[0][c] + red[1][c]) + (red[2][c] + red[3][c]);
 }
+__global__ void __launch_bounds__(256) k_st_symv_tiles(SymvArgs g) {
+  __shared__ double red[4][SV_C];
+  symv_tile(g, blockIdx.x, red);
+}
 struct SymvFinish {
   int N;
   const double *rowpart, *colpart;
@@ -2221,11 +2223,10 @@ struct SymvFinish {
   double *y;
   double scale;
 };
-__global__ void __launch_bounds__(256) k_st_symv_finish(SymvFinish g) {
+__device__ __forceinline__ void symv_finish_blk(const SymvFinish &g, const int blk, double (*red)[64]) {
   // 64 columns per workgroup, four threads per column: thread group q adds every fourth partial of the mirrored part
   // (eight loads in flight), group 0 the row parts and the carried rows' term; fixed order throughout
-  __shared__ double red[4][64];
-  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, j = blockIdx.x * 64 + cl;
+  const int cl = threadIdx.x & 63, q = threadIdx.x >> 6, j = blk * 64 + cl;
   double s = 0.0;
   if (j < g.N) {
     const int bi = j / SV_R, nrt = (g.N + SV_R - 1) / SV_R, ct = (bi * SV_R + SV_R - 1) / SV_C;
@@ -2258,6 +2259,51 @@ __global__ void __launch_bounds__(256) k_st_symv_finish(SymvFinish g) {
   red[q][cl] = s;
   __syncthreads();
   if (q == 0 && j < g.N) g.y[j] = g.scale * ((g.add ? g.add[j] : 0.0) + ((red[0][cl] + red[1][cl]) + (red[2][cl] + red[3][cl])));
+}
+__global__ void __launch_bounds__(256) k_st_symv_finish(SymvFinish g) {
+  __shared__ double red[4][64];
+  symv_finish_blk(g, blockIdx.x, red);
+}
+// The products with V that stand outside the chains of the two sweeps - g_k = V+ f_k with the dynamics' right-hand side
+// (known before the backward sweep starts), the dynamics rows' multipliers V+ x+ + v+ + B+' eta+ (wanted by nobody before
+// the sweep is over) - for MANY stages per launch: item i holds the tiles tile0 .. (next item's tile0) of the launch and
+// the finishing blocks fin0 ..; partial sums of its own.  The vectors of the caller (right-hand side, multipliers) are
+// addressed relative to a base, so that one table serves every set of vectors the solve runs on.
+struct SymvItem {
+  SymvArgs a;
+  SymvFinish f;
+  int tile0, fin0;      // first tile / finishing block inside the launch
+  int xrel, yrel;       // a.x = xbase + xoff / f.y = ybase + yoff
+  long long xoff, yoff;
+};
+__device__ __forceinline__ int symv_item_of(const SymvItem *items, int cnt, int blk, bool fin) {
+  int lo = 0, hi = cnt - 1;  // the last item whose first block is <= blk
+  while (lo < hi) {
+    const int mid = (lo + hi + 1) >> 1;
+    if ((fin ? items[mid].fin0 : items[mid].tile0) <= blk) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+// (a grid smaller than the number of tiles / blocks: every workgroup takes several, in a stride)
+__global__ void __launch_bounds__(256) k_st_symv_tiles_batch(const SymvItem *__restrict__ items, int cnt, int tiles, const double *xbase) {
+  __shared__ double red[4][SV_C];
+  for (int t = blockIdx.x; t < tiles; t += gridDim.x) {
+    const SymvItem &it = items[symv_item_of(items, cnt, t, false)];
+    SymvArgs a = it.a;
+    if (it.xrel) a.x = xbase + it.xoff;
+    symv_tile(a, t - it.tile0, red);
+    __syncthreads();
+  }
+}
+__global__ void __launch_bounds__(256) k_st_symv_finish_batch(const SymvItem *__restrict__ items, int cnt, int fins, double *ybase) {
+  __shared__ double red[4][64];
+  for (int t = blockIdx.x; t < fins; t += gridDim.x) {
+    const SymvItem &it = items[symv_item_of(items, cnt, t, true)];
+    SymvFinish f = it.f;
+    if (it.yrel) f.y = ybase + it.yoff;
+    symv_finish_blk(f, t - it.fin0, red);
+    __syncthreads();
+  }
 }
 // the same for few, long rows (Rm x with a handful of controls and thousands of states): one
 // workgroup per row, so that a row's bytes are in flight from 256 threads
@@ -2305,6 +2351,8 @@ struct GemvCols {
   double *y;
   double *part;  // nchunk x N
   int rows_per_chunk;
+  const double *add2 = nullptr;  // optional second result y2 = y + add2 (the backward sweep: v_k and, with the product
+  double *y2 = nullptr;          // V_k f_{k-1} computed ahead of the sweep, v_k + V_k f_{k-1})
 };
 __global__ void __launch_bounds__(256) k_st_gemv_cols(GemvCols g) {
   // two neighbouring columns per thread (one 16-byte load per row; rows 16-byte aligned when lda is even and the
@@ -2349,15 +2397,22 @@ __global__ void __launch_bounds__(256) k_st_gemv_cols(GemvCols g) {
     }
   }
   if (gridDim.y == 1) {
-    g.y[j] = (g.add ? g.add[j] : 0.0) + g.alpha * s0;
-    if (j + 1 < g.N) g.y[j + 1] = (g.add ? g.add[j + 1] : 0.0) + g.alpha * s1;
+    const double r0 = (g.add ? g.add[j] : 0.0) + g.alpha * s0;
+    g.y[j] = r0;
+    if (g.y2) g.y2[j] = r0 + g.add2[j];
+    if (j + 1 < g.N) {
+      const double r1 = (g.add ? g.add[j + 1] : 0.0) + g.alpha * s1;
+      g.y[j + 1] = r1;
+      if (g.y2) g.y2[j + 1] = r1 + g.add2[j + 1];
+    }
   } else {
     g.part[(long long)blockIdx.y * g.N + j] = s0;
     if (j + 1 < g.N) g.part[(long long)blockIdx.y * g.N + j + 1] = s1;
   }
 }
 __global__ void k_st_cols_finish(int N, int nchunk, const double *__restrict__ part, const double *__restrict__ add,
-                                 double alpha, double *__restrict__ y) {
+                                 double alpha, double *__restrict__ y, const double *__restrict__ add2 = nullptr,
+                                 double *__restrict__ y2 = nullptr) {
   const int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= N) return;
   double s = 0.0;
@@ -2370,7 +2425,9 @@ __global__ void k_st_cols_finish(int N, int nchunk, const double *__restrict__ p
     for (int u = 0; u < 8; u++) s += v[u];
   }
   for (; c < nchunk; c++) s += part[(long long)c * N + j];
-  y[j] = (add ? add[j] : 0.0) + alpha * s;
+  const double r = (add ? add[j] : 0.0) + alpha * s;
+  y[j] = r;
+  if (y2) y2[j] = r + add2[j];
 }
 
 // q = -(r1 - C' tz)   (the reference's gx, gu: hqp/Hqp_IpLQDOCP.C:884-918)
@@ -2652,6 +2709,12 @@ __global__ void k_st_gather(int e, const int *__restrict__ rows, const double *_
 __global__ void k_st_negate(int n, const double *__restrict__ s, double *__restrict__ dx) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dx[i] = -s[i];
+}
+// d = s, d2 = s + a2
+__global__ void k_st_copy_add(int n, const double *__restrict__ s, double *__restrict__ d, const double *__restrict__ a2,
+                              double *__restrict__ d2) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) d[i] = s[i], d2[i] = s[i] + a2[i];
 }
 __global__ void k_st_copy(int n, const double *__restrict__ s, double *__restrict__ d) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;

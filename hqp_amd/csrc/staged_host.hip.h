@@ -34,6 +34,17 @@ struct StagedDev {
   // ev_x[i] "exchange i has arrived" (i = 0, 1: the gathered F in buffer i, 2: the blocks of G_xx)
   hipStream_t stream_x = nullptr;
   hipEvent_t ev_x1 = nullptr, ev_w[3] = {nullptr, nullptr, nullptr}, ev_x[3] = {nullptr, nullptr, nullptr};
+  // The solve's products with V that stand outside its two chains, many stages per launch (k_st_symv_*_batch; not
+  // sharded): [0] g_k = V_{k+1} f_k ahead of the backward sweep, [1] the dynamics rows' multipliers behind the forward
+  // sweep.  A launch holds the stages whose partial sums fit StagedPlan::symb_elems; stages that do not take the
+  // triangle form (st_symv) go through k_st_gemv_rows one by one.
+  struct SymvGroup {
+    int first, count, tiles, fins;
+    int kfirst, klast;  // the stages k (products with V_{k+1}) of the launch
+  };
+  DBuf<stg::SymvItem> symv_items[2];
+  std::vector<SymvGroup> symv_groups[2];
+  std::vector<int> symv_rows_stage[2];
   DBuf<double> zeros;           // 256 zero doubles: the operand rows k >= K of the LDS-DMA staging (GemmArgs::zeros)
   int gemm_variant = stg::GEMM_DMA8;
   int cus = 0;
@@ -180,32 +191,113 @@ int st_gemv_rows(hqpkkt_t *h, stg::GemvRows g) {
 }
 // y = scale (add + V x + A2 x2) with the symmetric V of a stage: from 2048 states on only the tiles on and below the
 // diagonal are read (k_st_symv_tiles + k_st_symv_finish; HQPKKT_NO_SYMV: the rows form throughout)
-int st_symv(hqpkkt_t *h, StagedDev &d, stg::GemvRows g) {
+bool symv_tiles_form(const stg::GemvRows &g) {
   static const bool off = getenv("HQPKKT_NO_SYMV") != nullptr;
   static const int from = getenv("HQPKKT_SYMV_FROM") ? atoi(getenv("HQPKKT_SYMV_FROM")) : 2048;
-  if (off || g.M != g.N || g.N < from || (g.lda & 1) || (((size_t)g.A) & 15)) return st_gemv_rows(h, g);
-  const kktdev::StagedPlan &P = d.plan;
-  const int N = g.N, nct = (N + stg::SV_C - 1) / stg::SV_C, nrt = (N + stg::SV_R - 1) / stg::SV_R;
-  double *rowpart = d.misc.p + P.oSym, *colpart = rowpart + (long long)nct * N;
-  static_assert(stg::SV_R == 64 && stg::SV_C == 512, "StagedPlan::oSym is sized for these tiles");
+  return !(off || g.M != g.N || g.N < from || (g.lda & 1) || (((size_t)g.A) & 15));
+}
+long long symv_tiles(int N) {
+  const int nrt = (N + stg::SV_R - 1) / stg::SV_R;
   long long tiles = 0;
   for (int bi = 0; bi < nrt; bi++) tiles += bi / (stg::SV_C / stg::SV_R) + 1;
+  return tiles;
+}
+int st_symv(hqpkkt_t *h, StagedDev &d, stg::GemvRows g) {
+  if (!symv_tiles_form(g)) return st_gemv_rows(h, g);
+  const kktdev::StagedPlan &P = d.plan;
+  const int N = g.N, nct = (N + stg::SV_C - 1) / stg::SV_C;
+  double *rowpart = d.misc.p + P.oSym, *colpart = rowpart + (long long)nct * N;
+  static_assert(stg::SV_R == 64 && stg::SV_C == 512, "StagedPlan::oSym is sized for these tiles");
+  const long long tiles = symv_tiles(N);
   KLAUNCH(h, KC_ST_VEC, stg::k_st_symv_tiles<<<(unsigned)tiles, 256, 0, h->stream>>>(stg::SymvArgs{g.A, g.lda, N, g.x, rowpart, colpart}));
   KLAUNCH(h, KC_ST_VEC, stg::k_st_symv_finish<<<(N + 63) / 64, 256, 0, h->stream>>>(
                             stg::SymvFinish{N, rowpart, colpart, g.add, g.A2, g.lda2, g.n2, g.x2, g.y, g.scale}));
   return 0;
 }
 // y = add + alpha A'x over a K x N row-major block
+// (add2, y2: a second result y2 = y + add2)
 int st_gemv_cols(hqpkkt_t *h, StagedDev &d, const double *A, long long lda, int K, int N, const double *x,
-                 const double *add, double alpha, double *y) {
+                 const double *add, double alpha, double *y, const double *add2 = nullptr, double *y2 = nullptr) {
   if (N <= 0) return 0;
   const kktdev::StagedPlan &P = d.plan;
   int chunks = std::max(1, std::min(P.part_chunks, K / 64));
-  stg::GemvCols g{A, lda, K, N, x, add, alpha, y, d.misc.p + P.oPart, (K + chunks - 1) / chunks};
+  stg::GemvCols g{A, lda, K, N, x, add, alpha, y, d.misc.p + P.oPart, (K + chunks - 1) / chunks, add2, y2};
   KLAUNCH(h, KC_ST_VEC, stg::k_st_gemv_cols<<<dim3((N + 511) / 512, chunks), 256, 0, h->stream>>>(g));
   if (chunks > 1)
     KLAUNCH(h, KC_ST_VEC, stg::k_st_cols_finish<<<(N + 255) / 256, 256, 0, h->stream>>>(N, chunks, d.misc.p + P.oPart, add,
-                                                                                       alpha, y));
+                                                                                       alpha, y, add2, y2));
+  return 0;
+}
+
+// the two tables of StagedDev::symv_items (at upload time: the arenas' addresses are final)
+int staged_build_symv_tables(StagedDev &d) {
+  const kktdev::StagedPlan &P = d.plan;
+  for (int dir = 0; dir < 2; dir++) d.symv_items[dir].release(), d.symv_groups[dir].clear(), d.symv_rows_stage[dir].clear();
+  if (P.sharded) return 0;
+  double *M = d.misc.p, *S = M + P.oS, *gv = M + P.oGv;
+  auto up16 = [](long long x) { return (x + 15) / 16 * 16; };
+  for (int dir = 0; dir < 2; dir++) {
+    std::vector<stg::SymvItem> items;
+    StagedDev::SymvGroup g{0, 0, 0, 0, 0, 0};
+    long long used = 0;
+    for (int k = 0; k < P.K; k++) {
+      const StagePtr sn = stage_ptr(d, k + 1);
+      const int np = P.nk[k + 1];
+      if (np <= 0) continue;
+      const stg::GemvRows gr{sn.V, P.ldv[k + 1], np, np, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 1.0};
+      if (!symv_tiles_form(gr)) {
+        d.symv_rows_stage[dir].push_back(k);
+        continue;
+      }
+      const long long need = up16(kktdev::StagedPlan::symv_need(np));
+      if (g.count > 0 && used + need > P.symb_elems) {
+        d.symv_groups[dir].push_back(g);
+        g = StagedDev::SymvGroup{(int)items.size(), 0, 0, 0, k, k}, used = 0;
+      }
+      if (g.count == 0) g.kfirst = k;
+      g.klast = k;
+      const int nct = (np + stg::SV_C - 1) / stg::SV_C;
+      double *rowpart = M + P.oSymB + used, *colpart = rowpart + (long long)nct * np;
+      stg::SymvItem it{};
+      it.a = stg::SymvArgs{sn.V, P.ldv[k + 1], np, dir == 0 ? nullptr : S + P.nmk[k + 1], rowpart, colpart};
+      if (dir == 0)
+        it.f = stg::SymvFinish{np, rowpart, colpart, nullptr, nullptr, 0, nullptr, nullptr, gv + P.nks[k], 1.0};
+      else
+        it.f = stg::SymvFinish{np, rowpart, colpart, sn.v, P.cap[k + 1] > 0 ? sn.BT : nullptr, P.ldb[k + 1], sn.dyn + 1, sn.eta, nullptr, 1.0};
+      it.tile0 = g.tiles, it.fin0 = g.fins;
+      it.xrel = dir == 0, it.yrel = dir == 1, it.xoff = it.yoff = P.nks[k];
+      items.push_back(it);
+      g.tiles += (int)symv_tiles(np), g.fins += (np + 63) / 64, g.count++, used += need;
+    }
+    if (g.count > 0) d.symv_groups[dir].push_back(g);
+    if (!items.empty())
+      if (int e = d.symv_items[dir].upload(items)) return e;
+  }
+  return 0;
+}
+// one launch pair of StagedDev::symv_groups[dir] on h->stream.  dir 0: g_k = V_{k+1} f_k (f: the dynamics rows of r2) into
+// the plan's oGv; dir 1: the dynamics rows of dy = V+ x+ + v+ + B+' eta+
+int staged_symv_group(hqpkkt_t *h, StagedDev &d, int dir, int gi, const double *r2, double *dy) {
+  const StagedDev::SymvGroup &g = d.symv_groups[dir][gi];
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_symv_tiles_batch<<<(unsigned)g.tiles, 256, 0, h->stream>>>(d.symv_items[dir].p + g.first, g.count, g.tiles, r2));
+  KLAUNCH(h, KC_ST_VEC, stg::k_st_symv_finish_batch<<<(unsigned)g.fins, 256, 0, h->stream>>>(d.symv_items[dir].p + g.first, g.count, g.fins, dy));
+  return 0;
+}
+// ... and the stages outside the groups (no triangle form: few states), one launch each
+int staged_symv_rows(hqpkkt_t *h, StagedDev &d, int dir, const double *r2, double *dy) {
+  const kktdev::StagedPlan &P = d.plan;
+  double *M = d.misc.p, *S = M + P.oS, *gv = M + P.oGv;
+  for (int k : d.symv_rows_stage[dir]) {
+    const StagePtr sn = stage_ptr(d, k + 1);
+    const int np = P.nk[k + 1];
+    int e;
+    if (dir == 0)
+      e = st_gemv_rows(h, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, r2 + P.nks[k], nullptr, nullptr, 0, nullptr, nullptr, gv + P.nks[k], 1.0});
+    else
+      e = st_gemv_rows(h, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, S + P.nmk[k + 1], sn.v, P.cap[k + 1] > 0 ? sn.BT : nullptr, P.ldb[k + 1],
+                                        sn.dyn + 1, sn.eta, dy + P.nks[k], 1.0});
+    if (e) return e;
+  }
   return 0;
 }
 
@@ -583,6 +675,7 @@ static int staged_upload(hqpkkt_t *h) {
       attr_init_big = d.lds_init;
     }
   }
+  if ((e = staged_build_symv_tables(d))) return e;
   h->uploaded = true;
   return 0;
 }
@@ -1106,25 +1199,39 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
   int e;
   if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
   KLAUNCH(h, KC_VECTOR, stg::k_st_q<<<nblk(n), 256, 0, s>>>(n, h->CT.ptr.p, h->CT.col.p, h->CT.src.p, h->vals.p, h->tz.p, v.r1, qv));
-  {  // last stage
+  // The products with V are not part of the sweeps' chains: V+ f (f: the dynamics' right-hand side) is known before the
+  // backward sweep starts, the dynamics rows' multipliers are wanted by nobody before the forward sweep is over - both
+  // for many stages per launch (staged_symv_group), which leaves the F products and the control-sized kernels in the
+  // chains.
+  double *gv = M + P.oGv;
+  // (on a stream of their own beside the chains - lowest priority, or a few workgroups that take the tiles in a stride -
+  // the launches gained nothing: 35.8 - 37.4 ms per solve against 35.5; what the chains leave idle of HBM they lose again
+  // when they share it)
+  for (int gi = (int)d.symv_groups[0].size() - 1; gi >= 0; gi--)
+    if ((e = staged_symv_group(h, d, 0, gi, v.r2, nullptr))) return e;
+  if ((e = staged_symv_rows(h, d, 0, v.r2, nullptr))) return e;
+  {  // last stage: v_K, and tt = v_K + V_K f_{K-1} for the stage before
     StagePtr sp = stage_ptr(d, K);
     const int nK = P.nk[K], eK = P.eq_ptr[K + 1] - P.eq_ptr[K];
-    KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(nK), 256, 0, s>>>(nK, qv + P.nmk[K], sp.v));
+    if (K > 0)
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_copy_add<<<nblk(nK), 256, 0, s>>>(nK, qv + P.nmk[K], sp.v, gv + P.nks[K - 1], tt));
+    else
+      KLAUNCH(h, KC_ST_VEC, stg::k_st_copy<<<nblk(nK), 256, 0, s>>>(nK, qv + P.nmk[K], sp.v));
     if (eK) KLAUNCH(h, KC_ST_VEC, stg::k_st_gather<<<nblk(eK), 256, 0, s>>>(eK, d.eq_rows.p + P.eq_ptr[K], v.r2, sp.beta));
   }
   for (int k = K - 1; k >= 0; k--) {
     StagePtr sp = stage_ptr(d, k), sn = stage_ptr(d, k + 1);
     const int nn = P.nk[k], mm = P.mk[k], np = P.nk[k + 1], nz = nn + mm;
     const double *f = v.r2 + P.nks[k];
-    // tt = v+ + V+ f ; gam = q_k + F' tt
-    if ((e = st_symv(h, d, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, f, sn.v, nullptr, 0, nullptr, nullptr, tt, 1.0}))) return e;
+    // gam = q_k + F' tt with tt = v+ + V+ f (from the stage behind)
     if ((e = st_gemv_cols(h, d, sp.F, P.ldf[k], np, nz, tt, qv + P.nmk[k], 1.0, gam))) return e;
     stg::BwdSmall ba{nn, mm, np, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], d.eq_rows.p + P.eq_ptr[k], v.r2,
                      P.cap[k + 1] > 0 ? sn.dyn + 1 : nullptr, sn.beta, sn.BT, P.ldb[k + 1], f, gam, sp.Kinv, sp.Kmat, P.ldq[k], sp.T, P.ldt[k],
                      sp.dyn, sp.rho, sp.beta};
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_bwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 3 * P.qmax[k] + 4 + 256), s>>>(ba));
-    // v_k = gam_x - Y' rho
-    if ((e = st_gemv_cols(h, d, sp.Y, P.ldy[k], P.qmax[k], nn, sp.rho, gam, -1.0, sp.v))) return e;
+    // v_k = gam_x - Y' rho (and tt = v_k + V_k f_{k-1} for the next stage of the sweep)
+    if ((e = st_gemv_cols(h, d, sp.Y, P.ldy[k], P.qmax[k], nn, sp.rho, gam, -1.0, sp.v, k > 0 ? gv + P.nks[k - 1] : nullptr, k > 0 ? tt : nullptr)))
+      return e;
   }
   {
     StagePtr s0 = stage_ptr(d, 0);
@@ -1163,13 +1270,13 @@ static int staged_run_step(hqpkkt_t *h, const Vecs &v) {
     stg::FwdSmall fa{nn, mm, P.eq_ptr[k + 1] - P.eq_ptr[k], P.capn[k], P.cap[k], P.qmax[k], uy, sp.T, P.ldt[k],
                      sp.dyn, sp.eta, d.eq_rows.p + P.eq_ptr[k], xk + nn, v.dy, sn.eta, P.cap[k + 1]};
     KLAUNCH(h, KC_ST_SMALL, stg::k_st_fwd_small<<<1, 256, sizeof(double) * (P.capn[k] + 4), s>>>(fa));
-    // x+ = F s + f ; p = V+ x+ + v+ + B+' eta+
+    // x+ = F s + f (the multipliers p = V+ x+ + v+ + B+' eta+ behind the sweep)
     if ((e = st_gemv_rows(h, stg::GemvRows{sp.F, P.ldf[k], np, nz, xk, v.r2 + P.nks[k], nullptr, 0, nullptr, nullptr, S + P.nmk[k + 1], 1.0})))
       return e;
-    if ((e = st_symv(h, d, stg::GemvRows{sn.V, P.ldv[k + 1], np, np, S + P.nmk[k + 1], sn.v, P.cap[k + 1] > 0 ? sn.BT : nullptr,
-                                           P.ldb[k + 1], sn.dyn + 1, sn.eta, v.dy + P.nks[k], 1.0})))
-      return e;
   }
+  for (int gi = 0; gi < (int)d.symv_groups[1].size(); gi++)
+    if ((e = staged_symv_group(h, d, 1, gi, nullptr, v.dy))) return e;
+  if ((e = staged_symv_rows(h, d, 1, nullptr, v.dy))) return e;
   {
     StagePtr sK = stage_ptr(d, K), s0 = stage_ptr(d, 0);
     const int eK = P.eq_ptr[K + 1] - P.eq_ptr[K];

@@ -265,6 +265,14 @@ int StagedPlan::run(int n_, int me_, int m_, const int *Qp, const int *Qi, const
   oPart = mo, mo += up16((long long)part_chunks * (nzmax + 8));
   // partial sums of the symmetric products with V (k_st_symv_tiles: 64-row and 512-column tiles)
   oSym = mo, mo += up16(((long long)(nmax + 63) / 64 + (nmax + 511) / 512) * (nmax + 8));
+  oGv = oSymB = 0, symb_elems = 0;
+  if (!sharded) {
+    long long all = 0;
+    for (int k = 1; k <= K; k++) all += up16(symv_need(nk[k]));
+    symb_elems = std::min(all, std::max(up16(symv_need(nmax)), 16LL << 20));  // (up to 128 MB: 35 stages of 5000 states per launch)
+    oGv = mo, mo += up16(ndyn + 8);
+    oSymB = mo, mo += up16(symb_elems);
+  }
   oS = mo, mo += up16(n + 8);
   oQv = mo, mo += up16(n + 8);
   oScr = mo, mo += up16(scratch_elems);

@@ -43,6 +43,10 @@ struct StagedPlan {
   std::vector<long long> oY, oR, oK, oKm, oN, oBT, oT;  // misc arena (oKm: K itself, next to its inverse oK)
   std::vector<long long> oVec;                        // per stage: v(n) beta(cap) rho(qmax) eta(cap)
   long long oW = 0, oG = 0, oK0 = 0, oK0m = 0, oK0s = 0, oRes = 0, oGam = 0, oTT = 0, oPart = 0, oS = 0, oQv = 0, oTmp = 0, oUy = 0, oSym = 0;
+  // the solve's products with V that stand outside its two chains, many stages per launch (not sharded): g_k = V_{k+1} f_k
+  // for all stages (ndyn doubles) and the partial sums of one launch's stages (symb_elems; symv_need(N) per stage)
+  long long oGv = 0, oSymB = 0, symb_elems = 0;
+  static long long symv_need(long long N) { return ((N + 63) / 64 + (N + 511) / 512) * (N + 8); }
   long long f_elems = 0, v_elems = 0, misc_elems = 0;
   int part_chunks = 1;
   std::vector<int> dyn_off;  // int arena: per stage [r, nl, R(capn), L(capn)]
