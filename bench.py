@@ -356,14 +356,16 @@ _ref_lqdocp_time = _ref_time
 
 def cpu_baseline_c4(K, nx, nu):
     """The reference's own plugins (oracle/_ref, built from the reference's sources) timed on this box's host cores on a
-    BOUNDED sample of the workload, as SURVEY.md 8(d) C4 prescribes: the same QP family at K stages with nx = 50, 100,
-    200 and 400 states for the multistage plugin Hqp_IpLQDOCP (the full nx = 5000 needs ~10^14 flops of Meschach's
-    triple-loop m_mlt: about half a day on one core) and nx = 50, 100 for Hqp_IpSpBKP, the plugin north_star names as
-    the comparator (its band grows with nx: 13.7 s per factorisation at nx = 200 already).  Extrapolated to nx two ways:
-    with the exponent fitted over the samples (least squares in log-log; it still grows towards 3 over them, so this
-    flatters the CPU) and with nx^3 from the largest sample.  `value` uses the fitted exponent of Hqp_IpLQDOCP - the
-    faster plugin and the smaller extrapolation, i.e. the most favourable reading for the CPU.  One core (the path is
-    single-threaded) plus the aggregate of 8 instances on 8 cores."""
+    BOUNDED sample of the workload, as SURVEY.md 8(d) C4 prescribes.  The recursion's cost is linear in the number of
+    stages (measured: K = 2 -> 4 at nx = 1000 takes 1.94 x), so the sample is a SLICE of the workload at the widest stages
+    the budget allows - K = 2 stages of the same QP family at nx = 1000 and nx = 2000 (about 3 s and 20 s on one core;
+    the full nx = 5000 needs ~10^14 flops of Meschach's triple-loop m_mlt: hours) - and `value` is
+    1 / (K x the per-stage time at nx = 2000 x 2.5^e) with the exponent e of those two samples: an extrapolation over
+    2.5 x in nx (until round 5 the samples were K = 200 at nx <= 400 - 12.5 x - and their exponent 2.28 flattered the CPU:
+    a slice at the FULL width, K = 2 at nx = 5000, measured once in the build container, is in profiles/r05_ref_full_width.jsonl).
+    The small-size table (K stages at nx = 50, 100, 200) is kept for the size sweep of `staged_small_sizes`; Hqp_IpSpBKP,
+    the plugin north_star names as the comparator (its band grows with nx: 13.7 s per factorisation at nx = 200 already),
+    at nx = 50, 100.  One core (the path is single-threaded) plus the aggregate of 8 instances on 8 cores."""
     try:
         from oracle import refapi
         have_ref = refapi.available()
@@ -393,16 +395,25 @@ def cpu_baseline_c4(K, nx, nu):
                 "extrapolated_fit_s": float(times[-1] * (nx / sizes[-1]) ** expo),
                 "extrapolated_cubic_s": float(times[-1] * (nx / sizes[-1]) ** 3)}
 
-    sizes_l, reps_l = (50, 100, 200, 400), (5, 5, 3, 2)
+    sizes_l, reps_l = (50, 100, 200), (5, 5, 3)
     tl = [_ref_time((K, s_, nu, r_))[0] for s_, r_ in zip(sizes_l, reps_l)]
     lq = fit(sizes_l, tl)
-    out = {"value": 1.0 / lq["extrapolated_fit_s"], "unit": "KKT factor+solve/s", "cores": 1, "kind": "reference", "host_cores": cores,
-           "sample": f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve, median after one init, same QP family at K={K}, nu={nu}: "
-                     + ", ".join(f"nx={s_} {t_:.3f} s" for s_, t_ in zip(sizes_l, tl))
-                     + f"; EXTRAPOLATED to nx={nx}: fitted exponent {lq['exponent_fit']:.2f} -> {lq['extrapolated_fit_s']:.0f} s (used for `value`), "
-                       f"nx^3 from nx=400 -> {lq['extrapolated_cubic_s']:.0f} s per factor+solve",
+    # the slice at wide stages: K = 2 (per-stage time = half), nx = 1000 and 2000
+    ks, wide = 2, (1000, 2000)
+    tw = [_ref_time((ks, s_, nu, 1))[0] / ks for s_ in wide]
+    expo = float(np.log(tw[1] / tw[0]) / np.log(wide[1] / wide[0]))
+    per_stage = float(tw[1] * (nx / wide[1]) ** expo) if nx > wide[1] else float(np.interp(nx, wide, tw))
+    per_stage_cubic = float(tw[1] * (nx / wide[1]) ** 3) if nx > wide[1] else per_stage
+    full_s, full_cubic_s = K * per_stage, K * per_stage_cubic
+    lq.update({"slice_stages": ks, "slice_nx": list(wide), "slice_seconds_per_stage": tw, "slice_exponent": expo,
+               "extrapolated_fit_s": full_s, "extrapolated_cubic_s": full_cubic_s})
+    out = {"value": 1.0 / full_s, "unit": "KKT factor+solve/s", "cores": 1, "kind": "reference", "host_cores": cores,
+           "sample": f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve on a SLICE of the workload: K={ks} stages of the same QP family (nu={nu}) at "
+                     + ", ".join(f"nx={s_}: {t_:.2f} s per stage" for s_, t_ in zip(wide, tw))
+                     + f"; the cost is linear in the stages; EXTRAPOLATED over {nx / wide[1]:.1f}x in nx to nx={nx} with the samples' exponent "
+                       f"{expo:.2f}: {per_stage:.0f} s per stage x K={K} = {full_s:.0f} s per factor+solve (used for `value`); with nx^3: {full_cubic_s:.0f} s",
            "lqdocp": lq, "measured": {"nx100_s": tl[1], "nx200_s": tl[2], "exponent": lq["exponent_fit"]},
-           "extrapolated_s": lq["extrapolated_fit_s"]}
+           "extrapolated_s": full_s}
     try:  # Hqp_IpSpBKP, the comparator north_star names (full KKT system, RCM band of ~3 nx)
         sizes_s = (50, 100)
         ts_ = [_ref_time((K, s_, nu, 2, "SpBKP"))[0] for s_ in sizes_s]
@@ -790,8 +801,8 @@ def bench_c4(args):
         cb = out["cpu_baseline"]
         if "lqdocp" in cb:  # the same ratio under the other readings of the extrapolation (all of them extrapolations)
             out["speedup_vs_cpu_baseline_readings"] = {
-                "Hqp_IpLQDOCP, fitted exponent": out["value"] * cb["lqdocp"]["extrapolated_fit_s"],
-                "Hqp_IpLQDOCP, nx^3 from nx=400": out["value"] * cb["lqdocp"]["extrapolated_cubic_s"],
+                "Hqp_IpLQDOCP, exponent of the wide samples": out["value"] * cb["lqdocp"]["extrapolated_fit_s"],
+                "Hqp_IpLQDOCP, nx^3 from nx=2000": out["value"] * cb["lqdocp"]["extrapolated_cubic_s"],
                 "Hqp_IpSpBKP, nx^3 from nx=100": out["value"] * cb["spbkp"]["extrapolated_cubic_s"] if "extrapolated_cubic_s" in cb.get("spbkp", {}) else None}
         del mat
         torch.cuda.empty_cache()
