@@ -310,27 +310,9 @@ def c4_kkt_norms(F, K, nx, nu, c, b, d, x, y, z, w):
 
 def c4_program(K, nx, nu, seed=0):
     """The same QP family in CSR form (Hqp_Docp's layout) for the CPU reference: what
-    Hqp_IpLQDOCP::init / factor / step are timed on."""
+    Hqp_IpLQDOCP::init / factor / step are timed on (hqp_amd.problems.c4_docp_csr)."""
     from hqp_amd import problems
-    rng = np.random.default_rng(seed)
-    nz = nx + nu
-    n = K * nz + nx
-    ar, ac, av = [], [], []
-    rows = np.arange(nx)
-    for k in range(K):
-        blk = rng.uniform(-1.0, 1.0, (nx, nz))
-        blk[:, :nx] *= 0.9 / np.sqrt(nx / 3.0)
-        ar.append(np.repeat(k * nx + rows, nz)), ac.append(np.tile(k * nz + np.arange(nz), nx)), av.append(blk.ravel())
-        ar.append(k * nx + rows), ac.append((k + 1) * nz + rows), av.append(np.full(nx, -1.0))
-    ar.append(K * nx + rows), ac.append(rows), av.append(np.ones(nx))
-    A = problems._csr(np.concatenate(ar), np.concatenate(ac), np.concatenate(av), K * nx + nx)
-    qd = np.ones(n)
-    qd[:K * nz].reshape(K, nz)[:, nx:] = 0.1
-    Q = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), qd)
-    ucols = (np.arange(K)[:, None] * nz + nx + np.arange(nu)[None, :]).ravel()
-    cols = np.concatenate([ucols, ucols]).astype(np.int32)
-    C = (np.arange(cols.size + 1, dtype=np.int32), cols, np.concatenate([np.ones(ucols.size), -np.ones(ucols.size)]))
-    return problems.Program(n, K * nx + nx, cols.size, Q, A, C)
+    return problems.c4_docp_csr(K, nx, nu, seed)
 
 
 def _ref_time(args):

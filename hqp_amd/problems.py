@@ -343,3 +343,28 @@ def ip_state(prog, seed=1, spread=0.0):
         w = 0.1 + rng.uniform(0, 1, m)
     r = [rng.uniform(-0.5, 0.5, k) for k in (n, me, m, m)]
     return z, w, r[0], r[1], r[2], r[3]
+
+
+def c4_docp_csr(K, nx, nu, seed=0):
+    """The QP family of the headline workload (BASELINE configs[3]: multistage LQ optimal control, K stages of nx states and
+    nu controls, dense dynamics, x_0 fixed, box bounds on u) in CSR form (Hqp_Docp's layout): what the CPU reference's
+    Hqp_IpLQDOCP is timed on (bench.py) and checked against at wide stages (tests/golden_lqdocp_wide)."""
+    rng = np.random.default_rng(seed)
+    nz = nx + nu
+    n = K * nz + nx
+    ar, ac, av = [], [], []
+    rows = np.arange(nx)
+    for k in range(K):
+        blk = rng.uniform(-1.0, 1.0, (nx, nz))
+        blk[:, :nx] *= 0.9 / np.sqrt(nx / 3.0)
+        ar.append(np.repeat(k * nx + rows, nz)), ac.append(np.tile(k * nz + np.arange(nz), nx)), av.append(blk.ravel())
+        ar.append(k * nx + rows), ac.append((k + 1) * nz + rows), av.append(np.full(nx, -1.0))
+    ar.append(K * nx + rows), ac.append(rows), av.append(np.ones(nx))
+    A = _csr(np.concatenate(ar), np.concatenate(ac), np.concatenate(av), K * nx + nx)
+    qd = np.ones(n)
+    qd[:K * nz].reshape(K, nz)[:, nx:] = 0.1
+    Q = (np.arange(n + 1, dtype=np.int32), np.arange(n, dtype=np.int32), qd)
+    ucols = (np.arange(K)[:, None] * nz + nx + np.arange(nu)[None, :]).ravel()
+    cols = np.concatenate([ucols, ucols]).astype(np.int32)
+    C = (np.arange(cols.size + 1, dtype=np.int32), cols, np.concatenate([np.ones(ucols.size), -np.ones(ucols.size)]))
+    return Program(n, K * nx + nx, cols.size, Q, A, C)

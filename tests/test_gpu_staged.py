@@ -600,3 +600,37 @@ def test_against_the_reference_lqdocp_golden(name):
     assert rel_err(d, gold) <= 1e-8, rel_err(d, gold)
     gstep = [g[f"LQDOCP_step_{k}"] for k in ("dx", "dy", "dz", "dw")]
     assert abs(M.residuum(prog, *st, *gstep) - float(g["LQDOCP_res_of_step"])) <= 1e-12 * scale + 1e-13
+
+
+WIDE_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_lqdocp_wide")
+WIDE = sorted(os.path.splitext(os.path.basename(f))[0] for f in __import__("glob").glob(os.path.join(WIDE_DIR, "*.npz")))
+
+
+@pytest.mark.parametrize("name", WIDE)
+def test_wide_stages_against_the_reference_lqdocp_golden(name):
+    """Slices of the headline workload at WIDE stages against the REFERENCE's own Hqp_IpLQDOCP (committed results,
+    tests/golden_lqdocp_wide/make_golden.py; inputs regenerated from the seeds, guarded by a checksum): K = 2 stages of
+    1000 states and K = 3 stages of 2100 states (the triangle form of the solve's products with V, MFMA tiles with ragged
+    edges, split products), 50 controls, w / z spread over two decades in the second - the STAGED engine through the C
+    ABI: residual of solve() <= the reference's + 1e-10, solution to 1e-8, residuum() of the reference's own step result
+    to 1e-12.  (The reference takes 3 s / 35 s per factor + solve there, minutes per stage at 5000 states: the full-size
+    workload is checked by properties, test_full_size_c4_properties.)"""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_wide", os.path.join(WIDE_DIR, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = dict(np.load(os.path.join(WIDE_DIR, name + ".npz")))
+    case = tuple(g["case"])
+    prog, st = mg.inputs((int(case[0]), int(case[1]), int(case[2]), int(case[3]), int(case[4]), float(case[5])))
+    np.testing.assert_allclose(mg.checksum(prog, st), g["checksum"], rtol=1e-13)
+    M = ipmatrix.IpLQDOCP()
+    M.init(prog)
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    gold = [g[f"LQDOCP_solve_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    scale = max(1.0, max(np.abs(v).max() for v in gold if len(v)))
+    assert res <= float(g["LQDOCP_res"]) + 1e-10 * scale, (res, float(g["LQDOCP_res"]))
+    assert rel_err(d, gold) <= 1e-8, rel_err(d, gold)
+    gstep = [g[f"LQDOCP_step_{k}"] for k in ("dx", "dy", "dz", "dw")]
+    assert abs(M.residuum(prog, *st, *gstep) - float(g["LQDOCP_res_of_step"])) <= 1e-12 * scale + 1e-13
