@@ -2683,7 +2683,8 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
   const int skg = stg::gemm_wgs_per_cu(variant) * cus;
   // (HQPKKT_DGEMM_FORCE_SPLIT: the cut form whatever the launch rules say - same-box comparisons of the two forms)
-  const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && (stg::gemm_use_split(M, N, K, lower, skg) || getenv("HQPKKT_DGEMM_FORCE_SPLIT"));
+  const bool frac = !getenv("HQPKKT_NO_STREAMK") && !getenv("HQPKKT_NO_FRAC") && !getenv("HQPKKT_DGEMM_FORCE_SPLIT") && stg::gemm_use_frac(M, N, K, lower, skg);
+  const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && (frac || stg::gemm_use_split(M, N, K, lower, skg) || getenv("HQPKKT_DGEMM_FORCE_SPLIT"));
   const bool big = use_sk || stg::gemm_big_tiles(M, N, lower, K);
   const int b = big ? 128 : 64;
   const long long tiles = stg::gemm_tiles(M, N, b, lower);
@@ -2692,7 +2693,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   double *skws = nullptr;
   unsigned *skcnt = nullptr;
   if (use_sk) {
-    if (hipMalloc((void **)&skws, sizeof(double) * (size_t)(16 * tiles + 8) * 128 * 128) != hipSuccess ||
+    if (hipMalloc((void **)&skws, sizeof(double) * (size_t)std::max<long long>(16 * tiles + 8, 2LL * skg + 2) * 128 * 128) != hipSuccess ||
         hipMalloc((void **)&skcnt, sizeof(unsigned) * (tiles + 4)) != hipSuccess) {
       (void)hipFree(skws), (void)hipFree(skcnt);
       return fin(HQPKKT_E_MEM);
@@ -2704,7 +2705,8 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
     if (r == 0) (void)hipEventRecord(e0, 0);
     if (use_sk) {
       (void)hipMemsetAsync(skcnt, 0, sizeof(unsigned) * (tiles + 4), 0);
-      stg::SplitPlan skk = stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
+      stg::SplitPlan skk = frac ? stg::gemm_split_plan_frac(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)
+                                : stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
       skk.ws = skws, skk.cnt = skcnt;
       stg::gemm_launch_split(variant, skg, 0, g, skk);
     } else if (big)

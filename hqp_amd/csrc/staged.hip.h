@@ -605,6 +605,13 @@ struct SplitPlan {
   int whole;      // the first `whole` tiles are computed whole
   int nphase;
   int begin[3], count[3], split[3];
+  // The fractional form (gemm_split_plan_frac): the tiles' k-slabs in one sequence (tile t holds the units t nslab ...),
+  // cut into `per` units per workgroup - workgroup w takes [w per, (w + 1) per): the end of one tile, whole tiles, the
+  // start of another.  A tile that several workgroups share is summed by its last arriver in the order of the
+  // workgroups; a workgroup parks at most two partial tiles (slots 2 w: the tile its range starts in, 2 w + 1: the
+  // tile it ends in).  For products of a few hundred tiles (stages of 1000 - 3000 states, the strips of a system
+  // over several ranks), where whole rounds and cut remainders leave a large part of the chip idle.
+  int frac, per, ntiles;
 };
 
 // Host: the plan for `tiles` tiles of `nslab` k-slabs on `grid` workgroups.  The remainder R of the whole
@@ -631,6 +638,12 @@ static inline SplitPlan gemm_split_plan(long long tiles, long long nslab, int gr
   }
   return sp;
 }
+static inline SplitPlan gemm_split_plan_frac(long long tiles, long long nslab, int grid) {
+  SplitPlan sp{};
+  sp.frac = 1, sp.ntiles = (int)tiles;
+  sp.per = (int)((tiles * nslab + grid - 1) / grid);
+  return sp;
+}
 static inline long long gemm_split_plan_pieces(const SplitPlan &sp) {
   long long n = 0;
   for (int q = 0; q < sp.nphase; q++) n += (long long)sp.count[q] * sp.split[q];
@@ -654,6 +667,16 @@ static inline bool gemm_use_split(int M, int N, int K, int lower, int grid) {
   // (few tiles - a stage of ~1000 states: 72 - run on 64 x 64 tiles; cut pieces for them were measured slower)
   return false;
 }
+// The fractional form pays for a few hundred tiles - between 5/16 and 5/8 of the grid, where neither whole rounds nor
+// the 64 x 64 tiles fill the chip (measured, one MI355X, tools/dgemm_shapes.py: W of a stage of 2000 states, 272 tiles:
+// 367 us against 413; G of 3000 states, 300 lower tiles: 532 against 609; a 640-column strip of the headline's W, 200
+// tiles: 611 against 652).  Its workgroups are at different k at any moment, so they share less of the operands in L2
+// than the rounds of the plan above: with more tiles (the headline's 1600: 4.13 against 3.90 ms) the plan stays.
+static inline bool gemm_use_frac(int M, int N, int K, int lower, int grid) {
+  if (grid <= 0) return false;
+  const long long tiles = gemm_tiles(M, N, 128, lower), nslab = (K + GEMM_BK - 1) / GEMM_BK;
+  return nslab >= 64 && tiles * 16 >= grid * 5LL && tiles * 8 <= grid * 5LL;
+}
 template <bool DMA, int WGM = 2, int WGN = 2, int NBUF = 2, int BM = 128, int BN = 128>
 __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WGM * WGN / 2) k_dgemm_tn_sk(GemmArgs g, SplitPlan sk) {
   using T = GemmTile<BM, BN, WGM, WGN>;
@@ -670,6 +693,70 @@ __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WG
   // neighbours in the XCD work on the neighbouring tiles at the same k.  (A queue of units was measured in round 3
   // and does not pay: profiles/NOTES.md.)  The result does not depend on who computes what: a tile's pieces are fixed
   // k ranges, summed in their order.
+  if (sk.frac) {
+    const int U = sk.ntiles * nslab, per = sk.per;
+    const int lo = min(U, v * per), hi = min(U, lo + per), t_first = lo / nslab;
+    for (int x = lo; x < hi;) {
+      const int t = x / nslab, s0 = x - t * nslab, s1 = min(nslab, s0 + (hi - x));
+      const int w_first = (t * nslab) / per, w_last = ((t + 1) * nslab - 1) / per, pieces = w_last - w_first + 1;
+      int tm, tn;
+      T::tile_of(g, t, tm, tn);
+      double4_t acc[T::TM][T::TN];
+#pragma unroll
+      for (int xx = 0; xx < T::TM; xx++)
+#pragma unroll
+        for (int y = 0; y < T::TN; y++) acc[xx][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      if constexpr (DMA)
+        T::accumulate_dma(g, tm * BM, tn * BN, s0, s1, acc, As, Bs, g.lower && tm == tn, NBUF);
+      else
+        T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
+      bool finish = true;
+      if (pieces > 1) {
+        double *mine = sk.ws + (long long)(2 * v + (t == t_first ? 0 : 1)) * SLOT;
+#pragma unroll
+        for (int xx = 0; xx < T::TM; xx++)
+#pragma unroll
+          for (int y = 0; y < T::TN; y++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) mine[((xx * T::TN + y) * 4 + rg) * T::NT + threadIdx.x] = acc[xx][y][rg];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          *s_old = __hip_atomic_fetch_add(sk.cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        finish = *s_old == (unsigned)(pieces - 1);
+        if (finish) {
+          if (threadIdx.x == 0) {
+            sk.cnt[t] = 0;  // (ready for the next launch)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+#pragma unroll
+          for (int xx = 0; xx < T::TM; xx++)
+#pragma unroll
+            for (int y = 0; y < T::TN; y++) acc[xx][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+          for (int w = w_first; w <= w_last; w++) {  // in the order of the k ranges, whoever arrived last
+            const double *theirs = sk.ws + (long long)(2 * w + (t == (w * per) / nslab ? 0 : 1)) * SLOT;
+#pragma unroll
+            for (int xx = 0; xx < T::TM; xx++)
+#pragma unroll
+              for (int y = 0; y < T::TN; y++)
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) acc[xx][y][rg] += theirs[((xx * T::TN + y) * 4 + rg) * T::NT + threadIdx.x];
+          }
+        }
+        __syncthreads();  // s_old is rewritten at the next shared tile
+      }
+      if (finish) T::epilogue(g, tm, tn, acc, lds);  // (uniform: the whole workgroup)
+      __syncthreads();
+      x += s1 - s0;
+    }
+    return;
+  }
   const int n_whole = sk.whole;
   int n_units = n_whole;
   for (int q = 0; q < sk.nphase; q++) n_units += sk.count[q] * sk.split[q];

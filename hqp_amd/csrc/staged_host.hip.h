@@ -140,7 +140,10 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   // column (the control columns F + nn of a stage with an odd number of states) is staged through registers
   const bool al16 = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
   // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
-  const bool split = d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid);
+  static const bool no_frac = getenv("HQPKKT_NO_FRAC") != nullptr;  // (same-box comparisons)
+  const bool frac = d && allow_sk && d->sk_grid > 0 && !no_frac && stg::gemm_use_frac(g.M, g.N, g.K, g.lower, d->sk_grid) &&
+                    2LL * d->sk_grid * 128 * 128 <= d->sk_ws_elems;
+  const bool split = frac || (d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid));
   const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower, g.K);
   const int b = big ? 128 : 64;
   const long long tm = (g.M + b - 1) / b;
@@ -151,8 +154,10 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   if (split && tiles <= d->sk_tiles) {
     // tile count that does not fill the chip evenly: whole rounds, then the k ranges of the rest cut (k_dgemm_tn_sk)
     // (the arrival counters are zero between launches: the last arriver of a tile resets its counter)
-    stg::SplitPlan sk = stg::gemm_split_plan(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid);
-    if (stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
+    // (a few hundred tiles: the k-slabs of all tiles in one sequence, an equal share per workgroup - gemm_use_frac)
+    stg::SplitPlan sk = frac ? stg::gemm_split_plan_frac(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid)
+                             : stg::gemm_split_plan(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid);
+    if (frac || stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
       sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
       KLAUNCH(h, cls, stg::gemm_launch_split(d->gemm_variant, d->sk_grid, h->stream, g, sk));
       return 0;
