@@ -141,7 +141,10 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   const bool al16 = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
   // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
   static const bool no_frac = getenv("HQPKKT_NO_FRAC") != nullptr;  // (same-box comparisons)
-  const bool frac = d && allow_sk && d->sk_grid > 0 && !no_frac && stg::gemm_use_frac(g.M, g.N, g.K, g.lower, d->sk_grid) &&
+  // (not for one system over several ranks: there the strip product W_p = V+ F_p - 200 tiles at eight ranks - runs beside
+  // the second stream's control-sized products, and a launch whose 512 workgroups hold every CU for its whole duration
+  // starves them: 1.46 against 1.32 ms per stage, tools/shard_pieces.py 8 0)
+  const bool frac = d && allow_sk && d->sk_grid > 0 && !no_frac && !d->plan.sharded && stg::gemm_use_frac(g.M, g.N, g.K, g.lower, d->sk_grid) &&
                     2LL * d->sk_grid * 128 * 128 <= d->sk_ws_elems;
   const bool split = frac || (d && allow_sk && d->sk_grid > 0 && stg::gemm_use_split(g.M, g.N, g.K, g.lower, d->sk_grid));
   const bool big = split || stg::gemm_big_tiles(g.M, g.N, g.lower, g.K);
