@@ -172,3 +172,28 @@ def test_dissection_of_a_band_with_far_couplings():
     s = M.stats()
     assert s["dim"] == 150000
     assert s["max_front"] <= 4000 and s["flops_factor"] < 5e10, s
+
+
+def test_large_separators_are_cut_into_longer_pieces():
+    """Host-only: a separator of >= 768 vertices (the top of an irregular graph's tree: a 200 x 200 mesh with 1500 far
+    couplings) is cut into pieces of up to 192 pivots when the caller leaves max_pivots at its default - every piece
+    rewrites the whole update block of its front - and into pieces of <= 160 when the caller asks for 160; the tree stays
+    a valid postorder either way.  (On the GPU: tests/test_gpu_ordering.py, the 10^6-cell system and
+    test_update_blocks_on_128_tiles_against_the_oracle.)"""
+    from hqp_amd import ipmatrix, problems
+    prog = problems.grid_sparse_qp(200, 200, seed=5, long_range=1500)
+    got = {}
+    for name, kw in (("default", {}), ("160", dict(max_pivots=160))):
+        M = ipmatrix.IpRedSpBKP(ordering=2, **kw)
+        try:
+            M.init(prog)
+        except ipmatrix.KktError as e:  # no device here: the analysis has run, the upload of the values fails
+            assert e.code == 100
+        s = M.structure()
+        par, npiv = s["parent"], s["npiv"]
+        assert int(npiv.sum()) == M.stats()["dim"] and all(par[k] > k or par[k] < 0 for k in range(len(par)))
+        got[name] = npiv
+    assert 160 < int(got["default"].max()) <= 192
+    assert int(got["160"].max()) <= 160
+    # only the long separators change: the supernodes of <= 160 pivots are the same multiset apart from the re-cut chains
+    assert abs(len(got["default"]) - len(got["160"])) <= int((got["default"] > 160).sum()) + 4
