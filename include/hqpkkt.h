@@ -68,7 +68,8 @@ typedef struct hqpkkt_opts {
   double eps;        /* mat_eps (hqp/Hqp_IpMatrix.C:45-47): refinement target */
   double pivot_eps;  /* static pivot perturbation, relative to max|K_ij|      */
   int leaf_size;     /* nested-dissection leaf size in rows (0 = default)     */
-  int max_pivots;    /* max pivots per supernode, <= 192 (0 = default: 160)     */
+  int max_pivots;    /* max pivots per supernode, <= 192 (0 = default: 160, and 192 in
+                        the chains of separators of >= 768 vertices)            */
   int zd_policy;     /* placement of variables with a structurally zero diagonal
                         (equality multipliers): 2 = behind all their neighbours - the
                         pivot is the complete Schur complement A H^-1 A', all pivots 1x1
