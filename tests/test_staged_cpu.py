@@ -172,3 +172,48 @@ def test_column_cuts_of_a_sharded_system(world):
     wd = np.diff(c)
     assert np.all(wd[:-1] == wd[0]) and 0 < wd[-1] <= wd[0]
     assert max(flops) / (sum(flops) / world) < 1.10, flops  # (the last strip is the narrow one: 40 tiles over 3 ranks = 14 + 14 + 12)
+
+
+def test_fractional_cut_partition_properties():
+    """The index arithmetic of the fractional cut (k_dgemm_tn_sk with SplitPlan::frac, hqp_amd/csrc/staged.hip.h) restated in
+    Python: the k-slabs of all tiles as one sequence, `per` units per workgroup.  Every unit is computed exactly once; a
+    tile's sharers are consecutive workgroups w_first .. w_last and their k ranges follow each other in that order (the
+    order in which the last arriver adds the parked pieces); a workgroup parks at most two partial tiles and no two
+    pieces share a slot (2 w: the tile its range starts in, 2 w + 1: the tile it ends in)."""
+    for tiles, nslab, grid in ((272, 125, 512), (300, 188, 512), (200, 313, 512), (160, 64, 512), (320, 400, 512), (7, 64, 512), (45, 63, 512)):
+        U = tiles * nslab
+        per = (U + grid - 1) // grid
+        covered = np.zeros(U, dtype=np.int32)
+        slots = {}
+        for w in range(grid):
+            lo = min(U, w * per)
+            hi = min(U, lo + per)
+            t_first = lo // nslab
+            x, parked = lo, 0
+            while x < hi:
+                t = x // nslab
+                s0 = x - t * nslab
+                s1 = min(nslab, s0 + (hi - x))
+                covered[t * nslab + s0:t * nslab + s1] += 1
+                w_first, w_last = (t * nslab) // per, ((t + 1) * nslab - 1) // per
+                assert w_first <= w <= w_last
+                if w_last > w_first:  # shared tile: this piece is parked
+                    slot = 2 * w + (0 if t == t_first else 1)
+                    assert slot not in slots
+                    slots[slot] = (t, s0, s1)
+                    parked += 1
+                x += s1 - s0
+            assert parked <= 2
+        assert (covered == 1).all()
+        # what the last arriver of a tile reads: the slots of w_first .. w_last, k ranges in order, together the whole tile
+        for t in range(tiles):
+            w_first, w_last = (t * nslab) // per, ((t + 1) * nslab - 1) // per
+            if w_last == w_first:
+                continue
+            at = 0
+            for w in range(w_first, w_last + 1):
+                slot = 2 * w + (0 if t == (w * per) // nslab else 1)
+                tt, s0, s1 = slots[slot]
+                assert tt == t and s0 == at and s1 > s0
+                at = s1
+            assert at == nslab
