@@ -2142,41 +2142,40 @@ k_schur_update_big(DevTree T, const int *__restrict__ tiles, const double *__res
     load(0, k0 + 8 * KT);
     products(1, k0 + 4 * KT);
   }
-  // acc <- acc - (children's contributions); U = -acc
-  for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
-    const int c = T.child_idx[cc], bc = T.nbor[c];
-    const int *iv = T.pinv + T.pinv_off[c] + p;  // border part of the parent's front
-    const double *Uc = upd + T.upd_off[c];
-    int ci[TX], cj[TY][4];
+  // acc <- acc - (children's contributions); U = -acc.  One row block of the wave's tile at a time: its 16 x TY values
+  // of every child, then its part of U (the index maps are re-read per row block: they are small and cached)
 #pragma unroll
-    for (int x = 0; x < TX; x++) ci[x] = (i0 + 16 * x + lr < b) ? iv[i0 + 16 * x + lr] : -1;
+  for (int x = 0; x < TX; x++) {
+    const int i = i0 + 16 * x + lr;
+    for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
+      const int c = T.child_idx[cc], bc = T.nbor[c];
+      const int *iv = T.pinv + T.pinv_off[c] + p;  // border part of the parent's front
+      const double *Uc = upd + T.upd_off[c];
+      const int ci = i < b ? iv[i] : -1;
+      int cj[TY][4];
 #pragma unroll
-    for (int y = 0; y < TY; y++)
+      for (int y = 0; y < TY; y++)
 #pragma unroll
-      for (int rg = 0; rg < 4; rg++) cj[y][rg] = (j0 + 16 * y + lk + 4 * rg < b) ? iv[j0 + 16 * y + lk + 4 * rg] : -1;
-#pragma unroll
-    for (int x = 0; x < TX; x++) {
+        for (int rg = 0; rg < 4; rg++) cj[y][rg] = (j0 + 16 * y + lk + 4 * rg < b) ? iv[j0 + 16 * y + lk + 4 * rg] : -1;
       double gv[TY][4];
 #pragma unroll
       for (int y = 0; y < TY; y++)
 #pragma unroll
         for (int rg = 0; rg < 4; rg++)
-          gv[y][rg] = (ci[x] >= 0 && cj[y][rg] >= 0 && ci[x] >= cj[y][rg]) ? Uc[(long long)cj[y][rg] * bc + ci[x]] : 0.0;
+          gv[y][rg] = (ci >= 0 && cj[y][rg] >= 0 && ci >= cj[y][rg]) ? Uc[(long long)cj[y][rg] * bc + ci] : 0.0;
 #pragma unroll
       for (int y = 0; y < TY; y++)
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) acc[x][y][rg] -= gv[y][rg];
     }
-  }
-#pragma unroll
-  for (int x = 0; x < TX; x++)
 #pragma unroll
     for (int y = 0; y < TY; y++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
-        const int i = i0 + 16 * x + lr, j = j0 + 16 * y + lk + 4 * rg;
+        const int j = j0 + 16 * y + lk + 4 * rg;
         if (i < b && j < b && i >= j) U[(long long)j * b + i] = -acc[x][y][rg];
       }
+  }
 }
 
 // MFMA layout self-test: C(16x16) = A(16x16) * B(16x16), all row-major
