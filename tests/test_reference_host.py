@@ -589,9 +589,9 @@ def test_franke_hot_start_follows_the_reference(case, scale, kind):
     M.franke(prog, max_iters=400)
     x, _y, _z, _w, info = M.franke(prog2, max_iters=400, hot_start=1)
     assert info["result"] == ref["result"] == 0
-    slack = 0 if case == "banded" else max(2, ref["iters"] // 10)
+    slack = 0 if case == "banded" else 3  # (measured in round 5: 173 / 171, 171 / 171, 41 / 41; x to 7e-9 - was 10 %, 1e-4)
     assert abs(info["iters"] - ref["iters"]) <= slack, (info["iters"], ref["iters"])
-    assert np.abs(x - ref["x"]).max() <= 1e-4 * max(1.0, np.abs(ref["x"]).max())
+    assert np.abs(x - ref["x"]).max() <= 1e-6 * max(1.0, np.abs(ref["x"]).max())
 
 
 @pytest.mark.gpu
@@ -613,8 +613,10 @@ def test_franke_full_plugin_on_did_with_unit_hessian(K):
     M.init(prog)
     x, _y, _z, _w, info = M.franke(prog, max_iters=250)
     assert info["result"] == 0, (info, ref["iters"])
-    # the reference's own two plugins are up to 30 iterations apart on these
-    assert abs(info["iters"] - ref["iters"]) <= max(2, ref["iters"] // 10) + 2 * abs(other["iters"] - ref["iters"]), \
+    # the reference's own two plugins are up to 14 iterations apart on these (69 / 68, 95 / 94, 105 / 100, 156 / 148,
+    # 178 / 164); ours: 67, 91, 103, 145, 161 - within 4 of one of them (round 5; the bound was 10 % of the count + twice
+    # the plugins' distance until then)
+    assert min(abs(info["iters"] - ref["iters"]), abs(info["iters"] - other["iters"])) <= 4, \
         (info["iters"], ref["iters"], other["iters"])
     fr, fd = objective(prog, ref["x"]), objective(prog, x)
     assert abs(fr - fd) <= 1e-6 * max(1.0, abs(fr))
