@@ -166,7 +166,7 @@ def test_reference_ip_solver_drives_hip_plugin(solver, pair, case, monkeypatch):
     assert hip["result"] == ref["result"], info
     # Mehrotra ignores the residual solve() returns; Franke tests it against qp_eps
     # (hqp/Hqp_IpsFranke.C:372), so its count moves with the last digits of the refinement
-    slack = 2 if solver == "Mehrotra" else max(2, ref["iters"] // 10)
+    slack = 2 if solver == "Mehrotra" else min(6, max(2, ref["iters"] // 10))  # (Franke on DID K = 400: 135 +- 5 measured)
     assert abs(hip["iters"] - ref["iters"]) <= slack, info
     assert abs(fr - fh) <= 1e-6 * max(1.0, abs(fr)), info
     assert np.abs(hip["x"] - ref["x"]).max() <= 1e-5 * max(1.0, np.abs(ref["x"]).max()), info
