@@ -209,6 +209,10 @@ struct hqpkkt {
   // per schedule and tree level the largest pivot count among the general fronts of the level
   bool old_fd = false;
   std::vector<int> level_maxp[2];
+  // the device-resident interior-point loops: cancelled multiplier pivots are replaced (kernels.hip.h, TINY_REPLACE_WORD)
+  // only in the SECOND attempt of a run whose first attempt - without the replacement, i.e. with the factors the
+  // reference's own loop gets from this plugin through the shim - ended "degenerate" or singular
+  bool tiny_replace_in_loop = false;
   // the top levels of the tree solved in one launch (solve_top.hip.h): fronts of the levels >= top_lt, root first
   int top_n = 0, top_lt = 1 << 30, top_ns = 3;  // top_ns: 3 = k_solve_top<3, 11>, 4 = <4, 10>
   size_t top_lds = 0;
@@ -1953,7 +1957,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     }
     // the cold start's factorisation has succeeded (or a hot start carries on): the matrix is regular, cancelled multiplier
     // pivots are replaced from here on (kernels.hip.h, TINY_REPLACE_WORD)
-    HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));
+    if (h->tiny_replace_in_loop) HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));
     bool restart_cold = false;
     while (true) {
       double phi = 0.0;
@@ -2126,9 +2130,30 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     return finish(result);
   };
   // (a polled launch that gave up has switched the handle to the per-level launches: the loop runs once more)
-  int rc = guarded(loop);
-  if (rc == HQPKKT_E_POLL) rc = guarded(loop);
-  return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
+  auto attempt = [&]() {
+    int rc = guarded(loop);
+    if (rc == HQPKKT_E_POLL) rc = guarded(loop);
+    return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
+  };
+  // First with the factors as the reference's own loop gets them from this plugin through the shim; a run that ends
+  // "degenerate" (or singular) is made again with cancelled multiplier pivots replaced (hqpkkt::tiny_replace_in_loop;
+  // HQPKKT_TINY_IN_LOOP=1: replaced from the first attempt on, round 5's first policy; =0: never)
+  static const char *const pol = getenv("HQPKKT_TINY_IN_LOOP");
+  if (h) h->tiny_replace_in_loop = pol && atoi(pol) == 1;
+  int rc = attempt();
+  if (h && res && !h->tiny_replace_in_loop && !(pol && atoi(pol) == 0) && (rc == HQPKKT_E_SING || (rc == 0 && res->result == 4))) {
+    h->tiny_replace_in_loop = true;
+    // (from a cold start: the first attempt has used up what a hot start would start from; "2" keeps what the NEXT one needs)
+    hqpkkt_ip_opts again;
+    if (opts) {
+      again = *opts;
+      if (again.hot_start == 1) again.hot_start = 2;
+      opts = &again;
+    }
+    rc = attempt();
+    h->tiny_replace_in_loop = false;
+  }
+  return rc;
 }
 
 // ---- device-resident Franke loop ----------------------------------------------
@@ -2271,7 +2296,8 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     // ---- iterations (:381-416 around :271-378)
     while (true) {
       if (iter == 0) alphabar = 1.0;
-      if (iter == 1) HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));  // (the first factorisation + solve has succeeded: kernels.hip.h)
+      if (iter == 1 && h->tiny_replace_in_loop)
+        HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));  // (the first factorisation + solve has succeeded: kernels.hip.h)
       double mu;
       if (1.0 / gap < rhomin || alpha < 1.0) {
         mu = alphabar * gap / rhomin;             // potential reduction
@@ -2391,9 +2417,30 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     return finish(result);
   };
   // (a polled launch that gave up has switched the handle to the per-level launches: the loop runs once more)
-  int rc = guarded(loop);
-  if (rc == HQPKKT_E_POLL) rc = guarded(loop);
-  return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
+  auto attempt = [&]() {
+    int rc = guarded(loop);
+    if (rc == HQPKKT_E_POLL) rc = guarded(loop);
+    return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
+  };
+  // First with the factors as the reference's own loop gets them from this plugin through the shim; a run that ends
+  // "degenerate" (or singular) is made again with cancelled multiplier pivots replaced (hqpkkt::tiny_replace_in_loop;
+  // HQPKKT_TINY_IN_LOOP=1: replaced from the first attempt on, round 5's first policy; =0: never)
+  static const char *const pol = getenv("HQPKKT_TINY_IN_LOOP");
+  if (h) h->tiny_replace_in_loop = pol && atoi(pol) == 1;
+  int rc = attempt();
+  if (h && res && !h->tiny_replace_in_loop && !(pol && atoi(pol) == 0) && (rc == HQPKKT_E_SING || (rc == 0 && res->result == 4))) {
+    h->tiny_replace_in_loop = true;
+    // (from a cold start: the first attempt has used up what a hot start would start from; "2" keeps what the NEXT one needs)
+    hqpkkt_ip_opts again;
+    if (opts) {
+      again = *opts;
+      if (again.hot_start == 1) again.hot_start = 2;
+      opts = &again;
+    }
+    rc = attempt();
+    h->tiny_replace_in_loop = false;
+  }
+  return rc;
 }
 
 int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {

@@ -74,7 +74,8 @@ def test_large_stage_campaign_subset():
 
 # finds of tools/fuzz_ip.py: rounds 1-4 (profiles/r02_fuzz_big.txt: 12 000 cases, r04_fuzz_tree.txt: 6 000) - the first ten,
 # all cured in round 5 (cancelled multiplier pivots replaced, up to fifteen refinement rounds behind a perturbed pivot) -
-# and those that round 5's campaigns of 12 000 found instead (profiles/r05_fuzz_tree.txt: eight on the final code).  Those that differ from the
+# and those that round 5's campaigns of 12 000 found instead (profiles/r05_fuzz_tree.txt: eight; three on the final code,
+# profiles/r05_fuzz_ip_final.txt: 2536, 6258, 8650).  Those that differ from the
 # reference are reported as expected failures, not hidden (all on the double-integrator structure: pivoting confined to
 # the supernode's pivot block)
 IP_FINDS = [193, 2536, 5533, 5975, 6258, 7018, 7260, 7511, 8650, 10246, 803, 2419, 2532, 3015, 5466, 5921, 5954, 7818, 10258]
