@@ -2379,6 +2379,12 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       zeta *= (1.0 - alpha);
       gap = m > 0 ? C.hout[0] : 0.0;
       res->gap = gap, res->alpha = alpha, res->mu = mu, res->phi = zeta;
+      {
+        static const bool trace_ip = getenv("HQPKKT_TRACE_IP") != nullptr;  // (diagnosis: the loop's scalars after every step)
+        if (trace_ip)
+          fprintf(stderr, "franke: step %d gap %.17g alpha %.17g alphabar %.17g zeta %.17g rhomin %.17g resid %.3e mu %.6e\n", iter + 1, gap, alpha,
+                  alphabar, zeta, rhomin, resid, mu);
+      }
       if (!std::isfinite(gap) || !std::isfinite(C.hout[1])) {  // :351-354
         result = 4;
       } else {

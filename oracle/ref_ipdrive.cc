@@ -102,6 +102,52 @@ int hqpip_solve(int solver, const char *mat_solver, int n, int me, int m, const 
   return err;
 }
 
+// Diagnosis: Hqp_IpsFranke from a cold start, step by step (what its solve() does around step(), hqp/Hqp_IpsFranke.C:381-416,
+// without the hot-start branches), the solver's scalars after every step: trace[6 k ..] = gap, alpha, alphabar, zeta,
+// rhomin, Hqp_Result.  Returns 0 / the Meschach error; *niter = steps taken.
+namespace {
+struct FrankeProbe : public Hqp_IpsFranke {
+  void get(double *t) const { t[0] = _gap, t[1] = _alpha, t[2] = _alphabar, t[3] = _zeta, t[4] = _rhomin, t[5] = (double)_result; }
+};
+}  // namespace
+int hqpip_trace_franke(const char *mat_solver, int n, int me, int m, const int *Qp, const int *Qi, const double *Qx,
+                       const double *c, const int *Ap, const int *Ai, const double *Ax, const double *b, const int *Cp,
+                       const int *Ci, const double *Cx, const double *d, double qp_eps, int max_iters, double *trace,
+                       int *niter) {
+  if (hqpref_startup() != 0) return -1;
+  FrankeProbe *S = new FrankeProbe;
+  if (If_SetString("qp_mat_solver", mat_solver) != IF_OK) {
+    delete S;
+    return -2;
+  }
+  Hqp_Program *qp = new Hqp_Program;
+  qp->resize(n, me, m);
+  fill(qp->Q, n, Qp, Qi, Qx);
+  fill(qp->A, me, Ap, Ai, Ax);
+  fill(qp->C, m, Cp, Ci, Cx);
+  for (int i = 0; i < n; i++) qp->c->ve[i] = c[i], qp->x->ve[i] = 0.0;
+  for (int i = 0; i < me; i++) qp->b->ve[i] = b[i];
+  for (int i = 0; i < m; i++) qp->d->ve[i] = d[i];
+  S->qp(qp);
+  S->eps(qp_eps);
+  S->max_iters(max_iters);
+  (void)If_SetReal("qp_mu0", g_mu0);
+  int err = 0, k = 0;
+  m_catchall(S->init(); S->update(); S->cold_start();
+             for (k = 0; k < max_iters;) {
+               S->step();
+               S->get(trace + 6 * k);
+               k++;
+               const int r = (int)S->result();
+               if (r == Hqp_Optimal || r == Hqp_Suboptimal || r == Hqp_Degenerate) break;
+             },
+             err = _err_num);
+  *niter = k;
+  delete S;
+  delete qp;
+  return err;
+}
+
 // Time of Hqp_Solver::update() (= plugin update(): new values on the same pattern, once per SQP
 // iteration, hqp/Hqp_SqpSolver.C:285-296) with the plugin `mat_solver`: out[0] = median seconds of
 // `reps` updates (values scaled a little in between), out[1] = seconds of init + first update.
