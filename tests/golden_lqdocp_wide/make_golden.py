@@ -22,17 +22,24 @@ from oracle import refapi  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-# name: (K, nx, nu, seed of the QP, seed of the interior-point state, w / z spread in decades)
+# name: (K, nx, nu, seed of the QP, seed of the interior-point state, w / z spread in decades[, options of problems.lq_docp])
+# (five numbers: problems.c4_docp_csr; with options: problems.lq_docp - a free initial state of 600 components with
+#  final-state equalities carried back through the stages, path equalities with state bounds at 800 states)
 CASES = {
     "c4_K2_nx1000_nu50": (2, 1000, 50, 1, 1, 0.0),
     "c4_K3_nx2100_nu50": (3, 2100, 50, 2, 2, 1.0),
+    "free_x0_final_eq_K4_nx600_nu20": (4, 600, 20, 11, 3, 1.0, dict(x0_fixed=False, final_eq=40)),
+    "path_eq_bounds_K3_nx800_nu40": (3, 800, 40, 12, 4, 2.0, dict(path_eq=6, path_eq_every=1, x_bounds=100)),
 }
 
 
 def inputs(case):
-    K, nx, nu, seed, sseed, spread = case
-    prog = problems.c4_docp_csr(K, nx, nu, seed)
-    return prog, problems.ip_state(prog, sseed, spread)
+    K, nx, nu, seed, sseed, spread = case[:6]
+    if len(case) > 6:
+        prog = problems.lq_docp(int(K), int(nx), int(nu), seed=int(seed), **case[6])
+    else:
+        prog = problems.c4_docp_csr(int(K), int(nx), int(nu), int(seed))
+    return prog, problems.ip_state(prog, int(sseed), spread)
 
 
 def checksum(prog, st):
@@ -42,9 +49,11 @@ def checksum(prog, st):
 def main():
     assert refapi.available(), refapi.load_error()
     for name, case in CASES.items():
+        if os.path.exists(os.path.join(HERE, name + ".npz")) and "--all" not in sys.argv:
+            continue  # (python make_golden.py --all regenerates everything)
         prog, st = inputs(case)
         z, w, r1, r2, r3, r4 = st
-        out = dict(case=np.array(case, dtype=np.float64), checksum=checksum(prog, st))
+        out = dict(case=np.array(case[:6], dtype=np.float64), checksum=checksum(prog, st))
         R = refapi.RefIpMatrix("LQDOCP")
         R.init(prog)
         R.factor(z, w)

@@ -611,7 +611,9 @@ def test_wide_stages_against_the_reference_lqdocp_golden(name):
     """Slices of the headline workload at WIDE stages against the REFERENCE's own Hqp_IpLQDOCP (committed results,
     tests/golden_lqdocp_wide/make_golden.py; inputs regenerated from the seeds, guarded by a checksum): K = 2 stages of
     1000 states and K = 3 stages of 2100 states (the triangle form of the solve's products with V, MFMA tiles with ragged
-    edges, split products), 50 controls, w / z spread over two decades in the second - the STAGED engine through the C
+    edges, split products), 50 controls, w / z spread over two decades in the second; a free initial state of 600
+    components with 40 final-state equalities carried back through four stages (the blocked inverse of the initial
+    system); path equalities and state bounds at 800 states - the STAGED engine through the C
     ABI: residual of solve() <= the reference's + 1e-10, solution to 1e-8, residuum() of the reference's own step result
     to 1e-12.  (The reference takes 3 s / 35 s per factor + solve there, minutes per stage at 5000 states: the full-size
     workload is checked by properties, test_full_size_c4_properties.)"""
@@ -620,8 +622,8 @@ def test_wide_stages_against_the_reference_lqdocp_golden(name):
     mg = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(mg)
     g = dict(np.load(os.path.join(WIDE_DIR, name + ".npz")))
-    case = tuple(g["case"])
-    prog, st = mg.inputs((int(case[0]), int(case[1]), int(case[2]), int(case[3]), int(case[4]), float(case[5])))
+    prog, st = mg.inputs(mg.CASES[name])
+    assert tuple(g["case"]) == tuple(float(v) for v in mg.CASES[name][:6])
     np.testing.assert_allclose(mg.checksum(prog, st), g["checksum"], rtol=1e-13)
     M = ipmatrix.IpLQDOCP()
     M.init(prog)
