@@ -613,7 +613,8 @@ def test_wide_stages_against_the_reference_lqdocp_golden(name):
     1000 states and K = 3 stages of 2100 states (the triangle form of the solve's products with V, MFMA tiles with ragged
     edges, split products), 50 controls, w / z spread over two decades in the second; a free initial state of 600
     components with 40 final-state equalities carried back through four stages (the blocked inverse of the initial
-    system); path equalities and state bounds at 800 states - the STAGED engine through the C
+    system); path equalities and state bounds at 800 states; stages of 300 controls with carried final-state rows (the
+    blocked elimination) - the STAGED engine through the C
     ABI: residual of solve() <= the reference's + 1e-10, solution to 1e-8, residuum() of the reference's own step result
     to 1e-12.  (The reference takes 3 s / 35 s per factor + solve there, minutes per stage at 5000 states: the full-size
     workload is checked by properties, test_full_size_c4_properties.)"""
