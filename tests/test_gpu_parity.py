@@ -7,6 +7,8 @@ Tolerances (fp64, stated by BASELINE.json's north_star and SURVEY.md 8(c)):
     inputs (the pivot sequences differ by design, so no bit parity);
   * residuum() of a given d: 1e-12 relative (same arithmetic, other sum order).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -213,6 +215,40 @@ def test_full_size_c2_properties():
     d3 = new_d(prog)
     M.solve(prog, *st, *d3)
     assert rel_err(d3, d) <= 1e-12
+
+
+FULL_DIR = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden_full_size")
+FULL = sorted(os.path.splitext(os.path.basename(f))[0] for f in __import__("glob").glob(os.path.join(FULL_DIR, "*.npz")))
+
+
+@pytest.mark.parametrize("name", FULL)
+def test_full_size_c2_against_the_reference_golden(name):
+    """Config C2 of BASELINE.json at FULL size (n = 40 000, band 80: KKT dimension 10^5) against the REFERENCE's own
+    Hqp_IpSpBKP / Hqp_IpRedSpBKP (committed results, tests/golden_full_size/make_golden.py: every 37th component of the
+    reference's solve() result, the norms, the sums and the residual; inputs regenerated from the seeds, guarded by a
+    checksum), the second fixture with w / z spread over four decades: residual of solve() <= the reference's + 1e-10,
+    the sampled components to 1e-8 of the vector's norm, norms and sums to 1e-8."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("make_golden_full", os.path.join(FULL_DIR, "make_golden.py"))
+    mg = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mg)
+    g = dict(np.load(os.path.join(FULL_DIR, name + ".npz")))
+    case = mg.CASES[name]
+    prog, st = mg.inputs(case)
+    np.testing.assert_allclose(mg.checksum(prog, st), g["checksum"], rtol=1e-13)
+    M = CLS[case[5]]()
+    M.init(prog)
+    assert M.stats()["dim"] == (100000 if case[5] == "SpBKP" else 60000)
+    M.factor(prog, st[0], st[1])
+    d = new_d(prog)
+    res = M.solve(prog, *st, *d)
+    scale = max(1.0, max(float(g[k + "_norm"]) for k in ("dx", "dy", "dz", "dw")))
+    assert res <= float(g["res"]) + 1e-10 * scale, (res, float(g["res"]))
+    for nm, v in zip(("dx", "dy", "dz", "dw"), d):
+        nrm = max(float(g[nm + "_norm"]), 1e-300)
+        assert np.abs(v[::mg.STRIDE] - g[nm + "_sample"]).max() <= 1e-8 * nrm, nm
+        assert abs(np.abs(v).max() - nrm) <= 1e-8 * nrm, nm
+        assert abs(v.sum() - float(g[nm + "_sum"])) <= 1e-8 * nrm * max(1.0, np.sqrt(len(v))), nm
 
 
 def _empty_block():
