@@ -21,15 +21,18 @@ from oracle import refapi  # noqa: E402
 HERE = os.path.dirname(os.path.abspath(__file__))
 STRIDE = 37
 # name: (n, band, seed of the QP, seed of the interior-point state, w / z spread in decades, plugin)
+#   or: ("mesh", cells per side, seed of the QP, seed of the state, spread, plugin) - problems.grid_sparse_qp, the stand-in of
+#   BASELINE.json's configs[4] at 10^5 variables (the reference: RCM band 631, 51 s; ours: the dissection of the KKT graph)
 CASES = {
     "c2_banded_n40000_b80_SpBKP": (40000, 80, 12345, 1, 0.0, "SpBKP"),
     "c2_banded_n40000_b80_RedSpBKP_spread": (40000, 80, 12345, 2, 2.0, "RedSpBKP"),
+    "mesh_316x316_RedSpBKP": ("mesh", 316, 5, 1, 1.0, "RedSpBKP"),
 }
 
 
 def inputs(case):
     n, band, seed, sseed, spread, _kind = case
-    prog = problems.banded_qp(n, band, seed)
+    prog = problems.grid_sparse_qp(band, band, seed=seed) if n == "mesh" else problems.banded_qp(n, band, seed)
     return prog, problems.ip_state(prog, sseed, spread)
 
 
@@ -40,6 +43,8 @@ def checksum(prog, st):
 def main():
     assert refapi.available(), refapi.load_error()
     for name, case in CASES.items():
+        if os.path.exists(os.path.join(HERE, name + ".npz")) and "--all" not in sys.argv:
+            continue  # (python make_golden.py --all regenerates everything)
         prog, st = inputs(case)
         R = refapi.RefIpMatrix(case[5])
         R.init(prog)
