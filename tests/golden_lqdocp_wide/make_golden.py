@@ -29,6 +29,7 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 CASES = {
     "c4_K2_nx1000_nu50": (2, 1000, 50, 1, 1, 0.0),
     "c4_K3_nx2100_nu50": (3, 2100, 50, 2, 2, 1.0),
+    "c4_K2_nx5000_nu50": (2, 5000, 50, 3, 3, 1.0),  # the headline's FULL stage width: the reference needs 11 minutes
     "free_x0_final_eq_K4_nx600_nu20": (4, 600, 20, 11, 3, 1.0, dict(x0_fixed=False, final_eq=40)),
     "path_eq_bounds_K3_nx800_nu40": (3, 800, 40, 12, 4, 2.0, dict(path_eq=6, path_eq_every=1, x_bounds=100)),
     "many_controls_K3_nx400_nu300": (3, 400, 300, 13, 5, 1.0, dict(final_eq=30)),
