@@ -514,16 +514,17 @@ def test_mehrotra_on_wide_stages_satisfies_the_kkt_conditions():
     assert kkt["complementarity"] <= 1e-8, kkt
 
 
-def test_mehrotra_iterations_equal_the_references_on_the_c4_structure():
-    """... and at a width the reference finishes in seconds (60 states per stage, CSR hand-over) the device-resident
-    loop on the STAGED engine needs the iterations of the reference's own Hqp_IpsMehrotra with its Hqp_IpLQDOCP,
-    and ends at the same point."""
+@pytest.mark.parametrize("shape", [(12, 60, 4), (6, 500, 20)])
+def test_mehrotra_iterations_equal_the_references_on_the_c4_structure(shape):
+    """... and at widths the reference finishes in seconds (60 states per stage; 500 states: 12 s on one core; CSR
+    hand-over) the device-resident loop on the STAGED engine needs the iterations of the reference's own
+    Hqp_IpsMehrotra with its Hqp_IpLQDOCP, and ends at the same point."""
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
     from oracle import refapi
     if not refapi.available():
         pytest.skip("reference build not on this box")
-    K, nx, nu = 12, 60, 4
+    K, nx, nu = shape
     prog = bench.c4_program(K, nx, nu, seed=5)
     rng = np.random.default_rng(6)
     prog.c = rng.uniform(-0.5, 0.5, prog.n)
