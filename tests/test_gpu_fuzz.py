@@ -40,10 +40,12 @@ def test_tree_engine_campaign_subset():
     assert cnt.get("ok", 0) >= 270, cnt  # (a few per hundred are singular on both sides)
 
 
-def test_tree_engine_campaign_subset_with_graph_dissection(monkeypatch):
-    """... 40 cases through the tree of the graph's own dissection (hqpkkt_opts.ordering 1)"""
+@pytest.mark.parametrize("ordering", [1, 2])
+def test_tree_engine_campaign_subset_with_graph_dissection(monkeypatch, ordering):
+    """... 40 cases through the tree of the graph's own dissection (hqpkkt_opts.ordering 1; 2: without the reference's RCM
+    pass - no mat_sbw / permutation to compare there)"""
     import fuzz
-    monkeypatch.setenv("FUZZ_ORDERING", "1")
+    monkeypatch.setenv("FUZZ_ORDERING", str(ordering))
     bad, cnt = _run(fuzz.check, range(3000, 3040))
     assert not bad, bad
     assert cnt.get("ok", 0) >= 34, cnt
