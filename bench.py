@@ -380,22 +380,48 @@ def cpu_baseline_c4(K, nx, nu):
     sizes_l, reps_l = (50, 100, 200), (5, 5, 3)
     tl = [_ref_time((K, s_, nu, r_))[0] for s_, r_ in zip(sizes_l, reps_l)]
     lq = fit(sizes_l, tl)
-    # the slice at wide stages: K = 2 (per-stage time = half), nx = 1000 and 2000
     ks, wide = 2, (1000, 2000)
-    tw = [_ref_time((ks, s_, nu, 1))[0] / ks for s_ in wide]
-    expo = float(np.log(tw[1] / tw[0]) / np.log(wide[1] / wide[0]))
-    per_stage = float(tw[1] * (nx / wide[1]) ** expo) if nx > wide[1] else float(np.interp(nx, wide, tw))
-    per_stage_cubic = float(tw[1] * (nx / wide[1]) ** 3) if nx > wide[1] else per_stage
-    full_s, full_cubic_s = K * per_stage, K * per_stage_cubic
-    lq.update({"slice_stages": ks, "slice_nx": list(wide), "slice_seconds_per_stage": tw, "slice_exponent": expo,
-               "extrapolated_fit_s": full_s, "extrapolated_cubic_s": full_cubic_s})
+    if nx >= wide[0]:
+        # the slice at wide stages: K = 2 (per-stage time = half), nx = 1000 and 2000; the samples' power law in BOTH directions
+        # (between the samples that is an interpolation, beyond nx = 2000 an extrapolation)
+        tw = [_ref_time((ks, s_, nu, 1))[0] / ks for s_ in wide]
+        expo = float(np.log(tw[1] / tw[0]) / np.log(wide[1] / wide[0]))
+        per_stage = float(tw[1] * (nx / wide[1]) ** expo)
+        per_stage_cubic = float(tw[1] * (nx / wide[1]) ** 3)
+        how = (f"EXTRAPOLATED over {nx / wide[1]:.1f}x in nx" if nx > wide[1] else "INTERPOLATED between the samples") + \
+              f" to nx={nx} with the samples' exponent {expo:.2f}"
+        # Second reading: the one slice at the FULL width that was ever measured (build container, one core of another
+        # machine: profiles/r05_ref_full_width.jsonl - K = 2 at nx = 2000: 9.305 s per stage, at nx = 5000: 324.04 s per
+        # stage, i.e. an exponent of 3.87 over that factor 2.5, where Meschach's m_mlt leaves the caches) carried over
+        # to THIS host by the ratio of the two, applied to this host's own nx = 2000 sample.
+        fw_expo = float(np.log(324.04 / 9.305) / np.log(2.5))
+        per_stage_fw = float(tw[1] * (nx / wide[1]) ** fw_expo) if nx > wide[1] else per_stage
+        lq.update({"slice_stages": ks, "slice_nx": list(wide), "slice_seconds_per_stage": tw, "slice_exponent": expo,
+                   "full_width_exponent_build_container": fw_expo})
+        sample = (f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve on a SLICE of the workload: K={ks} stages of the same QP family (nu={nu}) at "
+                  + ", ".join(f"nx={s_}: {t_:.2f} s per stage" for s_, t_ in zip(wide, tw))
+                  + f"; the cost is linear in the stages; {how}: {per_stage:.0f} s per stage x K={K} = {K * per_stage:.0f} s per "
+                    f"factor+solve (used for `value`: the reading that favours the CPU); with nx^3: {K * per_stage_cubic:.0f} s; with the exponent "
+                    f"{fw_expo:.2f} of the one full-width slice measured in the build container (profiles/r05_ref_full_width.jsonl): "
+                    f"{K * per_stage_fw:.0f} s")
+    else:
+        # a small workload (--nx below the wide samples): the K-stage samples at nx = 50, 100, 200 and their power law in both
+        # directions; the wide samples (about 25 s of CPU) are not run
+        tw, expo = [], lq["exponent_fit"]
+        per_stage = float(tl[-1] / K * (nx / sizes_l[-1]) ** expo)
+        per_stage_cubic = float(tl[-1] / K * (nx / sizes_l[-1]) ** 3)
+        per_stage_fw = per_stage
+        inside = sizes_l[0] <= nx <= sizes_l[-1]
+        sample = (f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve on the workload's own K={K} stages (nu={nu}) at "
+                  + ", ".join(f"nx={s_}: {t_:.2f} s" for s_, t_ in zip(sizes_l, tl))
+                  + f"; {'INTERPOLATED' if inside else 'EXTRAPOLATED'} to nx={nx} with their fitted exponent {expo:.2f}: "
+                    f"{K * per_stage:.2f} s per factor+solve")
+    full_s, full_cubic_s, full_fw_s = K * per_stage, K * per_stage_cubic, K * per_stage_fw
+    lq.update({"extrapolated_fit_s": full_s, "extrapolated_cubic_s": full_cubic_s, "extrapolated_full_width_exponent_s": full_fw_s})
     out = {"value": 1.0 / full_s, "unit": "KKT factor+solve/s", "cores": 1, "kind": "reference", "host_cores": cores,
-           "sample": f"Hqp_IpLQDOCP::factor + Hqp_IpMatrix::solve on a SLICE of the workload: K={ks} stages of the same QP family (nu={nu}) at "
-                     + ", ".join(f"nx={s_}: {t_:.2f} s per stage" for s_, t_ in zip(wide, tw))
-                     + f"; the cost is linear in the stages; EXTRAPOLATED over {nx / wide[1]:.1f}x in nx to nx={nx} with the samples' exponent "
-                       f"{expo:.2f}: {per_stage:.0f} s per stage x K={K} = {full_s:.0f} s per factor+solve (used for `value`); with nx^3: {full_cubic_s:.0f} s",
+           "sample": sample, "value_full_width_exponent": 1.0 / full_fw_s,
            "lqdocp": lq, "measured": {"nx100_s": tl[1], "nx200_s": tl[2], "exponent": lq["exponent_fit"]},
-           "extrapolated_s": full_s}
+           "extrapolated_s": full_s, "extrapolated_full_width_exponent_s": full_fw_s}
     try:  # Hqp_IpSpBKP, the comparator north_star names (full KKT system, RCM band of ~3 nx)
         sizes_s = (50, 100)
         ts_ = [_ref_time((K, s_, nu, 2, "SpBKP"))[0] for s_ in sizes_s]
@@ -785,6 +811,7 @@ def bench_c4(args):
             out["speedup_vs_cpu_baseline_readings"] = {
                 "Hqp_IpLQDOCP, exponent of the wide samples": out["value"] * cb["lqdocp"]["extrapolated_fit_s"],
                 "Hqp_IpLQDOCP, nx^3 from nx=2000": out["value"] * cb["lqdocp"]["extrapolated_cubic_s"],
+                "Hqp_IpLQDOCP, exponent of the full-width slice of the build container (3.87)": out["value"] * cb["lqdocp"]["extrapolated_full_width_exponent_s"],
                 "Hqp_IpSpBKP, nx^3 from nx=100": out["value"] * cb["spbkp"]["extrapolated_cubic_s"] if "extrapolated_cubic_s" in cb.get("spbkp", {}) else None}
         del mat
         torch.cuda.empty_cache()

@@ -76,7 +76,7 @@ class IpOpts(C.Structure):
 class IpResult(C.Structure):
     _fields_ = [("result", C.c_int), ("iters", C.c_int), ("n_factor", C.c_int), ("n_solve", C.c_int),
                 ("gap", C.c_double), ("mu", C.c_double), ("phi", C.c_double), ("pcost", C.c_double),
-                ("alpha", C.c_double), ("ms_total", C.c_float)]
+                ("alpha", C.c_double), ("ms_total", C.c_float), ("attempts", C.c_int)]
 
     def asdict(self):
         return {k: getattr(self, k) for k, _ in self._fields_}

@@ -43,10 +43,18 @@ namespace kktdev {
 // (a compile-time constant of the two instantiations: 144 for blocks of up to 128 pivots, 208 up to 192 - the
 // k-rows of an operand are immediate offsets of one address then)
 __host__ __device__ inline int fb_ld_of(int p) { return p <= 128 ? 144 : 208; }
+// Where k-row k of a 16-row operand image starts (round 6): rows 2 j and 2 j + 1 are skewed by j doubles.  The reads of
+// the matrix products (ds_read_b64: a half-wave touches k-rows k and k + 1 with k even, 16 consecutive doubles of
+// each) stay conflict-free - ld = 16 mod 32 keeps the pair in different halves of the banks, the pair shares its
+// skew - and the TRANSPOSED stores (16 lanes = 16 k-rows of one column: the rows of M of the next panel, the pivot
+// rows times N, N itself) spread over eight bank pairs instead of hitting ONE (16-way conflicts: they were the 52 %
+// of profiles/r05_pmc_tree.txt).  An image takes 16 ld + 8 doubles.
+#define FBROW(k) ((k) * ld + ((k) >> 1))
+__host__ __device__ inline int fb_img_of(int ld) { return 16 * ld + 8; }
 __host__ __device__ inline size_t fb_lds_bytes(int p) {
   const int pp = ((p + 15) / 16) * 16, ld = fb_ld_of(p);
   // Op, Lb, Yb, Xq | Tb, Ld (two each), Gb | Ab, G2 | dvals, dinvs, cmaxf, flags (two each) | rm0 | dv | lp, pt (ints)
-  return sizeof(double) * ((size_t)64 * ld + 5 * 272 + 512 + 96 + (size_t)pp + 2 * (size_t)pp + (size_t)pp + 16);
+  return sizeof(double) * ((size_t)4 * fb_img_of(ld) + 5 * 272 + 512 + 96 + (size_t)pp + 2 * (size_t)pp + (size_t)pp + 16);
 }
 
 // Barrier of the panel loop: waits for this wavefront's LDS operations only.  __syncthreads() also waits for the
@@ -129,17 +137,17 @@ __device__ __forceinline__ void lds_max_pos(double *addr, double v) {
     const double nl = act ? -(g[S] * di) : 0.0;                                           \
     /* the test inside the block (hqp/spBKP.C:431-438): |d| >= alpha |column| <=> |multiplier| <= 1 / alpha */ \
     badm |= __any(!(fabs(nl) <= ialpha)) ? (1u << (S)) : 0u;                              \
+    /* the pivot and its inverse as this step computed it (0 in front of `off`): d and di are the same in every lane */ \
+    if (lane == 0) dvals[S] = d, dinvs[S] = (S) >= off ? di : 0.0;                         \
     if ((S) < 15) {                                                                       \
       asm volatile("s_nop 1" ::: "memory");                                               \
       FB_FMAC(((S) + 1) & 15, S, nl);                                                     \
       asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" FB_STR(FB_NEXT(S)) " row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(g[((S) + 1) & 15])); \
     }                                                                                     \
     g[S] = act ? nl : g[S];                                                               \
-    Lbk[(S)*LD + r] = nl;                                                                 \
+    Lbk[(S)*LD + ((S) >> 1) + r] = nl;                                                    \
     nlp = nl;                                                                             \
   }
-#define FB_STR2(x) #x
-#define FB_STR(x) FB_STR2(x)
 #define FB_NEXT(S) FB_NEXT_##S
 #define FB_NEXT_0 1
 #define FB_NEXT_1 2
@@ -167,45 +175,87 @@ __device__ __forceinline__ void lds_max_pos(double *addr, double v) {
 // Lbk[s * LD + r]; the pivots and their inverses (0 for the pivots in front of `off`); the pivots that failed
 // |d| >= alpha |column| against the rows of the block itself or |d| >= pert.  Tn (16 rows of stride LD): N alone,
 // Lbk (likewise): -L, both where the update's operand images keep the columns of this block.
-template <int LD>
-__device__ __forceinline__ void fb_eliminate_block(const double *Gb, double *Tb, double *Tn, double *Lbk,
-                                                   double *dvals, double *dinvs, int *bad_in, double alpha,
-                                                   double pert, int off, int lane) {
-  const int r = lane & 15, grp = lane >> 4;
-  const double ialpha = 1.0 / alpha;
-  unsigned int badm = 0;
-  double g[16];
+// In three pieces (round 6), so that the look-ahead can run the first steps of the NEXT block's elimination in front
+// of a panel's middle barrier and the rest behind it, with the block in registers across the barrier.
+#define FB_STR2(x) #x
+#define FB_STR(x) FB_STR2(x)
+#ifndef FB_SPEC_STEPS
+#define FB_SPEC_STEPS 4  // steps of the next block's elimination in front of a panel's middle barrier
+#endif
+// (the block's state as separate arguments - g: this lane's row of the block, d: the pivot on its way through the lanes,
+// nlp: the pending multiplier, badm: failed pivots - not as a structure: behind a structure hipcc turns the select chain
+// over g in fb_elim_finish into an indexed load and keeps the whole block in scratch memory)
+__device__ __forceinline__ void fb_elim_load(double (&g)[16], double &d, double &nlp, unsigned int &badm, const double *Gb, int off, int lane) {
+  const int r = lane & 15;
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const int hi = max(r, c), lo = min(r, c);
     g[c] = Gb[(c < off) ? r * 17 + c : hi * 17 + lo];
   }
-  double d, nlp = 0.0;
+  nlp = 0.0, badm = 0u;
   asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:0 row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(g[0]));
-  FB_STEP(0, -1) FB_STEP(1, 0) FB_STEP(2, 1) FB_STEP(3, 2) FB_STEP(4, 3) FB_STEP(5, 4) FB_STEP(6, 5) FB_STEP(7, 6)
-  FB_STEP(8, 7) FB_STEP(9, 8) FB_STEP(10, 9) FB_STEP(11, 10) FB_STEP(12, 11) FB_STEP(13, 12) FB_STEP(14, 13) FB_STEP(15, 14)
-  // (step 15 has no row below it: nothing pending)
-  // the pivot of row r is still the diagonal entry of its own lane; its inverse as the steps computed it
-  double myd = g[0];
+}
+// The block on its way through the elimination, parked in Gb (row-major, all 16 columns of every row; the pending
+// multipliers in the pad column) across a barrier, and taken up again in front of step FB_SPEC_STEPS
+__device__ __forceinline__ void fb_elim_park(const double (&g)[16], double nlp, double *Gb, int lane) {
+  const int r = lane & 15;
+  if (lane < 16) {
 #pragma unroll
-  for (int c = 1; c < 16; c++) myd = (r == c) ? g[c] : myd;
-  double mydi;
-  {
-    const double x = __builtin_amdgcn_rcp(myd);
-    const double e = fma(-myd, x, 1.0);
-    const double e2 = fma(e, e, e);
-    mydi = fma(x, e2, x);
+    for (int c = 0; c < 16; c++) Gb[r * 17 + c] = g[c];
+    Gb[r * 17 + 16] = nlp;
   }
-  if (grp == 0) dvals[r] = myd, dinvs[r] = r >= off ? mydi : 0.0;
-  badm |= (unsigned int)(__ballot(r >= off && !(fabs(myd) >= pert)) & 0xffffull);
+}
+__device__ __forceinline__ void fb_elim_resume(double (&g)[16], double &d, double &nlp, const double *Gb, int lane) {
+  const int r = lane & 15;
+#pragma unroll
+  for (int c = 0; c < 16; c++) g[c] = Gb[r * 17 + c];
+  nlp = Gb[r * 17 + 16];
+  asm volatile("s_nop 1\n\tv_mov_b64_dpp %0, %1 row_newbcast:" FB_STR(FB_SPEC_STEPS) " row_mask:0xf bank_mask:0xf" : "=v"(d) : "v"(g[FB_SPEC_STEPS]));
+}
+// steps S0 .. S1 - 1 (S0 = 0 or the step the call before ended with)
+#define FB_STEP_IF(S, SP) \
+  if constexpr (S0 <= (S) && (S) < S1) FB_STEP(S, SP)
+template <int LD, int S0, int S1>
+__device__ __forceinline__ void fb_elim_steps(double (&g)[16], double &d, double &nlp, unsigned int &badm, double *Lbk, double *dvals, double *dinvs,
+                                              double alpha, int off, int lane) {
+  const int r = lane & 15;
+  const double ialpha = 1.0 / alpha;
+  FB_STEP_IF(0, -1) FB_STEP_IF(1, 0) FB_STEP_IF(2, 1) FB_STEP_IF(3, 2) FB_STEP_IF(4, 3) FB_STEP_IF(5, 4) FB_STEP_IF(6, 5) FB_STEP_IF(7, 6)
+  FB_STEP_IF(8, 7) FB_STEP_IF(9, 8) FB_STEP_IF(10, 9) FB_STEP_IF(11, 10) FB_STEP_IF(12, 11) FB_STEP_IF(13, 12) FB_STEP_IF(14, 13) FB_STEP_IF(15, 14)
+  // (step 15 has no row below it: nothing pending)
+}
+template <int LD>
+__device__ __forceinline__ void fb_elim_finish(double (&g)[16], unsigned int badm, double *Tb, double *Tn, double *dvals, double *dinvs, int *bad_in,
+                                               double pert, int off, int lane) {
+  const int r = lane & 15, grp = lane >> 4;
+  // the pivots as the steps left them (read back instead of picked out of g by a chain of selects: hipcc turns that
+  // chain into an indexed load and puts the whole block into scratch memory for it)
+  const double myd = dvals[r];
+  // A row that a NaN has reached is of no use to the update with the accepted pivots either (a zero pivot makes the
+  // rows below it NaN, and 0 * NaN of the steps behind it every row above: the whole panel goes to the slow step then,
+  // as it did when this test looked at the row's diagonal entry at the END of the steps).
+  bool nan_row = false;
+#pragma unroll
+  for (int c = 0; c < 16; c++) nan_row |= !(g[c] == g[c]);
+  badm |= (unsigned int)(__ballot(r >= off && (nan_row || !(fabs(myd) >= pert))) & 0xffffull);
   if (lane == 0) *bad_in = (int)badm;  // bit s: pivot s failed against a row of its own block, or is tiny
 #pragma unroll
   for (int c = 0; c < 16; c++) {
     const double v = (c == r) ? 1.0 : (r < off ? 0.0 : g[c]);
     if ((c & 3) == grp) Tb[r * 17 + c] = v;
     // N alone (unit lower; the entries of M in front of `off`), as 16 k-rows of the operand images
-    if ((c & 3) == grp) Tn[r * LD + c] = c < r ? v : (c == r ? 1.0 : 0.0);
+    if ((c & 3) == grp) Tn[r * LD + (r >> 1) + c] = c < r ? v : (c == r ? 1.0 : 0.0);
   }
+}
+template <int LD>
+__device__ __forceinline__ void fb_eliminate_block(const double *Gb, double *Tb, double *Tn, double *Lbk,
+                                                   double *dvals, double *dinvs, int *bad_in, double alpha,
+                                                   double pert, int off, int lane) {
+  double g[16], d, nlp;
+  unsigned int badm;
+  fb_elim_load(g, d, nlp, badm, Gb, off, lane);
+  fb_elim_steps<LD, 0, 16>(g, d, nlp, badm, Lbk, dvals, dinvs, alpha, off, lane);
+  fb_elim_finish<LD>(g, badm, Tb, Tn, dvals, dinvs, bad_in, pert, off, lane);
 }
 
 #ifdef HQPKKT_STAMPS
@@ -250,12 +300,13 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
   double *W = linv + linv_off[node];  // p x p column-major
   const int nb = (p + 15) >> 4, pp = nb << 4;
   double *Op = lds;                 // 16 x ld: the pivot rows of [M | U] (k-major)
-  double *Lb = Op + 16 * ld;        // 16 x ld: -L of the panel (k-major)
-  double *Yb = Lb + 16 * ld;        // 16 x ld: the rows of M of the next panel's pivots as they stand (k-major)
-  double *Xq = Yb + 16 * ld;        // 16 x ld, columns 0..63: what the elimination of a diagonal block leaves as
+  constexpr int IMG = 16 * ld + 8, Q4 = 4 * ld + 2;  // an image (FBROW: skewed k-rows); from k-row k to k-row k + 4
+  double *Lb = Op + IMG;            // 16 x ld: -L of the panel (k-major)
+  double *Yb = Lb + IMG;            // 16 x ld: the rows of M of the next panel's pivots as they stand (k-major)
+  double *Xq = Yb + IMG;            // 16 x ld, columns 0..63: what the elimination of a diagonal block leaves as
                                     // operand images, for two panels in turn: -L of the block (columns 16 par ..),
                                     // N of the block (columns 32 + 16 par ..)
-  double *Tb = Xq + 16 * ld;        // two of 16 x 17: the eliminated diagonal block (rows of [N | U])
+  double *Tb = Xq + IMG;            // two of 16 x 17: the eliminated diagonal block (rows of [N | U])
   double *Ldg = Tb + 2 * 272;       // two of 16 x 17: -L inside the diagonal block, [pivot][row]
   double *Gb = Ldg + 2 * 272;       // 16 x 17: the diagonal block to eliminate
   double *Ab = Gb + 272, *G2 = Ab + 256;  // register images of the two blocks the next elimination starts from
@@ -370,7 +421,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
 #pragma unroll
         for (int q = 0; q < 4; q++) Gb[ln * 17 + lg + 4 * q] = R[s][q];
       } else {
-        double *y = Yb + (ln * ld + 16 * J_ + lg);
+        double *y = Yb + (FBROW(ln) + 16 * J_ + lg);
 #pragma unroll
         for (int q = 0; q < 4; q++) y[4 * q] = R[s][q];
       }
@@ -429,6 +480,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     // ---- C' = N A' for the blocks below the diagonal block, M rows <- N (M rows); the elimination wavefront:
     // the next diagonal block as this panel leaves it.  N (row ln, columns lg + 4 q: the A operand of the first
     // product, the B operand of the second) and D^-1 once per wavefront.
+    unsigned int spec_badm = 0u;  // (of the next diagonal block's first elimination steps, in front of the middle barrier)
     if (is_ge || (m_solve | m_mrow)) {
       double tn[4];
 #pragma unroll
@@ -454,6 +506,18 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
           for (int q = 0; q < 4; q++) G_ = mfma_f64(acc[q], -(acc[q] * dvi[q]), G_);
 #pragma unroll
           for (int q = 0; q < 4; q++) Gb[ln * 17 + lg + 4 * q] = G_[q];
+          // ... and the first steps of its elimination at once, in front of the panel's middle barrier (speculative: the
+          // test behind the barrier may still reject a pivot of THIS panel - the block in registers is dropped then,
+          // what the steps wrote lies in the other parity's buffers, which nobody reads before they are written again).
+          // The elimination wavefront used to idle through the solve phase and then be the last to reach the
+          // panel's end: 8560 of a panel's 13 400 cycles (profiles/r06_fb_panel_stamps.txt).
+#ifndef FB_NO_SPEC
+          if (lane < 16) cmaxf[16 * (par ^ 1) + lane] = 0.0f;
+          double eg[16], ed, enlp;
+          fb_elim_load(eg, ed, enlp, spec_badm, Gb, 0, lane);
+          fb_elim_steps<LD, 0, FB_SPEC_STEPS>(eg, ed, enlp, spec_badm, Xq + 16 * (par ^ 1), dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1), alpha, 0, lane);
+          fb_elim_park(eg, enlp, Gb, lane);  // (across the barrier in LDS: in registers it would be live in every wavefront's allocation)
+#endif
         }
       } else {
 #pragma unroll
@@ -466,26 +530,26 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
 #pragma unroll
             for (int q = 0; q < 4; q++) acc = mfma_f64(rowon ? tn[q] : 0.0, R[s][q], acc);
             const int row = 16 * SLOT_I(s) + ln;
-            double *o = Op + (lg * ld + row), *l = Lb + (lg * ld + row);
+            double *o = Op + (FBROW(lg) + row), *l = Lb + (FBROW(lg) + row);
 #pragma unroll
             for (int q = 0; q < 4; q++) {
               // acc[q] = C(row ln of block I, pivot lg + 4 q); zero for the pivots in front of `off`
-              o[4 * q * ld] = acc[q];
-              l[4 * q * ld] = -(acc[q] * dvi[q]);
+              o[q * Q4] = acc[q];
+              l[q * Q4] = -(acc[q] * dvi[q]);
               // column maxima in fp32, compared as bit patterns (a NaN is the largest)
               const unsigned v = row16_max_u(__float_as_uint((float)acc[q]) & 0x7fffffffu);
               if (ln == 0) atomicMax((unsigned int *)&cmp[lg + 4 * q], v);
             }
           } else if (SLOT_IN(m_mrow, s)) {
             const int J_ = SLOT_J(s);
-            const double *y = Yb + (lg * ld + 16 * J_ + ln);
+            const double *y = Yb + (FBROW(lg) + 16 * J_ + ln);
             double a[4];
 #pragma unroll
-            for (int q = 0; q < 4; q++) a[q] = y[4 * q * ld];  // A operand: m = ln (column of block j), k = lg + 4 q
+            for (int q = 0; q < 4; q++) a[q] = y[q * Q4];  // A operand: m = ln (column of block j), k = lg + 4 q
             double4_t acc = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
             for (int q = 0; q < 4; q++) acc = mfma_f64(a[q], tn[q], acc);
-            double *o = Op + (ln * ld + 16 * J_ + lg);
+            double *o = Op + (FBROW(ln) + 16 * J_ + lg);
 #pragma unroll
             for (int q = 0; q < 4; q++) o[4 * q] = acc[q];
           }
@@ -511,10 +575,18 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
     // runs beside the update.
     const bool la = done == 16 && kb + 1 < nb;
     if (la && is_ge) {
-      if (lane < 16) cmaxf[16 * (par ^ 1) + lane] = 0.0f;
 #ifndef FB_SKIP_GE  // (timing experiments only: wrong results)
+#ifdef FB_NO_SPEC
+      if (lane < 16) cmaxf[16 * (par ^ 1) + lane] = 0.0f;
       fb_eliminate_block<LD>(Gb, Tb + 272 * (par ^ 1), Xq + 32 + 16 * (par ^ 1), Xq + 16 * (par ^ 1),
                              dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1), badin + (par ^ 1), alpha, pert, 0, lane);
+#else
+      double eg[16], ed, enlp;
+      fb_elim_resume(eg, ed, enlp, Gb, lane);
+      fb_elim_steps<LD, FB_SPEC_STEPS, 16>(eg, ed, enlp, spec_badm, Xq + 16 * (par ^ 1), dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1), alpha, 0, lane);
+      fb_elim_finish<LD>(eg, spec_badm, Tb + 272 * (par ^ 1), Xq + 32 + 16 * (par ^ 1), dvals + 16 * (par ^ 1), dinvs + 16 * (par ^ 1),
+                         badin + (par ^ 1), pert, 0, lane);
+#endif
 #endif
 #pragma unroll
       for (int s = 0; s < NS; s++) R[s] = double4_t{0.0, 0.0, 0.0, 0.0};
@@ -527,11 +599,11 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       for (int s = 0; s < NS; s++) {
         if (!SLOT_IN(m_live, s)) continue;
         const int I_ = SLOT_I(s), J_ = SLOT_J(s);
-        const double *ab = J_ == kb ? Tnq + (lg * ld + ln) : Op + (lg * ld + 16 * J_ + ln);
-        const double *lb = I_ == kb ? Ldq + (lg * ld + ln) : Lb + (lg * ld + 16 * I_ + ln);
+        const double *ab = J_ == kb ? Tnq + (FBROW(lg) + ln) : Op + (FBROW(lg) + 16 * J_ + ln);
+        const double *lb = I_ == kb ? Ldq + (FBROW(lg) + ln) : Lb + (FBROW(lg) + 16 * I_ + ln);
         double a[4], l[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) a[q] = ab[4 * q * ld], l[q] = lb[4 * q * ld];
+        for (int q = 0; q < 4; q++) a[q] = ab[q * Q4], l[q] = lb[q * Q4];
         double4_t acc = R[s];
         if (J_ == kb) {  // the eliminated columns of the panel's own block turn into columns of M: from zero
 #pragma unroll
@@ -568,15 +640,15 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         km[q] = sp >= off && sp < done;
         const double t = Tp[sp * 17 + ln];
         town[q] = (!km[q] || (ln > sp && ln < done)) ? 0.0 : t;
-        ldg[q] = km[q] ? Ldq[sp * ld + ln] : 0.0;
+        ldg[q] = km[q] ? Ldq[FBROW(sp) + ln] : 0.0;
       }
 #pragma unroll
       for (int s = 0; s < NS; s++) {
         if (!SLOT_IN(m_live, s)) continue;
         const int I_ = SLOT_I(s), J_ = SLOT_J(s);
         const bool own = J_ == kb, dgr = I_ == kb;
-        const double *o = Op + (lg * ld + 16 * J_ + ln);
-        const double *lb = Lb + (lg * ld + 16 * I_ + ln);
+        const double *o = Op + (FBROW(lg) + 16 * J_ + ln);
+        const double *lb = Lb + (FBROW(lg) + 16 * I_ + ln);
         double4_t acc = R[s];
         if (own) {  // the columns of the accepted pivots turn into columns of M: from zero
 #pragma unroll
@@ -585,7 +657,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
         double *pc = P + ((16 * kb + lg) * Fi + 16 * I_ + ln);
 #pragma unroll
         for (int q = 0; q < 4; q++) {
-          const double ta = o[4 * q * ld], tl = lb[4 * q * ld];
+          const double ta = o[q * Q4], tl = lb[q * Q4];
           if (own && !dgr && km[q] && 16 * I_ + ln < p) pc[4 * q * Fi] = -tl;  // L11 columns of the accepted pivots
           const double a = own ? town[q] : (km[q] ? ta : 0.0);
           const double l = dgr ? ldg[q] : (km[q] ? tl : 0.0);
@@ -600,7 +672,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
       if (tid < 256) {
         const int sp = tid >> 4, rr = tid & 15;
         if (sp >= off && sp < done && rr > sp && 16 * kb + rr < p)
-          P[(16 * kb + sp) * Fi + 16 * kb + rr] = -Ldq[sp * ld + rr];
+          P[(16 * kb + sp) * Fi + 16 * kb + rr] = -Ldq[FBROW(sp) + rr];
       }
       if (tid >= off && tid < done) dv[2 * (16 * kb + tid)] = dip[tid], dv[2 * (16 * kb + tid) + 1] = 0.0, pt[16 * kb + tid] = 0;
     }

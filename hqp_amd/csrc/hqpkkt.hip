@@ -208,11 +208,13 @@ struct hqpkkt {
   // pivot blocks of the general fronts: k_factor_blk (round 4) unless HQPKKT_OLD_FD asks for k_factor_diag;
   // per schedule and tree level the largest pivot count among the general fronts of the level
   bool old_fd = false;
-  std::vector<int> level_maxp[2];
+  std::vector<int> level_maxp[2], level_maxb[2];
   // the device-resident interior-point loops: cancelled multiplier pivots are replaced (kernels.hip.h, TINY_REPLACE_WORD)
   // only in the SECOND attempt of a run whose first attempt - without the replacement, i.e. with the factors the
   // reference's own loop gets from this plugin through the shim - ended "degenerate" or singular
   bool tiny_replace_in_loop = false;
+  int xcd_ps = -1, xcd_su = -1;  // chunk of the border kernels' work lists per XCD (kernels.hip.h, xcd_order); -1: from the level's fronts; 0: list order (HQPKKT_XCD_PS / _SU)
+  int su1_max = 768;   // levels of at most this many 64 x 64 update tiles run k_schur_update with 32 x 16 per wave (HQPKKT_SU1_MAX)
   // the top levels of the tree solved in one launch (solve_top.hip.h): fronts of the levels >= top_lt, root first
   int top_n = 0, top_lt = 1 << 30, top_ns = 3;  // top_ns: 3 = k_solve_top<3, 11>, 4 = <4, 10>
   size_t top_lds = 0;
@@ -507,15 +509,20 @@ static int upload(hqpkkt_t *h) {
   h->lds_panel = (PS_LD * mp + 1 + 2 * mp) * sizeof(double) + mp * sizeof(int);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
   h->old_fd = getenv("HQPKKT_OLD_FD") != nullptr && mp <= 128;
+  if (getenv("HQPKKT_SU1_MAX")) h->su1_max = atoi(getenv("HQPKKT_SU1_MAX"));
+  if (getenv("HQPKKT_XCD_PS")) h->xcd_ps = atoi(getenv("HQPKKT_XCD_PS"));
+  if (getenv("HQPKKT_XCD_SU")) h->xcd_su = atoi(getenv("HQPKKT_XCD_SU"));
   if (!h->old_fd) h->lds_diag = 0;
   const size_t lds_blk = fb_lds_bytes((int)mp);
   if (h->lds_diag > 160 * 1024 || h->lds_bwdb > 160 * 1024 || lds_blk > 160 * 1024) return HQPKKT_E_MEM;
   for (int w = 0; w < 2; w++) {
     const Analysis::Sched &S = an.sched[w];
-    h->level_maxp[w].assign(an.nlevels, 0);
+    h->level_maxp[w].assign(an.nlevels, 0), h->level_maxb[w].assign(an.nlevels, 0);
     for (int l = 0; l < an.nlevels && S.nnodes; l++)
-      for (int q = S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l]; q < S.level_ptr[l + 1]; q++)
+      for (int q = S.level_ptr[l] + S.level_fsmall[l] + S.level_small[l]; q < S.level_ptr[l + 1]; q++) {
         h->level_maxp[w][l] = std::max(h->level_maxp[w][l], an.npiv[S.level_nodes[q]]);
+        h->level_maxb[w][l] = std::max(h->level_maxb[w][l], an.nbor[S.level_nodes[q]]);
+      }
   }
   {  // the counters of the polled exchanges: [0] solves, [1] factorisations so far (k_rhs_*, the assembly kernels count)
     std::vector<int> two(2, 0);
@@ -819,14 +826,23 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
                                                  h->flags.p + 1, h->upd.p)));
       }
       const int ns = S.slab_ptr[l + 1] - S.slab_ptr[l];
-      if (ns > 0)
-        KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<ns, 256, h->lds_panel, s>>>(T, D.slabs.p + 2 * (size_t)S.slab_ptr[l],
+      // the work lists go over the XCDs in chunks of about half a front's items (kernels.hip.h, xcd_order; measured on C2:
+      // 1.875 -> 1.826 ms per factor + solve; whole fronts per chunk 1.830, contiguous ranges per XCD 1.915)
+      const int lmb = h->level_maxb[which][l];
+      const int xps = h->xcd_ps >= 0 ? h->xcd_ps : std::max(1, (lmb + 31) / 32);
+      const int xtt = (lmb + 63) / 64, xsu = h->xcd_su >= 0 ? h->xcd_su : std::max(1, xtt * (xtt + 1) / 4);
+      if (ns > 0)  // (the schedule lists 32-row slabs; the kernel takes 16 rows per workgroup)
+        KLAUNCH(h, KC_PANEL_SOLVE, k_panel_solve<<<2 * ns, 256, h->lds_panel, s>>>(T, D.slabs.p + 2 * (size_t)S.slab_ptr[l],
                                                     h->panel.p, h->xar.p, h->dinv.p, h->ptype.p,
-                                                    h->lperm.p, h->linv.p, h->linv_off.p, h->upd.p));
+                                                    h->lperm.p, h->linv.p, h->linv_off.p, h->upd.p, xps));
       const int nt = S.upd_big_ptr[l] - S.upd_tile_ptr[l], ntb = S.upd_tile_ptr[l + 1] - S.upd_big_ptr[l];
-      if (nt > 0)
-        KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<<<nt, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_tile_ptr[l],
-                                          h->panel.p, h->xar.p, h->upd.p));
+      // a wave holds 32 x 32 of a tile while a level fills the chip; 32 x 16 (two workgroups per tile) on the thin levels above
+      if (nt > 0 && nt > h->su1_max)
+        KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<2><<<nt, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_tile_ptr[l],
+                                          h->panel.p, h->xar.p, h->upd.p, xsu));
+      else if (nt > 0)
+        KLAUNCH(h, KC_SCHUR_UPDATE, k_schur_update<1><<<2 * nt, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_tile_ptr[l],
+                                          h->panel.p, h->xar.p, h->upd.p, 2 * xsu));
       if (ntb > 0)
         KLAUNCH(h, KC_SCHUR_UPDATE, (k_schur_update_big<2, 2, 4, 4, 2, 2><<<ntb, 256, 0, s>>>(T, D.upd_tiles.p + 3 * (size_t)S.upd_big_ptr[l],
                                           h->panel.p, h->xar.p, h->upd.p)));
@@ -1214,6 +1230,55 @@ static int guarded(F body) {
   } catch (...) {
     return HQPKKT_E_INTERN;
   }
+}
+
+// The attempts of a device-resident loop (hqpkkt_mehrotra / hqpkkt_franke; `loop` reads the caller's `opts` through the
+// reference it captured).  ONE rule ("Pivoting"): the factors are first those the reference's own
+// loop gets from this plugin through the shim - a multiplier pivot that cancelled to rounding level is used as it
+// stands -, and STATIC PIVOTING is the fall-back: a run that ends "degenerate" (or singular) is made again, from a cold
+// start, with such pivots replaced (kernels.hip.h, TINY_REPLACE_WORD; what the reference's own PARDISO plugin is
+// configured to do, hqp/Hqp_IpPARDISO.C:138-142).  hqpkkt_ip_result.attempts says which happened; iterations, plugin
+// calls and device time are the totals over the attempts.  HQPKKT_TINY_IN_LOOP=1 / =0 (campaign switches): static
+// pivoting from the first attempt on / never.
+template <class Loop>
+static int ip_attempts(hqpkkt_t *h, const hqpkkt_ip_opts *&opts, hqpkkt_ip_result *res, Loop loop) {
+  hqpkkt_ip_opts again;
+  auto cold = [&]() {  // (a first attempt has used up what a hot start would start from; "2" keeps what the NEXT call needs)
+    if (opts && opts->hot_start == 1) {
+      again = *opts;
+      again.hot_start = 2;
+      opts = &again;
+    }
+  };
+  // (a polled launch that gave up has switched the handle to the per-level launches: the loop runs once more - from a cold
+  // start: the aborted pass has left its own iterates in the loop's vectors and may have overwritten the hot-start candidates)
+  auto attempt = [&]() {
+    int rc = guarded(loop);
+    if (rc == HQPKKT_E_POLL) {
+      cold();
+      if (h) h->ip_hot_valid = false, h->fr_hot_valid = false;
+      rc = guarded(loop);
+    }
+    return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
+  };
+  static const char *const pol = getenv("HQPKKT_TINY_IN_LOOP");
+  if (h) h->tiny_replace_in_loop = pol && atoi(pol) == 1;
+  int rc = attempt();
+  if (res && rc == 0) res->attempts = 1;
+  if (h && res && !h->tiny_replace_in_loop && !(pol && atoi(pol) == 0) && (rc == HQPKKT_E_SING || (rc == 0 && res->result == 4))) {
+    const hqpkkt_ip_result first = *res;  // (all zero but `result` when the first attempt ended with E_SING before its finish())
+    const bool counted = rc == 0;
+    h->tiny_replace_in_loop = true;
+    cold();
+    rc = attempt();
+    h->tiny_replace_in_loop = false;
+    if (rc == 0) {
+      res->attempts = 2;
+      if (counted)
+        res->iters += first.iters, res->n_factor += first.n_factor, res->n_solve += first.n_solve, res->ms_total += first.ms_total;
+    }
+  }
+  return rc;
 }
 
 extern "C" {
@@ -1652,7 +1717,11 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
   // eps, hqp/Hqp_IpsFranke.C:372)
   // (not behind a cancelled pivot that was USED as it was - soft_tiny alone: five rounds leave such factors at a residual
   // that says "singular", fifteen can drag a consistent singular system below mat_eps, and the reference reports it)
-  const int max_rounds = h->st.n_perturbed > 0 ? 15 : 5;
+  // Only inside the device-resident loops (h->lazy): a caller's own hqpkkt_solve - the reference's solvers through the
+  // shim - gets the reference's five rounds and with them the residual the reference's plugin contract describes
+  // (HQPKKT_REFINE_MAX overrides both for experiments).  Rounds beyond five show in hqpkkt_stats.refine_rounds.
+  static const int refine_max_env = getenv("HQPKKT_REFINE_MAX") ? atoi(getenv("HQPKKT_REFINE_MAX")) : 0;
+  const int max_rounds = refine_max_env > 0 ? refine_max_env : (h->st.n_perturbed > 0 && h->lazy) ? 15 : 5;
   for (int it = 0; it < max_rounds && res > target; it++) {
     if (it >= 5 && !(res < 0.5 * res_acc_prev)) break;  // beyond the reference's five: only while a round still halves the residual
     res_last = res;
@@ -2129,31 +2198,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     if (m > 0) h->ip_hot_valid = keep_hot;
     return finish(result);
   };
-  // (a polled launch that gave up has switched the handle to the per-level launches: the loop runs once more)
-  auto attempt = [&]() {
-    int rc = guarded(loop);
-    if (rc == HQPKKT_E_POLL) rc = guarded(loop);
-    return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
-  };
-  // First with the factors as the reference's own loop gets them from this plugin through the shim; a run that ends
-  // "degenerate" (or singular) is made again with cancelled multiplier pivots replaced (hqpkkt::tiny_replace_in_loop;
-  // HQPKKT_TINY_IN_LOOP=1: replaced from the first attempt on, round 5's first policy; =0: never)
-  static const char *const pol = getenv("HQPKKT_TINY_IN_LOOP");
-  if (h) h->tiny_replace_in_loop = pol && atoi(pol) == 1;
-  int rc = attempt();
-  if (h && res && !h->tiny_replace_in_loop && !(pol && atoi(pol) == 0) && (rc == HQPKKT_E_SING || (rc == 0 && res->result == 4))) {
-    h->tiny_replace_in_loop = true;
-    // (from a cold start: the first attempt has used up what a hot start would start from; "2" keeps what the NEXT one needs)
-    hqpkkt_ip_opts again;
-    if (opts) {
-      again = *opts;
-      if (again.hot_start == 1) again.hot_start = 2;
-      opts = &again;
-    }
-    rc = attempt();
-    h->tiny_replace_in_loop = false;
-  }
-  return rc;
+  return ip_attempts(h, opts, res, loop);
 }
 
 // ---- device-resident Franke loop ----------------------------------------------
@@ -2422,31 +2467,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     h->fr_rhomin = rhomin;
     return finish(result);
   };
-  // (a polled launch that gave up has switched the handle to the per-level launches: the loop runs once more)
-  auto attempt = [&]() {
-    int rc = guarded(loop);
-    if (rc == HQPKKT_E_POLL) rc = guarded(loop);
-    return rc == HQPKKT_E_POLL ? HQPKKT_E_DEVICE : rc;
-  };
-  // First with the factors as the reference's own loop gets them from this plugin through the shim; a run that ends
-  // "degenerate" (or singular) is made again with cancelled multiplier pivots replaced (hqpkkt::tiny_replace_in_loop;
-  // HQPKKT_TINY_IN_LOOP=1: replaced from the first attempt on, round 5's first policy; =0: never)
-  static const char *const pol = getenv("HQPKKT_TINY_IN_LOOP");
-  if (h) h->tiny_replace_in_loop = pol && atoi(pol) == 1;
-  int rc = attempt();
-  if (h && res && !h->tiny_replace_in_loop && !(pol && atoi(pol) == 0) && (rc == HQPKKT_E_SING || (rc == 0 && res->result == 4))) {
-    h->tiny_replace_in_loop = true;
-    // (from a cold start: the first attempt has used up what a hot start would start from; "2" keeps what the NEXT one needs)
-    hqpkkt_ip_opts again;
-    if (opts) {
-      again = *opts;
-      if (again.hot_start == 1) again.hot_start = 2;
-      opts = &again;
-    }
-    rc = attempt();
-    h->tiny_replace_in_loop = false;
-  }
-  return rc;
+  return ip_attempts(h, opts, res, loop);
 }
 
 int hqpkkt_get_sbw(const hqpkkt_t *h, int *sbw) {
@@ -3038,6 +3059,11 @@ int hqpkkt_debug_stamps(hqpkkt_t *h, int *out) {
 int hqpkkt_debug_fb_stamps(int *out) {
   HIPCHK(hipDeviceSynchronize());
   HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(kktdev::g_fb_stamps), sizeof(int) * 256));
+  return 0;
+}
+int hqpkkt_debug_ps_stamps(int *out) {
+  HIPCHK(hipDeviceSynchronize());
+  HIPCHK(hipMemcpyFromSymbol(out, HIP_SYMBOL(kktdev::g_ps_stamps), sizeof(int) * 64));
   return 0;
 }
 int hqpkkt_debug_gj_stamps(int *out) {

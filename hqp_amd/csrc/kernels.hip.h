@@ -274,12 +274,29 @@ k_assemble_simple(int nent, const int *__restrict__ src, const int *__restrict__
   __shared__ double red[4];
   double mx = 0.0;
   if (blockIdx.x == 0 && threadIdx.x == 0 && epoch) *epoch += 1;  // (see k_entry_values)
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nent; e += gridDim.x * blockDim.x) {
-    const int sg = src[e];
-    const double raw = vals[sg & 0x7fffffff] * wt[wi[e]];
-    const double v = (sg < 0 ? -raw : raw) * sc[ent_a[e]] * sc[ent_b[e]];
-    panel[ent_dst[e]] = v;
-    mx = fmax(mx, fabs(v));
+  // four entries per thread and trip: their records travel together, then their gathers (one entry per trip made every
+  // trip two dependent round trips to memory: 77 us for the 4.9e6 entries of C2, round 6: see profiles/r06_c2_timeline.txt)
+  const int stride = gridDim.x * blockDim.x;
+  for (int e0 = blockIdx.x * blockDim.x + threadIdx.x; e0 < nent; e0 += 4 * stride) {
+    int sg[4], wk[4], ea[4], eb[4];
+    long long ed[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const int e = min(e0 + k * stride, nent - 1);  // (behind the last entry: the last one again, not stored)
+      sg[k] = src[e], wk[k] = wi[e], ea[k] = ent_a[e], eb[k] = ent_b[e], ed[k] = ent_dst[e];
+    }
+    double va[4], wa[4], sa[4], sb[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) va[k] = vals[sg[k] & 0x7fffffff], wa[k] = wt[wk[k]], sa[k] = sc[ea[k]], sb[k] = sc[eb[k]];
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+      const double raw = va[k] * wa[k];
+      const double v = (sg[k] < 0 ? -raw : raw) * sa[k] * sb[k];
+      if (e0 + k * stride < nent) {
+        panel[ed[k]] = v;
+        mx = fmax(mx, fabs(v));
+      }
+    }
   }
   mx = wave_max(mx);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
@@ -1820,32 +1837,76 @@ k_solve_bwd_small(DevTree T, const int *__restrict__ level_nodes, const double *
 // MFMA operand layout (verified by hqpkkt_selftest_mfma): A: lane l holds
 // A[l&15][l>>4]; B: B[l>>4][l&15]; C/D: col = l&15, row = (l>>4) + 4*reg.
 
-static const int PS_LD = 33;  // doubles per column of the slab in LDS
+static const int PS_LD = 33;  // doubles per column of the RESULT slab in LDS (what the launch sizes its LDS by)
+#ifdef HQPKKT_STAMPS
+// instrumented build: s_memtime of lane 0 of every wavefront of workgroup 0 (the last launch wins: the top level)
+__device__ int g_ps_stamps[64];
+#define PSSTAMP(j)                                                                                           \
+  do {                                                                                                       \
+    if (blockIdx.x == 0 && (threadIdx.x & 63) == 0) g_ps_stamps[16 * (threadIdx.x >> 6) + (j)] = (int)__builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define PSSTAMP(j)
+#endif
+// Round 6: 16 border rows per workgroup (32 before: half the chain of matrix products per wavefront, twice the
+// workgroups - a level of a few fronts costs the latency of ONE workgroup, 25 us per level on C2 before), and ONE compact
+// loop over the wavefront's batches (column tile, 64 pivots of its k range):
+//  - the operands of the NEXT batch out of M travel while the products of this one run (loads without a condition,
+//    addresses clamped into the block, so that the compiler counts them; the sequence goes tile by tile, a tile's k
+//    ranges ascending: same bits as before);
+//  - a finished tile goes from the accumulator straight into the RESULT image in LDS - a region of its own beside the
+//    INPUT image, so no barrier in between and ONE accumulator: the loop's body exists once, a few hundred
+//    instructions.  That matters more than anything else here: a version with the products unrolled over the
+//    wavefront's four tiles and two register sets (50 KB of code, every line of it executed once per wavefront) spent
+//    25 us of its 35 in the products, waiting for INSTRUCTIONS (stamps: tools/stamps_ps.py, profiles/r06_ps_stamps.txt).
+// Input image: 16 doubles per pivot (a ds_read_b64 of the MFMA A operand touches k-rows t .. t + 3: 64 consecutive
+// doubles); result image: 17 per pivot (the waves store with the column index running over the lanes).
+// Workgroups of a launch are dealt round-robin over the eight XCDs (each with an L2 of its own): with the list of work
+// items in launch order, the 16 slabs (or the tiles) of ONE front would land on all eight and every XCD would pull
+// every front's M (L21, X) through its 4 MB.  (Speed only - nothing depends on where a workgroup runs.  A contiguous
+// range of the list per XCD was measured slower than the list order: a level's fronts are listed by falling size.)
+// Chunks of `mode` consecutive list entries (about the work of one front) go to one XCD, consecutive chunks to consecutive
+// XCDs: workgroup bid of a group of 8 ch takes entry (group, chunk bid % 8, position bid / 8 inside it); the entries
+// behind the last whole group keep their number.  mode 0: list order, > 0: chunks of that size
+__device__ __forceinline__ int xcd_order(int bid, int nwg, int mode) {
+  if (mode <= 0) return bid;
+  const int grp = 8 * mode, g = bid / grp;
+  if ((g + 1) * grp > nwg) return bid;
+  const int within = bid - g * grp;
+  return g * grp + mode * (within & 7) + (within >> 3);
+}
+static const int PS_ROWS = 16;
 __global__ void __launch_bounds__(256, 3)
 k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ panel,
               double *__restrict__ xar, const double *__restrict__ dinv,
               const int *__restrict__ ptype, const int *__restrict__ lperm,
               const double *__restrict__ linv, const long long *__restrict__ linv_off,
-              const double *__restrict__ upd) {
+              const double *__restrict__ upd, int xcd_mode) {
+  constexpr int ROWS = PS_ROWS;
+  constexpr int NG = 256 / ROWS;     // column groups of the staging pass
+  constexpr int NU = 128 / NG;       // columns per thread and trip of 128
+  constexpr int LDO = ROWS + 1;      // result image
   extern __shared__ __attribute__((aligned(16))) double lds[];
-  const int node = slabs[2 * blockIdx.x], slab = slabs[2 * blockIdx.x + 1];
+  PSSTAMP(0);
+  const int bid = xcd_order(blockIdx.x, gridDim.x, xcd_mode);
+  const int sidx = bid >> 1;  // (the host lists 32-row slabs: two workgroups each)
+  const int node = slabs[2 * sidx], slab = slabs[2 * sidx + 1];
   const int p = T.npiv[node], b = T.nbor[node];
+  const int r0 = slab * 32 + 16 * (bid & 1);
+  if (r0 >= b || p == 0) return;  // (the second half of a slab of <= 16 rows; a front without pivots has no columns here)
   const long long F = p + b;
   const int e0 = T.piv_start[node];
   double *P = panel + T.panel_off[node];
   double *X = xar + T.x_off[node];
   const double *W = linv + linv_off[node];
-  const int r0 = slab * 32;
-  const int tid = threadIdx.x, r = tid & 31, g = tid >> 5;
+  const int tid = threadIdx.x, r = tid & (ROWS - 1), g = tid / ROWS;
   const int wave = tid >> 6, lane = tid & 63;
   const bool live = (r0 + r) < b;
-  // 32 x p, s[r + PS_LD * k]: an odd number of doubles per column, so that the results, which the waves write with
-  // the COLUMN index running over the lanes, fall into different banks (with 32 the 16 lanes of a store hit one bank:
-  // 74 % of the kernel's LDS cycles were bank conflicts, profiles/r04_pmc_tree.txt)
-  double *s = lds;
+  double *s = lds;                 // input image: ROWS x p
+  double *so = s + ROWS * p;       // result image: LDO x p
   // pivot data (type, D^-1) of all columns: to LDS up front, together with the
   // permutation, so that the epilogue has no dependent global loads
-  double *pd = s + PS_LD * p + (p & 1);  // 2 p (16-byte aligned)
+  double *pd = so + LDO * p + (p & 1);  // 2 p (16-byte aligned)
   int *pty = (int *)(pd + 2 * p);  // p
   // the children list and the first two children (a dependent chain of scalar loads: requested before everything else)
   const int cc0 = T.child_ptr[node], cc1 = T.child_ptr[node + 1];
@@ -1855,17 +1916,18 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
     pd[2 * tid] = dinv[2 * (e0 + tid)];
     pd[2 * tid + 1] = dinv[2 * (e0 + tid) + 1];
   }
+  PSSTAMP(1);
   for (int c0 = 0; c0 < p; c0 += 128) {  // 128 columns per trip (fronts of up to 256 pivots: two trips)
-    int lc[16];  // 16 columns per thread and trip, loads batched
+    int lc[NU];  // NU columns per thread and trip, loads batched
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int kcol = c0 + g + 8 * u;
+    for (int u = 0; u < NU; u++) {
+      const int kcol = c0 + g + NG * u;
       lc[u] = kcol < p ? lperm[e0 + kcol] : 0;
     }
-    double v[16];
+    double v[NU];
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int kcol = c0 + g + 8 * u;
+    for (int u = 0; u < NU; u++) {
+      const int kcol = c0 + g + NG * u;
       v[u] = (live && kcol < p) ? P[(long long)lc[u] * F + p + r0 + r] : 0.0;
     }
     // + the children's update blocks at (border row, pivot column): two children at a time - their index maps
@@ -1877,92 +1939,97 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
       const int *ivA = T.pinv + T.pinv_off[cA], *ivB = T.pinv + T.pinv_off[cB];
       const double *UA = upd + T.upd_off[cA], *UB = upd + T.upd_off[cB];
       const int ciA = live ? ivA[p + r0 + r] : -1, ciB = (live && two) ? ivB[p + r0 + r] : -1;
-      int cjA[16], cjB[16];
+      int cjA[NU], cjB[NU];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
-        const bool on = c0 + g + 8 * u < p;
+      for (int u = 0; u < NU; u++) {
+        const bool on = c0 + g + NG * u < p;
         cjA[u] = on ? ivA[lc[u]] : -1, cjB[u] = (on && two) ? ivB[lc[u]] : -1;
       }
-      double gA[16], gB[16];
+      double gA[NU], gB[NU];
 #pragma unroll
-      for (int u = 0; u < 16; u++) {
+      for (int u = 0; u < NU; u++) {
         gA[u] = (ciA >= 0 && cjA[u] >= 0) ? UA[(long long)cjA[u] * bcA + ciA] : 0.0;
         gB[u] = (ciB >= 0 && cjB[u] >= 0) ? UB[(long long)cjB[u] * bcB + ciB] : 0.0;
       }
 #pragma unroll
-      for (int u = 0; u < 16; u++) v[u] = (v[u] + gA[u]) + gB[u];  // (children in slot order, as one by one)
+      for (int u = 0; u < NU; u++) v[u] = (v[u] + gA[u]) + gB[u];  // (children in slot order, as one by one)
     }
 #pragma unroll
-    for (int u = 0; u < 16; u++) {
-      const int kcol = c0 + g + 8 * u;
-      if (kcol < p) s[r + PS_LD * kcol] = v[u];
+    for (int u = 0; u < NU; u++) {
+      const int kcol = c0 + g + NG * u;
+      if (kcol < p) s[r + ROWS * kcol] = v[u];
     }
   }
+  PSSTAMP(2);
   __syncthreads();
+  PSSTAMP(3);
   const int nbc = (p + 15) >> 4;
   const int ml = lane & 15, kl = lane >> 4;
-  double4_t acc[4][2];  // [column tile of this wave][row half]
-  int ctile[4];
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    // column tiles from the most expensive down, dealt 0 1 2 3 3 2 1 0 0 1 2 3 3 2 1 0 to the waves
-    const int idx = 8 * (u >> 1) + ((u & 1) == 0 ? wave : 7 - wave);
-    const int ct = nbc - 1 - idx;
-    ctile[u] = ct;
-    acc[u][0] = double4_t{0.0, 0.0, 0.0, 0.0};
-    acc[u][1] = double4_t{0.0, 0.0, 0.0, 0.0};
-    if (ct < 0) continue;  // wave-uniform
+  // column tiles from the most expensive down, dealt 0 1 2 3 3 2 1 0 0 1 2 3 3 2 1 0 to the waves: slot u of this wave
+  auto ct_of = [&](int u) { return nbc - 1 - (8 * (u >> 1) + ((u & 1) == 0 ? wave : 7 - wave)); };
+  // the M operands of (column tile ct, k-steps 16 hb .. 16 hb + 15: 64 pivots): M(c, t) = W[t p + c].  NO select on the
+  // loaded value (hipcc turns "condition ? loaded : 0" into a branch around the load and waits for every pair of
+  // loads): addresses clamped into the tile's rows of M - finite numbers, multiplied by an A operand that is zero
+  // for the k-steps behind the tile's range; columns behind the last pivot give results nobody stores.
+  auto load_b = [&](double (&bv)[16], int ct, int hb) {
     const int c0 = 16 * ct, tend = min(p, c0 + 16);
-    const bool con = c0 + ml < p;
-    // the tile's M operands in batches of 16 k-steps (64 pivots): all loads of a
-    // batch are in flight together, then the products with the slab in LDS
-    // (batches of 32 were measured slower: 0.50 against 0.47 ms over the C2 levels)
+    const double *wc = W + min(c0 + ml, p - 1);
+#pragma unroll
+    for (int q = 0; q < 16; q++) bv[q] = wc[(long long)min(64 * hb + 4 * q + kl, tend - 1) * p];
+  };
+  {
+    double bv[16], bvn[16];
+    int u = 0, hb = 0, ct = ct_of(0);
+    double4_t acc = {0.0, 0.0, 0.0, 0.0};
+    if (ct >= 0) load_b(bvn, ct, 0);
 #pragma unroll 1
-    for (int half = 0; half < 4; half++) {
-      if (64 * half >= tend) break;  // wave-uniform
-      double bv[16];
+    while (ct >= 0) {  // (the tiles that exist are a prefix of the wave's slots; at most four: fronts of up to 256 pivots)
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        const int t = 64 * half + 4 * q + kl;
-        bv[q] = (con && t < tend) ? W[(long long)t * p + c0 + ml] : 0.0;
-      }
+      for (int q = 0; q < 16; q++) bv[q] = bvn[q];
+      const int tend = min(p, 16 * ct + 16);
+      // the batch after this one (behind the last one: this one again, from L1, unused)
+      const bool same = 64 * (hb + 1) < tend;
+      const int un = same ? u : u + 1;
+      const int ctn = same ? ct : (un < 4 ? ct_of(un) : -1), hn = same ? hb + 1 : 0;
+      load_b(bvn, ctn < 0 ? ct : ctn, ctn < 0 ? hb : hn);
 #pragma unroll
-      for (int q = 0; q < 16; q++) {
-        if (64 * half + 4 * q < tend) {  // wave-uniform
-          const int t = 64 * half + 4 * q + kl;
-          const bool ton = t < tend;
-          const double a0 = ton ? s[ml + PS_LD * t] : 0.0;
-          const double a1 = ton ? s[16 + ml + PS_LD * t] : 0.0;
-          acc[u][0] = mfma_f64(a0, bv[q], acc[u][0]);
-          acc[u][1] = mfma_f64(a1, bv[q], acc[u][1]);
+      for (int q4 = 0; q4 < 4; q4++) {
+        if (64 * hb + 16 * q4 < tend) {  // wave-uniform: 16 pivots at a time (their four LDS reads in flight together)
+          double a[4];
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++) a[qq] = s[ml + ROWS * min(64 * hb + 16 * q4 + 4 * qq + kl, p - 1)];
+#pragma unroll
+          for (int qq = 0; qq < 4; qq++) {
+            const int t = 64 * hb + 16 * q4 + 4 * qq + kl;
+            acc = mfma_f64(t < tend ? a[qq] : 0.0, bv[4 * q4 + qq], acc);
+          }
         }
       }
+      if (!same) {  // the tile is complete: x(row kl + 4 q, column 16 ct + ml)
+        const int c = 16 * ct + ml;
+        if (c < p) {
+#pragma unroll
+          for (int q = 0; q < 4; q++) so[kl + 4 * q + LDO * c] = acc[q];
+        }
+        acc = double4_t{0.0, 0.0, 0.0, 0.0};
+      }
+      u = un, hb = hn, ct = ctn;
     }
   }
-  __syncthreads();  // everybody has read s
-#pragma unroll
-  for (int u = 0; u < 4; u++) {
-    const int ct = ctile[u];
-    if (ct < 0) continue;
-    const int c = 16 * ct + ml;
-    if (c < p) {
-#pragma unroll
-      for (int h = 0; h < 2; h++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) s[16 * h + kl + 4 * q + PS_LD * c] = acc[u][h][q];
-    }
-  }
+  PSSTAMP(4);
   __syncthreads();
+  PSSTAMP(6);
   if (!live) return;
-  for (int kcol = g; kcol < p; kcol += 8) {
-    const double x = s[r + PS_LD * kcol];
+  for (int kcol = g; kcol < p; kcol += NG) {
+    const double x = so[r + LDO * kcol];
     const int ty = pty[kcol];
     // partner column of a 2x2 pivot (kcol+1 / kcol-1)
     const int kp = ty == 2 ? kcol - 1 : min(kcol + 1, p - 1);
-    const double l = ty == 0 ? x * pd[2 * kcol] : x * pd[2 * kcol] + s[r + PS_LD * kp] * pd[2 * kcol + 1];
+    const double l = ty == 0 ? x * pd[2 * kcol] : x * pd[2 * kcol] + so[r + LDO * kp] * pd[2 * kcol + 1];
     X[(long long)kcol * b + r0 + r] = x;
     P[(long long)kcol * F + p + r0 + r] = l;
   }
+  PSSTAMP(7);
 }
 
 // ----------------------------------------------------- Schur update (MFMA f64)
@@ -1971,65 +2038,98 @@ k_panel_solve(DevTree T, const int *__restrict__ slabs, double *__restrict__ pan
 // A operand: lane l holds A[l&15][l>>4]; B operand: B[l>>4][l&15];
 // C/D: 4 values per lane, col = l&15, row = (l>>4) + 4*reg  (f64 layout).
 
+// WJ = 2: one workgroup per 64 x 64 tile (a wave: 32 x 32); WJ = 1: two workgroups per tile, 64 x 32 each (a wave:
+// 32 x 16) - the thin upper levels of a tree, where a level costs the latency of one workgroup (half the chain of
+// products per wavefront).  Round 6: the operands of the next 16 pivots travel while the products of these 16 run
+// (two register sets, loads without a condition: clamped addresses, as in k_schur_update_big); until then every trip
+// of 32 pivots waited for its own loads.  Same products in the same order: same bits.
+template <int WJ>
 __global__ void __launch_bounds__(256, 3)
 k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restrict__ panel,
-               const double *__restrict__ xar, double *__restrict__ upd) {
-  const int node = tiles[3 * blockIdx.x], ti = tiles[3 * blockIdx.x + 1],
-            tj = tiles[3 * blockIdx.x + 2];
+               const double *__restrict__ xar, double *__restrict__ upd, int xcd_mode) {
+  static_assert(WJ == 1 || WJ == 2, "a wave holds 32 x 16 or 32 x 32");
+  const int bid = xcd_order(blockIdx.x, gridDim.x, xcd_mode);
+  const int bx = WJ == 2 ? bid : (bid >> 1);
+  const int node = tiles[3 * bx], ti = tiles[3 * bx + 1], tj = tiles[3 * bx + 2];
   const int p = T.npiv[node], b = T.nbor[node];
   const long long F = p + b;
   const double *L = panel + T.panel_off[node] + p;  // L21(i,k) = L[k*F + i]
   const double *X = xar + T.x_off[node];            // X(j,k)   = X[k*b + j]
   double *U = upd + T.upd_off[node];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  const int i0 = ti * 64 + (wave >> 1) * 32, j0 = tj * 64 + (wave & 1) * 32;
+  const int i0 = ti * 64 + (wave >> 1) * 32;
+  const int j0 = tj * 64 + (WJ == 2 ? (wave & 1) * 32 : (bid & 1) * 32 + (wave & 1) * 16);
   if (i0 >= b || j0 >= b || i0 + 31 < j0) return;  // wave-uniform
   const int lr = lane & 15, lk = lane >> 4;
-  double4_t acc[2][2];
+  double4_t acc[2][WJ];
 #pragma unroll
   for (int x = 0; x < 2; x++)
 #pragma unroll
-    for (int y = 0; y < 2; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
-  const int ia = i0 + lr, ib = i0 + 16 + lr, ja = j0 + lr, jb = j0 + 16 + lr;
-  // the children's contributions to this wave's part of U (there is no extend-add pass and
-  // U is not pre-zeroed: this kernel writes every entry once) travel while the products run
-  // the first trip's operands are requested before the index chase of the children's blocks
-  double a0[8], a1[8], b0[8], b1[8];
-  auto load = [&](int k0) {
+    for (int y = 0; y < WJ; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+  // rows / columns beyond the border read the last one (never written back), pivots beyond the last one read it again
+  // (zeroed by a select; whole k-steps beyond it are skipped)
+  const double *La[2], *Xb[WJ];
 #pragma unroll
-    for (int q = 0; q < 8; q++) {
-      const int k = k0 + 4 * q + lk;
-      const bool kin = k < p;
-      a0[q] = (kin && ia < b) ? L[(long long)k * F + ia] : 0.0;
-      a1[q] = (kin && ib < b) ? L[(long long)k * F + ib] : 0.0;
-      b0[q] = (kin && ja < b) ? X[(long long)k * b + ja] : 0.0;
-      b1[q] = (kin && jb < b) ? X[(long long)k * b + jb] : 0.0;
+  for (int x = 0; x < 2; x++) La[x] = L + min(i0 + 16 * x + lr, b - 1);
+#pragma unroll
+  for (int y = 0; y < WJ; y++) Xb[y] = X + min(j0 + 16 * y + lr, b - 1);
+  double av[2][4][2], bv[2][4][WJ];
+  auto load = [&](int set, int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int k = k0 + 4 * q + lk, kc = min(k, p - 1);
+      const long long ka = (long long)kc * F, kb = (long long)kc * b;
+#pragma unroll
+      for (int x = 0; x < 2; x++) {
+        const double v = La[x][ka];
+        av[set][q][x] = k < p ? v : 0.0;
+      }
+#pragma unroll
+      for (int y = 0; y < WJ; y++) {
+        const double v = Xb[y][kb];
+        bv[set][q][y] = k < p ? v : 0.0;
+      }
     }
   };
-  load(0);
-  double uold[2][2][4];
+  auto products = [&](int set, int k0) {
+#pragma unroll
+    for (int q = 0; q < 4; q++)
+      if (k0 + 4 * q < p) {  // wave-uniform
+        // D = X-tile * L-tile': the accumulator holds U(i,j) with i along the lanes, so that
+        // the writes of U below move 128-byte segments
+#pragma unroll
+        for (int x = 0; x < 2; x++)
+#pragma unroll
+          for (int y = 0; y < WJ; y++) acc[x][y] = mfma_f64(bv[set][q][y], av[set][q][x], acc[x][y]);
+      }
+  };
+  // the first operands are requested before the index chase of the children's blocks
+  if (p > 0) load(0, 0);
+  // the children's contributions to this wave's part of U (there is no extend-add pass and
+  // U is not pre-zeroed: this kernel writes every entry once) travel while the products run
+  double uold[2][WJ][4];
 #pragma unroll
   for (int x = 0; x < 2; x++)
 #pragma unroll
-    for (int y = 0; y < 2; y++)
+    for (int y = 0; y < WJ; y++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) uold[x][y][rg] = 0.0;
   for (int cc = T.child_ptr[node]; cc < T.child_ptr[node + 1]; cc++) {
     const int c = T.child_idx[cc], bc = T.nbor[c];
     const int *iv = T.pinv + T.pinv_off[c] + p;  // border part of the parent's front
     const double *Uc = upd + T.upd_off[c];
-    int ci[2], cj[2][4];  // this lane's two rows and eight columns in the child's numbering
+    int ci[2], cj[WJ][4];  // this lane's two rows and its columns in the child's numbering
 #pragma unroll
     for (int x = 0; x < 2; x++) ci[x] = (i0 + 16 * x + lr < b) ? iv[i0 + 16 * x + lr] : -1;
 #pragma unroll
-    for (int y = 0; y < 2; y++)
+    for (int y = 0; y < WJ; y++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) cj[y][rg] = (j0 + 16 * y + lk + 4 * rg < b) ? iv[j0 + 16 * y + lk + 4 * rg] : -1;
-    double gv[2][2][4];
+    double gv[2][WJ][4];
 #pragma unroll
     for (int x = 0; x < 2; x++)
 #pragma unroll
-      for (int y = 0; y < 2; y++)
+      for (int y = 0; y < WJ; y++)
 #pragma unroll
         for (int rg = 0; rg < 4; rg++)
           gv[x][y][rg] = (ci[x] >= 0 && cj[y][rg] >= 0 && ci[x] >= cj[y][rg])
@@ -2037,30 +2137,20 @@ k_schur_update(DevTree T, const int *__restrict__ tiles, const double *__restric
 #pragma unroll
     for (int x = 0; x < 2; x++)
 #pragma unroll
-      for (int y = 0; y < 2; y++)
+      for (int y = 0; y < WJ; y++)
 #pragma unroll
         for (int rg = 0; rg < 4; rg++) uold[x][y][rg] += gv[x][y][rg];
   }
-  // eight k-steps (32 pivots) per trip: all operand loads of the trip are in flight
-  // together, so a trip costs one memory latency instead of eight
   for (int k0 = 0; k0 < p; k0 += 32) {
-    if (k0) load(k0);
-#pragma unroll
-    for (int q = 0; q < 8; q++) {
-      if (k0 + 4 * q < p) {  // wave-uniform
-        // D = X-tile * L-tile': the accumulator holds U(i,j) with i along the lanes, so that
-        // the read-modify-write of U below moves 128-byte segments
-        acc[0][0] = mfma_f64(b0[q], a0[q], acc[0][0]);
-        acc[0][1] = mfma_f64(b1[q], a0[q], acc[0][1]);
-        acc[1][0] = mfma_f64(b0[q], a1[q], acc[1][0]);
-        acc[1][1] = mfma_f64(b1[q], a1[q], acc[1][1]);
-      }
-    }
+    load(1, k0 + 16);
+    products(0, k0);
+    load(0, k0 + 32);
+    products(1, k0 + 16);
   }
 #pragma unroll
   for (int x = 0; x < 2; x++)
 #pragma unroll
-    for (int y = 0; y < 2; y++)
+    for (int y = 0; y < WJ; y++)
 #pragma unroll
       for (int rg = 0; rg < 4; rg++) {
         const int i = i0 + 16 * x + lr, j = j0 + 16 * y + lk + 4 * rg;
@@ -2135,7 +2225,7 @@ k_schur_update_big(DevTree T, const int *__restrict__ tiles, const double *__res
           for (int y = 0; y < TY; y++) acc[x][y] = mfma_f64(bv[set][q][y], av[set][q][x], acc[x][y]);
       }
   };
-  load(0, 0);
+  if (p > 0) load(0, 0);  // (an empty supernode - the test hook HQPKKT_SCHUR_BIG_B=1 sends those here too - has no pivot to clamp to)
   for (int k0 = 0; k0 < p; k0 += 8 * KT) {
     load(1, k0 + 4 * KT);
     products(0, k0);

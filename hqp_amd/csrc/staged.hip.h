@@ -933,6 +933,24 @@ __global__ void k_st_add_h(int nent, const long long *__restrict__ dst, const in
     G[dst[e]] = s;
 }
 
+// The same for a system sharded over ranks: a rank computes only ITS tiles of the work block G (the plan's tile list);
+// everything else in G is left over from earlier stages.  H is added only into the rank's own tiles (bit
+// tr * ntc + tc of `owned`, 128 x 128 tiles): a "+=" on a tile nobody overwrites would grow from stage to stage and
+// from factorisation to factorisation.
+__global__ void k_st_add_h_owned(int nent, const long long *__restrict__ dst, const int *__restrict__ tptr,
+                                 const HTerm *__restrict__ terms, const double *__restrict__ vals,
+                                 const double *__restrict__ wt, double *__restrict__ G, long long ld,
+                                 const unsigned *__restrict__ owned, int ntc) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= nent) return;
+  const long long d = dst[e];
+  const int t = (int)(d / ld >> 7) * ntc + (int)(d % ld >> 7);
+  if (!((owned[t >> 5] >> (t & 31)) & 1u)) return;
+  double s = 0.0;
+  for (int k = tptr[e]; k < tptr[e + 1]; k++) s += vals[terms[k].s1] * vals[terms[k].s2] * wt[terms[k].wi];
+  G[d] += s;
+}
+
 // values of the A block scattered into dense storage: dst >= 0 offset into the F arena (dynamics
 // rows), dst <= -2 offset -(dst + 2) into the misc arena (own equality rows of N), -1 not stored
 // (the -1.0 of a dynamics row, the rows that fix x_0)

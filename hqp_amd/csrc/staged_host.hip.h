@@ -24,6 +24,8 @@ struct StagedDev {
   DBuf<stg::StripTab> wtabs;  // (the strips of the gathered F: offsets inside one of the two buffers)
   DBuf<stg::RectTab> rtabs;
   DBuf<int> gtile;
+  DBuf<unsigned> gowned;             // per stage: bitmap of the 128 x 128 tiles of G this rank computes (k_st_add_h_owned)
+  std::vector<long long> gowned_off;  // stage k's words start at gowned_off[k]
   DBuf<stg::PackRect> prects;
   std::vector<int> prect_ptr;
   DBuf<stg::DynLoc> dyn_loc;
@@ -89,7 +91,7 @@ struct StagedDev {
     dyn.release(), eq_rows.release(), fix_rows.release(), fix_src.release(), h_tptr.release();
     chk_idx.release(), chk_kind.release(), h_dst.release(), a_dst.release(), h_terms.release();
     dyn_desc.release(), dyn_x1.release(), dyn_x2.release(), dyn_part.release(), sk_ws.release(), ks_ws2.release(), sk_cnt.release(), zeros.release();
-    wtabs.release(), rtabs.release(), gtile.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
+    wtabs.release(), rtabs.release(), gtile.release(), gowned.release(), prects.release(), dyn_loc.release(), dyn_sum.release();
     if (stream_x) (void)hipStreamDestroy(stream_x), stream_x = nullptr;
     for (hipEvent_t *ev : {&ev_w[0], &ev_w[1], &ev_w[2], &ev_x[0], &ev_x[1], &ev_x[2]})
       if (*ev) (void)hipEventDestroy(*ev), *ev = nullptr;
@@ -615,7 +617,25 @@ static int staged_upload(hqpkkt_t *h) {
     if (pr.empty()) pr.push_back(stg::PackRect{});
     std::vector<int> gt = P.gtile;
     if (gt.empty()) gt.push_back(0);
-    if ((e = d.wtabs.upload(wt)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt)))
+    // which tiles of the work block G of a stage this rank computes (rows: its strip from c0 on)
+    std::vector<unsigned> ow;
+    d.gowned_off.assign(P.K + 1, 0);
+    for (int k = 0; k < P.K; k++) {
+      d.gowned_off[k] = (long long)ow.size();
+      const int ntc = (P.nk[k] + 127) / 128, r0 = P.xcut[(size_t)k * (NR + 1) + RK] / 128;
+      ow.resize(ow.size() + ((size_t)ntc * ntc + 31) / 32, 0u);
+      for (int t = P.gtile_ptr[k]; t < P.gtile_ptr[k + 1]; t++) {
+        const int tr = r0 + (P.gtile[t] >> 16), tc = P.gtile[t] & 0xffff;
+        if (tr < ntc && tc < ntc) {
+          const size_t bit = (size_t)tr * ntc + tc;
+          ow[d.gowned_off[k] + bit / 32] |= 1u << (bit % 32);
+        }
+      }
+    }
+    d.gowned_off[P.K] = (long long)ow.size();
+    if (ow.empty()) ow.push_back(0u);
+    if ((e = d.wtabs.upload(wt)) || (e = d.rtabs.upload(rt)) || (e = d.prects.upload(pr)) || (e = d.gtile.upload(gt)) ||
+        (e = d.gowned.upload(ow)))
       return e;
     if (!d.ev_x1) HIPCHK(hipEventCreateWithFlags(&d.ev_x1, hipEventDisableTiming));
     if (h->xchg_sfn && !d.stream_x) {
@@ -903,7 +923,9 @@ static int staged_stage_sharded(hqpkkt_t *h, int k) {
     gg.tile_map = d.gtile.p + P.gtile_ptr[k], gg.bstrips = d.wtabs.p + k;
     if ((e = st_gemm_tiles(h, gg, ntile, KC_ST_GEMM))) return e;
   }
-  add_h(P.h_ptr[k], ne_x);  // (entries outside this rank's blocks land in parts of G nobody reads)
+  if (ne_x)  // H_xx into the rank's own tiles only (everything else in G is left over from earlier stages and read by nobody)
+    KLAUNCH(h, KC_ASSEMBLE, stg::k_st_add_h_owned<<<nblk(ne_x), 256, 0, h->stream>>>(ne_x, d.h_dst.p + P.h_ptr[k], d.h_tptr.p + P.h_ptr[k], d.h_terms.p,
+                                                                                  h->vals.p, h->wt.p, G, ldg, d.gowned.p + d.gowned_off[k], (nn + 127) / 128));
   const int npk = d.prect_ptr[k + 1] - d.prect_ptr[k];
   if (npk > 0)
     KLAUNCH(h, KC_ST_VEC, stg::k_st_pack_rects<<<dim3(512, npk), 256, 0, sA>>>(d.prects.p + d.prect_ptr[k], G, ldg, xb + (long long)RK * P.xslot[k]));

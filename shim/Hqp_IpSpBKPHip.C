@@ -50,6 +50,7 @@ Hqp_IpMatrixHip::Hqp_IpMatrixHip(int mode)
   _nx = _nu = IVNULL;
   _wz_tol = HUGE_VAL;
   _a_sparse = 0;
+  _told_ignored = false;
   _logging = getenv("HQPKKT_SHIM_LOGGING") ? atoi(getenv("HQPKKT_SHIM_LOGGING")) : 0;
   if (mode == HQPKKT_MODE_STAGED) {
     _ifList.append(new If_Real("mat_wz_tol", &_wz_tol));
@@ -500,6 +501,14 @@ void Hqp_IpMatrixHip::factor(const Hqp_Program *qp, const VEC *z, const VEC *w)
 {
   int e;
   assert((int)z->dim == _m && (int)w->dim == _m);
+  if (_mode == HQPKKT_MODE_STAGED && !_told_ignored && (_wz_tol != HUGE_VAL || _a_sparse != 0)) {
+    // hqp/Hqp_IpLQDOCP.C:850-853 would take ExRiccatiFactor() instead of ExRiccatiFactorSc() with mat_wz_tol set,
+    // :437, 738, 1357-1368 the sparse forms of fx, fu with mat_a_sparse: neither exists here (one recursion on dense
+    // blocks, same solution up to the residual contract) - said once, never silently
+    _told_ignored = true;
+    fprintf(stderr, "LQDOCPHip: mat_wz_tol (%g) / mat_a_sparse (%d) are set to non-default values; this plugin has one "
+            "recursion (the scaled form of ExRiccatiFactorSc) on dense stage blocks and ignores both\n", (double)_wz_tol, _a_sparse);
+  }
   hqpkkt_set_tol(_h, _tol);
   e = hqpkkt_factor(_h, z->ve, w->ve);
   if (_mode_used == HQPKKT_MODE_STAGED && e == HQPKKT_E_SIZES) {

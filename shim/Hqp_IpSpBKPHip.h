@@ -37,11 +37,12 @@ class Hqp_IpMatrixHip : public Hqp_IpMatrix {
   int _staged_min_front; // mat_staged_min_front: LQDOCPHip uses the STAGED engine from this stage width on
   int _update_threads; // mat_update_threads: host threads of update()'s walk over the row lists
   // LQDOCPHip (hqp/Hqp_IpLQDOCP.C:177-179 registers the same three): mat_wz_tol and mat_a_sparse are accepted and
-  // not used (the first selects the reference's other recursion, off by default: HUGE_VAL, :111, 850-853; the
+  // not used - factor() says so once on stderr when either is set to a non-default value (the first selects the reference's other recursion, off by default: HUGE_VAL, :111, 850-853; the
   // second its sparse products with fx, fu, which have no counterpart on dense MFMA blocks), mat_logging > 0 prints
   // the stage structure and the engine chosen at init()
   Real _wz_tol;
   int _a_sparse, _logging;
+  bool _told_ignored;
   struct hqpkkt *_h;
   // STAGED engine with the dynamics handed over as dense blocks (hqpkkt_analyze_staged): stage sizes, the number of
   // dynamics rows, CSR of the OTHER equality rows only - the dynamics rows of A are never copied into a CSR

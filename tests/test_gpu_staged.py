@@ -548,8 +548,11 @@ def test_full_size_c4_properties():
     residual of the reference's 4-block system <= 1e-10 without a refinement round, residuum() of the solution equal
     to what solve() returned, linearity in the right-hand side, a second factorisation bit-identical."""
     import torch
-    free, _total = torch.cuda.mem_get_info()
+    free, total = torch.cuda.mem_get_info()
     if free < 150e9:
+        # an MI355X (288 GB) that cannot spare 150 GB is a FAILURE of the run (something else holds the memory): a green
+        # run must not hide that the headline configuration was not exercised.  A smaller device may skip.
+        assert total < 250e9, f"only {free / 1e9:.0f} of {total / 1e9:.0f} GB of HBM free: the headline configuration needs ~110 GB"
         pytest.skip("needs ~110 GB of HBM")
     sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
     import bench
