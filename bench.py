@@ -644,6 +644,13 @@ def bench_c4(args):
                 "ms_exchange_wait": prof.get("exchange", (0, 0))[0] / nprof,
                 "ms_control_sized_chain": prof.get("staged_small", (0, 0))[0] / nprof,
                 "ms_factor": st["ms_factor"], "ms_solve": st["ms_solve"]}
+        # what the exchanges of a factorisation move INTO this rank (every all-gather brings the other ranks' slots), over
+        # the time they hold the stream: a LOWER bound of the rate of a link (the time includes the wait for the slowest
+        # rank; xGMI is point to point, a gather arrives over world - 1 links at once)
+        rx = st["bytes_exchange_factor"] * (world - 1) / world
+        mine["gb_received_per_factor"] = rx / 1e9
+        mine["gbs_received"] = rx / 1e9 / (mine["ms_exchange_wait"] * 1e-3) if mine["ms_exchange_wait"] > 0 else None
+        mine["gbs_per_link"] = mine["gbs_received"] / (world - 1) if mine["gbs_received"] else None
         per_rank = [None] * world
         tdist.all_gather_object(per_rank, mine)
         # ... and, from a second timed pass, the aggregate of N independent systems, one per GPU (the metric's literal

@@ -18,6 +18,9 @@
 #include "kernels.hip.h"
 #include "factor_blk.hip.h"
 #include "solve_top.hip.h"
+#ifndef FB_NS160
+#define FB_NS160 5  // blocks per block-holding wavefront of k_factor_blk for fronts of 129 .. 160 pivots (7 with FB_OWNSIMD: nine such wavefronts)
+#endif
 #ifndef FB_OWNSIMD
 #define FB_OWNSIMD false  // true: the elimination wavefront of k_factor_blk shares its SIMD with no block-holding wavefront (measured slower)
 #endif
@@ -629,7 +632,7 @@ static int upload(hqpkkt_t *h) {
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(128))));
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_blk));
       HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 6, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(176))));
-      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 5, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(160))));
+      HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, FB_NS160, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)std::min(lds_blk, fb_lds_bytes(160))));
       a_blk = lds_blk;
     }
     if (h->lds_diag > a_diag) {
@@ -813,7 +816,7 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
         else if (lmp <= 160)  // (55 blocks on 11 wavefronts: five per wavefront)
-          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<12, 5, 208, 3, FB_OWNSIMD><<<nn - nfs - nsm, 768, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
+          KLAUNCH(h, KC_FACTOR_DIAG, (k_factor_blk<12, FB_NS160, 208, 3, FB_OWNSIMD><<<nn - nfs - nsm, 768, fb_lds_bytes(lmp), s>>>(T, D.level_nodes.p + S.level_ptr[l] + nfs + nsm, h->panel.p,
                                                  h->dinv.p, h->ptype.p, h->lperm.p, h->esign.p, h->linv.p, h->linv_off.p, alpha, h->opts.pivot_eps, h->bits.p,
                                                  h->flags.p + 1, h->upd.p)));
         else if (lmp <= 176)  // (66 blocks of the triangle on 11 wavefronts: six per wavefront - 16 registers fewer than with eight, no scratch)
@@ -1237,8 +1240,8 @@ static int guarded(F body) {
 // loop gets from this plugin through the shim - a multiplier pivot that cancelled to rounding level is used as it
 // stands -, and STATIC PIVOTING is the fall-back: a run that ends "degenerate" (or singular) is made again, from a cold
 // start, with such pivots replaced (kernels.hip.h, TINY_REPLACE_WORD; what the reference's own PARDISO plugin is
-// configured to do, hqp/Hqp_IpPARDISO.C:138-142).  hqpkkt_ip_result.attempts says which happened; iterations, plugin
-// calls and device time are the totals over the attempts.  HQPKKT_TINY_IN_LOOP=1 / =0 (campaign switches): static
+// configured to do, hqp/Hqp_IpPARDISO.C:138-142).  hqpkkt_ip_result.attempts says which happened; plugin calls and device
+// time are the totals over the attempts, `iters` is the count of the run that produced the result.  HQPKKT_TINY_IN_LOOP=1 / =0 (campaign switches): static
 // pivoting from the first attempt on / never.
 template <class Loop>
 static int ip_attempts(hqpkkt_t *h, const hqpkkt_ip_opts *&opts, hqpkkt_ip_result *res, Loop loop) {
@@ -1274,8 +1277,8 @@ static int ip_attempts(hqpkkt_t *h, const hqpkkt_ip_opts *&opts, hqpkkt_ip_resul
     h->tiny_replace_in_loop = false;
     if (rc == 0) {
       res->attempts = 2;
-      if (counted)
-        res->iters += first.iters, res->n_factor += first.n_factor, res->n_solve += first.n_solve, res->ms_total += first.ms_total;
+      if (counted)  // the work of both runs; `iters` stays the count of the run that gave the result (what the reference's count is compared with)
+        res->n_factor += first.n_factor, res->n_solve += first.n_solve, res->ms_total += first.ms_total;
     }
   }
   return rc;
@@ -1904,6 +1907,8 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       return hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, ox, oy, oz, ow, &resid);
     };
     const int OPS_NONE[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
+    // small QPs: an iteration's vector work between its solves in one workgroup each (ipdriver.hip.h, k_ip_pred_small)
+    const bool ip_small = !getenv("HQPKKT_NO_IP_SMALL") && m > 0 && m <= IP_SMALL_M && (long long)n + me + m <= 4 * IP_SMALL_M;
   
     // ------------------------------------------------------------ iterations
     std::vector<double> phimin((size_t)o.max_iters + 2, 0.0);
@@ -2127,6 +2132,9 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       // :583-590; the safe value when the predictor step is short and the reference skips the
       // first corrector, :612-616), the corrector's blocking components, the damped step length
       // (:629-672) are computed by thread 0 of the reduction kernels and consumed through device pointers.
+      if (ip_small) {  // one workgroup: the three launches below, same arithmetic (ipdriver.hip.h)
+        k_ip_pred_small<<<1, 1024, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, mu, gamma, S, C.r4);
+      } else {
       k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.part);
       {
         const int ops3[IP_SLOTS] = {IP_MIN, IP_MAX, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM, IP_SUM};
@@ -2135,6 +2143,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         k_ip_final<<<1, 256, 0, s>>>(C.part, o3, C.out, IpEpi{1, m, mu, gamma, 0.0, nullptr, S});
       }
       k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, 0.0, S + IPS_SMM, C.r4);
+      }
       if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
         if (e == HQPKKT_E_SING && hot) {
           sing_hot = true;
@@ -2143,6 +2152,9 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         if (e == HQPKKT_E_SING) return finish(4);
         return e;
       }
+      if (ip_small) {  // one workgroup: the five launches below, same arithmetic
+        k_ip_step_small<<<1, 1024, 0, s>>>(n, me, m, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, Bk, gamma, o.gammaf, S);
+      } else {
       k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
       k_ip_minratio_final<<<1, 256, 0, s>>>(C.part, C.z, C.w, C.dz, C.dw, Bk, m, gamma, S);
       k_ip_mupl<<<IP_BLOCKS, 256, 0, s>>>(m, 0.0, S + IPS_ALPHA_PRE, C.z, C.w, C.dz, C.dw, C.part);
@@ -2153,6 +2165,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       }
       k_ip_update<<<IP_BLOCKS, 256, 0, s>>>(n, me, m, 0.0, S + IPS_ALPHA, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw,
                                             C.part);
+      }
       // (:684-690: a non-finite mu or x ends the solve as degenerate; seen here by the next
       // pass through k_ip_rhs, whose sums and maximum carry the NaN / inf)
       iter++;
@@ -2427,8 +2440,8 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       {
         static const bool trace_ip = getenv("HQPKKT_TRACE_IP") != nullptr;  // (diagnosis: the loop's scalars after every step)
         if (trace_ip)
-          fprintf(stderr, "franke: step %d gap %.17g alpha %.17g alphabar %.17g zeta %.17g rhomin %.17g resid %.3e mu %.6e\n", iter + 1, gap, alpha,
-                  alphabar, zeta, rhomin, resid, mu);
+          fprintf(stderr, "franke: step %d gap %.17g alpha %.17g alphabar %.17g zeta %.17g rhomin %.17g resid %.3e mu %.6e hot %d\n", iter + 1, gap, alpha,
+                  alphabar, zeta, rhomin, resid, mu, hot ? 1 : 0);
       }
       if (!std::isfinite(gap) || !std::isfinite(C.hout[1])) {  // :351-354
         result = 4;
@@ -3160,7 +3173,7 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<8, 6, 144, 2, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(128)));
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 8, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
   HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 6, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
-  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, 5, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
+  HIPCHK(hipFuncSetAttribute((const void *)k_factor_blk<12, FB_NS160, 208, 3, FB_OWNSIMD>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)fb_lds_bytes(192)));
   hipEvent_t e0, e1;
   HIPCHK(hipEventCreate(&e0));
   HIPCHK(hipEventCreate(&e1));
@@ -3174,7 +3187,7 @@ int hqpkkt_debug_factor_block(int device, int p, const double *A, double tol, do
       k_factor_blk<8, 6, 144, 2, FB_OWNSIMD><<<1, 512, fb_lds_bytes(p), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                         d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
     else if (variant == 0 && p <= 160)  // (as run_factor chooses: five blocks per wavefront up to 160 pivots, six up to 176)
-      k_factor_blk<12, 5, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
+      k_factor_blk<12, FB_NS160, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,
                                                           d_loff.p, alpha, pivot_eps, kb, d_flags.p + 1, d_upd.p);
     else if ((variant == 0 || variant == 3) && p <= 176)
       k_factor_blk<12, 6, 208, 3, FB_OWNSIMD><<<1, 768, fb_lds_bytes(std::max(p, 129)), 0>>>(T, d_nodes.p + rp, d_P.p, d_dinv.p, d_pt.p, d_lp.p, d_sg.p, d_W.p,

@@ -30,6 +30,14 @@ __device__ __forceinline__ double nan_to_inf(double a) {
   return a == a ? a : __longlong_as_double(0x7ff0000000000000LL);
 }
 
+// element formulas shared by the separate launches and the one-workgroup kernels of small QPs (same expression, same
+// contraction into multiply-adds: the two forms give the same bits)
+__device__ __forceinline__ double ip_corr_elem(double z, double w, double dza, double dwa, double smm) {
+  return -(z * w + (dza * dwa - smm));
+}
+__device__ __forceinline__ double ip_mupl_elem(double z, double w, double dz, double dw, double alpha) {
+  return (z + alpha * dz) * (w + alpha * dw);
+}
 // partials[IP_BLOCKS][IP_SLOTS] -> out[IP_SLOTS], slot k combined with ops[k]
 struct IpOps {
   int op[IP_SLOTS];
@@ -208,7 +216,7 @@ __global__ void k_ip_corr_rhs(int m, const double *__restrict__ z, const double 
                               const double *__restrict__ smm_dev, double *__restrict__ r4) {
   if (smm_dev) smm = *smm_dev;  // sigma mu computed on the device (k_ip_sigma): no host round trip
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i < m) r4[i] = -(z[i] * w[i] + (dza[i] * dwa[i] - smm));
+  if (i < m) r4[i] = ip_corr_elem(z[i], w[i], dza[i], dwa[i], smm);
 }
 
 // Mehrotra's adaptive step (:629-646): the blocking component of z and of w, first
@@ -289,7 +297,7 @@ k_ip_mupl(int m, double alpha, const double *__restrict__ alpha_dev, const doubl
   if (alpha_dev) alpha = *alpha_dev;
   double s = 0.0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < m; i += gridDim.x * blockDim.x)
-    s += (z[i] + alpha * dz[i]) * (w[i] + alpha * dw[i]);
+    s += ip_mupl_elem(z[i], w[i], dz[i], dw[i], alpha);
   const double r = ip_block_reduce(s, IP_SUM, red);
   if (threadIdx.x == 0) {
     double *P = part + blockIdx.x * IP_SLOTS;
@@ -329,6 +337,153 @@ k_ip_update(int n, int me, int m, double alpha, const double *__restrict__ alpha
   if (threadIdx.x == 0) {
     P[1] = r;
     for (int k = 2; k < IP_SLOTS; k++) P[k] = 0.0;
+  }
+}
+
+// ---- small QPs: the vector work between the solves of an iteration in ONE workgroup ---------------------
+// With m <= IP_SMALL_M (the double-integrator QP at K = 2000: 8000) the five launches between the predictor solve and the
+// corrector solve - k_ip_ratio, k_ip_final, k_ip_corr_rhs - and the five behind the corrector solve - k_ip_minratio_part,
+// _final, k_ip_mupl, k_ip_final, k_ip_update - are each a few microseconds of launch and first-touch latency around a
+// few thousand elements (profiles/r05_ip_did_kstat.txt: 54 us of an iteration's 410).  k_ip_pred_small / k_ip_step_small
+// do the same work in one workgroup of 1024 threads each, with the SAME arithmetic: minima and maxima do not depend on
+// the order; the one sum - (z + alpha dz)'(w + alpha dw) - is added up exactly as the 256 blocks of 256 threads and
+// k_ip_final add it (virtual wavefront by virtual wavefront with the same butterfly, the four wavefronts of a block in
+// their order, then the 256 block sums the same way), so the loop's iterates are bit for bit those of the separate
+// launches (tests/test_gpu_franke.py::test_small_ip_kernels_bit_identical; HQPKKT_NO_IP_SMALL=1 keeps the launches).
+#define IP_SMALL_M 65536  // (with more, a thread of the separate launches holds more than one element)
+// combine over the workgroup's 1024 threads (any order: minima / maxima only); every thread gets the result
+__device__ __forceinline__ double ip_small_minmax(double v, bool is_max, double *red16) {
+  v = is_max ? wave_max(v) : -wave_max(-v);
+  if ((threadIdx.x & 63) == 0) red16[threadIdx.x >> 6] = v;
+  __syncthreads();
+  double r = red16[0];
+#pragma unroll
+  for (int k = 1; k < 16; k++) r = is_max ? fmax(r, red16[k]) : fmin(r, red16[k]);
+  __syncthreads();
+  return r;
+}
+__global__ void __launch_bounds__(1024)
+k_ip_pred_small(int m, const double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ dza,
+                const double *__restrict__ dwa, double mu, double gamma, double *__restrict__ S, double *__restrict__ r4) {
+  __shared__ double red16[16];
+  __shared__ double bc[2];
+  // k_ip_ratio + k_ip_final + ip_sigma
+  double a = 1e300, t = 0.0;
+  for (int i = threadIdx.x; i < m; i += 1024) {
+    const double zi = z[i], wi = w[i], dzi = dza[i], dwi = dwa[i];
+    if (dzi < 0.0) a = fmin(a, -zi / dzi);
+    if (dwi < 0.0) a = fmin(a, -wi / dwi);
+    if (dzi * dwi > 0.0) t = fmax(t, dzi * dwi / zi / wi);
+  }
+  const double amin = ip_small_minmax(a, false, red16), tmax = ip_small_minmax(t, true, red16);
+  if (threadIdx.x == 0) {
+    const double two[2] = {amin, tmax};
+    ip_sigma(two, mu, gamma, S);
+    bc[0] = S[IPS_SMM];
+  }
+  __syncthreads();
+  // k_ip_corr_rhs
+  const double smm = bc[0];
+  for (int i = threadIdx.x; i < m; i += 1024) r4[i] = ip_corr_elem(z[i], w[i], dza[i], dwa[i], smm);
+}
+
+__global__ void __launch_bounds__(1024)
+k_ip_step_small(int n, int me, int m, double *__restrict__ x, double *__restrict__ y, double *__restrict__ z,
+                double *__restrict__ w, const double *__restrict__ dx, const double *__restrict__ dy,
+                const double *__restrict__ dz, const double *__restrict__ dw, double *__restrict__ Bk, double gamma,
+                double gammaf, double *__restrict__ S) {
+  __shared__ double sv[16];
+  __shared__ int si[16];
+  __shared__ double ws[1024];  // sums of the virtual wavefronts of k_ip_mupl's 256 x 256 launch
+  __shared__ double red4[4];
+  __shared__ double bc[2];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // ---- k_ip_minratio_part + _final: the blocking components (smallest ratio, smallest index among equals)
+  double zv = 1e300, wv = 1e300;
+  int zi = 0x7fffffff, wi = 0x7fffffff;
+  for (int i = tid; i < m; i += 1024) {
+    if (dz[i] < 0.0) {
+      const double q = -z[i] / dz[i];
+      if (q < zv || (q == zv && i < zi)) zv = q, zi = i;
+    }
+    if (dw[i] < 0.0) {
+      const double q = -w[i] / dw[i];
+      if (q < wv || (q == wv && i < wi)) wv = q, wi = i;
+    }
+  }
+  double bk[12];
+  for (int pass = 0; pass < 2; pass++) {
+    double v = pass ? wv : zv;
+    int ix = pass ? wi : zi;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      const double ov = __shfl_xor(v, o);
+      const int oi = __shfl_xor(ix, o);
+      if (ov < v || (ov == v && oi < ix)) v = ov, ix = oi;
+    }
+    if (lane == 0) sv[wave] = v, si[wave] = ix;
+    __syncthreads();
+    if (tid == 0) {
+      for (int k = 1; k < 16; k++)
+        if (sv[k] < v || (sv[k] == v && si[k] < ix)) v = sv[k], ix = si[k];
+      const bool none = !(v < 1e300);
+      const int i = none ? -1 : ix;
+      bk[6 * pass] = v, bk[6 * pass + 1] = (double)i;
+      bk[6 * pass + 2] = none ? 0.0 : z[i], bk[6 * pass + 3] = none ? 0.0 : dz[i];
+      bk[6 * pass + 4] = none ? 0.0 : w[i], bk[6 * pass + 5] = none ? 0.0 : dw[i];
+    }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    for (int k = 0; k < 12; k++) Bk[k] = bk[k];
+    ip_alpha_pre(bk, m, gamma, S);
+    bc[0] = S[IPS_ALPHA_PRE];
+  }
+  __syncthreads();
+  // ---- k_ip_mupl + k_ip_final: (z + alpha dz)'(w + alpha dw), in the order of the 256 x 256 launch (m <= 65536: a
+  // thread of that launch holds at most one element, element 64 v + lane belongs to lane `lane` of virtual wavefront v)
+  const double alpha_pre = bc[0];
+  for (int v = wave; v < 1024; v += 16) {
+    const int i = 64 * v + lane;
+    double s = 0.0;
+    if (64 * v < m) {  // wave-uniform
+      if (i < m) s += ip_mupl_elem(z[i], w[i], dz[i], dw[i], alpha_pre);
+      s = wave_sum(s);
+    }
+    if (lane == 0) ws[v] = s;
+  }
+  __syncthreads();
+  {
+    double bs = 0.0;
+    if (tid < 256) {  // the block sums: the four wavefronts of a block in their order (ip_block_reduce)
+      bs = ws[4 * tid];
+#pragma unroll
+      for (int k = 1; k < 4; k++) bs = bs + ws[4 * tid + k];
+      bs = wave_sum(bs);  // k_ip_final: thread t holds block t's sum
+      if (lane == 0) red4[wave] = bs;
+    }
+    __syncthreads();
+    if (tid == 0) {
+      double r = red4[0];
+      for (int k = 1; k < 4; k++) r = r + red4[k];
+      const double one[1] = {r};
+      ip_alpha_fin(one, bk, m, gammaf, S);
+      bc[1] = S[IPS_ALPHA];
+    }
+    __syncthreads();
+  }
+  // ---- k_ip_update
+  const double alpha = bc[1];
+  const int total = n + me + m;
+  for (int q = tid; q < total; q += 1024) {
+    if (q < n) {
+      x[q] = x[q] + alpha * dx[q];
+    } else if (q < n + me) {
+      y[q - n] += alpha * dy[q - n];
+    } else {
+      const int j = q - n - me;
+      z[j] = z[j] + alpha * dz[j], w[j] = w[j] + alpha * dw[j];
+    }
   }
 }
 

@@ -398,9 +398,10 @@ typedef struct hqpkkt_ip_result {
   double gap, mu, phi, pcost, alpha; /* of the last iteration                         */
   float ms_total;        /* device time of the whole call                             */
   int attempts;          /* 1; 2: the first run ended degenerate / singular and the loop was run again, from a cold
-                          * start, with static pivoting (cancelled multiplier pivots replaced): iters, n_factor,
-                          * n_solve and ms_total are then the totals over both runs (the field takes the place of
-                          * the structure's tail padding: size and offsets are those of earlier builds) */
+                          * start, with static pivoting (cancelled multiplier pivots replaced): n_factor, n_solve
+                          * and ms_total are then the totals over both runs, iters the count of the second (the
+                          * field takes the place of the structure's tail padding: size and offsets are those of
+                          * earlier builds) */
 } hqpkkt_ip_result;
 int hqpkkt_default_ip_opts(hqpkkt_ip_opts *opts);
 int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, const double *b,

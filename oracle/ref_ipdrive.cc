@@ -148,6 +148,94 @@ int hqpip_trace_franke(const char *mat_solver, int n, int me, int m, const int *
   return err;
 }
 
+// Diagnosis: a HOT-started Hqp_IpsFranke step by step - (c, b, d) solved from a cold start, then (c2, b2, d2) after update()
+// + hot_start() and the loop of Hqp_IpsFranke::solve() (hqp/Hqp_IpsFranke.C:381-416) spelt out around step(), so that
+// the scalars of every step can be recorded: trace[8 k ..] = gap, alpha, alphabar, zeta, rhomin, Hqp_Result, hot (1 while
+// the hot start is alive, 0 after the restart from a cold start), iter as the solver counts it.  out[0] = total
+// iterations (with the failed ones), out[1] = result, out[2] = iterations of the first solve.
+namespace {
+struct FrankeHotProbe : public Hqp_IpsFranke {
+  void get(double *t) const {
+    t[0] = _gap, t[1] = _alpha, t[2] = _alphabar, t[3] = _zeta, t[4] = _rhomin, t[5] = (double)_result, t[6] = (double)_hot_started,
+    t[7] = (double)_iter;
+  }
+  int hot() const { return _hot_started; }
+  int iters() const { return _iter; }
+  int max_warm() const { return _max_warm_iters; }
+};
+}  // namespace
+int hqpip_trace_franke_hot(const char *mat_solver, int n, int me, int m, const int *Qp, const int *Qi, const double *Qx,
+                           const double *c, const int *Ap, const int *Ai, const double *Ax, const double *b, const int *Cp,
+                           const int *Ci, const double *Cx, const double *d, const double *c2, const double *b2,
+                           const double *d2, double qp_eps, int max_iters, double *trace, int *nsteps, double *out) {
+  if (hqpref_startup() != 0) return -1;
+  FrankeHotProbe *S = new FrankeHotProbe;
+  if (If_SetString("qp_mat_solver", mat_solver) != IF_OK) {
+    delete S;
+    return -2;
+  }
+  Hqp_Program *qp = new Hqp_Program;
+  qp->resize(n, me, m);
+  fill(qp->Q, n, Qp, Qi, Qx);
+  fill(qp->A, me, Ap, Ai, Ax);
+  fill(qp->C, m, Cp, Ci, Cx);
+  for (int i = 0; i < n; i++) qp->c->ve[i] = c[i], qp->x->ve[i] = 0.0;
+  for (int i = 0; i < me; i++) qp->b->ve[i] = b[i];
+  for (int i = 0; i < m; i++) qp->d->ve[i] = d[i];
+  S->qp(qp);
+  S->eps(qp_eps);
+  S->max_iters(max_iters);
+  (void)If_SetReal("qp_mu0", g_mu0);
+  int err = 0, k = 0, it1 = 0, fail = 0;
+  // (the loop as a lambda: the commas of its body would split the macro's arguments; an error longjmps out of it)
+  auto run = [&]() {
+    S->init();
+    S->update();
+    S->cold_start();
+    S->solve();
+    it1 = S->iter();
+    for (int i = 0; i < n; i++) qp->c->ve[i] = c2[i];
+    for (int i = 0; i < me; i++) qp->b->ve[i] = b2[i];
+    for (int i = 0; i < m; i++) qp->d->ve[i] = d2[i];
+    S->update();
+    S->hot_start();
+    double gap1 = 0.0, t[8];
+    for (;;) {
+      for (;;) {
+        S->step();
+        if (k < max_iters) {
+          S->get(trace + 8 * k);
+          k++;
+        }
+        if (S->hot()) {
+          S->get(t);
+          if (S->iters() == 1)
+            gap1 = t[0];
+          else if (t[0] > gap1) {
+            fail += S->iters();
+            S->cold_start();
+          }
+        }
+        if (S->iters() + fail >= max_iters) break;
+        if (S->hot() && S->iters() >= S->max_warm()) break;
+        const int r = (int)S->result();
+        if (r == Hqp_Optimal || r == Hqp_Suboptimal || r == Hqp_Degenerate) break;
+      }
+      if (S->hot() && S->result() != Hqp_Optimal) {
+        fail += S->iters();
+        S->cold_start();
+      } else
+        break;
+    }
+  };
+  m_catchall(run();, err = _err_num);
+  *nsteps = k;
+  out[0] = S->iter() + fail, out[1] = (double)S->result(), out[2] = it1;
+  delete S;
+  delete qp;
+  return err;
+}
+
 // Time of Hqp_Solver::update() (= plugin update(): new values on the same pattern, once per SQP
 // iteration, hqp/Hqp_SqpSolver.C:285-296) with the plugin `mat_solver`: out[0] = median seconds of
 // `reps` updates (values scaled a little in between), out[1] = seconds of init + first update.

@@ -271,6 +271,32 @@ def trace_franke(prog, mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=2
     return trace[:niter.value]
 
 
+def trace_franke_hot(prog, c2, b2, d2, mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=400):
+    """Diagnosis: the reference's Hqp_IpsFranke on ``prog`` from a cold start, then hot-started on (c2, b2, d2), step by step
+    (oracle/ref_ipdrive.cc, hqpip_trace_franke_hot): (array (steps, 8) of gap, alpha, alphabar, zeta, rhomin, Hqp_Result,
+    hot, iter after every step of the SECOND solve; dict(iters, result, first_iters))."""
+    lib = _host(host)
+    n, me, m = prog.dims
+    args = []
+    for (p, i, x), vec in zip((prog.Q, prog.A, prog.C), (prog.c, prog.b, prog.d)):
+        args += [np.ascontiguousarray(p, dtype=np.int32),
+                 np.ascontiguousarray(i, dtype=np.int32) if len(i) else np.zeros(1, np.int32),
+                 _pad(x), _pad(vec)]
+    args += [_pad(c2), _pad(b2), _pad(d2)]
+    trace = np.zeros((max_iters, 8))
+    niter = C.c_int(0)
+    out = np.zeros(4)
+    f = lib.hqpip_trace_franke_hot
+    f.restype = C.c_int
+    f.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int] + [np.ctypeslib.ndpointer(dtype=a.dtype, flags="C") for a in args] + \
+                 [C.c_double, C.c_int, np.ctypeslib.ndpointer(dtype=np.float64, flags="C"), C.POINTER(C.c_int),
+                  np.ctypeslib.ndpointer(dtype=np.float64, flags="C")]
+    e = f(mat_solver.encode(), n, me, m, *args, qp_eps, max_iters, trace, C.byref(niter), out)
+    if e:
+        raise RefError(e, f"trace_franke_hot[{mat_solver}]")
+    return trace[:niter.value], dict(iters=int(out[0]), result=int(out[1]), first_iters=int(out[2]))
+
+
 def ip_solve_hot(prog, c2, b2, d2, solver="Mehrotra", mat_solver="SpBKP", host="ref", qp_eps=1e-10, max_iters=250):
     """Two QPs in a row as an SQP iteration makes them: ``prog`` from a cold start, then the same
     matrices with (c2, b2, d2) after update() + hot_start() (hqp/Hqp_IpsMehrotra.C:330-352,

@@ -48,3 +48,26 @@ def test_loops_on_the_callers_vectors_give_the_same_iterates(case, monkeypatch):
         assert (a[-1]["result"], a[-1]["iters"]) == (b[-1]["result"], b[-1]["iters"]) and a[-1]["result"] == 0
         for u, v in zip(a[:4], b[:4]):
             assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("case", ["banded", "did400", "did2000", "lq", "banded_full"])
+def test_small_ip_kernels_bit_identical(case, monkeypatch):
+    """hqpkkt_mehrotra on small QPs runs an iteration's vector work between its solves in ONE workgroup each
+    (k_ip_pred_small, k_ip_step_small: ipdriver.hip.h) instead of ten launches - minima and maxima in any order, the
+    one sum in the order of the separate launches: the same iterates bit for bit (HQPKKT_NO_IP_SMALL keeps the launches)."""
+    prog = {"banded": lambda: problems.banded_qp(300, 8, 5), "did400": lambda: problems.did_like_qp(400),
+            "did2000": lambda: problems.did_like_qp(2000), "lq": lambda: problems.lq_docp(40, 6, 2, final_eq=2),
+            "banded_full": lambda: problems.banded_qp(2000, 20, 3)}[case]()
+    cls = ipmatrix.IpSpBKP if case == "banded_full" else ipmatrix.IpRedSpBKP
+    A = cls()
+    A.init(prog)
+    xa, ya, za, wa, ia = A.mehrotra(prog)
+    monkeypatch.setenv("HQPKKT_NO_IP_SMALL", "1")
+    B = cls()
+    B.init(prog)
+    xb, yb, zb, wb, ib = B.mehrotra(prog)
+    assert (ia["result"], ia["iters"], ia["n_solve"]) == (ib["result"], ib["iters"], ib["n_solve"]), (ia, ib)
+    assert ia["result"] == 0 and ia["iters"] >= 3
+    for u, v in ((xa, xb), (ya, yb), (za, zb), (wa, wb)):
+        assert np.array_equal(u, v)
+    assert ia["gap"] == ib["gap"] and ia["alpha"] == ib["alpha"]

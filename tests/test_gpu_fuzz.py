@@ -78,8 +78,10 @@ def test_large_stage_campaign_subset():
 # all cured in round 5 (cancelled multiplier pivots replaced, up to fifteen refinement rounds behind a perturbed pivot) -
 # and those that round 5's campaigns of 12 000 found instead (profiles/r05_fuzz_tree.txt: eight; three on the final code,
 # profiles/r05_fuzz_ip_final.txt: 2536, 6258, 8650).  Those that differ from the
-# reference are reported as expected failures, not hidden (all on the double-integrator structure: pivoting confined to
-# the supernode's pivot block)
+# reference are reported as expected failures, not hidden.  Their cause (shown by experiment in round 5):
+# ONE blocking decision of Hqp_IpsFranke's step-length rule near the solution, on the double-integrator structure, flips
+# with the rounding of the loop's own vector kernels (contracted multiply-adds where the reference's host code rounds
+# twice); with the kernels compiled without contraction these three agree and four other QPs of the 12 000 differ instead.
 IP_FINDS = [193, 2536, 5533, 5975, 6258, 7018, 7260, 7511, 8650, 10246, 803, 2419, 2532, 3015, 5466, 5921, 5954, 7818, 10258]
 
 
@@ -105,4 +107,33 @@ def test_ip_loop_finds_of_the_campaigns(case):
         pytest.skip("oracle/_ref not present")
     status, line = fuzz_ip.check(case)
     if status == "BAD":
-        pytest.xfail("known difference (pivoting confined to the supernode's pivot block): " + line)
+        pytest.xfail("known difference (one blocking decision near the solution flips with the rounding of the loop's own vector "
+                     "kernels, DESIGN.md section 6): " + line)
+
+
+def test_ip_loop_hot_start_subset():
+    """tools/fuzz_ip.py with hot starts (FUZZ_HOT=1), cases 0-99: two QPs in a row with the same matrices, the second
+    hot-started from the first as Hqp_SqpSolver does on every SQP iteration after the first - same result code and
+    objective as the reference's solver on the second QP, iteration counts within the campaign's bounds or apart like
+    those of the reference's own two plugins (a hot start begins at the end point of the solve before, where the last bits
+    decide about the first blocking component and a cold restart: profiles/r06_franke_hot_traces.txt)."""
+    import fuzz_ip
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    bad, cnt = _run(lambda c: fuzz_ip.check(c, hot=True), range(100))
+    assert not bad, bad
+    assert cnt.get("ok", 0) >= 90, cnt
+
+
+def test_ip_loop_hot_start_find_of_round_6():
+    """The one QP of the 800-case hot-start campaign of round 6 (profiles/r06_fuzz_hot.txt) on which the device loop is
+    further from the reference than the reference's own plugins are from each other: case 444, Franke on the
+    double-integrator structure - the hot start needs more than the 15 warm iterations (qp_max_warm_iters) the
+    reference converges in (at the 15th), so the loop restarts cold: 201 against 15 iterations, same solution."""
+    import fuzz_ip
+    if not refapi.host_available("ref"):
+        pytest.skip("oracle/_ref not present")
+    status, line = fuzz_ip.check(444, hot=True)
+    if status == "BAD":
+        pytest.xfail("known difference (the hot start misses qp_max_warm_iters by its first, short steps: "
+                     "profiles/r06_franke_hot_traces.txt): " + line)

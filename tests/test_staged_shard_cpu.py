@@ -1,4 +1,4 @@
-"""CPU (no GPU): the N > 1 path of the STAGED engine with world_size 2 and 3 over gloo.  The library's plan of the
+"""CPU (no GPU): the N > 1 path of the STAGED engine with world_size 2, 3, 4 and 8 over gloo.  The library's plan of the
 memory-sharded partition drives a numpy restatement of the stage's data flow with REAL collectives
 (tests/staged_shard_cpu_worker.py); separately the plan's invariants for 2 ... 8 ranks: the blocks cover the lower
 triangle of G_xx exactly once, every rank owns the same number of them, the tile lists are the owners' blocks."""
@@ -16,7 +16,7 @@ from hqp_amd import ipmatrix
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-@pytest.mark.parametrize("world,nx", [(2, 300), (3, 300), (3, 140), (4, 520)])
+@pytest.mark.parametrize("world,nx", [(2, 300), (3, 300), (3, 140), (4, 520), (8, 1100)])  # (8 ranks: the pairs P / 2 apart are cut in two)
 def test_sharded_stage_data_flow_over_gloo(world, nx):
     import socket
     with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
