@@ -511,7 +511,7 @@ static int upload(hqpkkt_t *h) {
                 2 * mp * sizeof(int) + 16;
   h->lds_panel = (PS_LD * mp + 1 + 2 * mp) * sizeof(double) + mp * sizeof(int);
   h->lds_bwdb = ((size_t)an.max_nbor + 2) * sizeof(double);
-  h->old_fd = getenv("HQPKKT_OLD_FD") != nullptr && mp <= 128;
+  h->old_fd = false;  // (k_factor_diag of rounds 1-3 stays reachable through hqpkkt_debug_factor_block: tests/test_gpu_block.py compares the two)
   if (getenv("HQPKKT_SU1_MAX")) h->su1_max = atoi(getenv("HQPKKT_SU1_MAX"));
   if (getenv("HQPKKT_XCD_PS")) h->xcd_ps = atoi(getenv("HQPKKT_XCD_PS"));
   if (getenv("HQPKKT_XCD_SU")) h->xcd_su = atoi(getenv("HQPKKT_XCD_SU"));
@@ -535,8 +535,7 @@ static int upload(hqpkkt_t *h) {
     const char *pl = getenv("HQPKKT_POLL_LIMIT");
     const int lim = pl ? atoi(pl) : 1 << 20;
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(xw_poll_limit), &lim, sizeof(int)));
-    const char *tp = getenv("HQPKKT_TINY_PERTURB");
-    const double spp = tp ? atof(tp) : 1e-6;
+    const double spp = 1e-6;  // (kernels.hip.h, soft_pivot_pert)
     HIPCHK(hipMemcpyToSymbol(HIP_SYMBOL(soft_pivot_pert), &spp, sizeof(double)));
   }
   // a tree of small fronts only: whole-tree sweeps
@@ -1402,7 +1401,6 @@ static int run_analysis(hqpkkt_t *h, int n, int me, int m, int zd) {
   int maxp = h->opts.max_pivots;
   h->an.long_chain_pivots = (maxp <= 0 && !getenv("HQPKKT_MAX_PIVOTS")) ? 192 : 0;
   if (maxp <= 0) maxp = getenv("HQPKKT_MAX_PIVOTS") ? std::atoi(getenv("HQPKKT_MAX_PIVOTS")) : 160;
-  if (getenv("HQPKKT_OLD_FD")) maxp = std::min(maxp, 128);
   int e = h->an.run(h->opts.mode, n, me, m, h->pQp.data(), h->pQi.data(), h->pAp.data(), h->pAi.data(),
                     h->pCp.data(), h->pCi.data(), h->opts.leaf_size, maxp, zd);
   if (e) return e;
@@ -1506,12 +1504,10 @@ static bool direct_vectors(const hqpkkt_t *h) {
 // A caller's own factor / solve calls (not the device-resident loops): direct from the SECOND call in a row with the same
 // set of pointers (a caller that passes fresh vectors every time would pay a graph capture per call), and only if no
 // two of the vectors overlap (the staging copies read every input before any output is written; the sequences do not).
-// HQPKKT_NO_DIRECT_CALLS: off.
 struct DirectCall {
   hqpkkt_t *h;
   DirectCall(hqpkkt_t *h_, const void *const *ptr, const int *len, int count, const void **last) : h(h_) {
-    static const bool off = getenv("HQPKKT_NO_DIRECT_CALLS") != nullptr;
-    bool same = !off && !h->lazy && h->an.m > 0;
+    bool same = !h->lazy && h->an.m > 0;
     for (int i = 0; i < count; i++) same = same && ptr[i] == last[i] && (ptr[i] != nullptr || len[i] == 0);
     for (int i = 0; i < count; i++) last[i] = ptr[i];
     for (int i = 0; same && i < count; i++)
@@ -1722,9 +1718,8 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
   // that says "singular", fifteen can drag a consistent singular system below mat_eps, and the reference reports it)
   // Only inside the device-resident loops (h->lazy): a caller's own hqpkkt_solve - the reference's solvers through the
   // shim - gets the reference's five rounds and with them the residual the reference's plugin contract describes
-  // (HQPKKT_REFINE_MAX overrides both for experiments).  Rounds beyond five show in hqpkkt_stats.refine_rounds.
-  static const int refine_max_env = getenv("HQPKKT_REFINE_MAX") ? atoi(getenv("HQPKKT_REFINE_MAX")) : 0;
-  const int max_rounds = refine_max_env > 0 ? refine_max_env : (h->st.n_perturbed > 0 && h->lazy) ? 15 : 5;
+  // (ADVICE r5).  Rounds beyond five show in hqpkkt_stats.refine_rounds.
+  const int max_rounds = (h->st.n_perturbed > 0 && h->lazy) ? 15 : 5;
   for (int it = 0; it < max_rounds && res > target; it++) {
     if (it >= 5 && !(res < 0.5 * res_acc_prev)) break;  // beyond the reference's five: only while a round still halves the residual
     res_last = res;
@@ -2770,8 +2765,8 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device);
   const int skg = stg::gemm_wgs_per_cu(variant) * cus;
   // (HQPKKT_DGEMM_FORCE_SPLIT: the cut form whatever the launch rules say - same-box comparisons of the two forms)
-  const bool frac = !getenv("HQPKKT_NO_STREAMK") && !getenv("HQPKKT_NO_FRAC") && !getenv("HQPKKT_DGEMM_FORCE_SPLIT") && stg::gemm_use_frac(M, N, K, lower, skg);
-  const bool use_sk = !getenv("HQPKKT_NO_STREAMK") && (frac || stg::gemm_use_split(M, N, K, lower, skg) || getenv("HQPKKT_DGEMM_FORCE_SPLIT"));
+  const bool frac = !getenv("HQPKKT_DGEMM_FORCE_SPLIT") && stg::gemm_use_frac(M, N, K, lower, skg);
+  const bool use_sk = frac || stg::gemm_use_split(M, N, K, lower, skg) || getenv("HQPKKT_DGEMM_FORCE_SPLIT");
   const bool big = use_sk || stg::gemm_big_tiles(M, N, lower, K);
   const int b = big ? 128 : 64;
   const long long tiles = stg::gemm_tiles(M, N, b, lower);

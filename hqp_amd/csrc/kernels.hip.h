@@ -190,9 +190,9 @@ struct TermDev {
 // of a late interior-point iteration are of its order whatever max|K| = z/w has grown to
 #define SOFT_PIVOT_REL 1e-13
 // > 0: such a pivot is REPLACED by this multiple of its row's scale (static pivoting as the reference's PARDISO plugin
-// configures it, hqp/Hqp_IpPARDISO.C: perturbed pivots + iterative refinement) instead of being used as it is.  Set when a
-// handle uploads its tree (HQPKKT_TINY_PERTURB, 0: off; default 1e-6: with 1e-8 two of the ten finds stay - a smaller
-// replacement amplifies the rounding errors of its row more than the refinement gains from the smaller change)
+// configures it, hqp/Hqp_IpPARDISO.C: perturbed pivots + iterative refinement) instead of being used as it is (1e-6: with
+// 1e-8 two of the ten finds of rounds 1-4 stayed - a smaller replacement amplifies the rounding errors of its row more
+// than the refinement gains from the smaller change)
 __device__ double soft_pivot_pert = 1e-6;
 // ... but only where the caller has said that the matrix is known to be regular: a cancelled multiplier pivot is ALSO what
 // a rank-deficient equality block leaves behind (two identical rows), which the reference reports as E_SING / "degenerate"

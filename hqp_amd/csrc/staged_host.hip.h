@@ -142,7 +142,7 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
   // column (the control columns F + nn of a stage with an odd number of states) is staged through registers
   const bool al16 = ((((uintptr_t)g.A | (uintptr_t)g.B) & 15) == 0) && (((g.lda | g.ldb) & 1) == 0);
   // (allow_sk false: launches of the second stream - the workspace of the split form belongs to the first)
-  static const bool no_frac = getenv("HQPKKT_NO_FRAC") != nullptr;  // (same-box comparisons)
+  const bool no_frac = false;
   // (not for one system over several ranks: there the strip product W_p = V+ F_p - 200 tiles at eight ranks - runs beside
   // the second stream's control-sized products, and a launch whose 512 workgroups hold every CU for its whole duration
   // starves them: 1.46 against 1.32 ms per stage, tools/shard_pieces.py 8 0)
@@ -332,7 +332,7 @@ static int st_blk_sweep(hqpkkt_t *h, double *scratch, int q, bool allow_sk) {
   return 0;
 }
 static int st_small_big(hqpkkt_t *h, StagedDev &d, stg::SmallArgs sa, bool allow_sk) {
-  static const bool legacy = getenv("HQPKKT_NO_BLOCK_GJ") != nullptr;
+  const bool legacy = false;  // (the one-workgroup inverse: the fall-back of the blocked sweep only)
   static const double tol = getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
   if (legacy) {
     sa.mode = 0;
@@ -539,7 +539,7 @@ static int staged_upload(hqpkkt_t *h) {
     // product - 3.4 GB at the headline width, per handle, sharded or not)
     pmax = std::max(pmax * 5 / 4 + 64, 4LL * cus + 64);
     d.sk_grid = 0, d.sk_tiles = (int)tmax;
-    if (cus > 0 && !getenv("HQPKKT_NO_STREAMK")) {
+    if (cus > 0) {
       d.sk_grid = stg::gemm_wgs_per_cu(stg::gemm_variant_from_env()) * cus;
       // (the cut form of the 64 x 64 tiles: at most two phases of one unit per workgroup, up to 3/4 of its grid in tiles)
       d.sk_ws_elems = std::max<long long>(pmax, 1) * 128 * 128;
@@ -551,11 +551,10 @@ static int staged_upload(hqpkkt_t *h) {
   // The control-sized chain of a stage on a second stream beside its large product G_xx.  Measured on one MI355X (same
   // box, tools/c4_bench.py): stages of 1500 / 2000 / 2500 / 3000 states + 2.7 / 2.5 / 3.5 / 2.7 %, 5000 states - 1.1 % (the
   // separate skinny product for the control rows of G and the contention cost more than the hidden chain), 1000 states
-  // - 13 %.  So: on for stages of 1280 .. 4096 states; HQPKKT_OVERLAP=1 everywhere, =0 nowhere.  When sharded the
+  // - 13 %.  So: on for stages of 1280 .. 4096 states.  When sharded the
   // separate product exists anyway (staged_stage_sharded).
   {
-    const char *ov = getenv("HQPKKT_OVERLAP");
-    d.overlap_mode = ov ? (atoi(ov) != 0 ? 1 : 0) : 2;  // 2: by stage width
+    d.overlap_mode = 2;  // by stage width
     bool any = d.overlap_mode == 1 || P.sharded;
     if (d.overlap_mode == 2)
       for (int k = 0; k < P.K; k++) any = any || (P.nk[k] >= 1280 && P.nk[k] <= 4096);
@@ -1068,10 +1067,9 @@ static int staged_run_factor(hqpkkt_t *h, const double *z, const double *w) {
       KLAUNCH(h, KC_ST_SMALL, stg::k_st_check_fixed<<<1, 64, 0, s>>>(s0.dyn, h->flags.p));
     else if (P.big0) {
       // the inverse by the blocked sweep on the whole chip, checked against K0; the LU factorisation by one workgroup
-      // behind it runs only where the sweep gave up (decided on the device).  HQPKKT_NO_BLOCK_X0: the LU form only
-      static const bool legacy0 = getenv("HQPKKT_NO_BLOCK_X0") != nullptr;
-      static const double tol0 = getenv("HQPKKT_BLOCK_X0_TOL") ? atof(getenv("HQPKKT_BLOCK_X0_TOL"))
-                                 : getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
+      // behind it runs only where the sweep gave up (decided on the device)
+      const bool legacy0 = false;
+      static const double tol0 = getenv("HQPKKT_BLOCK_GJ_TOL") ? atof(getenv("HQPKKT_BLOCK_GJ_TOL")) : 1e-6;
       double *scr = d.misc.p + P.oScr;
       const int q = P.q0max;
       if (!legacy0) {
