@@ -9,6 +9,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -193,6 +194,13 @@ struct hqpkkt {
     unsigned long long *p = nullptr;
   } bits;
   double *hpin = nullptr;  // 128 doubles: 0..63 status words (as ints), 64.. the IP loop's scalars
+  // Read-backs without a copy and without hipStreamSynchronize (round 6): hpin is mapped, coherent host memory; a
+  // one-wavefront kernel at the point of the stream where the words are final stores them there and a sequence number
+  // behind them (k_post_words, kernels.hip.h), the host spins on that number (post_wait).  Measured (tools/post_probe.hip):
+  // 6 us per read-back behind a queue of small kernels against 16 for hipMemcpyAsync + hipStreamSynchronize - the
+  // device-resident interior-point loops read back three times per iteration.
+  double *hpin_dev = nullptr;  // the device's address of hpin
+  unsigned post_seq = 0;       // the number the last posting kernel in the stream will store (hpin word HPIN_SEQ)
   // host vectors of a small system: packed into / out of pinned memory by the CPU, ONE
   // transfer each way instead of six + four staged copies from pageable memory
   double *hvals = nullptr;   // pinned host staging of Qx | Ax | Cx (hqpkkt_values_staging), nq + na + nc doubles
@@ -318,7 +326,7 @@ struct hqpkkt {
     for (auto b : db) b->release();
     if (!keep_ip) ipv.release();
     terms.release(), esign.release(), bits.p = nullptr;
-    if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr;
+    if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr, hpin_dev = nullptr;
     if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
     // (keep_ip = the re-analysis inside hqpkkt_solve, switch_to_policy0: the pattern and with it the sizes of the
     // pinned value staging stay, and a host may hold the pointers of hqpkkt_values_staging)
@@ -399,6 +407,15 @@ static bool poll_fallback(hqpkkt_t *h, const int *hs) {
   return true;
 }
 
+// the mapped, coherent host words of the read-backs (hqpkkt::hpin; both engines)
+static int alloc_hpin(hqpkkt_t *h) {
+  if (h->hpin) return 0;
+  HIPCHK(hipHostMalloc((void **)&h->hpin, sizeof(double) * HPIN_DOUBLES, hipHostMallocMapped | hipHostMallocCoherent));
+  std::memset(h->hpin, 0, sizeof(double) * HPIN_DOUBLES);
+  HIPCHK(hipHostGetDevicePointer((void **)&h->hpin_dev, h->hpin, 0));
+  h->post_seq = 0;
+  return 0;
+}
 static int upload(hqpkkt_t *h) {
   int e = ensure_device(h);
   if (e) return e;
@@ -488,7 +505,7 @@ static int upload(hqpkkt_t *h) {
   h->bits.p = (unsigned long long *)(h->flags.p + 120);
   HIPCHK(hipMemset(h->flags.p, 0, sizeof(int) * 128));
   h->res_slot = 0, h->res_read = 122;
-  if (!h->hpin) HIPCHK(hipHostMalloc((void **)&h->hpin, sizeof(double) * 128, hipHostMallocDefault));
+  if ((e = alloc_hpin(h))) return e;
   if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr;
   h->hstage_in = h->hstage_out = 0;
   {
@@ -1093,6 +1110,32 @@ static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
 // residual of (d) for rhs (r); leaves the residual vectors in h->vres
 // out != nullptr: the caller's copy of (d) is put into the stream before the read-back, so
 // that a solve that needs no refinement round is over with this one round trip
+// ---- read-backs through mapped host memory (hqpkkt::hpin_dev)
+// the status words (and, with `out`, n_out <= 40 of the IP loop's scalars) as they stand at this point of the stream
+static int post_words(hqpkkt_t *h, const double *out, int n_out) {
+  h->post_seq++;
+  k_post_words<<<1, 64, 0, h->stream>>>(h->flags.p, out, n_out, h->hpin_dev, h->post_seq);
+  return 0;
+}
+// waits until the last posted words have arrived (every earlier post of the stream has then arrived as well)
+static int post_wait(hqpkkt_t *h) {
+  volatile unsigned *seq = (volatile unsigned *)(h->hpin + HPIN_SEQ);
+  for (long long spin = 0;; spin++) {
+    if (*seq == h->post_seq) break;
+    if ((spin & 0xfffff) == 0xfffff) {  // (about every millisecond: has the stream died or drained without the word?)
+      const hipError_t q = hipStreamQuery(h->stream);
+      if (q == hipSuccess) {
+        if (*seq == h->post_seq) break;
+        (void)snprintf(g_last_hip_error, sizeof(g_last_hip_error), "posted read-back: the stream is empty and the sequence word is %u, not %u", *seq, h->post_seq);
+        return HQPKKT_E_DEVICE;
+      }
+      if (q != hipErrorNotReady) HIPCHK(q);
+    }
+  }
+  std::atomic_thread_fence(std::memory_order_acquire);
+  return 0;
+}
+
 struct OutPtrs {
   double *dx, *dy, *dz, *dw;
 };
@@ -1127,14 +1170,16 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
     int e2 = stage_out(h, v, out->dx, out->dy, out->dz, out->dw);
     if (e2) return e2;
   }
-  // one copy: the residual maximum and the status of the factorisation this solve belongs to
-  HIPCHK(hipMemcpyAsync((int *)h->hpin, h->flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost, s));
+  // one read-back: the residual maximum and the status of the factorisation this solve belongs to
+  int ep;
+  if ((ep = post_words(h, nullptr, 0))) return ep;
   if (h->defer_residual && !out) {  // the caller queues more work and waits once (collect_residual)
     h->residual_pending = true;
     *res = 0.0;
     return 0;
   }
-  HIPCHK(hipStreamSynchronize(s));
+  if (out) HIPCHK(hipStreamSynchronize(s));  // (the caller's vectors: copies into pageable memory have landed)
+  if ((ep = post_wait(h))) return ep;
   return collect_residual(h, res);
 }
 
@@ -1793,9 +1838,8 @@ struct IpCtx {
     IpOps o;
     for (int k = 0; k < IP_SLOTS; k++) o.op[k] = ops[k];
     k_ip_final<<<1, 256, 0, h->stream>>>(part, o, out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-    HIPCHK(hipMemcpyAsync(hout, out, sizeof(double) * nout, hipMemcpyDeviceToHost, h->stream));
-    HIPCHK(hipStreamSynchronize(h->stream));
-    return 0;
+    int e = post_words(h, out, nout);  // (hout = hpin + 64: where the posting kernel puts them)
+    return e ? e : post_wait(h);
   }
 };
 }  // namespace
@@ -2056,8 +2100,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         IpOps o2;
         for (int k = 0; k < IP_SLOTS; k++) o2.op[k] = ops2[k];
         k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-        HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
+        if ((e = post_words(h, C.out, 40)) || (e = post_wait(h))) return e;  // (C.hout = hpin + 64: where the posting kernel puts them)
       }
       if (pending) {
         pending = false;
@@ -2386,9 +2429,8 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
         for (int k = 0; k < IP_SLOTS; k++) ou.op[k] = IP_SUM;
         ou.op[1] = IP_MAX;
         k_ip_final<<<1, 256, 0, s>>>(C.part, ou, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-        HIPCHK(hipMemcpyAsync(C.hout, C.out, sizeof(double) * 40, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        return 0;
+        int ep = post_words(h, C.out, 40);  // (with the status words the solve's residual kernel has left: collect_residual)
+        return ep ? ep : post_wait(h);
       };
       const double target = h->refine_target > 0.0 ? std::fmin(h->opts.eps, h->refine_target) : h->opts.eps;  // (as solve_tail)
       h->defer_residual = !getenv("HQPKKT_FRANKE_TWO_READS");

@@ -350,7 +350,8 @@ k_ip_update(int n, int me, int m, double alpha, const double *__restrict__ alpha
 // k_ip_final add it (virtual wavefront by virtual wavefront with the same butterfly, the four wavefronts of a block in
 // their order, then the 256 block sums the same way), so the loop's iterates are bit for bit those of the separate
 // launches (tests/test_gpu_franke.py::test_small_ip_kernels_bit_identical; HQPKKT_NO_IP_SMALL=1 keeps the launches).
-#define IP_SMALL_M 65536  // (with more, a thread of the separate launches holds more than one element)
+#define IP_SMALL_M 8192  // at most IP_SMALL_E elements of an m-vector per thread: z, w and the step stay in registers over the phases
+#define IP_SMALL_E 8
 // combine over the workgroup's 1024 threads (any order: minima / maxima only); every thread gets the result
 __device__ __forceinline__ double ip_small_minmax(double v, bool is_max, double *red16) {
   v = is_max ? wave_max(v) : -wave_max(-v);
@@ -362,19 +363,30 @@ __device__ __forceinline__ double ip_small_minmax(double v, bool is_max, double 
   __syncthreads();
   return r;
 }
+// element tid + 1024 u of four m-vectors (u < IP_SMALL_E), all loads of a thread in flight together (a loop of dependent
+// loads - one memory latency per trip - was most of these kernels' time); beyond m: element 0, not used
+#define IP_SMALL_LOAD(A, B, Cc, D, a, b, c, d)                                 \
+  double a[IP_SMALL_E], b[IP_SMALL_E], c[IP_SMALL_E], d[IP_SMALL_E];           \
+  _Pragma("unroll") for (int u = 0; u < IP_SMALL_E; u++) {                     \
+    const int i_ = (int)threadIdx.x + 1024 * u, ic_ = i_ < m ? i_ : 0;         \
+    a[u] = A[ic_], b[u] = B[ic_], c[u] = Cc[ic_], d[u] = D[ic_];               \
+  }
 __global__ void __launch_bounds__(1024)
 k_ip_pred_small(int m, const double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ dza,
                 const double *__restrict__ dwa, double mu, double gamma, double *__restrict__ S, double *__restrict__ r4) {
   __shared__ double red16[16];
   __shared__ double bc[2];
+  IP_SMALL_LOAD(z, w, dza, dwa, zz, ww, dzz, dww)
   // k_ip_ratio + k_ip_final + ip_sigma
   double a = 1e300, t = 0.0;
-  for (int i = threadIdx.x; i < m; i += 1024) {
-    const double zi = z[i], wi = w[i], dzi = dza[i], dwi = dwa[i];
-    if (dzi < 0.0) a = fmin(a, -zi / dzi);
-    if (dwi < 0.0) a = fmin(a, -wi / dwi);
-    if (dzi * dwi > 0.0) t = fmax(t, dzi * dwi / zi / wi);
-  }
+#pragma unroll
+  for (int u = 0; u < IP_SMALL_E; u++)
+    if ((int)threadIdx.x + 1024 * u < m) {
+      const double zi = zz[u], wi = ww[u], dzi = dzz[u], dwi = dww[u];
+      if (dzi < 0.0) a = fmin(a, -zi / dzi);
+      if (dwi < 0.0) a = fmin(a, -wi / dwi);
+      if (dzi * dwi > 0.0) t = fmax(t, dzi * dwi / zi / wi);
+    }
   const double amin = ip_small_minmax(a, false, red16), tmax = ip_small_minmax(t, true, red16);
   if (threadIdx.x == 0) {
     const double two[2] = {amin, tmax};
@@ -384,7 +396,11 @@ k_ip_pred_small(int m, const double *__restrict__ z, const double *__restrict__ 
   __syncthreads();
   // k_ip_corr_rhs
   const double smm = bc[0];
-  for (int i = threadIdx.x; i < m; i += 1024) r4[i] = ip_corr_elem(z[i], w[i], dza[i], dwa[i], smm);
+#pragma unroll
+  for (int u = 0; u < IP_SMALL_E; u++) {
+    const int i = (int)threadIdx.x + 1024 * u;
+    if (i < m) r4[i] = ip_corr_elem(zz[u], ww[u], dzz[u], dww[u], smm);
+  }
 }
 
 __global__ void __launch_bounds__(1024)
@@ -398,17 +414,23 @@ k_ip_step_small(int n, int me, int m, double *__restrict__ x, double *__restrict
   __shared__ double red4[4];
   __shared__ double bc[2];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  ws[tid] = 0.0;  // (virtual wavefronts behind m: a sum of zeros)
+  IP_SMALL_LOAD(z, w, dz, dw, zz, ww, dzz, dww)
   // ---- k_ip_minratio_part + _final: the blocking components (smallest ratio, smallest index among equals)
   double zv = 1e300, wv = 1e300;
   int zi = 0x7fffffff, wi = 0x7fffffff;
-  for (int i = tid; i < m; i += 1024) {
-    if (dz[i] < 0.0) {
-      const double q = -z[i] / dz[i];
-      if (q < zv || (q == zv && i < zi)) zv = q, zi = i;
-    }
-    if (dw[i] < 0.0) {
-      const double q = -w[i] / dw[i];
-      if (q < wv || (q == wv && i < wi)) wv = q, wi = i;
+#pragma unroll
+  for (int u = 0; u < IP_SMALL_E; u++) {
+    const int i = tid + 1024 * u;
+    if (i < m) {
+      if (dzz[u] < 0.0) {
+        const double q = -zz[u] / dzz[u];
+        if (q < zv || (q == zv && i < zi)) zv = q, zi = i;
+      }
+      if (dww[u] < 0.0) {
+        const double q = -ww[u] / dww[u];
+        if (q < wv || (q == wv && i < wi)) wv = q, wi = i;
+      }
     }
   }
   double bk[12];
@@ -440,17 +462,19 @@ k_ip_step_small(int n, int me, int m, double *__restrict__ x, double *__restrict
     bc[0] = S[IPS_ALPHA_PRE];
   }
   __syncthreads();
-  // ---- k_ip_mupl + k_ip_final: (z + alpha dz)'(w + alpha dw), in the order of the 256 x 256 launch (m <= 65536: a
-  // thread of that launch holds at most one element, element 64 v + lane belongs to lane `lane` of virtual wavefront v)
+  // ---- k_ip_mupl + k_ip_final: (z + alpha dz)'(w + alpha dw), in the order of the 256 x 256 launch (m <= IP_SMALL_M: a
+  // thread of that launch holds at most one element; element tid + 1024 u belongs to lane `lane` of its virtual
+  // wavefront wave + 16 u)
   const double alpha_pre = bc[0];
-  for (int v = wave; v < 1024; v += 16) {
-    const int i = 64 * v + lane;
-    double s = 0.0;
+#pragma unroll
+  for (int u = 0; u < IP_SMALL_E; u++) {
+    const int v = wave + 16 * u;
     if (64 * v < m) {  // wave-uniform
-      if (i < m) s += ip_mupl_elem(z[i], w[i], dz[i], dw[i], alpha_pre);
+      double s = 0.0;
+      if (tid + 1024 * u < m) s += ip_mupl_elem(zz[u], ww[u], dzz[u], dww[u], alpha_pre);
       s = wave_sum(s);
+      if (lane == 0) ws[v] = s;
     }
-    if (lane == 0) ws[v] = s;
   }
   __syncthreads();
   {
@@ -474,17 +498,15 @@ k_ip_step_small(int n, int me, int m, double *__restrict__ x, double *__restrict
   }
   // ---- k_ip_update
   const double alpha = bc[1];
-  const int total = n + me + m;
-  for (int q = tid; q < total; q += 1024) {
-    if (q < n) {
-      x[q] = x[q] + alpha * dx[q];
-    } else if (q < n + me) {
-      y[q - n] += alpha * dy[q - n];
-    } else {
-      const int j = q - n - me;
-      z[j] = z[j] + alpha * dz[j], w[j] = w[j] + alpha * dw[j];
-    }
+#pragma unroll
+  for (int u = 0; u < IP_SMALL_E; u++) {
+    const int i = tid + 1024 * u;
+    if (i < m) z[i] = zz[u] + alpha * dzz[u], w[i] = ww[u] + alpha * dww[u];
   }
+#pragma unroll 4
+  for (int q = tid; q < n; q += 1024) x[q] = x[q] + alpha * dx[q];
+#pragma unroll 4
+  for (int q = tid; q < me; q += 1024) y[q] = y[q] + alpha * dy[q];
 }
 
 // cold start (:226-250): z = 1, w = w0 (1; a norm ratio with qp_init_method 1, 2), r1 = c,

@@ -2847,6 +2847,23 @@ __global__ void __launch_bounds__(256) k_clear(double *__restrict__ p, long long
   for (; i < b1; i += 256) q[i] = zero;
   if ((n & 1) && blockIdx.x == 0 && threadIdx.x == 0) p[n - 1] = 0.0;
 }
+// Read-back through mapped, coherent host memory (hqpkkt::hpin_dev): ONE wavefront stores the 128 status words of
+// `flags` (as 64 eight-byte words) and, with `out`, n_out <= 64 doubles behind double 64, then - behind a system-scope
+// fence - the sequence number the host spins on.  (One wavefront: its stores are ordered by its own fence.)
+#define HPIN_DOUBLES 256
+#define HPIN_SEQ 200  // the double of hpin whose first four bytes hold the sequence number
+__global__ void __launch_bounds__(64) k_post_words(const int *__restrict__ flags, const double *__restrict__ out, int n_out,
+                                                   double *__restrict__ host, unsigned seq) {
+  const int lane = threadIdx.x;
+  const unsigned long long w = ((const unsigned long long *)flags)[lane];
+  __hip_atomic_store((unsigned long long *)host + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (out && lane < n_out)
+    __hip_atomic_store((unsigned long long *)host + 64 + lane, (unsigned long long)__double_as_longlong(out[lane]), __ATOMIC_RELAXED,
+                       __HIP_MEMORY_SCOPE_SYSTEM);
+  __threadfence_system();
+  if (lane == 0) __hip_atomic_store((unsigned *)(host + HPIN_SEQ), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
 // sharded mode: clear the (offset, length) ranges of an arena this rank writes
 __global__ void k_zero_ranges(double *__restrict__ base, const long long *__restrict__ ranges) {
   const long long off = ranges[2 * blockIdx.y], len = ranges[2 * blockIdx.y + 1];

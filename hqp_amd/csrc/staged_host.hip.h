@@ -450,7 +450,7 @@ static int staged_upload(hqpkkt_t *h) {
       (e = h->vcor.alloc((size_t)n + me + 2 * (size_t)m)) || (e = h->tz.alloc(m)))
     return e;
   h->bits.p = (unsigned long long *)(h->flags.p + 120);
-  if (!h->hpin) HIPCHK(hipHostMalloc((void **)&h->hpin, sizeof(double) * 128, hipHostMallocDefault));
+  if ((e = alloc_hpin(h))) return e;
   if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr;
   h->hstage_in = h->hstage_out = 0;
   {
