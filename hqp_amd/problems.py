@@ -270,6 +270,45 @@ def random_sparse_qp(n, me, m, row_nnz=4, seed=7):
                    b=rng.uniform(-1, 1, me), d=rng.uniform(0.5, 1.5, m))
 
 
+def cute_like_qp(n, nnz_lo=10, nnz_hi=100, window=400, far=0.001, eq_frac=0.3, bound_frac=0.6, seed=17):
+    """SURVEY.md section 8(d) C5's row density - "CUTE-style" sparse QP with 10 ... 100 (nnz_lo ... nnz_hi) entries per
+    row - with the locality such programs have (hqp_cute/hqp_cute.tcl:22-46 runs the CUTE collection through
+    RedSpBKP: discretised control and structural problems, not random graphs): a row of Q couples variable i with
+    nnz_lo ... nnz_hi variables drawn from a window of `window` columns behind it, a fraction `far` of the entries
+    anywhere (irregular part: one entry in a thousand - 2600 far couplings at n = 10^5; with one in a hundred every second
+    variable has one and the graph has no small separators left: fronts of 19 000 rows at n = 5 10^4); diagonally dominant.  n eq_frac equality rows over nnz_lo / 2 ... nnz_hi / 2 columns of a
+    window around a random centre; bounds (one-entry inequality rows) on a fraction bound_frac of the variables."""
+    rng = np.random.default_rng(seed)
+    cnt = rng.integers(max(1, nnz_lo // 2), max(1, nnz_hi // 2) + 1, size=n)  # (entries behind the diagonal: a full row has about twice as many)
+    i = np.repeat(np.arange(n, dtype=np.int64), cnt)
+    off = rng.integers(1, window + 1, size=i.size)
+    j = i + off
+    is_far = rng.random(i.size) < far
+    j[is_far] = rng.integers(0, n, size=int(is_far.sum()))
+    keep = (j < n) & (j != i)
+    lo, hi = np.minimum(i[keep], j[keep]), np.maximum(i[keep], j[keep])
+    key = np.unique(lo * n + hi)
+    lo, hi = key // n, key % n
+    v = rng.uniform(-0.5, 0.5, size=lo.size)
+    rowsum = np.zeros(n)
+    np.add.at(rowsum, lo, np.abs(v))
+    np.add.at(rowsum, hi, np.abs(v))
+    Q = _csr(np.concatenate([np.arange(n), lo]), np.concatenate([np.arange(n), hi]), np.concatenate([1.0 + rowsum, v]), n)
+    me = int(eq_frac * n)
+    centre = np.sort(rng.integers(0, n, size=me))
+    ecnt = rng.integers(max(1, nnz_lo // 2), max(2, nnz_hi // 2) + 1, size=me)
+    er = np.repeat(np.arange(me, dtype=np.int64), ecnt)
+    ec = np.repeat(centre, ecnt) + rng.integers(-window // 2, window // 2 + 1, size=er.size)
+    ec = np.clip(ec, 0, n - 1)
+    ekey = np.unique(er * n + ec)
+    er, ec = ekey // n, ekey % n
+    A = _csr(er, ec, rng.uniform(-1.0, 1.0, size=er.size), me)
+    bounded = np.flatnonzero(rng.random(n) < bound_frac)
+    m = bounded.size
+    C = _csr(np.arange(m), bounded, np.ones(m), m)
+    return Program(n, me, m, Q, A, C, c=rng.uniform(-1, 1, n), b=0.1 * rng.uniform(-1, 1, me), d=rng.uniform(0.5, 1.5, m))
+
+
 def grid_sparse_qp(gx, gy, seed=11, eq_every=3, bound_frac=0.5, long_range=0):
     """Mesh-structured QP, the sparsity of a discretised control problem (what the CUTE collection's
     large programs look like, BASELINE configs[4]): one variable per cell of a gx x gy grid, Q couples

@@ -23,16 +23,21 @@ STRIDE = 37
 # name: (n, band, seed of the QP, seed of the interior-point state, w / z spread in decades, plugin)
 #   or: ("mesh", cells per side, seed of the QP, seed of the state, spread, plugin) - problems.grid_sparse_qp, the stand-in of
 #   BASELINE.json's configs[4] at 10^5 variables (the reference: RCM band 631, 51 s; ours: the dissection of the KKT graph)
+#   or: ("cute", n, seed of the QP, seed of the state, spread, plugin) - problems.cute_like_qp
 CASES = {
     "c2_banded_n40000_b80_SpBKP": (40000, 80, 12345, 1, 0.0, "SpBKP"),
     "c2_banded_n40000_b80_RedSpBKP_spread": (40000, 80, 12345, 2, 2.0, "RedSpBKP"),
     "mesh_316x316_RedSpBKP": ("mesh", 316, 5, 1, 1.0, "RedSpBKP"),
+    # SURVEY.md 8(d) C5's row density (problems.cute_like_qp: 10 ... 100 entries per row in a window of 400 columns, 0.1 % of
+    # them anywhere) at the largest size the reference finishes in about a minute (65 s): its RCM band is the whole matrix here
+    "cute_n6500_RedSpBKP": ("cute", 6500, 17, 1, 1.0, "RedSpBKP"),
 }
 
 
 def inputs(case):
     n, band, seed, sseed, spread, _kind = case
-    prog = problems.grid_sparse_qp(band, band, seed=seed) if n == "mesh" else problems.banded_qp(n, band, seed)
+    prog = problems.grid_sparse_qp(band, band, seed=seed) if n == "mesh" else \
+        problems.cute_like_qp(band, seed=seed) if n == "cute" else problems.banded_qp(n, band, seed)
     return prog, problems.ip_state(prog, sseed, spread)
 
 

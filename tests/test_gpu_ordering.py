@@ -138,6 +138,36 @@ def test_band_with_long_range_couplings_at_1e5_variables():
     assert all(np.array_equal(a, b) for a, b in zip(d1, d3))
 
 
+def test_cute_style_rows_at_1e5_variables():
+    """SURVEY.md 8(d) C5's row density at 10^5 variables (problems.cute_like_qp: 10 ... 100 entries per row of Q in a window
+    of 400 columns, 0.1 % of them anywhere; 30 000 equality rows of 5 ... 50 entries; KKT dimension 1.3e5 reduced, 6.6e6
+    entries) through the graph's own dissection (ordering 2) - the same generator the reference fixture of
+    tests/golden_full_size/ uses at n = 6500.  Size-independent properties: residual <= 1e-10, residuum() of the solution
+    equal to what solve() returned, linear in the right-hand side, a second factorisation bit-identical."""
+    prog = problems.cute_like_qp(100000)
+    st = problems.ip_state(prog, 2, 1.0)
+    M = ipmatrix.IpRedSpBKP(ordering=2)
+    M.init(prog)
+    s = M.stats()
+    assert s["bytes_panels"] + s["bytes_updates"] < 60e9, s
+    new = lambda: [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+    M.factor(prog, st[0], st[1])
+    d1 = new()
+    res = M.solve(prog, *st, *d1)
+    assert res <= 1e-10
+    assert abs(M.residuum(prog, *st, *d1) - res) <= 1e-13
+    st2 = (st[0], st[1]) + tuple(2.0 * v for v in st[2:])
+    d2 = new()
+    assert M.solve(prog, *st2, *d2) <= 1e-10
+    scale = max(np.abs(v).max() for v in d1)
+    assert max(np.abs(b - 2.0 * a).max() for a, b in zip(d1, d2)) <= 1e-9 * scale
+    M.factor(prog, st[0], st[1])
+    d3 = new()
+    M.solve(prog, *st, *d3)
+    assert all(np.array_equal(a, b) for a, b in zip(d1, d3))
+    print("cute_like_qp(1e5):", {k: s[k] for k in ("dim", "max_front", "n_levels", "n_supernodes", "flops_factor", "bytes_panels", "bytes_updates")})
+
+
 def test_sqp_loop_over_a_sparse_nlp_of_1e5_variables():
     """BASELINE configs[4]'s stand-in at 10^5 variables INSIDE the test suite: the reference's unmodified Hqp_SqpPowell
     over Prg_GridNLP on 320 x 320 cells (102 400 variables) with the reference's Hqp_IpsMehrotra driving RedSpBKPHip

@@ -228,7 +228,8 @@ def test_full_size_c2_against_the_reference_golden(name):
     reference's solve() result, the norms, the sums and the residual; inputs regenerated from the seeds, guarded by a
     checksum), the second fixture with w / z spread over four decades; and the 316 x 316 mesh of 10^5 variables (the
     stand-in of configs[4]; the reference factorises its RCM band of 631 in 51 s, the tree engine the dissection of the
-    KKT graph): residual of solve() <= the reference's + 1e-10,
+    KKT graph); and SURVEY.md 8(d) C5's row density - problems.cute_like_qp, 10 ... 100 entries per row, at n = 6500 (the
+    largest the reference finishes in about a minute: 65 s): residual of solve() <= the reference's + 1e-10,
     the sampled components to 1e-8 of the vector's norm, norms and sums to 1e-8."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("make_golden_full", os.path.join(FULL_DIR, "make_golden.py"))
@@ -238,9 +239,10 @@ def test_full_size_c2_against_the_reference_golden(name):
     case = mg.CASES[name]
     prog, st = mg.inputs(case)
     np.testing.assert_allclose(mg.checksum(prog, st), g["checksum"], rtol=1e-13)
-    M = CLS[case[5]](**(dict(ordering=2) if case[0] == "mesh" else {}))  # (the mesh: the dissection of the KKT graph itself)
+    irregular = case[0] in ("mesh", "cute")
+    M = CLS[case[5]](**(dict(ordering=2) if irregular else {}))  # (the mesh, the CUTE-style rows: the dissection of the KKT graph itself)
     M.init(prog)
-    if case[0] != "mesh":
+    if not irregular:
         assert M.stats()["dim"] == (100000 if case[5] == "SpBKP" else 60000)
     M.factor(prog, st[0], st[1])
     d = new_d(prog)
