@@ -11,5 +11,4 @@ echo "## rank-q update V = G_xx - Y'Rm (whole lower triangle, mirrored, by every
 python3 tools/dgemm_shapes.py 5000x5000x100x1x1 2>&1 | grep dgemm
 echo "## one rank's stage, per kernel"
 bash tools/shard_pieces.sh 1:0 2:0 2:1 4:0 4:3 8:0 8:7
-echo "## the model (tools/shard_model.py)"
-python3 tools/shard_model.py gpurun_out/r05_slice_products.txt
+# (the model from these pieces: python3 tools/shard_model.py <this output>)
