@@ -26,7 +26,7 @@ SYMBOLS = [
     "hqpkkt_selftest_mfma", "hqpkkt_set_profile", "hqpkkt_get_profile",
     "hqpkkt_profile_class_name", "hqpkkt_set_shard", "hqpkkt_debug_read",
     "hqpkkt_default_ip_opts", "hqpkkt_mehrotra", "hqpkkt_franke",
-    "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm",
+    "hqpkkt_set_stages", "hqpkkt_debug_stage_ranks", "hqpkkt_debug_dgemm", "hqpkkt_debug_sk_table",
     "hqpkkt_analyze_staged", "hqpkkt_set_values_staged", "hqpkkt_set_shard_stream",
     "hqpkkt_values_staging", "hqpkkt_detect_stages", "hqpkkt_stage_staging", "hqpkkt_set_stage_block",
     "hqpkkt_debug_factor_block", "hqpkkt_debug_solve_top_stamps",
@@ -138,6 +138,8 @@ def lib():
     L.hqpkkt_values_staging.argtypes = [vp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     L.hqpkkt_set_shard_stream.argtypes = [vp, C.c_int, C.c_int, vp, vp]
     L.hqpkkt_debug_dgemm.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_double)] * 2
+    L.hqpkkt_debug_sk_table.argtypes = [C.c_longlong, C.c_int, C.c_int, C.POINTER(C.c_int), C.c_longlong, C.POINTER(C.c_longlong),
+                                        C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.hqpkkt_debug_solve_top_stamps.argtypes = [vp, vp, C.c_int]
     L.hqpkkt_debug_factor_block.argtypes = [C.c_int, C.c_int, vp, C.c_double, C.c_double, C.c_int, C.c_int] + [vp] * 7
     _lib = L

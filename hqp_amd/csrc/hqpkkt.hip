@@ -2784,8 +2784,9 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   HIPCHK(hipSetDevice(device));
   const long long lda = (M + 7) / 8 * 8, ldb = (N + 7) / 8 * 8, ldc = ldb;
   double *A = nullptr, *B = nullptr, *Cm = nullptr, *err = nullptr, *zr = nullptr;
+  stg::SkUnit *sk_table_dev = nullptr;
   auto fin = [&](int rc) {
-    (void)hipFree(A), (void)hipFree(B), (void)hipFree(Cm), (void)hipFree(err), (void)hipFree(zr);
+    (void)hipFree(A), (void)hipFree(B), (void)hipFree(Cm), (void)hipFree(err), (void)hipFree(zr), (void)hipFree(sk_table_dev);
     return rc;
   };
   const size_t kk = K > 0 ? K : 1;
@@ -2823,6 +2824,17 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
       return fin(HQPKKT_E_MEM);
     }
   }
+  // (the cut form by a table with unequal shares for the two workgroups of a CU: gemm_split_table; HQPKKT_SK_TABLE=0: equal shares)
+  stg::SplitTable sk_tab;
+  if (use_sk && !frac && stg::gemm_sk_table_from_env() && stg::gemm_split_table(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg, sk_tab) &&
+      sk_tab.pieces <= 16 * tiles + 8) {
+    const size_t nu = sk_tab.units.size();
+    if (hipMalloc((void **)&sk_table_dev, sizeof(stg::SkUnit) * nu) != hipSuccess ||
+        hipMemcpy(sk_table_dev, sk_tab.units.data(), sizeof(stg::SkUnit) * nu, hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipFree(skws), (void)hipFree(skcnt);
+      return fin(HQPKKT_E_MEM);
+    }
+  }
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0), (void)hipEventCreate(&e1);
   for (int r = -1; r < reps; r++) {
@@ -2832,6 +2844,7 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
       stg::SplitPlan skk = frac ? stg::gemm_split_plan_frac(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg)
                                 : stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
       skk.ws = skws, skk.cnt = skcnt;
+      if (sk_table_dev) skk.table = sk_table_dev, skk.stride = sk_tab.stride;
       stg::gemm_launch_split(variant, skg, 0, g, skk);
     } else if (big)
       stg::gemm_launch_plain(variant, (unsigned)tiles, 0, g, cus);
@@ -2847,39 +2860,58 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   (void)hipEventElapsedTime(&t, e0, e1);
   (void)hipEventDestroy(e0), (void)hipEventDestroy(e1);
   if (se != hipSuccess) return fin(HQPKKT_E_DEVICE);
-  if (getenv("HQPKKT_DGEMM_STAMPS") && use_sk) {
-    // the split form with time stamps: per workgroup its start and, per round / split phase, the end of the k
-    // loop, of the parking / summing of partial tiles and of the epilogue (us after the first start)
+  if (getenv("HQPKKT_DGEMM_STAMPS") && use_sk && !frac) {
+    // the split form with time stamps: per workgroup its start and, per unit, the end of the k loop, of the
+    // parking / summing of partial tiles and of the epilogue (us after the first start)
     unsigned long long *st = nullptr;
     double *ws2 = nullptr;
     unsigned *cnt2 = nullptr;
-    if (hipMalloc((void **)&st, sizeof(unsigned long long) * 16 * skg) == hipSuccess &&
+    if (hipMalloc((void **)&st, sizeof(unsigned long long) * 32 * skg) == hipSuccess &&
         hipMalloc((void **)&ws2, sizeof(double) * (size_t)(16 * tiles + 8) * 128 * 128) == hipSuccess &&
         hipMalloc((void **)&cnt2, sizeof(unsigned) * (tiles + 4)) == hipSuccess) {
-      (void)hipMemset(st, 0, sizeof(unsigned long long) * 16 * skg);
+      (void)hipMemset(st, 0, sizeof(unsigned long long) * 32 * skg);
       (void)hipMemset(cnt2, 0, sizeof(unsigned) * (tiles + 4));
       stg::GemmArgs gs = g;
       gs.stamps = st;
       stg::SplitPlan skk = stg::gemm_split_plan(tiles, (K + stg::GEMM_BK - 1) / stg::GEMM_BK, skg);
       skk.ws = ws2, skk.cnt = cnt2;
+      if (sk_table_dev) skk.table = sk_table_dev, skk.stride = sk_tab.stride;
       stg::gemm_launch_split(variant, skg, 0, gs, skk);
-      std::vector<unsigned long long> hs(16 * (size_t)skg);
-      if (hipMemcpy(hs.data(), st, sizeof(unsigned long long) * 16 * skg, hipMemcpyDeviceToHost) == hipSuccess) {
+      std::vector<unsigned long long> hs(32 * (size_t)skg);
+      if (hipMemcpy(hs.data(), st, sizeof(unsigned long long) * 32 * skg, hipMemcpyDeviceToHost) == hipSuccess) {
         unsigned long long tmin = ~0ULL;
-        for (int w = 0; w < skg; w++) tmin = std::min(tmin, hs[16 * (size_t)w]);
-        fprintf(stderr, "split plan: %d whole tiles", skk.whole);
-        for (int q = 0; q < skk.nphase; q++) fprintf(stderr, ", %d tiles x %d pieces", skk.count[q], skk.split[q]);
-        fprintf(stderr, "; stamps of every %dth workgroup (us): start | per round: k loop end, parked / summed, epilogue end\n", std::max(1, skg / 32));
+        for (int w = 0; w < skg; w++) tmin = std::min(tmin, hs[32 * (size_t)w]);
+        if (sk_table_dev)
+          fprintf(stderr, "table plan: %d / %d whole tiles per first / second workgroup of a CU, %lld parked pieces", sk_tab.nA, sk_tab.nB, sk_tab.pieces);
+        else {
+          fprintf(stderr, "split plan: %d whole tiles", skk.whole);
+          for (int q = 0; q < skk.nphase; q++) fprintf(stderr, ", %d tiles x %d pieces", skk.count[q], skk.split[q]);
+        }
+        fprintf(stderr, "; stamps of every %dth workgroup (us): start | per unit: k loop end, parked / summed, epilogue end\n", std::max(1, skg / 32));
+        const int nr = sk_table_dev ? std::min(10, sk_tab.stride - 1) : std::min(5, skk.dp_rounds + skk.nphase);
         for (int w = 0; w < skg; w += std::max(1, skg / 32)) {
-          fprintf(stderr, "  wg %4d: %7.2f |", w, (hs[16 * (size_t)w] - tmin) * 0.01);
-          for (int r = 0; r < std::min(5, skk.dp_rounds + skk.nphase); r++) {
+          fprintf(stderr, "  wg %4d: %7.2f |", w, (hs[32 * (size_t)w] - tmin) * 0.01);
+          for (int r = 0; r < nr; r++) {
             for (int c = 1; c <= 3; c++) {
-              const unsigned long long x = hs[16 * (size_t)w + 3 * r + c];
+              const unsigned long long x = hs[32 * (size_t)w + 3 * r + c];
               if (x) fprintf(stderr, " %8.2f", (x - tmin) * 0.01); else fprintf(stderr, "        -");
             }
             fprintf(stderr, " |");
           }
           fprintf(stderr, "\n");
+        }
+        // the end of every workgroup's last unit, per class (first / second half of the launch)
+        for (int c = 0; c < 2; c++) {
+          double lo = 1e30, hi = 0.0, sum = 0.0;
+          int n = 0;
+          for (int w = c * skg / 2; w < (c + 1) * skg / 2; w++) {
+            unsigned long long last = 0;
+            for (int r = 0; r < 10; r++) last = std::max(last, hs[32 * (size_t)w + 3 * r + 3]);
+            if (!last) continue;
+            const double e = (last - tmin) * 0.01;
+            lo = std::min(lo, e), hi = std::max(hi, e), sum += e, n++;
+          }
+          if (n) fprintf(stderr, "  class %c (blockIdx %s grid / 2): last epilogue ends at %.1f ... %.1f us, mean %.1f\n", c ? 'B' : 'A', c ? ">=" : "<", lo, hi, sum / n);
         }
       }
     }
@@ -2918,6 +2950,23 @@ int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, i
   if (ms) *ms = t / reps;
   if (max_err) *max_err = he;
   return fin(0);
+}
+
+int hqpkkt_debug_sk_table(long long tiles, int nslab, int grid, int *units, long long cap_ints, long long *pieces, int *whole_a, int *whole_b) {
+  stg::SplitTable t;
+  if (!stg::gemm_split_table(tiles, nslab, grid, t)) return 0;
+  if (pieces) *pieces = t.pieces;
+  if (whole_a) *whole_a = t.nA;
+  if (whole_b) *whole_b = t.nB;
+  if (units) {
+    if ((long long)t.units.size() * 6 > cap_ints) return 0;
+    for (size_t i = 0; i < t.units.size(); i++) {
+      const stg::SkUnit &u = t.units[i];
+      int *o = units + 6 * i;
+      o[0] = u.tile, o[1] = u.s0, o[2] = u.s1, o[3] = u.slot0, o[4] = u.pieces, o[5] = u.j;
+    }
+  }
+  return t.stride;
 }
 
 int hqpkkt_set_profile(hqpkkt_t *h, int on) {

@@ -20,6 +20,7 @@
 #include <algorithm>
 
 #include "staged_plan.hpp"
+#include "sk_table.hpp"
 
 namespace stg {
 
@@ -612,6 +613,10 @@ struct SplitPlan {
   // tile it ends in).  For products of a few hundred tiles (stages of 1000 - 3000 states, the strips of a system
   // over several ranks), where whole rounds and cut remainders leave a large part of the chip idle.
   int frac, per, ntiles;
+  // The table form (gemm_split_table): the units of every workgroup listed by the host - workgroup b (blockIdx.x) does
+  // table[b * stride + i], i = 0 ... until a tile < 0 (SkUnit, sk_table.hpp).
+  const SkUnit *table;
+  int stride;
 };
 
 // Host: the plan for `tiles` tiles of `nslab` k-slabs on `grid` workgroups.  The remainder R of the whole
@@ -686,13 +691,85 @@ __global__ void __launch_bounds__(64 * WGM * WGN, NBUF == 3 ? WGM * WGN / 4 : WG
   const int G = gridDim.x, v = xcd_swizzle(blockIdx.x, G);
   const int nslab = (g.K + T::BK - 1) / T::BK;
   constexpr int SLOT = BM * BN;
-  unsigned long long *stamp = g.stamps ? g.stamps + 16 * (long long)blockIdx.x : nullptr;  // (diagnostic launches only)
+  unsigned long long *stamp = g.stamps ? g.stamps + 32 * (long long)blockIdx.x : nullptr;  // (diagnostic launches only)
   if (stamp && threadIdx.x == 0) stamp[0] = __builtin_amdgcn_s_memrealtime();
   // Units of work: the whole tiles of the rounds (unit u = tile u), then the pieces of the split phases (phase q:
   // unit = piece j of tile ti at j * count[q] + ti).  Workgroup w does unit w of every round and phase: its
   // neighbours in the XCD work on the neighbouring tiles at the same k.  (A queue of units was measured in round 3
   // and does not pay: profiles/NOTES.md.)  The result does not depend on who computes what: a tile's pieces are fixed
   // k ranges, summed in their order.
+  if (sk.table) {
+    auto unit = [&](const SkUnit u, int r) {
+      const int t = u.tile, s0 = u.s0, s1 = u.s1, pieces = u.pieces, j = u.j;
+      int tm, tn;
+      T::tile_of(g, t, tm, tn);
+      double4_t acc[T::TM][T::TN];
+#pragma unroll
+      for (int x = 0; x < T::TM; x++)
+#pragma unroll
+        for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+      if constexpr (DMA)
+        T::accumulate_dma(g, tm * BM, tn * BN, s0, s1, acc, As, Bs, g.lower && tm == tn, NBUF);
+      else
+        T::accumulate(g, tm * BM, tn * BN, s0, s1, acc, As, Bs);
+      bool finish = true;
+      if (stamp && threadIdx.x == 0 && r < 10) stamp[1 + 3 * r] = __builtin_amdgcn_s_memrealtime();
+      if (pieces > 1) {
+        double *mine = sk.ws + (long long)(u.slot0 + j) * SLOT;
+#pragma unroll
+        for (int x = 0; x < T::TM; x++)
+#pragma unroll
+          for (int y = 0; y < T::TN; y++)
+#pragma unroll
+            for (int rg = 0; rg < 4; rg++) mine[((x * T::TN + y) * 4 + rg) * T::NT + threadIdx.x] = acc[x][y][rg];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (threadIdx.x == 0) {
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          *s_old = __hip_atomic_fetch_add(sk.cnt + t, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        finish = *s_old == (unsigned)(pieces - 1);
+        if (finish) {
+          if (threadIdx.x == 0) {
+            sk.cnt[t] = 0;  // (every piece of the tile has arrived: the counter is ready for the next launch)
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();
+#pragma unroll
+          for (int x = 0; x < T::TM; x++)
+#pragma unroll
+            for (int y = 0; y < T::TN; y++) acc[x][y] = (double4_t){0.0, 0.0, 0.0, 0.0};
+          for (int jj = 0; jj < pieces; jj++) {  // in the order of the k ranges, whoever arrived last
+            const double *theirs = sk.ws + (long long)(u.slot0 + jj) * SLOT;
+#pragma unroll
+            for (int x = 0; x < T::TM; x++)
+#pragma unroll
+              for (int y = 0; y < T::TN; y++)
+#pragma unroll
+                for (int rg = 0; rg < 4; rg++) acc[x][y][rg] += theirs[((x * T::TN + y) * 4 + rg) * T::NT + threadIdx.x];
+          }
+        }
+        __syncthreads();  // s_old is rewritten at the next shared tile
+      }
+      if (stamp && threadIdx.x == 0 && r < 10) stamp[2 + 3 * r] = __builtin_amdgcn_s_memrealtime();
+      if (finish) T::epilogue(g, tm, tn, acc, lds);  // (uniform: the whole workgroup)
+      if (stamp && threadIdx.x == 0 && r < 10) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp[3 + 3 * r] = __builtin_amdgcn_s_memrealtime();
+      }
+      __syncthreads();
+    };
+    const SkUnit *tab = sk.table + (long long)blockIdx.x * sk.stride;
+    for (int r = 0; r < sk.stride; r++) {
+      const SkUnit u = tab[r];
+      if (u.tile < 0) break;
+      unit(u, r);
+    }
+    return;
+  }
   if (sk.frac) {
     const int U = sk.ntiles * nslab, per = sk.per;
     const int lo = min(U, v * per), hi = min(U, lo + per), t_first = lo / nslab;
@@ -906,6 +983,11 @@ static inline hipError_t gemm_set_attributes() {
   set((const void *)k_dgemm_tn<128, 128, true, 2, 4, 3>, gemm_lds_bytes(128, 128, 3));
   set((const void *)k_dgemm_tn_sk<true, 2, 4, 3>, gemm_sk_lds_bytes(3));
   return e;
+}
+// (HQPKKT_SK_TABLE=0: the cut form with equal shares, gemm_split_plan, for same-box comparisons)
+static inline bool gemm_sk_table_from_env() {
+  const char *r = getenv("HQPKKT_SK_TABLE");
+  return !r || atoi(r) != 0;
 }
 static inline int gemm_variant_from_env() {
   if (getenv("HQPKKT_NO_LDSDMA")) return GEMM_REG4;

@@ -84,6 +84,39 @@ struct StagedDev {
     tri_maps.push_back({T, b});
     return b->p;
   }
+  // work lists of the cut form of the large products (stg::gemm_split_table: unequal shares for the two workgroups of a
+  // CU), by (tiles, k-slabs); made at upload time for the shapes of the recursion - a shape without one (or
+  // HQPKKT_SK_TABLE=0) runs the equal-share plan
+  struct SkTab {
+    long long tiles, nslab, pieces;
+    int stride;
+    DBuf<stg::SkUnit> *units;
+  };
+  std::vector<SkTab> sk_tabs;
+  bool sk_tables_on = true;
+  const SkTab *sk_tab(long long tiles, long long nslab, bool create = false) {
+    if (!sk_tables_on || sk_grid <= 0) return nullptr;
+    for (auto &e : sk_tabs)
+      if (e.tiles == tiles && e.nslab == nslab) return e.units ? &e : nullptr;
+    if (!create) return nullptr;  // (no allocation inside a captured sequence)
+    stg::SplitTable t;
+    SkTab e{tiles, nslab, 0, 0, nullptr};
+    if (stg::gemm_split_table(tiles, nslab, sk_grid, t) && t.pieces * 128LL * 128 <= sk_ws_elems && tiles <= sk_tiles) {
+      DBuf<stg::SkUnit> *b = new (std::nothrow) DBuf<stg::SkUnit>;
+      if (b && !b->upload(t.units))
+        e.units = b, e.stride = t.stride, e.pieces = t.pieces;
+      else
+        delete b;
+    }
+    sk_tabs.push_back(e);
+    return e.units ? &sk_tabs.back() : nullptr;
+  }
+  // (the shape of a product as st_gemm launches it)
+  void sk_tab_prepare(int M, int N, int K, int lower) {
+    if (M <= 0 || N <= 0 || K <= 0 || sk_grid <= 0 || (lower && M < N)) return;
+    if (!stg::gemm_use_split(M, N, K, lower, sk_grid) || (!plan.sharded && stg::gemm_use_frac(M, N, K, lower, sk_grid))) return;
+    (void)sk_tab(stg::gemm_tiles(M, N, 128, lower), (K + stg::GEMM_BK - 1) / stg::GEMM_BK, true);
+  }
   size_t lds_small = 0, lds_small_big = 0, lds_init = 0, lds_x0 = 0;
   long long sk_ws_elems = 0, sk_cnt_elems = 0;
   void release() {
@@ -103,6 +136,9 @@ struct StagedDev {
     hblk_elems = 0, blocks_set.clear();
     for (auto &e : tri_maps) e.second->release(), delete e.second;
     tri_maps.clear();
+    for (auto &e : sk_tabs)
+      if (e.units) e.units->release(), delete e.units;
+    sk_tabs.clear();
     if (stream2) (void)hipStreamDestroy(stream2), stream2 = nullptr;
     if (ev_fork) (void)hipEventDestroy(ev_fork), ev_fork = nullptr;
     if (ev_join) (void)hipEventDestroy(ev_join), ev_join = nullptr;
@@ -162,7 +198,9 @@ int st_gemm(hqpkkt_t *h, stg::GemmArgs g, int cls = KC_ST_GEMM, bool allow_sk = 
     // (a few hundred tiles: the k-slabs of all tiles in one sequence, an equal share per workgroup - gemm_use_frac)
     stg::SplitPlan sk = frac ? stg::gemm_split_plan_frac(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid)
                              : stg::gemm_split_plan(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, d->sk_grid);
-    if (frac || stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
+    const StagedDev::SkTab *tab = frac ? nullptr : d->sk_tab(tiles, (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK, !h->capturing);
+    if (tab) sk.table = tab->units->p, sk.stride = tab->stride;
+    if (frac || tab || stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
       sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
       KLAUNCH(h, cls, stg::gemm_launch_split(d->gemm_variant, d->sk_grid, h->stream, g, sk));
       return 0;
@@ -649,6 +687,15 @@ static int staged_upload(hqpkkt_t *h) {
       const int T = (sz + 127) / 128;
       if (T >= 16) (void)d.tri_map(T, true);
     }
+  // work lists of the cut form of W = V+ F and G = F'W (staged_stage: the products over all columns, over the state
+  // columns alone when the control-sized chain runs beside them)
+  d.sk_tables_on = stg::gemm_sk_table_from_env();
+  if (!P.sharded)
+    for (int k = 0; k < P.K; k++) {
+      const int np = P.nk[k + 1], nn = P.nk[k], nz = nn + P.mk[k];
+      d.sk_tab_prepare(np, nz, np, 0), d.sk_tab_prepare(np, nn, np, 0);
+      d.sk_tab_prepare(nz, nz, np, 1), d.sk_tab_prepare(nn, nn, np, 1);
+    }
   d.lds_small = 0, d.lds_small_big = 0;
   for (int k = 0; k < P.K; k++) {
     if (P.big[k])
@@ -775,7 +822,9 @@ static int st_gemm_tiles(hqpkkt_t *h, stg::GemmArgs g, int ntiles, int cls) {
   const long long nslab = (g.K + stg::GEMM_BK - 1) / stg::GEMM_BK;
   if (d->sk_grid > 0 && ntiles % d->sk_grid != 0 && ntiles < 16LL * d->sk_grid && nslab >= 32 && ntiles <= d->sk_tiles) {
     stg::SplitPlan sk = stg::gemm_split_plan(ntiles, nslab, d->sk_grid);
-    if (stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
+    const StagedDev::SkTab *tab = d->sk_tab(ntiles, nslab, !h->capturing);
+    if (tab) sk.table = tab->units->p, sk.stride = tab->stride;
+    if (tab || stg::gemm_split_plan_pieces(sk) * 128LL * 128 <= d->sk_ws_elems) {
       sk.ws = d->sk_ws.p, sk.cnt = d->sk_cnt.p;
       KLAUNCH(h, cls, stg::gemm_launch_split(variant, d->sk_grid, h->stream, g, sk));
       return 0;

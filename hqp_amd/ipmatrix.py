@@ -424,6 +424,20 @@ def bench_dgemm(M, N, K, lower=False, mirror=False, reps=5, device=0):
     return ms.value, flops / (ms.value * 1e-3) / 1e12, err.value
 
 
+def sk_table(tiles, nslab, grid=512):
+    """The work lists of the cut form of the fp64 product (host only): (units[grid, stride, 6], pieces, whole_a, whole_b),
+    a unit = (tile or -1, first k-slab, one past the last, first parking slot of the tile, pieces of the tile, piece)."""
+    import numpy as np
+    pieces, wa, wb = C.c_longlong(), C.c_int(), C.c_int()
+    stride = _lib.lib().hqpkkt_debug_sk_table(tiles, nslab, grid, None, 0, C.byref(pieces), C.byref(wa), C.byref(wb))
+    if stride <= 0:
+        return None
+    u = np.zeros((grid, stride, 6), dtype=np.int32)
+    got = _lib.lib().hqpkkt_debug_sk_table(tiles, nslab, grid, u.ctypes.data_as(C.POINTER(C.c_int)), u.size, C.byref(pieces), C.byref(wa), C.byref(wb))
+    assert got == stride
+    return u, pieces.value, wa.value, wb.value
+
+
 def selftest_mfma(device=0):
     err = C.c_double()
     _check(_lib.lib().hqpkkt_selftest_mfma(device, C.byref(err)), "selftest_mfma")

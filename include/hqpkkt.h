@@ -348,6 +348,14 @@ int hqpkkt_debug_stage_ranks(hqpkkt_t *h, int *out, int cap);
  * over 4096 sampled entries. */
 int hqpkkt_debug_dgemm(int device, int M, int N, int K, int lower, int mirror, int reps, double *ms, double *max_err);
 
+/* Test hook, host only (no device needed): the work list of the cut form of that product (k_dgemm_tn_sk) for `tiles`
+ * tiles of `nslab` k-slabs on `grid` workgroups - unequal shares for the two workgroups of a CU, sk_table.hpp.
+ * units (or NULL): six ints per unit, (b * stride + i) * 6 for unit i of workgroup b: tile (-1: end of the list),
+ * first and one-past-last k-slab, first parking slot of the tile, pieces of the tile, number of this piece.
+ * Returns the stride (units per workgroup incl. the end mark), or 0 (no table for these sizes; cap_ints too small).
+ * *pieces: parking slots; *whole_a / *whole_b: whole tiles per workgroup of the first / second half of the launch. */
+int hqpkkt_debug_sk_table(long long tiles, int nslab, int grid, int *units, long long cap_ints, long long *pieces, int *whole_a, int *whole_b);
+
 /* Per-kernel-class device timing for bench.py's roofline line: with on != 0
  * every kernel launch is bracketed by HIP events on the handle's stream and the
  * elapsed times are summed per class (hqpkkt_profile_class_name(c), c = 0..) at
