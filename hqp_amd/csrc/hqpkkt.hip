@@ -243,10 +243,11 @@ struct hqpkkt {
   struct GraphSlot {
     hipGraph_t g = nullptr;
     hipGraphExec_t ge = nullptr;
+    unsigned n_posts = 0;  // posted read-backs inside (k_post_words counts on the device; the host counts along at every replay)
     void drop() {
       if (ge) (void)hipGraphExecDestroy(ge);
       if (g) (void)hipGraphDestroy(g);
-      ge = nullptr, g = nullptr;
+      ge = nullptr, g = nullptr, n_posts = 0;
     }
   } gfactor[2], gstep[2][3];  // [phase], [caller's / refinement's vectors][phase]
   // The device-resident interior-point loops hand over the same device vectors in every iteration: their sequences are
@@ -256,6 +257,9 @@ struct hqpkkt {
     GraphSlot g;
   };
   std::vector<DirectGraph> gdirect_step, gdirect_factor;
+  // ... and whole SEGMENTS of an iteration of the device-resident loops - everything between two read-backs: the
+  // factorisation, a solve, its residual and the posting kernel - as one graph (ip_segment)
+  std::vector<DirectGraph> gdirect_seg;
   GraphSlot &direct_slot(std::vector<DirectGraph> &cache, const void *const (&key)[10]) {
     for (auto &d : cache)
       if (std::memcmp(d.key, key, sizeof(key)) == 0) return d.g;
@@ -268,6 +272,8 @@ struct hqpkkt {
     return cache.back().g;
   }
   bool use_graphs = true, capturing = false;
+  unsigned cap_posts = 0;  // posted read-backs of the capture in progress
+  DBuf<unsigned> post_seq_dev;  // the sequence number of the posted read-backs, counted by k_post_words
   // inside hqpkkt_mehrotra: factor() returns without waiting for its status (read with the
   // residual of the solve that follows), solve() leaves its result in the stream
   bool lazy = false, factor_unchecked = false;
@@ -279,7 +285,7 @@ struct hqpkkt {
   // hqpkkt_franke: the first residual of a solve is not waited for - it comes back with the scalars of the iteration
   // (one read-back per iteration); residual_pending: such a residual is in the stream, collect_residual() reads it
   bool defer_residual = false, residual_pending = false;
-  int res_slot = 0, res_read = 122;  // which of the two residual words the next residual kernel uses / the last one used
+  int res_read = 122;  // the word of the flags buffer the residual kernels leave their maximum in (cleared by k_post_words)
   bool no_polled = false;      // a polled launch gave up once: per-level launches for the rest of the handle's life (poll_fallback)
   bool soft_singular = false;  // the factorisation perturbed an exactly zero pivot (counters[3])
   bool soft_tiny = false;      // ... or met a pivot below 1e-13 max|K| on a multiplier-type row (counters[4])
@@ -305,7 +311,8 @@ struct hqpkkt {
       for (auto &g : gs) g.drop();
     for (auto &d : gdirect_step) d.g.drop();
     for (auto &d : gdirect_factor) d.g.drop();
-    gdirect_step.clear(), gdirect_factor.clear();
+    for (auto &d : gdirect_seg) d.g.drop();
+    gdirect_step.clear(), gdirect_factor.clear(), gdirect_seg.clear();
   }
 
   DevTree tree() const {
@@ -326,7 +333,7 @@ struct hqpkkt {
     for (auto b : db) b->release();
     if (!keep_ip) ipv.release();
     terms.release(), esign.release(), bits.p = nullptr;
-    if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr, hpin_dev = nullptr;
+    if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr, hpin_dev = nullptr, post_seq_dev.release(), post_seq = 0;
     if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
     // (keep_ip = the re-analysis inside hqpkkt_solve, switch_to_policy0: the pattern and with it the sizes of the
     // pinned value staging stay, and a host may hold the pointers of hqpkkt_values_staging)
@@ -414,6 +421,9 @@ static int alloc_hpin(hqpkkt_t *h) {
   std::memset(h->hpin, 0, sizeof(double) * HPIN_DOUBLES);
   HIPCHK(hipHostGetDevicePointer((void **)&h->hpin_dev, h->hpin, 0));
   h->post_seq = 0;
+  int e = h->post_seq_dev.alloc(1);
+  if (e) return e;
+  HIPCHK(hipMemset(h->post_seq_dev.p, 0, sizeof(unsigned)));
   return 0;
 }
 static int upload(hqpkkt_t *h) {
@@ -504,7 +514,7 @@ static int upload(hqpkkt_t *h) {
     return e;
   h->bits.p = (unsigned long long *)(h->flags.p + 120);
   HIPCHK(hipMemset(h->flags.p, 0, sizeof(int) * 128));
-  h->res_slot = 0, h->res_read = 122;
+  h->res_read = 122;
   if ((e = alloc_hpin(h))) return e;
   if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr;
   h->hstage_in = h->hstage_out = 0;
@@ -1002,21 +1012,23 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
 // eager launches while per-kernel profiling is on
 template <class F>
 static int graphed(hqpkkt_t *h, hqpkkt::GraphSlot &slot, F body) {
-  if (!h->use_graphs || h->prof.on) return body();
+  if (!h->use_graphs || h->prof.on || h->capturing) return body();  // (capturing: a sequence inside a segment's capture)
   if (!slot.ge) {
     HIPCHK(hipStreamBeginCapture(h->stream, hipStreamCaptureModeThreadLocal));
-    h->capturing = true;
+    h->capturing = true, h->cap_posts = 0;
     int e = body();
     h->capturing = false;
     hipGraph_t g = nullptr;
     hipError_t ce = hipStreamEndCapture(h->stream, &g);
     if (e) {
       if (g) (void)hipGraphDestroy(g);
+      h->post_seq -= h->cap_posts;  // (nothing was posted)
       return e;
     }
     if (ce != hipSuccess || !g) {  // capture not possible: run eagerly from now on
       h->use_graphs = false;
       (void)hipGetLastError();
+      h->post_seq -= h->cap_posts;
       return body();
     }
     slot.g = g;
@@ -1024,9 +1036,12 @@ static int graphed(hqpkkt_t *h, hqpkkt::GraphSlot &slot, F body) {
       slot.drop();
       h->use_graphs = false;
       (void)hipGetLastError();
+      h->post_seq -= h->cap_posts;
       return body();
     }
-  }
+    slot.n_posts = h->cap_posts;  // (the host has counted them during the capture)
+  } else
+    h->post_seq += slot.n_posts;
   HIPCHK(hipGraphLaunch(slot.ge, h->stream));
   return 0;
 }
@@ -1112,9 +1127,10 @@ static int do_step(hqpkkt_t *h, const Vecs &v, int which) {
 // that a solve that needs no refinement round is over with this one round trip
 // ---- read-backs through mapped host memory (hqpkkt::hpin_dev)
 // the status words (and, with `out`, n_out <= 40 of the IP loop's scalars) as they stand at this point of the stream
-static int post_words(hqpkkt_t *h, const double *out, int n_out) {
+static int post_words(hqpkkt_t *h, const double *out, int n_out, bool residual = false) {
   h->post_seq++;
-  k_post_words<<<1, 64, 0, h->stream>>>(h->flags.p, out, n_out, h->hpin_dev, h->post_seq);
+  if (h->capturing) h->cap_posts++;
+  k_post_words<<<1, 64, 0, h->stream>>>(h->flags.p, out, n_out, h->hpin_dev, h->post_seq_dev.p, residual ? 1 : 0);
   return 0;
 }
 // waits until the last posted words have arrived (every earlier post of the stream has then arrived as well)
@@ -1147,11 +1163,10 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
   hipStream_t s = h->stream;
   const int n = an.n, me = an.me, m = an.m;
   double *o1 = h->vres.p, *o2 = o1 + n, *o3 = o2 + me, *o4 = o3 + m;
-  // the maximum is accumulated in one of two words (ints 122-123 / 118-119 of the flags buffer) in turn; a residual
-  // kernel zeroes the word of the next one.  (Both are zero after a factorisation: it clears the flags buffer.)
-  unsigned long long *const rb_now = h->bits.p + (h->res_slot ? -1 : 1), *const rb_next = h->bits.p + (h->res_slot ? 1 : -1);
-  h->res_read = h->res_slot ? 118 : 122;
-  h->res_slot ^= 1;
+  // the maximum is accumulated in the ints 122-123 of the flags buffer; the posting kernel behind every residual kernel
+  // clears it (and a factorisation clears the whole buffer).  (rb_next: the word the kernel zeroes for its successor - a
+  // spare one since the posting kernel does that.)
+  unsigned long long *const rb_now = h->bits.p + 1, *const rb_next = h->bits.p - 1;
   const double *x1 = nullptr, *x2 = nullptr;  // STAGED, dense dynamics: their share of A dx and A'dy
   int ndyn = 0;
   if (h->opts.mode == HQPKKT_MODE_STAGED) {
@@ -1172,7 +1187,7 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
   }
   // one read-back: the residual maximum and the status of the factorisation this solve belongs to
   int ep;
-  if ((ep = post_words(h, nullptr, 0))) return ep;
+  if ((ep = post_words(h, nullptr, 0, true))) return ep;
   if (h->defer_residual && !out) {  // the caller queues more work and waits once (collect_residual)
     h->residual_pending = true;
     *res = 0.0;
@@ -1599,9 +1614,12 @@ static int factor_once(hqpkkt_t *h, const double *z, const double *w) {
   else if ((e = stage_in(h, z, w, nullptr, nullptr, nullptr, nullptr, v)))
     return e;
   h->factored = false;
-  HIPCHK(hipEventRecord(h->ev0, h->stream));
+  // (inside the device-resident loops - lazy - nobody reads these times, and an event record between two graph launches
+  // is a packet the queue stops at: 22 us between the factorisation and the first solve of an iteration with three of
+  // them, profiles/r06_ip_did_timeline.txt)
+  if (!h->lazy) HIPCHK(hipEventRecord(h->ev0, h->stream));
   if ((e = do_factor(h, v))) return e;
-  if (h->use_graphs && !h->prof.on) {  // phases are not timed separately inside a graph replay
+  if (h->use_graphs && !h->prof.on && !h->lazy) {  // phases are not timed separately inside a graph replay
     HIPCHK(hipEventRecord(h->ev1, h->stream));
     HIPCHK(hipEventRecord(h->evs1, h->stream));
   }
@@ -1723,7 +1741,7 @@ static int solve_once(hqpkkt_t *h, const double *z, const double *w, const doubl
   Vecs v{};
   int e = solve_vecs(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, v);
   if (e) return e;
-  HIPCHK(hipEventRecord(h->ev0, s));
+  if (!h->lazy) HIPCHK(hipEventRecord(h->ev0, s));
   if ((e = do_step(h, v, 0))) return e;
   double res = 0.0;
   const OutPtrs outp{dx, dy, dz, dw};
@@ -1791,7 +1809,7 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
     if ((e = switch_to_policy0(h)) || (e = hqpkkt_factor(h, z, w))) return e;
     return hqpkkt_solve(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res_out);
   }
-  HIPCHK(hipEventRecord(h->ev1, s));
+  if (!h->lazy) HIPCHK(hipEventRecord(h->ev1, s));
   if (h->lazy) {
     if (v.dx != dx && (e = stage_out(h, v, dx, dy, dz, dw))) return e;
   } else {
@@ -2013,8 +2031,51 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       if (C.hout[32 + IPS_NEED2] != 0.0) return second_corrector(mu_pending);
       return 0;
     };
+    // The iteration's launches between two read-backs as ONE captured graph each (small QPs on the tree engine: an
+    // iteration of the double-integrator QP is 27 launches and 0.3 ms, and every boundary between a graph and the next
+    // launch costs the queue 5 - 20 us, profiles/r06_ip_did_timeline.txt):
+    //   A: factorisation + predictor solve + its residual + the posting kernel
+    //   B: predictor statistics + corrector solve + residual + post
+    //   C: the step + the next iterate's right-hand sides and reductions + post
+    // Whatever the read-back then asks for - refinement rounds, the second corrector - runs as before, launch by launch.
+    const bool seg_ok = ip_small && h->use_graphs && !h->prof.on && h->opts.mode != HQPKKT_MODE_STAGED && h->an.shard_count <= 1 &&
+                        !getenv("HQPKKT_NO_IP_SEGMENTS");
+    auto seg_slot = [&](int tag) -> hqpkkt::GraphSlot & {
+      unsigned long long gf;
+      std::memcpy(&gf, &o.gammaf, sizeof(gf));
+      const void *key[10] = {(const void *)(intptr_t)tag, (const void *)(uintptr_t)gf, C.x, C.z, C.r1, C.dx, C.dxa, C.out, nullptr, nullptr};
+      return h->direct_slot(h->gdirect_seg, key);
+    };
+    // a solve whose first residual is in the stream (run_residual with defer_residual): wait, read, and finish it as
+    // hqpkkt_solve does (refinement, the checks behind a perturbed pivot)
+    auto finish_solve = [&](double *ox, double *oy, double *oz, double *ow) -> int {
+      int e2 = post_wait(h);
+      if (e2) return e2;
+      if ((e2 = collect_residual(h, &resid))) return e2;
+      Vecs v{};
+      if ((e2 = solve_vecs(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, ox, oy, oz, ow, v))) return e2;
+      return solve_tail(h, v, C.z, C.w, C.r1, C.r2, C.r3, C.r4, ox, oy, oz, ow, resid, &resid);
+    };
+    auto enqueue_head = [&]() -> int {
+      if (h->short_rows)
+        k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                              h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
+                                              C.part, dx1, dx2, dndyn);
+      else
+        k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
+                                               h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
+                                               C.part, dx1, dx2, dndyn);
+      if (m == 0) return 0;
+      // the reductions of this iterate and what the step before left behind, one round trip
+      const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
+      IpOps o2;
+      for (int k = 0; k < IP_SLOTS; k++) o2.op[k] = ops2[k];
+      k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
+      return post_words(h, C.out, 40);  // (C.hout = hpin + 64: where the posting kernel puts them)
+    };
+    bool head_in_stream = false;  // segment C of the iteration before has queued this iterate's head already
     for (;;) {  // hot first (if asked for and possible), cold after a failed hot start
-    iter = 0, result = 2, stepped = false, pending = false, sing_hot = false;
+    iter = 0, result = 2, stepped = false, pending = false, sing_hot = false, head_in_stream = false;
     std::fill(phimin.begin(), phimin.end(), 0.0);
     res->alpha = 1.0;
     if (hot) {
@@ -2077,15 +2138,10 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       bool redo = false;  // the second corrector replaced the step: same step() call, new right-hand sides
       do {
       // ---- one step (hqp/Hqp_IpsMehrotra.C:355-693)
-      if ((e = dyn_products())) return e;
-      if (h->short_rows)
-        k_ip_rhs<4><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                              h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
-                                              C.part, dx1, dx2, dndyn);
-      else
-        k_ip_rhs<16><<<IP_BLOCKS, 256, 0, s>>>(n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(),
-                                               h->vals.p, C.c, C.b, C.d, C.x, C.y, C.z, C.w, C.r1, C.r2, C.r3, C.r4,
-                                               C.part, dx1, dx2, dndyn);
+      if (!head_in_stream) {
+        if ((e = dyn_products()) || (e = enqueue_head())) return e;
+      }
+      head_in_stream = false;
       if (m == 0) {  // equality-constrained QP: one Newton step (:364-413)
         if ((e = factor()) || (e = solve(C.dx, C.dy, C.dz, C.dw))) {
           if (e == HQPKKT_E_SING) return finish(4);
@@ -2095,13 +2151,7 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         iter++;
         return finish(0);
       }
-      {  // the reductions of this iterate and what the step before left behind, one round trip
-        const int ops2[IP_SLOTS] = {IP_SUM, IP_SUM, IP_SUM, IP_MAX, IP_MIN, IP_MIN, IP_SUM, IP_SUM};
-        IpOps o2;
-        for (int k = 0; k < IP_SLOTS; k++) o2.op[k] = ops2[k];
-        k_ip_final<<<1, 256, 0, s>>>(C.part, o2, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-        if ((e = post_words(h, C.out, 40)) || (e = post_wait(h))) return e;  // (C.hout = hpin + 64: where the posting kernel puts them)
-      }
+      if ((e = post_wait(h))) return e;
       if (pending) {
         pending = false;
         res->alpha = C.hout[32 + IPS_ALPHA];
@@ -2158,7 +2208,21 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       }
       if (norm_r > o.eps * norm_data && norm_r / mu >= 1.0e8 * norm_r0 / mu0) result = 3;  // :520-524 (no return)
       // factorise; predictor (affine) step
-      if ((e = factor()) || (e = solve(C.dxa, C.dya, C.dza, C.dwa))) {
+      if (seg_ok) {
+        h->defer_residual = true;
+        e = graphed(h, seg_slot(1), [&]() {
+          const int e2 = hqpkkt_factor(h, C.z, C.w);
+          return e2 ? e2 : hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dxa, C.dya, C.dza, C.dwa, &resid);
+        });
+        h->defer_residual = false;
+        n_factor++, n_solve++;
+        if (!e) {
+          h->factor_unchecked = true, h->factored = true, h->residual_pending = true;  // (what the two calls leave, replayed or not)
+          e = finish_solve(C.dxa, C.dya, C.dza, C.dwa);
+        }
+      } else if (!(e = factor()))
+        e = solve(C.dxa, C.dya, C.dza, C.dwa);
+      if (e) {
         if (e == HQPKKT_E_SING && hot) {  // a hot start that ends degenerate is thrown away (:723-727)
           sing_hot = true;
           break;
@@ -2170,8 +2234,21 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       // :583-590; the safe value when the predictor step is short and the reference skips the
       // first corrector, :612-616), the corrector's blocking components, the damped step length
       // (:629-672) are computed by thread 0 of the reduction kernels and consumed through device pointers.
+      if (seg_ok) {
+        h->defer_residual = true;
+        e = graphed(h, seg_slot(2), [&]() {
+          k_ip_pred_small<<<1, 1024, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.out + 2, gamma, S, C.r4);
+          return hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
+        });
+        h->defer_residual = false;
+        n_solve++;
+        if (!e) {
+          h->residual_pending = true;
+          e = finish_solve(C.dx, C.dy, C.dz, C.dw);
+        }
+      } else {
       if (ip_small) {  // one workgroup: the three launches below, same arithmetic (ipdriver.hip.h)
-        k_ip_pred_small<<<1, 1024, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, mu, gamma, S, C.r4);
+        k_ip_pred_small<<<1, 1024, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.out + 2, gamma, S, C.r4);
       } else {
       k_ip_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, C.part);
       {
@@ -2182,7 +2259,9 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
       }
       k_ip_corr_rhs<<<nblk(m), 256, 0, s>>>(m, C.z, C.w, C.dza, C.dwa, 0.0, S + IPS_SMM, C.r4);
       }
-      if ((e = solve(C.dx, C.dy, C.dz, C.dw))) {
+      e = solve(C.dx, C.dy, C.dz, C.dw);
+      }
+      if (e) {
         if (e == HQPKKT_E_SING && hot) {
           sing_hot = true;
           break;
@@ -2190,7 +2269,14 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
         if (e == HQPKKT_E_SING) return finish(4);
         return e;
       }
-      if (ip_small) {  // one workgroup: the five launches below, same arithmetic
+      if (seg_ok) {  // the step and the head of the next pass through this loop
+        if ((e = graphed(h, seg_slot(3), [&]() {
+               k_ip_step_small<<<1, 1024, 0, s>>>(n, me, m, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, Bk, gamma, o.gammaf, S);
+               return enqueue_head();
+             })))
+          return e;
+        head_in_stream = true;
+      } else if (ip_small) {  // one workgroup: the five launches below, same arithmetic
         k_ip_step_small<<<1, 1024, 0, s>>>(n, me, m, C.x, C.y, C.z, C.w, C.dx, C.dy, C.dz, C.dw, Bk, gamma, o.gammaf, S);
       } else {
       k_ip_minratio_part<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
@@ -2537,7 +2623,7 @@ int hqpkkt_get_perm(const hqpkkt_t *h, int *perm) {
 int hqpkkt_set_tol(hqpkkt_t *h, double tol) {
   if (!h) return HQPKKT_E_NULL;
   if (!(tol > 0.0 && tol <= 1.0)) return HQPKKT_E_RANGE;
-  if (tol != h->opts.tol) h->gfactor[0].drop(), h->gfactor[1].drop();  // alpha is baked into the captured launches
+  if (tol != h->opts.tol) h->drop_graphs();  // alpha is baked into the captured launches
   h->opts.tol = tol;
   return 0;
 }

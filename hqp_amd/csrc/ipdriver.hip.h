@@ -373,9 +373,14 @@ __device__ __forceinline__ double ip_small_minmax(double v, bool is_max, double 
   }
 __global__ void __launch_bounds__(1024)
 k_ip_pred_small(int m, const double *__restrict__ z, const double *__restrict__ w, const double *__restrict__ dza,
-                const double *__restrict__ dwa, double mu, double gamma, double *__restrict__ S, double *__restrict__ r4) {
+                const double *__restrict__ dwa, const double *__restrict__ gap_sum, double gamma, double *__restrict__ S,
+                double *__restrict__ r4) {
   __shared__ double red16[16];
   __shared__ double bc[2];
+  // mu = z'w / m of this iterate, from the sum the iteration's first reduction has left on the device (the same
+  // division the host makes with the word it read back: the kernel takes no value of the host, so that it can be
+  // replayed inside a captured graph)
+  const double mu = *gap_sum / m;
   IP_SMALL_LOAD(z, w, dza, dwa, zz, ww, dzz, dww)
   // k_ip_ratio + k_ip_final + ip_sigma
   double a = 1e300, t = 0.0;

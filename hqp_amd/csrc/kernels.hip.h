@@ -1396,6 +1396,26 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
             }
         }
       }
+      if constexpr (FRONT) {
+        // the border rows take part in the step like the pivot rows below k (their columns in s21 stay in the order of
+        // the front: column lp[j] is the j-th pivot's), and the update block with them: when the last pivot is done it
+        // is complete and goes to the parent before anything else (M, L21, the stores) is computed
+        if (b > 0) {
+          const int pk = lp[k], rc = min(r16, b - 1);
+          const bool ron = r16 < b;
+          const double lr = s21[rc + ldb * pk] * di;
+          for (int jb = k + 1; jb < p; jb += 4) {
+            const int j = min(jb + cq, p - 1), pj = lp[j];
+            const double akj = a[j + k * ldp], sv = s21[rc + ldb * pj];
+            if (ron && jb + cq < p) s21[r16 + ldb * pj] = fma(-lr, akj, sv);
+          }
+          for (int cb = 0; cb < b; cb += 4) {
+            const int c = min(cb + cq, b - 1);
+            const double cc = s21[c + ldb * pk], uv = ub[rc + ldb * c];
+            if (ron && cb + cq < b && r16 >= cb + cq) ub[r16 + ldb * c] = fma(-lr, cc, uv);
+          }
+        }
+      }
       k += 1;
     } else {
       double d11 = rdlane(ck, k), d21 = rdlane(ck, k + 1), d22 = a[k + 1 + (k + 1) * ldp];
@@ -1436,11 +1456,44 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
             }
         }
       }
+      if constexpr (FRONT) {
+        if (b > 0) {
+          const int pk0 = lp[k], pk1 = lp[k + 1], rc = min(r16, b - 1);
+          const bool ron = r16 < b;
+          const double c1 = s21[rc + ldb * pk0], c2 = s21[rc + ldb * pk1];
+          const double l1 = c1 * i11 + c2 * i21, l2 = c1 * i21 + c2 * i22;
+          for (int jb = k + 2; jb < p; jb += 4) {
+            const int j = min(jb + cq, p - 1), pj = lp[j];
+            const double ak0 = a[j + k * ldp], ak1 = a[j + (k + 1) * ldp], sv = s21[rc + ldb * pj];
+            if (ron && jb + cq < p) s21[r16 + ldb * pj] = fma(-l2, ak1, fma(-l1, ak0, sv));
+          }
+          for (int cb = 0; cb < b; cb += 4) {
+            const int c = min(cb + cq, b - 1);
+            const double cc0 = s21[c + ldb * pk0], cc1 = s21[c + ldb * pk1], uv = ub[rc + ldb * c];
+            if (ron && cb + cq < b && r16 >= cb + cq) ub[r16 + ldb * c] = fma(-l2, cc1, fma(-l1, cc0, uv));
+          }
+        }
+      }
       k += 2;
     }
     __syncthreads();
   }
   FSTAMP(3);
+  if constexpr (FRONT) {
+    if (b > 0) {  // the update block is complete: to the parent (its lower triangle, column by column)
+      double *U = upd + T.upd_off[node];
+      for (int cb = 0; cb < b; cb += 4) {
+        const int c2 = cb + cq;
+        if (r16 < b && c2 < b && r16 >= c2) {
+          const double acc = ub[r16 + ldb * c2];
+          if constexpr (TREE)
+            xw_post(U + (long long)c2 * b + r16, acc);
+          else
+            U[(long long)c2 * b + r16] = acc;
+        }
+      }
+    }
+  }
   if (lane == 0) {
     if (n2x2) atomicAdd(&counters[0], n2x2);
     if (npert) atomicAdd(&counters[1], npert);
@@ -1575,39 +1628,20 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
     if (b > 0) {
       const bool ron = r16 < b;
       const int rc = min(r16, b - 1);
-      {  // columns of the border rows in pivot order
+      {  // X = A21 P' M' is what the elimination has left in the border rows' columns (unscaled): into pivot order
         double t[FS_MAXP / 4];
 #pragma unroll
         for (int u = 0; u < FS_MAXP / 4; u++)
           if (4 * u < p) t[u] = s21[rc + ldb * lp[min(4 * u + cq, p - 1)]];
-        __syncthreads();
 #pragma unroll
         for (int u = 0; u < FS_MAXP / 4; u++)
           if (4 * u < p) {
-            if (ron && 4 * u + cq < p) s21[r16 + ldb * (4 * u + cq)] = t[u];
+            if (ron && 4 * u + cq < p) xs[r16 + ldb * (4 * u + cq)] = t[u];
           }
         __syncthreads();
       }
-      // x(r,c) = sum_{t <= c} s(r, t) M(c,t)
-      for (int u = 0; 4 * u < p; u++) {
-        const int c2 = 4 * u + cq, cc2 = min(c2, p - 1);
-        double acc = 0.0;
-        for (int tb = 0; tb <= 4 * u + 3 && tb < p; tb += 4) {
-          double sq[4], mq[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int t = min(tb + q, p - 1);
-            sq[q] = s21[rc + ldb * t], mq[q] = a[cc2 + t * ldp];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            if (tb + q <= c2 && tb + q < p) acc = fma(sq[q], mq[q], acc);
-        }
-        if (ron && c2 < p) xs[r16 + ldb * c2] = acc;
-      }
-      __syncthreads();
       FSTAMP(7);
-      // L21 = X D^-1 (over s21), both to memory
+      // L21 = X D^-1, both to memory
       double *X = xar + T.x_off[node];
       {
         double lv[FS_MAXP / 4], xv[FS_MAXP / 4];
@@ -1627,33 +1661,11 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
             if (ron && c2 < p) {
               X[(long long)c2 * b + r16] = xv[u];
               P[(long long)c2 * F + p + r16] = lv[u];
-              s21[r16 + ldb * c2] = lv[u];
             }
           }
       }
       __syncthreads();
       FSTAMP(8);
-      double *U = upd + T.upd_off[node];
-      for (int u = 0; 4 * u < b; u++) {
-        const int c2 = 4 * u + cq, cc2 = min(c2, b - 1);
-        double acc = ub[rc + ldb * cc2];
-        for (int tb = 0; tb < p; tb += 4) {
-          double lq[4], xq[4];
-#pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const int t = min(tb + q, p - 1);
-            lq[q] = s21[rc + ldb * t], xq[q] = xs[cc2 + ldb * t];
-          }
-#pragma unroll
-          for (int q = 0; q < 4; q++)
-            if (tb + q < p) acc = fma(-lq[q], xq[q], acc);
-        }
-        if constexpr (TREE) {
-          if (ron && c2 < b && r16 >= c2) xw_post(U + (long long)c2 * b + r16, acc);
-        } else {
-          if (ron && c2 < b && r16 >= c2) U[(long long)c2 * b + r16] = acc;
-        }
-      }
     }
   }
   FSTAMP(9);
@@ -2850,18 +2862,29 @@ __global__ void __launch_bounds__(256) k_clear(double *__restrict__ p, long long
 // Read-back through mapped, coherent host memory (hqpkkt::hpin_dev): ONE wavefront stores the 128 status words of
 // `flags` (as 64 eight-byte words) and, with `out`, n_out <= 64 doubles behind double 64, then - behind a system-scope
 // fence - the sequence number the host spins on.  (One wavefront: its stores are ordered by its own fence.)
+// The number is counted on the device (*dev_seq: this launch is the only writer, launches of a stream follow each
+// other), so that a launch replayed inside a captured graph posts the next number like any other; the host counts its
+// posts along.  residual != 0 (the post behind a residual kernel): the residual maximum (word 61 of `flags`, k_residual)
+// goes along and is cleared once it is on its way - the next residual kernel starts from zero whatever ran in between;
+// any other post leaves the host's copy of that word as the last such post has written it.
 #define HPIN_DOUBLES 256
 #define HPIN_SEQ 200  // the double of hpin whose first four bytes hold the sequence number
-__global__ void __launch_bounds__(64) k_post_words(const int *__restrict__ flags, const double *__restrict__ out, int n_out,
-                                                   double *__restrict__ host, unsigned seq) {
+__global__ void __launch_bounds__(64) k_post_words(int *__restrict__ flags, const double *__restrict__ out, int n_out,
+                                                   double *__restrict__ host, unsigned *__restrict__ dev_seq, int residual) {
   const int lane = threadIdx.x;
   const unsigned long long w = ((const unsigned long long *)flags)[lane];
-  __hip_atomic_store((unsigned long long *)host + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  const bool rword = lane == 59 || lane == 61;
+  if (!rword || residual) __hip_atomic_store((unsigned long long *)host + lane, w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (rword && residual) ((unsigned long long *)flags)[lane] = 0ULL;
   if (out && lane < n_out)
     __hip_atomic_store((unsigned long long *)host + 64 + lane, (unsigned long long)__double_as_longlong(out[lane]), __ATOMIC_RELAXED,
                        __HIP_MEMORY_SCOPE_SYSTEM);
   __threadfence_system();
-  if (lane == 0) __hip_atomic_store((unsigned *)(host + HPIN_SEQ), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (lane == 0) {
+    const unsigned seq = *dev_seq + 1u;
+    *dev_seq = seq;
+    __hip_atomic_store((unsigned *)(host + HPIN_SEQ), seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 
 // sharded mode: clear the (offset, length) ranges of an arena this rank writes
