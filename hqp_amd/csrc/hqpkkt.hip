@@ -2487,7 +2487,13 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       } else
         mu = gap * gap;  // quadratic convergence
       if (m == 0) mu = 0.0;
-      k_fr_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, zeta, mu, a1, a2, a3, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
+      h->hpin[HPIN_ZM] = zeta, h->hpin[HPIN_ZM + 1] = mu;
+      std::atomic_thread_fence(std::memory_order_release);
+      // The whole step - right-hand sides, factorisation, solve, its residual, the step length, the update, the new gap,
+      // both posts - as ONE captured graph (the launches take nothing from the host that changes from step to step)
+      const bool seg_ok = h->use_graphs && !h->prof.on && h->opts.mode != HQPKKT_MODE_STAGED && h->an.shard_count <= 1 &&
+                          !getenv("HQPKKT_NO_IP_SEGMENTS") && !getenv("HQPKKT_FRANKE_TWO_READS");
+      if (!seg_ok) k_fr_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, h->hpin_dev + HPIN_ZM, a1, a2, a3, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
       double resid = 0.0;
       n_factor++, n_solve++;
       // The step length below compares dw = C dx - r3 with w, whose active components are of the
@@ -2501,7 +2507,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
       // a perturbed pivot to judge, an error), the iterate of before the step is put back, the solve is finished as
       // hqpkkt_solve would have, and the step is taken again.
       double *const Sfr = C.out + 32;
-      auto take_step = [&]() -> int {
+      auto take_step_enqueue = [&]() -> int {
         if (m > 0) {
           k_fr_ratio<<<IP_BLOCKS, 256, 0, s>>>(m, C.z, C.w, C.dz, C.dw, C.part);
           IpOps orat;
@@ -2515,18 +2521,45 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
         for (int k = 0; k < IP_SLOTS; k++) ou.op[k] = IP_SUM;
         ou.op[1] = IP_MAX;
         k_ip_final<<<1, 256, 0, s>>>(C.part, ou, C.out, IpEpi{0, 0, 0.0, 0.0, 0.0, nullptr, nullptr});
-        int ep = post_words(h, C.out, 40);  // (with the status words the solve's residual kernel has left: collect_residual)
+        return post_words(h, C.out, 40);  // (the residual of the solve has gone to the host with the post behind its kernel)
+      };
+      auto take_step = [&]() -> int {
+        const int ep = take_step_enqueue();
         return ep ? ep : post_wait(h);
       };
       const double target = h->refine_target > 0.0 ? std::fmin(h->opts.eps, h->refine_target) : h->opts.eps;  // (as solve_tail)
-      h->defer_residual = !getenv("HQPKKT_FRANKE_TWO_READS");
-      e = hqpkkt_factor(h, C.z, C.w);
-      if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
-      h->defer_residual = false;
+      const CopyList Lkeep{{C.x, C.y, C.z, C.w, nullptr, nullptr}, {keep, keep + n, keep + n + me, keep + n + me + m, nullptr, nullptr}, {n, me, m, m, 0, 0}};
+      if (seg_ok) {
+        h->defer_residual = true;
+        {
+          unsigned long long kb;
+          std::memcpy(&kb, &beta, sizeof(kb));
+          const void *key[10] = {(const void *)(intptr_t)4, (const void *)(uintptr_t)kb, C.x, C.z, C.r1, C.dx, keep, C.out, a1, nullptr};
+          e = graphed(h, h->direct_slot(h->gdirect_seg, key), [&]() {
+            k_fr_rhs<<<nblk(total), 256, 0, s>>>(n, me, m, h->hpin_dev + HPIN_ZM, a1, a2, a3, C.z, C.w, C.r1, C.r2, C.r3, C.r4);
+            int e2 = hqpkkt_factor(h, C.z, C.w);
+            if (!e2) e2 = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
+            if (e2) return e2;
+            k_copy_vectors<<<copy_blocks(Lkeep), 256, 0, s>>>(Lkeep, 4);
+            return take_step_enqueue();
+          });
+        }
+        h->defer_residual = false;
+        if (!e) {
+          h->factor_unchecked = true, h->factored = true, h->residual_pending = true;  // (what the calls leave, replayed or not)
+          e = post_wait(h);
+        }
+      } else {
+        h->defer_residual = !getenv("HQPKKT_FRANKE_TWO_READS");
+        e = hqpkkt_factor(h, C.z, C.w);
+        if (!e) e = hqpkkt_solve(h, C.z, C.w, C.r1, C.r2, C.r3, C.r4, C.dx, C.dy, C.dz, C.dw, &resid);
+        h->defer_residual = false;
+        if (!e && h->residual_pending) {
+          k_copy_vectors<<<copy_blocks(Lkeep), 256, 0, s>>>(Lkeep, 4);
+          if ((e = take_step())) return e;
+        }
+      }
       if (!e && h->residual_pending) {
-        CopyList L{{C.x, C.y, C.z, C.w, nullptr, nullptr}, {keep, keep + n, keep + n + me, keep + n + me + m, nullptr, nullptr}, {n, me, m, m, 0, 0}};
-        k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 4);
-        if ((e = take_step())) return e;
         e = collect_residual(h, &resid);
         const bool unfinished = e || !(resid <= target) || h->soft_singular || h->soft_tiny;
         if (unfinished) {

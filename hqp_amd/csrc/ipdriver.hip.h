@@ -619,10 +619,19 @@ k_fr_cold(int n, int me, int m, CsrDev CT, double Ltilde, const double *__restri
   }
 }
 // right-hand sides of a step (:291-299): r1..r3 = -zeta a1..a3, r4 = z.*w - mu
-__global__ void k_fr_rhs(int n, int me, int m, double zeta, double mu, const double *__restrict__ a1,
-                         const double *__restrict__ a2, const double *__restrict__ a3, const double *__restrict__ z,
-                         const double *__restrict__ w, double *__restrict__ r1, double *__restrict__ r2,
-                         double *__restrict__ r3, double *__restrict__ r4) {
+// (zeta and mu - the host's scalars of the step - come through two words of mapped host memory, zm[0] and zm[1], read by
+// one thread of every workgroup: the launch takes no value that changes from step to step and can be replayed inside a
+// captured graph.  The host writes them before it launches and not again before the step's read-back has arrived.)
+__global__ void __launch_bounds__(256)
+k_fr_rhs(int n, int me, int m, const double *__restrict__ zm, const double *__restrict__ a1,
+         const double *__restrict__ a2, const double *__restrict__ a3, const double *__restrict__ z,
+         const double *__restrict__ w, double *__restrict__ r1, double *__restrict__ r2,
+         double *__restrict__ r3, double *__restrict__ r4) {
+  __shared__ double zmu[2];
+  if (threadIdx.x < 2)
+    zmu[threadIdx.x] = __longlong_as_double((long long)__hip_atomic_load((const unsigned long long *)zm + threadIdx.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM));
+  __syncthreads();
+  const double zeta = zmu[0], mu = zmu[1];
   const int q = blockIdx.x * blockDim.x + threadIdx.x;
   if (q < n)
     r1[q] = -zeta * a1[q];

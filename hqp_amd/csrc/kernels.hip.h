@@ -2869,6 +2869,7 @@ __global__ void __launch_bounds__(256) k_clear(double *__restrict__ p, long long
 // any other post leaves the host's copy of that word as the last such post has written it.
 #define HPIN_DOUBLES 256
 #define HPIN_SEQ 200  // the double of hpin whose first four bytes hold the sequence number
+#define HPIN_ZM 208   // two doubles the HOST writes for a kernel to read: zeta and mu of a step of the Franke loop (k_fr_rhs)
 __global__ void __launch_bounds__(64) k_post_words(int *__restrict__ flags, const double *__restrict__ out, int n_out,
                                                    double *__restrict__ host, unsigned *__restrict__ dev_seq, int residual) {
   const int lane = threadIdx.x;
