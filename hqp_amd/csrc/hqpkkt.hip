@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <chrono>
 #include <cstring>
 #include <atomic>
 #include <mutex>
@@ -208,6 +209,9 @@ struct hqpkkt {
   double *hstage = nullptr;
   size_t hstage_in = 0, hstage_out = 0;  // doubles; 0 = system too large, copy vector by vector
   const double *out_pending = nullptr;   // results wait in hstage + hstage_in for unstage()
+  bool out_by_kernel = false;            // ... written there by a kernel in front of the posting kernel (no stream synchronisation needed)
+  bool host_graph_call = false;          // inside a solve whose first part ran as hqpkkt::ghost_step (no timing events in the stream)
+  double *hstage_dev = nullptr;          // the device's address of hstage (pinned, coherent: kernels copy in and out of it)
   // vectors: staging for host pointers + refinement work vectors
   DBuf<double> vin;   // z w r1 r2 r3 r4
   DBuf<double> vout;  // dx dy dz dw
@@ -250,6 +254,11 @@ struct hqpkkt {
       ge = nullptr, g = nullptr, n_posts = 0;
     }
   } gfactor[2], gstep[2][3];  // [phase], [caller's / refinement's vectors][phase]
+  // A caller with HOST vectors (the reference's solvers through the shim): the packed vectors are read out of the pinned
+  // staging buffer by a kernel, the results written into it by a kernel, and the status words posted - a whole call is
+  // one graph on the compute queue (no copy engine between the launches: 9 - 13 us at each change of engine,
+  // profiles/r06_shim_timeline.txt) and ends with the posted words, not a stream synchronisation
+  GraphSlot ghost_factor, ghost_step;
   // The device-resident interior-point loops hand over the same device vectors in every iteration: their sequences are
   // captured ON those vectors (no copies into and out of the handle's staging buffers), one graph per set of pointers.
   struct DirectGraph {
@@ -307,6 +316,7 @@ struct hqpkkt {
   bool short_rows = false;  // CSR rows of a handful of entries: 4 lanes per row in the SpMV kernels
   void drop_graphs() {
     for (auto &g : gfactor) g.drop();
+    ghost_factor.drop(), ghost_step.drop();
     for (auto &gs : gstep)
       for (auto &g : gs) g.drop();
     for (auto &d : gdirect_step) d.g.drop();
@@ -334,7 +344,7 @@ struct hqpkkt {
     if (!keep_ip) ipv.release();
     terms.release(), esign.release(), bits.p = nullptr;
     if (hpin && !keep_ip) (void)hipHostFree(hpin), hpin = nullptr, hpin_dev = nullptr, post_seq_dev.release(), post_seq = 0;
-    if (hstage) (void)hipHostFree(hstage), hstage = nullptr;
+    if (hstage) (void)hipHostFree(hstage), hstage = nullptr, hstage_dev = nullptr;
     // (keep_ip = the re-analysis inside hqpkkt_solve, switch_to_policy0: the pattern and with it the sizes of the
     // pinned value staging stay, and a host may hold the pointers of hqpkkt_values_staging)
     if (hvals && !keep_ip) (void)hipHostFree(hvals), hvals = nullptr, hvals_elems = 0;
@@ -516,13 +526,15 @@ static int upload(hqpkkt_t *h) {
   HIPCHK(hipMemset(h->flags.p, 0, sizeof(int) * 128));
   h->res_read = 122;
   if ((e = alloc_hpin(h))) return e;
-  if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr;
+  if (h->hstage) (void)hipHostFree(h->hstage), h->hstage = nullptr, h->hstage_dev = nullptr;
   h->hstage_in = h->hstage_out = 0;
   {
     const size_t nin = 4 * (size_t)m + n + me, nout = (size_t)n + me + 2 * (size_t)m;
     if ((nin + nout) * sizeof(double) <= (size_t)512 * 1024 && nin + nout > 0) {
-      HIPCHK(hipHostMalloc((void **)&h->hstage, sizeof(double) * (nin + nout), hipHostMallocDefault));
+      HIPCHK(hipHostMalloc((void **)&h->hstage, sizeof(double) * (nin + nout), hipHostMallocMapped | hipHostMallocCoherent));
       h->hstage_in = nin, h->hstage_out = nout;
+      h->hstage_dev = nullptr;
+      if (hipHostGetDevicePointer((void **)&h->hstage_dev, h->hstage, 0) != hipSuccess) h->hstage_dev = nullptr, (void)hipGetLastError();
     }
   }
   {
@@ -691,6 +703,31 @@ struct Vecs {
   double *dx, *dy, *dz, *dw;
 };
 
+// (HQPKKT_NO_HOST_KERNEL_COPIES=1: the copy engine as before, for same-box comparisons)
+static bool host_kernel_copies(const hqpkkt_t *) {
+  static const bool on = getenv("HQPKKT_NO_HOST_KERNEL_COPIES") == nullptr;
+  return on;
+}
+// A call with host vectors as one graph (hqpkkt::ghost_factor / ghost_step): the tree engine on one GPU, vectors that
+// fit the pinned staging buffer.  (HQPKKT_NO_HOST_GRAPHS=1: launch by launch.)
+static bool host_graphs_ok(const hqpkkt_t *h) {
+  static const bool on = getenv("HQPKKT_NO_HOST_GRAPHS") == nullptr;
+  return on && host_kernel_copies(h) && !h->lazy && h->opts.loc != HQPKKT_LOC_DEVICE && h->hstage_in && h->hstage_dev && h->use_graphs &&
+         !h->prof.on && h->opts.mode != HQPKKT_MODE_STAGED && h->an.shard_count <= 1;
+}
+// the caller's vectors packed into the pinned buffer by the CPU (stage_in's layout); returns the doubles in use
+static size_t stage_pack(hqpkkt_t *h, const double *z, const double *w, const double *r1, const double *r2, const double *r3, const double *r4) {
+  const int n = h->an.n, me = h->an.me, m = h->an.m;
+  double *q = h->hstage;
+  const double *src[6] = {z, w, r1, r2, r3, r4};
+  const int len[6] = {m, m, n, me, m, m};
+  size_t used = 0, off = 0;
+  for (int k = 0; k < 6; k++) {
+    if (src[k] && len[k] > 0) std::memcpy(q + off, src[k], sizeof(double) * len[k]), used = off + len[k];
+    off += len[k];
+  }
+  return used;
+}
 static int stage_in(hqpkkt_t *h, const double *z, const double *w, const double *r1,
                     const double *r2, const double *r3, const double *r4, Vecs &v) {
   const int n = h->an.n, me = h->an.me, m = h->an.m;
@@ -709,7 +746,11 @@ static int stage_in(hqpkkt_t *h, const double *z, const double *w, const double 
       if (src[k] && len[k] > 0) std::memcpy(q + off, src[k], sizeof(double) * len[k]), used = off + len[k];
       off += len[k];
     }
-    if (used) HIPCHK(hipMemcpyAsync(b, q, sizeof(double) * used, hipMemcpyHostToDevice, h->stream));
+    if (used && h->hstage_dev && host_kernel_copies(h)) {  // read out of the pinned buffer by a kernel: no copy engine in the chain
+      CopyList L{{h->hstage_dev, nullptr, nullptr, nullptr, nullptr, nullptr}, {b, nullptr, nullptr, nullptr, nullptr, nullptr}, {(int)used, 0, 0, 0, 0, 0}};
+      k_copy_vectors<<<copy_blocks(L), 256, 0, h->stream>>>(L, 1);
+    } else if (used)
+      HIPCHK(hipMemcpyAsync(b, q, sizeof(double) * used, hipMemcpyHostToDevice, h->stream));
   } else {
 #define H2D(dst, src, k) \
   if ((src) && (k) > 0) HIPCHK(hipMemcpyAsync(dst, src, sizeof(double) * (k), hipMemcpyHostToDevice, h->stream))
@@ -738,8 +779,15 @@ static int stage_out(hqpkkt_t *h, const Vecs &v, double *dx, double *dy, double 
     return 0;
   }
   if (h->hstage_out) {  // one transfer into pinned memory; unstage() hands it out after the sync
-    HIPCHK(hipMemcpyAsync(h->hstage + h->hstage_in, v.dx, sizeof(double) * h->hstage_out, hipMemcpyDeviceToHost,
-                          h->stream));
+    if (h->hstage_dev && host_kernel_copies(h)) {  // ... written by a kernel (coherent host memory: there when the next kernel of the stream starts)
+      CopyList L{{v.dx, nullptr, nullptr, nullptr, nullptr, nullptr}, {h->hstage_dev + h->hstage_in, nullptr, nullptr, nullptr, nullptr, nullptr}, {(int)h->hstage_out, 0, 0, 0, 0, 0}};
+      k_copy_vectors<<<copy_blocks(L), 256, 0, h->stream>>>(L, 1);
+      h->out_by_kernel = true;
+    } else {
+      HIPCHK(hipMemcpyAsync(h->hstage + h->hstage_in, v.dx, sizeof(double) * h->hstage_out, hipMemcpyDeviceToHost,
+                            h->stream));
+      h->out_by_kernel = false;
+    }
     h->out_pending = h->hstage + h->hstage_in;
     return 0;
   }
@@ -1158,7 +1206,8 @@ struct OutPtrs {
 static int staged_dense_products(hqpkkt_t *h, const Vecs &v, const double **x1, const double **x2, int *ndyn);
 
 static int collect_residual(hqpkkt_t *h, double *res);
-static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *out = nullptr) {
+// the residual kernel alone (what run_residual puts into the stream first)
+static int residual_launch(hqpkkt_t *h, const Vecs &v) {
   Analysis &an = h->an;
   hipStream_t s = h->stream;
   const int n = an.n, me = an.me, m = an.m;
@@ -1181,6 +1230,14 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
     KLAUNCH(h, KC_RESIDUAL, k_residual<16><<<std::min(nblk(16LL * ((long long)n + me + m)), 1024), 256, 0, s>>>(
         n, me, m, h->Qf.dev(), h->AT.dev(), h->CT.dev(), h->A.dev(), h->C.dev(), h->vals.p, v.z, v.w,
         v.r1, v.r2, v.r3, v.r4, v.dx, v.dy, v.dz, v.dw, o1, o2, o3, o4, rb_now, rb_next, x1, x2, ndyn));
+  return 0;
+}
+static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *out = nullptr) {
+  hipStream_t s = h->stream;
+  {
+    const int e1 = residual_launch(h, v);
+    if (e1) return e1;
+  }
   if (out) {
     int e2 = stage_out(h, v, out->dx, out->dy, out->dz, out->dw);
     if (e2) return e2;
@@ -1193,7 +1250,7 @@ static int run_residual(hqpkkt_t *h, const Vecs &v, double *res, const OutPtrs *
     *res = 0.0;
     return 0;
   }
-  if (out) HIPCHK(hipStreamSynchronize(s));  // (the caller's vectors: copies into pageable memory have landed)
+  if (out && !(h->out_pending && h->out_by_kernel)) HIPCHK(hipStreamSynchronize(s));  // (the caller's vectors: copies into pageable memory have landed)
   if ((ep = post_wait(h))) return ep;
   return collect_residual(h, res);
 }
@@ -1609,6 +1666,24 @@ static int factor_once(hqpkkt_t *h, const double *z, const double *w) {
   DirectCall direct_call(h, fp, fl, 2, h->last_f);
   Vecs v{};
   int e = 0;
+  const bool hostg = host_graphs_ok(h) && !direct_vectors(h);
+  const auto wall0 = std::chrono::steady_clock::now();
+  if (hostg) {
+    // packed by the CPU, then ONE graph: the copy out of the pinned buffer, the factorisation, the posted status words
+    const size_t used = stage_pack(h, z, w, nullptr, nullptr, nullptr, nullptr);
+    const int m = h->an.m;
+    v.z = h->vin.p, v.w = h->vin.p + m;
+    h->factored = false;
+    if ((e = graphed(h, h->ghost_factor, [&]() {
+           if (used) {
+             CopyList L{{h->hstage_dev, nullptr, nullptr, nullptr, nullptr, nullptr}, {h->vin.p, nullptr, nullptr, nullptr, nullptr, nullptr}, {(int)used, 0, 0, 0, 0, 0}};
+             k_copy_vectors<<<copy_blocks(L), 256, 0, h->stream>>>(L, 1);
+           }
+           const int e2 = do_factor(h, v);
+           return e2 ? e2 : post_words(h, nullptr, 0);
+         })))
+      return e;
+  } else {
   if (direct_vectors(h))
     v.z = z, v.w = w;
   else if ((e = stage_in(h, z, w, nullptr, nullptr, nullptr, nullptr, v)))
@@ -1627,14 +1702,20 @@ static int factor_once(hqpkkt_t *h, const double *z, const double *w) {
     h->factor_unchecked = true, h->factored = true;
     return 0;
   }
+  }
   int *hs = (int *)h->hpin;
-  HIPCHK(hipMemcpyAsync(hs, h->flags.p, sizeof(int) * 128, hipMemcpyDeviceToHost, h->stream));
-  HIPCHK(hipStreamSynchronize(h->stream));
+  {  // the status words, posted (k_post_words) and waited for
+    int ep = hostg ? 0 : post_words(h, nullptr, 0);
+    if (ep || (ep = post_wait(h))) return ep;
+  }
   if (poll_fallback(h, hs)) return HQPKKT_E_POLL;  // (factored stays false)
   const int flags[4] = {hs[0], hs[1], hs[2], hs[3]};
   std::memcpy(&h->st.kmax, hs + 120, sizeof(double));
   h->prof.collect();
-  if (h->use_graphs && !h->prof.on) {
+  if (hostg) {  // (no events in the chain: the call's wall time, copies and read-back included)
+    h->st.ms_assemble = 0.f;
+    h->st.ms_factor = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  } else if (h->use_graphs && !h->prof.on) {
     h->st.ms_assemble = 0.f;  // inside the replayed graph
     h->st.ms_factor = elapsed(h->ev0, h->evs1);
   } else {
@@ -1739,8 +1820,42 @@ static int solve_once(hqpkkt_t *h, const double *z, const double *w, const doubl
   const int sl[10] = {h->an.m, h->an.m, h->an.n, h->an.me, h->an.m, h->an.m, h->an.n, h->an.me, h->an.m, h->an.m};
   DirectCall direct_call(h, sp, sl, 10, h->last_s);
   Vecs v{};
-  int e = solve_vecs(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, v);
-  if (e) return e;
+  int e = 0;
+  {
+    bool all = host_graphs_ok(h) && !direct_vectors(h) && h->hstage_out;
+    for (int k = 0; k < 10; k++) all = all && (sp[k] != nullptr || sl[k] == 0);
+    if (all) {
+      // packed by the CPU, then ONE graph: the copy out of the pinned buffer, the sweeps, the residual, the result into
+      // the pinned buffer, the posted words (residual and status); the CPU hands the result out when they have arrived
+      const auto wall0 = std::chrono::steady_clock::now();
+      const size_t used = stage_pack(h, z, w, r1, r2, r3, r4);
+      const int n = h->an.n, me = h->an.me, m = h->an.m;
+      double *b = h->vin.p;
+      v.z = b, v.w = b + m, v.r1 = b + 2 * (size_t)m, v.r2 = v.r1 + n, v.r3 = v.r2 + me, v.r4 = v.r3 + m;
+      stage_out_ptrs(h, v);
+      if ((e = graphed(h, h->ghost_step, [&]() {
+             if (used) {
+               CopyList L{{h->hstage_dev, nullptr, nullptr, nullptr, nullptr, nullptr}, {b, nullptr, nullptr, nullptr, nullptr, nullptr}, {(int)used, 0, 0, 0, 0, 0}};
+               k_copy_vectors<<<copy_blocks(L), 256, 0, s>>>(L, 1);
+             }
+             int e2 = do_step(h, v, 0);
+             if (e2 || (e2 = residual_launch(h, v))) return e2;
+             CopyList O{{v.dx, nullptr, nullptr, nullptr, nullptr, nullptr}, {h->hstage_dev + h->hstage_in, nullptr, nullptr, nullptr, nullptr, nullptr}, {(int)h->hstage_out, 0, 0, 0, 0, 0}};
+             k_copy_vectors<<<copy_blocks(O), 256, 0, s>>>(O, 1);
+             return post_words(h, nullptr, 0, true);
+           })))
+        return e;
+      h->out_pending = h->hstage + h->hstage_in, h->out_by_kernel = true;
+      double res = 0.0;
+      if ((e = post_wait(h)) || (e = collect_residual(h, &res))) return e;
+      h->host_graph_call = true;
+      e = solve_tail(h, v, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res, res_out);
+      h->host_graph_call = false;
+      h->st.ms_solve = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+      return e;
+    }
+  }
+  if ((e = solve_vecs(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, v))) return e;
   if (!h->lazy) HIPCHK(hipEventRecord(h->ev0, s));
   if ((e = do_step(h, v, 0))) return e;
   double res = 0.0;
@@ -1809,17 +1924,18 @@ static int solve_tail(hqpkkt_t *h, Vecs &v, const double *z, const double *w, co
     if ((e = switch_to_policy0(h)) || (e = hqpkkt_factor(h, z, w))) return e;
     return hqpkkt_solve(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res_out);
   }
-  if (!h->lazy) HIPCHK(hipEventRecord(h->ev1, s));
+  if (!h->lazy && !h->host_graph_call) HIPCHK(hipEventRecord(h->ev1, s));
   if (h->lazy) {
     if (v.dx != dx && (e = stage_out(h, v, dx, dy, dz, dw))) return e;
   } else {
     if (refined && v.dx != dx) {
       if ((e = stage_out(h, v, dx, dy, dz, dw))) return e;
     }
-    HIPCHK(hipStreamSynchronize(s));  // (returns at once when nothing was queued after the read-back)
+    // (a call whose result a kernel has put into the pinned buffer in front of the posted words, and no refinement: it is there)
+    if (!h->host_graph_call || rounds > 0 || refined) HIPCHK(hipStreamSynchronize(s));  // (returns at once when nothing was queued after the read-back)
     unstage(h, dx, dy, dz, dw);
     h->prof.collect();
-    h->st.ms_solve = elapsed(h->ev0, h->ev1);
+    if (!h->host_graph_call) h->st.ms_solve = elapsed(h->ev0, h->ev1);
   }
   h->st.refine_rounds = rounds;
   if (getenv("HQPKKT_TRACE_SOLVE")) fprintf(stderr, "solve: first residual %.3e, %d rounds, final %.3e\n", res_first, rounds, res);
