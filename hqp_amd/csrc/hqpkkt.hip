@@ -269,6 +269,8 @@ struct hqpkkt {
   // ... and whole SEGMENTS of an iteration of the device-resident loops - everything between two read-backs: the
   // factorisation, a solve, its residual and the posting kernel - as one graph (ip_segment)
   std::vector<DirectGraph> gdirect_seg;
+  // ... and a caller's own factor / solve call on its device vectors with its residual and the posted words
+  std::vector<DirectGraph> gdirect_call;
   GraphSlot &direct_slot(std::vector<DirectGraph> &cache, const void *const (&key)[10]) {
     for (auto &d : cache)
       if (std::memcmp(d.key, key, sizeof(key)) == 0) return d.g;
@@ -322,7 +324,8 @@ struct hqpkkt {
     for (auto &d : gdirect_step) d.g.drop();
     for (auto &d : gdirect_factor) d.g.drop();
     for (auto &d : gdirect_seg) d.g.drop();
-    gdirect_step.clear(), gdirect_factor.clear(), gdirect_seg.clear();
+    for (auto &d : gdirect_call) d.g.drop();
+    gdirect_step.clear(), gdirect_factor.clear(), gdirect_seg.clear(), gdirect_call.clear();
   }
 
   DevTree tree() const {
@@ -705,14 +708,12 @@ struct Vecs {
 
 // (HQPKKT_NO_HOST_KERNEL_COPIES=1: the copy engine as before, for same-box comparisons)
 static bool host_kernel_copies(const hqpkkt_t *) {
-  static const bool on = getenv("HQPKKT_NO_HOST_KERNEL_COPIES") == nullptr;
-  return on;
+  return getenv("HQPKKT_NO_HOST_KERNEL_COPIES") == nullptr;
 }
 // A call with host vectors as one graph (hqpkkt::ghost_factor / ghost_step): the tree engine on one GPU, vectors that
 // fit the pinned staging buffer.  (HQPKKT_NO_HOST_GRAPHS=1: launch by launch.)
 static bool host_graphs_ok(const hqpkkt_t *h) {
-  static const bool on = getenv("HQPKKT_NO_HOST_GRAPHS") == nullptr;
-  return on && host_kernel_copies(h) && !h->lazy && h->opts.loc != HQPKKT_LOC_DEVICE && h->hstage_in && h->hstage_dev && h->use_graphs &&
+  return getenv("HQPKKT_NO_HOST_GRAPHS") == nullptr && host_kernel_copies(h) && !h->lazy && h->opts.loc != HQPKKT_LOC_DEVICE && h->hstage_in && h->hstage_dev && h->use_graphs &&
          !h->prof.on && h->opts.mode != HQPKKT_MODE_STAGED && h->an.shard_count <= 1;
 }
 // the caller's vectors packed into the pinned buffer by the CPU (stage_in's layout); returns the doubles in use
@@ -1666,9 +1667,21 @@ static int factor_once(hqpkkt_t *h, const double *z, const double *w) {
   DirectCall direct_call(h, fp, fl, 2, h->last_f);
   Vecs v{};
   int e = 0;
-  const bool hostg = host_graphs_ok(h) && !direct_vectors(h);
+  // a caller's own call on its DEVICE vectors (from the second one in a row with the same pointers: DirectCall): the
+  // sequence and the posted status words as one graph as well, no timing events in the chain
+  const bool devg = !h->lazy && direct_vectors(h) && h->use_graphs && !h->prof.on && getenv("HQPKKT_NO_HOST_GRAPHS") == nullptr;
+  const bool hostg = devg || (host_graphs_ok(h) && !direct_vectors(h));
   const auto wall0 = std::chrono::steady_clock::now();
-  if (hostg) {
+  if (devg) {
+    v.z = z, v.w = w;
+    h->factored = false;
+    const void *key[10] = {z, w, (const void *)(intptr_t)1};
+    if ((e = graphed(h, h->direct_slot(h->gdirect_call, key), [&]() {
+           const int e2 = do_factor(h, v);
+           return e2 ? e2 : post_words(h, nullptr, 0);
+         })))
+      return e;
+  } else if (hostg) {
     // packed by the CPU, then ONE graph: the copy out of the pinned buffer, the factorisation, the posted status words
     const size_t used = stage_pack(h, z, w, nullptr, nullptr, nullptr, nullptr);
     const int m = h->an.m;
@@ -1821,6 +1834,25 @@ static int solve_once(hqpkkt_t *h, const double *z, const double *w, const doubl
   DirectCall direct_call(h, sp, sl, 10, h->last_s);
   Vecs v{};
   int e = 0;
+  if (!h->lazy && direct_vectors(h) && h->use_graphs && !h->prof.on && getenv("HQPKKT_NO_HOST_GRAPHS") == nullptr) {
+    // a caller's own solve on its DEVICE vectors: sweeps, residual and the posted words as one graph
+    const auto wall0 = std::chrono::steady_clock::now();
+    if ((e = solve_vecs(h, z, w, r1, r2, r3, r4, dx, dy, dz, dw, v))) return e;
+    const void *key[10] = {z, w, r1, r2, r3, r4, dx, dy, dz, (const void *)((const char *)dw + 1)};  // (+ 1: not the key of the sequence's own graph)
+    if ((e = graphed(h, h->direct_slot(h->gdirect_call, key), [&]() {
+           int e2 = do_step(h, v, 0);
+           if (e2 || (e2 = residual_launch(h, v))) return e2;
+           return post_words(h, nullptr, 0, true);
+         })))
+      return e;
+    double res = 0.0;
+    if ((e = post_wait(h)) || (e = collect_residual(h, &res))) return e;
+    h->host_graph_call = true;
+    e = solve_tail(h, v, z, w, r1, r2, r3, r4, dx, dy, dz, dw, res, res_out);
+    h->host_graph_call = false;
+    h->st.ms_solve = std::chrono::duration<float, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+    return e;
+  }
   {
     bool all = host_graphs_ok(h) && !direct_vectors(h) && h->hstage_out;
     for (int k = 0; k < 10; k++) all = all && (sp[k] != nullptr || sl[k] == 0);

@@ -200,8 +200,11 @@ __device__ double soft_pivot_pert = 1e-6;
 // TINY_REPLACE_WORD of the handle's flags (k_clear leaves it alone) switches the replacement on: the device-resident
 // interior-point loops set it once their first factorisation + solve has succeeded (hqpkkt_mehrotra: behind the cold
 // start; hqpkkt_franke: from the second iteration on) and clear it when they return; the plugin entry points
-// (hqpkkt_factor on its own, the reference's solvers through the shim) never replace.  An EXACTLY zero pivot is never
-// replaced: it stays the reference's E_SING (zero_pivot_slot above).
+// (hqpkkt_factor on its own, the reference's solvers through the shim) never replace.  Until round 6 an EXACTLY zero
+// pivot was never replaced; it is now, like any other cancelled one - where the replacement is on, a factorisation + solve of
+// the same structure has succeeded, so a zero that turns up later is cancellation at the end of an interior-point run (w / z
+// of 1e-21 beside 1e+9: campaign case 187 of round 6), not rank deficiency; without the replacement it stays the
+// reference's E_SING (zero_pivot_slot above).
 static const int TINY_REPLACE_WORD = 112;
 __device__ __forceinline__ bool tiny_replace(const int *counters) { return counters[TINY_REPLACE_WORD - 1] != 0 && soft_pivot_pert > 0.0; }
 // (The replacement cures the runs that ended early on garbage factors - all ten finds of the campaigns of rounds 1-4 - and
@@ -825,7 +828,7 @@ int dn;
         const int sgs = esign[e0 + lp[k]];
         if (sgs == 2 || sgs == -2) {
           counters[4] = 1;  // see SOFT_PIVOT_REL
-          if (d != 0.0 && tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rm0[lp[k]], pert), pertd = true;
+          if (tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rm0[lp[k]], pert), pertd = true;
         }
       }
       if (!(fabs(d) >= pert)) {
@@ -1363,7 +1366,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
         const int sgs = esign[e0 + lp[k]];
         if (sgs == 2 || sgs == -2) {
           counters[4] = 1;  // see SOFT_PIVOT_REL
-          if (d != 0.0 && tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rdlane(rowmax0, lp[k]), pert), pertd = true;
+          if (tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rdlane(rowmax0, lp[k]), pert), pertd = true;
         }
       }
       if (!(fabs(d) >= pert)) {

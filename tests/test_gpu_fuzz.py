@@ -82,7 +82,11 @@ def test_large_stage_campaign_subset():
 # ONE blocking decision of Hqp_IpsFranke's step-length rule near the solution, on the double-integrator structure, flips
 # with the rounding of the loop's own vector kernels (contracted multiply-adds where the reference's host code rounds
 # twice); with the kernels compiled without contraction these three agree and four other QPs of the 12 000 differ instead.
-IP_FINDS = [193, 2536, 5533, 5975, 6258, 7018, 7260, 7511, 8650, 10246, 803, 2419, 2532, 3015, 5466, 5921, 5954, 7818, 10258]
+# Round 6 (profiles/r06_fuzz_final.txt, 8000 QPs on the final code): 2536 and 8650 agree since the small fronts sum their update
+# blocks in another order (another rounding: the cause named above), 6258 stays; 187 - the loop ended "degenerate" one step
+# before the reference's "optimal" on an EXACTLY zero pivot (w / z of 1e-21 beside 1e+9) - agrees since the loops' second
+# attempt replaces such a pivot like any other cancelled one.
+IP_FINDS = [193, 2536, 5533, 5975, 6258, 7018, 7260, 7511, 8650, 10246, 803, 2419, 2532, 3015, 5466, 5921, 5954, 7818, 10258, 187]
 
 
 def test_ip_loop_campaign_subset():
@@ -125,15 +129,17 @@ def test_ip_loop_hot_start_subset():
     assert cnt.get("ok", 0) >= 90, cnt
 
 
-def test_ip_loop_hot_start_find_of_round_6():
-    """The one QP of the 800-case hot-start campaign of round 6 (profiles/r06_fuzz_hot.txt) on which the device loop is
-    further from the reference than the reference's own plugins are from each other: case 444, Franke on the
-    double-integrator structure - the hot start needs more than the 15 warm iterations (qp_max_warm_iters) the
-    reference converges in (at the 15th), so the loop restarts cold: 201 against 15 iterations, same solution."""
+@pytest.mark.parametrize("case", [444, 1075])
+def test_ip_loop_hot_start_find_of_round_6(case):
+    """The QPs of the hot-start campaigns of round 6 (profiles/r06_fuzz_hot.txt: 800 cases; r06_fuzz_final.txt: 2000) on
+    which the device loop is further from the reference than the reference's own plugins are from each other: cases 444
+    and 1075, Franke on the double-integrator structure - the hot start needs more than the 15 warm iterations
+    (qp_max_warm_iters) the reference converges in (at the 15th), so the loop restarts cold: 201 / 116 against 15
+    iterations, same solution."""
     import fuzz_ip
     if not refapi.host_available("ref"):
         pytest.skip("oracle/_ref not present")
-    status, line = fuzz_ip.check(444, hot=True)
+    status, line = fuzz_ip.check(case, hot=True)
     if status == "BAD":
         pytest.xfail("known difference (the hot start misses qp_max_warm_iters by its first, short steps: "
                      "profiles/r06_franke_hot_traces.txt): " + line)
