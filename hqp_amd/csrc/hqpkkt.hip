@@ -819,6 +819,9 @@ static_assert(FS_MAXP == kktdev::SMALL_PIVOTS && FS_MAXB == kktdev::SMALL_BORDER
 // ------------------------------------------------------------ numeric phases
 // phases: 1 = assemble + this rank's subtrees, 2 = replicated top of the tree
 // (3 = everything, the single-rank case)
+// (HQPKKT_NO_FUSED_VECTORS=1: the vector work around the sweeps and the assembly as the separate launches of round 5 - the
+// comparison the bit-identity test makes)
+static bool no_fused_vectors() { return getenv("HQPKKT_NO_FUSED_VECTORS") != nullptr; }
 static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases) {
   Analysis &an = h->an;
   hipStream_t s = h->stream;
@@ -833,19 +836,32 @@ static int run_factor(hqpkkt_t *h, const double *z, const double *w, int phases)
       k_clear<<<1, 256, 0, s>>>(nullptr, 0, h->flags.p);
     }
     if (!h->capturing) HIPCHK(hipEventRecord(h->ev0, s));
-    if (m > 0)
+    if (m > 0 && (h->simple_src.count || no_fused_vectors()))
       KLAUNCH(h, KC_ASSEMBLE, k_weights<<<nblk(m), 256, 0, s>>>(an.mode, m, an.n + an.me, z, w, h->wt.p, h->sc.p, h->flags.p));
     if (h->simple_src.count) {  // FULL: one pass
       KLAUNCH(h, KC_ASSEMBLE, k_assemble_simple<<<std::min(nblk(nent), 2048), 256, 0, s>>>(
                                   nent, h->simple_src.p, h->simple_wi.p, h->ent_a.p, h->ent_b.p, h->ent_dst.p,
                                   h->vals.p, h->wt.p, h->sc.p, h->panel.p, h->bits.p, h->tree_words.p + 1));
     } else {
-      KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
-                                                h->ent_val.p, h->tree_words.p + 1));
+      // weights + entry values, scales + scatter: one launch each (kernels.hip.h, k_wt_entry / k_scale_scatter)
+      if (no_fused_vectors()) {
+        KLAUNCH(h, KC_ASSEMBLE, k_entry_values<<<nblk(nent), 256, 0, s>>>(nent, h->term_ptr.p, h->terms.p, h->vals.p, h->wt.p,
+                                                  h->ent_val.p, h->tree_words.p + 1));
+        if (an.mode == 1 && an.n > 0)
+          KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
+        KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
+                                             h->sc.p, h->panel.p, h->bits.p));
+      } else {
+      KLAUNCH(h, KC_ASSEMBLE, k_wt_entry<<<nblk(nent) + (m > 0 ? nblk(m) : 0), 256, 0, s>>>(an.mode, m, an.n + an.me, nent, nblk(nent), z, w, h->wt.p, h->sc.p,
+                                                h->flags.p, h->term_ptr.p, h->terms.p, h->vals.p, h->ent_val.p, h->tree_words.p + 1));
+      const int nsc = std::min(nblk(nent), 2048);
       if (an.mode == 1 && an.n > 0)
-        KLAUNCH(h, KC_ASSEMBLE, k_red_scale<<<nblk(an.n), 256, 0, s>>>(an.n, h->diag_ent.p, h->ent_val.p, h->sc.p));
-      KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<std::min(nblk(nent), 2048), 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
-                                           h->sc.p, h->panel.p, h->bits.p));
+        KLAUNCH(h, KC_ASSEMBLE, k_scale_scatter<<<nsc + nblk(an.n), 256, 0, s>>>(an.n, nent, nsc, h->diag_ent.p, h->ent_a.p, h->ent_b.p, h->ent_dst.p,
+                                                 h->ent_val.p, h->sc.p, h->panel.p, h->bits.p));
+      else
+        KLAUNCH(h, KC_ASSEMBLE, k_scatter<<<nsc, 256, 0, s>>>(nent, h->ent_a.p, h->ent_b.p, h->ent_dst.p, h->ent_val.p,
+                                             h->sc.p, h->panel.p, h->bits.p));
+      }
     }
     if (!h->capturing) HIPCHK(hipEventRecord(h->ev1, s));
   }
@@ -1010,10 +1026,16 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
       KLAUNCH(h, KC_VECTOR, k_rhs_full<<<nblk(dim), 256, 0, s>>>(n, me, m, h->q2e.p, h->sc.p, v.z, v.r1, v.r2, v.r3, v.r4,
                                            h->rhs.p, h->tree_words.p));
     } else {
-      if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
-      KLAUNCH(h, KC_VECTOR, k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
-                                          h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p,
-                                          h->tree_words.p));
+      // (tz and the right-hand side that needs it in one launch: kernels.hip.h, k_rhs_red_t; HQPKKT_NO_FUSED_VECTORS=1: two)
+      if (no_fused_vectors()) {
+        if (m > 0) KLAUNCH(h, KC_VECTOR, k_red_t<<<nblk(m), 256, 0, s>>>(m, v.w, h->wt.p, v.r3, v.r4, h->tz.p));
+        KLAUNCH(h, KC_VECTOR, k_rhs_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
+                                            h->CT.src.p, h->vals.p, h->tz.p, v.r1, v.r2, h->rhs.p,
+                                            h->tree_words.p));
+      } else
+        KLAUNCH(h, KC_VECTOR, k_rhs_red_t<<<nblk(dim) + (m > 0 ? nblk(m) : 0), 256, 0, s>>>(n, me, m, nblk(dim), h->q2e.p, h->sc.p, h->CT.ptr.p, h->CT.col.p,
+                                            h->CT.src.p, h->vals.p, v.w, h->wt.p, v.r3, v.r4, h->tz.p, v.r1, v.r2, h->rhs.p,
+                                            h->tree_words.p));
     }
     forward(0);
   }
@@ -1047,10 +1069,16 @@ static int run_step(hqpkkt_t *h, const Vecs &v, int phases) {
         KLAUNCH(h, KC_VECTOR, k_dw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx, v.r3,
                                      v.z, v.w, v.r4, v.dz, v.dw));
     } else {
-      KLAUNCH(h, KC_VECTOR, k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy));
-      if (m > 0)
-        KLAUNCH(h, KC_VECTOR, k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx,
-                                           h->wt.p, h->tz.p, v.r3, v.dz, v.dw));
+      // (dx, dy and the dz, dw that need dx in one launch: kernels.hip.h, k_unpack_dzdw)
+      const int nb_dzdw = m > 0 ? nblk(m) : 0;
+      if (no_fused_vectors()) {
+        KLAUNCH(h, KC_VECTOR, k_unpack_red<<<nblk(dim), 256, 0, s>>>(n, me, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy));
+        if (m > 0)
+          KLAUNCH(h, KC_VECTOR, k_red_dzdw<<<nblk(m), 256, 0, s>>>(m, h->C.ptr.p, h->C.col.p, h->C.src.p, h->vals.p, v.dx,
+                                             h->wt.p, h->tz.p, v.r3, v.dz, v.dw));
+      } else
+      KLAUNCH(h, KC_VECTOR, k_unpack_dzdw<<<nb_dzdw + nblk(dim), 256, 0, s>>>(n, me, m, nb_dzdw, h->q2e.p, h->sc.p, h->xsol.p, v.dx, v.dy, h->C.ptr.p,
+                                           h->C.col.p, h->C.src.p, h->vals.p, h->wt.p, h->tz.p, v.r3, v.dz, v.dw));
     }
   }
   HIPCHK(hipGetLastError());

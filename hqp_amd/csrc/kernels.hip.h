@@ -231,13 +231,59 @@ __global__ void k_entry_values(int nent, const int *__restrict__ term_ptr,
   ent_val[e] = v;
 }
 
+// k_weights + k_entry_values as ONE launch (round 6, as k_rhs_red_t below: a launch inside a replayed graph is 4.6 us): the
+// first nb_first workgroups the entries, with the weight evaluated where a term needs it (the same quotient: the same
+// bits), the rest store the weights (the solves read them) and see zeros in z / w.
+__device__ __forceinline__ double weight_elem(int mode, int m, const double *__restrict__ z, const double *__restrict__ w, int j) {
+  if (j >= m) return 1.0;  // (wt[m]: the constant weight)
+  const double zj = z[j], wj = w[j];
+  if (zj == 0.0 || wj == 0.0) return 1.0;
+  return mode == 0 ? wj / zj : zj / wj;
+}
+__global__ void __launch_bounds__(256)
+k_wt_entry(int mode, int m, int nme, int nent, int nb_first, const double *__restrict__ z, const double *__restrict__ w, double *__restrict__ wt,
+           double *__restrict__ sc, int *__restrict__ status, const int *__restrict__ term_ptr, const TermDev *__restrict__ terms,
+           const double *__restrict__ vals, double *__restrict__ ent_val, int *__restrict__ epoch) {
+  if ((int)blockIdx.x >= nb_first) {
+    const int j = ((int)blockIdx.x - nb_first) * blockDim.x + threadIdx.x;
+    if (j == 0) wt[m] = 1.0;
+    if (j >= m) return;
+    const double zj = z[j], wj = w[j];
+    if (zj == 0.0 || wj == 0.0) {  // v_slash raises E_SING (meschach/vecop.c:346-348)
+      atomicExch(status, 4);
+      wt[j] = 1.0;
+      if (mode == 0) sc[nme + j] = 1.0;
+      return;
+    }
+    if (mode == 0) {
+      const double wz = wj / zj;
+      wt[j] = wz;
+      sc[nme + j] = fmin(1.0, sqrt(1.0 / wz));
+    } else
+      wt[j] = zj / wj;
+    return;
+  }
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e == 0 && epoch) *epoch += 1;  // the factorisation counter of the whole-tree launch (k_factor_diag_small<true, true>)
+  if (e >= nent) return;
+  double v = 0.0;
+  for (int t = term_ptr[e]; t < term_ptr[e + 1]; t++) {
+    const TermDev tm = terms[t];
+    v += tm.sgn * vals[tm.s1] * vals[tm.s2] * weight_elem(mode, m, z, w, tm.wi);
+  }
+  ent_val[e] = v;
+}
+
 // REDUCED: scale_i = min(1, sqrt(-1/J_ii))  (hqp/Hqp_IpRedSpBKP.C:130,138)
+__device__ __forceinline__ double red_scale_elem(const int *__restrict__ diag_ent, const double *__restrict__ ent_val, int i) {
+  const int e = diag_ent[i];
+  return e >= 0 ? fmin(1.0, sqrt(-1.0 / ent_val[e])) : 1.0;
+}
 __global__ void k_red_scale(int n, const int *__restrict__ diag_ent,
                             const double *__restrict__ ent_val, double *__restrict__ sc) {
   int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
-  int e = diag_ent[i];
-  sc[i] = e >= 0 ? fmin(1.0, sqrt(-1.0 / ent_val[e])) : 1.0;
+  sc[i] = red_scale_elem(diag_ent, ent_val, i);
 }
 
 // J <- S J S scattered into the supernode panels (hqp/Hqp_IpSpBKP.C:162-176);
@@ -253,6 +299,35 @@ k_scatter(int nent, const int *__restrict__ ent_a, const int *__restrict__ ent_b
   double mx = 0.0;
   for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nent; e += gridDim.x * blockDim.x) {
     const double v = ent_val[e] * sc[ent_a[e]] * sc[ent_b[e]];
+    panel[ent_dst[e]] = v;
+    mx = fmax(mx, fabs(v));
+  }
+  mx = wave_max(mx);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    mx = fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
+    if (mx > 0.0) atomic_max_pos(kmax, mx);
+  }
+}
+
+// k_red_scale + k_scatter as ONE launch (REDUCED): the first nb_first workgroups scatter, with the scale of a row of x
+// evaluated where an entry needs it (rows of the equality multipliers: 1, from memory), the rest store the scales.
+__global__ void __launch_bounds__(256)
+k_scale_scatter(int n, int nent, int nb_first, const int *__restrict__ diag_ent, const int *__restrict__ ent_a, const int *__restrict__ ent_b,
+                const long long *__restrict__ ent_dst, const double *__restrict__ ent_val, double *__restrict__ sc,
+                double *__restrict__ panel, unsigned long long *__restrict__ kmax) {
+  if ((int)blockIdx.x >= nb_first) {
+    const int i = ((int)blockIdx.x - nb_first) * blockDim.x + threadIdx.x;
+    if (i < n) sc[i] = red_scale_elem(diag_ent, ent_val, i);
+    return;
+  }
+  __shared__ double red[4];
+  double mx = 0.0;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < nent; e += nb_first * blockDim.x) {
+    const int a = ent_a[e], b = ent_b[e];
+    const double sa = a < n ? red_scale_elem(diag_ent, ent_val, a) : sc[a], sb = b < n ? red_scale_elem(diag_ent, ent_val, b) : sc[b];
+    const double v = ent_val[e] * sa * sb;
     panel[ent_dst[e]] = v;
     mx = fmax(mx, fabs(v));
   }
@@ -2682,12 +2757,16 @@ __global__ void k_dw(int m, const int *__restrict__ Cp, const int *__restrict__ 
 }
 
 // REDUCED, part 1: tz = r4./w + (z/w).*r3   (hqp/Hqp_IpRedSpBKP.C:339-341)
+__device__ __forceinline__ double red_t_elem(const double *__restrict__ w, const double *__restrict__ zw, const double *__restrict__ r3,
+                                             const double *__restrict__ r4, int j) {
+  return r4[j] / w[j] + zw[j] * r3[j];
+}
 __global__ void k_red_t(int m, const double *__restrict__ w, const double *__restrict__ zw,
                         const double *__restrict__ r3, const double *__restrict__ r4,
                         double *__restrict__ tz) {
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
-  tz[j] = r4[j] / w[j] + zw[j] * r3[j];
+  tz[j] = red_t_elem(w, zw, r3, r4, j);
 }
 // REDUCED, part 2: rhs = P [(r1 - C' tz) .* scale; r2]   (:342-348)
 __global__ void k_rhs_red(int n, int me, const int *__restrict__ q2e, const double *__restrict__ sc,
@@ -2726,6 +2805,59 @@ __global__ void k_red_dzdw(int m, const int *__restrict__ Cp, const int *__restr
   int j = blockIdx.x * blockDim.x + threadIdx.x;
   if (j >= m) return;
   double cdx = row_dot(Cp, Cc, Cs, vals, dx, j);
+  dz[j] = tz[j] - zw[j] * cdx;
+  dw[j] = -1.0 * r3[j] + cdx;
+}
+
+// REDUCED, parts 1 + 2 and parts 3 + 4 as ONE launch each (round 6: inside a replayed graph a launch takes 4.6 us whatever
+// it does, and these do a microsecond's work on the systems whose iterations are counted in launches).  The first
+// nb_first workgroups do the part that needs the other's result and evaluate it where they need it - tz_j where C' meets
+// it, dx_i = scale_i x_i where C meets it: the same expressions, so the same bits -, the rest store it.
+__global__ void __launch_bounds__(256)
+k_rhs_red_t(int n, int me, int m, int nb_first, const int *__restrict__ q2e, const double *__restrict__ sc, const int *__restrict__ CTp,
+            const int *__restrict__ CTc, const int *__restrict__ CTs, const double *__restrict__ vals, const double *__restrict__ w,
+            const double *__restrict__ zw, const double *__restrict__ r3, const double *__restrict__ r4, double *__restrict__ tz,
+            const double *__restrict__ r1, const double *__restrict__ r2, double *__restrict__ rhs, int *__restrict__ epoch) {
+  if ((int)blockIdx.x >= nb_first) {
+    const int j = ((int)blockIdx.x - nb_first) * blockDim.x + threadIdx.x;
+    if (j < m) tz[j] = red_t_elem(w, zw, r3, r4, j);
+    return;
+  }
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q == 0 && epoch) *epoch += 1;  // the solve counter of the whole-tree sweeps (solve_top.hip.h)
+  if (q >= n + me) return;
+  double v;
+  if (q < n) {
+    double s = 0.0;
+    for (int k = CTp[q]; k < CTp[q + 1]; k++) s += vals[CTs[k]] * red_t_elem(w, zw, r3, r4, CTc[k]);
+    v = (r1[q] - s) * sc[q];
+  } else
+    v = r2[q - n];
+  rhs[q2e[q]] = v;
+}
+__global__ void __launch_bounds__(256)
+k_unpack_dzdw(int n, int me, int m, int nb_first, const int *__restrict__ q2e, const double *__restrict__ sc, const double *__restrict__ xsol,
+              double *__restrict__ dx, double *__restrict__ dy, const int *__restrict__ Cp, const int *__restrict__ Cc,
+              const int *__restrict__ Cs, const double *__restrict__ vals, const double *__restrict__ zw, const double *__restrict__ tz,
+              const double *__restrict__ r3, double *__restrict__ dz, double *__restrict__ dw) {
+  if ((int)blockIdx.x >= nb_first) {
+    const int q = ((int)blockIdx.x - nb_first) * blockDim.x + threadIdx.x;
+    if (q >= n + me) return;
+    const double v = xsol[q2e[q]];
+    if (q < n)
+      dx[q] = v * sc[q];
+    else
+      dy[q - n] = v;
+    return;
+  }
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= m) return;
+  double cdx = 0.0;
+  for (int k = Cp[j]; k < Cp[j + 1]; k++) {
+    const int c = Cc[k];
+    const double dxc = xsol[q2e[c]] * sc[c];
+    cdx += vals[Cs[k]] * dxc;
+  }
   dz[j] = tz[j] - zw[j] * cdx;
   dw[j] = -1.0 * r3[j] + cdx;
 }

@@ -126,3 +126,30 @@ def test_calls_with_host_vectors_as_graphs_give_the_same_results(monkeypatch):
             assert ra == rb and ra < 1e-10
             for u, v in zip(da, db):
                 assert np.array_equal(u, v)
+
+
+@pytest.mark.parametrize("case", ["banded", "did400", "lq"])
+def test_fused_vector_launches_give_the_same_bits(case, monkeypatch):
+    """Round 6: the reduced plugin's vector work around the sweeps (tz + right-hand side; dx, dy + dz, dw) and its assembly
+    (weights + entry values; scales + scatter) are one launch each, the dependent half evaluating what it needs in place
+    with the same expressions - against the separate launches (HQPKKT_NO_FUSED_VECTORS): the same bits, solve and loop."""
+    prog = {"banded": lambda: problems.banded_qp(300, 8, 5), "did400": lambda: problems.did_like_qp(400),
+            "lq": lambda: problems.lq_docp(40, 6, 2, final_eq=2)}[case]()
+    outs = []
+    for env in ({}, {"HQPKKT_NO_FUSED_VECTORS": "1"}):
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
+        M = ipmatrix.IpRedSpBKP()
+        M.init(prog)
+        z, w, r1, r2, r3, r4 = problems.ip_state(prog, seed=5)
+        M.factor(prog, z, w)
+        d = [np.zeros(k) for k in (prog.n, prog.me, prog.m, prog.m)]
+        res = M.solve(prog, z, w, r1, r2, r3, r4, *d)
+        outs.append((res, d, M.mehrotra(prog)))
+    (ra, da, ma), (rb, db, mb) = outs
+    assert ra == rb
+    for u, v in zip(da, db):
+        assert np.array_equal(u, v)
+    assert (ma[4]["result"], ma[4]["iters"]) == (mb[4]["result"], mb[4]["iters"]) and ma[4]["result"] == 0
+    for u, v in zip(ma[:4], mb[:4]):
+        assert np.array_equal(u, v)

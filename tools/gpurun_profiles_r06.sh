@@ -31,6 +31,33 @@ timeout 300 python3 tools/block_time.py 2>&1 | grep -v amdgpu > $O/r06_block_tim
 timeout 300 bash tools/ipprof.sh 2000 > $O/r06_ip_did_kstat.txt 2>&1
 cp gpurun_out/prof_ip/timeline.txt $O/r06_ip_did_timeline.txt 2>/dev/null
 timeout 60 tools/post_probe > $O/r06_post_probe.txt 2>&1
+# ... the same loop launch by launch (no segment graphs), the bench line's IP section, and the reference's loop on the plugin
+# through the shim (calls with host vectors): it/s with and without the call graphs / kernel copies, one iteration launch by launch
+{ echo "== hqpkkt_mehrotra, Prg_DID K = 2000 (tools/ip_profile.py)"; python3 tools/ip_profile.py 2000 RedSpBKP 2>&1 | grep -v amdgpu
+  echo "== HQPKKT_NO_IP_SEGMENTS=1"; HQPKKT_NO_IP_SEGMENTS=1 python3 tools/ip_profile.py 2000 RedSpBKP 2>&1 | grep -v amdgpu; } > $O/r06_ip_gaps.txt
+{ echo "== the reference's Hqp_IpsMehrotra on RedSpBKPHip through the shim (tools/shim_profile.py 2000 5)"; python3 tools/shim_profile.py 2000 5 2>&1 | grep -v amdgpu
+  echo "== HQPKKT_NO_HOST_GRAPHS=1"; HQPKKT_NO_HOST_GRAPHS=1 python3 tools/shim_profile.py 2000 5 2>&1 | grep -v amdgpu
+  echo "== HQPKKT_NO_HOST_GRAPHS=1 HQPKKT_NO_HOST_KERNEL_COPIES=1 (the chain of round 5 but for the posted status words)"; HQPKKT_NO_HOST_GRAPHS=1 HQPKKT_NO_HOST_KERNEL_COPIES=1 python3 tools/shim_profile.py 2000 5 2>&1 | grep -v amdgpu; } > $O/r06_shim.txt
+mkdir -p $O/shim
+for v in graphs chain; do
+  rm -rf $O/shim/*
+  if [ $v = chain ]; then export HQPKKT_NO_HOST_GRAPHS=1 HQPKKT_NO_HOST_KERNEL_COPIES=1; fi
+  timeout 300 rocprofv3 --kernel-trace --memory-copy-trace -d $O/shim -o shim -- python3 tools/shim_profile.py 2000 2 > /dev/null 2>&1
+  unset HQPKKT_NO_HOST_GRAPHS HQPKKT_NO_HOST_KERNEL_COPIES
+  { echo "== one iteration of the reference's loop on the plugin, $v"; python3 tools/shim_timeline.py $O/shim/shim_results.db 40; } >> $O/r06_shim_timeline.txt 2>&1
+done
+rm -rf $O/shim
+# stamps inside the whole-tree launch of the small-front kernel (builds with -DHQPKKT_STAMPS -DFSTAMP_GRID=1023 -DFSTAMP_BLOCK=..: tools/_build)
+for B in 0 700 1000 1022; do
+  if [ -f tools/_build/libstamps_fds_$B.so ]; then
+    echo "== block $B of 1023" >> $O/r06_fds_tree_stamps.txt
+    HQPKKT_LIB=$PWD/tools/_build/libstamps_fds_$B.so timeout 120 python3 tools/stamps_small.py 2000 2>&1 | grep -v amdgpu >> $O/r06_fds_tree_stamps.txt
+  fi
+done
+# the cut form of the fp64 product: equal shares against the work table, and the table's stamps
+{ for t in 0 1 0 1; do echo "== HQPKKT_SK_TABLE=$t"; HQPKKT_SK_TABLE=$t python3 tools/dgemm_stamps.py 5000x5050x5000x0 5050x5050x5000x1 3000x3050x3000x0 2>&1 | grep -v amdgpu; done; } > $O/r06_sk_table.txt
+HQPKKT_DGEMM_STAMPS=1 python3 tools/dgemm_stamps.py 5000x5050x5000x0 5050x5050x5000x1 2>&1 | grep -v amdgpu > $O/r06_sk_stamps.txt
+HQPKKT_SK_TABLE=0 timeout 600 python bench.py --steps 10 --warmup 2 --no-cpu-baseline --no-ip 2>/dev/null | grep '^{' | tail -1 > $O/r06_bench_equal_shares.json
 # configs[4] stand-ins (mesh 300 x 300, 1000 x 1000, band of 21 with 1000 far couplings at 10^5 variables, the mesh with 1 % far couplings)
 timeout 600 python tools/mesh_bench.py 2>/dev/null | grep '^{' | tail -1 > $O/r06_mesh_bench.json
 # SURVEY C5's row density (10 ... 100 entries per row) at 1e5 variables
