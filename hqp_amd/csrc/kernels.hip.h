@@ -1225,6 +1225,9 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
   double *P = panel + T.panel_off[node];
   const int lane = threadIdx.x, i = lane & 31, h = lane >> 5, r16 = lane & 15, cq = lane >> 4;
   const bool row_on = i < p;
+  // lanes of the border rows' share of a pivot step (round 6): border row br, and bnq columns at a time - with the two
+  // border rows of a leaf sixteen columns per trip, with up to eight rows eight (a trip is two dependent LDS round trips)
+  const int brsh = b <= 4 ? 2 : b <= 8 ? 3 : 4, br = lane & ((1 << brsh) - 1), bq = lane >> brsh, bnq = 64 >> brsh;
   FSTAMP(0);
   const double pert = fmax(pivot_eps * __longlong_as_double((long long)*kmax_bits), 1e-300);
   // The columns in groups of 16 (most fronts have one), eight loads per lane and group in
@@ -1479,18 +1482,18 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
         // the front: column lp[j] is the j-th pivot's), and the update block with them: when the last pivot is done it
         // is complete and goes to the parent before anything else (M, L21, the stores) is computed
         if (b > 0) {
-          const int pk = lp[k], rc = min(r16, b - 1);
-          const bool ron = r16 < b;
+          const int pk = lp[k], rc = min(br, b - 1);
+          const bool ron = br < b;
           const double lr = s21[rc + ldb * pk] * di;
-          for (int jb = k + 1; jb < p; jb += 4) {
-            const int j = min(jb + cq, p - 1), pj = lp[j];
+          for (int jb = k + 1; jb < p; jb += bnq) {
+            const int j = min(jb + bq, p - 1), pj = lp[j];
             const double akj = a[j + k * ldp], sv = s21[rc + ldb * pj];
-            if (ron && jb + cq < p) s21[r16 + ldb * pj] = fma(-lr, akj, sv);
+            if (ron && jb + bq < p) s21[br + ldb * pj] = fma(-lr, akj, sv);
           }
-          for (int cb = 0; cb < b; cb += 4) {
-            const int c = min(cb + cq, b - 1);
+          for (int cb = 0; cb < b; cb += bnq) {
+            const int c = min(cb + bq, b - 1);
             const double cc = s21[c + ldb * pk], uv = ub[rc + ldb * c];
-            if (ron && cb + cq < b && r16 >= cb + cq) ub[r16 + ldb * c] = fma(-lr, cc, uv);
+            if (ron && cb + bq < b && br >= cb + bq) ub[br + ldb * c] = fma(-lr, cc, uv);
           }
         }
       }
@@ -1536,19 +1539,19 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
       }
       if constexpr (FRONT) {
         if (b > 0) {
-          const int pk0 = lp[k], pk1 = lp[k + 1], rc = min(r16, b - 1);
-          const bool ron = r16 < b;
+          const int pk0 = lp[k], pk1 = lp[k + 1], rc = min(br, b - 1);
+          const bool ron = br < b;
           const double c1 = s21[rc + ldb * pk0], c2 = s21[rc + ldb * pk1];
           const double l1 = c1 * i11 + c2 * i21, l2 = c1 * i21 + c2 * i22;
-          for (int jb = k + 2; jb < p; jb += 4) {
-            const int j = min(jb + cq, p - 1), pj = lp[j];
+          for (int jb = k + 2; jb < p; jb += bnq) {
+            const int j = min(jb + bq, p - 1), pj = lp[j];
             const double ak0 = a[j + k * ldp], ak1 = a[j + (k + 1) * ldp], sv = s21[rc + ldb * pj];
-            if (ron && jb + cq < p) s21[r16 + ldb * pj] = fma(-l2, ak1, fma(-l1, ak0, sv));
+            if (ron && jb + bq < p) s21[br + ldb * pj] = fma(-l2, ak1, fma(-l1, ak0, sv));
           }
-          for (int cb = 0; cb < b; cb += 4) {
-            const int c = min(cb + cq, b - 1);
+          for (int cb = 0; cb < b; cb += bnq) {
+            const int c = min(cb + bq, b - 1);
             const double cc0 = s21[c + ldb * pk0], cc1 = s21[c + ldb * pk1], uv = ub[rc + ldb * c];
-            if (ron && cb + cq < b && r16 >= cb + cq) ub[r16 + ldb * c] = fma(-l2, cc1, fma(-l1, cc0, uv));
+            if (ron && cb + bq < b && br >= cb + bq) ub[br + ldb * c] = fma(-l2, cc1, fma(-l1, cc0, uv));
           }
         }
       }
