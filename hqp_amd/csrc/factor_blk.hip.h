@@ -783,7 +783,7 @@ k_factor_blk(DevTree T, const int *__restrict__ level_nodes, double *__restrict_
           const int sgs = esign[e0 + lpk];
           if (sgs == 2 || sgs == -2) {
             if (tid == 0) counters[4] = 1;  // see SOFT_PIVOT_REL
-            if (tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * (double)rm0[lpk], pert), pertd = true;
+            if (tiny_replace(counters, d)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * (double)rm0[lpk], pert), pertd = true;
           }
         }
         if (!(fabs(d) >= pert)) {

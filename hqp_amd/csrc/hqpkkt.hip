@@ -2307,7 +2307,8 @@ int hqpkkt_mehrotra(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, co
     }
     // the cold start's factorisation has succeeded (or a hot start carries on): the matrix is regular, cancelled multiplier
     // pivots are replaced from here on (kernels.hip.h, TINY_REPLACE_WORD)
-    if (h->tiny_replace_in_loop) HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));
+    // (2: exactly zero pivots as well - only where the factorisation just checked met no cancelled multiplier pivot: kernels.hip.h)
+    if (h->tiny_replace_in_loop) HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, (!hot && !h->soft_tiny) ? 2 : 1, sizeof(int), s));
     bool restart_cold = false;
     while (true) {
       double phi = 0.0;
@@ -2655,7 +2656,7 @@ int hqpkkt_franke(hqpkkt_t *h, const hqpkkt_ip_opts *opts, const double *c, cons
     while (true) {
       if (iter == 0) alphabar = 1.0;
       if (iter == 1 && h->tiny_replace_in_loop)
-        HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, 1, sizeof(int), s));  // (the first factorisation + solve has succeeded: kernels.hip.h)
+        HIPCHK(hipMemsetAsync(h->flags.p + TINY_REPLACE_WORD, h->soft_tiny ? 1 : 2, sizeof(int), s));  // (the first factorisation + solve has succeeded; 2: exact zeros too, kernels.hip.h)
       double mu;
       if (1.0 / gap < rhomin || alpha < 1.0) {
         mu = alphabar * gap / rhomin;             // potential reduction

@@ -200,13 +200,20 @@ __device__ double soft_pivot_pert = 1e-6;
 // TINY_REPLACE_WORD of the handle's flags (k_clear leaves it alone) switches the replacement on: the device-resident
 // interior-point loops set it once their first factorisation + solve has succeeded (hqpkkt_mehrotra: behind the cold
 // start; hqpkkt_franke: from the second iteration on) and clear it when they return; the plugin entry points
-// (hqpkkt_factor on its own, the reference's solvers through the shim) never replace.  Until round 6 an EXACTLY zero
-// pivot was never replaced; it is now, like any other cancelled one - where the replacement is on, a factorisation + solve of
-// the same structure has succeeded, so a zero that turns up later is cancellation at the end of an interior-point run (w / z
-// of 1e-21 beside 1e+9: campaign case 187 of round 6), not rank deficiency; without the replacement it stays the
-// reference's E_SING (zero_pivot_slot above).
+// (hqpkkt_factor on its own, the reference's solvers through the shim) never replace.  An EXACTLY zero pivot is replaced
+// only where the loop's first factorisation of the run met NO cancelled multiplier pivot at all (the loops then set the
+// word to TINY_REPLACE_ZEROS): a rank-deficient equality block shows its cancelled pivot in every factorisation, the first
+// included - tiny there, exactly zero in the next (tests/test_reference_host.py, the duplicated equality row) - and stays
+// the reference's E_SING; a zero that turns up at the END of a run whose first factorisations were clean is cancellation
+// (w / z of 1e-21 beside 1e+9 at a gap of 4e-8: campaign case 187 of round 6) and is replaced like any other cancelled
+// pivot.  Without the replacement a zero stays the reference's E_SING (zero_pivot_slot above).
 static const int TINY_REPLACE_WORD = 112;
-__device__ __forceinline__ bool tiny_replace(const int *counters) { return counters[TINY_REPLACE_WORD - 1] != 0 && soft_pivot_pert > 0.0; }
+// (the word: 0 off; TINY_REPLACE_ON: cancelled pivots that are not exactly zero; TINY_REPLACE_ZEROS: exactly zero ones as well)
+static const int TINY_REPLACE_ON = 0x01010101, TINY_REPLACE_ZEROS = 0x02020202;  // (set by hipMemsetAsync: a byte value)
+__device__ __forceinline__ bool tiny_replace(const int *counters, double d) {
+  const int t = counters[TINY_REPLACE_WORD - 1];
+  return t != 0 && (d != 0.0 || t == TINY_REPLACE_ZEROS) && soft_pivot_pert > 0.0;
+}
 // (The replacement cures the runs that ended early on garbage factors - all ten finds of the campaigns of rounds 1-4 - and
 // breaks about as many others, where the pivot used as it was had been good enough: six of the 12 000 cases of
 // profiles/r05_fuzz_tree.txt against seven without it.  Trying both treatments per solve and keeping the better one was
@@ -903,7 +910,7 @@ int dn;
         const int sgs = esign[e0 + lp[k]];
         if (sgs == 2 || sgs == -2) {
           counters[4] = 1;  // see SOFT_PIVOT_REL
-          if (tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rm0[lp[k]], pert), pertd = true;
+          if (tiny_replace(counters, d)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rm0[lp[k]], pert), pertd = true;
         }
       }
       if (!(fabs(d) >= pert)) {
@@ -1444,7 +1451,7 @@ k_factor_diag_small(DevTree T, const int *__restrict__ level_nodes, double *__re
         const int sgs = esign[e0 + lp[k]];
         if (sgs == 2 || sgs == -2) {
           counters[4] = 1;  // see SOFT_PIVOT_REL
-          if (tiny_replace(counters)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rdlane(rowmax0, lp[k]), pert), pertd = true;
+          if (tiny_replace(counters, d)) d = (sgs < 0 ? -1.0 : 1.0) * fmax(soft_pivot_pert * rdlane(rowmax0, lp[k]), pert), pertd = true;
         }
       }
       if (!(fabs(d) >= pert)) {

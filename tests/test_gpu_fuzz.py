@@ -85,7 +85,7 @@ def test_large_stage_campaign_subset():
 # Round 6 (profiles/r06_fuzz_final.txt, 8000 QPs on the final code): 2536 and 8650 agree since the small fronts sum their update
 # blocks in another order (another rounding: the cause named above), 6258 stays; 187 - the loop ended "degenerate" one step
 # before the reference's "optimal" on an EXACTLY zero pivot (w / z of 1e-21 beside 1e+9) - agrees since the loops' second
-# attempt replaces such a pivot like any other cancelled one.
+# attempt replaces such a pivot like any other cancelled one where the run's first factorisation met none (kernels.hip.h).
 IP_FINDS = [193, 2536, 5533, 5975, 6258, 7018, 7260, 7511, 8650, 10246, 803, 2419, 2532, 3015, 5466, 5921, 5954, 7818, 10258, 187]
 
 
