@@ -454,21 +454,23 @@ def test_dgemm_kernel_against_exact_products():
         assert err <= 1e-14, (M, N, K, lower, mirror, err)
 
 
-@pytest.mark.parametrize("waves", ["8", "4", "reg"])
+@pytest.mark.parametrize("waves", ["8", "8-equal-shares", "4", "reg"])
 def test_large_dgemm_kernels_against_exact_products(waves, monkeypatch):
     """The kernels of the dominant products on their own, at the shapes the C4 recursion runs them: k_dgemm_tn<128,128>
-    (plain rounds) and k_dgemm_tn_sk (whole rounds + cut k ranges, partial sums parked and added by the last arriver)
+    (plain rounds) and k_dgemm_tn_sk (whole tiles by a work table, the rest cut in k: partial sums parked and added by the last arriver)
     with operands staged by LDS-DMA, 2 x 4 waves (default) and 2 x 2 waves, and round 2's register-staged loop; full,
     lower-triangular, mirrored and column-strip (trapezoid) outputs, ragged edges, K not a multiple of the slab.
     4096 sample entries each against exactly accumulated sums."""
     if waves == "reg":
         monkeypatch.setenv("HQPKKT_NO_LDSDMA", "1")
+    elif waves == "8-equal-shares":  # (round 6: the cut form runs from a work table with unequal shares; this is the plan before it)
+        monkeypatch.setenv("HQPKKT_SK_TABLE", "0")
     else:
         monkeypatch.setenv("HQPKKT_DGEMM_WAVES", waves)
     shapes = [(2600, 2600, 300, 1, 1), (5000, 5050, 5000, 0, 0), (5050, 5050, 5000, 1, 0), (3000, 3050, 3000, 0, 0),
               (5000, 640, 5000, 0, 0), (4360, 640, 5000, 1, 0), (5000, 1280, 1000, 1, 0), (2048, 2048, 2048, 0, 0),
               (5000, 5000, 50, 1, 1), (4097, 4097, 37, 1, 1)]
-    if waves != "8":
+    if waves not in ("8", "8-equal-shares"):
         shapes = shapes[:4]
     for (M, N, K, lower, mirror) in shapes:
         ms, tf, err = ipmatrix.bench_dgemm(M, N, K, lower, mirror, reps=1)
